@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (read-only at /root/reference) on CPU.
+
+Run in the build container only:   python tools/gen_goldens.py
+The reference never travels to the GPU box; only the small .npz outputs under tests/golden/ do.
+Inputs come from tests/golden_inputs.py (numpy seeds), so tests regenerate them instead of
+storing them.  Nothing from the reference is copied: this script calls its functions.
+"""
+import os
+import sys
+import types
+from argparse import Namespace
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(1, os.path.join(ROOT, "tests"))
+sys.path.insert(2, os.path.join(ROOT, "oracle"))
+for name in ("torchvision", "torchvision.datasets", "wget"):      # only the dataset loader needs them
+    sys.modules.setdefault(name, types.ModuleType(name))
+
+import numpy as np
+import torch
+
+import golden_inputs as gi
+import evae_oracle as orc
+
+from utils.distributions import pairwise_distance, log_normal_diag_vectorized           # noqa: E402
+from utils.distributions import log_normal_diag, log_bernoulli, log_logistic_256         # noqa: E402
+from utils.knn_on_latent import find_nearest_neighbors                                   # noqa: E402
+from utils.nn import GatedDense, NonLinear                                               # noqa: E402
+from utils.optimizer import AdamNormGrad                                                 # noqa: E402
+from models.VAE import VAE                                                               # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(os.cpu_count())
+T = torch.from_numpy
+
+
+def vae_args(**kw):
+    a = dict(prior="exemplar_prior", input_type="binary", input_size=[1, 28, 28], hidden_size=300,
+             z1_size=40, z2_size=40, model_name="vae", device="cpu", number_components=1000,
+             training_set_size=50000, approximate_prior=False, approximate_k=10, no_mask=False,
+             no_attention=False, same_variational_var=False, use_logit=False, lambd=1e-4,
+             bottleneck=6, dataset_name="dynamic_mnist", continuous=False)
+    a.update(kw)
+    return Namespace(**a)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def tie_gap(dist, k):
+    """min over rows of the gap between consecutive order statistics 1..k+1 (relative)."""
+    part = np.sort(dist, axis=1)[:, :k + 1]
+    gaps = np.diff(part, axis=1)
+    return float(gaps.min()), float((gaps / np.maximum(part[:, 1:], 1e-30)).min())
+
+
+# ---- G1 / G2 ------------------------------------------------------------------------------------
+def g1_g2():
+    out = {}
+    for zdim in (40, 256):
+        z, m = gi.latents(11 + zdim, 16, 257, zdim)
+        out["pd_z%d" % zdim] = pairwise_distance(T(z), T(m)).numpy()
+        for p in (-1.0, 0.3):
+            lv = torch.full((1, zdim), p)
+            ln, _ = log_normal_diag_vectorized(T(z), T(m), lv)
+            out["ln_z%d_p%s" % (zdim, str(p).replace("-", "m").replace(".", "_"))] = ln.numpy()
+    save("g1_g2_distance", **out)
+
+
+# ---- G3: prior with mask / test / sum=False, and gradients -----------------------------------------
+def g3():
+    model = VAE(vae_args())
+    out = {}
+    for tag, (B, C, N, seed) in {"small": (8, 300, 120, 21), "c2": (100, 25000, 50000, 22)}.items():
+        z_np, c_np = gi.clustered_latents(seed, B, C, 40)
+        zi_np, ci_np = gi.mask_indices(seed + 1, B, C, N)
+        gout = np.random.RandomState(seed + 2).standard_normal(B).astype(np.float32)
+        plv0 = -1.3
+        for mode in ("train", "test"):
+            z = T(z_np).clone().requires_grad_(True)
+            c = T(c_np).clone().requires_grad_(True)
+            plv = torch.tensor([plv0], requires_grad=True)
+            logvar = plv * torch.ones((C, 40))
+            model.train(mode == "train")
+            lp = model.log_p_z((z, T(zi_np)), (c, logvar, T(ci_np)))
+            (lp * T(gout)).sum().backward()
+            out["%s_%s_logp" % (tag, mode)] = lp.detach().numpy()
+            out["%s_%s_dz" % (tag, mode)] = z.grad.numpy()
+            out["%s_%s_dplv" % (tag, mode)] = plv.grad.numpy()
+            if tag == "small":
+                out["%s_%s_dc" % (tag, mode)] = c.grad.numpy()
+                with torch.no_grad():
+                    out["%s_%s_prob" % (tag, mode)] = model.log_p_z(
+                        (T(z_np), T(zi_np)), (T(c_np), logvar.detach(), T(ci_np)), sum=False).numpy()
+            else:
+                out["%s_%s_dc_head" % (tag, mode)] = c.grad.numpy()[:64]
+                out["%s_%s_dc_colsum" % (tag, mode)] = c.grad.double().sum(0).numpy()
+                out["%s_%s_dc_rownorm" % (tag, mode)] = c.grad.double().norm(dim=1).numpy().astype(np.float32)
+    save("g3_prior", **out)
+
+
+# ---- G4: distance + top-k (BaseModel.py:263-264) ---------------------------------------------------
+def g4():
+    out = {}
+    for tag, (B, C, zdim, seed) in {"c2": (100, 25000, 40, 31), "c5": (64, 100000, 256, 32)}.items():
+        z, c = gi.clustered_latents(seed, B, C, zdim)
+        d = pairwise_distance(T(z), T(c))
+        vals, idx = d.topk(k=10, largest=False, dim=1)
+        gap_abs, gap_rel = tie_gap(d.numpy(), 10)
+        assert gap_abs > 0, "fp32 tie inside top-(k+1): regenerate with another seed"
+        out[tag + "_idx"] = idx.numpy().astype(np.int32)
+        out[tag + "_val"] = vals.numpy()
+        out[tag + "_gap"] = np.asarray([gap_abs, gap_rel])
+        # cross-check: the build's tie rule equals torch.topk on tie-free rows
+        ov, oi = orc.topk_smallest(d.numpy(), 10)
+        assert np.array_equal(oi, idx.numpy())
+    save("g4_topk", **out)
+
+
+# ---- G5: find_nearest_neighbors (knn_on_latent.py:4-9) ----------------------------------------------
+def g5():
+    zv, zt = gi.clustered_latents(41, 100, 60000, 40)
+    idx = find_nearest_neighbors(T(zv), T(zt), None).numpy()
+    dist = np.sqrt(orc.pairdist_direct_f64(zv, zt))
+    gap_abs, gap_rel = tie_gap(dist, 20)
+    assert gap_abs > 0
+    save("g5_knn", idx=idx.astype(np.int32), gap=np.asarray([gap_abs, gap_rel]))
+
+
+# ---- G6: dense layers (utils/nn.py:29-69) -----------------------------------------------------------
+def g6():
+    rs = np.random.RandomState(51)
+    R, I, O = 37, 53, 24
+    x = rs.standard_normal((R, I)).astype(np.float32)
+    wh = (rs.standard_normal((O, I)) * 0.2).astype(np.float32); bh = (rs.standard_normal(O) * 0.1).astype(np.float32)
+    wg = (rs.standard_normal((O, I)) * 0.2).astype(np.float32); bg = (rs.standard_normal(O) * 0.1).astype(np.float32)
+    gout = rs.standard_normal((R, O)).astype(np.float32)
+    gd = GatedDense(I, O)
+    gd.load_state_dict({"h.weight": T(wh), "h.bias": T(bh), "g.weight": T(wg), "g.bias": T(bg)})
+    xt = T(x).clone().requires_grad_(True)
+    y = gd(xt)
+    y.backward(T(gout))
+    out = dict(gd_y=y.detach().numpy(), gd_dx=xt.grad.numpy(), gd_dwh=gd.h.weight.grad.numpy(),
+               gd_dbh=gd.h.bias.grad.numpy(), gd_dwg=gd.g.weight.grad.numpy(), gd_dbg=gd.g.bias.grad.numpy())
+    for name, act in (("sigmoid", torch.nn.Sigmoid()), ("hardtanh", torch.nn.Hardtanh(-6., 2.)), ("none", None)):
+        nl = NonLinear(I, O, activation=act)
+        nl.load_state_dict({"linear.weight": T(wh * 8), "linear.bias": T(bh)})
+        xt = T(x).clone().requires_grad_(True)
+        y = nl(xt)
+        y.backward(T(gout))
+        out["nl_%s_y" % name] = y.detach().numpy()
+        out["nl_%s_dx" % name] = xt.grad.numpy()
+        out["nl_%s_dw" % name] = nl.linear.weight.grad.numpy()
+        out["nl_%s_db" % name] = nl.linear.bias.grad.numpy()
+    # reconstruction / density terms
+    xm = 1 / (1 + np.exp(-rs.standard_normal((R, I)) * 6)).astype(np.float32)
+    xb = (rs.random_sample((R, I)) < 0.3).astype(np.float32)
+    out["log_bernoulli"] = log_bernoulli(T(xb), T(xm.astype(np.float32)), dim=1).numpy()
+    mu = rs.standard_normal((R, I)).astype(np.float32); lv = rs.uniform(-6, 2, (R, I)).astype(np.float32)
+    out["log_normal_diag"] = log_normal_diag(T(x), T(mu), T(lv), dim=1).numpy()
+    xc = ((rs.randint(0, 256, (R, I)) + 0.5) / 256).astype(np.float32)
+    mc = rs.uniform(1 / 512., 1 - 1 / 512., (R, I)).astype(np.float32)
+    ls = rs.uniform(-4.5, 0, (R, I)).astype(np.float32)
+    out["log_logistic_256"] = log_logistic_256(T(xc), T(mc), T(ls), dim=1).numpy()
+    save("g6_layers", **out)
+
+
+# ---- G7: VAE.calculate_loss, train (exact prior) and eval, with injected eps / exemplar indices -----
+def load_params(model, p):
+    model.load_state_dict({k: T(v.copy()) for k, v in p.items()})
+
+
+def g7():
+    out = {}
+    for tag, (B, C, N, seed) in {"small": (16, 200, 500, 61), "c1": (100, 1000, 4000, 62)}.items():
+        args = vae_args(number_components=C, training_set_size=N)
+        model = VAE(args)
+        p = orc.vae_init_params(np.random.RandomState(123))
+        load_params(model, p)
+        data = gi.gray_images(seed, N).astype(np.float32)            # dataset tensor (un-binarised)
+        rs = np.random.RandomState(seed + 1)
+        bidx = rs.randint(0, N, size=(B, 1)).astype(np.int64)
+        x = (rs.random_sample((B, 784)) < np.clip(data[bidx[:, 0]] + 0.1, 0, 1)).astype(np.float32)
+        eps = rs.standard_normal((B, 40)).astype(np.float32)
+        ex_idx = rs.randint(0, N, size=(C,)).astype(np.int64)
+        ex_idx[:3] = bidx[:3, 0]                                       # force some leave-one-out hits
+        dataset = torch.utils.data.TensorDataset(T(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+        model.reparameterize = lambda mu, logvar: T(eps) * logvar.mul(0.5).exp() + mu
+        orig_randint = torch.randint
+        torch.randint = lambda low=0, high=None, size=None, **kw: T(ex_idx)
+        try:
+            model.train()
+            model.zero_grad()
+            loss, RE, KL = model.calculate_loss((T(x), T(bidx)), beta=0.37, average=False, dataset=dataset)
+            loss.mean().backward()
+        finally:
+            torch.randint = orig_randint
+        out[tag + "_train_loss"] = loss.detach().numpy()
+        out[tag + "_train_RE"] = RE.detach().numpy()
+        out[tag + "_train_KL"] = KL.detach().numpy()
+        for k, v in model.named_parameters():
+            g = v.grad
+            out[tag + "_gnorm_" + k] = np.asarray([0.0 if g is None else g.double().norm().item()])
+            if g is not None:
+                out[tag + "_ghead_" + k] = g.reshape(-1)[:16].numpy().copy()
+        # evaluation mode: embedding = cache of the whole dataset, no mask (evaluation.py:15,26,56-59)
+        model.eval()
+        with torch.no_grad():
+            cz, clv = model.cache_z(dataset)
+            emb = (cz, clv, torch.arange(len(cz)))
+            loss, RE, KL = model.calculate_loss((T(x), None), average=False, exemplars_embedding=emb)
+        out[tag + "_eval_loss"] = loss.numpy(); out[tag + "_eval_RE"] = RE.numpy(); out[tag + "_eval_KL"] = KL.numpy()
+        out[tag + "_cache_head"] = cz.numpy()[:32]
+    save("g7_vae_loss", **out)
+
+
+# ---- G8: AdamNormGrad, 3 steps (optimizer.py:32-80) -------------------------------------------------
+def g8():
+    import warnings
+    rs = np.random.RandomState(71)
+    shapes = [(5, 7), (7,), (1,), (3, 2, 2)]
+    ps = [torch.nn.Parameter(T(rs.standard_normal(s).astype(np.float32))) for s in shapes]
+    grads = [[rs.standard_normal(s).astype(np.float32) * (10.0 ** (i - 1)) for s in shapes] for i in range(3)]
+    opt = AdamNormGrad(ps, lr=5e-4)
+    out = {}
+    for i, s in enumerate(shapes):
+        out["p0_%d" % i] = ps[i].detach().numpy().copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for step in range(3):
+            for p_, g in zip(ps, grads[step]):
+                p_.grad = T(g.copy())
+            opt.step()
+            for i, p_ in enumerate(ps):
+                out["g%d_%d" % (step, i)] = grads[step][i]
+                out["p%d_%d" % (step + 1, i)] = p_.detach().numpy().copy()
+    for i, p_ in enumerate(ps):
+        out["m_%d" % i] = opt.state[p_]["exp_avg"].numpy()
+        out["v_%d" % i] = opt.state[p_]["exp_avg_sq"].numpy()
+    save("g8_adam", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    for w in which:
+        globals()[w]()
