@@ -1,0 +1,178 @@
+// Row-wise latent sampling and log-density kernels (one wave per row, shuffle reductions).
+// Replaces models/BaseModel.py:79-82 (reparameterize) and utils/distributions.py:28-33,44-51
+// (log_normal_diag, log_bernoulli) and their autograd.
+#include "evae_common.h"
+
+namespace evae {
+
+constexpr int LNT = 256;  // 4 rows (waves) per block
+
+__global__ __launch_bounds__(LNT) void reparam_logq_fwd_kernel(const float* __restrict__ mu,
+                                                               const float* __restrict__ logvar,
+                                                               const float* __restrict__ eps, int B,
+                                                               int zdim, float* __restrict__ z,
+                                                               float* __restrict__ logq) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (LNT / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float acc = 0.f;
+  for (int k = lane; k < zdim; k += 64) {
+    const size_t o = (size_t)row * zdim + k;
+    const float m = mu[o], lv = logvar[o];
+    const float zz = eps[o] * expf(0.5f * lv) + m;
+    z[o] = zz;
+    const float d = zz - m;
+    acc += -0.5f * (lv + kLog2Pi + d * d / expf(lv));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0 && logq) logq[row] = acc;
+}
+
+__global__ void reparam_logq_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                        const float* __restrict__ eps, const float* __restrict__ z,
+                                        const float* __restrict__ dz, const float* __restrict__ dlogq,
+                                        int B, int zdim, float* __restrict__ dmu,
+                                        float* __restrict__ dlogvar) {
+  const size_t n = (size_t)B * zdim;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int row = (int)(i / zdim);
+  const float m = mu[i], lv = logvar[i];
+  const float var = expf(lv), sd = expf(0.5f * lv);
+  const float d = z[i] - m;
+  const float gq = dlogq ? dlogq[row] : 0.f;
+  const float gz = (dz ? dz[i] : 0.f) + gq * (-(d / var));       // total gradient reaching z
+  dmu[i] = gz + gq * (d / var);
+  dlogvar[i] = gz * eps[i] * sd * 0.5f + gq * (-0.5f) * (1.0f - d * d / var);
+}
+
+__global__ __launch_bounds__(LNT) void log_normal_diag_fwd_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ mu,
+                                                                  const float* __restrict__ logvar,
+                                                                  int B, int zdim,
+                                                                  float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (LNT / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float acc = 0.f;
+  for (int k = lane; k < zdim; k += 64) {
+    const size_t o = (size_t)row * zdim + k;
+    const float lv = logvar[o];
+    const float d = x[o] - mu[o];
+    acc += -0.5f * (lv + kLog2Pi + d * d / expf(lv));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[row] = acc;
+}
+
+__global__ void log_normal_diag_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                           const float* __restrict__ logvar,
+                                           const float* __restrict__ dout, int B, int zdim,
+                                           float* __restrict__ dx, float* __restrict__ dmu,
+                                           float* __restrict__ dlogvar) {
+  const size_t n = (size_t)B * zdim;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = dout[i / zdim];
+  const float var = expf(logvar[i]);
+  const float d = x[i] - mu[i];
+  const float t = g * (d / var);
+  if (dx) dx[i] = -t;
+  if (dmu) dmu[i] = t;
+  if (dlogvar) dlogvar[i] = g * (-0.5f) * (1.0f - d * d / var);
+}
+
+constexpr float kMinEps = 1e-5f, kMaxEps = 1.0f - 1e-5f;
+
+__global__ __launch_bounds__(LNT) void bernoulli_ll_fwd_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ mean, int B,
+                                                               int D, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (LNT / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float acc = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const size_t o = (size_t)row * D + k;
+    const float p = fminf(fmaxf(mean[o], kMinEps), kMaxEps);
+    const float xv = x[o];
+    acc += xv * logf(p) + (1.0f - xv) * logf(1.0f - p);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[row] = acc;
+}
+
+__global__ void bernoulli_ll_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                        const float* __restrict__ dout, int B, int D,
+                                        float* __restrict__ dmean) {
+  const size_t n = (size_t)B * D;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float mv = mean[i];
+  const bool inside = (mv >= kMinEps) && (mv <= kMaxEps);
+  const float p = fminf(fmaxf(mv, kMinEps), kMaxEps);
+  const float xv = x[i];
+  dmean[i] = inside ? dout[i / D] * (xv / p - (1.0f - xv) / (1.0f - p)) : 0.f;
+}
+
+}  // namespace evae
+
+using namespace evae;
+
+#define ROWS_GRID(B) dim3((unsigned)cdiv((B), LNT / 64))
+#define ELT_GRID(n) dim3((unsigned)(((n) + 255) / 256))
+
+extern "C" int evae_reparam_logq_fwd(const float* mu, const float* logvar, const float* eps, int B,
+                                     int zdim, float* z, float* logq, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && zdim > 0, "reparam_logq_fwd: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(mu && logvar && eps && z, "reparam_logq_fwd: null pointer");
+  reparam_logq_fwd_kernel<<<ROWS_GRID(B), LNT, 0, (hipStream_t)s>>>(mu, logvar, eps, B, zdim, z, logq);
+  return check_launch("reparam_logq_fwd");
+}
+
+extern "C" int evae_reparam_logq_bwd(const float* mu, const float* logvar, const float* eps,
+                                     const float* z, const float* dz, const float* dlogq, int B,
+                                     int zdim, float* dmu, float* dlogvar, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && zdim > 0, "reparam_logq_bwd: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(mu && logvar && eps && z && dmu && dlogvar, "reparam_logq_bwd: null pointer");
+  reparam_logq_bwd_kernel<<<ELT_GRID((size_t)B * zdim), 256, 0, (hipStream_t)s>>>(mu, logvar, eps, z, dz, dlogq, B, zdim, dmu, dlogvar);
+  return check_launch("reparam_logq_bwd");
+}
+
+extern "C" int evae_log_normal_diag_fwd(const float* x, const float* mu, const float* logvar, int B,
+                                        int zdim, float* out, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && zdim > 0, "log_normal_diag_fwd: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(x && mu && logvar && out, "log_normal_diag_fwd: null pointer");
+  log_normal_diag_fwd_kernel<<<ROWS_GRID(B), LNT, 0, (hipStream_t)s>>>(x, mu, logvar, B, zdim, out);
+  return check_launch("log_normal_diag_fwd");
+}
+
+extern "C" int evae_log_normal_diag_bwd(const float* x, const float* mu, const float* logvar,
+                                        const float* dout, int B, int zdim, float* dx, float* dmu,
+                                        float* dlogvar, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && zdim > 0, "log_normal_diag_bwd: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(x && mu && logvar && dout, "log_normal_diag_bwd: null pointer");
+  log_normal_diag_bwd_kernel<<<ELT_GRID((size_t)B * zdim), 256, 0, (hipStream_t)s>>>(x, mu, logvar, dout, B, zdim, dx, dmu, dlogvar);
+  return check_launch("log_normal_diag_bwd");
+}
+
+extern "C" int evae_bernoulli_ll_fwd(const float* x, const float* mean, int B, int D, float* out,
+                                     evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && D > 0, "bernoulli_ll_fwd: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(x && mean && out, "bernoulli_ll_fwd: null pointer");
+  bernoulli_ll_fwd_kernel<<<ROWS_GRID(B), LNT, 0, (hipStream_t)s>>>(x, mean, B, D, out);
+  return check_launch("bernoulli_ll_fwd");
+}
+
+extern "C" int evae_bernoulli_ll_bwd(const float* x, const float* mean, const float* dout, int B, int D,
+                                     float* dmean, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && D > 0, "bernoulli_ll_bwd: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(x && mean && dout && dmean, "bernoulli_ll_bwd: null pointer");
+  bernoulli_ll_bwd_kernel<<<ELT_GRID((size_t)B * D), 256, 0, (hipStream_t)s>>>(x, mean, dout, B, D, dmean);
+  return check_launch("bernoulli_ll_bwd");
+}

@@ -1,0 +1,528 @@
+// Exemplar prior on gfx950: fused all-pairs distance + leave-one-out mask + online log-sum-exp,
+// its backward by recomputation, and the shard merge.  See include/evae_hip.h for the contract
+// and the reference lines replaced (utils/distributions.py:12-25, models/BaseModel.py:98-128).
+//
+// Kernel shape (z_dim = 40 is a thin contraction, so the distance runs on the VALU in the exact
+// direct-difference form sum_k (z-c)^2, not as ||z||^2+||c||^2-2zc on MFMA):
+//   block = 256 threads = 16 (exemplar lanes) x 16 (query groups); block tile = 128 queries x 64
+//   exemplars; thread tile = 8 queries x 4 exemplars (32 fp32 accumulators).
+//   The query tile and each exemplar tile are staged in LDS pre-divided by sigma, row-major with a
+//   row stride of (kc + pad) floats chosen so stride/4 is odd: the 16 lanes of a ds_read_b128 group
+//   read 16 different rows and land on all 64 banks (conflict-free); query reads are broadcasts.
+//   Global reads of the [C x z] cache are flat float4 streams (each 64-row tile is one contiguous
+//   10 KB span), i.e. fully coalesced.
+//   Each thread keeps a running (dmin, sum exp(-(d-dmin)/2), #masked) per query; the 16 exemplar
+//   lanes are combined with wave shuffles once per block; blocks (exemplar splits) are combined by
+//   the merge kernel, which is the same code that merges GPU shards.
+#include "evae_tile.h"
+
+namespace evae {
+
+// inv_sigma[k] = exp(-log_var[k]/2) (zero-padded to nchunk*kc); returns -1/2 sum_k (lv_k + log 2pi)
+__device__ __forceinline__ float setup_sigma(float* __restrict__ inv_sigma, float* __restrict__ red,
+                                             const float* __restrict__ log_var, int zdim, int zpad) {
+  float part = 0.f;
+  for (int k = threadIdx.x; k < zpad; k += NT) {
+    float lv = k < zdim ? log_var[k] : 0.f;
+    inv_sigma[k] = k < zdim ? expf(-0.5f * lv) : 0.f;
+    if (k < zdim) part += lv + kLog2Pi;
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  float tot = red[0] + red[1] + red[2] + red[3];
+  return -0.5f * tot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: per (exemplar split, query tile) partial (max, sumexp, nmask)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void prior_fwd_kernel(
+    const float* __restrict__ z, int B, const float* __restrict__ centres, int C, int zdim,
+    const float* __restrict__ log_var, const int64_t* __restrict__ z_idx,
+    const int64_t* __restrict__ c_idx, int tiles_per_split, int nsplit, PriorGeom g,
+    float* __restrict__ part_m, float* __restrict__ part_s, float* __restrict__ part_n,
+    float* __restrict__ out_prob) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;
+  float* Es = Qs + BQ * g.ks;
+  float* inv_sigma = Es + BE * g.ks;     // [<= 4*KC_MAX]
+  float* red = inv_sigma + 4 * KC_MAX;   // [16]
+
+  const int split = blockIdx.x;
+  const int q0 = blockIdx.y * BQ;
+  const int te = threadIdx.x & 15;
+  const int tq = threadIdx.x >> 4;
+  const bool vec_ok = (zdim & 3) == 0 && (((uintptr_t)z | (uintptr_t)centres) & 15) == 0;
+  const bool masked = (z_idx != nullptr) && (c_idx != nullptr);
+  const int zpad = g.nchunk * g.kc;
+
+  const float cst = setup_sigma(inv_sigma, red, log_var, zdim, zpad);
+
+  int64_t zi[TQ];
+  bool qvalid[TQ];
+#pragma unroll
+  for (int i = 0; i < TQ; ++i) {
+    int q = q0 + tq + 16 * i;
+    qvalid[i] = q < B;
+    zi[i] = (masked && qvalid[i]) ? z_idx[q] : -1;
+  }
+
+  float dmin[TQ], ssum[TQ], nmask[TQ];
+#pragma unroll
+  for (int i = 0; i < TQ; ++i) { dmin[i] = INFINITY; ssum[i] = 0.f; nmask[i] = 0.f; }
+
+  if (g.nchunk == 1) stage_rows(Qs, z, q0, B, BQ, zdim, 0, g.kc, g.ks, inv_sigma, vec_ok);
+
+  const int tile_begin = split * tiles_per_split;
+  const int ntiles = (C + BE - 1) / BE;
+  int tile_end = tile_begin + tiles_per_split;
+  if (tile_end > ntiles) tile_end = ntiles;
+
+  for (int t = tile_begin; t < tile_end; ++t) {
+    const int e0 = t * BE;
+    float acc[TQ][TE];
+#pragma unroll
+    for (int i = 0; i < TQ; ++i)
+#pragma unroll
+      for (int j = 0; j < TE; ++j) acc[i][j] = 0.f;
+
+    for (int ch = 0; ch < g.nchunk; ++ch) {
+      __syncthreads();  // previous readers of Es (and Qs when re-staged) are done
+      if (g.nchunk > 1)
+        stage_rows(Qs, z, q0, B, BQ, zdim, ch * g.kc, g.kc, g.ks, inv_sigma + ch * g.kc, vec_ok);
+      stage_rows(Es, centres, e0, C, BE, zdim, ch * g.kc, g.kc, g.ks, inv_sigma + ch * g.kc, vec_ok);
+      __syncthreads();
+      dist_chunk(acc, Qs, Es, tq, te, g.kc, g.ks);
+    }
+
+    int64_t ci[TE];
+    bool evalid[TE];
+#pragma unroll
+    for (int j = 0; j < TE; ++j) {
+      int e = e0 + te + 16 * j;
+      evalid[j] = e < C;
+      ci[j] = (masked && evalid[j]) ? c_idx[e] : -2;
+    }
+#pragma unroll
+    for (int i = 0; i < TQ; ++i) {
+      bool ok[TE];
+      float cmin = INFINITY;
+#pragma unroll
+      for (int j = 0; j < TE; ++j) {
+        bool hit = masked && (zi[i] == ci[j]) && evalid[j];
+        ok[j] = evalid[j] && !hit;
+        if (hit) nmask[i] += 1.f;
+        if (ok[j]) cmin = fminf(cmin, acc[i][j]);
+      }
+      if (cmin < dmin[i]) {
+        ssum[i] *= fast_exp2((cmin - dmin[i]) * kHalfLog2e);   // dmin==inf -> 0*0 = 0
+        dmin[i] = cmin;
+      }
+#pragma unroll
+      for (int j = 0; j < TE; ++j)
+        if (ok[j]) ssum[i] += fast_exp2((dmin[i] - acc[i][j]) * kHalfLog2e);
+      if (out_prob != nullptr && qvalid[i]) {
+        size_t rowoff = (size_t)(q0 + tq + 16 * i) * C;
+#pragma unroll
+        for (int j = 0; j < TE; ++j)
+          if (evalid[j]) out_prob[rowoff + e0 + te + 16 * j] = ok[j] ? cst - 0.5f * acc[i][j] : -INFINITY;
+      }
+    }
+  }
+
+  // combine the 16 exemplar lanes (te = lane & 15) of each query group
+#pragma unroll
+  for (int i = 0; i < TQ; ++i) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      float od = __shfl_xor(dmin[i], o, 64);
+      float os = __shfl_xor(ssum[i], o, 64);
+      float on = __shfl_xor(nmask[i], o, 64);
+      float m = fminf(dmin[i], od);
+      float fa = (dmin[i] == m) ? 1.f : fast_exp2((m - dmin[i]) * kHalfLog2e);
+      float fb = (od == m) ? 1.f : fast_exp2((m - od) * kHalfLog2e);
+      ssum[i] = ssum[i] * fa + os * fb;
+      dmin[i] = m;
+      nmask[i] += on;
+    }
+    if (te == 0 && qvalid[i]) {
+      size_t o = (size_t)split * B + (q0 + tq + 16 * i);
+      part_m[o] = (dmin[i] == INFINITY) ? -INFINITY : cst - 0.5f * dmin[i];
+      part_s[o] = ssum[i];
+      part_n[o] = nmask[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge: one wave per row combines R partials.  finalize=0 -> (max, sumexp, nmask);
+// finalize=1 -> logprior = lse - log(c_total - nmask) and lse.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void prior_merge_kernel(const float* __restrict__ pm,
+                                                         const float* __restrict__ ps,
+                                                         const float* __restrict__ pn, int R, int B,
+                                                         int finalize, float c_total,
+                                                         float* __restrict__ o0, float* __restrict__ o1,
+                                                         float* __restrict__ o2) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float m = -INFINITY;
+  for (int r = lane; r < R; r += 64) m = fmaxf(m, pm[(size_t)r * B + row]);
+  m = wave_max(m);
+  float s = 0.f, n = 0.f;
+  for (int r = lane; r < R; r += 64) {
+    float mr = pm[(size_t)r * B + row];
+    float sr = ps[(size_t)r * B + row];
+    if (mr != -INFINITY) s += sr * expf(mr - m);
+    n += pn[(size_t)r * B + row];
+  }
+  s = wave_sum(s);
+  n = wave_sum(n);
+  if (lane == 0) {
+    if (finalize) {
+      float lse = m + logf(s);
+      o0[row] = lse - logf(c_total - n);
+      if (o1 != nullptr) o1[row] = lse;
+    } else {
+      o0[row] = m; o1[row] = s; o2[row] = n;
+    }
+  }
+}
+
+__global__ void prior_fill_empty_kernel(float* m, float* s, float* n, int B) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) { m[i] = -INFINITY; s[i] = 0.f; n[i] = 0.f; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+// grid (nsplit, nq).  Per exemplar tile: recompute distances, gw_ij = g_i exp(p_ij - lse_i) into LDS,
+// then  dC[e][k] += sum_i gw (zs_ik - cs_ek)   (thread <-> (e, k-group), direct differences)
+//       dV[k]    += sum_ie gw (zs_ik - cs_ek)^2
+//       dZ[i][k] += sum_e gw (cs_ek - zs_ik)   (thread <-> (i, k-group), registers across tiles)
+// all in sigma-scaled coordinates; the finishing kernel applies 1/sigma and reduces the splits.
+constexpr int KG_C = NT / BE;  // 4 k-groups for the dC phase
+constexpr int KG_Z = NT / BQ;  // 2 k-groups for the dZ phase
+constexpr int GWS = BE + 1;    // gw row stride (conflict-free column reads)
+constexpr int KPT_C_MAX = KC_MAX / KG_C;  // 16
+constexpr int KPT_Z_MAX = KC_MAX / KG_Z;  // 32
+
+__global__ __launch_bounds__(NT) void prior_bwd_kernel(
+    const float* __restrict__ z, int B, const float* __restrict__ centres, int C, int zdim,
+    const float* __restrict__ log_var, const int64_t* __restrict__ z_idx,
+    const int64_t* __restrict__ c_idx, const float* __restrict__ lse, const float* __restrict__ gout,
+    int tiles_per_split, int nsplit, PriorGeom g, int use_atomic_dc,
+    float* __restrict__ dz_part /* [nsplit][B][zdim] */, float* __restrict__ dc /* [C][zdim] */,
+    float* __restrict__ dlv_part /* [nsplit*nq][zdim+1] */) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;
+  float* Es = Qs + BQ * g.ks;
+  float* inv_sigma = Es + BE * g.ks;
+  float* red = inv_sigma + 4 * KC_MAX;
+  float* GW = red + 64;  // [BQ][GWS]
+
+  const int split = blockIdx.x;
+  const int q0 = blockIdx.y * BQ;
+  const int te = threadIdx.x & 15;
+  const int tq = threadIdx.x >> 4;
+  const bool vec_ok = (zdim & 3) == 0 && (((uintptr_t)z | (uintptr_t)centres) & 15) == 0;
+  const bool masked = (z_idx != nullptr) && (c_idx != nullptr);
+  const int zpad = g.nchunk * g.kc;
+  const float cst = setup_sigma(inv_sigma, red, log_var, zdim, zpad);
+
+  int64_t zi[TQ];
+  float gi[TQ], li[TQ];
+#pragma unroll
+  for (int i = 0; i < TQ; ++i) {
+    int q = q0 + tq + 16 * i;
+    bool v = q < B;
+    zi[i] = (masked && v) ? z_idx[q] : -1;
+    gi[i] = v ? gout[q] : 0.f;
+    li[i] = v ? lse[q] : 0.f;
+  }
+
+  // phase-2 roles
+  const int ce = threadIdx.x & (BE - 1);     // exemplar row for dC
+  const int ckg = threadIdx.x >> 6;          // 0..3
+  const int zi_row = threadIdx.x & (BQ - 1); // query row for dZ
+  const int zkg = threadIdx.x >> 7;          // 0..1
+  const int kpt_c = g.kc / KG_C;             // k per thread (dC); kc multiple of 4 -> integral
+  const int kpt_z = g.kc / KG_Z;
+
+  float gwsum = 0.f;                          // sum of gw handled in the dC role (for dlogvar)
+  const int tile_begin = split * tiles_per_split;
+  const int ntiles = (C + BE - 1) / BE;
+  int tile_end = tile_begin + tiles_per_split;
+  if (tile_end > ntiles) tile_end = ntiles;
+
+  if (g.nchunk == 1) stage_rows(Qs, z, q0, B, BQ, zdim, 0, g.kc, g.ks, inv_sigma, vec_ok);
+
+  for (int ch2 = 0; ch2 < g.nchunk; ++ch2) {
+    // accumulators for output chunk ch2
+    float accZ[KPT_Z_MAX];
+    float accV[KPT_C_MAX];
+#pragma unroll
+    for (int k = 0; k < KPT_Z_MAX; ++k) accZ[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KPT_C_MAX; ++k) accV[k] = 0.f;
+
+    for (int t = tile_begin; t < tile_end; ++t) {
+      const int e0 = t * BE;
+      float acc[TQ][TE];
+#pragma unroll
+      for (int i = 0; i < TQ; ++i)
+#pragma unroll
+        for (int j = 0; j < TE; ++j) acc[i][j] = 0.f;
+      // distances over all chunks; leave chunk ch2 staged last so phase 2 can use it
+      for (int c = 0; c < g.nchunk; ++c) {
+        int ch = (c == g.nchunk - 1) ? ch2 : (c < ch2 ? c : c + 1);
+        __syncthreads();
+        if (g.nchunk > 1)
+          stage_rows(Qs, z, q0, B, BQ, zdim, ch * g.kc, g.kc, g.ks, inv_sigma + ch * g.kc, vec_ok);
+        stage_rows(Es, centres, e0, C, BE, zdim, ch * g.kc, g.kc, g.ks, inv_sigma + ch * g.kc, vec_ok);
+        __syncthreads();
+        dist_chunk(acc, Qs, Es, tq, te, g.kc, g.ks);
+      }
+      // gw tile -> LDS
+#pragma unroll
+      for (int j = 0; j < TE; ++j) {
+        int e = e0 + te + 16 * j;
+        bool ev = e < C;
+        int64_t cj = (masked && ev) ? c_idx[e] : -2;
+#pragma unroll
+        for (int i = 0; i < TQ; ++i) {
+          bool ok = ev && !(masked && zi[i] == cj);
+          float w = ok ? gi[i] * expf(cst - 0.5f * acc[i][j] - li[i]) : 0.f;
+          GW[(tq + 16 * i) * GWS + te + 16 * j] = w;
+        }
+      }
+      __syncthreads();
+      // ---- dC / dV: thread <-> (exemplar ce, dims ckg*kpt_c ..)
+      {
+        float cs[KPT_C_MAX], aC[KPT_C_MAX];
+#pragma unroll
+        for (int k = 0; k < KPT_C_MAX; ++k) {
+          cs[k] = (k < kpt_c) ? Es[ce * g.ks + ckg * kpt_c + k] : 0.f;
+          aC[k] = 0.f;
+        }
+        for (int i = 0; i < BQ; ++i) {
+          float w = GW[i * GWS + ce];
+          if (ch2 == 0 && ckg == 0) gwsum += w;
+          const float* qrow = Qs + i * g.ks + ckg * kpt_c;
+#pragma unroll
+          for (int k = 0; k < KPT_C_MAX; ++k) {
+            if (k < kpt_c) {
+              float d = qrow[k] - cs[k];
+              float tw = w * d;
+              aC[k] += tw;
+              accV[k] = fmaf(tw, d, accV[k]);
+            }
+          }
+        }
+        int e = e0 + ce;
+        if (e < C) {
+#pragma unroll
+          for (int k = 0; k < KPT_C_MAX; ++k) {
+            int kk = ch2 * g.kc + ckg * kpt_c + k;
+            if (k < kpt_c && kk < zdim) {
+              float v = aC[k] * inv_sigma[kk];
+              if (use_atomic_dc) atomicAdd(&dc[(size_t)e * zdim + kk], v);
+              else dc[(size_t)e * zdim + kk] = v;
+            }
+          }
+        }
+      }
+      // ---- dZ: thread <-> (query zi_row, dims zkg*kpt_z ..)
+      {
+        float zs[KPT_Z_MAX];
+#pragma unroll
+        for (int k = 0; k < KPT_Z_MAX; ++k)
+          zs[k] = (k < kpt_z) ? Qs[zi_row * g.ks + zkg * kpt_z + k] : 0.f;
+        for (int e = 0; e < BE; ++e) {
+          float w = GW[zi_row * GWS + e];
+          const float* erow = Es + e * g.ks + zkg * kpt_z;
+#pragma unroll
+          for (int k = 0; k < KPT_Z_MAX; ++k)
+            if (k < kpt_z) accZ[k] = fmaf(w, erow[k] - zs[k], accZ[k]);
+        }
+      }
+    }
+    // flush chunk ch2
+    {
+      int q = q0 + zi_row;
+      if (q < B) {
+#pragma unroll
+        for (int k = 0; k < KPT_Z_MAX; ++k) {
+          int kk = ch2 * g.kc + zkg * kpt_z + k;
+          if (k < kpt_z && kk < zdim) dz_part[((size_t)split * B + q) * zdim + kk] = accZ[k];
+        }
+      }
+      // reduce accV over the 64 exemplar lanes of this wave (wave == k-group ckg)
+      float* dlv = dlv_part + (size_t)(blockIdx.y * nsplit + split) * (zdim + 1);
+#pragma unroll
+      for (int k = 0; k < KPT_C_MAX; ++k) {
+        float v = wave_sum(accV[k]);
+        int kk = ch2 * g.kc + ckg * kpt_c + k;
+        if ((threadIdx.x & 63) == 0 && k < kpt_c && kk < zdim) dlv[kk] = v;
+      }
+      if (ch2 == 0) {
+        float sg = wave_sum(gwsum);
+        if (threadIdx.x == 0) dlv[zdim] = sg;
+      }
+    }
+  }
+}
+
+// dz[i][k] = inv_sigma_k * sum_split dz_part ; dlogvar[k] = 0.5 * sum_blocks dV[k] - 0.5 * sum_blocks gwsum
+__global__ void prior_bwd_finish_kernel(const float* __restrict__ dz_part, int nsplit, int B, int zdim,
+                                        const float* __restrict__ log_var,
+                                        const float* __restrict__ dlv_part, int nblocks,
+                                        float* __restrict__ dz, float* __restrict__ dlogvar) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int n = B * zdim;
+  if (idx < n) {
+    int k = idx % zdim;
+    float s = 0.f;
+    for (int r = 0; r < nsplit; ++r) s += dz_part[(size_t)r * n + idx];
+    dz[idx] = s * expf(-0.5f * log_var[k]);
+  }
+  if (idx < zdim) {
+    float sv = 0.f, sg = 0.f;
+    for (int b = 0; b < nblocks; ++b) {
+      sv += dlv_part[(size_t)b * (zdim + 1) + idx];
+      sg += dlv_part[(size_t)b * (zdim + 1) + zdim];
+    }
+    dlogvar[idx] = 0.5f * sv - 0.5f * sg;
+  }
+}
+
+__global__ void zero_kernel(float* p, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
+static void choose_splits(int B, int C, int* nsplit, int* tiles_per_split, int* nq) {
+  int ntiles = cdiv(C, BE);
+  *nq = cdiv(B, BQ);
+  int target = cdiv(1024, *nq);  // aim for ~4 blocks per CU in total
+  if (target < 1) target = 1;
+  int ns = ntiles < target ? ntiles : target;
+  if (ns < 1) ns = 1;
+  *tiles_per_split = cdiv(ntiles, ns);
+  if (*tiles_per_split < 1) *tiles_per_split = 1;
+  *nsplit = cdiv(ntiles, *tiles_per_split);
+  if (*nsplit < 1) *nsplit = 1;
+}
+
+}  // namespace evae
+
+using namespace evae;
+
+extern "C" size_t evae_prior_lse_fwd_workspace_bytes(int B, int C, int zdim) {
+  (void)zdim;
+  if (B <= 0 || C <= 0) return 256;
+  int ns, tps, nq;
+  choose_splits(B, C, &ns, &tps, &nq);
+  return align_up((size_t)3 * ns * B * sizeof(float), 256) + 256;
+}
+
+extern "C" int evae_prior_lse_fwd(const float* z, int B, const float* centres, int C, int zdim,
+                                  const float* log_var, const int64_t* z_idx, const int64_t* c_idx,
+                                  float* out_max, float* out_sumexp, float* out_nmask, float* out_prob,
+                                  void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(B >= 0 && C >= 0 && zdim > 0, "prior_lse_fwd: bad sizes B=%d C=%d zdim=%d", B, C, zdim);
+  EVAE_REQUIRE(zdim <= 4 * KC_MAX, "prior_lse_fwd: zdim %d > %d unsupported", zdim, 4 * KC_MAX);
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(z && log_var && out_max && out_sumexp && out_nmask, "prior_lse_fwd: null pointer");
+  if (C == 0) {
+    prior_fill_empty_kernel<<<cdiv(B, 256), 256, 0, stream>>>(out_max, out_sumexp, out_nmask, B);
+    return check_launch("prior_fill_empty");
+  }
+  EVAE_REQUIRE(centres != nullptr, "prior_lse_fwd: null centres");
+  if (ws_bytes < evae_prior_lse_fwd_workspace_bytes(B, C, zdim) || ws == nullptr) {
+    set_error("prior_lse_fwd: workspace too small (%zu)", ws_bytes);
+    return EVAE_EWORKSPACE;
+  }
+  int ns, tps, nq;
+  choose_splits(B, C, &ns, &tps, &nq);
+  PriorGeom g = prior_geom(zdim);
+  float* pm = (float*)ws;
+  float* ps = pm + (size_t)ns * B;
+  float* pn = ps + (size_t)ns * B;
+  size_t lds = prior_lds_bytes(g, false);
+  prior_fwd_kernel<<<dim3(ns, nq), NT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, tps,
+                                                    ns, g, pm, ps, pn, out_prob);
+  int rc = check_launch("prior_fwd_kernel");
+  if (rc) return rc;
+  prior_merge_kernel<<<cdiv(B, NT / 64), NT, 0, stream>>>(pm, ps, pn, ns, B, 0, 0.f, out_max, out_sumexp,
+                                                        out_nmask);
+  return check_launch("prior_merge_kernel(splits)");
+}
+
+extern "C" int evae_prior_merge(const float* max, const float* sumexp, const float* nmask, int R, int B,
+                                float c_total, float* out_logprior, float* out_lse,
+                                evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(R >= 1 && B >= 0, "prior_merge: bad sizes R=%d B=%d", R, B);
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(max && sumexp && nmask && out_logprior, "prior_merge: null pointer");
+  prior_merge_kernel<<<cdiv(B, NT / 64), NT, 0, stream>>>(max, sumexp, nmask, R, B, 1, c_total,
+                                                        out_logprior, out_lse, nullptr);
+  return check_launch("prior_merge_kernel");
+}
+
+extern "C" size_t evae_prior_lse_bwd_workspace_bytes(int B, int C, int zdim) {
+  if (B <= 0 || C <= 0) return 256;
+  int ns, tps, nq;
+  choose_splits(B, C, &ns, &tps, &nq);
+  size_t a = align_up((size_t)ns * B * zdim * sizeof(float), 256);
+  size_t b = align_up((size_t)ns * nq * (zdim + 1) * sizeof(float), 256);
+  return a + b + 256;
+}
+
+extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, int C, int zdim,
+                                  const float* log_var, const int64_t* z_idx, const int64_t* c_idx,
+                                  const float* lse, const float* grad_out, float* dz, float* dcentres,
+                                  float* dlogvar, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(B >= 0 && C >= 0 && zdim > 0, "prior_lse_bwd: bad sizes");
+  EVAE_REQUIRE(zdim <= 4 * KC_MAX, "prior_lse_bwd: zdim %d > %d unsupported", zdim, 4 * KC_MAX);
+  if (B == 0 && C == 0) return EVAE_OK;
+  EVAE_REQUIRE(dz && dlogvar && log_var, "prior_lse_bwd: null pointer");
+  if (B == 0 || C == 0) {
+    if (B > 0) zero_kernel<<<cdiv(B * zdim, 256), 256, 0, stream>>>(dz, (size_t)B * zdim);
+    if (C > 0 && dcentres) zero_kernel<<<cdiv(C * zdim, 256), 256, 0, stream>>>(dcentres, (size_t)C * zdim);
+    zero_kernel<<<1, 256, 0, stream>>>(dlogvar, (size_t)zdim);
+    return check_launch("prior_bwd zero");
+  }
+  EVAE_REQUIRE(z && centres && lse && grad_out && dcentres, "prior_lse_bwd: null pointer");
+  if (ws_bytes < evae_prior_lse_bwd_workspace_bytes(B, C, zdim) || ws == nullptr) {
+    set_error("prior_lse_bwd: workspace too small (%zu)", ws_bytes);
+    return EVAE_EWORKSPACE;
+  }
+  int ns, tps, nq;
+  choose_splits(B, C, &ns, &tps, &nq);
+  PriorGeom g = prior_geom(zdim);
+  float* dz_part = (float*)ws;
+  float* dlv_part = (float*)((char*)ws + align_up((size_t)ns * B * zdim * sizeof(float), 256));
+  int use_atomic = nq > 1;
+  if (use_atomic) {
+    zero_kernel<<<cdiv(C * zdim, 256), 256, 0, stream>>>(dcentres, (size_t)C * zdim);
+    int rc = check_launch("zero dcentres");
+    if (rc) return rc;
+  }
+  size_t lds = prior_lds_bytes(g, true);
+  prior_bwd_kernel<<<dim3(ns, nq), NT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, lse,
+                                                    grad_out, tps, ns, g, use_atomic, dz_part, dcentres,
+                                                    dlv_part);
+  int rc = check_launch("prior_bwd_kernel");
+  if (rc) return rc;
+  int n = B * zdim > zdim ? B * zdim : zdim;
+  prior_bwd_finish_kernel<<<cdiv(n, 256), 256, 0, stream>>>(dz_part, ns, B, zdim, log_var, dlv_part,
+                                                           ns * nq, dz, dlogvar);
+  return check_launch("prior_bwd_finish_kernel");
+}

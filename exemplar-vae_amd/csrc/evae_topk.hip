@@ -1,0 +1,316 @@
+// Fused all-pairs distance + top-K on gfx950 (models/BaseModel.py:263-264, utils/knn_on_latent.py:4-9).
+//
+// Bit-exactness: the reference takes top-k of fp32(fp64 distance).  Here the distance is the direct
+// difference sum_k (q-c)^2 accumulated in fp64 (each fp32 operand converts exactly, each squared
+// difference is exact in fp64) and rounded ONCE to fp32; candidates are ordered by
+// (fp32 value ascending, index ascending).
+//
+// Shape: same 128-query x 64-exemplar LDS tile as the prior kernel (coalesced float4 streaming of the
+// [N x z] cache, conflict-free ds_read_b128), thread tile 8 x 4 with fp64 accumulators.  The fp32
+// distances of a tile go to LDS; each wave then owns 32 queries and keeps their running top-k lists in
+// LDS (lane s holds the s-th best): one broadcast read of the current k-th value, one ballot, and only
+// lanes that beat it are inserted by a wave-cooperative shift-insert.  A block scans a contiguous
+// split of the cache; per-split lists are merged by the same insertion code in a second kernel, which
+// is also the cross-shard (all-gathered) merge.
+#include "evae_tile.h"
+
+namespace evae {
+
+constexpr int DS = BE + 1;  // distance tile row stride
+
+struct TkList { float v; int64_t id; };
+
+__device__ __forceinline__ bool tk_less(float av, int64_t ai, float bv, int64_t bi) {
+  return (av < bv) || (av == bv && ai < bi);
+}
+
+// insert (cv, cid), known to be < entry k-1, into the sorted list held by lanes 0..k-1
+__device__ __forceinline__ void tk_insert(float& lv, int64_t& li, float cv, int64_t cid, int k, int lane) {
+  bool less = (lane < k) && tk_less(lv, li, cv, cid);
+  int pos = __popcll(__ballot(less));
+  float upv = __shfl_up(lv, 1, 64);
+  int64_t upi = __shfl_up(li, 1, 64);
+  if (lane > pos && lane < k) { lv = upv; li = upi; }
+  else if (lane == pos) { lv = cv; li = cid; }
+}
+
+// offer one candidate per lane to the list; returns true if the list changed
+__device__ __forceinline__ bool tk_offer(float& lv, int64_t& li, float v, int64_t id, bool valid, int k,
+                                         int lane) {
+  float tv = __shfl(lv, k - 1, 64);
+  int64_t ti = __shfl(li, k - 1, 64);
+  unsigned long long mask = __ballot(valid && tk_less(v, id, tv, ti));
+  bool changed = false;
+  while (mask) {
+    int L = __ffsll((long long)mask) - 1;
+    float cv = __shfl(v, L, 64);
+    int64_t cid = __shfl(id, L, 64);
+    if (tk_less(cv, cid, tv, ti)) {
+      tk_insert(lv, li, cv, cid, k, lane);
+      tv = __shfl(lv, k - 1, 64);
+      ti = __shfl(li, k - 1, 64);
+      changed = true;
+    }
+    mask &= mask - 1;
+  }
+  return changed;
+}
+
+__device__ __forceinline__ void dist_chunk_f64(double (&acc)[TQ][TE], const float* __restrict__ Qs,
+                                               const float* __restrict__ Es, int tq, int te, int kc,
+                                               int ks) {
+  for (int k = 0; k < kc; k += 4) {
+    double ed[TE][4];
+#pragma unroll
+    for (int j = 0; j < TE; ++j) {
+      const float4 e4 = *reinterpret_cast<const float4*>(Es + (te + 16 * j) * ks + k);
+      ed[j][0] = e4.x; ed[j][1] = e4.y; ed[j][2] = e4.z; ed[j][3] = e4.w;
+    }
+#pragma unroll
+    for (int i = 0; i < TQ; ++i) {
+      const float4 q4 = *reinterpret_cast<const float4*>(Qs + (tq + 16 * i) * ks + k);
+      const double q0 = q4.x, q1 = q4.y, q2 = q4.z, q3 = q4.w;
+#pragma unroll
+      for (int j = 0; j < TE; ++j) {
+        double d0 = q0 - ed[j][0], d1 = q1 - ed[j][1], d2 = q2 - ed[j][2], d3 = q3 - ed[j][3];
+        double a = acc[i][j];
+        a = fma(d0, d0, a);
+        a = fma(d1, d1, a);
+        a = fma(d2, d2, a);
+        a = fma(d3, d3, a);
+        acc[i][j] = a;
+      }
+    }
+  }
+}
+
+static size_t topk_lds_bytes(const PriorGeom& g, int k) {
+  size_t fl = (size_t)(BQ + BE) * g.ks + (size_t)BQ * DS + (size_t)BQ * k;  // + list values
+  size_t bytes = fl * sizeof(float);
+  bytes = align_up(bytes, 16) + (size_t)BQ * k * sizeof(int);
+  return bytes;
+}
+
+__global__ __launch_bounds__(NT) void pairdist_topk_kernel(
+    const float* __restrict__ q, int B, const float* __restrict__ cache, int N, int zdim, int k,
+    unsigned flags, int tiles_per_split, PriorGeom g, float* __restrict__ cand_val,
+    int64_t* __restrict__ cand_idx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;
+  float* Es = Qs + BQ * g.ks;
+  float* D = Es + BE * g.ks;          // [BQ][DS]
+  float* Lv = D + BQ * DS;            // [BQ][k]
+  int* Li = reinterpret_cast<int*>(   // shard-local exemplar index; INT_MAX = empty slot
+      reinterpret_cast<char*>(smem) + align_up(((size_t)(BQ + BE) * g.ks + (size_t)BQ * DS + (size_t)BQ * k) * 4, 16));
+
+  const int split = blockIdx.x;
+  const int q0 = blockIdx.y * BQ;
+  const int te = threadIdx.x & 15;
+  const int tq = threadIdx.x >> 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const bool vec_ok = (zdim & 3) == 0 && (((uintptr_t)q | (uintptr_t)cache) & 15) == 0;
+  const bool do_sqrt = (flags & EVAE_TOPK_SQRT) != 0;
+
+  for (int i = threadIdx.x; i < BQ * k; i += NT) { Lv[i] = INFINITY; Li[i] = INT_MAX; }
+  if (g.nchunk == 1) stage_rows<false>(Qs, q, q0, B, BQ, zdim, 0, g.kc, g.ks, nullptr, vec_ok);
+
+  const int ntiles = (N + BE - 1) / BE;
+  const int tile_begin = split * tiles_per_split;
+  int tile_end = tile_begin + tiles_per_split;
+  if (tile_end > ntiles) tile_end = ntiles;
+
+  for (int t = tile_begin; t < tile_end; ++t) {
+    const int e0 = t * BE;
+    double acc[TQ][TE];
+#pragma unroll
+    for (int i = 0; i < TQ; ++i)
+#pragma unroll
+      for (int j = 0; j < TE; ++j) acc[i][j] = 0.0;
+    for (int ch = 0; ch < g.nchunk; ++ch) {
+      __syncthreads();
+      if (g.nchunk > 1) stage_rows<false>(Qs, q, q0, B, BQ, zdim, ch * g.kc, g.kc, g.ks, nullptr, vec_ok);
+      stage_rows<false>(Es, cache, e0, N, BE, zdim, ch * g.kc, g.kc, g.ks, nullptr, vec_ok);
+      __syncthreads();
+      dist_chunk_f64(acc, Qs, Es, tq, te, g.kc, g.ks);
+    }
+#pragma unroll
+    for (int i = 0; i < TQ; ++i)
+#pragma unroll
+      for (int j = 0; j < TE; ++j) {
+        float v = (float)acc[i][j];
+        if (do_sqrt) v = sqrtf(v);
+        D[(tq + 16 * i) * DS + te + 16 * j] = v;
+      }
+    __syncthreads();
+    // wave w owns queries w*32 .. w*32+31
+    const int e = e0 + lane;
+    const bool valid = e < N;
+    for (int qq = 0; qq < BQ / 4; ++qq) {
+      const int ql = wave * (BQ / 4) + qq;
+      if (q0 + ql >= B) break;
+      const float v = D[ql * DS + lane];
+      const float tv = Lv[ql * k + k - 1];
+      const int64_t ti = Li[ql * k + k - 1];
+      if (__ballot(valid && tk_less(v, (int64_t)e, tv, ti)) == 0ull) continue;
+      float lv = lane < k ? Lv[ql * k + lane] : INFINITY;
+      int64_t li = lane < k ? (int64_t)Li[ql * k + lane] : (int64_t)INT_MAX;
+      tk_offer(lv, li, v, (int64_t)e, valid, k, lane);
+      if (lane < k) { Lv[ql * k + lane] = lv; Li[ql * k + lane] = (int)li; }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < BQ * k; i += NT) {
+    int ql = i / k;
+    if (q0 + ql < B) {
+      size_t o = ((size_t)split * B + q0 + ql) * k + (i - ql * k);
+      cand_val[o] = Lv[i];
+      cand_idx[o] = Li[i] == INT_MAX ? INT64_MAX : (int64_t)Li[i];
+    }
+  }
+}
+
+// materialised [B x N] distance matrix (API completeness: utils/distributions.py:12-18); fp64 accumulate
+__global__ __launch_bounds__(NT) void pairdist_kernel(const float* __restrict__ q, int B,
+                                                      const float* __restrict__ cache, int N, int zdim,
+                                                      PriorGeom g, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;
+  float* Es = Qs + BQ * g.ks;
+  const int e0 = blockIdx.x * BE, q0 = blockIdx.y * BQ;
+  const int te = threadIdx.x & 15, tq = threadIdx.x >> 4;
+  const bool vec_ok = (zdim & 3) == 0 && (((uintptr_t)q | (uintptr_t)cache) & 15) == 0;
+  double acc[TQ][TE];
+#pragma unroll
+  for (int i = 0; i < TQ; ++i)
+#pragma unroll
+    for (int j = 0; j < TE; ++j) acc[i][j] = 0.0;
+  for (int ch = 0; ch < g.nchunk; ++ch) {
+    __syncthreads();
+    stage_rows<false>(Qs, q, q0, B, BQ, zdim, ch * g.kc, g.kc, g.ks, nullptr, vec_ok);
+    stage_rows<false>(Es, cache, e0, N, BE, zdim, ch * g.kc, g.kc, g.ks, nullptr, vec_ok);
+    __syncthreads();
+    dist_chunk_f64(acc, Qs, Es, tq, te, g.kc, g.ks);
+  }
+#pragma unroll
+  for (int i = 0; i < TQ; ++i)
+#pragma unroll
+    for (int j = 0; j < TE; ++j) {
+      const int qi = q0 + tq + 16 * i, e = e0 + te + 16 * j;
+      if (qi < B && e < N) out[(size_t)qi * N + e] = (float)acc[i][j];
+    }
+}
+
+// one wave per query merges R lists of k (any order inside a list is fine)
+__global__ __launch_bounds__(NT) void topk_merge_kernel(const float* __restrict__ val,
+                                                        const int64_t* __restrict__ idx, int R, int B,
+                                                        int k, int64_t index_base,
+                                                        int64_t* __restrict__ out_idx,
+                                                        float* __restrict__ out_val) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float lv = INFINITY;
+  int64_t li = INT64_MAX;
+  const int total = R * k;
+  for (int c0 = 0; c0 < total; c0 += 64) {
+    int c = c0 + lane;
+    bool valid = c < total;
+    float v = INFINITY;
+    int64_t id = INT64_MAX;
+    if (valid) {
+      int r = c / k, s = c - r * k;
+      size_t o = ((size_t)r * B + row) * k + s;
+      v = val[o];
+      id = idx[o];
+      valid = id >= 0 && id != INT64_MAX;
+    }
+    tk_offer(lv, li, v, id, valid, k, lane);
+  }
+  if (lane < k) {
+    out_idx[(size_t)row * k + lane] = (li == INT64_MAX) ? (int64_t)-1 : li + index_base;
+    if (out_val) out_val[(size_t)row * k + lane] = lv;
+  }
+}
+
+static void topk_splits(int B, int N, int* nsplit, int* tps, int* nq) {
+  int ntiles = cdiv(N, BE);
+  *nq = cdiv(B, BQ);
+  int target = cdiv(768, *nq);
+  int ns = ntiles < target ? ntiles : target;
+  if (ns < 1) ns = 1;
+  *tps = cdiv(ntiles, ns);
+  if (*tps < 1) *tps = 1;
+  *nsplit = cdiv(ntiles, *tps);
+  if (*nsplit < 1) *nsplit = 1;
+}
+
+static bool g_topk_attr_set = false;
+
+}  // namespace evae
+
+using namespace evae;
+
+extern "C" size_t evae_pairdist_topk_workspace_bytes(int B, int N, int zdim, int k) {
+  (void)zdim;
+  if (B <= 0 || N <= 0 || k <= 0) return 256;
+  int ns, tps, nq;
+  topk_splits(B, N, &ns, &tps, &nq);
+  size_t n = (size_t)ns * B * k;
+  return align_up(n * sizeof(float), 256) + align_up(n * sizeof(int64_t), 256) + 256;
+}
+
+extern "C" int evae_pairdist_topk(const float* q, int B, const float* cache, int N, int zdim, int k,
+                                  unsigned flags, int64_t index_base, int64_t* out_idx, float* out_val,
+                                  void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(B >= 0 && N >= 0 && zdim > 0, "pairdist_topk: bad sizes B=%d N=%d zdim=%d", B, N, zdim);
+  EVAE_REQUIRE(k >= 1 && k <= 64, "pairdist_topk: k=%d outside [1,64]", k);
+  EVAE_REQUIRE(k <= N || N == 0, "pairdist_topk: k=%d > N=%d", k, N);
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(N > 0, "pairdist_topk: empty cache");
+  EVAE_REQUIRE(q && cache && out_idx, "pairdist_topk: null pointer");
+  EVAE_REQUIRE((size_t)N < (size_t)INT_MAX, "pairdist_topk: N too large for one shard");
+  if (ws == nullptr || ws_bytes < evae_pairdist_topk_workspace_bytes(B, N, zdim, k)) {
+    set_error("pairdist_topk: workspace too small (%zu)", ws_bytes);
+    return EVAE_EWORKSPACE;
+  }
+  int ns, tps, nq;
+  topk_splits(B, N, &ns, &tps, &nq);
+  PriorGeom g = prior_geom(zdim);
+  size_t n = (size_t)ns * B * k;
+  float* cv = (float*)ws;
+  int64_t* ci = (int64_t*)((char*)ws + align_up(n * sizeof(float), 256));
+  size_t lds = topk_lds_bytes(g, k);
+  if (!g_topk_attr_set) {
+    (void)hipFuncSetAttribute((const void*)pairdist_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    g_topk_attr_set = true;
+  }
+  pairdist_topk_kernel<<<dim3(ns, nq), NT, lds, stream>>>(q, B, cache, N, zdim, k, flags, tps, g, cv, ci);
+  int rc = check_launch("pairdist_topk_kernel");
+  if (rc) return rc;
+  topk_merge_kernel<<<cdiv(B, NT / 64), NT, 0, stream>>>(cv, ci, ns, B, k, index_base, out_idx, out_val);
+  return check_launch("topk_merge_kernel");
+}
+
+extern "C" int evae_topk_merge(const float* val, const int64_t* idx, int R, int B, int k,
+                               int64_t* out_idx, float* out_val, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(R >= 1 && B >= 0 && k >= 1 && k <= 64, "topk_merge: bad sizes R=%d B=%d k=%d", R, B, k);
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(val && idx && out_idx, "topk_merge: null pointer");
+  topk_merge_kernel<<<cdiv(B, NT / 64), NT, 0, stream>>>(val, idx, R, B, k, 0, out_idx, out_val);
+  return check_launch("topk_merge_kernel");
+}
+
+extern "C" int evae_pairwise_distance(const float* q, int B, const float* cache, int N, int zdim,
+                                      float* out, evae_stream_t stream_) {
+  EVAE_REQUIRE(B >= 0 && N >= 0 && zdim > 0, "pairwise_distance: bad sizes");
+  if (B == 0 || N == 0) return EVAE_OK;
+  EVAE_REQUIRE(q && cache && out, "pairwise_distance: null pointer");
+  PriorGeom g = prior_geom(zdim);
+  size_t lds = (size_t)(BQ + BE) * g.ks * sizeof(float);
+  pairdist_kernel<<<dim3(cdiv(N, BE), cdiv(B, BQ)), NT, lds, (hipStream_t)stream_>>>(q, B, cache, N, zdim, g, out);
+  return check_launch("pairdist_kernel");
+}

@@ -1,0 +1,86 @@
+"""ctypes binding of libevae_hip.so (C ABI: include/evae_hip.h).
+
+There is NO CPU fallback: `load()` raises if the shared library is missing, and every op in
+`evae.ops` raises on non-CUDA tensors.  The library is built in-tree by `__graft_entry__.build()`
+(or `make -C exemplar-vae_amd/csrc`)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libevae_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_d = C.c_double
+_z = C.c_size_t
+_l = C.c_int64
+_u = C.c_uint
+
+
+class AdamTensor(C.Structure):
+    """evae_adam_tensor_t"""
+    _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("numel", _l)]
+
+
+# name -> (restype, argtypes); mirrors include/evae_hip.h one to one
+SIGNATURES = {
+    "evae_version": (_i, []),
+    "evae_last_error": (C.c_char_p, []),
+    "evae_prior_lse_fwd_workspace_bytes": (_z, [_i, _i, _i]),
+    "evae_prior_lse_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_prior_merge": (_i, [_p, _p, _p, _i, _i, _f, _p, _p, _p]),
+    "evae_prior_lse_bwd_workspace_bytes": (_z, [_i, _i, _i]),
+    "evae_prior_lse_bwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_pairdist_topk_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "evae_pairdist_topk": (_i, [_p, _i, _p, _i, _i, _i, _u, _l, _p, _p, _p, _z, _p]),
+    "evae_pairwise_distance": (_i, [_p, _i, _p, _i, _i, _p, _p]),
+    "evae_topk_merge": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
+    "evae_gated_dense_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "evae_linear_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _f, _p, _p, _p]),
+    "evae_dense_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "evae_dense_bwd_weight_workspace_bytes": (_z, [_i, _i, _i]),
+    "evae_dense_bwd_weight": (_i, [_p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p, _z, _p]),
+    "evae_gated_dense_bwd_input": (_i, [_p, _p, _p, _z, _p, _p, _p]),
+    "evae_act_bwd": (_i, [_p, _p, _z, _i, _f, _f, _p, _p]),
+    "evae_reparam_logq_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
+    "evae_reparam_logq_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
+    "evae_log_normal_diag_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+    "evae_log_normal_diag_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "evae_bernoulli_ll_fwd": (_i, [_p, _p, _i, _i, _p, _p]),
+    "evae_bernoulli_ll_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+    "evae_adam_normgrad_workspace_bytes": (_z, [_i]),
+    "evae_adam_normgrad_step": (_i, [_p, _i, _l, _i, _d, _d, _d, _d, _d, _p, _z, _p]),
+}
+
+_lib = None
+
+
+class EvaeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libevae_hip.so and bind every entry point.  Fails loudly when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EvaeError(
+            "libevae_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C exemplar-vae_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch with include/evae_hip.h
+        fn.restype = res
+        fn.argtypes = args
+    if lib.evae_version() != 1:
+        raise EvaeError("libevae_hip.so ABI version %d, expected 1" % lib.evae_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().evae_last_error().decode("utf-8", "replace")
+        raise EvaeError("%s failed (%d): %s" % (what, rc, msg))

@@ -1,0 +1,422 @@
+"""Host-side operators over the C ABI: raw launches on the current HIP stream plus the
+torch.autograd.Function wrappers the reference-named modules (utils/nn.py, utils/distributions.py,
+models/BaseModel.py) are built from.  PyTorch here is device memory, streams and autograd plumbing;
+all arithmetic on [rows x features] data happens in libevae_hip.so.  No CPU fallback."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_SIGMOID, ACT_HARDTANH = 0, 1, 2
+TOPK_SQRT = 1
+
+_ws = {}
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.EvaeError(
+                "evae ops run on MI355X only (got a %s tensor); there is no CPU fallback" % t.device)
+
+
+def _workspace(name, nbytes, device):
+    key = (name, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _i64(t):
+    if t is None:
+        return None
+    if t.dtype != torch.int64:
+        t = t.long()
+    t = t.reshape(-1)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# exemplar prior
+# ------------------------------------------------------------------------------------------------
+def prior_lse_fwd(z, centres, log_var, z_idx=None, c_idx=None, want_prob=False):
+    """One shard's partials: (max [B], sumexp [B], nmask [B], prob [B x C] or None)."""
+    lib = _lib.load()
+    _need_cuda(z, centres, log_var, z_idx, c_idx)
+    z, centres, log_var = _f32(z), _f32(centres), _f32(log_var).reshape(-1)
+    B, zd = z.shape
+    Cn = centres.shape[0]
+    z_idx, c_idx = _i64(z_idx), _i64(c_idx)
+    if z_idx is not None and c_idx is not None:
+        assert z_idx.numel() == B and c_idx.numel() == Cn
+    else:
+        z_idx = c_idx = None
+    m = torch.empty(B, device=z.device); s = torch.empty_like(m); n = torch.empty_like(m)
+    prob = torch.empty((B, Cn), device=z.device) if want_prob else None
+    nb = lib.evae_prior_lse_fwd_workspace_bytes(B, Cn, zd)
+    ws = _workspace("prior_fwd", nb, z.device)
+    _lib.check(lib.evae_prior_lse_fwd(_p(z), B, _p(centres), Cn, zd, _p(log_var), _p(z_idx), _p(c_idx),
+                                      _p(m), _p(s), _p(n), _p(prob), _p(ws), ws.numel(), _stream()),
+               "evae_prior_lse_fwd")
+    return m, s, n, prob
+
+
+def prior_merge(m, s, n, c_total):
+    """[R x B] shard partials -> (logprior [B], lse [B])."""
+    lib = _lib.load()
+    _need_cuda(m, s, n)
+    m, s, n = _f32(m), _f32(s), _f32(n)
+    if m.dim() == 1:
+        m, s, n = m[None], s[None], n[None]
+    R, B = m.shape
+    lp = torch.empty(B, device=m.device); lse = torch.empty_like(lp)
+    _lib.check(lib.evae_prior_merge(_p(m), _p(s), _p(n), R, B, float(c_total), _p(lp), _p(lse), _stream()),
+               "evae_prior_merge")
+    return lp, lse
+
+
+def prior_lse_bwd(z, centres, log_var, z_idx, c_idx, lse, grad_out):
+    lib = _lib.load()
+    _need_cuda(z, centres, log_var, lse, grad_out)
+    z, centres, log_var = _f32(z), _f32(centres), _f32(log_var).reshape(-1)
+    lse, grad_out = _f32(lse), _f32(grad_out)
+    B, zd = z.shape
+    Cn = centres.shape[0]
+    z_idx, c_idx = _i64(z_idx), _i64(c_idx)
+    if z_idx is None or c_idx is None:
+        z_idx = c_idx = None
+    dz = torch.empty_like(z); dc = torch.empty_like(centres); dlv = torch.empty(zd, device=z.device)
+    nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cn, zd)
+    ws = _workspace("prior_bwd", nb, z.device)
+    _lib.check(lib.evae_prior_lse_bwd(_p(z), B, _p(centres), Cn, zd, _p(log_var), _p(z_idx), _p(c_idx),
+                                      _p(lse), _p(grad_out), _p(dz), _p(dc), _p(dlv), _p(ws), ws.numel(),
+                                      _stream()), "evae_prior_lse_bwd")
+    return dz, dc, dlv
+
+
+class PriorLogP(torch.autograd.Function):
+    """log p(z_i) under the exemplar mixture of ONE device's exemplars (models/BaseModel.py:98-128).
+    forward(z, centres, log_var_row [zdim], z_idx|None, c_idx|None) -> logprior [B]."""
+
+    @staticmethod
+    def forward(ctx, z, centres, log_var_row, z_idx, c_idx):
+        m, s, n, _ = prior_lse_fwd(z, centres, log_var_row, z_idx, c_idx)
+        lp, lse = prior_merge(m, s, n, centres.shape[0])
+        ctx.save_for_backward(z, centres, log_var_row, lse)
+        ctx.idx = (z_idx, c_idx)
+        return lp
+
+    @staticmethod
+    def backward(ctx, g):
+        z, centres, log_var_row, lse = ctx.saved_tensors
+        z_idx, c_idx = ctx.idx
+        dz, dc, dlv = prior_lse_bwd(z, centres, log_var_row, z_idx, c_idx, lse, g.contiguous())
+        return dz, dc, dlv.reshape(log_var_row.shape), None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# distance + top-K
+# ------------------------------------------------------------------------------------------------
+def pairdist_topk(q, cache, k, sqrt=False, index_base=0, want_val=True):
+    lib = _lib.load()
+    _need_cuda(q, cache)
+    q, cache = _f32(q), _f32(cache)
+    B, zd = q.shape
+    N = cache.shape[0]
+    idx = torch.empty((B, k), dtype=torch.int64, device=q.device)
+    val = torch.empty((B, k), device=q.device) if want_val else None
+    nb = lib.evae_pairdist_topk_workspace_bytes(B, N, zd, k)
+    ws = _workspace("topk", nb, q.device)
+    _lib.check(lib.evae_pairdist_topk(_p(q), B, _p(cache), N, zd, k, TOPK_SQRT if sqrt else 0,
+                                      int(index_base), _p(idx), _p(val), _p(ws), ws.numel(), _stream()),
+               "evae_pairdist_topk")
+    return idx, val
+
+
+def pairwise_distance(q, cache):
+    """[B x N] fp32 squared distances (fp64-accumulated)."""
+    lib = _lib.load()
+    _need_cuda(q, cache)
+    q, cache = _f32(q), _f32(cache)
+    out = torch.empty((q.shape[0], cache.shape[0]), device=q.device)
+    _lib.check(lib.evae_pairwise_distance(_p(q), q.shape[0], _p(cache), cache.shape[0], q.shape[1], _p(out),
+                                          _stream()), "evae_pairwise_distance")
+    return out
+
+
+def topk_merge(val, idx):
+    """[R x B x k] candidate lists -> global ([B x k] idx, [B x k] val)."""
+    lib = _lib.load()
+    _need_cuda(val, idx)
+    val = _f32(val)
+    idx = idx.long().contiguous()
+    R, B, k = val.shape
+    oi = torch.empty((B, k), dtype=torch.int64, device=val.device)
+    ov = torch.empty((B, k), device=val.device)
+    _lib.check(lib.evae_topk_merge(_p(val), _p(idx), R, B, k, _p(oi), _p(ov), _stream()), "evae_topk_merge")
+    return oi, ov
+
+
+# ------------------------------------------------------------------------------------------------
+# dense layers
+# ------------------------------------------------------------------------------------------------
+def _bwd_weight(dy, x, rows, K, want_db=True):
+    lib = _lib.load()
+    M, N = dy.shape
+    dw = torch.empty((N, K), device=dy.device)
+    db = torch.empty(N, device=dy.device) if want_db else None
+    nb = lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
+    ws = _workspace("wgrad", nb, dy.device)
+    _lib.check(lib.evae_dense_bwd_weight(_p(dy), M, N, _p(x), _p(rows), K, x.stride(0), _p(dw), _p(db), 0,
+                                         _p(ws), ws.numel(), _stream()), "evae_dense_bwd_weight")
+    return dw, db
+
+
+def _bwd_data(dy1, w1, dy2=None, w2=None, h_prev=None, s_prev=None):
+    lib = _lib.load()
+    M, N = dy1.shape
+    K = w1.shape[1]
+    out = torch.empty((M, K), device=dy1.device)
+    dg = torch.empty((M, K), device=dy1.device) if h_prev is not None else None
+    _lib.check(lib.evae_dense_bwd_data(_p(dy1), _p(w1), _p(dy2), _p(w2), M, N, K, _p(h_prev), _p(s_prev),
+                                       _p(out), _p(dg), _stream()), "evae_dense_bwd_data")
+    return out, dg
+
+
+def _rows_x(x, rows):
+    """Validate the (x, rows) pair: x is [R x K] with unit inner stride; rows gathers M rows of it."""
+    x = x if x.dtype == torch.float32 else x.float()
+    if x.dim() != 2:
+        x = x.reshape(x.shape[0], -1)
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    rows = _i64(rows)
+    M = x.shape[0] if rows is None else rows.numel()
+    return x, rows, M
+
+
+class GatedDenseFn(torch.autograd.Function):
+    """utils/nn.py:44-69 (activation None, gate on): h(x) * sigmoid(g(x)), optional row gather."""
+
+    @staticmethod
+    def forward(ctx, x, rows, wh, bh, wg, bg):
+        lib = _lib.load()
+        _need_cuda(x, rows, wh, wg)
+        x, rows, M = _rows_x(x, rows)
+        wh, wg = _f32(wh), _f32(wg)
+        N, K = wh.shape
+        out = torch.empty((M, N), device=x.device)
+        need_grad = any(ctx.needs_input_grad)
+        h = torch.empty_like(out) if need_grad else None
+        s = torch.empty_like(out) if need_grad else None
+        _lib.check(lib.evae_gated_dense_fwd(_p(x), _p(rows), M, K, x.stride(0), _p(wh), _p(bh), _p(wg), _p(bg),
+                                            N, _p(out), _p(h), _p(s), _stream()), "evae_gated_dense_fwd")
+        if need_grad:
+            ctx.save_for_backward(x, rows, wh, wg, h, s)
+        ctx.has_bias = (bh is not None, bg is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, rows, wh, wg, h, s = ctx.saved_tensors
+        dout = _f32(dout)
+        dh = torch.empty_like(h); dg = torch.empty_like(h)
+        _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(h), _p(s), h.numel(), _p(dh), _p(dg), _stream()),
+                   "evae_gated_dense_bwd_input")
+        K = wh.shape[1]
+        dwh, dbh = _bwd_weight(dh, x, rows, K)
+        dwg, dbg = _bwd_weight(dg, x, rows, K)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if rows is not None:
+                raise _lib.EvaeError("gradient wrt a row-gathered input is not supported")
+            dx, _ = _bwd_data(dh, wh, dg, wg)
+        return dx, None, dwh, (dbh if ctx.has_bias[0] else None), dwg, (dbg if ctx.has_bias[1] else None)
+
+
+class LinearFn(torch.autograd.Function):
+    """act(x W^T + b): torch.nn.Linear / utils/nn.py:29-41 NonLinear."""
+
+    @staticmethod
+    def forward(ctx, x, rows, w, b, act, lo, hi):
+        lib = _lib.load()
+        _need_cuda(x, rows, w)
+        x, rows, M = _rows_x(x, rows)
+        w = _f32(w)
+        N, K = w.shape
+        y = torch.empty((M, N), device=x.device)
+        need_grad = any(ctx.needs_input_grad)
+        pre = torch.empty_like(y) if (need_grad and act == ACT_HARDTANH) else None
+        _lib.check(lib.evae_linear_fwd(_p(x), _p(rows), M, K, x.stride(0), _p(w), _p(b), N, act, float(lo),
+                                       float(hi), _p(y), _p(pre), _stream()), "evae_linear_fwd")
+        if need_grad:
+            ctx.save_for_backward(x, rows, w, pre if pre is not None else y)
+        ctx.act = (act, float(lo), float(hi))
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, rows, w, aux = ctx.saved_tensors
+        act, lo, hi = ctx.act
+        dy = _f32(dy)
+        if act != ACT_NONE:
+            dpre = torch.empty_like(dy)
+            _lib.check(lib.evae_act_bwd(_p(dy), _p(aux), dy.numel(), act, lo, hi, _p(dpre), _stream()),
+                       "evae_act_bwd")
+        else:
+            dpre = dy
+        dw, db = _bwd_weight(dpre, x, rows, w.shape[1])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if rows is not None:
+                raise _lib.EvaeError("gradient wrt a row-gathered input is not supported")
+            dx, _ = _bwd_data(dpre, w)
+        return dx, None, dw, (db if ctx.has_bias else None), None, None, None
+
+
+def gated_dense(x, wh, bh, wg, bg, rows=None):
+    return GatedDenseFn.apply(x, rows, wh, bh, wg, bg)
+
+
+def linear(x, w, b, act=ACT_NONE, lo=0.0, hi=0.0, rows=None):
+    return LinearFn.apply(x, rows, w, b, act, lo, hi)
+
+
+# ------------------------------------------------------------------------------------------------
+# latent sampling / log-densities
+# ------------------------------------------------------------------------------------------------
+class ReparamLogQ(torch.autograd.Function):
+    """(mu, logvar, eps) -> (z = mu + eps*exp(logvar/2), log q(z|x))."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        lib = _lib.load()
+        _need_cuda(mu, logvar, eps)
+        mu, logvar, eps = _f32(mu), _f32(logvar), _f32(eps)
+        B, zd = mu.shape
+        z = torch.empty_like(mu); logq = torch.empty(B, device=mu.device)
+        _lib.check(lib.evae_reparam_logq_fwd(_p(mu), _p(logvar), _p(eps), B, zd, _p(z), _p(logq), _stream()),
+                   "evae_reparam_logq_fwd")
+        ctx.save_for_backward(mu, logvar, eps, z)
+        return z, logq
+
+    @staticmethod
+    def backward(ctx, dz, dlogq):
+        lib = _lib.load()
+        mu, logvar, eps, z = ctx.saved_tensors
+        B, zd = mu.shape
+        dz = None if dz is None else _f32(dz)
+        dlogq = None if dlogq is None else _f32(dlogq)
+        dmu = torch.empty_like(mu); dlv = torch.empty_like(mu)
+        _lib.check(lib.evae_reparam_logq_bwd(_p(mu), _p(logvar), _p(eps), _p(z), _p(dz), _p(dlogq), B, zd,
+                                             _p(dmu), _p(dlv), _stream()), "evae_reparam_logq_bwd")
+        return dmu, dlv, None
+
+
+class LogNormalDiag(torch.autograd.Function):
+    """utils/distributions.py:28-33 summed over dim=1 for [B x z] inputs."""
+
+    @staticmethod
+    def forward(ctx, x, mu, logvar):
+        lib = _lib.load()
+        _need_cuda(x, mu, logvar)
+        x, mu, logvar = _f32(x), _f32(mu), _f32(logvar)
+        B, zd = x.shape
+        out = torch.empty(B, device=x.device)
+        _lib.check(lib.evae_log_normal_diag_fwd(_p(x), _p(mu), _p(logvar), B, zd, _p(out), _stream()),
+                   "evae_log_normal_diag_fwd")
+        ctx.save_for_backward(x, mu, logvar)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, mu, logvar = ctx.saved_tensors
+        B, zd = x.shape
+        g = _f32(g)
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need[0] else None
+        dmu = torch.empty_like(x) if need[1] else None
+        dlv = torch.empty_like(x) if need[2] else None
+        _lib.check(lib.evae_log_normal_diag_bwd(_p(x), _p(mu), _p(logvar), _p(g), B, zd, _p(dx), _p(dmu), _p(dlv),
+                                                _stream()), "evae_log_normal_diag_bwd")
+        return dx, dmu, dlv
+
+
+class BernoulliLL(torch.autograd.Function):
+    """utils/distributions.py:44-51 summed over dim=1: x [B x D] (no grad), mean [B x D]."""
+
+    @staticmethod
+    def forward(ctx, x, mean):
+        lib = _lib.load()
+        _need_cuda(x, mean)
+        x, mean = _f32(x), _f32(mean)
+        B, D = mean.shape
+        out = torch.empty(B, device=mean.device)
+        _lib.check(lib.evae_bernoulli_ll_fwd(_p(x), _p(mean), B, D, _p(out), _stream()), "evae_bernoulli_ll_fwd")
+        ctx.save_for_backward(x, mean)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, mean = ctx.saved_tensors
+        B, D = mean.shape
+        g = _f32(g)
+        dmean = torch.empty_like(mean)
+        _lib.check(lib.evae_bernoulli_ll_bwd(_p(x), _p(mean), _p(g), B, D, _p(dmean), _stream()),
+                   "evae_bernoulli_ll_bwd")
+        return None, dmean
+
+
+# ------------------------------------------------------------------------------------------------
+# AdamNormGrad
+# ------------------------------------------------------------------------------------------------
+def adam_normgrad_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps, weight_decay,
+                       table_cache=None):
+    """One multi-tensor AdamNormGrad update (utils/optimizer.py:32-80).  `table_cache` (a dict) lets the
+    caller reuse the device pointer table while the tensor addresses stay the same."""
+    lib = _lib.load()
+    n = len(params)
+    if n == 0:
+        return
+    dev = params[0].device
+    _need_cuda(*params)
+    key = tuple(t.data_ptr() for ts in (params, grads, exp_avgs, exp_avg_sqs) for t in ts)
+    table = None if table_cache is None else table_cache.get("table")
+    if table is None or table_cache.get("key") != key:
+        arr = (_lib.AdamTensor * n)()
+        for i in range(n):
+            assert grads[i].is_contiguous() and params[i].is_contiguous()
+            arr[i].param = params[i].data_ptr(); arr[i].grad = grads[i].data_ptr()
+            arr[i].exp_avg = exp_avgs[i].data_ptr(); arr[i].exp_avg_sq = exp_avg_sqs[i].data_ptr()
+            arr[i].numel = params[i].numel()
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        table = host.to(dev)
+        if table_cache is not None:
+            table_cache["table"] = table; table_cache["key"] = key
+    nb = lib.evae_adam_normgrad_workspace_bytes(n)
+    ws = _workspace("adam", nb, dev)
+    _lib.check(lib.evae_adam_normgrad_step(_p(table), n, max(p.numel() for p in params), int(step), float(lr),
+                                           float(beta1), float(beta2), float(eps), float(weight_decay),
+                                           _p(ws), ws.numel(), _stream()), "evae_adam_normgrad_step")

@@ -1,0 +1,125 @@
+"""Sharding of the exemplar prior across the GPUs of one node.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  The C exemplar slots of a
+step are split into R contiguous, possibly uneven shards; every rank encodes only its shard (the
+dominant cost, 1/R each) and holds the full batch latents (the B-row batch path is replicated: same
+weights, same eps, same CPU-generator exemplar indices on every rank).
+
+Forward exchange: ONE all-gather of the packed per-row partials (max, sumexp, nmask) -- 3*B floats per
+rank, latency-bound, so a single one-shot collective instead of a MAX-then-SUM pair -- followed by the
+local merge kernel (evae_prior_merge): M = max_r m_r, lse = M + log sum_r s_r e^{m_r - M},
+logprior = lse - log(C - sum_r nmask_r).  This is the all-reduce of partial log-sum-exps.
+
+Backward: w_ij is recomputed from the GLOBAL lse; dcentres stays local, dz [B x z] and dlogvar [z] are
+sum-all-reduced.  Parameter gradients are then averaged over ranks (allreduce_grads, called by
+AdamNormGrad.step) -- dcentres is pre-scaled by R so that the average equals
+(replicated batch-path gradient) + sum_r (shard-r exemplar-path gradient), i.e. the single-GPU gradient.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class ShardedEmbedding(tuple):
+    """(centres_local, logvar_local, indices_local) plus the global exemplar count."""
+
+    def __new__(cls, items, total):
+        obj = super().__new__(cls, items)
+        obj.sharded_total = int(total)
+        return obj
+
+
+def is_active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world():
+    return (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+
+
+def bounds(n, rank=None, world_size=None):
+    """[lo, hi) of shard `rank` when n items are split into world_size contiguous shards whose sizes
+    differ by at most one (the first n % R shards get the extra item; shards may be empty)."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    q, r = divmod(int(n), int(world_size))
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def gather_partials(m, s, n, group=None):
+    """All-gather the packed [3 x B] partials of every rank -> ([R x B], [R x B], [R x B])."""
+    packed = torch.stack((m, s, n)).contiguous()
+    R = dist.get_world_size(group)
+    out = torch.empty((R,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    return out[:, 0].contiguous(), out[:, 1].contiguous(), out[:, 2].contiguous()
+
+
+def gather_topk(val, idx, group=None):
+    """All-gather per-shard top-k candidates ([B x k] values and GLOBAL indices) -> [R x B x k] each."""
+    R = dist.get_world_size(group)
+    v = torch.empty((R,) + tuple(val.shape), dtype=val.dtype, device=val.device)
+    i = torch.empty((R,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device)
+    dist.all_gather_into_tensor(v, val.contiguous(), group=group)
+    dist.all_gather_into_tensor(i, idx.contiguous(), group=group)
+    return v, i
+
+
+def sharded_topk(q, cache_local, k, index_base, sqrt=False, group=None):
+    """Exact global top-k over a row-sharded cache: local top-k, one all-gather, merge kernel."""
+    if cache_local.shape[0] >= k:
+        idx, val = ops.pairdist_topk(q, cache_local, k, sqrt=sqrt, index_base=index_base)
+    else:                                            # shard smaller than k (or empty): pad with empties
+        B = q.shape[0]
+        val = torch.full((B, k), float('inf'), device=q.device)
+        idx = torch.full((B, k), -1, dtype=torch.int64, device=q.device)
+        n = cache_local.shape[0]
+        if n > 0:
+            i2, v2 = ops.pairdist_topk(q, cache_local, n, sqrt=sqrt, index_base=index_base)
+            val[:, :n] = v2
+            idx[:, :n] = i2
+    v, i = gather_topk(val, idx, group)
+    return ops.topk_merge(v, i)
+
+
+class ShardedPriorLogP(torch.autograd.Function):
+    """log p(z_i) under the exemplar mixture whose exemplars are sharded over the ranks of `group`."""
+
+    @staticmethod
+    def forward(ctx, z, centres_local, log_var_row, z_idx, c_idx_local, c_total, group=None):
+        m, s, n, _ = ops.prior_lse_fwd(z, centres_local, log_var_row, z_idx, c_idx_local)
+        gm, gs, gn = gather_partials(m, s, n, group)
+        lp, lse = ops.prior_merge(gm, gs, gn, c_total)
+        ctx.save_for_backward(z, centres_local, log_var_row, lse)
+        ctx.misc = (z_idx, c_idx_local, group)
+        return lp
+
+    @staticmethod
+    def backward(ctx, g):
+        z, centres_local, log_var_row, lse = ctx.saved_tensors
+        z_idx, c_idx_local, group = ctx.misc
+        dz, dc, dlv = ops.prior_lse_bwd(z, centres_local, log_var_row, z_idx, c_idx_local, lse, g.contiguous())
+        packed = torch.cat((dz.reshape(-1), dlv.reshape(-1)))
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)          # one 16 KB collective
+        dz = packed[:dz.numel()].reshape(dz.shape)
+        dlv = packed[dz.numel():].reshape(log_var_row.shape)
+        R = dist.get_world_size(group)
+        return dz, dc * float(R), dlv, None, None, None, None
+
+
+def allreduce_grads(params, group=None):
+    """Average the gradients of `params` over ranks with ONE flat all-reduce (a few MB: 4.5 MB for vae,
+    9.7 MB for hvae -- one bucket, so one collective per step)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(dist.get_world_size(group))
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n

@@ -1,0 +1,93 @@
+"""Evaluation loops with the reference's signatures (reference utils/evaluation.py:11-140): ELBO against
+the full exemplar cache and the IWAE test log-likelihood.  The prior over ALL training exemplars
+([B x N_train], [S x N_train] with S = 5000 per test image) is where the fused prior kernel dominates;
+sums and the final log-sum-exp stay on the device (one host read per loop instead of one per batch /
+per image, reference :27-29,96)."""
+import math
+import time
+
+import numpy as np
+import torch
+
+from utils.utils import load_model
+
+
+def load_all_pseudo_input(args, model, dataset):
+    """Exemplar embedding of the whole training set: (z [N x z], logvar [N x z], arange(N))."""
+    if args.prior == 'exemplar_prior':
+        exemplars_z, exemplars_log_var = model.cache_z(dataset)
+        return (exemplars_z, exemplars_log_var, torch.arange(len(exemplars_z)))
+    if args.prior == 'vampprior':
+        pseudo_means = model.means(model.idle_input)
+        if 'conv' in args.model_name:
+            pseudo_means = pseudo_means.view(-1, args.input_size[0], args.input_size[1], args.input_size[2])
+        return model.q_z(pseudo_means, prior=True)
+    if args.prior == 'standard':
+        return None
+    raise Exception("wrong name of prior")
+
+
+def evaluate_loss(args, model, loader, dataset=None, exemplars_embedding=None):
+    model.eval()
+    if exemplars_embedding is None:
+        exemplars_embedding = load_all_pseudo_input(args, model, dataset)
+    totals = torch.zeros(3, device=args.device, dtype=torch.float64)
+    for batch in loader:
+        data = batch[0].to(args.device)
+        loss, RE, KL = model.calculate_loss((data, None), average=False, exemplars_embedding=exemplars_embedding)
+        totals += torch.stack((loss.sum(), -RE.sum(), KL.sum())).double()
+    elbo, re, kl = (totals / len(loader.dataset)).tolist()
+    return elbo, re, kl
+
+
+def calculate_likelihood(args, model, loader, S=5000, exemplars_embedding=None):
+    """IWAE estimate -mean_x [logsumexp_s(-loss_s) - log S]  (reference :72-103)."""
+    aux = torch.utils.data.DataLoader(loader.dataset, batch_size=1)
+    out = torch.empty(len(aux), device=args.device, dtype=torch.float64)
+    t0 = time.time()
+    for index, batch in enumerate(aux):
+        data = batch[0].to(args.device)
+        if index % 100 == 0:
+            print(time.time() - t0)
+            t0 = time.time()
+            print('{:.2f}%'.format(index / (1. * len(aux)) * 100))
+        x = data.expand(S, data.size(1)).contiguous()
+        prob, _, _ = model.calculate_loss((x, None), exemplars_embedding=exemplars_embedding)
+        ll = torch.logsumexp(-prob.double(), dim=0)
+        if model.args.use_logit:
+            lambd = model.args.lambd
+            sp = torch.nn.functional.softplus
+            ll = ll - (-sp(-x) - sp(x) - math.log((1 - 2 * lambd) / 256)).sum(dim=1).double()
+        out[index] = (ll - math.log(len(prob))).reshape(-1)[0]
+    return -float(out.mean().item())
+
+
+def final_evaluation(train_loader, test_loader, valid_loader, best_model_path_load, model, optimizer, args, dir):
+    _ = load_model(best_model_path_load, model, optimizer)
+    model.eval()
+    with torch.no_grad():
+        emb = load_all_pseudo_input(args, model, train_loader.dataset)
+        test_elbo, test_re, test_kl = evaluate_loss(args, model, test_loader, dataset=train_loader.dataset,
+                                                    exemplars_embedding=emb)
+        valid_elbo, _, _ = evaluate_loss(args, model, valid_loader, dataset=valid_loader.dataset,
+                                         exemplars_embedding=emb)
+        train_elbo, _, _ = evaluate_loss(args, model, train_loader, dataset=train_loader.dataset,
+                                         exemplars_embedding=emb)
+        test_log_likelihood = calculate_likelihood(args, model, test_loader, exemplars_embedding=emb, S=args.S)
+    txt = ('FINAL EVALUATION ON TEST SET\nLogL (TEST): {:.2f}\nLogL (TRAIN): {:.2f}\nELBO (TEST): {:.2f}\n'
+           'ELBO (TRAIN): {:.2f}\nELBO (VALID): {:.2f}\nRE: {:.2f}\nKL: {:.2f}').format(
+        test_log_likelihood, 0, test_elbo, train_elbo, valid_elbo, test_re, test_kl)
+    print(txt)
+    with open(dir + 'vae_experiment_log.txt', 'a') as f:
+        print(txt, file=f)
+    torch.save(test_log_likelihood, dir + args.model_name + '.test_log_likelihood')
+    torch.save(test_elbo, dir + args.model_name + '.test_loss')
+    torch.save(test_re, dir + args.model_name + '.test_re')
+    torch.save(test_kl, dir + args.model_name + '.test_kl')
+
+
+def compute_mean_variance_per_dimension(args, model, test_loader):
+    means = torch.cat([model.q_z(batch.to(args.device))[0] for batch, _ in test_loader], dim=0)
+    active = int((means.var(dim=0, unbiased=False) > 0.01).sum().item())
+    print('active dimensions', active)
+    return active

@@ -1,0 +1,134 @@
+"""Layer modules with the reference's names, constructor arguments and state_dict keys
+(reference utils/nn.py:12-114), computing through the HIP dense kernels (evae.ops).
+
+GatedDense / NonLinear / Linear run on the fp32-MFMA GEMM of libevae_hip.so with the bias,
+activation and gate fused into the epilogue.  GatedConv2d / Conv2d keep the reference interface; their
+convolutions currently go through MIOpen (torch.nn.functional.conv2d on the GPU) -- the fused
+implicit-GEMM HIP convolution is a later SURVEY section-8 row (a18), see DESIGN.md."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from evae import ops
+
+
+def he_init(m):
+    """N(0, sqrt(2 / fan_in)) on m.weight  (reference utils/nn.py:12-14)."""
+    m.weight.data.normal_(0, float(np.sqrt(2.0 / m.in_features)))
+
+
+def xavier_init(m):
+    m.weight.data.normal_(0, float(np.sqrt(2.0 / (m.in_features + m.out_features))))
+
+
+def normal_init(m, mean=0., std=0.01):
+    m.weight.data.normal_(mean, std)
+
+
+def _act_code(activation):
+    """Map an nn activation module onto an epilogue code; None if it has to run as a separate op."""
+    if activation is None:
+        return ops.ACT_NONE, 0.0, 0.0
+    if isinstance(activation, nn.Sigmoid):
+        return ops.ACT_SIGMOID, 0.0, 0.0
+    if isinstance(activation, nn.Hardtanh):
+        return ops.ACT_HARDTANH, float(activation.min_val), float(activation.max_val)
+    return None
+
+
+def dense(x, linear_module, activation=None, rows=None):
+    """activation(linear_module(x)) through evae_linear_fwd; x may be row-gathered by `rows`."""
+    x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
+    code = _act_code(activation)
+    if code is None:
+        y = ops.linear(x2, linear_module.weight, linear_module.bias, rows=rows)
+        y = activation(y)
+    else:
+        y = ops.linear(x2, linear_module.weight, linear_module.bias, code[0], code[1], code[2], rows=rows)
+    if rows is None and x.dim() != 2:
+        y = y.reshape(*x.shape[:-1], y.shape[-1])
+    return y
+
+
+class HipLinear(nn.Linear):
+    """torch.nn.Linear parameters (same state_dict keys), forward on the HIP GEMM."""
+
+    def forward(self, x, rows=None):
+        return dense(x, self, None, rows=rows)
+
+
+class NonLinear(nn.Module):
+    def __init__(self, input_size, output_size, bias=True, activation=None):
+        super().__init__()
+        self.activation = activation
+        self.linear = nn.Linear(int(input_size), int(output_size), bias=bias)
+
+    def forward(self, x, rows=None):
+        return dense(x, self.linear, self.activation, rows=rows)
+
+
+class GatedDense(nn.Module):
+    """h(x) * sigmoid(g(x)); with no_attention=True the reference degenerates to ReLU(h(x)) and builds
+    no gate (utils/nn.py:44-69)."""
+
+    def __init__(self, input_size, output_size, activation=None, no_attention=False):
+        super().__init__()
+        self.activation = activation
+        self.no_attention = no_attention
+        self.sigmoid = nn.Sigmoid()
+        self.h = nn.Linear(input_size, output_size)
+        if no_attention is False:
+            self.g = nn.Linear(input_size, output_size)
+        else:
+            self.activation = nn.ReLU()
+
+    def forward(self, x, rows=None):
+        if self.no_attention is False and self.activation is None:
+            x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
+            return ops.gated_dense(x2, self.h.weight, self.h.bias, self.g.weight, self.g.bias, rows=rows)
+        h = dense(x, self.h, None, rows=rows)
+        if self.activation is not None:
+            h = self.activation(h)
+        if self.no_attention is False:
+            return h * dense(x, self.g, self.sigmoid, rows=rows)
+        return h
+
+
+class GatedConv2d(nn.Module):
+    """act(h(x)) * sigmoid(g(x)) with two convolutions sharing the input (utils/nn.py:72-97).
+    Like the reference, no_attention=True cannot run (no `g` is built there either)."""
+
+    def __init__(self, input_channels, output_channels, kernel_size, stride, padding, dilation=1,
+                 activation=None, no_attention=False):
+        super().__init__()
+        self.no_attention = no_attention
+        self.activation = activation
+        self.sigmoid = nn.Sigmoid()
+        self.h = nn.Conv2d(input_channels, output_channels, kernel_size, stride, padding, dilation)
+        if no_attention is False:
+            self.g = nn.Conv2d(input_channels, output_channels, kernel_size, stride, padding, dilation)
+        else:
+            self.activation = nn.ELU()
+
+    def forward(self, x):
+        # one convolution over the concatenated [h | g] filters, then the gate
+        w = torch.cat((self.h.weight, self.g.weight), 0)
+        b = torch.cat((self.h.bias, self.g.bias), 0)
+        y = F.conv2d(x, w, b, self.h.stride, self.h.padding, self.h.dilation)
+        h, g = y.chunk(2, dim=1)
+        if self.activation is not None:
+            h = self.activation(h)
+        return h * torch.sigmoid(g)
+
+
+class Conv2d(nn.Module):
+    def __init__(self, input_channels, output_channels, kernel_size, stride, padding, dilation=1,
+                 activation=None, bias=True):
+        super().__init__()
+        self.activation = activation
+        self.conv = nn.Conv2d(input_channels, output_channels, kernel_size, stride, padding, dilation, bias=bias)
+
+    def forward(self, x):
+        h = self.conv(x)
+        return h if self.activation is None else self.activation(h)

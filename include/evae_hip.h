@@ -1,0 +1,195 @@
+/*
+ * evae_hip.h -- C ABI of libevae_hip.so, the MI355X (gfx950) hot path of Exemplar-VAE.
+ *
+ * The reference (sajadn/Exemplar-VAE) is pure Python and has no FFI: its hot path sits behind the
+ * Python API of models/BaseModel.py, models/AbsModel.py, utils/distributions.py, utils/nn.py,
+ * utils/knn_on_latent.py and utils/optimizer.py.  The drop-in therefore has two layers:
+ *   (1) exemplar-vae_amd/{models,utils}/ -- the reference's module/class/function names,
+ *   (2) this C ABI underneath, bound with ctypes (exemplar-vae_amd/evae/_lib.py; a reference
+ *       maintainer's binding stub is shown in INTEGRATION.md).
+ * Each entry point below cites the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - C linkage, plain pointers and sizes; no C++/torch types cross the boundary.
+ *   - Every pointer is a caller-owned DEVICE pointer (row-major, contiguous, fp32 unless stated;
+ *     indices int64).  Nothing is retained after return.
+ *   - Work is enqueued on `stream` (a hipStream_t passed as void*); no hidden synchronisation and no
+ *     hidden allocation: scratch is passed in (`ws`, size from the matching *_workspace_bytes).
+ *     All entry points are hipGraph-capturable.
+ *   - Return value: 0 = ok, <0 = EVAE_E*; evae_last_error() gives a thread-local message.
+ */
+#ifndef EVAE_HIP_H
+#define EVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVAE_OK 0
+#define EVAE_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported k, ...) */
+#define EVAE_EWORKSPACE (-2) /* workspace too small */
+#define EVAE_ELAUNCH (-3)  /* HIP launch error */
+
+#define EVAE_ABI_VERSION 1
+
+typedef void* evae_stream_t; /* hipStream_t */
+
+int evae_version(void);
+const char* evae_last_error(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * Exemplar prior: fused all-pairs distance + leave-one-out mask + online log-sum-exp.
+ * Replaces utils/distributions.py:12-25 (pairwise_distance, log_normal_diag_vectorized) and
+ * models/BaseModel.py:98-109,124-125 (log_p_z_exemplar, the max/log-sum-exp of log_p_z) without
+ * materialising the [B x C] matrix.
+ *
+ *   p_ij = -1/2 sum_k (log_var_k + log 2pi) - 1/2 sum_k (z_ik - c_jk)^2 / exp(log_var_k)
+ *   masked (p_ij := -inf) where z_idx_i == c_idx_j  (both non-NULL = training & !no_mask)
+ *
+ * evae_prior_lse_fwd returns, for ONE shard of exemplars, per row i:
+ *   out_max_i = max_j p_ij, out_sumexp_i = sum_j exp(p_ij - out_max_i), out_nmask_i = #masked.
+ * An empty shard (C == 0) yields (-inf, 0, 0).  `out_prob` (optional, [B x C]) receives p_ij
+ * (log_p_z(sum=False), BaseModel.py:126-127, before the `- log(denominator)` of :108).
+ * evae_prior_merge combines R shard partials ([R x B] each, R >= 1) into
+ *   out_logprior_i = LSE_i - log(c_total - sum_r nmask_ri)      (BaseModel.py:100,107-108,124-125)
+ *   out_lse_i      = LSE_i   (un-normalised, what the backward needs)
+ * which is the all-reduce of partial log-sum-exps of the sharded prior (gathered by the caller
+ * with one RCCL all-gather; see exemplar-vae_amd/evae/shard.py).
+ */
+size_t evae_prior_lse_fwd_workspace_bytes(int B, int C, int zdim);
+int evae_prior_lse_fwd(const float* z, int B, const float* centres, int C, int zdim,
+                       const float* log_var /* [zdim] */,
+                       const int64_t* z_idx /* [B] or NULL */, const int64_t* c_idx /* [C] or NULL */,
+                       float* out_max /* [B] */, float* out_sumexp /* [B] */, float* out_nmask /* [B] */,
+                       float* out_prob /* [B x C] or NULL */,
+                       void* ws, size_t ws_bytes, evae_stream_t stream);
+int evae_prior_merge(const float* max /* [R x B] */, const float* sumexp, const float* nmask,
+                     int R, int B, float c_total,
+                     float* out_logprior /* [B] */, float* out_lse /* [B] or NULL */,
+                     evae_stream_t stream);
+
+/* Backward of sum_i grad_out_i * logprior_i through the prior (what autograd derives from
+ * BaseModel.py:98-128 + distributions.py:12-25), by recomputation from the saved row LSE:
+ *   w_ij = exp(p_ij - lse_i);  dz_i = sum_j g_i w_ij (c_j - z_i)/var;  dc_j = sum_i g_i w_ij (z_i - c_j)/var;
+ *   dlogvar_k = sum_ij g_i w_ij (-1/2 + 1/2 (z_ik - c_jk)^2 / var_k).
+ * `lse` is the GLOBAL out_lse of evae_prior_merge; dz and dlogvar are this shard's partial sums
+ * (sum-all-reduce across shards), dcentres is complete for the shard's exemplars. */
+size_t evae_prior_lse_bwd_workspace_bytes(int B, int C, int zdim);
+int evae_prior_lse_bwd(const float* z, int B, const float* centres, int C, int zdim,
+                       const float* log_var, const int64_t* z_idx, const int64_t* c_idx,
+                       const float* lse /* [B] */, const float* grad_out /* [B] */,
+                       float* dz /* [B x zdim] */, float* dcentres /* [C x zdim] */,
+                       float* dlogvar /* [zdim] */,
+                       void* ws, size_t ws_bytes, evae_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Distance + top-K.  Replaces pairwise_distance(z, sub_cache).topk(k, largest=False)
+ * (models/BaseModel.py:263-264) and find_nearest_neighbors (utils/knn_on_latent.py:4-9: sqrt of the
+ * direct-difference distance, topk(k=20, sorted=True)).
+ * Distances are accumulated in fp64 and rounded once to fp32 (bit-compatible with the reference's
+ * fp64 pairwise_distance); selection order is (value ascending, index ascending); k <= 64.
+ * `index_base` is added to every returned index (shard offset).  out_idx/out_val are [B x k],
+ * sorted nearest first.  out_val may be NULL.
+ */
+#define EVAE_TOPK_SQRT 1u /* apply sqrtf to the fp32 distance before comparing (knn_on_latent.py:8) */
+size_t evae_pairdist_topk_workspace_bytes(int B, int N, int zdim, int k);
+int evae_pairdist_topk(const float* q, int B, const float* cache, int N, int zdim, int k,
+                       unsigned flags, int64_t index_base,
+                       int64_t* out_idx, float* out_val,
+                       void* ws, size_t ws_bytes, evae_stream_t stream);
+/* Materialised [B x N] squared distances, fp64-accumulated, rounded once to fp32: the value
+ * utils/distributions.py:12-18 returns.  Not on the hot path (kept for API completeness). */
+int evae_pairwise_distance(const float* q, int B, const float* cache, int N, int zdim,
+                           float* out /* [B x N] */, evae_stream_t stream);
+/* Merge R candidate lists ([R x B x k], e.g. all-gathered shard results) into the global top-k. */
+int evae_topk_merge(const float* val /* [R x B x k] */, const int64_t* idx, int R, int B, int k,
+                    int64_t* out_idx /* [B x k] */, float* out_val /* [B x k] or NULL */,
+                    evae_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Dense layers on fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replace utils/nn.py:29-69 (NonLinear,
+ * GatedDense) and torch.nn.Linear as used by models/VAE.py:15-30, models/HVAE_2level.py:15-66.
+ * Weights keep nn.Linear layout [out x in].  `rows` (optional int64 [M]) gathers the input rows
+ * x[rows[m], :] inside the A-tile load: the exemplar gather of models/BaseModel.py:247 without
+ * materialising the [C x D] copy.
+ *
+ * evae_gated_dense_fwd:  h = x Wh^T + bh ; s = sigmoid(x Wg^T + bg) ; out = h * s
+ *   saves h and s ([M x N] each, may be NULL for inference) for the backward.
+ * evae_linear_fwd:       y = act(x W^T + b), act in EVAE_ACT_*; `pre` (optional) saves the
+ *   pre-activation needed by hardtanh's backward.
+ * evae_gated_dense_bwd_input: given dout [M x N] and saved h, s:
+ *   dh = dout*s ; dg = dout*h*s*(1-s)   (written to dh, dg: [M x N] each)
+ * evae_dense_bwd_data:   dx = dy1 W1 (+ dy2 W2)         [M x K]   (dy [M x N], W [N x K])
+ *   optionally fused with the gated-dense input derivative of the layer below (h_prev, s_prev
+ *   non-NULL): writes dh_prev/dg_prev instead of dx.
+ * evae_dense_bwd_weight: dW = dy^T x (rows-gathered x allowed), db = column sums of dy.
+ */
+#define EVAE_ACT_NONE 0
+#define EVAE_ACT_SIGMOID 1
+#define EVAE_ACT_HARDTANH 2 /* clamp to [act_lo, act_hi] */
+
+int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, int K, int ldx,
+                         const float* wh, const float* bh, const float* wg, const float* bg, int N,
+                         float* out, float* save_h, float* save_s, evae_stream_t stream);
+int evae_linear_fwd(const float* x, const int64_t* rows, int M, int K, int ldx,
+                    const float* w, const float* b, int N, int act, float act_lo, float act_hi,
+                    float* y, float* pre, evae_stream_t stream);
+int evae_dense_bwd_data(const float* dy1, const float* w1, const float* dy2, const float* w2,
+                        int M, int N, int K,
+                        const float* h_prev, const float* s_prev,
+                        float* dx_or_dh, float* dg, evae_stream_t stream);
+size_t evae_dense_bwd_weight_workspace_bytes(int M, int N, int K);
+int evae_dense_bwd_weight(const float* dy, int M, int N, const float* x, const int64_t* rows, int K,
+                          int ldx, float* dw /* [N x K] */, float* db /* [N] or NULL */, int accumulate,
+                          void* ws, size_t ws_bytes, evae_stream_t stream);
+int evae_gated_dense_bwd_input(const float* dout, const float* h, const float* s, size_t n,
+                               float* dh, float* dg, evae_stream_t stream);
+int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, int act, float act_lo, float act_hi,
+                 float* dpre, evae_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Latent sampling and log-densities on [B x zdim] / [B x D] rows.
+ * evae_reparam_logq: z = mu + eps*exp(logvar/2) (models/BaseModel.py:79-82, eps supplied by the
+ *   caller's RNG) and log q(z|x) = log_normal_diag(z, mu, logvar) (utils/distributions.py:28-33).
+ * evae_bernoulli_ll: sum_d x log p + (1-x) log(1-p), p = clamp(mean, 1e-5, 1-1e-5)
+ *   (utils/distributions.py:44-51); backward gives d/dmean.
+ */
+int evae_reparam_logq_fwd(const float* mu, const float* logvar, const float* eps, int B, int zdim,
+                          float* z, float* logq, evae_stream_t stream);
+int evae_reparam_logq_bwd(const float* mu, const float* logvar, const float* eps, const float* z,
+                          const float* dz, const float* dlogq, int B, int zdim,
+                          float* dmu, float* dlogvar, evae_stream_t stream);
+int evae_log_normal_diag_fwd(const float* x, const float* mu, const float* logvar, int B, int zdim,
+                             float* out, evae_stream_t stream);
+int evae_log_normal_diag_bwd(const float* x, const float* mu, const float* logvar, const float* dout,
+                             int B, int zdim, float* dx, float* dmu, float* dlogvar,
+                             evae_stream_t stream);
+int evae_bernoulli_ll_fwd(const float* x, const float* mean, int B, int D, float* out,
+                          evae_stream_t stream);
+int evae_bernoulli_ll_bwd(const float* x, const float* mean, const float* dout, int B, int D,
+                          float* dmean, evae_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * AdamNormGrad (utils/optimizer.py:32-80): g <- g/(||g||_2 + 1e-7) per tensor, then Adam with eps
+ * added after the sqrt and a bias-corrected step size.  One launch pair updates ALL tensors:
+ * `ptrs` is a device array of n_tensors records {param, grad, exp_avg, exp_avg_sq, numel}.
+ */
+typedef struct {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+} evae_adam_tensor_t;
+size_t evae_adam_normgrad_workspace_bytes(int n_tensors);
+int evae_adam_normgrad_step(const evae_adam_tensor_t* tensors /* device */, int n_tensors,
+                            int64_t max_numel, int step, double lr, double beta1, double beta2, double eps,
+                            double weight_decay, void* ws, size_t ws_bytes, evae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVAE_HIP_H */

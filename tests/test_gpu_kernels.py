@@ -1,0 +1,298 @@
+"""GPU parity tests of the raw C-ABI entry points (through evae.ops) against the oracle.
+Run on a real MI355X:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+import evae_oracle as orc
+import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from evae import ops as o
+    o._lib.load()
+    return o
+
+
+# ---------------------------------------------------------------- prior
+@pytest.mark.parametrize("B,C,zd,masked", [(8, 300, 40, True), (100, 1000, 40, True), (100, 25000, 40, True),
+                                           (100, 25000, 40, False), (5, 7, 3, True), (130, 70, 256, False),
+                                           (300, 2000, 40, True), (1, 1, 40, False), (64, 1000, 100, True)])
+def test_prior_fwd_matches_oracle(ops, B, C, zd, masked):
+    z, c = gi.clustered_latents(100 + B + C, B, C, zd)
+    zi, ci = gi.mask_indices(7 + B, B, C, max(C // 2, 4))
+    lv = np.linspace(-1.5, -0.5, zd).astype(np.float32)
+    m, s, n, prob = ops.prior_lse_fwd(dev(z), dev(c), dev(lv), dev(zi) if masked else None,
+                                      dev(ci) if masked else None, want_prob=True)
+    lp, lse = ops.prior_merge(m, s, n, C)
+    ref_prob = orc.log_p_z_exemplar(z, zi, c, lv[None, :], ci, test=not masked)
+    ref = orc.logsumexp_rows(ref_prob)
+    assert rel(lp.cpu().numpy(), ref) < 1e-5          # north_star bar is 1e-4
+    pm, ps, pn = orc.prior_partials(z, zi, c, lv, ci, masked)
+    assert np.array_equal(n.cpu().numpy(), pn)
+    raw = prob.cpu().numpy()
+    assert np.array_equal(np.isinf(raw), np.isinf(ref_prob))
+    fin = np.isfinite(ref_prob)
+    denom = (C - pn)[:, None] * np.ones_like(ref_prob)
+    assert rel((raw - np.log(denom))[fin], ref_prob[fin]) < 1e-5
+
+
+def test_prior_golden_c2(ops, golden):
+    g = golden("g3_prior")
+    z, c = gi.clustered_latents(22, 100, 25000, 40)
+    zi, ci = gi.mask_indices(23, 100, 25000, 50000)
+    gout = np.random.RandomState(24).standard_normal(100).astype(np.float32)
+    lv = np.full(40, -1.3, np.float32)
+    for mode in ("train", "test"):
+        masked = mode == "train"
+        zt = dev(z).requires_grad_(True); ct = dev(c).requires_grad_(True); lvt = dev(lv).requires_grad_(True)
+        lp = ops.PriorLogP.apply(zt, ct, lvt, dev(zi) if masked else None, dev(ci) if masked else None)
+        (lp * dev(gout)).sum().backward()
+        assert rel(lp.detach().cpu().numpy(), g["c2_%s_logp" % mode]) < 1e-5
+        assert rel(zt.grad.cpu().numpy(), g["c2_%s_dz" % mode]) < 1e-4
+        assert rel(lvt.grad.sum().item(), g["c2_%s_dplv" % mode]) < 1e-4
+        dc = ct.grad.cpu().numpy()
+        assert rel(dc[:64], g["c2_%s_dc_head" % mode]) < 1e-4
+        assert rel(dc.astype(np.float64).sum(0), g["c2_%s_dc_colsum" % mode]) < 1e-4
+        assert rel(np.linalg.norm(dc.astype(np.float64), axis=1), g["c2_%s_dc_rownorm" % mode]) < 1e-4
+
+
+@pytest.mark.parametrize("B,C,zd,masked", [(8, 300, 40, True), (100, 1000, 40, True), (5, 7, 3, True),
+                                           (130, 70, 256, False), (200, 500, 40, True), (33, 129, 100, False)])
+def test_prior_bwd_matches_oracle(ops, B, C, zd, masked):
+    z, c = gi.clustered_latents(200 + B + C, B, C, zd)
+    zi, ci = gi.mask_indices(9 + B, B, C, max(C // 2, 4))
+    lv = np.linspace(-1.0, 0.2, zd).astype(np.float32)
+    gout = np.random.RandomState(B).standard_normal(B).astype(np.float32)
+    dz, dc, dlv, lse = orc.prior_grads(z.astype(np.float64), zi, c.astype(np.float64), lv.astype(np.float64), ci,
+                                       masked, gout.astype(np.float64))
+    m, s, n, _ = ops.prior_lse_fwd(dev(z), dev(c), dev(lv), dev(zi) if masked else None, dev(ci) if masked else None)
+    lp, lse_t = ops.prior_merge(m, s, n, C)
+    gz, gc, glv = ops.prior_lse_bwd(dev(z), dev(c), dev(lv), dev(zi) if masked else None,
+                                    dev(ci) if masked else None, lse_t, dev(gout))
+    # fp32 kernel vs fp64 oracle; the bar for the ELBO is 1e-4 relative
+    assert rel(gz.cpu().numpy(), dz) < 1e-4
+    assert rel(gc.cpu().numpy(), dc) < 1e-4
+    assert rel(glv.cpu().numpy(), dlv) < 1e-4
+
+
+def test_prior_sharded_merge_matches_single(ops):
+    """R logical shards on one GPU (uneven, one empty) merge to the single-shard answer."""
+    B, C, zd = 100, 11500, 40
+    z, c = gi.clustered_latents(77, B, C, zd)
+    zi, ci = gi.mask_indices(78, B, C, 23000)
+    lv = np.full(zd, -0.9, np.float32)
+    cuts = [0, 1438, 1438, 2876, 4314, 5752, 7189, 8626, 10063, 11500]
+    ms, ss, ns = [], [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        m, s, n, _ = ops.prior_lse_fwd(dev(z), dev(c[a:b]), dev(lv), dev(zi), dev(ci[a:b]))
+        ms.append(m); ss.append(s); ns.append(n)
+    lp, _ = ops.prior_merge(torch.stack(ms), torch.stack(ss), torch.stack(ns), C)
+    ref = orc.log_p_z(z, zi, c, lv[None, :], ci, test=False)
+    assert rel(lp.cpu().numpy(), ref) < 1e-5
+
+
+# ---------------------------------------------------------------- top-K
+def test_topk_golden_bit_exact(ops, golden):
+    g = golden("g4_topk")
+    for tag, (B, C, zd, seed) in {"c2": (100, 25000, 40, 31), "c5": (64, 100000, 256, 32)}.items():
+        z, c = gi.clustered_latents(seed, B, C, zd)
+        idx, val = ops.pairdist_topk(dev(z), dev(c), 10)
+        assert np.array_equal(idx.cpu().numpy(), g[tag + "_idx"].astype(np.int64)), tag
+        assert np.array_equal(val.cpu().numpy(), g[tag + "_val"]), tag
+
+
+def test_knn_golden_bit_exact(ops, golden):
+    g = golden("g5_knn")
+    zv, zt = gi.clustered_latents(41, 100, 60000, 40)
+    idx, _ = ops.pairdist_topk(dev(zv), dev(zt), 20, sqrt=True)
+    assert np.array_equal(idx.cpu().numpy(), g["idx"].astype(np.int64))
+
+
+@pytest.mark.parametrize("B,N,zd,k", [(3, 5, 2, 5), (130, 1000, 7, 1), (17, 64, 40, 64), (100, 777, 33, 20)])
+def test_topk_small_and_ragged(ops, B, N, zd, k):
+    z, c = gi.latents(5 + B, B, N, zd)
+    idx, val = ops.pairdist_topk(dev(z), dev(c), k)
+    ov, oi = orc.topk_smallest(orc.pairdist_direct_f64(z, c), k)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(val.cpu().numpy(), ov)
+
+
+def test_pairwise_distance_golden(ops, golden):
+    g = golden("g1_g2_distance")
+    for zdim in (40, 256):
+        z, m = gi.latents(11 + zdim, 16, 257, zdim)
+        pd = ops.pairwise_distance(dev(z), dev(m)).cpu().numpy()
+        ref = g["pd_z%d" % zdim]
+        assert np.abs(pd - ref).max() <= np.spacing(np.abs(ref).max())
+        assert (pd == ref).mean() > 0.999
+
+
+def test_topk_ties_index_order(ops):
+    c = np.zeros((300, 8), np.float32); c[::3] = 1.0
+    z = np.zeros((4, 8), np.float32)
+    idx, _ = ops.pairdist_topk(dev(z), dev(c), 10)
+    expect = np.asarray([i for i in range(300) if i % 3][:10])
+    assert np.array_equal(idx.cpu().numpy(), np.tile(expect, (4, 1)))
+
+
+def test_topk_sharded_merge(ops):
+    B, N, zd, k = 100, 20000, 40, 10
+    z, c = gi.clustered_latents(91, B, N, zd)
+    full, _ = ops.pairdist_topk(dev(z), dev(c), k)
+    cuts = [0, 2500, 2500, 9000, 20000]
+    vals, idxs = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b - a < k:
+            vals.append(torch.full((B, k), float("inf"), device="cuda")); idxs.append(torch.full((B, k), -1, dtype=torch.int64, device="cuda"))
+            continue
+        i, v = ops.pairdist_topk(dev(z), dev(c[a:b]), k, index_base=a)
+        vals.append(v); idxs.append(i)
+    mi, mv = ops.topk_merge(torch.stack(vals), torch.stack(idxs))
+    assert torch.equal(mi, full)
+
+
+# ---------------------------------------------------------------- dense layers
+@pytest.mark.parametrize("M,K,N", [(37, 53, 24), (100, 784, 300), (1000, 300, 300), (257, 40, 300), (5000, 784, 300),
+                                   (130, 294, 40)])
+def test_gated_dense_fwd_bwd(ops, M, K, N):
+    rs = np.random.RandomState(M + K)
+    x = rs.standard_normal((M, K)).astype(np.float32)
+    wh = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32); bh = (rs.standard_normal(N) * 0.1).astype(np.float32)
+    wg = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32); bg = (rs.standard_normal(N) * 0.1).astype(np.float32)
+    gout = rs.standard_normal((M, N)).astype(np.float32)
+    x64, wh64, wg64 = x.astype(np.float64), wh.astype(np.float64), wg.astype(np.float64)
+    y, saved = orc.gated_dense(x64, wh64, bh.astype(np.float64), wg64, bg.astype(np.float64))
+    dx, gr = orc.gated_dense_bwd(x64, wh64, wg64, saved, gout.astype(np.float64))
+    t = [dev(a).requires_grad_(True) for a in (x, wh, bh, wg, bg)]
+    out = ops.gated_dense(t[0], t[1], t[2], t[3], t[4])
+    out.backward(dev(gout))
+    assert rel(out.detach().cpu().numpy(), y) < 2e-6
+    assert rel(t[0].grad.cpu().numpy(), dx) < 1e-5
+    for ti, k in ((1, "wh"), (2, "bh"), (3, "wg"), (4, "bg")):
+        assert rel(t[ti].grad.cpu().numpy(), gr[k]) < 1e-5, k
+
+
+def test_gated_dense_row_gather(ops):
+    rs = np.random.RandomState(3)
+    data = rs.standard_normal((500, 784)).astype(np.float32)
+    rows = rs.randint(0, 500, 1000).astype(np.int64)
+    wh = (rs.standard_normal((300, 784)) / 28).astype(np.float32); wg = (rs.standard_normal((300, 784)) / 28).astype(np.float32)
+    b = np.zeros(300, np.float32)
+    w = [dev(a).requires_grad_(True) for a in (wh, b, wg, b)]
+    out = ops.gated_dense(dev(data), w[0], w[1], w[2], w[3], rows=dev(rows))
+    gout = rs.standard_normal((1000, 300)).astype(np.float32)
+    out.backward(dev(gout))
+    x64 = data[rows].astype(np.float64)
+    y, saved = orc.gated_dense(x64, wh.astype(np.float64), b.astype(np.float64), wg.astype(np.float64), b.astype(np.float64))
+    _, gr = orc.gated_dense_bwd(x64, wh.astype(np.float64), wg.astype(np.float64), saved, gout.astype(np.float64), need_dx=False)
+    assert rel(out.detach().cpu().numpy(), y) < 2e-6
+    assert rel(w[0].grad.cpu().numpy(), gr["wh"]) < 1e-5
+    assert rel(w[2].grad.cpu().numpy(), gr["wg"]) < 1e-5
+    assert rel(w[1].grad.cpu().numpy(), gr["bh"]) < 1e-5
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("M,K,N", [(37, 53, 24), (100, 300, 784), (1000, 300, 40)])
+def test_linear_fwd_bwd(ops, act, M, K, N):
+    rs = np.random.RandomState(M + N + act)
+    x = rs.standard_normal((M, K)).astype(np.float32)
+    w = (rs.standard_normal((N, K)) * 4 / np.sqrt(K)).astype(np.float32); b = (rs.standard_normal(N) * 0.1).astype(np.float32)
+    gout = rs.standard_normal((M, N)).astype(np.float32)
+    pre = x.astype(np.float64) @ w.astype(np.float64).T + b
+    if act == 1:
+        y = 1 / (1 + np.exp(-pre)); dpre = gout * y * (1 - y)
+    elif act == 2:
+        y = np.clip(pre, -6, 2); dpre = gout * ((pre > -6) & (pre < 2))
+    else:
+        y = pre; dpre = gout.astype(np.float64)
+    t = [dev(a).requires_grad_(True) for a in (x, w, b)]
+    out = ops.linear(t[0], t[1], t[2], act, -6.0, 2.0)
+    out.backward(dev(gout))
+    assert rel(out.detach().cpu().numpy(), y) < 2e-6
+    assert rel(t[0].grad.cpu().numpy(), dpre @ w) < 1e-5
+    assert rel(t[1].grad.cpu().numpy(), dpre.T @ x) < 1e-5
+    assert rel(t[2].grad.cpu().numpy(), dpre.sum(0)) < 1e-5
+
+
+def test_layers_golden(ops, golden):
+    g = golden("g6_layers")
+    rs = np.random.RandomState(51)
+    R, I, O = 37, 53, 24
+    x = rs.standard_normal((R, I)).astype(np.float32)
+    wh = (rs.standard_normal((O, I)) * 0.2).astype(np.float32); bh = (rs.standard_normal(O) * 0.1).astype(np.float32)
+    wg = (rs.standard_normal((O, I)) * 0.2).astype(np.float32); bg = (rs.standard_normal(O) * 0.1).astype(np.float32)
+    gout = rs.standard_normal((R, O)).astype(np.float32)
+    t = [dev(a).requires_grad_(True) for a in (x, wh, bh, wg, bg)]
+    out = ops.gated_dense(*t)
+    out.backward(dev(gout))
+    assert rel(out.detach().cpu().numpy(), g["gd_y"]) < 1e-5
+    assert rel(t[0].grad.cpu().numpy(), g["gd_dx"]) < 1e-5
+    assert rel(t[1].grad.cpu().numpy(), g["gd_dwh"]) < 1e-5
+    assert rel(t[4].grad.cpu().numpy(), g["gd_dbg"]) < 1e-5
+
+
+# ---------------------------------------------------------------- latent / loss rows
+def test_reparam_logq_and_densities(ops):
+    rs = np.random.RandomState(8)
+    B, zd, D = 100, 40, 784
+    mu = rs.standard_normal((B, zd)).astype(np.float32); lv = rs.uniform(-6, 2, (B, zd)).astype(np.float32)
+    eps = rs.standard_normal((B, zd)).astype(np.float32)
+    gz = rs.standard_normal((B, zd)).astype(np.float32); gq = rs.standard_normal(B).astype(np.float32)
+    t = [dev(a).requires_grad_(True) for a in (mu, lv)]
+    z, logq = ops.ReparamLogQ.apply(t[0], t[1], dev(eps))
+    ((z * dev(gz)).sum() + (logq * dev(gq)).sum()).backward()
+    mu64, lv64, e64 = mu.astype(np.float64), lv.astype(np.float64), eps.astype(np.float64)
+    z_ref = e64 * np.exp(0.5 * lv64) + mu64
+    assert rel(z.detach().cpu().numpy(), z_ref) < 1e-6
+    assert rel(logq.detach().cpu().numpy(), orc.log_normal_diag(z_ref, mu64, lv64)) < 1e-5
+    # analytic: logq = sum -0.5(lv + log2pi + eps^2) -> d/dmu = 0 (+gz), d/dlv = -0.5 (+ gz*eps*std/2)
+    assert rel(t[0].grad.cpu().numpy(), gz) < 1e-4
+    assert rel(t[1].grad.cpu().numpy(), gz * e64 * np.exp(0.5 * lv64) * 0.5 - 0.5 * gq[:, None]) < 1e-4
+    x = rs.standard_normal((B, zd)).astype(np.float32)
+    tt = [dev(a).requires_grad_(True) for a in (x, mu, lv)]
+    out = ops.LogNormalDiag.apply(*tt)
+    (out * dev(gq)).sum().backward()
+    assert rel(out.detach().cpu().numpy(), orc.log_normal_diag(x.astype(np.float64), mu64, lv64)) < 1e-5
+    d = x.astype(np.float64) - mu64
+    assert rel(tt[0].grad.cpu().numpy(), -gq[:, None] * d / np.exp(lv64)) < 1e-5
+    assert rel(tt[2].grad.cpu().numpy(), gq[:, None] * -0.5 * (1 - d * d / np.exp(lv64))) < 1e-5
+    xm = (1 / (1 + np.exp(-rs.standard_normal((B, D)) * 8))).astype(np.float32)
+    xb = (rs.random_sample((B, D)) < 0.3).astype(np.float32)
+    mt = dev(xm).requires_grad_(True)
+    re = ops.BernoulliLL.apply(dev(xb), mt)
+    (re * dev(gq)).sum().backward()
+    # fp32 oracle: the clamp constants 1e-5 / 1-1e-5 are fp32 roundings in the reference too
+    assert rel(re.detach().cpu().numpy(), orc.log_bernoulli(xb, xm)) < 1e-5
+    p = np.clip(xm, np.float32(1e-5), np.float32(1 - 1e-5)).astype(np.float64)
+    inside = (xm >= np.float32(1e-5)) & (xm <= np.float32(1 - 1e-5))
+    assert rel(mt.grad.cpu().numpy(), gq[:, None] * (xb / p - (1 - xb) / (1 - p)) * inside) < 1e-5
+
+
+def test_adam_normgrad_golden(ops, golden):
+    g = golden("g8_adam")
+    ps = [dev(g["p0_%d" % i]) for i in range(4)]
+    ms = [torch.zeros_like(p) for p in ps]; vs = [torch.zeros_like(p) for p in ps]
+    for step in range(3):
+        grads = [dev(g["g%d_%d" % (step, i)]) for i in range(4)]
+        ops.adam_normgrad_step(ps, grads, ms, vs, step + 1, 5e-4, 0.9, 0.999, 1e-8, 0.0)
+        for i in range(4):
+            assert rel(ps[i].cpu().numpy(), g["p%d_%d" % (step + 1, i)]) < 1e-6
+    for i in range(4):
+        assert rel(ms[i].cpu().numpy(), g["m_%d" % i]) < 1e-6
+        assert rel(vs[i].cpu().numpy(), g["v_%d" % i]) < 1e-6
