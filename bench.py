@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of `vae` + exemplar prior, dynamic_mnist-shaped synthetic
+data, 25 000 exemplars, exact prior, batch 100 (BASELINE.json configs[1]).
+
+A step is the body of the reference's training loop (utils/training.py:27-46): binarise the batch,
+forward, sample + encode the C exemplars, exemplar prior, backward, AdamNormGrad -- all through the
+drop-in API (models.VAE.VAE.calculate_loss -> loss.backward() -> utils.optimizer.AdamNormGrad.step),
+i.e. through libevae_hip.so.  With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU,
+RCCL) the C exemplars are sharded across the ranks and the per-shard partial log-sum-exps are merged by
+one all-gather (evae/shard.py); batch and C are unchanged, so scaling is "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (the fp32-MFMA GEMM behind GatedDense), algorithmic flops per
+                  launch / mean launch duration measured with HIP events inside the timed region
+  cpu_baseline -- the numpy oracle's train step (oracle/evae_oracle.py) timed on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "exemplar-vae_amd"))
+sys.path.insert(1, os.path.join(ROOT, "tests"))          # golden_inputs: the synthetic-data generator
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
+B, C, N_TRAIN, D, H, Z = 100, 25000, 50000, 784, 300, 40
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--exemplars", type=int, default=C)
+    ap.add_argument("--cpu-baseline-steps", type=int, default=25,
+                    help="oracle steps timed for cpu_baseline (0 disables)")
+    return ap.parse_args()
+
+
+def model_args(device, n_exemplars, sharded):
+    from argparse import Namespace
+    return Namespace(prior="exemplar_prior", input_type="binary", input_size=[1, 28, 28], hidden_size=H,
+                     z1_size=Z, z2_size=Z, model_name="vae", device=device, number_components=n_exemplars,
+                     training_set_size=N_TRAIN, approximate_prior=False, approximate_k=10, no_mask=False,
+                     no_attention=False, same_variational_var=False, use_logit=False, lambd=1e-4,
+                     bottleneck=6, dataset_name="dynamic_mnist", continuous=False, batch_size=B,
+                     dynamic_binarization=True, warmup=100, S=5000, shard_exemplars=sharded)
+
+
+def gated_flops(M, K, N):
+    return 2.0 * M * K * 2 * N
+
+
+def cpu_baseline(steps):
+    """The oracle's restatement of the same training step on the host cores (numpy + its BLAS threads)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import evae_oracle as orc
+    import golden_inputs as gi
+    rs = np.random.RandomState(0)
+    data = gi.binary_images(0, N_TRAIN)
+    p = orc.vae_init_params(np.random.RandomState(123))
+    opt = {}
+    t_tot, done = 0.0, 0
+    for s in range(steps + 1):
+        bidx = np.arange(s * B, (s + 1) * B).reshape(-1, 1) % N_TRAIN
+        x = data[bidx[:, 0]]
+        eps = rs.standard_normal((B, Z)).astype(np.float32)
+        ex_idx = rs.randint(0, N_TRAIN, size=(C,))
+        t0 = time.perf_counter()
+        orc.vae_train_step(p, opt, x, bidx, eps, data[ex_idx], ex_idx, beta=0.5)
+        dt = time.perf_counter() - t0
+        if s > 0:                       # first step warms the BLAS threads / page faults
+            t_tot += dt
+            done += 1
+    return {"value": round(B * done / t_tot, 2), "unit": "images/sec", "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": "%d steps of the numpy oracle's vae train step (B=%d, C=%d, N=%d), 1 untimed warm-up"
+                      % (done, B, C, N_TRAIN)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    n_ex = a.exemplars
+
+    import golden_inputs as gi
+    from evae import ops
+    from models.VAE import VAE
+    from utils.optimizer import AdamNormGrad
+    from utils.training import set_beta
+
+    # synthetic dynamic_mnist-shaped training set: binary 28x28, N=50 000, seed 0
+    data = torch.from_numpy(gi.binary_images(0, N_TRAIN))
+    dataset = torch.utils.data.TensorDataset(data, torch.arange(N_TRAIN).reshape(-1, 1), torch.arange(N_TRAIN) % 10)
+    args = model_args("cuda:%d" % local_rank, n_ex, sharded=world > 1)
+    torch.manual_seed(14)                    # same weights, eps stream and exemplar draws on every rank
+    torch.cuda.manual_seed(14)
+    model = VAE(args).to(dev)
+    opt = AdamNormGrad(model.parameters(), lr=5e-4)
+    data_dev = model.resident_data(dataset)  # one upload; exemplar gathers read HBM from here on
+    idx_all = torch.arange(N_TRAIN, device=dev).reshape(-1, 1)
+    beta = set_beta(args, 50)
+    model.train()
+    nb = N_TRAIN // B
+    loss_acc = torch.zeros((), device=dev)
+
+    def step(i):
+        s = (i % nb) * B
+        x = torch.bernoulli(data_dev[s:s + B])                     # dynamic binarisation (training.py:31)
+        opt.zero_grad()
+        loss, RE, KL = model.calculate_loss((x, idx_all[s:s + B]), beta, average=True, dataset=dataset)
+        loss.backward()
+        opt.step()
+        loss_acc.add_(loss.detach())
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    ops.PROBE = {"gated_dense_fwd": []}       # HIP-event pairs around every GatedDense forward launch
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    probe, ops.PROBE = ops.PROBE, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss_acc.item()) / (a.warmup + a.steps)
+
+    # roofline of the dominant kernel: gemm_kernel<KC,KC,EPI_GATED> (6 launches per step)
+    ev = probe["gated_dense_fwd"]
+    durs_ms = [s.elapsed_time(e) for s, e, _ in ev]
+    flops = [f for _, _, f in ev]
+    roof = None
+    if durs_ms:
+        achieved = sum(flops) / (sum(durs_ms) * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_gated_dense.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "kernel": "evae::gemm_kernel<KC,KC,EPI_GATED> (GatedDense forward)",
+                "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "launches": len(durs_ms), "avg_launch_us": round(1e3 * sum(durs_ms) / len(durs_ms), 2),
+                "flops_per_launch_avg": round(sum(flops) / len(flops))}
+
+    if rank == 0:
+        out = {
+            "metric": "training images/sec", "value": round(B * a.steps / dt, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "vae + exemplar_prior, dynamic_mnist-shaped binary 28x28, N=%d, batch %d, "
+                                   "%d exemplars, exact prior (BASELINE.json configs[1])" % (N_TRAIN, B, n_ex),
+                       "global_batch": B, "exemplars": n_ex,
+                       "parallelism": "exemplar-shard x%d" % world if world > 1 else "single GPU"},
+            "mean_loss": round(final_loss, 4),
+            "roofline": roof,
+            "cpu_baseline": None,
+        }
+        if world == 1 and a.cpu_baseline_steps > 0:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_steps)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -3,21 +3,25 @@
 // Replaces utils/nn.py:29-69 (NonLinear, GatedDense) + torch.nn.Linear and their autograd.
 //
 // One templated LDS-tiled GEMM serves every call:
-//   block tile 128 x 128 x 32, 256 threads = 4 waves in a 2 x 2 grid, wave tile 64 x 64 =
-//   2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs), LDS double-buffered, the next K-slab's
-//   global loads are issued before the current slab's MFMAs (register prefetch).
-//   Operands come in two layouts, chosen per call so that global reads are always contiguous
-//   float4 streams and no transposition pass is ever needed:
-//     KC ("k-contiguous", [rows][k]):  x and nn.Linear weights in the forward;   fragments are read
-//        as ds_read_b128 along k -- lanes 0-31 take k..k+3 and lanes 32-63 take k+4..k+7 of an
-//        8-wide k-group, feeding four consecutive MFMAs; row stride 36 floats (stride/4 odd) makes
-//        the 16-lane b128 groups conflict-free;
+//   block tile 128 x BN x 32 (BN = 128 or 64), 256 threads = 4 waves in a 2 x 2 grid, wave tile
+//   64 x BN/2 = 2 x (1|2) MFMA tiles of 32 x 32, LDS double-buffered; the next K-slab's global loads are
+//   issued before the current slab's MFMAs and land in LDS after them (register prefetch, one barrier
+//   per slab).
+//   Operands come in two layouts, chosen per call so that global reads are always contiguous float4
+//   streams and no transposition pass is ever needed:
+//     KC ("k-contiguous", [rows][k]):  x and nn.Linear weights in the forward; fragments are read as
+//        ds_read_b128 along k -- lanes 0-31 take k..k+3 and lanes 32-63 take k+4..k+7 of an 8-wide
+//        k-group, feeding four consecutive MFMAs; row stride 36 floats (stride/4 odd) makes the
+//        16-lane b128 groups conflict-free;
 //     RC ("row-contiguous", [k][rows]): dy^T and x in the weight gradient, W in the data gradient;
 //        fragments are ds_read_b32 of 32 consecutive floats (conflict-free by construction).
 //   Row gathers (the exemplar gather of models/BaseModel.py:247) are folded into the tile loads.
-//   Epilogues: bias + activation, the GatedDense gate h*sigmoid(g) (h and g column tiles live in
-//   the same wave, so the product is register-local), the gate derivative for the layer below, and
-//   raw split-K partials (weight gradient; reduced deterministically by a second kernel).
+//   Epilogues: bias + activation, the GatedDense gate h*sigmoid(g) (h and g column tiles live in the
+//   same wave, so the product is register-local), the gate derivative for the layer below, or raw
+//   split-K partials finished by a second kernel (deterministic reduction order).
+//   A host-side planner picks BN and the split-K factor per call from a wave-quantisation model
+//   (512 resident blocks per launch round), so that thin problems (the 100-row batch path, the
+//   [600 x 784] weight gradient over 25 000 rows) still fill the 256 CUs.
 //   Workgroup ids are remapped so that each XCD owns a contiguous run of tiles (shared A row-panels
 //   stay in one L2).
 #include "evae_common.h"
@@ -26,41 +30,42 @@ namespace evae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, GNT = 256;
-constexpr int KS = BK + 4;           // KC tile row stride (floats); 36/4 = 9 odd
-constexpr int RS = BM + 4;           // RC tile row stride
-constexpr int TILE_FLOATS = BM * KS; // 4608 >= BK * RS = 4224
+constexpr int BM = 128, BK = 32, GNT = 256;
+constexpr int KS = BK + 4;  // KC tile row stride (floats); 36/4 = 9 odd
 
-enum { EPI_LINEAR = 0, EPI_GATED = 1, EPI_GATE_BWD = 2, EPI_PARTIAL = 3 };
+enum { EPI_LINEAR = 0, EPI_GATED = 1, EPI_GATE_BWD = 2, EPI_RAW = 3, EPI_RAW_GATED = 4 };
 
 struct GemmArgs {
   const float* A[2];
   const float* B[2];
   int lda[2], ldb[2];
-  int Kc[2];                 // contraction length of each (A,B) pair
+  int Kc[2];               // contraction length of each (A,B) pair
   int npairs;
-  const int64_t* a_rows;     // KC A: gather of output rows;   RC A: unused
-  const int64_t* b_krows;    // RC B: gather along the contraction index (weight gradient x rows)
-  const float* Bg;           // EPI_GATED: second weight matrix (g), same layout as B[0]
-  int M, N;                  // output rows / columns
-  int ksplit;                // contraction steps (of BK) per blockIdx.z; 0 = no split
+  const int64_t* a_rows;   // KC A: gather of output rows
+  const int64_t* b_krows;  // RC B: gather along the contraction index (weight gradient x rows)
+  const float* Bg;         // gated: second weight matrix (g), same layout as B[0]
+  int M, N;                // output rows / columns
+  int ksplit;              // K-slabs per blockIdx.z (split-K); 0 = whole contraction
   const float* bias0;
   const float* bias1;
   float* out0;
   float* out1;
   float* out2;
   int ldo;
-  const float* e0;           // EPI_GATE_BWD: h of the layer below
-  const float* e1;           //               s of the layer below
+  const float* e0;         // EPI_GATE_BWD: h of the layer below
+  const float* e1;         //               s of the layer below
   int act;
   float lo, hi;
   int tiles_m, tiles_n;
 };
 
-__device__ __forceinline__ float4 ld4(const float* p, int valid, bool vec) {
-  // valid = number of in-range elements (0..4) starting at p
+// Out-of-range chunks are loaded from a clamped, always-mapped address and zeroed LATER, when the
+// prefetched registers are written to LDS: masking right after the load would make the compiler wait
+// for the prefetch before the MFMAs it is meant to overlap.
+__device__ __forceinline__ float4 ld4v(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// Scalar path for odd extents (e.g. the 294-wide head of convhvae_2level): correct, not fast.
+__device__ __forceinline__ float4 ld4s(const float* p, int valid) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid >= 4 && vec) return *reinterpret_cast<const float4*>(p);
   if (valid > 0) v.x = p[0];
   if (valid > 1) v.y = p[1];
   if (valid > 2) v.z = p[2];
@@ -68,17 +73,21 @@ __device__ __forceinline__ float4 ld4(const float* p, int valid, bool vec) {
   return v;
 }
 
-// ---- tile loaders: 4 float4 per thread per operand per K-slab -------------------------------------
-// KC: tile[row][k], row = r0 + (f >> 3), k = k0 + 4*(f & 7);   f = tid + 256*i
-template <bool KC>
+// ---- tile loader: ROWS x BK floats per K-slab, NV float4 per thread -------------------------------
+// KC: tile[row][k], f = tid + 256 i -> row = f >> 3, k = 4 (f & 7)
+// RC: tile[k][row], f -> k = f / (ROWS/4), row = 4 (f % (ROWS/4))
+template <int ROWS, bool KC>
 struct TileLoader {
-  const float* base[4];   // KC: row base pointers (gather resolved once)
-  int rowok[4];
-  __device__ __forceinline__ void init(const float* src, int ld, int r0, int nrows,
-                                       const int64_t* gather) {
+  static constexpr int NV = ROWS * BK / 4 / GNT;
+  static constexpr int RS = ROWS + 4;
+  static constexpr int RQ = ROWS / 4;
+  const float* base[NV];
+  bool rowok[NV];
+
+  __device__ __forceinline__ void init(const float* src, int ld, int r0, int nrows, const int64_t* gather) {
     if (KC) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NV; ++i) {
         int f = threadIdx.x + GNT * i;
         int r = r0 + (f >> 3);
         rowok[i] = r < nrows;
@@ -87,47 +96,67 @@ struct TileLoader {
       }
     }
   }
-  // KC load: kleft = contraction elements remaining from k0
-  __device__ __forceinline__ void load_kc(float4 (&v)[4], int k0, int kend, bool vec) const {
+  template <bool VEC>
+  __device__ __forceinline__ unsigned load_kc(float4 (&v)[NV], int k0, int kend) const {
+    unsigned mask = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
       int f = threadIdx.x + GNT * i;
       int k = k0 + 4 * (f & 7);
-      int valid = rowok[i] ? (kend - k) : 0;
-      v[i] = ld4(base[i] + k0, valid, vec);
+      if (VEC) {
+        const bool ok = rowok[i] && (k + 4 <= kend);
+        v[i] = ld4v(base[i] + (ok ? k0 : -4 * (f & 7)));   // invalid -> start of a mapped row
+        mask |= (ok ? 1u : 0u) << i;
+      } else {
+        v[i] = ld4s(base[i] + k0, rowok[i] ? (kend - k) : 0);
+        mask |= 1u << i;
+      }
     }
+    return mask;
   }
-  // RC load: tile[k][row], k = k0 + (f >> 5), row = r0 + 4*(f & 31)
-  __device__ __forceinline__ void load_rc(float4 (&v)[4], const float* src, int ld, int r0, int nrows,
-                                          int k0, int kend, const int64_t* kgather, bool vec) const {
+  template <bool VEC>
+  __device__ __forceinline__ unsigned load_rc(float4 (&v)[NV], const float* src, int ld, int r0, int nrows,
+                                              int k0, int kend, const int64_t* kgather) const {
+    unsigned mask = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
       int f = threadIdx.x + GNT * i;
-      int k = k0 + (f >> 5);
-      int r = r0 + 4 * (f & 31);
-      int valid = (k < kend) ? (nrows - r) : 0;
-      int64_t gk = (k < kend) ? (kgather ? kgather[k] : (int64_t)k) : 0;
-      v[i] = ld4(src + gk * ld + r, valid, vec);
+      int k = k0 + f / RQ;
+      int r = r0 + 4 * (f % RQ);
+      const bool kok = k < kend;
+      int64_t gk = kok ? (kgather ? kgather[k] : (int64_t)k) : 0;
+      if (VEC) {
+        const bool ok = kok && (r + 4 <= nrows);
+        v[i] = ld4v(src + gk * ld + (ok ? r : 0));
+        mask |= (ok ? 1u : 0u) << i;
+      } else {
+        v[i] = ld4s(src + gk * ld + r, kok ? (nrows - r) : 0);
+        mask |= 1u << i;
+      }
     }
+    return mask;
   }
-  __device__ __forceinline__ void store(float* tile, const float4 (&v)[4]) const {
+  __device__ __forceinline__ void store(float* tile, const float4 (&v)[NV], unsigned mask) const {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
       int f = threadIdx.x + GNT * i;
-      if (KC) *reinterpret_cast<float4*>(tile + (f >> 3) * KS + 4 * (f & 7)) = v[i];
-      else    *reinterpret_cast<float4*>(tile + (f >> 5) * RS + 4 * (f & 31)) = v[i];
+      const float4 w = ((mask >> i) & 1u) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KC) *reinterpret_cast<float4*>(tile + (f >> 3) * KS + 4 * (f & 7)) = w;
+      else    *reinterpret_cast<float4*>(tile + (f / RQ) * RS + 4 * (f % RQ)) = w;
     }
   }
 };
 
-template <bool A_KC, bool B_KC>
-__device__ __forceinline__ void mma_slab(f32x16 (&acc)[2][2], const float* __restrict__ As,
+// one K-slab of MFMAs: wave tile 64 x (32 NT) at rows wr*64.., cols wc*32*NT..
+template <bool A_KC, bool B_KC, int NT, int BN_>
+__device__ __forceinline__ void mma_slab(f32x16 (&acc)[2][NT], const float* __restrict__ As,
                                          const float* __restrict__ Bs, int wr, int wc, int lane) {
+  constexpr int ARS = BM + 4, BRS = BN_ + 4;
   const int l31 = lane & 31;
   const int kh = (lane >> 5) * 4;
 #pragma unroll
   for (int kg = 0; kg < BK; kg += 8) {
-    float a[2][4], b[2][4];
+    float a[2][4], b[NT][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if (A_KC) {
@@ -135,14 +164,17 @@ __device__ __forceinline__ void mma_slab(f32x16 (&acc)[2][2], const float* __res
         a[t][0] = v.x; a[t][1] = v.y; a[t][2] = v.z; a[t][3] = v.w;
       } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[t][s] = As[(kg + kh + s) * RS + wr * 64 + t * 32 + l31];
+        for (int s = 0; s < 4; ++s) a[t][s] = As[(kg + kh + s) * ARS + wr * 64 + t * 32 + l31];
       }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
       if (B_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(Bs + (wc * 64 + t * 32 + l31) * KS + kg + kh);
+        const float4 v = *reinterpret_cast<const float4*>(Bs + (wc * 32 * NT + t * 32 + l31) * KS + kg + kh);
         b[t][0] = v.x; b[t][1] = v.y; b[t][2] = v.z; b[t][3] = v.w;
       } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) b[t][s] = Bs[(kg + kh + s) * RS + wc * 64 + t * 32 + l31];
+        for (int s = 0; s < 4; ++s) b[t][s] = Bs[(kg + kh + s) * BRS + wc * 32 * NT + t * 32 + l31];
       }
     }
 #pragma unroll
@@ -150,7 +182,7 @@ __device__ __forceinline__ void mma_slab(f32x16 (&acc)[2][2], const float* __res
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
   }
 }
@@ -161,11 +193,19 @@ __device__ __forceinline__ float apply_act(float v, int act, float lo, float hi)
   return v;
 }
 
-template <bool A_KC, bool B_KC, int EPI>
+constexpr int A_TILE_FLOATS = BM * KS;  // 4608 (>= 32 * 132 for the RC layout)
+constexpr int b_tile_floats(int bn) { return bn * KS; }  // >= 32 * (bn + 4)
+constexpr size_t gemm_lds_bytes(int bn) { return 2 * (size_t)(A_TILE_FLOATS + b_tile_floats(bn)) * sizeof(float); }
+
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_>
 __global__ __launch_bounds__(GNT, 2) void gemm_kernel(const GemmArgs g) {
+  constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
+  constexpr int NT = BN_ / 64;
+  static_assert(!GATED || BN_ == 128, "gated epilogue needs the h and g column tiles in one wave");
+  constexpr int STAGE = A_TILE_FLOATS + b_tile_floats(BN_);
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  auto As = [&](int b) -> float* { return smem + (2 * b) * TILE_FLOATS; };
-  auto Bs = [&](int b) -> float* { return smem + (2 * b + 1) * TILE_FLOATS; };
+  auto As = [&](int b) -> float* { return smem + b * STAGE; };
+  auto Bs = [&](int b) -> float* { return smem + b * STAGE + A_TILE_FLOATS; };
 
   // XCD-aware bijective remap: XCD x (= id % 8) works on a contiguous run of tiles
   const int ntiles = g.tiles_m * g.tiles_n;
@@ -177,16 +217,16 @@ __global__ __launch_bounds__(GNT, 2) void gemm_kernel(const GemmArgs g) {
   }
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
   const int m0 = tm * BM;
-  // EPI_GATED: a block covers 64 gated output columns; B tile rows = [wc][h|g][32]
-  const int n0 = (EPI == EPI_GATED) ? tn * 64 : tn * BN;
+  // gated: a block covers 64 gated output columns; B tile rows = [wc][h|g][32]
+  const int n0 = GATED ? tn * 64 : tn * BN_;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -201,26 +241,23 @@ __global__ __launch_bounds__(GNT, 2) void gemm_kernel(const GemmArgs g) {
     if (e < s_end) s_end = e;
   }
 
-  TileLoader<A_KC> la[2];
-  TileLoader<B_KC> lb[2];
-  bool veca[2], vecb[2];
+  typedef TileLoader<BM, A_KC> LA;
+  typedef TileLoader<BN_, B_KC> LB;
+  LA la[2];
+  LB lb[2];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     if (p < g.npairs) {
-      veca[p] = ((g.lda[p] & 3) == 0) && (((uintptr_t)g.A[p] & 15) == 0);
-      vecb[p] = ((g.ldb[p] & 3) == 0) && (((uintptr_t)g.B[p] & 15) == 0);
       la[p].init(g.A[p], g.lda[p], m0, g.M, g.a_rows);
-      if (EPI != EPI_GATED) lb[p].init(g.B[p], g.ldb[p], n0, g.N, nullptr);
+      if (!GATED) lb[p].init(g.B[p], g.ldb[p], n0, g.N, nullptr);
     }
   }
-  // EPI_GATED B tile: LDS row r -> weight row n0 + (r>>6)*32 + (r&31) of (r&32 ? Bg : B[0])
-  const float* gb_base[4];
-  int gb_ok[4];
-  bool vecg = true;
-  if (EPI == EPI_GATED) {
-    vecg = ((g.ldb[0] & 3) == 0) && ((((uintptr_t)g.B[0] | (uintptr_t)g.Bg) & 15) == 0);
+  // gated B tile: LDS row r -> weight row n0 + (r>>6)*32 + (r&31) of (r&32 ? Bg : B[0])
+  const float* gb_base[LB::NV];
+  bool gb_ok[LB::NV];
+  if (GATED) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < LB::NV; ++i) {
       int f = threadIdx.x + GNT * i;
       int r = f >> 3;
       int n = n0 + (r >> 6) * 32 + (r & 31);
@@ -230,72 +267,88 @@ __global__ __launch_bounds__(GNT, 2) void gemm_kernel(const GemmArgs g) {
     }
   }
 
-  auto load_slab = [&](int s, float4 (&ra)[4], float4 (&rb)[4]) {
+  auto load_slab = [&](int s, float4 (&ra)[LA::NV], float4 (&rb)[LB::NV], unsigned& ma, unsigned& mb) {
     const int p = (s < nslab[0]) ? 0 : 1;
     const int k0 = (p == 0 ? s : s - nslab[0]) * BK;
     const int kend = g.Kc[p];
-    if (A_KC) la[p].load_kc(ra, k0, kend, veca[p]);
-    else la[p].load_rc(ra, g.A[p], g.lda[p], m0, g.M, k0, kend, nullptr, veca[p]);
-    if (EPI == EPI_GATED) {
+    if (A_KC) ma = la[p].template load_kc<VEC>(ra, k0, kend);
+    else ma = la[p].template load_rc<VEC>(ra, g.A[p], g.lda[p], m0, g.M, k0, kend, nullptr);
+    if (GATED) {
+      mb = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < LB::NV; ++i) {
         int f = threadIdx.x + GNT * i;
         int k = k0 + 4 * (f & 7);
-        rb[i] = ld4(gb_base[i] + k0, gb_ok[i] ? (kend - k) : 0, vecg);
+        if (VEC) {
+          const bool ok = gb_ok[i] && (k + 4 <= kend);
+          rb[i] = ld4v(gb_base[i] + (ok ? k0 : -4 * (f & 7)));
+          mb |= (ok ? 1u : 0u) << i;
+        } else {
+          rb[i] = ld4s(gb_base[i] + k0, gb_ok[i] ? (kend - k) : 0);
+          mb |= 1u << i;
+        }
       }
     } else if (B_KC) {
-      lb[p].load_kc(rb, k0, kend, vecb[p]);
+      mb = lb[p].template load_kc<VEC>(rb, k0, kend);
     } else {
-      lb[p].load_rc(rb, g.B[p], g.ldb[p], n0, g.N, k0, kend, g.b_krows, vecb[p]);
+      mb = lb[p].template load_rc<VEC>(rb, g.B[p], g.ldb[p], n0, g.N, k0, kend, g.b_krows);
     }
   };
 
   if (s_begin < s_end) {
-    float4 ra[4], rb[4];
-    load_slab(s_begin, ra, rb);
-    la[0].store(As(0), ra);
-    lb[0].store(Bs(0), rb);
+    float4 ra[LA::NV], rb[LB::NV];
+    unsigned ma, mb;
+    load_slab(s_begin, ra, rb, ma, mb);
+    la[0].store(As(0), ra, ma);
+    lb[0].store(Bs(0), rb, mb);
     __syncthreads();
     for (int s = s_begin; s < s_end; ++s) {
       const int cur = (s - s_begin) & 1;
       const bool more = s + 1 < s_end;
-      if (more) load_slab(s + 1, ra, rb);
-      mma_slab<A_KC, B_KC>(acc, As(cur), Bs(cur), wr, wc, lane);
+      if (more) load_slab(s + 1, ra, rb, ma, mb);
+      mma_slab<A_KC, B_KC, NT, BN_>(acc, As(cur), Bs(cur), wr, wc, lane);
       if (more) {
-        la[0].store(As(cur ^ 1), ra);
-        lb[0].store(Bs(cur ^ 1), rb);
+        la[0].store(As(cur ^ 1), ra, ma);
+        lb[0].store(Bs(cur ^ 1), rb, mb);
       }
       __syncthreads();
     }
   }
 
   // ---- epilogue.  acc[mt][nt][r] <-> row m0 + wr*64 + mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
-  //                                    col (within wave tile) nt*32 + (lane&31)
+  //                                    col (within the wave tile) nt*32 + (lane&31)
   const int l31 = lane & 31, lh = lane >> 5;
-  if (EPI == EPI_GATED) {
+  if (GATED) {
     const int n = n0 + wc * 32 + l31;
     if (n < g.N) {
-      const float bh = g.bias0 ? g.bias0[n] : 0.f;
-      const float bg = g.bias1 ? g.bias1[n] : 0.f;
+      const float bh = (EPI == EPI_GATED && g.bias0) ? g.bias0[n] : 0.f;
+      const float bg = (EPI == EPI_GATED && g.bias1) ? g.bias1[n] : 0.f;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (m < g.M) {
-            const float h = acc[mt][0][r] + bh;
-            const float s = 1.0f / (1.0f + expf(-(acc[mt][1][r] + bg)));
-            const size_t o = (size_t)m * g.ldo + n;
-            g.out0[o] = h * s;
-            if (g.out1) g.out1[o] = h;
-            if (g.out2) g.out2[o] = s;
+            if (EPI == EPI_GATED) {
+              const float h = acc[mt][0][r] + bh;
+              const float s = 1.0f / (1.0f + expf(-(acc[mt][NT - 1][r] + bg)));
+              const size_t o = (size_t)m * g.ldo + n;
+              g.out0[o] = h * s;
+              if (g.out1) g.out1[o] = h;
+              if (g.out2) g.out2[o] = s;
+            } else {   // EPI_RAW_GATED: partial planes [z][2][M][N]
+              const size_t plane = (size_t)g.M * g.N;
+              const size_t o = (size_t)blockIdx.z * 2 * plane + (size_t)m * g.N + n;
+              g.out0[o] = acc[mt][0][r];
+              g.out0[o + plane] = acc[mt][NT - 1][r];
+            }
           }
         }
     }
   } else {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int n = n0 + wc * 64 + nt * 32 + l31;
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
       if (n >= g.N) continue;
       const float bias = (EPI == EPI_LINEAR && g.bias0) ? g.bias0[n] : 0.f;
 #pragma unroll
@@ -311,31 +364,73 @@ __global__ __launch_bounds__(GNT, 2) void gemm_kernel(const GemmArgs g) {
             if (g.out1) g.out1[o] = pre;
             g.out0[o] = apply_act(pre, g.act, g.lo, g.hi);
           } else if (EPI == EPI_GATE_BWD) {
-            const float h = g.e0[o], s = g.e1[o];
-            g.out0[o] = v * s;                       // dh
-            g.out1[o] = v * h * s * (1.0f - s);      // dg
-          } else {                                    // EPI_PARTIAL
-            g.out0[(size_t)blockIdx.z * g.M * g.ldo + o] = v;
+            const size_t oe = (size_t)m * g.N + n;   // h/s of the layer below are dense [M x N]
+            const float h = g.e0[oe], s = g.e1[oe];
+            g.out0[o] = v * s;                   // dh
+            g.out1[o] = v * h * s * (1.0f - s);  // dg
+          } else {                                // EPI_RAW: partial plane [z][M][N]
+            g.out0[(size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n] = v;
           }
         }
     }
   }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_z part[z][i]
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n,
-                                     float* __restrict__ out, int accumulate) {
+// ---- split-K finish: sum the partial planes in a fixed order, then the real epilogue ----------------
+struct FinishArgs {
+  const float* part;
+  int nz, M, N, ldo;
+  int epi;
+  const float* bias0;
+  const float* bias1;
+  float* out0;
+  float* out1;
+  float* out2;
+  const float* e0;
+  const float* e1;
+  int act;
+  float lo, hi;
+  int accumulate;
+};
+
+__global__ __launch_bounds__(256) void gemm_finish_kernel(const FinishArgs f) {
+  const size_t plane = (size_t)f.M * f.N;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = accumulate ? out[i] : 0.f;
-  for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * n + i];
-  out[i] = s;
+  if (i >= plane) return;
+  const int m = (int)(i / f.N), n = (int)(i - (size_t)m * f.N);
+  const size_t o = (size_t)m * f.ldo + n;
+  if (f.epi == EPI_GATED) {
+    float h = 0.f, gg = 0.f;
+    for (int z = 0; z < f.nz; ++z) {
+      h += f.part[(size_t)z * 2 * plane + i];
+      gg += f.part[(size_t)z * 2 * plane + plane + i];
+    }
+    h += f.bias0 ? f.bias0[n] : 0.f;
+    const float s = 1.0f / (1.0f + expf(-(gg + (f.bias1 ? f.bias1[n] : 0.f))));
+    f.out0[o] = h * s;
+    if (f.out1) f.out1[o] = h;
+    if (f.out2) f.out2[o] = s;
+    return;
+  }
+  float v = 0.f;
+  for (int z = 0; z < f.nz; ++z) v += f.part[(size_t)z * plane + i];
+  if (f.epi == EPI_LINEAR) {
+    const float pre = v + (f.bias0 ? f.bias0[n] : 0.f);
+    if (f.out1) f.out1[o] = pre;
+    f.out0[o] = apply_act(pre, f.act, f.lo, f.hi);
+  } else if (f.epi == EPI_GATE_BWD) {
+    const float h = f.e0[i], s = f.e1[i];
+    f.out0[o] = v * s;
+    f.out1[o] = v * h * s * (1.0f - s);
+  } else {  // EPI_RAW: plain sum (weight gradient), optional accumulate
+    f.out0[o] = (f.accumulate ? f.out0[o] : 0.f) + v;
+  }
 }
 
-// db[n] = sum_m dy[m][n]: 64 columns x 4 row-slices per block, then a second pass over row blocks.
+// db[n] = sum_m dy[m][n]: 64 columns x 4 row-slices per block over 512-row bands, then a band reduce.
 constexpr int CS_ROWS = 512;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dy, int M, int N,
-                                                             float* __restrict__ part) {
+                                                             int ld, float* __restrict__ part) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rs = threadIdx.x >> 6;
@@ -344,22 +439,33 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   if (mend > M) mend = M;
   float s = 0.f;
   if (c < N)
-    for (int m = mbeg + rs; m < mend; m += 4) s += dy[(size_t)m * N + c];
+    for (int m = mbeg + rs; m < mend; m += 4) s += dy[(size_t)m * ld + c];
   red[rs][threadIdx.x & 63] = s;
   __syncthreads();
   if (rs == 0 && c < N)
     part[(size_t)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+__global__ void band_reduce_kernel(const float* __restrict__ part, int nb, int n, float* __restrict__ out,
+                                   int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = accumulate ? out[i] : 0.f;
+  for (int b = 0; b < nb; ++b) s += part[(size_t)b * n + i];
+  out[i] = s;
+}
+
 __global__ void gated_bwd_input_kernel(const float* __restrict__ dout, const float* __restrict__ h,
-                                       const float* __restrict__ s, size_t n, float* __restrict__ dh,
-                                       float* __restrict__ dg) {
+                                       const float* __restrict__ s, int M, int N, int ldo,
+                                       float* __restrict__ dh, float* __restrict__ dg) {
+  const size_t n = (size_t)M * N;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     const float d = dout[i], hv = h[i], sv = s[i];
-    dh[i] = d * sv;
-    dg[i] = d * hv * sv * (1.0f - sv);
+    const size_t o = (i / N) * (size_t)ldo + (i % N);
+    dh[o] = d * sv;
+    dg[o] = d * hv * sv * (1.0f - sv);
   }
 }
 
@@ -376,21 +482,89 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
   }
 }
 
-constexpr size_t GEMM_LDS = 4 * TILE_FLOATS * sizeof(float);  // 73,728 B
+// ---- host side: plan, launch --------------------------------------------------------------------------
+struct Plan {
+  int bn;      // 128 or 64
+  int nz;      // split-K factor (blockIdx.z extent)
+  int ksplit;  // slabs per split
+};
 
-template <bool A_KC, bool B_KC, int EPI>
-static int launch_gemm(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
+// Wave-quantisation model: a launch runs in rounds of 512 resident blocks (256 CUs x 2); a block costs
+// (slabs + fixed prologue/epilogue) slab-times, a BN=64 slab ~0.6 of a BN=128 slab; split-K adds the
+// finish kernel (launch + partial traffic).  Deterministic in (M, N, slabs, gated, must_split).
+static Plan make_plan(int M, int N, int slabs, bool gated, bool must_split, int planes) {
+  Plan best = {128, 1, slabs};
+  double best_t = 1e30;
+  const int bns[2] = {128, 64};
+  for (int bi = 0; bi < (gated ? 1 : 2); ++bi) {
+    const int bn = bns[bi];
+    const long tiles = (long)cdiv(M, BM) * cdiv(N, gated ? 64 : bn);
+    const double slab_cost = bn == 64 ? 0.6 : 1.0;
+    for (int nz = 1; nz <= slabs && nz <= 512; ++nz) {
+      const int ks = cdiv(slabs, nz);
+      const int nze = cdiv(slabs, ks);
+      if (nze != nz) continue;
+      const long rounds = (tiles * nze + 511) / 512;
+      double t = rounds * (ks + 1.5) * slab_cost;
+      if (nze > 1 || must_split) t += 2.0 + (double)M * N * planes * nze * 4.0 / 12e6;
+      if (t < best_t) { best_t = t; best = {bn, nze, ks}; }
+    }
+  }
+  return best;
+}
+
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <bool A_KC, bool B_KC>
+static bool gemm_vec_ok(const GemmArgs& g) {
+  bool ok = true;
+  for (int p = 0; p < g.npairs; ++p) {
+    ok = ok && al16(g.A[p]) && al16(g.B[p]) && (g.lda[p] % 4 == 0) && (g.ldb[p] % 4 == 0);
+    if (A_KC || B_KC) ok = ok && (g.Kc[p] % 4 == 0);
+  }
+  if (!A_KC) ok = ok && (g.M % 4 == 0);
+  if (!B_KC) ok = ok && (g.N % 4 == 0);
+  if (g.Bg) ok = ok && al16(g.Bg);
+  return ok;
+}
+
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_>
+static int launch_gemm_v(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
   static bool attr = false;
+  constexpr size_t lds = gemm_lds_bytes(BN_);
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KC, B_KC, EPI>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KC, B_KC, EPI, VEC, BN_>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
+  constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
   g.tiles_m = cdiv(g.M, BM);
-  g.tiles_n = cdiv(g.N, EPI == EPI_GATED ? 64 : BN);
+  g.tiles_n = cdiv(g.N, GATED ? 64 : BN_);
   dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
-  gemm_kernel<A_KC, B_KC, EPI><<<grid, GNT, GEMM_LDS, stream>>>(g);
+  gemm_kernel<A_KC, B_KC, EPI, VEC, BN_><<<grid, GNT, lds, stream>>>(g);
   return check_launch(what);
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+static int launch_gemm(GemmArgs& g, const Plan& pl, hipStream_t stream, const char* what) {
+  constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
+  const bool vec = gemm_vec_ok<A_KC, B_KC>(g);
+  g.ksplit = pl.nz > 1 ? pl.ksplit : 0;
+  if (GATED || pl.bn == 128) {
+    if (vec) return launch_gemm_v<A_KC, B_KC, EPI, true, 128>(g, pl.nz, stream, what);
+    return launch_gemm_v<A_KC, B_KC, EPI, false, 128>(g, pl.nz, stream, what);
+  }
+  if constexpr (!GATED) {
+    if (vec) return launch_gemm_v<A_KC, B_KC, EPI, true, 64>(g, pl.nz, stream, what);
+    return launch_gemm_v<A_KC, B_KC, EPI, false, 64>(g, pl.nz, stream, what);
+  }
+  return EVAE_EINVAL;
+}
+
+static int launch_finish(const FinishArgs& f, hipStream_t stream) {
+  size_t n = (size_t)f.M * f.N;
+  gemm_finish_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(f);
+  return check_launch("gemm_finish_kernel");
 }
 
 static int elt_grid(size_t n) {
@@ -398,80 +572,132 @@ static int elt_grid(size_t n) {
   return (int)(b < 4096 ? (b ? b : 1) : 4096);
 }
 
-static void wgrad_split(int M, int N, int K, int* nz, int* ksplit) {
-  int tiles = cdiv(N, BM) * cdiv(K, BN);
-  int slabs = cdiv(M, BK);
-  int want = cdiv(1024, tiles);           // ~4 blocks per CU in flight
-  if (want > slabs) want = slabs;
-  if (want < 1) want = 1;
-  *ksplit = cdiv(slabs, want);
-  *nz = cdiv(slabs, *ksplit);
-}
+static int total_slabs(int k0, int k1) { return cdiv(k0, BK) + (k1 > 0 ? cdiv(k1, BK) : 0); }
 
 }  // namespace evae
 
 using namespace evae;
 
+// ---- forward -------------------------------------------------------------------------------------------
+extern "C" size_t evae_dense_fwd_workspace_bytes(int M, int K, int N, int gated) {
+  if (M <= 0 || K <= 0 || N <= 0) return 256;
+  Plan pl = make_plan(M, N, cdiv(K, BK), gated != 0, false, gated ? 2 : 1);
+  if (pl.nz <= 1) return 256;
+  return align_up((size_t)pl.nz * (gated ? 2 : 1) * M * N * sizeof(float), 256) + 256;
+}
+
 extern "C" int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, int K, int ldx,
                                     const float* wh, const float* bh, const float* wg, const float* bg,
-                                    int N, float* out, float* save_h, float* save_s,
-                                    evae_stream_t stream_) {
+                                    int N, float* out, float* save_h, float* save_s, void* ws,
+                                    size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(M >= 0 && K > 0 && N > 0 && ldx >= K, "gated_dense_fwd: bad sizes M=%d K=%d N=%d ldx=%d", M, K, N, ldx);
   if (M == 0) return EVAE_OK;
   EVAE_REQUIRE(x && wh && wg && out, "gated_dense_fwd: null pointer");
+  Plan pl = make_plan(M, N, cdiv(K, BK), true, false, 2);
   GemmArgs g = {};
   g.A[0] = x; g.B[0] = wh; g.Bg = wg; g.lda[0] = ldx; g.ldb[0] = K; g.Kc[0] = K; g.npairs = 1;
   g.a_rows = rows; g.M = M; g.N = N; g.bias0 = bh; g.bias1 = bg;
   g.out0 = out; g.out1 = save_h; g.out2 = save_s; g.ldo = N;
-  return launch_gemm<true, true, EPI_GATED>(g, 1, (hipStream_t)stream_, "gated_dense_fwd");
+  if (pl.nz <= 1) return launch_gemm<true, true, EPI_GATED>(g, pl, stream, "gated_dense_fwd");
+  if (ws == nullptr || ws_bytes < evae_dense_fwd_workspace_bytes(M, K, N, 1)) {
+    set_error("gated_dense_fwd: workspace too small (%zu)", ws_bytes);
+    return EVAE_EWORKSPACE;
+  }
+  g.out0 = (float*)ws; g.out1 = g.out2 = nullptr;
+  int rc = launch_gemm<true, true, EPI_RAW_GATED>(g, pl, stream, "gated_dense_fwd(split-K)");
+  if (rc) return rc;
+  FinishArgs f = {};
+  f.part = (const float*)ws; f.nz = pl.nz; f.M = M; f.N = N; f.ldo = N; f.epi = EPI_GATED;
+  f.bias0 = bh; f.bias1 = bg; f.out0 = out; f.out1 = save_h; f.out2 = save_s;
+  return launch_finish(f, stream);
 }
 
 extern "C" int evae_linear_fwd(const float* x, const int64_t* rows, int M, int K, int ldx,
                                const float* w, const float* b, int N, int act, float act_lo,
-                               float act_hi, float* y, float* pre, evae_stream_t stream_) {
+                               float act_hi, float* y, float* pre, void* ws, size_t ws_bytes,
+                               evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(M >= 0 && K > 0 && N > 0 && ldx >= K, "linear_fwd: bad sizes M=%d K=%d N=%d ldx=%d", M, K, N, ldx);
   EVAE_REQUIRE(act >= 0 && act <= 2, "linear_fwd: bad activation %d", act);
   if (M == 0) return EVAE_OK;
   EVAE_REQUIRE(x && w && y, "linear_fwd: null pointer");
+  Plan pl = make_plan(M, N, cdiv(K, BK), false, false, 1);
   GemmArgs g = {};
   g.A[0] = x; g.B[0] = w; g.lda[0] = ldx; g.ldb[0] = K; g.Kc[0] = K; g.npairs = 1;
   g.a_rows = rows; g.M = M; g.N = N; g.bias0 = b; g.out0 = y; g.out1 = pre; g.ldo = N;
   g.act = act; g.lo = act_lo; g.hi = act_hi;
-  return launch_gemm<true, true, EPI_LINEAR>(g, 1, (hipStream_t)stream_, "linear_fwd");
+  if (pl.nz <= 1) return launch_gemm<true, true, EPI_LINEAR>(g, pl, stream, "linear_fwd");
+  if (ws == nullptr || ws_bytes < evae_dense_fwd_workspace_bytes(M, K, N, 0)) {
+    set_error("linear_fwd: workspace too small (%zu)", ws_bytes);
+    return EVAE_EWORKSPACE;
+  }
+  g.out0 = (float*)ws; g.out1 = nullptr;
+  int rc = launch_gemm<true, true, EPI_RAW>(g, pl, stream, "linear_fwd(split-K)");
+  if (rc) return rc;
+  FinishArgs f = {};
+  f.part = (const float*)ws; f.nz = pl.nz; f.M = M; f.N = N; f.ldo = N; f.epi = EPI_LINEAR;
+  f.bias0 = b; f.out0 = y; f.out1 = pre; f.act = act; f.lo = act_lo; f.hi = act_hi;
+  return launch_finish(f, stream);
+}
+
+// ---- data gradient ---------------------------------------------------------------------------------------
+extern "C" size_t evae_dense_bwd_data_workspace_bytes(int M, int N, int K, int npairs) {
+  if (M <= 0 || K <= 0 || N <= 0) return 256;
+  Plan pl = make_plan(M, K, total_slabs(N, npairs > 1 ? N : 0), false, false, 1);
+  if (pl.nz <= 1) return 256;
+  return align_up((size_t)pl.nz * M * K * sizeof(float), 256) + 256;
 }
 
 extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const float* dy2, const float* w2,
-                                   int M, int N, int K, const float* h_prev, const float* s_prev,
-                                   float* dx_or_dh, float* dg, evae_stream_t stream_) {
-  EVAE_REQUIRE(M >= 0 && N > 0 && K > 0, "dense_bwd_data: bad sizes M=%d N=%d K=%d", M, N, K);
+                                   int M, int N, int ldy, int K, const float* h_prev, const float* s_prev,
+                                   float* dx_or_dh, float* dg, int ldo, void* ws, size_t ws_bytes,
+                                   evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldy >= N && ldo >= K, "dense_bwd_data: bad sizes M=%d N=%d K=%d", M, N, K);
   if (M == 0) return EVAE_OK;
   EVAE_REQUIRE(dy1 && w1 && dx_or_dh, "dense_bwd_data: null pointer");
   EVAE_REQUIRE((dy2 == nullptr) == (w2 == nullptr), "dense_bwd_data: dy2/w2 must come together");
   const bool gate = h_prev != nullptr;
   EVAE_REQUIRE(!gate || (s_prev && dg), "dense_bwd_data: gate fusion needs h_prev, s_prev and dg");
+  const int np = dy2 ? 2 : 1;
+  Plan pl = make_plan(M, K, total_slabs(N, np > 1 ? N : 0), false, false, 1);
   GemmArgs g = {};
-  g.A[0] = dy1; g.B[0] = w1; g.lda[0] = N; g.ldb[0] = K; g.Kc[0] = N; g.npairs = 1;
-  if (dy2) { g.A[1] = dy2; g.B[1] = w2; g.lda[1] = N; g.ldb[1] = K; g.Kc[1] = N; g.npairs = 2; }
-  g.M = M; g.N = K; g.out0 = dx_or_dh; g.out1 = dg; g.ldo = K; g.e0 = h_prev; g.e1 = s_prev;
-  if (gate) return launch_gemm<true, false, EPI_GATE_BWD>(g, 1, (hipStream_t)stream_, "dense_bwd_data(gate)");
-  g.out1 = nullptr;
-  return launch_gemm<true, false, EPI_LINEAR>(g, 1, (hipStream_t)stream_, "dense_bwd_data");
+  g.A[0] = dy1; g.B[0] = w1; g.lda[0] = ldy; g.ldb[0] = K; g.Kc[0] = N; g.npairs = np;
+  if (dy2) { g.A[1] = dy2; g.B[1] = w2; g.lda[1] = ldy; g.ldb[1] = K; g.Kc[1] = N; }
+  g.M = M; g.N = K; g.out0 = dx_or_dh; g.out1 = gate ? dg : nullptr; g.ldo = ldo; g.e0 = h_prev; g.e1 = s_prev;
+  if (pl.nz <= 1) {
+    if (gate) return launch_gemm<true, false, EPI_GATE_BWD>(g, pl, stream, "dense_bwd_data(gate)");
+    return launch_gemm<true, false, EPI_LINEAR>(g, pl, stream, "dense_bwd_data");
+  }
+  if (ws == nullptr || ws_bytes < evae_dense_bwd_data_workspace_bytes(M, N, K, np)) {
+    set_error("dense_bwd_data: workspace too small (%zu)", ws_bytes);
+    return EVAE_EWORKSPACE;
+  }
+  g.out0 = (float*)ws; g.out1 = nullptr;
+  int rc = launch_gemm<true, false, EPI_RAW>(g, pl, stream, "dense_bwd_data(split-K)");
+  if (rc) return rc;
+  FinishArgs f = {};
+  f.part = (const float*)ws; f.nz = pl.nz; f.M = M; f.N = K; f.ldo = ldo;
+  f.epi = gate ? EPI_GATE_BWD : EPI_LINEAR; f.out0 = dx_or_dh; f.out1 = gate ? dg : nullptr;
+  f.e0 = h_prev; f.e1 = s_prev;
+  return launch_finish(f, stream);
 }
 
+// ---- weight gradient -------------------------------------------------------------------------------------
 extern "C" size_t evae_dense_bwd_weight_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 256;
-  int nz, ks;
-  wgrad_split(M, N, K, &nz, &ks);
-  size_t part = (size_t)nz * N * K * sizeof(float);
+  Plan pl = make_plan(N, K, cdiv(M, BK), false, true, 1);
+  size_t part = (size_t)pl.nz * N * K * sizeof(float);
   size_t cs = (size_t)cdiv(M, CS_ROWS) * N * sizeof(float);
   return align_up(part, 256) + align_up(cs, 256) + 256;
 }
 
-extern "C" int evae_dense_bwd_weight(const float* dy, int M, int N, const float* x, const int64_t* rows,
-                                     int K, int ldx, float* dw, float* db, int accumulate, void* ws,
-                                     size_t ws_bytes, evae_stream_t stream_) {
+extern "C" int evae_dense_bwd_weight(const float* dy, int M, int N, int ldy, const float* x,
+                                     const int64_t* rows, int K, int ldx, float* dw, float* db,
+                                     int accumulate, void* ws, size_t ws_bytes, evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K, "dense_bwd_weight: bad sizes M=%d N=%d K=%d", M, N, K);
+  EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N, "dense_bwd_weight: bad sizes M=%d N=%d K=%d", M, N, K);
   EVAE_REQUIRE(dw != nullptr, "dense_bwd_weight: null dw");
   if (ws == nullptr || ws_bytes < evae_dense_bwd_weight_workspace_bytes(M, N, K)) {
     set_error("dense_bwd_weight: workspace too small (%zu)", ws_bytes);
@@ -485,32 +711,31 @@ extern "C" int evae_dense_bwd_weight(const float* dy, int M, int N, const float*
     return check_launch("dense_bwd_weight(empty)");
   }
   EVAE_REQUIRE(dy && x, "dense_bwd_weight: null pointer");
-  int nz, ks;
-  wgrad_split(M, N, K, &nz, &ks);
+  Plan pl = make_plan(N, K, cdiv(M, BK), false, true, 1);
   float* part = (float*)ws;
-  float* cs = (float*)((char*)ws + align_up((size_t)nz * N * K * sizeof(float), 256));
+  float* cs = (float*)((char*)ws + align_up((size_t)pl.nz * N * K * sizeof(float), 256));
   GemmArgs g = {};
-  g.A[0] = dy; g.B[0] = x; g.lda[0] = N; g.ldb[0] = ldx; g.Kc[0] = M; g.npairs = 1;
-  g.b_krows = rows; g.M = N; g.N = K; g.ksplit = ks; g.out0 = part; g.ldo = K;
-  int rc = launch_gemm<false, false, EPI_PARTIAL>(g, nz, stream, "dense_bwd_weight");
+  g.A[0] = dy; g.B[0] = x; g.lda[0] = ldy; g.ldb[0] = ldx; g.Kc[0] = M; g.npairs = 1;
+  g.b_krows = rows; g.M = N; g.N = K; g.out0 = part; g.ldo = K;
+  int rc = launch_gemm<false, false, EPI_RAW>(g, pl, stream, "dense_bwd_weight");
   if (rc) return rc;
-  size_t n = (size_t)N * K;
-  splitk_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(part, nz, n, dw, accumulate);
-  rc = check_launch("splitk_reduce");
+  FinishArgs f = {};
+  f.part = part; f.nz = pl.nz; f.M = N; f.N = K; f.ldo = K; f.epi = EPI_RAW; f.out0 = dw; f.accumulate = accumulate;
+  rc = launch_finish(f, stream);
   if (rc || !db) return rc;
   int nb = cdiv(M, CS_ROWS);
-  colsum_partial_kernel<<<dim3(cdiv(N, 64), nb), 256, 0, stream>>>(dy, M, N, cs);
+  colsum_partial_kernel<<<dim3(cdiv(N, 64), nb), 256, 0, stream>>>(dy, M, N, ldy, cs);
   rc = check_launch("colsum_partial");
   if (rc) return rc;
-  splitk_reduce_kernel<<<cdiv(N, 256), 256, 0, stream>>>(cs, nb, (size_t)N, db, accumulate);
-  return check_launch("colsum_reduce");
+  band_reduce_kernel<<<cdiv(N, 256), 256, 0, stream>>>(cs, nb, N, db, accumulate);
+  return check_launch("band_reduce");
 }
 
-extern "C" int evae_gated_dense_bwd_input(const float* dout, const float* h, const float* s, size_t n,
-                                          float* dh, float* dg, evae_stream_t stream_) {
-  if (n == 0) return EVAE_OK;
-  EVAE_REQUIRE(dout && h && s && dh && dg, "gated_dense_bwd_input: null pointer");
-  gated_bwd_input_kernel<<<elt_grid(n), 256, 0, (hipStream_t)stream_>>>(dout, h, s, n, dh, dg);
+extern "C" int evae_gated_dense_bwd_input(const float* dout, const float* h, const float* s, int M, int N,
+                                          float* dh, float* dg, int ldo, evae_stream_t stream_) {
+  if (M <= 0 || N <= 0) return EVAE_OK;
+  EVAE_REQUIRE(dout && h && s && dh && dg && ldo >= N, "gated_dense_bwd_input: bad arguments");
+  gated_bwd_input_kernel<<<elt_grid((size_t)M * N), 256, 0, (hipStream_t)stream_>>>(dout, h, s, M, N, ldo, dh, dg);
   return check_launch("gated_dense_bwd_input");
 }
 

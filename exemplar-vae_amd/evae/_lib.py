@@ -36,12 +36,14 @@ SIGNATURES = {
     "evae_pairdist_topk": (_i, [_p, _i, _p, _i, _i, _i, _u, _l, _p, _p, _p, _z, _p]),
     "evae_pairwise_distance": (_i, [_p, _i, _p, _i, _i, _p, _p]),
     "evae_topk_merge": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
-    "evae_gated_dense_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
-    "evae_linear_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _f, _p, _p, _p]),
-    "evae_dense_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "evae_dense_fwd_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "evae_gated_dense_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _z, _p]),
+    "evae_linear_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _f, _p, _p, _p, _z, _p]),
+    "evae_dense_bwd_data_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "evae_dense_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _z, _p]),
     "evae_dense_bwd_weight_workspace_bytes": (_z, [_i, _i, _i]),
-    "evae_dense_bwd_weight": (_i, [_p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p, _z, _p]),
-    "evae_gated_dense_bwd_input": (_i, [_p, _p, _p, _z, _p, _p, _p]),
+    "evae_dense_bwd_weight": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p, _z, _p]),
+    "evae_gated_dense_bwd_input": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "evae_act_bwd": (_i, [_p, _p, _z, _i, _f, _f, _p, _p]),
     "evae_reparam_logq_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_reparam_logq_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),

@@ -12,6 +12,7 @@ ACT_NONE, ACT_SIGMOID, ACT_HARDTANH = 0, 1, 2
 TOPK_SQRT = 1
 
 _ws = {}
+PROBE = None   # bench.py sets {'gated_dense_fwd': []} to collect (start, end, flops) HIP-event triples
 
 
 def _need_cuda(*ts):
@@ -177,27 +178,40 @@ def topk_merge(val, idx):
 # ------------------------------------------------------------------------------------------------
 # dense layers
 # ------------------------------------------------------------------------------------------------
+def _vp(ptr):
+    return C.c_void_p(ptr)
+
+
 def _bwd_weight(dy, x, rows, K, want_db=True):
+    """dw [N x K] = dy^T x(rows), db [N]; dy may be the combined [M x 2N] buffer [dh | dg]."""
     lib = _lib.load()
     M, N = dy.shape
     dw = torch.empty((N, K), device=dy.device)
     db = torch.empty(N, device=dy.device) if want_db else None
     nb = lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
     ws = _workspace("wgrad", nb, dy.device)
-    _lib.check(lib.evae_dense_bwd_weight(_p(dy), M, N, _p(x), _p(rows), K, x.stride(0), _p(dw), _p(db), 0,
-                                         _p(ws), ws.numel(), _stream()), "evae_dense_bwd_weight")
+    _lib.check(lib.evae_dense_bwd_weight(_p(dy), M, N, dy.stride(0), _p(x), _p(rows), K, x.stride(0), _p(dw),
+                                         _p(db), 0, _p(ws), ws.numel(), _stream()), "evae_dense_bwd_weight")
     return dw, db
 
 
-def _bwd_data(dy1, w1, dy2=None, w2=None, h_prev=None, s_prev=None):
+def _bwd_data(dy1_ptr, w1, dy2_ptr, w2, M, N, ldy, device, h_prev=None, s_prev=None, out=None, dg_ptr=None, ldo=None):
+    """dx [M x K] = dy1 W1 (+ dy2 W2); with h_prev/s_prev the gate derivative of the layer below is applied
+    in the epilogue and (dh, dg) are written instead (optionally into the halves of one [M x 2K] buffer)."""
     lib = _lib.load()
-    M, N = dy1.shape
     K = w1.shape[1]
-    out = torch.empty((M, K), device=dy1.device)
-    dg = torch.empty((M, K), device=dy1.device) if h_prev is not None else None
-    _lib.check(lib.evae_dense_bwd_data(_p(dy1), _p(w1), _p(dy2), _p(w2), M, N, K, _p(h_prev), _p(s_prev),
-                                       _p(out), _p(dg), _stream()), "evae_dense_bwd_data")
-    return out, dg
+    if out is None:
+        out = torch.empty((M, K), device=device)
+        ldo = K
+    np_ = 2 if dy2_ptr is not None else 1
+    nb = lib.evae_dense_bwd_data_workspace_bytes(M, N, K, np_)
+    ws = _workspace("dgrad", nb, device)
+    out_ptr = out if isinstance(out, int) else out.data_ptr()
+    _lib.check(lib.evae_dense_bwd_data(_vp(dy1_ptr), _p(w1), None if dy2_ptr is None else _vp(dy2_ptr), _p(w2),
+                                       M, N, ldy, K, _p(h_prev), _p(s_prev), _vp(out_ptr),
+                                       None if dg_ptr is None else _vp(dg_ptr), ldo, _p(ws), ws.numel(), _stream()),
+               "evae_dense_bwd_data")
+    return out
 
 
 def _rows_x(x, rows):
@@ -226,8 +240,18 @@ class GatedDenseFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         h = torch.empty_like(out) if need_grad else None
         s = torch.empty_like(out) if need_grad else None
+        nb = lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
+        ws = _workspace("fwd", nb, x.device)
+        probe = PROBE
+        if probe is not None:
+            ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         _lib.check(lib.evae_gated_dense_fwd(_p(x), _p(rows), M, K, x.stride(0), _p(wh), _p(bh), _p(wg), _p(bg),
-                                            N, _p(out), _p(h), _p(s), _stream()), "evae_gated_dense_fwd")
+                                            N, _p(out), _p(h), _p(s), _p(ws), ws.numel(), _stream()),
+                   "evae_gated_dense_fwd")
+        if probe is not None:
+            ev1.record()
+            probe["gated_dense_fwd"].append((ev0, ev1, 2.0 * M * K * 2 * N))
         if need_grad:
             ctx.save_for_backward(x, rows, wh, wg, h, s)
         ctx.has_bias = (bh is not None, bg is not None)
@@ -238,18 +262,20 @@ class GatedDenseFn(torch.autograd.Function):
         lib = _lib.load()
         x, rows, wh, wg, h, s = ctx.saved_tensors
         dout = _f32(dout)
-        dh = torch.empty_like(h); dg = torch.empty_like(h)
-        _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(h), _p(s), h.numel(), _p(dh), _p(dg), _stream()),
-                   "evae_gated_dense_bwd_input")
+        M, N = h.shape
         K = wh.shape[1]
-        dwh, dbh = _bwd_weight(dh, x, rows, K)
-        dwg, dbg = _bwd_weight(dg, x, rows, K)
+        dpre = torch.empty((M, 2 * N), device=h.device)          # [dh | dg]: one buffer, one weight-grad GEMM
+        base = dpre.data_ptr()
+        _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(h), _p(s), M, N, _vp(base), _vp(base + 4 * N),
+                                                  2 * N, _stream()), "evae_gated_dense_bwd_input")
+        dw, db = _bwd_weight(dpre, x, rows, K)                    # [dWh ; dWg], [dbh ; dbg]
         dx = None
         if ctx.needs_input_grad[0]:
             if rows is not None:
                 raise _lib.EvaeError("gradient wrt a row-gathered input is not supported")
-            dx, _ = _bwd_data(dh, wh, dg, wg)
-        return dx, None, dwh, (dbh if ctx.has_bias[0] else None), dwg, (dbg if ctx.has_bias[1] else None)
+            dx = _bwd_data(base, wh, base + 4 * N, wg, M, N, 2 * N, h.device)
+        return (dx, None, dw[:N], (db[:N] if ctx.has_bias[0] else None), dw[N:],
+                (db[N:] if ctx.has_bias[1] else None))
 
 
 class LinearFn(torch.autograd.Function):
@@ -265,8 +291,10 @@ class LinearFn(torch.autograd.Function):
         y = torch.empty((M, N), device=x.device)
         need_grad = any(ctx.needs_input_grad)
         pre = torch.empty_like(y) if (need_grad and act == ACT_HARDTANH) else None
+        nb = lib.evae_dense_fwd_workspace_bytes(M, K, N, 0)
+        ws = _workspace("fwd", nb, x.device)
         _lib.check(lib.evae_linear_fwd(_p(x), _p(rows), M, K, x.stride(0), _p(w), _p(b), N, act, float(lo),
-                                       float(hi), _p(y), _p(pre), _stream()), "evae_linear_fwd")
+                                       float(hi), _p(y), _p(pre), _p(ws), ws.numel(), _stream()), "evae_linear_fwd")
         if need_grad:
             ctx.save_for_backward(x, rows, w, pre if pre is not None else y)
         ctx.act = (act, float(lo), float(hi))
@@ -290,7 +318,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if rows is not None:
                 raise _lib.EvaeError("gradient wrt a row-gathered input is not supported")
-            dx, _ = _bwd_data(dpre, w)
+            dx = _bwd_data(dpre.data_ptr(), w, None, None, dpre.shape[0], dpre.shape[1], dpre.stride(0), dpre.device)
         return dx, None, dw, (db if ctx.has_bias else None), None, None, None
 
 

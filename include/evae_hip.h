@@ -126,27 +126,39 @@ int evae_topk_merge(const float* val /* [R x B x k] */, const int64_t* idx, int 
  *   optionally fused with the gated-dense input derivative of the layer below (h_prev, s_prev
  *   non-NULL): writes dh_prev/dg_prev instead of dx.
  * evae_dense_bwd_weight: dW = dy^T x (rows-gathered x allowed), db = column sums of dy.
+ * Thin problems (the 100-row batch path, the small weight-gradient outputs) are split along the
+ * contraction into `ws` partials and finished by a second kernel in a fixed order (deterministic);
+ * the split is chosen by a wave-quantisation model of the 256-CU chip, see csrc/evae_dense.hip.
  */
 #define EVAE_ACT_NONE 0
 #define EVAE_ACT_SIGMOID 1
 #define EVAE_ACT_HARDTANH 2 /* clamp to [act_lo, act_hi] */
 
+size_t evae_dense_fwd_workspace_bytes(int M, int K, int N, int gated);
 int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, int K, int ldx,
                          const float* wh, const float* bh, const float* wg, const float* bg, int N,
-                         float* out, float* save_h, float* save_s, evae_stream_t stream);
+                         float* out, float* save_h, float* save_s,
+                         void* ws, size_t ws_bytes, evae_stream_t stream);
 int evae_linear_fwd(const float* x, const int64_t* rows, int M, int K, int ldx,
                     const float* w, const float* b, int N, int act, float act_lo, float act_hi,
-                    float* y, float* pre, evae_stream_t stream);
+                    float* y, float* pre, void* ws, size_t ws_bytes, evae_stream_t stream);
+/* dy1/dy2: [M x N] with row stride ldy (so dh and dg may be the two halves of one [M x 2N] buffer);
+ * output(s) [M x K] with row stride ldo; h_prev/s_prev are dense [M x K]. */
+size_t evae_dense_bwd_data_workspace_bytes(int M, int N, int K, int npairs);
 int evae_dense_bwd_data(const float* dy1, const float* w1, const float* dy2, const float* w2,
-                        int M, int N, int K,
+                        int M, int N, int ldy, int K,
                         const float* h_prev, const float* s_prev,
-                        float* dx_or_dh, float* dg, evae_stream_t stream);
+                        float* dx_or_dh, float* dg, int ldo,
+                        void* ws, size_t ws_bytes, evae_stream_t stream);
+/* dw [N x K] = dy^T x with dy [M x N] (row stride ldy), x [* x K] (row stride ldx, optional row gather);
+ * db [N] = column sums of dy.  Passing the [M x 2N] buffer [dh | dg] yields [dWh ; dWg] in one launch. */
 size_t evae_dense_bwd_weight_workspace_bytes(int M, int N, int K);
-int evae_dense_bwd_weight(const float* dy, int M, int N, const float* x, const int64_t* rows, int K,
-                          int ldx, float* dw /* [N x K] */, float* db /* [N] or NULL */, int accumulate,
-                          void* ws, size_t ws_bytes, evae_stream_t stream);
-int evae_gated_dense_bwd_input(const float* dout, const float* h, const float* s, size_t n,
-                               float* dh, float* dg, evae_stream_t stream);
+int evae_dense_bwd_weight(const float* dy, int M, int N, int ldy, const float* x, const int64_t* rows,
+                          int K, int ldx, float* dw /* [N x K] */, float* db /* [N] or NULL */,
+                          int accumulate, void* ws, size_t ws_bytes, evae_stream_t stream);
+/* dh, dg: [M x N] with row stride ldo (the two halves of one [M x 2N] buffer when ldo = 2N) */
+int evae_gated_dense_bwd_input(const float* dout, const float* h, const float* s, int M, int N,
+                               float* dh, float* dg, int ldo, evae_stream_t stream);
 int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, int act, float act_lo, float act_hi,
                  float* dpre, evae_stream_t stream);
 
