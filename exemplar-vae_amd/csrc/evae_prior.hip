@@ -37,6 +37,7 @@ __device__ __forceinline__ float setup_sigma(float* __restrict__ inv_sigma, floa
 // ------------------------------------------------------------------------------------------------
 // forward: per (exemplar split, query tile) partial (max, sumexp, nmask)
 // ------------------------------------------------------------------------------------------------
+template <int KC>
 __global__ __launch_bounds__(NT) void prior_fwd_kernel(
     const float* __restrict__ z, int B, const float* __restrict__ centres, int C, int zdim,
     const float* __restrict__ log_var, const int64_t* __restrict__ z_idx,
@@ -45,8 +46,8 @@ __global__ __launch_bounds__(NT) void prior_fwd_kernel(
     float* __restrict__ out_prob) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;
-  float* Es = Qs + BQ * g.ks;
-  float* inv_sigma = Es + BE * g.ks;     // [<= 4*KC_MAX]
+  float* Es = Qs + BQ * Geom<KC>::ks;
+  float* inv_sigma = Es + BE * Geom<KC>::ks;     // [<= 4*KC_MAX]
   float* red = inv_sigma + 4 * KC_MAX;   // [16]
 
   const int split = blockIdx.x;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(NT) void prior_fwd_kernel(
   const int tq = threadIdx.x >> 4;
   const bool vec_ok = (zdim & 3) == 0 && (((uintptr_t)z | (uintptr_t)centres) & 15) == 0;
   const bool masked = (z_idx != nullptr) && (c_idx != nullptr);
-  const int zpad = g.nchunk * g.kc;
+  const int zpad = g.nchunk * KC;
 
   const float cst = setup_sigma(inv_sigma, red, log_var, zdim, zpad);
 
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(NT) void prior_fwd_kernel(
 #pragma unroll
   for (int i = 0; i < TQ; ++i) { dmin[i] = INFINITY; ssum[i] = 0.f; nmask[i] = 0.f; }
 
-  if (g.nchunk == 1) stage_rows(Qs, z, q0, B, BQ, zdim, 0, g.kc, g.ks, inv_sigma, vec_ok);
+  if (g.nchunk == 1) stage_rows<KC>(Qs, z, q0, B, BQ, zdim, 0, inv_sigma, vec_ok);
 
   const int tile_begin = split * tiles_per_split;
   const int ntiles = (C + BE - 1) / BE;
@@ -90,10 +91,10 @@ __global__ __launch_bounds__(NT) void prior_fwd_kernel(
     for (int ch = 0; ch < g.nchunk; ++ch) {
       __syncthreads();  // previous readers of Es (and Qs when re-staged) are done
       if (g.nchunk > 1)
-        stage_rows(Qs, z, q0, B, BQ, zdim, ch * g.kc, g.kc, g.ks, inv_sigma + ch * g.kc, vec_ok);
-      stage_rows(Es, centres, e0, C, BE, zdim, ch * g.kc, g.kc, g.ks, inv_sigma + ch * g.kc, vec_ok);
+        stage_rows<KC>(Qs, z, q0, B, BQ, zdim, ch * KC, inv_sigma + ch * KC, vec_ok);
+      stage_rows<KC>(Es, centres, e0, C, BE, zdim, ch * KC, inv_sigma + ch * KC, vec_ok);
       __syncthreads();
-      dist_chunk(acc, Qs, Es, tq, te, g.kc, g.ks);
+      dist_chunk<KC>(acc, Qs, Es, tq, te);
     }
 
     int64_t ci[TE];
@@ -203,24 +204,26 @@ __global__ void prior_fill_empty_kernel(float* m, float* s, float* n, int B) {
 // then  dC[e][k] += sum_i gw (zs_ik - cs_ek)   (thread <-> (e, k-group), direct differences)
 //       dV[k]    += sum_ie gw (zs_ik - cs_ek)^2
 //       dZ[i][k] += sum_e gw (cs_ek - zs_ik)   (thread <-> (i, k-group), registers across tiles)
-// all in sigma-scaled coordinates; the finishing kernel applies 1/sigma and reduces the splits.
+// all in sigma-scaled coordinates; the finishing kernels apply 1/sigma and reduce the splits.
 constexpr int KG_C = NT / BE;  // 4 k-groups for the dC phase
 constexpr int KG_Z = NT / BQ;  // 2 k-groups for the dZ phase
 constexpr int GWS = BE + 1;    // gw row stride (conflict-free column reads)
-constexpr int KPT_C_MAX = KC_MAX / KG_C;  // 16
-constexpr int KPT_Z_MAX = KC_MAX / KG_Z;  // 32
 
+template <int KC>
 __global__ __launch_bounds__(NT) void prior_bwd_kernel(
     const float* __restrict__ z, int B, const float* __restrict__ centres, int C, int zdim,
     const float* __restrict__ log_var, const int64_t* __restrict__ z_idx,
     const int64_t* __restrict__ c_idx, const float* __restrict__ lse, const float* __restrict__ gout,
     int tiles_per_split, int nsplit, PriorGeom g, int use_atomic_dc,
     float* __restrict__ dz_part /* [nsplit][B][zdim] */, float* __restrict__ dc /* [C][zdim] */,
-    float* __restrict__ dlv_part /* [nsplit*nq][zdim+1] */) {
+    float* __restrict__ dlv_part /* [nq*nsplit][zdim+1] */) {
+  constexpr int ks = Geom<KC>::ks;
+  constexpr int KPC = KC / KG_C;   // dims per thread in the dC phase
+  constexpr int KPZ = KC / KG_Z;   // dims per thread in the dZ phase
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;
-  float* Es = Qs + BQ * g.ks;
-  float* inv_sigma = Es + BE * g.ks;
+  float* Es = Qs + BQ * ks;
+  float* inv_sigma = Es + BE * ks;
   float* red = inv_sigma + 4 * KC_MAX;
   float* GW = red + 64;  // [BQ][GWS]
 
@@ -230,8 +233,9 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
   const int tq = threadIdx.x >> 4;
   const bool vec_ok = (zdim & 3) == 0 && (((uintptr_t)z | (uintptr_t)centres) & 15) == 0;
   const bool masked = (z_idx != nullptr) && (c_idx != nullptr);
-  const int zpad = g.nchunk * g.kc;
+  const int zpad = g.nchunk * KC;
   const float cst = setup_sigma(inv_sigma, red, log_var, zdim, zpad);
+  const int nq_valid = (B - q0) < BQ ? (B - q0) : BQ;      // live query rows of this tile
 
   int64_t zi[TQ];
   float gi[TQ], li[TQ];
@@ -245,29 +249,26 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
   }
 
   // phase-2 roles
-  const int ce = threadIdx.x & (BE - 1);     // exemplar row for dC
-  const int ckg = threadIdx.x >> 6;          // 0..3
-  const int zi_row = threadIdx.x & (BQ - 1); // query row for dZ
-  const int zkg = threadIdx.x >> 7;          // 0..1
-  const int kpt_c = g.kc / KG_C;             // k per thread (dC); kc multiple of 4 -> integral
-  const int kpt_z = g.kc / KG_Z;
+  const int ce = threadIdx.x & (BE - 1);      // exemplar row for dC
+  const int ckg = threadIdx.x >> 6;           // 0..3 (one wave per k-group)
+  const int zi_row = threadIdx.x & (BQ - 1);  // query row for dZ
+  const int zkg = threadIdx.x >> 7;           // 0..1
 
-  float gwsum = 0.f;                          // sum of gw handled in the dC role (for dlogvar)
+  float gwsum = 0.f;                           // sum of gw seen in the dC role (for dlogvar)
   const int tile_begin = split * tiles_per_split;
   const int ntiles = (C + BE - 1) / BE;
   int tile_end = tile_begin + tiles_per_split;
   if (tile_end > ntiles) tile_end = ntiles;
 
-  if (g.nchunk == 1) stage_rows(Qs, z, q0, B, BQ, zdim, 0, g.kc, g.ks, inv_sigma, vec_ok);
+  if (g.nchunk == 1) stage_rows<KC>(Qs, z, q0, B, BQ, zdim, 0, inv_sigma, vec_ok);
 
   for (int ch2 = 0; ch2 < g.nchunk; ++ch2) {
-    // accumulators for output chunk ch2
-    float accZ[KPT_Z_MAX];
-    float accV[KPT_C_MAX];
+    float accZ[KPZ];
+    float accV[KPC];
 #pragma unroll
-    for (int k = 0; k < KPT_Z_MAX; ++k) accZ[k] = 0.f;
+    for (int k = 0; k < KPZ; ++k) accZ[k] = 0.f;
 #pragma unroll
-    for (int k = 0; k < KPT_C_MAX; ++k) accV[k] = 0.f;
+    for (int k = 0; k < KPC; ++k) accV[k] = 0.f;
 
     for (int t = tile_begin; t < tile_end; ++t) {
       const int e0 = t * BE;
@@ -276,15 +277,14 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
       for (int i = 0; i < TQ; ++i)
 #pragma unroll
         for (int j = 0; j < TE; ++j) acc[i][j] = 0.f;
-      // distances over all chunks; leave chunk ch2 staged last so phase 2 can use it
+      // distances over all chunks; chunk ch2 is staged last so phase 2 can use it
       for (int c = 0; c < g.nchunk; ++c) {
         int ch = (c == g.nchunk - 1) ? ch2 : (c < ch2 ? c : c + 1);
         __syncthreads();
-        if (g.nchunk > 1)
-          stage_rows(Qs, z, q0, B, BQ, zdim, ch * g.kc, g.kc, g.ks, inv_sigma + ch * g.kc, vec_ok);
-        stage_rows(Es, centres, e0, C, BE, zdim, ch * g.kc, g.kc, g.ks, inv_sigma + ch * g.kc, vec_ok);
+        if (g.nchunk > 1) stage_rows<KC>(Qs, z, q0, B, BQ, zdim, ch * KC, inv_sigma + ch * KC, vec_ok);
+        stage_rows<KC>(Es, centres, e0, C, BE, zdim, ch * KC, inv_sigma + ch * KC, vec_ok);
         __syncthreads();
-        dist_chunk(acc, Qs, Es, tq, te, g.kc, g.ks);
+        dist_chunk<KC>(acc, Qs, Es, tq, te);
       }
       // gw tile -> LDS
 #pragma unroll
@@ -295,108 +295,115 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < TQ; ++i) {
           bool ok = ev && !(masked && zi[i] == cj);
-          float w = ok ? gi[i] * expf(cst - 0.5f * acc[i][j] - li[i]) : 0.f;
+          float w = ok ? gi[i] * __expf(cst - 0.5f * acc[i][j] - li[i]) : 0.f;
           GW[(tq + 16 * i) * GWS + te + 16 * j] = w;
         }
       }
       __syncthreads();
-      // ---- dC / dV: thread <-> (exemplar ce, dims ckg*kpt_c ..)
+      // ---- dC / dV: thread <-> (exemplar ce, dims ckg*KPC ..)
       {
-        float cs[KPT_C_MAX], aC[KPT_C_MAX];
+        float cs[KPC], aC[KPC];
 #pragma unroll
-        for (int k = 0; k < KPT_C_MAX; ++k) {
-          cs[k] = (k < kpt_c) ? Es[ce * g.ks + ckg * kpt_c + k] : 0.f;
-          aC[k] = 0.f;
-        }
-        for (int i = 0; i < BQ; ++i) {
-          float w = GW[i * GWS + ce];
-          if (ch2 == 0 && ckg == 0) gwsum += w;
-          const float* qrow = Qs + i * g.ks + ckg * kpt_c;
+        for (int k = 0; k < KPC; ++k) { cs[k] = Es[ce * ks + ckg * KPC + k]; aC[k] = 0.f; }
+        float wsum = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < nq_valid; ++i) {
+          const float w = GW[i * GWS + ce];
+          wsum += w;
+          const float* qrow = Qs + i * ks + ckg * KPC;
 #pragma unroll
-          for (int k = 0; k < KPT_C_MAX; ++k) {
-            if (k < kpt_c) {
-              float d = qrow[k] - cs[k];
-              float tw = w * d;
-              aC[k] += tw;
-              accV[k] = fmaf(tw, d, accV[k]);
-            }
+          for (int k = 0; k < KPC; ++k) {
+            const float d = qrow[k] - cs[k];
+            const float tw = w * d;
+            aC[k] += tw;
+            accV[k] = fmaf(tw, d, accV[k]);
           }
         }
-        int e = e0 + ce;
+        if (ch2 == 0 && ckg == 0) gwsum += wsum;
+        const int e = e0 + ce;
         if (e < C) {
 #pragma unroll
-          for (int k = 0; k < KPT_C_MAX; ++k) {
-            int kk = ch2 * g.kc + ckg * kpt_c + k;
-            if (k < kpt_c && kk < zdim) {
-              float v = aC[k] * inv_sigma[kk];
+          for (int k = 0; k < KPC; ++k) {
+            const int kk = ch2 * KC + ckg * KPC + k;
+            if (kk < zdim) {
+              const float v = aC[k] * inv_sigma[kk];
               if (use_atomic_dc) atomicAdd(&dc[(size_t)e * zdim + kk], v);
               else dc[(size_t)e * zdim + kk] = v;
             }
           }
         }
       }
-      // ---- dZ: thread <-> (query zi_row, dims zkg*kpt_z ..)
-      {
-        float zs[KPT_Z_MAX];
+      // ---- dZ: thread <-> (query zi_row, dims zkg*KPZ ..)
+      if (zi_row < nq_valid) {
+        float zs[KPZ];
 #pragma unroll
-        for (int k = 0; k < KPT_Z_MAX; ++k)
-          zs[k] = (k < kpt_z) ? Qs[zi_row * g.ks + zkg * kpt_z + k] : 0.f;
+        for (int k = 0; k < KPZ; ++k) zs[k] = Qs[zi_row * ks + zkg * KPZ + k];
+#pragma unroll 4
         for (int e = 0; e < BE; ++e) {
-          float w = GW[zi_row * GWS + e];
-          const float* erow = Es + e * g.ks + zkg * kpt_z;
+          const float w = GW[zi_row * GWS + e];
+          const float* erow = Es + e * ks + zkg * KPZ;
 #pragma unroll
-          for (int k = 0; k < KPT_Z_MAX; ++k)
-            if (k < kpt_z) accZ[k] = fmaf(w, erow[k] - zs[k], accZ[k]);
+          for (int k = 0; k < KPZ; ++k) accZ[k] = fmaf(w, erow[k] - zs[k], accZ[k]);
         }
       }
     }
     // flush chunk ch2
     {
-      int q = q0 + zi_row;
+      const int q = q0 + zi_row;
       if (q < B) {
 #pragma unroll
-        for (int k = 0; k < KPT_Z_MAX; ++k) {
-          int kk = ch2 * g.kc + zkg * kpt_z + k;
-          if (k < kpt_z && kk < zdim) dz_part[((size_t)split * B + q) * zdim + kk] = accZ[k];
+        for (int k = 0; k < KPZ; ++k) {
+          const int kk = ch2 * KC + zkg * KPZ + k;
+          if (kk < zdim) dz_part[((size_t)split * B + q) * zdim + kk] = accZ[k];
         }
       }
       // reduce accV over the 64 exemplar lanes of this wave (wave == k-group ckg)
       float* dlv = dlv_part + (size_t)(blockIdx.y * nsplit + split) * (zdim + 1);
 #pragma unroll
-      for (int k = 0; k < KPT_C_MAX; ++k) {
-        float v = wave_sum(accV[k]);
-        int kk = ch2 * g.kc + ckg * kpt_c + k;
-        if ((threadIdx.x & 63) == 0 && k < kpt_c && kk < zdim) dlv[kk] = v;
+      for (int k = 0; k < KPC; ++k) {
+        const float v = wave_sum(accV[k]);
+        const int kk = ch2 * KC + ckg * KPC + k;
+        if ((threadIdx.x & 63) == 0 && kk < zdim) dlv[kk] = v;
       }
       if (ch2 == 0) {
-        float sg = wave_sum(gwsum);
+        const float sg = wave_sum(gwsum);
         if (threadIdx.x == 0) dlv[zdim] = sg;
       }
     }
   }
 }
 
-// dz[i][k] = inv_sigma_k * sum_split dz_part ; dlogvar[k] = 0.5 * sum_blocks dV[k] - 0.5 * sum_blocks gwsum
-__global__ void prior_bwd_finish_kernel(const float* __restrict__ dz_part, int nsplit, int B, int zdim,
-                                        const float* __restrict__ log_var,
-                                        const float* __restrict__ dlv_part, int nblocks,
-                                        float* __restrict__ dz, float* __restrict__ dlogvar) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  int n = B * zdim;
-  if (idx < n) {
-    int k = idx % zdim;
-    float s = 0.f;
-    for (int r = 0; r < nsplit; ++r) s += dz_part[(size_t)r * n + idx];
-    dz[idx] = s * expf(-0.5f * log_var[k]);
+// dz[e] = inv_sigma_k * sum_split dz_part[split][e]: 64 outputs x 4 split-lanes per block
+__global__ __launch_bounds__(256) void prior_bwd_finish_dz_kernel(const float* __restrict__ dz_part, int nsplit,
+                                                                  int n, int zdim,
+                                                                  const float* __restrict__ log_var,
+                                                                  float* __restrict__ dz) {
+  __shared__ float red[4][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  float s = 0.f;
+  if (e < n)
+    for (int r = part; r < nsplit; r += 4) s += dz_part[(size_t)r * n + e];
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && e < n) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    dz[e] = t * expf(-0.5f * log_var[e % zdim]);
   }
-  if (idx < zdim) {
-    float sv = 0.f, sg = 0.f;
-    for (int b = 0; b < nblocks; ++b) {
-      sv += dlv_part[(size_t)b * (zdim + 1) + idx];
-      sg += dlv_part[(size_t)b * (zdim + 1) + zdim];
-    }
-    dlogvar[idx] = 0.5f * sv - 0.5f * sg;
+}
+
+// dlogvar[k] = 0.5 * sum_blocks dV[k] - 0.5 * sum_blocks gwsum: one wave per k
+__global__ __launch_bounds__(64) void prior_bwd_finish_dlv_kernel(const float* __restrict__ dlv_part, int nblocks,
+                                                                  int zdim, float* __restrict__ dlogvar) {
+  const int k = blockIdx.x, lane = threadIdx.x;
+  float sv = 0.f, sg = 0.f;
+  for (int b = lane; b < nblocks; b += 64) {
+    sv += dlv_part[(size_t)b * (zdim + 1) + k];
+    sg += dlv_part[(size_t)b * (zdim + 1) + zdim];
   }
+  sv = wave_sum(sv);
+  sg = wave_sum(sg);
+  if (lane == 0) dlogvar[k] = 0.5f * sv - 0.5f * sg;
 }
 
 __global__ void zero_kernel(float* p, size_t n) {
@@ -454,8 +461,8 @@ extern "C" int evae_prior_lse_fwd(const float* z, int B, const float* centres, i
   float* ps = pm + (size_t)ns * B;
   float* pn = ps + (size_t)ns * B;
   size_t lds = prior_lds_bytes(g, false);
-  prior_fwd_kernel<<<dim3(ns, nq), NT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, tps,
-                                                    ns, g, pm, ps, pn, out_prob);
+  EVAE_DISPATCH_KC(g.kc, (prior_fwd_kernel<KC_><<<dim3(ns, nq), NT, lds, stream>>>(
+                             z, B, centres, C, zdim, log_var, z_idx, c_idx, tps, ns, g, pm, ps, pn, out_prob)));
   int rc = check_launch("prior_fwd_kernel");
   if (rc) return rc;
   prior_merge_kernel<<<cdiv(B, NT / 64), NT, 0, stream>>>(pm, ps, pn, ns, B, 0, 0.f, out_max, out_sumexp,
@@ -516,13 +523,22 @@ extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, i
     if (rc) return rc;
   }
   size_t lds = prior_lds_bytes(g, true);
-  prior_bwd_kernel<<<dim3(ns, nq), NT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, lse,
-                                                    grad_out, tps, ns, g, use_atomic, dz_part, dcentres,
-                                                    dlv_part);
+  EVAE_DISPATCH_KC(g.kc, {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)prior_bwd_kernel<KC_>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+      attr = true;
+    }
+    prior_bwd_kernel<KC_><<<dim3(ns, nq), NT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, lse,
+                                                           grad_out, tps, ns, g, use_atomic, dz_part, dcentres,
+                                                           dlv_part);
+  });
   int rc = check_launch("prior_bwd_kernel");
   if (rc) return rc;
-  int n = B * zdim > zdim ? B * zdim : zdim;
-  prior_bwd_finish_kernel<<<cdiv(n, 256), 256, 0, stream>>>(dz_part, ns, B, zdim, log_var, dlv_part,
-                                                           ns * nq, dz, dlogvar);
-  return check_launch("prior_bwd_finish_kernel");
+  prior_bwd_finish_dz_kernel<<<cdiv(B * zdim, 64), 256, 0, stream>>>(dz_part, ns, B * zdim, zdim, log_var, dz);
+  rc = check_launch("prior_bwd_finish_dz_kernel");
+  if (rc) return rc;
+  prior_bwd_finish_dlv_kernel<<<zdim, 64, 0, stream>>>(dlv_part, ns * nq, zdim, dlogvar);
+  return check_launch("prior_bwd_finish_dlv_kernel");
 }

@@ -12,36 +12,43 @@ constexpr int NT = 256;
 constexpr int KC_MAX = 64;  // z-dims staged per chunk
 constexpr float kHalfLog2e = 0.5f * kLog2e;
 
+// Chunk geometry is a compile-time parameter (KC = z-dims staged per chunk, one of 16/32/40/64) so that
+// every inner loop is fully unrolled with static register indices and batched LDS reads.
+// LDS row stride KS = KC + pad with KS/4 odd: the 16 lanes of a ds_read_b128 group hit 16 different
+// rows and cover all 64 banks.
+template <int KC> struct Geom {
+  static constexpr int kc = KC;
+  static constexpr int ks = KC + ((((KC / 4) + 1) & 1) ? 4 : 8);
+};
+
 struct PriorGeom {
-  int kc;       // chunk width (multiple of 4, <= KC_MAX)
-  int ks;       // LDS row stride in floats, ks/4 odd
+  int kc;       // chunk width actually instantiated (16, 32, 40 or 64)
   int nchunk;   // ceil(zdim / kc)
 };
 
 static PriorGeom prior_geom(int zdim) {
   PriorGeom g;
-  int zp = (zdim + 3) & ~3;
-  g.kc = zp < KC_MAX ? zp : KC_MAX;
+  g.kc = zdim <= 16 ? 16 : zdim <= 32 ? 32 : zdim <= 40 ? 40 : 64;
   g.nchunk = (zdim + g.kc - 1) / g.kc;
-  int q = g.kc / 4;
-  g.ks = g.kc + (((q + 1) & 1) ? 4 : 8);
   return g;
 }
 
+static int geom_ks(int kc) { return kc == 16 ? Geom<16>::ks : kc == 32 ? Geom<32>::ks : kc == 40 ? Geom<40>::ks : Geom<64>::ks; }
+
 static size_t prior_lds_bytes(const PriorGeom& g, bool bwd) {
-  size_t fl = (size_t)(BQ + BE) * g.ks + 2 * KC_MAX * 4 /*inv_sigma, lv scratch*/ + 64;
+  size_t fl = (size_t)(BQ + BE) * geom_ks(g.kc) + 2 * KC_MAX * 4 /*inv_sigma*/ + 64;
   if (bwd) fl += (size_t)BQ * (BE + 1);
   return fl * sizeof(float);
 }
 
-// Stage `nrows` rows x `kc` dims (dims k0..k0+kc of rows r0..) of src[nrows_total x zdim] into LDS,
+// Stage tile_rows x KC dims (dims k0.. of rows r0..) of src[nrows_total x zdim] into LDS, optionally
 // multiplied by inv_sigma.  Rows >= nrows_total and dims >= zdim are zero-filled.
-template <bool SCALE = true>
+template <int KC, bool SCALE = true>
 __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src,
                                            int r0, int nrows_total, int tile_rows, int zdim, int k0,
-                                           int kc, int ks, const float* __restrict__ inv_sigma_lds,
-                                           bool vec_ok) {
-  const int kq = kc >> 2;
+                                           const float* __restrict__ inv_sigma_lds, bool vec_ok) {
+  constexpr int ks = Geom<KC>::ks;
+  constexpr int kq = KC >> 2;
   const int total = tile_rows * kq;
   for (int f = threadIdx.x; f < total; f += NT) {
     int row = f / kq;
@@ -69,10 +76,12 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
 }
 
 // acc[i][j] += sum_k (q_i[k] - e_j[k])^2 over one staged chunk
+template <int KC>
 __device__ __forceinline__ void dist_chunk(float (&acc)[TQ][TE], const float* __restrict__ Qs,
-                                           const float* __restrict__ Es, int tq, int te, int kc,
-                                           int ks) {
-  for (int k = 0; k < kc; k += 4) {
+                                           const float* __restrict__ Es, int tq, int te) {
+  constexpr int ks = Geom<KC>::ks;
+#pragma unroll 2
+  for (int k = 0; k < KC; k += 4) {
     float4 e4[TE];
 #pragma unroll
     for (int j = 0; j < TE; ++j)
@@ -94,5 +103,13 @@ __device__ __forceinline__ void dist_chunk(float (&acc)[TQ][TE], const float* __
   }
 }
 
+// dispatch a kernel template over the supported chunk widths
+#define EVAE_DISPATCH_KC(kc, ...)                                   \
+  do {                                                              \
+    if ((kc) == 16) { constexpr int KC_ = 16; __VA_ARGS__; }        \
+    else if ((kc) == 32) { constexpr int KC_ = 32; __VA_ARGS__; }   \
+    else if ((kc) == 40) { constexpr int KC_ = 40; __VA_ARGS__; }   \
+    else { constexpr int KC_ = 64; __VA_ARGS__; }                   \
+  } while (0)
 
 }  // namespace evae

@@ -56,10 +56,12 @@ __device__ __forceinline__ bool tk_offer(float& lv, int64_t& li, float v, int64_
   return changed;
 }
 
+template <int KC>
 __device__ __forceinline__ void dist_chunk_f64(double (&acc)[TQ][TE], const float* __restrict__ Qs,
-                                               const float* __restrict__ Es, int tq, int te, int kc,
-                                               int ks) {
-  for (int k = 0; k < kc; k += 4) {
+                                               const float* __restrict__ Es, int tq, int te) {
+  constexpr int ks = Geom<KC>::ks;
+#pragma unroll 2
+  for (int k = 0; k < KC; k += 4) {
     double ed[TE][4];
 #pragma unroll
     for (int j = 0; j < TE; ++j) {
@@ -85,23 +87,25 @@ __device__ __forceinline__ void dist_chunk_f64(double (&acc)[TQ][TE], const floa
 }
 
 static size_t topk_lds_bytes(const PriorGeom& g, int k) {
-  size_t fl = (size_t)(BQ + BE) * g.ks + (size_t)BQ * DS + (size_t)BQ * k;  // + list values
+  size_t fl = (size_t)(BQ + BE) * geom_ks(g.kc) + (size_t)BQ * DS + (size_t)BQ * k;  // + list values
   size_t bytes = fl * sizeof(float);
   bytes = align_up(bytes, 16) + (size_t)BQ * k * sizeof(int);
   return bytes;
 }
 
+template <int KC>
 __global__ __launch_bounds__(NT) void pairdist_topk_kernel(
     const float* __restrict__ q, int B, const float* __restrict__ cache, int N, int zdim, int k,
     unsigned flags, int tiles_per_split, PriorGeom g, float* __restrict__ cand_val,
     int64_t* __restrict__ cand_idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;
-  float* Es = Qs + BQ * g.ks;
-  float* D = Es + BE * g.ks;          // [BQ][DS]
+  constexpr int ks = Geom<KC>::ks;
+  float* Es = Qs + BQ * ks;
+  float* D = Es + BE * ks;            // [BQ][DS]
   float* Lv = D + BQ * DS;            // [BQ][k]
   int* Li = reinterpret_cast<int*>(   // shard-local exemplar index; INT_MAX = empty slot
-      reinterpret_cast<char*>(smem) + align_up(((size_t)(BQ + BE) * g.ks + (size_t)BQ * DS + (size_t)BQ * k) * 4, 16));
+      reinterpret_cast<char*>(smem) + align_up(((size_t)(BQ + BE) * ks + (size_t)BQ * DS + (size_t)BQ * k) * 4, 16));
 
   const int split = blockIdx.x;
   const int q0 = blockIdx.y * BQ;
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(NT) void pairdist_topk_kernel(
   const bool do_sqrt = (flags & EVAE_TOPK_SQRT) != 0;
 
   for (int i = threadIdx.x; i < BQ * k; i += NT) { Lv[i] = INFINITY; Li[i] = INT_MAX; }
-  if (g.nchunk == 1) stage_rows<false>(Qs, q, q0, B, BQ, zdim, 0, g.kc, g.ks, nullptr, vec_ok);
+  if (g.nchunk == 1) stage_rows<KC, false>(Qs, q, q0, B, BQ, zdim, 0, nullptr, vec_ok);
 
   const int ntiles = (N + BE - 1) / BE;
   const int tile_begin = split * tiles_per_split;
@@ -129,10 +133,10 @@ __global__ __launch_bounds__(NT) void pairdist_topk_kernel(
       for (int j = 0; j < TE; ++j) acc[i][j] = 0.0;
     for (int ch = 0; ch < g.nchunk; ++ch) {
       __syncthreads();
-      if (g.nchunk > 1) stage_rows<false>(Qs, q, q0, B, BQ, zdim, ch * g.kc, g.kc, g.ks, nullptr, vec_ok);
-      stage_rows<false>(Es, cache, e0, N, BE, zdim, ch * g.kc, g.kc, g.ks, nullptr, vec_ok);
+      if (g.nchunk > 1) stage_rows<KC, false>(Qs, q, q0, B, BQ, zdim, ch * KC, nullptr, vec_ok);
+      stage_rows<KC, false>(Es, cache, e0, N, BE, zdim, ch * KC, nullptr, vec_ok);
       __syncthreads();
-      dist_chunk_f64(acc, Qs, Es, tq, te, g.kc, g.ks);
+      dist_chunk_f64<KC>(acc, Qs, Es, tq, te);
     }
 #pragma unroll
     for (int i = 0; i < TQ; ++i)
@@ -171,12 +175,13 @@ __global__ __launch_bounds__(NT) void pairdist_topk_kernel(
 }
 
 // materialised [B x N] distance matrix (API completeness: utils/distributions.py:12-18); fp64 accumulate
+template <int KC>
 __global__ __launch_bounds__(NT) void pairdist_kernel(const float* __restrict__ q, int B,
                                                       const float* __restrict__ cache, int N, int zdim,
                                                       PriorGeom g, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;
-  float* Es = Qs + BQ * g.ks;
+  float* Es = Qs + BQ * Geom<KC>::ks;
   const int e0 = blockIdx.x * BE, q0 = blockIdx.y * BQ;
   const int te = threadIdx.x & 15, tq = threadIdx.x >> 4;
   const bool vec_ok = (zdim & 3) == 0 && (((uintptr_t)q | (uintptr_t)cache) & 15) == 0;
@@ -187,10 +192,10 @@ __global__ __launch_bounds__(NT) void pairdist_kernel(const float* __restrict__ 
     for (int j = 0; j < TE; ++j) acc[i][j] = 0.0;
   for (int ch = 0; ch < g.nchunk; ++ch) {
     __syncthreads();
-    stage_rows<false>(Qs, q, q0, B, BQ, zdim, ch * g.kc, g.kc, g.ks, nullptr, vec_ok);
-    stage_rows<false>(Es, cache, e0, N, BE, zdim, ch * g.kc, g.kc, g.ks, nullptr, vec_ok);
+    stage_rows<KC, false>(Qs, q, q0, B, BQ, zdim, ch * KC, nullptr, vec_ok);
+    stage_rows<KC, false>(Es, cache, e0, N, BE, zdim, ch * KC, nullptr, vec_ok);
     __syncthreads();
-    dist_chunk_f64(acc, Qs, Es, tq, te, g.kc, g.ks);
+    dist_chunk_f64<KC>(acc, Qs, Es, tq, te);
   }
 #pragma unroll
   for (int i = 0; i < TQ; ++i)
@@ -245,7 +250,6 @@ static void topk_splits(int B, int N, int* nsplit, int* tps, int* nq) {
   if (*nsplit < 1) *nsplit = 1;
 }
 
-static bool g_topk_attr_set = false;
 
 }  // namespace evae
 
@@ -282,12 +286,15 @@ extern "C" int evae_pairdist_topk(const float* q, int B, const float* cache, int
   float* cv = (float*)ws;
   int64_t* ci = (int64_t*)((char*)ws + align_up(n * sizeof(float), 256));
   size_t lds = topk_lds_bytes(g, k);
-  if (!g_topk_attr_set) {
-    (void)hipFuncSetAttribute((const void*)pairdist_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
-    g_topk_attr_set = true;
-  }
-  pairdist_topk_kernel<<<dim3(ns, nq), NT, lds, stream>>>(q, B, cache, N, zdim, k, flags, tps, g, cv, ci);
+  EVAE_DISPATCH_KC(g.kc, {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)pairdist_topk_kernel<KC_>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+      attr = true;
+    }
+    pairdist_topk_kernel<KC_><<<dim3(ns, nq), NT, lds, stream>>>(q, B, cache, N, zdim, k, flags, tps, g, cv, ci);
+  });
   int rc = check_launch("pairdist_topk_kernel");
   if (rc) return rc;
   topk_merge_kernel<<<cdiv(B, NT / 64), NT, 0, stream>>>(cv, ci, ns, B, k, index_base, out_idx, out_val);
@@ -310,7 +317,8 @@ extern "C" int evae_pairwise_distance(const float* q, int B, const float* cache,
   if (B == 0 || N == 0) return EVAE_OK;
   EVAE_REQUIRE(q && cache && out, "pairwise_distance: null pointer");
   PriorGeom g = prior_geom(zdim);
-  size_t lds = (size_t)(BQ + BE) * g.ks * sizeof(float);
-  pairdist_kernel<<<dim3(cdiv(N, BE), cdiv(B, BQ)), NT, lds, (hipStream_t)stream_>>>(q, B, cache, N, zdim, g, out);
+  size_t lds = (size_t)(BQ + BE) * geom_ks(g.kc) * sizeof(float);
+  EVAE_DISPATCH_KC(g.kc, (pairdist_kernel<KC_><<<dim3(cdiv(N, BE), cdiv(B, BQ)), NT, lds, (hipStream_t)stream_>>>(
+                             q, B, cache, N, zdim, g, out)));
   return check_launch("pairdist_kernel");
 }

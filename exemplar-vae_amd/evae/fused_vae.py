@@ -1,0 +1,225 @@
+"""One-node autograd implementation of the `vae` exact-prior training loss (the body of
+models/BaseModel.py:65-77 + AbsModel.py:13-19,44-49 + BaseModel.py:243-248 in the reference).
+
+Same arithmetic as the modular path (utils.nn.GatedDense, evae.ops.PriorLogP, ...), arranged for the
+hardware:
+
+* the B batch rows ride along the C exemplar rows through the encoder: the binarised batch is copied
+  into staging rows behind the HBM-resident dataset and ONE row-gathered GEMM per encoder layer
+  serves all C + B rows (forward, data gradient and weight gradient), so the replicated 100-row batch
+  path costs three thin decoder layers instead of a second pass over every encoder layer;
+* every GatedDense backward uses the merged [dh | dg] buffer (one weight-gradient GEMM per layer) and
+  the gate derivative of the layer below is applied in the epilogue of the data-gradient GEMM;
+* one autograd node instead of ~25: ~50 kernel launches per step and no per-op autograd bookkeeping.
+
+With torch.distributed active and shard=True the exemplar rows are this rank's shard: the per-row
+partials (max, sumexp, nmask) are all-gathered and merged, dz / dlogvar are sum-all-reduced and
+dcentres is scaled by the world size (see evae/shard.py for why)."""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _lib, ops, shard
+
+ACT_NONE, ACT_SIGMOID, ACT_HARDTANH = ops.ACT_NONE, ops.ACT_SIGMOID, ops.ACT_HARDTANH
+
+PARAM_ORDER = [
+    "prior_log_variance",
+    "p_x_mean.linear.weight", "p_x_mean.linear.bias",
+    "q_z_layers.0.h.weight", "q_z_layers.0.h.bias", "q_z_layers.0.g.weight", "q_z_layers.0.g.bias",
+    "q_z_layers.1.h.weight", "q_z_layers.1.h.bias", "q_z_layers.1.g.weight", "q_z_layers.1.g.bias",
+    "q_z_mean.weight", "q_z_mean.bias",
+    "q_z_logvar.linear.weight", "q_z_logvar.linear.bias",
+    "p_x_layers.0.h.weight", "p_x_layers.0.h.bias", "p_x_layers.0.g.weight", "p_x_layers.0.g.bias",
+    "p_x_layers.1.h.weight", "p_x_layers.1.h.bias", "p_x_layers.1.g.weight", "p_x_layers.1.g.bias",
+]
+
+
+def _vp(v):
+    if v is None:
+        return None
+    return C.c_void_p(v if isinstance(v, int) else v.data_ptr())
+
+
+class _K:
+    """Thin raw launchers over the C ABI (no autograd, caller-owned outputs)."""
+
+    def __init__(self, device):
+        self.lib = _lib.load()
+        self.dev = device
+        self.st = ops._stream()
+
+    def ws(self, name, nbytes):
+        return ops._workspace(name, nbytes, self.dev)
+
+    def gated_fwd(self, x, rows, M, K, ldx, wh, bh, wg, bg, N, out, h, s):
+        nb = self.lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
+        w = self.ws("fwd", nb)
+        _lib.check(self.lib.evae_gated_dense_fwd(_vp(x), _vp(rows), M, K, ldx, _vp(wh), _vp(bh), _vp(wg), _vp(bg), N,
+                                                 _vp(out), _vp(h), _vp(s), _vp(w), w.numel(), self.st), "gated_fwd")
+
+    def linear_fwd(self, x, M, K, ldx, w_, b, N, act, lo, hi, y, pre):
+        nb = self.lib.evae_dense_fwd_workspace_bytes(M, K, N, 0)
+        w = self.ws("fwd", nb)
+        _lib.check(self.lib.evae_linear_fwd(_vp(x), None, M, K, ldx, _vp(w_), _vp(b), N, act, lo, hi, _vp(y), _vp(pre),
+                                            _vp(w), w.numel(), self.st), "linear_fwd")
+
+    def bwd_data(self, dy1, w1, dy2, w2, M, N, ldy, K, h_prev, s_prev, out, dg, ldo):
+        nb = self.lib.evae_dense_bwd_data_workspace_bytes(M, N, K, 2 if dy2 is not None else 1)
+        w = self.ws("dgrad", nb)
+        _lib.check(self.lib.evae_dense_bwd_data(_vp(dy1), _vp(w1), _vp(dy2), _vp(w2), M, N, ldy, K, _vp(h_prev),
+                                                _vp(s_prev), _vp(out), _vp(dg), ldo, _vp(w), w.numel(), self.st),
+                   "bwd_data")
+
+    def bwd_weight(self, dy, M, N, ldy, x, rows, K, ldx, dw, db):
+        nb = self.lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
+        w = self.ws("wgrad", nb)
+        _lib.check(self.lib.evae_dense_bwd_weight(_vp(dy), M, N, ldy, _vp(x), _vp(rows), K, ldx, _vp(dw), _vp(db), 0,
+                                                  _vp(w), w.numel(), self.st), "bwd_weight")
+
+
+class VaeExactLoss(torch.autograd.Function):
+    """forward(x [B x D] binarised batch, x_idx [B], data_ext [(N + pad) x D] resident dataset with staging
+    rows, n_data, ex_idx_local [Cl] int64 (device), c_total, eps [B x z], beta, sharded, *params (PARAM_ORDER))
+    -> (loss [B], RE [B], KL [B])."""
+
+    @staticmethod
+    def forward(ctx, x, x_idx, data_ext, n_data, ex_idx, c_total, eps, beta, sharded, no_mask, *params):
+        (plv, wp, bp, w1h, b1h, w1g, b1g, w2h, b2h, w2g, b2g, wm, bm, wl, bl,
+         d1h, e1h, d1g, e1g, d2h, e2h, d2g, e2g) = params
+        dev = x.device
+        k = _K(dev)
+        lib = k.lib
+        B, D = x.shape
+        Cl = ex_idx.numel()
+        Mp = Cl + B
+        H = w1h.shape[0]
+        Z = wm.shape[0]
+        f32 = dict(device=dev, dtype=torch.float32)
+        x = x.contiguous()
+        # stage the batch behind the dataset; one gather list for exemplars + batch
+        data_ext[n_data:n_data + B].copy_(x)
+        rows = torch.cat((ex_idx, torch.arange(n_data, n_data + B, device=dev)))
+        ldd = data_ext.stride(0)
+        # ---- encoder over C + B rows
+        A1 = torch.empty((Mp, H), **f32); h1 = torch.empty_like(A1); s1 = torch.empty_like(A1)
+        k.gated_fwd(data_ext, rows, Mp, D, ldd, w1h, b1h, w1g, b1g, H, A1, h1, s1)
+        A2 = torch.empty((Mp, H), **f32); h2 = torch.empty_like(A2); s2 = torch.empty_like(A2)
+        k.gated_fwd(A1, None, Mp, H, H, w2h, b2h, w2g, b2g, H, A2, h2, s2)
+        mean_all = torch.empty((Mp, Z), **f32)
+        k.linear_fwd(A2, Mp, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, mean_all, None)
+        centres = mean_all[:Cl]
+        z_mean = mean_all[Cl:]
+        A2b = A2[Cl:]
+        logvar = torch.empty((B, Z), **f32); lv_pre = torch.empty_like(logvar)
+        k.linear_fwd(A2b, B, H, H, wl, bl, Z, ACT_HARDTANH, -6.0, 2.0, logvar, lv_pre)
+        # ---- sample, decode, reconstruct
+        z = torch.empty((B, Z), **f32); logq = torch.empty(B, **f32)
+        _lib.check(lib.evae_reparam_logq_fwd(_vp(z_mean), _vp(logvar), _vp(eps), B, Z, _vp(z), _vp(logq), k.st), "reparam")
+        D1 = torch.empty((B, H), **f32); hd1 = torch.empty_like(D1); sd1 = torch.empty_like(D1)
+        k.gated_fwd(z, None, B, Z, Z, d1h, e1h, d1g, e1g, H, D1, hd1, sd1)
+        D2 = torch.empty((B, H), **f32); hd2 = torch.empty_like(D2); sd2 = torch.empty_like(D2)
+        k.gated_fwd(D1, None, B, H, H, d2h, e2h, d2g, e2g, H, D2, hd2, sd2)
+        xmean = torch.empty((B, D), **f32)
+        k.linear_fwd(D2, B, H, H, wp, bp, D, ACT_SIGMOID, 0.0, 0.0, xmean, None)
+        RE = torch.empty(B, **f32)
+        _lib.check(lib.evae_bernoulli_ll_fwd(_vp(x), _vp(xmean), B, D, _vp(RE), k.st), "bernoulli")
+        # ---- exemplar prior (leave-one-out mask in training unless no_mask)
+        lv_row = plv.detach().expand(Z).contiguous()
+        zi = None if no_mask else x_idx.reshape(-1)
+        ci = None if no_mask else ex_idx
+        m, s, n, _ = ops.prior_lse_fwd(z, centres, lv_row, zi, ci)
+        if sharded:
+            m, s, n = shard.gather_partials(m, s, n)
+        logp, lse = ops.prior_merge(m, s, n, c_total)
+        KL = logq - logp
+        loss = beta * KL - RE
+        ctx.k_dev = dev
+        ctx.dims = (B, D, H, Z, Cl, Mp, ldd, float(beta), bool(sharded))
+        ctx.bufs = (x, rows, data_ext, A1, h1, s1, A2, h2, s2, mean_all, logvar, lv_pre, z, D1, hd1, sd1, D2, hd2, sd2,
+                    xmean, lv_row, zi, ci, lse, eps)
+        ctx.save_for_backward(*params)
+        return loss, RE, KL
+
+    @staticmethod
+    def backward(ctx, dloss, dRE, dKL):
+        params = ctx.saved_tensors
+        (plv, wp, bp, w1h, b1h, w1g, b1g, w2h, b2h, w2g, b2g, wm, bm, wl, bl,
+         d1h, e1h, d1g, e1g, d2h, e2h, d2g, e2g) = params
+        (x, rows, data_ext, A1, h1, s1, A2, h2, s2, mean_all, logvar, lv_pre, z, D1, hd1, sd1, D2, hd2, sd2,
+         xmean, lv_row, zi, ci, lse, eps) = ctx.bufs
+        B, D, H, Z, Cl, Mp, ldd, beta, sharded = ctx.dims
+        dev = ctx.k_dev
+        k = _K(dev)
+        lib = k.lib
+        f32 = dict(device=dev, dtype=torch.float32)
+        zero = torch.zeros(B, **f32)
+        dloss = zero if dloss is None else dloss
+        cRE = (zero if dRE is None else dRE) - dloss                     # d/dRE_i
+        cKL = (zero if dKL is None else dKL) + beta * dloss              # d/dKL_i ; KL = logq - logp
+        cRE = cRE.contiguous(); cKL = cKL.contiguous()
+        # ---- reconstruction term through the decoder
+        dxm = torch.empty((B, D), **f32)
+        _lib.check(lib.evae_bernoulli_ll_bwd(_vp(x), _vp(xmean), _vp(cRE), B, D, _vp(dxm), k.st), "bernoulli_bwd")
+        dpx = torch.empty((B, D), **f32)
+        _lib.check(lib.evae_act_bwd(_vp(dxm), _vp(xmean), B * D, ACT_SIGMOID, 0.0, 0.0, _vp(dpx), k.st), "act_bwd")
+        g_wp = torch.empty_like(wp); g_bp = torch.empty_like(bp)
+        k.bwd_weight(dpx, B, D, D, D2, None, H, H, g_wp, g_bp)
+        dp2 = torch.empty((B, 2 * H), **f32)                              # [dh | dg] of decoder layer 2
+        k.bwd_data(dpx, wp, None, None, B, D, D, H, hd2, sd2, dp2, dp2.data_ptr() + 4 * H, 2 * H)
+        g_d2 = torch.empty((2 * H, H), **f32); g_e2 = torch.empty(2 * H, **f32)
+        k.bwd_weight(dp2, B, 2 * H, 2 * H, D1, None, H, H, g_d2, g_e2)
+        dp1 = torch.empty((B, 2 * H), **f32)
+        k.bwd_data(dp2, d2h, dp2.data_ptr() + 4 * H, d2g, B, H, 2 * H, H, hd1, sd1, dp1, dp1.data_ptr() + 4 * H, 2 * H)
+        g_d1 = torch.empty((2 * H, Z), **f32); g_e1 = torch.empty(2 * H, **f32)
+        k.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1)
+        dz = torch.empty((B, Z), **f32)
+        k.bwd_data(dp1, d1h, dp1.data_ptr() + 4 * H, d1g, B, H, 2 * H, Z, None, None, dz, None, Z)
+        # ---- prior term: d(-cKL * logp); dcentres lands directly in the head-gradient buffer
+        dmean_all = torch.empty((Mp, Z), **f32)
+        dzp = torch.empty((B, Z), **f32); dlv = torch.empty(Z, **f32)
+        gp = (-cKL).contiguous()
+        nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cl, Z)
+        w = k.ws("prior_bwd", nb)
+        centres = mean_all[:Cl]
+        _lib.check(lib.evae_prior_lse_bwd(_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp),
+                                          _vp(dzp), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), k.st), "prior_bwd")
+        if sharded:
+            packed = torch.cat((dzp.reshape(-1), dlv))
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+            dzp = packed[:B * Z].reshape(B, Z); dlv = packed[B * Z:]
+            if Cl > 0:
+                dmean_all[:Cl].mul_(float(dist.get_world_size()))
+        dz.add_(dzp)
+        # ---- reparameterisation + log q
+        dlogvar = torch.empty((B, Z), **f32)
+        z_mean = mean_all[Cl:]
+        _lib.check(lib.evae_reparam_logq_bwd(_vp(z_mean), _vp(logvar), _vp(eps), _vp(z), _vp(dz), _vp(cKL), B, Z,
+                                             _vp(dmean_all.data_ptr() + 4 * Cl * Z), _vp(dlogvar), k.st), "reparam_bwd")
+        dlvp = torch.empty((B, Z), **f32)
+        _lib.check(lib.evae_act_bwd(_vp(dlogvar), _vp(lv_pre), B * Z, ACT_HARDTANH, -6.0, 2.0, _vp(dlvp), k.st), "act_bwd")
+        # ---- heads
+        A2b_ptr = A2.data_ptr() + 4 * Cl * H
+        g_wl = torch.empty_like(wl); g_bl = torch.empty_like(bl)
+        k.bwd_weight(dlvp, B, Z, Z, A2b_ptr, None, H, H, g_wl, g_bl)
+        g_wm = torch.empty_like(wm); g_bm = torch.empty_like(bm)
+        k.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)
+        dq2 = torch.empty((Mp, 2 * H), **f32)                              # [dh2 | dg2] for all C + B rows
+        if Cl > 0:
+            k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, h2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H)
+        off = 4 * Cl
+        k.bwd_data(dmean_all.data_ptr() + off * Z, wm, dlvp, wl, B, Z, Z, H, h2.data_ptr() + off * H,
+                   s2.data_ptr() + off * H, dq2.data_ptr() + off * 2 * H, dq2.data_ptr() + off * 2 * H + 4 * H, 2 * H)
+        # ---- encoder layers over C + B rows
+        g_w2 = torch.empty((2 * H, H), **f32); g_b2 = torch.empty(2 * H, **f32)
+        k.bwd_weight(dq2, Mp, 2 * H, 2 * H, A1, None, H, H, g_w2, g_b2)
+        dq1 = torch.empty((Mp, 2 * H), **f32)
+        k.bwd_data(dq2, w2h, dq2.data_ptr() + 4 * H, w2g, Mp, H, 2 * H, H, h1, s1, dq1, dq1.data_ptr() + 4 * H, 2 * H)
+        g_w1 = torch.empty((2 * H, D), **f32); g_b1 = torch.empty(2 * H, **f32)
+        k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)
+        g_plv = dlv.sum().reshape(1)
+        ctx.bufs = None
+        grads = (g_plv, g_wp, g_bp, g_w1[:H], g_b1[:H], g_w1[H:], g_b1[H:], g_w2[:H], g_b2[:H], g_w2[H:], g_b2[H:],
+                 g_wm, g_bm, g_wl, g_bl, g_d1[:H], g_e1[:H], g_d1[H:], g_e1[H:], g_d2[:H], g_e2[:H], g_d2[H:], g_e2[H:])
+        return (None,) * 10 + grads

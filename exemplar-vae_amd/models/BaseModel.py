@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from evae import ops, shard
+from evae import fused_vae, ops, shard
 from utils.distributions import log_bernoulli, log_normal_diag, log_normal_standard, log_logistic_256
 from utils.nn import NonLinear, he_init, normal_init
 
@@ -71,8 +71,38 @@ class BaseModel(nn.Module, ABC):
             return log_logistic_256(x, x_mean, x_logvar, dim=1)
         raise Exception('Wrong input type!')
 
+    def _fused_path(self, x, x_indices, exemplars_embedding, dataset):
+        """The one-node implementation (evae/fused_vae.py) covers the headline configuration: MLP `vae`,
+        exemplar prior, exact (non-approximate) exemplar sets, binary inputs, training mode."""
+        a = self.args
+        return (getattr(self, '_use_fused', True) and a.model_name == 'vae' and a.prior == 'exemplar_prior'
+                and a.input_type == 'binary' and self.training and exemplars_embedding is None
+                and a.approximate_prior is False and a.no_attention is False
+                and not getattr(a, 'same_variational_var', False) and dataset is not None
+                and x_indices is not None and x.is_cuda and torch.is_grad_enabled())
+
+    def _calculate_loss_fused(self, x, x_indices, beta, dataset):
+        a = self.args
+        C = a.number_components
+        exemplars_indices = torch.randint(low=0, high=a.training_set_size, size=(C,))   # reference :245
+        sharded = self._sharded()
+        lo, hi = shard.bounds(C) if sharded else (0, C)
+        ex_local = exemplars_indices[lo:hi].to(x.device)
+        data_ext, n_data = self.resident_data_ext(dataset, x.shape[0])
+        x2 = x.reshape(x.shape[0], -1).float()
+        eps = self._draw_eps(torch.empty((x2.shape[0], a.z1_size), device=x.device))
+        named = dict(self.named_parameters())
+        params = [named[n] for n in fused_vae.PARAM_ORDER]
+        return fused_vae.VaeExactLoss.apply(x2, x_indices.reshape(-1), data_ext, n_data, ex_local, C, eps,
+                                            float(beta), sharded, bool(a.no_mask), *params)
+
     def calculate_loss(self, x, beta=1., average=False, exemplars_embedding=None, cache=None, dataset=None):
         x, x_indices = x
+        if self._fused_path(x, x_indices, exemplars_embedding, dataset):
+            loss, RE, KL = self._calculate_loss_fused(x, x_indices, beta, dataset)
+            if average:
+                loss, RE, KL = torch.mean(loss), torch.mean(RE), torch.mean(KL)
+            return loss, RE, KL
         x_mean, x_logvar, latent_stats = self.forward(x)
         x_flat = x.reshape(x.shape[0], -1) if x.dim() != 2 else x
         RE = self.reconstruction_loss(x_flat, x_mean, x_logvar)
@@ -243,16 +273,27 @@ class BaseModel(nn.Module, ABC):
             lvs.append(lv)
         return torch.cat(zs, dim=0), torch.cat(lvs, dim=0)
 
-    def resident_data(self, dataset):
-        """Device-resident fp32 copy of dataset.tensors[0] (uploaded once per dataset object)."""
+    STAGING_ROWS = 1024      # rows kept behind the resident dataset for the current batch (fused path)
+
+    def resident_data_ext(self, dataset, batch_rows=0):
+        """(buffer [(N + STAGING_ROWS) x D], N): device-resident fp32 copy of dataset.tensors[0], uploaded once
+        per dataset object, followed by staging rows the fused training path copies the batch into."""
         src = dataset.tensors[0]
-        if src.is_cuda:
-            return src
         key = id(dataset)
         hit = self._resident.get(key)
-        if hit is None or hit[0] is not src:
-            self._resident[key] = (src, src.to(self.args.device, dtype=torch.float32).contiguous())
-        return self._resident[key][1]
+        need = max(self.STAGING_ROWS, int(batch_rows))
+        if hit is None or hit[0] is not src or hit[1].shape[0] < src.shape[0] + need:
+            flat = src.reshape(src.shape[0], -1)
+            buf = torch.empty((flat.shape[0] + need, flat.shape[1]), device=self.args.device, dtype=torch.float32)
+            buf[:flat.shape[0]].copy_(flat)
+            buf[flat.shape[0]:].zero_()
+            self._resident[key] = (src, buf)
+        return self._resident[key][1], src.shape[0]
+
+    def resident_data(self, dataset):
+        """Device-resident fp32 view [N x D] of dataset.tensors[0]."""
+        buf, n = self.resident_data_ext(dataset)
+        return buf[:n]
 
     # ------------------------------------------------------------------ exemplar sets
     def get_exemplar_set(self, z_mean, z_log_var, dataset, cache, x_indices):

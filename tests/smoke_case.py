@@ -39,7 +39,7 @@ def rel(np, a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def run(torch, np, orc, B=16, C=200, N=500, seed=61, beta=0.37, verbose=False, tol=1e-4):
+def run(torch, np, orc, B=16, C=200, N=500, seed=61, beta=0.37, verbose=False, tol=1e-4, fused=True):
     import golden_inputs as gi
     from utils.optimizer import AdamNormGrad
     args = vae_args(number_components=C, training_set_size=N)
@@ -47,6 +47,7 @@ def run(torch, np, orc, B=16, C=200, N=500, seed=61, beta=0.37, verbose=False, t
     data, bidx, x, eps, ex_idx = make_case(np, B, C, N, seed, gi)
     dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
     model._draw_eps = lambda like: torch.from_numpy(eps).to(like.device)
+    model._use_fused = fused
     orig_randint = torch.randint
     torch.randint = lambda low=0, high=None, size=None, **kw: torch.from_numpy(ex_idx)
     opt = AdamNormGrad(model.parameters(), lr=5e-4)

@@ -15,12 +15,14 @@ def rel(a, b):
     return smoke_case.rel(np, a, b)
 
 
-def test_vae_train_step_matches_oracle():
-    smoke_case.run(torch, np, orc, verbose=True)
+@pytest.mark.parametrize("fused", [True, False])
+def test_vae_train_step_matches_oracle(fused):
+    smoke_case.run(torch, np, orc, verbose=True, fused=fused)
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("tag,B,C,N,seed", [("small", 16, 200, 500, 61), ("c1", 100, 1000, 4000, 62)])
-def test_vae_calculate_loss_matches_reference_golden(golden, tag, B, C, N, seed):
+def test_vae_calculate_loss_matches_reference_golden(golden, tag, B, C, N, seed, fused):
     """ELBO / RE / KL per sample and gradient norms vs the REAL reference (1e-4 relative bar)."""
     g = golden("g7_vae_loss")
     args = smoke_case.vae_args(number_components=C, training_set_size=N)
@@ -28,6 +30,7 @@ def test_vae_calculate_loss_matches_reference_golden(golden, tag, B, C, N, seed)
     data, bidx, x, eps, ex_idx = smoke_case.make_case(np, B, C, N, seed, gi)
     dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
     model._draw_eps = lambda like: torch.from_numpy(eps).to(like.device)
+    model._use_fused = fused          # one-node fused path (evae/fused_vae.py) vs the modular autograd path
     orig = torch.randint
     torch.randint = lambda low=0, high=None, size=None, **kw: torch.from_numpy(ex_idx)
     try:
