@@ -24,13 +24,15 @@
 //   [600 x 784] weight gradient over 25 000 rows) still fill the 256 CUs.
 //   Workgroup ids are remapped so that each XCD owns a contiguous run of tiles (shared A row-panels
 //   stay in one L2).
+#include <stdlib.h>
+
 #include "evae_common.h"
 
 namespace evae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BK = 32, GNT = 256;
+constexpr int BM = 128, BK = 32;
 constexpr int KS = BK + 4;  // KC tile row stride (floats); 36/4 = 9 odd
 
 enum { EPI_LINEAR = 0, EPI_GATED = 1, EPI_GATE_BWD = 2, EPI_RAW = 3, EPI_RAW_GATED = 4 };
@@ -57,6 +59,7 @@ struct GemmArgs {
   int act;
   float lo, hi;
   int tiles_m, tiles_n;
+  int dbg;                 // ablation switches for tools/kernel_bench.py (EVAE_GEMM_DBG); 0 in production
 };
 
 // Out-of-range chunks are loaded from a clamped, always-mapped address and zeroed LATER, when the
@@ -76,7 +79,7 @@ __device__ __forceinline__ float4 ld4s(const float* p, int valid) {
 // ---- tile loader: ROWS x BK floats per K-slab, NV float4 per thread -------------------------------
 // KC: tile[row][k], f = tid + 256 i -> row = f >> 3, k = 4 (f & 7)
 // RC: tile[k][row], f -> k = f / (ROWS/4), row = 4 (f % (ROWS/4))
-template <int ROWS, bool KC>
+template <int ROWS, bool KC, int GNT>
 struct TileLoader {
   static constexpr int NV = ROWS * BK / 4 / GNT;
   static constexpr int RS = ROWS + 4;
@@ -148,23 +151,24 @@ struct TileLoader {
 };
 
 // one K-slab of MFMAs: wave tile 64 x (32 NT) at rows wr*64.., cols wc*32*NT..
-template <bool A_KC, bool B_KC, int NT, int BN_>
-__device__ __forceinline__ void mma_slab(f32x16 (&acc)[2][NT], const float* __restrict__ As,
+// (k-groups [KG0, KG1) of 8 within the slab, so that LDS stores / global loads can be placed between them)
+template <bool A_KC, bool B_KC, int MT, int NT, int BN_, int KG0, int KG1>
+__device__ __forceinline__ void mma_slab(f32x16 (&acc)[MT][NT], const float* __restrict__ As,
                                          const float* __restrict__ Bs, int wr, int wc, int lane) {
   constexpr int ARS = BM + 4, BRS = BN_ + 4;
   const int l31 = lane & 31;
   const int kh = (lane >> 5) * 4;
 #pragma unroll
-  for (int kg = 0; kg < BK; kg += 8) {
-    float a[2][4], b[NT][4];
+  for (int kg = KG0 * 8; kg < KG1 * 8; kg += 8) {
+    float a[MT][4], b[NT][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < MT; ++t) {
       if (A_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(As + (wr * 64 + t * 32 + l31) * KS + kg + kh);
+        const float4 v = *reinterpret_cast<const float4*>(As + (wr * 32 * MT + t * 32 + l31) * KS + kg + kh);
         a[t][0] = v.x; a[t][1] = v.y; a[t][2] = v.z; a[t][3] = v.w;
       } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[t][s] = As[(kg + kh + s) * ARS + wr * 64 + t * 32 + l31];
+        for (int s = 0; s < 4; ++s) a[t][s] = As[(kg + kh + s) * ARS + wr * 32 * MT + t * 32 + l31];
       }
     }
 #pragma unroll
@@ -180,7 +184,7 @@ __device__ __forceinline__ void mma_slab(f32x16 (&acc)[2][NT], const float* __re
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
@@ -197,9 +201,11 @@ constexpr int A_TILE_FLOATS = BM * KS;  // 4608 (>= 32 * 132 for the RC layout)
 constexpr int b_tile_floats(int bn) { return bn * KS; }  // >= 32 * (bn + 4)
 constexpr size_t gemm_lds_bytes(int bn) { return 2 * (size_t)(A_TILE_FLOATS + b_tile_floats(bn)) * sizeof(float); }
 
-template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_>
-__global__ __launch_bounds__(GNT, 2) void gemm_kernel(const GemmArgs g) {
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g) {
   constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
+  constexpr int GNT = 64 * NW;
+  constexpr int MT = 8 / NW;        // NW/2 wave rows x 2 wave columns; wave tile (32 MT) x (32 NT)
   constexpr int NT = BN_ / 64;
   static_assert(!GATED || BN_ == 128, "gated epilogue needs the h and g column tiles in one wave");
   constexpr int STAGE = A_TILE_FLOATS + b_tile_floats(BN_);
@@ -222,9 +228,9 @@ __global__ __launch_bounds__(GNT, 2) void gemm_kernel(const GemmArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -241,8 +247,8 @@ __global__ __launch_bounds__(GNT, 2) void gemm_kernel(const GemmArgs g) {
     if (e < s_end) s_end = e;
   }
 
-  typedef TileLoader<BM, A_KC> LA;
-  typedef TileLoader<BN_, B_KC> LB;
+  typedef TileLoader<BM, A_KC, GNT> LA;
+  typedef TileLoader<BN_, B_KC, GNT> LB;
   LA la[2];
   LB lb[2];
 #pragma unroll
@@ -295,27 +301,33 @@ __global__ __launch_bounds__(GNT, 2) void gemm_kernel(const GemmArgs g) {
     }
   };
 
+  // Pipeline: registers always hold the slab AFTER the one being multiplied.  Its global loads were
+  // issued a whole slab earlier; they are written to the idle LDS buffer after the first k-group of
+  // MFMAs and the loads of the slab after that are issued right behind, so VMEM latency, the LDS
+  // stores and their address arithmetic all sit in the shadow of the 64-cycle MFMAs.
   if (s_begin < s_end) {
     float4 ra[LA::NV], rb[LB::NV];
     unsigned ma, mb;
     load_slab(s_begin, ra, rb, ma, mb);
     la[0].store(As(0), ra, ma);
     lb[0].store(Bs(0), rb, mb);
+    if (s_begin + 1 < s_end) load_slab(s_begin + 1, ra, rb, ma, mb);
     __syncthreads();
+    const bool dbg_nobar = g.dbg & 1, dbg_nomem = g.dbg & 2;
     for (int s = s_begin; s < s_end; ++s) {
       const int cur = (s - s_begin) & 1;
-      const bool more = s + 1 < s_end;
-      if (more) load_slab(s + 1, ra, rb, ma, mb);
-      mma_slab<A_KC, B_KC, NT, BN_>(acc, As(cur), Bs(cur), wr, wc, lane);
-      if (more) {
+      mma_slab<A_KC, B_KC, MT, NT, BN_, 0, 1>(acc, As(cur), Bs(cur), wr, wc, lane);
+      if (s + 1 < s_end && !dbg_nomem) {
         la[0].store(As(cur ^ 1), ra, ma);
         lb[0].store(Bs(cur ^ 1), rb, mb);
       }
-      __syncthreads();
+      if (s + 2 < s_end && !dbg_nomem) load_slab(s + 2, ra, rb, ma, mb);
+      mma_slab<A_KC, B_KC, MT, NT, BN_, 1, 4>(acc, As(cur), Bs(cur), wr, wc, lane);
+      if (!dbg_nobar) __syncthreads();
     }
   }
 
-  // ---- epilogue.  acc[mt][nt][r] <-> row m0 + wr*64 + mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
+  // ---- epilogue.  acc[mt][nt][r] <-> row m0 + wr*32*MT + mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
   //                                    col (within the wave tile) nt*32 + (lane&31)
   const int l31 = lane & 31, lh = lane >> 5;
   if (GATED) {
@@ -324,10 +336,10 @@ __global__ __launch_bounds__(GNT, 2) void gemm_kernel(const GemmArgs g) {
       const float bh = (EPI == EPI_GATED && g.bias0) ? g.bias0[n] : 0.f;
       const float bg = (EPI == EPI_GATED && g.bias1) ? g.bias1[n] : 0.f;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (m < g.M) {
             if (EPI == EPI_GATED) {
               const float h = acc[mt][0][r] + bh;
@@ -352,10 +364,10 @@ __global__ __launch_bounds__(GNT, 2) void gemm_kernel(const GemmArgs g) {
       if (n >= g.N) continue;
       const float bias = (EPI == EPI_LINEAR && g.bias0) ? g.bias0[n] : 0.f;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (m >= g.M) continue;
           const size_t o = (size_t)m * g.ldo + n;
           const float v = acc[mt][nt][r];
@@ -528,12 +540,12 @@ static bool gemm_vec_ok(const GemmArgs& g) {
   return ok;
 }
 
-template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_>
-static int launch_gemm_v(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW>
+static int launch_gemm_w(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
   static bool attr = false;
   constexpr size_t lds = gemm_lds_bytes(BN_);
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KC, B_KC, EPI, VEC, BN_>,
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KC, B_KC, EPI, VEC, BN_, NW>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
@@ -541,8 +553,29 @@ static int launch_gemm_v(GemmArgs& g, int nz, hipStream_t stream, const char* wh
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, GATED ? 64 : BN_);
   dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
-  gemm_kernel<A_KC, B_KC, EPI, VEC, BN_><<<grid, GNT, lds, stream>>>(g);
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("EVAE_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    g.dbg = dbg;
+  }
+  gemm_kernel<A_KC, B_KC, EPI, VEC, BN_, NW><<<grid, 64 * NW, lds, stream>>>(g);
   return check_launch(what);
+}
+
+// waves per block: 8 (4 waves/SIMD at 2 blocks/CU, the default) or 4; EVAE_GEMM_NW=4 selects the latter
+static int gemm_nw() {
+  static int nw = 0;
+  if (nw == 0) {
+    const char* e = getenv("EVAE_GEMM_NW");
+    nw = (e && atoi(e) == 4) ? 4 : 8;
+  }
+  return nw;
+}
+
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_>
+static int launch_gemm_v(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
+  if (gemm_nw() == 4) return launch_gemm_w<A_KC, B_KC, EPI, VEC, BN_, 4>(g, nz, stream, what);
+  return launch_gemm_w<A_KC, B_KC, EPI, VEC, BN_, 8>(g, nz, stream, what);
 }
 
 template <bool A_KC, bool B_KC, int EPI>
