@@ -48,23 +48,24 @@ def bounds(n, rank=None, world_size=None):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def _all_gather_flat(t, group=None):
+    """One all-gather of a contiguous tensor -> [R x *t.shape] (flat 1-D buffers: accepted by RCCL and gloo)."""
+    R = dist.get_world_size(group)
+    out = torch.empty(R * t.numel(), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.reshape(-1), group=group)
+    return out.reshape((R,) + tuple(t.shape))
+
+
 def gather_partials(m, s, n, group=None):
     """All-gather the packed [3 x B] partials of every rank -> ([R x B], [R x B], [R x B])."""
     packed = torch.stack((m, s, n)).contiguous()
-    R = dist.get_world_size(group)
-    out = torch.empty((R,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed, group=group)
+    out = _all_gather_flat(packed, group)                     # [R x 3 x B]
     return out[:, 0].contiguous(), out[:, 1].contiguous(), out[:, 2].contiguous()
 
 
 def gather_topk(val, idx, group=None):
     """All-gather per-shard top-k candidates ([B x k] values and GLOBAL indices) -> [R x B x k] each."""
-    R = dist.get_world_size(group)
-    v = torch.empty((R,) + tuple(val.shape), dtype=val.dtype, device=val.device)
-    i = torch.empty((R,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device)
-    dist.all_gather_into_tensor(v, val.contiguous(), group=group)
-    dist.all_gather_into_tensor(i, idx.contiguous(), group=group)
-    return v, i
+    return _all_gather_flat(val.contiguous(), group), _all_gather_flat(idx.contiguous(), group)
 
 
 def sharded_topk(q, cache_local, k, index_base, sqrt=False, group=None):

@@ -1,0 +1,113 @@
+"""CPU-only checks of the host-side mirror of the reference interface: class / function names, constructor
+arguments, state_dict keys (so reference checkpoints load), the model-name mapping and the loop helpers."""
+import inspect
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+import evae_oracle as orc
+import smoke_case
+
+
+def args_for(model_name, **kw):
+    return smoke_case.vae_args(device="cpu", model_name=model_name, **kw)
+
+
+def test_vae_state_dict_names_and_shapes():
+    from models.VAE import VAE
+    m = VAE(args_for("vae"))
+    sd = m.state_dict()
+    assert list(sd.keys()) == orc.VAE_PARAM_NAMES
+    ref = orc.vae_init_params(np.random.RandomState(0))
+    for k, v in sd.items():
+        assert tuple(v.shape) == ref[k].shape, k
+
+
+@pytest.mark.parametrize("name,module,n_entries,n_params", [
+    ("hvae_2level", "models.HVAE_2level", 55, 2431025),
+    ("convhvae_2level", "models.convHVAE_2level", 99, 2210862)])
+def test_hierarchical_models_match_reference_parameter_counts(name, module, n_entries, n_params):
+    mod = __import__(module, fromlist=["VAE"])
+    m = mod.VAE(args_for(name))
+    assert len(m.state_dict()) == n_entries            # SURVEY.md section 8a, probed from the reference
+    assert sum(p.numel() for p in m.parameters()) == n_params
+    for key in ("q_z1_layers_x.0.h.weight", "p_z1_layers_z2.1.g.bias", "prior_log_variance"):
+        assert key in m.state_dict()
+
+
+def test_fully_conv_state_dict_entries():
+    from models.fully_conv import VAE
+    m = VAE(args_for("single_conv", input_size=[3, 64, 64], input_type="continuous", bottleneck=1, z1_size=256))
+    sd = m.state_dict()
+    assert len(sd) == 289 and sum(p.numel() for p in m.parameters()) == 1341087
+    assert any(k.endswith("weight_g") for k in sd) and any("normalization" in k for k in sd)
+
+
+def test_importing_model_mapping():
+    from utils.utils import importing_model
+    import models.VAE, models.HVAE_2level, models.convHVAE_2level, models.fully_conv
+    assert importing_model(Namespace(model_name="vae")) is models.VAE.VAE
+    assert importing_model(Namespace(model_name="hvae_2level")) is models.HVAE_2level.VAE
+    assert importing_model(Namespace(model_name="convhvae_2level")) is models.convHVAE_2level.VAE
+    assert importing_model(Namespace(model_name="single_conv")) is models.fully_conv.VAE
+    with pytest.raises(Exception):
+        importing_model(Namespace(model_name="nope"))
+
+
+def test_reference_signatures_are_kept():
+    from models.BaseModel import BaseModel
+    from utils import distributions, knn_on_latent, training, evaluation
+    from utils.nn import GatedDense, NonLinear, GatedConv2d, Conv2d
+    sig = lambda f: list(inspect.signature(f).parameters)
+    assert sig(BaseModel.calculate_loss) == ["self", "x", "beta", "average", "exemplars_embedding", "cache", "dataset"]
+    assert sig(BaseModel.log_p_z) == ["self", "z", "exemplars_embedding", "sum", "test"]
+    assert sig(BaseModel.log_p_z_exemplar) == ["self", "z", "z_indices", "exemplars_embedding", "test"]
+    assert sig(BaseModel.cache_z) == ["self", "dataset", "prior", "cuda"]
+    assert sig(BaseModel.get_exemplar_set) == ["self", "z_mean", "z_log_var", "dataset", "cache", "x_indices"]
+    assert sig(BaseModel.get_approximate_nearest_exemplars) == ["self", "z", "cache", "dataset"]
+    assert sig(BaseModel.q_z)[:3] == ["self", "x", "prior"]
+    assert sig(distributions.pairwise_distance) == ["z", "means"]
+    assert sig(distributions.log_normal_diag_vectorized) == ["x", "mean", "log_var"]
+    assert sig(knn_on_latent.find_nearest_neighbors) == ["z_val", "z_train", "z_train_log_var"]
+    assert sig(knn_on_latent.report_knn_on_latent) == ["train_loader", "val_loader", "test_loader", "model", "dir",
+                                                       "knn_dictionary", "args", "val"]
+    assert sig(training.train_one_epoch) == ["epoch", "args", "train_loader", "model", "optimizer"]
+    assert sig(evaluation.evaluate_loss) == ["args", "model", "loader", "dataset", "exemplars_embedding"]
+    assert sig(evaluation.calculate_likelihood) == ["args", "model", "loader", "S", "exemplars_embedding"]
+    assert sig(GatedDense.__init__) == ["self", "input_size", "output_size", "activation", "no_attention"]
+    assert sig(NonLinear.__init__) == ["self", "input_size", "output_size", "bias", "activation"]
+    assert sig(GatedConv2d.__init__)[:6] == ["self", "input_channels", "output_channels", "kernel_size", "stride", "padding"]
+    assert sig(Conv2d.__init__)[-1] == "bias"
+
+
+def test_set_beta_and_optimizer_state_layout():
+    from utils.training import set_beta
+    from utils.optimizer import AdamNormGrad
+    a = Namespace(warmup=100)
+    assert set_beta(a, 50) == 0.5 and set_beta(a, 500) == 1.0 and set_beta(Namespace(warmup=0), 3) == 1.0
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = AdamNormGrad([p], lr=5e-4)
+    assert opt.defaults["betas"] == (0.9, 0.999) and opt.defaults["eps"] == 1e-8 and opt.defaults["weight_decay"] == 0
+
+
+def test_he_initializer_statistics():
+    from models.VAE import VAE
+    torch.manual_seed(0)
+    m = VAE(args_for("vae"))
+    w = m.q_z_layers[0].h.weight
+    assert abs(w.std().item() - (2.0 / 784) ** 0.5) < 2e-3       # reference utils/nn.py:12-14
+
+
+def test_oracle_sharded_merge_is_associative():
+    """Merging shard partials in any grouping gives the single-shard log-prior (fp32 noise only)."""
+    import golden_inputs as gi
+    z, c = gi.clustered_latents(5, 32, 1000, 40)
+    zi, ci = gi.mask_indices(6, 32, 1000, 400)
+    lv = np.full(40, -1.1, np.float32)
+    full = orc.log_p_z(z, zi, c, lv[None], ci, test=False)
+    for cuts in ([0, 1000], [0, 1, 999, 1000], [0, 125, 250, 375, 500, 625, 750, 875, 1000], [0, 0, 1000, 1000]):
+        parts = [orc.prior_partials(z, zi, c[a:b], lv, ci[a:b], True) for a, b in zip(cuts[:-1], cuts[1:])]
+        merged = orc.prior_merge([p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts], 1000)
+        assert np.abs(merged - full).max() < 2e-5 * np.abs(full).max()
