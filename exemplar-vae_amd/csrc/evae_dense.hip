@@ -59,6 +59,7 @@ struct GemmArgs {
   int act;
   float lo, hi;
   int tiles_m, tiles_n;
+  int ones_col;            // RC B: virtual all-ones column index (bias gradient folded into the weight GEMM); -1 = none
   int dbg;                 // ablation switches for tools/kernel_bench.py (EVAE_GEMM_DBG); 0 in production
 };
 
@@ -109,17 +110,18 @@ struct TileLoader {
       if (VEC) {
         const bool ok = rowok[i] && (k + 4 <= kend);
         v[i] = ld4v(base[i] + (ok ? k0 : -4 * (f & 7)));   // invalid -> start of a mapped row
-        mask |= (ok ? 1u : 0u) << i;
+        mask |= (ok ? 1u : 0u) << (2 * i);
       } else {
         v[i] = ld4s(base[i] + k0, rowok[i] ? (kend - k) : 0);
-        mask |= 1u << i;
+        mask |= 1u << (2 * i);
       }
     }
     return mask;
   }
+  // mask: 2 bits per chunk -- 0 = zero fill, 1 = loaded data, 2 = the virtual ones column (1,0,0,0)
   template <bool VEC>
   __device__ __forceinline__ unsigned load_rc(float4 (&v)[NV], const float* src, int ld, int r0, int nrows,
-                                              int k0, int kend, const int64_t* kgather) const {
+                                              int k0, int kend, const int64_t* kgather, int ones_col) const {
     unsigned mask = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -131,10 +133,11 @@ struct TileLoader {
       if (VEC) {
         const bool ok = kok && (r + 4 <= nrows);
         v[i] = ld4v(src + gk * ld + (ok ? r : 0));
-        mask |= (ok ? 1u : 0u) << i;
+        mask |= (ok ? 1u : ((kok && r == ones_col) ? 2u : 0u)) << (2 * i);
       } else {
         v[i] = ld4s(src + gk * ld + r, kok ? (nrows - r) : 0);
-        mask |= 1u << i;
+        if (kok && ones_col >= r && ones_col < r + 4) (&v[i].x)[ones_col - r] = 1.0f;
+        mask |= 1u << (2 * i);
       }
     }
     return mask;
@@ -143,7 +146,8 @@ struct TileLoader {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int f = threadIdx.x + GNT * i;
-      const float4 w = ((mask >> i) & 1u) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const unsigned sel = (mask >> (2 * i)) & 3u;
+      const float4 w = sel == 1u ? v[i] : make_float4(sel == 2u ? 1.f : 0.f, 0.f, 0.f, 0.f);
       if (KC) *reinterpret_cast<float4*>(tile + (f >> 3) * KS + 4 * (f & 7)) = w;
       else    *reinterpret_cast<float4*>(tile + (f / RQ) * RS + 4 * (f % RQ)) = w;
     }
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
     const int k0 = (p == 0 ? s : s - nslab[0]) * BK;
     const int kend = g.Kc[p];
     if (A_KC) ma = la[p].template load_kc<VEC>(ra, k0, kend);
-    else ma = la[p].template load_rc<VEC>(ra, g.A[p], g.lda[p], m0, g.M, k0, kend, nullptr);
+    else ma = la[p].template load_rc<VEC>(ra, g.A[p], g.lda[p], m0, g.M, k0, kend, nullptr, -1);
     if (GATED) {
       mb = 0;
 #pragma unroll
@@ -288,16 +292,16 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
         if (VEC) {
           const bool ok = gb_ok[i] && (k + 4 <= kend);
           rb[i] = ld4v(gb_base[i] + (ok ? k0 : -4 * (f & 7)));
-          mb |= (ok ? 1u : 0u) << i;
+          mb |= (ok ? 1u : 0u) << (2 * i);
         } else {
           rb[i] = ld4s(gb_base[i] + k0, gb_ok[i] ? (kend - k) : 0);
-          mb |= 1u << i;
+          mb |= 1u << (2 * i);
         }
       }
     } else if (B_KC) {
       mb = lb[p].template load_kc<VEC>(rb, k0, kend);
     } else {
-      mb = lb[p].template load_rc<VEC>(rb, g.B[p], g.ldb[p], n0, g.N, k0, kend, g.b_krows);
+      mb = lb[p].template load_rc<VEC>(rb, g.B[p], g.ldb[p], n0, g.ones_col >= 0 ? g.ones_col : g.N, k0, kend, g.b_krows, g.ones_col);
     }
   };
 
@@ -403,6 +407,8 @@ struct FinishArgs {
   int act;
   float lo, hi;
   int accumulate;
+  int ones_col;            // EPI_RAW: column that carries the bias gradient (-1 = none)
+  float* out_db;
 };
 
 __global__ __launch_bounds__(256) void gemm_finish_kernel(const FinishArgs f) {
@@ -434,37 +440,14 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(const FinishArgs f) {
     const float h = f.e0[i], s = f.e1[i];
     f.out0[o] = v * s;
     f.out1[o] = v * h * s * (1.0f - s);
-  } else {  // EPI_RAW: plain sum (weight gradient), optional accumulate
-    f.out0[o] = (f.accumulate ? f.out0[o] : 0.f) + v;
+  } else {  // EPI_RAW: plain sum (weight gradient), optional accumulate; column ones_col is db
+    if (f.ones_col >= 0) {
+      if (n == f.ones_col) { if (f.out_db) f.out_db[m] = (f.accumulate ? f.out_db[m] : 0.f) + v; }
+      else { const size_t ow = (size_t)m * f.ones_col + n; f.out0[ow] = (f.accumulate ? f.out0[ow] : 0.f) + v; }
+    } else {
+      f.out0[o] = (f.accumulate ? f.out0[o] : 0.f) + v;
+    }
   }
-}
-
-// db[n] = sum_m dy[m][n]: 64 columns x 4 row-slices per block over 512-row bands, then a band reduce.
-constexpr int CS_ROWS = 512;
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dy, int M, int N,
-                                                             int ld, float* __restrict__ part) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rs = threadIdx.x >> 6;
-  const int mbeg = blockIdx.y * CS_ROWS;
-  int mend = mbeg + CS_ROWS;
-  if (mend > M) mend = M;
-  float s = 0.f;
-  if (c < N)
-    for (int m = mbeg + rs; m < mend; m += 4) s += dy[(size_t)m * ld + c];
-  red[rs][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (rs == 0 && c < N)
-    part[(size_t)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-
-__global__ void band_reduce_kernel(const float* __restrict__ part, int nb, int n, float* __restrict__ out,
-                                   int accumulate) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = accumulate ? out[i] : 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(size_t)b * n + i];
-  out[i] = s;
 }
 
 __global__ void gated_bwd_input_kernel(const float* __restrict__ dout, const float* __restrict__ h,
@@ -535,7 +518,7 @@ static bool gemm_vec_ok(const GemmArgs& g) {
     if (A_KC || B_KC) ok = ok && (g.Kc[p] % 4 == 0);
   }
   if (!A_KC) ok = ok && (g.M % 4 == 0);
-  if (!B_KC) ok = ok && (g.N % 4 == 0);
+  if (!B_KC) ok = ok && ((g.ones_col >= 0 ? g.ones_col : g.N) % 4 == 0);
   if (g.Bg) ok = ok && al16(g.Bg);
   return ok;
 }
@@ -629,6 +612,7 @@ extern "C" int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, 
   EVAE_REQUIRE(x && wh && wg && out, "gated_dense_fwd: null pointer");
   Plan pl = make_plan(M, N, cdiv(K, BK), true, false, 2);
   GemmArgs g = {};
+  g.ones_col = -1;
   g.A[0] = x; g.B[0] = wh; g.Bg = wg; g.lda[0] = ldx; g.ldb[0] = K; g.Kc[0] = K; g.npairs = 1;
   g.a_rows = rows; g.M = M; g.N = N; g.bias0 = bh; g.bias1 = bg;
   g.out0 = out; g.out1 = save_h; g.out2 = save_s; g.ldo = N;
@@ -641,6 +625,7 @@ extern "C" int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, 
   int rc = launch_gemm<true, true, EPI_RAW_GATED>(g, pl, stream, "gated_dense_fwd(split-K)");
   if (rc) return rc;
   FinishArgs f = {};
+  f.ones_col = -1;
   f.part = (const float*)ws; f.nz = pl.nz; f.M = M; f.N = N; f.ldo = N; f.epi = EPI_GATED;
   f.bias0 = bh; f.bias1 = bg; f.out0 = out; f.out1 = save_h; f.out2 = save_s;
   return launch_finish(f, stream);
@@ -657,6 +642,7 @@ extern "C" int evae_linear_fwd(const float* x, const int64_t* rows, int M, int K
   EVAE_REQUIRE(x && w && y, "linear_fwd: null pointer");
   Plan pl = make_plan(M, N, cdiv(K, BK), false, false, 1);
   GemmArgs g = {};
+  g.ones_col = -1;
   g.A[0] = x; g.B[0] = w; g.lda[0] = ldx; g.ldb[0] = K; g.Kc[0] = K; g.npairs = 1;
   g.a_rows = rows; g.M = M; g.N = N; g.bias0 = b; g.out0 = y; g.out1 = pre; g.ldo = N;
   g.act = act; g.lo = act_lo; g.hi = act_hi;
@@ -669,6 +655,7 @@ extern "C" int evae_linear_fwd(const float* x, const int64_t* rows, int M, int K
   int rc = launch_gemm<true, true, EPI_RAW>(g, pl, stream, "linear_fwd(split-K)");
   if (rc) return rc;
   FinishArgs f = {};
+  f.ones_col = -1;
   f.part = (const float*)ws; f.nz = pl.nz; f.M = M; f.N = N; f.ldo = N; f.epi = EPI_LINEAR;
   f.bias0 = b; f.out0 = y; f.out1 = pre; f.act = act; f.lo = act_lo; f.hi = act_hi;
   return launch_finish(f, stream);
@@ -696,6 +683,7 @@ extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const floa
   const int np = dy2 ? 2 : 1;
   Plan pl = make_plan(M, K, total_slabs(N, np > 1 ? N : 0), false, false, 1);
   GemmArgs g = {};
+  g.ones_col = -1;
   g.A[0] = dy1; g.B[0] = w1; g.lda[0] = ldy; g.ldb[0] = K; g.Kc[0] = N; g.npairs = np;
   if (dy2) { g.A[1] = dy2; g.B[1] = w2; g.lda[1] = ldy; g.ldb[1] = K; g.Kc[1] = N; }
   g.M = M; g.N = K; g.out0 = dx_or_dh; g.out1 = gate ? dg : nullptr; g.ldo = ldo; g.e0 = h_prev; g.e1 = s_prev;
@@ -711,6 +699,7 @@ extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const floa
   int rc = launch_gemm<true, false, EPI_RAW>(g, pl, stream, "dense_bwd_data(split-K)");
   if (rc) return rc;
   FinishArgs f = {};
+  f.ones_col = -1;
   f.part = (const float*)ws; f.nz = pl.nz; f.M = M; f.N = K; f.ldo = ldo;
   f.epi = gate ? EPI_GATE_BWD : EPI_LINEAR; f.out0 = dx_or_dh; f.out1 = gate ? dg : nullptr;
   f.e0 = h_prev; f.e1 = s_prev;
@@ -718,12 +707,12 @@ extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const floa
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------
+// The bias gradient db = column sums of dy is folded into the same GEMM: x gets a virtual all-ones
+// column K (never read from memory), so column K of dy^T [x | 1] is db.
 extern "C" size_t evae_dense_bwd_weight_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 256;
-  Plan pl = make_plan(N, K, cdiv(M, BK), false, true, 1);
-  size_t part = (size_t)pl.nz * N * K * sizeof(float);
-  size_t cs = (size_t)cdiv(M, CS_ROWS) * N * sizeof(float);
-  return align_up(part, 256) + align_up(cs, 256) + 256;
+  Plan pl = make_plan(N, K + 1, cdiv(M, BK), false, true, 1);
+  return align_up((size_t)pl.nz * N * (K + 1) * sizeof(float), 256) + 256;
 }
 
 extern "C" int evae_dense_bwd_weight(const float* dy, int M, int N, int ldy, const float* x,
@@ -744,24 +733,18 @@ extern "C" int evae_dense_bwd_weight(const float* dy, int M, int N, int ldy, con
     return check_launch("dense_bwd_weight(empty)");
   }
   EVAE_REQUIRE(dy && x, "dense_bwd_weight: null pointer");
-  Plan pl = make_plan(N, K, cdiv(M, BK), false, true, 1);
+  const int Kp = K + 1;
+  Plan pl = make_plan(N, Kp, cdiv(M, BK), false, true, 1);
   float* part = (float*)ws;
-  float* cs = (float*)((char*)ws + align_up((size_t)pl.nz * N * K * sizeof(float), 256));
   GemmArgs g = {};
   g.A[0] = dy; g.B[0] = x; g.lda[0] = ldy; g.ldb[0] = ldx; g.Kc[0] = M; g.npairs = 1;
-  g.b_krows = rows; g.M = N; g.N = K; g.out0 = part; g.ldo = K;
+  g.b_krows = rows; g.M = N; g.N = Kp; g.out0 = part; g.ldo = Kp; g.ones_col = K;
   int rc = launch_gemm<false, false, EPI_RAW>(g, pl, stream, "dense_bwd_weight");
   if (rc) return rc;
   FinishArgs f = {};
-  f.part = part; f.nz = pl.nz; f.M = N; f.N = K; f.ldo = K; f.epi = EPI_RAW; f.out0 = dw; f.accumulate = accumulate;
-  rc = launch_finish(f, stream);
-  if (rc || !db) return rc;
-  int nb = cdiv(M, CS_ROWS);
-  colsum_partial_kernel<<<dim3(cdiv(N, 64), nb), 256, 0, stream>>>(dy, M, N, ldy, cs);
-  rc = check_launch("colsum_partial");
-  if (rc) return rc;
-  band_reduce_kernel<<<cdiv(N, 256), 256, 0, stream>>>(cs, nb, N, db, accumulate);
-  return check_launch("band_reduce");
+  f.part = part; f.nz = pl.nz; f.M = N; f.N = Kp; f.ldo = Kp; f.epi = EPI_RAW; f.out0 = dw; f.accumulate = accumulate;
+  f.ones_col = K; f.out_db = db;
+  return launch_finish(f, stream);
 }
 
 extern "C" int evae_gated_dense_bwd_input(const float* dout, const float* h, const float* s, int M, int N,
