@@ -29,10 +29,12 @@ __global__ __launch_bounds__(256) void adam_sumsq_kernel(const evae_adam_tensor_
 }
 
 __global__ __launch_bounds__(256) void adam_step_kernel(const evae_adam_tensor_t* __restrict__ ts,
-                                                        const float* __restrict__ part, float step_size,
+                                                        const float* __restrict__ part, float step_size_host,
+                                                        const float* __restrict__ step_size_dev,
                                                         float beta1, float omb1, float beta2,
                                                         float omb2, float eps, float weight_decay) {
   const evae_adam_tensor_t t = ts[blockIdx.y];
+  const float step_size = step_size_dev ? step_size_dev[0] : step_size_host;
   double tot = 0.0;
   for (int i = 0; i < ANB; ++i) tot += (double)part[blockIdx.y * ANB + i];
   const float inv = 1.0f / ((float)sqrt(tot) + 1e-7f);
@@ -62,8 +64,8 @@ extern "C" size_t evae_adam_normgrad_workspace_bytes(int n_tensors) {
 
 extern "C" int evae_adam_normgrad_step(const evae_adam_tensor_t* tensors, int n_tensors,
                                        int64_t max_numel, int step, double lr, double beta1, double beta2,
-                                       double eps, double weight_decay, void* ws, size_t ws_bytes,
-                                       evae_stream_t stream_) {
+                                       double eps, double weight_decay, const float* step_size_dev,
+                                       void* ws, size_t ws_bytes, evae_stream_t stream_) {
   (void)max_numel;
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(n_tensors >= 0 && step >= 1, "adam_normgrad_step: bad arguments");
@@ -80,7 +82,7 @@ extern "C" int evae_adam_normgrad_step(const evae_adam_tensor_t* tensors, int n_
   adam_sumsq_kernel<<<dim3(ANB, n_tensors), 256, 0, stream>>>(tensors, part);
   int rc = check_launch("adam_sumsq");
   if (rc) return rc;
-  adam_step_kernel<<<dim3(ANB, n_tensors), 256, 0, stream>>>(tensors, part, step_size, (float)beta1, (float)(1.0 - beta1),
+  adam_step_kernel<<<dim3(ANB, n_tensors), 256, 0, stream>>>(tensors, part, step_size, step_size_dev, (float)beta1, (float)(1.0 - beta1),
                                                            (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay);
   return check_launch("adam_step");
 }

@@ -56,8 +56,15 @@ class _K:
     def gated_fwd(self, x, rows, M, K, ldx, wh, bh, wg, bg, N, out, h, s):
         nb = self.lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
         w = self.ws("fwd", nb)
+        probe = ops.PROBE
+        if probe is not None:
+            ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         _lib.check(self.lib.evae_gated_dense_fwd(_vp(x), _vp(rows), M, K, ldx, _vp(wh), _vp(bh), _vp(wg), _vp(bg), N,
                                                  _vp(out), _vp(h), _vp(s), _vp(w), w.numel(), self.st), "gated_fwd")
+        if probe is not None:
+            ev1.record()
+            probe["gated_dense_fwd"].append((ev0, ev1, 2.0 * M * K * 2 * N))
 
     def linear_fwd(self, x, M, K, ldx, w_, b, N, act, lo, hi, y, pre):
         nb = self.lib.evae_dense_fwd_workspace_bytes(M, K, N, 0)
@@ -136,7 +143,7 @@ class VaeExactLoss(torch.autograd.Function):
         KL = logq - logp
         loss = beta * KL - RE
         ctx.k_dev = dev
-        ctx.dims = (B, D, H, Z, Cl, Mp, ldd, float(beta), bool(sharded))
+        ctx.dims = (B, D, H, Z, Cl, Mp, ldd, beta, bool(sharded))
         ctx.bufs = (x, rows, data_ext, A1, h1, s1, A2, h2, s2, mean_all, logvar, lv_pre, z, D1, hd1, sd1, D2, hd2, sd2,
                     xmean, lv_row, zi, ci, lse, eps)
         ctx.save_for_backward(*params)

@@ -420,8 +420,13 @@ class BernoulliLL(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # AdamNormGrad
 # ------------------------------------------------------------------------------------------------
+def adam_step_size(step, lr, beta1, beta2):
+    """lr * sqrt(1 - beta2^t) / (1 - beta1^t)  (reference utils/optimizer.py:74-76)."""
+    return lr * (1.0 - beta2 ** step) ** 0.5 / (1.0 - beta1 ** step)
+
+
 def adam_normgrad_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps, weight_decay,
-                       table_cache=None):
+                       table_cache=None, step_size_dev=None):
     """One multi-tensor AdamNormGrad update (utils/optimizer.py:32-80).  `table_cache` (a dict) lets the
     caller reuse the device pointer table while the tensor addresses stay the same."""
     lib = _lib.load()
@@ -431,8 +436,17 @@ def adam_normgrad_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, be
     dev = params[0].device
     _need_cuda(*params)
     key = tuple(t.data_ptr() for ts in (params, grads, exp_avgs, exp_avg_sqs) for t in ts)
-    table = None if table_cache is None else table_cache.get("table")
-    if table is None or table_cache.get("key") != key:
+    if table_cache is None:
+        table_cache = {}
+    nbytes = C.sizeof(_lib.AdamTensor) * n
+    if "table" not in table_cache:
+        # device table + a pinned staging buffer, both allocated eagerly (allocation is illegal while a
+        # hipGraph is being captured; the copies below are not)
+        table_cache["table"] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        table_cache["pinned"] = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        table_cache["key"] = None
+    table = table_cache["table"]
+    if table_cache["key"] != key:
         arr = (_lib.AdamTensor * n)()
         for i in range(n):
             assert grads[i].is_contiguous() and params[i].is_contiguous()
@@ -440,11 +454,16 @@ def adam_normgrad_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, be
             arr[i].exp_avg = exp_avgs[i].data_ptr(); arr[i].exp_avg_sq = exp_avg_sqs[i].data_ptr()
             arr[i].numel = params[i].numel()
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        table = host.to(dev)
-        if table_cache is not None:
-            table_cache["table"] = table; table_cache["key"] = key
+        if torch.cuda.is_current_stream_capturing():
+            # becomes a memcpy node that re-reads the (persistent, from now on unchanged) pinned bytes
+            table_cache["pinned"].copy_(host)
+            table.copy_(table_cache["pinned"], non_blocking=True)
+        else:
+            table.copy_(host)          # pageable source: staged before the call returns, so it cannot race
+        table_cache["key"] = key
     nb = lib.evae_adam_normgrad_workspace_bytes(n)
     ws = _workspace("adam", nb, dev)
     _lib.check(lib.evae_adam_normgrad_step(_p(table), n, max(p.numel() for p in params), int(step), float(lr),
                                            float(beta1), float(beta2), float(eps), float(weight_decay),
-                                           _p(ws), ws.numel(), _stream()), "evae_adam_normgrad_step")
+                                           _p(step_size_dev), _p(ws), ws.numel(), _stream()),
+               "evae_adam_normgrad_step")

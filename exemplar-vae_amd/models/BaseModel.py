@@ -84,17 +84,22 @@ class BaseModel(nn.Module, ABC):
     def _calculate_loss_fused(self, x, x_indices, beta, dataset):
         a = self.args
         C = a.number_components
-        exemplars_indices = torch.randint(low=0, high=a.training_set_size, size=(C,))   # reference :245
         sharded = self._sharded()
         lo, hi = shard.bounds(C) if sharded else (0, C)
-        ex_local = exemplars_indices[lo:hi].to(x.device)
+        override = getattr(self, '_exemplar_indices_override', None)
+        if override is not None:          # graph-captured step: indices were drawn into a static device buffer
+            ex_local = override[lo:hi]
+        else:
+            exemplars_indices = torch.randint(low=0, high=a.training_set_size, size=(C,))   # reference :245
+            ex_local = exemplars_indices[lo:hi].to(x.device)
         data_ext, n_data = self.resident_data_ext(dataset, x.shape[0])
         x2 = x.reshape(x.shape[0], -1).float()
         eps = self._draw_eps(torch.empty((x2.shape[0], a.z1_size), device=x.device))
         named = dict(self.named_parameters())
         params = [named[n] for n in fused_vae.PARAM_ORDER]
+        beta = beta if torch.is_tensor(beta) else float(beta)
         return fused_vae.VaeExactLoss.apply(x2, x_indices.reshape(-1), data_ext, n_data, ex_local, C, eps,
-                                            float(beta), sharded, bool(a.no_mask), *params)
+                                            beta, sharded, bool(a.no_mask), *params)
 
     def calculate_loss(self, x, beta=1., average=False, exemplars_embedding=None, cache=None, dataset=None):
         x, x_indices = x

@@ -1,5 +1,12 @@
 """AdamNormGrad with the reference's constructor and state layout (reference utils/optimizer.py:7-80;
-state keys 'step', 'exp_avg', 'exp_avg_sq'), one fused multi-tensor HIP launch pair per step."""
+state keys 'step', 'exp_avg', 'exp_avg_sq'), one fused multi-tensor HIP launch pair per step.
+
+Two ways to run a step:
+  * eager (`step()`): the bias-corrected step size is computed on the host and passed by value;
+  * inside a captured hipGraph (`evae.graph.GraphedTrainStep`): kernel arguments are frozen at capture, so
+    the step size lives in a device scalar that `advance_graph_step()` updates before every replay.
+With torch.distributed active the gradients are averaged over ranks first (the per-tensor norm needs the
+reduced gradient)."""
 import torch
 from torch.optim import Optimizer
 
@@ -13,9 +20,39 @@ class AdamNormGrad(Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self._tables = {}
+        self._graph_step_size = None      # device scalars (one per param group) while graph-captured
+
+    def _init_state(self, p):
+        state = self.state[p]
+        if len(state) == 0:
+            state['step'] = 0
+            state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return state
+
+    # ---- graph mode ---------------------------------------------------------------------------------
+    def enable_graph_mode(self):
+        """Call before capturing a step: the captured launches read the step size from device memory."""
+        dev = self.param_groups[0]['params'][0].device
+        self._graph_step_size = [torch.zeros(1, device=dev) for _ in self.param_groups]
+
+    def advance_graph_step(self):
+        """Before each replay: bump the step counters (all parameters of a group share one count here) and
+        upload the bias-corrected step size."""
+        for gi, group in enumerate(self.param_groups):
+            step = None
+            for p in group['params']:
+                st = self._init_state(p)
+                st['step'] += 1
+                step = st['step']
+            if step is None:
+                continue
+            beta1, beta2 = group['betas']
+            # fill kernel (value travels as a kernel argument: no host buffer to race with later steps)
+            self._graph_step_size[gi].fill_(ops.adam_step_size(step, group['lr'], beta1, beta2))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, _captured=False):
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -29,18 +66,16 @@ class AdamNormGrad(Optimizer):
             for p in group['params']:
                 if p.grad is None:
                     continue
-                state = self.state[p]
-                if len(state) == 0:
-                    state['step'] = 0
-                    state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                state['step'] += 1
+                state = self._init_state(p)
+                if not _captured:
+                    state['step'] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                by_step.setdefault(state['step'], []).append((p, g, state))
+                by_step.setdefault(state['step'] if not _captured else 1, []).append((p, g, state))
             for step, items in by_step.items():
                 ops.adam_normgrad_step([p.data for p, _, _ in items], [g for _, g, _ in items],
                                        [s['exp_avg'] for _, _, s in items],
                                        [s['exp_avg_sq'] for _, _, s in items],
                                        step, group['lr'], beta1, beta2, group['eps'], group['weight_decay'],
-                                       table_cache=self._tables.setdefault((gi, len(items)), {}))
+                                       table_cache=self._tables.setdefault((gi, len(items), _captured), {}),
+                                       step_size_dev=self._graph_step_size[gi] if _captured else None)
         return loss

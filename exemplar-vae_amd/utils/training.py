@@ -5,6 +5,8 @@ epoch instead of three .item() syncs per step (training.py:42-44), and the exemp
 HBM (the model keeps a device-resident copy of dataset.tensors[0])."""
 import torch
 
+from evae.graph import GraphedTrainStep
+
 
 def set_beta(args, epoch):
     if args.warmup == 0:
@@ -22,7 +24,12 @@ def train_one_epoch(epoch, args, train_loader, model, optimizer):
     else:
         cache = None
     totals = None
+    graphed = _graphed_step(args, model, optimizer, train_loader)
     for data, indices, target in train_loader:
+        if graphed is not None and len(data) == graphed.B:
+            step_vals = graphed(data, indices, beta).clone()     # one hipGraph launch per step
+            totals = step_vals if totals is None else totals + step_vals
+            continue
         data, indices = data.to(args.device), indices.to(args.device)
         x = torch.bernoulli(data) if args.dynamic_binarization else data
         optimizer.zero_grad()
@@ -37,3 +44,22 @@ def train_one_epoch(epoch, args, train_loader, model, optimizer):
                 cache = (cache[0].detach(), cache[1].detach())
     train_loss, train_re, train_kl = (totals / len(train_loader)).tolist()
     return train_loss, train_re, train_kl
+
+
+def _graphed_step(args, model, optimizer, train_loader):
+    """The captured-step runner for this (model, optimizer, dataset), or None when the configuration is not
+    the graph-capturable one (fused `vae` exact-prior path on a GPU) or args.use_hip_graph is False."""
+    if not getattr(args, 'use_hip_graph', True) or not str(args.device).startswith('cuda'):
+        return None
+    a = model.args
+    ok = (a.model_name == 'vae' and a.prior == 'exemplar_prior' and a.input_type == 'binary'
+          and a.approximate_prior is False and a.no_attention is False
+          and not getattr(a, 'same_variational_var', False) and getattr(model, '_use_fused', True))
+    if not ok:
+        return None
+    key = (id(optimizer), id(train_loader.dataset), train_loader.batch_size)
+    cache = model.__dict__.setdefault('_graphed_steps', {})
+    if key not in cache:
+        cache[key] = GraphedTrainStep(model, optimizer, train_loader.dataset, train_loader.batch_size,
+                                      args.dynamic_binarization)
+    return cache[key]

@@ -188,6 +188,9 @@ int evae_bernoulli_ll_bwd(const float* x, const float* mean, const float* dout, 
  * AdamNormGrad (utils/optimizer.py:32-80): g <- g/(||g||_2 + 1e-7) per tensor, then Adam with eps
  * added after the sqrt and a bias-corrected step size.  One launch pair updates ALL tensors:
  * `ptrs` is a device array of n_tensors records {param, grad, exp_avg, exp_avg_sq, numel}.
+ * The bias-corrected step size lr*sqrt(1-b2^t)/(1-b1^t) is computed on the host from `step`, or -- when
+ * the step is replayed from a hipGraph, where kernel arguments are frozen -- read from the device scalar
+ * `step_size_dev`, which the caller updates before each replay.
  */
 typedef struct {
   float* param;
@@ -199,7 +202,8 @@ typedef struct {
 size_t evae_adam_normgrad_workspace_bytes(int n_tensors);
 int evae_adam_normgrad_step(const evae_adam_tensor_t* tensors /* device */, int n_tensors,
                             int64_t max_numel, int step, double lr, double beta1, double beta2, double eps,
-                            double weight_decay, void* ws, size_t ws_bytes, evae_stream_t stream);
+                            double weight_decay, const float* step_size_dev /* device scalar or NULL */,
+                            void* ws, size_t ws_bytes, evae_stream_t stream);
 
 #ifdef __cplusplus
 }

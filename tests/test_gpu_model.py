@@ -68,3 +68,39 @@ def test_no_cpu_fallback():
     from evae import ops, _lib
     with pytest.raises(_lib.EvaeError):
         ops.prior_lse_fwd(torch.zeros(2, 4), torch.zeros(3, 4), torch.zeros(4))
+
+
+def test_graphed_step_matches_eager():
+    """hipGraph replay of the whole step (evae/graph.py) == the same steps launched eagerly."""
+    from evae.graph import GraphedTrainStep
+    from utils.optimizer import AdamNormGrad
+    B, C, N = 32, 500, 2000
+    data = gi.binary_images(5, N)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    results = []
+    for use_graph in (False, True):
+        args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=B)
+        model, _ = smoke_case.build_model(torch, np, orc, args)
+        model.train()
+        opt = AdamNormGrad(model.parameters(), lr=5e-4)
+        torch.manual_seed(3); torch.cuda.manual_seed(3)
+        runner = GraphedTrainStep(model, opt, dataset, B, False) if use_graph else None
+        losses = []
+        for it in range(7):
+            xb = torch.from_numpy(data[it * B:(it + 1) * B]).cuda()
+            ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1).cuda()
+            if runner is not None:
+                losses.append(runner(xb, ib, 0.5)[0].item())
+            else:
+                opt.zero_grad()
+                loss, RE, KL = model.calculate_loss((xb, ib), 0.5, average=True, dataset=dataset)
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+        results.append((losses, {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}))
+        if runner is not None:
+            assert runner.graph is not None                       # steps 4.. were replays
+    (l0, p0), (l1, p1) = results
+    assert rel(np.asarray(l1), np.asarray(l0)) < 1e-5
+    for k in p0:
+        assert rel(p1[k], p0[k]) < 1e-5, k
