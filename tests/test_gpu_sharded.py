@@ -1,0 +1,79 @@
+"""Two ranks sharing one MI355X (gloo backend over CUDA tensors, since RCCL refuses duplicate devices):
+the sharded exemplar prior (evae/shard.py + evae/fused_vae.py, shard_exemplars=True) must reproduce the
+single-process training trajectory: same losses, same parameters after several AdamNormGrad steps."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B, C, N, STEPS = 32, 501, 2000, 4          # odd C: shards of 251 / 250
+
+
+def _run(rank, world, port, q, fused):
+    for p in (os.path.join(ROOT, "exemplar-vae_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import evae_oracle as orc
+    import golden_inputs as gi
+    import smoke_case
+    from utils.optimizer import AdamNormGrad
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        data = gi.binary_images(5, N)
+        dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+        args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=B, shard_exemplars=world > 1)
+        model, _ = smoke_case.build_model(torch, np, orc, args)
+        model._use_fused = fused
+        model.train()
+        opt = AdamNormGrad(model.parameters(), lr=5e-4)
+        torch.manual_seed(11); torch.cuda.manual_seed(11)        # identical eps / exemplar draws on every rank
+        losses = []
+        for it in range(STEPS):
+            xb = torch.from_numpy(data[it * B:(it + 1) * B]).cuda()
+            ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1).cuda()
+            opt.zero_grad()
+            loss, RE, KL = model.calculate_loss((xb, ib), 0.7, average=True, dataset=dataset)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        out = {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}
+        q.put((rank, losses, out))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def _spawn(world, fused):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000) + (7 if fused else 0)
+    procs = [ctx.Process(target=_run, args=(r, world, port, q, fused)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_two_rank_sharded_training_matches_single(fused):
+    single = _spawn(1, fused)[0]
+    double = _spawn(2, fused)
+
+    def rel(a, b):
+        a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+        return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    for rank, losses, params in double:
+        assert rel(losses, single[1]) < 1e-5, (rank, losses, single[1])
+        for k in params:
+            assert rel(params[k], single[2][k]) < 2e-5, (rank, k)
