@@ -114,6 +114,49 @@ __global__ void bernoulli_ll_bwd_kernel(const float* __restrict__ x, const float
   dmean[i] = inside ? dout[i / D] * (xv / p - (1.0f - xv) / (1.0f - p)) : 0.f;
 }
 
+// ELBO assembly on [B] rows in one launch: KL_i = logq_i - logp_i, loss_i = beta*KL_i - RE_i, and the three
+// batch means (models/BaseModel.py:71-75).  beta comes from device memory when the step is graph-captured.
+__global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* __restrict__ RE, const float* __restrict__ logq,
+                                                       const float* __restrict__ logp,
+                                                       const float* __restrict__ beta_dev, float beta_host, int B,
+                                                       float* __restrict__ loss, float* __restrict__ KL,
+                                                       float* __restrict__ means) {
+  __shared__ float red[3][4];
+  const float beta = beta_dev ? beta_dev[0] : beta_host;
+  float sl = 0.f, sr = 0.f, sk = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    const float kl = logq[i] - logp[i];
+    const float l = beta * kl - RE[i];
+    KL[i] = kl;
+    loss[i] = l;
+    sl += l; sr += RE[i]; sk += kl;
+  }
+  if (means == nullptr) return;
+  sl = wave_sum(sl); sr = wave_sum(sr); sk = wave_sum(sk);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sl; red[1][threadIdx.x >> 6] = sr; red[2][threadIdx.x >> 6] = sk; }
+  __syncthreads();
+  if (threadIdx.x < 3) means[threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) / (float)B;
+}
+
+// Backward coefficients: cRE_i = d/dRE_i, cKL_i = d/dKL_i of the objective given upstream gradients of
+// (loss, RE, KL), each NULL, a scalar (n = 1: gradient of the batch mean, spread as g/B) or a [B] vector.
+__global__ void elbo_bwd_kernel(const float* __restrict__ dloss, int n_dloss, const float* __restrict__ dRE,
+                                int n_dRE, const float* __restrict__ dKL, int n_dKL,
+                                const float* __restrict__ beta_dev, float beta_host, int B,
+                                float* __restrict__ cRE, float* __restrict__ cKL, float* __restrict__ neg_cKL) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const float beta = beta_dev ? beta_dev[0] : beta_host;
+  const float invb = 1.0f / (float)B;
+  const float gl = dloss ? (n_dloss == 1 ? dloss[0] * invb : dloss[i]) : 0.f;
+  const float gr = dRE ? (n_dRE == 1 ? dRE[0] * invb : dRE[i]) : 0.f;
+  const float gk = dKL ? (n_dKL == 1 ? dKL[0] * invb : dKL[i]) : 0.f;
+  const float ck = gk + beta * gl;
+  cRE[i] = gr - gl;
+  cKL[i] = ck;
+  neg_cKL[i] = -ck;
+}
+
 }  // namespace evae
 
 using namespace evae;
@@ -175,4 +218,24 @@ extern "C" int evae_bernoulli_ll_bwd(const float* x, const float* mean, const fl
   EVAE_REQUIRE(x && mean && dout && dmean, "bernoulli_ll_bwd: null pointer");
   bernoulli_ll_bwd_kernel<<<ELT_GRID((size_t)B * D), 256, 0, (hipStream_t)s>>>(x, mean, dout, B, D, dmean);
   return check_launch("bernoulli_ll_bwd");
+}
+
+extern "C" int evae_elbo_fwd(const float* RE, const float* logq, const float* logp, const float* beta_dev,
+                             float beta_host, int B, float* loss, float* KL, float* means, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0, "elbo_fwd: bad size");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(RE && logq && logp && loss && KL, "elbo_fwd: null pointer");
+  elbo_fwd_kernel<<<1, 256, 0, (hipStream_t)s>>>(RE, logq, logp, beta_dev, beta_host, B, loss, KL, means);
+  return check_launch("elbo_fwd");
+}
+
+extern "C" int evae_elbo_bwd(const float* dloss, int n_dloss, const float* dRE, int n_dRE, const float* dKL,
+                             int n_dKL, const float* beta_dev, float beta_host, int B, float* cRE, float* cKL,
+                             float* neg_cKL, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0, "elbo_bwd: bad size");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(cRE && cKL && neg_cKL, "elbo_bwd: null pointer");
+  elbo_bwd_kernel<<<ELT_GRID((size_t)B), 256, 0, (hipStream_t)s>>>(dloss, n_dloss, dRE, n_dRE, dKL, n_dKL, beta_dev,
+                                                                   beta_host, B, cRE, cKL, neg_cKL);
+  return check_launch("elbo_bwd");
 }

@@ -374,20 +374,22 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
 }
 
 // dz[e] = inv_sigma_k * sum_split dz_part[split][e]: 64 outputs x 4 split-lanes per block
-__global__ __launch_bounds__(256) void prior_bwd_finish_dz_kernel(const float* __restrict__ dz_part, int nsplit,
-                                                                  int n, int zdim,
-                                                                  const float* __restrict__ log_var,
-                                                                  float* __restrict__ dz) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void prior_bwd_finish_dz_kernel(const float* __restrict__ dz_part, int nsplit,
+                                                                   int n, int zdim,
+                                                                   const float* __restrict__ log_var,
+                                                                   float* __restrict__ dz) {
+  __shared__ float red[16][64];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6;
+  const int part = threadIdx.x >> 6;      // 16 split-lanes per output, fixed assignment => fixed order
   float s = 0.f;
   if (e < n)
-    for (int r = part; r < nsplit; r += 4) s += dz_part[(size_t)r * n + e];
+    for (int r = part; r < nsplit; r += 16) s += dz_part[(size_t)r * n + e];
   red[part][threadIdx.x & 63] = s;
   __syncthreads();
   if (part == 0 && e < n) {
-    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
     dz[e] = t * expf(-0.5f * log_var[e % zdim]);
   }
 }
@@ -536,7 +538,7 @@ extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, i
   });
   int rc = check_launch("prior_bwd_kernel");
   if (rc) return rc;
-  prior_bwd_finish_dz_kernel<<<cdiv(B * zdim, 64), 256, 0, stream>>>(dz_part, ns, B * zdim, zdim, log_var, dz);
+  prior_bwd_finish_dz_kernel<<<cdiv(B * zdim, 64), 1024, 0, stream>>>(dz_part, ns, B * zdim, zdim, log_var, dz);
   rc = check_launch("prior_bwd_finish_dz_kernel");
   if (rc) return rc;
   prior_bwd_finish_dlv_kernel<<<zdim, 64, 0, stream>>>(dlv_part, ns * nq, zdim, dlogvar);

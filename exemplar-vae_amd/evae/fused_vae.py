@@ -92,7 +92,7 @@ class VaeExactLoss(torch.autograd.Function):
     -> (loss [B], RE [B], KL [B])."""
 
     @staticmethod
-    def forward(ctx, x, x_idx, data_ext, n_data, ex_idx, c_total, eps, beta, sharded, no_mask, *params):
+    def forward(ctx, x, x_idx, data_ext, n_data, ex_idx, c_total, eps, beta, sharded, no_mask, average, *params):
         (plv, wp, bp, w1h, b1h, w1g, b1g, w2h, b2h, w2g, b2g, wm, bm, wl, bl,
          d1h, e1h, d1g, e1g, d2h, e2h, d2g, e2g) = params
         dev = x.device
@@ -140,13 +140,20 @@ class VaeExactLoss(torch.autograd.Function):
         if sharded:
             m, s, n = shard.gather_partials(m, s, n)
         logp, lse = ops.prior_merge(m, s, n, c_total)
-        KL = logq - logp
-        loss = beta * KL - RE
+        # ---- ELBO assembly (+ batch means) in one launch
+        loss = torch.empty(B, **f32); KL = torch.empty(B, **f32)
+        means = torch.empty(3, **f32) if average else None
+        beta_dev = beta if torch.is_tensor(beta) else None
+        _lib.check(lib.evae_elbo_fwd(_vp(RE), _vp(logq), _vp(logp), _vp(beta_dev), 0.0 if beta_dev is not None else float(beta),
+                                     B, _vp(loss), _vp(KL), _vp(means), k.st), "elbo_fwd")
         ctx.k_dev = dev
         ctx.dims = (B, D, H, Z, Cl, Mp, ldd, beta, bool(sharded))
         ctx.bufs = (x, rows, data_ext, A1, h1, s1, A2, h2, s2, mean_all, logvar, lv_pre, z, D1, hd1, sd1, D2, hd2, sd2,
                     xmean, lv_row, zi, ci, lse, eps)
         ctx.save_for_backward(*params)
+        if average:
+            l, r, kl = means.unbind(0)
+            return l, r, kl
         return loss, RE, KL
 
     @staticmethod
@@ -161,11 +168,16 @@ class VaeExactLoss(torch.autograd.Function):
         k = _K(dev)
         lib = k.lib
         f32 = dict(device=dev, dtype=torch.float32)
-        zero = torch.zeros(B, **f32)
-        dloss = zero if dloss is None else dloss
-        cRE = (zero if dRE is None else dRE) - dloss                     # d/dRE_i
-        cKL = (zero if dKL is None else dKL) + beta * dloss              # d/dKL_i ; KL = logq - logp
-        cRE = cRE.contiguous(); cKL = cKL.contiguous()
+        # upstream gradients are per-row vectors (average=False) or scalars of the batch means (average=True)
+        cRE = torch.empty(B, **f32); cKL = torch.empty(B, **f32); gp = torch.empty(B, **f32)
+        gl = None if dloss is None else dloss.contiguous()
+        gr = None if dRE is None else dRE.contiguous()
+        gk = None if dKL is None else dKL.contiguous()
+        beta_dev = beta if torch.is_tensor(beta) else None
+        _lib.check(lib.evae_elbo_bwd(_vp(gl), 0 if gl is None else gl.numel(), _vp(gr), 0 if gr is None else gr.numel(),
+                                     _vp(gk), 0 if gk is None else gk.numel(), _vp(beta_dev),
+                                     0.0 if beta_dev is not None else float(beta), B, _vp(cRE), _vp(cKL), _vp(gp), k.st),
+                   "elbo_bwd")
         # ---- reconstruction term through the decoder
         dxm = torch.empty((B, D), **f32)
         _lib.check(lib.evae_bernoulli_ll_bwd(_vp(x), _vp(xmean), _vp(cRE), B, D, _vp(dxm), k.st), "bernoulli_bwd")
@@ -186,7 +198,6 @@ class VaeExactLoss(torch.autograd.Function):
         # ---- prior term: d(-cKL * logp); dcentres lands directly in the head-gradient buffer
         dmean_all = torch.empty((Mp, Z), **f32)
         dzp = torch.empty((B, Z), **f32); dlv = torch.empty(Z, **f32)
-        gp = (-cKL).contiguous()
         nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cl, Z)
         w = k.ws("prior_bwd", nb)
         centres = mean_all[:Cl]
@@ -229,4 +240,4 @@ class VaeExactLoss(torch.autograd.Function):
         ctx.bufs = None
         grads = (g_plv, g_wp, g_bp, g_w1[:H], g_b1[:H], g_w1[H:], g_b1[H:], g_w2[:H], g_b2[:H], g_w2[H:], g_b2[H:],
                  g_wm, g_bm, g_wl, g_bl, g_d1[:H], g_e1[:H], g_d1[H:], g_e1[H:], g_d2[:H], g_e2[:H], g_d2[H:], g_e2[H:])
-        return (None,) * 10 + grads
+        return (None,) * 11 + grads

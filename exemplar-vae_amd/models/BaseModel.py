@@ -81,7 +81,7 @@ class BaseModel(nn.Module, ABC):
                 and not getattr(a, 'same_variational_var', False) and dataset is not None
                 and x_indices is not None and x.is_cuda and torch.is_grad_enabled())
 
-    def _calculate_loss_fused(self, x, x_indices, beta, dataset):
+    def _calculate_loss_fused(self, x, x_indices, beta, dataset, average):
         a = self.args
         C = a.number_components
         sharded = self._sharded()
@@ -99,15 +99,12 @@ class BaseModel(nn.Module, ABC):
         params = [named[n] for n in fused_vae.PARAM_ORDER]
         beta = beta if torch.is_tensor(beta) else float(beta)
         return fused_vae.VaeExactLoss.apply(x2, x_indices.reshape(-1), data_ext, n_data, ex_local, C, eps,
-                                            beta, sharded, bool(a.no_mask), *params)
+                                            beta, sharded, bool(a.no_mask), bool(average), *params)
 
     def calculate_loss(self, x, beta=1., average=False, exemplars_embedding=None, cache=None, dataset=None):
         x, x_indices = x
         if self._fused_path(x, x_indices, exemplars_embedding, dataset):
-            loss, RE, KL = self._calculate_loss_fused(x, x_indices, beta, dataset)
-            if average:
-                loss, RE, KL = torch.mean(loss), torch.mean(RE), torch.mean(KL)
-            return loss, RE, KL
+            return self._calculate_loss_fused(x, x_indices, beta, dataset, average)
         x_mean, x_logvar, latent_stats = self.forward(x)
         x_flat = x.reshape(x.shape[0], -1) if x.dim() != 2 else x
         RE = self.reconstruction_loss(x_flat, x_mean, x_logvar)

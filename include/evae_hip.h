@@ -179,6 +179,15 @@ int evae_log_normal_diag_fwd(const float* x, const float* mu, const float* logva
 int evae_log_normal_diag_bwd(const float* x, const float* mu, const float* logvar, const float* dout,
                              int B, int zdim, float* dx, float* dmu, float* dlogvar,
                              evae_stream_t stream);
+/* ELBO assembly (models/BaseModel.py:71-75): KL = logq - logp, loss = beta*KL - RE, optional batch means
+ * means[3] = (mean loss, mean RE, mean KL).  beta is read from `beta_dev` when non-NULL (graph-captured
+ * steps), else `beta_host`.  evae_elbo_bwd turns upstream gradients of (loss, RE, KL) -- each NULL, a scalar
+ * (n = 1: gradient of the batch mean) or a [B] vector -- into per-row coefficients cRE = d/dRE, cKL = d/dKL. */
+int evae_elbo_fwd(const float* RE, const float* logq, const float* logp, const float* beta_dev,
+                  float beta_host, int B, float* loss, float* KL, float* means, evae_stream_t stream);
+int evae_elbo_bwd(const float* dloss, int n_dloss, const float* dRE, int n_dRE, const float* dKL, int n_dKL,
+                  const float* beta_dev, float beta_host, int B, float* cRE, float* cKL, float* neg_cKL,
+                  evae_stream_t stream);
 int evae_bernoulli_ll_fwd(const float* x, const float* mean, int B, int D, float* out,
                           evae_stream_t stream);
 int evae_bernoulli_ll_bwd(const float* x, const float* mean, const float* dout, int B, int D,
