@@ -104,3 +104,87 @@ def test_graphed_step_matches_eager():
     assert rel(np.asarray(l1), np.asarray(l0)) < 1e-5
     for k in p0:
         assert rel(p1[k], p0[k]) < 1e-5, k
+
+
+# ---- the other architectures against goldens of the real reference ----------
+def seeded_state_dict(model, seed):
+    """Same deterministic fill as tools/gen_goldens.py::seeded_state_dict (walks the state_dict in order)."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for k, v in model.state_dict().items():
+        shp = tuple(v.shape)
+        if "normalization" in k or k.endswith("num_batches_tracked"):
+            sd[k] = v.clone()
+        elif k.endswith("weight_g"):
+            sd[k] = torch.from_numpy((0.5 + rs.random_sample(shp)).astype(np.float32))
+        elif len(shp) >= 2:
+            fan_in = int(np.prod(shp[1:]))
+            sd[k] = torch.from_numpy((rs.standard_normal(shp) * np.sqrt(2.0 / fan_in)).astype(np.float32))
+        elif k in ("prior_log_variance",):
+            sd[k] = torch.from_numpy(np.asarray([-1.2], np.float32))
+        else:
+            sd[k] = torch.from_numpy((rs.standard_normal(shp) * 0.05).astype(np.float32))
+    return sd
+
+
+G9_CASES = {
+    "hvae_2level": dict(model_name="hvae_2level", input_size=[1, 28, 28], input_type="binary", B=8, C=64, N=200),
+    "convhvae_2level": dict(model_name="convhvae_2level", input_size=[1, 28, 28], input_type="binary", B=6, C=40, N=120),
+    "single_conv": dict(model_name="single_conv", input_size=[3, 16, 16], input_type="continuous", B=4, C=24, N=60,
+                        bottleneck=1, z1_size=16, use_logit=False),
+}
+
+
+@pytest.mark.parametrize("tag", list(G9_CASES))
+def test_other_architectures_match_reference_golden(golden, tag):
+    from utils.utils import importing_model
+    g = golden("g9_models")
+    cfg = dict(G9_CASES[tag])
+    B, C, N = cfg.pop("B"), cfg.pop("C"), cfg.pop("N")
+    args = smoke_case.vae_args(number_components=C, training_set_size=N, **cfg)
+    model = importing_model(args)(args)
+    model.load_state_dict(seeded_state_dict(model, 77))
+    model = model.to("cuda")
+    D = int(np.prod(args.input_size))
+    rs = np.random.RandomState(91)
+    if args.input_type == "binary":
+        data = gi.gray_images(92, N, D)
+        x = (rs.random_sample((B, D)) < 0.3).astype(np.float32)
+    else:
+        data = ((rs.randint(0, 256, (N, D)) + 0.5) / 256).astype(np.float32)
+        x = ((rs.randint(0, 256, (B, D)) + 0.5) / 256).astype(np.float32)
+    bidx = rs.randint(0, N, size=(B, 1)).astype(np.int64)
+    ex_idx = rs.randint(0, N, size=(C,)).astype(np.int64)
+    ex_idx[:2] = bidx[:2, 0]
+    eps_list = [rs.standard_normal((B, args.z1_size)).astype(np.float32) for _ in range(2)]
+    it = {"i": 0}
+
+    def draw(like):
+        e = torch.from_numpy(eps_list[it["i"] % 2]).to(like.device).reshape(like.shape); it["i"] += 1
+        return e
+    model._draw_eps = draw
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    orig = torch.randint
+    torch.randint = lambda low=0, high=None, size=None, **kw: torch.from_numpy(ex_idx)
+    try:
+        model.train(); model.zero_grad(); it["i"] = 0
+        loss, RE, KL = model.calculate_loss((torch.from_numpy(x).cuda(), torch.from_numpy(bidx).cuda()), beta=0.6,
+                                            average=False, dataset=dataset)
+        loss.mean().backward()
+    finally:
+        torch.randint = orig
+    for k, v in (("loss", loss), ("RE", RE), ("KL", KL)):
+        assert rel(v.detach().cpu().numpy(), g["%s_train_%s" % (tag, k)]) < 1e-4, (tag, k)
+    norms = np.asarray([0.0 if p.grad is None else p.grad.double().norm().item() for _, p in model.named_parameters()])
+    ref = g[tag + "_gnorms"]
+    assert norms.shape == ref.shape
+    assert np.all(np.abs(norms - ref) <= 2e-3 * np.maximum(ref, 1e-5)), (tag, np.abs(norms - ref).max())
+    model.eval()
+    with torch.no_grad():
+        it["i"] = 0
+        cz, clv = model.cache_z(dataset)
+        loss, RE, KL = model.calculate_loss((torch.from_numpy(x).cuda(), None), average=False,
+                                            exemplars_embedding=(cz, clv, torch.arange(len(cz))))
+    assert rel(cz[:16].cpu().numpy(), g[tag + "_cache_head"]) < 1e-4
+    for k, v in (("loss", loss), ("RE", RE), ("KL", KL)):
+        assert rel(v.cpu().numpy(), g["%s_eval_%s" % (tag, k)]) < 1e-4, (tag, k)

@@ -248,7 +248,93 @@ def g8():
     save("g8_adam", **out)
 
 
+# ---- G9: calculate_loss of the other architectures (hvae_2level, convhvae_2level, single_conv) -------------
+def seeded_state_dict(model, seed):
+    """Deterministic weights for any architecture: walk the state_dict in order and draw from one RandomState
+    (scaled like He-init for matrices / filters; weight-norm g kept positive; BatchNorm buffers untouched)."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for k, v in model.state_dict().items():
+        shp = tuple(v.shape)
+        if "normalization" in k or k.endswith("num_batches_tracked"):
+            sd[k] = v.clone()
+        elif k.endswith("weight_g"):
+            sd[k] = T((0.5 + rs.random_sample(shp)).astype(np.float32))
+        elif len(shp) >= 2:
+            fan_in = int(np.prod(shp[1:]))
+            sd[k] = T((rs.standard_normal(shp) * np.sqrt(2.0 / fan_in)).astype(np.float32))
+        elif k in ("prior_log_variance",):
+            sd[k] = T(np.asarray([-1.2], np.float32))
+        else:
+            sd[k] = T((rs.standard_normal(shp) * 0.05).astype(np.float32))
+    return sd
+
+
+G9_CASES = {
+    "hvae_2level": dict(model_name="hvae_2level", input_size=[1, 28, 28], input_type="binary", B=8, C=64, N=200),
+    "convhvae_2level": dict(model_name="convhvae_2level", input_size=[1, 28, 28], input_type="binary", B=6, C=40, N=120),
+    "single_conv": dict(model_name="single_conv", input_size=[3, 16, 16], input_type="continuous", B=4, C=24, N=60,
+                        bottleneck=1, z1_size=16, use_logit=False),
+}
+
+
+def g9():
+    from utils.utils import importing_model
+    out = {}
+    for tag, cfg in G9_CASES.items():
+        cfg = dict(cfg)
+        B, C, N = cfg.pop("B"), cfg.pop("C"), cfg.pop("N")
+        args = vae_args(number_components=C, training_set_size=N, **cfg)
+        torch.manual_seed(0)
+        model = importing_model(args)(args)
+        model.load_state_dict(seeded_state_dict(model, 77))
+        D = int(np.prod(args.input_size))
+        rs = np.random.RandomState(91)
+        if args.input_type == "binary":
+            data = gi.gray_images(92, N, D)
+            x = (rs.random_sample((B, D)) < 0.3).astype(np.float32)
+        else:
+            data = ((rs.randint(0, 256, (N, D)) + 0.5) / 256).astype(np.float32)
+            x = ((rs.randint(0, 256, (B, D)) + 0.5) / 256).astype(np.float32)
+        bidx = rs.randint(0, N, size=(B, 1)).astype(np.int64)
+        ex_idx = rs.randint(0, N, size=(C,)).astype(np.int64)
+        ex_idx[:2] = bidx[:2, 0]
+        zsz = args.z1_size
+        eps_list = [rs.standard_normal((B, zsz)).astype(np.float32) for _ in range(2)]
+        it = {"i": 0}
+
+        def reparam(mu, logvar, it=it, eps_list=eps_list):
+            e = T(eps_list[it["i"] % 2]).reshape(mu.shape); it["i"] += 1
+            return e * logvar.mul(0.5).exp() + mu
+        model.reparameterize = reparam
+        dataset = torch.utils.data.TensorDataset(T(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+        orig = torch.randint
+        torch.randint = lambda low=0, high=None, size=None, **kw: T(ex_idx)
+        try:
+            model.train(); model.zero_grad(); it["i"] = 0
+            loss, RE, KL = model.calculate_loss((T(x), T(bidx)), beta=0.6, average=False, dataset=dataset)
+            loss.mean().backward()
+        finally:
+            torch.randint = orig
+        out[tag + "_train_loss"] = loss.detach().numpy(); out[tag + "_train_RE"] = RE.detach().numpy()
+        out[tag + "_train_KL"] = KL.detach().numpy()
+        names, norms = [], []
+        for k, v in model.named_parameters():
+            names.append(k); norms.append(0.0 if v.grad is None else v.grad.double().norm().item())
+        out[tag + "_gnorms"] = np.asarray(norms)
+        model.eval()
+        with torch.no_grad():
+            it["i"] = 0
+            cz, clv = model.cache_z(dataset)
+            loss, RE, KL = model.calculate_loss((T(x), None), average=False,
+                                                exemplars_embedding=(cz, clv, torch.arange(len(cz))))
+        out[tag + "_eval_loss"] = loss.numpy(); out[tag + "_eval_RE"] = RE.numpy(); out[tag + "_eval_KL"] = KL.numpy()
+        out[tag + "_cache_head"] = cz.numpy()[:16]
+        print(tag, "params", len(names), "train loss mean", float(loss.mean()))
+    save("g9_models", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()
