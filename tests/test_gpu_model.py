@@ -188,3 +188,38 @@ def test_other_architectures_match_reference_golden(golden, tag):
     assert rel(cz[:16].cpu().numpy(), g[tag + "_cache_head"]) < 1e-4
     for k, v in (("loss", loss), ("RE", RE), ("KL", KL)):
         assert rel(v.cpu().numpy(), g["%s_eval_%s" % (tag, k)]) < 1e-4, (tag, k)
+
+
+def test_approximate_prior_matches_reference_golden(golden):
+    """kNN-pruned exemplar prior (reference models/BaseModel.py:256-271): loss, gradients and the in-place cache
+    refresh against the real reference."""
+    g = golden("g10_approx")
+    B, C, N, k = 16, 300, 1000, 10
+    args = smoke_case.vae_args(number_components=C, training_set_size=N, approximate_prior=True, approximate_k=k)
+    model, p = smoke_case.build_model(torch, np, orc, args)
+    data = gi.gray_images(63, N).astype(np.float32)
+    rs = np.random.RandomState(64)
+    bidx = rs.choice(N, size=(B, 1), replace=False).astype(np.int64)
+    x = (rs.random_sample((B, 784)) < np.clip(data[bidx[:, 0]] + 0.1, 0, 1)).astype(np.float32)
+    eps = rs.standard_normal((B, 40)).astype(np.float32)
+    cand = rs.choice(N, size=C, replace=False).astype(np.int64)    # distinct candidates: no exact distance ties
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    model._draw_eps = lambda like: torch.from_numpy(eps).to(like.device)
+    model.train()
+    with torch.no_grad():
+        cache = tuple(model.cache_z(dataset))
+    assert rel(cache[0].cpu().numpy(), g["cache_before"]) < 1e-5
+    orig = torch.randint
+    torch.randint = lambda low=0, high=None, size=None, **kw: torch.from_numpy(cand.copy())
+    try:
+        model.zero_grad()
+        loss, RE, KL = model.calculate_loss((torch.from_numpy(x).cuda(), torch.from_numpy(bidx).cuda()), beta=0.8,
+                                            average=False, cache=cache, dataset=dataset)
+        loss.mean().backward()
+    finally:
+        torch.randint = orig
+    for kk, v in (("loss", loss), ("RE", RE), ("KL", KL)):
+        assert rel(v.detach().cpu().numpy(), g[kk]) < 1e-4, kk
+    assert rel(cache[0].detach().cpu().numpy(), g["cache_after"]) < 1e-5      # refreshed rows identical
+    norms = np.asarray([prm.grad.double().norm().item() for _, prm in model.named_parameters()])
+    assert np.all(np.abs(norms - g["gnorm"]) <= 1e-3 * np.maximum(g["gnorm"], 1e-5))

@@ -334,7 +334,44 @@ def g9():
     save("g9_models", **out)
 
 
+# ---- G10: approximate prior (cache + top-k), models/BaseModel.py:256-271 via calculate_loss ------------------
+def g10():
+    B, C, N, k = 16, 300, 1000, 10
+    args = vae_args(number_components=C, training_set_size=N, approximate_prior=True, approximate_k=k)
+    model = VAE(args)
+    p = orc.vae_init_params(np.random.RandomState(123))
+    load_params(model, p)
+    data = gi.gray_images(63, N).astype(np.float32)
+    rs = np.random.RandomState(64)
+    bidx = rs.choice(N, size=(B, 1), replace=False).astype(np.int64)
+    x = (rs.random_sample((B, 784)) < np.clip(data[bidx[:, 0]] + 0.1, 0, 1)).astype(np.float32)
+    eps = rs.standard_normal((B, 40)).astype(np.float32)
+    cand = rs.choice(N, size=C, replace=False).astype(np.int64)    # distinct candidates: no exact distance ties
+    dataset = torch.utils.data.TensorDataset(T(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    model.reparameterize = lambda mu, logvar: T(eps) * logvar.mul(0.5).exp() + mu
+    model.train()
+    with torch.no_grad():
+        cache = model.cache_z(dataset)
+    cache0 = cache[0].numpy().copy()
+    orig = torch.randint
+    torch.randint = lambda low=0, high=None, size=None, **kw: T(cand.copy())
+    try:
+        model.zero_grad()
+        loss, RE, KL = model.calculate_loss((T(x), T(bidx)), beta=0.8, average=False, cache=cache, dataset=dataset)
+        loss.mean().backward()
+    finally:
+        torch.randint = orig
+    # tie check on the top-k boundary of the candidate distances
+    zq = model.q_z(T(x))[0].detach()
+    d = pairwise_distance(zq, T(cache0)[T(cand)]).numpy()
+    assert tie_gap(d, k)[0] > 0
+    out = dict(loss=loss.detach().numpy(), RE=RE.detach().numpy(), KL=KL.detach().numpy(),
+               cache_after=cache[0].detach().numpy(), cache_before=cache0,
+               gnorm=np.asarray([v.grad.double().norm().item() for _, v in model.named_parameters()]))
+    save("g10_approx", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()
