@@ -223,3 +223,28 @@ def test_approximate_prior_matches_reference_golden(golden):
     assert rel(cache[0].detach().cpu().numpy(), g["cache_after"]) < 1e-5      # refreshed rows identical
     norms = np.asarray([prm.grad.double().norm().item() for _, prm in model.named_parameters()])
     assert np.all(np.abs(norms - g["gnorm"]) <= 1e-3 * np.maximum(g["gnorm"], 1e-5))
+
+
+def test_evaluation_loops_match_reference_golden(golden):
+    """utils.evaluation.evaluate_loss / calculate_likelihood (ELBO over a loader, IWAE test log p(x)) vs the
+    reference's loops on identical data, weights and eps stream."""
+    from models.VAE import VAE
+    from utils.evaluation import evaluate_loss, calculate_likelihood
+    g = golden("g11_eval")
+    N, NT, S = 400, 12, 50
+    args = smoke_case.vae_args(number_components=N, training_set_size=N, batch_size=5)
+    model, _ = smoke_case.build_model(torch, np, orc, args)
+    data = gi.binary_images(71, N)
+    test = gi.binary_images(72, NT)
+    train_ds = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    test_ds = torch.utils.data.TensorDataset(torch.from_numpy(test), torch.zeros(NT))
+    loader = torch.utils.data.DataLoader(test_ds, batch_size=5, shuffle=False)
+    eps_rs = np.random.RandomState(73)
+    model._draw_eps = lambda like: torch.from_numpy(eps_rs.standard_normal(tuple(like.shape)).astype(np.float32)).to(like.device)
+    with torch.no_grad():
+        elbo, re, kl = evaluate_loss(args, model, loader, dataset=train_ds)
+        model.eval()
+        cz, clv = model.cache_z(train_ds)
+        ll = calculate_likelihood(args, model, loader, S=S, exemplars_embedding=(cz, clv, torch.arange(len(cz))))
+    assert rel(np.asarray([elbo, re, kl]), g["elbo"]) < 1e-4
+    assert abs(ll - g["ll"][0]) <= 1e-4 * abs(g["ll"][0])

@@ -371,7 +371,34 @@ def g10():
     save("g10_approx", **out)
 
 
+# ---- G11: evaluation loops (utils/evaluation.py:11-33, 72-103): ELBO over a loader and IWAE log-likelihood ----
+def g11():
+    from utils.evaluation import evaluate_loss, calculate_likelihood
+    N, NT, S = 400, 12, 50
+    args = vae_args(number_components=N, training_set_size=N)
+    args.batch_size = 5
+    model = VAE(args)
+    load_params(model, orc.vae_init_params(np.random.RandomState(123)))
+    data = gi.binary_images(71, N)
+    test = gi.binary_images(72, NT)
+    train_ds = torch.utils.data.TensorDataset(T(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    test_ds = torch.utils.data.TensorDataset(T(test), torch.zeros(NT))
+    loader = torch.utils.data.DataLoader(test_ds, batch_size=5, shuffle=False)
+    eps_rs = np.random.RandomState(73)
+
+    def reparam(mu, logvar):
+        e = T(eps_rs.standard_normal(tuple(mu.shape)).astype(np.float32))
+        return e * logvar.mul(0.5).exp() + mu
+    model.reparameterize = reparam
+    with torch.no_grad():
+        elbo, re, kl = evaluate_loss(args, model, loader, dataset=train_ds)
+        model.eval()
+        emb = (lambda z, lv: (z, lv, torch.arange(len(z))))(*model.cache_z(train_ds))
+        ll = calculate_likelihood(args, model, loader, S=S, exemplars_embedding=emb)
+    save("g11_eval", elbo=np.asarray([elbo, re, kl]), ll=np.asarray([ll]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()
