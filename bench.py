@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--probe-steps", type=int, default=20,
                     help="eager steps run after the timed region to time the dominant kernel with HIP events")
+    ap.add_argument("--iwae-images", type=int, default=16,
+                    help="test images for the IWAE test log p(x) leg (S=5000 samples each vs all 50 000 exemplars); 0 disables")
     ap.add_argument("--cpu-baseline-steps", type=int, default=25,
                     help="oracle steps timed for cpu_baseline (0 disables)")
     return ap.parse_args()
@@ -202,6 +204,31 @@ def main():
                 "launches": len(durs_ms), "avg_launch_us": round(1e3 * sum(durs_ms) / len(durs_ms), 2),
                 "flops_per_launch_avg": round(sum(flops) / len(flops))}
 
+    # second half of BASELINE.json's metric: test log p(x) (IWAE, S = 5000, all N_train exemplars as the prior)
+    iwae = None
+    if world == 1 and a.iwae_images > 0:
+        from utils.evaluation import calculate_likelihood
+        test = torch.from_numpy(gi.binary_images(2, a.iwae_images))
+        test_ds = torch.utils.data.TensorDataset(test, torch.zeros(len(test)))
+        loader = torch.utils.data.DataLoader(test_ds, batch_size=100)
+        import contextlib, io
+        model.eval()
+        with torch.no_grad():
+            cz, clv = model.cache_z(dataset)
+            emb = (cz, clv, torch.arange(len(cz)))
+            with contextlib.redirect_stdout(io.StringIO()):
+                calculate_likelihood(args, model, torch.utils.data.DataLoader(
+                    torch.utils.data.TensorDataset(test[:2], torch.zeros(2)), batch_size=2), S=args.S, exemplars_embedding=emb)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ll = calculate_likelihood(args, model, loader, S=args.S, exemplars_embedding=emb)
+                torch.cuda.synchronize()
+                t_ll = time.perf_counter() - t1
+        model.train()
+        iwae = {"neg_log_px": round(ll, 3), "images": a.iwae_images, "S": args.S, "exemplars": N_TRAIN,
+                "ms_per_image": round(1e3 * t_ll / a.iwae_images, 3),
+                "note": "utils.evaluation.calculate_likelihood on synthetic test images after the benchmark's training steps"}
+
     if rank == 0:
         out = {
             "metric": "training images/sec", "value": round(B * a.steps / dt, 1), "unit": "images/sec",
@@ -215,6 +242,7 @@ def main():
                        "launch": "eager" if graphed is None else "hipGraph replay of the whole step"},
             "mean_loss": round(final_loss, 4),
             "roofline": roof,
+            "test_log_px": iwae,
             "cpu_baseline": None,
         }
         if world == 1 and a.cpu_baseline_steps > 0:
