@@ -242,7 +242,7 @@ class GatedDenseFn(torch.autograd.Function):
         s = torch.empty_like(out) if need_grad else None
         nb = lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
         ws = _workspace("fwd", nb, x.device)
-        probe = PROBE
+        probe = PROBE if nb <= 256 else None         # only the direct EPI_GATED kernel (no split-K partials)
         if probe is not None:
             ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record()
