@@ -18,42 +18,90 @@ namespace evae {
 
 constexpr int DS = BE + 1;  // distance tile row stride
 
-struct TkList { float v; int64_t id; };
+// Lists and candidates are (fp32 value, index) pairs ordered by (value, index); IdT is int inside the scan
+// kernel (shard-local exemplar index, one shuffle) and int64_t in the merge kernel (global indices).
+template <typename IdT> struct IdLimit;
+template <> struct IdLimit<int> { static constexpr int max() { return INT_MAX; } };
+template <> struct IdLimit<int64_t> { static constexpr int64_t max() { return INT64_MAX; } };
 
-__device__ __forceinline__ bool tk_less(float av, int64_t ai, float bv, int64_t bi) {
+template <typename IdT>
+__device__ __forceinline__ bool tk_less(float av, IdT ai, float bv, IdT bi) {
   return (av < bv) || (av == bv && ai < bi);
 }
 
 // insert (cv, cid), known to be < entry k-1, into the sorted list held by lanes 0..k-1
-__device__ __forceinline__ void tk_insert(float& lv, int64_t& li, float cv, int64_t cid, int k, int lane) {
+template <typename IdT>
+__device__ __forceinline__ void tk_insert(float& lv, IdT& li, float cv, IdT cid, int k, int lane) {
   bool less = (lane < k) && tk_less(lv, li, cv, cid);
   int pos = __popcll(__ballot(less));
   float upv = __shfl_up(lv, 1, 64);
-  int64_t upi = __shfl_up(li, 1, 64);
+  IdT upi = __shfl_up(li, 1, 64);
   if (lane > pos && lane < k) { lv = upv; li = upi; }
   else if (lane == pos) { lv = cv; li = cid; }
 }
 
-// offer one candidate per lane to the list; returns true if the list changed
-__device__ __forceinline__ bool tk_offer(float& lv, int64_t& li, float v, int64_t id, bool valid, int k,
-                                         int lane) {
+// full bitonic sort of one (value, index) per lane, ascending by (value, index): 21 compare-exchange stages
+template <typename IdT>
+__device__ __forceinline__ void bitonic_sort64(float& v, IdT& id, int lane) {
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const float ov = __shfl_xor(v, stride, 64);
+      const IdT oi = __shfl_xor(id, stride, 64);
+      const bool want_min = (((lane & stride) == 0) == ((lane & size) == 0));
+      const bool take = want_min ? tk_less(ov, oi, v, id) : tk_less(v, id, ov, oi);
+      if (take) { v = ov; id = oi; }
+    }
+  }
+}
+
+// bitonic merge (6 stages) of a 64-lane bitonic sequence into ascending order
+template <typename IdT>
+__device__ __forceinline__ void bitonic_merge64(float& v, IdT& id, int lane) {
+#pragma unroll
+  for (int stride = 32; stride > 0; stride >>= 1) {
+    const float ov = __shfl_xor(v, stride, 64);
+    const IdT oi = __shfl_xor(id, stride, 64);
+    const bool want_min = (lane & stride) == 0;
+    const bool take = want_min ? tk_less(ov, oi, v, id) : tk_less(v, id, ov, oi);
+    if (take) { v = ov; id = oi; }
+  }
+}
+
+// Offer one candidate per lane to the sorted list (lanes 0..k-1).  Few qualifying lanes: wave-cooperative
+// shift-inserts.  Many (a fresh list, an early tile): sort the 64 candidates, lay list (ascending, lanes
+// 0..k-1), +inf filler and the k best candidates (descending, lanes 63..64-k) out as ONE bitonic sequence and
+// merge it -- ~27 compare-exchange stages regardless of how many candidates enter.
+template <typename IdT>
+__device__ __forceinline__ void tk_offer(float& lv, IdT& li, float v, IdT id, bool valid, int k, int lane) {
   float tv = __shfl(lv, k - 1, 64);
-  int64_t ti = __shfl(li, k - 1, 64);
+  IdT ti = __shfl(li, k - 1, 64);
   unsigned long long mask = __ballot(valid && tk_less(v, id, tv, ti));
-  bool changed = false;
+  if (mask == 0ull) return;
+  if (__popcll(mask) > 4 && k <= 32) {
+    float cv = valid ? v : INFINITY;
+    IdT ci = valid ? id : IdLimit<IdT>::max();
+    bitonic_sort64(cv, ci, lane);
+    const float rv = __shfl(cv, 63 - lane, 64);       // candidates reversed: lane 63-j holds the j-th best
+    const IdT ri = __shfl(ci, 63 - lane, 64);
+    if (lane >= 64 - k) { lv = rv; li = ri; }
+    else if (lane >= k) { lv = INFINITY; li = IdLimit<IdT>::max(); }
+    bitonic_merge64(lv, li, lane);
+    if (lane >= k) { lv = INFINITY; li = IdLimit<IdT>::max(); }
+    return;
+  }
   while (mask) {
-    int L = __ffsll((long long)mask) - 1;
-    float cv = __shfl(v, L, 64);
-    int64_t cid = __shfl(id, L, 64);
+    const int L = __ffsll((long long)mask) - 1;
+    const float cv = __shfl(v, L, 64);
+    const IdT cid = __shfl(id, L, 64);
     if (tk_less(cv, cid, tv, ti)) {
       tk_insert(lv, li, cv, cid, k, lane);
       tv = __shfl(lv, k - 1, 64);
       ti = __shfl(li, k - 1, 64);
-      changed = true;
     }
     mask &= mask - 1;
   }
-  return changed;
 }
 
 template <int KC>
@@ -155,12 +203,12 @@ __global__ __launch_bounds__(NT) void pairdist_topk_kernel(
       if (q0 + ql >= B) break;
       const float v = D[ql * DS + lane];
       const float tv = Lv[ql * k + k - 1];
-      const int64_t ti = Li[ql * k + k - 1];
-      if (__ballot(valid && tk_less(v, (int64_t)e, tv, ti)) == 0ull) continue;
+      const int ti = Li[ql * k + k - 1];
+      if (__ballot(valid && tk_less(v, e, tv, ti)) == 0ull) continue;
       float lv = lane < k ? Lv[ql * k + lane] : INFINITY;
-      int64_t li = lane < k ? (int64_t)Li[ql * k + lane] : (int64_t)INT_MAX;
-      tk_offer(lv, li, v, (int64_t)e, valid, k, lane);
-      if (lane < k) { Lv[ql * k + lane] = lv; Li[ql * k + lane] = (int)li; }
+      int li = lane < k ? Li[ql * k + lane] : INT_MAX;
+      tk_offer<int>(lv, li, v, e, valid, k, lane);
+      if (lane < k) { Lv[ql * k + lane] = lv; Li[ql * k + lane] = li; }
     }
   }
   __syncthreads();
@@ -230,7 +278,7 @@ __global__ __launch_bounds__(NT) void topk_merge_kernel(const float* __restrict_
       id = idx[o];
       valid = id >= 0 && id != INT64_MAX;
     }
-    tk_offer(lv, li, v, id, valid, k, lane);
+    tk_offer<int64_t>(lv, li, v, id, valid, k, lane);
   }
   if (lane < k) {
     out_idx[(size_t)row * k + lane] = (li == INT64_MAX) ? (int64_t)-1 : li + index_base;
