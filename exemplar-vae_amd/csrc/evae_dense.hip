@@ -24,18 +24,9 @@
 //   [600 x 784] weight gradient over 25 000 rows) still fill the 256 CUs.
 //   Workgroup ids are remapped so that each XCD owns a contiguous run of tiles (shared A row-panels
 //   stay in one L2).
-#include <stdlib.h>
-
-#include "evae_common.h"
+#include "evae_gemm_core.h"
 
 namespace evae {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128, BK = 32;
-constexpr int KS = BK + 4;  // KC tile row stride (floats); 36/4 = 9 odd
-
-enum { EPI_LINEAR = 0, EPI_GATED = 1, EPI_GATE_BWD = 2, EPI_RAW = 3, EPI_RAW_GATED = 4 };
 
 struct GemmArgs {
   const float* A[2];
@@ -153,57 +144,6 @@ struct TileLoader {
     }
   }
 };
-
-// one K-slab of MFMAs: wave tile 64 x (32 NT) at rows wr*64.., cols wc*32*NT..
-// (k-groups [KG0, KG1) of 8 within the slab, so that LDS stores / global loads can be placed between them)
-template <bool A_KC, bool B_KC, int MT, int NT, int BN_, int KG0, int KG1>
-__device__ __forceinline__ void mma_slab(f32x16 (&acc)[MT][NT], const float* __restrict__ As,
-                                         const float* __restrict__ Bs, int wr, int wc, int lane) {
-  constexpr int ARS = BM + 4, BRS = BN_ + 4;
-  const int l31 = lane & 31;
-  const int kh = (lane >> 5) * 4;
-#pragma unroll
-  for (int kg = KG0 * 8; kg < KG1 * 8; kg += 8) {
-    float a[MT][4], b[NT][4];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      if (A_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(As + (wr * 32 * MT + t * 32 + l31) * KS + kg + kh);
-        a[t][0] = v.x; a[t][1] = v.y; a[t][2] = v.z; a[t][3] = v.w;
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a[t][s] = As[(kg + kh + s) * ARS + wr * 32 * MT + t * 32 + l31];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (B_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(Bs + (wc * 32 * NT + t * 32 + l31) * KS + kg + kh);
-        b[t][0] = v.x; b[t][1] = v.y; b[t][2] = v.z; b[t][3] = v.w;
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[t][s] = Bs[(kg + kh + s) * BRS + wc * 32 * NT + t * 32 + l31];
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
-  }
-}
-
-__device__ __forceinline__ float apply_act(float v, int act, float lo, float hi) {
-  if (act == EVAE_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
-  if (act == EVAE_ACT_HARDTANH) return fminf(fmaxf(v, lo), hi);
-  return v;
-}
-
-constexpr int A_TILE_FLOATS = BM * KS;  // 4608 (>= 32 * 132 for the RC layout)
-constexpr int b_tile_floats(int bn) { return bn * KS; }  // >= 32 * (bn + 4)
-constexpr size_t gemm_lds_bytes(int bn) { return 2 * (size_t)(A_TILE_FLOATS + b_tile_floats(bn)) * sizeof(float); }
 
 template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g) {
@@ -392,64 +332,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
   }
 }
 
-// ---- split-K finish: sum the partial planes in a fixed order, then the real epilogue ----------------
-struct FinishArgs {
-  const float* part;
-  int nz, M, N, ldo;
-  int epi;
-  const float* bias0;
-  const float* bias1;
-  float* out0;
-  float* out1;
-  float* out2;
-  const float* e0;
-  const float* e1;
-  int act;
-  float lo, hi;
-  int accumulate;
-  int ones_col;            // EPI_RAW: column that carries the bias gradient (-1 = none)
-  float* out_db;
-};
-
-__global__ __launch_bounds__(256) void gemm_finish_kernel(const FinishArgs f) {
-  const size_t plane = (size_t)f.M * f.N;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= plane) return;
-  const int m = (int)(i / f.N), n = (int)(i - (size_t)m * f.N);
-  const size_t o = (size_t)m * f.ldo + n;
-  if (f.epi == EPI_GATED) {
-    float h = 0.f, gg = 0.f;
-    for (int z = 0; z < f.nz; ++z) {
-      h += f.part[(size_t)z * 2 * plane + i];
-      gg += f.part[(size_t)z * 2 * plane + plane + i];
-    }
-    h += f.bias0 ? f.bias0[n] : 0.f;
-    const float s = 1.0f / (1.0f + expf(-(gg + (f.bias1 ? f.bias1[n] : 0.f))));
-    f.out0[o] = h * s;
-    if (f.out1) f.out1[o] = h;
-    if (f.out2) f.out2[o] = s;
-    return;
-  }
-  float v = 0.f;
-  for (int z = 0; z < f.nz; ++z) v += f.part[(size_t)z * plane + i];
-  if (f.epi == EPI_LINEAR) {
-    const float pre = v + (f.bias0 ? f.bias0[n] : 0.f);
-    if (f.out1) f.out1[o] = pre;
-    f.out0[o] = apply_act(pre, f.act, f.lo, f.hi);
-  } else if (f.epi == EPI_GATE_BWD) {
-    const float h = f.e0[i], s = f.e1[i];
-    f.out0[o] = v * s;
-    f.out1[o] = v * h * s * (1.0f - s);
-  } else {  // EPI_RAW: plain sum (weight gradient), optional accumulate; column ones_col is db
-    if (f.ones_col >= 0) {
-      if (n == f.ones_col) { if (f.out_db) f.out_db[m] = (f.accumulate ? f.out_db[m] : 0.f) + v; }
-      else { const size_t ow = (size_t)m * f.ones_col + n; f.out0[ow] = (f.accumulate ? f.out0[ow] : 0.f) + v; }
-    } else {
-      f.out0[o] = (f.accumulate ? f.out0[o] : 0.f) + v;
-    }
-  }
-}
-
 __global__ void gated_bwd_input_kernel(const float* __restrict__ dout, const float* __restrict__ h,
                                        const float* __restrict__ s, int M, int N, int ldo,
                                        float* __restrict__ dh, float* __restrict__ dg) {
@@ -478,36 +360,6 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 }
 
 // ---- host side: plan, launch --------------------------------------------------------------------------
-struct Plan {
-  int bn;      // 128 or 64
-  int nz;      // split-K factor (blockIdx.z extent)
-  int ksplit;  // slabs per split
-};
-
-// Wave-quantisation model: a launch runs in rounds of 512 resident blocks (256 CUs x 2); a block costs
-// (slabs + fixed prologue/epilogue) slab-times, a BN=64 slab ~0.6 of a BN=128 slab; split-K adds the
-// finish kernel (launch + partial traffic).  Deterministic in (M, N, slabs, gated, must_split).
-static Plan make_plan(int M, int N, int slabs, bool gated, bool must_split, int planes) {
-  Plan best = {128, 1, slabs};
-  double best_t = 1e30;
-  const int bns[2] = {128, 64};
-  for (int bi = 0; bi < (gated ? 1 : 2); ++bi) {
-    const int bn = bns[bi];
-    const long tiles = (long)cdiv(M, BM) * cdiv(N, gated ? 64 : bn);
-    const double slab_cost = bn == 64 ? 0.6 : 1.0;
-    for (int nz = 1; nz <= slabs && nz <= 512; ++nz) {
-      const int ks = cdiv(slabs, nz);
-      const int nze = cdiv(slabs, ks);
-      if (nze != nz) continue;
-      const long rounds = (tiles * nze + 511) / 512;
-      double t = rounds * (ks + 1.5) * slab_cost;
-      if (nze > 1 || must_split) t += 2.0 + (double)M * N * planes * nze * 4.0 / 12e6;
-      if (t < best_t) { best_t = t; best = {bn, nze, ks}; }
-    }
-  }
-  return best;
-}
-
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <bool A_KC, bool B_KC>
@@ -575,17 +427,6 @@ static int launch_gemm(GemmArgs& g, const Plan& pl, hipStream_t stream, const ch
     return launch_gemm_v<A_KC, B_KC, EPI, false, 64>(g, pl.nz, stream, what);
   }
   return EVAE_EINVAL;
-}
-
-static int launch_finish(const FinishArgs& f, hipStream_t stream) {
-  size_t n = (size_t)f.M * f.N;
-  gemm_finish_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(f);
-  return check_launch("gemm_finish_kernel");
-}
-
-static int elt_grid(size_t n) {
-  size_t b = (n + 255) / 256;
-  return (int)(b < 4096 ? (b ? b : 1) : 4096);
 }
 
 static int total_slabs(int k0, int k1) { return cdiv(k0, BK) + (k1 > 0 ? cdiv(k1, BK) : 0); }

@@ -18,6 +18,11 @@ _l = C.c_int64
 _u = C.c_uint
 
 
+class ConvDesc(C.Structure):
+    """evae_conv_desc_t"""
+    _fields_ = [(n, C.c_int) for n in ("N", "C", "H", "W", "Co", "KH", "KW", "stride", "pad")]
+
+
 class AdamTensor(C.Structure):
     """evae_adam_tensor_t"""
     _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("numel", _l)]
@@ -45,6 +50,10 @@ SIGNATURES = {
     "evae_dense_bwd_weight": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p, _z, _p]),
     "evae_gated_dense_bwd_input": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "evae_act_bwd": (_i, [_p, _p, _z, _i, _f, _f, _p, _p]),
+    "evae_conv2d_workspace_bytes": (_z, [_p, _i, _i]),
+    "evae_conv2d_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _z, _p]),
+    "evae_conv2d_bwd_data": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_conv2d_bwd_weight": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_reparam_logq_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_reparam_logq_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_log_normal_diag_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),

@@ -331,6 +331,100 @@ def linear(x, w, b, act=ACT_NONE, lo=0.0, hi=0.0, rows=None):
 
 
 # ------------------------------------------------------------------------------------------------
+# convolutions (implicit GEMM)
+# ------------------------------------------------------------------------------------------------
+def _conv_desc(x, w, stride, pad):
+    N, Cc, H, W = x.shape
+    Co, Ci, KH, KW = w.shape
+    assert Ci == Cc, "groups != 1 is not supported"
+    d = _lib.ConvDesc(N, Cc, H, W, Co, KH, KW, int(stride), int(pad))
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    return d, OH, OW
+
+
+def _int1(v):
+    if isinstance(v, (tuple, list)):
+        assert all(e == v[0] for e in v), "only square stride / padding"
+        return int(v[0])
+    return int(v)
+
+
+class Conv2dFn(torch.autograd.Function):
+    """act(conv2d(x, wh) + bh) [* sigmoid(conv2d(x, wg) + bg)]  -- utils/nn.py:72-114, nn.Conv2d."""
+
+    @staticmethod
+    def forward(ctx, x, wh, bh, wg, bg, stride, pad, act, lo, hi):
+        lib = _lib.load()
+        _need_cuda(x, wh, wg)
+        x = _f32(x); wh = _f32(wh); wg = None if wg is None else _f32(wg)
+        d, OH, OW = _conv_desc(x, wh, stride, pad)
+        gated = wg is not None
+        out = torch.empty((d.N, d.Co, OH, OW), device=x.device)
+        need_grad = any(ctx.needs_input_grad)
+        h = torch.empty_like(out) if (gated and need_grad) else None
+        s = torch.empty_like(out) if (gated and need_grad) else None
+        pre = torch.empty_like(out) if (not gated and need_grad and act == ACT_HARDTANH) else None
+        nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 0, int(gated))
+        ws = _workspace("conv", nb, x.device)
+        _lib.check(lib.evae_conv2d_fwd(_p(x), C.byref(d), _p(wh), _p(bh), _p(wg), _p(bg), act, float(lo), float(hi),
+                                       _p(out), _p(h if gated else pre), _p(s), _p(ws), ws.numel(), _stream()),
+                   "evae_conv2d_fwd")
+        if need_grad:
+            ctx.save_for_backward(x, wh, wg, h, s, pre if pre is not None else out)
+        ctx.cfg = (d, gated, act, float(lo), float(hi), bh is not None, bg is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, wh, wg, h, s, aux = ctx.saved_tensors
+        d, gated, act, lo, hi, has_bh, has_bg = ctx.cfg
+        dout = _f32(dout)
+        n = dout.numel()
+        if gated:
+            if act != ACT_NONE:
+                raise _lib.EvaeError("gated conv with an activation on h: compose it from two plain convs")
+            dh = torch.empty_like(dout); dg = torch.empty_like(dout)
+            _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(h), _p(s), 1, n, _p(dh), _p(dg), n, _stream()),
+                       "evae_gated_dense_bwd_input")
+        else:
+            dg = None
+            if act != ACT_NONE:
+                dh = torch.empty_like(dout)
+                _lib.check(lib.evae_act_bwd(_p(dout), _p(aux), n, act, lo, hi, _p(dh), _stream()), "evae_act_bwd")
+            else:
+                dh = dout
+        K = d.C * d.KH * d.KW
+        rows = d.Co * (2 if gated else 1)
+        dw = torch.empty((rows, K), device=dout.device); db = torch.empty(rows, device=dout.device)
+        nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 2, int(gated))
+        ws = _workspace("conv", nb, dout.device)
+        _lib.check(lib.evae_conv2d_bwd_weight(_p(dh), _p(dg), _p(x), C.byref(d), _p(dw), _p(db), _p(ws), ws.numel(),
+                                              _stream()), "evae_conv2d_bwd_weight")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 1, int(gated))
+            ws = _workspace("conv", nb, dout.device)
+            _lib.check(lib.evae_conv2d_bwd_data(_p(dh), _p(wh), _p(dg), _p(wg), C.byref(d), _p(dx), _p(ws), ws.numel(),
+                                                _stream()), "evae_conv2d_bwd_data")
+        shp = wh.shape
+        gwh = dw[:d.Co].reshape(shp)
+        gwg = dw[d.Co:].reshape(shp) if gated else None
+        return (dx, gwh, db[:d.Co] if has_bh else None, gwg, (db[d.Co:] if (gated and has_bg) else None),
+                None, None, None, None, None)
+
+
+def conv2d(x, w, b, stride=1, padding=0, act=ACT_NONE, lo=0.0, hi=0.0):
+    return Conv2dFn.apply(x, w, b, None, None, _int1(stride), _int1(padding), act, lo, hi)
+
+
+def gated_conv2d(x, wh, bh, wg, bg, stride=1, padding=0):
+    return Conv2dFn.apply(x, wh, bh, wg, bg, _int1(stride), _int1(padding), ACT_NONE, 0.0, 0.0)
+
+
+# ------------------------------------------------------------------------------------------------
 # latent sampling / log-densities
 # ------------------------------------------------------------------------------------------------
 class ReparamLogQ(torch.autograd.Function):

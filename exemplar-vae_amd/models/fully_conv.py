@@ -6,6 +6,7 @@ import torch.nn as nn
 from torch.nn.utils import weight_norm
 
 from models.AbsModel import AbsModel
+from utils.nn import HipConv2d
 
 
 class block(nn.Module):
@@ -14,7 +15,7 @@ class block(nn.Module):
     def __init__(self, input_size, output_size, stride=1, kernel=3, padding=1):
         super().__init__()
         self.normalization = nn.BatchNorm2d(input_size)       # present in the state_dict, unused (as in the reference)
-        self.conv1 = weight_norm(nn.Conv2d(input_size, output_size, kernel_size=kernel, stride=stride,
+        self.conv1 = weight_norm(HipConv2d(input_size, output_size, kernel_size=kernel, stride=stride,
                                            padding=padding, bias=True))
         self.activation = torch.nn.ELU()
         self.f = torch.nn.Sequential(self.activation, self.conv1)
@@ -24,7 +25,7 @@ class block(nn.Module):
 
 
 def _wn_conv(cin, cout, stride=1):
-    return weight_norm(nn.Conv2d(in_channels=cin, out_channels=cout, kernel_size=3, stride=stride, padding=1))
+    return weight_norm(HipConv2d(in_channels=cin, out_channels=cout, kernel_size=3, stride=stride, padding=1))
 
 
 class VAE(AbsModel):
@@ -46,7 +47,7 @@ class VAE(AbsModel):
             *[block(cs * 2, cs * 2) for _ in range(6)],
             nn.Upsample(scale_factor=2), _wn_conv(cs * 2, cs), nn.ELU(), *[block(cs, cs) for _ in range(6)])
         if self.args.input_type == 'binary':
-            self.p_x_mean = nn.Sequential(nn.Conv2d(cs, c_in, kernel_size=3, stride=1, padding=1), nn.Sigmoid())
+            self.p_x_mean = nn.Sequential(HipConv2d(cs, c_in, kernel_size=3, stride=1, padding=1), nn.Sigmoid())
         elif self.args.input_type in ('gray', 'continuous'):
             self.p_x_mean = _wn_conv(cs, c_in)
-            self.p_x_logvar = nn.Conv2d(cs, c_in, kernel_size=3, stride=1, padding=1)
+            self.p_x_logvar = HipConv2d(cs, c_in, kernel_size=3, stride=1, padding=1)

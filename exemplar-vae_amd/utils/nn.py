@@ -1,10 +1,10 @@
 """Layer modules with the reference's names, constructor arguments and state_dict keys
 (reference utils/nn.py:12-114), computing through the HIP dense kernels (evae.ops).
 
-GatedDense / NonLinear / Linear run on the fp32-MFMA GEMM of libevae_hip.so with the bias,
-activation and gate fused into the epilogue.  GatedConv2d / Conv2d keep the reference interface; their
-convolutions currently go through MIOpen (torch.nn.functional.conv2d on the GPU) -- the fused
-implicit-GEMM HIP convolution is a later SURVEY section-8 row (a18), see DESIGN.md."""
+GatedDense / NonLinear / Linear run on the fp32-MFMA GEMM of libevae_hip.so with the bias, activation and
+gate fused into the epilogue.  GatedConv2d / Conv2d / HipConv2d run on the implicit-GEMM convolution kernels
+(csrc/evae_conv.hip: LDS-staged im2col + the same MFMA core; one pass over x computes both filter banks of a
+gated layer and applies the gate in the epilogue)."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -112,14 +112,13 @@ class GatedConv2d(nn.Module):
             self.activation = nn.ELU()
 
     def forward(self, x):
-        # one convolution over the concatenated [h | g] filters, then the gate
-        w = torch.cat((self.h.weight, self.g.weight), 0)
-        b = torch.cat((self.h.bias, self.g.bias), 0)
-        y = F.conv2d(x, w, b, self.h.stride, self.h.padding, self.h.dilation)
-        h, g = y.chunk(2, dim=1)
-        if self.activation is not None:
-            h = self.activation(h)
-        return h * torch.sigmoid(g)
+        assert self.h.dilation == (1, 1) and self.h.groups == 1
+        if self.activation is None:
+            # both filter banks in one implicit GEMM over x, gate applied in its epilogue
+            return ops.gated_conv2d(x, self.h.weight, self.h.bias, self.g.weight, self.g.bias,
+                                    self.h.stride, self.h.padding)
+        h = self.activation(ops.conv2d(x, self.h.weight, self.h.bias, self.h.stride, self.h.padding))
+        return h * ops.conv2d(x, self.g.weight, self.g.bias, self.g.stride, self.g.padding, ops.ACT_SIGMOID)
 
 
 class Conv2d(nn.Module):
@@ -130,5 +129,17 @@ class Conv2d(nn.Module):
         self.conv = nn.Conv2d(input_channels, output_channels, kernel_size, stride, padding, dilation, bias=bias)
 
     def forward(self, x):
-        h = self.conv(x)
-        return h if self.activation is None else self.activation(h)
+        c = self.conv
+        assert c.dilation == (1, 1) and c.groups == 1
+        code = _act_code(self.activation)
+        if code is None:
+            return self.activation(ops.conv2d(x, c.weight, c.bias, c.stride, c.padding))
+        return ops.conv2d(x, c.weight, c.bias, c.stride, c.padding, code[0], code[1], code[2])
+
+
+class HipConv2d(nn.Conv2d):
+    """torch.nn.Conv2d parameters / state_dict keys (weight-norm hooks included), forward on the HIP kernels."""
+
+    def forward(self, x):
+        assert self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == 'zeros'
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding)

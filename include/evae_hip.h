@@ -163,6 +163,32 @@ int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, int act, floa
                  float* dpre, evae_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Convolutions as implicit GEMMs on fp32 MFMA (LDS-staged im2col, never materialised).  Replace
+ * utils/nn.py:72-114 (GatedConv2d, Conv2d) and the nn.Conv2d layers of models/convHVAE_2level.py:13-92 and
+ * models/fully_conv.py:12-81, forward and backward.  Tensors are NCHW fp32 contiguous, filters keep the
+ * nn.Conv2d layout [Co x C x KH x KW]; square stride/padding, dilation 1, groups 1.
+ *   evae_conv2d_fwd:        out = act(conv(x, wh) + bh)                       (wg == NULL)
+ *                           out = act(conv(x, wh) + bh) * sigmoid(conv(x, wg) + bg), saving h and s
+ *   evae_conv2d_bwd_data:   dx = conv_transpose(dyh, wh) (+ conv_transpose(dyg, wg))
+ *   evae_conv2d_bwd_weight: dw [(1|2) Co x C*KH*KW] = dy^T im2col(x) for dyh (and dyg, stacked), db [(1|2) Co]
+ * `what` in the workspace query: 0 forward, 1 data gradient, 2 weight gradient.
+ */
+typedef struct {
+  int N, C, H, W;        /* input [N x C x H x W] */
+  int Co, KH, KW, stride, pad;
+} evae_conv_desc_t;
+size_t evae_conv2d_workspace_bytes(const evae_conv_desc_t* d, int what, int gated);
+int evae_conv2d_fwd(const float* x, const evae_conv_desc_t* d, const float* wh, const float* bh,
+                    const float* wg, const float* bg, int act, float act_lo, float act_hi,
+                    float* out, float* save_h, float* save_s, void* ws, size_t ws_bytes,
+                    evae_stream_t stream);
+int evae_conv2d_bwd_data(const float* dyh, const float* wh, const float* dyg, const float* wg,
+                         const evae_conv_desc_t* d, float* dx, void* ws, size_t ws_bytes,
+                         evae_stream_t stream);
+int evae_conv2d_bwd_weight(const float* dyh, const float* dyg, const float* x, const evae_conv_desc_t* d,
+                           float* dw, float* db, void* ws, size_t ws_bytes, evae_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Latent sampling and log-densities on [B x zdim] / [B x D] rows.
  * evae_reparam_logq: z = mu + eps*exp(logvar/2) (models/BaseModel.py:79-82, eps supplied by the
  *   caller's RNG) and log q(z|x) = log_normal_diag(z, mu, logvar) (utils/distributions.py:28-33).
