@@ -50,6 +50,9 @@ struct ConvArgs {
   float lo, hi;
   int tiles_m, tiles_n;
   int rows_per_bank;    // WGRAD: Co (row r >= Co reads dy_g)
+  // DGRAD: one GEMM per stride-parity class (blockIdx.z): an input pixel (ih, iw) only meets the taps with
+  // kh = (ih + pad) mod s (mod s), so each class has its own (shorter) tap list and permuted filter block
+  int cls_K[9], cls_tab[9], cls_w[9];
 };
 
 __device__ __forceinline__ void decomp_row(int m, int P, int OWW, int& n, int& y, int& x) {
@@ -102,9 +105,22 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_gemm_kernel(const ConvAr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nslab = (a.K + BK - 1) / BK;
+  int KK = a.K;                         // contraction length (per class in DGRAD)
+  const int* tabp = a.tab;
+  const float* w0p = a.w0;
+  int cls_py = 0, cls_px = 0, Hc = g.H, Wc = g.W, Mrows = a.M;
+  if (MODE == CONV_DGRAD) {
+    const int cls = blockIdx.z;
+    cls_py = cls / g.stride; cls_px = cls - cls_py * g.stride;
+    Hc = (g.H - cls_py + g.stride - 1) / g.stride;
+    Wc = (g.W - cls_px + g.stride - 1) / g.stride;
+    Mrows = g.N * Hc * Wc;
+    if (m0 >= Mrows) return;
+    KK = a.cls_K[cls]; tabp = a.tab + a.cls_tab[cls]; w0p = a.w0 + a.cls_w[cls];
+  }
+  const int nslab = (KK + BK - 1) / BK;
   int s_begin = 0, s_end = nslab;
-  if (a.ksplit > 0) {
+  if (a.ksplit > 0 && MODE != CONV_DGRAD) {
     s_begin = blockIdx.z * a.ksplit;
     int e = s_begin + a.ksplit;
     if (e < s_end) s_end = e;
@@ -121,9 +137,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_gemm_kernel(const ConvAr
     if (MODE == CONV_FWD) {            // row = output pixel (n, oh, ow)
       ar_ok = m < a.M;
       if (ar_ok) { decomp_row(m, P, g.OW, ar_n, ar_y, ar_x); ar_y = ar_y * g.stride - g.pad; ar_x = ar_x * g.stride - g.pad; }
-    } else if (MODE == CONV_DGRAD) {   // row = input pixel (n, ih, iw)
-      ar_ok = m < a.M;
-      if (ar_ok) { decomp_row(m, HW, g.W, ar_n, ar_y, ar_x); ar_y += g.pad; ar_x += g.pad; }
+    } else if (MODE == CONV_DGRAD) {   // row = input pixel (n, ih, iw) of this parity class
+      ar_ok = m < Mrows;
+      if (ar_ok) {
+        decomp_row(m, Hc * Wc, Wc, ar_n, ar_y, ar_x);
+        ar_y = ar_y * g.stride + cls_py + g.pad; ar_x = ar_x * g.stride + cls_px + g.pad;
+      }
     } else {                           // WGRAD: row = output channel of bank 0/1
       ar_ok = m < a.M;
     }
@@ -134,7 +153,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_gemm_kernel(const ConvAr
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = k0 + akq + j;
-      bool ok = ar_ok && k < a.K;
+      bool ok = ar_ok && k < KK;
       size_t addr = 0;
       const float* src = a.src0;
       if (MODE == CONV_FWD) {
@@ -144,16 +163,13 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_gemm_kernel(const ConvAr
         ok = ok && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
         addr = ok ? ((size_t)(ar_n * g.C + c) * HW + y * g.W + x) : 0;
       } else if (MODE == CONV_DGRAD) {
-        const int t = ok ? a.tab[k] : 0;
+        const int t = ok ? tabp[k] : 0;
         int c = t >> 16;
         const int kh = (t >> 8) & 255, kw = t & 255;
         if (c >= g.Co) { c -= g.Co; src = a.src1; }
-        int yy = ar_y - kh, xx = ar_x - kw;
+        int yy = ar_y - kh, xx = ar_x - kw;      // multiples of the stride by construction of the class
         ok = ok && yy >= 0 && xx >= 0;
-        if (g.stride != 1) {
-          ok = ok && (yy % g.stride == 0) && (xx % g.stride == 0);
-          yy /= g.stride; xx /= g.stride;
-        }
+        if (g.stride != 1) { yy /= g.stride; xx /= g.stride; }
         ok = ok && yy < g.OH && xx < g.OW;
         addr = ok ? ((size_t)(ar_n * g.Co + c) * P + yy * g.OW + xx) : 0;
       } else {                          // WGRAD: A[row = co'][k = m]: dy in NCHW, m = (n, pix)
@@ -242,14 +258,14 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_gemm_kernel(const ConvAr
         const int f = tid + GNT * i;
         const int k = k0 + f / RQ;
         const int c = n0 + 4 * (f % RQ);
-        const bool ok = k < a.K && (c + 4 <= a.Ncols);
+        const bool ok = k < KK && (c + 4 <= a.Ncols);
         if ((a.Ncols & 3) == 0) {
-          r.v[i] = *reinterpret_cast<const float4*>(a.w0 + (size_t)(ok ? k : 0) * a.Ncols + (ok ? c : 0));
+          r.v[i] = *reinterpret_cast<const float4*>(w0p + (size_t)(ok ? k : 0) * a.Ncols + (ok ? c : 0));
           r.mask |= (ok ? 15u : 0u) << (4 * i);
         } else {                                   // C = 1 or 3: element-wise
           float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (k < a.K) {
-            const float* p = a.w0 + (size_t)k * a.Ncols;
+          if (k < KK) {
+            const float* p = w0p + (size_t)k * a.Ncols;
             if (c + 0 < a.Ncols) t.x = p[c + 0];
             if (c + 1 < a.Ncols) t.y = p[c + 1];
             if (c + 2 < a.Ncols) t.z = p[c + 2];
@@ -336,17 +352,22 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_gemm_kernel(const ConvAr
   const int PO = (MODE == CONV_FWD) ? P : HW;
   const int CO = a.Ncols;
   const int mbase = m0 + wr * 32 * MT;
-  int nb = mbase / PO;
-  int pb = mbase - nb * PO;
+  const int PC = (MODE == CONV_DGRAD) ? Hc * Wc : PO;   // rows per image in this launch's row space
+  int nb = mbase / PC;
+  int pb = mbase - nb * PC;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int d = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const int m = mbase + d;
-      if (m >= a.M) continue;
+      if (m >= Mrows) continue;
       int n = nb, pix = pb + d;
-      while (pix >= PO) { pix -= PO; ++n; }
+      while (pix >= PC) { pix -= PC; ++n; }
+      if (MODE == CONV_DGRAD && g.stride != 1) {           // class-local (y', x') -> input pixel
+        const int yc = pix / Wc, xc = pix - yc * Wc;
+        pix = (yc * g.stride + cls_py) * g.W + xc * g.stride + cls_px;
+      }
       if (GATED) {
         const int co = n0 + wc * 32 + l31;
         if (co < CO) {
@@ -383,18 +404,29 @@ __global__ void conv_tab_kernel(int* __restrict__ tab, int K, int KHKW, int KW) 
   tab[k] = (c << 16) | (kh << 8) | kw;
 }
 
-// W' [pair*Co*KH*KW + (co, kh, kw)][ci] = W_pair[co][ci][kh][kw]
-__global__ void conv_permute_w_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int Co, int C,
-                                      int KHKW, float* __restrict__ wp) {
-  const int per = Co * C * KHKW;
+// data-gradient tap table of one stride-parity class: k = (c, i, j) -> (c << 16 | kh << 8 | kw) with
+// kh = rh + i*s, kw = rw + j*s; c = pair*Co + co
+__global__ void conv_tab_class_kernel(int* __restrict__ tab, int K, int nkh, int nkw, int rh, int rw, int s) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const int per = nkh * nkw;
+  const int c = k / per, r = k - c * per, i = r / nkw, j = r - i * nkw;
+  tab[k] = (c << 16) | ((rh + i * s) << 8) | (rw + j * s);
+}
+
+// W'[k][ci] = W_pair[co][ci][kh][kw] for the taps listed in tab (c = pair*Co + co)
+__global__ void conv_permute_w_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                      const int* __restrict__ tab, int K, int Co, int C, int KH, int KW,
+                                      float* __restrict__ wp) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int total = per * (w1 ? 2 : 1);
-  if (i >= total) return;
-  const int pair = i / per, j = i - pair * per;
-  const int ci = j % C, rest = j / C;             // rest = co*KHKW + khw
-  const int co = rest / KHKW, khw = rest - co * KHKW;
-  const float* w = pair ? w1 : w0;
-  wp[i] = w[((size_t)co * C + ci) * KHKW + khw];
+  if (i >= K * C) return;
+  const int k = i / C, ci = i - k * C;
+  const int t = tab[k];
+  int c = t >> 16;
+  const int kh = (t >> 8) & 255, kw = t & 255;
+  const float* w = w0;
+  if (c >= Co) { c -= Co; w = w1; }
+  wp[i] = w[(((size_t)c * C + ci) * KH + kh) * KW + kw];
 }
 
 static bool geom_ok(const evae_conv_desc_t* d, ConvGeom* g) {
@@ -485,19 +517,36 @@ extern "C" int evae_conv2d_bwd_data(const float* dyh, const float* wh, const flo
   }
   const int khw = g.KH * g.KW;
   const int Kd = g.Co * khw * (gated ? 2 : 1);
+  const int ctot = g.Co * (gated ? 2 : 1);
   int* tab = (int*)ws;
   float* wp = (float*)((char*)ws + align_up((size_t)Kd * sizeof(int), 256));
-  conv_tab_kernel<<<cdiv(Kd, 256), 256, 0, stream>>>(tab, Kd, khw, g.KW);   // c field = pair*Co + co
-  int rc = check_launch("conv_tab");
-  if (rc) return rc;
-  conv_permute_w_kernel<<<cdiv(Kd * g.C, 256), 256, 0, stream>>>(wh, wg, g.Co, g.C, khw, wp);
-  rc = check_launch("conv_permute_w");
-  if (rc) return rc;
+  EVAE_REQUIRE(g.stride <= 3, "conv2d_bwd_data: stride %d > 3 unsupported", g.stride);
   ConvArgs a = {};
   a.g = g; a.src0 = dyh; a.src1 = dyg ? dyg : dyh; a.w0 = wp; a.tab = tab; a.out0 = dx;
-  a.M = g.N * g.H * g.W; a.Ncols = g.C; a.K = Kd;
-  if (g.C > 64) return launch_conv<CONV_DGRAD, CEPI_DX, 128>(a, 1, stream, "conv2d_bwd_data");
-  return launch_conv<CONV_DGRAD, CEPI_DX, 64>(a, 1, stream, "conv2d_bwd_data");
+  a.M = g.N * cdiv(g.H, g.stride) * cdiv(g.W, g.stride);   // rows of the largest class (0, 0)
+  a.Ncols = g.C; a.K = Kd;
+  int off = 0, rc = 0;
+  const int ncls = g.stride * g.stride;
+  for (int cls = 0; cls < ncls; ++cls) {
+    const int py = cls / g.stride, px = cls % g.stride;
+    const int rh = (py + g.pad) % g.stride, rw = (px + g.pad) % g.stride;
+    const int nkh = rh < g.KH ? (g.KH - rh + g.stride - 1) / g.stride : 0;
+    const int nkw = rw < g.KW ? (g.KW - rw + g.stride - 1) / g.stride : 0;
+    const int Kc = ctot * nkh * nkw;
+    a.cls_K[cls] = Kc; a.cls_tab[cls] = off; a.cls_w[cls] = off * g.C;
+    if (Kc > 0) {
+      conv_tab_class_kernel<<<cdiv(Kc, 256), 256, 0, stream>>>(tab + off, Kc, nkh, nkw, rh, rw, g.stride);
+      rc = check_launch("conv_tab_class");
+      if (rc) return rc;
+      conv_permute_w_kernel<<<cdiv(Kc * g.C, 256), 256, 0, stream>>>(wh, wg, tab + off, Kc, g.Co, g.C, g.KH, g.KW,
+                                                                   wp + (size_t)off * g.C);
+      rc = check_launch("conv_permute_w");
+      if (rc) return rc;
+    }
+    off += Kc;
+  }
+  if (g.C > 64) return launch_conv<CONV_DGRAD, CEPI_DX, 128>(a, ncls, stream, "conv2d_bwd_data");
+  return launch_conv<CONV_DGRAD, CEPI_DX, 64>(a, ncls, stream, "conv2d_bwd_data");
 }
 
 extern "C" int evae_conv2d_bwd_weight(const float* dyh, const float* dyg, const float* x,
