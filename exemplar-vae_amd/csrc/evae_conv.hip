@@ -323,14 +323,27 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_gemm_kernel(const ConvAr
     __syncthreads();
     for (int s = s_begin; s < s_end; ++s) {
       const int cur = (s - s_begin) & 1;
-      mma_slab<true, B_KC, MT, NT, BN_, 0, 1>(acc, As(cur), Bs(cur), wr, wc, lane);
+      Frag<MT, NT> f0, f1;
+      load_frag<true, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 0);
+      load_frag<true, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_frag<MT, NT>(acc, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frag<true, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 2);
       if (s + 1 < s_end) { store_a(As(cur ^ 1), ra); store_b(Bs(cur ^ 1), rb); }
       if (s + 2 < s_end) { ra = gather_a((s + 2) * BK); rb = load_b((s + 2) * BK); }
-      mma_slab<true, B_KC, MT, NT, BN_, 1, 4>(acc, As(cur), Bs(cur), wr, wc, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_frag<MT, NT>(acc, f1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frag<true, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_frag<MT, NT>(acc, f0);
+      mma_frag<MT, NT>(acc, f1);
       __syncthreads();
     }
   }
 
+  mma_drain();
   // ---- epilogue -------------------------------------------------------------------------------------------
   const int l31 = lane & 31, lh = lane >> 5;
   if (EPI == CEPI_RAW) {                 // weight gradient partials [z][rows][Ncols]

@@ -25,6 +25,7 @@
 //   Workgroup ids are remapped so that each XCD owns a contiguous run of tiles (shared A row-panels
 //   stay in one L2).
 #include "evae_gemm_core.h"
+#include <type_traits>
 
 namespace evae {
 
@@ -66,6 +67,26 @@ __device__ __forceinline__ float4 ld4s(const float* p, int valid) {
   if (valid > 2) v.z = p[2];
   if (valid > 3) v.w = p[3];
   return v;
+}
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// Raw buffer resource over a wave-uniform pointer (stride 0, DATA_FORMAT = 32-bit): offsets at or beyond
+// num_records read as zero, which is how tails and out-of-matrix rows are blanked without any VALU work.
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned num_records) {
+  const uintptr_t u = (uintptr_t)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, num_records, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(rsrc_t r, unsigned voff, unsigned soff) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  const f32x4 v = __builtin_bit_cast(f32x4, u);   // (component access on the integer vector degrades to a dword load)
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ unsigned buf_ld1(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
 }
 
 // ---- tile loader: ROWS x BK floats per K-slab, NV float4 per thread -------------------------------
@@ -172,6 +193,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
 
+  const long long dbg_c0 = __builtin_readcyclecounter(), dbg_w0 = wall_clock64();
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -191,86 +213,350 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
     if (e < s_end) s_end = e;
   }
 
-  typedef TileLoader<BM, A_KC, GNT> LA;
-  typedef TileLoader<BN_, B_KC, GNT> LB;
-  LA la[2];
-  LB lb[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    if (p < g.npairs) {
-      la[p].init(g.A[p], g.lda[p], m0, g.M, g.a_rows);
-      if (!GATED) lb[p].init(g.B[p], g.ldb[p], n0, g.N, nullptr);
-    }
-  }
-  // gated B tile: LDS row r -> weight row n0 + (r>>6)*32 + (r&31) of (r&32 ? Bg : B[0])
-  const float* gb_base[LB::NV];
-  bool gb_ok[LB::NV];
-  if (GATED) {
-#pragma unroll
-    for (int i = 0; i < LB::NV; ++i) {
-      int f = threadIdx.x + GNT * i;
-      int r = f >> 3;
-      int n = n0 + (r >> 6) * 32 + (r & 31);
-      gb_ok[i] = n < g.N;
-      const float* w = (r & 32) ? g.Bg : g.B[0];
-      gb_base[i] = w + (size_t)(gb_ok[i] ? n : 0) * g.ldb[0] + 4 * (f & 7);
-    }
-  }
+  if constexpr (VEC) {
+    // ---- fast path: every extent a multiple of 4, non-gathered operands below 2 GiB.  The slab loop
+    // holds almost no VALU work (measured: each VALU instruction costs the matrix pipe its 4 issue
+    // cycles): non-gathered tiles come through buffer loads -- per-thread byte offset fixed at kernel
+    // start, the slab offset in an SGPR, rows/columns outside the matrix and the K tail parked on an
+    // out-of-range offset that the hardware returns as zero -- so nothing is masked afterwards.
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NVA = BM * BK / 4 / GNT, NVB = BN_ * BK / 4 / GNT;
+    constexpr int RQA = BM / 4, RQB = BN_ / 4, RSA = BM + 4, RSB = BN_ + 4;
+    constexpr bool PAIRS = A_KC && !B_KC;   // only the data gradient chains two (A,B) pairs
+    const bool gatherA = A_KC && g.a_rows != nullptr;
+    const bool gatherB = !B_KC && g.b_krows != nullptr;
+    const bool has_ones = !B_KC && g.ones_col >= n0 && g.ones_col < n0 + BN_;
+    const rsrc_t rA0 = make_rsrc(g.A[0], 0x7FFFFFFFu);
+    const rsrc_t rA1 = make_rsrc(PAIRS && g.npairs > 1 ? g.A[1] : g.A[0], 0x7FFFFFFFu);
+    const rsrc_t rB0 = make_rsrc(g.B[0], 0x7FFFFFFFu);
+    const rsrc_t rB1 = make_rsrc(GATED ? g.Bg : (PAIRS && g.npairs > 1 ? g.B[1] : g.B[0]), 0x7FFFFFFFu);
+    const rsrc_t rIdx = make_rsrc(gatherB ? (const void*)g.b_krows : (const void*)g.B[0],
+                                  gatherB ? (unsigned)g.Kc[0] * 8u : 0u);
+    const bool wave_upper = (__builtin_amdgcn_readfirstlane(threadIdx.x) & 256) != 0;
 
-  auto load_slab = [&](int s, float4 (&ra)[LA::NV], float4 (&rb)[LB::NV], unsigned& ma, unsigned& mb) {
-    const int p = (s < nslab[0]) ? 0 : 1;
-    const int k0 = (p == 0 ? s : s - nslab[0]) * BK;
-    const int kend = g.Kc[p];
-    if (A_KC) ma = la[p].template load_kc<VEC>(ra, k0, kend);
-    else ma = la[p].template load_rc<VEC>(ra, g.A[p], g.lda[p], m0, g.M, k0, kend, nullptr, -1);
-    if (GATED) {
-      mb = 0;
+    unsigned voA[PAIRS ? 2 : 1][NVA], voB[PAIRS ? 2 : 1][NVB];
+    const float* gpA[NVA];
+    const float* gpB[NVB];
+    unsigned kidx[NVB];
+    bool onesB[NVB];
 #pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+      const int f = threadIdx.x + GNT * i;
+      gpA[i] = g.A[0];
+      if (A_KC) {
+        const int r = m0 + (f >> 3);
+        const bool ok = r < g.M;
+        if (gatherA) {
+          gpA[i] = g.A[0] + (size_t)g.a_rows[ok ? r : m0] * g.lda[0] + 4 * (f & 7);
+        }
+#pragma unroll
+        for (int p = 0; p < (PAIRS ? 2 : 1); ++p)
+          voA[p][i] = ok ? (unsigned)(r * g.lda[p] + 4 * (f & 7)) * 4u : OOB;
+      } else {
+        const int c = m0 + 4 * (f % RQA);
+        voA[0][i] = (c + 4 <= g.M) ? (unsigned)((f / RQA) * g.lda[0] + c) * 4u : OOB;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      const int f = threadIdx.x + GNT * i;
+      gpB[i] = g.B[0];
+      onesB[i] = false;
+      kidx[i] = 0;
+      if (GATED) {
+        const int r = f >> 3;
+        const int n = n0 + (r >> 6) * 32 + (r & 31);
+        voB[0][i] = (n < g.N) ? (unsigned)(n * g.ldb[0] + 4 * (f & 7)) * 4u : OOB;
+      } else if (B_KC) {
+        const int n = n0 + (f >> 3);
+        voB[0][i] = (n < g.N) ? (unsigned)(n * g.ldb[0] + 4 * (f & 7)) * 4u : OOB;
+      } else {
+        const int c = n0 + 4 * (f % RQB);
+        const int nlim = g.ones_col >= 0 ? g.ones_col : g.N;
+        const bool ok = c + 4 <= nlim;
+        onesB[i] = (c == g.ones_col);
+        if (gatherB) gpB[i] = g.B[0] + (ok ? c : 0);
+#pragma unroll
+        for (int p = 0; p < (PAIRS ? 2 : 1); ++p)
+          voB[p][i] = ok ? (unsigned)((f / RQB) * g.ldb[p] + c) * 4u : OOB;
+      }
+    }
+    if (gatherB) {
+#pragma unroll
+      for (int i = 0; i < NVB; ++i)
+        kidx[i] = buf_ld1(rIdx, (unsigned)(s_begin * BK + (threadIdx.x + GNT * i) / RQB) * 8u, 0u);
+    }
+
+    // The slab loop must not branch around memory instructions: the compiler's s_waitcnt bookkeeping
+    // merges pessimistically at every join, and a "vmcnt(0)" in front of the B loads then waits for the
+    // A loads issued a few cycles earlier -- a full memory latency per slab with the matrix pipe idle
+    // (measured: 15 % of the kernel).  So gather / plain operands are compile-time variants of the
+    // loop (GA, GB), the two (A,B) pairs of the data gradient are selected with scalar selects, and
+    // the last two slabs (nothing left to store / load) are peeled off as compile-time variants too.
+    // kv = valid contraction rows of a slab (>= BK: full slab).
+    auto run = [&](auto GA_, auto GB_) {
+      constexpr bool GA = decltype(GA_)::value, GB = decltype(GB_)::value;
+      auto load_a = [&](int s, float4 (&ra)[NVA], int& kv) {
+        const bool p1 = PAIRS && s >= nslab[0];
+        const int k0 = (p1 ? s - nslab[0] : s) * BK;
+        kv = (p1 ? g.Kc[1] : g.Kc[0]) - k0;
+        const bool tail = kv < BK;
+        if constexpr (GA) {
+#pragma unroll
+          for (int i = 0; i < NVA; ++i) {
+            const int kc = 4 * ((threadIdx.x + GNT * i) & 7);
+            ra[i] = ld4v(gpA[i] + ((tail && kc + 4 > kv) ? -kc : k0));
+          }
+        } else {
+          const rsrc_t rA = p1 ? rA1 : rA0;
+          const unsigned so = A_KC ? (unsigned)k0 * 4u : (unsigned)(k0 * (p1 ? g.lda[1] : g.lda[0])) * 4u;
+#pragma unroll
+          for (int i = 0; i < NVA; ++i) {
+            const int f = threadIdx.x + GNT * i;
+            const bool dead = tail && (A_KC ? 4 * (f & 7) + 4 > kv : f / RQA >= kv);
+            const unsigned vo = (PAIRS && p1) ? voA[PAIRS ? 1 : 0][i] : voA[0][i];
+            ra[i] = buf_ld4(rA, dead ? OOB : vo, so);
+          }
+        }
+      };
+      auto load_b = [&](int s, float4 (&rb)[NVB], int& kv) {
+        const bool p1 = PAIRS && s >= nslab[0];
+        const int k0 = (p1 ? s - nslab[0] : s) * BK;
+        kv = (p1 ? g.Kc[1] : g.Kc[0]) - k0;
+        const bool tail = kv < BK;
+        if constexpr (GB) {
+#pragma unroll
+          for (int i = 0; i < NVB; ++i) rb[i] = ld4v(gpB[i] + (size_t)kidx[i] * g.ldb[0]);
+#pragma unroll
+          for (int i = 0; i < NVB; ++i)   // indices of the slab after this one (past the end -> 0)
+            kidx[i] = buf_ld1(rIdx, (unsigned)(k0 + BK + (threadIdx.x + GNT * i) / RQB) * 8u, 0u);
+        } else {
+          const unsigned so = B_KC ? (unsigned)k0 * 4u : (unsigned)(k0 * (p1 ? g.ldb[1] : g.ldb[0])) * 4u;
+#pragma unroll
+          for (int i = 0; i < NVB; ++i) {
+            const int f = threadIdx.x + GNT * i;
+            const bool dead = tail && (B_KC ? 4 * (f & 7) + 4 > kv : f / RQB >= kv);
+            const bool up = GATED ? ((GNT == 512) ? wave_upper : ((i & 1) != 0)) : p1;
+            const unsigned vo = (PAIRS && p1) ? voB[PAIRS ? 1 : 0][i] : voB[0][i];
+            rb[i] = buf_ld4(up ? rB1 : rB0, dead ? OOB : vo, so);
+          }
+        }
+      };
+      auto store_a = [&](int buf, float4 (&ra)[NVA], int kv) {
+        float* at = As(buf);
+        if (GA && kv < BK) {
+#pragma unroll
+          for (int i = 0; i < NVA; ++i)
+            if (4 * ((threadIdx.x + GNT * i) & 7) + 4 > kv) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+          const int f = threadIdx.x + GNT * i;
+          if (A_KC) *reinterpret_cast<float4*>(at + (f >> 3) * KS + 4 * (f & 7)) = ra[i];
+          else      *reinterpret_cast<float4*>(at + (f / RQA) * RSA + 4 * (f % RQA)) = ra[i];
+        }
+      };
+      auto store_b = [&](int buf, float4 (&rb)[NVB], int kv) {
+        float* bt = Bs(buf);
+        if (GB && kv < BK) {
+#pragma unroll
+          for (int i = 0; i < NVB; ++i)
+            if ((threadIdx.x + GNT * i) / RQB >= kv) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (has_ones) {
+#pragma unroll
+          for (int i = 0; i < NVB; ++i)
+            if (onesB[i]) rb[i] = make_float4((threadIdx.x + GNT * i) / RQB < kv ? 1.f : 0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+          const int f = threadIdx.x + GNT * i;
+          if (B_KC) *reinterpret_cast<float4*>(bt + (f >> 3) * KS + 4 * (f & 7)) = rb[i];
+          else      *reinterpret_cast<float4*>(bt + (f / RQB) * RSB + 4 * (f % RQB)) = rb[i];
+        }
+      };
+
+      float4 ra[NVA], rb[NVB];
+      int kva = 0, kvb = 0;
+      load_a(s_begin, ra, kva);
+      load_b(s_begin, rb, kvb);
+      store_a(0, ra, kva);
+      store_b(0, rb, kvb);
+      if (s_begin + 1 < s_end) { load_a(s_begin + 1, ra, kva); load_b(s_begin + 1, rb, kvb); }
+      __syncthreads();
+      // Schedule of one slab (per wave).  Memory instructions are slotted one by one between the MFMAs
+      // of the same wave: a wave has only MT*NT independent accumulator chains, so after MT*NT MFMAs
+      // it stalls on the dependency anyway and whatever issues in that shadow is free.  The barrier sits
+      // before the last k-group, whose fragments are already in registers, and the first fragments of
+      // the next slab are requested right behind it.
+      Frag<MT, NT> f0, f1;
+      load_frag<A_KC, B_KC, MT, NT, BN_>(f0, As(0), Bs(0), wr, wc, lane, 0);
+#define EVAE_SB __builtin_amdgcn_sched_barrier(0)
+      // ST: the registers hold slab s+1 -> write it to the idle LDS buffer; LD: fetch slab s+2; NX: slab s+1 exists
+      auto slab = [&](int s, auto ST_, auto LD_, auto NX_) {
+        constexpr bool ST = decltype(ST_)::value, LD = decltype(LD_)::value, NX = decltype(NX_)::value;
+        const int cur = (s - s_begin) & 1;
+        EVAE_SB; mma_step<MT, NT>(acc, f0, 0); EVAE_SB;
+        load_frag<A_KC, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 1);
+        if constexpr (ST) store_a(cur ^ 1, ra, kva);
+        EVAE_SB; mma_step<MT, NT>(acc, f0, 1); EVAE_SB;
+        if constexpr (ST) store_b(cur ^ 1, rb, kvb);
+        EVAE_SB; mma_step<MT, NT>(acc, f0, 2); EVAE_SB;
+        if constexpr (LD) load_a(s + 2, ra, kva);
+        EVAE_SB; mma_step<MT, NT>(acc, f0, 3); EVAE_SB;
+        if constexpr (LD) load_b(s + 2, rb, kvb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          EVAE_SB; mma_step<MT, NT>(acc, f1, q); EVAE_SB;
+          if (q < MT + NT) load_frag_part<A_KC, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 2, q);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          EVAE_SB; mma_step<MT, NT>(acc, f0, q); EVAE_SB;
+          if (q < MT + NT) load_frag_part<A_KC, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 3, q);
+        }
+        EVAE_SB;
+        __syncthreads();
+        EVAE_SB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          mma_step<MT, NT>(acc, f1, q); EVAE_SB;
+          if constexpr (NX) {
+            if (q < MT + NT) load_frag_part<A_KC, B_KC, MT, NT, BN_>(f0, As(cur ^ 1), Bs(cur ^ 1), wr, wc, lane, 0, q);
+          }
+          EVAE_SB;
+        }
+      };
+      constexpr std::true_type T{};
+      constexpr std::false_type F{};
+      int s = s_begin;
+      for (; s + 2 < s_end; ++s) slab(s, T, T, T);
+      if (s + 1 < s_end) { slab(s, T, F, T); ++s; }
+      slab(s, F, F, F);
+#undef EVAE_SB
+    };
+    if (s_begin < s_end) {
+      if (gatherA) run(std::true_type{}, std::false_type{});
+      else if (gatherB) run(std::false_type{}, std::true_type{});
+      else run(std::false_type{}, std::false_type{});
+    }
+  } else {
+    typedef TileLoader<BM, A_KC, GNT> LA;
+    typedef TileLoader<BN_, B_KC, GNT> LB;
+    LA la[2];
+    LB lb[2];
+  #pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (p < g.npairs) {
+        la[p].init(g.A[p], g.lda[p], m0, g.M, g.a_rows);
+        if (!GATED) lb[p].init(g.B[p], g.ldb[p], n0, g.N, nullptr);
+      }
+    }
+    // gated B tile: LDS row r -> weight row n0 + (r>>6)*32 + (r&31) of (r&32 ? Bg : B[0])
+    const float* gb_base[LB::NV];
+    bool gb_ok[LB::NV];
+    if (GATED) {
+  #pragma unroll
       for (int i = 0; i < LB::NV; ++i) {
         int f = threadIdx.x + GNT * i;
-        int k = k0 + 4 * (f & 7);
-        if (VEC) {
-          const bool ok = gb_ok[i] && (k + 4 <= kend);
-          rb[i] = ld4v(gb_base[i] + (ok ? k0 : -4 * (f & 7)));
-          mb |= (ok ? 1u : 0u) << (2 * i);
-        } else {
-          rb[i] = ld4s(gb_base[i] + k0, gb_ok[i] ? (kend - k) : 0);
-          mb |= 1u << (2 * i);
-        }
+        int r = f >> 3;
+        int n = n0 + (r >> 6) * 32 + (r & 31);
+        gb_ok[i] = n < g.N;
+        const float* w = (r & 32) ? g.Bg : g.B[0];
+        gb_base[i] = w + (size_t)(gb_ok[i] ? n : 0) * g.ldb[0] + 4 * (f & 7);
       }
-    } else if (B_KC) {
-      mb = lb[p].template load_kc<VEC>(rb, k0, kend);
-    } else {
-      mb = lb[p].template load_rc<VEC>(rb, g.B[p], g.ldb[p], n0, g.ones_col >= 0 ? g.ones_col : g.N, k0, kend, g.b_krows, g.ones_col);
     }
-  };
 
-  // Pipeline: registers always hold the slab AFTER the one being multiplied.  Its global loads were
-  // issued a whole slab earlier; they are written to the idle LDS buffer after the first k-group of
-  // MFMAs and the loads of the slab after that are issued right behind, so VMEM latency, the LDS
-  // stores and their address arithmetic all sit in the shadow of the 64-cycle MFMAs.
-  if (s_begin < s_end) {
-    float4 ra[LA::NV], rb[LB::NV];
-    unsigned ma, mb;
-    load_slab(s_begin, ra, rb, ma, mb);
-    la[0].store(As(0), ra, ma);
-    lb[0].store(Bs(0), rb, mb);
-    if (s_begin + 1 < s_end) load_slab(s_begin + 1, ra, rb, ma, mb);
-    __syncthreads();
-    const bool dbg_nobar = g.dbg & 1, dbg_nomem = g.dbg & 2;
-    for (int s = s_begin; s < s_end; ++s) {
-      const int cur = (s - s_begin) & 1;
-      mma_slab<A_KC, B_KC, MT, NT, BN_, 0, 1>(acc, As(cur), Bs(cur), wr, wc, lane);
-      if (s + 1 < s_end && !dbg_nomem) {
-        la[0].store(As(cur ^ 1), ra, ma);
-        lb[0].store(Bs(cur ^ 1), rb, mb);
+    auto load_slab = [&](int s, float4 (&ra)[LA::NV], float4 (&rb)[LB::NV], unsigned& ma, unsigned& mb) {
+      const int p = (s < nslab[0]) ? 0 : 1;
+      const int k0 = (p == 0 ? s : s - nslab[0]) * BK;
+      const int kend = g.Kc[p];
+      if (A_KC) ma = la[p].template load_kc<VEC>(ra, k0, kend);
+      else ma = la[p].template load_rc<VEC>(ra, g.A[p], g.lda[p], m0, g.M, k0, kend, nullptr, -1);
+      if (GATED) {
+        mb = 0;
+  #pragma unroll
+        for (int i = 0; i < LB::NV; ++i) {
+          int f = threadIdx.x + GNT * i;
+          int k = k0 + 4 * (f & 7);
+          if (VEC) {
+            const bool ok = gb_ok[i] && (k + 4 <= kend);
+            rb[i] = ld4v(gb_base[i] + (ok ? k0 : -4 * (f & 7)));
+            mb |= (ok ? 1u : 0u) << (2 * i);
+          } else {
+            rb[i] = ld4s(gb_base[i] + k0, gb_ok[i] ? (kend - k) : 0);
+            mb |= 1u << (2 * i);
+          }
+        }
+      } else if (B_KC) {
+        mb = lb[p].template load_kc<VEC>(rb, k0, kend);
+      } else {
+        mb = lb[p].template load_rc<VEC>(rb, g.B[p], g.ldb[p], n0, g.ones_col >= 0 ? g.ones_col : g.N, k0, kend, g.b_krows, g.ones_col);
       }
-      if (s + 2 < s_end && !dbg_nomem) load_slab(s + 2, ra, rb, ma, mb);
-      mma_slab<A_KC, B_KC, MT, NT, BN_, 1, 4>(acc, As(cur), Bs(cur), wr, wc, lane);
-      if (!dbg_nobar) __syncthreads();
+    };
+
+    // Pipeline: registers always hold the slab AFTER the one being multiplied.  Its global loads were
+    // issued a whole slab earlier; they are written to the idle LDS buffer after the first k-group of
+    // MFMAs and the loads of the slab after that are issued right behind, so VMEM latency, the LDS
+    // stores and their address arithmetic all sit in the shadow of the 64-cycle MFMAs.
+    if (s_begin < s_end) {
+      float4 ra[LA::NV], rb[LB::NV];
+      unsigned ma, mb;
+      load_slab(s_begin, ra, rb, ma, mb);
+      la[0].store(As(0), ra, ma);
+      lb[0].store(Bs(0), rb, mb);
+      if (s_begin + 1 < s_end) load_slab(s_begin + 1, ra, rb, ma, mb);
+      __syncthreads();
+      const bool dbg_nobar = g.dbg & 1, dbg_nomem = g.dbg & 2;
+      for (int s = s_begin; s < s_end; ++s) {
+        const int cur = (s - s_begin) & 1;
+        Frag<MT, NT> f0, f1;
+        load_frag<A_KC, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 0);
+        load_frag<A_KC, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag<MT, NT>(acc, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag<A_KC, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 2);
+        if (s + 1 < s_end && !dbg_nomem) {
+          la[0].store(As(cur ^ 1), ra, ma);
+          lb[0].store(Bs(cur ^ 1), rb, mb);
+        }
+        if (s + 2 < s_end && !dbg_nomem) load_slab(s + 2, ra, rb, ma, mb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag<MT, NT>(acc, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag<A_KC, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag<MT, NT>(acc, f0);
+        mma_frag<MT, NT>(acc, f1);
+        if (!dbg_nobar) __syncthreads();
+      }
     }
+
   }
 
+  mma_drain();
+  if ((g.dbg & 512) && g.out2) {   // clock probe: shader-clock ticks vs the constant 100 MHz counter over this block's main loop
+    const long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 5) {
+      float* d = g.out2 + (size_t)(g.M - 1) * g.ldo;   // last row of the save_s output (overwritten, debug only)
+      atomicAdd(d + 0, (float)(c1 - dbg_c0));
+      atomicAdd(d + 1, (float)(w1 - dbg_w0));
+      atomicAdd(d + 2, 1.0f);
+    }
+    return;
+  }
+  if (g.dbg & 4) {           // ablation: no epilogue (the accumulators stay live through an impossible store)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 1.2345e-30f) g.out0[0] = t;
+    return;
+  }
   // ---- epilogue.  acc[mt][nt][r] <-> row m0 + wr*32*MT + mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
   //                                    col (within the wave tile) nt*32 + (lane&31)
   const int l31 = lane & 31, lh = lane >> 5;
@@ -372,6 +658,15 @@ static bool gemm_vec_ok(const GemmArgs& g) {
   if (!A_KC) ok = ok && (g.M % 4 == 0);
   if (!B_KC) ok = ok && ((g.ones_col >= 0 ? g.ones_col : g.N) % 4 == 0);
   if (g.Bg) ok = ok && al16(g.Bg);
+  // buffer-load offsets of the fast path are 31-bit byte offsets (gathered operands use 64-bit pointers)
+  const int64_t lim = (int64_t)1 << 29;   // floats
+  const int Bn = (!B_KC && g.ones_col >= 0) ? g.ones_col : g.N;
+  for (int p = 0; p < g.npairs; ++p) {
+    const int64_t ea = A_KC ? (int64_t)g.M * g.lda[p] + g.Kc[p] : (int64_t)g.Kc[p] * g.lda[p] + g.M;
+    const int64_t eb = B_KC ? (int64_t)g.N * g.ldb[p] + g.Kc[p] : (int64_t)g.Kc[p] * g.ldb[p] + Bn;
+    if (!(A_KC && g.a_rows)) ok = ok && ea + BK * (int64_t)g.lda[p] < lim;
+    if (!(!B_KC && g.b_krows)) ok = ok && eb + BK * (int64_t)g.ldb[p] < lim;
+  }
   return ok;
 }
 

@@ -57,6 +57,100 @@ __device__ __forceinline__ void mma_slab(f32x16 (&acc)[MT][NT], const float* __r
   }
 }
 
+// Register fragments of one k-group (8 k values) of a wave tile, so the LDS reads of k-group g+1 can be
+// issued before the MFMAs of k-group g (the compiler otherwise reuses one register set and exposes the
+// LDS latency once per k-group per wave).
+template <int MT, int NT>
+struct Frag {
+  float a[MT][4], b[NT][4];
+};
+
+template <bool A_KC, bool B_KC, int MT, int NT, int BN_>
+__device__ __forceinline__ void load_frag(Frag<MT, NT>& f, const float* __restrict__ As,
+                                          const float* __restrict__ Bs, int wr, int wc, int lane, int kgi) {
+  constexpr int ARS = BM + 4, BRS = BN_ + 4;
+  const int l31 = lane & 31;
+  const int k = kgi * 8 + (lane >> 5) * 4;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    if (A_KC) {
+      const float4 v = *reinterpret_cast<const float4*>(As + (wr * 32 * MT + t * 32 + l31) * KS + k);
+      f.a[t][0] = v.x; f.a[t][1] = v.y; f.a[t][2] = v.z; f.a[t][3] = v.w;
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) f.a[t][s] = As[(k + s) * ARS + wr * 32 * MT + t * 32 + l31];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (B_KC) {
+      const float4 v = *reinterpret_cast<const float4*>(Bs + (wc * 32 * NT + t * 32 + l31) * KS + k);
+      f.b[t][0] = v.x; f.b[t][1] = v.y; f.b[t][2] = v.z; f.b[t][3] = v.w;
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) f.b[t][s] = Bs[(k + s) * BRS + wc * 32 * NT + t * 32 + l31];
+    }
+  }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void mma_frag(f32x16 (&acc)[MT][NT], const Frag<MT, NT>& f) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#ifdef EVAE_MFMA_AGPR
+        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(f.a[mt][s]), "v"(f.b[nt][s]));
+#else
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mt][s], f.b[nt][s], acc[mt][nt], 0, 0, 0);
+#endif
+}
+// one of the four k-steps of a fragment (MT x NT MFMAs)
+template <int MT, int NT>
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[MT][NT], const Frag<MT, NT>& f, int s) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mt][s], f.b[nt][s], acc[mt][nt], 0, 0, 0);
+}
+// the LDS reads of one fragment, split so they can be slotted between MFMAs: part 0..MT-1 = A tiles, MT.. = B tiles
+template <bool A_KC, bool B_KC, int MT, int NT, int BN_>
+__device__ __forceinline__ void load_frag_part(Frag<MT, NT>& f, const float* __restrict__ As,
+                                               const float* __restrict__ Bs, int wr, int wc, int lane, int kgi, int part) {
+  constexpr int ARS = BM + 4, BRS = BN_ + 4;
+  const int l31 = lane & 31;
+  const int k = kgi * 8 + (lane >> 5) * 4;
+  if (part < MT) {
+    const int t = part;
+    if (A_KC) {
+      const float4 v = *reinterpret_cast<const float4*>(As + (wr * 32 * MT + t * 32 + l31) * KS + k);
+      f.a[t][0] = v.x; f.a[t][1] = v.y; f.a[t][2] = v.z; f.a[t][3] = v.w;
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) f.a[t][s] = As[(k + s) * ARS + wr * 32 * MT + t * 32 + l31];
+    }
+  } else {
+    const int t = part - MT;
+    if (B_KC) {
+      const float4 v = *reinterpret_cast<const float4*>(Bs + (wc * 32 * NT + t * 32 + l31) * KS + k);
+      f.b[t][0] = v.x; f.b[t][1] = v.y; f.b[t][2] = v.z; f.b[t][3] = v.w;
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) f.b[t][s] = Bs[(k + s) * BRS + wc * 32 * NT + t * 32 + l31];
+    }
+  }
+}
+
+// after the last mma_frag and before the accumulators are read (the compiler cannot see the MFMA latency of the asm form)
+__device__ __forceinline__ void mma_drain() {
+#ifdef EVAE_MFMA_AGPR
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float lo, float hi) {
   if (act == EVAE_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
   if (act == EVAE_ACT_HARDTANH) return fminf(fmaxf(v, lo), hi);
