@@ -229,6 +229,21 @@ extern "C" int evae_elbo_fwd(const float* RE, const float* logq, const float* lo
   return check_launch("elbo_fwd");
 }
 
+__global__ void step_stats_kernel(const float* loss, const float* re, const float* kl, float* step3, float* totals3) {
+  if (threadIdx.x < 3) {
+    const float v = threadIdx.x == 0 ? loss[0] : (threadIdx.x == 1 ? -re[0] : kl[0]);
+    step3[threadIdx.x] = v;
+    if (totals3) totals3[threadIdx.x] += v;
+  }
+}
+
+extern "C" int evae_step_stats_add(const float* loss, const float* re, const float* kl, float* step3, float* totals3,
+                                   evae_stream_t s) {
+  EVAE_REQUIRE(loss && re && kl && step3, "step_stats_add: null pointer");
+  step_stats_kernel<<<1, 64, 0, (hipStream_t)s>>>(loss, re, kl, step3, totals3);
+  return check_launch("step_stats_add");
+}
+
 extern "C" int evae_elbo_bwd(const float* dloss, int n_dloss, const float* dRE, int n_dRE, const float* dKL,
                              int n_dKL, const float* beta_dev, float beta_host, int B, float* cRE, float* cKL,
                              float* neg_cKL, evae_stream_t s) {

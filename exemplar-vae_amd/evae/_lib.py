@@ -60,6 +60,7 @@ SIGNATURES = {
     "evae_log_normal_diag_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
     "evae_elbo_fwd": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p, _p]),
     "evae_elbo_bwd": (_i, [_p, _i, _p, _i, _p, _i, _p, _f, _i, _p, _p, _p, _p]),
+    "evae_step_stats_add": (_i, [_p, _p, _p, _p, _p, _p]),
     "evae_bernoulli_ll_fwd": (_i, [_p, _p, _i, _i, _p, _p]),
     "evae_bernoulli_ll_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_adam_normgrad_workspace_bytes": (_z, [_i]),

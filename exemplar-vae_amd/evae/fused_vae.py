@@ -92,7 +92,7 @@ class VaeExactLoss(torch.autograd.Function):
     -> (loss [B], RE [B], KL [B])."""
 
     @staticmethod
-    def forward(ctx, x, x_idx, data_ext, n_data, ex_idx, c_total, eps, beta, sharded, no_mask, average, *params):
+    def forward(ctx, x, x_idx, data_ext, n_data, ex_idx, c_total, eps, beta, sharded, no_mask, average, rows_ext, *params):
         (plv, wp, bp, w1h, b1h, w1g, b1g, w2h, b2h, w2g, b2g, wm, bm, wl, bl,
          d1h, e1h, d1g, e1g, d2h, e2h, d2g, e2g) = params
         dev = x.device
@@ -107,7 +107,11 @@ class VaeExactLoss(torch.autograd.Function):
         x = x.contiguous()
         # stage the batch behind the dataset; one gather list for exemplars + batch
         data_ext[n_data:n_data + B].copy_(x)
-        rows = torch.cat((ex_idx, torch.arange(n_data, n_data + B, device=dev)))
+        # rows_ext: caller-kept [Cl + B] gather list whose head IS ex_idx and whose tail already names the staging rows
+        if rows_ext is not None and rows_ext.numel() == Cl + B and rows_ext.data_ptr() == ex_idx.data_ptr():
+            rows = rows_ext
+        else:
+            rows = torch.cat((ex_idx, torch.arange(n_data, n_data + B, device=dev)))
         ldd = data_ext.stride(0)
         # ---- encoder over C + B rows
         A1 = torch.empty((Mp, H), **f32); h1 = torch.empty_like(A1); s1 = torch.empty_like(A1)
@@ -146,6 +150,7 @@ class VaeExactLoss(torch.autograd.Function):
         beta_dev = beta if torch.is_tensor(beta) else None
         _lib.check(lib.evae_elbo_fwd(_vp(RE), _vp(logq), _vp(logp), _vp(beta_dev), 0.0 if beta_dev is not None else float(beta),
                                      B, _vp(loss), _vp(KL), _vp(means), k.st), "elbo_fwd")
+        ctx.set_materialize_grads(False)       # unused outputs (RE, KL) then arrive as None, not as zero-filled tensors
         ctx.k_dev = dev
         ctx.dims = (B, D, H, Z, Cl, Mp, ldd, beta, bool(sharded))
         ctx.bufs = (x, rows, data_ext, A1, h1, s1, A2, h2, s2, mean_all, logvar, lv_pre, z, D1, hd1, sd1, D2, hd2, sd2,
@@ -240,4 +245,4 @@ class VaeExactLoss(torch.autograd.Function):
         ctx.bufs = None
         grads = (g_plv, g_wp, g_bp, g_w1[:H], g_b1[:H], g_w1[H:], g_b1[H:], g_w2[:H], g_b2[:H], g_w2[H:], g_b2[H:],
                  g_wm, g_bm, g_wl, g_bl, g_d1[:H], g_e1[:H], g_d1[H:], g_e1[H:], g_d2[:H], g_e2[:H], g_d2[H:], g_e2[H:])
-        return (None,) * 11 + grads
+        return (None,) * 12 + grads

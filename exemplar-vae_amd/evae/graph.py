@@ -5,13 +5,14 @@ over 8 GPUs it is a few hundred microseconds, far below what eager launching can
 
 What varies between steps lives in static device buffers that are refreshed before each replay:
   the batch (images + dataset indices), the exemplar indices (still drawn by the CPU generator exactly like
-  reference models/BaseModel.py:245), beta, and AdamNormGrad's bias-corrected step size.  eps and the dynamic
+  reference models/BaseModel.py:245), beta, and AdamNormGrad's bias-corrected step size (one upload for the
+  scalars, pinned double-buffered staging, no fill kernels).  eps and the dynamic
   binarisation come from the CUDA generator inside the graph (torch registers it with the capture, so every
   replay advances the Philox offset).  RCCL collectives of the sharded prior are captured too.
 """
 import torch
 
-from . import shard
+from . import ops, shard
 
 
 class GraphedTrainStep:
@@ -22,41 +23,64 @@ class GraphedTrainStep:
         self.binarize = bool(dynamic_binarization)
         dev = torch.device(a.device)
         D = int(torch.tensor(a.input_size).prod().item())
+        C = int(a.number_components)
         self.x_in = torch.zeros((self.B, D), device=dev)
         self.idx_in = torch.zeros((self.B, 1), dtype=torch.int64, device=dev)
-        self.beta = torch.ones((), device=dev)
-        self.ex_idx = torch.zeros(a.number_components, dtype=torch.int64, device=dev)
-        self._ex_host = torch.zeros(a.number_components, dtype=torch.int64)   # pageable on purpose, see _refresh
-        self.out = None
+        # gather list of the fused step: [this rank's exemplar indices | the staging rows of the batch]; only the head
+        # changes between steps, so the captured graph needs no arange/cat
+        self.lo, self.hi = shard.bounds(C) if model._sharded() else (0, C)
+        _, n_data = model.resident_data_ext(dataset, self.B)
+        self.rows = torch.zeros((self.hi - self.lo) + self.B, dtype=torch.int64, device=dev)
+        self.rows[self.hi - self.lo:] = torch.arange(n_data, n_data + self.B, device=dev)
+        # per-step scalars (beta, Adam step size per group) travel in ONE small upload; host staging is pinned and
+        # double-buffered, an event per buffer says when its upload has been consumed
+        self.ngroups = len(optimizer.param_groups)
+        self.scal = torch.zeros(1 + self.ngroups, device=dev)
+        self.beta = self.scal[0:1].reshape(())
+        self._h_scal = [torch.zeros(1 + self.ngroups).pin_memory() for _ in range(2)]
+        self._h_idx = [torch.zeros(C, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self._h_ev = [torch.cuda.Event() for _ in range(2)]
+        self._one = torch.ones((), device=dev)
+        self.out = torch.zeros(3, device=dev)       # (loss, -RE, KL) of the last step
+        self.totals = torch.zeros(3, device=dev)    # running sums since reset_totals()
         self.graph = None
         self.warmup_steps = warmup_steps
         self._calls = 0
+
+    def reset_totals(self):
+        self.totals.zero_()
 
     # the body that gets captured
     def _body(self):
         x = torch.bernoulli(self.x_in) if self.binarize else self.x_in
         self.opt.zero_grad(set_to_none=True)      # backward then installs the fused node's gradient buffers
         loss, RE, KL = self.model.calculate_loss((x, self.idx_in), self.beta, average=True, dataset=self.dataset)
-        loss.backward()
+        loss.backward(gradient=self._one)
         self.opt.step(_captured=True)
-        return torch.stack((loss.detach(), -RE.detach(), KL.detach()))
+        ops.step_stats_add(loss.detach(), RE.detach(), KL.detach(), self.out, self.totals)
+        return self.out
 
     def _refresh(self, data, indices, beta):
-        self.x_in.copy_(data.reshape(self.B, -1))
-        self.idx_in.copy_(indices.reshape(self.B, 1))
-        self.beta.fill_(float(beta))
+        k = self._calls & 1
+        self._h_ev[k].synchronize()               # the upload issued two steps ago from this buffer is done
+        self.x_in.copy_(data.reshape(self.B, -1), non_blocking=True)
+        self.idx_in.copy_(indices.reshape(self.B, 1), non_blocking=True)
         # same CPU-generator draw, with replacement, as the reference (models/BaseModel.py:245)
         a = self.model.args
-        torch.randint(low=0, high=a.training_set_size, size=(a.number_components,), out=self._ex_host)
-        # pageable source: the runtime stages it before returning, so the next draw cannot race the copy
-        self.ex_idx.copy_(self._ex_host)
-        self.opt.advance_graph_step()
+        hi_ = self._h_idx[k]
+        torch.randint(low=0, high=a.training_set_size, size=(a.number_components,), out=hi_)
+        self.rows[:self.hi - self.lo].copy_(hi_[self.lo:self.hi], non_blocking=True)
+        hs = self._h_scal[k]
+        hs[0] = float(beta)
+        self.opt.advance_graph_step(host_out=hs[1:])
+        self.scal.copy_(hs, non_blocking=True)
+        self._h_ev[k].record()
 
     def __call__(self, data, indices, beta):
         """One training step; returns a device tensor (loss, -RE, KL) valid until the next call."""
         if self.graph is None and self._calls == 0:
-            self.opt.enable_graph_mode()
-        self.model._exemplar_indices_override = self.ex_idx
+            self.opt.enable_graph_mode(storage=[self.scal[1 + g:2 + g] for g in range(self.ngroups)])
+        self.model._exemplar_indices_override = (self.rows, self.hi - self.lo)
         try:
             self._refresh(data, indices, beta)
             if self.graph is None:
@@ -72,7 +96,7 @@ class GraphedTrainStep:
                 torch.cuda.synchronize()
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
-                    self.out = self._body()
+                    self._body()
                 # capture does not execute: replay once for this call's step
             self.graph.replay()
             self._calls += 1

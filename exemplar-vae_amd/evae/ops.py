@@ -519,6 +519,13 @@ def adam_step_size(step, lr, beta1, beta2):
     return lr * (1.0 - beta2 ** step) ** 0.5 / (1.0 - beta1 ** step)
 
 
+def step_stats_add(loss, re, kl, step3, totals3=None):
+    """step3 <- (loss, -re, kl); totals3 += step3 (the per-epoch sums of utils/training.py:41-46, kept on the device)."""
+    _need_cuda(loss, re, kl, step3, totals3)
+    _lib.check(_lib.load().evae_step_stats_add(_p(loss), _p(re), _p(kl), _p(step3), _p(totals3), _stream()), "step_stats_add")
+    return step3
+
+
 def adam_normgrad_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps, weight_decay,
                        table_cache=None, step_size_dev=None):
     """One multi-tensor AdamNormGrad update (utils/optimizer.py:32-80).  `table_cache` (a dict) lets the

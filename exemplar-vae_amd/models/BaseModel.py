@@ -87,7 +87,11 @@ class BaseModel(nn.Module, ABC):
         sharded = self._sharded()
         lo, hi = shard.bounds(C) if sharded else (0, C)
         override = getattr(self, '_exemplar_indices_override', None)
-        if override is not None:          # graph-captured step: indices were drawn into a static device buffer
+        rows_ext = None
+        if isinstance(override, tuple):   # graph-captured step: (gather list [local exemplars | staging rows], #local)
+            rows_ext, n_local = override
+            ex_local = rows_ext[:n_local]
+        elif override is not None:        # indices drawn into a static device buffer
             ex_local = override[lo:hi]
         else:
             exemplars_indices = torch.randint(low=0, high=a.training_set_size, size=(C,))   # reference :245
@@ -99,7 +103,7 @@ class BaseModel(nn.Module, ABC):
         params = [named[n] for n in fused_vae.PARAM_ORDER]
         beta = beta if torch.is_tensor(beta) else float(beta)
         return fused_vae.VaeExactLoss.apply(x2, x_indices.reshape(-1), data_ext, n_data, ex_local, C, eps,
-                                            beta, sharded, bool(a.no_mask), bool(average), *params)
+                                            beta, sharded, bool(a.no_mask), bool(average), rows_ext, *params)
 
     def calculate_loss(self, x, beta=1., average=False, exemplars_embedding=None, cache=None, dataset=None):
         x, x_indices = x

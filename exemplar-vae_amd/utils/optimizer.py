@@ -31,14 +31,15 @@ class AdamNormGrad(Optimizer):
         return state
 
     # ---- graph mode ---------------------------------------------------------------------------------
-    def enable_graph_mode(self):
-        """Call before capturing a step: the captured launches read the step size from device memory."""
+    def enable_graph_mode(self, storage=None):
+        """Call before capturing a step: the captured launches read the step size from device memory
+        (`storage`: caller-owned 1-element device tensors, one per param group)."""
         dev = self.param_groups[0]['params'][0].device
-        self._graph_step_size = [torch.zeros(1, device=dev) for _ in self.param_groups]
+        self._graph_step_size = storage if storage is not None else [torch.zeros(1, device=dev) for _ in self.param_groups]
 
-    def advance_graph_step(self):
+    def advance_graph_step(self, host_out=None):
         """Before each replay: bump the step counters (all parameters of a group share one count here) and
-        upload the bias-corrected step size."""
+        upload the bias-corrected step size -- or, with `host_out`, write it there for the caller to upload."""
         for gi, group in enumerate(self.param_groups):
             step = None
             for p in group['params']:
@@ -48,8 +49,11 @@ class AdamNormGrad(Optimizer):
             if step is None:
                 continue
             beta1, beta2 = group['betas']
-            # fill kernel (value travels as a kernel argument: no host buffer to race with later steps)
-            self._graph_step_size[gi].fill_(ops.adam_step_size(step, group['lr'], beta1, beta2))
+            v = ops.adam_step_size(step, group['lr'], beta1, beta2)
+            if host_out is not None:
+                host_out[gi] = v
+            else:   # fill kernel (value travels as a kernel argument: no host buffer to race with later steps)
+                self._graph_step_size[gi].fill_(v)
 
     @torch.no_grad()
     def step(self, closure=None, _captured=False):

@@ -25,10 +25,11 @@ def train_one_epoch(epoch, args, train_loader, model, optimizer):
         cache = None
     totals = None
     graphed = _graphed_step(args, model, optimizer, train_loader)
+    if graphed is not None:
+        graphed.reset_totals()
     for data, indices, target in train_loader:
         if graphed is not None and len(data) == graphed.B:
-            step_vals = graphed(data, indices, beta).clone()     # one hipGraph launch per step
-            totals = step_vals if totals is None else totals + step_vals
+            graphed(data, indices, beta)     # one hipGraph launch per step; sums accumulate in graphed.totals
             continue
         data, indices = data.to(args.device), indices.to(args.device)
         x = torch.bernoulli(data) if args.dynamic_binarization else data
@@ -42,6 +43,8 @@ def train_one_epoch(epoch, args, train_loader, model, optimizer):
             totals = step_vals if totals is None else totals + step_vals
             if cache is not None:
                 cache = (cache[0].detach(), cache[1].detach())
+    if graphed is not None:
+        totals = graphed.totals.clone() if totals is None else totals + graphed.totals
     train_loss, train_re, train_kl = (totals / len(train_loader)).tolist()
     return train_loss, train_re, train_kl
 

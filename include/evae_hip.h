@@ -214,6 +214,10 @@ int evae_elbo_fwd(const float* RE, const float* logq, const float* logp, const f
 int evae_elbo_bwd(const float* dloss, int n_dloss, const float* dRE, int n_dRE, const float* dKL, int n_dKL,
                   const float* beta_dev, float beta_host, int B, float* cRE, float* cKL, float* neg_cKL,
                   evae_stream_t stream);
+/* Running epoch statistics on the device (utils/training.py:41-46 keeps train_loss / train_re / train_kl as
+ * host floats read back every step): step3 = (loss, -re, kl) of this step, totals3 += step3.  One launch. */
+int evae_step_stats_add(const float* loss, const float* re, const float* kl, float* step3, float* totals3,
+                        evae_stream_t stream);
 int evae_bernoulli_ll_fwd(const float* x, const float* mean, int B, int D, float* out,
                           evae_stream_t stream);
 int evae_bernoulli_ll_bwd(const float* x, const float* mean, const float* dout, int B, int D,
