@@ -181,17 +181,30 @@ struct FinishArgs {
   float* out_db;
 };
 
+// LANES = 1: one thread per output element walks the nz planes.  LANES = 8 (many planes, small output -- e.g.
+// the [40 x 301] head gradient over 25 000 rows): eight lanes share an element, lane j sums planes j, j+8, ... and
+// a fixed butterfly adds the eight sums, so the walk is 8x shorter and still deterministic.
+template <int LANES>
 static __global__ __launch_bounds__(256) void gemm_finish_kernel(const FinishArgs f) {
   const size_t plane = (size_t)f.M * f.N;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= plane) return;
-  const int m = (int)(i / f.N), n = (int)(i - (size_t)m * f.N);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = t / LANES;
+  const int j = (int)(t % LANES);
+  const bool live = i < plane;
+  if (LANES == 1 && !live) return;
+  const int m = live ? (int)(i / f.N) : 0, n = live ? (int)(i - (size_t)m * f.N) : 0;
   const size_t o = (size_t)m * f.ldo + n;
   if (f.epi == EPI_GATED) {
     float h = 0.f, gg = 0.f;
-    for (int z = 0; z < f.nz; ++z) {
-      h += f.part[(size_t)z * 2 * plane + i];
-      gg += f.part[(size_t)z * 2 * plane + plane + i];
+    if (live)
+      for (int z = j; z < f.nz; z += LANES) {
+        h += f.part[(size_t)z * 2 * plane + i];
+        gg += f.part[(size_t)z * 2 * plane + plane + i];
+      }
+    if (LANES > 1) {
+#pragma unroll
+      for (int d = 1; d < LANES; d <<= 1) { h += __shfl_xor(h, d); gg += __shfl_xor(gg, d); }
+      if (!live || j != 0) return;
     }
     h += f.bias0 ? f.bias0[n] : 0.f;
     const float s = 1.0f / (1.0f + expf(-(gg + (f.bias1 ? f.bias1[n] : 0.f))));
@@ -201,7 +214,13 @@ static __global__ __launch_bounds__(256) void gemm_finish_kernel(const FinishArg
     return;
   }
   float v = 0.f;
-  for (int z = 0; z < f.nz; ++z) v += f.part[(size_t)z * plane + i];
+  if (live)
+    for (int z = j; z < f.nz; z += LANES) v += f.part[(size_t)z * plane + i];
+  if (LANES > 1) {
+#pragma unroll
+    for (int d = 1; d < LANES; d <<= 1) v += __shfl_xor(v, d);
+    if (!live || j != 0) return;
+  }
   if (f.epi == EPI_LINEAR) {
     const float pre = v + (f.bias0 ? f.bias0[n] : 0.f);
     if (f.out1) f.out1[o] = pre;
@@ -254,7 +273,10 @@ static Plan make_plan(int M, int N, int slabs, bool gated, bool must_split, int 
 
 static int launch_finish(const FinishArgs& f, hipStream_t stream) {
   size_t n = (size_t)f.M * f.N;
-  gemm_finish_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(f);
+  if (f.nz >= 16 && n * 8 <= ((size_t)1 << 22))
+    gemm_finish_kernel<8><<<(unsigned)((n * 8 + 255) / 256), 256, 0, stream>>>(f);
+  else
+    gemm_finish_kernel<1><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(f);
   return check_launch("gemm_finish_kernel");
 }
 

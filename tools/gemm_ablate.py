@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     torch.manual_seed(0)
     N, D, H = 50000, 784, 300
     data = (torch.rand(N, D, device=dev) < 0.13).float()
-    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
     wh = torch.randn(H, D, device=dev) * 0.05; wg = torch.randn(H, D, device=dev) * 0.05; b = torch.zeros(H, device=dev)
     for M in [int(x) for x in sys.argv[2].split(",")]:
         rows = torch.randint(0, N, (M,), device=dev)

@@ -14,7 +14,7 @@ data = (torch.rand(N, D, device=dev) < 0.13).float()
 rows = torch.randint(0, N, (M,), device=dev)
 wh = torch.randn(H, D, device=dev) * 0.05; wg = torch.randn(H, D, device=dev) * 0.05; b = torch.zeros(H, device=dev)
 out = torch.empty(M, H, device=dev); h = torch.empty_like(out); s = torch.empty_like(out)
-ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev); nws = ws.numel()
+ws = torch.zeros(256 << 20, dtype=torch.uint8, device=dev); nws = ws.numel()
 dpre = torch.randn(M, 2 * H, device=dev); dw = torch.empty(2 * H, D, device=dev); db = torch.empty(2 * H, device=dev)
 w2h = torch.randn(H, H, device=dev) * 0.05; w2g = torch.randn(H, H, device=dev) * 0.05
 dx = torch.empty(M, 2 * H, device=dev)

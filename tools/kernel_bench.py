@@ -37,7 +37,7 @@ def main():
         wh = torch.randn(H, D, device=dev) * 0.05; wg = torch.randn(H, D, device=dev) * 0.05
         b = torch.zeros(H, device=dev)
         out = torch.empty(M, H, device=dev); h = torch.empty_like(out); s = torch.empty_like(out)
-        wsf = torch.empty(64 << 20, dtype=torch.uint8, device=dev); nwf = wsf.numel()
+        wsf = torch.zeros(64 << 20, dtype=torch.uint8, device=dev); nwf = wsf.numel()
         report("gated_fwd L1 M=%d K=784 N=300 (gather)" % M,
                timeit(lambda: lib.evae_gated_dense_fwd(p(data), p(rows), M, D, D, p(wh), p(b), p(wg), p(b), H, p(out), p(h), p(s), p(wsf), nwf, st())),
                2.0 * M * D * 2 * H)
@@ -60,7 +60,7 @@ def main():
                timeit(lambda: lib.evae_dense_bwd_data(p(dy), p(wm), None, None, M, Z, Z, H, None, None, p(dx), None, H, p(wsf), nwf, st())),
                2.0 * M * Z * H)
         nb = max(lib.evae_dense_bwd_weight_workspace_bytes(M, 2 * H, D), lib.evae_dense_bwd_weight_workspace_bytes(M, 2 * H, H))
-        ws = torch.empty(nb, dtype=torch.uint8, device=dev); dw = torch.empty(2 * H, D, device=dev); db = torch.empty(2 * H, device=dev)
+        ws = torch.zeros(nb, dtype=torch.uint8, device=dev); dw = torch.empty(2 * H, D, device=dev); db = torch.empty(2 * H, device=dev)
         report("bwd_weight L1 M=%d N=600 K=784 (gather, +db)" % M,
                timeit(lambda: lib.evae_dense_bwd_weight(p(dpre), M, 2 * H, 2 * H, p(data), p(rows), D, D, p(dw), p(db), 0, p(ws), nb, st())),
                2.0 * M * 2 * H * D)
