@@ -53,6 +53,17 @@ class _K:
     def ws(self, name, nbytes):
         return ops._workspace(name, nbytes, self.dev)
 
+    _side = {}
+
+    def side_stream(self):
+        """Second stream for the exemplar-prior kernels: they only meet the decoder path at the ELBO, so the two
+        chains of small launches run side by side (captured as parallel branches of the step's hipGraph)."""
+        key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        st = _K._side.get(key)
+        if st is None:
+            st = _K._side[key] = torch.cuda.Stream(device=self.dev)
+        return st
+
     def gated_fwd(self, x, rows, M, K, ldx, wh, bh, wg, bg, N, out, h, s):
         nb = self.lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
         w = self.ws("fwd", nb)
@@ -128,6 +139,20 @@ class VaeExactLoss(torch.autograd.Function):
         # ---- sample, decode, reconstruct
         z = torch.empty((B, Z), **f32); logq = torch.empty(B, **f32)
         _lib.check(lib.evae_reparam_logq_fwd(_vp(z_mean), _vp(logvar), _vp(eps), B, Z, _vp(z), _vp(logq), k.st), "reparam")
+        # ---- exemplar prior (leave-one-out mask in training unless no_mask) on the side stream ...
+        lv_row = plv.detach().expand(Z).contiguous()
+        zi = None if no_mask else x_idx.reshape(-1)
+        ci = None if no_mask else ex_idx
+        logp = torch.empty(B, **f32); lse = torch.empty(B, **f32)
+        main = torch.cuda.current_stream()
+        side = k.side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            m, s, n, _ = ops.prior_lse_fwd(z, centres, lv_row, zi, ci)      # temporaries live and die on `side`
+            if sharded:
+                m, s, n = shard.gather_partials(m, s, n)
+            ops.prior_merge(m, s, n, c_total, out=(logp, lse))
+        # ---- ... while the decoder reconstructs on the main stream
         D1 = torch.empty((B, H), **f32); hd1 = torch.empty_like(D1); sd1 = torch.empty_like(D1)
         k.gated_fwd(z, None, B, Z, Z, d1h, e1h, d1g, e1g, H, D1, hd1, sd1)
         D2 = torch.empty((B, H), **f32); hd2 = torch.empty_like(D2); sd2 = torch.empty_like(D2)
@@ -136,14 +161,7 @@ class VaeExactLoss(torch.autograd.Function):
         k.linear_fwd(D2, B, H, H, wp, bp, D, ACT_SIGMOID, 0.0, 0.0, xmean, None)
         RE = torch.empty(B, **f32)
         _lib.check(lib.evae_bernoulli_ll_fwd(_vp(x), _vp(xmean), B, D, _vp(RE), k.st), "bernoulli")
-        # ---- exemplar prior (leave-one-out mask in training unless no_mask)
-        lv_row = plv.detach().expand(Z).contiguous()
-        zi = None if no_mask else x_idx.reshape(-1)
-        ci = None if no_mask else ex_idx
-        m, s, n, _ = ops.prior_lse_fwd(z, centres, lv_row, zi, ci)
-        if sharded:
-            m, s, n = shard.gather_partials(m, s, n)
-        logp, lse = ops.prior_merge(m, s, n, c_total)
+        main.wait_stream(side)
         # ---- ELBO assembly (+ batch means) in one launch
         loss = torch.empty(B, **f32); KL = torch.empty(B, **f32)
         means = torch.empty(3, **f32) if average else None
@@ -183,7 +201,25 @@ class VaeExactLoss(torch.autograd.Function):
                                      _vp(gk), 0 if gk is None else gk.numel(), _vp(beta_dev),
                                      0.0 if beta_dev is not None else float(beta), B, _vp(cRE), _vp(cKL), _vp(gp), k.st),
                    "elbo_bwd")
-        # ---- reconstruction term through the decoder
+        # ---- prior term d(-cKL * logp) on the side stream; dcentres lands directly in the head-gradient buffer,
+        #      dz' and dlogvar' in one packed buffer so that the sharded case all-reduces it in place
+        dmean_all = torch.empty((Mp, Z), **f32)
+        packed = torch.empty(B * Z + Z, **f32)
+        dzp = packed[:B * Z].view(B, Z); dlv = packed[B * Z:]
+        nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cl, Z)
+        w = k.ws("prior_bwd", nb)
+        centres = mean_all[:Cl]
+        main = torch.cuda.current_stream()
+        side = k.side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _lib.check(lib.evae_prior_lse_bwd(_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp),
+                                              _vp(dzp), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), ops._stream()), "prior_bwd")
+            if sharded:
+                dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+                if Cl > 0:
+                    dmean_all[:Cl].mul_(float(dist.get_world_size()))
+        # ---- reconstruction term through the decoder (main stream, concurrently)
         dxm = torch.empty((B, D), **f32)
         _lib.check(lib.evae_bernoulli_ll_bwd(_vp(x), _vp(xmean), _vp(cRE), B, D, _vp(dxm), k.st), "bernoulli_bwd")
         dpx = torch.empty((B, D), **f32)
@@ -200,20 +236,7 @@ class VaeExactLoss(torch.autograd.Function):
         k.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1)
         dz = torch.empty((B, Z), **f32)
         k.bwd_data(dp1, d1h, dp1.data_ptr() + 4 * H, d1g, B, H, 2 * H, Z, None, None, dz, None, Z)
-        # ---- prior term: d(-cKL * logp); dcentres lands directly in the head-gradient buffer
-        dmean_all = torch.empty((Mp, Z), **f32)
-        dzp = torch.empty((B, Z), **f32); dlv = torch.empty(Z, **f32)
-        nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cl, Z)
-        w = k.ws("prior_bwd", nb)
-        centres = mean_all[:Cl]
-        _lib.check(lib.evae_prior_lse_bwd(_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp),
-                                          _vp(dzp), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), k.st), "prior_bwd")
-        if sharded:
-            packed = torch.cat((dzp.reshape(-1), dlv))
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
-            dzp = packed[:B * Z].reshape(B, Z); dlv = packed[B * Z:]
-            if Cl > 0:
-                dmean_all[:Cl].mul_(float(dist.get_world_size()))
+        main.wait_stream(side)
         dz.add_(dzp)
         # ---- reparameterisation + log q
         dlogvar = torch.empty((B, Z), **f32)

@@ -79,15 +79,15 @@ def prior_lse_fwd(z, centres, log_var, z_idx=None, c_idx=None, want_prob=False):
     return m, s, n, prob
 
 
-def prior_merge(m, s, n, c_total):
-    """[R x B] shard partials -> (logprior [B], lse [B])."""
+def prior_merge(m, s, n, c_total, out=None):
+    """[R x B] shard partials -> (logprior [B], lse [B]); `out` = caller-allocated (logprior, lse)."""
     lib = _lib.load()
     _need_cuda(m, s, n)
     m, s, n = _f32(m), _f32(s), _f32(n)
     if m.dim() == 1:
         m, s, n = m[None], s[None], n[None]
     R, B = m.shape
-    lp = torch.empty(B, device=m.device); lse = torch.empty_like(lp)
+    lp, lse = out if out is not None else (torch.empty(B, device=m.device), torch.empty(B, device=m.device))
     _lib.check(lib.evae_prior_merge(_p(m), _p(s), _p(n), R, B, float(c_total), _p(lp), _p(lse), _stream()),
                "evae_prior_merge")
     return lp, lse
