@@ -19,6 +19,7 @@
 // loads; row decomposition (n, y, x) is done once per tile (or once per slab when the row index is the
 // contraction index), the (c, kh, kw) decomposition comes from a small table built per call.
 #include "evae_gemm_core.h"
+#include <type_traits>
 
 namespace evae {
 
@@ -321,26 +322,53 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_gemm_kernel(const ConvAr
     store_b(Bs(0), rb);
     if (s_begin + 1 < s_end) { ra = gather_a((s_begin + 1) * BK); rb = load_b((s_begin + 1) * BK); }
     __syncthreads();
-    for (int s = s_begin; s < s_end; ++s) {
+    // same slab schedule as the dense kernel (evae_dense.hip): memory work slotted between the MFMA steps,
+    // no branches around memory instructions in the steady state (last two slabs peeled), barrier before
+    // the last k-group with the next slab's first fragments requested right behind it
+    Frag<MT, NT> f0, f1;
+    load_frag<true, B_KC, MT, NT, BN_>(f0, As(0), Bs(0), wr, wc, lane, 0);
+#define EVAE_SB __builtin_amdgcn_sched_barrier(0)
+    auto slab = [&](int s, auto ST_, auto LD_, auto NX_) {
+      constexpr bool ST = decltype(ST_)::value, LD = decltype(LD_)::value, NX = decltype(NX_)::value;
       const int cur = (s - s_begin) & 1;
-      Frag<MT, NT> f0, f1;
-      load_frag<true, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 0);
+      EVAE_SB; mma_step<MT, NT>(acc, f0, 0); EVAE_SB;
       load_frag<true, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_frag<MT, NT>(acc, f0);
-      __builtin_amdgcn_sched_barrier(0);
-      load_frag<true, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 2);
-      if (s + 1 < s_end) { store_a(As(cur ^ 1), ra); store_b(Bs(cur ^ 1), rb); }
-      if (s + 2 < s_end) { ra = gather_a((s + 2) * BK); rb = load_b((s + 2) * BK); }
-      __builtin_amdgcn_sched_barrier(0);
-      mma_frag<MT, NT>(acc, f1);
-      __builtin_amdgcn_sched_barrier(0);
-      load_frag<true, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 3);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_frag<MT, NT>(acc, f0);
-      mma_frag<MT, NT>(acc, f1);
+      if constexpr (ST) store_a(As(cur ^ 1), ra);
+      EVAE_SB; mma_step<MT, NT>(acc, f0, 1); EVAE_SB;
+      if constexpr (ST) store_b(Bs(cur ^ 1), rb);
+      EVAE_SB; mma_step<MT, NT>(acc, f0, 2); EVAE_SB;
+      if constexpr (LD) ra = gather_a((s + 2) * BK);
+      EVAE_SB; mma_step<MT, NT>(acc, f0, 3); EVAE_SB;
+      if constexpr (LD) rb = load_b((s + 2) * BK);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        EVAE_SB; mma_step<MT, NT>(acc, f1, q); EVAE_SB;
+        if (q < MT + NT) load_frag_part<true, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 2, q);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        EVAE_SB; mma_step<MT, NT>(acc, f0, q); EVAE_SB;
+        if (q < MT + NT) load_frag_part<true, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 3, q);
+      }
+      EVAE_SB;
       __syncthreads();
-    }
+      EVAE_SB;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        mma_step<MT, NT>(acc, f1, q); EVAE_SB;
+        if constexpr (NX) {
+          if (q < MT + NT) load_frag_part<true, B_KC, MT, NT, BN_>(f0, As(cur ^ 1), Bs(cur ^ 1), wr, wc, lane, 0, q);
+        }
+        EVAE_SB;
+      }
+    };
+    constexpr std::true_type T{};
+    constexpr std::false_type F{};
+    int s = s_begin;
+    for (; s + 2 < s_end; ++s) slab(s, T, T, T);
+    if (s + 1 < s_end) { slab(s, T, F, T); ++s; }
+    slab(s, F, F, F);
+#undef EVAE_SB
   }
 
   mma_drain();

@@ -145,7 +145,7 @@ class VaeExactLoss(torch.autograd.Function):
         ci = None if no_mask else ex_idx
         logp = torch.empty(B, **f32); lse = torch.empty(B, **f32)
         main = torch.cuda.current_stream()
-        side = k.side_stream()
+        side = main if sharded else k.side_stream()     # collectives stay on the main stream
         side.wait_stream(main)
         with torch.cuda.stream(side):
             m, s, n, _ = ops.prior_lse_fwd(z, centres, lv_row, zi, ci)      # temporaries live and die on `side`
@@ -210,7 +210,7 @@ class VaeExactLoss(torch.autograd.Function):
         w = k.ws("prior_bwd", nb)
         centres = mean_all[:Cl]
         main = torch.cuda.current_stream()
-        side = k.side_stream()
+        side = main if sharded else k.side_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
             _lib.check(lib.evae_prior_lse_bwd(_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp),
