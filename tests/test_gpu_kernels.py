@@ -207,6 +207,49 @@ def test_gated_dense_row_gather(ops):
     assert rel(w[1].grad.cpu().numpy(), gr["bh"]) < 1e-5
 
 
+def test_dense_operand_beyond_2gib(ops):
+    """Maximum sizes: the fast tile loads address non-gathered operands with 31-bit byte offsets; a 2.3 GiB input
+    must take the 64-bit path (plain), and a row gather out of it must work (gathered operands always use 64-bit
+    pointers).  Checked on the last rows, which lie beyond the 2 GiB mark."""
+    M, K, N = 800_000, 784, 40
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    x = torch.randn((M, K), device="cuda", generator=g)
+    w = torch.randn((N, K), device="cuda", generator=g) / 28
+    b = torch.zeros(N, device="cuda")
+    tail = slice(M - 300, M)
+    ref = (x[tail].double() @ w.double().T).float()
+    y = ops.linear(x, w, b, 0, 0.0, 0.0)
+    assert rel(y[tail].cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    rows = torch.arange(M - 300, M, device="cuda")
+    yg = ops.linear(x, w, b, 0, 0.0, 0.0, rows=rows)
+    assert rel(yg.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    wh = torch.randn((64, K), device="cuda", generator=g) / 28; wg = torch.randn((64, K), device="cuda", generator=g) / 28
+    bz = torch.zeros(64, device="cuda")
+    og = ops.gated_dense(x, wh, bz, wg, bz, rows=rows)
+    xr = x[tail].double()
+    refg = ((xr @ wh.double().T) * torch.sigmoid(xr @ wg.double().T)).float()
+    assert rel(og.cpu().numpy(), refg.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("K", [4, 28, 32, 36, 60, 64, 68, 96, 100])
+def test_dense_k_tails(ops, K):
+    """K tails of every length around the 32-wide slab (zero fill by out-of-range buffer offsets / masked gathers)."""
+    rs = np.random.RandomState(K)
+    M, N = 200, 72
+    x = rs.standard_normal((M + 50, K)).astype(np.float32)
+    w = rs.standard_normal((N, K)).astype(np.float32); b = rs.standard_normal(N).astype(np.float32)
+    gout = rs.standard_normal((M, N)).astype(np.float32)
+    rows = rs.randint(0, M + 50, M).astype(np.int64)
+    for gather in (False, True):
+        xin = x[rows] if gather else x[:M]
+        t = [dev(x if gather else x[:M].copy()).requires_grad_(not gather), dev(w).requires_grad_(True), dev(b).requires_grad_(True)]
+        out = ops.linear(t[0], t[1], t[2], 0, 0.0, 0.0, rows=dev(rows) if gather else None)
+        out.backward(dev(gout))
+        assert rel(out.detach().cpu().numpy(), xin.astype(np.float64) @ w.astype(np.float64).T + b) < 2e-6
+        assert rel(t[1].grad.cpu().numpy(), gout.astype(np.float64).T @ xin.astype(np.float64)) < 1e-5
+        assert rel(t[2].grad.cpu().numpy(), gout.astype(np.float64).sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("act", [0, 1, 2])
 @pytest.mark.parametrize("M,K,N", [(37, 53, 24), (100, 300, 784), (1000, 300, 40)])
 def test_linear_fwd_bwd(ops, act, M, K, N):
