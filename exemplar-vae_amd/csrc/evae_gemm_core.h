@@ -108,13 +108,18 @@ __device__ __forceinline__ void mma_frag(f32x16 (&acc)[MT][NT], const Frag<MT, N
 #endif
 }
 // one of the four k-steps of a fragment (MT x NT MFMAs)
+// live_mt / live_nt: how many of the wave's 32-row / 32-column sub-tiles reach into the matrix (wave-uniform);
+// sub-tiles wholly outside (the 17-column last tile of a [600 x 785] weight gradient, the 12-row last row tile)
+// are not multiplied at all.
 template <int MT, int NT>
-__device__ __forceinline__ void mma_step(f32x16 (&acc)[MT][NT], const Frag<MT, NT>& f, int s) {
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[MT][NT], const Frag<MT, NT>& f, int s, int live_mt = MT,
+                                         int live_nt = NT) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mt][s], f.b[nt][s], acc[mt][nt], 0, 0, 0);
+      if (mt < live_mt && nt < live_nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mt][s], f.b[nt][s], acc[mt][nt], 0, 0, 0);
 }
 // the LDS reads of one fragment, split so they can be slotted between MFMAs: part 0..MT-1 = A tiles, MT.. = B tiles
 template <bool A_KC, bool B_KC, int MT, int NT, int BN_>
