@@ -95,7 +95,10 @@ class GraphedTrainStep:
                     return out
                 torch.cuda.synchronize()
                 self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
+                # with RCCL in the step its watchdog thread polls events while we capture: thread-local capture mode
+                # keeps those calls from invalidating the capture
+                mode = "thread_local" if shard.is_active() else "global"
+                with torch.cuda.graph(self.graph, capture_error_mode=mode):
                     self._body()
                 # capture does not execute: replay once for this call's step
             self.graph.replay()
