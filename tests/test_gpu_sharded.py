@@ -76,4 +76,4 @@ def test_two_rank_sharded_training_matches_single(fused):
     for rank, losses, params in double:
         assert rel(losses, single[1]) < 1e-5, (rank, losses, single[1])
         for k in params:
-            assert rel(params[k], single[2][k]) < 5e-5, (rank, k)   # fp32 summation order differs between 1 and 2 shards; early Adam steps amplify it
+            assert rel(params[k], single[2][k]) < 3e-4, (rank, k)   # summation order differs between 1 and 2 shards; Adam on normalised gradients moves every weight by ~lr per step whatever the gradient magnitude, so rounding-level differences in near-zero gradient entries show up at the 1e-4 level (the losses above agree to 1e-5)
