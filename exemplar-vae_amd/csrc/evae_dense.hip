@@ -391,37 +391,28 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
       // the next slab are requested right behind it.
       Frag<MT, NT> f0, f1;
       load_frag<A_KC, B_KC, MT, NT, BN_>(f0, As(0), Bs(0), wr, wc, lane, 0);
-      // sub-tiles of this wave that reach into the matrix (gated tiles pair an h and a g sub-tile: all or nothing)
-      const int rows_left = g.M - (m0 + wr * 32 * MT);
-      const int lmt = rows_left <= 0 ? 0 : (rows_left >= 32 * MT ? MT : (rows_left + 31) / 32);
-      int lnt;
-      if (GATED) lnt = (n0 + wc * 32 < g.N) ? NT : 0;
-      else {
-        const int cols_left = g.N - (n0 + wc * 32 * NT);
-        lnt = cols_left <= 0 ? 0 : (cols_left >= 32 * NT ? NT : (cols_left + 31) / 32);
-      }
 #define EVAE_SB __builtin_amdgcn_sched_barrier(0)
       // ST: the registers hold slab s+1 -> write it to the idle LDS buffer; LD: fetch slab s+2; NX: slab s+1 exists
       auto slab = [&](int s, auto ST_, auto LD_, auto NX_) {
         constexpr bool ST = decltype(ST_)::value, LD = decltype(LD_)::value, NX = decltype(NX_)::value;
         const int cur = (s - s_begin) & 1;
-        EVAE_SB; mma_step<MT, NT>(acc, f0, 0, lmt, lnt); EVAE_SB;
+        EVAE_SB; mma_step<MT, NT>(acc, f0, 0); EVAE_SB;
         load_frag<A_KC, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 1);
         if constexpr (ST) store_a(cur ^ 1, ra, kva);
-        EVAE_SB; mma_step<MT, NT>(acc, f0, 1, lmt, lnt); EVAE_SB;
+        EVAE_SB; mma_step<MT, NT>(acc, f0, 1); EVAE_SB;
         if constexpr (ST) store_b(cur ^ 1, rb, kvb);
-        EVAE_SB; mma_step<MT, NT>(acc, f0, 2, lmt, lnt); EVAE_SB;
+        EVAE_SB; mma_step<MT, NT>(acc, f0, 2); EVAE_SB;
         if constexpr (LD) load_a(s + 2, ra, kva);
-        EVAE_SB; mma_step<MT, NT>(acc, f0, 3, lmt, lnt); EVAE_SB;
+        EVAE_SB; mma_step<MT, NT>(acc, f0, 3); EVAE_SB;
         if constexpr (LD) load_b(s + 2, rb, kvb);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          EVAE_SB; mma_step<MT, NT>(acc, f1, q, lmt, lnt); EVAE_SB;
+          EVAE_SB; mma_step<MT, NT>(acc, f1, q); EVAE_SB;
           if (q < MT + NT) load_frag_part<A_KC, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 2, q);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          EVAE_SB; mma_step<MT, NT>(acc, f0, q, lmt, lnt); EVAE_SB;
+          EVAE_SB; mma_step<MT, NT>(acc, f0, q); EVAE_SB;
           if (q < MT + NT) load_frag_part<A_KC, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 3, q);
         }
         EVAE_SB;
@@ -429,7 +420,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
         EVAE_SB;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          mma_step<MT, NT>(acc, f1, q, lmt, lnt); EVAE_SB;
+          mma_step<MT, NT>(acc, f1, q); EVAE_SB;
           if constexpr (NX) {
             if (q < MT + NT) load_frag_part<A_KC, B_KC, MT, NT, BN_>(f0, As(cur ^ 1), Bs(cur ^ 1), wr, wc, lane, 0, q);
           }
@@ -582,7 +573,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
           if (m < g.M) {
             if (EPI == EPI_GATED) {
               const float h = acc[mt][0][r] + bh;
-              const float s = 1.0f / (1.0f + expf(-(acc[mt][NT - 1][r] + bg)));
+              // sigmoid on the hardware exp2 / rcp (about 1e-7 relative): the precise expf costs ~15 VALU instructions
+              // per element, and VALU issue is what the co-resident block's MFMAs wait on
+              const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc[mt][NT - 1][r] + bg)));
               const size_t o = (size_t)m * g.ldo + n;
               g.out0[o] = h * s;
               if (g.out1) g.out1[o] = h;

@@ -67,15 +67,21 @@ class _K:
     def gated_fwd(self, x, rows, M, K, ldx, wh, bh, wg, bg, N, out, h, s):
         nb = self.lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
         w = self.ws("fwd", nb)
-        probe = ops.PROBE if nb <= 256 else None     # only the direct EPI_GATED kernel (no split-K partials)
+        # bench.py's roofline probe times the dominant launch only: encoder layer 1 (row-gathered, no split-K)
+        probe = ops.PROBE if (nb <= 256 and rows is not None) else None
+        reps = 1
         if probe is not None:
+            # bench.py's roofline probe: the launch is repeated (same arguments, idempotent) between one event pair so
+            # that the ~5 us an event pair adds around a single launch does not inflate the kernel's duration
+            reps = 4
             ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record()
-        _lib.check(self.lib.evae_gated_dense_fwd(_vp(x), _vp(rows), M, K, ldx, _vp(wh), _vp(bh), _vp(wg), _vp(bg), N,
-                                                 _vp(out), _vp(h), _vp(s), _vp(w), w.numel(), self.st), "gated_fwd")
+        for _ in range(reps):
+            _lib.check(self.lib.evae_gated_dense_fwd(_vp(x), _vp(rows), M, K, ldx, _vp(wh), _vp(bh), _vp(wg), _vp(bg), N,
+                                                     _vp(out), _vp(h), _vp(s), _vp(w), w.numel(), self.st), "gated_fwd")
         if probe is not None:
             ev1.record()
-            probe["gated_dense_fwd"].append((ev0, ev1, 2.0 * M * K * 2 * N))
+            probe["gated_dense_fwd"].append((ev0, ev1, 2.0 * M * K * 2 * N * reps, reps))
 
     def linear_fwd(self, x, M, K, ldx, w_, b, N, act, lo, hi, y, pre):
         nb = self.lib.evae_dense_fwd_workspace_bytes(M, K, N, 0)
