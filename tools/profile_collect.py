@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Copy the judged evidence of a tools/profile_round.sh run from gpurun_out/<tag>/ into profiles/ (tracked)."""
+import csv, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, "r01_bench_line.json"))
+shutil.copy(os.path.join(src, "stats", tag + "_kernel_stats.csv"), os.path.join(dst, "r01_bench_kernel_stats.csv"))
+with open(os.path.join(src, "bench_under_rocprof_stdout.txt")) as f:
+    lines = [l for l in f if l.startswith("{")]
+open(os.path.join(dst, "r01_bench_under_rocprof_stdout.txt"), "w").write(lines[-1] if lines else "")
+os.makedirs(os.path.join(dst, "r01_pmc"), exist_ok=True)
+for d, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_sq", "SQ"), ("pmc_sq2", "SQ2")):
+    rows = [r for r in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv"))) if "gemm_kernel" in r["Kernel_Name"]]
+    with open(os.path.join(dst, "r01_pmc", "gated_fwd_L1_%s.csv" % name), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+# the dominant launch inside the profiled bench: first gemm_kernel<true,true,1,...> launch of every step (encoder layer 1)
+tr = list(csv.DictReader(open(os.path.join(src, "stats", tag + "_kernel_trace.csv"))))
+tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+durs, prev_gated = [], False
+for r in tr:
+    n = r["Kernel_Name"]
+    gated = "gemm_kernel<true, true, 1, true, 128, 8>" in n
+    if gated and not prev_gated:
+        durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    if "gemm_kernel" in n or "adam_step" in n:
+        prev_gated = gated
+# keep launches of the layer-1 size only (decoder layer 1 is also a 'first' launch of its pair)
+big = [d for d in durs if d > 0.5 * max(durs)]
+summary = {"kernel": "evae::gemm_kernel<true,true,1,true,128,8>, encoder layer 1 launch of each step",
+           "launches": len(big), "avg_us": round(sum(big) / len(big), 2), "min_us": round(min(big), 2), "max_us": round(max(big), 2),
+           "source": "r01_kernel_trace.csv of the rocprofv3 --kernel-trace --stats run (tools/profile_round.sh); the kernel-stats CSV "
+                     "averages this launch with the smaller encoder-layer-2 and decoder launches of the same kernel"}
+json.dump(summary, open(os.path.join(dst, "r01_dominant_launch.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
+print(open(os.path.join(dst, "r01_bench_line.json")).read()[:600])
