@@ -371,7 +371,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_gemm_kernel(const ConvAr
 #undef EVAE_SB
   }
 
-  mma_drain();
   // ---- epilogue -------------------------------------------------------------------------------------------
   const int l31 = lane & 31, lh = lane >> 5;
   if (EPI == CEPI_RAW) {                 // weight gradient partials [z][rows][Ncols]

@@ -52,7 +52,7 @@ struct GemmArgs {
   float lo, hi;
   int tiles_m, tiles_n;
   int ones_col;            // RC B: virtual all-ones column index (bias gradient folded into the weight GEMM); -1 = none
-  int dbg;                 // ablation switches for tools/kernel_bench.py (EVAE_GEMM_DBG); 0 in production
+  int dbg;                 // EVAE_GEMM_DBG (tools/gemm_ablate.py): 4 = skip the epilogue, 512 = clock probe; 0 in production
 };
 
 // Out-of-range chunks are loaded from a clamped, always-mapped address and zeroed LATER, when the
@@ -507,7 +507,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
       lb[0].store(Bs(0), rb, mb);
       if (s_begin + 1 < s_end) load_slab(s_begin + 1, ra, rb, ma, mb);
       __syncthreads();
-      const bool dbg_nobar = g.dbg & 1, dbg_nomem = g.dbg & 2;
       for (int s = s_begin; s < s_end; ++s) {
         const int cur = (s - s_begin) & 1;
         Frag<MT, NT> f0, f1;
@@ -517,11 +516,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
         mma_frag<MT, NT>(acc, f0);
         __builtin_amdgcn_sched_barrier(0);
         load_frag<A_KC, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 2);
-        if (s + 1 < s_end && !dbg_nomem) {
+        if (s + 1 < s_end) {
           la[0].store(As(cur ^ 1), ra, ma);
           lb[0].store(Bs(cur ^ 1), rb, mb);
         }
-        if (s + 2 < s_end && !dbg_nomem) load_slab(s + 2, ra, rb, ma, mb);
+        if (s + 2 < s_end) load_slab(s + 2, ra, rb, ma, mb);
         __builtin_amdgcn_sched_barrier(0);
         mma_frag<MT, NT>(acc, f1);
         __builtin_amdgcn_sched_barrier(0);
@@ -529,13 +528,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
         __builtin_amdgcn_sched_barrier(0);
         mma_frag<MT, NT>(acc, f0);
         mma_frag<MT, NT>(acc, f1);
-        if (!dbg_nobar) __syncthreads();
+        __syncthreads();
       }
     }
 
   }
 
-  mma_drain();
   if ((g.dbg & 512) && g.out2) {   // clock probe: shader-clock ticks vs the constant 100 MHz counter over this block's main loop
     const long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     if (threadIdx.x == 0 && (blockIdx.x & 63) == 5) {

@@ -18,45 +18,6 @@ enum { EPI_LINEAR = 0, EPI_GATED = 1, EPI_GATE_BWD = 2, EPI_RAW = 3, EPI_RAW_GAT
 
 // one K-slab of MFMAs: wave tile 64 x (32 NT) at rows wr*64.., cols wc*32*NT..
 // (k-groups [KG0, KG1) of 8 within the slab, so that LDS stores / global loads can be placed between them)
-template <bool A_KC, bool B_KC, int MT, int NT, int BN_, int KG0, int KG1>
-__device__ __forceinline__ void mma_slab(f32x16 (&acc)[MT][NT], const float* __restrict__ As,
-                                         const float* __restrict__ Bs, int wr, int wc, int lane) {
-  constexpr int ARS = BM + 4, BRS = BN_ + 4;
-  const int l31 = lane & 31;
-  const int kh = (lane >> 5) * 4;
-#pragma unroll
-  for (int kg = KG0 * 8; kg < KG1 * 8; kg += 8) {
-    float a[MT][4], b[NT][4];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      if (A_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(As + (wr * 32 * MT + t * 32 + l31) * KS + kg + kh);
-        a[t][0] = v.x; a[t][1] = v.y; a[t][2] = v.z; a[t][3] = v.w;
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a[t][s] = As[(kg + kh + s) * ARS + wr * 32 * MT + t * 32 + l31];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (B_KC) {
-        const float4 v = *reinterpret_cast<const float4*>(Bs + (wc * 32 * NT + t * 32 + l31) * KS + kg + kh);
-        b[t][0] = v.x; b[t][1] = v.y; b[t][2] = v.z; b[t][3] = v.w;
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[t][s] = Bs[(kg + kh + s) * BRS + wc * 32 * NT + t * 32 + l31];
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
-  }
-}
-
 // Register fragments of one k-group (8 k values) of a wave tile, so the LDS reads of k-group g+1 can be
 // issued before the MFMAs of k-group g (the compiler otherwise reuses one register set and exposes the
 // LDS latency once per k-group per wave).
@@ -101,25 +62,17 @@ __device__ __forceinline__ void mma_frag(f32x16 (&acc)[MT][NT], const Frag<MT, N
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-#ifdef EVAE_MFMA_AGPR
-        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(f.a[mt][s]), "v"(f.b[nt][s]));
-#else
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mt][s], f.b[nt][s], acc[mt][nt], 0, 0, 0);
-#endif
 }
+
 // one of the four k-steps of a fragment (MT x NT MFMAs)
-// live_mt / live_nt: how many of the wave's 32-row / 32-column sub-tiles reach into the matrix (wave-uniform);
-// sub-tiles wholly outside (the 17-column last tile of a [600 x 785] weight gradient, the 12-row last row tile)
-// are not multiplied at all.
 template <int MT, int NT>
-__device__ __forceinline__ void mma_step(f32x16 (&acc)[MT][NT], const Frag<MT, NT>& f, int s, int live_mt = MT,
-                                         int live_nt = NT) {
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[MT][NT], const Frag<MT, NT>& f, int s) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      if (mt < live_mt && nt < live_nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mt][s], f.b[nt][s], acc[mt][nt], 0, 0, 0);
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mt][s], f.b[nt][s], acc[mt][nt], 0, 0, 0);
 }
 // the LDS reads of one fragment, split so they can be slotted between MFMAs: part 0..MT-1 = A tiles, MT.. = B tiles
 template <bool A_KC, bool B_KC, int MT, int NT, int BN_>
@@ -147,13 +100,6 @@ __device__ __forceinline__ void load_frag_part(Frag<MT, NT>& f, const float* __r
       for (int s = 0; s < 4; ++s) f.b[t][s] = Bs[(k + s) * BRS + wc * 32 * NT + t * 32 + l31];
     }
   }
-}
-
-// after the last mma_frag and before the accumulators are read (the compiler cannot see the MFMA latency of the asm form)
-__device__ __forceinline__ void mma_drain() {
-#ifdef EVAE_MFMA_AGPR
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#endif
 }
 
 __device__ __forceinline__ float apply_act(float v, int act, float lo, float hi) {

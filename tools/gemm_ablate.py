@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""GatedDense forward L1 under the EVAE_GEMM_DBG ablation bits (1 no barrier, 2 no in-loop memory, 4 no epilogue)
-and at M values that give an exact number of block rounds.  Each setting runs in a fresh process (the flag is read once)."""
+"""GatedDense forward L1 at M values that give an exact number of block rounds, under the EVAE_GEMM_DBG switches the
+shipped kernel still carries (4: skip the epilogue, 512: shader-clock probe).  The in-loop ablations quoted in DESIGN.md
+(no loads / no stores / no barrier / L1-resident loads) were compile-time experiments of round 1 and are gone.
+Each setting runs in a fresh process (the flag is read once); EVAE_LIB_PATH selects an alternative build for A/B runs."""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -37,6 +39,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             2.0 * blocks * 128 * 128 * 800 / us / 1e6))
 else:
     Ms = sys.argv[2] if len(sys.argv) > 2 else "13056,25000,26112,52224,104448"
-    for dbg in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("0", "4", "2", "6", "7")):
+    for dbg in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("0", "4", "512")):
         env = dict(os.environ, EVAE_GEMM_DBG=dbg)
         subprocess.run([sys.executable, __file__, "child", Ms], env=env, check=False)
