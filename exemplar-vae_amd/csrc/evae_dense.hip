@@ -29,6 +29,49 @@
 
 namespace evae {
 
+// Convolution as a GEMM over channels-last tensors (template parameter CV of gemm_kernel):
+//   CV = 1 (forward, data gradient): A rows are the pixels (n, ry, rx) of a grid, the contraction runs over
+//          (tap, channel) with the channel fastest and Cg % 32 == 0, so a 32-wide K-slab is 32 consecutive
+//          channels of ONE tap for the whole block: the A tile is the dense KC tile with a per-slab byte
+//          offset (tap) in an SGPR and one validity bit per (row, tap) -- no im2col arithmetic in the loop;
+//          out-of-image taps ride the same out-of-range buffer offset as every other zero fill;
+//   CV = 2 (weight gradient): the contraction runs over the pixels, B is the im2col matrix
+//          [pixel][(tap, channel)] gathered as float4 (4 channels of one tap), A is dy, row-contiguous.
+// Source element of row (n, ry, rx), tap t, channel c:
+//   src[((n*IH + ry*rs + roy + tdy[t]) * IW + rx*rs + rox + tdx[t]) * ps + c]
+// Output row (CV = 1): ((n*OH2 + ry*os + ooy) * OW2 + rx*os + oox)  (identity for the forward; the strided
+// pixels of one stride-parity class for the data gradient).
+struct FastDiv { unsigned mul, sh, one; };   // q = one ? n : (t = umulhi(mul, n), (t + ((n - t) >> 1)) >> sh)
+__host__ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv d) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const unsigned t = __umulhi(d.mul, n);
+#else
+  const unsigned t = (unsigned)(((unsigned long long)d.mul * n) >> 32);
+#endif
+  return d.one ? n : (t + ((n - t) >> 1)) >> d.sh;
+}
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f = {0u, 0u, 0u};
+  if (d <= 1) { f.one = 1; return f; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  f.sh = l - 1;
+  return f;
+}
+struct ConvMap {
+  int Cg, ntaps;
+  int ps;                      // floats per source pixel (Cg, or 2 Cg when the h and g gradients share one buffer)
+  int RH, RW, IH, IW;
+  int rs, roy, rox;
+  int OH2, OW2, os, ooy, oox;
+  int remap;                   // CV = 1: output rows are not the identity
+  unsigned bias;               // bytes added to every per-row offset (the buffer base is moved back by bias + tbias)
+  FastDiv div_rw, div_rhw;
+  signed char tdy[64], tdx[64];
+  int tsoff[64];               // CV = 1: byte offset of tap t, >= 0 after adding tbias
+};
+
 struct GemmArgs {
   const float* A[2];
   const float* B[2];
@@ -53,6 +96,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int ones_col;            // RC B: virtual all-ones column index (bias gradient folded into the weight GEMM); -1 = none
   int dbg;                 // EVAE_GEMM_DBG (tools/gemm_ablate.py): 4 = skip the epilogue, 512 = clock probe; 0 in production
+  ConvMap cv;              // used by the CV != 0 instances only
 };
 
 // Out-of-range chunks are loaded from a clamped, always-mapped address and zeroed LATER, when the
@@ -166,7 +210,7 @@ struct TileLoader {
   }
 };
 
-template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW>
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW, int CV = 0>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g) {
   constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
   constexpr int GNT = 64 * NW;
@@ -235,6 +279,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
     const bool wave_upper = (__builtin_amdgcn_readfirstlane(threadIdx.x) & 256) != 0;
 
     unsigned voA[PAIRS ? 2 : 1][NVA], voB[PAIRS ? 2 : 1][NVB];
+    unsigned long long tapmask[NVA];       // CV = 1: bit t = tap t of this chunk's row lies inside the source image
+    int colch[NVB], coltap[NVB];           // CV = 2: channel offset / tap of this chunk's four im2col columns
     const float* gpA[NVA];
     const float* gpB[NVB];
     unsigned kidx[NVB];
@@ -243,7 +289,24 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
     for (int i = 0; i < NVA; ++i) {
       const int f = threadIdx.x + GNT * i;
       gpA[i] = g.A[0];
-      if (A_KC) {
+      tapmask[i] = 0ull;
+      if (A_KC && CV == 1) {
+        // row = pixel (n, ry, rx): anchor offset in the channels-last source + which taps fall inside the image
+        const int r = m0 + (f >> 3);
+        const bool ok = r < g.M;
+        const unsigned rr = ok ? (unsigned)r : 0u;
+        const unsigned n = fdiv(rr, g.cv.div_rhw), rem = rr - n * (unsigned)(g.cv.RH * g.cv.RW);
+        const unsigned ry = fdiv(rem, g.cv.div_rw), rx = rem - ry * (unsigned)g.cv.RW;
+        const int ay = (int)ry * g.cv.rs + g.cv.roy, ax = (int)rx * g.cv.rs + g.cv.rox;
+        const long long off = (((long long)n * g.cv.IH + ay) * g.cv.IW + ax) * g.cv.ps * 4 + 16 * (f & 7) + (long long)g.cv.bias;
+#pragma unroll
+        for (int p = 0; p < (PAIRS ? 2 : 1); ++p) voA[p][i] = ok ? (unsigned)off : OOB;
+        if (ok)
+          for (int t = 0; t < g.cv.ntaps; ++t) {
+            const int y = ay + g.cv.tdy[t], x = ax + g.cv.tdx[t];
+            if ((unsigned)y < (unsigned)g.cv.IH && (unsigned)x < (unsigned)g.cv.IW) tapmask[i] |= 1ull << t;
+          }
+      } else if (A_KC) {
         const int r = m0 + (f >> 3);
         const bool ok = r < g.M;
         if (gatherA) {
@@ -275,6 +338,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
         const int nlim = g.ones_col >= 0 ? g.ones_col : g.N;
         const bool ok = c + 4 <= nlim;
         onesB[i] = (c == g.ones_col);
+        coltap[i] = -1; colch[i] = 0;
+        if (CV == 2 && ok) { coltap[i] = c / g.cv.Cg; colch[i] = c - coltap[i] * g.cv.Cg; }
         if (gatherB) gpB[i] = g.B[0] + (ok ? c : 0);
 #pragma unroll
         for (int p = 0; p < (PAIRS ? 2 : 1); ++p)
@@ -307,6 +372,16 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
             const int kc = 4 * ((threadIdx.x + GNT * i) & 7);
             ra[i] = ld4v(gpA[i] + ((tail && kc + 4 > kv) ? -kc : k0));
           }
+        } else if constexpr (CV == 1 && A_KC) {
+          // the slab is 32 channels of one tap: tap offset in an SGPR, validity = one bit per row
+          const rsrc_t rA = p1 ? rA1 : rA0;
+          const int tap = k0 / g.cv.Cg;                    // uniform; Cg is a multiple of 32
+          const unsigned so = (unsigned)(g.cv.tsoff[tap] + (k0 - tap * g.cv.Cg) * 4);
+#pragma unroll
+          for (int i = 0; i < NVA; ++i) {
+            const bool live = (tapmask[i] >> tap) & 1ull;
+            ra[i] = buf_ld4(rA, live ? voA[0][i] : OOB, so);
+          }
         } else {
           const rsrc_t rA = p1 ? rA1 : rA0;
           const unsigned so = A_KC ? (unsigned)k0 * 4u : (unsigned)(k0 * (p1 ? g.lda[1] : g.lda[0])) * 4u;
@@ -330,6 +405,20 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
 #pragma unroll
           for (int i = 0; i < NVB; ++i)   // indices of the slab after this one (past the end -> 0)
             kidx[i] = buf_ld1(rIdx, (unsigned)(k0 + BK + (threadIdx.x + GNT * i) / RQB) * 8u, 0u);
+        } else if constexpr (CV == 2 && !B_KC) {
+          // im2col(x)[pixel m = k0 + kk][4 channels of one tap]: pixel decomposed per slab, tap fixed per thread
+#pragma unroll
+          for (int i = 0; i < NVB; ++i) {
+            const int kk = (threadIdx.x + GNT * i) / RQB;
+            const unsigned m = (unsigned)(k0 + kk);
+            const unsigned n = fdiv(m, g.cv.div_rhw), rem = m - n * (unsigned)(g.cv.RH * g.cv.RW);
+            const unsigned ry = fdiv(rem, g.cv.div_rw), rx = rem - ry * (unsigned)g.cv.RW;
+            const int t = coltap[i] < 0 ? 0 : coltap[i];
+            const int y = (int)ry * g.cv.rs + g.cv.roy + g.cv.tdy[t], x = (int)rx * g.cv.rs + g.cv.rox + g.cv.tdx[t];
+            const bool live = coltap[i] >= 0 && kk < kv && (unsigned)y < (unsigned)g.cv.IH && (unsigned)x < (unsigned)g.cv.IW;
+            const unsigned off = (unsigned)((((int)n * g.cv.IH + y) * g.cv.IW + x) * g.cv.ps + colch[i]) * 4u;
+            rb[i] = buf_ld4(rB0, live ? off : OOB, 0u);
+          }
         } else {
           const unsigned so = B_KC ? (unsigned)k0 * 4u : (unsigned)(k0 * (p1 ? g.ldb[1] : g.ldb[0])) * 4u;
 #pragma unroll
@@ -558,6 +647,15 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
   // ---- epilogue.  acc[mt][nt][r] <-> row m0 + wr*32*MT + mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
   //                                    col (within the wave tile) nt*32 + (lane&31)
   const int l31 = lane & 31, lh = lane >> 5;
+  // output row of GEMM row m (identity unless this is the data gradient of a strided convolution)
+  auto orow = [&](int m) -> size_t {
+    if (CV == 1 && g.cv.remap) {
+      const unsigned nn = fdiv((unsigned)m, g.cv.div_rhw), rem = (unsigned)m - nn * (unsigned)(g.cv.RH * g.cv.RW);
+      const unsigned ry = fdiv(rem, g.cv.div_rw), rx = rem - ry * (unsigned)g.cv.RW;
+      return ((size_t)nn * g.cv.OH2 + ry * g.cv.os + g.cv.ooy) * g.cv.OW2 + rx * g.cv.os + g.cv.oox;
+    }
+    return (size_t)m;
+  };
   if (GATED) {
     const int n = n0 + wc * 32 + l31;
     if (n < g.N) {
@@ -574,7 +672,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
               // sigmoid on the hardware exp2 / rcp (about 1e-7 relative): the precise expf costs ~15 VALU instructions
               // per element, and VALU issue is what the co-resident block's MFMAs wait on
               const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc[mt][NT - 1][r] + bg)));
-              const size_t o = (size_t)m * g.ldo + n;
+              const size_t o = orow(m) * g.ldo + n;
               g.out0[o] = h * s;
               if (g.out1) g.out1[o] = h;
               if (g.out2) g.out2[o] = s;
@@ -599,7 +697,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (m >= g.M) continue;
-          const size_t o = (size_t)m * g.ldo + n;
+          const size_t o = orow(m) * g.ldo + n;
           const float v = acc[mt][nt][r];
           if (EPI == EPI_LINEAR) {
             const float pre = v + bias;
@@ -670,12 +768,12 @@ static bool gemm_vec_ok(const GemmArgs& g) {
   return ok;
 }
 
-template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW>
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW, int CV = 0>
 static int launch_gemm_w(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
   static bool attr = false;
   constexpr size_t lds = gemm_lds_bytes(BN_);
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KC, B_KC, EPI, VEC, BN_, NW>,
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KC, B_KC, EPI, VEC, BN_, NW, CV>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
@@ -688,7 +786,7 @@ static int launch_gemm_w(GemmArgs& g, int nz, hipStream_t stream, const char* wh
     if (dbg < 0) { const char* e = getenv("EVAE_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
     g.dbg = dbg;
   }
-  gemm_kernel<A_KC, B_KC, EPI, VEC, BN_, NW><<<grid, 64 * NW, lds, stream>>>(g);
+  gemm_kernel<A_KC, B_KC, EPI, VEC, BN_, NW, CV><<<grid, 64 * NW, lds, stream>>>(g);
   return check_launch(what);
 }
 
@@ -898,4 +996,235 @@ extern "C" int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, in
   EVAE_REQUIRE(act >= 0 && act <= 2, "act_bwd: bad activation %d", act);
   act_bwd_kernel<<<elt_grid(n), 256, 0, (hipStream_t)stream_>>>(dy, y_or_pre ? y_or_pre : dy, n, act, act_lo, act_hi, dpre);
   return check_launch("act_bwd");
+}
+
+// ========================================================================================================
+// Convolutions over channels-last tensors as instances of the GEMM above (CV = 1 / 2, see ConvMap).
+// Activations are [N][H][W][C] ("NHWC": torch.channels_last storage of a logical NCHW tensor); filters keep the
+// nn.Conv2d layout [Co][C][KH][KW] at the boundary and are re-ordered to (kh, kw, c) by a small pre-pass.
+// ========================================================================================================
+namespace evae {
+
+// wp[co][t][c] = w[co][c][t]          (forward B operand, k-contiguous rows of K = taps * C)
+__global__ void cl_permute_fwd_kernel(const float* __restrict__ w, int Co, int C, int taps, float* __restrict__ wp) {
+  const size_t n = (size_t)Co * C * taps;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int t = (int)((i / C) % taps);
+    const int co = (int)(i / ((size_t)C * taps));
+    wp[i] = w[((size_t)co * C + c) * taps + t];
+  }
+}
+// wp[j][co][c] = w[co][c][tap_list[j]]   (data-gradient B operand of one stride-parity class, rows k' = (j, co))
+struct TapList { int n; int t[64]; };
+__global__ void cl_permute_dgrad_kernel(const float* __restrict__ w, int Co, int C, int taps, TapList tl,
+                                        float* __restrict__ wp) {
+  const size_t n = (size_t)tl.n * Co * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int co = (int)((i / C) % Co);
+    const int j = (int)(i / ((size_t)C * Co));
+    wp[i] = w[((size_t)co * C + c) * taps + tl.t[j]];
+  }
+}
+
+static bool cl_fits(const evae_conv_desc_t* d, int OH, int OW, int chan_in, int chan_out) {
+  const int64_t lim = ((int64_t)1 << 29) - ((int64_t)1 << 22);   // floats; room for the bias terms
+  return (int64_t)d->N * d->H * d->W * chan_in < lim && (int64_t)d->N * OH * OW * chan_out < lim;
+}
+static void cl_out_dims(const evae_conv_desc_t* d, int* OH, int* OW) {
+  *OH = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+  *OW = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+}
+
+}  // namespace evae
+
+using namespace evae;
+
+extern "C" int evae_conv2d_cl_supported(const evae_conv_desc_t* d, int what, int gated) {
+  if (!d || d->N <= 0 || d->stride < 1 || d->KH * d->KW > 64) return 0;
+  int OH, OW;
+  cl_out_dims(d, &OH, &OW);
+  if (OH <= 0 || OW <= 0) return 0;
+  const int ctot = d->Co * (gated ? 2 : 1);
+  if (!cl_fits(d, OH, OW, d->C, ctot)) return 0;
+  if (what == 0) return d->C % 32 == 0;
+  if (what == 1) return d->Co % 32 == 0 && d->C % 4 == 0;
+  return d->C % 4 == 0 && ctot % 4 == 0;
+}
+
+extern "C" size_t evae_conv2d_cl_workspace_bytes(const evae_conv_desc_t* d, int what, int gated) {
+  if (!d) return 256;
+  const size_t K = (size_t)d->C * d->KH * d->KW;
+  const size_t wbytes = align_up((size_t)d->Co * K * sizeof(float), 256);
+  if (what == 0) return (gated ? 2 : 1) * wbytes + 256;
+  if (what == 1) return (size_t)(gated ? 2 : 1) * wbytes * 1 + 4096;      // class slices are disjoint parts of one permuted copy
+  // weight gradient: split-K partial planes [nz][ctot][K + 1]
+  int OH, OW;
+  cl_out_dims(d, &OH, &OW);
+  const int ctot = d->Co * (gated ? 2 : 1);
+  Plan pl = make_plan(ctot, (int)K + 1, cdiv(d->N * OH * OW, BK), false, true, 1);
+  return align_up((size_t)pl.nz * ctot * (K + 1) * sizeof(float), 256) + 256;
+}
+
+extern "C" int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, const float* wh, const float* bh,
+                                  const float* wg, const float* bg, int act, float act_lo, float act_hi,
+                                  float* out, float* save_h, float* save_s, void* ws, size_t ws_bytes,
+                                  evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(d && x && wh && out, "conv2d_cl_fwd: null pointer");
+  const bool gated = wg != nullptr;
+  EVAE_REQUIRE(evae_conv2d_cl_supported(d, 0, gated), "conv2d_cl_fwd: unsupported geometry (C %% 32, size)");
+  EVAE_REQUIRE(ws && ws_bytes >= evae_conv2d_cl_workspace_bytes(d, 0, gated), "conv2d_cl_fwd: workspace too small");
+  EVAE_REQUIRE(act >= 0 && act <= 2, "conv2d_cl_fwd: bad activation %d", act);
+  int OH, OW;
+  cl_out_dims(d, &OH, &OW);
+  const int taps = d->KH * d->KW, K = taps * d->C, M = d->N * OH * OW;
+  float* wph = (float*)ws;
+  float* wpg = (float*)((char*)ws + align_up((size_t)d->Co * K * sizeof(float), 256));
+  cl_permute_fwd_kernel<<<elt_grid((size_t)d->Co * K), 256, 0, stream>>>(wh, d->Co, d->C, taps, wph);
+  if (gated) cl_permute_fwd_kernel<<<elt_grid((size_t)d->Co * K), 256, 0, stream>>>(wg, d->Co, d->C, taps, wpg);
+  int rc = check_launch("cl_permute_fwd_kernel");
+  if (rc) return rc;
+  GemmArgs g = {};
+  g.ones_col = -1;
+  ConvMap& cv = g.cv;
+  cv.Cg = d->C; cv.ps = d->C; cv.ntaps = taps;
+  cv.RH = OH; cv.RW = OW; cv.IH = d->H; cv.IW = d->W;
+  cv.rs = d->stride; cv.roy = -d->pad; cv.rox = -d->pad;
+  cv.remap = 0;
+  cv.div_rw = make_fastdiv((unsigned)OW); cv.div_rhw = make_fastdiv((unsigned)(OH * OW));
+  cv.bias = (unsigned)((d->pad * d->W + d->pad) * d->C * 4);
+  for (int kh = 0; kh < d->KH; ++kh)
+    for (int kw = 0; kw < d->KW; ++kw) {
+      const int t = kh * d->KW + kw;
+      cv.tdy[t] = (signed char)kh; cv.tdx[t] = (signed char)kw;
+      cv.tsoff[t] = (kh * d->W + kw) * d->C * 4;
+    }
+  g.A[0] = x - cv.bias / 4;          // the per-row offsets carry +bias (they are never negative)
+  g.B[0] = wph; g.Bg = gated ? wpg : nullptr;
+  g.lda[0] = d->C; g.ldb[0] = K; g.Kc[0] = K; g.npairs = 1;
+  g.M = M; g.N = d->Co; g.bias0 = bh; g.bias1 = bg; g.ldo = d->Co;
+  g.act = act; g.lo = act_lo; g.hi = act_hi;
+  g.ksplit = 0;
+  if (gated) {
+    g.out0 = out; g.out1 = save_h; g.out2 = save_s;
+    return launch_gemm_w<true, true, EPI_GATED, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_fwd(gated)");
+  }
+  g.out0 = out; g.out1 = save_h;    // pre-activation when requested
+  if (d->Co <= 64) return launch_gemm_w<true, true, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_fwd");
+  return launch_gemm_w<true, true, EPI_LINEAR, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_fwd");
+}
+
+// dy: [N][OH][OW][ctot] with ctot = Co (plain) or 2 Co (gated: [dh | dg] per pixel); dx: [N][H][W][C]
+extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const float* wg, const evae_conv_desc_t* d,
+                                       float* dx, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(d && dy && wh && dx, "conv2d_cl_bwd_data: null pointer");
+  const bool gated = wg != nullptr;
+  EVAE_REQUIRE(evae_conv2d_cl_supported(d, 1, gated), "conv2d_cl_bwd_data: unsupported geometry");
+  EVAE_REQUIRE(ws && ws_bytes >= evae_conv2d_cl_workspace_bytes(d, 1, gated), "conv2d_cl_bwd_data: workspace too small");
+  int OH, OW;
+  cl_out_dims(d, &OH, &OW);
+  const int taps = d->KH * d->KW, s = d->stride, Co = d->Co, C = d->C;
+  const int ctot = Co * (gated ? 2 : 1);
+  const size_t wslice = align_up((size_t)Co * C * taps * sizeof(float), 256);
+  float* wp_h = (float*)ws;
+  float* wp_g = (float*)((char*)ws + wslice);
+  size_t used = 0;      // floats of the permuted copy consumed by the classes so far
+  bool any_empty = false;
+  for (int py = 0; py < s && py < d->H; ++py)
+    for (int px = 0; px < s && px < d->W; ++px) {
+      TapList tl; tl.n = 0;
+      for (int kh = 0; kh < d->KH; ++kh)
+        for (int kw = 0; kw < d->KW; ++kw)
+          if ((py + d->pad - kh) % s == 0 && (px + d->pad - kw) % s == 0) tl.t[tl.n++] = kh * d->KW + kw;
+      if (tl.n == 0) any_empty = true;
+    }
+  if (any_empty) {
+    hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->N * d->H * d->W * C * sizeof(float), stream);
+    EVAE_REQUIRE(e == hipSuccess, "conv2d_cl_bwd_data: memset failed");
+  }
+  for (int py = 0; py < s && py < d->H; ++py)
+    for (int px = 0; px < s && px < d->W; ++px) {
+      TapList tl; tl.n = 0;
+      GemmArgs g = {};
+      g.ones_col = -1;
+      ConvMap& cv = g.cv;
+      int tmin = 0;
+      for (int kh = 0; kh < d->KH; ++kh)
+        for (int kw = 0; kw < d->KW; ++kw)
+          if ((py + d->pad - kh) % s == 0 && (px + d->pad - kw) % s == 0) {
+            const int j = tl.n++;
+            tl.t[j] = kh * d->KW + kw;
+            const int dy_ = (py + d->pad - kh) / s, dx_ = (px + d->pad - kw) / s;   // exact; may be negative
+            cv.tdy[j] = (signed char)dy_; cv.tdx[j] = (signed char)dx_;
+            cv.tsoff[j] = (dy_ * OW + dx_) * ctot * 4;
+            if (cv.tsoff[j] < tmin) tmin = cv.tsoff[j];
+          }
+      if (tl.n == 0) continue;
+      const unsigned tbias = (unsigned)(-tmin);
+      for (int j = 0; j < tl.n; ++j) cv.tsoff[j] += (int)tbias;
+      const int RH = (d->H - py + s - 1) / s, RW = (d->W - px + s - 1) / s;
+      const size_t cls = (size_t)tl.n * Co * C;
+      float* wch = wp_h + used;
+      float* wcg = wp_g + used;
+      used += cls;
+      cl_permute_dgrad_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, Co, C, taps, tl, wch);
+      if (gated) cl_permute_dgrad_kernel<<<elt_grid(cls), 256, 0, stream>>>(wg, Co, C, taps, tl, wcg);
+      int rc = check_launch("cl_permute_dgrad_kernel");
+      if (rc) return rc;
+      cv.Cg = Co; cv.ps = ctot; cv.ntaps = tl.n;
+      cv.RH = RH; cv.RW = RW; cv.IH = OH; cv.IW = OW;
+      cv.rs = 1; cv.roy = 0; cv.rox = 0;
+      cv.OH2 = d->H; cv.OW2 = d->W; cv.os = s; cv.ooy = py; cv.oox = px;
+      cv.remap = 1;
+      cv.div_rw = make_fastdiv((unsigned)RW); cv.div_rhw = make_fastdiv((unsigned)(RH * RW));
+      cv.bias = 0;
+      g.A[0] = dy - tbias / 4;
+      g.A[1] = dy + Co - tbias / 4;
+      g.B[0] = wch; g.B[1] = wcg;
+      g.lda[0] = g.lda[1] = ctot; g.ldb[0] = g.ldb[1] = C;
+      g.Kc[0] = tl.n * Co; g.Kc[1] = gated ? tl.n * Co : 0; g.npairs = gated ? 2 : 1;
+      g.M = d->N * RH * RW; g.N = C; g.out0 = dx; g.ldo = C;
+      g.ksplit = 0;
+      if (C <= 64) rc = launch_gemm_w<true, false, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data");
+      else rc = launch_gemm_w<true, false, EPI_LINEAR, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data");
+      if (rc) return rc;
+    }
+  return EVAE_OK;
+}
+
+// dy as above; x: [N][H][W][C]; dw: [ctot][C][KH][KW] (nn.Conv2d layout, h rows then g rows), db: [ctot]
+extern "C" int evae_conv2d_cl_bwd_weight(const float* dy, const float* x, const evae_conv_desc_t* d, int gated,
+                                         float* dw, float* db, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(d && dy && x && dw, "conv2d_cl_bwd_weight: null pointer");
+  EVAE_REQUIRE(evae_conv2d_cl_supported(d, 2, gated), "conv2d_cl_bwd_weight: unsupported geometry");
+  EVAE_REQUIRE(ws && ws_bytes >= evae_conv2d_cl_workspace_bytes(d, 2, gated), "conv2d_cl_bwd_weight: workspace too small");
+  int OH, OW;
+  cl_out_dims(d, &OH, &OW);
+  const int taps = d->KH * d->KW, K = taps * d->C, Mpix = d->N * OH * OW;
+  const int ctot = d->Co * (gated ? 2 : 1);
+  Plan pl = make_plan(ctot, K + 1, cdiv(Mpix, BK), false, true, 1);
+  GemmArgs g = {};
+  ConvMap& cv = g.cv;
+  cv.Cg = d->C; cv.ps = d->C; cv.ntaps = taps;
+  cv.RH = OH; cv.RW = OW; cv.IH = d->H; cv.IW = d->W;
+  cv.rs = d->stride; cv.roy = -d->pad; cv.rox = -d->pad;
+  cv.div_rw = make_fastdiv((unsigned)OW); cv.div_rhw = make_fastdiv((unsigned)(OH * OW));
+  for (int kh = 0; kh < d->KH; ++kh)
+    for (int kw = 0; kw < d->KW; ++kw) { cv.tdy[kh * d->KW + kw] = (signed char)kh; cv.tdx[kh * d->KW + kw] = (signed char)kw; }
+  g.A[0] = dy; g.B[0] = x; g.lda[0] = ctot; g.ldb[0] = K + 1; g.Kc[0] = Mpix; g.npairs = 1;
+  g.M = ctot; g.N = K + 1; g.ones_col = K; g.ldo = K + 1;
+  g.out0 = (float*)ws;
+  g.ksplit = pl.nz > 1 ? pl.ksplit : 0;
+  int rc;
+  if (pl.bn == 128) rc = launch_gemm_w<false, false, EPI_RAW, true, 128, 8, 2>(g, pl.nz, stream, "conv2d_cl_bwd_weight");
+  else rc = launch_gemm_w<false, false, EPI_RAW, true, 64, 8, 2>(g, pl.nz, stream, "conv2d_cl_bwd_weight");
+  if (rc) return rc;
+  FinishArgs f = {};
+  f.part = (const float*)ws; f.nz = pl.nz; f.M = ctot; f.N = K + 1; f.ldo = K + 1; f.epi = EPI_RAW; f.out0 = dw;
+  f.ones_col = K; f.out_db = db; f.perm_c = d->C; f.perm_taps = taps;
+  return launch_finish(f, stream);
 }

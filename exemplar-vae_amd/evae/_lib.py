@@ -54,6 +54,11 @@ SIGNATURES = {
     "evae_conv2d_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _z, _p]),
     "evae_conv2d_bwd_data": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_conv2d_bwd_weight": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_conv2d_cl_supported": (_i, [_p, _i, _i]),
+    "evae_conv2d_cl_workspace_bytes": (_z, [_p, _i, _i]),
+    "evae_conv2d_cl_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _z, _p]),
+    "evae_conv2d_cl_bwd_data": (_i, [_p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_conv2d_cl_bwd_weight": (_i, [_p, _p, _p, _i, _p, _p, _p, _z, _p]),
     "evae_reparam_logq_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_reparam_logq_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_log_normal_diag_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),

@@ -353,66 +353,146 @@ def _int1(v):
     return int(v)
 
 
+CL = torch.channels_last
+
+
+def _cl(t):
+    """channels-last storage ([N][H][W][C]) of a logical NCHW tensor"""
+    return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
+
+
 class Conv2dFn(torch.autograd.Function):
-    """act(conv2d(x, wh) + bh) [* sigmoid(conv2d(x, wg) + bg)]  -- utils/nn.py:72-114, nn.Conv2d."""
+    """act(conv2d(x, wh) + bh) [* sigmoid(conv2d(x, wg) + bg)]  -- utils/nn.py:72-114, nn.Conv2d.
+
+    Two kernel families behind one interface (include/evae_hip.h): channels-last GEMM instances when the geometry
+    qualifies (input channels a multiple of 32: every layer but the first of the reference's conv stacks), the NCHW
+    implicit-GEMM kernels otherwise.  Tensors keep their logical NCHW shape; outputs of the channels-last family
+    are torch.channels_last tensors, so a stack of qualifying layers never changes layout."""
 
     @staticmethod
     def forward(ctx, x, wh, bh, wg, bg, stride, pad, act, lo, hi):
         lib = _lib.load()
         _need_cuda(x, wh, wg)
-        x = _f32(x); wh = _f32(wh); wg = None if wg is None else _f32(wg)
+        x = x.float(); wh = _f32(wh); wg = None if wg is None else _f32(wg)
         d, OH, OW = _conv_desc(x, wh, stride, pad)
         gated = wg is not None
-        out = torch.empty((d.N, d.Co, OH, OW), device=x.device)
         need_grad = any(ctx.needs_input_grad)
-        h = torch.empty_like(out) if (gated and need_grad) else None
-        s = torch.empty_like(out) if (gated and need_grad) else None
-        pre = torch.empty_like(out) if (not gated and need_grad and act == ACT_HARDTANH) else None
-        nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 0, int(gated))
-        ws = _workspace("conv", nb, x.device)
-        _lib.check(lib.evae_conv2d_fwd(_p(x), C.byref(d), _p(wh), _p(bh), _p(wg), _p(bg), act, float(lo), float(hi),
-                                       _p(out), _p(h if gated else pre), _p(s), _p(ws), ws.numel(), _stream()),
-                   "evae_conv2d_fwd")
+        cl = bool(lib.evae_conv2d_cl_supported(C.byref(d), 0, int(gated)))
+        if cl:
+            x = _cl(x)
+            fmt = dict(device=x.device, memory_format=CL)
+        else:
+            x = x.contiguous()
+            fmt = dict(device=x.device)
+        out = torch.empty((d.N, d.Co, OH, OW), **fmt)
+        h = torch.empty((d.N, d.Co, OH, OW), **fmt) if (gated and need_grad) else None
+        s = torch.empty((d.N, d.Co, OH, OW), **fmt) if (gated and need_grad) else None
+        pre = torch.empty((d.N, d.Co, OH, OW), **fmt) if (not gated and need_grad and act == ACT_HARDTANH) else None
+        if cl:
+            nb = lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 0, int(gated))
+            ws = _workspace("conv", nb, x.device)
+            _lib.check(lib.evae_conv2d_cl_fwd(_p(x), C.byref(d), _p(wh), _p(bh), _p(wg), _p(bg), act, float(lo), float(hi),
+                                              _p(out), _p(h if gated else pre), _p(s), _p(ws), ws.numel(), _stream()),
+                       "evae_conv2d_cl_fwd")
+        else:
+            nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 0, int(gated))
+            ws = _workspace("conv", nb, x.device)
+            _lib.check(lib.evae_conv2d_fwd(_p(x), C.byref(d), _p(wh), _p(bh), _p(wg), _p(bg), act, float(lo), float(hi),
+                                           _p(out), _p(h if gated else pre), _p(s), _p(ws), ws.numel(), _stream()),
+                       "evae_conv2d_fwd")
         if need_grad:
             ctx.save_for_backward(x, wh, wg, h, s, pre if pre is not None else out)
-        ctx.cfg = (d, gated, act, float(lo), float(hi), bh is not None, bg is not None)
+        ctx.cfg = (d, gated, act, float(lo), float(hi), bh is not None, bg is not None, cl)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
         x, wh, wg, h, s, aux = ctx.saved_tensors
-        d, gated, act, lo, hi, has_bh, has_bg = ctx.cfg
-        dout = _f32(dout)
-        n = dout.numel()
-        if gated:
-            if act != ACT_NONE:
-                raise _lib.EvaeError("gated conv with an activation on h: compose it from two plain convs")
-            dh = torch.empty_like(dout); dg = torch.empty_like(dout)
-            _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(h), _p(s), 1, n, _p(dh), _p(dg), n, _stream()),
-                       "evae_gated_dense_bwd_input")
-        else:
-            dg = None
-            if act != ACT_NONE:
-                dh = torch.empty_like(dout)
-                _lib.check(lib.evae_act_bwd(_p(dout), _p(aux), n, act, lo, hi, _p(dh), _stream()), "evae_act_bwd")
-            else:
-                dh = dout
-        K = d.C * d.KH * d.KW
-        rows = d.Co * (2 if gated else 1)
-        dw = torch.empty((rows, K), device=dout.device); db = torch.empty(rows, device=dout.device)
-        nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 2, int(gated))
-        ws = _workspace("conv", nb, dout.device)
-        _lib.check(lib.evae_conv2d_bwd_weight(_p(dh), _p(dg), _p(x), C.byref(d), _p(dw), _p(db), _p(ws), ws.numel(),
-                                              _stream()), "evae_conv2d_bwd_weight")
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 1, int(gated))
-            ws = _workspace("conv", nb, dout.device)
-            _lib.check(lib.evae_conv2d_bwd_data(_p(dh), _p(wh), _p(dg), _p(wg), C.byref(d), _p(dx), _p(ws), ws.numel(),
-                                                _stream()), "evae_conv2d_bwd_data")
+        d, gated, act, lo, hi, has_bh, has_bg, cl = ctx.cfg
+        dev = dout.device
         shp = wh.shape
+        ctot = d.Co * (2 if gated else 1)
+        K = d.C * d.KH * d.KW
+        OH, OW = dout.shape[2], dout.shape[3]
+        # channels-last family for the gradients when this layer ran it forward (saved tensors are channels-last)
+        # or when the weight gradient qualifies anyway (then x is re-laid out once)
+        cl_w = bool(lib.evae_conv2d_cl_supported(C.byref(d), 2, int(gated))) and cl
+        cl_d = bool(lib.evae_conv2d_cl_supported(C.byref(d), 1, int(gated))) and cl
+        if cl:
+            dout = _cl(dout.float())
+        else:
+            dout = _f32(dout)
+        n = dout.numel()
+        if cl:
+            # [dh | dg] per pixel in ONE buffer: logical [N, ctot, OH, OW], channels-last
+            dy = torch.empty((d.N, ctot, OH, OW), device=dev, memory_format=CL)
+            if gated:
+                if act != ACT_NONE:
+                    raise _lib.EvaeError("gated conv with an activation on h: compose it from two plain convs")
+                # rows = pixels, columns = Co channels: dh to columns [0, Co), dg to [Co, 2 Co)
+                _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(h), _p(s), n // d.Co, d.Co, _p(dy),
+                                                          C.c_void_p(dy.data_ptr() + 4 * d.Co), 2 * d.Co, _stream()),
+                           "evae_gated_dense_bwd_input")
+            elif act != ACT_NONE:
+                _lib.check(lib.evae_act_bwd(_p(dout), _p(aux), n, act, lo, hi, _p(dy), _stream()), "evae_act_bwd")
+            else:
+                dy = dout
+            dw = torch.empty((ctot, K), device=dev); db = torch.empty(ctot, device=dev)
+            if cl_w:
+                nb = lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 2, int(gated))
+                ws = _workspace("conv", nb, dev)
+                _lib.check(lib.evae_conv2d_cl_bwd_weight(_p(dy), _p(x), C.byref(d), int(gated), _p(dw), _p(db), _p(ws),
+                                                         ws.numel(), _stream()), "evae_conv2d_cl_bwd_weight")
+            dx = None
+            if ctx.needs_input_grad[0] and cl_d:
+                dx = torch.empty(x.shape, device=dev, memory_format=CL)
+                nb = lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 1, int(gated))
+                ws = _workspace("conv", nb, dev)
+                _lib.check(lib.evae_conv2d_cl_bwd_data(_p(dy), _p(wh), _p(wg), C.byref(d), _p(dx), _p(ws), ws.numel(),
+                                                       _stream()), "evae_conv2d_cl_bwd_data")
+            if (not cl_w) or (ctx.needs_input_grad[0] and not cl_d):
+                # the rest through the NCHW kernels (e.g. the data gradient of a 6-channel output layer)
+                dhn = dy[:, :d.Co].contiguous()
+                dgn = dy[:, d.Co:].contiguous() if gated else None
+                xn = x.contiguous()
+                if not cl_w:
+                    nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 2, int(gated))
+                    ws = _workspace("conv", nb, dev)
+                    _lib.check(lib.evae_conv2d_bwd_weight(_p(dhn), _p(dgn), _p(xn), C.byref(d), _p(dw), _p(db), _p(ws),
+                                                          ws.numel(), _stream()), "evae_conv2d_bwd_weight")
+                if ctx.needs_input_grad[0] and not cl_d:
+                    dx = torch.empty(xn.shape, device=dev)
+                    nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 1, int(gated))
+                    ws = _workspace("conv", nb, dev)
+                    _lib.check(lib.evae_conv2d_bwd_data(_p(dhn), _p(wh), _p(dgn), _p(wg), C.byref(d), _p(dx), _p(ws),
+                                                        ws.numel(), _stream()), "evae_conv2d_bwd_data")
+        else:
+            if gated:
+                if act != ACT_NONE:
+                    raise _lib.EvaeError("gated conv with an activation on h: compose it from two plain convs")
+                dh = torch.empty_like(dout); dg = torch.empty_like(dout)
+                _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(h), _p(s), 1, n, _p(dh), _p(dg), n, _stream()),
+                           "evae_gated_dense_bwd_input")
+            else:
+                dg = None
+                if act != ACT_NONE:
+                    dh = torch.empty_like(dout)
+                    _lib.check(lib.evae_act_bwd(_p(dout), _p(aux), n, act, lo, hi, _p(dh), _stream()), "evae_act_bwd")
+                else:
+                    dh = dout
+            dw = torch.empty((ctot, K), device=dev); db = torch.empty(ctot, device=dev)
+            nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 2, int(gated))
+            ws = _workspace("conv", nb, dev)
+            _lib.check(lib.evae_conv2d_bwd_weight(_p(dh), _p(dg), _p(x), C.byref(d), _p(dw), _p(db), _p(ws), ws.numel(),
+                                                  _stream()), "evae_conv2d_bwd_weight")
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 1, int(gated))
+                ws = _workspace("conv", nb, dev)
+                _lib.check(lib.evae_conv2d_bwd_data(_p(dh), _p(wh), _p(dg), _p(wg), C.byref(d), _p(dx), _p(ws), ws.numel(),
+                                                    _stream()), "evae_conv2d_bwd_data")
         gwh = dw[:d.Co].reshape(shp)
         gwg = dw[d.Co:].reshape(shp) if gated else None
         return (dx, gwh, db[:d.Co] if has_bh else None, gwg, (db[d.Co:] if (gated and has_bg) else None),

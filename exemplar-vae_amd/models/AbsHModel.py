@@ -35,7 +35,7 @@ class BaseHModel(BaseModel):
     def q_z1(self, x, z2):
         hx = self.q_z1_layers_x(x)
         if self.args.model_name == 'convhvae_2level':
-            hx = hx.view(hx.size(0), -1)
+            hx = hx.reshape(hx.size(0), -1)      # conv outputs may be channels-last tensors: reshape keeps the logical (c, y, x) order
         hz = self.q_z1_layers_z2(z2)
         h = self.q_z1_layers_joint(torch.cat((hx, hz), 1))
         return self.q_z1_mean(h), self.q_z1_logvar(h)
@@ -50,14 +50,14 @@ class BaseHModel(BaseModel):
         x_mean = self.p_x_mean(h_decoder)
         d_in = int(np.prod(self.args.input_size))
         if conv:
-            x_mean = x_mean.view(-1, d_in)
+            x_mean = x_mean.reshape(-1, d_in)
         if self.args.input_type == 'binary':
             x_logvar = 0.
         else:
             x_mean = torch.clamp(x_mean, min=0. + 1. / 512., max=1. - 1. / 512.)
             x_logvar = self.p_x_logvar(h_decoder)
             if conv:
-                x_logvar = x_logvar.view(-1, d_in)
+                x_logvar = x_logvar.reshape(-1, d_in)
         return x_mean, x_logvar
 
     def forward(self, x):

@@ -259,7 +259,7 @@ class BaseModel(nn.Module, ABC):
             x = x.view(-1, self.args.input_size[0], self.args.input_size[1], self.args.input_size[2])
         h = self._encode_rows(self.q_z_layers, x, rows)
         if self.args.model_name == 'convhvae_2level':
-            h = h.view(h.size(0), -1)
+            h = h.reshape(h.size(0), -1)         # conv outputs may be channels-last tensors
         z_q_mean = self.q_z_mean(h)
         n = h.shape[0]
         if prior is True and self.args.prior == 'exemplar_prior':
