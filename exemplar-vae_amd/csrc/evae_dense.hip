@@ -26,6 +26,7 @@
 //   stay in one L2).
 #include "evae_gemm_core.h"
 #include <type_traits>
+#include <algorithm>
 
 namespace evae {
 
@@ -1015,22 +1016,34 @@ __global__ void cl_permute_fwd_kernel(const float* __restrict__ w, int Co, int C
     wp[i] = w[((size_t)co * C + c) * taps + t];
   }
 }
-// wp[j][co][c] = w[co][c][tap_list[j]]   (data-gradient B operand of one stride-parity class, rows k' = (j, co))
+// wp[j][cc][c], cc < ld: rows of the data-gradient B operand of one stride-parity class, k' = (j, cc) with cc running
+// over the channels of the merged gradient buffer: cc < Co -> wh[cc][c][tap_j], Co <= cc < 2Co -> wg[cc - Co][c][tap_j]
+// (gated), anything beyond -> 0 (the buffer's zero padding up to a multiple of 32)
 struct TapList { int n; int t[64]; };
-__global__ void cl_permute_dgrad_kernel(const float* __restrict__ w, int Co, int C, int taps, TapList tl,
-                                        float* __restrict__ wp) {
-  const size_t n = (size_t)tl.n * Co * C;
+__global__ void cl_permute_dgrad_kernel(const float* __restrict__ wh, const float* __restrict__ wg, int Co, int C,
+                                        int taps, int ld, TapList tl, float* __restrict__ wp) {
+  const size_t n = (size_t)tl.n * ld * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
-    const int co = (int)((i / C) % Co);
-    const int j = (int)(i / ((size_t)C * Co));
-    wp[i] = w[((size_t)co * C + c) * taps + tl.t[j]];
+    const int cc = (int)((i / C) % ld);
+    const int j = (int)(i / ((size_t)C * ld));
+    float v = 0.f;
+    if (cc < Co) v = wh[((size_t)cc * C + c) * taps + tl.t[j]];
+    else if (wg != nullptr && cc < 2 * Co) v = wg[((size_t)(cc - Co) * C + c) * taps + tl.t[j]];
+    wp[i] = v;
   }
 }
 
-static bool cl_fits(const evae_conv_desc_t* d, int OH, int OW, int chan_in, int chan_out) {
+// The buffer-load offsets are 31-bit: a pass handles at most this many images (0: one image alone is too big)
+static int cl_images_per_pass(const evae_conv_desc_t* d, int OH, int OW, int chan_in, int chan_out) {
   const int64_t lim = ((int64_t)1 << 29) - ((int64_t)1 << 22);   // floats; room for the bias terms
-  return (int64_t)d->N * d->H * d->W * chan_in < lim && (int64_t)d->N * OH * OW * chan_out < lim;
+  const int64_t per = std::max((int64_t)d->H * d->W * chan_in, (int64_t)OH * OW * chan_out);
+  int64_t n = lim / (per > 0 ? per : 1);
+  if (const char* e = getenv("EVAE_CL_IMAGES_PER_PASS")) {       // tests: exercise the multi-pass logic on small tensors
+    const int64_t f = atoll(e);
+    if (f > 0 && f < n) n = f;
+  }
+  return (int)std::min<int64_t>(n, d->N);
 }
 static void cl_out_dims(const evae_conv_desc_t* d, int* OH, int* OW) {
   *OH = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
@@ -1041,30 +1054,44 @@ static void cl_out_dims(const evae_conv_desc_t* d, int* OH, int* OW) {
 
 using namespace evae;
 
+extern "C" int evae_conv2d_cl_dy_stride(int ctot);
+
 extern "C" int evae_conv2d_cl_supported(const evae_conv_desc_t* d, int what, int gated) {
   if (!d || d->N <= 0 || d->stride < 1 || d->KH * d->KW > 64) return 0;
   int OH, OW;
   cl_out_dims(d, &OH, &OW);
   if (OH <= 0 || OW <= 0) return 0;
   const int ctot = d->Co * (gated ? 2 : 1);
-  if (!cl_fits(d, OH, OW, d->C, ctot)) return 0;
+  if (cl_images_per_pass(d, OH, OW, d->C, evae_conv2d_cl_dy_stride(ctot)) < 1) return 0;
   if (what == 0) return d->C % 32 == 0;
-  if (what == 1) return d->Co % 32 == 0 && d->C % 4 == 0;
+  if (what == 1) return d->C % 4 == 0;
   return d->C % 4 == 0 && ctot % 4 == 0;
 }
+
+// channels per pixel of the merged gradient buffer: ctot rounded up to a multiple of 32 (zero padding)
+extern "C" int evae_conv2d_cl_dy_stride(int ctot) { return (ctot + 31) / 32 * 32; }
 
 extern "C" size_t evae_conv2d_cl_workspace_bytes(const evae_conv_desc_t* d, int what, int gated) {
   if (!d) return 256;
   const size_t K = (size_t)d->C * d->KH * d->KW;
   const size_t wbytes = align_up((size_t)d->Co * K * sizeof(float), 256);
   if (what == 0) return (gated ? 2 : 1) * wbytes + 256;
-  if (what == 1) return (size_t)(gated ? 2 : 1) * wbytes * 1 + 4096;      // class slices are disjoint parts of one permuted copy
+  if (what == 1) {   // one permuted copy [taps][ldy][C], class slices are disjoint parts of it
+    const int ctot1 = d->Co * (gated ? 2 : 1);
+    return align_up((size_t)d->KH * d->KW * evae_conv2d_cl_dy_stride(ctot1) * d->C * sizeof(float), 256) + 256;
+  }
   // weight gradient: split-K partial planes [nz][ctot][K + 1]
   int OH, OW;
   cl_out_dims(d, &OH, &OW);
   const int ctot = d->Co * (gated ? 2 : 1);
-  Plan pl = make_plan(ctot, (int)K + 1, cdiv(d->N * OH * OW, BK), false, true, 1);
-  return align_up((size_t)pl.nz * ctot * (K + 1) * sizeof(float), 256) + 256;
+  const int per = cl_images_per_pass(d, OH, OW, d->C, evae_conv2d_cl_dy_stride(ctot));
+  size_t best = 0;     // the first (full) pass and the last (remainder) pass may plan different splits
+  for (int nn : {std::min(per, d->N), per > 0 ? (d->N % per) : 0}) {
+    if (nn <= 0) continue;
+    Plan pl = make_plan(ctot, (int)K + 1, cdiv(nn * OH * OW, BK), false, true, 1);
+    best = std::max(best, (size_t)pl.nz * ctot * (K + 1) * sizeof(float));
+  }
+  return align_up(best, 256) + 256;
 }
 
 extern "C" int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, const float* wh, const float* bh,
@@ -1101,22 +1128,34 @@ extern "C" int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, con
       cv.tdy[t] = (signed char)kh; cv.tdx[t] = (signed char)kw;
       cv.tsoff[t] = (kh * d->W + kw) * d->C * 4;
     }
-  g.A[0] = x - cv.bias / 4;          // the per-row offsets carry +bias (they are never negative)
   g.B[0] = wph; g.Bg = gated ? wpg : nullptr;
   g.lda[0] = d->C; g.ldb[0] = K; g.Kc[0] = K; g.npairs = 1;
-  g.M = M; g.N = d->Co; g.bias0 = bh; g.bias1 = bg; g.ldo = d->Co;
+  g.N = d->Co; g.bias0 = bh; g.bias1 = bg; g.ldo = d->Co;
   g.act = act; g.lo = act_lo; g.hi = act_hi;
   g.ksplit = 0;
-  if (gated) {
-    g.out0 = out; g.out1 = save_h; g.out2 = save_s;
-    return launch_gemm_w<true, true, EPI_GATED, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_fwd(gated)");
+  (void)M;
+  const int per = cl_images_per_pass(d, OH, OW, d->C, d->Co);
+  for (int n0 = 0; n0 < d->N; n0 += per) {           // independent images: passes of at most 2 GiB each
+    const int nn = std::min(per, d->N - n0);
+    const size_t xo = (size_t)n0 * d->H * d->W * d->C, oo = (size_t)n0 * OH * OW * d->Co;
+    g.A[0] = x + xo - cv.bias / 4;     // the per-row offsets carry +bias (they are never negative)
+    g.M = nn * OH * OW;
+    int rc;
+    if (gated) {
+      g.out0 = out + oo; g.out1 = save_h ? save_h + oo : nullptr; g.out2 = save_s ? save_s + oo : nullptr;
+      rc = launch_gemm_w<true, true, EPI_GATED, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_fwd(gated)");
+    } else {
+      g.out0 = out + oo; g.out1 = save_h ? save_h + oo : nullptr;    // pre-activation when requested
+      if (d->Co <= 64) rc = launch_gemm_w<true, true, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_fwd");
+      else rc = launch_gemm_w<true, true, EPI_LINEAR, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_fwd");
+    }
+    if (rc) return rc;
   }
-  g.out0 = out; g.out1 = save_h;    // pre-activation when requested
-  if (d->Co <= 64) return launch_gemm_w<true, true, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_fwd");
-  return launch_gemm_w<true, true, EPI_LINEAR, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_fwd");
+  return EVAE_OK;
 }
 
-// dy: [N][OH][OW][ctot] with ctot = Co (plain) or 2 Co (gated: [dh | dg] per pixel); dx: [N][H][W][C]
+// dy: [N][OH][OW][ldy], ldy = evae_conv2d_cl_dy_stride(ctot): channels [0, Co) = dh, [Co, 2Co) = dg (gated), the rest
+// zero; dx: [N][H][W][C].  One GEMM per stride-parity class, contraction over (tap of the class, buffer channel).
 extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const float* wg, const evae_conv_desc_t* d,
                                        float* dx, void* ws, size_t ws_bytes, evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -1127,19 +1166,17 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
   int OH, OW;
   cl_out_dims(d, &OH, &OW);
   const int taps = d->KH * d->KW, s = d->stride, Co = d->Co, C = d->C;
-  const int ctot = Co * (gated ? 2 : 1);
-  const size_t wslice = align_up((size_t)Co * C * taps * sizeof(float), 256);
-  float* wp_h = (float*)ws;
-  float* wp_g = (float*)((char*)ws + wslice);
+  const int ldy = evae_conv2d_cl_dy_stride(Co * (gated ? 2 : 1));
+  float* wp = (float*)ws;
   size_t used = 0;      // floats of the permuted copy consumed by the classes so far
   bool any_empty = false;
   for (int py = 0; py < s && py < d->H; ++py)
     for (int px = 0; px < s && px < d->W; ++px) {
-      TapList tl; tl.n = 0;
+      int n = 0;
       for (int kh = 0; kh < d->KH; ++kh)
         for (int kw = 0; kw < d->KW; ++kw)
-          if ((py + d->pad - kh) % s == 0 && (px + d->pad - kw) % s == 0) tl.t[tl.n++] = kh * d->KW + kw;
-      if (tl.n == 0) any_empty = true;
+          if ((py + d->pad - kh) % s == 0 && (px + d->pad - kw) % s == 0) ++n;
+      if (n == 0) any_empty = true;
     }
   if (any_empty) {
     hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->N * d->H * d->W * C * sizeof(float), stream);
@@ -1159,43 +1196,46 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
             tl.t[j] = kh * d->KW + kw;
             const int dy_ = (py + d->pad - kh) / s, dx_ = (px + d->pad - kw) / s;   // exact; may be negative
             cv.tdy[j] = (signed char)dy_; cv.tdx[j] = (signed char)dx_;
-            cv.tsoff[j] = (dy_ * OW + dx_) * ctot * 4;
+            cv.tsoff[j] = (dy_ * OW + dx_) * ldy * 4;
             if (cv.tsoff[j] < tmin) tmin = cv.tsoff[j];
           }
       if (tl.n == 0) continue;
       const unsigned tbias = (unsigned)(-tmin);
       for (int j = 0; j < tl.n; ++j) cv.tsoff[j] += (int)tbias;
       const int RH = (d->H - py + s - 1) / s, RW = (d->W - px + s - 1) / s;
-      const size_t cls = (size_t)tl.n * Co * C;
-      float* wch = wp_h + used;
-      float* wcg = wp_g + used;
+      const size_t cls = (size_t)tl.n * ldy * C;
+      float* wc = wp + used;
       used += cls;
-      cl_permute_dgrad_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, Co, C, taps, tl, wch);
-      if (gated) cl_permute_dgrad_kernel<<<elt_grid(cls), 256, 0, stream>>>(wg, Co, C, taps, tl, wcg);
+      cl_permute_dgrad_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, C, taps, ldy, tl, wc);
       int rc = check_launch("cl_permute_dgrad_kernel");
       if (rc) return rc;
-      cv.Cg = Co; cv.ps = ctot; cv.ntaps = tl.n;
+      cv.Cg = ldy; cv.ps = ldy; cv.ntaps = tl.n;
       cv.RH = RH; cv.RW = RW; cv.IH = OH; cv.IW = OW;
       cv.rs = 1; cv.roy = 0; cv.rox = 0;
       cv.OH2 = d->H; cv.OW2 = d->W; cv.os = s; cv.ooy = py; cv.oox = px;
       cv.remap = 1;
       cv.div_rw = make_fastdiv((unsigned)RW); cv.div_rhw = make_fastdiv((unsigned)(RH * RW));
       cv.bias = 0;
-      g.A[0] = dy - tbias / 4;
-      g.A[1] = dy + Co - tbias / 4;
-      g.B[0] = wch; g.B[1] = wcg;
-      g.lda[0] = g.lda[1] = ctot; g.ldb[0] = g.ldb[1] = C;
-      g.Kc[0] = tl.n * Co; g.Kc[1] = gated ? tl.n * Co : 0; g.npairs = gated ? 2 : 1;
-      g.M = d->N * RH * RW; g.N = C; g.out0 = dx; g.ldo = C;
+      g.B[0] = wc;
+      g.lda[0] = ldy; g.ldb[0] = C;
+      g.Kc[0] = tl.n * ldy; g.npairs = 1;
+      g.N = C; g.ldo = C;
       g.ksplit = 0;
-      if (C <= 64) rc = launch_gemm_w<true, false, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data");
-      else rc = launch_gemm_w<true, false, EPI_LINEAR, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data");
-      if (rc) return rc;
+      const int per = cl_images_per_pass(d, OH, OW, C, ldy);
+      for (int n0 = 0; n0 < d->N; n0 += per) {
+        const int nn = std::min(per, d->N - n0);
+        g.A[0] = dy + (size_t)n0 * OH * OW * ldy - tbias / 4;
+        g.out0 = dx + (size_t)n0 * d->H * d->W * C;
+        g.M = nn * RH * RW;
+        if (C <= 64) rc = launch_gemm_w<true, false, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data");
+        else rc = launch_gemm_w<true, false, EPI_LINEAR, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data");
+        if (rc) return rc;
+      }
     }
   return EVAE_OK;
 }
 
-// dy as above; x: [N][H][W][C]; dw: [ctot][C][KH][KW] (nn.Conv2d layout, h rows then g rows), db: [ctot]
+// dy as above ([..][ldy] per pixel); x: [N][H][W][C]; dw: [ctot][C][KH][KW] (nn.Conv2d layout, h rows then g rows), db: [ctot]
 extern "C" int evae_conv2d_cl_bwd_weight(const float* dy, const float* x, const evae_conv_desc_t* d, int gated,
                                          float* dw, float* db, void* ws, size_t ws_bytes, evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -1206,7 +1246,9 @@ extern "C" int evae_conv2d_cl_bwd_weight(const float* dy, const float* x, const 
   cl_out_dims(d, &OH, &OW);
   const int taps = d->KH * d->KW, K = taps * d->C, Mpix = d->N * OH * OW;
   const int ctot = d->Co * (gated ? 2 : 1);
-  Plan pl = make_plan(ctot, K + 1, cdiv(Mpix, BK), false, true, 1);
+  const int ldy = evae_conv2d_cl_dy_stride(ctot);
+  const int per = cl_images_per_pass(d, OH, OW, d->C, ldy);
+  (void)Mpix;
   GemmArgs g = {};
   ConvMap& cv = g.cv;
   cv.Cg = d->C; cv.ps = d->C; cv.ntaps = taps;
@@ -1215,16 +1257,26 @@ extern "C" int evae_conv2d_cl_bwd_weight(const float* dy, const float* x, const 
   cv.div_rw = make_fastdiv((unsigned)OW); cv.div_rhw = make_fastdiv((unsigned)(OH * OW));
   for (int kh = 0; kh < d->KH; ++kh)
     for (int kw = 0; kw < d->KW; ++kw) { cv.tdy[kh * d->KW + kw] = (signed char)kh; cv.tdx[kh * d->KW + kw] = (signed char)kw; }
-  g.A[0] = dy; g.B[0] = x; g.lda[0] = ctot; g.ldb[0] = K + 1; g.Kc[0] = Mpix; g.npairs = 1;
+  g.lda[0] = ldy; g.ldb[0] = K + 1; g.npairs = 1;
   g.M = ctot; g.N = K + 1; g.ones_col = K; g.ldo = K + 1;
   g.out0 = (float*)ws;
-  g.ksplit = pl.nz > 1 ? pl.ksplit : 0;
-  int rc;
-  if (pl.bn == 128) rc = launch_gemm_w<false, false, EPI_RAW, true, 128, 8, 2>(g, pl.nz, stream, "conv2d_cl_bwd_weight");
-  else rc = launch_gemm_w<false, false, EPI_RAW, true, 64, 8, 2>(g, pl.nz, stream, "conv2d_cl_bwd_weight");
-  if (rc) return rc;
-  FinishArgs f = {};
-  f.part = (const float*)ws; f.nz = pl.nz; f.M = ctot; f.N = K + 1; f.ldo = K + 1; f.epi = EPI_RAW; f.out0 = dw;
-  f.ones_col = K; f.out_db = db; f.perm_c = d->C; f.perm_taps = taps;
-  return launch_finish(f, stream);
+  for (int n0 = 0; n0 < d->N; n0 += per) {            // passes over at most 2 GiB of images, accumulated by the finish
+    const int nn = std::min(per, d->N - n0);
+    const int mp = nn * OH * OW;
+    Plan pl = make_plan(ctot, K + 1, cdiv(mp, BK), false, true, 1);
+    g.A[0] = dy + (size_t)n0 * OH * OW * ldy;
+    g.B[0] = x + (size_t)n0 * d->H * d->W * d->C;
+    g.Kc[0] = mp;
+    g.ksplit = pl.nz > 1 ? pl.ksplit : 0;
+    int rc;
+    if (pl.bn == 128) rc = launch_gemm_w<false, false, EPI_RAW, true, 128, 8, 2>(g, pl.nz, stream, "conv2d_cl_bwd_weight");
+    else rc = launch_gemm_w<false, false, EPI_RAW, true, 64, 8, 2>(g, pl.nz, stream, "conv2d_cl_bwd_weight");
+    if (rc) return rc;
+    FinishArgs f = {};
+    f.part = (const float*)ws; f.nz = pl.nz; f.M = ctot; f.N = K + 1; f.ldo = K + 1; f.epi = EPI_RAW; f.out0 = dw;
+    f.ones_col = K; f.out_db = db; f.perm_c = d->C; f.perm_taps = taps; f.accumulate = n0 > 0;
+    rc = launch_finish(f, stream);
+    if (rc) return rc;
+  }
+  return EVAE_OK;
 }

@@ -55,6 +55,7 @@ SIGNATURES = {
     "evae_conv2d_bwd_data": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_conv2d_bwd_weight": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_conv2d_cl_supported": (_i, [_p, _i, _i]),
+    "evae_conv2d_cl_dy_stride": (_i, [_i]),
     "evae_conv2d_cl_workspace_bytes": (_z, [_p, _i, _i]),
     "evae_conv2d_cl_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _z, _p]),
     "evae_conv2d_cl_bwd_data": (_i, [_p, _p, _p, _p, _p, _p, _z, _p]),

@@ -425,19 +425,29 @@ class Conv2dFn(torch.autograd.Function):
             dout = _f32(dout)
         n = dout.numel()
         if cl:
-            # [dh | dg] per pixel in ONE buffer: logical [N, ctot, OH, OW], channels-last
-            dy = torch.empty((d.N, ctot, OH, OW), device=dev, memory_format=CL)
+            # [dh | dg | zero padding] per pixel in ONE buffer: logical [N, ldy, OH, OW], channels-last
+            ldy = lib.evae_conv2d_cl_dy_stride(ctot)
+            if ldy == ctot:
+                dy = torch.empty((d.N, ldy, OH, OW), device=dev, memory_format=CL)
+            else:
+                dy = torch.empty((d.N, ldy, OH, OW), device=dev, memory_format=CL).zero_()
             if gated:
                 if act != ACT_NONE:
                     raise _lib.EvaeError("gated conv with an activation on h: compose it from two plain convs")
                 # rows = pixels, columns = Co channels: dh to columns [0, Co), dg to [Co, 2 Co)
                 _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(h), _p(s), n // d.Co, d.Co, _p(dy),
-                                                          C.c_void_p(dy.data_ptr() + 4 * d.Co), 2 * d.Co, _stream()),
+                                                          C.c_void_p(dy.data_ptr() + 4 * d.Co), ldy, _stream()),
                            "evae_gated_dense_bwd_input")
-            elif act != ACT_NONE:
+            elif ldy == ctot and act != ACT_NONE:
                 _lib.check(lib.evae_act_bwd(_p(dout), _p(aux), n, act, lo, hi, _p(dy), _stream()), "evae_act_bwd")
-            else:
+            elif ldy == ctot:
                 dy = dout
+            else:
+                src = dout
+                if act != ACT_NONE:
+                    src = torch.empty_like(dout)
+                    _lib.check(lib.evae_act_bwd(_p(dout), _p(aux), n, act, lo, hi, _p(src), _stream()), "evae_act_bwd")
+                dy[:, :ctot].copy_(src)
             dw = torch.empty((ctot, K), device=dev); db = torch.empty(ctot, device=dev)
             if cl_w:
                 nb = lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 2, int(gated))
@@ -454,7 +464,7 @@ class Conv2dFn(torch.autograd.Function):
             if (not cl_w) or (ctx.needs_input_grad[0] and not cl_d):
                 # the rest through the NCHW kernels (e.g. the data gradient of a 6-channel output layer)
                 dhn = dy[:, :d.Co].contiguous()
-                dgn = dy[:, d.Co:].contiguous() if gated else None
+                dgn = dy[:, d.Co:ctot].contiguous() if gated else None
                 xn = x.contiguous()
                 if not cl_w:
                     nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 2, int(gated))

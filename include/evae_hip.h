@@ -192,11 +192,13 @@ int evae_conv2d_bwd_weight(const float* dyh, const float* dyg, const float* x, c
  * 32-wide K-slab is 32 channels of ONE filter tap, so the im2col gather is a per-slab scalar offset plus one
  * validity bit per pixel.  Filters and their gradients keep the nn.Conv2d layout [Co][C][KH][KW].
  * `evae_conv2d_cl_supported(d, what, gated)` (what: 0 forward, 1 data gradient, 2 weight gradient) tells whether
- * the geometry qualifies (forward: C % 32 == 0; data gradient: Co % 32 == 0 and C % 4 == 0; weight gradient:
+ * the geometry qualifies (forward: C % 32 == 0; data gradient: C % 4 == 0; weight gradient:
  * C % 4 == 0 and (1|2)Co % 4 == 0; tensors below 2 GiB); otherwise use the NCHW entry points above.
- * dy of the backward calls is ONE buffer [N][OH][OW][ctot], ctot = Co, or 2 Co with [dh | dg] per pixel for a
- * gated layer (evae_gated_dense_bwd_input writes exactly that with ldo = 2 Co). */
+ * dy of the backward calls is ONE buffer [N][OH][OW][ldy], ldy = evae_conv2d_cl_dy_stride(ctot) = ctot rounded up to a
+ * multiple of 32, ctot = Co or 2 Co: channels [0, Co) hold dh, [Co, 2 Co) dg (gated layers;
+ * evae_gated_dense_bwd_input writes exactly that with ldo = ldy), the padding channels must be ZERO. */
 int evae_conv2d_cl_supported(const evae_conv_desc_t* d, int what, int gated);
+int evae_conv2d_cl_dy_stride(int ctot);
 size_t evae_conv2d_cl_workspace_bytes(const evae_conv_desc_t* d, int what, int gated);
 int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, const float* wh, const float* bh,
                        const float* wg, const float* bg, int act, float act_lo, float act_hi,

@@ -67,3 +67,30 @@ def test_conv2d_activations_and_modules():
     ref = g.h.double()(x.double()) * torch.sigmoid(g.g.double()(x.double()))
     g = g.float().cuda()
     assert rel(g(x.cuda()), ref) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(5, 32, 28, 28, 32, 3, 2, 1), (7, 64, 7, 7, 6, 3, 1, 1), (6, 32, 14, 14, 64, 5, 1, 2)])
+def test_conv2d_channels_last_multi_pass(case, monkeypatch):
+    """Tensors beyond 2 GiB are processed in passes over the images (31-bit buffer offsets); force 2 images per
+    pass on small tensors and compare with the single-pass result."""
+    from evae import ops
+    N, C, H, W, Co, k, s, p = case
+    rs = np.random.RandomState(11)
+    x = torch.from_numpy(rs.standard_normal((N, C, H, W)).astype(np.float32)).cuda()
+    ws_ = [torch.from_numpy((rs.standard_normal((Co, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)).cuda() for _ in range(2)]
+    bs_ = [torch.from_numpy((rs.standard_normal(Co) * 0.1).astype(np.float32)).cuda() for _ in range(2)]
+    gout = None
+    res = []
+    for per in (None, "2"):
+        if per is None:
+            monkeypatch.delenv("EVAE_CL_IMAGES_PER_PASS", raising=False)
+        else:
+            monkeypatch.setenv("EVAE_CL_IMAGES_PER_PASS", per)
+        t = [a.clone().requires_grad_(True) for a in (x, ws_[0], bs_[0], ws_[1], bs_[1])]
+        y = ops.gated_conv2d(t[0], t[1], t[2], t[3], t[4], s, p)
+        if gout is None:
+            gout = torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32)).cuda()
+        y.backward(gout)
+        res.append([y.detach()] + [a.grad for a in t])
+    for a, b in zip(*res):
+        assert rel(a, b) < 2e-6
