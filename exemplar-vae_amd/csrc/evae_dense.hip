@@ -1034,6 +1034,55 @@ __global__ void cl_permute_dgrad_kernel(const float* __restrict__ wh, const floa
   }
 }
 
+// Patch matrix of a thin first layer (C*KH*KW <= 64, e.g. 1 x 7 x 7): P[m = (n, oy, ox)][k = (tap, c)], zero-padded to
+// Kp columns, so that the layer is ONE dense GEMM with a 32- or 64-wide contraction and a channels-last output.
+__global__ void cl_patches_kernel(const float* __restrict__ x, int C, int H, int W, int OH, int OW, int KH, int KW,
+                                  int stride, int pad, int Kp, size_t npix, float* __restrict__ P) {
+  const int cpr = Kp / 4;
+  const size_t total = npix * cpr;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / cpr;
+    const int k0 = 4 * (int)(i - m * cpr);
+    const int ox = (int)(m % OW), oy = (int)((m / OW) % OH);
+    const size_t n = m / ((size_t)OW * OH);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j;
+      const int t = k / C, c = k - t * C;
+      const int kh = t / KW, kw = t - kh * KW;
+      const int y = oy * stride - pad + kh, xx = ox * stride - pad + kw;
+      const bool ok = t < KH * KW && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+      v[j] = ok ? x[((n * H + y) * W + xx) * C + c] : 0.f;
+    }
+    *reinterpret_cast<float4*>(P + m * Kp + k0) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+// wp[co][k] = w[co][c][t] for k = t*C + c < C*taps, 0 for the padding columns
+__global__ void cl_permute_patch_w_kernel(const float* __restrict__ w, int Co, int C, int taps, int Kp,
+                                          float* __restrict__ wp) {
+  const size_t n = (size_t)Co * Kp;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kp);
+    const int co = (int)(i / Kp);
+    const int t = k / C, c = k - t * C;
+    wp[i] = t < taps ? w[((size_t)co * C + c) * taps + t] : 0.f;
+  }
+}
+static bool cl_patch_mode(const evae_conv_desc_t* d) { return d->C % 32 != 0 && d->C * d->KH * d->KW <= 64; }
+static int cl_patch_kp(const evae_conv_desc_t* d) { return (d->C * d->KH * d->KW + 31) / 32 * 32; }
+// images per pass of the patch path: the patch matrix of a pass stays below 1 GiB
+static int cl_patch_images(const evae_conv_desc_t* d, int OH, int OW, int chan_out) {
+  const int64_t lim = (int64_t)1 << 28;     // floats
+  const int64_t per = std::max((int64_t)OH * OW * cl_patch_kp(d), (int64_t)OH * OW * chan_out);
+  int64_t n = lim / (per > 0 ? per : 1);
+  if (const char* e = getenv("EVAE_CL_IMAGES_PER_PASS")) {
+    const int64_t f = atoll(e);
+    if (f > 0 && f < n) n = f;
+  }
+  return (int)std::min<int64_t>(n, d->N);
+}
+
 // The buffer-load offsets are 31-bit: a pass handles at most this many images (0: one image alone is too big)
 static int cl_images_per_pass(const evae_conv_desc_t* d, int OH, int OW, int chan_in, int chan_out) {
   const int64_t lim = ((int64_t)1 << 29) - ((int64_t)1 << 22);   // floats; room for the bias terms
@@ -1063,6 +1112,10 @@ extern "C" int evae_conv2d_cl_supported(const evae_conv_desc_t* d, int what, int
   if (OH <= 0 || OW <= 0) return 0;
   const int ctot = d->Co * (gated ? 2 : 1);
   if (cl_images_per_pass(d, OH, OW, d->C, evae_conv2d_cl_dy_stride(ctot)) < 1) return 0;
+  if (cl_patch_mode(d)) {                       // thin first layer: patch matrix + dense GEMM (no data gradient)
+    if (cl_patch_images(d, OH, OW, evae_conv2d_cl_dy_stride(ctot)) < 1) return 0;
+    return what == 0 || (what == 2 && ctot % 4 == 0);
+  }
   if (what == 0) return d->C % 32 == 0;
   if (what == 1) return d->C % 4 == 0;
   return d->C % 4 == 0 && ctot % 4 == 0;
@@ -1075,6 +1128,16 @@ extern "C" size_t evae_conv2d_cl_workspace_bytes(const evae_conv_desc_t* d, int 
   if (!d) return 256;
   const size_t K = (size_t)d->C * d->KH * d->KW;
   const size_t wbytes = align_up((size_t)d->Co * K * sizeof(float), 256);
+  if (cl_patch_mode(d)) {
+    int OH, OW;
+    cl_out_dims(d, &OH, &OW);
+    const int ctot = d->Co * (gated ? 2 : 1), Kp = cl_patch_kp(d);
+    const int per = cl_patch_images(d, OH, OW, evae_conv2d_cl_dy_stride(ctot));
+    const size_t pbytes = align_up((size_t)per * OH * OW * Kp * sizeof(float), 256);
+    if (what == 0) return pbytes + 2 * align_up((size_t)d->Co * Kp * sizeof(float), 256) + 256;
+    Plan pl = make_plan(ctot, Kp + 1, cdiv(per * OH * OW, BK), false, true, 1);
+    return pbytes + align_up((size_t)pl.nz * ctot * (Kp + 1) * sizeof(float), 256) + 256;
+  }
   if (what == 0) return (gated ? 2 : 1) * wbytes + 256;
   if (what == 1) {   // one permuted copy [taps][ldy][C], class slices are disjoint parts of it
     const int ctot1 = d->Co * (gated ? 2 : 1);
@@ -1106,6 +1169,36 @@ extern "C" int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, con
   EVAE_REQUIRE(act >= 0 && act <= 2, "conv2d_cl_fwd: bad activation %d", act);
   int OH, OW;
   cl_out_dims(d, &OH, &OW);
+  if (cl_patch_mode(d)) {
+    const int taps = d->KH * d->KW, Kp = cl_patch_kp(d);
+    const int per = cl_patch_images(d, OH, OW, d->Co);
+    float* P = (float*)ws;
+    const size_t pbytes = align_up((size_t)per * OH * OW * Kp * sizeof(float), 256);
+    float* wph = (float*)((char*)ws + pbytes);
+    float* wpg = (float*)((char*)wph + align_up((size_t)d->Co * Kp * sizeof(float), 256));
+    cl_permute_patch_w_kernel<<<elt_grid((size_t)d->Co * Kp), 256, 0, stream>>>(wh, d->Co, d->C, taps, Kp, wph);
+    if (gated) cl_permute_patch_w_kernel<<<elt_grid((size_t)d->Co * Kp), 256, 0, stream>>>(wg, d->Co, d->C, taps, Kp, wpg);
+    for (int n0 = 0; n0 < d->N; n0 += per) {
+      const int nn = std::min(per, d->N - n0);
+      const size_t npix = (size_t)nn * OH * OW, oo = (size_t)n0 * OH * OW * d->Co;
+      cl_patches_kernel<<<elt_grid(npix * (Kp / 4)), 256, 0, stream>>>(x + (size_t)n0 * d->H * d->W * d->C, d->C, d->H, d->W,
+                                                                     OH, OW, d->KH, d->KW, d->stride, d->pad, Kp, npix, P);
+      int rc = check_launch("cl_patches_kernel");
+      if (rc) return rc;
+      GemmArgs g = {};
+      g.ones_col = -1;
+      g.A[0] = P; g.B[0] = wph; g.Bg = gated ? wpg : nullptr;
+      g.lda[0] = Kp; g.ldb[0] = Kp; g.Kc[0] = Kp; g.npairs = 1;
+      g.M = (int)npix; g.N = d->Co; g.bias0 = bh; g.bias1 = bg; g.ldo = d->Co;
+      g.act = act; g.lo = act_lo; g.hi = act_hi; g.ksplit = 0;
+      g.out0 = out + oo; g.out1 = save_h ? save_h + oo : nullptr; g.out2 = (gated && save_s) ? save_s + oo : nullptr;
+      if (gated) rc = launch_gemm_w<true, true, EPI_GATED, true, 128, 8>(g, 1, stream, "conv2d_cl_fwd(patches, gated)");
+      else if (d->Co <= 64) rc = launch_gemm_w<true, true, EPI_LINEAR, true, 64, 8>(g, 1, stream, "conv2d_cl_fwd(patches)");
+      else rc = launch_gemm_w<true, true, EPI_LINEAR, true, 128, 8>(g, 1, stream, "conv2d_cl_fwd(patches)");
+      if (rc) return rc;
+    }
+    return EVAE_OK;
+  }
   const int taps = d->KH * d->KW, K = taps * d->C, M = d->N * OH * OW;
   float* wph = (float*)ws;
   float* wpg = (float*)((char*)ws + align_up((size_t)d->Co * K * sizeof(float), 256));
@@ -1247,6 +1340,34 @@ extern "C" int evae_conv2d_cl_bwd_weight(const float* dy, const float* x, const 
   const int taps = d->KH * d->KW, K = taps * d->C, Mpix = d->N * OH * OW;
   const int ctot = d->Co * (gated ? 2 : 1);
   const int ldy = evae_conv2d_cl_dy_stride(ctot);
+  if (cl_patch_mode(d)) {
+    const int Kp = cl_patch_kp(d);
+    const int per = cl_patch_images(d, OH, OW, ldy);
+    float* P = (float*)ws;
+    float* part = (float*)((char*)ws + align_up((size_t)per * OH * OW * Kp * sizeof(float), 256));
+    for (int n0 = 0; n0 < d->N; n0 += per) {
+      const int nn = std::min(per, d->N - n0);
+      const size_t npix = (size_t)nn * OH * OW;
+      cl_patches_kernel<<<elt_grid(npix * (Kp / 4)), 256, 0, stream>>>(x + (size_t)n0 * d->H * d->W * d->C, d->C, d->H, d->W,
+                                                                     OH, OW, d->KH, d->KW, d->stride, d->pad, Kp, npix, P);
+      int rc = check_launch("cl_patches_kernel");
+      if (rc) return rc;
+      Plan pl = make_plan(ctot, Kp + 1, cdiv((int)npix, BK), false, true, 1);
+      GemmArgs g = {};
+      g.A[0] = dy + (size_t)n0 * OH * OW * ldy; g.B[0] = P; g.lda[0] = ldy; g.ldb[0] = Kp; g.Kc[0] = (int)npix; g.npairs = 1;
+      g.M = ctot; g.N = Kp + 1; g.ones_col = Kp; g.ldo = Kp + 1; g.out0 = part;
+      g.ksplit = pl.nz > 1 ? pl.ksplit : 0;
+      if (pl.bn == 128) rc = launch_gemm_w<false, false, EPI_RAW, true, 128, 8>(g, pl.nz, stream, "conv2d_cl_bwd_weight(patches)");
+      else rc = launch_gemm_w<false, false, EPI_RAW, true, 64, 8>(g, pl.nz, stream, "conv2d_cl_bwd_weight(patches)");
+      if (rc) return rc;
+      FinishArgs f = {};
+      f.part = part; f.nz = pl.nz; f.M = ctot; f.N = Kp + 1; f.ldo = Kp + 1; f.epi = EPI_RAW; f.out0 = dw;
+      f.ones_col = Kp; f.out_db = db; f.perm_c = d->C; f.perm_taps = taps; f.perm_k = K; f.accumulate = n0 > 0;
+      rc = launch_finish(f, stream);
+      if (rc) return rc;
+    }
+    return EVAE_OK;
+  }
   const int per = cl_images_per_pass(d, OH, OW, d->C, ldy);
   (void)Mpix;
   GemmArgs g = {};
@@ -1274,7 +1395,7 @@ extern "C" int evae_conv2d_cl_bwd_weight(const float* dy, const float* x, const 
     if (rc) return rc;
     FinishArgs f = {};
     f.part = (const float*)ws; f.nz = pl.nz; f.M = ctot; f.N = K + 1; f.ldo = K + 1; f.epi = EPI_RAW; f.out0 = dw;
-    f.ones_col = K; f.out_db = db; f.perm_c = d->C; f.perm_taps = taps; f.accumulate = n0 > 0;
+    f.ones_col = K; f.out_db = db; f.perm_c = d->C; f.perm_taps = taps; f.perm_k = K; f.accumulate = n0 > 0;
     rc = launch_finish(f, stream);
     if (rc) return rc;
   }

@@ -131,6 +131,7 @@ struct FinishArgs {
   int ones_col;            // EPI_RAW: column that carries the bias gradient (-1 = none)
   float* out_db;
   int perm_c, perm_taps;   // EPI_RAW of a convolution weight gradient: column t*perm_c + c -> c*perm_taps + t (OIHW order)
+  int perm_k;              //   ... real filter size C*taps (row stride of dw); columns [perm_k, ones_col) are padding
 };
 
 // LANES = 1: one thread per output element walks the nz planes.  LANES = 8 (many planes, small output -- e.g.
@@ -184,10 +185,14 @@ static __global__ __launch_bounds__(256) void gemm_finish_kernel(const FinishArg
   } else {  // EPI_RAW: plain sum (weight gradient), optional accumulate; column ones_col is db
     if (f.ones_col >= 0) {
       if (n == f.ones_col) { if (f.out_db) f.out_db[m] = (f.accumulate ? f.out_db[m] : 0.f) + v; }
-      else {
-        int nn = n;
-        if (f.perm_taps > 0) { const int t = n / f.perm_c; nn = (n - t * f.perm_c) * f.perm_taps + t; }
-        const size_t ow = (size_t)m * f.ones_col + nn;
+      else if (f.perm_taps > 0) {
+        if (n < f.perm_k) {
+          const int t = n / f.perm_c;
+          const size_t ow = (size_t)m * f.perm_k + (n - t * f.perm_c) * f.perm_taps + t;
+          f.out0[ow] = (f.accumulate ? f.out0[ow] : 0.f) + v;
+        }
+      } else {
+        const size_t ow = (size_t)m * f.ones_col + n;
         f.out0[ow] = (f.accumulate ? f.out0[ow] : 0.f) + v;
       }
     } else {
