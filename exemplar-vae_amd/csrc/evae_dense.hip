@@ -90,8 +90,8 @@ struct GemmArgs {
   float* out1;
   float* out2;
   int ldo;
-  const float* e0;         // EPI_GATE_BWD: h of the layer below
-  const float* e1;         //               s of the layer below
+  const float* e0;         // EPI_GATE_BWD: gated output h*s of the layer below
+  const float* e1;         //               gate s of the layer below
   int act;
   float lo, hi;
   int tiles_m, tiles_n;
@@ -706,9 +706,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
             g.out0[o] = apply_act(pre, g.act, g.lo, g.hi);
           } else if (EPI == EPI_GATE_BWD) {
             const size_t oe = (size_t)m * g.N + n;   // h/s of the layer below are dense [M x N]
-            const float h = g.e0[oe], s = g.e1[oe];
+            const float go = g.e0[oe], s = g.e1[oe];   // gated output h*s and gate s of the layer below
             g.out0[o] = v * s;                   // dh
-            g.out1[o] = v * h * s * (1.0f - s);  // dg
+            g.out1[o] = v * go * (1.0f - s);     // dg = v * h * s * (1 - s)
           } else {                                // EPI_RAW: partial plane [z][M][N]
             g.out0[(size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n] = v;
           }
@@ -717,17 +717,17 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
   }
 }
 
-__global__ void gated_bwd_input_kernel(const float* __restrict__ dout, const float* __restrict__ h,
+__global__ void gated_bwd_input_kernel(const float* __restrict__ dout, const float* __restrict__ gout,
                                        const float* __restrict__ s, int M, int N, int ldo,
                                        float* __restrict__ dh, float* __restrict__ dg) {
   const size_t n = (size_t)M * N;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    const float d = dout[i], hv = h[i], sv = s[i];
+    const float d = dout[i], ov = gout[i], sv = s[i];
     const size_t o = (i / N) * (size_t)ldo + (i % N);
     dh[o] = d * sv;
-    dg[o] = d * hv * sv * (1.0f - sv);
+    dg[o] = d * ov * (1.0f - sv);
   }
 }
 
@@ -905,7 +905,7 @@ extern "C" size_t evae_dense_bwd_data_workspace_bytes(int M, int N, int K, int n
 }
 
 extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const float* dy2, const float* w2,
-                                   int M, int N, int ldy, int K, const float* h_prev, const float* s_prev,
+                                   int M, int N, int ldy, int K, const float* out_prev, const float* s_prev,
                                    float* dx_or_dh, float* dg, int ldo, void* ws, size_t ws_bytes,
                                    evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -913,15 +913,15 @@ extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const floa
   if (M == 0) return EVAE_OK;
   EVAE_REQUIRE(dy1 && w1 && dx_or_dh, "dense_bwd_data: null pointer");
   EVAE_REQUIRE((dy2 == nullptr) == (w2 == nullptr), "dense_bwd_data: dy2/w2 must come together");
-  const bool gate = h_prev != nullptr;
-  EVAE_REQUIRE(!gate || (s_prev && dg), "dense_bwd_data: gate fusion needs h_prev, s_prev and dg");
+  const bool gate = out_prev != nullptr;
+  EVAE_REQUIRE(!gate || (s_prev && dg), "dense_bwd_data: gate fusion needs out_prev, s_prev and dg");
   const int np = dy2 ? 2 : 1;
   Plan pl = make_plan(M, K, total_slabs(N, np > 1 ? N : 0), false, false, 1);
   GemmArgs g = {};
   g.ones_col = -1;
   g.A[0] = dy1; g.B[0] = w1; g.lda[0] = ldy; g.ldb[0] = K; g.Kc[0] = N; g.npairs = np;
   if (dy2) { g.A[1] = dy2; g.B[1] = w2; g.lda[1] = ldy; g.ldb[1] = K; g.Kc[1] = N; }
-  g.M = M; g.N = K; g.out0 = dx_or_dh; g.out1 = gate ? dg : nullptr; g.ldo = ldo; g.e0 = h_prev; g.e1 = s_prev;
+  g.M = M; g.N = K; g.out0 = dx_or_dh; g.out1 = gate ? dg : nullptr; g.ldo = ldo; g.e0 = out_prev; g.e1 = s_prev;
   if (pl.nz <= 1) {
     if (gate) return launch_gemm<true, false, EPI_GATE_BWD>(g, pl, stream, "dense_bwd_data(gate)");
     return launch_gemm<true, false, EPI_LINEAR>(g, pl, stream, "dense_bwd_data");
@@ -937,7 +937,7 @@ extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const floa
   f.ones_col = -1;
   f.part = (const float*)ws; f.nz = pl.nz; f.M = M; f.N = K; f.ldo = ldo;
   f.epi = gate ? EPI_GATE_BWD : EPI_LINEAR; f.out0 = dx_or_dh; f.out1 = gate ? dg : nullptr;
-  f.e0 = h_prev; f.e1 = s_prev;
+  f.e0 = out_prev; f.e1 = s_prev;
   return launch_finish(f, stream);
 }
 
@@ -982,11 +982,11 @@ extern "C" int evae_dense_bwd_weight(const float* dy, int M, int N, int ldy, con
   return launch_finish(f, stream);
 }
 
-extern "C" int evae_gated_dense_bwd_input(const float* dout, const float* h, const float* s, int M, int N,
+extern "C" int evae_gated_dense_bwd_input(const float* dout, const float* out, const float* s, int M, int N,
                                           float* dh, float* dg, int ldo, evae_stream_t stream_) {
   if (M <= 0 || N <= 0) return EVAE_OK;
-  EVAE_REQUIRE(dout && h && s && dh && dg && ldo >= N, "gated_dense_bwd_input: bad arguments");
-  gated_bwd_input_kernel<<<elt_grid((size_t)M * N), 256, 0, (hipStream_t)stream_>>>(dout, h, s, M, N, ldo, dh, dg);
+  EVAE_REQUIRE(dout && out && s && dh && dg && ldo >= N, "gated_dense_bwd_input: bad arguments");
+  gated_bwd_input_kernel<<<elt_grid((size_t)M * N), 256, 0, (hipStream_t)stream_>>>(dout, out, s, M, N, ldo, dh, dg);
   return check_launch("gated_dense_bwd_input");
 }
 

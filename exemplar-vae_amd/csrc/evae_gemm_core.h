@@ -179,9 +179,9 @@ static __global__ __launch_bounds__(256) void gemm_finish_kernel(const FinishArg
     if (f.out1) f.out1[o] = pre;
     f.out0[o] = apply_act(pre, f.act, f.lo, f.hi);
   } else if (f.epi == EPI_GATE_BWD) {
-    const float h = f.e0[i], s = f.e1[i];
+    const float go = f.e0[i], s = f.e1[i];
     f.out0[o] = v * s;
-    f.out1[o] = v * h * s * (1.0f - s);
+    f.out1[o] = v * go * (1.0f - s);
   } else {  // EPI_RAW: plain sum (weight gradient), optional accumulate; column ones_col is db
     if (f.ones_col >= 0) {
       if (n == f.ones_col) { if (f.out_db) f.out_db[m] = (f.accumulate ? f.out_db[m] : 0.f) + v; }

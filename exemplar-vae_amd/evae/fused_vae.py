@@ -89,10 +89,10 @@ class _K:
         _lib.check(self.lib.evae_linear_fwd(_vp(x), None, M, K, ldx, _vp(w_), _vp(b), N, act, lo, hi, _vp(y), _vp(pre),
                                             _vp(w), w.numel(), self.st), "linear_fwd")
 
-    def bwd_data(self, dy1, w1, dy2, w2, M, N, ldy, K, h_prev, s_prev, out, dg, ldo):
+    def bwd_data(self, dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, out, dg, ldo):
         nb = self.lib.evae_dense_bwd_data_workspace_bytes(M, N, K, 2 if dy2 is not None else 1)
         w = self.ws("dgrad", nb)
-        _lib.check(self.lib.evae_dense_bwd_data(_vp(dy1), _vp(w1), _vp(dy2), _vp(w2), M, N, ldy, K, _vp(h_prev),
+        _lib.check(self.lib.evae_dense_bwd_data(_vp(dy1), _vp(w1), _vp(dy2), _vp(w2), M, N, ldy, K, _vp(out_prev),
                                                 _vp(s_prev), _vp(out), _vp(dg), ldo, _vp(w), w.numel(), self.st),
                    "bwd_data")
 
@@ -131,10 +131,11 @@ class VaeExactLoss(torch.autograd.Function):
             rows = torch.cat((ex_idx, torch.arange(n_data, n_data + B, device=dev)))
         ldd = data_ext.stride(0)
         # ---- encoder over C + B rows
-        A1 = torch.empty((Mp, H), **f32); h1 = torch.empty_like(A1); s1 = torch.empty_like(A1)
-        k.gated_fwd(data_ext, rows, Mp, D, ldd, w1h, b1h, w1g, b1g, H, A1, h1, s1)
-        A2 = torch.empty((Mp, H), **f32); h2 = torch.empty_like(A2); s2 = torch.empty_like(A2)
-        k.gated_fwd(A1, None, Mp, H, H, w2h, b2h, w2g, b2g, H, A2, h2, s2)
+        # a gated layer keeps its output and its gate s for the backward (dg = dout * out * (1 - s)); h is never stored
+        A1 = torch.empty((Mp, H), **f32); s1 = torch.empty_like(A1)
+        k.gated_fwd(data_ext, rows, Mp, D, ldd, w1h, b1h, w1g, b1g, H, A1, None, s1)
+        A2 = torch.empty((Mp, H), **f32); s2 = torch.empty_like(A2)
+        k.gated_fwd(A1, None, Mp, H, H, w2h, b2h, w2g, b2g, H, A2, None, s2)
         mean_all = torch.empty((Mp, Z), **f32)
         k.linear_fwd(A2, Mp, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, mean_all, None)
         centres = mean_all[:Cl]
@@ -159,10 +160,10 @@ class VaeExactLoss(torch.autograd.Function):
                 m, s, n = shard.gather_partials(m, s, n)
             ops.prior_merge(m, s, n, c_total, out=(logp, lse))
         # ---- ... while the decoder reconstructs on the main stream
-        D1 = torch.empty((B, H), **f32); hd1 = torch.empty_like(D1); sd1 = torch.empty_like(D1)
-        k.gated_fwd(z, None, B, Z, Z, d1h, e1h, d1g, e1g, H, D1, hd1, sd1)
-        D2 = torch.empty((B, H), **f32); hd2 = torch.empty_like(D2); sd2 = torch.empty_like(D2)
-        k.gated_fwd(D1, None, B, H, H, d2h, e2h, d2g, e2g, H, D2, hd2, sd2)
+        D1 = torch.empty((B, H), **f32); sd1 = torch.empty_like(D1)
+        k.gated_fwd(z, None, B, Z, Z, d1h, e1h, d1g, e1g, H, D1, None, sd1)
+        D2 = torch.empty((B, H), **f32); sd2 = torch.empty_like(D2)
+        k.gated_fwd(D1, None, B, H, H, d2h, e2h, d2g, e2g, H, D2, None, sd2)
         xmean = torch.empty((B, D), **f32)
         k.linear_fwd(D2, B, H, H, wp, bp, D, ACT_SIGMOID, 0.0, 0.0, xmean, None)
         RE = torch.empty(B, **f32)
@@ -177,7 +178,7 @@ class VaeExactLoss(torch.autograd.Function):
         ctx.set_materialize_grads(False)       # unused outputs (RE, KL) then arrive as None, not as zero-filled tensors
         ctx.k_dev = dev
         ctx.dims = (B, D, H, Z, Cl, Mp, ldd, beta, bool(sharded))
-        ctx.bufs = (x, rows, data_ext, A1, h1, s1, A2, h2, s2, mean_all, logvar, lv_pre, z, D1, hd1, sd1, D2, hd2, sd2,
+        ctx.bufs = (x, rows, data_ext, A1, s1, A2, s2, mean_all, logvar, lv_pre, z, D1, sd1, D2, sd2,
                     xmean, lv_row, zi, ci, lse, eps)
         ctx.save_for_backward(*params)
         if average:
@@ -190,7 +191,7 @@ class VaeExactLoss(torch.autograd.Function):
         params = ctx.saved_tensors
         (plv, wp, bp, w1h, b1h, w1g, b1g, w2h, b2h, w2g, b2g, wm, bm, wl, bl,
          d1h, e1h, d1g, e1g, d2h, e2h, d2g, e2g) = params
-        (x, rows, data_ext, A1, h1, s1, A2, h2, s2, mean_all, logvar, lv_pre, z, D1, hd1, sd1, D2, hd2, sd2,
+        (x, rows, data_ext, A1, s1, A2, s2, mean_all, logvar, lv_pre, z, D1, sd1, D2, sd2,
          xmean, lv_row, zi, ci, lse, eps) = ctx.bufs
         B, D, H, Z, Cl, Mp, ldd, beta, sharded = ctx.dims
         dev = ctx.k_dev
@@ -233,11 +234,11 @@ class VaeExactLoss(torch.autograd.Function):
         g_wp = torch.empty_like(wp); g_bp = torch.empty_like(bp)
         k.bwd_weight(dpx, B, D, D, D2, None, H, H, g_wp, g_bp)
         dp2 = torch.empty((B, 2 * H), **f32)                              # [dh | dg] of decoder layer 2
-        k.bwd_data(dpx, wp, None, None, B, D, D, H, hd2, sd2, dp2, dp2.data_ptr() + 4 * H, 2 * H)
+        k.bwd_data(dpx, wp, None, None, B, D, D, H, D2, sd2, dp2, dp2.data_ptr() + 4 * H, 2 * H)
         g_d2 = torch.empty((2 * H, H), **f32); g_e2 = torch.empty(2 * H, **f32)
         k.bwd_weight(dp2, B, 2 * H, 2 * H, D1, None, H, H, g_d2, g_e2)
         dp1 = torch.empty((B, 2 * H), **f32)
-        k.bwd_data(dp2, d2h, dp2.data_ptr() + 4 * H, d2g, B, H, 2 * H, H, hd1, sd1, dp1, dp1.data_ptr() + 4 * H, 2 * H)
+        k.bwd_data(dp2, d2h, dp2.data_ptr() + 4 * H, d2g, B, H, 2 * H, H, D1, sd1, dp1, dp1.data_ptr() + 4 * H, 2 * H)
         g_d1 = torch.empty((2 * H, Z), **f32); g_e1 = torch.empty(2 * H, **f32)
         k.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1)
         dz = torch.empty((B, Z), **f32)
@@ -259,15 +260,15 @@ class VaeExactLoss(torch.autograd.Function):
         k.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)
         dq2 = torch.empty((Mp, 2 * H), **f32)                              # [dh2 | dg2] for all C + B rows
         if Cl > 0:
-            k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, h2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H)
+            k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H)
         off = 4 * Cl
-        k.bwd_data(dmean_all.data_ptr() + off * Z, wm, dlvp, wl, B, Z, Z, H, h2.data_ptr() + off * H,
+        k.bwd_data(dmean_all.data_ptr() + off * Z, wm, dlvp, wl, B, Z, Z, H, A2.data_ptr() + off * H,
                    s2.data_ptr() + off * H, dq2.data_ptr() + off * 2 * H, dq2.data_ptr() + off * 2 * H + 4 * H, 2 * H)
         # ---- encoder layers over C + B rows
         g_w2 = torch.empty((2 * H, H), **f32); g_b2 = torch.empty(2 * H, **f32)
         k.bwd_weight(dq2, Mp, 2 * H, 2 * H, A1, None, H, H, g_w2, g_b2)
         dq1 = torch.empty((Mp, 2 * H), **f32)
-        k.bwd_data(dq2, w2h, dq2.data_ptr() + 4 * H, w2g, Mp, H, 2 * H, H, h1, s1, dq1, dq1.data_ptr() + 4 * H, 2 * H)
+        k.bwd_data(dq2, w2h, dq2.data_ptr() + 4 * H, w2g, Mp, H, 2 * H, H, A1, s1, dq1, dq1.data_ptr() + 4 * H, 2 * H)
         g_w1 = torch.empty((2 * H, D), **f32); g_b1 = torch.empty(2 * H, **f32)
         k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)
         g_plv = dlv.sum().reshape(1)

@@ -195,8 +195,8 @@ def _bwd_weight(dy, x, rows, K, want_db=True):
     return dw, db
 
 
-def _bwd_data(dy1_ptr, w1, dy2_ptr, w2, M, N, ldy, device, h_prev=None, s_prev=None, out=None, dg_ptr=None, ldo=None):
-    """dx [M x K] = dy1 W1 (+ dy2 W2); with h_prev/s_prev the gate derivative of the layer below is applied
+def _bwd_data(dy1_ptr, w1, dy2_ptr, w2, M, N, ldy, device, out_prev=None, s_prev=None, out=None, dg_ptr=None, ldo=None):
+    """dx [M x K] = dy1 W1 (+ dy2 W2); with out_prev/s_prev (forward output and gate of the layer below) the gate derivative of the layer below is applied
     in the epilogue and (dh, dg) are written instead (optionally into the halves of one [M x 2K] buffer)."""
     lib = _lib.load()
     K = w1.shape[1]
@@ -208,7 +208,7 @@ def _bwd_data(dy1_ptr, w1, dy2_ptr, w2, M, N, ldy, device, h_prev=None, s_prev=N
     ws = _workspace("dgrad", nb, device)
     out_ptr = out if isinstance(out, int) else out.data_ptr()
     _lib.check(lib.evae_dense_bwd_data(_vp(dy1_ptr), _p(w1), None if dy2_ptr is None else _vp(dy2_ptr), _p(w2),
-                                       M, N, ldy, K, _p(h_prev), _p(s_prev), _vp(out_ptr),
+                                       M, N, ldy, K, _p(out_prev), _p(s_prev), _vp(out_ptr),
                                        None if dg_ptr is None else _vp(dg_ptr), ldo, _p(ws), ws.numel(), _stream()),
                "evae_dense_bwd_data")
     return out
@@ -238,8 +238,7 @@ class GatedDenseFn(torch.autograd.Function):
         N, K = wh.shape
         out = torch.empty((M, N), device=x.device)
         need_grad = any(ctx.needs_input_grad)
-        h = torch.empty_like(out) if need_grad else None
-        s = torch.empty_like(out) if need_grad else None
+        s = torch.empty_like(out) if need_grad else None     # the backward needs out and s only (dg = dout*out*(1-s))
         nb = lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
         ws = _workspace("fwd", nb, x.device)
         # bench.py's roofline probe (modular path): the row-gathered, un-split launch = encoder layer 1
@@ -250,33 +249,33 @@ class GatedDenseFn(torch.autograd.Function):
             ev0.record()
         for _ in range(reps):
             _lib.check(lib.evae_gated_dense_fwd(_p(x), _p(rows), M, K, x.stride(0), _p(wh), _p(bh), _p(wg), _p(bg),
-                                                N, _p(out), _p(h), _p(s), _p(ws), ws.numel(), _stream()),
+                                                N, _p(out), None, _p(s), _p(ws), ws.numel(), _stream()),
                        "evae_gated_dense_fwd")
         if probe is not None:
             ev1.record()
             probe["gated_dense_fwd"].append((ev0, ev1, 2.0 * M * K * 2 * N * reps, reps))
         if need_grad:
-            ctx.save_for_backward(x, rows, wh, wg, h, s)
+            ctx.save_for_backward(x, rows, wh, wg, out, s)
         ctx.has_bias = (bh is not None, bg is not None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        x, rows, wh, wg, h, s = ctx.saved_tensors
+        x, rows, wh, wg, gout, s = ctx.saved_tensors
         dout = _f32(dout)
-        M, N = h.shape
+        M, N = gout.shape
         K = wh.shape[1]
-        dpre = torch.empty((M, 2 * N), device=h.device)          # [dh | dg]: one buffer, one weight-grad GEMM
+        dpre = torch.empty((M, 2 * N), device=gout.device)          # [dh | dg]: one buffer, one weight-grad GEMM
         base = dpre.data_ptr()
-        _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(h), _p(s), M, N, _vp(base), _vp(base + 4 * N),
+        _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(gout), _p(s), M, N, _vp(base), _vp(base + 4 * N),
                                                   2 * N, _stream()), "evae_gated_dense_bwd_input")
         dw, db = _bwd_weight(dpre, x, rows, K)                    # [dWh ; dWg], [dbh ; dbg]
         dx = None
         if ctx.needs_input_grad[0]:
             if rows is not None:
                 raise _lib.EvaeError("gradient wrt a row-gathered input is not supported")
-            dx = _bwd_data(base, wh, base + 4 * N, wg, M, N, 2 * N, h.device)
+            dx = _bwd_data(base, wh, base + 4 * N, wg, M, N, 2 * N, gout.device)
         return (dx, None, dw[:N], (db[:N] if ctx.has_bias[0] else None), dw[N:],
                 (db[N:] if ctx.has_bias[1] else None))
 
@@ -385,30 +384,29 @@ class Conv2dFn(torch.autograd.Function):
             x = x.contiguous()
             fmt = dict(device=x.device)
         out = torch.empty((d.N, d.Co, OH, OW), **fmt)
-        h = torch.empty((d.N, d.Co, OH, OW), **fmt) if (gated and need_grad) else None
-        s = torch.empty((d.N, d.Co, OH, OW), **fmt) if (gated and need_grad) else None
+        s = torch.empty((d.N, d.Co, OH, OW), **fmt) if (gated and need_grad) else None   # out and s suffice for the backward
         pre = torch.empty((d.N, d.Co, OH, OW), **fmt) if (not gated and need_grad and act == ACT_HARDTANH) else None
         if cl:
             nb = lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 0, int(gated))
             ws = _workspace("conv", nb, x.device)
             _lib.check(lib.evae_conv2d_cl_fwd(_p(x), C.byref(d), _p(wh), _p(bh), _p(wg), _p(bg), act, float(lo), float(hi),
-                                              _p(out), _p(h if gated else pre), _p(s), _p(ws), ws.numel(), _stream()),
+                                              _p(out), _p(None if gated else pre), _p(s), _p(ws), ws.numel(), _stream()),
                        "evae_conv2d_cl_fwd")
         else:
             nb = lib.evae_conv2d_workspace_bytes(C.byref(d), 0, int(gated))
             ws = _workspace("conv", nb, x.device)
             _lib.check(lib.evae_conv2d_fwd(_p(x), C.byref(d), _p(wh), _p(bh), _p(wg), _p(bg), act, float(lo), float(hi),
-                                           _p(out), _p(h if gated else pre), _p(s), _p(ws), ws.numel(), _stream()),
+                                           _p(out), _p(None if gated else pre), _p(s), _p(ws), ws.numel(), _stream()),
                        "evae_conv2d_fwd")
         if need_grad:
-            ctx.save_for_backward(x, wh, wg, h, s, pre if pre is not None else out)
+            ctx.save_for_backward(x, wh, wg, s, pre if pre is not None else out)
         ctx.cfg = (d, gated, act, float(lo), float(hi), bh is not None, bg is not None, cl)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        x, wh, wg, h, s, aux = ctx.saved_tensors
+        x, wh, wg, s, aux = ctx.saved_tensors
         d, gated, act, lo, hi, has_bh, has_bg, cl = ctx.cfg
         dev = dout.device
         shp = wh.shape
@@ -435,7 +433,7 @@ class Conv2dFn(torch.autograd.Function):
                 if act != ACT_NONE:
                     raise _lib.EvaeError("gated conv with an activation on h: compose it from two plain convs")
                 # rows = pixels, columns = Co channels: dh to columns [0, Co), dg to [Co, 2 Co)
-                _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(h), _p(s), n // d.Co, d.Co, _p(dy),
+                _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(aux), _p(s), n // d.Co, d.Co, _p(dy),
                                                           C.c_void_p(dy.data_ptr() + 4 * d.Co), ldy, _stream()),
                            "evae_gated_dense_bwd_input")
             elif ldy == ctot and act != ACT_NONE:
@@ -482,7 +480,7 @@ class Conv2dFn(torch.autograd.Function):
                 if act != ACT_NONE:
                     raise _lib.EvaeError("gated conv with an activation on h: compose it from two plain convs")
                 dh = torch.empty_like(dout); dg = torch.empty_like(dout)
-                _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(h), _p(s), 1, n, _p(dh), _p(dg), n, _stream()),
+                _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(aux), _p(s), 1, n, _p(dh), _p(dg), n, _stream()),
                            "evae_gated_dense_bwd_input")
             else:
                 dg = None

@@ -117,14 +117,15 @@ int evae_topk_merge(const float* val /* [R x B x k] */, const int64_t* idx, int 
  * materialising the [C x D] copy.
  *
  * evae_gated_dense_fwd:  h = x Wh^T + bh ; s = sigmoid(x Wg^T + bg) ; out = h * s
- *   saves h and s ([M x N] each, may be NULL for inference) for the backward.
+ *   The backward needs only `out` and `s` (dg = dout*h*s*(1-s) = dout*out*(1-s)): save_s ([M x N], NULL for
+ *   inference) is the one extra array to keep; save_h (optional, normally NULL) also returns h.
  * evae_linear_fwd:       y = act(x W^T + b), act in EVAE_ACT_*; `pre` (optional) saves the
  *   pre-activation needed by hardtanh's backward.
- * evae_gated_dense_bwd_input: given dout [M x N] and saved h, s:
- *   dh = dout*s ; dg = dout*h*s*(1-s)   (written to dh, dg: [M x N] each)
+ * evae_gated_dense_bwd_input: given dout [M x N], the layer's forward output `out` (= h*s) and s:
+ *   dh = dout*s ; dg = dout*out*(1-s)   (written to dh, dg: [M x N] each)
  * evae_dense_bwd_data:   dx = dy1 W1 (+ dy2 W2)         [M x K]   (dy [M x N], W [N x K])
- *   optionally fused with the gated-dense input derivative of the layer below (h_prev, s_prev
- *   non-NULL): writes dh_prev/dg_prev instead of dx.
+ *   optionally fused with the gated-dense input derivative of the layer below (out_prev, s_prev
+ *   non-NULL: that layer's forward output and gate): writes dh_prev/dg_prev instead of dx.
  * evae_dense_bwd_weight: dW = dy^T x (rows-gathered x allowed), db = column sums of dy.
  * Thin problems (the 100-row batch path, the small weight-gradient outputs) are split along the
  * contraction into `ws` partials and finished by a second kernel in a fixed order (deterministic);
@@ -143,11 +144,11 @@ int evae_linear_fwd(const float* x, const int64_t* rows, int M, int K, int ldx,
                     const float* w, const float* b, int N, int act, float act_lo, float act_hi,
                     float* y, float* pre, void* ws, size_t ws_bytes, evae_stream_t stream);
 /* dy1/dy2: [M x N] with row stride ldy (so dh and dg may be the two halves of one [M x 2N] buffer);
- * output(s) [M x K] with row stride ldo; h_prev/s_prev are dense [M x K]. */
+ * output(s) [M x K] with row stride ldo; out_prev/s_prev are dense [M x K]. */
 size_t evae_dense_bwd_data_workspace_bytes(int M, int N, int K, int npairs);
 int evae_dense_bwd_data(const float* dy1, const float* w1, const float* dy2, const float* w2,
                         int M, int N, int ldy, int K,
-                        const float* h_prev, const float* s_prev,
+                        const float* out_prev, const float* s_prev,
                         float* dx_or_dh, float* dg, int ldo,
                         void* ws, size_t ws_bytes, evae_stream_t stream);
 /* dw [N x K] = dy^T x with dy [M x N] (row stride ldy), x [* x K] (row stride ldx, optional row gather);
@@ -157,7 +158,7 @@ int evae_dense_bwd_weight(const float* dy, int M, int N, int ldy, const float* x
                           int K, int ldx, float* dw /* [N x K] */, float* db /* [N] or NULL */,
                           int accumulate, void* ws, size_t ws_bytes, evae_stream_t stream);
 /* dh, dg: [M x N] with row stride ldo (the two halves of one [M x 2N] buffer when ldo = 2N) */
-int evae_gated_dense_bwd_input(const float* dout, const float* h, const float* s, int M, int N,
+int evae_gated_dense_bwd_input(const float* dout, const float* out, const float* s, int M, int N,
                                float* dh, float* dg, int ldo, evae_stream_t stream);
 int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, int act, float act_lo, float act_hi,
                  float* dpre, evae_stream_t stream);

@@ -21,7 +21,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         if os.environ.get("ROWS") == "seq": rows = torch.arange(M, device=dev) % N
         if os.environ.get("ROWS") == "none": rows = None; data = torch.cat([data] * (1 + M // N))[:max(M, N)]
         out = torch.empty(M, H, device=dev); h = torch.empty_like(out); s = torch.empty_like(out)
-        fn = lambda: lib.evae_gated_dense_fwd(p(data), p(rows) if rows is not None else None, M, D, D, p(wh), p(b), p(wg), p(b), H, p(out), p(h), p(s), p(ws), ws.numel(), st())
+        fn = lambda: lib.evae_gated_dense_fwd(p(data), p(rows) if rows is not None else None, M, D, D, p(wh), p(b), p(wg), p(b), H, p(out), None, p(s), p(ws), ws.numel(), st())
         for _ in range(3): fn()
         torch.cuda.synchronize()
         ts = []

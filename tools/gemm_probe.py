@@ -20,7 +20,7 @@ w2h = torch.randn(H, H, device=dev) * 0.05; w2g = torch.randn(H, H, device=dev) 
 dx = torch.empty(M, 2 * H, device=dev)
 for _ in range(reps):
     if which == "fwd1":
-        lib.evae_gated_dense_fwd(p(data), p(rows), M, D, D, p(wh), p(b), p(wg), p(b), H, p(out), p(h), p(s), p(ws), nws, st())
+        lib.evae_gated_dense_fwd(p(data), p(rows), M, D, D, p(wh), p(b), p(wg), p(b), H, p(out), None, p(s), p(ws), nws, st())
     elif which == "wgrad1":
         lib.evae_dense_bwd_weight(p(dpre), M, 2 * H, 2 * H, p(data), p(rows), D, D, p(dw), p(db), 0, p(ws), nws, st())
     elif which == "dgrad2":

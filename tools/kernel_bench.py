@@ -39,12 +39,12 @@ def main():
         out = torch.empty(M, H, device=dev); h = torch.empty_like(out); s = torch.empty_like(out)
         wsf = torch.zeros(64 << 20, dtype=torch.uint8, device=dev); nwf = wsf.numel()
         report("gated_fwd L1 M=%d K=784 N=300 (gather)" % M,
-               timeit(lambda: lib.evae_gated_dense_fwd(p(data), p(rows), M, D, D, p(wh), p(b), p(wg), p(b), H, p(out), p(h), p(s), p(wsf), nwf, st())),
+               timeit(lambda: lib.evae_gated_dense_fwd(p(data), p(rows), M, D, D, p(wh), p(b), p(wg), p(b), H, p(out), None, p(s), p(wsf), nwf, st())),
                2.0 * M * D * 2 * H)
         w2h = torch.randn(H, H, device=dev) * 0.05; w2g = torch.randn(H, H, device=dev) * 0.05
         out2 = torch.empty(M, H, device=dev)
         report("gated_fwd L2 M=%d K=300 N=300" % M,
-               timeit(lambda: lib.evae_gated_dense_fwd(p(out), None, M, H, H, p(w2h), p(b), p(w2g), p(b), H, p(out2), p(h), p(s), p(wsf), nwf, st())),
+               timeit(lambda: lib.evae_gated_dense_fwd(p(out), None, M, H, H, p(w2h), p(b), p(w2g), p(b), H, p(out2), None, p(s), p(wsf), nwf, st())),
                2.0 * M * H * 2 * H)
         wm = torch.randn(Z, H, device=dev) * 0.05; bm = torch.zeros(Z, device=dev); y = torch.empty(M, Z, device=dev)
         report("linear_fwd mean M=%d K=300 N=40" % M,
