@@ -44,6 +44,7 @@ class GraphedTrainStep:
         self.out = torch.zeros(3, device=dev)       # (loss, -RE, KL) of the last step
         self.totals = torch.zeros(3, device=dev)    # running sums since reset_totals()
         self.graph = None
+        self.failed = False
         self.warmup_steps = warmup_steps
         self._calls = 0
 
@@ -93,13 +94,28 @@ class GraphedTrainStep:
                     torch.cuda.current_stream().wait_stream(s)
                     self._calls += 1
                     return out
+                if self.failed:
+                    self._body()                 # capture was refused once: keep stepping eagerly
+                    self._calls += 1
+                    return self.out
                 torch.cuda.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
+                graph = torch.cuda.CUDAGraph()
                 # with RCCL in the step its watchdog thread polls events while we capture: thread-local capture mode
                 # keeps those calls from invalidating the capture
                 mode = "thread_local" if shard.is_active() else "global"
-                with torch.cuda.graph(self.graph, capture_error_mode=mode):
+                try:
+                    with torch.cuda.graph(graph, capture_error_mode=mode):
+                        self._body()
+                    self.graph = graph
+                except Exception as e:           # an op of this model that cannot be captured: eager from here on
+                    import sys
+                    print("evae.graph: hipGraph capture of the training step failed (%s: %s); running eagerly"
+                          % (type(e).__name__, str(e).splitlines()[0][:120]), file=sys.stderr)
+                    self.failed = True
+                    torch.cuda.synchronize()
                     self._body()
+                    self._calls += 1
+                    return self.out
                 # capture does not execute: replay once for this call's step
             self.graph.replay()
             self._calls += 1

@@ -304,6 +304,15 @@ class BaseModel(nn.Module, ABC):
     # ------------------------------------------------------------------ exemplar sets
     def get_exemplar_set(self, z_mean, z_log_var, dataset, cache, x_indices):
         if self.args.approximate_prior is False:
+            override = getattr(self, '_exemplar_indices_override', None)
+            if isinstance(override, tuple):
+                # graph-captured step (evae/graph.py): this rank's indices already sit in a static device buffer
+                rows_ext, n_local = override
+                local = rows_ext[:n_local]
+                centres, logvar = self.q_z(self.resident_data(dataset), prior=True, rows=local)
+                if self._sharded():
+                    return shard.ShardedEmbedding((centres, logvar, local), total=self.args.number_components)
+                return (centres, logvar, local)
             # same CPU-generator draw, with replacement, as the reference (:245)
             exemplars_indices = torch.randint(low=0, high=self.args.training_set_size,
                                               size=(self.args.number_components,))

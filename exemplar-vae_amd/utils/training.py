@@ -55,9 +55,9 @@ def _graphed_step(args, model, optimizer, train_loader):
     if not getattr(args, 'use_hip_graph', True) or not str(args.device).startswith('cuda'):
         return None
     a = model.args
-    ok = (a.model_name == 'vae' and a.prior == 'exemplar_prior' and a.input_type == 'binary'
-          and a.approximate_prior is False and a.no_attention is False
-          and not getattr(a, 'same_variational_var', False) and getattr(model, '_use_fused', True))
+    # capturable: exact exemplar prior (the approximate prior re-selects exemplars on the host every step); the `vae`
+    # model runs the one-node fused step inside the graph, every other architecture its modular autograd path
+    ok = a.prior == 'exemplar_prior' and a.approximate_prior is False
     if not ok:
         return None
     key = (id(optimizer), id(train_loader.dataset), train_loader.batch_size)

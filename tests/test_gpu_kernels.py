@@ -52,6 +52,25 @@ def test_prior_fwd_matches_oracle(ops, B, C, zd, masked):
     assert rel((raw - np.log(denom))[fin], ref_prob[fin]) < 1e-5
 
 
+@pytest.mark.parametrize("B,C,zd,masked", [(8, 300, 40, True), (100, 1000, 40, True), (100, 25000, 40, True),
+                                           (100, 25000, 40, False), (5, 7, 4, True), (130, 70, 64, False),
+                                           (300, 2000, 40, True), (1, 1, 40, False), (129, 129, 24, True),
+                                           (128, 127, 8, False), (700, 3000, 56, True)])
+def test_prior_fwd_matrix_core_kernel_matches_oracle(ops, B, C, zd, masked):
+    """The forward without the probability matrix and z <= 64 runs on the matrix cores (expanded-form distances):
+    same bar as the direct-difference kernel above, on full, ragged and single-element tiles."""
+    z, c = gi.clustered_latents(200 + B + C, B, C, zd)
+    zi, ci = gi.mask_indices(9 + B, B, C, max(C // 2, 4))
+    lv = np.linspace(-1.5, -0.5, zd).astype(np.float32)
+    m, s, n, prob = ops.prior_lse_fwd(dev(z), dev(c), dev(lv), dev(zi) if masked else None, dev(ci) if masked else None)
+    assert prob is None
+    lp, lse = ops.prior_merge(m, s, n, C)
+    ref = orc.logsumexp_rows(orc.log_p_z_exemplar(z, zi, c, lv[None, :], ci, test=not masked))
+    assert rel(lp.cpu().numpy(), ref) < 1e-5          # north_star bar is 1e-4
+    pm, ps, pn = orc.prior_partials(z, zi, c, lv, ci, masked)
+    assert np.array_equal(n.cpu().numpy(), pn)
+
+
 def test_prior_golden_c2(ops, golden):
     g = golden("g3_prior")
     z, c = gi.clustered_latents(22, 100, 25000, 40)

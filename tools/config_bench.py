@@ -58,6 +58,16 @@ def step(i):
     return loss
 
 
+if os.environ.get("GRAPH"):       # replay the whole step from a hipGraph (evae/graph.py) instead of launching eagerly
+    from evae.graph import GraphedTrainStep
+    runner = GraphedTrainStep(model, opt, ds, B, False)
+
+    def step(i):      # noqa: F811
+        s = (i * B) % (N - B)
+        return runner(dev_data[s:s + B], torch.arange(s, s + B, device="cuda").reshape(-1, 1), 0.5)[0]
+    for i in range(4):
+        step(i)
+
 for i in range(2):
     step(i)
 torch.cuda.synchronize()
