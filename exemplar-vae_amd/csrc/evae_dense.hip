@@ -39,9 +39,10 @@ namespace evae {
 //   CV = 2 (weight gradient): the contraction runs over the pixels, B is the im2col matrix
 //          [pixel][(tap, channel)] gathered as float4 (4 channels of one tap), A is dy, row-contiguous.
 // Source element of row (n, ry, rx), tap t, channel c:
-//   src[((n*IH + ry*rs + roy + tdy[t]) * IW + rx*rs + rox + tdx[t]) * ps + c]
-// Output row (CV = 1): ((n*OH2 + ry*os + ooy) * OW2 + rx*os + oox)  (identity for the forward; the strided
-// pixels of one stride-parity class for the data gradient).
+//   src[((n*IH + ry*rs + roy + tdy[t]) * IW + rx*rsx + rox + tdx[t]) * ps + c]
+// Output row (CV = 1): ((n*OH2 + ry*os + ooy) * OW2 + rx*osx + oox)  (identity for the forward; the strided
+// pixels of one stride-parity class -- or pairs of x-adjacent pixels, see evae_conv2d_cl_bwd_data -- for the data
+// gradient).
 struct FastDiv { unsigned mul, sh, one; };   // q = one ? n : (t = umulhi(mul, n), (t + ((n - t) >> 1)) >> sh)
 __host__ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv d) {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -64,8 +65,8 @@ struct ConvMap {
   int Cg, ntaps;
   int ps;                      // floats per source pixel (Cg, or 2 Cg when the h and g gradients share one buffer)
   int RH, RW, IH, IW;
-  int rs, roy, rox;
-  int OH2, OW2, os, ooy, oox;
+  int rs, rsx, roy, rox;       // anchor of row (ry, rx) in the source: (ry*rs + roy, rx*rsx + rox)
+  int OH2, OW2, os, osx, ooy, oox;   // output row of (n, ry, rx): (n*OH2 + ry*os + ooy)*OW2 + rx*osx + oox
   int remap;                   // CV = 1: output rows are not the identity
   unsigned bias;               // bytes added to every per-row offset (the buffer base is moved back by bias + tbias)
   FastDiv div_rw, div_rhw;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
         const unsigned rr = ok ? (unsigned)r : 0u;
         const unsigned n = fdiv(rr, g.cv.div_rhw), rem = rr - n * (unsigned)(g.cv.RH * g.cv.RW);
         const unsigned ry = fdiv(rem, g.cv.div_rw), rx = rem - ry * (unsigned)g.cv.RW;
-        const int ay = (int)ry * g.cv.rs + g.cv.roy, ax = (int)rx * g.cv.rs + g.cv.rox;
+        const int ay = (int)ry * g.cv.rs + g.cv.roy, ax = (int)rx * g.cv.rsx + g.cv.rox;
         const long long off = (((long long)n * g.cv.IH + ay) * g.cv.IW + ax) * g.cv.ps * 4 + 16 * (f & 7) + (long long)g.cv.bias;
 #pragma unroll
         for (int p = 0; p < (PAIRS ? 2 : 1); ++p) voA[p][i] = ok ? (unsigned)off : OOB;
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
             const unsigned n = fdiv(m, g.cv.div_rhw), rem = m - n * (unsigned)(g.cv.RH * g.cv.RW);
             const unsigned ry = fdiv(rem, g.cv.div_rw), rx = rem - ry * (unsigned)g.cv.RW;
             const int t = coltap[i] < 0 ? 0 : coltap[i];
-            const int y = (int)ry * g.cv.rs + g.cv.roy + g.cv.tdy[t], x = (int)rx * g.cv.rs + g.cv.rox + g.cv.tdx[t];
+            const int y = (int)ry * g.cv.rs + g.cv.roy + g.cv.tdy[t], x = (int)rx * g.cv.rsx + g.cv.rox + g.cv.tdx[t];
             const bool live = coltap[i] >= 0 && kk < kv && (unsigned)y < (unsigned)g.cv.IH && (unsigned)x < (unsigned)g.cv.IW;
             const unsigned off = (unsigned)((((int)n * g.cv.IH + y) * g.cv.IW + x) * g.cv.ps + colch[i]) * 4u;
             rb[i] = buf_ld4(rB0, live ? off : OOB, 0u);
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
     if (CV == 1 && g.cv.remap) {
       const unsigned nn = fdiv((unsigned)m, g.cv.div_rhw), rem = (unsigned)m - nn * (unsigned)(g.cv.RH * g.cv.RW);
       const unsigned ry = fdiv(rem, g.cv.div_rw), rx = rem - ry * (unsigned)g.cv.RW;
-      return ((size_t)nn * g.cv.OH2 + ry * g.cv.os + g.cv.ooy) * g.cv.OW2 + rx * g.cv.os + g.cv.oox;
+      return ((size_t)nn * g.cv.OH2 + ry * g.cv.os + g.cv.ooy) * g.cv.OW2 + rx * g.cv.osx + g.cv.oox;
     }
     return (size_t)m;
   };
@@ -1069,6 +1070,27 @@ __global__ void cl_permute_patch_w_kernel(const float* __restrict__ w, int Co, i
     wp[i] = t < taps ? w[((size_t)co * C + c) * taps + t] : 0.f;
   }
 }
+// Data gradient into a 32-channel input, two x-adjacent output pixels per GEMM row (64 output columns = a full tile):
+// wp[u][cc][b*32 + c] = w_merged[cc][c][tb[b][u]] when tap u of the union belongs to pixel b (tb >= 0), else 0
+struct PairTaps { int n; int tb[2][64]; };
+__global__ void cl_permute_dgrad_pair_kernel(const float* __restrict__ wh, const float* __restrict__ wg, int Co, int taps,
+                                             int ld, PairTaps pt, float* __restrict__ wp) {
+  const int C = 32;
+  const size_t n = (size_t)pt.n * ld * 64;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % 64), b = col >> 5, c = col & 31;
+    const int cc = (int)((i / 64) % ld);
+    const int u = (int)(i / ((size_t)64 * ld));
+    const int t = pt.tb[b][u];
+    float v = 0.f;
+    if (t >= 0) {
+      if (cc < Co) v = wh[((size_t)cc * C + c) * taps + t];
+      else if (wg != nullptr && cc < 2 * Co) v = wg[((size_t)(cc - Co) * C + c) * taps + t];
+    }
+    wp[i] = v;
+  }
+}
+
 static bool cl_patch_mode(const evae_conv_desc_t* d) { return d->C % 32 != 0 && d->C * d->KH * d->KW <= 64; }
 static int cl_patch_kp(const evae_conv_desc_t* d) { return (d->C * d->KH * d->KW + 31) / 32 * 32; }
 // images per pass of the patch path: the patch matrix of a pass stays below 1 GiB
@@ -1141,7 +1163,9 @@ extern "C" size_t evae_conv2d_cl_workspace_bytes(const evae_conv_desc_t* d, int 
   if (what == 0) return (gated ? 2 : 1) * wbytes + 256;
   if (what == 1) {   // one permuted copy [taps][ldy][C], class slices are disjoint parts of it
     const int ctot1 = d->Co * (gated ? 2 : 1);
-    return align_up((size_t)d->KH * d->KW * evae_conv2d_cl_dy_stride(ctot1) * d->C * sizeof(float), 256) + 256;
+    const size_t plain = (size_t)d->KH * d->KW * evae_conv2d_cl_dy_stride(ctot1) * d->C;
+    const size_t paired = (size_t)d->KH * (d->KW + 1) * evae_conv2d_cl_dy_stride(ctot1) * 64;   // pixel-pair form (C = 32)
+    return align_up(std::max(plain, paired) * sizeof(float), 256) + 256;
   }
   // weight gradient: split-K partial planes [nz][ctot][K + 1]
   int OH, OW;
@@ -1211,7 +1235,7 @@ extern "C" int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, con
   ConvMap& cv = g.cv;
   cv.Cg = d->C; cv.ps = d->C; cv.ntaps = taps;
   cv.RH = OH; cv.RW = OW; cv.IH = d->H; cv.IW = d->W;
-  cv.rs = d->stride; cv.roy = -d->pad; cv.rox = -d->pad;
+  cv.rs = d->stride; cv.rsx = d->stride; cv.roy = -d->pad; cv.rox = -d->pad;
   cv.remap = 0;
   cv.div_rw = make_fastdiv((unsigned)OW); cv.div_rhw = make_fastdiv((unsigned)(OH * OW));
   cv.bias = (unsigned)((d->pad * d->W + d->pad) * d->C * 4);
@@ -1261,6 +1285,82 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
   const int taps = d->KH * d->KW, s = d->stride, Co = d->Co, C = d->C;
   const int ldy = evae_conv2d_cl_dy_stride(Co * (gated ? 2 : 1));
   float* wp = (float*)ws;
+  if (C == 32 && (s == 1 || s == 2) && d->W % 2 == 0 && d->KH * (d->KW + 1) <= 64) {
+    // A 32-column result would leave half of the 64-wide tile idle.  Two x-adjacent output pixels (x = 2 rx + b) share
+    // one GEMM row instead: their taps are the same source pixels shifted by one, so the contraction runs over the
+    // union of the two tap sets with zero filter blocks where a tap belongs to only one of them, and the 64 output
+    // columns are the two pixels' channels -- contiguous in the channels-last dx.
+    const int W2 = d->W / 2;
+    size_t usedp = 0;
+    for (int py = 0; py < s && py < d->H; ++py) {
+      PairTaps pt; pt.n = 0;
+      GemmArgs g = {};
+      g.ones_col = -1;
+      ConvMap& cv = g.cv;
+      int tmin = 0;
+      for (int kh = 0; kh < d->KH; ++kh) {
+        if ((py + d->pad - kh) % s != 0) continue;
+        const int dy_ = (py + d->pad - kh) / s;
+        for (int b = 0; b < 2; ++b)
+          for (int kw = 0; kw < d->KW; ++kw) {
+            // source column of tap kw for pixel b, relative to the anchor (rx*rsx): s = 1: x = 2rx + b -> b + pad - kw;
+            // s = 2: x = 2rx + b is the pixel of class px = b -> (b + pad - kw) / 2 when divisible
+            if (s == 2 && (b + d->pad - kw) % 2 != 0) continue;
+            const int dx_ = s == 1 ? b + d->pad - kw : (b + d->pad - kw) / 2;
+            int u = -1;
+            for (int q = 0; q < pt.n; ++q)
+              if (cv.tdy[q] == dy_ && cv.tdx[q] == dx_) u = q;
+            if (u < 0) {
+              u = pt.n++;
+              cv.tdy[u] = (signed char)dy_; cv.tdx[u] = (signed char)dx_;
+              pt.tb[0][u] = pt.tb[1][u] = -1;
+              cv.tsoff[u] = (dy_ * OW + dx_) * ldy * 4;
+              if (cv.tsoff[u] < tmin) tmin = cv.tsoff[u];
+            }
+            pt.tb[b][u] = kh * d->KW + kw;
+          }
+      }
+      const int RH = (d->H - py + s - 1) / s;
+      if (pt.n == 0) {     // no tap reaches these rows (stride larger than the filter): their gradient is zero
+        for (int n = 0; n < d->N; ++n)
+          for (int ry = 0; ry < RH; ++ry) {
+            hipError_t e = hipMemsetAsync(dx + (((size_t)n * d->H + ry * s + py) * d->W) * C, 0, (size_t)d->W * C * sizeof(float), stream);
+            EVAE_REQUIRE(e == hipSuccess, "conv2d_cl_bwd_data: memset failed");
+          }
+        continue;
+      }
+      const unsigned tbias = (unsigned)(-tmin);
+      for (int u = 0; u < pt.n; ++u) cv.tsoff[u] += (int)tbias;
+      const size_t cls = (size_t)pt.n * ldy * 64;
+      float* wc = wp + usedp;
+      usedp += cls;
+      cl_permute_dgrad_pair_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, taps, ldy, pt, wc);
+      int rc = check_launch("cl_permute_dgrad_pair_kernel");
+      if (rc) return rc;
+      cv.Cg = ldy; cv.ps = ldy; cv.ntaps = pt.n;
+      cv.RH = RH; cv.RW = W2; cv.IH = OH; cv.IW = OW;
+      cv.rs = 1; cv.rsx = (s == 1) ? 2 : 1; cv.roy = 0; cv.rox = 0;
+      cv.OH2 = d->H; cv.OW2 = W2; cv.os = s; cv.osx = 1; cv.ooy = py; cv.oox = 0;   // output rows in units of pixel pairs
+      cv.remap = 1;
+      cv.div_rw = make_fastdiv((unsigned)W2); cv.div_rhw = make_fastdiv((unsigned)(RH * W2));
+      cv.bias = 0;
+      g.B[0] = wc;
+      g.lda[0] = ldy; g.ldb[0] = 64;
+      g.Kc[0] = pt.n * ldy; g.npairs = 1;
+      g.N = 64; g.ldo = 64;
+      g.ksplit = 0;
+      const int per = cl_images_per_pass(d, OH, OW, C, ldy);
+      for (int n0 = 0; n0 < d->N; n0 += per) {
+        const int nn = std::min(per, d->N - n0);
+        g.A[0] = dy + (size_t)n0 * OH * OW * ldy - tbias / 4;
+        g.out0 = dx + (size_t)n0 * d->H * d->W * C;
+        g.M = nn * RH * W2;
+        rc = launch_gemm_w<true, false, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data(pixel pairs)");
+        if (rc) return rc;
+      }
+    }
+    return EVAE_OK;
+  }
   size_t used = 0;      // floats of the permuted copy consumed by the classes so far
   bool any_empty = false;
   for (int py = 0; py < s && py < d->H; ++py)
@@ -1304,8 +1404,8 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
       if (rc) return rc;
       cv.Cg = ldy; cv.ps = ldy; cv.ntaps = tl.n;
       cv.RH = RH; cv.RW = RW; cv.IH = OH; cv.IW = OW;
-      cv.rs = 1; cv.roy = 0; cv.rox = 0;
-      cv.OH2 = d->H; cv.OW2 = d->W; cv.os = s; cv.ooy = py; cv.oox = px;
+      cv.rs = 1; cv.rsx = 1; cv.roy = 0; cv.rox = 0;
+      cv.OH2 = d->H; cv.OW2 = d->W; cv.os = s; cv.osx = s; cv.ooy = py; cv.oox = px;
       cv.remap = 1;
       cv.div_rw = make_fastdiv((unsigned)RW); cv.div_rhw = make_fastdiv((unsigned)(RH * RW));
       cv.bias = 0;
@@ -1374,7 +1474,7 @@ extern "C" int evae_conv2d_cl_bwd_weight(const float* dy, const float* x, const 
   ConvMap& cv = g.cv;
   cv.Cg = d->C; cv.ps = d->C; cv.ntaps = taps;
   cv.RH = OH; cv.RW = OW; cv.IH = d->H; cv.IW = d->W;
-  cv.rs = d->stride; cv.roy = -d->pad; cv.rox = -d->pad;
+  cv.rs = d->stride; cv.rsx = d->stride; cv.roy = -d->pad; cv.rox = -d->pad;
   cv.div_rw = make_fastdiv((unsigned)OW); cv.div_rhw = make_fastdiv((unsigned)(OH * OW));
   for (int kh = 0; kh < d->KH; ++kh)
     for (int kw = 0; kw < d->KW; ++kw) { cv.tdy[kh * d->KW + kw] = (signed char)kh; cv.tdx[kh * d->KW + kw] = (signed char)kw; }
