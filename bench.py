@@ -6,8 +6,11 @@ A step is the body of the reference's training loop (utils/training.py:27-46): b
 forward, sample + encode the C exemplars, exemplar prior, backward, AdamNormGrad -- all through the
 drop-in API (models.VAE.VAE.calculate_loss -> loss.backward() -> utils.optimizer.AdamNormGrad.step),
 i.e. through libevae_hip.so.  With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU,
-RCCL) the C exemplars are sharded across the ranks and the per-shard partial log-sum-exps are merged by
-one all-gather (evae/shard.py); batch and C are unchanged, so scaling is "strong".
+RCCL) the C exemplars are sharded across the ranks and the per-shard partial log-sum-exps are merged
+(evae/shard.py, evae/fused_vae.py).  Default (--parallel dp): every rank trains on its OWN 100-image batch --
+global batch 100 N, gradients averaged, each rank scores the queries of all ranks against its exemplar shard and
+the partials return to their owners -- so the per-GPU batch is fixed ("weak" scaling) while the 25 000 exemplars
+in total are split N ways.  --parallel replica keeps one replicated 100-image batch ("strong" scaling).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel (the fp32-MFMA GEMM behind GatedDense), algorithmic flops per
@@ -39,6 +42,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--exemplars", type=int, default=C)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--parallel", choices=("dp", "replica"), default="dp",
+                    help="with --gpus N > 1: 'dp' = every rank trains on its own 100-image batch (global batch 100 N) "
+                         "against the exemplar set sharded over the ranks (weak scaling in the batch); 'replica' = the "
+                         "same 100-image batch replicated on every rank, only the exemplars sharded (strong scaling)")
     ap.add_argument("--probe-steps", type=int, default=20,
                     help="eager steps run after the timed region to time the dominant kernel with HIP events")
     ap.add_argument("--iwae-images", type=int, default=16,
@@ -48,14 +55,14 @@ def parse():
     return ap.parse_args()
 
 
-def model_args(device, n_exemplars, sharded):
+def model_args(device, n_exemplars, sharded, shard_batch=False):
     from argparse import Namespace
     return Namespace(prior="exemplar_prior", input_type="binary", input_size=[1, 28, 28], hidden_size=H,
                      z1_size=Z, z2_size=Z, model_name="vae", device=device, number_components=n_exemplars,
                      training_set_size=N_TRAIN, approximate_prior=False, approximate_k=10, no_mask=False,
                      no_attention=False, same_variational_var=False, use_logit=False, lambd=1e-4,
                      bottleneck=6, dataset_name="dynamic_mnist", continuous=False, batch_size=B,
-                     dynamic_binarization=True, warmup=100, S=5000, shard_exemplars=sharded)
+                     dynamic_binarization=True, warmup=100, S=5000, shard_exemplars=sharded, shard_batch=shard_batch)
 
 
 def gated_flops(M, K, N):
@@ -95,11 +102,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # test hook (tests/test_gpu_sharded.py style): several ranks on ONE GPU over gloo, since RCCL refuses duplicate devices
+    one_device = os.environ.get("EVAE_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     n_ex = a.exemplars
 
     import golden_inputs as gi
@@ -111,10 +125,13 @@ def main():
     # synthetic dynamic_mnist-shaped training set: binary 28x28, N=50 000, seed 0
     data = torch.from_numpy(gi.binary_images(0, N_TRAIN))
     dataset = torch.utils.data.TensorDataset(data, torch.arange(N_TRAIN).reshape(-1, 1), torch.arange(N_TRAIN) % 10)
-    args = model_args("cuda:%d" % local_rank, n_ex, sharded=world > 1)
-    torch.manual_seed(14)                    # same weights, eps stream and exemplar draws on every rank
+    dp = world > 1 and a.parallel == "dp"
+    args = model_args("cuda:%d" % local_rank, n_ex, sharded=world > 1, shard_batch=dp)
+    torch.manual_seed(14)                    # same weights and (CPU-generator) exemplar draws on every rank
     torch.cuda.manual_seed(14)
     model = VAE(args).to(dev)
+    if dp:
+        torch.cuda.manual_seed(14 + rank)    # data-parallel batches: every rank its own eps / binarisation stream
     opt = AdamNormGrad(model.parameters(), lr=5e-4)
     data_dev = model.resident_data(dataset)  # one upload; exemplar gathers read HBM from here on
     idx_all = torch.arange(N_TRAIN, device=dev).reshape(-1, 1)
@@ -123,8 +140,11 @@ def main():
     nb = N_TRAIN // B
     loss_acc = torch.zeros((), device=dev)
 
+    def batch_start(i):                      # data-parallel: rank r takes the r-th batch of every group of `world`
+        return (((i * world + rank) if dp else i) % nb) * B
+
     def eager_step(i):
-        s = (i % nb) * B
+        s = batch_start(i)
         x = torch.bernoulli(data_dev[s:s + B])                     # dynamic binarisation (training.py:31)
         opt.zero_grad()
         loss, RE, KL = model.calculate_loss((x, idx_all[s:s + B]), beta, average=True, dataset=dataset)
@@ -141,7 +161,7 @@ def main():
         g = state["graphed"]
         if g is None:
             return eager_step(i)
-        s = (i % nb) * B
+        s = batch_start(i)
         try:
             out = g(data_dev[s:s + B], idx_all[s:s + B], beta)     # one hipGraph launch (after 3 eager warm-ups)
         except Exception as e:                                      # capture refused (e.g. by the collective
@@ -234,16 +254,20 @@ def main():
                 "ms_per_image": round(1e3 * t_ll / a.iwae_images, 3),
                 "note": "utils.evaluation.calculate_likelihood on synthetic test images after the benchmark's training steps"}
 
+    gb = B * world if dp else B              # images per step over all ranks
     if rank == 0:
         out = {
-            "metric": "training images/sec", "value": round(B * a.steps / dt, 1), "unit": "images/sec",
+            "metric": "training images/sec", "value": round(gb * a.steps / dt, 1), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "vae + exemplar_prior, dynamic_mnist-shaped binary 28x28, N=%d, batch %d, "
-                                   "%d exemplars, exact prior (BASELINE.json configs[1])" % (N_TRAIN, B, n_ex),
-                       "global_batch": B, "exemplars": n_ex,
-                       "parallelism": "exemplar-shard x%d" % world if world > 1 else "single GPU",
+            "higher_is_better": True, "scaling": "strong" if (world > 1 and not dp) else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "vae + exemplar_prior, dynamic_mnist-shaped binary 28x28, N=%d, batch %d per GPU, "
+                                   "%d exemplars in total, exact prior (BASELINE.json configs[1])" % (N_TRAIN, B, n_ex),
+                       "global_batch": gb, "exemplars": n_ex,
+                       "parallelism": ("single GPU" if world == 1 else
+                                       ("dp%d (own %d-image batch per rank) x exemplar-shard x%d, partial-LSE exchange over RCCL"
+                                        % (world, B, world)) if dp else
+                                       ("replicated batch, exemplar-shard x%d" % world)),
                        "launch": "eager" if graphed is None else "hipGraph replay of the whole step"},
             "mean_loss": round(final_loss, 4),
             "roofline": roof,

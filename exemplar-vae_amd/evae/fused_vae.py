@@ -154,10 +154,21 @@ class VaeExactLoss(torch.autograd.Function):
         main = torch.cuda.current_stream()
         side = main if sharded else k.side_stream()     # collectives stay on the main stream
         side.wait_stream(main)
+        z_all, zi_all = z, zi
         with torch.cuda.stream(side):
-            m, s, n, _ = ops.prior_lse_fwd(z, centres, lv_row, zi, ci)      # temporaries live and die on `side`
-            if sharded:
-                m, s, n = shard.gather_partials(m, s, n)
+            if sharded == 2:
+                # data-parallel batches over sharded exemplars: every rank scores the queries of ALL ranks against its
+                # shard (same pair count as B queries against all C), the partials go back to their owners
+                z_all = shard._all_gather_flat(z).reshape(-1, Z)
+                zi_all = None if zi is None else shard._all_gather_flat(zi.contiguous()).reshape(-1)
+                m, s, n, _ = ops.prior_lse_fwd(z_all, centres, lv_row, zi_all, ci)
+                m, s, n = shard.gather_partials(m, s, n)                  # [R x R*B] each
+                r0 = dist.get_rank() * B
+                m, s, n = (t[:, r0:r0 + B].contiguous() for t in (m, s, n))
+            else:
+                m, s, n, _ = ops.prior_lse_fwd(z, centres, lv_row, zi, ci)      # temporaries live and die on `side`
+                if sharded:
+                    m, s, n = shard.gather_partials(m, s, n)
             ops.prior_merge(m, s, n, c_total, out=(logp, lse))
         # ---- ... while the decoder reconstructs on the main stream
         D1 = torch.empty((B, H), **f32); sd1 = torch.empty_like(D1)
@@ -177,7 +188,8 @@ class VaeExactLoss(torch.autograd.Function):
                                      B, _vp(loss), _vp(KL), _vp(means), k.st), "elbo_fwd")
         ctx.set_materialize_grads(False)       # unused outputs (RE, KL) then arrive as None, not as zero-filled tensors
         ctx.k_dev = dev
-        ctx.dims = (B, D, H, Z, Cl, Mp, ldd, beta, bool(sharded))
+        ctx.dims = (B, D, H, Z, Cl, Mp, ldd, beta, int(sharded))
+        ctx.dp = (z_all, zi_all)
         ctx.bufs = (x, rows, data_ext, A1, s1, A2, s2, mean_all, logvar, lv_pre, z, D1, sd1, D2, sd2,
                     xmean, lv_row, zi, ci, lse, eps)
         ctx.save_for_backward(*params)
@@ -211,18 +223,38 @@ class VaeExactLoss(torch.autograd.Function):
         # ---- prior term d(-cKL * logp) on the side stream; dcentres lands directly in the head-gradient buffer,
         #      dz' and dlogvar' in one packed buffer so that the sharded case all-reduces it in place
         dmean_all = torch.empty((Mp, Z), **f32)
-        packed = torch.empty(B * Z + Z, **f32)
-        dzp = packed[:B * Z].view(B, Z); dlv = packed[B * Z:]
-        nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cl, Z)
-        w = k.ws("prior_bwd", nb)
         centres = mean_all[:Cl]
         main = torch.cuda.current_stream()
         side = main if sharded else k.side_stream()
         side.wait_stream(main)
+        if sharded == 2:
+            # data-parallel batches: the shard-side backward runs over the queries of all ranks (their lse and upstream
+            # coefficients are gathered first); dz partials are summed over the shards and every rank keeps its rows.
+            # dcentres and dlogvar are complete sums over all queries: the mean all-reduce of the parameter gradients
+            # in AdamNormGrad.step then yields the gradient of the global-batch mean loss, no rescaling needed.
+            z_all, zi_all = ctx.dp
+            RB = z_all.shape[0]
+            lg = shard._all_gather_flat(torch.stack((lse, gp)))            # [R x 2 x B]
+            lse_all = lg[:, 0].reshape(-1).contiguous(); gp_all = lg[:, 1].reshape(-1).contiguous()
+            dz_all = torch.empty((RB, Z), **f32); dlv = torch.empty(Z, **f32)
+            nb = lib.evae_prior_lse_bwd_workspace_bytes(RB, Cl, Z)
+            w = k.ws("prior_bwd", nb)
+            _lib.check(lib.evae_prior_lse_bwd(_vp(z_all), RB, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi_all), _vp(ci), _vp(lse_all),
+                                              _vp(gp_all), _vp(dz_all), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), ops._stream()),
+                       "prior_bwd")
+            dist.all_reduce(dz_all, op=dist.ReduceOp.SUM)
+            r0 = dist.get_rank() * B
+            dzp = dz_all[r0:r0 + B]
+        else:
+            packed = torch.empty(B * Z + Z, **f32)
+            dzp = packed[:B * Z].view(B, Z); dlv = packed[B * Z:]
+            nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cl, Z)
+            w = k.ws("prior_bwd", nb)
         with torch.cuda.stream(side):
-            _lib.check(lib.evae_prior_lse_bwd(_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp),
-                                              _vp(dzp), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), ops._stream()), "prior_bwd")
-            if sharded:
+            if sharded != 2:
+                _lib.check(lib.evae_prior_lse_bwd(_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp),
+                                                  _vp(dzp), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), ops._stream()), "prior_bwd")
+            if sharded == 1:
                 dist.all_reduce(packed, op=dist.ReduceOp.SUM)
                 if Cl > 0:
                     dmean_all[:Cl].mul_(float(dist.get_world_size()))

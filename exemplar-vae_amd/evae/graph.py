@@ -103,6 +103,8 @@ class GraphedTrainStep:
                 # with RCCL in the step its watchdog thread polls events while we capture: thread-local capture mode
                 # keeps those calls from invalidating the capture
                 mode = "thread_local" if shard.is_active() else "global"
+                import os
+                mode = os.environ.get("EVAE_CAPTURE_MODE", mode)
                 try:
                     with torch.cuda.graph(graph, capture_error_mode=mode):
                         self._body()
@@ -112,7 +114,12 @@ class GraphedTrainStep:
                     print("evae.graph: hipGraph capture of the training step failed (%s: %s); running eagerly"
                           % (type(e).__name__, str(e).splitlines()[0][:120]), file=sys.stderr)
                     self.failed = True
-                    torch.cuda.synchronize()
+                    for _ in range(4):           # a failed capture can leave a sticky HIP error behind: drain it
+                        try:
+                            torch.cuda.synchronize()
+                            break
+                        except Exception:
+                            pass
                     self._body()
                     self._calls += 1
                     return self.out

@@ -14,6 +14,15 @@ Backward: w_ij is recomputed from the GLOBAL lse; dcentres stays local, dz [B x 
 sum-all-reduced.  Parameter gradients are then averaged over ranks (allreduce_grads, called by
 AdamNormGrad.step) -- dcentres is pre-scaled by R so that the average equals
 (replicated batch-path gradient) + sum_r (shard-r exemplar-path gradient), i.e. the single-GPU gradient.
+
+Data-parallel batches (args.shard_batch, evae/fused_vae.py): every rank trains on its OWN batch (global batch R*B,
+gradients averaged as usual) while the exemplars stay sharded.  Each rank then scores the latents of ALL ranks
+against its shard -- all-gather of z [R*B x z] (and the dataset indices for the leave-one-out mask), the same number
+of pairs as B queries against all C exemplars -- the partials are all-gathered and every rank merges its own B
+rows; backward: all-gather of (lse, upstream coefficient), shard-side backward over all R*B queries, sum-all-reduce
+of dz [R*B x z] of which every rank keeps its rows.  dcentres / dlogvar are then complete sums over all queries, so
+the mean all-reduce of the parameter gradients gives exactly the gradient of the global-batch mean loss (no
+rescaling): tests/test_gpu_sharded.py checks 2 ranks x B against 1 process x 2B.
 """
 import torch
 import torch.distributed as dist

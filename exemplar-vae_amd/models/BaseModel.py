@@ -103,7 +103,8 @@ class BaseModel(nn.Module, ABC):
         params = [named[n] for n in fused_vae.PARAM_ORDER]
         beta = beta if torch.is_tensor(beta) else float(beta)
         return fused_vae.VaeExactLoss.apply(x2, x_indices.reshape(-1), data_ext, n_data, ex_local, C, eps,
-                                            beta, sharded, bool(a.no_mask), bool(average), rows_ext, *params)
+                                            beta, (2 if getattr(a, 'shard_batch', False) else 1) if sharded else 0,
+                                            bool(a.no_mask), bool(average), rows_ext, *params)
 
     def calculate_loss(self, x, beta=1., average=False, exemplars_embedding=None, cache=None, dataset=None):
         x, x_indices = x

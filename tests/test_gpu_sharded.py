@@ -77,3 +77,72 @@ def test_two_rank_sharded_training_matches_single(fused):
         assert rel(losses, single[1]) < 1e-5, (rank, losses, single[1])
         for k in params:
             assert rel(params[k], single[2][k]) < 3e-4, (rank, k)   # summation order differs between 1 and 2 shards; Adam on normalised gradients moves every weight by ~lr per step whatever the gradient magnitude, so rounding-level differences in near-zero gradient entries show up at the 1e-4 level (the losses above agree to 1e-5)
+
+
+# ---- data-parallel batches over sharded exemplars (args.shard_batch): 2 ranks x B images == 1 process x 2B images ----
+def _run_dp(rank, world, port, q):
+    for p in (os.path.join(ROOT, "exemplar-vae_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import evae_oracle as orc
+    import golden_inputs as gi
+    import smoke_case
+    from utils.optimizer import AdamNormGrad
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        data = gi.binary_images(5, N)
+        dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+        GB = 2 * B                                                   # global batch
+        lb = GB // world                                             # this process's share
+        args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=lb, shard_exemplars=world > 1,
+                                   shard_batch=world > 1)
+        model, _ = smoke_case.build_model(torch, np, orc, args)
+        model.train()
+        opt = AdamNormGrad(model.parameters(), lr=5e-4)
+        torch.manual_seed(11)                                        # identical exemplar draws in every process
+        losses = []
+        for it in range(STEPS):
+            lo = it * GB + rank * lb
+            xb = torch.from_numpy(data[lo:lo + lb]).cuda()
+            ib = torch.arange(lo, lo + lb).reshape(-1, 1).cuda()
+            eps = np.random.RandomState(100 + it).standard_normal((GB, 40)).astype(np.float32)[rank * lb:(rank + 1) * lb]
+            model._draw_eps = lambda like, e=eps: torch.from_numpy(e).to(like.device)
+            opt.zero_grad()
+            loss, RE, KL = model.calculate_loss((xb, ib), 0.7, average=True, dataset=dataset)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        out = {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}
+        q.put((rank, losses, out))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_batches_match_single_process_global_batch():
+    ctx = mp.get_context("spawn")
+
+    def spawn(world):
+        q = ctx.Queue()
+        port = 29900 + (os.getpid() % 1000)
+        procs = [ctx.Process(target=_run_dp, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return res
+    single = spawn(1)[0]
+    double = spawn(2)
+
+    def rel(a, b):
+        a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+        return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    mean_losses = np.mean([np.asarray(l) for _, l, _ in double], axis=0)   # global-batch mean = mean of the rank means
+    assert rel(mean_losses, single[1]) < 1e-5, (mean_losses, single[1])
+    for rank, _, params in double:
+        for k in params:
+            assert rel(params[k], single[2][k]) < 3e-4, (rank, k)
