@@ -210,6 +210,21 @@ class VaeExactLoss(torch.autograd.Function):
         k = _K(dev)
         lib = k.lib
         f32 = dict(device=dev, dtype=torch.float32)
+        # every parameter gradient is a view of one buffer (slots padded to 256 B), see shard.register_flat_grads
+        slots = (("plv", 1), ("wp", D * H), ("bp", D), ("w1", 2 * H * D), ("b1", 2 * H), ("w2", 2 * H * H), ("b2", 2 * H),
+                 ("wm", Z * H), ("bm", Z), ("wl", Z * H), ("bl", Z), ("d1", 2 * H * Z), ("e1", 2 * H), ("d2", 2 * H * H),
+                 ("e2", 2 * H))
+        offs, tot = {}, 0
+        for name, n in slots:
+            offs[name] = (tot, n)
+            tot += (n + 63) // 64 * 64
+        gflat = torch.empty(tot, **f32)          # the padding between slots is never read (only summed by the all-reduce)
+
+        def gslot(name, *shape):
+            o, n = offs[name]
+            return gflat[o:o + n].view(*shape)
+        if sharded:
+            shard.register_flat_grads(gflat)
         # upstream gradients are per-row vectors (average=False) or scalars of the batch means (average=True)
         cRE = torch.empty(B, **f32); cKL = torch.empty(B, **f32); gp = torch.empty(B, **f32)
         gl = None if dloss is None else dloss.contiguous()
@@ -263,15 +278,15 @@ class VaeExactLoss(torch.autograd.Function):
         _lib.check(lib.evae_bernoulli_ll_bwd(_vp(x), _vp(xmean), _vp(cRE), B, D, _vp(dxm), k.st), "bernoulli_bwd")
         dpx = torch.empty((B, D), **f32)
         _lib.check(lib.evae_act_bwd(_vp(dxm), _vp(xmean), B * D, ACT_SIGMOID, 0.0, 0.0, _vp(dpx), k.st), "act_bwd")
-        g_wp = torch.empty_like(wp); g_bp = torch.empty_like(bp)
+        g_wp = gslot("wp", D, H); g_bp = gslot("bp", D)
         k.bwd_weight(dpx, B, D, D, D2, None, H, H, g_wp, g_bp)
         dp2 = torch.empty((B, 2 * H), **f32)                              # [dh | dg] of decoder layer 2
         k.bwd_data(dpx, wp, None, None, B, D, D, H, D2, sd2, dp2, dp2.data_ptr() + 4 * H, 2 * H)
-        g_d2 = torch.empty((2 * H, H), **f32); g_e2 = torch.empty(2 * H, **f32)
+        g_d2 = gslot("d2", 2 * H, H); g_e2 = gslot("e2", 2 * H)
         k.bwd_weight(dp2, B, 2 * H, 2 * H, D1, None, H, H, g_d2, g_e2)
         dp1 = torch.empty((B, 2 * H), **f32)
         k.bwd_data(dp2, d2h, dp2.data_ptr() + 4 * H, d2g, B, H, 2 * H, H, D1, sd1, dp1, dp1.data_ptr() + 4 * H, 2 * H)
-        g_d1 = torch.empty((2 * H, Z), **f32); g_e1 = torch.empty(2 * H, **f32)
+        g_d1 = gslot("d1", 2 * H, Z); g_e1 = gslot("e1", 2 * H)
         k.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1)
         dz = torch.empty((B, Z), **f32)
         k.bwd_data(dp1, d1h, dp1.data_ptr() + 4 * H, d1g, B, H, 2 * H, Z, None, None, dz, None, Z)
@@ -286,9 +301,9 @@ class VaeExactLoss(torch.autograd.Function):
         _lib.check(lib.evae_act_bwd(_vp(dlogvar), _vp(lv_pre), B * Z, ACT_HARDTANH, -6.0, 2.0, _vp(dlvp), k.st), "act_bwd")
         # ---- heads
         A2b_ptr = A2.data_ptr() + 4 * Cl * H
-        g_wl = torch.empty_like(wl); g_bl = torch.empty_like(bl)
+        g_wl = gslot("wl", Z, H); g_bl = gslot("bl", Z)
         k.bwd_weight(dlvp, B, Z, Z, A2b_ptr, None, H, H, g_wl, g_bl)
-        g_wm = torch.empty_like(wm); g_bm = torch.empty_like(bm)
+        g_wm = gslot("wm", Z, H); g_bm = gslot("bm", Z)
         k.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)
         dq2 = torch.empty((Mp, 2 * H), **f32)                              # [dh2 | dg2] for all C + B rows
         if Cl > 0:
@@ -297,13 +312,14 @@ class VaeExactLoss(torch.autograd.Function):
         k.bwd_data(dmean_all.data_ptr() + off * Z, wm, dlvp, wl, B, Z, Z, H, A2.data_ptr() + off * H,
                    s2.data_ptr() + off * H, dq2.data_ptr() + off * 2 * H, dq2.data_ptr() + off * 2 * H + 4 * H, 2 * H)
         # ---- encoder layers over C + B rows
-        g_w2 = torch.empty((2 * H, H), **f32); g_b2 = torch.empty(2 * H, **f32)
+        g_w2 = gslot("w2", 2 * H, H); g_b2 = gslot("b2", 2 * H)
         k.bwd_weight(dq2, Mp, 2 * H, 2 * H, A1, None, H, H, g_w2, g_b2)
         dq1 = torch.empty((Mp, 2 * H), **f32)
         k.bwd_data(dq2, w2h, dq2.data_ptr() + 4 * H, w2g, Mp, H, 2 * H, H, A1, s1, dq1, dq1.data_ptr() + 4 * H, 2 * H)
-        g_w1 = torch.empty((2 * H, D), **f32); g_b1 = torch.empty(2 * H, **f32)
+        g_w1 = gslot("w1", 2 * H, D); g_b1 = gslot("b1", 2 * H)
         k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)
-        g_plv = dlv.sum().reshape(1)
+        g_plv = gslot("plv", 1)
+        torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
         ctx.bufs = None
         grads = (g_plv, g_wp, g_bp, g_w1[:H], g_b1[:H], g_w1[H:], g_b1[H:], g_w2[:H], g_b2[:H], g_w2[H:], g_b2[H:],
                  g_wm, g_bm, g_wl, g_bl, g_d1[:H], g_e1[:H], g_d1[H:], g_e1[H:], g_d2[:H], g_e2[:H], g_d2[H:], g_e2[H:])

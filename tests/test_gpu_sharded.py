@@ -115,6 +115,11 @@ def _run_dp(rank, world, port, q):
             opt.step()
             losses.append(loss.item())
         out = {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}
+        if world > 1:
+            # the fused step's gradients must be views of ONE buffer, so that their averaging is a single in-place collective
+            from evae import shard
+            base = shard._FLAT[0].untyped_storage().data_ptr()
+            out["__flat__"] = np.asarray([float(all(p.grad.untyped_storage().data_ptr() == base for p in model.parameters()))])
         q.put((rank, losses, out))
     finally:
         if world > 1:
@@ -144,5 +149,6 @@ def test_two_rank_data_parallel_batches_match_single_process_global_batch():
     mean_losses = np.mean([np.asarray(l) for _, l, _ in double], axis=0)   # global-batch mean = mean of the rank means
     assert rel(mean_losses, single[1]) < 1e-5, (mean_losses, single[1])
     for rank, _, params in double:
+        assert params.pop("__flat__")[0] == 1.0
         for k in params:
             assert rel(params[k], single[2][k]) < 3e-4, (rank, k)
