@@ -96,7 +96,38 @@ def cpu_baseline(steps):
                       % (done, B, C, N_TRAIN)}
 
 
+def capture_probe():
+    """Child process of a multi-GPU run: capture an all-reduce and an all-gather into a hipGraph, replay, check."""
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = 0 if os.environ.get("EVAE_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if os.environ.get("EVAE_BENCH_ONE_DEVICE") == "1":
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
+    x = torch.full((256,), float(rank + 1), device=dev)
+    out = torch.empty(256 * world, device=dev)
+    y = x.clone()
+    dist.all_reduce(y); dist.all_gather_into_tensor(out, x)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        y.copy_(x)
+        dist.all_reduce(y)
+        dist.all_gather_into_tensor(out, x)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    ok = abs(float(y[0].item()) - world * (world + 1) / 2.0) < 1e-3 and abs(float(out[-1].item()) - world) < 1e-3
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
 def main():
+    if "--capture-probe" in sys.argv:
+        capture_probe()
+        return
     a = parse()
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -115,6 +146,25 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     n_ex = a.exemplars
+
+    # Can this RCCL build capture collectives into a hipGraph (and replay them without hanging)?  A capture that fails
+    # half-way cannot be recovered from in-process (the collective library's internal streams and torch's RNG state stay
+    # in capture mode), so the question is put to a throw-away child process per rank, under a timeout; the ranks then
+    # agree on the verdict.
+    if world > 1 and not a.no_graph:
+        import subprocess
+        env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
+        try:
+            rc = subprocess.run([sys.executable, os.path.abspath(__file__), "--capture-probe"], env=env, timeout=90,
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+        except Exception:
+            rc = 1
+        flag = torch.tensor([1.0 if rc == 0 else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 0.5:
+            if rank == 0:
+                print("bench: RCCL collectives cannot be captured into a hipGraph here; launching eagerly", file=sys.stderr)
+            a.no_graph = True
 
     import golden_inputs as gi
     from evae import ops

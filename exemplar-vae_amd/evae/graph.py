@@ -99,6 +99,7 @@ class GraphedTrainStep:
                     self._calls += 1
                     return self.out
                 torch.cuda.synchronize()
+                main_stream = torch.cuda.current_stream()
                 graph = torch.cuda.CUDAGraph()
                 # with RCCL in the step its watchdog thread polls events while we capture: thread-local capture mode
                 # keeps those calls from invalidating the capture
@@ -114,6 +115,9 @@ class GraphedTrainStep:
                     print("evae.graph: hipGraph capture of the training step failed (%s: %s); running eagerly"
                           % (type(e).__name__, str(e).splitlines()[0][:120]), file=sys.stderr)
                     self.failed = True
+                    # torch.cuda.graph.__exit__ does not restore the stream when capture_end() itself raises: the current
+                    # stream would stay the (invalidated, still "capturing") capture stream and every later launch fail
+                    torch.cuda.set_stream(main_stream)
                     for _ in range(4):           # a failed capture can leave a sticky HIP error behind: drain it
                         try:
                             torch.cuda.synchronize()
