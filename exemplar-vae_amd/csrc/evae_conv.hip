@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_gemm_kernel(const ConvAr
     store_b(Bs(0), rb);
     if (s_begin + 1 < s_end) { ra = gather_a((s_begin + 1) * BK); rb = load_b((s_begin + 1) * BK); }
     __syncthreads();
-    // same slab schedule as the dense kernel (evae_dense.hip): memory work slotted between the MFMA steps,
+    // same slab schedule as the dense kernel (evae_gemm_kernel.h): memory work slotted between the MFMA steps,
     // no branches around memory instructions in the steady state (last two slabs peeled), barrier before
     // the last k-group with the next slab's first fragments requested right behind it
     Frag<MT, NT> f0, f1;

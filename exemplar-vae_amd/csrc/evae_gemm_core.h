@@ -1,4 +1,4 @@
-// Shared core of the fp32-MFMA GEMM family (dense layers: evae_dense.hip; convolutions: evae_conv.hip):
+// Shared core of the fp32-MFMA GEMM family (evae_gemm_kernel.h: dense layers and channels-last convolutions; evae_conv.hip: NCHW convolutions):
 // tile constants, the per-slab MFMA loop over LDS tiles, the split-K finish kernel and the host planner.
 #pragma once
 #include <stdlib.h>

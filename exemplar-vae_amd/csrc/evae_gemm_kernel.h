@@ -1,0 +1,780 @@
+// The fp32-MFMA GEMM kernel shared by the dense layers (evae_dense.hip) and the channels-last convolutions
+// (evae_conv_cl.hip): argument block, tile loaders, the kernel and its launch helpers.  The header comment of
+// evae_dense.hip describes the tiling; the slab schedule is explained where it is built, in the kernel below.
+#pragma once
+#include "evae_gemm_core.h"
+#include <type_traits>
+#include <algorithm>
+
+namespace evae {
+
+// Convolution as a GEMM over channels-last tensors (template parameter CV of gemm_kernel):
+//   CV = 1 (forward, data gradient): A rows are the pixels (n, ry, rx) of a grid, the contraction runs over
+//          (tap, channel) with the channel fastest and Cg % 32 == 0, so a 32-wide K-slab is 32 consecutive
+//          channels of ONE tap for the whole block: the A tile is the dense KC tile with a per-slab byte
+//          offset (tap) in an SGPR and one validity bit per (row, tap) -- no im2col arithmetic in the loop;
+//          out-of-image taps ride the same out-of-range buffer offset as every other zero fill;
+//   CV = 2 (weight gradient): the contraction runs over the pixels, B is the im2col matrix
+//          [pixel][(tap, channel)] gathered as float4 (4 channels of one tap), A is dy, row-contiguous.
+// Source element of row (n, ry, rx), tap t, channel c:
+//   src[((n*IH + ry*rs + roy + tdy[t]) * IW + rx*rsx + rox + tdx[t]) * ps + c]
+// Output row (CV = 1): ((n*OH2 + ry*os + ooy) * OW2 + rx*osx + oox)  (identity for the forward; the strided
+// pixels of one stride-parity class -- or pairs of x-adjacent pixels, see evae_conv2d_cl_bwd_data -- for the data
+// gradient).
+struct FastDiv { unsigned mul, sh, one; };   // q = one ? n : (t = umulhi(mul, n), (t + ((n - t) >> 1)) >> sh)
+__host__ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv d) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const unsigned t = __umulhi(d.mul, n);
+#else
+  const unsigned t = (unsigned)(((unsigned long long)d.mul * n) >> 32);
+#endif
+  return d.one ? n : (t + ((n - t) >> 1)) >> d.sh;
+}
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f = {0u, 0u, 0u};
+  if (d <= 1) { f.one = 1; return f; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  f.sh = l - 1;
+  return f;
+}
+struct ConvMap {
+  int Cg, ntaps;
+  int ps;                      // floats per source pixel (Cg, or 2 Cg when the h and g gradients share one buffer)
+  int RH, RW, IH, IW;
+  int rs, rsx, roy, rox;       // anchor of row (ry, rx) in the source: (ry*rs + roy, rx*rsx + rox)
+  int OH2, OW2, os, osx, ooy, oox;   // output row of (n, ry, rx): (n*OH2 + ry*os + ooy)*OW2 + rx*osx + oox
+  int remap;                   // CV = 1: output rows are not the identity
+  unsigned bias;               // bytes added to every per-row offset (the buffer base is moved back by bias + tbias)
+  FastDiv div_rw, div_rhw;
+  signed char tdy[64], tdx[64];
+  int tsoff[64];               // CV = 1: byte offset of tap t, >= 0 after adding tbias
+};
+
+struct GemmArgs {
+  const float* A[2];
+  const float* B[2];
+  int lda[2], ldb[2];
+  int Kc[2];               // contraction length of each (A,B) pair
+  int npairs;
+  const int64_t* a_rows;   // KC A: gather of output rows
+  const int64_t* b_krows;  // RC B: gather along the contraction index (weight gradient x rows)
+  const float* Bg;         // gated: second weight matrix (g), same layout as B[0]
+  int M, N;                // output rows / columns
+  int ksplit;              // K-slabs per blockIdx.z (split-K); 0 = whole contraction
+  const float* bias0;
+  const float* bias1;
+  float* out0;
+  float* out1;
+  float* out2;
+  int ldo;
+  const float* e0;         // EPI_GATE_BWD: gated output h*s of the layer below
+  const float* e1;         //               gate s of the layer below
+  int act;
+  float lo, hi;
+  int tiles_m, tiles_n;
+  int ones_col;            // RC B: virtual all-ones column index (bias gradient folded into the weight GEMM); -1 = none
+  int dbg;                 // EVAE_GEMM_DBG (tools/gemm_ablate.py): 4 = skip the epilogue, 512 = clock probe; 0 in production
+  ConvMap cv;              // used by the CV != 0 instances only
+};
+
+// Out-of-range chunks are loaded from a clamped, always-mapped address and zeroed LATER, when the
+// prefetched registers are written to LDS: masking right after the load would make the compiler wait
+// for the prefetch before the MFMAs it is meant to overlap.
+__device__ __forceinline__ float4 ld4v(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// Scalar path for odd extents (e.g. the 294-wide head of convhvae_2level): correct, not fast.
+__device__ __forceinline__ float4 ld4s(const float* p, int valid) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid > 0) v.x = p[0];
+  if (valid > 1) v.y = p[1];
+  if (valid > 2) v.z = p[2];
+  if (valid > 3) v.w = p[3];
+  return v;
+}
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// Raw buffer resource over a wave-uniform pointer (stride 0, DATA_FORMAT = 32-bit): offsets at or beyond
+// num_records read as zero, which is how tails and out-of-matrix rows are blanked without any VALU work.
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned num_records) {
+  const uintptr_t u = (uintptr_t)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, num_records, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(rsrc_t r, unsigned voff, unsigned soff) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  const f32x4 v = __builtin_bit_cast(f32x4, u);   // (component access on the integer vector degrades to a dword load)
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ unsigned buf_ld1(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+
+// ---- tile loader: ROWS x BK floats per K-slab, NV float4 per thread -------------------------------
+// KC: tile[row][k], f = tid + 256 i -> row = f >> 3, k = 4 (f & 7)
+// RC: tile[k][row], f -> k = f / (ROWS/4), row = 4 (f % (ROWS/4))
+template <int ROWS, bool KC, int GNT>
+struct TileLoader {
+  static constexpr int NV = ROWS * BK / 4 / GNT;
+  static constexpr int RS = ROWS + 4;
+  static constexpr int RQ = ROWS / 4;
+  const float* base[NV];
+  bool rowok[NV];
+
+  __device__ __forceinline__ void init(const float* src, int ld, int r0, int nrows, const int64_t* gather) {
+    if (KC) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        int f = threadIdx.x + GNT * i;
+        int r = r0 + (f >> 3);
+        rowok[i] = r < nrows;
+        int64_t gr = rowok[i] ? (gather ? gather[r] : (int64_t)r) : 0;
+        base[i] = src + gr * ld + 4 * (f & 7);
+      }
+    }
+  }
+  template <bool VEC>
+  __device__ __forceinline__ unsigned load_kc(float4 (&v)[NV], int k0, int kend) const {
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int f = threadIdx.x + GNT * i;
+      int k = k0 + 4 * (f & 7);
+      if (VEC) {
+        const bool ok = rowok[i] && (k + 4 <= kend);
+        v[i] = ld4v(base[i] + (ok ? k0 : -4 * (f & 7)));   // invalid -> start of a mapped row
+        mask |= (ok ? 1u : 0u) << (2 * i);
+      } else {
+        v[i] = ld4s(base[i] + k0, rowok[i] ? (kend - k) : 0);
+        mask |= 1u << (2 * i);
+      }
+    }
+    return mask;
+  }
+  // mask: 2 bits per chunk -- 0 = zero fill, 1 = loaded data, 2 = the virtual ones column (1,0,0,0)
+  template <bool VEC>
+  __device__ __forceinline__ unsigned load_rc(float4 (&v)[NV], const float* src, int ld, int r0, int nrows,
+                                              int k0, int kend, const int64_t* kgather, int ones_col) const {
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int f = threadIdx.x + GNT * i;
+      int k = k0 + f / RQ;
+      int r = r0 + 4 * (f % RQ);
+      const bool kok = k < kend;
+      int64_t gk = kok ? (kgather ? kgather[k] : (int64_t)k) : 0;
+      if (VEC) {
+        const bool ok = kok && (r + 4 <= nrows);
+        v[i] = ld4v(src + gk * ld + (ok ? r : 0));
+        mask |= (ok ? 1u : ((kok && r == ones_col) ? 2u : 0u)) << (2 * i);
+      } else {
+        v[i] = ld4s(src + gk * ld + r, kok ? (nrows - r) : 0);
+        if (kok && ones_col >= r && ones_col < r + 4) (&v[i].x)[ones_col - r] = 1.0f;
+        mask |= 1u << (2 * i);
+      }
+    }
+    return mask;
+  }
+  __device__ __forceinline__ void store(float* tile, const float4 (&v)[NV], unsigned mask) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int f = threadIdx.x + GNT * i;
+      const unsigned sel = (mask >> (2 * i)) & 3u;
+      const float4 w = sel == 1u ? v[i] : make_float4(sel == 2u ? 1.f : 0.f, 0.f, 0.f, 0.f);
+      if (KC) *reinterpret_cast<float4*>(tile + (f >> 3) * KS + 4 * (f & 7)) = w;
+      else    *reinterpret_cast<float4*>(tile + (f / RQ) * RS + 4 * (f % RQ)) = w;
+    }
+  }
+};
+
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW, int CV = 0>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g) {
+  constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
+  constexpr int GNT = 64 * NW;
+  constexpr int MT = 8 / NW;        // NW/2 wave rows x 2 wave columns; wave tile (32 MT) x (32 NT)
+  constexpr int NT = BN_ / 64;
+  static_assert(!GATED || BN_ == 128, "gated epilogue needs the h and g column tiles in one wave");
+  constexpr int STAGE = A_TILE_FLOATS + b_tile_floats(BN_);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  auto As = [&](int b) -> float* { return smem + b * STAGE; };
+  auto Bs = [&](int b) -> float* { return smem + b * STAGE + A_TILE_FLOATS; };
+
+  // XCD-aware bijective remap: XCD x (= id % 8) works on a contiguous run of tiles
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int tile;
+  {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int qq = ntiles >> 3, rr = ntiles & 7;
+    tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM;
+  // gated: a block covers 64 gated output columns; B tile rows = [wc][h|g][32]
+  const int n0 = GATED ? tn * 64 : tn * BN_;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const long long dbg_c0 = __builtin_readcyclecounter(), dbg_w0 = wall_clock64();
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // flattened list of K-slabs over the (A,B) pairs
+  int nslab[2];
+  nslab[0] = (g.Kc[0] + BK - 1) / BK;
+  nslab[1] = g.npairs > 1 ? (g.Kc[1] + BK - 1) / BK : 0;
+  int s_begin = 0, s_end = nslab[0] + nslab[1];
+  if (g.ksplit > 0) {
+    s_begin = blockIdx.z * g.ksplit;
+    int e = s_begin + g.ksplit;
+    if (e < s_end) s_end = e;
+  }
+
+  if constexpr (VEC) {
+    // ---- fast path: every extent a multiple of 4, non-gathered operands below 2 GiB.  The slab loop
+    // holds almost no VALU work (measured: each VALU instruction costs the matrix pipe its 4 issue
+    // cycles): non-gathered tiles come through buffer loads -- per-thread byte offset fixed at kernel
+    // start, the slab offset in an SGPR, rows/columns outside the matrix and the K tail parked on an
+    // out-of-range offset that the hardware returns as zero -- so nothing is masked afterwards.
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NVA = BM * BK / 4 / GNT, NVB = BN_ * BK / 4 / GNT;
+    constexpr int RQA = BM / 4, RQB = BN_ / 4, RSA = BM + 4, RSB = BN_ + 4;
+    constexpr bool PAIRS = A_KC && !B_KC;   // only the data gradient chains two (A,B) pairs
+    const bool gatherA = A_KC && g.a_rows != nullptr;
+    const bool gatherB = !B_KC && g.b_krows != nullptr;
+    const bool has_ones = !B_KC && g.ones_col >= n0 && g.ones_col < n0 + BN_;
+    const rsrc_t rA0 = make_rsrc(g.A[0], 0x7FFFFFFFu);
+    const rsrc_t rA1 = make_rsrc(PAIRS && g.npairs > 1 ? g.A[1] : g.A[0], 0x7FFFFFFFu);
+    const rsrc_t rB0 = make_rsrc(g.B[0], 0x7FFFFFFFu);
+    const rsrc_t rB1 = make_rsrc(GATED ? g.Bg : (PAIRS && g.npairs > 1 ? g.B[1] : g.B[0]), 0x7FFFFFFFu);
+    const rsrc_t rIdx = make_rsrc(gatherB ? (const void*)g.b_krows : (const void*)g.B[0],
+                                  gatherB ? (unsigned)g.Kc[0] * 8u : 0u);
+    const bool wave_upper = (__builtin_amdgcn_readfirstlane(threadIdx.x) & 256) != 0;
+
+    unsigned voA[PAIRS ? 2 : 1][NVA], voB[PAIRS ? 2 : 1][NVB];
+    unsigned long long tapmask[NVA];       // CV = 1: bit t = tap t of this chunk's row lies inside the source image
+    int colch[NVB], coltap[NVB];           // CV = 2: channel offset / tap of this chunk's four im2col columns
+    const float* gpA[NVA];
+    const float* gpB[NVB];
+    unsigned kidx[NVB];
+    bool onesB[NVB];
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+      const int f = threadIdx.x + GNT * i;
+      gpA[i] = g.A[0];
+      tapmask[i] = 0ull;
+      if (A_KC && CV == 1) {
+        // row = pixel (n, ry, rx): anchor offset in the channels-last source + which taps fall inside the image
+        const int r = m0 + (f >> 3);
+        const bool ok = r < g.M;
+        const unsigned rr = ok ? (unsigned)r : 0u;
+        const unsigned n = fdiv(rr, g.cv.div_rhw), rem = rr - n * (unsigned)(g.cv.RH * g.cv.RW);
+        const unsigned ry = fdiv(rem, g.cv.div_rw), rx = rem - ry * (unsigned)g.cv.RW;
+        const int ay = (int)ry * g.cv.rs + g.cv.roy, ax = (int)rx * g.cv.rsx + g.cv.rox;
+        const long long off = (((long long)n * g.cv.IH + ay) * g.cv.IW + ax) * g.cv.ps * 4 + 16 * (f & 7) + (long long)g.cv.bias;
+#pragma unroll
+        for (int p = 0; p < (PAIRS ? 2 : 1); ++p) voA[p][i] = ok ? (unsigned)off : OOB;
+        if (ok)
+          for (int t = 0; t < g.cv.ntaps; ++t) {
+            const int y = ay + g.cv.tdy[t], x = ax + g.cv.tdx[t];
+            if ((unsigned)y < (unsigned)g.cv.IH && (unsigned)x < (unsigned)g.cv.IW) tapmask[i] |= 1ull << t;
+          }
+      } else if (A_KC) {
+        const int r = m0 + (f >> 3);
+        const bool ok = r < g.M;
+        if (gatherA) {
+          gpA[i] = g.A[0] + (size_t)g.a_rows[ok ? r : m0] * g.lda[0] + 4 * (f & 7);
+        }
+#pragma unroll
+        for (int p = 0; p < (PAIRS ? 2 : 1); ++p)
+          voA[p][i] = ok ? (unsigned)(r * g.lda[p] + 4 * (f & 7)) * 4u : OOB;
+      } else {
+        const int c = m0 + 4 * (f % RQA);
+        voA[0][i] = (c + 4 <= g.M) ? (unsigned)((f / RQA) * g.lda[0] + c) * 4u : OOB;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      const int f = threadIdx.x + GNT * i;
+      gpB[i] = g.B[0];
+      onesB[i] = false;
+      kidx[i] = 0;
+      if (GATED) {
+        const int r = f >> 3;
+        const int n = n0 + (r >> 6) * 32 + (r & 31);
+        voB[0][i] = (n < g.N) ? (unsigned)(n * g.ldb[0] + 4 * (f & 7)) * 4u : OOB;
+      } else if (B_KC) {
+        const int n = n0 + (f >> 3);
+        voB[0][i] = (n < g.N) ? (unsigned)(n * g.ldb[0] + 4 * (f & 7)) * 4u : OOB;
+      } else {
+        const int c = n0 + 4 * (f % RQB);
+        const int nlim = g.ones_col >= 0 ? g.ones_col : g.N;
+        const bool ok = c + 4 <= nlim;
+        onesB[i] = (c == g.ones_col);
+        coltap[i] = -1; colch[i] = 0;
+        if (CV == 2 && ok) { coltap[i] = c / g.cv.Cg; colch[i] = c - coltap[i] * g.cv.Cg; }
+        if (gatherB) gpB[i] = g.B[0] + (ok ? c : 0);
+#pragma unroll
+        for (int p = 0; p < (PAIRS ? 2 : 1); ++p)
+          voB[p][i] = ok ? (unsigned)((f / RQB) * g.ldb[p] + c) * 4u : OOB;
+      }
+    }
+    if (gatherB) {
+#pragma unroll
+      for (int i = 0; i < NVB; ++i)
+        kidx[i] = buf_ld1(rIdx, (unsigned)(s_begin * BK + (threadIdx.x + GNT * i) / RQB) * 8u, 0u);
+    }
+
+    // The slab loop must not branch around memory instructions: the compiler's s_waitcnt bookkeeping
+    // merges pessimistically at every join, and a "vmcnt(0)" in front of the B loads then waits for the
+    // A loads issued a few cycles earlier -- a full memory latency per slab with the matrix pipe idle
+    // (measured: 15 % of the kernel).  So gather / plain operands are compile-time variants of the
+    // loop (GA, GB), the two (A,B) pairs of the data gradient are selected with scalar selects, and
+    // the last two slabs (nothing left to store / load) are peeled off as compile-time variants too.
+    // kv = valid contraction rows of a slab (>= BK: full slab).
+    auto run = [&](auto GA_, auto GB_) {
+      constexpr bool GA = decltype(GA_)::value, GB = decltype(GB_)::value;
+      auto load_a = [&](int s, float4 (&ra)[NVA], int& kv) {
+        const bool p1 = PAIRS && s >= nslab[0];
+        const int k0 = (p1 ? s - nslab[0] : s) * BK;
+        kv = (p1 ? g.Kc[1] : g.Kc[0]) - k0;
+        const bool tail = kv < BK;
+        if constexpr (GA) {
+#pragma unroll
+          for (int i = 0; i < NVA; ++i) {
+            const int kc = 4 * ((threadIdx.x + GNT * i) & 7);
+            ra[i] = ld4v(gpA[i] + ((tail && kc + 4 > kv) ? -kc : k0));
+          }
+        } else if constexpr (CV == 1 && A_KC) {
+          // the slab is 32 channels of one tap: tap offset in an SGPR, validity = one bit per row
+          const rsrc_t rA = p1 ? rA1 : rA0;
+          const int tap = k0 / g.cv.Cg;                    // uniform; Cg is a multiple of 32
+          const unsigned so = (unsigned)(g.cv.tsoff[tap] + (k0 - tap * g.cv.Cg) * 4);
+#pragma unroll
+          for (int i = 0; i < NVA; ++i) {
+            const bool live = (tapmask[i] >> tap) & 1ull;
+            ra[i] = buf_ld4(rA, live ? voA[0][i] : OOB, so);
+          }
+        } else {
+          const rsrc_t rA = p1 ? rA1 : rA0;
+          const unsigned so = A_KC ? (unsigned)k0 * 4u : (unsigned)(k0 * (p1 ? g.lda[1] : g.lda[0])) * 4u;
+#pragma unroll
+          for (int i = 0; i < NVA; ++i) {
+            const int f = threadIdx.x + GNT * i;
+            const bool dead = tail && (A_KC ? 4 * (f & 7) + 4 > kv : f / RQA >= kv);
+            const unsigned vo = (PAIRS && p1) ? voA[PAIRS ? 1 : 0][i] : voA[0][i];
+            ra[i] = buf_ld4(rA, dead ? OOB : vo, so);
+          }
+        }
+      };
+      auto load_b = [&](int s, float4 (&rb)[NVB], int& kv) {
+        const bool p1 = PAIRS && s >= nslab[0];
+        const int k0 = (p1 ? s - nslab[0] : s) * BK;
+        kv = (p1 ? g.Kc[1] : g.Kc[0]) - k0;
+        const bool tail = kv < BK;
+        if constexpr (GB) {
+#pragma unroll
+          for (int i = 0; i < NVB; ++i) rb[i] = ld4v(gpB[i] + (size_t)kidx[i] * g.ldb[0]);
+#pragma unroll
+          for (int i = 0; i < NVB; ++i)   // indices of the slab after this one (past the end -> 0)
+            kidx[i] = buf_ld1(rIdx, (unsigned)(k0 + BK + (threadIdx.x + GNT * i) / RQB) * 8u, 0u);
+        } else if constexpr (CV == 2 && !B_KC) {
+          // im2col(x)[pixel m = k0 + kk][4 channels of one tap]: pixel decomposed per slab, tap fixed per thread
+#pragma unroll
+          for (int i = 0; i < NVB; ++i) {
+            const int kk = (threadIdx.x + GNT * i) / RQB;
+            const unsigned m = (unsigned)(k0 + kk);
+            const unsigned n = fdiv(m, g.cv.div_rhw), rem = m - n * (unsigned)(g.cv.RH * g.cv.RW);
+            const unsigned ry = fdiv(rem, g.cv.div_rw), rx = rem - ry * (unsigned)g.cv.RW;
+            const int t = coltap[i] < 0 ? 0 : coltap[i];
+            const int y = (int)ry * g.cv.rs + g.cv.roy + g.cv.tdy[t], x = (int)rx * g.cv.rsx + g.cv.rox + g.cv.tdx[t];
+            const bool live = coltap[i] >= 0 && kk < kv && (unsigned)y < (unsigned)g.cv.IH && (unsigned)x < (unsigned)g.cv.IW;
+            const unsigned off = (unsigned)((((int)n * g.cv.IH + y) * g.cv.IW + x) * g.cv.ps + colch[i]) * 4u;
+            rb[i] = buf_ld4(rB0, live ? off : OOB, 0u);
+          }
+        } else {
+          const unsigned so = B_KC ? (unsigned)k0 * 4u : (unsigned)(k0 * (p1 ? g.ldb[1] : g.ldb[0])) * 4u;
+#pragma unroll
+          for (int i = 0; i < NVB; ++i) {
+            const int f = threadIdx.x + GNT * i;
+            const bool dead = tail && (B_KC ? 4 * (f & 7) + 4 > kv : f / RQB >= kv);
+            const bool up = GATED ? ((GNT == 512) ? wave_upper : ((i & 1) != 0)) : p1;
+            const unsigned vo = (PAIRS && p1) ? voB[PAIRS ? 1 : 0][i] : voB[0][i];
+            rb[i] = buf_ld4(up ? rB1 : rB0, dead ? OOB : vo, so);
+          }
+        }
+      };
+      auto store_a = [&](int buf, float4 (&ra)[NVA], int kv) {
+        float* at = As(buf);
+        if (GA && kv < BK) {
+#pragma unroll
+          for (int i = 0; i < NVA; ++i)
+            if (4 * ((threadIdx.x + GNT * i) & 7) + 4 > kv) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+          const int f = threadIdx.x + GNT * i;
+          if (A_KC) *reinterpret_cast<float4*>(at + (f >> 3) * KS + 4 * (f & 7)) = ra[i];
+          else      *reinterpret_cast<float4*>(at + (f / RQA) * RSA + 4 * (f % RQA)) = ra[i];
+        }
+      };
+      auto store_b = [&](int buf, float4 (&rb)[NVB], int kv) {
+        float* bt = Bs(buf);
+        if (GB && kv < BK) {
+#pragma unroll
+          for (int i = 0; i < NVB; ++i)
+            if ((threadIdx.x + GNT * i) / RQB >= kv) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (has_ones) {
+#pragma unroll
+          for (int i = 0; i < NVB; ++i)
+            if (onesB[i]) rb[i] = make_float4((threadIdx.x + GNT * i) / RQB < kv ? 1.f : 0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+          const int f = threadIdx.x + GNT * i;
+          if (B_KC) *reinterpret_cast<float4*>(bt + (f >> 3) * KS + 4 * (f & 7)) = rb[i];
+          else      *reinterpret_cast<float4*>(bt + (f / RQB) * RSB + 4 * (f % RQB)) = rb[i];
+        }
+      };
+
+      float4 ra[NVA], rb[NVB];
+      int kva = 0, kvb = 0;
+      load_a(s_begin, ra, kva);
+      load_b(s_begin, rb, kvb);
+      store_a(0, ra, kva);
+      store_b(0, rb, kvb);
+      if (s_begin + 1 < s_end) { load_a(s_begin + 1, ra, kva); load_b(s_begin + 1, rb, kvb); }
+      __syncthreads();
+      // Schedule of one slab (per wave).  Memory instructions are slotted one by one between the MFMAs
+      // of the same wave: a wave has only MT*NT independent accumulator chains, so after MT*NT MFMAs
+      // it stalls on the dependency anyway and whatever issues in that shadow is free.  The barrier sits
+      // before the last k-group, whose fragments are already in registers, and the first fragments of
+      // the next slab are requested right behind it.
+      Frag<MT, NT> f0, f1;
+      load_frag<A_KC, B_KC, MT, NT, BN_>(f0, As(0), Bs(0), wr, wc, lane, 0);
+#define EVAE_SB __builtin_amdgcn_sched_barrier(0)
+      // ST: the registers hold slab s+1 -> write it to the idle LDS buffer; LD: fetch slab s+2; NX: slab s+1 exists
+      auto slab = [&](int s, auto ST_, auto LD_, auto NX_) {
+        constexpr bool ST = decltype(ST_)::value, LD = decltype(LD_)::value, NX = decltype(NX_)::value;
+        const int cur = (s - s_begin) & 1;
+        EVAE_SB; mma_step<MT, NT>(acc, f0, 0); EVAE_SB;
+        load_frag<A_KC, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 1);
+        if constexpr (ST) store_a(cur ^ 1, ra, kva);
+        EVAE_SB; mma_step<MT, NT>(acc, f0, 1); EVAE_SB;
+        if constexpr (ST) store_b(cur ^ 1, rb, kvb);
+        EVAE_SB; mma_step<MT, NT>(acc, f0, 2); EVAE_SB;
+        if constexpr (LD) load_a(s + 2, ra, kva);
+        EVAE_SB; mma_step<MT, NT>(acc, f0, 3); EVAE_SB;
+        if constexpr (LD) load_b(s + 2, rb, kvb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          EVAE_SB; mma_step<MT, NT>(acc, f1, q); EVAE_SB;
+          if (q < MT + NT) load_frag_part<A_KC, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 2, q);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          EVAE_SB; mma_step<MT, NT>(acc, f0, q); EVAE_SB;
+          if (q < MT + NT) load_frag_part<A_KC, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 3, q);
+        }
+        EVAE_SB;
+        __syncthreads();
+        EVAE_SB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          mma_step<MT, NT>(acc, f1, q); EVAE_SB;
+          if constexpr (NX) {
+            if (q < MT + NT) load_frag_part<A_KC, B_KC, MT, NT, BN_>(f0, As(cur ^ 1), Bs(cur ^ 1), wr, wc, lane, 0, q);
+          }
+          EVAE_SB;
+        }
+      };
+      constexpr std::true_type T{};
+      constexpr std::false_type F{};
+      int s = s_begin;
+      for (; s + 2 < s_end; ++s) slab(s, T, T, T);
+      if (s + 1 < s_end) { slab(s, T, F, T); ++s; }
+      slab(s, F, F, F);
+#undef EVAE_SB
+    };
+    if (s_begin < s_end) {
+      if (gatherA) run(std::true_type{}, std::false_type{});
+      else if (gatherB) run(std::false_type{}, std::true_type{});
+      else run(std::false_type{}, std::false_type{});
+    }
+  } else {
+    typedef TileLoader<BM, A_KC, GNT> LA;
+    typedef TileLoader<BN_, B_KC, GNT> LB;
+    LA la[2];
+    LB lb[2];
+  #pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (p < g.npairs) {
+        la[p].init(g.A[p], g.lda[p], m0, g.M, g.a_rows);
+        if (!GATED) lb[p].init(g.B[p], g.ldb[p], n0, g.N, nullptr);
+      }
+    }
+    // gated B tile: LDS row r -> weight row n0 + (r>>6)*32 + (r&31) of (r&32 ? Bg : B[0])
+    const float* gb_base[LB::NV];
+    bool gb_ok[LB::NV];
+    if (GATED) {
+  #pragma unroll
+      for (int i = 0; i < LB::NV; ++i) {
+        int f = threadIdx.x + GNT * i;
+        int r = f >> 3;
+        int n = n0 + (r >> 6) * 32 + (r & 31);
+        gb_ok[i] = n < g.N;
+        const float* w = (r & 32) ? g.Bg : g.B[0];
+        gb_base[i] = w + (size_t)(gb_ok[i] ? n : 0) * g.ldb[0] + 4 * (f & 7);
+      }
+    }
+
+    auto load_slab = [&](int s, float4 (&ra)[LA::NV], float4 (&rb)[LB::NV], unsigned& ma, unsigned& mb) {
+      const int p = (s < nslab[0]) ? 0 : 1;
+      const int k0 = (p == 0 ? s : s - nslab[0]) * BK;
+      const int kend = g.Kc[p];
+      if (A_KC) ma = la[p].template load_kc<VEC>(ra, k0, kend);
+      else ma = la[p].template load_rc<VEC>(ra, g.A[p], g.lda[p], m0, g.M, k0, kend, nullptr, -1);
+      if (GATED) {
+        mb = 0;
+  #pragma unroll
+        for (int i = 0; i < LB::NV; ++i) {
+          int f = threadIdx.x + GNT * i;
+          int k = k0 + 4 * (f & 7);
+          if (VEC) {
+            const bool ok = gb_ok[i] && (k + 4 <= kend);
+            rb[i] = ld4v(gb_base[i] + (ok ? k0 : -4 * (f & 7)));
+            mb |= (ok ? 1u : 0u) << (2 * i);
+          } else {
+            rb[i] = ld4s(gb_base[i] + k0, gb_ok[i] ? (kend - k) : 0);
+            mb |= 1u << (2 * i);
+          }
+        }
+      } else if (B_KC) {
+        mb = lb[p].template load_kc<VEC>(rb, k0, kend);
+      } else {
+        mb = lb[p].template load_rc<VEC>(rb, g.B[p], g.ldb[p], n0, g.ones_col >= 0 ? g.ones_col : g.N, k0, kend, g.b_krows, g.ones_col);
+      }
+    };
+
+    // Pipeline: registers always hold the slab AFTER the one being multiplied.  Its global loads were
+    // issued a whole slab earlier; they are written to the idle LDS buffer after the first k-group of
+    // MFMAs and the loads of the slab after that are issued right behind, so VMEM latency, the LDS
+    // stores and their address arithmetic all sit in the shadow of the 64-cycle MFMAs.
+    if (s_begin < s_end) {
+      float4 ra[LA::NV], rb[LB::NV];
+      unsigned ma, mb;
+      load_slab(s_begin, ra, rb, ma, mb);
+      la[0].store(As(0), ra, ma);
+      lb[0].store(Bs(0), rb, mb);
+      if (s_begin + 1 < s_end) load_slab(s_begin + 1, ra, rb, ma, mb);
+      __syncthreads();
+      for (int s = s_begin; s < s_end; ++s) {
+        const int cur = (s - s_begin) & 1;
+        Frag<MT, NT> f0, f1;
+        load_frag<A_KC, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 0);
+        load_frag<A_KC, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag<MT, NT>(acc, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag<A_KC, B_KC, MT, NT, BN_>(f0, As(cur), Bs(cur), wr, wc, lane, 2);
+        if (s + 1 < s_end) {
+          la[0].store(As(cur ^ 1), ra, ma);
+          lb[0].store(Bs(cur ^ 1), rb, mb);
+        }
+        if (s + 2 < s_end) load_slab(s + 2, ra, rb, ma, mb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag<MT, NT>(acc, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag<A_KC, B_KC, MT, NT, BN_>(f1, As(cur), Bs(cur), wr, wc, lane, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frag<MT, NT>(acc, f0);
+        mma_frag<MT, NT>(acc, f1);
+        __syncthreads();
+      }
+    }
+
+  }
+
+  if ((g.dbg & 512) && g.out2) {   // clock probe: shader-clock ticks vs the constant 100 MHz counter over this block's main loop
+    const long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 5) {
+      float* d = g.out2 + (size_t)(g.M - 1) * g.ldo;   // last row of the save_s output (overwritten, debug only)
+      atomicAdd(d + 0, (float)(c1 - dbg_c0));
+      atomicAdd(d + 1, (float)(w1 - dbg_w0));
+      atomicAdd(d + 2, 1.0f);
+    }
+    return;
+  }
+  if (g.dbg & 4) {           // ablation: no epilogue (the accumulators stay live through an impossible store)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 1.2345e-30f) g.out0[0] = t;
+    return;
+  }
+  // ---- epilogue.  acc[mt][nt][r] <-> row m0 + wr*32*MT + mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
+  //                                    col (within the wave tile) nt*32 + (lane&31)
+  const int l31 = lane & 31, lh = lane >> 5;
+  // output row of GEMM row m (identity unless this is the data gradient of a strided convolution)
+  auto orow = [&](int m) -> size_t {
+    if (CV == 1 && g.cv.remap) {
+      const unsigned nn = fdiv((unsigned)m, g.cv.div_rhw), rem = (unsigned)m - nn * (unsigned)(g.cv.RH * g.cv.RW);
+      const unsigned ry = fdiv(rem, g.cv.div_rw), rx = rem - ry * (unsigned)g.cv.RW;
+      return ((size_t)nn * g.cv.OH2 + ry * g.cv.os + g.cv.ooy) * g.cv.OW2 + rx * g.cv.osx + g.cv.oox;
+    }
+    return (size_t)m;
+  };
+  if (GATED) {
+    const int n = n0 + wc * 32 + l31;
+    if (n < g.N) {
+      const float bh = (EPI == EPI_GATED && g.bias0) ? g.bias0[n] : 0.f;
+      const float bg = (EPI == EPI_GATED && g.bias1) ? g.bias1[n] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < g.M) {
+            if (EPI == EPI_GATED) {
+              const float h = acc[mt][0][r] + bh;
+              // sigmoid on the hardware exp2 / rcp (about 1e-7 relative): the precise expf costs ~15 VALU instructions
+              // per element, and VALU issue is what the co-resident block's MFMAs wait on
+              const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc[mt][NT - 1][r] + bg)));
+              const size_t o = orow(m) * g.ldo + n;
+              g.out0[o] = h * s;
+              if (g.out1) g.out1[o] = h;
+              if (g.out2) g.out2[o] = s;
+            } else {   // EPI_RAW_GATED: partial planes [z][2][M][N]
+              const size_t plane = (size_t)g.M * g.N;
+              const size_t o = (size_t)blockIdx.z * 2 * plane + (size_t)m * g.N + n;
+              g.out0[o] = acc[mt][0][r];
+              g.out0[o + plane] = acc[mt][NT - 1][r];
+            }
+          }
+        }
+    }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      if (n >= g.N) continue;
+      const float bias = (EPI == EPI_LINEAR && g.bias0) ? g.bias0[n] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m >= g.M) continue;
+          const size_t o = orow(m) * g.ldo + n;
+          const float v = acc[mt][nt][r];
+          if (EPI == EPI_LINEAR) {
+            const float pre = v + bias;
+            if (g.out1) g.out1[o] = pre;
+            g.out0[o] = apply_act(pre, g.act, g.lo, g.hi);
+          } else if (EPI == EPI_GATE_BWD) {
+            const size_t oe = (size_t)m * g.N + n;   // h/s of the layer below are dense [M x N]
+            const float go = g.e0[oe], s = g.e1[oe];   // gated output h*s and gate s of the layer below
+            g.out0[o] = v * s;                   // dh
+            g.out1[o] = v * go * (1.0f - s);     // dg = v * h * s * (1 - s)
+          } else {                                // EPI_RAW: partial plane [z][M][N]
+            g.out0[(size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n] = v;
+          }
+        }
+    }
+  }
+}
+
+// ---- host side: plan, launch --------------------------------------------------------------------------
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <bool A_KC, bool B_KC>
+static bool gemm_vec_ok(const GemmArgs& g) {
+  bool ok = true;
+  for (int p = 0; p < g.npairs; ++p) {
+    ok = ok && al16(g.A[p]) && al16(g.B[p]) && (g.lda[p] % 4 == 0) && (g.ldb[p] % 4 == 0);
+    if (A_KC || B_KC) ok = ok && (g.Kc[p] % 4 == 0);
+  }
+  if (!A_KC) ok = ok && (g.M % 4 == 0);
+  if (!B_KC) ok = ok && ((g.ones_col >= 0 ? g.ones_col : g.N) % 4 == 0);
+  if (g.Bg) ok = ok && al16(g.Bg);
+  // buffer-load offsets of the fast path are 31-bit byte offsets (gathered operands use 64-bit pointers)
+  const int64_t lim = (int64_t)1 << 29;   // floats
+  const int Bn = (!B_KC && g.ones_col >= 0) ? g.ones_col : g.N;
+  for (int p = 0; p < g.npairs; ++p) {
+    const int64_t ea = A_KC ? (int64_t)g.M * g.lda[p] + g.Kc[p] : (int64_t)g.Kc[p] * g.lda[p] + g.M;
+    const int64_t eb = B_KC ? (int64_t)g.N * g.ldb[p] + g.Kc[p] : (int64_t)g.Kc[p] * g.ldb[p] + Bn;
+    if (!(A_KC && g.a_rows)) ok = ok && ea + BK * (int64_t)g.lda[p] < lim;
+    if (!(!B_KC && g.b_krows)) ok = ok && eb + BK * (int64_t)g.ldb[p] < lim;
+  }
+  return ok;
+}
+
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW, int CV = 0>
+static int launch_gemm_w(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
+  static bool attr = false;
+  constexpr size_t lds = gemm_lds_bytes(BN_);
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KC, B_KC, EPI, VEC, BN_, NW, CV>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
+  g.tiles_m = cdiv(g.M, BM);
+  g.tiles_n = cdiv(g.N, GATED ? 64 : BN_);
+  dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("EVAE_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    g.dbg = dbg;
+  }
+  gemm_kernel<A_KC, B_KC, EPI, VEC, BN_, NW, CV><<<grid, 64 * NW, lds, stream>>>(g);
+  return check_launch(what);
+}
+
+// waves per block: 8 (4 waves/SIMD at 2 blocks/CU, the default) or 4; EVAE_GEMM_NW=4 selects the latter
+static int gemm_nw() {
+  static int nw = 0;
+  if (nw == 0) {
+    const char* e = getenv("EVAE_GEMM_NW");
+    nw = (e && atoi(e) == 4) ? 4 : 8;
+  }
+  return nw;
+}
+
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_>
+static int launch_gemm_v(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
+  if (gemm_nw() == 4) return launch_gemm_w<A_KC, B_KC, EPI, VEC, BN_, 4>(g, nz, stream, what);
+  return launch_gemm_w<A_KC, B_KC, EPI, VEC, BN_, 8>(g, nz, stream, what);
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+static int launch_gemm(GemmArgs& g, const Plan& pl, hipStream_t stream, const char* what) {
+  constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
+  const bool vec = gemm_vec_ok<A_KC, B_KC>(g);
+  g.ksplit = pl.nz > 1 ? pl.ksplit : 0;
+  if (GATED || pl.bn == 128) {
+    if (vec) return launch_gemm_v<A_KC, B_KC, EPI, true, 128>(g, pl.nz, stream, what);
+    return launch_gemm_v<A_KC, B_KC, EPI, false, 128>(g, pl.nz, stream, what);
+  }
+  if constexpr (!GATED) {
+    if (vec) return launch_gemm_v<A_KC, B_KC, EPI, true, 64>(g, pl.nz, stream, what);
+    return launch_gemm_v<A_KC, B_KC, EPI, false, 64>(g, pl.nz, stream, what);
+  }
+  return EVAE_EINVAL;
+}
+
+static int total_slabs(int k0, int k1) { return cdiv(k0, BK) + (k1 > 0 ? cdiv(k1, BK) : 0); }
+
+}  // namespace evae

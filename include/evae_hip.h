@@ -129,7 +129,7 @@ int evae_topk_merge(const float* val /* [R x B x k] */, const int64_t* idx, int 
  * evae_dense_bwd_weight: dW = dy^T x (rows-gathered x allowed), db = column sums of dy.
  * Thin problems (the 100-row batch path, the small weight-gradient outputs) are split along the
  * contraction into `ws` partials and finished by a second kernel in a fixed order (deterministic);
- * the split is chosen by a wave-quantisation model of the 256-CU chip, see csrc/evae_dense.hip.
+ * the split is chosen by a wave-quantisation model of the 256-CU chip, see csrc/evae_gemm_core.h (make_plan).
  */
 #define EVAE_ACT_NONE 0
 #define EVAE_ACT_SIGMOID 1
