@@ -13,7 +13,10 @@ constexpr int BM = 128, BK = 32;
 constexpr int KS = BK + 4;  // KC tile row stride (floats); 36/4 = 9 odd
 
 
-enum { EPI_LINEAR = 0, EPI_GATED = 1, EPI_GATE_BWD = 2, EPI_RAW = 3, EPI_RAW_GATED = 4 };
+enum { EPI_LINEAR = 0, EPI_GATED = 1, EPI_GATE_BWD = 2, EPI_RAW = 3, EPI_RAW_GATED = 4,
+       // squared distances |a_m|^2 + |b_n|^2 - 2 a_m.b_n from the dot products (top-K screening, evae_topk_screen.hip):
+       EPI_DIST_TILEMIN = 5,   // out0[tile_m][n] = min over the tile's rows
+       EPI_DIST_COLLECT = 6 }; // rows with distance <= bias0[n] are appended to the candidate list of column n
 
 
 // one K-slab of MFMAs: wave tile 64 x (32 NT) at rows wr*64.., cols wc*32*NT..

@@ -77,6 +77,8 @@ struct GemmArgs {
   int ones_col;            // RC B: virtual all-ones column index (bias gradient folded into the weight GEMM); -1 = none
   int dbg;                 // EVAE_GEMM_DBG (tools/gemm_ablate.py): 4 = skip the epilogue, 512 = clock probe; 0 in production
   ConvMap cv;              // used by the CV != 0 instances only
+  int* aux_cnt;            // EPI_DIST_COLLECT: per-column candidate counters
+  int* aux_cand;           //                   candidate rows, [column][ldo]
 };
 
 // Out-of-range chunks are loaded from a clamped, always-mapped address and zeroed LATER, when the
@@ -636,7 +638,45 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
     }
     return (size_t)m;
   };
-  if (GATED) {
+  if constexpr (EPI == EPI_DIST_TILEMIN || EPI == EPI_DIST_COLLECT) {
+    // e0 = squared norms of the A rows, e1 = of the B rows; acc = dot products
+    float tmin[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      const bool nok = n < g.N;
+      const float bn = nok ? g.e1[n] : 0.f;
+      const float thr = (EPI == EPI_DIST_COLLECT && nok) ? g.bias0[n] : -INFINITY;
+      tmin[nt] = INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < g.M) {
+            const float d = g.e0[m] + bn - 2.0f * acc[mt][nt][r];
+            if (EPI == EPI_DIST_TILEMIN) tmin[nt] = fminf(tmin[nt], d);
+            else if (nok && d <= thr) g.aux_cand[(size_t)n * g.ldo + atomicAdd(&g.aux_cnt[n], 1)] = m;
+          }
+        }
+    }
+    if (EPI == EPI_DIST_TILEMIN) {
+      // lanes l / l+32 hold the same column; then the NW/2 wave rows through LDS (free after the last barrier)
+      float* red = smem;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        tmin[nt] = fminf(tmin[nt], __shfl_xor(tmin[nt], 32, 64));
+        if (lh == 0) red[wr * BN_ + wc * 32 * NT + nt * 32 + l31] = tmin[nt];
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < BN_ && n0 + (int)threadIdx.x < g.N) {
+        float v = red[threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < NW / 2; ++w) v = fminf(v, red[w * BN_ + threadIdx.x]);
+        g.out0[(size_t)tm * g.ldo + n0 + threadIdx.x] = v;
+      }
+    }
+  } else if (GATED) {
     const int n = n0 + wc * 32 + l31;
     if (n < g.N) {
       const float bh = (EPI == EPI_GATED && g.bias0) ? g.bias0[n] : 0.f;

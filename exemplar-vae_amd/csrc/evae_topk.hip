@@ -13,6 +13,7 @@
 // split of the cache; per-split lists are merged by the same insertion code in a second kernel, which
 // is also the cross-shard (all-gathered) merge.
 #include "evae_tile.h"
+#include "evae_topk_screen.h"
 
 namespace evae {
 
@@ -309,7 +310,9 @@ extern "C" size_t evae_pairdist_topk_workspace_bytes(int B, int N, int zdim, int
   int ns, tps, nq;
   topk_splits(B, N, &ns, &tps, &nq);
   size_t n = (size_t)ns * B * k;
-  return align_up(n * sizeof(float), 256) + align_up(n * sizeof(int64_t), 256) + 256;
+  const size_t scan = align_up(n * sizeof(float), 256) + align_up(n * sizeof(int64_t), 256) + 256;
+  const size_t screen = topk_screen_workspace_bytes(B, N, zdim, k);      // 0 when the screening path does not apply
+  return scan > screen ? scan : screen;
 }
 
 extern "C" int evae_pairdist_topk(const float* q, int B, const float* cache, int N, int zdim, int k,
@@ -326,6 +329,11 @@ extern "C" int evae_pairdist_topk(const float* q, int B, const float* cache, int
   if (ws == nullptr || ws_bytes < evae_pairdist_topk_workspace_bytes(B, N, zdim, k)) {
     set_error("pairdist_topk: workspace too small (%zu)", ws_bytes);
     return EVAE_EWORKSPACE;
+  }
+  {   // large caches: fp32 matrix-core screening + exact re-ranking of the survivors (evae_topk_screen.hip)
+    int handled = 0;
+    int rc = topk_screen(q, B, cache, N, zdim, k, flags, index_base, out_idx, out_val, ws, ws_bytes, stream, &handled);
+    if (rc || handled) return rc;
   }
   int ns, tps, nq;
   topk_splits(B, N, &ns, &tps, &nq);

@@ -1,0 +1,194 @@
+// Top-K by screening: the all-pairs distances are a GEMM (cache rows x queries on the fp32 matrix cores, the kernel of
+// evae_gemm_kernel.h with a distance epilogue), but only to FIND the few exemplars that can be among the k nearest;
+// those are then re-evaluated exactly -- fp64 direct differences rounded once to fp32, the arithmetic of the scan
+// kernel in evae_topk.hip -- and ordered by (value, index).  Indices and values are bit-identical to the scan kernel
+// (and to the reference's fp64 distance + topk) because the candidate set provably contains the true top-k:
+//   1. squared norms of all rows (fp32) and the largest exemplar norm;
+//   2. GEMM pass 1: per query the minimum approximate distance of every 128-exemplar tile.  The k-th smallest tile
+//      minimum T is an upper bound of the k-th smallest approximate distance (k tiles hold one element <= T each);
+//   3. with E = gamma (|q|^2 + max|c|^2) bounding the fp32 error of one approximate distance, every true top-k member
+//      has approximate distance <= T + 2E: GEMM pass 2 appends exactly those rows to the query's candidate list;
+//   4. exact distances of the candidates, k rounds of (value, index) arg-min.
+// Cost: two passes over the [N x z] cache at GEMM speed instead of one at fp64-VALU speed (c5: 1.6 ms -> see DESIGN).
+#include "evae_gemm_kernel.h"
+#include "evae_topk_screen.h"
+
+namespace evae {
+
+// |row|^2 in fp32; rows of the cache also feed the global maximum (positive floats order like their bit patterns)
+__global__ void sq_norms_kernel(const float* __restrict__ x, int rows, int zdim, float* __restrict__ out,
+                                unsigned* __restrict__ max_bits) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  float wmax = 0.f;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {   // one wave per row
+    float s = 0.f;
+    for (int k = lane; k < zdim; k += 64) { const float v = x[(size_t)row * zdim + k]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+    wmax = fmaxf(wmax, s);
+  }
+  if (max_bits && lane == 0) atomicMax(max_bits, __float_as_uint(wmax));   // one atomic per wave, not per row
+}
+
+// thr[n] = (k-th smallest of tmin[:, n]) + 2 gamma (qn[n] + cnmax); one wave per query
+__global__ void kth_threshold_kernel(const float* __restrict__ tmin, int ntiles, int ldt, int B, int k,
+                                     const float* __restrict__ qn, const unsigned* __restrict__ cnmax_bits, float gamma,
+                                     float* __restrict__ thr) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= B) return;
+  // step through the (value, tile) pairs in ascending order k times
+  float lastv = -INFINITY;
+  int lastt = -1;
+  for (int j = 0; j < k; ++j) {
+    float bv = INFINITY;
+    int bt = INT_MAX;
+    for (int t = lane; t < ntiles; t += 64) {
+      const float v = tmin[(size_t)t * ldt + n];
+      const bool after = (v > lastv) || (v == lastv && t > lastt);
+      if (after && ((v < bv) || (v == bv && t < bt))) { bv = v; bt = t; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int ot = __shfl_xor(bt, o, 64);
+      if ((ov < bv) || (ov == bv && ot < bt)) { bv = ov; bt = ot; }
+    }
+    lastv = bv; lastt = bt;
+  }
+  if (lane == 0) thr[n] = lastv + 2.0f * gamma * (qn[n] + __uint_as_float(*cnmax_bits));
+}
+
+// exact re-ranking of one query's candidates: block = 256 threads
+__global__ __launch_bounds__(256) void topk_exact_kernel(const float* __restrict__ q, const float* __restrict__ cache,
+                                                         int zdim, int k, unsigned flags, int64_t index_base,
+                                                         const int* __restrict__ cnt, const int* __restrict__ cand,
+                                                         float* __restrict__ val, size_t ldc,
+                                                         int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int n = blockIdx.x;
+  const int M = cnt[n];
+  const int* cl = cand + (size_t)n * ldc;
+  float* vl = val + (size_t)n * ldc;
+  const float* qr = q + (size_t)n * zdim;
+  const bool do_sqrt = (flags & EVAE_TOPK_SQRT) != 0;
+  for (int c = threadIdx.x; c < M; c += 256) {
+    const float* cr = cache + (size_t)cl[c] * zdim;
+    double a = 0.0;
+    for (int d = 0; d < zdim; ++d) {       // same order and operations as dist_chunk_f64 (evae_topk.hip)
+      const double df = (double)qr[d] - (double)cr[d];
+      a = fma(df, df, a);
+    }
+    float v = (float)a;
+    if (do_sqrt) v = sqrtf(v);
+    vl[c] = v;
+  }
+  __syncthreads();
+  float lastv = -INFINITY;
+  int lasti = -1;
+  for (int j = 0; j < k; ++j) {
+    float bv = INFINITY;
+    int bi = INT_MAX;
+    for (int c = threadIdx.x; c < M; c += 256) {
+      const float v = vl[c];
+      const int id = cl[c];
+      const bool after = (v > lastv) || (v == lastv && id > lasti);
+      if (after && ((v < bv) || (v == bv && id < bi))) { bv = v; bi = id; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if ((ov < bv) || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    bv = sv[0]; bi = si[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if ((sv[w] < bv) || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+    __syncthreads();
+    lastv = bv; lasti = bi;
+    if (threadIdx.x == 0) {
+      out_idx[(size_t)n * k + j] = (bi == INT_MAX) ? (int64_t)-1 : (int64_t)bi + index_base;
+      if (out_val) out_val[(size_t)n * k + j] = bv;
+    }
+  }
+}
+
+__global__ void zero_ints_kernel(int* p, int n, unsigned* q) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+  if (i == 0 && q) *q = 0u;
+}
+
+struct ScreenLayout {
+  size_t cn, qn, cnmax, tmin, thr, cnt, cand, val, total;
+  int ntiles, ldt;
+};
+static bool screen_applies(int B, int N, int zdim, int k) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("EVAE_TOPK_EXACT_SCAN"); off = (e && atoi(e)) ? 1 : 0; }
+  if (off) return false;
+  const int ntiles = cdiv(N, BM);
+  return N >= 2048 && ntiles >= k && (zdim & 3) == 0 && (int64_t)B * N <= ((int64_t)1 << 26) &&
+         (int64_t)N * zdim < ((int64_t)1 << 29) - (1 << 22) && (int64_t)B * zdim < ((int64_t)1 << 29) - (1 << 22);
+}
+static ScreenLayout screen_layout(int B, int N) {
+  ScreenLayout L;
+  L.ntiles = cdiv(N, BM);
+  L.ldt = (B + 63) / 64 * 64;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
+  L.cn = take((size_t)N * 4); L.qn = take((size_t)L.ldt * 4); L.cnmax = take(256);
+  L.tmin = take((size_t)L.ntiles * L.ldt * 4); L.thr = take((size_t)L.ldt * 4); L.cnt = take((size_t)L.ldt * 4);
+  L.cand = take((size_t)B * N * 4); L.val = take((size_t)B * N * 4);
+  L.total = o + 256;
+  return L;
+}
+
+size_t topk_screen_workspace_bytes(int B, int N, int zdim, int k) {
+  if (!screen_applies(B, N, zdim, k)) return 0;
+  return screen_layout(B, N).total;
+}
+
+int topk_screen(const float* q, int B, const float* cache, int N, int zdim, int k, unsigned flags, int64_t index_base,
+                int64_t* out_idx, float* out_val, void* ws, size_t ws_bytes, hipStream_t stream, int* handled) {
+  *handled = 0;
+  if (!screen_applies(B, N, zdim, k) || (((uintptr_t)q | (uintptr_t)cache) & 15) != 0) return EVAE_OK;
+  const ScreenLayout L = screen_layout(B, N);
+  if (ws == nullptr || ws_bytes < L.total) return EVAE_OK;
+  *handled = 1;
+  char* w = (char*)ws;
+  float* cn = (float*)(w + L.cn); float* qn = (float*)(w + L.qn); unsigned* cnmax = (unsigned*)(w + L.cnmax);
+  float* tmin = (float*)(w + L.tmin); float* thr = (float*)(w + L.thr); int* cnt = (int*)(w + L.cnt);
+  int* cand = (int*)(w + L.cand); float* val = (float*)(w + L.val);
+  zero_ints_kernel<<<cdiv(L.ldt, 256), 256, 0, stream>>>(cnt, L.ldt, cnmax);
+  sq_norms_kernel<<<std::min(cdiv(N, 4), 2048), 256, 0, stream>>>(cache, N, zdim, cn, cnmax);
+  sq_norms_kernel<<<std::min(cdiv(B, 4), 2048), 256, 0, stream>>>(q, B, zdim, qn, nullptr);
+  int rc = check_launch("sq_norms_kernel");
+  if (rc) return rc;
+  GemmArgs g = {};
+  g.ones_col = -1;
+  g.A[0] = cache; g.B[0] = q; g.lda[0] = zdim; g.ldb[0] = zdim; g.Kc[0] = zdim; g.npairs = 1;
+  g.M = N; g.N = B; g.e0 = cn; g.e1 = qn; g.ksplit = 0;
+  g.out0 = tmin; g.ldo = L.ldt;
+  if (B <= 64) rc = launch_gemm_w<true, true, EPI_DIST_TILEMIN, true, 64, 8>(g, 1, stream, "topk_screen(tile minima)");
+  else rc = launch_gemm_w<true, true, EPI_DIST_TILEMIN, true, 128, 8>(g, 1, stream, "topk_screen(tile minima)");
+  if (rc) return rc;
+  // error bound of one approximate distance: (2K + 3) roundings of magnitude <= u (|q|^2 + |c|^2), u = 2^-24, doubled
+  const float gamma = 2.0f * (2.0f * zdim + 3.0f) * 5.9604645e-08f;
+  kth_threshold_kernel<<<cdiv(B, 4), 256, 0, stream>>>(tmin, L.ntiles, L.ldt, B, k, qn, cnmax, gamma, thr);
+  rc = check_launch("kth_threshold_kernel");
+  if (rc) return rc;
+  g.bias0 = thr; g.aux_cnt = cnt; g.aux_cand = cand; g.out0 = nullptr; g.ldo = N;
+  if (B <= 64) rc = launch_gemm_w<true, true, EPI_DIST_COLLECT, true, 64, 8>(g, 1, stream, "topk_screen(collect)");
+  else rc = launch_gemm_w<true, true, EPI_DIST_COLLECT, true, 128, 8>(g, 1, stream, "topk_screen(collect)");
+  if (rc) return rc;
+  topk_exact_kernel<<<B, 256, 0, stream>>>(q, cache, zdim, k, flags, index_base, cnt, cand, val, (size_t)N, out_idx, out_val);
+  return check_launch("topk_exact_kernel");
+}
+
+}  // namespace evae

@@ -1,5 +1,7 @@
 """GPU parity tests of the raw C-ABI entry points (through evae.ops) against the oracle.
 Run on a real MI355X:  python -m pytest tests -m gpu"""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -8,6 +10,7 @@ import evae_oracle as orc
 import golden_inputs as gi
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def dev(a, dtype=None):
@@ -150,6 +153,30 @@ def test_topk_small_and_ragged(ops, B, N, zd, k):
     ov, oi = orc.topk_smallest(orc.pairdist_direct_f64(z, c), k)
     assert np.array_equal(idx.cpu().numpy(), oi)
     assert np.array_equal(val.cpu().numpy(), ov)
+
+
+@pytest.mark.parametrize("B,N,zd,k,sqrt", [(64, 100000, 256, 10, False), (100, 25000, 40, 10, False), (37, 5000, 24, 64, True),
+                                          (130, 4099, 40, 7, False), (3, 2048, 8, 16, False)])
+def test_topk_screening_path_equals_exact_scan(ops, B, N, zd, k, sqrt):
+    """Large caches take the matrix-core screening + exact re-ranking path; it must return the very same indices and
+    values as the exact fp64 scan kernel (forced with EVAE_TOPK_EXACT_SCAN=1 in a child process), including on
+    duplicated exemplars (ties broken by index) and clustered data."""
+    import subprocess, sys, tempfile
+    z, c = gi.clustered_latents(300 + B + N, B, N, zd)
+    c[N // 2:N // 2 + 50] = c[:50]                    # exact duplicates -> ties
+    c[-7:] = z[:7] if B >= 7 else c[-7:]              # zero-distance hits at the very end of the cache
+    idx, val = ops.pairdist_topk(dev(z), dev(c), k, sqrt=sqrt)
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "z.npy"), z); np.save(os.path.join(td, "c.npy"), c)
+        code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from evae import ops;"
+                "z=torch.from_numpy(np.load(%r)).cuda(); c=torch.from_numpy(np.load(%r)).cuda();"
+                "i,v=ops.pairdist_topk(z,c,%d,sqrt=%r); np.save(%r,i.cpu().numpy()); np.save(%r,v.cpu().numpy())"
+                % (os.path.join(ROOT, "exemplar-vae_amd"), os.path.join(td, "z.npy"), os.path.join(td, "c.npy"), k, sqrt,
+                   os.path.join(td, "i.npy"), os.path.join(td, "v.npy")))
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, EVAE_TOPK_EXACT_SCAN="1"))
+        ri, rv = np.load(os.path.join(td, "i.npy")), np.load(os.path.join(td, "v.npy"))
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert np.array_equal(val.cpu().numpy(), rv)
 
 
 def test_pairwise_distance_golden(ops, golden):
