@@ -195,7 +195,7 @@ extern "C" int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, con
   cl_out_dims(d, &OH, &OW);
   if (cl_patch_mode(d)) {
     const int taps = d->KH * d->KW, Kp = cl_patch_kp(d);
-    const int per = cl_patch_images(d, OH, OW, d->Co);
+    const int per = cl_patch_images(d, OH, OW, evae_conv2d_cl_dy_stride(d->Co * (gated ? 2 : 1)));   // as sized in the workspace query
     float* P = (float*)ws;
     const size_t pbytes = align_up((size_t)per * OH * OW * Kp * sizeof(float), 256);
     float* wph = (float*)((char*)ws + pbytes);

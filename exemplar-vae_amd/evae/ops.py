@@ -3,6 +3,7 @@ torch.autograd.Function wrappers the reference-named modules (utils/nn.py, utils
 models/BaseModel.py) are built from.  PyTorch here is device memory, streams and autograd plumbing;
 all arithmetic on [rows x features] data happens in libevae_hip.so.  No CPU fallback."""
 import ctypes as C
+import os
 
 import torch
 
@@ -387,6 +388,8 @@ class Conv2dFn(torch.autograd.Function):
         s = torch.empty((d.N, d.Co, OH, OW), **fmt) if (gated and need_grad) else None   # out and s suffice for the backward
         pre = torch.empty((d.N, d.Co, OH, OW), **fmt) if (not gated and need_grad and act == ACT_HARDTANH) else None
         if cl:
+            if os.environ.get("EVAE_CONV_TRACE"):
+                print("conv_cl_fwd N=%d C=%d H=%d W=%d Co=%d k=%d s=%d p=%d gated=%d grad=%d" % (d.N, d.C, d.H, d.W, d.Co, d.KH, d.stride, d.pad, gated, need_grad), flush=True)
             nb = lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 0, int(gated))
             ws = _workspace("conv", nb, x.device)
             _lib.check(lib.evae_conv2d_cl_fwd(_p(x), C.byref(d), _p(wh), _p(bh), _p(wg), _p(bg), act, float(lo), float(hi),

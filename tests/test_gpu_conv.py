@@ -94,3 +94,22 @@ def test_conv2d_channels_last_multi_pass(case, monkeypatch):
         res.append([y.detach()] + [a.grad for a in t])
     for a, b in zip(*res):
         assert rel(a, b) < 2e-6
+
+
+def test_conv2d_patch_matrix_layer_many_images():
+    """First layer of models/fully_conv.py at cache_z scale (3 -> 48 channels, 64x64, stride 2, thousands of images):
+    the patch matrix is built in passes whose size must agree between the workspace query and the launch
+    (regression: a pass larger than the workspace faulted).  Reference: torch's own GPU convolution."""
+    from evae import ops
+    torch.manual_seed(0)
+    N = 4600
+    x = torch.rand(N, 3, 64, 64, device="cuda")
+    w = (torch.randn(48, 3, 3, 3, device="cuda") / 5).requires_grad_(True)
+    b = torch.randn(48, device="cuda").requires_grad_(True)
+    y = ops.conv2d(x, w, b, 2, 1)
+    g = torch.randn_like(y)
+    y.backward(g)
+    wr = w.detach().clone().requires_grad_(True); br = b.detach().clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, br, 2, 1)
+    yr.backward(g)
+    assert rel(y, yr) < 1e-5 and rel(w.grad, wr.grad) < 2e-5 and rel(b.grad, br.grad) < 2e-5
