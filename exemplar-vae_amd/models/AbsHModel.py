@@ -1,70 +1,77 @@
-"""Two-level hierarchical VAE base (reference models/AbsHModel.py:8-107): exemplar prior on z2,
-Gaussian p(z1|z2)."""
+"""Two-latent-layer VAE (z2 under the exemplar prior, z1 | z2 Gaussian): composition of the sub-networks a concrete
+model declares (models.HVAE_2level, models.convHVAE_2level).  Behavioural contract: reference
+models/AbsHModel.py:8-107 -- method names, argument order, the 8-tuple of latent statistics and the flat
+[B x D] decoder outputs are what models.BaseModel and utils.evaluation rely on."""
 import numpy as np
 import torch
 
 from models.BaseModel import BaseModel
 from utils.distributions import log_normal_diag
 
+_CLAMP_LO, _CLAMP_HI = 1.0 / 512.0, 1.0 - 1.0 / 512.0
+
 
 class BaseHModel(BaseModel):
     def __init__(self, args):
         super().__init__(args)
 
-    def kl_loss(self, latent_stats, exemplars_embedding, dataset, cache, x_indices):
-        z1_q, z1_q_mean, z1_q_logvar, z2_q, z2_q_mean, z2_q_logvar, z1_p_mean, z1_p_logvar = latent_stats
-        if exemplars_embedding is None and self.args.prior == 'exemplar_prior':
-            exemplars_embedding = self.get_exemplar_set(z2_q_mean, z2_q_logvar, dataset, cache, x_indices)
-        z1s, z2s = self.args.z1_size, self.args.z2_size
-        log_p_z1 = log_normal_diag(z1_q.view(-1, z1s), z1_p_mean.view(-1, z1s), z1_p_logvar.view(-1, z1s), dim=1)
-        log_q_z1 = log_normal_diag(z1_q.view(-1, z1s), z1_q_mean.view(-1, z1s), z1_q_logvar.view(-1, z1s), dim=1)
-        log_p_z2 = self.log_p_z(z=(z2_q, x_indices), exemplars_embedding=exemplars_embedding)
-        log_q_z2 = log_normal_diag(z2_q.view(-1, z2s), z2_q_mean.view(-1, z2s), z2_q_logvar.view(-1, z2s), dim=1)
-        return -(log_p_z1 + log_p_z2 - log_q_z1 - log_q_z2)
+    def _is_conv_hvae(self):
+        return 'convhvae_2level' in self.args.model_name
 
-    def generate_x_from_z(self, z, with_reparameterize=True):
-        z1_mean, z1_logvar = self.p_z1(z)
-        z1 = self.reparameterize(z1_mean, z1_logvar) if with_reparameterize else z1_mean
-        xs, _ = self.p_x(z1.view(-1, self.args.z1_size), z.view(-1, self.args.z2_size))
-        return xs
-
+    # ---- conditionals ----------------------------------------------------------------------------------------------
     def p_z1(self, z2):
-        h = self.p_z1_layers_z2(z2)
-        return self.p_z1_mean(h), self.p_z1_logvar(h)
+        """p(z1 | z2): mean, log-variance"""
+        trunk = self.p_z1_layers_z2(z2)
+        return self.p_z1_mean(trunk), self.p_z1_logvar(trunk)
 
     def q_z1(self, x, z2):
-        hx = self.q_z1_layers_x(x)
+        """q(z1 | x, z2): the image branch and the z2 branch are concatenated before the joint layer"""
+        img = self.q_z1_layers_x(x)
         if self.args.model_name == 'convhvae_2level':
-            hx = hx.reshape(hx.size(0), -1)      # conv outputs may be channels-last tensors: reshape keeps the logical (c, y, x) order
-        hz = self.q_z1_layers_z2(z2)
-        h = self.q_z1_layers_joint(torch.cat((hx, hz), 1))
-        return self.q_z1_mean(h), self.q_z1_logvar(h)
+            img = img.reshape(img.size(0), -1)   # conv features may be channels-last tensors: reshape keeps (c, y, x) order
+        joint = self.q_z1_layers_joint(torch.cat((img, self.q_z1_layers_z2(z2)), dim=1))
+        return self.q_z1_mean(joint), self.q_z1_logvar(joint)
 
     def p_x(self, z1, z2, x=None):
-        h = torch.cat((self.p_x_layers_z1(z1), self.p_x_layers_z2(z2)), 1)
-        conv = 'convhvae_2level' in self.args.model_name
-        if conv:
-            h = self.p_x_layers_joint_pre(h)
-            h = h.view(-1, self.args.input_size[0], self.args.input_size[1], self.args.input_size[2])
-        h_decoder = self.p_x_layers_joint(h)
-        x_mean = self.p_x_mean(h_decoder)
-        d_in = int(np.prod(self.args.input_size))
-        if conv:
-            x_mean = x_mean.reshape(-1, d_in)
+        """p(x | z1, z2) -> (mean, log-variance); log-variance is the scalar 0 for binary data"""
+        feat = torch.cat((self.p_x_layers_z1(z1), self.p_x_layers_z2(z2)), dim=1)
+        conv, D = self._is_conv_hvae(), int(np.prod(self.args.input_size))
+        if conv:                                   # dense pre-layer -> image -> gated conv stack
+            c, hh, ww = self.args.input_size
+            feat = self.p_x_layers_joint_pre(feat).view(-1, c, hh, ww)
+        top = self.p_x_layers_joint(feat)
+        flat = (lambda t: t.reshape(-1, D)) if conv else (lambda t: t)
+        mean = flat(self.p_x_mean(top))
         if self.args.input_type == 'binary':
-            x_logvar = 0.
-        else:
-            x_mean = torch.clamp(x_mean, min=0. + 1. / 512., max=1. - 1. / 512.)
-            x_logvar = self.p_x_logvar(h_decoder)
-            if conv:
-                x_logvar = x_logvar.reshape(-1, d_in)
-        return x_mean, x_logvar
+            return mean, 0.
+        return mean.clamp(min=_CLAMP_LO, max=_CLAMP_HI), flat(self.p_x_logvar(top))
+
+    def generate_x_from_z(self, z, with_reparameterize=True):
+        mu1, lv1 = self.p_z1(z)
+        z1 = self.reparameterize(mu1, lv1) if with_reparameterize else mu1
+        return self.p_x(z1.view(-1, self.args.z1_size), z.view(-1, self.args.z2_size))[0]
+
+    # ---- objective -------------------------------------------------------------------------------------------------
+    def kl_loss(self, latent_stats, exemplars_embedding, dataset, cache, x_indices):
+        """[log q(z1|x,z2) - log p(z1|z2)] + [log q(z2|x) - log p(z2)], one value per row"""
+        z1, q1_mu, q1_lv, z2, q2_mu, q2_lv, p1_mu, p1_lv = latent_stats
+        emb = exemplars_embedding
+        if emb is None and self.args.prior == 'exemplar_prior':
+            emb = self.get_exemplar_set(q2_mu, q2_lv, dataset, cache, x_indices)
+        d1, d2 = self.args.z1_size, self.args.z2_size
+        rows1 = lambda t: t.view(-1, d1)
+        rows2 = lambda t: t.view(-1, d2)
+        kl_z1 = (log_normal_diag(rows1(z1), rows1(q1_mu), rows1(q1_lv), dim=1)
+                 - log_normal_diag(rows1(z1), rows1(p1_mu), rows1(p1_lv), dim=1))
+        kl_z2 = (log_normal_diag(rows2(z2), rows2(q2_mu), rows2(q2_lv), dim=1)
+                 - self.log_p_z(z=(z2, x_indices), exemplars_embedding=emb))
+        return kl_z1 + kl_z2
 
     def forward(self, x):
-        z2_q_mean, z2_q_logvar = self.q_z(x)
-        z2_q = self.reparameterize(z2_q_mean, z2_q_logvar)
-        z1_q_mean, z1_q_logvar = self.q_z1(x, z2_q)
-        z1_q = self.reparameterize(z1_q_mean, z1_q_logvar)
-        z1_p_mean, z1_p_logvar = self.p_z1(z2_q)
-        x_mean, x_logvar = self.p_x(z1_q, z2_q)
-        return x_mean, x_logvar, (z1_q, z1_q_mean, z1_q_logvar, z2_q, z2_q_mean, z2_q_logvar, z1_p_mean, z1_p_logvar)
+        q2_mu, q2_lv = self.q_z(x)
+        z2 = self.reparameterize(q2_mu, q2_lv)
+        q1_mu, q1_lv = self.q_z1(x, z2)
+        z1 = self.reparameterize(q1_mu, q1_lv)
+        p1_mu, p1_lv = self.p_z1(z2)
+        mean, logvar = self.p_x(z1, z2)
+        return mean, logvar, (z1, q1_mu, q1_lv, z2, q2_mu, q2_lv, p1_mu, p1_lv)

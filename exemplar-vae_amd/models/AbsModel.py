@@ -1,47 +1,61 @@
-"""One-level VAE on top of BaseModel (reference models/AbsModel.py:8-49)."""
+"""Single-latent-layer VAE: how the pieces defined by a concrete model (q_z layers, p_x layers, heads) combine into
+KL term, decoder call and forward pass.  Behavioural contract: reference models/AbsModel.py:8-49 (same method
+names, argument order and return conventions, so models.VAE / models.fully_conv and the evaluation code work unchanged)."""
 import numpy as np
 import torch
 
 from models.BaseModel import BaseModel
 from utils.distributions import log_normal_diag
 
+_CLAMP_LO, _CLAMP_HI = 1.0 / 512.0, 1.0 - 1.0 / 512.0      # continuous means are kept off 0 / 1 (one half grey level)
+
 
 class AbsModel(BaseModel):
     def __init__(self, args):
         super().__init__(args)
 
-    def kl_loss(self, latent_stats, exemplars_embedding, dataset, cache, x_indices):
-        z_q, z_q_mean, z_q_logvar = latent_stats
-        if exemplars_embedding is None and self.args.prior == 'exemplar_prior':
-            exemplars_embedding = self.get_exemplar_set(z_q_mean, z_q_logvar, dataset, cache, x_indices)
-        log_p_z = self.log_p_z(z=(z_q, x_indices), exemplars_embedding=exemplars_embedding)
-        log_q_z = log_normal_diag(z_q, z_q_mean, z_q_logvar, dim=1)
-        return -(log_p_z - log_q_z)
+    # ---- decoder -------------------------------------------------------------------------------------------------
+    def _flat_dim(self):
+        return int(np.prod(self.args.input_size))
 
-    def generate_x_from_z(self, z, with_reparameterize=True):
-        generated_x, _ = self.p_x(z)
-        if getattr(self.args, 'use_logit', False) is True:
-            return self.logit_inverse(generated_x)
-        return generated_x
+    def _decoder_input(self, z):
+        """conv decoders consume the latent as a [bottleneck x H/4 x W/4] map"""
+        if 'conv' not in self.args.model_name:
+            return z
+        side = self.args.input_size[1] // 4
+        return z.reshape(-1, self.bottleneck, side, side)
 
     def p_x(self, z):
-        if 'conv' in self.args.model_name:
-            z = z.reshape(-1, self.bottleneck, self.args.input_size[1] // 4, self.args.input_size[1] // 4)
-        h = self.p_x_layers(z)
-        x_mean = self.p_x_mean(h)
-        d_in = int(np.prod(self.args.input_size))
-        if self.args.input_type == 'binary':
-            x_logvar = torch.zeros(1, d_in)
+        """-> (mean [B x D], log-variance [B x D] or [1 x D] zeros for binary data)"""
+        mean = self.p_x_mean(self.p_x_layers(self._decoder_input(z)))
+        D = self._flat_dim()
+        kind = self.args.input_type
+        if kind == 'binary':
+            logvar = torch.zeros(1, D)
         elif self.args.use_logit is False:
-            x_mean = torch.clamp(x_mean, min=0. + 1. / 512., max=1. - 1. / 512.)
-            x_logvar = self.decoder_logstd * x_mean.new_ones(size=x_mean.shape)
+            mean = mean.clamp(min=_CLAMP_LO, max=_CLAMP_HI)
+            logvar = self.decoder_logstd * torch.ones_like(mean)
         else:
-            # the reference leaves x_logvar unbound here (AbsModel.py:36-42); same failure, clearer message
+            # undefined in the reference as well (it falls through with no log-variance bound); fail with a message
             raise UnboundLocalError("AbsModel.p_x: continuous input with use_logit=True has no x_logvar")
-        return x_mean.reshape(-1, d_in), x_logvar.reshape(-1, d_in)
+        return mean.reshape(-1, D), logvar.reshape(-1, D)
+
+    def generate_x_from_z(self, z, with_reparameterize=True):
+        x, _ = self.p_x(z)
+        return self.logit_inverse(x) if getattr(self.args, 'use_logit', False) is True else x
+
+    # ---- objective -------------------------------------------------------------------------------------------------
+    def kl_loss(self, latent_stats, exemplars_embedding, dataset, cache, x_indices):
+        """log q(z|x) - log p(z), one value per row"""
+        z, mu, logvar = latent_stats
+        emb = exemplars_embedding
+        if emb is None and self.args.prior == 'exemplar_prior':
+            emb = self.get_exemplar_set(mu, logvar, dataset, cache, x_indices)
+        prior_term = self.log_p_z(z=(z, x_indices), exemplars_embedding=emb)
+        posterior_term = log_normal_diag(z, mu, logvar, dim=1)
+        return posterior_term - prior_term
 
     def forward(self, x, label=0, num_categories=10):
-        z_q_mean, z_q_logvar = self.q_z(x)
-        z_q = self.reparameterize(z_q_mean, z_q_logvar)
-        x_mean, x_logvar = self.p_x(z_q)
-        return x_mean, x_logvar, (z_q, z_q_mean, z_q_logvar)
+        mu, logvar = self.q_z(x)
+        z = self.reparameterize(mu, logvar)
+        return (*self.p_x(z), (z, mu, logvar))

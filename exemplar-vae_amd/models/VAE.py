@@ -1,5 +1,5 @@
-"""MLP VAE 784 -> 300 -> 300 -> 40 / 40 -> 300 -> 300 -> 784 (reference models/VAE.py:11-30), same
-submodule names and state_dict keys."""
+"""Fully-connected VAE, MNIST-sized by default: 784 -> 300 -> 300 -> 40 and back.  Widths and submodule names
+(= state_dict keys) follow reference models/VAE.py:11-30; the output heads come from models.BaseModel."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -12,14 +12,16 @@ class VAE(AbsModel):
     def __init__(self, args):
         super().__init__(args)
 
+    def _gated_pair(self, n_in, width):
+        plain = self.args.no_attention
+        return nn.Sequential(GatedDense(n_in, width, no_attention=plain), GatedDense(width, width, no_attention=plain))
+
     def create_model(self, args, train_data_size=None):
         self.train_data_size = train_data_size
-        d_in, hid, zd = int(np.prod(self.args.input_size)), self.args.hidden_size, self.args.z1_size
-        na = self.args.no_attention
-        self.q_z_layers = nn.Sequential(GatedDense(d_in, hid, no_attention=na), GatedDense(hid, hid, no_attention=na))
-        self.q_z_mean = HipLinear(hid, zd)
-        if args.same_variational_var:
-            self.q_z_logvar = torch.nn.Parameter(torch.randn((1)))
-        else:
-            self.q_z_logvar = NonLinear(hid, zd, activation=nn.Hardtanh(min_val=-6., max_val=2.))
-        self.p_x_layers = nn.Sequential(GatedDense(zd, hid, no_attention=na), GatedDense(hid, hid, no_attention=na))
+        n_pix, width, zdim = int(np.prod(self.args.input_size)), self.args.hidden_size, self.args.z1_size
+        self.q_z_layers = self._gated_pair(n_pix, width)
+        self.q_z_mean = HipLinear(width, zdim)
+        # log-variance of q: one learnt scalar shared by all inputs, or a clipped linear head
+        self.q_z_logvar = (torch.nn.Parameter(torch.randn((1))) if args.same_variational_var
+                           else NonLinear(width, zdim, activation=nn.Hardtanh(min_val=-6., max_val=2.)))
+        self.p_x_layers = self._gated_pair(zdim, width)

@@ -1,13 +1,25 @@
-"""Gated-convolutional two-level HVAE (reference models/convHVAE_2level.py:9-97), same submodule names.
-Dense parts run on the HIP GEMM; the gated convolutions go through utils.nn.GatedConv2d."""
+"""Gated-convolutional two-level HVAE.  Architecture and submodule names (= state_dict keys) follow reference
+models/convHVAE_2level.py:9-97; the network is described by the tables below and instantiated in table order, which
+is also the order the reference draws its initial weights in.  Dense parts run on the HIP GEMM, the gated convolutions
+go through utils.nn.GatedConv2d (channels-last implicit GEMM)."""
 import numpy as np
 import torch.nn as nn
 
 from models.AbsHModel import BaseHModel
 from utils.nn import Conv2d, GatedConv2d, GatedDense, NonLinear
 
+# flattened size of the 6-channel feature map the two conv encoders end in, per dataset family
+_ENCODER_FEATURES = {'freyfaces': 210, 'cifar10': 384, 'svhn': 384}
+_ENCODER_FEATURES_DEFAULT = 294          # 28 x 28 inputs: 6 x 7 x 7
+_DENSE_WIDTH = 300
+_DECODER_CHANNELS = 64
 
-def _ht(lo=-6., hi=2.):
+# (out_channels, kernel, stride, padding) of the five gated convolutions of an encoder
+_ENCODER_WIDE = ((32, 7, 1, 3), (32, 3, 2, 1), (64, 5, 1, 2), (64, 3, 2, 1), (6, 3, 1, 1))      # q(z2 | x)
+_ENCODER_NARROW = ((32, 3, 1, 1), (32, 3, 2, 1), (64, 3, 1, 1), (64, 3, 2, 1), (6, 3, 1, 1))    # x-branch of q(z1 | x, z2)
+
+
+def _clip(lo, hi):
     return nn.Hardtanh(min_val=lo, max_val=hi)
 
 
@@ -15,56 +27,49 @@ class VAE(BaseHModel):
     def __init__(self, args):
         super().__init__(args)
 
+    def _conv_stack(self, c_in, table):
+        layers = []
+        for c_out, k, s, p in table:
+            layers.append(GatedConv2d(c_in, c_out, k, s, p, no_attention=self.args.no_attention))
+            c_in = c_out
+        return nn.Sequential(*layers)
+
+    def _dense_stack(self, *widths, plain=False):
+        kw = {} if plain else {'no_attention': self.args.no_attention}
+        return nn.Sequential(*[GatedDense(a, b, **kw) for a, b in zip(widths[:-1], widths[1:])])
+
+    def _gaussian_heads(self, prefix, width, zdim):
+        setattr(self, prefix + '_mean', NonLinear(width, zdim, activation=None))
+        setattr(self, prefix + '_logvar', NonLinear(width, zdim, activation=_clip(-6., 2.)))
+
     def create_model(self, args):
-        if args.dataset_name == 'freyfaces':
-            self.h_size = 210
-        elif args.dataset_name in ('cifar10', 'svhn'):
-            self.h_size = 384
-        else:
-            self.h_size = 294
-        fc = 300
-        c_in, na = self.args.input_size[0], args.no_attention
+        self.h_size = _ENCODER_FEATURES.get(args.dataset_name, _ENCODER_FEATURES_DEFAULT)
+        feat, fc, ch = self.h_size, _DENSE_WIDTH, _DECODER_CHANNELS
+        colours, n_pix = self.args.input_size[0], int(np.prod(self.args.input_size))
         z1, z2 = self.args.z1_size, self.args.z2_size
 
-        def enc(first_k, first_p, mid_k, mid_p):
-            return nn.Sequential(
-                GatedConv2d(c_in, 32, first_k, 1, first_p, no_attention=na),
-                GatedConv2d(32, 32, 3, 2, 1, no_attention=na),
-                GatedConv2d(32, 64, mid_k, 1, mid_p, no_attention=na),
-                GatedConv2d(64, 64, 3, 2, 1, no_attention=na),
-                GatedConv2d(64, 6, 3, 1, 1, no_attention=na))
+        self.q_z_layers = self._conv_stack(colours, _ENCODER_WIDE)
+        self._gaussian_heads('q_z', feat, z2)
 
-        # q(z2 | x)
-        self.q_z_layers = enc(7, 3, 5, 2)
-        self.q_z_mean = NonLinear(self.h_size, z2, activation=None)
-        self.q_z_logvar = NonLinear(self.h_size, z2, activation=_ht())
-        # q(z1 | x, z2)
-        self.q_z1_layers_x = enc(3, 1, 3, 1)
-        self.q_z1_layers_z2 = nn.Sequential(GatedDense(z2, self.h_size))
-        self.q_z1_layers_joint = nn.Sequential(GatedDense(2 * self.h_size, fc))
-        self.q_z1_mean = NonLinear(fc, z1, activation=None)
-        self.q_z1_logvar = NonLinear(fc, z1, activation=_ht())
-        # p(z1 | z2)
-        self.p_z1_layers_z2 = nn.Sequential(GatedDense(z2, fc, no_attention=na), GatedDense(fc, fc, no_attention=na))
-        self.p_z1_mean = NonLinear(fc, z1, activation=None)
-        self.p_z1_logvar = NonLinear(fc, z1, activation=_ht())
-        # p(x | z1, z2)
-        self.p_x_layers_z1 = nn.Sequential(GatedDense(z1, fc, no_attention=na))
-        self.p_x_layers_z2 = nn.Sequential(GatedDense(z2, fc, no_attention=na))
-        self.p_x_layers_joint_pre = nn.Sequential(
-            GatedDense(2 * fc, int(np.prod(self.args.input_size)), no_attention=na))
-        self.p_x_layers_joint = nn.Sequential(
-            GatedConv2d(c_in, 64, 3, 1, 1, no_attention=na), GatedConv2d(64, 64, 3, 1, 1, no_attention=na),
-            GatedConv2d(64, 64, 3, 1, 1, no_attention=na), GatedConv2d(64, 64, 3, 1, 1, no_attention=na))
-        if self.args.input_type == 'binary':
-            self.p_x_mean = Conv2d(64, 1, 1, 1, 0, activation=nn.Sigmoid())
-        elif self.args.input_type in ('gray', 'continuous'):
-            self.p_x_mean = Conv2d(64, c_in, 1, 1, 0)
-            self.p_x_logvar = Conv2d(64, c_in, 1, 1, 0, activation=_ht(-4.5, 0.))
-        elif self.args.input_type == 'pca':
-            self.p_x_mean = Conv2d(64, 1, 1, 1, 0)
-            self.p_x_logvar = Conv2d(64, c_in, 1, 1, 0, activation=_ht(-4.5, 0.))
+        self.q_z1_layers_x = self._conv_stack(colours, _ENCODER_NARROW)
+        self.q_z1_layers_z2 = self._dense_stack(z2, feat, plain=True)
+        self.q_z1_layers_joint = self._dense_stack(2 * feat, fc, plain=True)
+        self._gaussian_heads('q_z1', fc, z1)
+
+        self.p_z1_layers_z2 = self._dense_stack(z2, fc, fc)
+        self._gaussian_heads('p_z1', fc, z1)
+
+        self.p_x_layers_z1 = self._dense_stack(z1, fc)
+        self.p_x_layers_z2 = self._dense_stack(z2, fc)
+        self.p_x_layers_joint_pre = self._dense_stack(2 * fc, n_pix)
+        self.p_x_layers_joint = self._conv_stack(colours, ((ch, 3, 1, 1),) * 4)
+
+        kind = self.args.input_type                       # 1x1 output convolutions
+        if kind == 'binary':
+            self.p_x_mean = Conv2d(ch, 1, 1, 1, 0, activation=nn.Sigmoid())
+        elif kind in ('gray', 'continuous', 'pca'):
+            self.p_x_mean = Conv2d(ch, 1 if kind == 'pca' else colours, 1, 1, 0)
+            self.p_x_logvar = Conv2d(ch, colours, 1, 1, 0, activation=_clip(-4.5, 0.))
 
     def forward(self, x):
-        x = x.view(-1, self.args.input_size[0], self.args.input_size[1], self.args.input_size[2])
-        return super().forward(x)
+        return super().forward(x.view(-1, *self.args.input_size))

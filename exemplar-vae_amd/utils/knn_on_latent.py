@@ -1,61 +1,64 @@
-"""Latent-space kNN with the reference's signatures (reference utils/knn_on_latent.py:4-74) on the
-fused distance + top-K kernel."""
+"""kNN classification in the latent space (function names and arguments of reference utils/knn_on_latent.py:4-74).
+The neighbour search is ONE launch of the fused distance + top-K kernel over the whole evaluation set; the label
+vote is a vectorised count instead of a per-row loop."""
 import torch
 
 from evae import ops
 
+_NEIGHBOURS = 20          # neighbours kept per query; the k values voted on are prefixes of this list
+_CLASSES = 10
+
 
 def find_nearest_neighbors(z_val, z_train, z_train_log_var):
-    """Indices [len(z_val) x 20] of the 20 nearest training latents, nearest first; the third argument is
-    ignored, as in the reference (:4-9)."""
-    idx, _ = ops.pairdist_topk(z_val, z_train, 20, sqrt=True, want_val=False)
-    return idx
+    """[len(z_val) x 20] training-row indices, nearest first.  `z_train_log_var` takes no part in the distance
+    (reference :4-9 ignores it too)."""
+    return ops.pairdist_topk(z_val, z_train, _NEIGHBOURS, sqrt=True, want_val=False)[0]
 
 
 def extract_full_data(data_loader):
-    """Concatenate a loader of (data, [indices,] labels) batches (:12-28)."""
-    datas, labels, indices = [], [], []
+    """Whole content of a loader of (data, labels) or (data, indices, labels) batches -> (data, indices, labels);
+    indices is an empty list when the loader carries none (reference :12-28)."""
+    columns = {'data': [], 'indices': [], 'labels': []}
     for batch in data_loader:
+        columns['data'].append(batch[0])
+        columns['labels'].append(batch[-1])
         if len(batch) == 3:
-            d, i, l = batch
-            indices.append(i)
-        else:
-            d, l = batch
-        datas.append(d)
-        labels.append(l)
-    full_indices = torch.cat(indices, dim=0) if len(indices) > 0 else indices
-    return torch.cat(datas, dim=0), full_indices, torch.cat(labels, dim=0)
+            columns['indices'].append(batch[1])
+    idx = columns['indices']
+    return (torch.cat(columns['data'], dim=0), torch.cat(idx, dim=0) if idx else idx,
+            torch.cat(columns['labels'], dim=0))
+
+
+def _posterior_means(model, data, batch_size):
+    """q(z|x) means of the full batches of `data` (a trailing partial batch is dropped, as in the reference)"""
+    chunks = [model.q_z(data[lo:lo + batch_size], prior=True)[0]
+              for lo in range(0, (len(data) // batch_size) * batch_size, batch_size)]
+    return torch.cat(chunks, dim=0)
 
 
 def report_knn_on_latent(train_loader, val_loader, test_loader, model, dir, knn_dictionary, args, val=True):
-    """kNN label vote on q(z|x) means for k in knn_dictionary (:32-74); appends the accuracy (%)."""
-    train_data, _, train_labels = extract_full_data(train_loader)
-    val_data, _, val_labels = extract_full_data(val_loader)
-    test_data, _, test_labels = extract_full_data(test_loader)
-    train_data = train_data.to(args.device)
-    val_data = val_data.to(args.device)
+    """For every k in knn_dictionary: majority vote over the k nearest training latents, accuracy in percent
+    (two decimals) appended to knn_dictionary[k].  val=True scores the validation split against the training split;
+    val=False scores the test split against training + validation (reference :32-74)."""
+    splits = [extract_full_data(loader) for loader in (train_loader, val_loader, test_loader)]
+    (ref_x, _, ref_y), (val_x, _, val_y), (test_x, _, test_y) = splits
+    ref_x, val_x = ref_x.to(args.device), val_x.to(args.device)
     if val is True:
-        data_to_evaluate, labels = val_data, val_labels
+        query_x, query_y = val_x, val_y
     else:
-        train_data = torch.cat((train_data, val_data), dim=0)
-        train_labels = torch.cat((train_labels, val_labels), dim=0)
-        data_to_evaluate, labels = test_data.to(args.device), test_labels
-    bs = args.batch_size
+        ref_x, ref_y = torch.cat((ref_x, val_x), dim=0), torch.cat((ref_y, val_y), dim=0)
+        query_x, query_y = test_x.to(args.device), test_y
     with torch.no_grad():
-        z_train = torch.cat([model.q_z(train_data[i * bs:(i + 1) * bs], prior=True)[0]
-                             for i in range(len(train_data) // bs)], dim=0)
-        n_eval = (len(data_to_evaluate) // bs) * bs
-        z_eval = torch.cat([model.q_z(data_to_evaluate[i * bs:(i + 1) * bs], prior=True)[0]
-                            for i in range(len(data_to_evaluate) // bs)], dim=0)
-        indices = find_nearest_neighbors(z_eval, z_train, None).cpu()   # one scan for the whole eval set
-    print(z_train.shape)
-    labels = labels[:n_eval]
-    for k in knn_dictionary.keys():
-        k = int(k)
-        k_labels = train_labels[indices[:, :k]].reshape(len(indices), k).long()
-        num_classes = 10
-        counts = torch.stack([(k_labels == c).sum(dim=1) for c in range(num_classes)], dim=1)
-        y_pred = torch.argmax(counts, dim=1)
-        acc = (torch.mean((y_pred == labels.long()).float()) * 10000).round().item() / 100
+        z_ref = _posterior_means(model, ref_x, args.batch_size)
+        z_query = _posterior_means(model, query_x, args.batch_size)
+        neighbours = find_nearest_neighbors(z_query, z_ref, None).cpu()
+    print(z_ref.shape)
+    query_y = query_y[:len(neighbours)].long()
+    classes = torch.arange(_CLASSES).view(1, 1, -1)
+    for key in knn_dictionary.keys():
+        k = int(key)
+        votes = (ref_y[neighbours[:, :k]].reshape(len(neighbours), k, 1).long() == classes).sum(dim=1)
+        hit = (votes.argmax(dim=1) == query_y).float().mean()
+        acc = (hit * 10000).round().item() / 100
         print('K:', k, 'Accuracy:', acc)
         knn_dictionary[str(k)].append(acc)
