@@ -185,6 +185,7 @@ def main():
     opt = AdamNormGrad(model.parameters(), lr=5e-4)
     data_dev = model.resident_data(dataset)  # one upload; exemplar gathers read HBM from here on
     idx_all = torch.arange(N_TRAIN, device=dev).reshape(-1, 1)
+    idx_host = torch.arange(N_TRAIN).reshape(-1, 1)      # what a DataLoader over the training set hands out
     beta = set_beta(args, 50)
     model.train()
     nb = N_TRAIN // B
@@ -213,7 +214,7 @@ def main():
             return eager_step(i)
         s = batch_start(i)
         try:
-            out = g(data_dev[s:s + B], idx_all[s:s + B], beta)     # one hipGraph launch (after 3 eager warm-ups)
+            out = g(data_dev[s:s + B], idx_host[s:s + B], beta)     # one hipGraph launch (after 3 eager warm-ups)
         except Exception as e:                                      # capture refused (e.g. by the collective
             if g.graph is not None and g._calls > g.warmup_steps + 1:  # library): keep measuring, eagerly
                 raise

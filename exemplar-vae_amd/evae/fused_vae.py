@@ -89,18 +89,19 @@ class _K:
         _lib.check(self.lib.evae_linear_fwd(_vp(x), None, M, K, ldx, _vp(w_), _vp(b), N, act, lo, hi, _vp(y), _vp(pre),
                                             _vp(w), w.numel(), self.st), "linear_fwd")
 
-    def bwd_data(self, dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, out, dg, ldo):
+    def bwd_data(self, dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, out, dg, ldo, st=None, ws_name="dgrad"):
+        """`st` / `ws_name`: launches issued on the side stream name it and use their own workspace"""
         nb = self.lib.evae_dense_bwd_data_workspace_bytes(M, N, K, 2 if dy2 is not None else 1)
-        w = self.ws("dgrad", nb)
+        w = self.ws(ws_name, nb)
         _lib.check(self.lib.evae_dense_bwd_data(_vp(dy1), _vp(w1), _vp(dy2), _vp(w2), M, N, ldy, K, _vp(out_prev),
-                                                _vp(s_prev), _vp(out), _vp(dg), ldo, _vp(w), w.numel(), self.st),
-                   "bwd_data")
+                                                _vp(s_prev), _vp(out), _vp(dg), ldo, _vp(w), w.numel(),
+                                                self.st if st is None else st), "bwd_data")
 
-    def bwd_weight(self, dy, M, N, ldy, x, rows, K, ldx, dw, db):
+    def bwd_weight(self, dy, M, N, ldy, x, rows, K, ldx, dw, db, st=None, ws_name="wgrad"):
         nb = self.lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
-        w = self.ws("wgrad", nb)
+        w = self.ws(ws_name, nb)
         _lib.check(self.lib.evae_dense_bwd_weight(_vp(dy), M, N, ldy, _vp(x), _vp(rows), K, ldx, _vp(dw), _vp(db), 0,
-                                                  _vp(w), w.numel(), self.st), "bwd_weight")
+                                                  _vp(w), w.numel(), self.st if st is None else st), "bwd_weight")
 
 
 class VaeExactLoss(torch.autograd.Function):
@@ -123,7 +124,9 @@ class VaeExactLoss(torch.autograd.Function):
         f32 = dict(device=dev, dtype=torch.float32)
         x = x.contiguous()
         # stage the batch behind the dataset; one gather list for exemplars + batch
-        data_ext[n_data:n_data + B].copy_(x)
+        stage = data_ext[n_data:n_data + B]
+        if x.data_ptr() != stage.data_ptr():      # the captured step (evae/graph.py) gathers the batch there itself
+            stage.copy_(x)
         # rows_ext: caller-kept [Cl + B] gather list whose head IS ex_idx and whose tail already names the staging rows
         if rows_ext is not None and rows_ext.numel() == Cl + B and rows_ext.data_ptr() == ex_idx.data_ptr():
             rows = rows_ext
@@ -147,7 +150,6 @@ class VaeExactLoss(torch.autograd.Function):
         z = torch.empty((B, Z), **f32); logq = torch.empty(B, **f32)
         _lib.check(lib.evae_reparam_logq_fwd(_vp(z_mean), _vp(logvar), _vp(eps), B, Z, _vp(z), _vp(logq), k.st), "reparam")
         # ---- exemplar prior (leave-one-out mask in training unless no_mask) on the side stream ...
-        lv_row = plv.detach().expand(Z).contiguous()
         zi = None if no_mask else x_idx.reshape(-1)
         ci = None if no_mask else ex_idx
         logp = torch.empty(B, **f32); lse = torch.empty(B, **f32)
@@ -156,6 +158,7 @@ class VaeExactLoss(torch.autograd.Function):
         side.wait_stream(main)
         z_all, zi_all = z, zi
         with torch.cuda.stream(side):
+            lv_row = plv.detach().expand(Z).contiguous()
             if sharded == 2:
                 # data-parallel batches over sharded exemplars: every rank scores the queries of ALL ranks against its
                 # shard (same pair count as B queries against all C), the partials go back to their owners
@@ -235,9 +238,15 @@ class VaeExactLoss(torch.autograd.Function):
                                      _vp(gk), 0 if gk is None else gk.numel(), _vp(beta_dev),
                                      0.0 if beta_dev is not None else float(beta), B, _vp(cRE), _vp(cKL), _vp(gp), k.st),
                    "elbo_bwd")
-        # ---- prior term d(-cKL * logp) on the side stream; dcentres lands directly in the head-gradient buffer,
-        #      dz' and dlogvar' in one packed buffer so that the sharded case all-reduces it in place
+        # ---- two chains from here to the weight gradients:
+        #   side stream: prior term d(-cKL * logp) -> dcentres (lands in the head-gradient buffer) -> data gradients of the
+        #                head and of encoder layer 2 for the Cl exemplar rows (none of it needs the decoder);
+        #   main stream: reconstruction term through the decoder -> dz -> the same data gradients for the B batch rows.
+        #   They meet at the weight gradients, which run over all Cl + B rows in one launch per layer.
+        #   dz' and dlogvar' share one packed buffer so that the sharded case all-reduces it in place.
         dmean_all = torch.empty((Mp, Z), **f32)
+        dq2 = torch.empty((Mp, 2 * H), **f32)                              # [dh2 | dg2] for all C + B rows
+        dq1 = torch.empty((Mp, 2 * H), **f32)
         centres = mean_all[:Cl]
         main = torch.cuda.current_stream()
         side = main if sharded else k.side_stream()
@@ -265,32 +274,34 @@ class VaeExactLoss(torch.autograd.Function):
             dzp = packed[:B * Z].view(B, Z); dlv = packed[B * Z:]
             nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cl, Z)
             w = k.ws("prior_bwd", nb)
+        dz_ready = torch.cuda.Event()
         with torch.cuda.stream(side):
+            sst = ops._stream()
             if sharded != 2:
                 _lib.check(lib.evae_prior_lse_bwd(_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp),
-                                                  _vp(dzp), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), ops._stream()), "prior_bwd")
+                                                  _vp(dzp), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), sst), "prior_bwd")
             if sharded == 1:
                 dist.all_reduce(packed, op=dist.ReduceOp.SUM)
                 if Cl > 0:
                     dmean_all[:Cl].mul_(float(dist.get_world_size()))
+            dz_ready.record()
+            if Cl > 0:
+                k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H,
+                           st=sst, ws_name="dgrad_side")
+                k.bwd_data(dq2, w2h, dq2.data_ptr() + 4 * H, w2g, Cl, H, 2 * H, H, A1, s1, dq1, dq1.data_ptr() + 4 * H, 2 * H,
+                           st=sst, ws_name="dgrad_side")
         # ---- reconstruction term through the decoder (main stream, concurrently)
         dxm = torch.empty((B, D), **f32)
         _lib.check(lib.evae_bernoulli_ll_bwd(_vp(x), _vp(xmean), _vp(cRE), B, D, _vp(dxm), k.st), "bernoulli_bwd")
         dpx = torch.empty((B, D), **f32)
         _lib.check(lib.evae_act_bwd(_vp(dxm), _vp(xmean), B * D, ACT_SIGMOID, 0.0, 0.0, _vp(dpx), k.st), "act_bwd")
-        g_wp = gslot("wp", D, H); g_bp = gslot("bp", D)
-        k.bwd_weight(dpx, B, D, D, D2, None, H, H, g_wp, g_bp)
         dp2 = torch.empty((B, 2 * H), **f32)                              # [dh | dg] of decoder layer 2
         k.bwd_data(dpx, wp, None, None, B, D, D, H, D2, sd2, dp2, dp2.data_ptr() + 4 * H, 2 * H)
-        g_d2 = gslot("d2", 2 * H, H); g_e2 = gslot("e2", 2 * H)
-        k.bwd_weight(dp2, B, 2 * H, 2 * H, D1, None, H, H, g_d2, g_e2)
         dp1 = torch.empty((B, 2 * H), **f32)
         k.bwd_data(dp2, d2h, dp2.data_ptr() + 4 * H, d2g, B, H, 2 * H, H, D1, sd1, dp1, dp1.data_ptr() + 4 * H, 2 * H)
-        g_d1 = gslot("d1", 2 * H, Z); g_e1 = gslot("e1", 2 * H)
-        k.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1)
         dz = torch.empty((B, Z), **f32)
         k.bwd_data(dp1, d1h, dp1.data_ptr() + 4 * H, d1g, B, H, 2 * H, Z, None, None, dz, None, Z)
-        main.wait_stream(side)
+        main.wait_event(dz_ready)
         dz.add_(dzp)
         # ---- reparameterisation + log q
         dlogvar = torch.empty((B, Z), **f32)
@@ -299,25 +310,39 @@ class VaeExactLoss(torch.autograd.Function):
                                              _vp(dmean_all.data_ptr() + 4 * Cl * Z), _vp(dlogvar), k.st), "reparam_bwd")
         dlvp = torch.empty((B, Z), **f32)
         _lib.check(lib.evae_act_bwd(_vp(dlogvar), _vp(lv_pre), B * Z, ACT_HARDTANH, -6.0, 2.0, _vp(dlvp), k.st), "act_bwd")
-        # ---- heads
-        A2b_ptr = A2.data_ptr() + 4 * Cl * H
-        g_wl = gslot("wl", Z, H); g_bl = gslot("bl", Z)
-        k.bwd_weight(dlvp, B, Z, Z, A2b_ptr, None, H, H, g_wl, g_bl)
-        g_wm = gslot("wm", Z, H); g_bm = gslot("bm", Z)
-        k.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)
-        dq2 = torch.empty((Mp, 2 * H), **f32)                              # [dh2 | dg2] for all C + B rows
-        if Cl > 0:
-            k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H)
+        # ---- heads and encoder layer 2, batch rows
         off = 4 * Cl
         k.bwd_data(dmean_all.data_ptr() + off * Z, wm, dlvp, wl, B, Z, Z, H, A2.data_ptr() + off * H,
                    s2.data_ptr() + off * H, dq2.data_ptr() + off * 2 * H, dq2.data_ptr() + off * 2 * H + 4 * H, 2 * H)
-        # ---- encoder layers over C + B rows
+        k.bwd_data(dq2.data_ptr() + off * 2 * H, w2h, dq2.data_ptr() + off * 2 * H + 4 * H, w2g, B, H, 2 * H, H,
+                   A1.data_ptr() + off * H, s1.data_ptr() + off * H, dq1.data_ptr() + off * 2 * H,
+                   dq1.data_ptr() + off * 2 * H + 4 * H, 2 * H)
+        # ---- the B-row weight gradients of the decoder and of the log-variance head are leaves (nobody waits for them
+        #      before the optimizer): they go to the side stream, behind its data gradients, and run next to the big
+        #      weight-gradient GEMMs instead of lengthening the chain above
+        chain_done = torch.cuda.Event(); chain_done.record()
+        side_dgrads = torch.cuda.Event()
+        g_wp = gslot("wp", D, H); g_bp = gslot("bp", D)
+        g_d2 = gslot("d2", 2 * H, H); g_e2 = gslot("e2", 2 * H)
+        g_d1 = gslot("d1", 2 * H, Z); g_e1 = gslot("e1", 2 * H)
+        g_wl = gslot("wl", Z, H); g_bl = gslot("bl", Z)
+        with torch.cuda.stream(side):
+            side_dgrads.record()
+            side.wait_event(chain_done)
+            kw = dict(st=ops._stream(), ws_name="wgrad_side")
+            k.bwd_weight(dpx, B, D, D, D2, None, H, H, g_wp, g_bp, **kw)
+            k.bwd_weight(dp2, B, 2 * H, 2 * H, D1, None, H, H, g_d2, g_e2, **kw)
+            k.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1, **kw)
+            k.bwd_weight(dlvp, B, Z, Z, A2.data_ptr() + off * H, None, H, H, g_wl, g_bl, **kw)
+        main.wait_event(side_dgrads)
+        # ---- weight gradients over all C + B rows
+        g_wm = gslot("wm", Z, H); g_bm = gslot("bm", Z)
+        k.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)
         g_w2 = gslot("w2", 2 * H, H); g_b2 = gslot("b2", 2 * H)
         k.bwd_weight(dq2, Mp, 2 * H, 2 * H, A1, None, H, H, g_w2, g_b2)
-        dq1 = torch.empty((Mp, 2 * H), **f32)
-        k.bwd_data(dq2, w2h, dq2.data_ptr() + 4 * H, w2g, Mp, H, 2 * H, H, A1, s1, dq1, dq1.data_ptr() + 4 * H, 2 * H)
         g_w1 = gslot("w1", 2 * H, D); g_b1 = gslot("b1", 2 * H)
         k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)
+        main.wait_stream(side)
         g_plv = gslot("plv", 1)
         torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
         ctx.bufs = None

@@ -3,12 +3,15 @@ optimizer) so that a step costs ONE graph launch on the host instead of ~90 kern
 between them.  At the 25 000-exemplar configuration a step is < 2 ms of GPU work; with the exemplars sharded
 over 8 GPUs it is a few hundred microseconds, far below what eager launching can feed.
 
-What varies between steps lives in static device buffers that are refreshed before each replay:
-  the batch (images + dataset indices), the exemplar indices (still drawn by the CPU generator exactly like
-  reference models/BaseModel.py:245), beta, and AdamNormGrad's bias-corrected step size (one upload for the
-  scalars, pinned double-buffered staging, no fill kernels).  eps and the dynamic
-  binarisation come from the CUDA generator inside the graph (torch registers it with the capture, so every
-  replay advances the Philox offset).  RCCL collectives of the sharded prior are captured too.
+What varies between steps lives in ONE static int64 control block that is refreshed before each replay: the exemplar
+indices (still drawn by the CPU generator exactly like reference models/BaseModel.py:245), the dataset indices of the
+batch, beta and AdamNormGrad's bias-corrected step sizes.  The host writes a pinned copy (double-buffered), a copy
+stream uploads it ahead of time and the step's stream only runs a device-to-device copy in front of the graph launch.
+The batch images themselves are rows of the HBM-resident dataset: the graph gathers (and binarises) them by index, so
+no image bytes cross PCIe (checked once against the loader's first batch; a loader that hands out other images gets
+them uploaded instead).  eps and the dynamic binarisation come from the CUDA generator inside the graph (torch
+registers it with the capture, so every replay advances the Philox offset).  RCCL collectives of the sharded prior
+are captured too.
 """
 import torch
 
@@ -25,21 +28,39 @@ class GraphedTrainStep:
         D = int(torch.tensor(a.input_size).prod().item())
         C = int(a.number_components)
         self.x_in = torch.zeros((self.B, D), device=dev)
-        self.idx_in = torch.zeros((self.B, 1), dtype=torch.int64, device=dev)
         # gather list of the fused step: [this rank's exemplar indices | the staging rows of the batch]; only the head
         # changes between steps, so the captured graph needs no arange/cat
         self.lo, self.hi = shard.bounds(C) if model._sharded() else (0, C)
-        _, n_data = model.resident_data_ext(dataset, self.B)
-        self.rows = torch.zeros((self.hi - self.lo) + self.B, dtype=torch.int64, device=dev)
-        self.rows[self.hi - self.lo:] = torch.arange(n_data, n_data + self.B, device=dev)
-        # per-step scalars (beta, Adam step size per group) travel in ONE small upload; host staging is pinned and
-        # double-buffered, an event per buffer says when its upload has been consumed
+        Cl = self.hi - self.lo
+        self.data_ext, self.n_data = model.resident_data_ext(dataset, self.B)
+        self.data_rows = self.data_ext[:self.n_data]
+        self.stage_rows = self.data_ext[self.n_data:self.n_data + self.B]      # where the fused step wants the batch
+        # Everything that varies between steps is ONE int64 control block in static device memory:
+        #   [exemplar rows (Cl) | staging rows (B, constant) | batch dataset indices (B) | beta, Adam step sizes (fp32)]
+        # The host fills a pinned copy (double-buffered), a copy stream uploads it ahead of time into a device staging
+        # block, and the step's own stream only runs one device-to-device copy in front of the graph launch -- it never
+        # waits for a DMA engine or for the host.
         self.ngroups = len(optimizer.param_groups)
-        self.scal = torch.zeros(1 + self.ngroups, device=dev)
+        nsc = 1 + self.ngroups
+        self._o_idx, self._o_scal = Cl + self.B, Cl + 2 * self.B
+        words = self._o_scal + (nsc + 1) // 2
+        self.ctl = torch.zeros(words, dtype=torch.int64, device=dev)
+        self.rows = self.ctl[:self._o_idx]
+        self.idx_flat = self.ctl[self._o_idx:self._o_scal]
+        self.idx_in = self.idx_flat.view(self.B, 1)
+        self.scal = self.ctl[self._o_scal:].view(torch.float32)[:nsc]
         self.beta = self.scal[0:1].reshape(())
-        self._h_scal = [torch.zeros(1 + self.ngroups).pin_memory() for _ in range(2)]
-        self._h_idx = [torch.zeros(C, dtype=torch.int64).pin_memory() for _ in range(2)]
-        self._h_ev = [torch.cuda.Event() for _ in range(2)]
+        tail = torch.arange(self.n_data, self.n_data + self.B)
+        self.rows[Cl:] = tail.to(dev)
+        self._h_ctl = [torch.zeros(words, dtype=torch.int64).pin_memory() for _ in range(2)]
+        for h in self._h_ctl:
+            h[Cl:self._o_idx] = tail
+        self._h_draw = torch.zeros(C, dtype=torch.int64)                 # the full draw when only a shard is uploaded
+        self._d_ctl = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(2)]
+        self._up = torch.cuda.Stream(device=dev)
+        self._ev_up = [torch.cuda.Event() for _ in range(2)]             # upload k finished (host buffer k reusable)
+        self._ev_used = [torch.cuda.Event() for _ in range(2)]           # device staging k consumed by the step stream
+        self.by_index = None      # True once the loader's images are known to be rows of the resident dataset
         self._one = torch.ones((), device=dev)
         self.out = torch.zeros(3, device=dev)       # (loss, -RE, KL) of the last step
         self.totals = torch.zeros(3, device=dev)    # running sums since reset_totals()
@@ -53,7 +74,16 @@ class GraphedTrainStep:
 
     # the body that gets captured
     def _body(self):
-        x = torch.bernoulli(self.x_in) if self.binarize else self.x_in
+        if self.by_index:
+            # the batch is rows `idx` of the HBM-resident dataset: gathered (and binarised) straight into the staging rows
+            # of the fused step, no image bytes cross PCIe
+            x = self.stage_rows
+            if self.binarize:
+                torch.bernoulli(torch.index_select(self.data_rows, 0, self.idx_flat), out=x)
+            else:
+                torch.index_select(self.data_rows, 0, self.idx_flat, out=x)
+        else:
+            x = torch.bernoulli(self.x_in) if self.binarize else self.x_in
         self.opt.zero_grad(set_to_none=True)      # backward then installs the fused node's gradient buffers
         loss, RE, KL = self.model.calculate_loss((x, self.idx_in), self.beta, average=True, dataset=self.dataset)
         loss.backward(gradient=self._one)
@@ -63,19 +93,39 @@ class GraphedTrainStep:
 
     def _refresh(self, data, indices, beta):
         k = self._calls & 1
-        self._h_ev[k].synchronize()               # the upload issued two steps ago from this buffer is done
-        self.x_in.copy_(data.reshape(self.B, -1), non_blocking=True)
-        self.idx_in.copy_(indices.reshape(self.B, 1), non_blocking=True)
-        # same CPU-generator draw, with replacement, as the reference (models/BaseModel.py:245)
+        Cl = self.hi - self.lo
         a = self.model.args
-        hi_ = self._h_idx[k]
-        torch.randint(low=0, high=a.training_set_size, size=(a.number_components,), out=hi_)
-        self.rows[:self.hi - self.lo].copy_(hi_[self.lo:self.hi], non_blocking=True)
-        hs = self._h_scal[k]
+        if self.by_index is None:                 # once: are the loader's images the resident rows its indices name?
+            ii = indices.reshape(-1).to(self.ctl.device)
+            ok = bool(ii.numel() == self.B and int(ii.min()) >= 0 and int(ii.max()) < self.n_data)
+            self.by_index = ok and torch.equal(self.data_rows.index_select(0, ii),
+                                               data.reshape(self.B, -1).to(self.ctl.device, torch.float32))
+        self._ev_up[k].synchronize()              # the upload issued two steps ago from this host buffer is done
+        h = self._h_ctl[k]
+        # same CPU-generator draw, with replacement, as the reference (models/BaseModel.py:245)
+        if Cl == a.number_components:
+            torch.randint(low=0, high=a.training_set_size, size=(Cl,), out=h[:Cl])
+        else:
+            torch.randint(low=0, high=a.training_set_size, size=(a.number_components,), out=self._h_draw)
+            h[:Cl] = self._h_draw[self.lo:self.hi]
+        idx_on_device = indices.is_cuda
+        if not idx_on_device:
+            h[self._o_idx:self._o_scal] = indices.reshape(-1)
+        hs = h[self._o_scal:].view(torch.float32)
         hs[0] = float(beta)
-        self.opt.advance_graph_step(host_out=hs[1:])
-        self.scal.copy_(hs, non_blocking=True)
-        self._h_ev[k].record()
+        self.opt.advance_graph_step(host_out=hs[1:1 + self.ngroups])
+        main = torch.cuda.current_stream()
+        self._up.wait_event(self._ev_used[k])     # device staging block k was consumed two steps ago
+        with torch.cuda.stream(self._up):
+            self._d_ctl[k].copy_(h, non_blocking=True)
+            self._ev_up[k].record()
+        main.wait_event(self._ev_up[k])
+        self.ctl.copy_(self._d_ctl[k])
+        self._ev_used[k].record()
+        if idx_on_device:
+            self.idx_in.copy_(indices.reshape(self.B, 1))
+        if not self.by_index:
+            self.x_in.copy_(data.reshape(self.B, -1), non_blocking=True)
 
     def __call__(self, data, indices, beta):
         """One training step; returns a device tensor (loss, -RE, KL) valid until the next call."""

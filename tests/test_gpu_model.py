@@ -70,8 +70,11 @@ def test_no_cpu_fallback():
         ops.prior_lse_fwd(torch.zeros(2, 4), torch.zeros(3, 4), torch.zeros(4))
 
 
-def test_graphed_step_matches_eager():
-    """hipGraph replay of the whole step (evae/graph.py) == the same steps launched eagerly."""
+@pytest.mark.parametrize("feed", ["device_indices", "host_loader", "foreign_images"])
+def test_graphed_step_matches_eager(feed):
+    """hipGraph replay of the whole step (evae/graph.py) == the same steps launched eagerly.  `host_loader`: CPU batches
+    as a DataLoader yields them (the step gathers the images from the resident dataset by index); `foreign_images`:
+    batches that are NOT rows of the dataset (the step must notice and upload the images instead)."""
     from evae.graph import GraphedTrainStep
     from utils.optimizer import AdamNormGrad
     B, C, N = 32, 500, 2000
@@ -87,11 +90,18 @@ def test_graphed_step_matches_eager():
         runner = GraphedTrainStep(model, opt, dataset, B, False) if use_graph else None
         losses = []
         for it in range(7):
-            xb = torch.from_numpy(data[it * B:(it + 1) * B]).cuda()
-            ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1).cuda()
+            xb = torch.from_numpy(data[it * B:(it + 1) * B])
+            if feed == "foreign_images":
+                xb = 1.0 - xb
+            ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1)
             if runner is not None:
+                if feed != "host_loader":
+                    xb = xb.cuda()
+                if feed == "device_indices":
+                    ib = ib.cuda()
                 losses.append(runner(xb, ib, 0.5)[0].item())
             else:
+                xb, ib = xb.cuda(), ib.cuda()
                 opt.zero_grad()
                 loss, RE, KL = model.calculate_loss((xb, ib), 0.5, average=True, dataset=dataset)
                 loss.backward()
@@ -100,6 +110,7 @@ def test_graphed_step_matches_eager():
         results.append((losses, {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}))
         if runner is not None:
             assert runner.graph is not None                       # steps 4.. were replays
+            assert runner.by_index == (feed != "foreign_images")
     (l0, p0), (l1, p1) = results
     assert rel(np.asarray(l1), np.asarray(l0)) < 1e-5
     for k in p0:
