@@ -7,25 +7,56 @@
 
 namespace evae {
 
-constexpr int ANB = 32;  // blocks per tensor
+constexpr int ANB = 128;       // partial-sum slots per tensor
+constexpr int ACHUNK = 2048;   // elements per block: 256 threads x 2 float4 (tensors above ANB * ACHUNK take more)
+
+// elements per block for a tensor: a multiple of 1024 (float4 x 256 threads), at most ANB blocks per tensor
+__device__ __forceinline__ int64_t adam_chunk(int64_t numel) {
+  int64_t c = (numel + ANB - 1) / ANB;
+  c = (c + 1023) / 1024 * 1024;
+  return c < ACHUNK ? ACHUNK : c;
+}
 
 __global__ __launch_bounds__(256) void adam_sumsq_kernel(const evae_adam_tensor_t* __restrict__ ts,
                                                          float* __restrict__ part /* [nt][ANB] */) {
   __shared__ double red[4];
   const evae_adam_tensor_t t = ts[blockIdx.y];
-  const int64_t chunk = (t.numel + ANB - 1) / ANB;
+  const int64_t chunk = adam_chunk(t.numel);
   const int64_t beg = (int64_t)blockIdx.x * chunk;
+  if (beg >= t.numel) return;                    // this tensor needs fewer blocks than the grid is wide
   int64_t end = beg + chunk;
   if (end > t.numel) end = t.numel;
   double s = 0.0;
-  for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
-    const float g = t.grad[i];
-    s += (double)g * (double)g;
+  if ((reinterpret_cast<uintptr_t>(t.grad) & 15) == 0) {
+    const int64_t nv = (end - beg) >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(t.grad + beg);   // beg is a multiple of 1024
+    for (int64_t i = threadIdx.x; i < nv; i += 256) {
+      const float4 g = g4[i];
+      s += (double)g.x * (double)g.x + (double)g.y * (double)g.y + (double)g.z * (double)g.z + (double)g.w * (double)g.w;
+    }
+    for (int64_t i = beg + (nv << 2) + threadIdx.x; i < end; i += 256) {
+      const float g = t.grad[i];
+      s += (double)g * (double)g;
+    }
+  } else {
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
+      const float g = t.grad[i];
+      s += (double)g * (double)g;
+    }
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.y * ANB + blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+__device__ __forceinline__ void adam_one(float gr, float& p, float& m, float& v, float inv, float step_size, float beta1,
+                                         float omb1, float beta2, float omb2, float eps, float weight_decay) {
+  float g = gr * inv;
+  if (weight_decay != 0.f) g += weight_decay * p;
+  m = m * beta1 + omb1 * g;
+  v = v * beta2 + omb2 * g * g;
+  p = p - step_size * (m / (sqrtf(v) + eps));
 }
 
 __global__ __launch_bounds__(256) void adam_step_kernel(const evae_adam_tensor_t* __restrict__ ts,
@@ -34,23 +65,40 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const evae_adam_tensor_t
                                                         float beta1, float omb1, float beta2,
                                                         float omb2, float eps, float weight_decay) {
   const evae_adam_tensor_t t = ts[blockIdx.y];
-  const float step_size = step_size_dev ? step_size_dev[0] : step_size_host;
-  double tot = 0.0;
-  for (int i = 0; i < ANB; ++i) tot += (double)part[blockIdx.y * ANB + i];
-  const float inv = 1.0f / ((float)sqrt(tot) + 1e-7f);
-  const int64_t chunk = (t.numel + ANB - 1) / ANB;
+  const int64_t chunk = adam_chunk(t.numel);
   const int64_t beg = (int64_t)blockIdx.x * chunk;
+  if (beg >= t.numel) return;
   int64_t end = beg + chunk;
   if (end > t.numel) end = t.numel;
-  for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
-    float g = t.grad[i] * inv;
-    float p = t.param[i];
-    if (weight_decay != 0.f) g += weight_decay * p;
-    const float m = t.exp_avg[i] * beta1 + omb1 * g;
-    const float v = t.exp_avg_sq[i] * beta2 + omb2 * g * g;
-    t.exp_avg[i] = m;
-    t.exp_avg_sq[i] = v;
-    t.param[i] = p - step_size * (m / (sqrtf(v) + eps));
+  const float step_size = step_size_dev ? step_size_dev[0] : step_size_host;
+  const int nparts = (int)((t.numel + chunk - 1) / chunk);
+  double tot = 0.0;                              // same order in every block: every block sees the same norm
+  for (int i = 0; i < nparts; ++i) tot += (double)part[blockIdx.y * ANB + i];
+  const float inv = 1.0f / ((float)sqrt(tot) + 1e-7f);
+  const bool vec = ((reinterpret_cast<uintptr_t>(t.grad) | reinterpret_cast<uintptr_t>(t.param) |
+                     reinterpret_cast<uintptr_t>(t.exp_avg) | reinterpret_cast<uintptr_t>(t.exp_avg_sq)) & 15) == 0;
+  int64_t done = beg;
+  if (vec) {
+    const int64_t nv = (end - beg) >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(t.grad + beg);
+    float4* p4 = reinterpret_cast<float4*>(t.param + beg);
+    float4* m4 = reinterpret_cast<float4*>(t.exp_avg + beg);
+    float4* v4 = reinterpret_cast<float4*>(t.exp_avg_sq + beg);
+    for (int64_t i = threadIdx.x; i < nv; i += 256) {
+      const float4 g = g4[i];
+      float4 p = p4[i], m = m4[i], v = v4[i];
+      adam_one(g.x, p.x, m.x, v.x, inv, step_size, beta1, omb1, beta2, omb2, eps, weight_decay);
+      adam_one(g.y, p.y, m.y, v.y, inv, step_size, beta1, omb1, beta2, omb2, eps, weight_decay);
+      adam_one(g.z, p.z, m.z, v.z, inv, step_size, beta1, omb1, beta2, omb2, eps, weight_decay);
+      adam_one(g.w, p.w, m.w, v.w, inv, step_size, beta1, omb1, beta2, omb2, eps, weight_decay);
+      m4[i] = m; v4[i] = v; p4[i] = p;
+    }
+    done = beg + (nv << 2);
+  }
+  for (int64_t i = done + threadIdx.x; i < end; i += 256) {
+    float p = t.param[i], m = t.exp_avg[i], v = t.exp_avg_sq[i];
+    adam_one(t.grad[i], p, m, v, inv, step_size, beta1, omb1, beta2, omb2, eps, weight_decay);
+    t.exp_avg[i] = m; t.exp_avg_sq[i] = v; t.param[i] = p;
   }
 }
 
@@ -66,7 +114,6 @@ extern "C" int evae_adam_normgrad_step(const evae_adam_tensor_t* tensors, int n_
                                        int64_t max_numel, int step, double lr, double beta1, double beta2,
                                        double eps, double weight_decay, const float* step_size_dev,
                                        void* ws, size_t ws_bytes, evae_stream_t stream_) {
-  (void)max_numel;
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(n_tensors >= 0 && step >= 1, "adam_normgrad_step: bad arguments");
   if (n_tensors == 0) return EVAE_OK;
@@ -79,10 +126,14 @@ extern "C" int evae_adam_normgrad_step(const evae_adam_tensor_t* tensors, int n_
   const double bc2 = 1.0 - pow(beta2, step);
   const float step_size = (float)(lr * sqrt(bc2) / bc1);
   float* part = (float*)ws;
-  adam_sumsq_kernel<<<dim3(ANB, n_tensors), 256, 0, stream>>>(tensors, part);
+  // grid.x = an upper bound on the blocks any tensor needs (every tensor's chunk is >= ACHUNK and it never needs more
+  // than ANB blocks); max_numel <= 0: unknown, assume the worst
+  int gx = ANB;
+  if (max_numel > 0 && (max_numel + ACHUNK - 1) / ACHUNK < ANB) gx = (int)((max_numel + ACHUNK - 1) / ACHUNK);
+  adam_sumsq_kernel<<<dim3(gx, n_tensors), 256, 0, stream>>>(tensors, part);
   int rc = check_launch("adam_sumsq");
   if (rc) return rc;
-  adam_step_kernel<<<dim3(ANB, n_tensors), 256, 0, stream>>>(tensors, part, step_size, step_size_dev, (float)beta1, (float)(1.0 - beta1),
+  adam_step_kernel<<<dim3(gx, n_tensors), 256, 0, stream>>>(tensors, part, step_size, step_size_dev, (float)beta1, (float)(1.0 - beta1),
                                                            (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay);
   return check_launch("adam_step");
 }

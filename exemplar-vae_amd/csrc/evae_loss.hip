@@ -114,6 +114,45 @@ __global__ void bernoulli_ll_bwd_kernel(const float* __restrict__ x, const float
   dmean[i] = inside ? dout[i / D] * (xv / p - (1.0f - xv) / (1.0f - p)) : 0.f;
 }
 
+// Bernoulli log-likelihood backward through the sigmoid that produced `mean`: d/dpre = d/dmean * mean * (1 - mean)
+__global__ void bernoulli_sigmoid_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                             const float* __restrict__ dout, int B, int D,
+                                             float* __restrict__ dpre) {
+  const size_t n = (size_t)B * D;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float mv = mean[i];
+  const bool inside = (mv >= kMinEps) && (mv <= kMaxEps);
+  const float p = fminf(fmaxf(mv, kMinEps), kMaxEps);
+  const float xv = x[i];
+  const float dm = inside ? dout[i / D] * (xv / p - (1.0f - xv) / (1.0f - p)) : 0.f;
+  dpre[i] = dm * mv * (1.0f - mv);
+}
+
+// reparam_logq_bwd with a second upstream gradient of z (dz + dz2) and the Hardtanh(lo, hi) that produced logvar
+// from lv_pre folded in: dlogvar comes out as the gradient of the pre-activation
+__global__ void reparam_logq_bwd_ht_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                           const float* __restrict__ eps, const float* __restrict__ z,
+                                           const float* __restrict__ dz, const float* __restrict__ dz2,
+                                           const float* __restrict__ dlogq, const float* __restrict__ lv_pre,
+                                           float lo, float hi, int B, int zdim, float* __restrict__ dmu,
+                                           float* __restrict__ dlv_pre) {
+  const size_t n = (size_t)B * zdim;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int row = (int)(i / zdim);
+  const float m = mu[i], lv = logvar[i];
+  const float var = expf(lv), sd = expf(0.5f * lv);
+  const float d = z[i] - m;
+  const float gq = dlogq ? dlogq[row] : 0.f;
+  const float up = (dz ? dz[i] : 0.f) + (dz2 ? dz2[i] : 0.f);
+  const float gz = up + gq * (-(d / var));
+  dmu[i] = gz + gq * (d / var);
+  const float dl = gz * eps[i] * sd * 0.5f + gq * (-0.5f) * (1.0f - d * d / var);
+  const float pre = lv_pre[i];
+  dlv_pre[i] = (pre > lo && pre < hi) ? dl : 0.f;
+}
+
 // ELBO assembly on [B] rows in one launch: KL_i = logq_i - logp_i, loss_i = beta*KL_i - RE_i, and the three
 // batch means (models/BaseModel.py:71-75).  beta comes from device memory when the step is graph-captured.
 __global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* __restrict__ RE, const float* __restrict__ logq,
@@ -218,6 +257,27 @@ extern "C" int evae_bernoulli_ll_bwd(const float* x, const float* mean, const fl
   EVAE_REQUIRE(x && mean && dout && dmean, "bernoulli_ll_bwd: null pointer");
   bernoulli_ll_bwd_kernel<<<ELT_GRID((size_t)B * D), 256, 0, (hipStream_t)s>>>(x, mean, dout, B, D, dmean);
   return check_launch("bernoulli_ll_bwd");
+}
+
+extern "C" int evae_bernoulli_sigmoid_bwd(const float* x, const float* mean, const float* dout, int B, int D,
+                                          float* dpre, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && D > 0, "bernoulli_sigmoid_bwd: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(x && mean && dout && dpre, "bernoulli_sigmoid_bwd: null pointer");
+  bernoulli_sigmoid_bwd_kernel<<<ELT_GRID((size_t)B * D), 256, 0, (hipStream_t)s>>>(x, mean, dout, B, D, dpre);
+  return check_launch("bernoulli_sigmoid_bwd");
+}
+
+extern "C" int evae_reparam_logq_bwd_hardtanh(const float* mu, const float* logvar, const float* eps, const float* z,
+                                              const float* dz, const float* dz2, const float* dlogq,
+                                              const float* lv_pre, float lo, float hi, int B, int zdim, float* dmu,
+                                              float* dlv_pre, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && zdim > 0, "reparam_logq_bwd_hardtanh: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(mu && logvar && eps && z && lv_pre && dmu && dlv_pre, "reparam_logq_bwd_hardtanh: null pointer");
+  reparam_logq_bwd_ht_kernel<<<ELT_GRID((size_t)B * zdim), 256, 0, (hipStream_t)s>>>(mu, logvar, eps, z, dz, dz2, dlogq, lv_pre,
+                                                                                      lo, hi, B, zdim, dmu, dlv_pre);
+  return check_launch("reparam_logq_bwd_hardtanh");
 }
 
 extern "C" int evae_elbo_fwd(const float* RE, const float* logq, const float* logp, const float* beta_dev,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "evae_conv2d_cl_bwd_weight": (_i, [_p, _p, _p, _i, _p, _p, _p, _z, _p]),
     "evae_reparam_logq_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_reparam_logq_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
+    "evae_reparam_logq_bwd_hardtanh": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p]),
     "evae_log_normal_diag_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_log_normal_diag_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
     "evae_elbo_fwd": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p, _p]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "evae_step_stats_add": (_i, [_p, _p, _p, _p, _p, _p]),
     "evae_bernoulli_ll_fwd": (_i, [_p, _p, _i, _i, _p, _p]),
     "evae_bernoulli_ll_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+    "evae_bernoulli_sigmoid_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_adam_normgrad_workspace_bytes": (_z, [_i]),
     "evae_adam_normgrad_step": (_i, [_p, _i, _l, _i, _d, _d, _d, _d, _d, _p, _p, _z, _p]),
 }

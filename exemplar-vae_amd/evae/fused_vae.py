@@ -291,10 +291,8 @@ class VaeExactLoss(torch.autograd.Function):
                 k.bwd_data(dq2, w2h, dq2.data_ptr() + 4 * H, w2g, Cl, H, 2 * H, H, A1, s1, dq1, dq1.data_ptr() + 4 * H, 2 * H,
                            st=sst, ws_name="dgrad_side")
         # ---- reconstruction term through the decoder (main stream, concurrently)
-        dxm = torch.empty((B, D), **f32)
-        _lib.check(lib.evae_bernoulli_ll_bwd(_vp(x), _vp(xmean), _vp(cRE), B, D, _vp(dxm), k.st), "bernoulli_bwd")
-        dpx = torch.empty((B, D), **f32)
-        _lib.check(lib.evae_act_bwd(_vp(dxm), _vp(xmean), B * D, ACT_SIGMOID, 0.0, 0.0, _vp(dpx), k.st), "act_bwd")
+        dpx = torch.empty((B, D), **f32)               # through the Bernoulli log-likelihood and the sigmoid head at once
+        _lib.check(lib.evae_bernoulli_sigmoid_bwd(_vp(x), _vp(xmean), _vp(cRE), B, D, _vp(dpx), k.st), "bernoulli_sigmoid_bwd")
         dp2 = torch.empty((B, 2 * H), **f32)                              # [dh | dg] of decoder layer 2
         k.bwd_data(dpx, wp, None, None, B, D, D, H, D2, sd2, dp2, dp2.data_ptr() + 4 * H, 2 * H)
         dp1 = torch.empty((B, 2 * H), **f32)
@@ -302,14 +300,12 @@ class VaeExactLoss(torch.autograd.Function):
         dz = torch.empty((B, Z), **f32)
         k.bwd_data(dp1, d1h, dp1.data_ptr() + 4 * H, d1g, B, H, 2 * H, Z, None, None, dz, None, Z)
         main.wait_event(dz_ready)
-        dz.add_(dzp)
-        # ---- reparameterisation + log q
-        dlogvar = torch.empty((B, Z), **f32)
+        # ---- reparameterisation + log q (+ the prior's dz', + the Hardtanh of the log-variance head): one launch
         z_mean = mean_all[Cl:]
-        _lib.check(lib.evae_reparam_logq_bwd(_vp(z_mean), _vp(logvar), _vp(eps), _vp(z), _vp(dz), _vp(cKL), B, Z,
-                                             _vp(dmean_all.data_ptr() + 4 * Cl * Z), _vp(dlogvar), k.st), "reparam_bwd")
         dlvp = torch.empty((B, Z), **f32)
-        _lib.check(lib.evae_act_bwd(_vp(dlogvar), _vp(lv_pre), B * Z, ACT_HARDTANH, -6.0, 2.0, _vp(dlvp), k.st), "act_bwd")
+        _lib.check(lib.evae_reparam_logq_bwd_hardtanh(_vp(z_mean), _vp(logvar), _vp(eps), _vp(z), _vp(dz), _vp(dzp), _vp(cKL),
+                                                      _vp(lv_pre), -6.0, 2.0, B, Z, _vp(dmean_all.data_ptr() + 4 * Cl * Z),
+                                                      _vp(dlvp), k.st), "reparam_bwd")
         # ---- heads and encoder layer 2, batch rows
         off = 4 * Cl
         k.bwd_data(dmean_all.data_ptr() + off * Z, wm, dlvp, wl, B, Z, Z, H, A2.data_ptr() + off * H,

@@ -159,6 +159,7 @@ class GraphedTrainStep:
                 try:
                     with torch.cuda.graph(graph, capture_error_mode=mode):
                         self._body()
+                    getattr(self.opt, 'finish_capture', lambda: None)()
                     self.graph = graph
                 except Exception as e:           # an op of this model that cannot be captured: eager from here on
                     import sys

@@ -620,6 +620,15 @@ def step_stats_add(loss, re, kl, step3, totals3=None):
     return step3
 
 
+def adam_flush_tables(table_caches):
+    """Upload the pointer tables that adam_normgrad_step prepared while a hipGraph was being captured (call after the
+    capture has ended and before the first replay)."""
+    for tc in table_caches:
+        if tc.get("pending"):
+            tc["table"].copy_(tc["pinned"])
+            tc["pending"] = False
+
+
 def adam_normgrad_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps, weight_decay,
                        table_cache=None, step_size_dev=None):
     """One multi-tensor AdamNormGrad update (utils/optimizer.py:32-80).  `table_cache` (a dict) lets the
@@ -650,9 +659,11 @@ def adam_normgrad_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, be
             arr[i].numel = params[i].numel()
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         if torch.cuda.is_current_stream_capturing():
-            # becomes a memcpy node that re-reads the (persistent, from now on unchanged) pinned bytes
+            # the captured launches read the table at replay time and its content (the addresses of this capture's
+            # buffers) never changes afterwards: keep the bytes in the pinned buffer and let the caller upload them ONCE
+            # after the capture (adam_flush_tables) instead of capturing a memcpy node that every replay would pay for
             table_cache["pinned"].copy_(host)
-            table.copy_(table_cache["pinned"], non_blocking=True)
+            table_cache["pending"] = True
         else:
             table.copy_(host)          # pageable source: staged before the call returns, so it cannot race
         table_cache["key"] = key

@@ -55,6 +55,10 @@ class AdamNormGrad(Optimizer):
             else:   # fill kernel (value travels as a kernel argument: no host buffer to race with later steps)
                 self._graph_step_size[gi].fill_(v)
 
+    def finish_capture(self):
+        """After the capture of a step that contained step(_captured=True): upload the pointer tables of its launches."""
+        ops.adam_flush_tables(self._tables.values())
+
     @torch.no_grad()
     def step(self, closure=None, _captured=False):
         loss = None

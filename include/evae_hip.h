@@ -222,6 +222,12 @@ int evae_reparam_logq_fwd(const float* mu, const float* logvar, const float* eps
 int evae_reparam_logq_bwd(const float* mu, const float* logvar, const float* eps, const float* z,
                           const float* dz, const float* dlogq, int B, int zdim,
                           float* dmu, float* dlogvar, evae_stream_t stream);
+/* The same with a second upstream gradient of z (dz + dz2, either may be NULL) and the Hardtanh(lo, hi) of the
+ * log-variance head (models/VAE.py:25-26) folded in: dlv_pre is the gradient of the head's pre-activation lv_pre. */
+int evae_reparam_logq_bwd_hardtanh(const float* mu, const float* logvar, const float* eps, const float* z,
+                                   const float* dz, const float* dz2, const float* dlogq, const float* lv_pre,
+                                   float lo, float hi, int B, int zdim, float* dmu, float* dlv_pre,
+                                   evae_stream_t stream);
 int evae_log_normal_diag_fwd(const float* x, const float* mu, const float* logvar, int B, int zdim,
                              float* out, evae_stream_t stream);
 int evae_log_normal_diag_bwd(const float* x, const float* mu, const float* logvar, const float* dout,
@@ -244,6 +250,9 @@ int evae_bernoulli_ll_fwd(const float* x, const float* mean, int B, int D, float
                           evae_stream_t stream);
 int evae_bernoulli_ll_bwd(const float* x, const float* mean, const float* dout, int B, int D,
                           float* dmean, evae_stream_t stream);
+/* d/dpre when mean = sigmoid(pre) (the p_x_mean head of models/BaseModel.py:28-29): the two steps in one launch */
+int evae_bernoulli_sigmoid_bwd(const float* x, const float* mean, const float* dout, int B, int D,
+                               float* dpre, evae_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * AdamNormGrad (utils/optimizer.py:32-80): g <- g/(||g||_2 + 1e-7) per tensor, then Adam with eps

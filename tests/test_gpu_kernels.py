@@ -385,3 +385,56 @@ def test_adam_normgrad_golden(ops, golden):
     for i in range(4):
         assert rel(ms[i].cpu().numpy(), g["m_%d" % i]) < 1e-6
         assert rel(vs[i].cpu().numpy(), g["v_%d" % i]) < 1e-6
+
+
+def test_adam_normgrad_ragged_sizes_vs_oracle(ops):
+    """Tensor sizes around the kernel's block / vector boundaries (1 element, odd counts, one above ANB * ACHUNK elements,
+    a weight-decay run) against the numpy restatement of reference utils/optimizer.py:32-80."""
+    rs = np.random.RandomState(21)
+    sizes = [1, 7, 1023, 2049, 300 * 784, 128 * 2048 + 5, 40]
+    for wd in (0.0, 1e-3):
+        p_np = [rs.standard_normal(n).astype(np.float32) for n in sizes]
+        m_np = [np.zeros(n, np.float32) for n in sizes]; v_np = [np.zeros(n, np.float32) for n in sizes]
+        ps = [dev(a.copy()) for a in p_np]
+        ms = [torch.zeros_like(p) for p in ps]; vs = [torch.zeros_like(p) for p in ps]
+        for step in range(1, 4):
+            g_np = [(rs.standard_normal(n) * 10.0 ** rs.uniform(-3, 1)).astype(np.float32) for n in sizes]
+            ops.adam_normgrad_step(ps, [dev(g) for g in g_np], ms, vs, step, 5e-4, 0.9, 0.999, 1e-8, wd)
+            for i in range(len(sizes)):
+                p_np[i], m_np[i], v_np[i] = orc.adam_normgrad_step(p_np[i], g_np[i], m_np[i], v_np[i], step, weight_decay=wd)
+                assert rel(ps[i].cpu().numpy(), p_np[i]) < 1e-6, (sizes[i], step)
+                assert rel(ms[i].cpu().numpy(), m_np[i]) < 1e-5, (sizes[i], step)
+                assert rel(vs[i].cpu().numpy(), v_np[i]) < 1e-5, (sizes[i], step)
+
+
+def test_fused_elementwise_backward_launches_match_their_parts():
+    """evae_bernoulli_sigmoid_bwd == evae_bernoulli_ll_bwd then evae_act_bwd(sigmoid);
+    evae_reparam_logq_bwd_hardtanh == (dz + dz2) -> evae_reparam_logq_bwd -> evae_act_bwd(hardtanh)."""
+    import ctypes as C
+    from evae import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    rs = np.random.RandomState(22)
+    B, D, zd = 37, 784, 40
+    xm = dev((1 / (1 + np.exp(-rs.standard_normal((B, D)) * 8))).astype(np.float32))     # saturates: clamp region hit
+    xb = dev((rs.random_sample((B, D)) < 0.3).astype(np.float32))
+    c = dev(rs.standard_normal(B).astype(np.float32))
+    d1 = torch.empty_like(xm); d2 = torch.empty_like(xm); fused = torch.empty_like(xm)
+    _lib.check(lib.evae_bernoulli_ll_bwd(vp(xb), vp(xm), vp(c), B, D, vp(d1), st), "a")
+    _lib.check(lib.evae_act_bwd(vp(d1), vp(xm), B * D, 1, 0.0, 0.0, vp(d2), st), "b")
+    _lib.check(lib.evae_bernoulli_sigmoid_bwd(vp(xb), vp(xm), vp(c), B, D, vp(fused), st), "c")
+    assert rel(fused.cpu().numpy(), d2.cpu().numpy()) < 1e-6
+    mu, eps, dz, dz2 = (dev(rs.standard_normal((B, zd)).astype(np.float32)) for _ in range(4))
+    pre = dev(rs.uniform(-8, 4, (B, zd)).astype(np.float32))            # part of it outside Hardtanh(-6, 2)
+    lv = pre.clamp(-6.0, 2.0)
+    z = mu + eps * torch.exp(0.5 * lv)
+    dmu_a = torch.empty_like(mu); dlv_a = torch.empty_like(mu); dpre_a = torch.empty_like(mu)
+    _lib.check(lib.evae_reparam_logq_bwd(vp(mu), vp(lv), vp(eps), vp(z), vp(dz + dz2), vp(c), B, zd, vp(dmu_a), vp(dlv_a), st), "d")
+    _lib.check(lib.evae_act_bwd(vp(dlv_a), vp(pre), B * zd, 2, -6.0, 2.0, vp(dpre_a), st), "e")
+    dmu_b = torch.empty_like(mu); dpre_b = torch.empty_like(mu)
+    _lib.check(lib.evae_reparam_logq_bwd_hardtanh(vp(mu), vp(lv), vp(eps), vp(z), vp(dz), vp(dz2), vp(c), vp(pre), -6.0, 2.0,
+                                                  B, zd, vp(dmu_b), vp(dpre_b), st), "f")
+    assert rel(dmu_b.cpu().numpy(), dmu_a.cpu().numpy()) < 1e-6
+    assert rel(dpre_b.cpu().numpy(), dpre_a.cpu().numpy()) < 1e-6
+    assert float((dpre_b == 0).float().mean()) > 0.1                    # the clipped entries really are in the sample
