@@ -607,18 +607,36 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
   }
 }
 
-// dz[e] = inv_sigma_k * sum_split dz_part[split][e]: 64 outputs x 4 split-lanes per block
-__global__ __launch_bounds__(1024) void prior_bwd_finish_dz_kernel(const float* __restrict__ dz_part, int nsplit,
-                                                                   int n, int zdim,
-                                                                   const float* __restrict__ log_var,
-                                                                   float* __restrict__ dz) {
+// Both reductions that follow prior_bwd_kernel, in one launch.
+//   blocks [0, nb_dz): dz[e] = exp(-logvar/2) * sum over splits of dz_part (16 split-lanes per output, fixed assignment
+//                      => fixed order);
+//   the blocks after:  dlogvar[k] = 0.5 * sum_blocks dV[k] - 0.5 * sum_blocks gwsum, one wave per k.
+__global__ __launch_bounds__(1024) void prior_bwd_finish_kernel(const float* __restrict__ dz_part, int nsplit, int n,
+                                                                int zdim, const float* __restrict__ log_var,
+                                                                float* __restrict__ dz, int nb_dz,
+                                                                const float* __restrict__ dlv_part, int nblocks,
+                                                                float* __restrict__ dlogvar) {
   __shared__ float red[16][64];
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6;      // 16 split-lanes per output, fixed assignment => fixed order
+  const int lane = threadIdx.x & 63;
+  const int part = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= nb_dz) {
+    const int k = ((int)blockIdx.x - nb_dz) * 16 + part;
+    if (k >= zdim) return;
+    float sv = 0.f, sg = 0.f;
+    for (int b = lane; b < nblocks; b += 64) {
+      sv += dlv_part[(size_t)b * (zdim + 1) + k];
+      sg += dlv_part[(size_t)b * (zdim + 1) + zdim];
+    }
+    sv = wave_sum(sv);
+    sg = wave_sum(sg);
+    if (lane == 0) dlogvar[k] = 0.5f * sv - 0.5f * sg;
+    return;
+  }
+  const int e = blockIdx.x * 64 + lane;
   float s = 0.f;
   if (e < n)
     for (int r = part; r < nsplit; r += 16) s += dz_part[(size_t)r * n + e];
-  red[part][threadIdx.x & 63] = s;
+  red[part][lane] = s;
   __syncthreads();
   if (part == 0 && e < n) {
     float t = 0.f;
@@ -626,20 +644,6 @@ __global__ __launch_bounds__(1024) void prior_bwd_finish_dz_kernel(const float* 
     for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
     dz[e] = t * expf(-0.5f * log_var[e % zdim]);
   }
-}
-
-// dlogvar[k] = 0.5 * sum_blocks dV[k] - 0.5 * sum_blocks gwsum: one wave per k
-__global__ __launch_bounds__(64) void prior_bwd_finish_dlv_kernel(const float* __restrict__ dlv_part, int nblocks,
-                                                                  int zdim, float* __restrict__ dlogvar) {
-  const int k = blockIdx.x, lane = threadIdx.x;
-  float sv = 0.f, sg = 0.f;
-  for (int b = lane; b < nblocks; b += 64) {
-    sv += dlv_part[(size_t)b * (zdim + 1) + k];
-    sg += dlv_part[(size_t)b * (zdim + 1) + zdim];
-  }
-  sv = wave_sum(sv);
-  sg = wave_sum(sg);
-  if (lane == 0) dlogvar[k] = 0.5f * sv - 0.5f * sg;
 }
 
 __global__ void zero_kernel(float* p, size_t n) {
@@ -792,9 +796,8 @@ extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, i
   });
   int rc = check_launch("prior_bwd_kernel");
   if (rc) return rc;
-  prior_bwd_finish_dz_kernel<<<cdiv(B * zdim, 64), 1024, 0, stream>>>(dz_part, ns, B * zdim, zdim, log_var, dz);
-  rc = check_launch("prior_bwd_finish_dz_kernel");
-  if (rc) return rc;
-  prior_bwd_finish_dlv_kernel<<<zdim, 64, 0, stream>>>(dlv_part, ns * nq, zdim, dlogvar);
-  return check_launch("prior_bwd_finish_dlv_kernel");
+  const int nb_dz = cdiv(B * zdim, 64);
+  prior_bwd_finish_kernel<<<nb_dz + cdiv(zdim, 16), 1024, 0, stream>>>(dz_part, ns, B * zdim, zdim, log_var, dz, nb_dz,
+                                                                       dlv_part, ns * nq, dlogvar);
+  return check_launch("prior_bwd_finish_kernel");
 }

@@ -285,6 +285,8 @@ class VaeExactLoss(torch.autograd.Function):
                 if Cl > 0:
                     dmean_all[:Cl].mul_(float(dist.get_world_size()))
             dz_ready.record()
+            g_plv = gslot("plv", 1)
+            torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
             if Cl > 0:
                 k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H,
                            st=sst, ws_name="dgrad_side")
@@ -339,8 +341,6 @@ class VaeExactLoss(torch.autograd.Function):
         g_w1 = gslot("w1", 2 * H, D); g_b1 = gslot("b1", 2 * H)
         k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)
         main.wait_stream(side)
-        g_plv = gslot("plv", 1)
-        torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
         ctx.bufs = None
         grads = (g_plv, g_wp, g_bp, g_w1[:H], g_b1[:H], g_w1[H:], g_b1[H:], g_w2[:H], g_b2[:H], g_w2[H:], g_b2[H:],
                  g_wm, g_bm, g_wl, g_bl, g_d1[:H], g_e1[:H], g_d1[H:], g_e1[H:], g_d2[:H], g_e2[:H], g_d2[H:], g_e2[H:])
