@@ -153,6 +153,60 @@ __global__ void reparam_logq_bwd_ht_kernel(const float* __restrict__ mu, const f
   dlv_pre[i] = (pre > lo && pre < hi) ? dl : 0.f;
 }
 
+// ---- head of a training step: batch gather + dynamic binarisation + eps, one launch ---------------------------------
+// Counter-based generator (Philox4x32-10): element e of stream s at step t always gets the same 128 random bits for a
+// given seed, whatever the launch geometry -- a replayed hipGraph only needs the step counter in device memory.
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }          // [0, 1)
+__device__ __forceinline__ float u01_open(uint32_t r) { return (float)((r >> 8) + 1u) * 5.9604644775390625e-8f; }  // (0, 1]
+
+__global__ __launch_bounds__(256) void batch_prologue_kernel(const float* __restrict__ data, int64_t ldd,
+                                                             const int64_t* __restrict__ idx, int B, int D, int binarize,
+                                                             const int64_t* __restrict__ seed_ctr, float* __restrict__ x_out,
+                                                             int64_t ldx, float* __restrict__ eps_out, int zdim,
+                                                             int64_t nq_img) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t seed = (uint64_t)seed_ctr[0], step = (uint64_t)seed_ctr[1];
+  const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+  if (t < nq_img) {                                   // four consecutive elements of the flattened [B x D] batch
+    const int64_t e0 = t * 4, n = (int64_t)B * D;
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (binarize) r = philox4x32(make_uint4((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)step, (uint32_t)(step >> 32) << 1), key);
+    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t e = e0 + j;
+      if (e >= n) break;
+      const int b = (int)(e / D), d = (int)(e - (int64_t)b * D);
+      const float p = data[idx[b] * ldd + d];
+      x_out[(int64_t)b * ldx + d] = binarize ? (u01(rr[j]) < p ? 1.0f : 0.0f) : p;
+    }
+    return;
+  }
+  if (eps_out == nullptr) return;
+  const int64_t q = t - nq_img, e0 = q * 4, n = (int64_t)B * zdim;    // four standard normals (two Box-Muller pairs)
+  if (e0 >= n) return;
+  const uint4 r = philox4x32(make_uint4((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)step, ((uint32_t)(step >> 32) << 1) | 1u), key);
+  const float r0 = sqrtf(-2.0f * logf(u01_open(r.x))), r1 = sqrtf(-2.0f * logf(u01_open(r.z)));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u01(r.y), &s0, &c0);
+  sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
+  const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (e0 + j < n) eps_out[e0 + j] = v[j];
+}
+
 // ELBO assembly on [B] rows in one launch: KL_i = logq_i - logp_i, loss_i = beta*KL_i - RE_i, and the three
 // batch means (models/BaseModel.py:71-75).  beta comes from device memory when the step is graph-captured.
 __global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* __restrict__ RE, const float* __restrict__ logq,
@@ -257,6 +311,20 @@ extern "C" int evae_bernoulli_ll_bwd(const float* x, const float* mean, const fl
   EVAE_REQUIRE(x && mean && dout && dmean, "bernoulli_ll_bwd: null pointer");
   bernoulli_ll_bwd_kernel<<<ELT_GRID((size_t)B * D), 256, 0, (hipStream_t)s>>>(x, mean, dout, B, D, dmean);
   return check_launch("bernoulli_ll_bwd");
+}
+
+extern "C" int evae_batch_prologue(const float* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
+                                   const int64_t* seed_ctr, float* x_out, int64_t ldx, float* eps_out, int zdim,
+                                   evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && D > 0 && zdim >= 0 && ldd >= D && ldx >= D, "batch_prologue: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(data && idx && x_out && seed_ctr, "batch_prologue: null pointer");
+  EVAE_REQUIRE(eps_out == nullptr || zdim > 0, "batch_prologue: eps_out needs zdim > 0");
+  const int64_t nq_img = ((int64_t)B * D + 3) / 4;
+  const int64_t nq_eps = eps_out ? ((int64_t)B * zdim + 3) / 4 : 0;
+  batch_prologue_kernel<<<(unsigned)cdiv(nq_img + nq_eps, (int64_t)256), 256, 0, (hipStream_t)s>>>(
+      data, ldd, idx, B, D, binarize, seed_ctr, x_out, ldx, eps_out, zdim, nq_img);
+  return check_launch("batch_prologue");
 }
 
 extern "C" int evae_bernoulli_sigmoid_bwd(const float* x, const float* mean, const float* dout, int B, int D,

@@ -69,6 +69,7 @@ SIGNATURES = {
     "evae_elbo_bwd": (_i, [_p, _i, _p, _i, _p, _i, _p, _f, _i, _p, _p, _p, _p]),
     "evae_step_stats_add": (_i, [_p, _p, _p, _p, _p, _p]),
     "evae_bernoulli_ll_fwd": (_i, [_p, _p, _i, _i, _p, _p]),
+    "evae_batch_prologue": (_i, [_p, _l, _p, _i, _i, _i, _p, _p, _l, _p, _i, _p]),
     "evae_bernoulli_ll_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_bernoulli_sigmoid_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_adam_normgrad_workspace_bytes": (_z, [_i]),

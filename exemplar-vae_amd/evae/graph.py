@@ -9,9 +9,10 @@ batch, beta and AdamNormGrad's bias-corrected step sizes.  The host writes a pin
 stream uploads it ahead of time and the step's stream only runs a device-to-device copy in front of the graph launch.
 The batch images themselves are rows of the HBM-resident dataset: the graph gathers (and binarises) them by index, so
 no image bytes cross PCIe (checked once against the loader's first batch; a loader that hands out other images gets
-them uploaded instead).  eps and the dynamic binarisation come from the CUDA generator inside the graph (torch
-registers it with the capture, so every replay advances the Philox offset).  RCCL collectives of the sharded prior
-are captured too.
+them uploaded instead).  The gather, the dynamic binarisation and the eps of the fused `vae` step are one launch of a
+counter-based generator (evae_batch_prologue: seed = torch's seed when the runner is built, counter = step number, both
+in the control block); whatever else draws random numbers uses the CUDA generator, which torch registers with the
+capture so that every replay advances its Philox offset.  RCCL collectives of the sharded prior are captured too.
 """
 import torch
 
@@ -36,17 +37,20 @@ class GraphedTrainStep:
         self.data_rows = self.data_ext[:self.n_data]
         self.stage_rows = self.data_ext[self.n_data:self.n_data + self.B]      # where the fused step wants the batch
         # Everything that varies between steps is ONE int64 control block in static device memory:
-        #   [exemplar rows (Cl) | staging rows (B, constant) | batch dataset indices (B) | beta, Adam step sizes (fp32)]
+        #   [exemplar rows (Cl) | staging rows (B, constant) | batch dataset indices (B) | generator seed, step counter |
+        #    beta, Adam step sizes (fp32)]
         # The host fills a pinned copy (double-buffered), a copy stream uploads it ahead of time into a device staging
         # block, and the step's own stream only runs one device-to-device copy in front of the graph launch -- it never
         # waits for a DMA engine or for the host.
         self.ngroups = len(optimizer.param_groups)
         nsc = 1 + self.ngroups
-        self._o_idx, self._o_scal = Cl + self.B, Cl + 2 * self.B
+        self._o_idx, self._o_seed = Cl + self.B, Cl + 2 * self.B
+        self._o_scal = self._o_seed + 2
         words = self._o_scal + (nsc + 1) // 2
         self.ctl = torch.zeros(words, dtype=torch.int64, device=dev)
         self.rows = self.ctl[:self._o_idx]
-        self.idx_flat = self.ctl[self._o_idx:self._o_scal]
+        self.idx_flat = self.ctl[self._o_idx:self._o_seed]
+        self.seed_ctr = self.ctl[self._o_seed:self._o_scal]
         self.idx_in = self.idx_flat.view(self.B, 1)
         self.scal = self.ctl[self._o_scal:].view(torch.float32)[:nsc]
         self.beta = self.scal[0:1].reshape(())
@@ -61,6 +65,14 @@ class GraphedTrainStep:
         self._ev_up = [torch.cuda.Event() for _ in range(2)]             # upload k finished (host buffer k reusable)
         self._ev_used = [torch.cuda.Event() for _ in range(2)]           # device staging k consumed by the step stream
         self.by_index = None      # True once the loader's images are known to be rows of the resident dataset
+        # by-index batches are gathered, binarised and given their eps by ONE launch with a counter-based generator
+        # (evae_batch_prologue); the seed is torch's at construction time, the counter is the step number
+        self.seed = int(torch.initial_seed())
+        if model._sharded() and getattr(a, 'shard_batch', False):
+            # data-parallel batches: every rank needs its own noise (replicated batches need the SAME noise on every rank)
+            self.seed += 0x9E3779B97F4A7C15 * (shard.world()[0] + 1)
+        self.seed &= 0x7FFFFFFFFFFFFFFF
+        self.eps_buf = torch.zeros((self.B, int(a.z1_size)), device=dev) if a.model_name == 'vae' else None
         self._one = torch.ones((), device=dev)
         self.out = torch.zeros(3, device=dev)       # (loss, -RE, KL) of the last step
         self.totals = torch.zeros(3, device=dev)    # running sums since reset_totals()
@@ -78,10 +90,7 @@ class GraphedTrainStep:
             # the batch is rows `idx` of the HBM-resident dataset: gathered (and binarised) straight into the staging rows
             # of the fused step, no image bytes cross PCIe
             x = self.stage_rows
-            if self.binarize:
-                torch.bernoulli(torch.index_select(self.data_rows, 0, self.idx_flat), out=x)
-            else:
-                torch.index_select(self.data_rows, 0, self.idx_flat, out=x)
+            ops.batch_prologue(self.data_rows, self.idx_flat, self.binarize, self.seed_ctr, x, self.eps_buf)
         else:
             x = torch.bernoulli(self.x_in) if self.binarize else self.x_in
         self.opt.zero_grad(set_to_none=True)      # backward then installs the fused node's gradient buffers
@@ -110,7 +119,9 @@ class GraphedTrainStep:
             h[:Cl] = self._h_draw[self.lo:self.hi]
         idx_on_device = indices.is_cuda
         if not idx_on_device:
-            h[self._o_idx:self._o_scal] = indices.reshape(-1)
+            h[self._o_idx:self._o_seed] = indices.reshape(-1)
+        h[self._o_seed] = self.seed
+        h[self._o_seed + 1] = self._calls
         hs = h[self._o_scal:].view(torch.float32)
         hs[0] = float(beta)
         self.opt.advance_graph_step(host_out=hs[1:1 + self.ngroups])
@@ -134,6 +145,7 @@ class GraphedTrainStep:
         self.model._exemplar_indices_override = (self.rows, self.hi - self.lo)
         try:
             self._refresh(data, indices, beta)
+            self.model._eps_override = self.eps_buf if self.by_index else None
             if self.graph is None:
                 # eager warm-up steps on a side stream (workspaces, attributes, RCCL channels), then capture
                 if self._calls < self.warmup_steps:
@@ -184,3 +196,4 @@ class GraphedTrainStep:
             return self.out
         finally:
             self.model._exemplar_indices_override = None
+            self.model._eps_override = None

@@ -620,6 +620,23 @@ def step_stats_add(loss, re, kl, step3, totals3=None):
     return step3
 
 
+def batch_prologue(data, idx, binarize, seed_ctr, x_out, eps_out=None):
+    """Head of a training step in one launch: x_out[b] = (binarised) data[idx[b]], eps_out ~ N(0, 1).
+    seed_ctr: device int64 [2] = (seed, step counter) of the counter-based generator."""
+    lib = _lib.load()
+    _need_cuda(data, idx, seed_ctr, x_out)
+    B, D = x_out.shape
+    assert data.dtype == torch.float32 and x_out.dtype == torch.float32 and data.stride(1) == 1 and x_out.stride(1) == 1
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == B and seed_ctr.dtype == torch.int64
+    zd = 0
+    if eps_out is not None:
+        assert eps_out.is_contiguous() and eps_out.dtype == torch.float32 and eps_out.shape[0] == B
+        zd = eps_out.shape[1]
+    _lib.check(lib.evae_batch_prologue(_p(data), data.stride(0), _p(idx), B, D, 1 if binarize else 0, _p(seed_ctr),
+                                       _p(x_out), x_out.stride(0), _p(eps_out), zd, _stream()), "evae_batch_prologue")
+    return x_out, eps_out
+
+
 def adam_flush_tables(table_caches):
     """Upload the pointer tables that adam_normgrad_step prepared while a hipGraph was being captured (call after the
     capture has ended and before the first replay)."""

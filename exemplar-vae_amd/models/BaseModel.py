@@ -98,7 +98,9 @@ class BaseModel(nn.Module, ABC):
             ex_local = exemplars_indices[lo:hi].to(x.device)
         data_ext, n_data = self.resident_data_ext(dataset, x.shape[0])
         x2 = x.reshape(x.shape[0], -1).float()
-        eps = self._draw_eps(torch.empty((x2.shape[0], a.z1_size), device=x.device))
+        eps = getattr(self, '_eps_override', None)          # the captured step draws eps in its prologue launch
+        if eps is None or tuple(eps.shape) != (x2.shape[0], a.z1_size):
+            eps = self._draw_eps(torch.empty((x2.shape[0], a.z1_size), device=x.device))
         named = dict(self.named_parameters())
         params = [named[n] for n in fused_vae.PARAM_ORDER]
         beta = beta if torch.is_tensor(beta) else float(beta)

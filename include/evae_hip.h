@@ -246,6 +246,14 @@ int evae_elbo_bwd(const float* dloss, int n_dloss, const float* dRE, int n_dRE, 
  * host floats read back every step): step3 = (loss, -re, kl) of this step, totals3 += step3.  One launch. */
 int evae_step_stats_add(const float* loss, const float* re, const float* kl, float* step3, float* totals3,
                         evae_stream_t stream);
+/* Head of a training step in one launch (utils/training.py:27-31 + models/BaseModel.py:79-81): gather the batch rows
+ * idx[b] of the device-resident dataset, binarise them (x = 1 with probability data, the `torch.bernoulli(data)` of
+ * dynamic binarisation) or copy them (binarize = 0), and draw eps ~ N(0, 1) [B x zdim] (eps_out may be NULL).
+ * Randomness is counter-based (Philox4x32-10): seed_ctr is a DEVICE array {seed, step counter}; the same (seed, counter)
+ * always yields the same draws, so a replayed hipGraph advances by updating the counter in place. */
+int evae_batch_prologue(const float* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
+                        const int64_t* seed_ctr /* device [2] */, float* x_out, int64_t ldx,
+                        float* eps_out /* [B x zdim] or NULL */, int zdim, evae_stream_t stream);
 int evae_bernoulli_ll_fwd(const float* x, const float* mean, int B, int D, float* out,
                           evae_stream_t stream);
 int evae_bernoulli_ll_bwd(const float* x, const float* mean, const float* dout, int B, int D,

@@ -438,3 +438,42 @@ def test_fused_elementwise_backward_launches_match_their_parts():
     assert rel(dmu_b.cpu().numpy(), dmu_a.cpu().numpy()) < 1e-6
     assert rel(dpre_b.cpu().numpy(), dpre_a.cpu().numpy()) < 1e-6
     assert float((dpre_b == 0).float().mean()) > 0.1                    # the clipped entries really are in the sample
+
+
+def test_batch_prologue_gather_binarise_eps(ops):
+    """evae_batch_prologue: exact gather without binarisation; Bernoulli(p) frequencies and N(0,1) moments with it;
+    same (seed, counter) -> same draws, another counter -> other draws."""
+    rs = np.random.RandomState(23)
+    N, B, D, zd = 500, 100, 784, 40
+    data = dev(rs.random_sample((N + 8, D)).astype(np.float32))[:N]           # a row-strided view, like the resident set
+    idx = dev(rs.randint(0, N, B).astype(np.int64))
+    sc = lambda seed, ctr: torch.tensor([seed, ctr], dtype=torch.int64, device="cuda")
+    x0 = torch.empty((B, D), device="cuda"); e0 = torch.empty((B, zd), device="cuda")
+    ops.batch_prologue(data, idx, False, sc(5, 0), x0, e0)
+    assert torch.equal(x0, data[idx])
+    xs, es = [], []
+    for ctr in range(60):
+        x = torch.empty((B, D), device="cuda"); e = torch.empty((B, zd), device="cuda")
+        ops.batch_prologue(data, idx, True, sc(5, ctr), x, e)
+        xs.append(x); es.append(e)
+    x_again = torch.empty((B, D), device="cuda"); e_again = torch.empty((B, zd), device="cuda")
+    ops.batch_prologue(data, idx, True, sc(5, 7), x_again, e_again)
+    assert torch.equal(x_again, xs[7]) and torch.equal(e_again, es[7])
+    assert not torch.equal(xs[7], xs[8]) and not torch.equal(es[7], es[8])
+    ops.batch_prologue(data, idx, True, sc(6, 7), x_again, e_again)
+    assert not torch.equal(e_again, es[7])
+    X = torch.stack(xs)                                                       # [60 x B x D] of {0, 1}
+    assert set(np.unique(X.cpu().numpy())) <= {0.0, 1.0}
+    freq = X.mean(dim=0)
+    p = data[idx]
+    # per pixel: |freq - p| is a binomial deviation with sigma <= 0.5 / sqrt(60) = 0.065; averaged over 78 400 pixels
+    assert float((freq - p).abs().max()) < 0.33
+    assert abs(float((freq - p).mean())) < 2e-3
+    E = torch.stack(es).double()                                              # 240 000 draws
+    assert abs(float(E.mean())) < 0.01 and abs(float(E.var()) - 1.0) < 0.01
+    assert abs(float((E ** 3).mean())) < 0.03 and abs(float((E ** 4).mean()) - 3.0) < 0.08
+    assert float(E.abs().max()) > 3.5 and bool(torch.isfinite(E).all())
+    # no correlation between the two outputs of a Box-Muller pair or between neighbouring steps
+    flat = E.reshape(60, -1)
+    assert abs(float((flat[:, 0::2] * flat[:, 1::2]).mean())) < 0.01
+    assert abs(float((flat[:-1] * flat[1:]).mean())) < 0.01

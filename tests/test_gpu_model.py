@@ -102,6 +102,14 @@ def test_graphed_step_matches_eager(feed):
                 losses.append(runner(xb, ib, 0.5)[0].item())
             else:
                 xb, ib = xb.cuda(), ib.cuda()
+                if feed != "foreign_images":
+                    # the captured step draws eps with the counter-based generator of its prologue launch
+                    # (seed = torch's seed when the runner was built, counter = step number): same draw here
+                    from evae import ops as _ops
+                    eps = torch.empty((B, args.z1_size), device="cuda")
+                    _ops.batch_prologue(torch.from_numpy(data).cuda(), ib.reshape(-1).contiguous(), False,
+                                        torch.tensor([3, it], dtype=torch.int64, device="cuda"), torch.empty_like(xb), eps)
+                    model._eps_override = eps
                 opt.zero_grad()
                 loss, RE, KL = model.calculate_loss((xb, ib), 0.5, average=True, dataset=dataset)
                 loss.backward()
