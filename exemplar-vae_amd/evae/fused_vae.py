@@ -45,19 +45,23 @@ def _vp(v):
 class _K:
     """Thin raw launchers over the C ABI (no autograd, caller-owned outputs)."""
 
-    def __init__(self, device):
+    def __init__(self, device, stream=None, suffix=""):
+        """Launches go to `stream` (default: the current one) and take their split-K workspaces from buffers named with
+        `suffix`, so that two launchers on two streams never share scratch memory."""
         self.lib = _lib.load()
         self.dev = device
-        self.st = ops._stream()
+        self.st = ops._stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        self.sfx = suffix
 
     def ws(self, name, nbytes):
-        return ops._workspace(name, nbytes, self.dev)
+        return ops._workspace(name + self.sfx, nbytes, self.dev)
 
     _side = {}
 
     def side_stream(self):
-        """Second stream for the exemplar-prior kernels: they only meet the decoder path at the ELBO, so the two
-        chains of small launches run side by side (captured as parallel branches of the step's hipGraph)."""
+        """Second stream for the decoder chain of the batch rows: it only meets the exemplar-prior chain at the ELBO (forward)
+        and at dz (backward), so the two chains of small launches run side by side, captured as parallel branches of the
+        step's hipGraph.  Collectives of the sharded prior stay on the main stream."""
         key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         st = _K._side.get(key)
         if st is None:
@@ -89,19 +93,17 @@ class _K:
         _lib.check(self.lib.evae_linear_fwd(_vp(x), None, M, K, ldx, _vp(w_), _vp(b), N, act, lo, hi, _vp(y), _vp(pre),
                                             _vp(w), w.numel(), self.st), "linear_fwd")
 
-    def bwd_data(self, dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, out, dg, ldo, st=None, ws_name="dgrad"):
-        """`st` / `ws_name`: launches issued on the side stream name it and use their own workspace"""
+    def bwd_data(self, dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, out, dg, ldo):
         nb = self.lib.evae_dense_bwd_data_workspace_bytes(M, N, K, 2 if dy2 is not None else 1)
-        w = self.ws(ws_name, nb)
+        w = self.ws("dgrad", nb)
         _lib.check(self.lib.evae_dense_bwd_data(_vp(dy1), _vp(w1), _vp(dy2), _vp(w2), M, N, ldy, K, _vp(out_prev),
-                                                _vp(s_prev), _vp(out), _vp(dg), ldo, _vp(w), w.numel(),
-                                                self.st if st is None else st), "bwd_data")
+                                                _vp(s_prev), _vp(out), _vp(dg), ldo, _vp(w), w.numel(), self.st), "bwd_data")
 
-    def bwd_weight(self, dy, M, N, ldy, x, rows, K, ldx, dw, db, st=None, ws_name="wgrad"):
+    def bwd_weight(self, dy, M, N, ldy, x, rows, K, ldx, dw, db):
         nb = self.lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
-        w = self.ws(ws_name, nb)
+        w = self.ws("wgrad", nb)
         _lib.check(self.lib.evae_dense_bwd_weight(_vp(dy), M, N, ldy, _vp(x), _vp(rows), K, ldx, _vp(dw), _vp(db), 0,
-                                                  _vp(w), w.numel(), self.st if st is None else st), "bwd_weight")
+                                                  _vp(w), w.numel(), self.st), "bwd_weight")
 
 
 class VaeExactLoss(torch.autograd.Function):
@@ -133,6 +135,13 @@ class VaeExactLoss(torch.autograd.Function):
         else:
             rows = torch.cat((ex_idx, torch.arange(n_data, n_data + B, device=dev)))
         ldd = data_ext.stride(0)
+        main = torch.cuda.current_stream()
+        side = k.side_stream()
+        kd = _K(dev, stream=side, suffix="_side")        # launcher of the decoder chain
+        side.wait_stream(main)
+        with torch.cuda.stream(side):                    # the prior's log-variance row, out of everybody's way
+            lv_row = plv.detach().expand(Z).contiguous()
+            lv_ready = torch.cuda.Event(); lv_ready.record()
         # ---- encoder over C + B rows
         # a gated layer keeps its output and its gate s for the backward (dg = dout * out * (1 - s)); h is never stored
         A1 = torch.empty((Mp, H), **f32); s1 = torch.empty_like(A1)
@@ -149,39 +158,38 @@ class VaeExactLoss(torch.autograd.Function):
         # ---- sample, decode, reconstruct
         z = torch.empty((B, Z), **f32); logq = torch.empty(B, **f32)
         _lib.check(lib.evae_reparam_logq_fwd(_vp(z_mean), _vp(logvar), _vp(eps), B, Z, _vp(z), _vp(logq), k.st), "reparam")
-        # ---- exemplar prior (leave-one-out mask in training unless no_mask) on the side stream ...
+        # ---- exemplar prior (leave-one-out mask in training unless no_mask; with its collectives when sharded) on the
+        #      main stream ...
         zi = None if no_mask else x_idx.reshape(-1)
         ci = None if no_mask else ex_idx
         logp = torch.empty(B, **f32); lse = torch.empty(B, **f32)
-        main = torch.cuda.current_stream()
-        side = main if sharded else k.side_stream()     # collectives stay on the main stream
-        side.wait_stream(main)
-        z_all, zi_all = z, zi
-        with torch.cuda.stream(side):
-            lv_row = plv.detach().expand(Z).contiguous()
-            if sharded == 2:
-                # data-parallel batches over sharded exemplars: every rank scores the queries of ALL ranks against its
-                # shard (same pair count as B queries against all C), the partials go back to their owners
-                z_all = shard._all_gather_flat(z).reshape(-1, Z)
-                zi_all = None if zi is None else shard._all_gather_flat(zi.contiguous()).reshape(-1)
-                m, s, n, _ = ops.prior_lse_fwd(z_all, centres, lv_row, zi_all, ci)
-                m, s, n = shard.gather_partials(m, s, n)                  # [R x R*B] each
-                r0 = dist.get_rank() * B
-                m, s, n = (t[:, r0:r0 + B].contiguous() for t in (m, s, n))
-            else:
-                m, s, n, _ = ops.prior_lse_fwd(z, centres, lv_row, zi, ci)      # temporaries live and die on `side`
-                if sharded:
-                    m, s, n = shard.gather_partials(m, s, n)
-            ops.prior_merge(m, s, n, c_total, out=(logp, lse))
-        # ---- ... while the decoder reconstructs on the main stream
         D1 = torch.empty((B, H), **f32); sd1 = torch.empty_like(D1)
-        k.gated_fwd(z, None, B, Z, Z, d1h, e1h, d1g, e1g, H, D1, None, sd1)
         D2 = torch.empty((B, H), **f32); sd2 = torch.empty_like(D2)
-        k.gated_fwd(D1, None, B, H, H, d2h, e2h, d2g, e2g, H, D2, None, sd2)
         xmean = torch.empty((B, D), **f32)
-        k.linear_fwd(D2, B, H, H, wp, bp, D, ACT_SIGMOID, 0.0, 0.0, xmean, None)
         RE = torch.empty(B, **f32)
-        _lib.check(lib.evae_bernoulli_ll_fwd(_vp(x), _vp(xmean), B, D, _vp(RE), k.st), "bernoulli")
+        side.wait_stream(main)
+        main.wait_event(lv_ready)
+        z_all, zi_all = z, zi
+        if sharded == 2:
+            # data-parallel batches over sharded exemplars: every rank scores the queries of ALL ranks against its
+            # shard (same pair count as B queries against all C), the partials go back to their owners
+            z_all = shard._all_gather_flat(z).reshape(-1, Z)
+            zi_all = None if zi is None else shard._all_gather_flat(zi.contiguous()).reshape(-1)
+            m, s, n, _ = ops.prior_lse_fwd(z_all, centres, lv_row, zi_all, ci)
+            m, s, n = shard.gather_partials(m, s, n)                  # [R x R*B] each
+            r0 = dist.get_rank() * B
+            m, s, n = (t[:, r0:r0 + B].contiguous() for t in (m, s, n))
+        else:
+            m, s, n, _ = ops.prior_lse_fwd(z, centres, lv_row, zi, ci)
+            if sharded:
+                m, s, n = shard.gather_partials(m, s, n)
+        ops.prior_merge(m, s, n, c_total, out=(logp, lse))
+        # ---- ... while the decoder reconstructs on the side stream
+        with torch.cuda.stream(side):
+            kd.gated_fwd(z, None, B, Z, Z, d1h, e1h, d1g, e1g, H, D1, None, sd1)
+            kd.gated_fwd(D1, None, B, H, H, d2h, e2h, d2g, e2g, H, D2, None, sd2)
+            kd.linear_fwd(D2, B, H, H, wp, bp, D, ACT_SIGMOID, 0.0, 0.0, xmean, None)
+            _lib.check(lib.evae_bernoulli_ll_fwd(_vp(x), _vp(xmean), B, D, _vp(RE), kd.st), "bernoulli")
         main.wait_stream(side)
         # ---- ELBO assembly (+ batch means) in one launch
         loss = torch.empty(B, **f32); KL = torch.empty(B, **f32)
@@ -238,18 +246,29 @@ class VaeExactLoss(torch.autograd.Function):
                                      _vp(gk), 0 if gk is None else gk.numel(), _vp(beta_dev),
                                      0.0 if beta_dev is not None else float(beta), B, _vp(cRE), _vp(cKL), _vp(gp), k.st),
                    "elbo_bwd")
-        # ---- two chains from here to the weight gradients:
-        #   side stream: prior term d(-cKL * logp) -> dcentres (lands in the head-gradient buffer) -> data gradients of the
-        #                head and of encoder layer 2 for the Cl exemplar rows (none of it needs the decoder);
-        #   main stream: reconstruction term through the decoder -> dz -> the same data gradients for the B batch rows.
+        # ---- two chains from here to the weight gradients (the order of issue below is the order the captured graph starts
+        #      things in, and it matters: a chain of small launches crawls next to a GEMM that fills every CU):
+        #   main stream: prior term d(-cKL * logp) (+ its collectives when sharded) -> dcentres, which land in the
+        #                head-gradient buffer -> data gradients of the head and of encoder layer 2 for the Cl exemplar rows
+        #                (none of it needs the decoder);
+        #   side stream: reconstruction term through the decoder -> dz (+ the prior's dz') -> the same data gradients for
+        #                the B batch rows, then the B-row weight gradients of decoder / log-variance head, which are leaves.
         #   They meet at the weight gradients, which run over all Cl + B rows in one launch per layer.
         #   dz' and dlogvar' share one packed buffer so that the sharded case all-reduces it in place.
+        main = torch.cuda.current_stream()
+        side = k.side_stream()
+        kd = _K(dev, stream=side, suffix="_side")
         dmean_all = torch.empty((Mp, Z), **f32)
         dq2 = torch.empty((Mp, 2 * H), **f32)                              # [dh2 | dg2] for all C + B rows
         dq1 = torch.empty((Mp, 2 * H), **f32)
+        dpx = torch.empty((B, D), **f32)
+        dp2 = torch.empty((B, 2 * H), **f32)                               # [dh | dg] of decoder layer 2
+        dp1 = torch.empty((B, 2 * H), **f32)
+        dz = torch.empty((B, Z), **f32)
+        dlvp = torch.empty((B, Z), **f32)
         centres = mean_all[:Cl]
-        main = torch.cuda.current_stream()
-        side = main if sharded else k.side_stream()
+        z_mean = mean_all[Cl:]
+        off = 4 * Cl
         side.wait_stream(main)
         if sharded == 2:
             # data-parallel batches: the shard-side backward runs over the queries of all ranks (their lse and upstream
@@ -264,7 +283,7 @@ class VaeExactLoss(torch.autograd.Function):
             nb = lib.evae_prior_lse_bwd_workspace_bytes(RB, Cl, Z)
             w = k.ws("prior_bwd", nb)
             _lib.check(lib.evae_prior_lse_bwd(_vp(z_all), RB, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi_all), _vp(ci), _vp(lse_all),
-                                              _vp(gp_all), _vp(dz_all), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), ops._stream()),
+                                              _vp(gp_all), _vp(dz_all), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), k.st),
                        "prior_bwd")
             dist.all_reduce(dz_all, op=dist.ReduceOp.SUM)
             r0 = dist.get_rank() * B
@@ -274,65 +293,47 @@ class VaeExactLoss(torch.autograd.Function):
             dzp = packed[:B * Z].view(B, Z); dlv = packed[B * Z:]
             nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cl, Z)
             w = k.ws("prior_bwd", nb)
-        dz_ready = torch.cuda.Event()
-        with torch.cuda.stream(side):
-            sst = ops._stream()
-            if sharded != 2:
-                _lib.check(lib.evae_prior_lse_bwd(_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp),
-                                                  _vp(dzp), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), sst), "prior_bwd")
+            _lib.check(lib.evae_prior_lse_bwd(_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp),
+                                              _vp(dzp), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), k.st), "prior_bwd")
             if sharded == 1:
                 dist.all_reduce(packed, op=dist.ReduceOp.SUM)
                 if Cl > 0:
                     dmean_all[:Cl].mul_(float(dist.get_world_size()))
-            dz_ready.record()
-            g_plv = gslot("plv", 1)
-            torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
-            if Cl > 0:
-                k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H,
-                           st=sst, ws_name="dgrad_side")
-                k.bwd_data(dq2, w2h, dq2.data_ptr() + 4 * H, w2g, Cl, H, 2 * H, H, A1, s1, dq1, dq1.data_ptr() + 4 * H, 2 * H,
-                           st=sst, ws_name="dgrad_side")
-        # ---- reconstruction term through the decoder (main stream, concurrently)
-        dpx = torch.empty((B, D), **f32)               # through the Bernoulli log-likelihood and the sigmoid head at once
-        _lib.check(lib.evae_bernoulli_sigmoid_bwd(_vp(x), _vp(xmean), _vp(cRE), B, D, _vp(dpx), k.st), "bernoulli_sigmoid_bwd")
-        dp2 = torch.empty((B, 2 * H), **f32)                              # [dh | dg] of decoder layer 2
-        k.bwd_data(dpx, wp, None, None, B, D, D, H, D2, sd2, dp2, dp2.data_ptr() + 4 * H, 2 * H)
-        dp1 = torch.empty((B, 2 * H), **f32)
-        k.bwd_data(dp2, d2h, dp2.data_ptr() + 4 * H, d2g, B, H, 2 * H, H, D1, sd1, dp1, dp1.data_ptr() + 4 * H, 2 * H)
-        dz = torch.empty((B, Z), **f32)
-        k.bwd_data(dp1, d1h, dp1.data_ptr() + 4 * H, d1g, B, H, 2 * H, Z, None, None, dz, None, Z)
-        main.wait_event(dz_ready)
-        # ---- reparameterisation + log q (+ the prior's dz', + the Hardtanh of the log-variance head): one launch
-        z_mean = mean_all[Cl:]
-        dlvp = torch.empty((B, Z), **f32)
-        _lib.check(lib.evae_reparam_logq_bwd_hardtanh(_vp(z_mean), _vp(logvar), _vp(eps), _vp(z), _vp(dz), _vp(dzp), _vp(cKL),
-                                                      _vp(lv_pre), -6.0, 2.0, B, Z, _vp(dmean_all.data_ptr() + 4 * Cl * Z),
-                                                      _vp(dlvp), k.st), "reparam_bwd")
-        # ---- heads and encoder layer 2, batch rows
-        off = 4 * Cl
-        k.bwd_data(dmean_all.data_ptr() + off * Z, wm, dlvp, wl, B, Z, Z, H, A2.data_ptr() + off * H,
-                   s2.data_ptr() + off * H, dq2.data_ptr() + off * 2 * H, dq2.data_ptr() + off * 2 * H + 4 * H, 2 * H)
-        k.bwd_data(dq2.data_ptr() + off * 2 * H, w2h, dq2.data_ptr() + off * 2 * H + 4 * H, w2g, B, H, 2 * H, H,
-                   A1.data_ptr() + off * H, s1.data_ptr() + off * H, dq1.data_ptr() + off * 2 * H,
-                   dq1.data_ptr() + off * 2 * H + 4 * H, 2 * H)
-        # ---- the B-row weight gradients of the decoder and of the log-variance head are leaves (nobody waits for them
-        #      before the optimizer): they go to the side stream, behind its data gradients, and run next to the big
-        #      weight-gradient GEMMs instead of lengthening the chain above
-        chain_done = torch.cuda.Event(); chain_done.record()
-        side_dgrads = torch.cuda.Event()
+        dz_ready = torch.cuda.Event(); dz_ready.record()
+        if Cl > 0:
+            k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H)
+            k.bwd_data(dq2, w2h, dq2.data_ptr() + 4 * H, w2g, Cl, H, 2 * H, H, A1, s1, dq1, dq1.data_ptr() + 4 * H, 2 * H)
+        batch_rows_done = torch.cuda.Event()
+        g_plv = gslot("plv", 1)
         g_wp = gslot("wp", D, H); g_bp = gslot("bp", D)
         g_d2 = gslot("d2", 2 * H, H); g_e2 = gslot("e2", 2 * H)
         g_d1 = gslot("d1", 2 * H, Z); g_e1 = gslot("e1", 2 * H)
         g_wl = gslot("wl", Z, H); g_bl = gslot("bl", Z)
         with torch.cuda.stream(side):
-            side_dgrads.record()
-            side.wait_event(chain_done)
-            kw = dict(st=ops._stream(), ws_name="wgrad_side")
-            k.bwd_weight(dpx, B, D, D, D2, None, H, H, g_wp, g_bp, **kw)
-            k.bwd_weight(dp2, B, 2 * H, 2 * H, D1, None, H, H, g_d2, g_e2, **kw)
-            k.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1, **kw)
-            k.bwd_weight(dlvp, B, Z, Z, A2.data_ptr() + off * H, None, H, H, g_wl, g_bl, **kw)
-        main.wait_event(side_dgrads)
+            # through the Bernoulli log-likelihood and the sigmoid head at once, then down the decoder
+            _lib.check(lib.evae_bernoulli_sigmoid_bwd(_vp(x), _vp(xmean), _vp(cRE), B, D, _vp(dpx), kd.st), "bernoulli_sigmoid_bwd")
+            kd.bwd_data(dpx, wp, None, None, B, D, D, H, D2, sd2, dp2, dp2.data_ptr() + 4 * H, 2 * H)
+            kd.bwd_data(dp2, d2h, dp2.data_ptr() + 4 * H, d2g, B, H, 2 * H, H, D1, sd1, dp1, dp1.data_ptr() + 4 * H, 2 * H)
+            kd.bwd_data(dp1, d1h, dp1.data_ptr() + 4 * H, d1g, B, H, 2 * H, Z, None, None, dz, None, Z)
+            side.wait_event(dz_ready)
+            # reparameterisation + log q (+ the prior's dz', + the Hardtanh of the log-variance head): one launch
+            _lib.check(lib.evae_reparam_logq_bwd_hardtanh(_vp(z_mean), _vp(logvar), _vp(eps), _vp(z), _vp(dz), _vp(dzp), _vp(cKL),
+                                                          _vp(lv_pre), -6.0, 2.0, B, Z, _vp(dmean_all.data_ptr() + off * Z),
+                                                          _vp(dlvp), kd.st), "reparam_bwd")
+            # head and encoder layer 2, batch rows
+            kd.bwd_data(dmean_all.data_ptr() + off * Z, wm, dlvp, wl, B, Z, Z, H, A2.data_ptr() + off * H,
+                        s2.data_ptr() + off * H, dq2.data_ptr() + off * 2 * H, dq2.data_ptr() + off * 2 * H + 4 * H, 2 * H)
+            kd.bwd_data(dq2.data_ptr() + off * 2 * H, w2h, dq2.data_ptr() + off * 2 * H + 4 * H, w2g, B, H, 2 * H, H,
+                        A1.data_ptr() + off * H, s1.data_ptr() + off * H, dq1.data_ptr() + off * 2 * H,
+                        dq1.data_ptr() + off * 2 * H + 4 * H, 2 * H)
+            batch_rows_done.record()
+            # leaves: nobody waits for them before the optimizer
+            kd.bwd_weight(dpx, B, D, D, D2, None, H, H, g_wp, g_bp)
+            kd.bwd_weight(dp2, B, 2 * H, 2 * H, D1, None, H, H, g_d2, g_e2)
+            kd.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1)
+            kd.bwd_weight(dlvp, B, Z, Z, A2.data_ptr() + off * H, None, H, H, g_wl, g_bl)
+            torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
+        main.wait_event(batch_rows_done)
         # ---- weight gradients over all C + B rows
         g_wm = gslot("wm", Z, H); g_bm = gslot("bm", Z)
         k.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)
