@@ -705,6 +705,37 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
           }
         }
     }
+  } else if constexpr (EPI == EPI_GATE_BWD) {
+    // dh = v * s, dg = v * (h s) * (1 - s) with h s and s of the layer below read from dense [M x N] arrays.  All the
+    // reads of a fragment are issued before the first store: the stores may alias them as far as the compiler knows,
+    // and a read -> store -> read chain would pay one memory latency per element (that is the whole run time of a
+    // launch with few blocks, and of a block's tail in any launch).
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      if (n >= g.N) continue;
+      float go[MT][16], sv[MT][16];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const size_t oe = (size_t)(m < g.M ? m : 0) * g.N + n;
+          go[mt][r] = g.e0[oe];
+          sv[mt][r] = g.e1[oe];
+        }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m >= g.M) continue;
+          const size_t o = orow(m) * g.ldo + n;
+          const float v = acc[mt][nt][r], s_ = sv[mt][r];
+          g.out0[o] = v * s_;                          // dh
+          g.out1[o] = v * go[mt][r] * (1.0f - s_);     // dg = v * h * s * (1 - s)
+        }
+    }
   } else {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -723,11 +754,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
             const float pre = v + bias;
             if (g.out1) g.out1[o] = pre;
             g.out0[o] = apply_act(pre, g.act, g.lo, g.hi);
-          } else if (EPI == EPI_GATE_BWD) {
-            const size_t oe = (size_t)m * g.N + n;   // h/s of the layer below are dense [M x N]
-            const float go = g.e0[oe], s = g.e1[oe];   // gated output h*s and gate s of the layer below
-            g.out0[o] = v * s;                   // dh
-            g.out1[o] = v * go * (1.0f - s);     // dg = v * h * s * (1 - s)
           } else {                                // EPI_RAW: partial plane [z][M][N]
             g.out0[(size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n] = v;
           }

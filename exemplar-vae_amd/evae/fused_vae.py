@@ -327,12 +327,15 @@ class VaeExactLoss(torch.autograd.Function):
                         A1.data_ptr() + off * H, s1.data_ptr() + off * H, dq1.data_ptr() + off * 2 * H,
                         dq1.data_ptr() + off * 2 * H + 4 * H, 2 * H)
             batch_rows_done.record()
-            # leaves: nobody waits for them before the optimizer
-            kd.bwd_weight(dpx, B, D, D, D2, None, H, H, g_wp, g_bp)
-            kd.bwd_weight(dp2, B, 2 * H, 2 * H, D1, None, H, H, g_d2, g_e2)
-            kd.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1)
-            kd.bwd_weight(dlvp, B, Z, Z, A2.data_ptr() + off * H, None, H, H, g_wl, g_bl)
-            torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
+
+        def leaves():     # nobody waits for them before the optimizer
+            with torch.cuda.stream(side):
+                kd.bwd_weight(dpx, B, D, D, D2, None, H, H, g_wp, g_bp)
+                kd.bwd_weight(dp2, B, 2 * H, 2 * H, D1, None, H, H, g_d2, g_e2)
+                kd.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1)
+                kd.bwd_weight(dlvp, B, Z, Z, A2.data_ptr() + off * H, None, H, H, g_wl, g_bl)
+                torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
+        leaves()
         main.wait_event(batch_rows_done)
         # ---- weight gradients over all C + B rows
         g_wm = gslot("wm", Z, H); g_bm = gslot("bm", Z)
