@@ -46,6 +46,8 @@ def parse():
                     help="with --gpus N > 1: 'dp' = every rank trains on its own 100-image batch (global batch 100 N) "
                          "against the exemplar set sharded over the ranks (weak scaling in the batch); 'replica' = the "
                          "same 100-image batch replicated on every rank, only the exemplars sharded (strong scaling)")
+    ap.add_argument("--probe-warmup", type=int, default=20,
+                    help="untimed eager steps in front of the probe steps (clock ramp after the host pause)")
     ap.add_argument("--probe-steps", type=int, default=20,
                     help="eager steps run after the timed region to time the dominant kernel with HIP events")
     ap.add_argument("--iwae-images", type=int, default=16,
@@ -245,10 +247,14 @@ def main():
     # Event pairs cannot be read back from inside a replayed graph, so the same steps are run eagerly right
     # after the timed region (identical kernels, identical shapes); the rocprofv3 summary of the whole
     # command (profiles/) reports the same average for this kernel.
-    ops.PROBE = {"gated_dense_fwd": []}
     graphed = state["graphed"]
-    for i in range(a.probe_steps if graphed is not None else 0):
+    # the clocks sag during the host pause above and take ~12 eager steps (30 ms) to come back: untimed steps first,
+    # otherwise the event pairs time the launch at a lower clock than the timed region (and rocprof's trace of it) ran at
+    for i in range(a.probe_warmup if graphed is not None else 0):
         eager_step(a.warmup + a.steps + i)
+    ops.PROBE = {"gated_dense_fwd": []}
+    for i in range(a.probe_steps if graphed is not None else 0):
+        eager_step(a.warmup + a.steps + a.probe_warmup + i)
     fence()
     probe, ops.PROBE = ops.PROBE, None
     if world > 1:
@@ -260,6 +266,8 @@ def main():
     # roofline of the dominant launch: gemm_kernel<KC,KC,EPI_GATED>, encoder layer 1 (one launch per step)
     ev = probe["gated_dense_fwd"]
     durs_ms = [s.elapsed_time(e) for s, e, _, _ in ev]
+    if os.environ.get("EVAE_BENCH_DUMP_PROBE"):
+        print("probe us per launch:", [round(1e3 * d / r, 1) for d, (_, _, _, r) in zip(durs_ms, ev)], file=sys.stderr)
     flops = [f for _, _, f, _ in ev]
     nlaunch = sum(r for _, _, _, r in ev)
     roof = None
