@@ -607,6 +607,273 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward on the matrix cores (z_dim <= 56, multiple of 4).  Same tiling as prior_fwd_mfma_kernel: block = 8 waves,
+// tile = 128 exemplars x 128 queries, S = (c/s).(z/s)^T on v_mfma_f32_32x32x2_f32.  Then, per tile,
+//   P[e][q] = g_q exp(log N(z_q | c_e) - lse_q)      (0 for masked / absent pairs), written once to LDS,
+//   T = P  . [Zs | 1]  -> T[e][k] = sum_q P Zs_qk,  T[e][KP] = colsum_e(P)       (contraction over the 128 queries)
+//   U = P^T. [Cs | 1]  -> U[q][k] = sum_e P Cs_ek,  U[q][KP] = rowsum_q(P)       (contraction over the 128 exemplars;
+//                                                                                  accumulated over the split's tiles)
+// both again on the matrix cores -- the column of ones that yields the row / column sums sits in the padding column KP
+// of the staged tiles, outside the k range of S.  From those:
+//   dC[e][k] = (T[e][k] - colsum_e Cs_ek) / s_k          dZ'[q][k] = U[q][k] - rowsum_q Zs_qk   (finish: / s_k, sum of splits)
+//   dV[k]    = sum_q rowsum_q Zs_qk^2 + sum_e colsum_e Cs_ek^2 - 2 sum_e Cs_ek T[e][k]          (= sum P (Zs - Cs)^2)
+// i.e. the same partial outputs as prior_bwd_kernel, so the finish kernel is shared.
+// ------------------------------------------------------------------------------------------------
+template <int KG>
+__global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
+    const float* __restrict__ z, int B, const float* __restrict__ centres, int C, int zdim,
+    const float* __restrict__ log_var, const int64_t* __restrict__ z_idx, const int64_t* __restrict__ c_idx,
+    const float* __restrict__ lse, const float* __restrict__ gout, int tiles_per_split, int nsplit, int use_atomic_dc,
+    float* __restrict__ dz_part /* [nsplit][B][zdim] */, float* __restrict__ dc /* [C][zdim] */,
+    float* __restrict__ dlv_part /* [nq*nsplit][zdim+1] */) {
+  constexpr int KP = KG * 8, KS2 = KP + 4, CPR = KP / 4, PP = 132;
+  constexpr int NV = (MFE * CPR + MFT - 1) / MFT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;                          // [128][KS2]   scaled queries, column KP = 1
+  float* Es = Qs + MFQ * KS2;                // [128][KS2]   scaled exemplars, column KP = 1
+  float* Ps = Es + MFE * KS2;                // [128 e][PP]
+  float* zn = Ps + MFE * PP;                 // [128]
+  float* cn = zn + MFQ;                      // [128]
+  float* cs = cn + MFE;                      // [128] column sums of P (per exemplar)
+  float* rs = cs + MFE;                      // [128] row sums of P (per query)
+  float* inv_sigma = rs + MFQ;               // [64]
+  float* red = inv_sigma + 64;               // [16]
+  float* dvs = red + 16;                     // [8][64] per-(wave row, lane half) partials of dV
+  long long* ci_s = reinterpret_cast<long long*>(dvs + 8 * 64);   // [128]
+
+  const int split = blockIdx.x;
+  const int q0 = blockIdx.y * MFQ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  const bool masked = (z_idx != nullptr) && (c_idx != nullptr);
+  const float cst = setup_sigma(inv_sigma, red, log_var, zdim, KP);   // contains a barrier
+
+  auto load_tile = [&](const float* src, int r0, int nrows, float4 (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + MFT * i;
+      const int r = f / CPR, c = f - r * CPR;
+      const bool ok = f < MFE * CPR && r0 + r < nrows && 4 * c + 4 <= zdim;
+      v[i] = ok ? *reinterpret_cast<const float4*>(src + (size_t)(r0 + r) * zdim + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&](float* tile, const float4 (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + MFT * i;
+      const int r = f / CPR, c = f - r * CPR;
+      if (f < MFE * CPR) {
+        const float4 s4 = *reinterpret_cast<const float4*>(inv_sigma + 4 * c);
+        *reinterpret_cast<float4*>(tile + r * KS2 + 4 * c) = make_float4(v[i].x * s4.x, v[i].y * s4.y, v[i].z * s4.z, v[i].w * s4.w);
+      }
+    }
+    if (tid < MFE) *reinterpret_cast<float4*>(tile + tid * KS2 + KP) = make_float4(1.f, 0.f, 0.f, 0.f);   // the ones column
+  };
+  auto row_norms = [&](const float* tile, float* out) {
+    if (tid < MFE) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPR; ++c) {
+        const float4 t = *reinterpret_cast<const float4*>(tile + tid * KS2 + 4 * c);
+        sacc += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+      }
+      out[tid] = sacc;
+    }
+  };
+
+  float4 rv[NV];
+  load_tile(z, q0, B, rv);
+  store_tile(Qs, rv);
+  const int ntiles = (C + MFE - 1) / MFE;
+  const int tile_begin = split * tiles_per_split;
+  int tile_end = tile_begin + tiles_per_split;
+  if (tile_end > ntiles) tile_end = ntiles;
+  if (tile_begin < tile_end) load_tile(centres, tile_begin * MFE, C, rv);
+  __syncthreads();
+  row_norms(Qs, zn);
+  __syncthreads();
+
+  // this lane's two query columns of S
+  float znq[2], gq[2], lq[2];
+  long long zi[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int ql = wc * 64 + nt * 32 + l31;
+    const bool v = q0 + ql < B;
+    znq[nt] = zn[ql];
+    gq[nt] = v ? gout[q0 + ql] : 0.f;
+    lq[nt] = v ? lse[q0 + ql] : 0.f;
+    zi[nt] = (masked && v) ? (long long)z_idx[q0 + ql] : -1;
+  }
+  // column of the T / U tiles this lane holds (clamped to the zero padding column for the operand reads)
+  const int ncol = wc * 32 + l31;
+  const int nread = ncol < KS2 ? ncol : KS2 - 1;
+  const float isg = ncol < zdim ? inv_sigma[ncol] : 0.f;
+
+  f32x16_t U;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) U[r] = 0.f;
+  float dv_acc = 0.f;        // this lane's share of dV[ncol]
+  float gw_acc = 0.f;        // threads 0..127: sum of the column sums they saw
+
+  for (int t = tile_begin; t < tile_end; ++t) {
+    const int e0 = t * MFE;
+    store_tile(Es, rv);
+    if (tid < MFE) ci_s[tid] = (masked && e0 + tid < C) ? (long long)c_idx[e0 + tid] : -2;
+    __syncthreads();
+    if (t + 1 < tile_end) load_tile(centres, (t + 1) * MFE, C, rv);
+    row_norms(Es, cn);
+
+    // ---- S = Es . Qs^T
+    f32x16_t acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    {
+      const float* ea = Es + (wr * 32 + l31) * KS2 + lh * 4;
+      const float* qb = Qs + (wc * 64 + l31) * KS2 + lh * 4;
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+        const float4 a = *reinterpret_cast<const float4*>(ea + kg * 8);
+        const float4 b0 = *reinterpret_cast<const float4*>(qb + kg * 8);
+        const float4 b1 = *reinterpret_cast<const float4*>(qb + 32 * KS2 + kg * 8);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+      }
+    }
+    __syncthreads();     // cn, ci_s complete
+
+    // ---- P into LDS (rows of this lane: e = wr*32 + (r&3) + 8*(r>>2) + 4*lh)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int ql = wc * 64 + nt * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int el = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float d = fmaxf(cn[el] + znq[nt] - 2.0f * acc[nt][r], 0.f);
+        bool ok = e0 + el < C;
+        if (masked) ok = ok && (ci_s[el] != zi[nt]);
+        // exp(cst - d/2 - lse) = 2^((cst - lse) log2e - d log2e / 2)
+        const float w = gq[nt] * fast_exp2((cst - lq[nt]) * kLog2e - d * kHalfLog2e);
+        Ps[el * PP + ql] = ok ? w : 0.f;
+      }
+    }
+    __syncthreads();
+
+    // ---- T = P . [Zs | 1]  (wave: exemplar rows wr*32.., columns wc*32..)   and   U += P^T . [Cs | 1]
+    f32x16_t T;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[r] = 0.f;
+    {
+      const float* pa = Ps + (wr * 32 + l31) * PP + lh * 4;        // P[e][q..q+3]
+      const float* pu = Ps + (lh * 4) * PP + wr * 32 + l31;        // P[e..e+3][q]
+      const float* qb = Qs + (lh * 4) * KS2 + nread;
+      const float* eb = Es + (lh * 4) * KS2 + nread;
+#pragma unroll 4
+      for (int kg = 0; kg < 16; ++kg) {
+        const float4 a = *reinterpret_cast<const float4*>(pa + kg * 8);
+        const float* q8 = qb + kg * 8 * KS2;
+        T = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q8[0], T, 0, 0, 0);
+        T = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q8[KS2], T, 0, 0, 0);
+        T = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q8[2 * KS2], T, 0, 0, 0);
+        T = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q8[3 * KS2], T, 0, 0, 0);
+        const float* p8 = pu + kg * 8 * PP;
+        const float* e8 = eb + kg * 8 * KS2;
+        U = __builtin_amdgcn_mfma_f32_32x32x2f32(p8[0], e8[0], U, 0, 0, 0);
+        U = __builtin_amdgcn_mfma_f32_32x32x2f32(p8[PP], e8[KS2], U, 0, 0, 0);
+        U = __builtin_amdgcn_mfma_f32_32x32x2f32(p8[2 * PP], e8[2 * KS2], U, 0, 0, 0);
+        U = __builtin_amdgcn_mfma_f32_32x32x2f32(p8[3 * PP], e8[3 * KS2], U, 0, 0, 0);
+      }
+    }
+    // column sums of P: the lanes that hold column KP of T
+    if (ncol == KP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cs[wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = T[r];
+    }
+    __syncthreads();
+    if (tid < MFE) gw_acc += cs[tid];
+    if (ncol < zdim) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int el = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float c_ = Es[el * KS2 + ncol], csum = cs[el];
+        dv_acc += c_ * (csum * c_ - 2.0f * T[r]);
+        const int e = e0 + el;
+        if (e < C) {
+          const float v = (T[r] - csum * c_) * isg;
+          if (use_atomic_dc) atomicAdd(&dc[(size_t)e * zdim + ncol], v);
+          else dc[(size_t)e * zdim + ncol] = v;
+        }
+      }
+    }
+    __syncthreads();     // everybody is done with Es / Ps / cs of this tile
+  }
+
+  // ---- row sums, dZ' partial of this split, the query part of dV
+  if (ncol == KP) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rs[wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = U[r];
+  }
+  __syncthreads();
+  if (ncol < zdim) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ql = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float z_ = Qs[ql * KS2 + ncol], rsum = rs[ql];
+      dv_acc += rsum * z_ * z_;
+      if (q0 + ql < B) dz_part[((size_t)split * B + q0 + ql) * zdim + ncol] = U[r] - rsum * z_;
+    }
+  }
+  dvs[(wr * 2 + lh) * 64 + ncol] = dv_acc;
+  __syncthreads();
+  float* dlv = dlv_part + (size_t)(blockIdx.y * nsplit + split) * (zdim + 1);
+  if (tid < zdim) {
+    float v = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v += dvs[p * 64 + tid];     // fixed order
+    dlv[tid] = v;
+  }
+  __syncthreads();
+  // sum of all of P seen by this block: threads 0..127 hold the column sums of their exemplar slot
+  if (wave < 2) {
+    const float sg = wave_sum(gw_acc);
+    if (lane == 0) dvs[wave] = sg;
+  }
+  __syncthreads();
+  if (tid == 0) dlv[zdim] = dvs[0] + dvs[1];
+}
+
+template <int KG>
+static int launch_prior_bwd_mfma(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+                                 const int64_t* z_idx, const int64_t* c_idx, const float* lse, const float* gout,
+                                 int ns_max, int use_atomic, float* dz_part, float* dc, float* dlv_part, int* ns_out,
+                                 hipStream_t stream) {
+  constexpr int KS2 = KG * 8 + 4;
+  const size_t lds = (size_t)(2 * 128 * KS2 + 128 * 132 + 4 * 128 + 64 + 16 + 8 * 64) * sizeof(float) + 128 * sizeof(long long);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)prior_bwd_mfma_kernel<KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int nq = cdiv(B, MFQ), ntiles = cdiv(C, MFE);
+  int ns = cdiv(512, nq);
+  if (ns > ntiles) ns = ntiles;
+  if (ns > ns_max) ns = ns_max;
+  if (ns < 1) ns = 1;
+  const int tps = cdiv(ntiles, ns);
+  ns = cdiv(ntiles, tps);
+  *ns_out = ns;
+  prior_bwd_mfma_kernel<KG><<<dim3(ns, nq), MFT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, lse, gout, tps, ns,
+                                                                use_atomic, dz_part, dc, dlv_part);
+  return check_launch("prior_bwd_mfma_kernel");
+}
+
 // Both reductions that follow prior_bwd_kernel, in one launch.
 //   blocks [0, nb_dz): dz[e] = exp(-logvar/2) * sum over splits of dz_part (16 split-lanes per output, fixed assignment
 //                      => fixed order);
@@ -781,6 +1048,29 @@ extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, i
     zero_kernel<<<cdiv(C * zdim, 256), 256, 0, stream>>>(dcentres, (size_t)C * zdim);
     int rc = check_launch("zero dcentres");
     if (rc) return rc;
+  }
+  // matrix-core path (see prior_bwd_mfma_kernel); EVAE_PRIOR_VALU=1 forces the direct-difference kernel
+  static int force_valu = -1;
+  if (force_valu < 0) { const char* e = getenv("EVAE_PRIOR_VALU"); force_valu = (e && atoi(e)) ? 1 : 0; }
+  if (!force_valu && zdim <= 56 && (zdim & 3) == 0 && ((((uintptr_t)z) | ((uintptr_t)centres)) & 15) == 0) {
+    int ns2 = 1, rc;
+#define EVAE_BWD_MFMA(KG_) rc = launch_prior_bwd_mfma<KG_>(z, B, centres, C, zdim, log_var, z_idx, c_idx, lse, grad_out, ns, \
+                                                          use_atomic, dz_part, dcentres, dlv_part, &ns2, stream)
+    switch ((zdim + 7) / 8) {
+      case 1: EVAE_BWD_MFMA(1); break;
+      case 2: EVAE_BWD_MFMA(2); break;
+      case 3: EVAE_BWD_MFMA(3); break;
+      case 4: EVAE_BWD_MFMA(4); break;
+      case 5: EVAE_BWD_MFMA(5); break;
+      case 6: EVAE_BWD_MFMA(6); break;
+      default: EVAE_BWD_MFMA(7); break;
+    }
+#undef EVAE_BWD_MFMA
+    if (rc) return rc;
+    const int nb = cdiv(B * zdim, 64);
+    prior_bwd_finish_kernel<<<nb + cdiv(zdim, 16), 1024, 0, stream>>>(dz_part, ns2, B * zdim, zdim, log_var, dz, nb, dlv_part,
+                                                                     ns2 * nq, dlogvar);
+    return check_launch("prior_bwd_finish_kernel");
   }
   size_t lds = prior_lds_bytes(g, true);
   EVAE_DISPATCH_KC(g.kc, {

@@ -95,7 +95,11 @@ def test_prior_golden_c2(ops, golden):
 
 
 @pytest.mark.parametrize("B,C,zd,masked", [(8, 300, 40, True), (100, 1000, 40, True), (5, 7, 3, True),
-                                           (130, 70, 256, False), (200, 500, 40, True), (33, 129, 100, False)])
+                                           (130, 70, 256, False), (200, 500, 40, True), (33, 129, 100, False),
+                                           # matrix-core backward: every z_dim group up to 56, several query tiles
+                                           # (atomic dcentres), ragged last exemplar tile, 60 / 64 fall back to the VALU kernel
+                                           (100, 3125, 40, True), (300, 777, 8, True), (129, 128, 56, False),
+                                           (64, 1000, 24, True), (100, 257, 60, True), (40, 300, 64, False)])
 def test_prior_bwd_matches_oracle(ops, B, C, zd, masked):
     z, c = gi.clustered_latents(200 + B + C, B, C, zd)
     zi, ci = gi.mask_indices(9 + B, B, C, max(C // 2, 4))
@@ -108,6 +112,23 @@ def test_prior_bwd_matches_oracle(ops, B, C, zd, masked):
     gz, gc, glv = ops.prior_lse_bwd(dev(z), dev(c), dev(lv), dev(zi) if masked else None,
                                     dev(ci) if masked else None, lse_t, dev(gout))
     # fp32 kernel vs fp64 oracle; the bar for the ELBO is 1e-4 relative
+    assert rel(gz.cpu().numpy(), dz) < 1e-4
+    assert rel(gc.cpu().numpy(), dc) < 1e-4
+    assert rel(glv.cpu().numpy(), dlv) < 1e-4
+
+
+def test_prior_bwd_many_tiles_per_block(ops):
+    """More exemplar tiles than blocks (70 000 exemplars: two 128-row tiles per split), against the fp64 oracle."""
+    B, C, zd = 100, 70000, 40
+    z, c = gi.clustered_latents(31, B, C, zd)
+    zi, ci = gi.mask_indices(32, B, C, 50000)
+    lv = np.full(zd, -0.7, np.float32)
+    gout = np.random.RandomState(5).standard_normal(B).astype(np.float32)
+    dz, dc, dlv, lse = orc.prior_grads(z.astype(np.float64), zi, c.astype(np.float64), lv.astype(np.float64), ci, True,
+                                       gout.astype(np.float64))
+    m, s, n, _ = ops.prior_lse_fwd(dev(z), dev(c), dev(lv), dev(zi), dev(ci))
+    lp, lse_t = ops.prior_merge(m, s, n, C)
+    gz, gc, glv = ops.prior_lse_bwd(dev(z), dev(c), dev(lv), dev(zi), dev(ci), lse_t, dev(gout))
     assert rel(gz.cpu().numpy(), dz) < 1e-4
     assert rel(gc.cpu().numpy(), dc) < 1e-4
     assert rel(glv.cpu().numpy(), dlv) < 1e-4
