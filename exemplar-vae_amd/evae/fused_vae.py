@@ -139,13 +139,13 @@ class VaeExactLoss(torch.autograd.Function):
         side = k.side_stream()
         kd = _K(dev, stream=side, suffix="_side")        # launcher of the decoder chain
         side.wait_stream(main)
-        with torch.cuda.stream(side):                    # the prior's log-variance row, out of everybody's way
-            lv_row = plv.detach().expand(Z).contiguous()
-            lv_ready = torch.cuda.Event(); lv_ready.record()
         # ---- encoder over C + B rows
         # a gated layer keeps its output and its gate s for the backward (dg = dout * out * (1 - s)); h is never stored
         A1 = torch.empty((Mp, H), **f32); s1 = torch.empty_like(A1)
         k.gated_fwd(data_ext, rows, Mp, D, ldd, w1h, b1h, w1g, b1g, H, A1, None, s1)
+        with torch.cuda.stream(side):                    # the prior's log-variance row, issued behind the big launch so
+            lv_row = plv.detach().expand(Z).contiguous()   # that it runs next to it instead of in front of it
+            lv_ready = torch.cuda.Event(); lv_ready.record()
         A2 = torch.empty((Mp, H), **f32); s2 = torch.empty_like(A2)
         k.gated_fwd(A1, None, Mp, H, H, w2h, b2h, w2g, b2g, H, A2, None, s2)
         mean_all = torch.empty((Mp, Z), **f32)
@@ -328,8 +328,11 @@ class VaeExactLoss(torch.autograd.Function):
                         dq1.data_ptr() + off * 2 * H + 4 * H, 2 * H)
             batch_rows_done.record()
 
+        g_wm = gslot("wm", Z, H); g_bm = gslot("bm", Z)
+
         def leaves():     # nobody waits for them before the optimizer
             with torch.cuda.stream(side):
+                kd.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)     # mean head, all C + B rows
                 kd.bwd_weight(dpx, B, D, D, D2, None, H, H, g_wp, g_bp)
                 kd.bwd_weight(dp2, B, 2 * H, 2 * H, D1, None, H, H, g_d2, g_e2)
                 kd.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1)
@@ -337,9 +340,7 @@ class VaeExactLoss(torch.autograd.Function):
                 torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
         leaves()
         main.wait_event(batch_rows_done)
-        # ---- weight gradients over all C + B rows
-        g_wm = gslot("wm", Z, H); g_bm = gslot("bm", Z)
-        k.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)
+        # ---- weight gradients of the two encoder layers over all C + B rows
         g_w2 = gslot("w2", 2 * H, H); g_b2 = gslot("b2", 2 * H)
         k.bwd_weight(dq2, Mp, 2 * H, 2 * H, A1, None, H, H, g_w2, g_b2)
         g_w1 = gslot("w1", 2 * H, D); g_b1 = gslot("b1", 2 * H)
