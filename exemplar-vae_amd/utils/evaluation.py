@@ -40,25 +40,38 @@ def evaluate_loss(args, model, loader, dataset=None, exemplars_embedding=None):
     return elbo, re, kl
 
 
+IWAE_ROWS_PER_LAUNCH = 20000     # importance samples scored per calculate_loss call (several test images at once)
+
+
 def calculate_likelihood(args, model, loader, S=5000, exemplars_embedding=None):
-    """IWAE estimate -mean_x [logsumexp_s(-loss_s) - log S]  (reference :72-103)."""
-    aux = torch.utils.data.DataLoader(loader.dataset, batch_size=1)
-    out = torch.empty(len(aux), device=args.device, dtype=torch.float64)
+    """IWAE estimate -mean_x [logsumexp_s(-loss_s) - log S]  (reference :72-103).  The reference scores one test image
+    (S samples) per pass and takes the log-sum-exp on the host; here a pass carries as many images as fit in
+    IWAE_ROWS_PER_LAUNCH rows -- the S copies of an image are consecutive rows, so the eps stream is consumed in the
+    same order as image-by-image -- and the per-image log-sum-exp stays on the device."""
+    dataset = loader.dataset
+    group = max(1, min(IWAE_ROWS_PER_LAUNCH // max(int(S), 1), 64))
+    aux = torch.utils.data.DataLoader(dataset, batch_size=group)
+    n_img = len(dataset)
+    out = torch.empty(n_img, device=args.device, dtype=torch.float64)
     t0 = time.time()
-    for index, batch in enumerate(aux):
+    done = 0
+    for batch in aux:
         data = batch[0].to(args.device)
-        if index % 100 == 0:
+        data = data.reshape(data.size(0), -1)
+        g = data.size(0)
+        if done // 100 != (done + g) // 100 or done == 0:
             print(time.time() - t0)
             t0 = time.time()
-            print('{:.2f}%'.format(index / (1. * len(aux)) * 100))
-        x = data.expand(S, data.size(1)).contiguous()
+            print('{:.2f}%'.format(done / (1. * n_img) * 100))
+        x = data.repeat_interleave(S, dim=0)
         prob, _, _ = model.calculate_loss((x, None), exemplars_embedding=exemplars_embedding)
-        ll = torch.logsumexp(-prob.double(), dim=0)
+        ll = torch.logsumexp(-prob.double().view(g, S), dim=1)
         if model.args.use_logit:
             lambd = model.args.lambd
             sp = torch.nn.functional.softplus
-            ll = ll - (-sp(-x) - sp(x) - math.log((1 - 2 * lambd) / 256)).sum(dim=1).double()
-        out[index] = (ll - math.log(len(prob))).reshape(-1)[0]
+            ll = ll - (-sp(-data) - sp(data) - math.log((1 - 2 * lambd) / 256)).sum(dim=1).double()
+        out[done:done + g] = ll - math.log(S)
+        done += g
     return -float(out.mean().item())
 
 
