@@ -304,3 +304,25 @@ def test_evaluation_loops_match_reference_golden(golden):
         ll = calculate_likelihood(args, model, loader, S=S, exemplars_embedding=(cz, clv, torch.arange(len(cz))))
     assert rel(np.asarray([elbo, re, kl]), g["elbo"]) < 1e-4
     assert abs(ll - g["ll"][0]) <= 1e-4 * abs(g["ll"][0])
+
+
+def test_training_continues_from_a_reference_checkpoint(golden):
+    """Load the checkpoint the reference wrote (two steps in), take the third step with the HIP optimizer: parameters
+    equal the reference's own third step (the step count / bias correction travelled with the checkpoint)."""
+    import os
+    from models.VAE import VAE
+    from utils.optimizer import AdamNormGrad
+    from utils.utils import load_model
+    g = golden("g12_checkpoint")
+    args = smoke_case.vae_args(input_size=[1, 8, 8], hidden_size=16, z1_size=8, z2_size=8, number_components=10,
+                               training_set_size=50)
+    model = VAE(args).cuda()
+    opt = AdamNormGrad(model.parameters(), lr=5e-4)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_checkpoint.pth")
+    load_model(path, model, opt)
+    for n, p in model.named_parameters():
+        assert p.is_cuda and opt.state[p]["exp_avg"].is_cuda
+        p.grad = torch.from_numpy(g["s3_grad_" + n]).cuda()
+    opt.step()
+    for n, p in model.named_parameters():
+        assert rel(p.detach().cpu().numpy(), g["after_" + n]) < 1e-6, n

@@ -111,3 +111,46 @@ def test_oracle_sharded_merge_is_associative():
         parts = [orc.prior_partials(z, zi, c[a:b], lv, ci[a:b], True) for a, b in zip(cuts[:-1], cuts[1:])]
         merged = orc.prior_merge([p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts], 1000)
         assert np.abs(merged - full).max() < 2e-5 * np.abs(full).max()
+
+
+def _tiny_vae(device):
+    from models.VAE import VAE
+    from utils.optimizer import AdamNormGrad
+    args = smoke_case.vae_args(input_size=[1, 8, 8], hidden_size=16, z1_size=8, z2_size=8, number_components=10,
+                               training_set_size=50, device=device)
+    model = VAE(args).to(device)
+    return model, AdamNormGrad(model.parameters(), lr=5e-4)
+
+
+def test_reference_checkpoint_loads_into_model_and_optimizer():
+    """tests/golden/g12_checkpoint.pth was written by the REFERENCE's utils.utils.save_model (content of
+    density_estimation.py:148-149) after two AdamNormGrad steps: utils.utils.load_model must restore the model and the
+    optimizer state exactly as the reference's own load_model does (values recorded in g12_checkpoint.npz)."""
+    import os
+    from utils.utils import load_model, save_model
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(here, "g12_checkpoint.npz"))
+    model, opt = _tiny_vae("cpu")
+    ck = load_model(os.path.join(here, "g12_checkpoint.pth"), model, opt)
+    assert ck["epoch"] == 7 and ck["e"] == 3 and ck["best_loss"] == 123.5
+    assert [n for n, _ in model.named_parameters()] == list(g["names"])
+    for n, p in model.named_parameters():
+        st = opt.state[p]
+        assert np.array_equal(p.detach().numpy(), g["loaded_" + n]), n
+        assert np.array_equal(st["exp_avg"].numpy(), g["loaded_m_" + n]), n
+        assert np.array_equal(st["exp_avg_sq"].numpy(), g["loaded_v_" + n]), n
+        assert int(st["step"]) == int(g["loaded_step_" + n]) == 2
+    # and the file this build writes has the same layout (keys, per-parameter state entries, param_groups fields)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        content = {'epoch': 8, 'state_dict': model.state_dict(), 'optimizer': opt.state_dict(), 'best_loss': 1.0, 'e': 0}
+        save_model(os.path.join(d, "c.tmp"), os.path.join(d, "c.pth"), content)
+        mine = torch.load(os.path.join(d, "c.pth"))
+    ref = torch.load(os.path.join(here, "g12_checkpoint.pth"))
+    assert set(mine.keys()) == set(ref.keys())
+    assert list(mine["state_dict"].keys()) == list(ref["state_dict"].keys())
+    assert set(mine["optimizer"].keys()) == set(ref["optimizer"].keys())
+    assert set(mine["optimizer"]["param_groups"][0].keys()) >= {"lr", "betas", "eps", "weight_decay", "params"}
+    assert mine["optimizer"]["param_groups"][0]["params"] == ref["optimizer"]["param_groups"][0]["params"]
+    for k in ref["optimizer"]["state"]:
+        assert set(mine["optimizer"]["state"][k].keys()) == set(ref["optimizer"]["state"][k].keys()) == {"step", "exp_avg", "exp_avg_sq"}

@@ -398,7 +398,55 @@ def g11():
     save("g11_eval", elbo=np.asarray([elbo, re, kl]), ll=np.asarray([ll]))
 
 
+# ---- G12: the checkpoint wire format (density_estimation.py:148-156 + utils/utils.py:22-32) ------------------
+def g12():
+    """A checkpoint written by the REFERENCE's save_model after two optimizer steps of a tiny vae, plus what the
+    reference holds after loading it back and taking one more step -- the build must load the file (model and
+    optimizer) and continue on the same trajectory."""
+    import warnings
+    from utils.utils import save_model, load_model
+    args = vae_args(input_size=[1, 8, 8], hidden_size=16, z1_size=8, z2_size=8, number_components=10, training_set_size=50)
+    torch.manual_seed(12)
+    model = VAE(args)
+    opt = AdamNormGrad(model.parameters(), lr=5e-4)
+    rs = np.random.RandomState(120)
+    names = [n for n, _ in model.named_parameters()]
+    out = {}
+
+    def step(tag):
+        for n, p_ in model.named_parameters():
+            g = rs.standard_normal(tuple(p_.shape)).astype(np.float32)
+            out["%s_grad_%s" % (tag, n)] = g
+            p_.grad = T(g.copy())
+        opt.step()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        step("s1"); step("s2")
+        path = os.path.join(OUT, "g12_checkpoint.pth")
+        content = {'epoch': 7, 'state_dict': model.state_dict(), 'optimizer': opt.state_dict(), 'best_loss': 123.5, 'e': 3}
+        save_model(path + ".tmp", path, content)
+        # what a fresh reference model + optimizer hold after load_model, then one more step
+        torch.manual_seed(99)
+        model2 = VAE(args)
+        opt2 = AdamNormGrad(model2.parameters(), lr=5e-4)
+        ck = load_model(path, model2, opt2)
+        assert ck['epoch'] == 7 and ck['e'] == 3
+        for n, p_ in model2.named_parameters():
+            out["loaded_" + n] = p_.detach().numpy().copy()
+            out["loaded_m_" + n] = opt2.state[p_]["exp_avg"].numpy().copy()
+            out["loaded_v_" + n] = opt2.state[p_]["exp_avg_sq"].numpy().copy()
+            out["loaded_step_" + n] = np.asarray(opt2.state[p_]["step"])
+        model, opt = model2, opt2
+        step("s3")
+        for n, p_ in model2.named_parameters():
+            out["after_" + n] = p_.detach().numpy().copy()
+    out["names"] = np.asarray(names)
+    save("g12_checkpoint", **out)
+    print("g12_checkpoint.pth %8.1f KB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()
