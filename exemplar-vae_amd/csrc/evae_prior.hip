@@ -1026,7 +1026,7 @@ extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, i
   EVAE_REQUIRE(B >= 0 && C >= 0 && zdim > 0, "prior_lse_bwd: bad sizes");
   EVAE_REQUIRE(zdim <= 4 * KC_MAX, "prior_lse_bwd: zdim %d > %d unsupported", zdim, 4 * KC_MAX);
   if (B == 0 && C == 0) return EVAE_OK;
-  EVAE_REQUIRE(dz && dlogvar && log_var, "prior_lse_bwd: null pointer");
+  EVAE_REQUIRE((dz || B == 0) && dlogvar && log_var, "prior_lse_bwd: null pointer");   // an empty batch has no dz
   if (B == 0 || C == 0) {
     if (B > 0) zero_kernel<<<cdiv(B * zdim, 256), 256, 0, stream>>>(dz, (size_t)B * zdim);
     if (C > 0 && dcentres) zero_kernel<<<cdiv(C * zdim, 256), 256, 0, stream>>>(dcentres, (size_t)C * zdim);

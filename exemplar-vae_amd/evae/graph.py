@@ -14,6 +14,9 @@ counter-based generator (evae_batch_prologue: seed = torch's seed when the runne
 in the control block); whatever else draws random numbers uses the CUDA generator, which torch registers with the
 capture so that every replay advances its Philox offset.  RCCL collectives of the sharded prior are captured too.
 """
+import os
+import sys
+
 import torch
 
 from . import ops, shard
@@ -166,7 +169,6 @@ class GraphedTrainStep:
                 # with RCCL in the step its watchdog thread polls events while we capture: thread-local capture mode
                 # keeps those calls from invalidating the capture
                 mode = "thread_local" if shard.is_active() else "global"
-                import os
                 mode = os.environ.get("EVAE_CAPTURE_MODE", mode)
                 try:
                     with torch.cuda.graph(graph, capture_error_mode=mode):
@@ -174,7 +176,6 @@ class GraphedTrainStep:
                     getattr(self.opt, 'finish_capture', lambda: None)()
                     self.graph = graph
                 except Exception as e:           # an op of this model that cannot be captured: eager from here on
-                    import sys
                     print("evae.graph: hipGraph capture of the training step failed (%s: %s); running eagerly"
                           % (type(e).__name__, str(e).splitlines()[0][:120]), file=sys.stderr)
                     self.failed = True

@@ -498,3 +498,40 @@ def test_batch_prologue_gather_binarise_eps(ops):
     flat = E.reshape(60, -1)
     assert abs(float((flat[:, 0::2] * flat[:, 1::2]).mean())) < 0.01
     assert abs(float((flat[:-1] * flat[1:]).mean())) < 0.01
+
+
+def test_empty_inputs(ops):
+    """The empty cases of the domain: a rank whose exemplar shard is empty (C = 0), an empty batch (B = 0), an empty
+    row-gather list, an optimizer without tensors.  Nothing may crash; results are the neutral elements."""
+    zd = 40
+    z = dev(np.random.RandomState(1).standard_normal((6, zd)).astype(np.float32))
+    c = dev(np.random.RandomState(2).standard_normal((50, zd)).astype(np.float32))
+    lv = dev(np.zeros(zd, np.float32))
+    # empty shard: max = -inf, sumexp = 0, nothing masked; merging it with a real shard changes nothing
+    m0, s0, n0, _ = ops.prior_lse_fwd(z, c[:0], lv)
+    assert bool(torch.isneginf(m0).all()) and float(s0.abs().sum()) == 0.0 and float(n0.abs().sum()) == 0.0
+    m1, s1, n1, _ = ops.prior_lse_fwd(z, c, lv)
+    lp_a, lse_a = ops.prior_merge(torch.stack((m1, m0)), torch.stack((s1, s0)), torch.stack((n1, n0)), 50)
+    lp_b, lse_b = ops.prior_merge(m1, s1, n1, 50)
+    assert torch.equal(lp_a, lp_b) and torch.equal(lse_a, lse_b)
+    gz, gc, glv = ops.prior_lse_bwd(z, c[:0], lv, None, None, lse_b, torch.ones(6, device="cuda"))
+    assert gc.shape == (0, zd) and float(gz.abs().sum()) == 0.0 and float(glv.abs().sum()) == 0.0
+    # empty batch
+    mb, sb, nb, _ = ops.prior_lse_fwd(z[:0], c, lv)
+    assert mb.numel() == 0
+    gz, gc, glv = ops.prior_lse_bwd(z[:0], c, lv, None, None, lse_b[:0], torch.ones(0, device="cuda"))
+    assert gz.shape == (0, zd) and float(gc.abs().sum()) == 0.0
+    # dense layers over zero rows: outputs empty, weight gradients zero
+    w = [dev(a).requires_grad_(True) for a in (np.ones((8, zd), np.float32), np.zeros(8, np.float32),
+                                               np.ones((8, zd), np.float32), np.zeros(8, np.float32))]
+    out = ops.gated_dense(z[:0], *w)
+    assert out.shape == (0, 8)
+    out.sum().backward()
+    assert all(float(t.grad.abs().sum()) == 0.0 for t in w)
+    rows = torch.zeros(0, dtype=torch.int64, device="cuda")
+    assert ops.gated_dense(z, *[t.detach() for t in w], rows=rows).shape == (0, 8)
+    # optimizer without tensors, prologue without rows
+    ops.adam_normgrad_step([], [], [], [], 1, 5e-4, 0.9, 0.999, 1e-8, 0.0)
+    ops.batch_prologue(c, rows, True, torch.tensor([1, 0], dtype=torch.int64, device="cuda"), torch.empty((0, zd), device="cuda"),
+                       torch.empty((0, 8), device="cuda"))
+    torch.cuda.synchronize()
