@@ -4,13 +4,16 @@ models/BaseModel.py:65-77 + AbsModel.py:13-19,44-49 + BaseModel.py:243-248 in th
 Same arithmetic as the modular path (utils.nn.GatedDense, evae.ops.PriorLogP, ...), arranged for the
 hardware:
 
-* the B batch rows ride along the C exemplar rows through the encoder: the binarised batch is copied
-  into staging rows behind the HBM-resident dataset and ONE row-gathered GEMM per encoder layer
-  serves all C + B rows (forward, data gradient and weight gradient), so the replicated 100-row batch
+* the B batch rows ride along the C exemplar rows through the encoder: the binarised batch sits in staging
+  rows behind the HBM-resident dataset (the captured step gathers it there itself, evae/graph.py) and ONE
+  row-gathered GEMM per encoder layer serves all C + B rows (forward and weight gradient), so the 100-row batch
   path costs three thin decoder layers instead of a second pass over every encoder layer;
 * every GatedDense backward uses the merged [dh | dg] buffer (one weight-gradient GEMM per layer) and
   the gate derivative of the layer below is applied in the epilogue of the data-gradient GEMM;
-* one autograd node instead of ~25: ~50 kernel launches per step and no per-op autograd bookkeeping.
+* one autograd node instead of ~25: 61 kernel launches per step and no per-op autograd bookkeeping;
+* two streams scheduled by hand: the exemplar-prior chain (with its collectives when sharded) and the big
+  GEMMs on the main stream, the decoder chain of the batch rows and every weight gradient nobody waits for on
+  the side stream (DESIGN.md section 4 for what was measured to arrive at this order of issue).
 
 With torch.distributed active and shard=True the exemplar rows are this rank's shard: the per-row
 partials (max, sumexp, nmask) are all-gathered and merged, dz / dlogvar are sum-all-reduced and
