@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Eager timing of one training step for the BASELINE.json configurations (parity-test cases, not bench lines).
-usage: config_bench.py c1|c2|c3|c4|c5 [exemplars] [steps]"""
+usage: config_bench.py c1|c2|c2a|c3|c4|c5 [exemplars] [steps]   (c2a = c2 with the approximate kNN prior)"""
 import os, sys, time
 from argparse import Namespace
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +13,7 @@ which = sys.argv[1]
 CFG = {
     "c1": dict(model_name="vae", C=1000, N=50000, input_size=[1, 28, 28], input_type="binary", z=40),
     "c2": dict(model_name="vae", C=25000, N=50000, input_size=[1, 28, 28], input_type="binary", z=40),
+    "c2a": dict(model_name="vae", C=25000, N=50000, input_size=[1, 28, 28], input_type="binary", z=40, approximate=True),
     "c3": dict(model_name="convhvae_2level", C=25000, N=50000, input_size=[1, 28, 28], input_type="binary", z=40),
     "c4": dict(model_name="hvae_2level", C=11500, N=23000, input_size=[1, 28, 28], input_type="binary", z=40),
     "c5": dict(model_name="single_conv", C=100000, N=100000, input_size=[3, 64, 64], input_type="continuous", z=256,
