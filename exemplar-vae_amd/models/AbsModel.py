@@ -55,6 +55,18 @@ class AbsModel(BaseModel):
         posterior_term = log_normal_diag(z, mu, logvar, dim=1)
         return posterior_term - prior_term
 
+    def importance_sample_losses(self, data, S, exemplars_embedding):
+        """q(z|x) is the same for the S copies of an image: encode the g images once, expand mean / log-variance,
+        then sample, decode and score the g * S rows as calculate_loss does (beta = 1, per-row values)."""
+        flat = data.reshape(data.size(0), -1)
+        mu, logvar = self.q_z(flat)
+        mu, logvar = mu.repeat_interleave(S, dim=0), logvar.repeat_interleave(S, dim=0)
+        z = self.reparameterize(mu, logvar)
+        x_mean, x_logvar = self.p_x(z)
+        RE = self.reconstruction_loss(flat.repeat_interleave(S, dim=0), x_mean, x_logvar)
+        KL = self.kl_loss((z, mu, logvar), exemplars_embedding, None, None, None)
+        return -RE + KL
+
     def forward(self, x, label=0, num_categories=10):
         mu, logvar = self.q_z(x)
         z = self.reparameterize(mu, logvar)

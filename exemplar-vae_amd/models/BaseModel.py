@@ -121,6 +121,14 @@ class BaseModel(nn.Module, ABC):
             loss, RE, KL = torch.mean(loss), torch.mean(RE), torch.mean(KL)
         return loss, RE, KL
 
+    def importance_sample_losses(self, data, S, exemplars_embedding):
+        """-ELBO of S importance samples for each row of `data` [g x D] -> [g * S], sample s of image i at row i * S + s
+        (what utils.evaluation.calculate_likelihood needs; the reference builds it by expanding the image S times and
+        calling calculate_loss, utils/evaluation.py:88-90).  Subclasses whose encoder only sees x encode each image
+        once instead of S times."""
+        x = data.reshape(data.size(0), -1).repeat_interleave(S, dim=0)
+        return self.calculate_loss((x, None), exemplars_embedding=exemplars_embedding)[0]
+
     def _draw_eps(self, like):
         """Standard-normal noise from the device generator (reference :81); tests override this to inject
         identical eps into the reference, the oracle and this model."""

@@ -63,8 +63,7 @@ def calculate_likelihood(args, model, loader, S=5000, exemplars_embedding=None):
             print(time.time() - t0)
             t0 = time.time()
             print('{:.2f}%'.format(done / (1. * n_img) * 100))
-        x = data.repeat_interleave(S, dim=0)
-        prob, _, _ = model.calculate_loss((x, None), exemplars_embedding=exemplars_embedding)
+        prob = model.importance_sample_losses(data, S, exemplars_embedding)
         ll = torch.logsumexp(-prob.double().view(g, S), dim=1)
         if model.args.use_logit:
             lambd = model.args.lambd
