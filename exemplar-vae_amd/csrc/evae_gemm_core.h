@@ -228,7 +228,8 @@ static Plan make_plan(int M, int N, int slabs, bool gated, bool must_split, int 
       if (nze != nz) continue;
       const long rounds = (tiles * nze + 511) / 512;
       double t = rounds * (ks + 1.5) * slab_cost;
-      if (nze > 1 || must_split) t += 2.0 + (double)M * N * planes * nze * 4.0 / 12e6;
+      // the finish launch: ~3 slab-times of a dependent launch inside a graph (measured: 2 -> 3 takes 0.7 % off the c2 step)
+      if (nze > 1 || must_split) t += 3.0 + (double)M * N * planes * nze * 4.0 / 12e6;
       if (t < best_t) { best_t = t; best = {bn, nze, ks}; }
     }
   }
