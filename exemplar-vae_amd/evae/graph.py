@@ -75,7 +75,9 @@ class GraphedTrainStep:
             # data-parallel batches: every rank needs its own noise (replicated batches need the SAME noise on every rank)
             self.seed += 0x9E3779B97F4A7C15 * (shard.world()[0] + 1)
         self.seed &= 0x7FFFFFFFFFFFFFFF
-        self.eps_buf = torch.zeros((self.B, int(a.z1_size)), device=dev) if a.model_name == 'vae' else None
+        # ... unless the model carries its own noise hook (an instance-level _draw_eps: tests, deterministic runs)
+        own_noise = a.model_name == 'vae' and '_draw_eps' not in model.__dict__
+        self.eps_buf = torch.zeros((self.B, int(a.z1_size)), device=dev) if own_noise else None
         self._one = torch.ones((), device=dev)
         self.out = torch.zeros(3, device=dev)       # (loss, -RE, KL) of the last step
         self.totals = torch.zeros(3, device=dev)    # running sums since reset_totals()

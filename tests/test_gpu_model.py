@@ -326,3 +326,49 @@ def test_training_continues_from_a_reference_checkpoint(golden):
     opt.step()
     for n, p in model.named_parameters():
         assert rel(p.detach().cpu().numpy(), g["after_" + n]) < 1e-6, n
+
+
+def test_epoch_loops_match_reference_golden(golden, tmp_path):
+    """utils.training.train_one_epoch (two epochs, hipGraph step for the full batches, eager for the partial last one),
+    utils.knn_on_latent.report_knn_on_latent and utils.evaluation.final_evaluation against the reference's own loops on
+    the same data, weights and exemplar draws (tools/gen_goldens.py::g13; z = mean in both trees)."""
+    from utils.optimizer import AdamNormGrad
+    from utils.training import train_one_epoch
+    from utils.knn_on_latent import report_knn_on_latent
+    from utils.evaluation import final_evaluation
+    from utils.utils import save_model
+    g = golden("g13_loops")
+    N, NV, B, C = 200, 64, 32, 50
+    args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=B, dynamic_binarization=False,
+                               warmup=100, S=20)
+    model, _ = smoke_case.build_model(torch, np, orc, args)
+    model._draw_eps = lambda like: torch.zeros_like(like)
+    mk = lambda seed, n: torch.from_numpy(gi.binary_images(seed, n))
+    train_ds = torch.utils.data.TensorDataset(mk(81, N), torch.arange(N).reshape(-1, 1), torch.arange(N) % 10)
+    val_ds = torch.utils.data.TensorDataset(mk(82, NV), (torch.arange(NV) * 3) % 10)
+    test_ds = torch.utils.data.TensorDataset(mk(83, NV), (torch.arange(NV) * 7) % 10)
+    L = lambda ds: torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False)
+    train_loader, val_loader, test_loader = L(train_ds), L(val_ds), L(test_ds)
+    opt = AdamNormGrad(model.parameters(), lr=5e-4)
+    torch.manual_seed(130)
+    r1 = train_one_epoch(1, args, train_loader, model, opt)
+    r2 = train_one_epoch(2, args, train_loader, model, opt)
+    runners = list(model._graphed_steps.values())
+    assert len(runners) == 1 and runners[0].graph is not None and runners[0].by_index     # the full batches were replays
+    assert rel(np.asarray(r1), g["epoch1"]) < 1e-4
+    assert rel(np.asarray(r2), g["epoch2"]) < 1e-4
+    for n, p in model.named_parameters():
+        assert abs(p.detach().double().norm().item() - float(g["norm_" + n])) <= 1e-4 * max(float(g["norm_" + n]), 1e-3), n
+        assert abs(p.detach().double().sum().item() - float(g["sum_" + n])) <= 2e-4 * max(float(g["norm_" + n]), 1e-3), n
+    model.eval()
+    for flag, key in ((True, "knn_val"), (False, "knn_test")):
+        d = {"3": [], "5": [], "7": [], "15": []}
+        report_knn_on_latent(train_loader, val_loader, test_loader, model, "", d, args, val=flag)
+        assert np.array_equal(np.asarray([d[k][0] for k in ("3", "5", "7", "15")]), g[key]), key
+    out = str(tmp_path) + "/"
+    save_model(out + "c.tmp", out + "best.model", {'epoch': 2, 'state_dict': model.state_dict(), 'optimizer': opt.state_dict(),
+                                                  'best_loss': 0.0, 'e': 0})
+    final_evaluation(train_loader, test_loader, val_loader, out + "best.model", model, opt, args, out)
+    got = [float(torch.load(out + "vae." + k, weights_only=False)) for k in ("test_log_likelihood", "test_loss", "test_re", "test_kl")]
+    assert rel(np.asarray(got), g["final"]) < 1e-4
+    assert open(out + "vae_experiment_log.txt").read().split("\n")[0] == "FINAL EVALUATION ON TEST SET"

@@ -446,7 +446,59 @@ def g12():
     print("g12_checkpoint.pth %8.1f KB" % (os.path.getsize(path) / 1024))
 
 
+# ---- G13: the loops either side of the hot path (utils/training.py:15-51, knn_on_latent.py:32-74, evaluation.py:106-140)
+def g13():
+    """Two epochs of the reference's train_one_epoch on a tiny dataset (last batch partial), then its kNN report and its
+    final_evaluation.  z = mean (reparameterize patched) so that the run is deterministic and a captured step can
+    reproduce it; exemplar indices come from the seeded CPU generator in both trees."""
+    import tempfile, warnings
+    import utils.evaluation as ev
+    from utils.training import train_one_epoch
+    from utils.knn_on_latent import report_knn_on_latent
+    from utils.utils import save_model
+    N, NV, B, C = 200, 64, 32, 50
+    args = vae_args(number_components=C, training_set_size=N)
+    args.batch_size, args.dynamic_binarization, args.warmup, args.S = B, False, 100, 20
+    model = VAE(args)
+    load_params(model, orc.vae_init_params(np.random.RandomState(123)))
+    model.reparameterize = lambda mu, logvar: mu
+    mk = lambda seed, n: T(gi.binary_images(seed, n))
+    train_ds = torch.utils.data.TensorDataset(mk(81, N), torch.arange(N).reshape(-1, 1), torch.arange(N) % 10)
+    val_ds = torch.utils.data.TensorDataset(mk(82, NV), (torch.arange(NV) * 3) % 10)
+    test_ds = torch.utils.data.TensorDataset(mk(83, NV), (torch.arange(NV) * 7) % 10)
+    L = lambda ds: torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False)
+    train_loader, val_loader, test_loader = L(train_ds), L(val_ds), L(test_ds)
+    opt = AdamNormGrad(model.parameters(), lr=5e-4)
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(130)
+        out["epoch1"] = np.asarray(train_one_epoch(1, args, train_loader, model, opt))
+        out["epoch2"] = np.asarray(train_one_epoch(2, args, train_loader, model, opt))
+        for n, p_ in model.named_parameters():
+            out["sum_" + n] = np.asarray(p_.detach().double().sum().item())
+            out["norm_" + n] = np.asarray(p_.detach().double().norm().item())
+        model.eval()
+        for flag in (True, False):
+            d = {"3": [], "5": [], "7": [], "15": []}
+            report_knn_on_latent(train_loader, val_loader, test_loader, model, "", d, args, val=flag)
+            out["knn_val" if flag else "knn_test"] = np.asarray([d[k][0] for k in ("3", "5", "7", "15")])
+        ev.visualize_reconstruction = lambda *a, **k: None       # plotting, outside the path
+        ev.visualize_generation = lambda *a, **k: None
+        with tempfile.TemporaryDirectory() as tmp:
+            tmp = tmp + "/"
+            save_model(tmp + "c.tmp", tmp + "best.model", {'epoch': 2, 'state_dict': model.state_dict(),
+                                                           'optimizer': opt.state_dict(), 'best_loss': 0.0, 'e': 0})
+            with torch.no_grad():                                  # as density_estimation.py calls it
+                ev.final_evaluation(train_loader, test_loader, val_loader, tmp + "best.model", model, opt, args, tmp)
+            out["final"] = np.asarray([float(torch.load(tmp + "vae." + k, weights_only=False))
+                                       for k in ("test_log_likelihood", "test_loss", "test_re", "test_kl")])
+            out["log_txt"] = np.asarray(open(tmp + "vae_experiment_log.txt").read())
+    save("g13_loops", **out)
+    print(out["epoch1"], out["epoch2"], out["knn_val"], out["knn_test"], out["final"])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()
