@@ -192,7 +192,10 @@ struct TileLoader {
   }
 };
 
-template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW, int CV = 0>
+// GATHER_A: the rows of a KC A operand are gathered through g.a_rows (the exemplar gather of the first encoder layer).  A
+// template parameter rather than a run-time test so that the gathered launch -- the dominant one of a training step -- is
+// a kernel symbol of its own in per-kernel profiles.
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW, int CV = 0, bool GATHER_A = false>
 __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g) {
   constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
   constexpr int GNT = 64 * NW;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
     constexpr int NVA = BM * BK / 4 / GNT, NVB = BN_ * BK / 4 / GNT;
     constexpr int RQA = BM / 4, RQB = BN_ / 4, RSA = BM + 4, RSB = BN_ + 4;
     constexpr bool PAIRS = A_KC && !B_KC;   // only the data gradient chains two (A,B) pairs
-    const bool gatherA = A_KC && g.a_rows != nullptr;
+    constexpr bool gatherA = A_KC && GATHER_A;
     const bool gatherB = !B_KC && g.b_krows != nullptr;
     const bool has_ones = !B_KC && g.ones_col >= n0 && g.ones_col < n0 + BN_;
     const rsrc_t rA0 = make_rsrc(g.A[0], 0x7FFFFFFFu);
@@ -507,9 +510,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
 #undef EVAE_SB
     };
     if (s_begin < s_end) {
-      if (gatherA) run(std::true_type{}, std::false_type{});
-      else if (gatherB) run(std::false_type{}, std::true_type{});
-      else run(std::false_type{}, std::false_type{});
+      if constexpr (gatherA) run(std::true_type{}, std::false_type{});
+      else {
+        if (gatherB) run(std::false_type{}, std::true_type{});
+        else run(std::false_type{}, std::false_type{});
+      }
     }
   } else {
     typedef TileLoader<BM, A_KC, GNT> LA;
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
   #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if (p < g.npairs) {
-        la[p].init(g.A[p], g.lda[p], m0, g.M, g.a_rows);
+        la[p].init(g.A[p], g.lda[p], m0, g.M, GATHER_A ? g.a_rows : nullptr);
         if (!GATED) lb[p].init(g.B[p], g.ldb[p], n0, g.N, nullptr);
       }
     }
@@ -787,12 +792,13 @@ static bool gemm_vec_ok(const GemmArgs& g) {
   return ok;
 }
 
-template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW, int CV = 0>
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW, int CV = 0, bool GA = false>
 static int launch_gemm_w(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
+  if ((g.a_rows != nullptr) != GA) { set_error("%s: row gather does not match the kernel variant", what); return EVAE_EINVAL; }
   static bool attr = false;
   constexpr size_t lds = gemm_lds_bytes(BN_);
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KC, B_KC, EPI, VEC, BN_, NW, CV>,
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KC, B_KC, EPI, VEC, BN_, NW, CV, GA>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
@@ -805,7 +811,7 @@ static int launch_gemm_w(GemmArgs& g, int nz, hipStream_t stream, const char* wh
     if (dbg < 0) { const char* e = getenv("EVAE_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
     g.dbg = dbg;
   }
-  gemm_kernel<A_KC, B_KC, EPI, VEC, BN_, NW, CV><<<grid, 64 * NW, lds, stream>>>(g);
+  gemm_kernel<A_KC, B_KC, EPI, VEC, BN_, NW, CV, GA><<<grid, 64 * NW, lds, stream>>>(g);
   return check_launch(what);
 }
 
@@ -819,26 +825,34 @@ static int gemm_nw() {
   return nw;
 }
 
-template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_>
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, bool GA = false>
 static int launch_gemm_v(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
-  if (gemm_nw() == 4) return launch_gemm_w<A_KC, B_KC, EPI, VEC, BN_, 4>(g, nz, stream, what);
-  return launch_gemm_w<A_KC, B_KC, EPI, VEC, BN_, 8>(g, nz, stream, what);
+  if (gemm_nw() == 4) return launch_gemm_w<A_KC, B_KC, EPI, VEC, BN_, 4, 0, GA>(g, nz, stream, what);
+  return launch_gemm_w<A_KC, B_KC, EPI, VEC, BN_, 8, 0, GA>(g, nz, stream, what);
 }
 
-template <bool A_KC, bool B_KC, int EPI>
-static int launch_gemm(GemmArgs& g, const Plan& pl, hipStream_t stream, const char* what) {
+template <bool A_KC, bool B_KC, int EPI, bool GA>
+static int launch_gemm_ga(GemmArgs& g, const Plan& pl, hipStream_t stream, const char* what) {
   constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
   const bool vec = gemm_vec_ok<A_KC, B_KC>(g);
   g.ksplit = pl.nz > 1 ? pl.ksplit : 0;
   if (GATED || pl.bn == 128) {
-    if (vec) return launch_gemm_v<A_KC, B_KC, EPI, true, 128>(g, pl.nz, stream, what);
-    return launch_gemm_v<A_KC, B_KC, EPI, false, 128>(g, pl.nz, stream, what);
+    if (vec) return launch_gemm_v<A_KC, B_KC, EPI, true, 128, GA>(g, pl.nz, stream, what);
+    return launch_gemm_v<A_KC, B_KC, EPI, false, 128, GA>(g, pl.nz, stream, what);
   }
   if constexpr (!GATED) {
-    if (vec) return launch_gemm_v<A_KC, B_KC, EPI, true, 64>(g, pl.nz, stream, what);
-    return launch_gemm_v<A_KC, B_KC, EPI, false, 64>(g, pl.nz, stream, what);
+    if (vec) return launch_gemm_v<A_KC, B_KC, EPI, true, 64, GA>(g, pl.nz, stream, what);
+    return launch_gemm_v<A_KC, B_KC, EPI, false, 64, GA>(g, pl.nz, stream, what);
   }
   return EVAE_EINVAL;
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+static int launch_gemm(GemmArgs& g, const Plan& pl, hipStream_t stream, const char* what) {
+  if constexpr (A_KC && B_KC) {       // only the forward launches take a row-gather list
+    if (g.a_rows != nullptr) return launch_gemm_ga<A_KC, B_KC, EPI, true>(g, pl, stream, what);
+  }
+  return launch_gemm_ga<A_KC, B_KC, EPI, false>(g, pl, stream, what);
 }
 
 static int total_slabs(int k0, int k1) { return cdiv(k0, BK) + (k1 > 0 ? cdiv(k1, BK) : 0); }
