@@ -154,3 +154,67 @@ def test_reference_checkpoint_loads_into_model_and_optimizer():
     assert mine["optimizer"]["param_groups"][0]["params"] == ref["optimizer"]["param_groups"][0]["params"]
     for k in ref["optimizer"]["state"]:
         assert set(mine["optimizer"]["state"][k].keys()) == set(ref["optimizer"]["state"][k].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_load_data_pipeline_matches_reference_golden():
+    """utils.load_data.base_load_data.load_dataset == the reference's on the same raw arrays and numpy seed: split,
+    value range (three variants), fixed-seed binarisation of validation / test, dataset tuples (tools/gen_goldens.py::g14)."""
+    import os
+    from types import SimpleNamespace
+    from utils.load_data.base_load_data import base_load_data
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14_load_data.npz"))
+    T = torch.from_numpy
+
+    class stub(base_load_data):
+        def obtain_data(self):
+            return (SimpleNamespace(data=T(g["raw_train"]), train_labels=T(g["lab_train"])),
+                    SimpleNamespace(data=T(g["raw_test"]), test_labels=T(g["lab_test"])))
+    variants = {"dyn": dict(input_type="binary", dynamic_binarization=True, continuous=False, use_logit=False),
+                "grey": dict(input_type="gray", dynamic_binarization=False, continuous=True, use_logit=False),
+                "logit": dict(input_type="gray", dynamic_binarization=False, continuous=False, use_logit=True)}
+    for tag, kw in variants.items():
+        a = Namespace(dataset_name="dynamic_mnist", input_size=[1, 8, 8], training_set_size=250, batch_size=32, test_batch_size=20,
+                      use_training_data_init=0, number_components=10, lambd=1e-4, **kw)
+        np.random.seed(141)
+        tr, va, te, a2 = stub(a, no_binarization=(tag != "dyn")).load_dataset()
+        got = dict(zip(("x_train", "idx", "y_train"), tr.dataset.tensors))
+        got.update(zip(("x_val", "y_val"), va.dataset.tensors)); got.update(zip(("x_test", "y_test"), te.dataset.tensors))
+        for k, v in got.items():
+            ref = g[tag + "_" + k]
+            assert v.numpy().dtype == ref.dtype and np.array_equal(v.numpy(), ref), (tag, k)
+        assert str(g[tag + "_input_type"]) == a2.input_type
+        assert [tr.batch_size, va.batch_size, te.batch_size] == list(g[tag + "_batch"])
+        assert tr.dataset.tensors[1].shape == (250, 1) and tr.dataset.tensors[1].dtype == torch.int64
+
+
+def test_load_dataset_dispatch_reads_local_idx_files(tmp_path, monkeypatch):
+    """utils.load_data.data_loader_instances.load_dataset('dynamic_mnist') from IDX files on disk (no torchvision, no
+    network): args fields as the reference sets them, loaders of the documented shapes; a missing dataset fails loudly."""
+    import struct
+    from utils.load_data.data_loader_instances import load_dataset
+    raw = tmp_path / "datasets" / "dynamic_mnist" / "MNIST" / "raw"
+    raw.mkdir(parents=True)
+    rs = np.random.RandomState(3)
+
+    def idx(name, arr):
+        with open(raw / name, "wb") as f:
+            f.write(struct.pack(">HBB", 0, 8, arr.ndim) + struct.pack(">" + "I" * arr.ndim, *arr.shape) + arr.tobytes())
+    idx("train-images-idx3-ubyte", rs.randint(0, 256, (120, 28, 28)).astype(np.uint8))
+    idx("train-labels-idx1-ubyte", rs.randint(0, 10, 120).astype(np.uint8))
+    idx("t10k-images-idx3-ubyte", rs.randint(0, 256, (30, 28, 28)).astype(np.uint8))
+    idx("t10k-labels-idx1-ubyte", rs.randint(0, 10, 30).astype(np.uint8))
+    monkeypatch.chdir(tmp_path)
+    a = Namespace(dataset_name="dynamic_mnist", continuous=False, use_logit=False, lambd=1e-4, batch_size=16, test_batch_size=10,
+                  training_set_size=None, use_training_data_init=0, number_components=5)
+    tr, va, te, a = load_dataset(a, training_num=100)
+    assert (a.input_size, a.input_type, a.dynamic_binarization, a.training_set_size) == ([1, 28, 28], "binary", True, 100)
+    x, i, y = tr.dataset.tensors
+    assert x.shape == (100, 784) and x.dtype == torch.float32 and float(x.max()) <= 1.0 and i.shape == (100, 1)
+    assert va.dataset.tensors[0].shape == (20, 784) and te.dataset.tensors[0].shape == (30, 784)
+    assert set(np.unique(te.dataset.tensors[0].numpy())) <= {0.0, 1.0}          # evaluation splits binarised once
+    a.dataset_name = "fashion_mnist"
+    with pytest.raises(FileNotFoundError):
+        load_dataset(a)
+    a.dataset_name = "imagenet"
+    with pytest.raises(Exception, match="Wrong name of the dataset"):
+        load_dataset(a)

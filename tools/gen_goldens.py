@@ -498,7 +498,39 @@ def g13():
     print(out["epoch1"], out["epoch2"], out["knn_val"], out["knn_test"], out["final"])
 
 
+# ---- G14: raw arrays -> loaders (utils/load_data/base_load_data.py:8-120) ---------------------------------------
+def g14():
+    """The reference's load_dataset pipeline on synthetic 8-bit images behind a stub obtain_data: split, value range,
+    fixed-seed binarisation of the evaluation splits, dataset tuples.  Three variants: dynamically binarised, grey with
+    (x + 0.5) / 256, grey with the logit transform (noise from the global numpy generator)."""
+    from types import SimpleNamespace
+    from utils.load_data.base_load_data import base_load_data
+    rs = np.random.RandomState(140)
+    raw_train = rs.randint(0, 256, (300, 8, 8)).astype(np.uint8); lab_train = rs.randint(0, 10, 300)
+    raw_test = rs.randint(0, 256, (60, 8, 8)).astype(np.uint8); lab_test = rs.randint(0, 10, 60)
+
+    class stub(base_load_data):
+        def obtain_data(self):
+            return (SimpleNamespace(data=T(raw_train), train_labels=T(lab_train)),
+                    SimpleNamespace(data=T(raw_test), test_labels=T(lab_test)))
+    out = {"raw_train": raw_train, "lab_train": lab_train, "raw_test": raw_test, "lab_test": lab_test}
+    variants = {"dyn": dict(input_type="binary", dynamic_binarization=True, continuous=False, use_logit=False),
+                "grey": dict(input_type="gray", dynamic_binarization=False, continuous=True, use_logit=False),
+                "logit": dict(input_type="gray", dynamic_binarization=False, continuous=False, use_logit=True)}
+    for tag, kw in variants.items():
+        a = Namespace(dataset_name="dynamic_mnist", input_size=[1, 8, 8], training_set_size=250, batch_size=32, test_batch_size=20,
+                      use_training_data_init=0, number_components=10, lambd=1e-4, **kw)
+        np.random.seed(141)
+        tr, va, te, a2 = stub(a, no_binarization=(tag != "dyn")).load_dataset()
+        out[tag + "_x_train"], out[tag + "_idx"], out[tag + "_y_train"] = (t.numpy() for t in tr.dataset.tensors)
+        out[tag + "_x_val"], out[tag + "_y_val"] = (t.numpy() for t in va.dataset.tensors)
+        out[tag + "_x_test"], out[tag + "_y_test"] = (t.numpy() for t in te.dataset.tensors)
+        out[tag + "_input_type"] = np.asarray(a2.input_type)
+        out[tag + "_batch"] = np.asarray([tr.batch_size, va.batch_size, te.batch_size])
+    save("g14_load_data", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()
