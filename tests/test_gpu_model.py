@@ -372,3 +372,61 @@ def test_epoch_loops_match_reference_golden(golden, tmp_path):
     got = [float(torch.load(out + "vae." + k, weights_only=False)) for k in ("test_log_likelihood", "test_loss", "test_re", "test_kl")]
     assert rel(np.asarray(got), g["final"]) < 1e-4
     assert open(out + "vae_experiment_log.txt").read().split("\n")[0] == "FINAL EVALUATION ON TEST SET"
+
+
+def test_end_to_end_run_on_grey_data_with_dynamic_binarisation(tmp_path, monkeypatch):
+    """What density_estimation.py does, with this build's modules only: load_dataset from IDX files on disk (grey-level
+    training rows, dynamically binarised per step, evaluation splits binarised once), importing_model, AdamNormGrad,
+    epochs of train_one_epoch (shuffled CPU batches -> the captured step gathers them by index and binarises them in its
+    prologue launch; the exemplars stay grey, as in the reference) + evaluate_loss + save_model, then final_evaluation."""
+    import struct
+    from argparse import Namespace
+    from utils.load_data.data_loader_instances import load_dataset
+    from utils.utils import importing_model, save_model
+    from utils.optimizer import AdamNormGrad
+    from utils.training import train_one_epoch
+    from utils.evaluation import evaluate_loss, final_evaluation
+    raw = tmp_path / "datasets" / "dynamic_mnist" / "MNIST" / "raw"
+    raw.mkdir(parents=True)
+    rs = np.random.RandomState(11)
+    protos = (gi.gray_images(5, 10) * 255.0).reshape(10, 28, 28)               # ten grey prototypes
+
+    def split(n):
+        lab = rs.randint(0, 10, n)
+        img = np.clip(protos[lab] + rs.normal(0, 12, (n, 28, 28)), 0, 255).astype(np.uint8)
+        return img, lab.astype(np.uint8)
+
+    def idx(name, arr):
+        with open(raw / name, "wb") as f:
+            f.write(struct.pack(">HBB", 0, 8, arr.ndim) + struct.pack(">" + "I" * arr.ndim, *arr.shape) + arr.tobytes())
+    xtr, ytr = split(700); xte, yte = split(100)
+    idx("train-images-idx3-ubyte", xtr); idx("train-labels-idx1-ubyte", ytr)
+    idx("t10k-images-idx3-ubyte", xte); idx("t10k-labels-idx1-ubyte", yte)
+    monkeypatch.chdir(tmp_path)
+    args = smoke_case.vae_args(dataset_name="dynamic_mnist", number_components=200, batch_size=50, test_batch_size=50, S=20,
+                               warmup=2, use_training_data_init=0, training_set_size=None)
+    torch.manual_seed(4); np.random.seed(4)
+    train_loader, val_loader, test_loader, args = load_dataset(args, training_num=600)
+    assert args.dynamic_binarization is True and args.input_type == "binary" and args.training_set_size == 600
+    grey = train_loader.dataset.tensors[0]
+    assert float(((grey > 0.05) & (grey < 0.95)).float().mean()) > 0.2          # the training rows really are grey
+    model = importing_model(args)(args).cuda()
+    opt = AdamNormGrad(model.parameters(), lr=2e-3)
+    out = str(tmp_path) + "/"
+    val_hist, train_hist = [], []
+    for epoch in range(1, 5):
+        tr = train_one_epoch(epoch, args, train_loader, model, opt)
+        with torch.no_grad():
+            va = evaluate_loss(args, model, val_loader, dataset=train_loader.dataset)
+        assert all(np.isfinite(tr)) and all(np.isfinite(va))
+        train_hist.append(tr[1]); val_hist.append(va[0])           # reconstruction error / validation ELBO
+        save_model(out + "ck.tmp", out + "best.model", {'epoch': epoch, 'state_dict': model.state_dict(),
+                                                        'optimizer': opt.state_dict(), 'best_loss': va[0], 'e': 0})
+    runner = list(model._graphed_steps.values())[0]
+    assert runner.graph is not None and runner.by_index and runner.binarize       # 12 captured steps per epoch
+    assert train_hist[-1] < train_hist[0] and val_hist[-1] < val_hist[0]          # it learns
+    with torch.no_grad():
+        final_evaluation(train_loader, test_loader, val_loader, out + "best.model", model, opt, args, out)
+    ll = float(torch.load(out + "vae.test_log_likelihood", weights_only=False))
+    elbo = float(torch.load(out + "vae.test_loss", weights_only=False))
+    assert np.isfinite(ll) and np.isfinite(elbo) and ll <= elbo + 1e-3             # the IWAE bound is at least as tight
