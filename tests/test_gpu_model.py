@@ -430,3 +430,39 @@ def test_end_to_end_run_on_grey_data_with_dynamic_binarisation(tmp_path, monkeyp
     ll = float(torch.load(out + "vae.test_log_likelihood", weights_only=False))
     elbo = float(torch.load(out + "vae.test_loss", weights_only=False))
     assert np.isfinite(ll) and np.isfinite(elbo) and ll <= elbo + 1e-3             # the IWAE bound is at least as tight
+
+
+@pytest.mark.parametrize("prior", ["standard", "vampprior"])
+def test_other_priors_match_reference_golden(golden, prior):
+    """models.BaseModel.log_p_z for prior = 'standard' and 'vampprior' (the reference's default) behind the same API:
+    calculate_loss, its gradients and evaluate_loss against the reference on identical weights, batch and eps."""
+    from models.VAE import VAE
+    from utils.evaluation import evaluate_loss
+    g = golden("g15_priors")
+    B, D = 16, 64
+    args = smoke_case.vae_args(prior=prior, input_size=[1, 8, 8], hidden_size=32, z1_size=8, z2_size=8, number_components=20,
+                               training_set_size=100, batch_size=B, pseudoinputs_mean=0.05, pseudoinputs_std=0.01,
+                               use_training_data_init=False)
+    model = VAE(args).cuda()
+    sd = {k[len(prior) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prior + "_sd_")}
+    assert set(sd) == set(model.state_dict().keys())
+    model.load_state_dict(sd)
+    model.train()
+    eps = torch.from_numpy(g["eps"]).cuda()
+    model._draw_eps = lambda like: eps[:like.shape[0]]
+    x = torch.from_numpy(gi.binary_images(151, B, D)).cuda()
+    loss, RE, KL = model.calculate_loss((x, torch.arange(B).reshape(-1, 1).cuda()), 0.7, average=False)
+    loss.mean().backward()
+    for name, t in (("loss", loss), ("RE", RE), ("KL", KL)):
+        assert rel(t.detach().cpu().numpy(), g[prior + "_" + name]) < 1e-4, name
+    for n, p in model.named_parameters():
+        ref = float(g[prior + "_gnorm_" + n])
+        got = 0.0 if p.grad is None else p.grad.double().norm().item()
+        assert abs(got - ref) <= 1e-3 * max(ref, 1e-6), n
+    model.eval()
+    model._draw_eps = lambda like: torch.zeros_like(like)
+    test = torch.from_numpy(gi.binary_images(152, 24, D))
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(test, torch.zeros(24)), batch_size=8)
+    with torch.no_grad():
+        ev = evaluate_loss(args, model, loader, dataset=None)
+    assert rel(np.asarray(ev), g[prior + "_eval"]) < 1e-4

@@ -530,7 +530,40 @@ def g14():
     save("g14_load_data", **out)
 
 
+# ---- G15: the other priors behind the same API (models/BaseModel.py:111-128: standard, vampprior) -------------
+def g15():
+    from utils.evaluation import evaluate_loss
+    out = {}
+    B, D = 16, 64
+    x = gi.binary_images(151, B, D)
+    test = gi.binary_images(152, 24, D)
+    eps = np.random.RandomState(153).standard_normal((B, 8)).astype(np.float32)
+    out["eps"] = eps
+    for prior in ("standard", "vampprior"):
+        args = vae_args(prior=prior, input_size=[1, 8, 8], hidden_size=32, z1_size=8, z2_size=8, number_components=20,
+                        training_set_size=100)
+        args.pseudoinputs_mean, args.pseudoinputs_std, args.use_training_data_init = 0.05, 0.01, False
+        args.batch_size = B
+        torch.manual_seed(150)
+        model = VAE(args)
+        model.train()
+        for k, v in model.state_dict().items():
+            out[prior + "_sd_" + k] = v.numpy().copy()
+        model.reparameterize = lambda mu, logvar: T(eps[:mu.shape[0]]) * logvar.mul(0.5).exp() + mu
+        loss, RE, KL = model.calculate_loss((T(x), torch.arange(B).reshape(-1, 1)), 0.7, average=False)
+        loss.mean().backward()
+        out[prior + "_loss"], out[prior + "_RE"], out[prior + "_KL"] = (t.detach().numpy() for t in (loss, RE, KL))
+        for n, p_ in model.named_parameters():
+            out[prior + "_gnorm_" + n] = np.asarray(0.0 if p_.grad is None else p_.grad.double().norm().item())
+        model.eval()
+        model.reparameterize = lambda mu, logvar: mu
+        loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(T(test), torch.zeros(24)), batch_size=8)
+        with torch.no_grad():
+            out[prior + "_eval"] = np.asarray(evaluate_loss(args, model, loader, dataset=None))
+    save("g15_priors", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for w in which:
         globals()[w]()
