@@ -466,3 +466,30 @@ def test_other_priors_match_reference_golden(golden, prior):
     with torch.no_grad():
         ev = evaluate_loss(args, model, loader, dataset=None)
     assert rel(np.asarray(ev), g[prior + "_eval"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag,kw", [("no_attention", dict(no_attention=True)), ("no_mask", dict(no_mask=True)), ("plain", dict())])
+def test_option_flags_match_reference_golden(golden, tag, kw):
+    """args.no_attention (GatedDense degenerates to ReLU(h), modular path) and args.no_mask (no leave-one-out mask, fused
+    path) against the reference: loss, RE, KL and gradient norms on identical weights, batch, eps and exemplar draw."""
+    from models.VAE import VAE
+    g = golden("g16_options")
+    B, D, N, C = 16, 64, 120, 40
+    args = smoke_case.vae_args(input_size=[1, 8, 8], hidden_size=32, z1_size=8, z2_size=8, number_components=C,
+                               training_set_size=N, **kw)
+    model = VAE(args).cuda()
+    model.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "_sd_")})
+    model.train()
+    eps = torch.from_numpy(g["eps"]).cuda()
+    model._draw_eps = lambda like: eps[:like.shape[0]]
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(gi.gray_images(161, N, D)), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    x = torch.from_numpy(gi.binary_images(162, B, D)).cuda()
+    torch.manual_seed(165)
+    loss, RE, KL = model.calculate_loss((x, torch.from_numpy(g["bidx"]).cuda()), 0.6, average=False, dataset=dataset)
+    loss.mean().backward()
+    for name, t in (("loss", loss), ("RE", RE), ("KL", KL)):
+        assert rel(t.detach().cpu().numpy(), g[tag + "_" + name]) < 1e-4, name
+    for n, p in model.named_parameters():
+        ref = float(g[tag + "_gnorm_" + n])
+        got = 0.0 if p.grad is None else p.grad.double().norm().item()
+        assert abs(got - ref) <= 1e-3 * max(ref, 1e-6), n

@@ -563,7 +563,34 @@ def g15():
     save("g15_priors", **out)
 
 
+# ---- G16: option flags consumed on the path (utils/nn.py:38-47 no_attention, models/BaseModel.py:103-107 no_mask) ----
+def g16():
+    out = {}
+    B, D, N, C = 16, 64, 120, 40
+    data = gi.gray_images(161, N, D)
+    x = (gi.binary_images(162, B, D))
+    bidx = np.random.RandomState(163).randint(0, N, (B, 1)).astype(np.int64)
+    eps = np.random.RandomState(164).standard_normal((B, 8)).astype(np.float32)
+    out["eps"], out["bidx"] = eps, bidx
+    dataset = torch.utils.data.TensorDataset(T(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    for tag, kw in (("no_attention", dict(no_attention=True)), ("no_mask", dict(no_mask=True)), ("plain", dict())):
+        args = vae_args(input_size=[1, 8, 8], hidden_size=32, z1_size=8, z2_size=8, number_components=C, training_set_size=N, **kw)
+        torch.manual_seed(160)
+        model = VAE(args)
+        model.train()
+        for k, v in model.state_dict().items():
+            out[tag + "_sd_" + k] = v.numpy().copy()
+        model.reparameterize = lambda mu, logvar: T(eps[:mu.shape[0]]) * logvar.mul(0.5).exp() + mu
+        torch.manual_seed(165)                                  # the exemplar draw
+        loss, RE, KL = model.calculate_loss((T(x), T(bidx)), 0.6, average=False, dataset=dataset)
+        loss.mean().backward()
+        out[tag + "_loss"], out[tag + "_RE"], out[tag + "_KL"] = (t.detach().numpy() for t in (loss, RE, KL))
+        for n, p_ in model.named_parameters():
+            out[tag + "_gnorm_" + n] = np.asarray(0.0 if p_.grad is None else p_.grad.double().norm().item())
+    save("g16_options", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     for w in which:
         globals()[w]()
