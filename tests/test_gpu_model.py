@@ -493,3 +493,32 @@ def test_option_flags_match_reference_golden(golden, tag, kw):
         ref = float(g[tag + "_gnorm_" + n])
         got = 0.0 if p.grad is None else p.grad.double().norm().item()
         assert abs(got - ref) <= 1e-3 * max(ref, 1e-6), n
+
+
+@pytest.mark.parametrize("tag,model_name", [("vae_gray", "vae"), ("hvae_gray", "hvae_2level")])
+def test_grey_inputs_through_mlp_models_match_reference_golden(golden, tag, model_name):
+    """input_type = 'gray' (continuous=True): clamped means, decoder_logstd / p_x_logvar head and the 256-bin discretised
+    logistic likelihood through vae and hvae_2level, against the reference on identical weights, batch, eps, exemplars."""
+    from utils.utils import importing_model
+    g = golden("g17_grey_mlp")
+    B, D, N, C = 12, 64, 90, 30
+    args = smoke_case.vae_args(model_name=model_name, input_type="gray", continuous=True, input_size=[1, 8, 8], hidden_size=32,
+                               z1_size=8, z2_size=8, number_components=C, training_set_size=N)
+    model = importing_model(args)(args).cuda()
+    sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "_sd_")}
+    assert list(sd) and set(sd) == set(model.state_dict().keys())
+    model.load_state_dict(sd)
+    model.train()
+    rs = np.random.RandomState(174)
+    model._draw_eps = lambda like: torch.from_numpy(rs.standard_normal(tuple(like.shape)).astype(np.float32)).to(like.device)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(gi.gray_images(171, N, D)), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    x = torch.from_numpy(np.clip(gi.gray_images(172, B, D) + 0.002, 0.0, 1.0).astype(np.float32)).cuda()
+    torch.manual_seed(175)
+    loss, RE, KL = model.calculate_loss((x, torch.from_numpy(g["bidx"]).cuda()), 0.8, average=False, dataset=dataset)
+    loss.mean().backward()
+    for name, t in (("loss", loss), ("RE", RE), ("KL", KL)):
+        assert rel(t.detach().cpu().numpy(), g[tag + "_" + name]) < 1e-4, name
+    for n, p in model.named_parameters():
+        ref = float(g[tag + "_gnorm_" + n])
+        got = 0.0 if p.grad is None else p.grad.double().norm().item()
+        assert abs(got - ref) <= 2e-3 * max(ref, 1e-6), n

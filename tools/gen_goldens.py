@@ -590,7 +590,36 @@ def g16():
     save("g16_options", **out)
 
 
+# ---- G17: grey-level inputs through the MLP models (AbsModel.py:26-37 / AbsHModel.py:70-86, log_logistic_256) ----
+def g17():
+    from models.HVAE_2level import VAE as HVAE
+    out = {}
+    B, D, N, C = 12, 64, 90, 30
+    data = gi.gray_images(171, N, D)
+    x = np.clip(gi.gray_images(172, B, D) + 0.002, 0.0, 1.0).astype(np.float32)
+    bidx = np.random.RandomState(173).randint(0, N, (B, 1)).astype(np.int64)
+    out["bidx"] = bidx
+    dataset = torch.utils.data.TensorDataset(T(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    for tag, cls, name in (("vae_gray", VAE, "vae"), ("hvae_gray", HVAE, "hvae_2level")):
+        args = vae_args(model_name=name, input_type="gray", continuous=True, input_size=[1, 8, 8], hidden_size=32, z1_size=8,
+                        z2_size=8, number_components=C, training_set_size=N)
+        torch.manual_seed(170)
+        model = cls(args)
+        model.train()
+        for k, v in model.state_dict().items():
+            out[tag + "_sd_" + k] = v.numpy().copy()
+        rs = np.random.RandomState(174)
+        model.reparameterize = lambda mu, logvar: T(rs.standard_normal(tuple(mu.shape)).astype(np.float32)) * logvar.mul(0.5).exp() + mu
+        torch.manual_seed(175)
+        loss, RE, KL = model.calculate_loss((T(x), T(bidx)), 0.8, average=False, dataset=dataset)
+        loss.mean().backward()
+        out[tag + "_loss"], out[tag + "_RE"], out[tag + "_KL"] = (t.detach().numpy() for t in (loss, RE, KL))
+        for n, p_ in model.named_parameters():
+            out[tag + "_gnorm_" + n] = np.asarray(0.0 if p_.grad is None else p_.grad.double().norm().item())
+    save("g17_grey_mlp", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for w in which:
         globals()[w]()
