@@ -522,3 +522,25 @@ def test_grey_inputs_through_mlp_models_match_reference_golden(golden, tag, mode
         ref = float(g[tag + "_gnorm_" + n])
         got = 0.0 if p.grad is None else p.grad.double().norm().item()
         assert abs(got - ref) <= 2e-3 * max(ref, 1e-6), n
+
+
+@pytest.mark.parametrize("model_name", ["vae", "hvae_2level", "convhvae_2level"])
+def test_generation_helpers_run(model_name):
+    """generate_x / reference_based_generation_x / reconstruct_x / generate_z (reference models/BaseModel.py:130-200): the
+    helpers the reference's evaluation and analysis scripts call.  Random by construction: shapes, ranges, finiteness."""
+    from utils.utils import importing_model
+    N = 300
+    args = smoke_case.vae_args(model_name=model_name, number_components=50, training_set_size=N)
+    torch.manual_seed(2)
+    model = importing_model(args)(args).cuda().eval()
+    data = torch.from_numpy(gi.binary_images(9, N))
+    dataset = torch.utils.data.TensorDataset(data, torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    with torch.no_grad():
+        gx = model.generate_x(N=9, dataset=dataset)
+        rx = model.reference_based_generation_x(N=6, reference_image=data[:1].cuda())
+        rec = model.reconstruct_x(data[:7].cuda())
+        gz = model.generate_z(N=9, dataset=dataset)
+    zdim = args.z2_size if "hvae" in model_name else args.z1_size
+    assert gx.shape == (9, 784) and rx.shape == (6, 784) and rec.shape == (7, 784) and gz.shape == (9, zdim)
+    for t in (gx, rx, rec):
+        assert bool(torch.isfinite(t).all()) and float(t.min()) >= 0.0 and float(t.max()) <= 1.0
