@@ -29,9 +29,16 @@ def _run(rank, world, port, q, fused):
         torch.cuda.set_device(0)
         data = gi.binary_images(5, N)
         dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
-        args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=B, shard_exemplars=world > 1)
-        model, _ = smoke_case.build_model(torch, np, orc, args)
-        model._use_fused = fused
+        if fused == "hvae_2level":       # BASELINE.json configs[3]: the hierarchical model over a sharded exemplar set
+            from utils.utils import importing_model
+            args = smoke_case.vae_args(model_name="hvae_2level", number_components=C, training_set_size=N, batch_size=B,
+                                       shard_exemplars=world > 1)
+            torch.manual_seed(5)
+            model = importing_model(args)(args).cuda()
+        else:
+            args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=B, shard_exemplars=world > 1)
+            model, _ = smoke_case.build_model(torch, np, orc, args)
+            model._use_fused = fused
         model.train()
         opt = AdamNormGrad(model.parameters(), lr=5e-4)
         torch.manual_seed(11); torch.cuda.manual_seed(11)        # identical eps / exemplar draws on every rank
@@ -54,7 +61,7 @@ def _run(rank, world, port, q, fused):
 def _spawn(world, fused):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000) + (7 if fused else 0)
+    port = 29700 + (os.getpid() % 1000) + {True: 7, False: 0}.get(fused, 13)
     procs = [ctx.Process(target=_run, args=(r, world, port, q, fused)) for r in range(world)]
     for p in procs:
         p.start()
@@ -65,7 +72,7 @@ def _spawn(world, fused):
     return res
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "hvae_2level"])
 def test_two_rank_sharded_training_matches_single(fused):
     single = _spawn(1, fused)[0]
     double = _spawn(2, fused)
