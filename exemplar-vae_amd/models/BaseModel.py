@@ -369,8 +369,15 @@ class BaseModel(nn.Module, ABC):
         z, _, indices = z
         cached_z, cached_log_variance = cache
         cached_z[indices.reshape(-1)] = z.detach() if not cached_z.requires_grad else z
-        sub_cache = cached_z[exemplars_indices, :]
-        nearest_indices, _ = ops.pairdist_topk(z.detach(), sub_cache.detach(), self.args.approximate_k, want_val=False)
+        if self._sharded():
+            # the candidate list is split over the ranks: local top-k over this rank's slice, one all-gather of the
+            # R x k (value, candidate position) lists per row, merge -- the exact global top-k on every rank
+            lo, hi = shard.bounds(exemplars_indices.numel())
+            nearest_indices, _ = shard.sharded_topk(z.detach(), cached_z[exemplars_indices[lo:hi], :].detach(),
+                                                    self.args.approximate_k, index_base=lo)
+        else:
+            sub_cache = cached_z[exemplars_indices, :]
+            nearest_indices, _ = ops.pairdist_topk(z.detach(), sub_cache.detach(), self.args.approximate_k, want_val=False)
         nearest_indices = torch.unique(nearest_indices.view(-1))
         exemplars_indices = exemplars_indices[nearest_indices].view(-1)
         data = self.resident_data(dataset)

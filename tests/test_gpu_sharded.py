@@ -29,7 +29,12 @@ def _run(rank, world, port, q, fused):
         torch.cuda.set_device(0)
         data = gi.binary_images(5, N)
         dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
-        if fused == "hvae_2level":       # BASELINE.json configs[3]: the hierarchical model over a sharded exemplar set
+        cache = None
+        if fused == "approximate":       # the cache + top-K prior with the candidate list sharded (BASELINE.json configs[4] style)
+            args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=B, shard_exemplars=world > 1,
+                                       approximate_prior=True, approximate_k=7)
+            model, _ = smoke_case.build_model(torch, np, orc, args)
+        elif fused == "hvae_2level":       # BASELINE.json configs[3]: the hierarchical model over a sharded exemplar set
             from utils.utils import importing_model
             args = smoke_case.vae_args(model_name="hvae_2level", number_components=C, training_set_size=N, batch_size=B,
                                        shard_exemplars=world > 1)
@@ -43,15 +48,22 @@ def _run(rank, world, port, q, fused):
         opt = AdamNormGrad(model.parameters(), lr=5e-4)
         torch.manual_seed(11); torch.cuda.manual_seed(11)        # identical eps / exemplar draws on every rank
         losses = []
+        if fused == "approximate":
+            with torch.no_grad():
+                cache = tuple(model.cache_z(dataset))
         for it in range(STEPS):
             xb = torch.from_numpy(data[it * B:(it + 1) * B]).cuda()
             ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1).cuda()
             opt.zero_grad()
-            loss, RE, KL = model.calculate_loss((xb, ib), 0.7, average=True, dataset=dataset)
+            loss, RE, KL = model.calculate_loss((xb, ib), 0.7, average=True, dataset=dataset, cache=cache)
             loss.backward()
             opt.step()
             losses.append(loss.item())
+            if cache is not None:
+                cache = (cache[0].detach(), cache[1].detach())
         out = {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}
+        if cache is not None:
+            out["__cache__"] = cache[0].cpu().numpy()
         q.put((rank, losses, out))
     finally:
         if world > 1:
@@ -61,7 +73,7 @@ def _run(rank, world, port, q, fused):
 def _spawn(world, fused):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000) + {True: 7, False: 0}.get(fused, 13)
+    port = 29700 + (os.getpid() % 1000) + {True: 7, False: 0, "approximate": 19}.get(fused, 13)
     procs = [ctx.Process(target=_run, args=(r, world, port, q, fused)) for r in range(world)]
     for p in procs:
         p.start()
@@ -72,7 +84,7 @@ def _spawn(world, fused):
     return res
 
 
-@pytest.mark.parametrize("fused", [True, False, "hvae_2level"])
+@pytest.mark.parametrize("fused", [True, False, "hvae_2level", "approximate"])
 def test_two_rank_sharded_training_matches_single(fused):
     single = _spawn(1, fused)[0]
     double = _spawn(2, fused)
