@@ -185,8 +185,12 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
   float* cn = zn + MFQ;                      // [2][128]
   float* inv_sigma = cn + 2 * MFE;           // [64]
   float* red = inv_sigma + 64;               // [16]
-  float* comb = red + 16;                    // [4][128][3]
-  long long* ci_s = reinterpret_cast<long long*>(comb + 4 * MFQ * 3);   // [2][128]
+  long long* ci_s = reinterpret_cast<long long*>(red + 16);             // [2][128]
+  // the cross-wave combine buffer [4][128][3] is only needed after the last tile: it reuses the exemplar tile, which
+  // keeps the block at 48 KB of LDS -- three blocks (24 waves) per CU instead of two, and it is waves of OTHER blocks
+  // that fill a SIMD while one block sits in its exp / log-sum-exp epilogue
+  float* comb = Es;
+  static_assert(4 * MFQ * 3 <= MFE * KS2, "combine buffer must fit in the exemplar tile");
 
   const int split = blockIdx.x;
   const int q0 = blockIdx.y * MFQ;
@@ -372,7 +376,7 @@ static int launch_prior_mfma(const float* z, int B, const float* centres, int C,
                              const int64_t* z_idx, const int64_t* c_idx, int ns_max, float* pm, float* ps, float* pn,
                              int* ns_out, hipStream_t stream) {
   constexpr int KS2 = KG * 8 + 4;
-  const size_t lds = (size_t)(2 * 128 * KS2 + 128 + 256 + 64 + 16 + 4 * 128 * 3) * sizeof(float) + 2 * 128 * sizeof(long long);
+  const size_t lds = (size_t)(2 * 128 * KS2 + 128 + 256 + 64 + 16) * sizeof(float) + 2 * 128 * sizeof(long long);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)prior_fwd_mfma_kernel<KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
