@@ -60,7 +60,8 @@ def _graphed_step(args, model, optimizer, train_loader):
     ok = a.prior == 'exemplar_prior' and a.approximate_prior is False
     if not ok:
         return None
-    key = (id(optimizer), id(train_loader.dataset), train_loader.batch_size)
+    # the runner keeps the optimizer and the dataset alive, so their ids cannot be recycled while it is cached
+    key = (id(optimizer), id(train_loader.dataset), train_loader.batch_size, bool(args.dynamic_binarization))
     cache = model.__dict__.setdefault('_graphed_steps', {})
     if key not in cache:
         cache[key] = GraphedTrainStep(model, optimizer, train_loader.dataset, train_loader.batch_size,
