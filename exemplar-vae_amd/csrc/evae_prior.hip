@@ -254,6 +254,7 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
     zi[nt] = (masked && q0 + ql < B) ? (long long)z_idx[q0 + ql] : -1;
   }
   float dmin[2] = {INFINITY, INFINITY}, ssum[2] = {0.f, 0.f}, nmask[2] = {0.f, 0.f};
+  float tm[2] = {-INFINITY, -INFINITY};        // running max of t = s - |c|^2/2 per query column
 
   for (int t = tile_begin; t < tile_end; ++t) {
     const int e0 = t * MFE;
@@ -285,58 +286,63 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
     }
     __syncthreads();     // cn (and ci_s) of this tile are complete; every wave is done reading Es
 
-    // rows of this lane: e = wr*32 + (r&3) + 8*(r>>2) + 4*lh; bit r of `live` = that exemplar exists
-    float cnr[16];
+    // rows of this lane: e = wr*32 + (r&3) + 8*(r>>2) + 4*lh; bit r of `live` = that exemplar exists.
+    // The epilogue works on t = s - |c|^2/2 (s = the dot product): -d2/2 = t - |z|^2/2, so the query's norm drops out of
+    // every difference and an element costs sub, max, fma, exp2, add -- VALU issue is what this kernel is bound by.
+    float hc[16];
     unsigned live = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int el = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      cnr[r] = cn[pb * MFE + el];
+      hc[r] = 0.5f * cn[pb * MFE + el];
       if (e0 + el < C) live |= 1u << r;
     }
     if (!masked && e0 + MFE <= C) {       // whole tile present, nothing to mask: no per-element predicates
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        float d[16];
-        float cmin = INFINITY;
+        float t[16];
+        float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          d[r] = fmaxf(cnr[r] + znq[nt] - 2.0f * acc[nt][r], 0.f);
-          cmin = fminf(cmin, d[r]);
+          t[r] = acc[nt][r] - hc[r];
+          tmax = fmaxf(tmax, t[r]);
         }
-        if (cmin < dmin[nt]) {
-          ssum[nt] *= fast_exp2((cmin - dmin[nt]) * kHalfLog2e);
-          dmin[nt] = cmin;
+        if (tmax > tm[nt]) {
+          ssum[nt] *= fast_exp2((tm[nt] - tmax) * kLog2e);      // tm == -inf -> 0 * 0 = 0
+          tm[nt] = tmax;
         }
-        const float dk = dmin[nt] * kHalfLog2e;
+        const float mk = -tm[nt] * kLog2e;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ssum[nt] += fast_exp2(dk - d[r] * kHalfLog2e);
+        for (int r = 0; r < 16; ++r) ssum[nt] += fast_exp2(fmaf(t[r], kLog2e, mk));
       }
       continue;
     }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      float d[16];
+      float t[16];
       unsigned use = live;
-      float cmin = INFINITY;
+      float tmax = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        d[r] = fmaxf(cnr[r] + znq[nt] - 2.0f * acc[nt][r], 0.f);
+        t[r] = acc[nt][r] - hc[r];
         if (masked) {
           const int el = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (((use >> r) & 1u) && ci_s[pb * MFE + el] == zi[nt]) { nmask[nt] += 1.f; use &= ~(1u << r); }
         }
-        if ((use >> r) & 1u) cmin = fminf(cmin, d[r]);
+        if ((use >> r) & 1u) tmax = fmaxf(tmax, t[r]);
       }
-      if (cmin < dmin[nt]) {
-        ssum[nt] *= fast_exp2((cmin - dmin[nt]) * kHalfLog2e);   // dmin == inf -> 0 * 0 = 0
-        dmin[nt] = cmin;
+      if (tmax > tm[nt]) {
+        ssum[nt] *= fast_exp2((tm[nt] - tmax) * kLog2e);
+        tm[nt] = tmax;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if ((use >> r) & 1u) ssum[nt] += fast_exp2((dmin[nt] - d[r]) * kHalfLog2e);
+        if ((use >> r) & 1u) ssum[nt] += fast_exp2((t[r] - tm[nt]) * kLog2e);
     }
   }
+  // back to squared distances for the combine below: d2_min = |z|^2 - 2 t_max  (no live exemplar: +inf)
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) dmin[nt] = (tm[nt] == -INFINITY) ? INFINITY : fmaxf(znq[nt] - 2.0f * tm[nt], 0.f);
 
   // combine lanes l and l+32 (same query, other rows), then the four wave rows through LDS
 #pragma unroll
