@@ -218,3 +218,22 @@ def test_load_dataset_dispatch_reads_local_idx_files(tmp_path, monkeypatch):
     a.dataset_name = "imagenet"
     with pytest.raises(Exception, match="Wrong name of the dataset"):
         load_dataset(a)
+
+
+def test_state_dict_names_and_shapes_of_every_architecture():
+    """Names, order and shapes of model.state_dict() for every architecture x input geometry the reference's datasets
+    produce (dumped from the reference's own constructors, tools/gen_goldens.py::g18): a checkpoint of either tree loads
+    into the other."""
+    import json, os
+    from utils.utils import importing_model
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g18_state_dict_shapes.json")
+    spec = json.load(open(path))
+    assert len(spec) == 9
+    for key, d in spec.items():
+        name, ds = key.split("|")
+        args = smoke_case.vae_args(model_name=name, dataset_name=ds, input_size=d["input_size"], input_type=d["input_type"],
+                                   bottleneck=d["bottleneck"], z1_size=d["z1_size"], continuous=(d["input_type"] != "binary"),
+                                   device="cpu", rs_blocks=4)
+        model = importing_model(args)(args)
+        got = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        assert got == d["entries"], key

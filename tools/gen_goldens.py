@@ -619,7 +619,32 @@ def g17():
     save("g17_grey_mlp", **out)
 
 
+# ---- G18: state_dict names and shapes of every architecture x input geometry the reference's datasets produce --------
+def g18():
+    import json
+    from utils.utils import importing_model
+    combos = [("vae", "dynamic_mnist", [1, 28, 28], "binary"), ("vae", "freyfaces", [1, 28, 20], "gray"),
+              ("hvae_2level", "omniglot", [1, 28, 28], "binary"), ("hvae_2level", "freyfaces", [1, 28, 20], "gray"),
+              ("convhvae_2level", "fashion_mnist", [1, 28, 28], "binary"), ("convhvae_2level", "cifar10", [3, 32, 32], "continuous"),
+              ("convhvae_2level", "freyfaces", [1, 28, 20], "gray"),
+              ("single_conv", "dynamic_mnist", [1, 28, 28], "binary"), ("single_conv", "celeba", [3, 64, 64], "continuous")]
+    out = {}
+    for name, ds, isz, it in combos:
+        bott = 1 if isz[1] == 64 else 6
+        z1 = bott * (isz[1] // 4) * (isz[2] // 4) if name == "single_conv" else 40
+        args = vae_args(model_name=name, dataset_name=ds, input_size=isz, input_type=it, bottleneck=bott, z1_size=z1,
+                        continuous=(it != "binary"))
+        args.rs_blocks = 4
+        torch.manual_seed(0)
+        m = importing_model(args)(args)
+        out["%s|%s" % (name, ds)] = {"input_size": isz, "input_type": it, "bottleneck": bott, "z1_size": z1,
+                                      "entries": [[k, list(v.shape)] for k, v in m.state_dict().items()]}
+    path = os.path.join(OUT, "g18_state_dict_shapes.json")
+    json.dump(out, open(path, "w"))
+    print("g18_state_dict_shapes.json %.1f KB, %d architectures" % (os.path.getsize(path) / 1024, len(out)))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     for w in which:
         globals()[w]()
