@@ -47,8 +47,8 @@ __global__ __launch_bounds__(NT) void prior_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;
   float* Es = Qs + BQ * Geom<KC>::ks;
-  float* inv_sigma = Es + BE * Geom<KC>::ks;     // [<= 4*KC_MAX]
-  float* red = inv_sigma + 4 * KC_MAX;   // [16]
+  float* inv_sigma = Es + BE * Geom<KC>::ks;     // [ZDIM_MAX]
+  float* red = inv_sigma + ZDIM_MAX;     // [16]
 
   const int split = blockIdx.x;
   const int q0 = blockIdx.y * BQ;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
   float* Qs = smem;
   float* Es = Qs + BQ * ks;
   float* inv_sigma = Es + BE * ks;
-  float* red = inv_sigma + 4 * KC_MAX;
+  float* red = inv_sigma + ZDIM_MAX;
   float* GW = red + 64;  // [BQ][GWS]
 
   const int split = blockIdx.x;
@@ -959,7 +959,7 @@ extern "C" int evae_prior_lse_fwd(const float* z, int B, const float* centres, i
                                   void* ws, size_t ws_bytes, evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(B >= 0 && C >= 0 && zdim > 0, "prior_lse_fwd: bad sizes B=%d C=%d zdim=%d", B, C, zdim);
-  EVAE_REQUIRE(zdim <= 4 * KC_MAX, "prior_lse_fwd: zdim %d > %d unsupported", zdim, 4 * KC_MAX);
+  EVAE_REQUIRE(zdim <= ZDIM_MAX, "prior_lse_fwd: zdim %d > %d unsupported", zdim, ZDIM_MAX);
   if (B == 0) return EVAE_OK;
   EVAE_REQUIRE(z && log_var && out_max && out_sumexp && out_nmask, "prior_lse_fwd: null pointer");
   if (C == 0) {
@@ -1034,7 +1034,7 @@ extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, i
                                   float* dlogvar, void* ws, size_t ws_bytes, evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(B >= 0 && C >= 0 && zdim > 0, "prior_lse_bwd: bad sizes");
-  EVAE_REQUIRE(zdim <= 4 * KC_MAX, "prior_lse_bwd: zdim %d > %d unsupported", zdim, 4 * KC_MAX);
+  EVAE_REQUIRE(zdim <= ZDIM_MAX, "prior_lse_bwd: zdim %d > %d unsupported", zdim, ZDIM_MAX);
   if (B == 0 && C == 0) return EVAE_OK;
   EVAE_REQUIRE((dz || B == 0) && dlogvar && log_var, "prior_lse_bwd: null pointer");   // an empty batch has no dz
   if (B == 0 || C == 0) {

@@ -10,6 +10,7 @@ constexpr int BQ = 128;   // queries per block tile
 constexpr int BE = 64;    // exemplars per block tile
 constexpr int NT = 256;
 constexpr int KC_MAX = 64;  // z-dims staged per chunk
+constexpr int ZDIM_MAX = 8 * KC_MAX;   // largest latent size of the VALU prior kernels (512: fully_conv on 28x28 has 6*7*7 = 294)
 constexpr float kHalfLog2e = 0.5f * kLog2e;
 
 // Chunk geometry is a compile-time parameter (KC = z-dims staged per chunk, one of 16/32/40/64) so that
@@ -36,7 +37,7 @@ static PriorGeom prior_geom(int zdim) {
 static int geom_ks(int kc) { return kc == 16 ? Geom<16>::ks : kc == 32 ? Geom<32>::ks : kc == 40 ? Geom<40>::ks : Geom<64>::ks; }
 
 static size_t prior_lds_bytes(const PriorGeom& g, bool bwd) {
-  size_t fl = (size_t)(BQ + BE) * geom_ks(g.kc) + 2 * KC_MAX * 4 /*inv_sigma*/ + 64;
+  size_t fl = (size_t)(BQ + BE) * geom_ks(g.kc) + ZDIM_MAX /*inv_sigma*/ + 128;
   if (bwd) fl += (size_t)BQ * (BE + 1);
   return fl * sizeof(float);
 }

@@ -35,7 +35,8 @@ def ops():
 # ---------------------------------------------------------------- prior
 @pytest.mark.parametrize("B,C,zd,masked", [(8, 300, 40, True), (100, 1000, 40, True), (100, 25000, 40, True),
                                            (100, 25000, 40, False), (5, 7, 3, True), (130, 70, 256, False),
-                                           (300, 2000, 40, True), (1, 1, 40, False), (64, 1000, 100, True)])
+                                           (300, 2000, 40, True), (1, 1, 40, False), (64, 1000, 100, True),
+                                           (20, 150, 294, True), (9, 70, 512, False)])
 def test_prior_fwd_matches_oracle(ops, B, C, zd, masked):
     z, c = gi.clustered_latents(100 + B + C, B, C, zd)
     zi, ci = gi.mask_indices(7 + B, B, C, max(C // 2, 4))
@@ -99,7 +100,9 @@ def test_prior_golden_c2(ops, golden):
                                            # matrix-core backward: every z_dim group up to 56, several query tiles
                                            # (atomic dcentres), ragged last exemplar tile, 60 / 64 fall back to the VALU kernel
                                            (100, 3125, 40, True), (300, 777, 8, True), (129, 128, 56, False),
-                                           (64, 1000, 24, True), (100, 257, 60, True), (40, 300, 64, False)])
+                                           (64, 1000, 24, True), (100, 257, 60, True), (40, 300, 64, False),
+                                           # fully_conv on 28 x 28 with the default bottleneck: z = 6 * 7 * 7 = 294; the limit 512
+                                           (20, 150, 294, True), (9, 70, 512, False)])
 def test_prior_bwd_matches_oracle(ops, B, C, zd, masked):
     z, c = gi.clustered_latents(200 + B + C, B, C, zd)
     zi, ci = gi.mask_indices(9 + B, B, C, max(C // 2, 4))

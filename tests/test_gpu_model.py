@@ -163,7 +163,7 @@ def test_graphed_step_other_architectures(model_name):
 
 
 # ---- the other architectures against goldens of the real reference ----------
-def seeded_state_dict(model, seed):
+def seeded_state_dict(model, seed, gain=1.0):
     """Same deterministic fill as tools/gen_goldens.py::seeded_state_dict (walks the state_dict in order)."""
     rs = np.random.RandomState(seed)
     sd = {}
@@ -172,10 +172,10 @@ def seeded_state_dict(model, seed):
         if "normalization" in k or k.endswith("num_batches_tracked"):
             sd[k] = v.clone()
         elif k.endswith("weight_g"):
-            sd[k] = torch.from_numpy((0.5 + rs.random_sample(shp)).astype(np.float32))
+            sd[k] = torch.from_numpy(((0.5 + rs.random_sample(shp)) * gain).astype(np.float32))
         elif len(shp) >= 2:
             fan_in = int(np.prod(shp[1:]))
-            sd[k] = torch.from_numpy((rs.standard_normal(shp) * np.sqrt(2.0 / fan_in)).astype(np.float32))
+            sd[k] = torch.from_numpy((rs.standard_normal(shp) * np.sqrt(2.0 / fan_in) * gain).astype(np.float32))
         elif k in ("prior_log_variance",):
             sd[k] = torch.from_numpy(np.asarray([-1.2], np.float32))
         else:
@@ -191,15 +191,28 @@ G9_CASES = {
 }
 
 
-@pytest.mark.parametrize("tag", list(G9_CASES))
+G19_CASES = {      # the other input geometries of the reference's datasets: RGB 32x32, non-square grey 28x20, binary single_conv
+    "convhvae_cifar": dict(model_name="convhvae_2level", dataset_name="cifar10", input_size=[3, 32, 32], input_type="continuous",
+                           continuous=True, B=4, C=16, N=40),
+    "convhvae_frey": dict(model_name="convhvae_2level", dataset_name="freyfaces", input_size=[1, 28, 20], input_type="gray",
+                          continuous=True, B=4, C=16, N=40),
+    # gain: twelve residual blocks of He-scaled random filters blow the activations up by 2^12; |log p| ~ 5e7 is beyond what
+    # fp32 resolves in ANY implementation (the reference's own gradients are ~1e8 there), so this case runs at a sane scale
+    "single_conv_mnist": dict(model_name="single_conv", input_size=[1, 28, 28], input_type="binary", bottleneck=6, z1_size=294,
+                              B=4, C=16, N=40, gain=0.35),
+}
+
+
+@pytest.mark.parametrize("tag", list(G9_CASES) + list(G19_CASES))
 def test_other_architectures_match_reference_golden(golden, tag):
     from utils.utils import importing_model
-    g = golden("g9_models")
-    cfg = dict(G9_CASES[tag])
+    g = golden("g9_models" if tag in G9_CASES else "g19_models_geometries")
+    cfg = dict(G9_CASES[tag] if tag in G9_CASES else G19_CASES[tag])
     B, C, N = cfg.pop("B"), cfg.pop("C"), cfg.pop("N")
+    gain = cfg.pop("gain", 1.0)
     args = smoke_case.vae_args(number_components=C, training_set_size=N, **cfg)
     model = importing_model(args)(args)
-    model.load_state_dict(seeded_state_dict(model, 77))
+    model.load_state_dict(seeded_state_dict(model, 77, gain))
     model = model.to("cuda")
     D = int(np.prod(args.input_size))
     rs = np.random.RandomState(91)

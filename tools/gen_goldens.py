@@ -249,7 +249,7 @@ def g8():
 
 
 # ---- G9: calculate_loss of the other architectures (hvae_2level, convhvae_2level, single_conv) -------------
-def seeded_state_dict(model, seed):
+def seeded_state_dict(model, seed, gain=1.0):
     """Deterministic weights for any architecture: walk the state_dict in order and draw from one RandomState
     (scaled like He-init for matrices / filters; weight-norm g kept positive; BatchNorm buffers untouched)."""
     rs = np.random.RandomState(seed)
@@ -259,10 +259,10 @@ def seeded_state_dict(model, seed):
         if "normalization" in k or k.endswith("num_batches_tracked"):
             sd[k] = v.clone()
         elif k.endswith("weight_g"):
-            sd[k] = T((0.5 + rs.random_sample(shp)).astype(np.float32))
+            sd[k] = T(((0.5 + rs.random_sample(shp)) * gain).astype(np.float32))
         elif len(shp) >= 2:
             fan_in = int(np.prod(shp[1:]))
-            sd[k] = T((rs.standard_normal(shp) * np.sqrt(2.0 / fan_in)).astype(np.float32))
+            sd[k] = T((rs.standard_normal(shp) * np.sqrt(2.0 / fan_in) * gain).astype(np.float32))
         elif k in ("prior_log_variance",):
             sd[k] = T(np.asarray([-1.2], np.float32))
         else:
@@ -278,16 +278,37 @@ G9_CASES = {
 }
 
 
+G19_CASES = {      # the other input geometries of the reference's datasets: RGB 32x32, non-square grey 28x20, binary single_conv
+    "convhvae_cifar": dict(model_name="convhvae_2level", dataset_name="cifar10", input_size=[3, 32, 32], input_type="continuous",
+                           continuous=True, B=4, C=16, N=40),
+    "convhvae_frey": dict(model_name="convhvae_2level", dataset_name="freyfaces", input_size=[1, 28, 20], input_type="gray",
+                          continuous=True, B=4, C=16, N=40),
+    # gain: twelve residual blocks of He-scaled random filters blow the activations up by 2^12; |log p| ~ 5e7 is beyond what
+    # fp32 resolves in ANY implementation (the reference's own gradients are ~1e8 there), so this case runs at a sane scale
+    "single_conv_mnist": dict(model_name="single_conv", input_size=[1, 28, 28], input_type="binary", bottleneck=6, z1_size=294,
+                              B=4, C=16, N=40, gain=0.35),
+}
+
+
 def g9():
+    _model_cases(G9_CASES, "g9_models")
+
+
+def g19():
+    _model_cases(G19_CASES, "g19_models_geometries")
+
+
+def _model_cases(cases, fixture):
     from utils.utils import importing_model
     out = {}
-    for tag, cfg in G9_CASES.items():
+    for tag, cfg in cases.items():
         cfg = dict(cfg)
         B, C, N = cfg.pop("B"), cfg.pop("C"), cfg.pop("N")
+        gain = cfg.pop("gain", 1.0)
         args = vae_args(number_components=C, training_set_size=N, **cfg)
         torch.manual_seed(0)
         model = importing_model(args)(args)
-        model.load_state_dict(seeded_state_dict(model, 77))
+        model.load_state_dict(seeded_state_dict(model, 77, gain))
         D = int(np.prod(args.input_size))
         rs = np.random.RandomState(91)
         if args.input_type == "binary":
@@ -331,7 +352,7 @@ def g9():
         out[tag + "_eval_loss"] = loss.numpy(); out[tag + "_eval_RE"] = RE.numpy(); out[tag + "_eval_KL"] = KL.numpy()
         out[tag + "_cache_head"] = cz.numpy()[:16]
         print(tag, "params", len(names), "train loss mean", float(loss.mean()))
-    save("g9_models", **out)
+    save(fixture, **out)
 
 
 # ---- G10: approximate prior (cache + top-k), models/BaseModel.py:256-271 via calculate_loss ------------------
@@ -645,6 +666,6 @@ def g18():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     for w in which:
         globals()[w]()
