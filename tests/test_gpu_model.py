@@ -557,3 +557,77 @@ def test_generation_helpers_run(model_name):
     assert gx.shape == (9, 784) and rx.shape == (6, 784) and rec.shape == (7, 784) and gz.shape == (9, zdim)
     for t in (gx, rx, rec):
         assert bool(torch.isfinite(t).all()) and float(t.min()) >= 0.0 and float(t.max()) <= 1.0
+
+
+# combinations the reference itself cannot run fail here too, loudly (same place, same reason): index -> why
+_MATRIX_FAILS_LIKE_REFERENCE = {
+    3: "top-k of approximate_k = 10 over 5 candidates (torch.topk raises in the reference, evae_pairdist_topk here)",
+    6: "AbsModel.p_x has no x_logvar for continuous inputs with use_logit=True (unbound local in the reference)",
+    7: "q_z reshapes to z1_size although the hvae encoder emits z2_size: z1 != z2 is not runnable",
+    9: "GatedConv2d(no_attention=True) builds no `g` but its forward uses it",
+}
+_MATRIX = [
+    # (model, input_size, input_type, extra args, batch, exemplars)
+    ("vae", [1, 28, 28], "binary", dict(), 1, 7),
+    ("vae", [1, 28, 28], "binary", dict(), 257, 33),
+    ("vae", [1, 28, 28], "binary", dict(z1_size=3), 5, 40),
+    ("vae", [1, 28, 28], "binary", dict(approximate_prior=True, approximate_k=10), 16, 5),      # fewer candidates than k
+    ("vae", [1, 28, 28], "binary", dict(approximate_prior=True, approximate_k=3), 16, 64),
+    ("vae", [1, 28, 20], "gray", dict(continuous=True, dataset_name="freyfaces"), 9, 30),
+    ("vae", [3, 32, 32], "continuous", dict(continuous=True, use_logit=True, dataset_name="cifar10"), 6, 20),
+    ("hvae_2level", [1, 28, 28], "binary", dict(z1_size=24, z2_size=56), 11, 50),
+    ("hvae_2level", [1, 28, 28], "binary", dict(approximate_prior=True, z2_size=40), 8, 40),
+    ("convhvae_2level", [1, 28, 28], "binary", dict(no_attention=True), 3, 12),
+    ("convhvae_2level", [3, 32, 32], "continuous", dict(continuous=True, dataset_name="svhn"), 2, 10),
+    ("single_conv", [1, 28, 28], "binary", dict(bottleneck=6, z1_size=294), 2, 9),
+    ("single_conv", [3, 32, 32], "continuous", dict(continuous=True, bottleneck=2, z1_size=128, dataset_name="cifar10"), 2, 9),
+]
+
+
+@pytest.mark.parametrize("case", range(len(_MATRIX)))
+def test_configuration_matrix_trains_one_step(case):
+    """One training step (loss, backward, AdamNormGrad) for a spread of model x geometry x option combinations the
+    reference's argument parser admits: nothing may be refused by a kernel-side limit, everything stays finite."""
+    from utils.utils import importing_model
+    from utils.optimizer import AdamNormGrad
+    name, isz, itype, extra, B, C = _MATRIX[case]
+    N = 90
+    D = int(np.prod(isz))
+    kw = dict(model_name=name, input_size=isz, input_type=itype, number_components=C, training_set_size=N, batch_size=B)
+    kw.update(extra)
+    args = smoke_case.vae_args(**kw)
+    torch.manual_seed(100 + case)
+    model = importing_model(args)(args).cuda()
+    model.train()
+    opt = AdamNormGrad(model.parameters(), lr=1e-4)
+    rs = np.random.RandomState(case)
+    if itype == "binary":
+        data = (rs.random_sample((N, D)) < 0.3).astype(np.float32)
+    else:
+        data = ((rs.randint(0, 256, (N, D)) + 0.5) / 256).astype(np.float32)
+        if extra.get("use_logit"):
+            data = np.log(data / (1 - data)).astype(np.float32)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    idx = torch.from_numpy(rs.randint(0, N, (B, 1)).astype(np.int64))
+    x = torch.from_numpy(data[idx[:, 0].numpy()]).cuda()
+    cache = None
+    if extra.get("approximate_prior"):
+        with torch.no_grad():
+            cache = tuple(model.cache_z(dataset))
+    before = [p.detach().clone() for p in model.parameters()]
+    opt.zero_grad()
+    if case in _MATRIX_FAILS_LIKE_REFERENCE:
+        with pytest.raises(Exception):
+            loss, RE, KL = model.calculate_loss((x, idx.cuda()), 0.5, average=True, dataset=dataset, cache=cache)
+            loss.backward()
+        return
+    loss, RE, KL = model.calculate_loss((x, idx.cuda()), 0.5, average=True, dataset=dataset, cache=cache)
+    loss.backward()
+    with_grad = [p.grad is not None for p in model.parameters()]      # fully_conv carries BatchNorm modules it never calls
+    opt.step()
+    assert all(bool(torch.isfinite(t).all()) for t in (loss, RE, KL))
+    moved = 0
+    for p, b, has in zip(model.parameters(), before, with_grad):
+        assert bool(torch.isfinite(p).all())
+        moved += int(has and not torch.equal(p.detach(), b))
+    assert moved >= 0.9 * sum(with_grad) and sum(with_grad) > 0.6 * len(before)
