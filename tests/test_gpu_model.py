@@ -631,3 +631,41 @@ def test_configuration_matrix_trains_one_step(case):
         assert bool(torch.isfinite(p).all())
         moved += int(has and not torch.equal(p.detach(), b))
     assert moved >= 0.9 * sum(with_grad) and sum(with_grad) > 0.6 * len(before)
+
+
+@pytest.mark.parametrize("name,isz,itype,extra", [
+    ("hvae_2level", [1, 28, 28], "binary", dict()),
+    ("convhvae_2level", [1, 28, 28], "binary", dict()),
+    ("convhvae_2level", [3, 32, 32], "continuous", dict(continuous=True, dataset_name="cifar10")),
+    ("single_conv", [3, 32, 32], "continuous", dict(continuous=True, bottleneck=2, z1_size=128, dataset_name="cifar10")),
+])
+def test_evaluation_loops_run_for_every_architecture(name, isz, itype, extra):
+    """evaluate_loss, calculate_likelihood (several images per pass) and report_knn_on_latent through the hierarchical and
+    convolutional models: shapes and reshapes of the evaluation side, finite results, IWAE bound <= ELBO bound."""
+    from utils.utils import importing_model
+    from utils.evaluation import evaluate_loss, calculate_likelihood
+    from utils.knn_on_latent import report_knn_on_latent
+    N, NE, B = 96, 24, 12
+    D = int(np.prod(isz))
+    args = smoke_case.vae_args(model_name=name, input_size=isz, input_type=itype, number_components=N, training_set_size=N,
+                               batch_size=B, **extra)
+    torch.manual_seed(21)
+    model = importing_model(args)(args).cuda().eval()
+    rs = np.random.RandomState(3)
+    mk = (lambda n: (rs.random_sample((n, D)) < 0.3).astype(np.float32)) if itype == "binary" else \
+         (lambda n: ((rs.randint(0, 256, (n, D)) + 0.5) / 256).astype(np.float32))
+    train = torch.utils.data.TensorDataset(torch.from_numpy(mk(N)), torch.arange(N).reshape(-1, 1), torch.arange(N) % 10)
+    val = torch.utils.data.TensorDataset(torch.from_numpy(mk(NE)), torch.arange(NE) % 10)
+    test = torch.utils.data.TensorDataset(torch.from_numpy(mk(NE)), (torch.arange(NE) * 3) % 10)
+    L = lambda ds: torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False)
+    with torch.no_grad():
+        elbo, re, kl = evaluate_loss(args, model, L(test), dataset=train)
+        cz, clv = model.cache_z(train)
+        emb = (cz, clv, torch.arange(len(cz)))
+        ll = calculate_likelihood(args, model, L(test), S=40, exemplars_embedding=emb)
+    assert all(np.isfinite(v) for v in (elbo, re, kl, ll))
+    assert ll <= elbo + 0.02 * abs(elbo)                     # 40 importance samples already tighten the bound (or tie it)
+    d = {"3": [], "7": []}
+    report_knn_on_latent(L(train), L(val), L(test), model, "", d, args, val=True)
+    report_knn_on_latent(L(train), L(val), L(test), model, "", d, args, val=False)
+    assert all(len(v) == 2 and all(0.0 <= a <= 100.0 for a in v) for v in d.values())
