@@ -438,6 +438,11 @@ def test_end_to_end_run_on_grey_data_with_dynamic_binarisation(tmp_path, monkeyp
     runner = list(model._graphed_steps.values())[0]
     assert runner.graph is not None and runner.by_index and runner.binarize       # 12 captured steps per epoch
     assert train_hist[-1] < train_hist[0] and val_hist[-1] < val_hist[0]          # it learns
+    from utils.knn_on_latent import report_knn_on_latent
+    knn = {"3": [], "7": []}
+    model.eval()
+    report_knn_on_latent(train_loader, val_loader, test_loader, model, out, knn, args, val=True)
+    assert knn["3"][0] > 60.0 and knn["7"][0] > 60.0            # ten prototype classes: the latent space separates them (chance: 10 %)
     with torch.no_grad():
         final_evaluation(train_loader, test_loader, val_loader, out + "best.model", model, opt, args, out)
     ll = float(torch.load(out + "vae.test_log_likelihood", weights_only=False))
