@@ -50,7 +50,7 @@ def parse():
                     help="untimed eager steps in front of the probe steps (clock ramp after the host pause)")
     ap.add_argument("--probe-steps", type=int, default=20,
                     help="eager steps run after the timed region to time the dominant kernel with HIP events")
-    ap.add_argument("--iwae-images", type=int, default=16,
+    ap.add_argument("--iwae-images", type=int, default=64,
                     help="test images for the IWAE test log p(x) leg (S=5000 samples each vs all 50 000 exemplars); 0 disables")
     ap.add_argument("--cpu-baseline-steps", type=int, default=80,
                     help="oracle steps timed for cpu_baseline (0 disables)")
