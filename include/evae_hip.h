@@ -58,6 +58,9 @@ const char* evae_last_error(void);
  *   out_lse_i      = LSE_i   (un-normalised, what the backward needs)
  * which is the all-reduce of partial log-sum-exps of the sharded prior (gathered by the caller
  * with one RCCL all-gather; see exemplar-vae_amd/evae/shard.py).
+ * Sizes: zdim <= 512.  zdim <= 64 (multiple of 4, no out_prob) runs the forward on the matrix cores in the expanded form
+ * |z|^2 + |c|^2 - 2 z.c -- the reference's own formulation --, zdim <= 56 the backward too; everything else takes the
+ * direct-difference VALU kernels.  The backward recomputes w_ij from the fp32 row LSE: exact to rounding while |lse| <~ 1e5.
  */
 size_t evae_prior_lse_fwd_workspace_bytes(int B, int C, int zdim);
 int evae_prior_lse_fwd(const float* z, int B, const float* centres, int C, int zdim,
