@@ -158,23 +158,117 @@ __global__ __launch_bounds__(NT) void prior_fwd_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // forward on the matrix cores (z_dim <= 64, multiple of 4, no probability matrix requested):
-//   d2_ij = |z_i/s|^2 + |c_j/s|^2 - 2 (z_i/s).(c_j/s), the dot products on v_mfma_f32_32x32x2_f32.
-//   This is the reference's own formulation (utils/distributions.py:12-18 expands the square, in fp64);
-//   in fp32 the cancellation error is ~1e-5 absolute on d2 ~ 1e1..1e3, i.e. < 1e-6 of log p(z).
+//   d2_ij = |z_i'|^2 + |c_j'|^2 - 2 z_i'.c_j' with x' = x/s - mu, the dot products on v_mfma_f32_32x32x2_f32.
+//   This is the reference's own formulation (utils/distributions.py:12-18 expands the square, in fp64).  In fp32 the
+//   cancellation costs ~2e-7 (|z'|^2 + |c'|^2) absolute on d2/2, so two things keep it inside the 1e-5 bar whatever
+//   the latents look like:
+//     * centring -- the distance is translation invariant, and every block subtracts the mean mu of ITS query tile
+//       (in sigma units) from the queries and from every exemplar it stages: a common offset of the latent cloud no
+//       longer enters the norms;
+//     * a guard -- only the QUERY's centred norm enters the error that matters: an exemplar far from the tile mean is
+//       as far from the query (d >= |c'| - |z'|), its error eps |c'|^2 is a relative error eps of its own d2, so
+//       |err(log p)| <~ eps (1.5 |z'|^2 + 2 |log p|).  A block whose max|z'|^2 exceeds kPriorNormLimit (a query tile
+//       spread widely at a small prior variance) computes its tiles as direct differences sum_k (z'-c')^2 on the VALU
+//       from the staged tiles instead (no cancellation; ~3x the time of a matrix-core tile).  Block-uniform.
+//   The running log-sum-exp state of a query is kept on u = -d2/2 (the MFMA epilogue works on t = s - |c'|^2/2 =
+//   u + |z'|^2/2: the query's norm drops out of every difference).
 //   Block = 512 threads = 8 waves (4 x 2), tile = 128 exemplars (MFMA rows) x 128 queries (MFMA columns):
 //   a lane owns ONE query column of each 32 x 32 result tile and 16 exemplar rows of it in registers, so
-//   the running (dmin, sum exp, #masked) of a query is lane-local; lanes l / l+32 and the 4 wave rows are
+//   the running (max, sum exp, #masked) of a query is lane-local; lanes l / l+32 and the 4 wave rows are
 //   combined once per block.  Scaled tiles are staged row-major [row][8 KG + 4] (stride/4 odd ->
 //   conflict-free ds_read_b128 fragments); the next exemplar tile is prefetched into registers.
 //   ~5x the direct-difference VALU kernel at S = 5000 importance samples x 50 000 exemplars.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 constexpr int MFQ = 128, MFE = 128, MFT = 512;
+// max|z'|^2 (centred, sigma units) of a query tile above which the expanded form is not trusted: the fp32 cancellation
+// error on log p is ~3e-7 of it, i.e. < 1e-3 absolute -- 1e-5 of a log-density of magnitude ~1e2
+constexpr float kPriorNormLimit = 2048.f;
+
+// Centre the staged (sigma-scaled) query tile: mu[k] = mean over its nvalid live rows, subtracted from those rows in place;
+// then the squared row norms and their maximum over the tile.  `scratch` = 512 floats of LDS nobody uses yet.
+// Fixed reduction order.  Contains barriers: every thread of the block calls it.
+template <int KP, int KS2>
+__device__ __forceinline__ float centre_queries(float* __restrict__ Qs, float* __restrict__ mu_s, float* __restrict__ zn,
+                                                float* __restrict__ zmx, float* __restrict__ scratch, int nvalid) {
+  const int tid = threadIdx.x, col = tid & 63, part = tid >> 6;
+  if (col < KP) {
+    float a = 0.f;
+#pragma unroll 4
+    for (int r = part * 16; r < part * 16 + 16; ++r) a += (r < nvalid) ? Qs[r * KS2 + col] : 0.f;
+    scratch[part * 64 + col] = a;
+  }
+  __syncthreads();
+  if (tid < KP) {
+    float a = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) a += scratch[p * 64 + tid];
+    mu_s[tid] = a / (float)nvalid;
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = KP / 4;
+    for (int f = tid; f < MFQ * CPR; f += MFT) {
+      const int r = f / CPR, c = f - r * CPR;
+      if (r < nvalid) {
+        float4 v = *reinterpret_cast<float4*>(Qs + r * KS2 + 4 * c);
+        const float4 m = *reinterpret_cast<const float4*>(mu_s + 4 * c);
+        v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w;
+        *reinterpret_cast<float4*>(Qs + r * KS2 + 4 * c) = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < MFQ) {
+    constexpr int CPR = KP / 4;
+    float sacc = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPR; ++c) {
+      const float4 t = *reinterpret_cast<const float4*>(Qs + tid * KS2 + 4 * c);
+      sacc += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+    }
+    zn[tid] = sacc;
+    const float wm = wave_max(sacc);
+    if ((tid & 63) == 0) zmx[tid >> 6] = wm;
+  }
+  __syncthreads();
+  return fmaxf(zmx[0], zmx[1]);
+}
+
+// a[nt][r] <- sum_k (Es[e(r)][k] - Qs[q(nt)][k])^2 from the staged, centred tiles (the guard's direct-difference path):
+// rows of this lane e = wr*32 + (r&3) + 8*(r>>2) + 4*lh (half-wave broadcast reads), columns q = wc*64 + nt*32 + l31.
+template <int KP, int KS2>
+__device__ __forceinline__ void direct_tile(f32x16_t (&a)[2], const float* __restrict__ Es, const float* __restrict__ Qs,
+                                            int wr, int wc, int l31, int lh) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { a[0][r] = 0.f; a[1][r] = 0.f; }
+  const float* q0p = Qs + (wc * 64 + l31) * KS2;
+  const float* q1p = q0p + 32 * KS2;
+  const float* ep = Es + (wr * 32 + 4 * lh) * KS2;
+  for (int c = 0; c < KP / 4; ++c) {
+    const float4 q0 = *reinterpret_cast<const float4*>(q0p + 4 * c);
+    const float4 q1 = *reinterpret_cast<const float4*>(q1p + 4 * c);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 e = *reinterpret_cast<const float4*>(ep + ((r & 3) + 8 * (r >> 2)) * KS2 + 4 * c);
+      float d, s0 = a[0][r], s1 = a[1][r];
+      d = e.x - q0.x; s0 = fmaf(d, d, s0);
+      d = e.y - q0.y; s0 = fmaf(d, d, s0);
+      d = e.z - q0.z; s0 = fmaf(d, d, s0);
+      d = e.w - q0.w; s0 = fmaf(d, d, s0);
+      d = e.x - q1.x; s1 = fmaf(d, d, s1);
+      d = e.y - q1.y; s1 = fmaf(d, d, s1);
+      d = e.z - q1.z; s1 = fmaf(d, d, s1);
+      d = e.w - q1.w; s1 = fmaf(d, d, s1);
+      a[0][r] = s0; a[1][r] = s1;
+    }
+  }
+}
 
 template <int KG>
 __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
     const float* __restrict__ z, int B, const float* __restrict__ centres, int C, int zdim,
     const float* __restrict__ log_var, const int64_t* __restrict__ z_idx,
-    const int64_t* __restrict__ c_idx, int tiles_per_split,
+    const int64_t* __restrict__ c_idx, int tiles_per_split, float norm_limit,
     float* __restrict__ part_m, float* __restrict__ part_s, float* __restrict__ part_n) {
   constexpr int KP = KG * 8, KS2 = KP + 4, CPR = KP / 4;       // chunks (float4) per row
   constexpr int NV = (MFE * CPR + MFT - 1) / MFT;
@@ -184,13 +278,16 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
   float* zn = Es + MFE * KS2;                // [128]
   float* cn = zn + MFQ;                      // [2][128]
   float* inv_sigma = cn + 2 * MFE;           // [64]
-  float* red = inv_sigma + 64;               // [16]
-  long long* ci_s = reinterpret_cast<long long*>(red + 16);             // [2][128]
+  float* mu_s = inv_sigma + 64;              // [64]  mean of the query tile (sigma units)
+  float* red = mu_s + 64;                    // [16]
+  float* zmx = red + 16;                     // [2] (+6 padding)
+  long long* ci_s = reinterpret_cast<long long*>(zmx + 8);             // [2][128]
   // the cross-wave combine buffer [4][128][3] is only needed after the last tile: it reuses the exemplar tile, which
   // keeps the block at 48 KB of LDS -- three blocks (24 waves) per CU instead of two, and it is waves of OTHER blocks
   // that fill a SIMD while one block sits in its exp / log-sum-exp epilogue
   float* comb = Es;
   static_assert(4 * MFQ * 3 <= MFE * KS2, "combine buffer must fit in the exemplar tile");
+  static_assert(512 <= MFE * KS2, "centre_queries scratch must fit in the exemplar tile");
 
   const int split = blockIdx.x;
   const int q0 = blockIdx.y * MFQ;
@@ -199,7 +296,7 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
   const bool masked = (z_idx != nullptr) && (c_idx != nullptr);
   const float cst = setup_sigma(inv_sigma, red, log_var, zdim, KP);   // contains a barrier
 
-  // stage one 128-row tile of `src` (rows r0.., nrows total), scaled, zero-padded
+  // stage one 128-row tile of `src` (rows r0.., nrows total), scaled (and centred), zero-padded
   auto load_tile = [&](const float* src, int r0, int nrows, float4 (&v)[NV]) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -209,14 +306,17 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
       v[i] = ok ? *reinterpret_cast<const float4*>(src + (size_t)(r0 + r) * zdim + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto store_tile = [&](float* tile, const float4 (&v)[NV]) {
+  auto store_tile = [&](float* tile, const float4 (&v)[NV], const bool centre) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid + MFT * i;
       const int r = f / CPR, c = f - r * CPR;
       if (f < MFE * CPR) {
         const float4 s4 = *reinterpret_cast<const float4*>(inv_sigma + 4 * c);
-        *reinterpret_cast<float4*>(tile + r * KS2 + 4 * c) = make_float4(v[i].x * s4.x, v[i].y * s4.y, v[i].z * s4.z, v[i].w * s4.w);
+        float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (centre) m4 = *reinterpret_cast<const float4*>(mu_s + 4 * c);
+        *reinterpret_cast<float4*>(tile + r * KS2 + 4 * c) =
+            make_float4(fmaf(v[i].x, s4.x, -m4.x), fmaf(v[i].y, s4.y, -m4.y), fmaf(v[i].z, s4.z, -m4.z), fmaf(v[i].w, s4.w, -m4.w));
       }
     }
   };
@@ -234,115 +334,129 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
 
   float4 rv[NV];
   load_tile(z, q0, B, rv);
-  store_tile(Qs, rv);
+  store_tile(Qs, rv, false);
   const int ntiles = (C + MFE - 1) / MFE;
   const int tile_begin = split * tiles_per_split;
   int tile_end = tile_begin + tiles_per_split;
   if (tile_end > ntiles) tile_end = ntiles;
   if (tile_begin < tile_end) load_tile(centres, tile_begin * MFE, C, rv);
   __syncthreads();
-  row_norms(Qs, zn);
-  __syncthreads();
+  // the guard (block-uniform): queries too far from their tile mean for the expanded form -> direct differences
+  const bool slow = centre_queries<KP, KS2>(Qs, mu_s, zn, zmx, Es, (B - q0) < MFQ ? (B - q0) : MFQ) > norm_limit;
 
   // this lane's two query columns
-  float znq[2];
+  float hz[2];
   long long zi[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int ql = wc * 64 + nt * 32 + l31;
-    znq[nt] = zn[ql];
+    hz[nt] = 0.5f * zn[ql];
     zi[nt] = (masked && q0 + ql < B) ? (long long)z_idx[q0 + ql] : -1;
   }
-  float dmin[2] = {INFINITY, INFINITY}, ssum[2] = {0.f, 0.f}, nmask[2] = {0.f, 0.f};
-  float tm[2] = {-INFINITY, -INFINITY};        // running max of t = s - |c|^2/2 per query column
+  float dmin[2], ssum[2] = {0.f, 0.f}, nmask[2] = {0.f, 0.f};
+  float um[2] = {-INFINITY, -INFINITY};        // running max of u = -d2/2 per query column
 
   for (int t = tile_begin; t < tile_end; ++t) {
     const int e0 = t * MFE;
     const int pb = (t - tile_begin) & 1;
-    store_tile(Es, rv);
+    store_tile(Es, rv, true);
     if (masked && tid < MFE) ci_s[pb * MFE + tid] = (e0 + tid < C) ? (long long)c_idx[e0 + tid] : -2;
     __syncthreads();
     if (t + 1 < tile_end) load_tile(centres, (t + 1) * MFE, C, rv);
-    row_norms(Es, cn + pb * MFE);
+    if (!slow) row_norms(Es, cn + pb * MFE);
 
     f32x16_t acc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-    const float* ea = Es + (wr * 32 + l31) * KS2 + lh * 4;
-    const float* qb = Qs + (wc * 64 + l31) * KS2 + lh * 4;
+    if (!slow) {
+      const float* ea = Es + (wr * 32 + l31) * KS2 + lh * 4;
+      const float* qb = Qs + (wc * 64 + l31) * KS2 + lh * 4;
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg) {
-      const float4 a = *reinterpret_cast<const float4*>(ea + kg * 8);
-      const float4 b0 = *reinterpret_cast<const float4*>(qb + kg * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(qb + 32 * KS2 + kg * 8);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+      for (int kg = 0; kg < KG; ++kg) {
+        const float4 a = *reinterpret_cast<const float4*>(ea + kg * 8);
+        const float4 b0 = *reinterpret_cast<const float4*>(qb + kg * 8);
+        const float4 b1 = *reinterpret_cast<const float4*>(qb + 32 * KS2 + kg * 8);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+      }
+    } else {
+      direct_tile<KP, KS2>(acc, Es, Qs, wr, wc, l31, lh);      // acc <- d2
     }
     __syncthreads();     // cn (and ci_s) of this tile are complete; every wave is done reading Es
 
     // rows of this lane: e = wr*32 + (r&3) + 8*(r>>2) + 4*lh; bit r of `live` = that exemplar exists.
-    // The epilogue works on t = s - |c|^2/2 (s = the dot product): -d2/2 = t - |z|^2/2, so the query's norm drops out of
-    // every difference and an element costs sub, max, fma, exp2, add -- VALU issue is what this kernel is bound by.
+    // The epilogue works on v with u = -d2/2 = v - off: matrix-core tiles v = t = s - |c'|^2/2 (s = the dot product), off =
+    // |z'|^2/2, so the query's norm drops out of every difference and an element costs sub, max, fma, exp2, add -- VALU
+    // issue is what this kernel is bound by; direct tiles v = -d2/2, off = 0.
     float hc[16];
     unsigned live = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int el = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      hc[r] = 0.5f * cn[pb * MFE + el];
+      hc[r] = slow ? 0.f : 0.5f * cn[pb * MFE + el];
       if (e0 + el < C) live |= 1u << r;
+    }
+    if (slow) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[0][r] *= -0.5f; acc[1][r] *= -0.5f; }
     }
     if (!masked && e0 + MFE <= C) {       // whole tile present, nothing to mask: no per-element predicates
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        float t[16];
-        float tmax = -INFINITY;
+        const float off = slow ? 0.f : hz[nt];
+        float v[16];
+        float vmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          t[r] = acc[nt][r] - hc[r];
-          tmax = fmaxf(tmax, t[r]);
+          v[r] = acc[nt][r] - hc[r];
+          vmax = fmaxf(vmax, v[r]);
         }
-        if (tmax > tm[nt]) {
-          ssum[nt] *= fast_exp2((tm[nt] - tmax) * kLog2e);      // tm == -inf -> 0 * 0 = 0
-          tm[nt] = tmax;
+        const float ut = vmax - off;
+        if (ut > um[nt]) {
+          ssum[nt] *= fast_exp2((um[nt] - ut) * kLog2e);      // um == -inf -> 0 * 0 = 0
+          um[nt] = ut;
         }
-        const float mk = -tm[nt] * kLog2e;
+        const float mk = -(um[nt] + off) * kLog2e;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ssum[nt] += fast_exp2(fmaf(t[r], kLog2e, mk));
+        for (int r = 0; r < 16; ++r) ssum[nt] += fast_exp2(fmaf(v[r], kLog2e, mk));
       }
       continue;
     }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      float t[16];
+      const float off = slow ? 0.f : hz[nt];
+      float v[16];
       unsigned use = live;
-      float tmax = -INFINITY;
+      float vmax = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        t[r] = acc[nt][r] - hc[r];
+        v[r] = acc[nt][r] - hc[r];
         if (masked) {
           const int el = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (((use >> r) & 1u) && ci_s[pb * MFE + el] == zi[nt]) { nmask[nt] += 1.f; use &= ~(1u << r); }
         }
-        if ((use >> r) & 1u) tmax = fmaxf(tmax, t[r]);
+        if ((use >> r) & 1u) vmax = fmaxf(vmax, v[r]);
       }
-      if (tmax > tm[nt]) {
-        ssum[nt] *= fast_exp2((tm[nt] - tmax) * kLog2e);
-        tm[nt] = tmax;
+      const float ut = vmax - off;
+      if (ut > um[nt]) {
+        ssum[nt] *= fast_exp2((um[nt] - ut) * kLog2e);
+        um[nt] = ut;
       }
+      const float mk = -(um[nt] + off) * kLog2e;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if ((use >> r) & 1u) ssum[nt] += fast_exp2((t[r] - tm[nt]) * kLog2e);
+        if ((use >> r) & 1u) ssum[nt] += fast_exp2(fmaf(v[r], kLog2e, mk));
     }
   }
-  // back to squared distances for the combine below: d2_min = |z|^2 - 2 t_max  (no live exemplar: +inf)
+  // back to squared distances for the combine below: d2_min = -2 u_max  (no live exemplar: +inf)
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) dmin[nt] = (tm[nt] == -INFINITY) ? INFINITY : fmaxf(znq[nt] - 2.0f * tm[nt], 0.f);
+  for (int nt = 0; nt < 2; ++nt) dmin[nt] = (um[nt] == -INFINITY) ? INFINITY : fmaxf(-2.0f * um[nt], 0.f);
 
   // combine lanes l and l+32 (same query, other rows), then the four wave rows through LDS
 #pragma unroll
@@ -377,12 +491,16 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
   }
 }
 
+// evae_prior_set_norm_limit overrides kPriorNormLimit (tests: 0 sends every tile through the direct-difference path)
+static float g_norm_limit = kPriorNormLimit;
+static float prior_norm_limit() { return g_norm_limit; }
+
 template <int KG>
 static int launch_prior_mfma(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
                              const int64_t* z_idx, const int64_t* c_idx, int ns_max, float* pm, float* ps, float* pn,
                              int* ns_out, hipStream_t stream) {
   constexpr int KS2 = KG * 8 + 4;
-  const size_t lds = (size_t)(2 * 128 * KS2 + 128 + 256 + 64 + 16) * sizeof(float) + 2 * 128 * sizeof(long long);
+  const size_t lds = (size_t)(2 * 128 * KS2 + 128 + 256 + 64 + 64 + 16 + 8) * sizeof(float) + 2 * 128 * sizeof(long long);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)prior_fwd_mfma_kernel<KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -396,7 +514,8 @@ static int launch_prior_mfma(const float* z, int B, const float* centres, int C,
   const int tps = cdiv(ntiles, ns);
   ns = cdiv(ntiles, tps);
   *ns_out = ns;
-  prior_fwd_mfma_kernel<KG><<<dim3(ns, nq), MFT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, tps, pm, ps, pn);
+  prior_fwd_mfma_kernel<KG><<<dim3(ns, nq), MFT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, tps,
+                                                                prior_norm_limit(), pm, ps, pn);
   return check_launch("prior_fwd_mfma_kernel");
 }
 
@@ -635,7 +754,7 @@ __global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
     const float* __restrict__ z, int B, const float* __restrict__ centres, int C, int zdim,
     const float* __restrict__ log_var, const int64_t* __restrict__ z_idx, const int64_t* __restrict__ c_idx,
     const float* __restrict__ lse, const float* __restrict__ gout, int tiles_per_split, int nsplit, int use_atomic_dc,
-    float* __restrict__ dz_part /* [nsplit][B][zdim] */, float* __restrict__ dc /* [C][zdim] */,
+    float norm_limit, float* __restrict__ dz_part /* [nsplit][B][zdim] */, float* __restrict__ dc /* [C][zdim] */,
     float* __restrict__ dlv_part /* [nq*nsplit][zdim+1] */) {
   constexpr int KP = KG * 8, KS2 = KP + 4, CPR = KP / 4, PP = 132;
   constexpr int NV = (MFE * CPR + MFT - 1) / MFT;
@@ -648,8 +767,10 @@ __global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
   float* cs = cn + MFE;                      // [128] column sums of P (per exemplar)
   float* rs = cs + MFE;                      // [128] row sums of P (per query)
   float* inv_sigma = rs + MFQ;               // [64]
-  float* red = inv_sigma + 64;               // [16]
-  float* dvs = red + 16;                     // [8][64] per-(wave row, lane half) partials of dV
+  float* mu_s = inv_sigma + 64;              // [64]  mean of the query tile (sigma units), see prior_fwd_mfma_kernel
+  float* red = mu_s + 64;                    // [16]
+  float* zmx = red + 16;                     // [2] (+6 padding)
+  float* dvs = zmx + 8;                      // [8][64] per-(wave row, lane half) partials of dV
   long long* ci_s = reinterpret_cast<long long*>(dvs + 8 * 64);   // [128]
 
   const int split = blockIdx.x;
@@ -668,14 +789,17 @@ __global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
       v[i] = ok ? *reinterpret_cast<const float4*>(src + (size_t)(r0 + r) * zdim + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto store_tile = [&](float* tile, const float4 (&v)[NV]) {
+  auto store_tile = [&](float* tile, const float4 (&v)[NV], const bool centre) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid + MFT * i;
       const int r = f / CPR, c = f - r * CPR;
       if (f < MFE * CPR) {
         const float4 s4 = *reinterpret_cast<const float4*>(inv_sigma + 4 * c);
-        *reinterpret_cast<float4*>(tile + r * KS2 + 4 * c) = make_float4(v[i].x * s4.x, v[i].y * s4.y, v[i].z * s4.z, v[i].w * s4.w);
+        float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (centre) m4 = *reinterpret_cast<const float4*>(mu_s + 4 * c);
+        *reinterpret_cast<float4*>(tile + r * KS2 + 4 * c) =
+            make_float4(fmaf(v[i].x, s4.x, -m4.x), fmaf(v[i].y, s4.y, -m4.y), fmaf(v[i].z, s4.z, -m4.z), fmaf(v[i].w, s4.w, -m4.w));
       }
     }
     if (tid < MFE) *reinterpret_cast<float4*>(tile + tid * KS2 + KP) = make_float4(1.f, 0.f, 0.f, 0.f);   // the ones column
@@ -694,15 +818,16 @@ __global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
 
   float4 rv[NV];
   load_tile(z, q0, B, rv);
-  store_tile(Qs, rv);
+  store_tile(Qs, rv, false);
   const int ntiles = (C + MFE - 1) / MFE;
   const int tile_begin = split * tiles_per_split;
   int tile_end = tile_begin + tiles_per_split;
   if (tile_end > ntiles) tile_end = ntiles;
   if (tile_begin < tile_end) load_tile(centres, tile_begin * MFE, C, rv);
   __syncthreads();
-  row_norms(Qs, zn);
-  __syncthreads();
+  // centred coordinates (every formula below is translation invariant); rows past B stay zero.  The guard of
+  // prior_fwd_mfma_kernel (block-uniform): queries too far from their tile mean for the expanded form -> direct differences
+  const bool slow = centre_queries<KP, KS2>(Qs, mu_s, zn, zmx, Ps, (B - q0) < MFQ ? (B - q0) : MFQ) > norm_limit;
 
   // this lane's two query columns of S
   float znq[2], gq[2], lq[2];
@@ -729,7 +854,7 @@ __global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
 
   for (int t = tile_begin; t < tile_end; ++t) {
     const int e0 = t * MFE;
-    store_tile(Es, rv);
+    store_tile(Es, rv, true);
     if (tid < MFE) ci_s[tid] = (masked && e0 + tid < C) ? (long long)c_idx[e0 + tid] : -2;
     __syncthreads();
     if (t + 1 < tile_end) load_tile(centres, (t + 1) * MFE, C, rv);
@@ -759,6 +884,8 @@ __global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
     }
     __syncthreads();     // cn, ci_s complete
 
+    if (slow) direct_tile<KP, KS2>(acc, Es, Qs, wr, wc, l31, lh);      // acc <- d2 (Es stays put until the end of the tile)
+
     // ---- P into LDS (rows of this lane: e = wr*32 + (r&3) + 8*(r>>2) + 4*lh)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -766,7 +893,7 @@ __global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int el = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float d = fmaxf(cn[el] + znq[nt] - 2.0f * acc[nt][r], 0.f);
+        const float d = slow ? acc[nt][r] : fmaxf(cn[el] + znq[nt] - 2.0f * acc[nt][r], 0.f);
         bool ok = e0 + el < C;
         if (masked) ok = ok && (ci_s[el] != zi[nt]);
         // exp(cst - d/2 - lse) = 2^((cst - lse) log2e - d log2e / 2)
@@ -865,7 +992,7 @@ static int launch_prior_bwd_mfma(const float* z, int B, const float* centres, in
                                  int ns_max, int use_atomic, float* dz_part, float* dc, float* dlv_part, int* ns_out,
                                  hipStream_t stream) {
   constexpr int KS2 = KG * 8 + 4;
-  const size_t lds = (size_t)(2 * 128 * KS2 + 128 * 132 + 4 * 128 + 64 + 16 + 8 * 64) * sizeof(float) + 128 * sizeof(long long);
+  const size_t lds = (size_t)(2 * 128 * KS2 + 128 * 132 + 4 * 128 + 64 + 64 + 16 + 8 + 8 * 64) * sizeof(float) + 128 * sizeof(long long);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)prior_bwd_mfma_kernel<KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -880,7 +1007,7 @@ static int launch_prior_bwd_mfma(const float* z, int B, const float* centres, in
   ns = cdiv(ntiles, tps);
   *ns_out = ns;
   prior_bwd_mfma_kernel<KG><<<dim3(ns, nq), MFT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, lse, gout, tps, ns,
-                                                                use_atomic, dz_part, dc, dlv_part);
+                                                                use_atomic, prior_norm_limit(), dz_part, dc, dlv_part);
   return check_launch("prior_bwd_mfma_kernel");
 }
 
@@ -944,6 +1071,11 @@ static void choose_splits(int B, int C, int* nsplit, int* tiles_per_split, int* 
 }  // namespace evae
 
 using namespace evae;
+
+extern "C" int evae_prior_set_norm_limit(float limit) {
+  g_norm_limit = limit >= 0.f ? limit : kPriorNormLimit;
+  return EVAE_OK;
+}
 
 extern "C" size_t evae_prior_lse_fwd_workspace_bytes(int B, int C, int zdim) {
   (void)zdim;

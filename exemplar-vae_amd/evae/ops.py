@@ -13,6 +13,7 @@ ACT_NONE, ACT_SIGMOID, ACT_HARDTANH = 0, 1, 2
 TOPK_SQRT = 1
 
 _ws = {}
+_ws_retired = []   # replaced buffers stay allocated: a captured hipGraph (evae/graph.py) may hold their addresses
 PROBE = None   # bench.py sets {'gated_dense_fwd': []} to collect (start event, end event, flops, launches) tuples
 
 
@@ -27,6 +28,12 @@ def _workspace(name, nbytes, device):
     key = (name, device.index if device.index is not None else torch.cuda.current_device())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            # Never free a workspace: launches captured into a hipGraph have its raw address baked in, and a later,
+            # larger request under the same name (evaluate_loss scores against all N_train exemplars) must not turn
+            # every replay into a write to freed memory.  Growth is geometric, so the retired total stays < the live size.
+            _ws_retired.append(buf)
+            nbytes = max(int(nbytes), 2 * buf.numel())
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws[key] = buf
     return buf
@@ -78,6 +85,12 @@ def prior_lse_fwd(z, centres, log_var, z_idx=None, c_idx=None, want_prob=False):
                                       _p(m), _p(s), _p(n), _p(prob), _p(ws), ws.numel(), _stream()),
                "evae_prior_lse_fwd")
     return m, s, n, prob
+
+
+def prior_set_norm_limit(limit):
+    """Largest centred squared norm (sigma units) of a query tile the matrix-core prior kernels still evaluate in the
+    expanded form; above it they switch to direct differences.  Negative restores the default, 0 forces the direct path."""
+    _lib.check(_lib.load().evae_prior_set_norm_limit(float(limit)), "evae_prior_set_norm_limit")
 
 
 def prior_merge(m, s, n, c_total, out=None):

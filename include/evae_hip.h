@@ -59,9 +59,14 @@ const char* evae_last_error(void);
  * which is the all-reduce of partial log-sum-exps of the sharded prior (gathered by the caller
  * with one RCCL all-gather; see exemplar-vae_amd/evae/shard.py).
  * Sizes: zdim <= 512.  zdim <= 64 (multiple of 4, no out_prob) runs the forward on the matrix cores in the expanded form
- * |z|^2 + |c|^2 - 2 z.c -- the reference's own formulation --, zdim <= 56 the backward too; everything else takes the
- * direct-difference VALU kernels.  The backward recomputes w_ij from the fp32 row LSE: exact to rounding while |lse| <~ 1e5.
+ * |z|^2 + |c|^2 - 2 z.c -- the reference's own formulation (there in fp64) --, zdim <= 56 the backward too; everything else
+ * takes the direct-difference VALU kernels.  The fp32 expanded form is kept inside the 1e-5 bar for any input: latents are
+ * centred per query tile (the distance is translation invariant) and a tile whose centred squared norms (sigma units)
+ * still exceed a limit is recomputed as direct differences by the same launch (evae_prior_set_norm_limit; default 4096).
+ * The backward recomputes w_ij from the fp32 row LSE: exact to rounding while |lse| <~ 1e5.
  */
+/* limit < 0 restores the default; 0 sends every tile through the direct-difference path (tests).  Process-wide. */
+int evae_prior_set_norm_limit(float limit);
 size_t evae_prior_lse_fwd_workspace_bytes(int B, int C, int zdim);
 int evae_prior_lse_fwd(const float* z, int B, const float* centres, int C, int zdim,
                        const float* log_var /* [zdim] */,

@@ -120,6 +120,54 @@ def test_prior_bwd_matches_oracle(ops, B, C, zd, masked):
     assert rel(glv.cpu().numpy(), dlv) < 1e-4
 
 
+def _prior_fwd_bwd_vs_oracle(ops, z, c, lv, zi, ci, masked, gout, tol_lp=1e-5, tol_g=1e-4):
+    """forward log p and the three gradients of the fused prior against the fp64 oracle (reference arithmetic:
+    utils/distributions.py:12-25 computes the distance in fp64)"""
+    C = len(c)
+    dz, dc, dlv, _ = orc.prior_grads(z.astype(np.float64), zi, c.astype(np.float64), lv.astype(np.float64), ci, masked,
+                                     gout.astype(np.float64))
+    ref = orc.log_p_z(z.astype(np.float64), zi, c.astype(np.float64), lv[None, :].astype(np.float64), ci, test=not masked)
+    a = (dev(z), dev(c), dev(lv), dev(zi) if masked else None, dev(ci) if masked else None)
+    m, s, n, _ = ops.prior_lse_fwd(*a)
+    lp, lse_t = ops.prior_merge(m, s, n, C)
+    gz, gc, glv = ops.prior_lse_bwd(*a, lse_t, dev(gout))
+    assert rel(lp.cpu().numpy(), ref) < tol_lp
+    assert rel(gz.cpu().numpy(), dz) < tol_g
+    assert rel(gc.cpu().numpy(), dc) < tol_g
+    assert rel(glv.cpu().numpy(), dlv) < tol_g
+
+
+@pytest.mark.parametrize("offset,scale", [(10.0, 1.0), (30.0, 1.0), (100.0, 1.0), (-300.0, 1.0), (0.0, 12.0), (25.0, 40.0)])
+@pytest.mark.parametrize("masked", [True, False])
+def test_prior_offset_and_large_scale_latents(ops, offset, scale, masked):
+    """The matrix-core kernels evaluate |z|^2 + |c|^2 - 2 z.c in fp32 where the reference works in fp64
+    (utils/distributions.py:13-18).  A common offset of the latent cloud is removed by centring, widely spread latents
+    fall through the norm guard to direct differences: the 1e-5 bar holds either way."""
+    B, C, zd = 100, 5000, 40
+    z, c = gi.clustered_latents(300 + int(abs(offset)) + int(scale), B, C, zd)
+    z = (z * scale + offset).astype(np.float32); c = (c * scale + offset).astype(np.float32)
+    zi, ci = gi.mask_indices(11, B, C, 9000)
+    lv = np.full(zd, -1.3, np.float32)
+    gout = np.random.RandomState(3).standard_normal(B).astype(np.float32)
+    _prior_fwd_bwd_vs_oracle(ops, z, c, lv, zi, ci, masked, gout)
+
+
+@pytest.mark.parametrize("B,C,zd,masked", [(100, 3125, 40, True), (300, 777, 8, True), (129, 128, 56, False),
+                                           (130, 70, 64, False), (1, 1, 40, False)])
+def test_prior_direct_difference_path_of_the_matrix_core_kernels(ops, B, C, zd, masked):
+    """Norm limit 0: every block of the matrix-core kernels takes its guard's direct-difference path."""
+    z, c = gi.clustered_latents(400 + B + C, B, C, zd)
+    zi, ci = gi.mask_indices(13 + B, B, C, max(C // 2, 4))
+    lv = np.linspace(-1.0, 0.2, zd).astype(np.float32)
+    gout = np.random.RandomState(B).standard_normal(B).astype(np.float32)
+    ops.prior_set_norm_limit(0.0)
+    try:
+        _prior_fwd_bwd_vs_oracle(ops, z, c, lv, zi, ci, masked, gout)
+    finally:
+        ops.prior_set_norm_limit(-1.0)
+
+
+
 def test_prior_bwd_many_tiles_per_block(ops):
     """More exemplar tiles than blocks (70 000 exemplars: two 128-row tiles per split), against the fp64 oracle."""
     B, C, zd = 100, 70000, 40
@@ -538,3 +586,15 @@ def test_empty_inputs(ops):
     ops.batch_prologue(c, rows, True, torch.tensor([1, 0], dtype=torch.int64, device="cuda"), torch.empty((0, zd), device="cuda"),
                        torch.empty((0, 8), device="cuda"))
     torch.cuda.synchronize()
+
+
+def test_workspace_growth_keeps_the_old_buffer_alive(ops):
+    """A captured hipGraph has the workspace address baked in: a later, larger request under the same name must not free
+    the buffer the graph still writes to."""
+    d = torch.device("cuda", torch.cuda.current_device())
+    a = ops._workspace("test_ws_growth", 1000, d)
+    pa = a.data_ptr()
+    b = ops._workspace("test_ws_growth", 5000, d)
+    assert b.data_ptr() != pa and b.numel() >= 5000
+    assert any(t.data_ptr() == pa for t in ops._ws_retired)
+    assert ops._workspace("test_ws_growth", 4000, d).data_ptr() == b.data_ptr()

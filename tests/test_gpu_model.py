@@ -259,6 +259,65 @@ def test_other_architectures_match_reference_golden(golden, tag):
         assert rel(v.cpu().numpy(), g["%s_eval_%s" % (tag, k)]) < 1e-4, (tag, k)
 
 
+def test_c5_geometry_matches_reference_golden(golden):
+    """BASELINE config 5's geometry through the model API: single_conv (models/fully_conv.py) on 3 x 64 x 64, z1 = 256
+    (bottleneck 1), 256-bin logistic likelihood, approximate cache + top-k prior (models/BaseModel.py:256-271) -- loss,
+    gradients and the cache refresh in training, then the evaluation path against the whole cache (G20)."""
+    from utils.utils import importing_model
+    g = golden("g20_c5_geometry")
+    B, C, N, k, gain = 4, 24, 48, 3, 0.35
+    args = smoke_case.vae_args(model_name="single_conv", dataset_name="celeba", input_size=[3, 64, 64], input_type="continuous",
+                               continuous=True, use_logit=False, bottleneck=1, z1_size=256, number_components=C,
+                               training_set_size=N, approximate_prior=True, approximate_k=k)
+    model = importing_model(args)(args)
+    model.load_state_dict(seeded_state_dict(model, 78, gain))
+    model = model.to("cuda")
+    D = int(np.prod(args.input_size))
+    rs = np.random.RandomState(93)
+    data = ((rs.randint(0, 256, (N, D)) + 0.5) / 256).astype(np.float32)
+    bidx = rs.choice(N, size=(B, 1), replace=False).astype(np.int64)
+    x = np.clip(data[bidx[:, 0]] + rs.randint(-6, 7, (B, D)).astype(np.float32) / 256, 0.5 / 256, 255.5 / 256).astype(np.float32)
+    cand = rs.choice(N, size=C, replace=False).astype(np.int64)
+    eps = rs.standard_normal((B, args.z1_size)).astype(np.float32)
+    model._draw_eps = lambda like: torch.from_numpy(eps).to(like.device).reshape(like.shape)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    model.train()
+    with torch.no_grad():
+        cache = tuple(model.cache_z(dataset))
+    assert rel(cache[0].cpu().numpy(), g["cache_before"]) < 1e-4
+    orig = torch.randint
+    torch.randint = lambda low=0, high=None, size=None, **kw: torch.from_numpy(cand.copy())
+    try:
+        model.zero_grad()
+        loss, RE, KL = model.calculate_loss((torch.from_numpy(x).cuda(), torch.from_numpy(bidx).cuda()), beta=0.7,
+                                            average=False, cache=cache, dataset=dataset)
+        loss.mean().backward()
+    finally:
+        torch.randint = orig
+    for kk, v in (("loss", loss), ("RE", RE), ("KL", KL)):
+        assert rel(v.detach().cpu().numpy(), g[kk]) < 1e-4, kk
+    assert rel(cache[0].detach().cpu().numpy(), g["cache_after"]) < 1e-4
+    norms = np.asarray([0.0 if p.grad is None else p.grad.double().norm().item() for _, p in model.named_parameters()])
+    ref = g["gnorms"]
+    assert norms.shape == ref.shape
+    assert np.all(np.abs(norms - ref) <= 2e-3 * np.maximum(ref, 1e-5)), np.abs(norms - ref).max()
+    model.eval()
+    with torch.no_grad():
+        cz, clv = model.cache_z(dataset)
+        loss, RE, KL = model.calculate_loss((torch.from_numpy(x).cuda(), None), average=False,
+                                            exemplars_embedding=(cz, clv, torch.arange(len(cz))))
+    for kk, v in (("loss", loss), ("RE", RE), ("KL", KL)):
+        assert rel(v.cpu().numpy(), g["eval_" + kk]) < 1e-4, kk
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_vae_train_step_at_config2_size_matches_oracle(fused):
+    """The benchmarked shapes themselves: B = 100, C = 25 000 gathered exemplar rows out of N = 50 000 (985 blocks on the
+    XCD remap of the dominant launch, the split-K plans of both big weight gradients) -- loss / RE / KL, every gradient
+    and the AdamNormGrad update against the oracle's train step."""
+    smoke_case.run(torch, np, orc, B=100, C=25000, N=50000, seed=71, verbose=True, fused=fused)
+
+
 def test_approximate_prior_matches_reference_golden(golden):
     """kNN-pruned exemplar prior (reference models/BaseModel.py:256-271): loss, gradients and the in-place cache
     refresh against the real reference."""

@@ -392,6 +392,56 @@ def g10():
     save("g10_approx", **out)
 
 
+# ---- G20: config-5 geometry -- single_conv on 3x64x64, z1 = 256 (bottleneck 1), 256-bin logistic likelihood, ----------
+#      approximate (cache + top-k) prior, through calculate_loss; then the evaluation path against the whole cache
+G20 = dict(B=4, C=24, N=48, k=3, gain=0.35)
+
+
+def g20():
+    from utils.utils import importing_model
+    B, C, N, k, gain = (G20[x] for x in ("B", "C", "N", "k", "gain"))
+    args = vae_args(model_name="single_conv", dataset_name="celeba", input_size=[3, 64, 64], input_type="continuous",
+                    continuous=True, use_logit=False, bottleneck=1, z1_size=256, number_components=C,
+                    training_set_size=N, approximate_prior=True, approximate_k=k)
+    torch.manual_seed(0)
+    model = importing_model(args)(args)
+    model.load_state_dict(seeded_state_dict(model, 78, gain))
+    D = int(np.prod(args.input_size))
+    rs = np.random.RandomState(93)
+    data = ((rs.randint(0, 256, (N, D)) + 0.5) / 256).astype(np.float32)
+    bidx = rs.choice(N, size=(B, 1), replace=False).astype(np.int64)
+    x = np.clip(data[bidx[:, 0]] + rs.randint(-6, 7, (B, D)).astype(np.float32) / 256, 0.5 / 256, 255.5 / 256).astype(np.float32)
+    cand = rs.choice(N, size=C, replace=False).astype(np.int64)    # distinct candidates: no exact distance ties
+    eps = rs.standard_normal((B, args.z1_size)).astype(np.float32)
+    model.reparameterize = lambda mu, logvar: T(eps).reshape(mu.shape) * logvar.mul(0.5).exp() + mu
+    dataset = torch.utils.data.TensorDataset(T(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    model.train()
+    with torch.no_grad():
+        cache = model.cache_z(dataset)
+    cache0 = cache[0].numpy().copy()
+    orig = torch.randint
+    torch.randint = lambda low=0, high=None, size=None, **kw: T(cand.copy())
+    try:
+        model.zero_grad()
+        loss, RE, KL = model.calculate_loss((T(x), T(bidx)), beta=0.7, average=False, cache=cache, dataset=dataset)
+        loss.mean().backward()
+    finally:
+        torch.randint = orig
+    zq = model.q_z(T(x))[0].detach()
+    d = pairwise_distance(zq, T(cache0)[T(cand)]).numpy()
+    assert tie_gap(d, k)[0] > 0
+    out = dict(loss=loss.detach().numpy(), RE=RE.detach().numpy(), KL=KL.detach().numpy(),
+               cache_before=cache0, cache_after=cache[0].detach().numpy(),
+               gnorms=np.asarray([0.0 if v.grad is None else v.grad.double().norm().item() for _, v in model.named_parameters()]))
+    model.eval()
+    with torch.no_grad():
+        cz, clv = model.cache_z(dataset)
+        loss, RE, KL = model.calculate_loss((T(x), None), average=False, exemplars_embedding=(cz, clv, torch.arange(len(cz))))
+    out.update(eval_loss=loss.numpy(), eval_RE=RE.numpy(), eval_KL=KL.numpy())
+    print("g20 train loss mean", float(out["loss"].mean()), "KL", out["KL"], "eval", float(loss.mean()))
+    save("g20_c5_geometry", **out)
+
+
 # ---- G11: evaluation loops (utils/evaluation.py:11-33, 72-103): ELBO over a loader and IWAE log-likelihood ----
 def g11():
     from utils.evaluation import evaluate_loss, calculate_likelihood
@@ -666,6 +716,6 @@ def g18():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
     for w in which:
         globals()[w]()
