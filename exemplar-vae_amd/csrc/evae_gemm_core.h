@@ -16,7 +16,10 @@ constexpr int KS = BK + 4;  // KC tile row stride (floats); 36/4 = 9 odd
 enum { EPI_LINEAR = 0, EPI_GATED = 1, EPI_GATE_BWD = 2, EPI_RAW = 3, EPI_RAW_GATED = 4,
        // squared distances |a_m|^2 + |b_n|^2 - 2 a_m.b_n from the dot products (top-K screening, evae_topk_screen.hip):
        EPI_DIST_TILEMIN = 5,   // out0[tile_m][n] = min over the tile's rows
-       EPI_DIST_COLLECT = 6 }; // rows with distance <= bias0[n] are appended to the candidate list of column n
+       EPI_DIST_COLLECT = 6,   // rows with distance <= bias0[n] are appended to the candidate list of column n
+       // exemplar prior at large latent sizes (evae_prior_gemm.hip): rows = exemplars, columns = queries, acc = c'.z'
+       EPI_PRIOR_LSE = 7,      // per (row tile, column): max / sum exp / #masked of log N(z_n | c_m) over the tile's rows
+       EPI_PRIOR_P = 8 };      // out0[m][n] = bias1[n] exp(log N(z_n | c_m) - bias0[n])   (0 where masked)
 
 
 // one K-slab of MFMAs: wave tile 64 x (32 NT) at rows wr*64.., cols wc*32*NT..

@@ -79,6 +79,13 @@ struct GemmArgs {
   ConvMap cv;              // used by the CV != 0 instances only
   int* aux_cnt;            // EPI_DIST_COLLECT: per-column candidate counters
   int* aux_cand;           //                   candidate rows, [column][ldo]
+  // EPI_PRIOR_*: dataset indices of the rows (exemplars) / columns (queries) for the leave-one-out mask (both or
+  // neither), the constant -1/2 sum (log_var + log 2 pi) (one device float), and a device flag that, when non-zero,
+  // cancels the launch
+  const int64_t* pr_ridx;
+  const int64_t* pr_cidx;
+  const float* pr_cst_dev;
+  const unsigned* skip_flag;
 };
 
 // Out-of-range chunks are loaded from a clamped, always-mapped address and zeroed LATER, when the
@@ -204,6 +211,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
   static_assert(!GATED || BN_ == 128, "gated epilogue needs the h and g column tiles in one wave");
   constexpr int STAGE = A_TILE_FLOATS + b_tile_floats(BN_);
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if constexpr (EPI == EPI_PRIOR_LSE || EPI == EPI_PRIOR_P) {
+    if (g.skip_flag != nullptr && *g.skip_flag != 0u) return;     // block-uniform: the caller's guard chose the other path
+  }
   auto As = [&](int b) -> float* { return smem + b * STAGE; };
   auto Bs = [&](int b) -> float* { return smem + b * STAGE + A_TILE_FLOATS; };
 
@@ -680,6 +690,101 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
         for (int w = 1; w < NW / 2; ++w) v = fminf(v, red[w * BN_ + threadIdx.x]);
         g.out0[(size_t)tm * g.ldo + n0 + threadIdx.x] = v;
       }
+    }
+  } else if constexpr (EPI == EPI_PRIOR_LSE) {
+    // e0 = |c'_m|^2 (rows), e1 = |z'_n|^2 (columns), acc = c'_m . z'_n.  Per column the block's rows are reduced on
+    // t = acc - |c'|^2/2 (= -d2/2 + |z'|^2/2: the column's own norm drops out of every difference) to
+    // (max, sum exp(t - max), #masked); lanes l / l+32 hold the same column, the NW/2 wave rows meet in LDS.
+    const bool masked = g.pr_ridx != nullptr && g.pr_cidx != nullptr;
+    float hc[MT][16];
+    long long ri[MT][16];
+    unsigned live[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      live[mt] = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = m < g.M;
+        hc[mt][r] = ok ? 0.5f * g.e0[m] : 0.f;
+        ri[mt][r] = (masked && ok) ? (long long)g.pr_ridx[m] : -2;
+        if (ok) live[mt] |= 1u << r;
+      }
+    }
+    float* red = smem;          // [NW/2][BN][3], free after the last barrier of the slab loop
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      const long long zi = (masked && n < g.N) ? (long long)g.pr_cidx[n] : -1;
+      float tmax = -INFINITY, ssum = 0.f, nm = 0.f;
+      unsigned use[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        use[mt] = live[mt];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[mt][nt][r] -= hc[mt][r];
+          if (masked && ((use[mt] >> r) & 1u) && ri[mt][r] == zi) { nm += 1.f; use[mt] &= ~(1u << r); }
+          if ((use[mt] >> r) & 1u) tmax = fmaxf(tmax, acc[mt][nt][r]);
+        }
+      }
+      const float mk = -tmax * kLog2e;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if ((use[mt] >> r) & 1u) ssum += fast_exp2(fmaf(acc[mt][nt][r], kLog2e, mk));
+      const float ot = __shfl_xor(tmax, 32, 64), os = __shfl_xor(ssum, 32, 64), on = __shfl_xor(nm, 32, 64);
+      const float mx = fmaxf(tmax, ot);
+      const float fa = (tmax == mx) ? 1.f : fast_exp2((tmax - mx) * kLog2e);      // -inf - (-inf) never evaluated
+      const float fb = (ot == mx) ? 1.f : fast_exp2((ot - mx) * kLog2e);
+      if (lh == 0) {
+        float* cb = red + (wr * BN_ + wc * 32 * NT + nt * 32 + l31) * 3;
+        cb[0] = mx; cb[1] = ssum * fa + os * fb; cb[2] = nm + on;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < BN_ && n0 + (int)threadIdx.x < g.N) {
+      float mx = -INFINITY, sacc = 0.f, nacc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW / 2; ++w) mx = fmaxf(mx, red[(w * BN_ + threadIdx.x) * 3]);
+#pragma unroll
+      for (int w = 0; w < NW / 2; ++w) {
+        const float tw = red[(w * BN_ + threadIdx.x) * 3];
+        if (tw != -INFINITY) sacc += red[(w * BN_ + threadIdx.x) * 3 + 1] * fast_exp2((tw - mx) * kLog2e);
+        nacc += red[(w * BN_ + threadIdx.x) * 3 + 2];
+      }
+      const int n = n0 + threadIdx.x;
+      const size_t o = (size_t)tm * g.ldo + n;
+      g.out0[o] = (mx == -INFINITY) ? -INFINITY : *g.pr_cst_dev + (mx - 0.5f * g.e1[n]);
+      g.out1[o] = sacc;
+      g.out2[o] = nacc;
+    }
+  } else if constexpr (EPI == EPI_PRIOR_P) {
+    // P[m][n] = g_n exp(cst - d2_mn / 2 - lse_n), d2 = |c'|^2 + |z'|^2 - 2 acc; bias0 = lse, bias1 = upstream gradient.
+    // Columns N <= n < ldo (padding up to a multiple of 4) are written as zeros: P is the operand of two more GEMMs.
+    const bool masked = g.pr_ridx != nullptr && g.pr_cidx != nullptr;
+    const float cst = *g.pr_cst_dev;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      if (n >= g.ldo) continue;
+      const bool nok = n < g.N;
+      const float zn = nok ? g.e1[n] : 0.f;
+      const float gq = nok ? g.bias1[n] : 0.f;
+      const float kq = nok ? (cst - g.bias0[n]) * kLog2e : 0.f;
+      const long long zi = (masked && nok) ? (long long)g.pr_cidx[n] : -1;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m >= g.M) continue;
+          const float d = fmaxf(g.e0[m] + zn - 2.0f * acc[mt][nt][r], 0.f);
+          bool ok = nok;
+          if (masked) ok = ok && ((long long)g.pr_ridx[m] != zi);
+          g.out0[(size_t)m * g.ldo + n] = ok ? gq * fast_exp2(kq - d * (0.5f * kLog2e)) : 0.f;
+        }
     }
   } else if (GATED) {
     const int n = n0 + wc * 32 + l31;

@@ -14,7 +14,9 @@
 //   Each thread keeps a running (dmin, sum exp(-(d-dmin)/2), #masked) per query; the 16 exemplar
 //   lanes are combined with wave shuffles once per block; blocks (exemplar splits) are combined by
 //   the merge kernel, which is the same code that merges GPU shards.
+#include <algorithm>
 #include "evae_tile.h"
+#include "evae_prior_gemm.h"
 
 namespace evae {
 
@@ -43,8 +45,10 @@ __global__ __launch_bounds__(NT) void prior_fwd_kernel(
     const float* __restrict__ log_var, const int64_t* __restrict__ z_idx,
     const int64_t* __restrict__ c_idx, int tiles_per_split, int nsplit, PriorGeom g,
     float* __restrict__ part_m, float* __restrict__ part_s, float* __restrict__ part_n,
-    float* __restrict__ out_prob) {
+    float* __restrict__ out_prob, const unsigned* __restrict__ run_flag) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // fallback of the GEMM path (evae_prior_gemm.hip): runs only when that path's norm guard raised the flag
+  if (run_flag != nullptr && *run_flag == 0u) return;
   float* Qs = smem;
   float* Es = Qs + BQ * Geom<KC>::ks;
   float* inv_sigma = Es + BE * Geom<KC>::ks;     // [ZDIM_MAX]
@@ -579,8 +583,9 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
     const int64_t* __restrict__ c_idx, const float* __restrict__ lse, const float* __restrict__ gout,
     int tiles_per_split, int nsplit, PriorGeom g, int use_atomic_dc,
     float* __restrict__ dz_part /* [nsplit][B][zdim] */, float* __restrict__ dc /* [C][zdim] */,
-    float* __restrict__ dlv_part /* [nq*nsplit][zdim+1] */) {
+    float* __restrict__ dlv_part /* [nq*nsplit][zdim+1] */, const unsigned* __restrict__ run_flag) {
   constexpr int ks = Geom<KC>::ks;
+  if (run_flag != nullptr && *run_flag == 0u) return;      // see prior_fwd_kernel
   constexpr int KPC = KC / KG_C;   // dims per thread in the dC phase
   constexpr int KPZ = KC / KG_Z;   // dims per thread in the dZ phase
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1019,8 +1024,10 @@ __global__ __launch_bounds__(1024) void prior_bwd_finish_kernel(const float* __r
                                                                 int zdim, const float* __restrict__ log_var,
                                                                 float* __restrict__ dz, int nb_dz,
                                                                 const float* __restrict__ dlv_part, int nblocks,
-                                                                float* __restrict__ dlogvar) {
+                                                                float* __restrict__ dlogvar,
+                                                                const unsigned* __restrict__ run_flag) {
   __shared__ float red[16][64];
+  if (run_flag != nullptr && *run_flag == 0u) return;
   const int lane = threadIdx.x & 63;
   const int part = threadIdx.x >> 6;
   if ((int)blockIdx.x >= nb_dz) {
@@ -1077,12 +1084,19 @@ extern "C" int evae_prior_set_norm_limit(float limit) {
   return EVAE_OK;
 }
 
+// large latent sizes: the GEMM path of evae_prior_gemm.hip (forward z > 64, backward z > 56)
+static bool fwd_uses_gemm(int B, int C, int zdim) { return zdim > 64 && prior_gemm_applies(B, C, zdim); }
+static bool bwd_uses_gemm(int B, int C, int zdim) {
+  return zdim > 56 && prior_gemm_applies(B, C, zdim) && (int64_t)B * C <= ((int64_t)1 << 28);
+}
+
 extern "C" size_t evae_prior_lse_fwd_workspace_bytes(int B, int C, int zdim) {
-  (void)zdim;
   if (B <= 0 || C <= 0) return 256;
   int ns, tps, nq;
   choose_splits(B, C, &ns, &tps, &nq);
-  return align_up((size_t)3 * ns * B * sizeof(float), 256) + 256;
+  const size_t valu = align_up((size_t)3 * ns * B * sizeof(float), 256) + 256;
+  if (fwd_uses_gemm(B, C, zdim)) return std::max(valu, prior_gemm_fwd_layout(B, C, zdim, ns).total);
+  return valu;
 }
 
 extern "C" int evae_prior_lse_fwd(const float* z, int B, const float* centres, int C, int zdim,
@@ -1130,8 +1144,22 @@ extern "C" int evae_prior_lse_fwd(const float* z, int B, const float* centres, i
     return check_launch("prior_merge_kernel(splits)");
   }
   size_t lds = prior_lds_bytes(g, false);
+  if (!force_valu && out_prob == nullptr && fwd_uses_gemm(B, C, zdim)) {
+    // matrix-core GEMM with a log-sum-exp epilogue; its norm guard hands over to the direct-difference kernel on the device
+    const PriorGemmFwdLayout L = prior_gemm_fwd_layout(B, C, zdim, ns);
+    int rc = prior_gemm_fwd(z, B, centres, C, zdim, log_var, z_idx, c_idx, prior_norm_limit(), (char*)ws, L, stream);
+    if (rc) return rc;
+    const unsigned* flag = (const unsigned*)((char*)ws + L.flag);
+    float* gm = (float*)((char*)ws + L.pm); float* gs = (float*)((char*)ws + L.ps); float* gn = (float*)((char*)ws + L.pn);
+    EVAE_DISPATCH_KC(g.kc, (prior_fwd_kernel<KC_><<<dim3(ns, nq), NT, lds, stream>>>(
+                               z, B, centres, C, zdim, log_var, z_idx, c_idx, tps, ns, g, gm, gs, gn, nullptr, flag)));
+    rc = check_launch("prior_fwd_kernel(guard fallback)");
+    if (rc) return rc;
+    prior_gemm_merge((const char*)ws, L, B, ns, out_max, out_sumexp, out_nmask, stream);
+    return check_launch("prior_merge_sel_kernel");
+  }
   EVAE_DISPATCH_KC(g.kc, (prior_fwd_kernel<KC_><<<dim3(ns, nq), NT, lds, stream>>>(
-                             z, B, centres, C, zdim, log_var, z_idx, c_idx, tps, ns, g, pm, ps, pn, out_prob)));
+                             z, B, centres, C, zdim, log_var, z_idx, c_idx, tps, ns, g, pm, ps, pn, out_prob, nullptr)));
   int rc = check_launch("prior_fwd_kernel");
   if (rc) return rc;
   prior_merge_kernel<<<cdiv(B, NT / 64), NT, 0, stream>>>(pm, ps, pn, ns, B, 0, 0.f, out_max, out_sumexp,
@@ -1157,7 +1185,9 @@ extern "C" size_t evae_prior_lse_bwd_workspace_bytes(int B, int C, int zdim) {
   choose_splits(B, C, &ns, &tps, &nq);
   size_t a = align_up((size_t)ns * B * zdim * sizeof(float), 256);
   size_t b = align_up((size_t)ns * nq * (zdim + 1) * sizeof(float), 256);
-  return a + b + 256;
+  size_t tot = a + b + 256;
+  if (bwd_uses_gemm(B, C, zdim)) tot += prior_gemm_bwd_layout(B, C, zdim).total;     // GEMM buffers behind the VALU partials
+  return tot;
 }
 
 extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, int C, int zdim,
@@ -1211,10 +1241,21 @@ extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, i
     if (rc) return rc;
     const int nb = cdiv(B * zdim, 64);
     prior_bwd_finish_kernel<<<nb + cdiv(zdim, 16), 1024, 0, stream>>>(dz_part, ns2, B * zdim, zdim, log_var, dz, nb, dlv_part,
-                                                                     ns2 * nq, dlogvar);
+                                                                     ns2 * nq, dlogvar, nullptr);
     return check_launch("prior_bwd_finish_kernel");
   }
   size_t lds = prior_lds_bytes(g, true);
+  const unsigned* run_flag = nullptr;
+  if (!force_valu && bwd_uses_gemm(B, C, zdim)) {
+    // three GEMMs on the matrix cores (evae_prior_gemm.hip); its norm guard releases the kernels below on the device
+    const PriorGemmBwdLayout L = prior_gemm_bwd_layout(B, C, zdim);
+    char* gws = (char*)ws + align_up((size_t)ns * B * zdim * sizeof(float), 256) +
+                align_up((size_t)ns * nq * (zdim + 1) * sizeof(float), 256);
+    int rc = prior_gemm_bwd(z, B, centres, C, zdim, log_var, z_idx, c_idx, lse, grad_out, prior_norm_limit(), dz, dcentres,
+                            dlogvar, gws, L, stream);
+    if (rc) return rc;
+    run_flag = (const unsigned*)(gws + L.flag);
+  }
   EVAE_DISPATCH_KC(g.kc, {
     static bool attr = false;
     if (!attr) {
@@ -1224,12 +1265,12 @@ extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, i
     }
     prior_bwd_kernel<KC_><<<dim3(ns, nq), NT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, lse,
                                                            grad_out, tps, ns, g, use_atomic, dz_part, dcentres,
-                                                           dlv_part);
+                                                           dlv_part, run_flag);
   });
   int rc = check_launch("prior_bwd_kernel");
   if (rc) return rc;
   const int nb_dz = cdiv(B * zdim, 64);
   prior_bwd_finish_kernel<<<nb_dz + cdiv(zdim, 16), 1024, 0, stream>>>(dz_part, ns, B * zdim, zdim, log_var, dz, nb_dz,
-                                                                       dlv_part, ns * nq, dlogvar);
+                                                                       dlv_part, ns * nq, dlogvar, run_flag);
   return check_launch("prior_bwd_finish_kernel");
 }

@@ -1,0 +1,316 @@
+// Exemplar prior at large latent sizes (z_dim > 64: fully_conv's z = 256 / 294) as a dense contraction on the matrix
+// cores.  Reference: utils/distributions.py:12-25 (the expanded-form distance is the reference's own, there in fp64),
+// models/BaseModel.py:98-128.  With z' = z/s - mu, c' = c/s - mu (mu = the mean of the call's queries in sigma units;
+// the distance is translation invariant):
+//   forward   S = C' Z'^T on the fp32-MFMA GEMM of evae_gemm_kernel.h with a log-sum-exp epilogue (EPI_PRIOR_LSE): one
+//             (max, sum exp, #masked) partial per 128-exemplar tile and query, merged by prior_merge_sel_kernel;
+//   backward  the same GEMM with the epilogue P[e][q] = g_q exp(log N(z_q | c_e) - lse_q) (EPI_PRIOR_P), then two
+//             library-shaped GEMMs of the dense family: T = P [Z' | 1] (evae_dense_bwd_data) and U = P^T C' with the
+//             row sums of P in the bias-gradient column (evae_dense_bwd_weight); dC, dZ, dlogvar come out of T and U
+//             exactly as in prior_bwd_mfma_kernel (evae_prior.hip).
+// The fp32 expanded form is guarded like the small-z kernels: if any centred query norm exceeds the limit, a device flag
+// cancels the GEMM launches and releases the direct-difference VALU kernels of evae_prior.hip instead -- both sets of
+// launches are enqueued, the flag decides on the device, nothing is read back (hipGraph-capturable).
+#include "evae_gemm_kernel.h"
+#include "evae_prior_gemm.h"
+
+namespace evae {
+
+// ---- mu[k] = mean over the B queries of z[q][k] exp(-log_var[k]/2); also clears the guard flag ------------------------
+__global__ __launch_bounds__(1024) void prior_colmean_kernel(const float* __restrict__ z, int B, int zdim, int zp,
+                                                             const float* __restrict__ log_var, float* __restrict__ mu,
+                                                             unsigned* __restrict__ flag) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  float a = 0.f;
+  if (k < zdim)
+    for (int q = part; q < B; q += 16) a += z[(size_t)q * zdim + k];
+  red[part][lane] = a;
+  __syncthreads();
+  if (part == 0 && k < zp) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += red[p][lane];      // fixed order
+    mu[k] = k < zdim ? (t / (float)B) * expf(-0.5f * log_var[k]) : 0.f;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 0u;
+}
+
+// ---- scaled, centred, padded copies + squared norms; one wave per row ------------------------------------------------
+// rows [0, Bp): queries -> Zs [Bp x ldz] (ones column at zp when ldz > zp; rows B..Bp are zero padding, Bp = B rounded
+// up to 4: the matrix is an operand of a GEMM whose contraction runs over its rows), zn; a norm above `limit` raises the flag.
+// rows [Bp, Bp + C): exemplars -> Cs [C x zp], cn.
+__global__ __launch_bounds__(256) void prior_prep_kernel(const float* __restrict__ z, int B, int Bp, float* __restrict__ Zs,
+                                                         int ldz, float* __restrict__ zn, const float* __restrict__ c, int C,
+                                                         float* __restrict__ Cs, float* __restrict__ cn, int zdim, int zp,
+                                                         const float* __restrict__ log_var, const float* __restrict__ mu,
+                                                         float limit, unsigned* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= Bp + C) return;
+  const bool isq = row < Bp;
+  if (isq && row >= B) {
+    for (int k = lane; k < ldz; k += 64) Zs[(size_t)row * ldz + k] = 0.f;
+    return;
+  }
+  const float* src = isq ? z + (size_t)row * zdim : c + (size_t)(row - Bp) * zdim;
+  float* dst = isq ? Zs + (size_t)row * ldz : Cs + (size_t)(row - Bp) * zp;
+  const int ld = isq ? ldz : zp;
+  float s = 0.f;
+  for (int k = lane; k < ld; k += 64) {
+    float v = 0.f;
+    if (k < zdim) {
+      v = fmaf(src[k], expf(-0.5f * log_var[k]), -mu[k]);
+      s = fmaf(v, v, s);
+    } else if (isq && k == zp) {
+      v = 1.f;                       // the ones column of [Z' | 1]
+    }
+    dst[k] = v;
+  }
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (isq) {
+      zn[row] = s;
+      if (s > limit) atomicOr(flag, 1u);
+    } else {
+      cn[row - Bp] = s;
+    }
+  }
+}
+
+// ---- merge of per-tile partials [R x ldp] -> (max, sumexp, nmask) per query; R is chosen on the device ----------------
+// lanes <-> consecutive queries (coalesced rows of the partial planes), the 16 waves of a block stride over R.
+__global__ __launch_bounds__(1024) void prior_merge_sel_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
+                                                               const float* __restrict__ pn, int ldp, int B, int R_gemm,
+                                                               int R_valu, int ld_valu, const unsigned* __restrict__ flag,
+                                                               float* __restrict__ om, float* __restrict__ os,
+                                                               float* __restrict__ on) {
+  __shared__ float red[16][64][3];
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + lane;
+  const bool valu = *flag != 0u;
+  const int R = valu ? R_valu : R_gemm;
+  const int ld = valu ? ld_valu : ldp;
+  float m = -INFINITY, s = 0.f, n = 0.f;
+  if (q < B) {
+    for (int r = part; r < R; r += 16) {
+      const float mr = pm[(size_t)r * ld + q], sr = ps[(size_t)r * ld + q];
+      n += pn[(size_t)r * ld + q];
+      if (mr > m) { s = s * __expf(m - mr) + sr; m = mr; }      // m == -inf: s == 0, exp(-inf) = 0
+      else if (mr != -INFINITY) s += sr * __expf(mr - m);
+    }
+  }
+  red[part][lane][0] = m; red[part][lane][1] = s; red[part][lane][2] = n;
+  __syncthreads();
+  if (part == 0 && q < B) {
+    float mm = -INFINITY, ss = 0.f, nn = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) mm = fmaxf(mm, red[p][lane][0]);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const float mp = red[p][lane][0];
+      if (mp != -INFINITY) ss += red[p][lane][1] * __expf(mp - mm);
+      nn += red[p][lane][2];
+    }
+    om[q] = mm; os[q] = ss; on[q] = nn;
+  }
+}
+
+// ---- backward finish -------------------------------------------------------------------------------------------------
+// T [C x ldt] = P [Z' | 1] (column zp = column sums of P), U [B x zp] = P^T C', rs [B] = row sums of P.
+//   rows [0, C):      dC[e][k]  = (T[e][k] - T[e][zp] C'[e][k]) / s_k ;  dV partial += C'_ek (T[e][zp] C'_ek - 2 T[e][k])
+//   rows [C, C + B):  dZ[q][k]  = (U[q][k] - rs_q Z'[q][k]) / s_k     ;  dV partial += rs_q Z'_qk^2 ;  sum_P partial += rs_q
+// One wave per row, 4 rows per block; per-block partials of dV [zp] and of sum P go to dvp [nblocks x (zp + 1)].
+__global__ __launch_bounds__(256) void prior_gemm_bwd_rows_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Cs,
+                                                                  int C, const float* __restrict__ U, const float* __restrict__ rs,
+                                                                  const float* __restrict__ Zs, int ldz, int B, int zdim, int zp,
+                                                                  const float* __restrict__ log_var, float* __restrict__ dc,
+                                                                  float* __restrict__ dz, float* __restrict__ dvp,
+                                                                  const unsigned* __restrict__ flag) {
+  extern __shared__ float sh[];            // [4][zp + 1]
+  if (*flag != 0u) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  float* mine = sh + w * (zp + 1);
+  for (int k = lane; k <= zp; k += 64) mine[k] = 0.f;
+  if (row < C) {
+    const float csum = T[(size_t)row * ldt + zp];
+    for (int k = lane; k < zdim; k += 64) {
+      const float t = T[(size_t)row * ldt + k], c_ = Cs[(size_t)row * zp + k];
+      dc[(size_t)row * zdim + k] = (t - csum * c_) * expf(-0.5f * log_var[k]);
+      mine[k] = c_ * (csum * c_ - 2.0f * t);
+    }
+  } else if (row < C + B) {
+    const int q = row - C;
+    const float rsum = rs[q];
+    for (int k = lane; k < zdim; k += 64) {
+      const float z_ = Zs[(size_t)q * ldz + k];
+      dz[(size_t)q * zdim + k] = (U[(size_t)q * zp + k] - rsum * z_) * expf(-0.5f * log_var[k]);
+      mine[k] = rsum * z_ * z_;
+    }
+    if (lane == 0) mine[zp] = rsum;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k <= zp; k += 256)
+    dvp[(size_t)blockIdx.x * (zp + 1) + k] = sh[k] + sh[(zp + 1) + k] + sh[2 * (zp + 1) + k] + sh[3 * (zp + 1) + k];
+}
+
+// dlogvar[k] = 0.5 sum_blocks dV[k] - 0.5 sum_blocks sumP; one block (1024 threads = 64 k x 16 parts) per 64 k
+__global__ __launch_bounds__(1024) void prior_gemm_bwd_dlv_kernel(const float* __restrict__ dvp, int nblocks, int zdim, int zp,
+                                                                  float* __restrict__ dlogvar, const unsigned* __restrict__ flag) {
+  __shared__ float red[16][64][2];
+  if (*flag != 0u) return;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  float sv = 0.f, sg = 0.f;
+  for (int b = part; b < nblocks; b += 16) {
+    if (k < zdim) sv += dvp[(size_t)b * (zp + 1) + k];
+    sg += dvp[(size_t)b * (zp + 1) + zp];
+  }
+  red[part][lane][0] = sv; red[part][lane][1] = sg;
+  __syncthreads();
+  if (part == 0 && k < zdim) {
+    float a = 0.f, g_ = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) { a += red[p][lane][0]; g_ += red[p][lane][1]; }
+    dlogvar[k] = 0.5f * a - 0.5f * g_;
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+static int zpad(int zdim) { return (zdim + 3) / 4 * 4; }
+static int bpad(int B) { return (B + 3) / 4 * 4; }
+
+PriorGemmFwdLayout prior_gemm_fwd_layout(int B, int C, int zdim, int ns_valu) {
+  PriorGemmFwdLayout L;
+  const int zp = zpad(zdim);
+  L.zp = zp; L.ldp = bpad(B); L.tiles_m = cdiv(C, BM);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
+  L.flag = take(256); L.mu = take((size_t)zp * 4);
+  L.Zs = take((size_t)L.ldp * zp * 4); L.zn = take((size_t)L.ldp * 4);
+  L.Cs = take((size_t)C * zp * 4); L.cn = take((size_t)C * 4);
+  const size_t rows = (size_t)(L.tiles_m > ns_valu ? L.tiles_m : ns_valu);
+  L.pm = take(rows * L.ldp * 4); L.ps = take(rows * L.ldp * 4); L.pn = take(rows * L.ldp * 4);
+  L.total = o + 256;
+  return L;
+}
+
+bool prior_gemm_applies(int B, int C, int zdim) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("EVAE_PRIOR_VALU"); off = (e && atoi(e)) ? 1 : 0; }
+  // 31-bit buffer offsets of the GEMM's operand loads; the P matrix of the backward is [C x B]
+  return !off && B > 0 && C > 0 && (int64_t)C * zpad(zdim) < ((int64_t)1 << 29) - (1 << 22) &&
+         (int64_t)B * (zpad(zdim) + 4) < ((int64_t)1 << 29) - (1 << 22);
+}
+
+static int launch_prior_gemm(GemmArgs& g, int B, bool lse, hipStream_t stream) {
+  if (lse) {
+    if (B <= 64) return launch_gemm_w<true, true, EPI_PRIOR_LSE, true, 64, 8>(g, 1, stream, "prior_gemm(lse)");
+    return launch_gemm_w<true, true, EPI_PRIOR_LSE, true, 128, 8>(g, 1, stream, "prior_gemm(lse)");
+  }
+  if (B <= 64) return launch_gemm_w<true, true, EPI_PRIOR_P, true, 64, 8>(g, 1, stream, "prior_gemm(P)");
+  return launch_gemm_w<true, true, EPI_PRIOR_P, true, 128, 8>(g, 1, stream, "prior_gemm(P)");
+}
+
+// cst = -1/2 sum_k (log_var_k + log 2 pi) is needed on the host side of the GEMM arguments but lives on the device: the
+// epilogues take it from a one-float device buffer instead (written by this kernel), so nothing is read back.
+__global__ void prior_cst_kernel(const float* __restrict__ log_var, int zdim, float* __restrict__ out) {
+  float part = 0.f;
+  for (int k = threadIdx.x; k < zdim; k += 64) part += log_var[k] + kLog2Pi;
+  part = wave_sum(part);
+  if (threadIdx.x == 0) *out = -0.5f * part;
+}
+
+int prior_gemm_fwd(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+                   const int64_t* z_idx, const int64_t* c_idx, float norm_limit, char* ws, const PriorGemmFwdLayout& L,
+                   hipStream_t stream) {
+  unsigned* flag = (unsigned*)(ws + L.flag);
+  float* cstp = (float*)(ws + L.flag) + 16;
+  float* mu = (float*)(ws + L.mu);
+  float* Zs = (float*)(ws + L.Zs); float* zn = (float*)(ws + L.zn);
+  float* Cs = (float*)(ws + L.Cs); float* cn = (float*)(ws + L.cn);
+  prior_colmean_kernel<<<cdiv(L.zp, 64), 1024, 0, stream>>>(z, B, zdim, L.zp, log_var, mu, flag);
+  prior_cst_kernel<<<1, 64, 0, stream>>>(log_var, zdim, cstp);
+  prior_prep_kernel<<<cdiv(L.ldp + C, 4), 256, 0, stream>>>(z, B, L.ldp, Zs, L.zp, zn, centres, C, Cs, cn, zdim, L.zp, log_var,
+                                                            mu, norm_limit, flag);
+  int rc = check_launch("prior_prep_kernel");
+  if (rc) return rc;
+  GemmArgs g = {};
+  g.ones_col = -1;
+  g.A[0] = Cs; g.B[0] = Zs; g.lda[0] = L.zp; g.ldb[0] = L.zp; g.Kc[0] = L.zp; g.npairs = 1;
+  g.M = C; g.N = B; g.e0 = cn; g.e1 = zn; g.ksplit = 0;
+  g.out0 = (float*)(ws + L.pm); g.out1 = (float*)(ws + L.ps); g.out2 = (float*)(ws + L.pn); g.ldo = L.ldp;
+  g.pr_ridx = c_idx; g.pr_cidx = z_idx; g.pr_cst_dev = cstp; g.skip_flag = flag;
+  return launch_prior_gemm(g, B, true, stream);
+}
+
+void prior_gemm_merge(const char* ws, const PriorGemmFwdLayout& L, int B, int ns_valu, float* om, float* os, float* on,
+                      hipStream_t stream) {
+  prior_merge_sel_kernel<<<cdiv(B, 64), 1024, 0, stream>>>((const float*)(ws + L.pm), (const float*)(ws + L.ps),
+                                                          (const float*)(ws + L.pn), L.ldp, B, L.tiles_m, ns_valu, B,
+                                                          (const unsigned*)(ws + L.flag), om, os, on);
+}
+
+PriorGemmBwdLayout prior_gemm_bwd_layout(int B, int C, int zdim) {
+  PriorGemmBwdLayout L;
+  const int zp = zpad(zdim);
+  L.zp = zp; L.ldz = zp + 4; L.ldp = bpad(B);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
+  L.flag = take(256); L.mu = take((size_t)zp * 4);
+  L.Zs = take((size_t)L.ldp * L.ldz * 4); L.zn = take((size_t)L.ldp * 4);
+  L.Cs = take((size_t)C * zp * 4); L.cn = take((size_t)C * 4);
+  L.P = take((size_t)C * L.ldp * 4);
+  L.T = take((size_t)C * L.ldz * 4);
+  L.U = take((size_t)L.ldp * zp * 4); L.rs = take((size_t)L.ldp * 4);
+  L.nblk = cdiv(C + B, 4);
+  L.dvp = take((size_t)L.nblk * (zp + 1) * 4);
+  L.ws_data_bytes = evae_dense_bwd_data_workspace_bytes(C, L.ldp, L.ldz, 1);
+  L.ws_data = take(L.ws_data_bytes);
+  L.ws_weight_bytes = evae_dense_bwd_weight_workspace_bytes(C, L.ldp, zp);
+  L.ws_weight = take(L.ws_weight_bytes);
+  L.total = o + 256;
+  return L;
+}
+
+int prior_gemm_bwd(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+                   const int64_t* z_idx, const int64_t* c_idx, const float* lse, const float* gout, float norm_limit,
+                   float* dz, float* dc, float* dlogvar, char* ws, const PriorGemmBwdLayout& L, hipStream_t stream) {
+  unsigned* flag = (unsigned*)(ws + L.flag);
+  float* cstp = (float*)(ws + L.flag) + 16;
+  float* mu = (float*)(ws + L.mu);
+  float* Zs = (float*)(ws + L.Zs); float* zn = (float*)(ws + L.zn);
+  float* Cs = (float*)(ws + L.Cs); float* cn = (float*)(ws + L.cn);
+  float* P = (float*)(ws + L.P); float* T = (float*)(ws + L.T); float* U = (float*)(ws + L.U); float* rs = (float*)(ws + L.rs);
+  float* dvp = (float*)(ws + L.dvp);
+  prior_colmean_kernel<<<cdiv(L.zp, 64), 1024, 0, stream>>>(z, B, zdim, L.zp, log_var, mu, flag);
+  prior_cst_kernel<<<1, 64, 0, stream>>>(log_var, zdim, cstp);
+  prior_prep_kernel<<<cdiv(L.ldp + C, 4), 256, 0, stream>>>(z, B, L.ldp, Zs, L.ldz, zn, centres, C, Cs, cn, zdim, L.zp, log_var,
+                                                            mu, norm_limit, flag);
+  int rc = check_launch("prior_prep_kernel");
+  if (rc) return rc;
+  GemmArgs g = {};
+  g.ones_col = -1;
+  g.A[0] = Cs; g.B[0] = Zs; g.lda[0] = L.zp; g.ldb[0] = L.ldz; g.Kc[0] = L.zp; g.npairs = 1;
+  g.M = C; g.N = B; g.e0 = cn; g.e1 = zn; g.ksplit = 0;
+  g.out0 = P; g.ldo = L.ldp; g.bias0 = lse; g.bias1 = gout;
+  g.pr_ridx = c_idx; g.pr_cidx = z_idx; g.pr_cst_dev = cstp; g.skip_flag = flag;
+  rc = launch_prior_gemm(g, B, false, stream);
+  if (rc) return rc;
+  // T [C x ldz] = P [C x ldp] . Zs1 [ldp x ldz] (P's padding columns and Zs1's padding rows are zero)
+  rc = evae_dense_bwd_data(P, Zs, nullptr, nullptr, C, L.ldp, L.ldp, L.ldz, nullptr, nullptr, T, nullptr, L.ldz,
+                           ws + L.ws_data, L.ws_data_bytes, (evae_stream_t)stream);
+  if (rc) return rc;
+  // U [B x zp] = P^T C', rs [B] = column sums of P^T's operand = row sums over the exemplars (the bias-gradient column)
+  rc = evae_dense_bwd_weight(P, C, L.ldp, L.ldp, Cs, nullptr, L.zp, L.zp, U, rs, 0, ws + L.ws_weight, L.ws_weight_bytes,
+                             (evae_stream_t)stream);
+  if (rc) return rc;
+  prior_gemm_bwd_rows_kernel<<<L.nblk, 256, (size_t)4 * (L.zp + 1) * sizeof(float), stream>>>(
+      T, L.ldz, Cs, C, U, rs, Zs, L.ldz, B, zdim, L.zp, log_var, dc, dz, dvp, flag);
+  prior_gemm_bwd_dlv_kernel<<<cdiv(zdim, 64), 1024, 0, stream>>>(dvp, L.nblk, zdim, L.zp, dlogvar, flag);
+  return check_launch("prior_gemm_bwd finish");
+}
+
+}  // namespace evae

@@ -131,6 +131,9 @@ def _prior_fwd_bwd_vs_oracle(ops, z, c, lv, zi, ci, masked, gout, tol_lp=1e-5, t
     m, s, n, _ = ops.prior_lse_fwd(*a)
     lp, lse_t = ops.prior_merge(m, s, n, C)
     gz, gc, glv = ops.prior_lse_bwd(*a, lse_t, dev(gout))
+    # softmax weights exp(p_ij - lse_i) are formed from fp32 log-densities here and in the reference alike (its p_ij is the
+    # fp64 distance cast to fp32, utils/distributions.py:18): half an ulp of |lse| is a relative error of every weight
+    tol_g = max(tol_g, 1.5 * 2.0 ** -24 * float(np.abs(ref).max()))
     assert rel(lp.cpu().numpy(), ref) < tol_lp
     assert rel(gz.cpu().numpy(), dz) < tol_g
     assert rel(gc.cpu().numpy(), dc) < tol_g
@@ -152,8 +155,33 @@ def test_prior_offset_and_large_scale_latents(ops, offset, scale, masked):
     _prior_fwd_bwd_vs_oracle(ops, z, c, lv, zi, ci, masked, gout)
 
 
+@pytest.mark.parametrize("B,C,zd,masked", [(100, 3000, 256, True), (300, 2000, 128, False), (64, 1000, 100, True),
+                                           (20, 150, 294, True), (9, 70, 512, False), (130, 257, 68, True),
+                                           (1, 1, 256, False), (5, 3, 72, True)])
+def test_prior_large_latent_sizes_run_as_gemms_on_the_matrix_cores(ops, B, C, zd, masked):
+    """z > 64 (fully_conv: 256 on 64 x 64 inputs, 294 on 28 x 28): forward = GEMM with a log-sum-exp epilogue, backward =
+    three GEMMs (evae_prior_gemm.hip), against the fp64 oracle; odd sizes are padded by the staging pass."""
+    z, c = gi.clustered_latents(500 + B + C, B, C, zd)
+    zi, ci = gi.mask_indices(17 + B, B, C, max(C // 2, 4))
+    lv = np.linspace(-1.0, 0.2, zd).astype(np.float32)
+    gout = np.random.RandomState(B).standard_normal(B).astype(np.float32)
+    _prior_fwd_bwd_vs_oracle(ops, z, c, lv, zi, ci, masked, gout)
+
+
+def test_prior_gemm_path_with_an_offset_latent_cloud(ops):
+    B, C, zd = 100, 2000, 256
+    z, c = gi.clustered_latents(77, B, C, zd)
+    z = (z * 0.5 + 40.0).astype(np.float32); c = (c * 0.5 + 40.0).astype(np.float32)
+    zi, ci = gi.mask_indices(19, B, C, 5000)
+    lv = np.full(zd, -0.4, np.float32)
+    gout = np.random.RandomState(4).standard_normal(B).astype(np.float32)
+    _prior_fwd_bwd_vs_oracle(ops, z, c, lv, zi, ci, True, gout)
+
+
 @pytest.mark.parametrize("B,C,zd,masked", [(100, 3125, 40, True), (300, 777, 8, True), (129, 128, 56, False),
-                                           (130, 70, 64, False), (1, 1, 40, False)])
+                                           (130, 70, 64, False), (1, 1, 40, False),
+                                           # z > 64: the GEMM path's guard flag releases the direct-difference kernels instead
+                                           (100, 1500, 256, True), (20, 150, 294, False)])
 def test_prior_direct_difference_path_of_the_matrix_core_kernels(ops, B, C, zd, masked):
     """Norm limit 0: every block of the matrix-core kernels takes its guard's direct-difference path."""
     z, c = gi.clustered_latents(400 + B + C, B, C, zd)
