@@ -15,6 +15,7 @@
 //   lanes are combined with wave shuffles once per block; blocks (exemplar splits) are combined by
 //   the merge kernel, which is the same code that merges GPU shards.
 #include <algorithm>
+#include <type_traits>
 #include "evae_tile.h"
 #include "evae_prior_gemm.h"
 
@@ -268,8 +269,8 @@ __device__ __forceinline__ void direct_tile(f32x16_t (&a)[2], const float* __res
   }
 }
 
-template <int KG>
-__global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
+template <int KG, int OCC>
+__global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
     const float* __restrict__ z, int B, const float* __restrict__ centres, int C, int zdim,
     const float* __restrict__ log_var, const int64_t* __restrict__ z_idx,
     const int64_t* __restrict__ c_idx, int tiles_per_split, float norm_limit,
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
   if (tile_begin < tile_end) load_tile(centres, tile_begin * MFE, C, rv);
   __syncthreads();
   // the guard (block-uniform): queries too far from their tile mean for the expanded form -> direct differences
-  const bool slow = centre_queries<KP, KS2>(Qs, mu_s, zn, zmx, Es, (B - q0) < MFQ ? (B - q0) : MFQ) > norm_limit;
+  const bool slow_block = centre_queries<KP, KS2>(Qs, mu_s, zn, zmx, Es, (B - q0) < MFQ ? (B - q0) : MFQ) > norm_limit;
 
   // this lane's two query columns
   float hz[2];
@@ -360,6 +361,10 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
   float dmin[2], ssum[2] = {0.f, 0.f}, nmask[2] = {0.f, 0.f};
   float um[2] = {-INFINITY, -INFINITY};        // running max of u = -d2/2 per query column
 
+  // the tile loop exists twice, with the guard's verdict as a compile-time constant inside (the epilogue is bound by VALU
+  // issue: not one select on `slow` may survive in the matrix-core variant)
+  auto tile_loop = [&](auto SLOW_) {
+  constexpr bool slow = decltype(SLOW_)::value;
   for (int t = tile_begin; t < tile_end; ++t) {
     const int e0 = t * MFE;
     const int pb = (t - tile_begin) & 1;
@@ -367,15 +372,16 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
     if (masked && tid < MFE) ci_s[pb * MFE + tid] = (e0 + tid < C) ? (long long)c_idx[e0 + tid] : -2;
     __syncthreads();
     if (t + 1 < tile_end) load_tile(centres, (t + 1) * MFE, C, rv);
-    if (!slow) row_norms(Es, cn + pb * MFE);
+    if constexpr (!slow) row_norms(Es, cn + pb * MFE);
 
     f32x16_t acc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-    if (!slow) {
+    if constexpr (!slow) {
       const float* ea = Es + (wr * 32 + l31) * KS2 + lh * 4;
       const float* qb = Qs + (wc * 64 + l31) * KS2 + lh * 4;
-#pragma unroll
+      constexpr int UNR = (OCC >= 2 && KG > 2) ? 2 : KG;     // fragments in flight vs registers (two blocks per CU need <= 128)
+#pragma unroll UNR
       for (int kg = 0; kg < KG; ++kg) {
         const float4 a = *reinterpret_cast<const float4*>(ea + kg * 8);
         const float4 b0 = *reinterpret_cast<const float4*>(qb + kg * 8);
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
       hc[r] = slow ? 0.f : 0.5f * cn[pb * MFE + el];
       if (e0 + el < C) live |= 1u << r;
     }
-    if (slow) {
+    if constexpr (slow) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[0][r] *= -0.5f; acc[1][r] *= -0.5f; }
     }
@@ -458,6 +464,8 @@ __global__ __launch_bounds__(MFT) void prior_fwd_mfma_kernel(
         if ((use >> r) & 1u) ssum[nt] += fast_exp2(fmaf(v[r], kLog2e, mk));
     }
   }
+  };
+  if (slow_block) tile_loop(std::true_type{}); else tile_loop(std::false_type{});
   // back to squared distances for the combine below: d2_min = -2 u_max  (no live exemplar: +inf)
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) dmin[nt] = (um[nt] == -INFINITY) ? INFINITY : fmaxf(-2.0f * um[nt], 0.f);
@@ -507,9 +515,12 @@ static int launch_prior_mfma(const float* z, int B, const float* centres, int C,
   const size_t lds = (size_t)(2 * 128 * KS2 + 128 + 256 + 64 + 64 + 16 + 8) * sizeof(float) + 2 * 128 * sizeof(long long);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)prior_fwd_mfma_kernel<KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)prior_fwd_mfma_kernel<KG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)prior_fwd_mfma_kernel<KG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
+  static int occ = 0;
+  if (occ == 0) { const char* e = getenv("EVAE_PRIOR_OCC"); occ = (e && atoi(e) == 2) ? 2 : 1; }
   const int nq = cdiv(B, MFQ), ntiles = cdiv(C, MFE);
   int ns = cdiv(512, nq);
   if (ns > ntiles) ns = ntiles;
@@ -518,8 +529,12 @@ static int launch_prior_mfma(const float* z, int B, const float* centres, int C,
   const int tps = cdiv(ntiles, ns);
   ns = cdiv(ntiles, tps);
   *ns_out = ns;
-  prior_fwd_mfma_kernel<KG><<<dim3(ns, nq), MFT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, tps,
-                                                                prior_norm_limit(), pm, ps, pn);
+  if (occ == 1)
+    prior_fwd_mfma_kernel<KG, 1><<<dim3(ns, nq), MFT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, tps,
+                                                                     prior_norm_limit(), pm, ps, pn);
+  else
+    prior_fwd_mfma_kernel<KG, 2><<<dim3(ns, nq), MFT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, tps,
+                                                                     prior_norm_limit(), pm, ps, pn);
   return check_launch("prior_fwd_mfma_kernel");
 }
 

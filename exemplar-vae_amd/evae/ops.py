@@ -176,6 +176,32 @@ def pairwise_distance(q, cache):
     return out
 
 
+class PairwiseDistance(torch.autograd.Function):
+    """utils/distributions.py:12-18 with its gradient: D_ij = |q_i - c_j|^2,
+    dq = 2 (rowsum(G) q - G c), dc = 2 (colsum(G) c - G^T q), the two products on the dense GEMM kernels."""
+
+    @staticmethod
+    def forward(ctx, q, cache):
+        ctx.save_for_backward(q, cache)
+        return pairwise_distance(q.detach(), cache.detach())
+
+    @staticmethod
+    def backward(ctx, G):
+        q, cache = ctx.saved_tensors
+        lib = _lib.load()
+        qf, cf, G = _f32(q.detach()), _f32(cache.detach()), _f32(G)
+        B, zd = qf.shape
+        Cn = cf.shape[0]
+        dq = dc = None
+        if ctx.needs_input_grad[0]:
+            Gc = _bwd_data(G.data_ptr(), cf, None, None, B, Cn, Cn, G.device)          # G c  [B x z]
+            dq = 2.0 * (G.sum(dim=1, keepdim=True) * qf - Gc)
+        if ctx.needs_input_grad[1]:
+            Gtq, colsum = _bwd_weight(G, qf, None, zd)                                    # G^T q [C x z], colsum(G) [C]
+            dc = 2.0 * (colsum.unsqueeze(1) * cf - Gtq)
+        return dq, dc
+
+
 def topk_merge(val, idx):
     """[R x B x k] candidate lists -> global ([B x k] idx, [B x k] val)."""
     lib = _lib.load()

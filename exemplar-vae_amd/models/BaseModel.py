@@ -21,7 +21,8 @@ import torch
 import torch.nn as nn
 
 from evae import fused_vae, ops, shard
-from utils.distributions import log_bernoulli, log_normal_diag, log_normal_standard, log_logistic_256
+from utils.distributions import (log_bernoulli, log_normal_diag, log_normal_standard, log_logistic_256,
+                                 log_normal_diag_vectorized)
 from utils.nn import NonLinear, he_init, normal_init
 
 
@@ -153,11 +154,20 @@ class BaseModel(nn.Module, ABC):
 
     def log_p_z_exemplar(self, z, z_indices, exemplars_embedding, test):
         """[B x C] matrix of log N(z_i | c_j, exp(logvar)) - log(C - #masked_i), -inf on leave-one-out hits
-        (reference :98-109).  Kept for API parity (log_p_z(sum=False)); forward only -- the loss path uses
-        the fused kernel in log_p_z."""
+        (reference :98-109).  Kept for API parity (log_p_z(sum=False)) -- the loss path uses the fused kernel in log_p_z.
+        Differentiable like the reference's: with a gradient requested the matrix is composed from the differentiable
+        distance (utils.distributions.log_normal_diag_vectorized), otherwise it is one pass of the fused kernel."""
         centers, center_log_variance, center_indices = exemplars_embedding
         masked = (test is False) and (self.args.no_mask is False) and z_indices is not None
         lv_row = center_log_variance[0, :]
+        if torch.is_grad_enabled() and (z.requires_grad or centers.requires_grad or lv_row.requires_grad):
+            prob, _ = log_normal_diag_vectorized(z, centers, lv_row.unsqueeze(0))
+            denominator = torch.full((len(z),), float(len(centers)), device=z.device)
+            if masked:
+                mask = z_indices.reshape(-1, 1) == center_indices.to(z.device).reshape(1, -1)
+                prob = prob.masked_fill(mask, float('-inf'))
+                denominator = denominator - mask.sum(dim=1)
+            return prob - torch.log(denominator).unsqueeze(1)
         _, _, nmask, prob = ops.prior_lse_fwd(z.detach(), centers.detach(), lv_row.detach(),
                                               z_indices if masked else None,
                                               center_indices.to(z.device) if masked else None, want_prob=True)
@@ -256,7 +266,7 @@ class BaseModel(nn.Module, ABC):
         if rows is None:
             return layers(x)
         if self._is_conv():
-            return layers(x[rows])          # conv stacks: gather first (MIOpen path, see utils/nn.py)
+            return layers(x[rows])          # conv stacks: gather first, then the HIP convolution kernels (utils/nn.py)
         mods = list(layers)
         h = mods[0](x, rows=rows)
         for m in mods[1:]:

@@ -12,19 +12,24 @@ log_2_pi = math.log(2 * math.pi)
 
 
 def pairwise_distance(z, means):
-    """[B x C] squared L2 distances, fp64-accumulated and rounded once to fp32 like the reference
-    (:12-18).  Forward only: the training path differentiates through the fused prior kernel
-    (evae.ops.PriorLogP), never through a materialised distance matrix."""
-    return ops.pairwise_distance(z.detach(), means.detach())
+    """[B x C] squared L2 distances, fp64-accumulated and rounded once to fp32 like the reference (:12-18).
+    Differentiable like the reference's (evae.ops.PairwiseDistance); the training path itself never materialises the
+    matrix -- it differentiates through the fused prior kernel (evae.ops.PriorLogP)."""
+    return ops.PairwiseDistance.apply(z, means)
 
 
 def log_normal_diag_vectorized(x, mean, log_var):
     """(:21-25) log N(x_i | mean_j, diag exp(log_var)) for all pairs; `log_var` is [1 x z].
-    Returns (log_normal [B x C], pair_dist [B x C]).  Forward only (see pairwise_distance)."""
+    Returns (log_normal [B x C], pair_dist [B x C]).  With a gradient requested it is the reference's own composition
+    (scale by 1/sigma, distance, affine map) on the differentiable distance; without, one fused kernel pass."""
+    if torch.is_grad_enabled() and (x.requires_grad or mean.requires_grad or log_var.requires_grad):
+        sd = log_var.mul(0.5).exp()
+        pair_dist = pairwise_distance(x / sd, mean / sd)
+        return -0.5 * torch.sum(log_var + log_2_pi, dim=1) - 0.5 * pair_dist, pair_dist
     lv = log_var.reshape(-1)
     _, _, _, prob = ops.prior_lse_fwd(x.detach(), mean.detach(), lv.detach(), want_prob=True)
     sd = lv.detach().mul(0.5).exp()
-    return prob, pairwise_distance(x.detach() / sd, mean.detach() / sd)
+    return prob, ops.pairwise_distance(x.detach() / sd, mean.detach() / sd)
 
 
 def _rows(t, like=None):

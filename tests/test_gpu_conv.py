@@ -113,3 +113,48 @@ def test_conv2d_patch_matrix_layer_many_images():
     yr = F.conv2d(x, wr, br, 2, 1)
     yr.backward(g)
     assert rel(y, yr) < 1e-5 and rel(w.grad, wr.grad) < 2e-5 and rel(b.grad, br.grad) < 2e-5
+
+
+G6_CONV_CASES = [   # tools/gen_goldens.py::G6_CONV_CASES
+    ("gated", 1, 32, 7, 1, 3, 28, 28, 3, None), ("gated", 32, 32, 3, 2, 1, 28, 28, 2, None),
+    ("gated", 32, 64, 5, 1, 2, 14, 14, 2, None), ("gated", 64, 6, 3, 1, 1, 7, 7, 3, None),
+    ("gated", 3, 32, 3, 2, 1, 16, 12, 2, "elu"),
+    ("plain", 64, 1, 1, 1, 0, 28, 28, 2, "sigmoid"), ("plain", 64, 3, 1, 1, 0, 16, 16, 2, "hardtanh"),
+    ("plain", 32, 48, 3, 1, 1, 9, 9, 2, None),
+]
+
+
+@pytest.mark.parametrize("i", range(len(G6_CONV_CASES)))
+def test_conv_modules_match_reference_golden(golden, i):
+    """utils.nn.GatedConv2d / Conv2d (reference utils/nn.py:72-114) as modules: output and every gradient against the
+    real reference's modules on the same weights and inputs (G6)."""
+    from utils.nn import GatedConv2d, Conv2d
+    g = golden("g6_conv_layers")
+    kind, ci, co, k, st, pd, H, W, N, act = G6_CONV_CASES[i]
+    acts = {None: None, "elu": torch.nn.ELU(), "sigmoid": torch.nn.Sigmoid(), "hardtanh": torch.nn.Hardtanh(-4.5, 0.)}
+    rs = np.random.RandomState(600 + i)
+    x = rs.standard_normal((N, ci, H, W)).astype(np.float32)
+    sc = 1.0 / np.sqrt(ci * k * k)
+    wh = (rs.standard_normal((co, ci, k, k)) * sc).astype(np.float32); bh = (rs.standard_normal(co) * 0.1).astype(np.float32)
+    wg = (rs.standard_normal((co, ci, k, k)) * sc).astype(np.float32); bg = (rs.standard_normal(co) * 0.1).astype(np.float32)
+    T = torch.from_numpy
+    if kind == "gated":
+        m = GatedConv2d(ci, co, k, st, pd, activation=acts[act])
+        m.load_state_dict({"h.weight": T(wh), "h.bias": T(bh), "g.weight": T(wg), "g.bias": T(bg)})
+    else:
+        m = Conv2d(ci, co, k, st, pd, activation=acts[act])
+        m.load_state_dict({"conv.weight": T(wh), "conv.bias": T(bh)})
+    m = m.cuda()
+    xt = T(x).cuda().requires_grad_(True)
+    y = m(xt)
+    gout = rs.standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(T(gout).cuda())
+
+    def rel(a, b):
+        a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+        return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    for key, arr, tol in (("y", y.detach().cpu().numpy(), 1e-5), ("dx", xt.grad.cpu().numpy(), 1e-4)):
+        assert rel(arr.reshape(-1)[::5], g["c%d_%s" % (i, key)]) < tol, key        # every 5th element + the L2 norm are kept
+        assert abs(np.linalg.norm(arr.astype(np.float64)) - float(g["c%d_%s_norm" % (i, key)])) <= tol * float(g["c%d_%s_norm" % (i, key)])
+    for name, prm in m.named_parameters():
+        assert rel(prm.grad.cpu().numpy(), g["c%d_d_%s" % (i, name)]) < 1e-4, name

@@ -173,6 +173,45 @@ def g6():
     save("g6_layers", **out)
 
 
+# ---- G6b: the convolution modules, utils/nn.py:72-114 (GatedConv2d, Conv2d), forward + all gradients -------------
+G6_CONV_CASES = [   # (kind, Cin, Cout, k, stride, pad, H, W, N, activation)
+    ("gated", 1, 32, 7, 1, 3, 28, 28, 3, None), ("gated", 32, 32, 3, 2, 1, 28, 28, 2, None),
+    ("gated", 32, 64, 5, 1, 2, 14, 14, 2, None), ("gated", 64, 6, 3, 1, 1, 7, 7, 3, None),
+    ("gated", 3, 32, 3, 2, 1, 16, 12, 2, "elu"),
+    ("plain", 64, 1, 1, 1, 0, 28, 28, 2, "sigmoid"), ("plain", 64, 3, 1, 1, 0, 16, 16, 2, "hardtanh"),
+    ("plain", 32, 48, 3, 1, 1, 9, 9, 2, None),
+]
+
+
+def g6_conv():
+    from utils.nn import GatedConv2d, Conv2d
+    acts = {None: None, "elu": torch.nn.ELU(), "sigmoid": torch.nn.Sigmoid(), "hardtanh": torch.nn.Hardtanh(-4.5, 0.)}
+    out = {}
+    for i, (kind, ci, co, k, st, pd, H, W, N, act) in enumerate(G6_CONV_CASES):
+        rs = np.random.RandomState(600 + i)
+        x = rs.standard_normal((N, ci, H, W)).astype(np.float32)
+        sc = 1.0 / np.sqrt(ci * k * k)
+        wh = (rs.standard_normal((co, ci, k, k)) * sc).astype(np.float32); bh = (rs.standard_normal(co) * 0.1).astype(np.float32)
+        wg = (rs.standard_normal((co, ci, k, k)) * sc).astype(np.float32); bg = (rs.standard_normal(co) * 0.1).astype(np.float32)
+        if kind == "gated":
+            m = GatedConv2d(ci, co, k, st, pd, activation=acts[act])
+            m.load_state_dict({"h.weight": T(wh), "h.bias": T(bh), "g.weight": T(wg), "g.bias": T(bg)})
+        else:
+            m = Conv2d(ci, co, k, st, pd, activation=acts[act])
+            m.load_state_dict({"conv.weight": T(wh), "conv.bias": T(bh)})
+        xt = T(x).clone().requires_grad_(True)
+        y = m(xt)
+        gout = rs.standard_normal(tuple(y.shape)).astype(np.float32)
+        y.backward(T(gout))
+        # big tensors are kept as every 5th element + their fp64 L2 norm (fixtures stay small)
+        for key, arr in (("y", y.detach().numpy()), ("dx", xt.grad.numpy())):
+            out["c%d_%s" % (i, key)] = arr.reshape(-1)[::5].copy()
+            out["c%d_%s_norm" % (i, key)] = np.asarray(np.linalg.norm(arr.astype(np.float64)))
+        for name, prm in m.named_parameters():
+            out["c%d_d_%s" % (i, name)] = prm.grad.numpy()
+    save("g6_conv_layers", **out)
+
+
 # ---- G7: VAE.calculate_loss, train (exact prior) and eval, with injected eps / exemplar indices -----
 def load_params(model, p):
     model.load_state_dict({k: T(v.copy()) for k, v in p.items()})
@@ -716,6 +755,6 @@ def g18():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g6_conv", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
     for w in which:
         globals()[w]()
