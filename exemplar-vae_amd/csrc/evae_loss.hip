@@ -114,6 +114,75 @@ __global__ void bernoulli_ll_bwd_kernel(const float* __restrict__ x, const float
   dmean[i] = inside ? dout[i / D] * (xv / p - (1.0f - xv) / (1.0f - p)) : 0.f;
 }
 
+// ---- 256-bin discretised logistic (utils/distributions.py:54-66), summed over dim 1; one wave per row ---------------
+//   scale = exp(logvar), xs = (floor(256 x)/256 - mean)/scale, ll = log(sigmoid(xs + 1/(256 scale)) - sigmoid(xs) + 1e-7)
+// logvar: [B x D] (lv_scalar = 0) or ONE value (lv_scalar = 1: fully_conv's decoder_logstd, models/AbsModel.py:35-37)
+__device__ __forceinline__ float ll256_terms(float xv, float m, float lv, float& cp, float& cm, float& u, float& v) {
+  const float bin = 1.0f / 256.0f;
+  const float is = expf(-lv);
+  v = (floorf(xv / bin) * bin - m) * is;
+  u = v + bin * is;
+  cp = 1.0f / (1.0f + expf(-u));
+  cm = 1.0f / (1.0f + expf(-v));
+  return cp - cm + 1e-7f;
+}
+
+__global__ __launch_bounds__(LNT) void log_logistic256_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                  const float* __restrict__ logvar, int lv_scalar, int B,
+                                                                  int D, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (LNT / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float lv0 = lv_scalar ? logvar[0] : 0.f;
+  float acc = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const size_t o = (size_t)row * D + k;
+    float cp, cm, u, v;
+    acc += logf(ll256_terms(x[o], mean[o], lv_scalar ? lv0 : logvar[o], cp, cm, u, v));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[row] = acc;
+}
+
+// dmean [B x D]; dlogvar [B x D], or per-row partial sums [B] when logvar is one value (summed by the kernel below)
+__global__ __launch_bounds__(LNT) void log_logistic256_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                  const float* __restrict__ logvar, int lv_scalar,
+                                                                  const float* __restrict__ dout, int B, int D,
+                                                                  float* __restrict__ dmean, float* __restrict__ dlogvar) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (LNT / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float lv0 = lv_scalar ? logvar[0] : 0.f;
+  const float g = dout[row];
+  float acc = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const size_t o = (size_t)row * D + k;
+    const float lv = lv_scalar ? lv0 : logvar[o];
+    float cp, cm, u, v;
+    const float r = g / ll256_terms(x[o], mean[o], lv, cp, cm, u, v);
+    const float a = cp * (1.0f - cp), b = cm * (1.0f - cm);
+    if (dmean) dmean[o] = -r * (a - b) * expf(-lv);
+    const float dl = -r * (a * u - b * v);
+    if (lv_scalar) acc += dl;
+    else if (dlogvar) dlogvar[o] = dl;
+  }
+  if (lv_scalar && dlogvar) {
+    acc = wave_sum(acc);
+    if (lane == 0) dlogvar[row] = acc;
+  }
+}
+
+// out[0] = sum of v[0..n) in a fixed order (one block)
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += v[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+
 // Bernoulli log-likelihood backward through the sigmoid that produced `mean`: d/dpre = d/dmean * mean * (1 - mean)
 __global__ void bernoulli_sigmoid_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                              const float* __restrict__ dout, int B, int D,
@@ -311,6 +380,31 @@ extern "C" int evae_bernoulli_ll_bwd(const float* x, const float* mean, const fl
   EVAE_REQUIRE(x && mean && dout && dmean, "bernoulli_ll_bwd: null pointer");
   bernoulli_ll_bwd_kernel<<<ELT_GRID((size_t)B * D), 256, 0, (hipStream_t)s>>>(x, mean, dout, B, D, dmean);
   return check_launch("bernoulli_ll_bwd");
+}
+
+extern "C" int evae_log_logistic256_fwd(const float* x, const float* mean, const float* logvar, int lv_scalar, int B, int D,
+                                        float* out, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && D > 0, "log_logistic256_fwd: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(x && mean && logvar && out, "log_logistic256_fwd: null pointer");
+  log_logistic256_fwd_kernel<<<ROWS_GRID(B), LNT, 0, (hipStream_t)s>>>(x, mean, logvar, lv_scalar, B, D, out);
+  return check_launch("log_logistic256_fwd");
+}
+
+extern "C" int evae_log_logistic256_bwd(const float* x, const float* mean, const float* logvar, int lv_scalar,
+                                        const float* dout, int B, int D, float* dmean, float* dlogvar, float* ws_rows,
+                                        evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && D > 0, "log_logistic256_bwd: bad sizes");
+  if (B == 0) {
+    if (lv_scalar && dlogvar) (void)hipMemsetAsync(dlogvar, 0, sizeof(float), (hipStream_t)s);
+    return EVAE_OK;
+  }
+  EVAE_REQUIRE(x && mean && logvar && dout, "log_logistic256_bwd: null pointer");
+  EVAE_REQUIRE(!(lv_scalar && dlogvar) || ws_rows, "log_logistic256_bwd: a scalar log-variance needs ws_rows [B]");
+  log_logistic256_bwd_kernel<<<ROWS_GRID(B), LNT, 0, (hipStream_t)s>>>(x, mean, logvar, lv_scalar, dout, B, D, dmean,
+                                                                       lv_scalar ? (dlogvar ? ws_rows : nullptr) : dlogvar);
+  if (lv_scalar && dlogvar) sum_rows_kernel<<<1, 256, 0, (hipStream_t)s>>>(ws_rows, B, dlogvar);
+  return check_launch("log_logistic256_bwd");
 }
 
 extern "C" int evae_batch_prologue(const float* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,

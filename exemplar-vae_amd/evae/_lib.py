@@ -73,6 +73,8 @@ SIGNATURES = {
     "evae_batch_prologue": (_i, [_p, _l, _p, _i, _i, _i, _p, _p, _l, _p, _i, _p]),
     "evae_bernoulli_ll_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_bernoulli_sigmoid_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+    "evae_log_logistic256_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
+    "evae_log_logistic256_bwd": (_i, [_p, _p, _p, _i, _p, _i, _i, _p, _p, _p, _p]),
     "evae_adam_normgrad_workspace_bytes": (_z, [_i]),
     "evae_adam_normgrad_step": (_i, [_p, _i, _l, _i, _d, _d, _d, _d, _d, _p, _p, _z, _p]),
 }

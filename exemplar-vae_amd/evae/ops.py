@@ -644,6 +644,38 @@ class BernoulliLL(torch.autograd.Function):
         return None, dmean
 
 
+class LogLogistic256(torch.autograd.Function):
+    """utils/distributions.py:54-66 summed over dim=1: x [B x D] (no grad), mean [B x D], logvar [B x D] or one value."""
+
+    @staticmethod
+    def forward(ctx, x, mean, logvar):
+        lib = _lib.load()
+        _need_cuda(x, mean, logvar)
+        x, mean, logvar = _f32(x), _f32(mean), _f32(logvar)
+        B, D = mean.shape
+        scalar = logvar.numel() == 1
+        assert scalar or logvar.shape == mean.shape
+        out = torch.empty(B, device=mean.device)
+        _lib.check(lib.evae_log_logistic256_fwd(_p(x), _p(mean), _p(logvar), int(scalar), B, D, _p(out), _stream()),
+                   "evae_log_logistic256_fwd")
+        ctx.save_for_backward(x, mean, logvar)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, mean, logvar = ctx.saved_tensors
+        B, D = mean.shape
+        scalar = logvar.numel() == 1
+        g = _f32(g)
+        dmean = torch.empty_like(mean) if ctx.needs_input_grad[1] else None
+        dlv = torch.empty_like(logvar) if ctx.needs_input_grad[2] else None
+        rows = torch.empty(B, device=mean.device) if (scalar and dlv is not None) else None
+        _lib.check(lib.evae_log_logistic256_bwd(_p(x), _p(mean), _p(logvar), int(scalar), _p(g), B, D, _p(dmean), _p(dlv),
+                                                _p(rows), _stream()), "evae_log_logistic256_bwd")
+        return None, dmean, dlv
+
+
 # ------------------------------------------------------------------------------------------------
 # AdamNormGrad
 # ------------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@ class AbsModel(BaseModel):
             logvar = torch.zeros(1, D)
         elif self.args.use_logit is False:
             mean = mean.clamp(min=_CLAMP_LO, max=_CLAMP_HI)
-            logvar = self.decoder_logstd * torch.ones_like(mean)
+            logvar = self.decoder_logstd.expand_as(mean)        # one value: the likelihood kernel reduces its gradient itself
         else:
             # undefined in the reference as well (it falls through with no log-variance bound); fail with a message
             raise UnboundLocalError("AbsModel.p_x: continuous input with use_logit=True has no x_logvar")

@@ -65,7 +65,13 @@ def log_bernoulli(x, mean, average=False, dim=None):
 
 
 def log_logistic_256(x, mean, logvar, average=False, reduce=True, dim=None):
-    """(:54-66) 256-bin discretised logistic (continuous inputs, use_logit=False)."""
+    """(:54-66) 256-bin discretised logistic (continuous inputs, use_logit=False).  The [B x D] / dim=1 / sum case is one
+    fused row kernel; a log-variance that is ONE value broadcast over the batch (fully_conv's decoder_logstd, passed as
+    an expanded view) stays one value, so its gradient is reduced inside the kernel."""
+    if (not average) and dim == 1 and mean.dim() == 2 and x.shape == mean.shape and mean.is_cuda and logvar.shape == mean.shape:
+        if all(s == 0 for s in logvar.stride()):
+            return ops.LogLogistic256.apply(x, mean, logvar.reshape(-1)[:1])
+        return ops.LogLogistic256.apply(x, mean, logvar)
     bin_size = 1. / 256.
     scale = torch.exp(logvar)
     xs = (torch.floor(x / bin_size) * bin_size - mean) / scale

@@ -266,6 +266,16 @@ int evae_bernoulli_ll_fwd(const float* x, const float* mean, int B, int D, float
                           evae_stream_t stream);
 int evae_bernoulli_ll_bwd(const float* x, const float* mean, const float* dout, int B, int D,
                           float* dmean, evae_stream_t stream);
+/* 256-bin discretised logistic log-likelihood summed over dim 1 (utils/distributions.py:54-66: continuous inputs with
+ * use_logit = False, the reconstruction term of config 5): out_i = sum_k log(sigmoid(xs + 1/(256 s)) - sigmoid(xs) + 1e-7),
+ * xs = (floor(256 x)/256 - mean)/s, s = exp(logvar).  logvar is [B x D], or ONE device value when lv_scalar != 0
+ * (models/fully_conv.py's decoder_logstd, models/AbsModel.py:35-37).  Backward of sum_i dout_i out_i: dmean [B x D] (or NULL),
+ * dlogvar [B x D] -- or [1] for a scalar log-variance, reduced in a fixed order through ws_rows [B] -- (or NULL). */
+int evae_log_logistic256_fwd(const float* x, const float* mean, const float* logvar, int lv_scalar, int B, int D,
+                             float* out /* [B] */, evae_stream_t stream);
+int evae_log_logistic256_bwd(const float* x, const float* mean, const float* logvar, int lv_scalar,
+                             const float* dout /* [B] */, int B, int D, float* dmean, float* dlogvar,
+                             float* ws_rows /* [B], scalar log-variance only */, evae_stream_t stream);
 /* d/dpre when mean = sigmoid(pre) (the p_x_mean head of models/BaseModel.py:28-29): the two steps in one launch */
 int evae_bernoulli_sigmoid_bwd(const float* x, const float* mean, const float* dout, int B, int D,
                                float* dpre, evae_stream_t stream);

@@ -107,3 +107,48 @@ def test_log_p_z_sum_false_matches_golden_and_is_differentiable(golden):
         assert rel(zt.grad.cpu().numpy(), z64.grad.cpu().numpy()) < 1e-4
         assert rel(ct.grad.cpu().numpy(), c64.grad.cpu().numpy()) < 1e-4
         assert rel(plv.grad.cpu().numpy(), p64.grad.cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("B,D,scalar", [(37, 53, False), (4, 12288, True), (100, 784, False), (1, 7, True)])
+def test_log_logistic_256_row_kernel(golden, B, D, scalar):
+    """utils.distributions.log_logistic_256 (reference :54-66) on the fused row kernel: values against the oracle (and G6
+    for its case), gradients wrt mean and log-variance -- a full [B x D] tensor or ONE broadcast value, the way
+    models/fully_conv.py feeds its decoder_logstd -- against torch autograd on the reference's formula in fp64."""
+    import evae_oracle as orc
+    from utils.distributions import log_logistic_256
+    if (B, D) == (37, 53):
+        rs = np.random.RandomState(51)          # replay tools/gen_goldens.py::g6 up to its log_logistic_256 inputs
+        R, I, O = 37, 53, 24
+        rs.standard_normal((R, I)); [rs.standard_normal(sh) for sh in ((O, I), O, (O, I), O)]; rs.standard_normal((R, O))
+        rs.standard_normal((R, I)); rs.random_sample((R, I)); rs.standard_normal((R, I)); rs.uniform(-6, 2, (R, I))
+    else:
+        rs = np.random.RandomState(B + D)
+    xc = ((rs.randint(0, 256, (B, D)) + 0.5) / 256).astype(np.float32)
+    mc = rs.uniform(1 / 512., 1 - 1 / 512., (B, D)).astype(np.float32)
+    ls = rs.uniform(-4.5, 0, (B, D)).astype(np.float32)
+    if scalar:
+        ls = np.full((B, D), -1.7, np.float32)
+    if (B, D) == (37, 53):
+        g = golden("g6_layers")
+        got = log_logistic_256(dev(xc), dev(mc), dev(ls), dim=1).cpu().numpy()
+        assert rel(got, g["log_logistic_256"]) < 1e-5
+    mt = dev(mc).requires_grad_(True)
+    if scalar:
+        lt = torch.tensor([-1.7], device="cuda", requires_grad=True)
+        lv_in = lt.expand(B, D)
+    else:
+        lt = dev(ls).requires_grad_(True)
+        lv_in = lt
+    out = log_logistic_256(dev(xc), mt, lv_in, dim=1)
+    assert rel(out.detach().cpu().numpy(), orc.log_logistic_256(xc.astype(np.float64), mc.astype(np.float64), ls.astype(np.float64))) < 1e-5
+    w = dev(np.random.RandomState(3).standard_normal(B).astype(np.float32))
+    (out * w).sum().backward()
+    m64 = dev(mc).double().requires_grad_(True)
+    l64 = (torch.tensor([-1.7], device="cuda", dtype=torch.float64) if scalar else dev(ls).double()).requires_grad_(True)
+    x64 = dev(xc).double()
+    scale = torch.exp(l64.expand(B, D) if scalar else l64)
+    xs = (torch.floor(x64 * 256) / 256 - m64) / scale
+    ref = torch.log(torch.sigmoid(xs + 1 / (256 * scale)) - torch.sigmoid(xs) + 1e-7).sum(1)
+    (ref * w.double()).sum().backward()
+    assert rel(mt.grad.cpu().numpy(), m64.grad.cpu().numpy()) < 1e-4
+    assert rel(lt.grad.cpu().numpy(), l64.grad.cpu().numpy()) < 1e-4
