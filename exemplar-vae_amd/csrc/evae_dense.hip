@@ -181,10 +181,11 @@ extern "C" size_t evae_dense_bwd_weight_workspace_bytes(int M, int N, int K) {
   return align_up((size_t)pl.nz * N * (K + 1) * sizeof(float), 256) + 256;
 }
 
-extern "C" int evae_dense_bwd_weight(const float* dy, int M, int N, int ldy, const float* x,
-                                     const int64_t* rows, int K, int ldx, float* dw, float* db,
-                                     int accumulate, void* ws, size_t ws_bytes, evae_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+// phase 0: both launches; 1: the split-K GEMM into the workspace partials; 2: the finish (sum of the partial planes in a fixed
+// order -> dw, db) -- so that a caller can put the finish on another stream than the GEMM that follows
+static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const float* x,
+                                 const int64_t* rows, int K, int ldx, float* dw, float* db,
+                                 int accumulate, void* ws, size_t ws_bytes, int phase, hipStream_t stream) {
   EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N, "dense_bwd_weight: bad sizes M=%d N=%d K=%d", M, N, K);
   EVAE_REQUIRE(dw != nullptr, "dense_bwd_weight: null dw");
   if (ws == nullptr || ws_bytes < evae_dense_bwd_weight_workspace_bytes(M, N, K)) {
@@ -192,6 +193,7 @@ extern "C" int evae_dense_bwd_weight(const float* dy, int M, int N, int ldy, con
     return EVAE_EWORKSPACE;
   }
   if (M == 0) {
+    if (phase == 1) return EVAE_OK;
     if (!accumulate) {
       (void)hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), stream);
       if (db) (void)hipMemsetAsync(db, 0, (size_t)N * sizeof(float), stream);
@@ -205,12 +207,28 @@ extern "C" int evae_dense_bwd_weight(const float* dy, int M, int N, int ldy, con
   GemmArgs g = {};
   g.A[0] = dy; g.B[0] = x; g.lda[0] = ldy; g.ldb[0] = ldx; g.Kc[0] = M; g.npairs = 1;
   g.b_krows = rows; g.M = N; g.N = Kp; g.out0 = part; g.ldo = Kp; g.ones_col = K;
-  int rc = launch_gemm<false, false, EPI_RAW>(g, pl, stream, "dense_bwd_weight");
-  if (rc) return rc;
+  if (phase != 2) {
+    int rc = launch_gemm<false, false, EPI_RAW>(g, pl, stream, "dense_bwd_weight");
+    if (rc) return rc;
+    if (phase == 1) return EVAE_OK;
+  }
   FinishArgs f = {};
   f.part = part; f.nz = pl.nz; f.M = N; f.N = Kp; f.ldo = Kp; f.epi = EPI_RAW; f.out0 = dw; f.accumulate = accumulate;
   f.ones_col = K; f.out_db = db;
   return launch_finish(f, stream);
+}
+
+extern "C" int evae_dense_bwd_weight(const float* dy, int M, int N, int ldy, const float* x,
+                                     const int64_t* rows, int K, int ldx, float* dw, float* db,
+                                     int accumulate, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  return dense_bwd_weight_core(dy, M, N, ldy, x, rows, K, ldx, dw, db, accumulate, ws, ws_bytes, 0, (hipStream_t)stream_);
+}
+
+extern "C" int evae_dense_bwd_weight_phased(const float* dy, int M, int N, int ldy, const float* x,
+                                            const int64_t* rows, int K, int ldx, float* dw, float* db,
+                                            int accumulate, void* ws, size_t ws_bytes, int phase, evae_stream_t stream_) {
+  EVAE_REQUIRE(phase == 1 || phase == 2, "dense_bwd_weight_phased: phase must be 1 or 2");
+  return dense_bwd_weight_core(dy, M, N, ldy, x, rows, K, ldx, dw, db, accumulate, ws, ws_bytes, phase, (hipStream_t)stream_);
 }
 
 extern "C" int evae_gated_dense_bwd_input(const float* dout, const float* out, const float* s, int M, int N,

@@ -574,6 +574,69 @@ __global__ __launch_bounds__(NT) void prior_merge_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tail of the training step's forward in ONE launch (single block, 16 waves): merge R partial rows per query (the splits
+// of one device, or the gathered shard partials), logp = lse - log(c_total - nmask), KL = logq - logp, loss = beta KL - RE,
+// and the three batch means (models/BaseModel.py:71-75,124-125).  One wave per row, rows strided over the waves.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void prior_elbo_fwd_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
+                                                              const float* __restrict__ pn, int R, int ldp, int B,
+                                                              float c_total, const float* __restrict__ RE,
+                                                              const float* __restrict__ logq,
+                                                              const float* __restrict__ beta_dev, float beta_host,
+                                                              float* __restrict__ logp, float* __restrict__ lse_out,
+                                                              float* __restrict__ loss, float* __restrict__ KL,
+                                                              float* __restrict__ means) {
+  // thread = (query row within a chunk of 128, one of 8 groups of partial rows): consecutive lanes read consecutive
+  // queries of one partial row (coalesced), every thread keeps an online (max, sum exp, #masked) over its rows r = g, g+8, ..
+  __shared__ float cm[8][128], cs[8][128], cn[8][128];
+  __shared__ float red[3][2];
+  const int q = threadIdx.x & 127, grp = threadIdx.x >> 7;
+  const float beta = beta_dev ? beta_dev[0] : beta_host;
+  float sl = 0.f, sr = 0.f, sk = 0.f;          // threads of group 0 accumulate their rows
+  for (int row0 = 0; row0 < B; row0 += 128) {
+    const int row = row0 + q;
+    float m = -INFINITY, s = 0.f, n = 0.f;
+    if (row < B) {
+      for (int r = grp; r < R; r += 8) {
+        const float mr = pm[(size_t)r * ldp + row], sr_ = ps[(size_t)r * ldp + row];
+        n += pn[(size_t)r * ldp + row];
+        if (mr > m) { s = s * expf(m - mr) + sr_; m = mr; }      // m == -inf: s == 0 and exp(-inf) = 0
+        else if (mr != -INFINITY) s += sr_ * expf(mr - m);
+      }
+    }
+    cm[grp][q] = m; cs[grp][q] = s; cn[grp][q] = n;
+    __syncthreads();
+    if (grp == 0 && row < B) {
+      float mm = -INFINITY, ss = 0.f, nn = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) mm = fmaxf(mm, cm[g][q]);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {                // fixed order
+        if (cm[g][q] != -INFINITY) ss += cs[g][q] * expf(cm[g][q] - mm);
+        nn += cn[g][q];
+      }
+      const float lse = mm + logf(ss);
+      const float lp = lse - logf(c_total - nn);
+      logp[row] = lp;
+      if (lse_out) lse_out[row] = lse;
+      const float kl = logq[row] - lp;
+      const float l = beta * kl - RE[row];
+      KL[row] = kl;
+      loss[row] = l;
+      sl += l; sr += RE[row]; sk += kl;
+    }
+    __syncthreads();
+  }
+  if (means == nullptr) return;
+  if (grp == 0) {                                  // waves 0 and 1
+    sl = wave_sum(sl); sr = wave_sum(sr); sk = wave_sum(sk);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sl; red[1][threadIdx.x >> 6] = sr; red[2][threadIdx.x >> 6] = sk; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) means[threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) / (float)B;
+}
+
 __global__ void prior_fill_empty_kernel(float* m, float* s, float* n, int B) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) { m[i] = -INFINITY; s[i] = 0.f; n[i] = 0.f; }
@@ -1114,17 +1177,25 @@ extern "C" size_t evae_prior_lse_fwd_workspace_bytes(int B, int C, int zdim) {
   return valu;
 }
 
-extern "C" int evae_prior_lse_fwd(const float* z, int B, const float* centres, int C, int zdim,
-                                  const float* log_var, const int64_t* z_idx, const int64_t* c_idx,
-                                  float* out_max, float* out_sumexp, float* out_nmask, float* out_prob,
-                                  void* ws, size_t ws_bytes, evae_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+// splits_out != nullptr: leave the per-split partials in the workspace (planes of *splits_out rows x B at ws, ws + R B,
+// ws + 2 R B floats, R = the split count of choose_splits) instead of merging them into out_*; z <= 64 / VALU paths only
+static int prior_lse_fwd_core(const float* z, int B, const float* centres, int C, int zdim,
+                              const float* log_var, const int64_t* z_idx, const int64_t* c_idx,
+                              float* out_max, float* out_sumexp, float* out_nmask, float* out_prob,
+                              void* ws, size_t ws_bytes, int* splits_out, hipStream_t stream) {
   EVAE_REQUIRE(B >= 0 && C >= 0 && zdim > 0, "prior_lse_fwd: bad sizes B=%d C=%d zdim=%d", B, C, zdim);
   EVAE_REQUIRE(zdim <= ZDIM_MAX, "prior_lse_fwd: zdim %d > %d unsupported", zdim, ZDIM_MAX);
   if (B == 0) return EVAE_OK;
-  EVAE_REQUIRE(z && log_var && out_max && out_sumexp && out_nmask, "prior_lse_fwd: null pointer");
+  EVAE_REQUIRE(z && log_var && (splits_out || (out_max && out_sumexp && out_nmask)), "prior_lse_fwd: null pointer");
   if (C == 0) {
-    prior_fill_empty_kernel<<<cdiv(B, 256), 256, 0, stream>>>(out_max, out_sumexp, out_nmask, B);
+    if (splits_out) {
+      EVAE_REQUIRE(ws != nullptr && ws_bytes >= (size_t)3 * B * sizeof(float), "prior_lse_fwd: workspace too small");
+      float* w = (float*)ws;
+      prior_fill_empty_kernel<<<cdiv(B, 256), 256, 0, stream>>>(w, w + B, w + 2 * B, B);
+      *splits_out = 1;
+    } else {
+      prior_fill_empty_kernel<<<cdiv(B, 256), 256, 0, stream>>>(out_max, out_sumexp, out_nmask, B);
+    }
     return check_launch("prior_fill_empty");
   }
   EVAE_REQUIRE(centres != nullptr, "prior_lse_fwd: null centres");
@@ -1155,11 +1226,17 @@ extern "C" int evae_prior_lse_fwd(const float* z, int B, const float* centres, i
       default: rc = launch_prior_mfma<8>(z, B, centres, C, zdim, log_var, z_idx, c_idx, ns, pm, ps, pn, &ns2, stream); break;
     }
     if (rc) return rc;
+    if (splits_out) {
+      // the kernel wrote ns2 <= ns rows into planes laid out for ns rows: hand over the plane stride with the count
+      *splits_out = ns2 | (ns << 16);
+      return EVAE_OK;
+    }
     prior_merge_kernel<<<cdiv(B, NT / 64), NT, 0, stream>>>(pm, ps, pn, ns2, B, 0, 0.f, out_max, out_sumexp, out_nmask);
     return check_launch("prior_merge_kernel(splits)");
   }
   size_t lds = prior_lds_bytes(g, false);
   if (!force_valu && out_prob == nullptr && fwd_uses_gemm(B, C, zdim)) {
+    EVAE_REQUIRE(splits_out == nullptr, "prior_lse_fwd: raw split partials are not available on the GEMM path (z_dim > 64)");
     // matrix-core GEMM with a log-sum-exp epilogue; its norm guard hands over to the direct-difference kernel on the device
     const PriorGemmFwdLayout L = prior_gemm_fwd_layout(B, C, zdim, ns);
     int rc = prior_gemm_fwd(z, B, centres, C, zdim, log_var, z_idx, c_idx, prior_norm_limit(), (char*)ws, L, stream);
@@ -1177,10 +1254,49 @@ extern "C" int evae_prior_lse_fwd(const float* z, int B, const float* centres, i
                              z, B, centres, C, zdim, log_var, z_idx, c_idx, tps, ns, g, pm, ps, pn, out_prob, nullptr)));
   int rc = check_launch("prior_fwd_kernel");
   if (rc) return rc;
+  if (splits_out) { *splits_out = ns | (ns << 16); return EVAE_OK; }
   prior_merge_kernel<<<cdiv(B, NT / 64), NT, 0, stream>>>(pm, ps, pn, ns, B, 0, 0.f, out_max, out_sumexp,
                                                         out_nmask);
   return check_launch("prior_merge_kernel(splits)");
 }
+
+extern "C" int evae_prior_lse_fwd(const float* z, int B, const float* centres, int C, int zdim,
+                                  const float* log_var, const int64_t* z_idx, const int64_t* c_idx,
+                                  float* out_max, float* out_sumexp, float* out_nmask, float* out_prob,
+                                  void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  return prior_lse_fwd_core(z, B, centres, C, zdim, log_var, z_idx, c_idx, out_max, out_sumexp, out_nmask, out_prob, ws,
+                            ws_bytes, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int evae_prior_lse_fwd_splits(const float* z, int B, const float* centres, int C, int zdim,
+                                         const float* log_var, const int64_t* z_idx, const int64_t* c_idx,
+                                         void* ws, size_t ws_bytes, int* nsplit, int* plane_rows, evae_stream_t stream_) {
+  EVAE_REQUIRE(nsplit && plane_rows, "prior_lse_fwd_splits: null pointer");
+  EVAE_REQUIRE(zdim <= 64 || !fwd_uses_gemm(B, C, zdim), "prior_lse_fwd_splits: z_dim > 64 runs on the GEMM path; use evae_prior_lse_fwd");
+  int packed = 0;
+  *nsplit = 0; *plane_rows = 0;
+  if (B == 0) return EVAE_OK;
+  int rc = prior_lse_fwd_core(z, B, centres, C, zdim, log_var, z_idx, c_idx, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
+                              &packed, (hipStream_t)stream_);
+  if (rc) return rc;
+  if (C == 0) { *nsplit = 1; *plane_rows = 1; return EVAE_OK; }
+  *nsplit = packed & 0xFFFF; *plane_rows = packed >> 16;
+  return EVAE_OK;
+}
+
+extern "C" int evae_prior_elbo_fwd(const float* pmax, const float* psum, const float* pnmask, int R, int ldp, int B,
+                                   float c_total, const float* RE, const float* logq, const float* beta_dev,
+                                   float beta_host, float* logp, float* lse, float* loss, float* KL, float* means,
+                                   evae_stream_t stream_) {
+  EVAE_REQUIRE(R >= 1 && B >= 0 && ldp >= B, "prior_elbo_fwd: bad sizes R=%d B=%d ldp=%d", R, B, ldp);
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(pmax && psum && pnmask && RE && logq && logp && loss && KL, "prior_elbo_fwd: null pointer");
+  prior_elbo_fwd_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(pmax, psum, pnmask, R, ldp, B, c_total, RE, logq, beta_dev,
+                                                             beta_host, logp, lse, loss, KL, means);
+  return check_launch("prior_elbo_fwd_kernel");
+}
+
+
 
 extern "C" int evae_prior_merge(const float* max, const float* sumexp, const float* nmask, int R, int B,
                                 float c_total, float* out_logprior, float* out_lse,
@@ -1205,16 +1321,19 @@ extern "C" size_t evae_prior_lse_bwd_workspace_bytes(int B, int C, int zdim) {
   return tot;
 }
 
-extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, int C, int zdim,
-                                  const float* log_var, const int64_t* z_idx, const int64_t* c_idx,
-                                  const float* lse, const float* grad_out, float* dz, float* dcentres,
-                                  float* dlogvar, void* ws, size_t ws_bytes, evae_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+// phase 0: everything.  phase 1 / 2 (evae_prior_lse_bwd_phased): 1 = up to and including dcentres, 2 = what is left (the
+// reduction of the per-split dz / dlogvar partials in the workspace) -- the matrix-core path splits there, every other path
+// does all its work in phase 1.
+static int prior_lse_bwd_core(const float* z, int B, const float* centres, int C, int zdim,
+                              const float* log_var, const int64_t* z_idx, const int64_t* c_idx,
+                              const float* lse, const float* grad_out, float* dz, float* dcentres,
+                              float* dlogvar, void* ws, size_t ws_bytes, int phase, hipStream_t stream) {
   EVAE_REQUIRE(B >= 0 && C >= 0 && zdim > 0, "prior_lse_bwd: bad sizes");
   EVAE_REQUIRE(zdim <= ZDIM_MAX, "prior_lse_bwd: zdim %d > %d unsupported", zdim, ZDIM_MAX);
   if (B == 0 && C == 0) return EVAE_OK;
   EVAE_REQUIRE((dz || B == 0) && dlogvar && log_var, "prior_lse_bwd: null pointer");   // an empty batch has no dz
   if (B == 0 || C == 0) {
+    if (phase == 2) return EVAE_OK;
     if (B > 0) zero_kernel<<<cdiv(B * zdim, 256), 256, 0, stream>>>(dz, (size_t)B * zdim);
     if (C > 0 && dcentres) zero_kernel<<<cdiv(C * zdim, 256), 256, 0, stream>>>(dcentres, (size_t)C * zdim);
     zero_kernel<<<1, 256, 0, stream>>>(dlogvar, (size_t)zdim);
@@ -1231,16 +1350,31 @@ extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, i
   float* dz_part = (float*)ws;
   float* dlv_part = (float*)((char*)ws + align_up((size_t)ns * B * zdim * sizeof(float), 256));
   int use_atomic = nq > 1;
-  if (use_atomic) {
+  // matrix-core path (see prior_bwd_mfma_kernel); EVAE_PRIOR_VALU=1 forces the direct-difference kernel
+  static int force_valu = -1;
+  if (force_valu < 0) { const char* e = getenv("EVAE_PRIOR_VALU"); force_valu = (e && atoi(e)) ? 1 : 0; }
+  const bool mfma = !force_valu && zdim <= 56 && (zdim & 3) == 0 && ((((uintptr_t)z) | ((uintptr_t)centres)) & 15) == 0;
+  if (phase == 2 && !mfma) return EVAE_OK;           // everything happened in phase 1
+  if (use_atomic && phase != 2) {
     zero_kernel<<<cdiv(C * zdim, 256), 256, 0, stream>>>(dcentres, (size_t)C * zdim);
     int rc = check_launch("zero dcentres");
     if (rc) return rc;
   }
-  // matrix-core path (see prior_bwd_mfma_kernel); EVAE_PRIOR_VALU=1 forces the direct-difference kernel
-  static int force_valu = -1;
-  if (force_valu < 0) { const char* e = getenv("EVAE_PRIOR_VALU"); force_valu = (e && atoi(e)) ? 1 : 0; }
-  if (!force_valu && zdim <= 56 && (zdim & 3) == 0 && ((((uintptr_t)z) | ((uintptr_t)centres)) & 15) == 0) {
+  if (mfma) {
     int ns2 = 1, rc;
+    if (phase == 2) {
+      // the split count of launch_prior_bwd_mfma, recomputed (deterministic in (B, C))
+      const int nq2 = cdiv(B, MFQ), ntiles = cdiv(C, MFE);
+      int n2 = cdiv(512, nq2);
+      if (n2 > ntiles) n2 = ntiles;
+      if (n2 > ns) n2 = ns;
+      if (n2 < 1) n2 = 1;
+      ns2 = cdiv(ntiles, cdiv(ntiles, n2));
+      const int nb = cdiv(B * zdim, 64);
+      prior_bwd_finish_kernel<<<nb + cdiv(zdim, 16), 1024, 0, stream>>>(dz_part, ns2, B * zdim, zdim, log_var, dz, nb, dlv_part,
+                                                                       ns2 * nq, dlogvar, nullptr);
+      return check_launch("prior_bwd_finish_kernel");
+    }
 #define EVAE_BWD_MFMA(KG_) rc = launch_prior_bwd_mfma<KG_>(z, B, centres, C, zdim, log_var, z_idx, c_idx, lse, grad_out, ns, \
                                                           use_atomic, dz_part, dcentres, dlv_part, &ns2, stream)
     switch ((zdim + 7) / 8) {
@@ -1254,6 +1388,7 @@ extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, i
     }
 #undef EVAE_BWD_MFMA
     if (rc) return rc;
+    if (phase == 1) return EVAE_OK;
     const int nb = cdiv(B * zdim, 64);
     prior_bwd_finish_kernel<<<nb + cdiv(zdim, 16), 1024, 0, stream>>>(dz_part, ns2, B * zdim, zdim, log_var, dz, nb, dlv_part,
                                                                      ns2 * nq, dlogvar, nullptr);
@@ -1289,3 +1424,21 @@ extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, i
                                                                        dlv_part, ns * nq, dlogvar, run_flag);
   return check_launch("prior_bwd_finish_kernel");
 }
+
+extern "C" int evae_prior_lse_bwd(const float* z, int B, const float* centres, int C, int zdim,
+                                  const float* log_var, const int64_t* z_idx, const int64_t* c_idx,
+                                  const float* lse, const float* grad_out, float* dz, float* dcentres,
+                                  float* dlogvar, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  return prior_lse_bwd_core(z, B, centres, C, zdim, log_var, z_idx, c_idx, lse, grad_out, dz, dcentres, dlogvar, ws, ws_bytes,
+                            0, (hipStream_t)stream_);
+}
+
+extern "C" int evae_prior_lse_bwd_phased(const float* z, int B, const float* centres, int C, int zdim,
+                                         const float* log_var, const int64_t* z_idx, const int64_t* c_idx,
+                                         const float* lse, const float* grad_out, float* dz, float* dcentres,
+                                         float* dlogvar, void* ws, size_t ws_bytes, int phase, evae_stream_t stream_) {
+  EVAE_REQUIRE(phase == 1 || phase == 2, "prior_lse_bwd_phased: phase must be 1 or 2");
+  return prior_lse_bwd_core(z, B, centres, C, zdim, log_var, z_idx, c_idx, lse, grad_out, dz, dcentres, dlogvar, ws, ws_bytes,
+                            phase, (hipStream_t)stream_);
+}
+

@@ -36,8 +36,11 @@ SIGNATURES = {
     "evae_prior_lse_fwd_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_prior_lse_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_prior_merge": (_i, [_p, _p, _p, _i, _i, _f, _p, _p, _p]),
+    "evae_prior_lse_fwd_splits": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _z, C.POINTER(C.c_int), C.POINTER(C.c_int), _p]),
+    "evae_prior_elbo_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
     "evae_prior_lse_bwd_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_prior_lse_bwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_prior_lse_bwd_phased": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _p]),
     "evae_pairdist_topk_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "evae_pairdist_topk": (_i, [_p, _i, _p, _i, _i, _i, _u, _l, _p, _p, _p, _z, _p]),
     "evae_pairwise_distance": (_i, [_p, _i, _p, _i, _i, _p, _p]),
@@ -49,6 +52,7 @@ SIGNATURES = {
     "evae_dense_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _z, _p]),
     "evae_dense_bwd_weight_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_dense_bwd_weight": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p, _z, _p]),
+    "evae_dense_bwd_weight_phased": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p, _z, _i, _p]),
     "evae_gated_dense_bwd_input": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "evae_act_bwd": (_i, [_p, _p, _z, _i, _f, _f, _p, _p]),
     "evae_conv2d_workspace_bytes": (_z, [_p, _i, _i]),

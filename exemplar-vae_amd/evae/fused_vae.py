@@ -19,6 +19,7 @@ With torch.distributed active and shard=True the exemplar rows are this rank's s
 partials (max, sumexp, nmask) are all-gathered and merged, dz / dlogvar are sum-all-reduced and
 dcentres is scaled by the world size (see evae/shard.py for why)."""
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -26,6 +27,12 @@ import torch.distributed as dist
 from . import _lib, ops, shard
 
 ACT_NONE, ACT_SIGMOID, ACT_HARDTANH = ops.ACT_NONE, ops.ACT_SIGMOID, ops.ACT_HARDTANH
+
+# schedule switches (bit mask; tools/chain_bench.sh sweeps them): 1 = the prior's dz' / dlogvar reduction on the side stream,
+# 2 = the finish launch of encoder layer 2's weight gradient on the side stream.  Both OFF: measured at config 2 (r02), 0 ->
+# 0.975 ms/step, 1 -> 1.002, 2 -> 1.085, 3 -> 1.076 -- a launch that runs beside a CU-filling GEMM costs that GEMM more than
+# the launch saves on the main stream.
+SCHED = int(os.environ.get("EVAE_SCHED", "0"))
 
 PARAM_ORDER = [
     "prior_log_variance",
@@ -68,14 +75,14 @@ class _K:
         key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         st = _K._side.get(key)
         if st is None:
-            st = _K._side[key] = torch.cuda.Stream(device=self.dev)
+            st = _K._side[key] = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("EVAE_SIDE_PRIORITY", "-1")))
         return st
 
     def gated_fwd(self, x, rows, M, K, ldx, wh, bh, wg, bg, N, out, h, s):
         nb = self.lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
         w = self.ws("fwd", nb)
         # bench.py's roofline probe times the dominant launch only: encoder layer 1 (row-gathered, no split-K)
-        probe = ops.PROBE if (nb <= 256 and rows is not None) else None
+        probe = ops.PROBE if (nb <= 256 and rows is not None and M >= 1024) else None
         reps = 1
         if probe is not None:
             # bench.py's roofline probe: the launch is repeated (same arguments, idempotent) between one event pair so
@@ -102,11 +109,17 @@ class _K:
         _lib.check(self.lib.evae_dense_bwd_data(_vp(dy1), _vp(w1), _vp(dy2), _vp(w2), M, N, ldy, K, _vp(out_prev),
                                                 _vp(s_prev), _vp(out), _vp(dg), ldo, _vp(w), w.numel(), self.st), "bwd_data")
 
-    def bwd_weight(self, dy, M, N, ldy, x, rows, K, ldx, dw, db):
+    def bwd_weight(self, dy, M, N, ldy, x, rows, K, ldx, dw, db, phase=0, ws_name="wgrad", finish_on=None):
+        """phase 1 / 2: the split-K GEMM and its finish as separate calls (finish_on = the launcher whose stream runs it)"""
         nb = self.lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
-        w = self.ws("wgrad", nb)
-        _lib.check(self.lib.evae_dense_bwd_weight(_vp(dy), M, N, ldy, _vp(x), _vp(rows), K, ldx, _vp(dw), _vp(db), 0,
-                                                  _vp(w), w.numel(), self.st), "bwd_weight")
+        w = ops._workspace(ws_name + self.sfx, nb, self.dev)
+        if phase == 0:
+            _lib.check(self.lib.evae_dense_bwd_weight(_vp(dy), M, N, ldy, _vp(x), _vp(rows), K, ldx, _vp(dw), _vp(db), 0,
+                                                      _vp(w), w.numel(), self.st), "bwd_weight")
+        else:
+            st = self.st if finish_on is None else finish_on.st
+            _lib.check(self.lib.evae_dense_bwd_weight_phased(_vp(dy), M, N, ldy, _vp(x), _vp(rows), K, ldx, _vp(dw), _vp(db), 0,
+                                                             _vp(w), w.numel(), phase, st), "bwd_weight_phased")
 
 
 class VaeExactLoss(torch.autograd.Function):
@@ -142,36 +155,51 @@ class VaeExactLoss(torch.autograd.Function):
         side = k.side_stream()
         kd = _K(dev, stream=side, suffix="_side")        # launcher of the decoder chain
         side.wait_stream(main)
-        # ---- encoder over C + B rows
+        # ---- encoder.  The Cl exemplar rows on the main stream (the big GEMMs); the B batch rows as thin launches on the
+        #      side stream, writing the tail rows of the same activation buffers (the weight gradients later run over all
+        #      Cl + B rows in one launch per layer).  The whole batch-row path -- encoder, heads, sampling, decoder,
+        #      reconstruction term -- thereby runs BESIDE the exemplar encoder instead of behind it; the two streams meet
+        #      at the prior (which needs z) and at the ELBO.
         # a gated layer keeps its output and its gate s for the backward (dg = dout * out * (1 - s)); h is never stored
         A1 = torch.empty((Mp, H), **f32); s1 = torch.empty_like(A1)
-        k.gated_fwd(data_ext, rows, Mp, D, ldd, w1h, b1h, w1g, b1g, H, A1, None, s1)
-        with torch.cuda.stream(side):                    # the prior's log-variance row, issued behind the big launch so
-            lv_row = plv.detach().expand(Z).contiguous()   # that it runs next to it instead of in front of it
-            lv_ready = torch.cuda.Event(); lv_ready.record()
         A2 = torch.empty((Mp, H), **f32); s2 = torch.empty_like(A2)
-        k.gated_fwd(A1, None, Mp, H, H, w2h, b2h, w2g, b2g, H, A2, None, s2)
         mean_all = torch.empty((Mp, Z), **f32)
-        k.linear_fwd(A2, Mp, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, mean_all, None)
         centres = mean_all[:Cl]
         z_mean = mean_all[Cl:]
         A2b = A2[Cl:]
         logvar = torch.empty((B, Z), **f32); lv_pre = torch.empty_like(logvar)
-        k.linear_fwd(A2b, B, H, H, wl, bl, Z, ACT_HARDTANH, -6.0, 2.0, logvar, lv_pre)
-        # ---- sample, decode, reconstruct
         z = torch.empty((B, Z), **f32); logq = torch.empty(B, **f32)
-        _lib.check(lib.evae_reparam_logq_fwd(_vp(z_mean), _vp(logvar), _vp(eps), B, Z, _vp(z), _vp(logq), k.st), "reparam")
+        D1 = torch.empty((B, H), **f32); sd1 = torch.empty_like(D1)
+        D2 = torch.empty((B, H), **f32); sd2 = torch.empty_like(D2)
+        xmean = torch.empty((B, D), **f32)
+        RE = torch.empty(B, **f32)
+        offb = 4 * Cl                                    # byte offset of the batch rows, per float of row width
+        if Cl > 0:
+            k.gated_fwd(data_ext, rows, Cl, D, ldd, w1h, b1h, w1g, b1g, H, A1, None, s1)
+        with torch.cuda.stream(side):
+            lv_row = plv.detach().expand(Z).contiguous()   # the prior's log-variance row
+            kd.gated_fwd(data_ext, rows.data_ptr() + 8 * Cl, B, D, ldd, w1h, b1h, w1g, b1g, H,
+                         A1.data_ptr() + offb * H, None, s1.data_ptr() + offb * H)
+            kd.gated_fwd(A1.data_ptr() + offb * H, None, B, H, H, w2h, b2h, w2g, b2g, H,
+                         A2.data_ptr() + offb * H, None, s2.data_ptr() + offb * H)
+            kd.linear_fwd(A2b, B, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, z_mean, None)
+            kd.linear_fwd(A2b, B, H, H, wl, bl, Z, ACT_HARDTANH, -6.0, 2.0, logvar, lv_pre)
+            # ---- sample, decode, reconstruct
+            _lib.check(lib.evae_reparam_logq_fwd(_vp(z_mean), _vp(logvar), _vp(eps), B, Z, _vp(z), _vp(logq), kd.st), "reparam")
+            z_ready = torch.cuda.Event(); z_ready.record()
+            kd.gated_fwd(z, None, B, Z, Z, d1h, e1h, d1g, e1g, H, D1, None, sd1)
+            kd.gated_fwd(D1, None, B, H, H, d2h, e2h, d2g, e2g, H, D2, None, sd2)
+            kd.linear_fwd(D2, B, H, H, wp, bp, D, ACT_SIGMOID, 0.0, 0.0, xmean, None)
+            _lib.check(lib.evae_bernoulli_ll_fwd(_vp(x), _vp(xmean), B, D, _vp(RE), kd.st), "bernoulli")
+        if Cl > 0:
+            k.gated_fwd(A1, None, Cl, H, H, w2h, b2h, w2g, b2g, H, A2, None, s2)
+            k.linear_fwd(A2, Cl, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, mean_all, None)
+        main.wait_event(z_ready)
         # ---- exemplar prior (leave-one-out mask in training unless no_mask; with its collectives when sharded) on the
         #      main stream ...
         zi = None if no_mask else x_idx.reshape(-1)
         ci = None if no_mask else ex_idx
         logp = torch.empty(B, **f32); lse = torch.empty(B, **f32)
-        D1 = torch.empty((B, H), **f32); sd1 = torch.empty_like(D1)
-        D2 = torch.empty((B, H), **f32); sd2 = torch.empty_like(D2)
-        xmean = torch.empty((B, D), **f32)
-        RE = torch.empty(B, **f32)
-        side.wait_stream(main)
-        main.wait_event(lv_ready)
         z_all, zi_all = z, zi
         if sharded == 2:
             # data-parallel batches over sharded exemplars: every rank scores the queries of ALL ranks against its
@@ -182,24 +210,31 @@ class VaeExactLoss(torch.autograd.Function):
             m, s, n = shard.gather_partials(m, s, n)                  # [R x R*B] each
             r0 = dist.get_rank() * B
             m, s, n = (t[:, r0:r0 + B].contiguous() for t in (m, s, n))
-        else:
+        elif sharded:
             m, s, n, _ = ops.prior_lse_fwd(z, centres, lv_row, zi, ci)
-            if sharded:
-                m, s, n = shard.gather_partials(m, s, n)
-        ops.prior_merge(m, s, n, c_total, out=(logp, lse))
-        # ---- ... while the decoder reconstructs on the side stream
-        with torch.cuda.stream(side):
-            kd.gated_fwd(z, None, B, Z, Z, d1h, e1h, d1g, e1g, H, D1, None, sd1)
-            kd.gated_fwd(D1, None, B, H, H, d2h, e2h, d2g, e2g, H, D2, None, sd2)
-            kd.linear_fwd(D2, B, H, H, wp, bp, D, ACT_SIGMOID, 0.0, 0.0, xmean, None)
-            _lib.check(lib.evae_bernoulli_ll_fwd(_vp(x), _vp(xmean), B, D, _vp(RE), kd.st), "bernoulli")
+            m, s, n = shard.gather_partials(m, s, n)
+        if sharded:
+            R, ldp = m.shape[0], m.shape[1]
+            pm, ps, pn = m, s, n
+        else:
+            # one device: the per-split partials stay un-merged in the workspace
+            nb = lib.evae_prior_lse_fwd_workspace_bytes(B, Cl, Z)
+            w = k.ws("prior_fwd", nb)
+            ns, prow = C.c_int(0), C.c_int(0)
+            _lib.check(lib.evae_prior_lse_fwd_splits(_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(w),
+                                                     w.numel(), C.byref(ns), C.byref(prow), k.st), "prior_lse_fwd_splits")
+            R, ldp = ns.value, B
+            pm = w.data_ptr(); ps = pm + 4 * prow.value * B; pn = ps + 4 * prow.value * B
         main.wait_stream(side)
-        # ---- ELBO assembly (+ batch means) in one launch
+        # ---- merge of the partial log-sum-exps (splits of this device, or the gathered shards) + ELBO assembly (+ batch
+        #      means) in ONE launch
         loss = torch.empty(B, **f32); KL = torch.empty(B, **f32)
         means = torch.empty(3, **f32) if average else None
         beta_dev = beta if torch.is_tensor(beta) else None
-        _lib.check(lib.evae_elbo_fwd(_vp(RE), _vp(logq), _vp(logp), _vp(beta_dev), 0.0 if beta_dev is not None else float(beta),
-                                     B, _vp(loss), _vp(KL), _vp(means), k.st), "elbo_fwd")
+        beta_host = 0.0 if beta_dev is not None else float(beta)
+        _lib.check(lib.evae_prior_elbo_fwd(_vp(pm), _vp(ps), _vp(pn), R, ldp, B, float(c_total), _vp(RE), _vp(logq),
+                                           _vp(beta_dev), beta_host, _vp(logp), _vp(lse), _vp(loss), _vp(KL), _vp(means),
+                                           k.st), "prior_elbo_fwd")
         ctx.set_materialize_grads(False)       # unused outputs (RE, KL) then arrive as None, not as zero-filled tensors
         ctx.k_dev = dev
         ctx.dims = (B, D, H, Z, Cl, Mp, ldd, beta, int(sharded))
@@ -272,6 +307,7 @@ class VaeExactLoss(torch.autograd.Function):
         centres = mean_all[:Cl]
         z_mean = mean_all[Cl:]
         off = 4 * Cl
+        prior_finish = None
         side.wait_stream(main)
         if sharded == 2:
             # data-parallel batches: the shard-side backward runs over the queries of all ranks (their lse and upstream
@@ -296,12 +332,19 @@ class VaeExactLoss(torch.autograd.Function):
             dzp = packed[:B * Z].view(B, Z); dlv = packed[B * Z:]
             nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cl, Z)
             w = k.ws("prior_bwd", nb)
-            _lib.check(lib.evae_prior_lse_bwd(_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp),
-                                              _vp(dzp), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), k.st), "prior_bwd")
-            if sharded == 1:
-                dist.all_reduce(packed, op=dist.ReduceOp.SUM)
-                if Cl > 0:
-                    dmean_all[:Cl].mul_(float(dist.get_world_size()))
+            pb_args = (_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp), _vp(dzp),
+                       _vp(dmean_all), _vp(dlv), _vp(w), w.numel())
+            if sharded == 1 or not (SCHED & 1):
+                _lib.check(lib.evae_prior_lse_bwd(*pb_args, k.st), "prior_bwd")
+                if sharded == 1:
+                    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+                    if Cl > 0:
+                        dmean_all[:Cl].mul_(float(dist.get_world_size()))
+            else:
+                # one device: the main stream only needs dcentres (phase 1); the reduction of the dz' / dlogvar partials
+                # (phase 2) is issued on the side stream, in front of its only consumer
+                _lib.check(lib.evae_prior_lse_bwd_phased(*pb_args, 1, k.st), "prior_bwd(1)")
+                prior_finish = lambda: _lib.check(lib.evae_prior_lse_bwd_phased(*pb_args, 2, kd.st), "prior_bwd(2)")
         dz_ready = torch.cuda.Event(); dz_ready.record()
         if Cl > 0:
             k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H)
@@ -319,6 +362,8 @@ class VaeExactLoss(torch.autograd.Function):
             kd.bwd_data(dp2, d2h, dp2.data_ptr() + 4 * H, d2g, B, H, 2 * H, H, D1, sd1, dp1, dp1.data_ptr() + 4 * H, 2 * H)
             kd.bwd_data(dp1, d1h, dp1.data_ptr() + 4 * H, d1g, B, H, 2 * H, Z, None, None, dz, None, Z)
             side.wait_event(dz_ready)
+            if prior_finish is not None:
+                prior_finish()
             # reparameterisation + log q (+ the prior's dz', + the Hardtanh of the log-variance head): one launch
             _lib.check(lib.evae_reparam_logq_bwd_hardtanh(_vp(z_mean), _vp(logvar), _vp(eps), _vp(z), _vp(dz), _vp(dzp), _vp(cKL),
                                                           _vp(lv_pre), -6.0, 2.0, B, Z, _vp(dmean_all.data_ptr() + off * Z),
@@ -344,10 +389,20 @@ class VaeExactLoss(torch.autograd.Function):
         leaves()
         main.wait_event(batch_rows_done)
         # ---- weight gradients of the two encoder layers over all C + B rows
+        #      (layer 2's finish launch runs on the side stream, beside layer 1's GEMM instead of in front of it)
         g_w2 = gslot("w2", 2 * H, H); g_b2 = gslot("b2", 2 * H)
-        k.bwd_weight(dq2, Mp, 2 * H, 2 * H, A1, None, H, H, g_w2, g_b2)
+        w2_args = (dq2, Mp, 2 * H, 2 * H, A1, None, H, H, g_w2, g_b2)
         g_w1 = gslot("w1", 2 * H, D); g_b1 = gslot("b1", 2 * H)
-        k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)
+        if SCHED & 2:
+            k.bwd_weight(*w2_args, phase=1, ws_name="wgrad2")
+            w2_done = torch.cuda.Event(); w2_done.record()
+            k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)
+            with torch.cuda.stream(side):
+                side.wait_event(w2_done)
+                k.bwd_weight(*w2_args, phase=2, ws_name="wgrad2", finish_on=kd)
+        else:
+            k.bwd_weight(*w2_args)
+            k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)
         main.wait_stream(side)
         ctx.bufs = None
         grads = (g_plv, g_wp, g_bp, g_w1[:H], g_b1[:H], g_w1[H:], g_b1[H:], g_w2[:H], g_b2[:H], g_w2[H:], g_b2[H:],

@@ -282,7 +282,7 @@ class GatedDenseFn(torch.autograd.Function):
         nb = lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
         ws = _workspace("fwd", nb, x.device)
         # bench.py's roofline probe (modular path): the row-gathered, un-split launch = encoder layer 1
-        probe = PROBE if (nb <= 256 and rows is not None) else None
+        probe = PROBE if (nb <= 256 and rows is not None and M >= 1024) else None
         reps = 4 if probe is not None else 1         # repeated (idempotent) so the event pair's own cost is amortised
         if probe is not None:
             ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)

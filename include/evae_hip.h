@@ -78,6 +78,21 @@ int evae_prior_merge(const float* max /* [R x B] */, const float* sumexp, const 
                      int R, int B, float c_total,
                      float* out_logprior /* [B] */, float* out_lse /* [B] or NULL */,
                      evae_stream_t stream);
+/* The same forward, but the per-split partials of the launch stay in the workspace un-merged: three planes of
+ * *plane_rows x B floats at ws, ws + plane_rows B, ws + 2 plane_rows B (max, sumexp, nmask), of which the first *nsplit
+ * rows are valid (both are host integers, fixed by (B, C, zdim)).  For callers that merge them together with something
+ * else -- evae_prior_elbo_fwd below.  zdim <= 64 only (larger latents run on the GEMM path and merge on the device). */
+int evae_prior_lse_fwd_splits(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+                              const int64_t* z_idx, const int64_t* c_idx, void* ws, size_t ws_bytes,
+                              int* nsplit, int* plane_rows, evae_stream_t stream);
+/* Tail of a training step's forward in ONE launch (utils/training.py:33 -> models/BaseModel.py:65-77,124-125): merge R
+ * partial rows (row stride ldp) per query -- the splits of evae_prior_lse_fwd_splits, or the all-gathered shard partials --,
+ *   logp_i = LSE_i - log(c_total - sum_r nmask_ri),  KL_i = logq_i - logp_i,  loss_i = beta KL_i - RE_i,
+ * and, when means != NULL, the batch means (loss, RE, KL).  beta from device memory when beta_dev != NULL. */
+int evae_prior_elbo_fwd(const float* pmax, const float* psum, const float* pnmask, int R, int ldp, int B, float c_total,
+                        const float* RE, const float* logq, const float* beta_dev, float beta_host,
+                        float* logp /* [B] */, float* lse /* [B] or NULL */, float* loss /* [B] */, float* KL /* [B] */,
+                        float* means /* [3] or NULL */, evae_stream_t stream);
 
 /* Backward of sum_i grad_out_i * logprior_i through the prior (what autograd derives from
  * BaseModel.py:98-128 + distributions.py:12-25), by recomputation from the saved row LSE:
@@ -92,6 +107,13 @@ int evae_prior_lse_bwd(const float* z, int B, const float* centres, int C, int z
                        float* dz /* [B x zdim] */, float* dcentres /* [C x zdim] */,
                        float* dlogvar /* [zdim] */,
                        void* ws, size_t ws_bytes, evae_stream_t stream);
+/* The same in two halves: phase 1 = everything up to and including dcentres (complete on return of the launch), phase 2 = the
+ * reduction of the per-split dz / dlogvar partials left in the workspace -> dz, dlogvar (a no-op on the paths that do all
+ * their work in phase 1).  Lets a caller continue with dcentres on one stream while dz is finished on another. */
+int evae_prior_lse_bwd_phased(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+                              const int64_t* z_idx, const int64_t* c_idx, const float* lse, const float* grad_out,
+                              float* dz, float* dcentres, float* dlogvar, void* ws, size_t ws_bytes, int phase,
+                              evae_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Distance + top-K.  Replaces pairwise_distance(z, sub_cache).topk(k, largest=False)
@@ -165,6 +187,12 @@ size_t evae_dense_bwd_weight_workspace_bytes(int M, int N, int K);
 int evae_dense_bwd_weight(const float* dy, int M, int N, int ldy, const float* x, const int64_t* rows,
                           int K, int ldx, float* dw /* [N x K] */, float* db /* [N] or NULL */,
                           int accumulate, void* ws, size_t ws_bytes, evae_stream_t stream);
+/* The same in two halves for callers that schedule by hand: phase 1 = the split-K GEMM into the workspace partials,
+ * phase 2 = the finish launch (fixed-order sum of the partial planes -> dw, db), possibly on another stream once phase 1
+ * has completed; the workspace must not be reused in between. */
+int evae_dense_bwd_weight_phased(const float* dy, int M, int N, int ldy, const float* x, const int64_t* rows,
+                                 int K, int ldx, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes,
+                                 int phase, evae_stream_t stream);
 /* dh, dg: [M x N] with row stride ldo (the two halves of one [M x 2N] buffer when ldo = 2N) */
 int evae_gated_dense_bwd_input(const float* dout, const float* out, const float* s, int M, int N,
                                float* dh, float* dg, int ldo, evae_stream_t stream);
