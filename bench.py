@@ -32,7 +32,10 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
+PEAK_HBM_GBS = 8000.0                # same guide: HBM3E
 B, C, N_TRAIN, D, H, Z = 100, 25000, 50000, 784, 300, 40
+# the MLP configurations that run through main(): model, exemplars, training-set size
+MLP_CONFIGS = {"c1": ("vae", 1000, 50000), "c2": ("vae", 25000, 50000), "c4": ("hvae_2level", 11500, 23000)}
 
 
 def parse():
@@ -40,7 +43,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--exemplars", type=int, default=C)
+    ap.add_argument("--config", default="c2", choices=("c1", "c2", "c3", "c4", "c5", "iwae", "topk"),
+                    help="BASELINE.json configuration (default c2 = the one the metric is quoted on): c1 vae C=1000; c2 vae "
+                         "C=25000; c3 convhvae_2level C=25000; c4 hvae_2level C=11500 (N=23000); c5 single_conv 3x64x64, z=256, "
+                         "approximate prior over 100 000 cached latents; iwae = the test log p(x) evaluator at c2 sizes; "
+                         "topk = the cache + top-K scan at c2 and c5 sizes.  Every config prints the same JSON line with its "
+                         "own roofline object.")
+    ap.add_argument("--exemplars", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--parallel", choices=("dp", "replica"), default="dp",
                     help="with --gpus N > 1: 'dp' = every rank trains on its own 100-image batch (global batch 100 N) "
@@ -57,11 +66,11 @@ def parse():
     return ap.parse_args()
 
 
-def model_args(device, n_exemplars, sharded, shard_batch=False):
+def model_args(device, n_exemplars, sharded, shard_batch=False, model_name="vae", n_train=N_TRAIN):
     from argparse import Namespace
     return Namespace(prior="exemplar_prior", input_type="binary", input_size=[1, 28, 28], hidden_size=H,
-                     z1_size=Z, z2_size=Z, model_name="vae", device=device, number_components=n_exemplars,
-                     training_set_size=N_TRAIN, approximate_prior=False, approximate_k=10, no_mask=False,
+                     z1_size=Z, z2_size=Z, model_name=model_name, device=device, number_components=n_exemplars,
+                     training_set_size=n_train, approximate_prior=False, approximate_k=10, no_mask=False,
                      no_attention=False, same_variational_var=False, use_logit=False, lambd=1e-4,
                      bottleneck=6, dataset_name="dynamic_mnist", continuous=False, batch_size=B,
                      dynamic_binarization=True, warmup=100, S=5000, shard_exemplars=sharded, shard_batch=shard_batch)
@@ -71,7 +80,7 @@ def gated_flops(M, K, N):
     return 2.0 * M * K * 2 * N
 
 
-def cpu_baseline(steps):
+def cpu_baseline(steps, C=C, N_TRAIN=N_TRAIN):
     """The oracle's restatement of the same training step on the host cores (numpy + its BLAS threads).  More BLAS
     threads are not faster on these hosts (64 threads: 170-180 images/s, 16 threads: 560-630 on the 2 x 64-core box), so
     a short calibration picks the thread count and `cores` reports the one used."""
@@ -123,6 +132,197 @@ def cpu_baseline(steps):
                       % (steps, B, C, N_TRAIN, threads, os.cpu_count(), note)}
 
 
+def pmc_traffic(name):
+    """HBM bytes per launch of a named kernel from the committed PMC passes (profiles/r02_pmc/<name>.json, written by
+    tools/profile_collect.py from `rocprofv3 --pmc` runs of the same launch): counters cannot be read from inside the
+    process, so the bench line carries the file's number and says where it came from."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc", name + ".json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path)).get("hbm_bytes_per_launch"), "file:profiles/r02_pmc/%s.json (rocprofv3 --pmc, not measured in this run)" % name
+        except Exception:
+            pass
+    return None, None
+
+
+def time_launches(fn, reps=4, pairs=12, warm=6):
+    """Mean duration (us) of one call of fn: `reps` back-to-back calls between one HIP event pair (amortises the pair's own
+    ~5 us), `pairs` pairs, after `warm` untimed calls (clock ramp)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(pairs):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    return 1e3 * sum(a.elapsed_time(b) for a, b in evs) / (pairs * reps)
+
+
+def line(metric, value, unit, a, dt, workload, roof, extra=None, world=1, launch="eager"):
+    out = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic", "config": {"workload": workload, "launch": launch}, "roofline": roof,
+           "cpu_baseline": None}
+    out.update(extra or {})
+    return out
+
+
+def other_config(a, dev, rank, world):
+    """c3 / c5 (the convolutional configurations), iwae (the test log p(x) evaluator), topk (cache + top-K): the same JSON
+    line as the headline, each with the roofline object of ITS dominant kernel.  Single GPU."""
+    assert world == 1, "--config %s runs on one GPU" % a.config
+    from argparse import Namespace
+    import golden_inputs as gi
+    from evae import ops
+    torch.manual_seed(14); torch.cuda.manual_seed(14)
+    if a.config in ("c3", "c5"):
+        from utils.utils import importing_model
+        from utils.optimizer import AdamNormGrad
+        from evae.graph import GraphedTrainStep
+        c5 = a.config == "c5"
+        n_train = 100000 if c5 else N_TRAIN
+        n_ex = a.exemplars if a.exemplars is not None else (100000 if c5 else C)
+        isz = [3, 64, 64] if c5 else [1, 28, 28]
+        args = Namespace(prior="exemplar_prior", input_type="continuous" if c5 else "binary", input_size=isz, hidden_size=H,
+                         z1_size=256 if c5 else Z, z2_size=Z, model_name="single_conv" if c5 else "convhvae_2level",
+                         device=str(dev), number_components=n_ex, training_set_size=n_train, approximate_prior=c5,
+                         approximate_k=10, no_mask=False, no_attention=False, same_variational_var=False, use_logit=False,
+                         lambd=1e-4, bottleneck=1, dataset_name="celeba" if c5 else "fashion_mnist", continuous=c5, batch_size=B,
+                         dynamic_binarization=False, warmup=100, S=5000, shard_exemplars=False, shard_batch=False)
+        model = importing_model(args)(args).to(dev)
+        opt = AdamNormGrad(model.parameters(), lr=5e-4)
+        Dn = isz[0] * isz[1] * isz[2]
+        if c5:       # 100 000 x 12 288 floats = 4.9 GB: generated on the device, handed to the model as its resident copy
+            data_dev = (torch.randint(0, 256, (n_train, Dn), device=dev, dtype=torch.int16).float() + 0.5) / 256
+            dataset = torch.utils.data.TensorDataset(data_dev, torch.arange(n_train).reshape(-1, 1), torch.zeros(n_train))
+        else:
+            data = torch.from_numpy(gi.binary_images(0, n_train))
+            dataset = torch.utils.data.TensorDataset(data, torch.arange(n_train).reshape(-1, 1), torch.zeros(n_train))
+        data_dev = model.resident_data(dataset)
+        idx_all = torch.arange(n_train, device=dev).reshape(-1, 1)
+        model.train()
+        cache = None
+        if c5:
+            with torch.no_grad():
+                cache = tuple(model.cache_z(dataset))
+        runner = None if (c5 or a.no_graph) else GraphedTrainStep(model, opt, dataset, B, False)
+
+        def step(i):
+            s_ = (i * B) % (n_train - B)
+            if runner is not None:
+                return runner(data_dev[s_:s_ + B], idx_all[s_:s_ + B], 0.5)
+            opt.zero_grad()
+            loss, _, _ = model.calculate_loss((data_dev[s_:s_ + B], idx_all[s_:s_ + B]), 0.5, average=True, cache=cache,
+                                              dataset=dataset)
+            loss.backward()
+            opt.step()
+        for i in range(a.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(a.warmup + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # the dominant kernel, timed with HIP events at the shape it has in the step
+        with torch.no_grad():
+            if c5:
+                nimg, ci, co, k_, hw = 1100, 96, 96, 3, 16      # residual-block convolution over batch + re-encoded exemplars
+                xx = torch.randn(nimg, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+                w_ = torch.randn(co, ci, k_, k_, device=dev) * 0.03; b_ = torch.zeros(co, device=dev)
+                us = time_launches(lambda: ops.conv2d(xx, w_, b_, 1, 1), reps=2)
+                flops = 2.0 * nimg * hw * hw * ci * k_ * k_ * co
+                kern = "channels-last conv 96 -> 96, 3x3, 16 x 16, %d images (evae_conv2d_cl_fwd: gemm_kernel<..., CV = 1>)" % nimg
+            else:
+                nimg, ci, co, k_, hw = n_ex, 32, 64, 5, 14       # gated 5x5 layer of q_z_layers over the exemplar images
+                xx = torch.randn(nimg, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+                wh = torch.randn(co, ci, k_, k_, device=dev) * 0.03; wg = torch.randn(co, ci, k_, k_, device=dev) * 0.03
+                b_ = torch.zeros(co, device=dev)
+                us = time_launches(lambda: ops.gated_conv2d(xx, wh, b_, wg, b_, 1, 2), reps=2)
+                flops = 2.0 * nimg * hw * hw * ci * k_ * k_ * 2 * co
+                kern = ("channels-last gated conv 32 -> 64, 5x5, 14 x 14, %d images (evae_conv2d_cl_fwd: both filter banks, gate in "
+                        "the epilogue)" % nimg)
+        tf = flops / us / 1e6
+        traffic, tsrc = pmc_traffic("conv_fwd_" + a.config)
+        roof = {"bound": "mfma", "kernel": kern, "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                "avg_launch_us": round(us, 2), "flops_per_launch": round(flops)}
+        wl = ("single_conv (fully_conv) + exemplar_prior, 3x64x64 continuous, z=256, approximate prior: top-10 over %d cached "
+              "latents, <= 1000 exemplars re-encoded per step, batch %d (BASELINE.json configs[4], one GPU)" % (n_ex, B)) if c5 else \
+             ("convhvae_2level + exemplar_prior, fashion_mnist-shaped binary 28x28, N=%d, batch %d, %d exemplars, exact prior "
+              "(BASELINE.json configs[2])" % (n_train, B, n_ex))
+        print(json.dumps(line("training images/sec", round(B * a.steps / dt, 1), "images/sec", a, dt, wl, roof,
+                              launch="eager" if runner is None or runner.graph is None else "hipGraph replay of the whole step")))
+        return
+    if a.config == "iwae":
+        from models.VAE import VAE
+        from utils.evaluation import calculate_likelihood
+        import contextlib, io
+        args = model_args(str(dev), C, sharded=False)
+        model = VAE(args).to(dev)
+        data = torch.from_numpy(gi.binary_images(0, N_TRAIN))
+        dataset = torch.utils.data.TensorDataset(data, torch.arange(N_TRAIN).reshape(-1, 1), torch.zeros(N_TRAIN))
+        nimg = a.iwae_images
+        test = torch.from_numpy(gi.binary_images(2, nimg))
+        loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(test, torch.zeros(nimg)), batch_size=100)
+        model.eval()
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            cz, clv = model.cache_z(dataset)
+            emb = (cz, clv, torch.arange(len(cz)))
+            calculate_likelihood(args, model, torch.utils.data.DataLoader(
+                torch.utils.data.TensorDataset(test[:4], torch.zeros(4)), batch_size=4), S=args.S, exemplars_embedding=emb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(max(1, a.steps // 50)):
+                ll = calculate_likelihood(args, model, loader, S=args.S, exemplars_embedding=emb)
+            torch.cuda.synchronize()
+            n_pass = max(1, a.steps // 50)
+            dt = time.perf_counter() - t0
+            # dominant kernel: the prior's forward for one evaluator pass (4 images x S samples against all N exemplars)
+            zq = cz[:1] + 0.3 * torch.randn(4 * args.S, Z, device=dev)
+            lv = clv[0].contiguous()
+            us = time_launches(lambda: ops.prior_lse_fwd(zq, cz, lv), reps=2)
+        flops = 2.0 * 4 * args.S * N_TRAIN * Z
+        tf = flops / us / 1e6
+        traffic, tsrc = pmc_traffic("prior_fwd_iwae")
+        roof = {"bound": "mfma", "kernel": "evae::prior_fwd_mfma_kernel<5, 1> (+ the split merge): 4 x %d importance samples x %d "
+                                           "exemplars x z=%d, distance on the matrix cores, online log-sum-exp" % (args.S, N_TRAIN, Z),
+                "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": traffic, "traffic_source": tsrc, "avg_launch_us": round(us, 2), "flops_per_launch": round(flops)}
+        a.steps = n_pass * nimg
+        print(json.dumps(line("IWAE test log p(x) images/sec", round(n_pass * nimg / dt, 2), "images/sec", a, dt,
+                              "utils.evaluation.calculate_likelihood: vae, S=%d importance samples per test image against all %d "
+                              "training exemplars (the test-log-p(x) half of BASELINE.json's metric), %d test images per pass"
+                              % (args.S, N_TRAIN, nimg), roof, extra={"neg_log_px": round(float(ll), 3)})))
+        return
+    # topk: models/BaseModel.py:263-264 (distance + topk over the candidate cache), utils/knn_on_latent.py:4-9
+    res = []
+    for tag, Bq, N, zd in (("c2", 100, 25000, 40), ("c5", 100, 100000, 256)):
+        z_np, c_np = gi.clustered_latents(3, Bq, N, zd)
+        q = torch.from_numpy(z_np).to(dev); cache = torch.from_numpy(c_np).to(dev)
+        us = time_launches(lambda: ops.pairdist_topk(q, cache, 10, want_val=False), reps=2)
+        res.append((tag, Bq, N, zd, us))
+    tag, Bq, N, zd, us = res[1]
+    bytes_ = 2.0 * 4 * N * zd
+    gbs = bytes_ / us / 1e3
+    traffic, tsrc = pmc_traffic("topk_c5")
+    roof = {"bound": "hbm", "kernel": "evae_pairdist_topk at config 5 (B=%d queries, N=%d cached latents, z=%d, k=10): screening GEMM "
+                                      "passes + exact re-ranking; algorithmic bytes = two streaming passes over the [N x z] cache" % (Bq, N, zd),
+            "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
+            "traffic_source": tsrc, "avg_launch_us": round(us, 2), "bytes_per_launch": round(bytes_),
+            "other_sizes": {r[0]: {"B": r[1], "N": r[2], "z": r[3], "us": round(r[4], 2),
+                                   "GB/s": round(2.0 * 4 * r[2] * r[3] / r[4] / 1e3, 1)} for r in res}}
+    a.steps = 1
+    print(json.dumps(line("top-K cache scan", round(Bq / (us * 1e-6), 1), "queries/sec", a, us * 1e-6,
+                          "evae_pairdist_topk: k=10 nearest cached latents per query, bit-exact indices (config 5 sizes; config 2 "
+                          "sizes in roofline.other_sizes)", roof)))
+
+
 def capture_probe():
     """Child process of a multi-GPU run: capture an all-reduce and an all-gather into a hipGraph, replay, check."""
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
@@ -172,7 +372,10 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    n_ex = a.exemplars
+    if a.config in ("c3", "c5", "iwae", "topk"):
+        return other_config(a, dev, rank, world)
+    model_name, c_default, n_train = MLP_CONFIGS[a.config]
+    n_ex = a.exemplars if a.exemplars is not None else c_default
 
     # Can this RCCL build capture collectives into a hipGraph (and replay them without hanging)?  A capture that fails
     # half-way cannot be recovered from in-process (the collective library's internal streams and torch's RNG state stay
@@ -200,22 +403,23 @@ def main():
     from utils.training import set_beta
 
     # synthetic dynamic_mnist-shaped training set: binary 28x28, N=50 000, seed 0
-    data = torch.from_numpy(gi.binary_images(0, N_TRAIN))
-    dataset = torch.utils.data.TensorDataset(data, torch.arange(N_TRAIN).reshape(-1, 1), torch.arange(N_TRAIN) % 10)
+    data = torch.from_numpy(gi.binary_images(0, n_train))
+    dataset = torch.utils.data.TensorDataset(data, torch.arange(n_train).reshape(-1, 1), torch.arange(n_train) % 10)
     dp = world > 1 and a.parallel == "dp"
-    args = model_args("cuda:%d" % local_rank, n_ex, sharded=world > 1, shard_batch=dp)
+    args = model_args("cuda:%d" % local_rank, n_ex, sharded=world > 1, shard_batch=dp, model_name=model_name, n_train=n_train)
     torch.manual_seed(14)                    # same weights and (CPU-generator) exemplar draws on every rank
     torch.cuda.manual_seed(14)
-    model = VAE(args).to(dev)
+    from utils.utils import importing_model
+    model = importing_model(args)(args).to(dev)
     if dp:
         torch.cuda.manual_seed(14 + rank)    # data-parallel batches: every rank its own eps / binarisation stream
     opt = AdamNormGrad(model.parameters(), lr=5e-4)
     data_dev = model.resident_data(dataset)  # one upload; exemplar gathers read HBM from here on
-    idx_all = torch.arange(N_TRAIN, device=dev).reshape(-1, 1)
-    idx_host = torch.arange(N_TRAIN).reshape(-1, 1)      # what a DataLoader over the training set hands out
+    idx_all = torch.arange(n_train, device=dev).reshape(-1, 1)
+    idx_host = torch.arange(n_train).reshape(-1, 1)      # what a DataLoader over the training set hands out
     beta = set_beta(args, 50)
     model.train()
-    nb = N_TRAIN // B
+    nb = n_train // B
     loss_acc = torch.zeros((), device=dev)
 
     def batch_start(i):                      # data-parallel: rank r takes the r-th batch of every group of `world`
@@ -298,24 +502,19 @@ def main():
     roof = None
     if durs_ms:
         achieved = sum(flops) / (sum(durs_ms) * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_gated_dense.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = pmc_traffic("gated_fwd_L1") if a.config == "c2" and n_ex == C else (None, None)
         roof = {"bound": "mfma",
                 "kernel": "evae::gemm_kernel<true, true, 1, true, 128, 8, 0, true> -- GatedDense forward of encoder layer 1 "
-                          "([C+B] gathered rows x 784 -> 2 x 300, gate fused; the row-gathered variant is a symbol of its own)",
+                          "(the C gathered exemplar rows x 784 -> 2 x 300, gate fused; the row-gathered variant is a symbol of its "
+                          "own; the 100 batch rows run as a thin launch of their own beside it)",
                 "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": nlaunch, "avg_launch_us": round(1e3 * sum(durs_ms) / nlaunch, 2),
                 "flops_per_launch": round(sum(flops) / nlaunch)}
 
     # second half of BASELINE.json's metric: test log p(x) (IWAE, S = 5000, all N_train exemplars as the prior)
     iwae = None
-    if world == 1 and a.iwae_images > 0:
+    if world == 1 and a.iwae_images > 0 and a.config == "c2":
         from utils.evaluation import calculate_likelihood
         test = torch.from_numpy(gi.binary_images(2, a.iwae_images))
         test_ds = torch.utils.data.TensorDataset(test, torch.zeros(len(test)))
@@ -334,7 +533,7 @@ def main():
                 torch.cuda.synchronize()
                 t_ll = time.perf_counter() - t1
         model.train()
-        iwae = {"neg_log_px": round(ll, 3), "images": a.iwae_images, "S": args.S, "exemplars": N_TRAIN,
+        iwae = {"neg_log_px": round(ll, 3), "images": a.iwae_images, "S": args.S, "exemplars": n_train,
                 "ms_per_image": round(1e3 * t_ll / a.iwae_images, 3),
                 "note": "utils.evaluation.calculate_likelihood on synthetic test images after the benchmark's training steps"}
 
@@ -345,8 +544,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
             "higher_is_better": True, "scaling": "strong" if (world > 1 and not dp) else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "vae + exemplar_prior, dynamic_mnist-shaped binary 28x28, N=%d, batch %d per GPU, "
-                                   "%d exemplars in total, exact prior (BASELINE.json configs[1])" % (N_TRAIN, B, n_ex),
+            "config": {"workload": "%s + exemplar_prior, %s-shaped binary 28x28, N=%d, batch %d per GPU, "
+                                   "%d exemplars in total, exact prior (BASELINE.json configs[%d])"
+                                   % (model_name, "omniglot" if a.config == "c4" else "dynamic_mnist", n_train, B, n_ex,
+                                      {"c1": 0, "c2": 1, "c4": 3}[a.config]),
                        "global_batch": gb, "exemplars": n_ex,
                        "parallelism": ("single GPU" if world == 1 else
                                        ("dp%d (own %d-image batch per rank) x exemplar-shard x%d, partial-LSE exchange over RCCL"
@@ -358,8 +559,8 @@ def main():
             "test_log_px": iwae,
             "cpu_baseline": None,
         }
-        if world == 1 and a.cpu_baseline_steps > 0:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_steps)
+        if world == 1 and a.cpu_baseline_steps > 0 and model_name == "vae":
+            out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_steps, n_ex, n_train)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
