@@ -1,0 +1,408 @@
+// First encoder layer on the uint8-resident image store (reference contract utils/load_data/base_load_data.py:39-40:
+// pixels are k/255, and the exemplar rows of models/BaseModel.py:247 are read un-binarised, i.e. grey).
+//
+// The store keeps a pixel as the byte k (value = k * x_scale, x_scale = 1/255): 4x less HBM than fp32 rows.  A byte is an
+// integer <= 255, hence EXACT in bf16 (8 significant bits), and an fp32 weight splits exactly into three bf16 terms
+// w = w0 + w1 + w2 (24 = 3 x 8 significant bits).  So  sum_k x_k w_k = x_scale * sum_k k (w0 + w1 + w2)  runs as three
+// bf16 products per element on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- every product k * w_j is exact in fp32
+// (16 significant bits), the rounding that is left is the fp32 accumulation, as in an fp32 GEMM -- at 16/3 times the rate
+// of the fp32 matrix pipe (v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate).  Not a reduced-precision path: tests
+// hold it against the fp64 oracle at the fp32 kernel's bar.
+//
+//   evae_dense_u8_prepare   weights [N x K] fp32 (h and g banks) -> the three bf16 terms, laid out as the LDS images of the
+//                           GEMM's B tiles (one 24 KB image per (column tile, K-slab): a block stages it with straight
+//                           16-byte copies)
+//   evae_gated_dense_fwd_u8 out = (x W_h^T + b_h) * sigmoid(x W_g^T + b_g) for M gathered rows of the byte store
+//
+// Kernel: block = 256 threads = 4 waves (2 x 2), block tile 128 rows x 64 gated outputs (= 128 MFMA columns [h | g]), wave
+// tile 64 x (32 h + 32 g): the gate meets its h in the same lane.  K-slab = 32 bytes of a row.  LDS rows are 64 B with the
+// four 16-byte slots XOR-swizzled by (row >> 2) & 3, so every ds_read_b128 fragment read and every staging write is
+// conflict-free without padding; two stages of (A 8 KB + B 24 KB) = 64 KB per block, two blocks per CU.
+#include "evae_common.h"
+
+namespace evae {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16u __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));    // native vector (HIP's uint4 struct does not always stay in registers)
+
+constexpr int U8_BM = 128, U8_BN = 64, U8_BK = 32, U8_NT = 256;
+constexpr int U8_A_BYTES = U8_BM * 64;                 // 128 rows x 32 bf16
+constexpr int U8_B_BYTES = 3 * 128 * 64;               // 3 terms x 128 columns x 32 bf16
+constexpr int U8_STAGE = U8_A_BYTES + U8_B_BYTES;      // 32 KB
+
+__device__ __forceinline__ unsigned short bf16_rn(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// B-tile images: image (tn, s) = [term p][column c = wc*64 + hg*32 + j][slot^swz][8 k], 24 KB each
+__global__ void u8_prepare_kernel(const float* __restrict__ wh, const float* __restrict__ wg, int N, int K, int nslab,
+                                  unsigned short* __restrict__ img) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one (tn, s, c, k) element, all three terms
+  const size_t per_img = (size_t)128 * 32;
+  const size_t tot = (size_t)gridDim.y * 0 + per_img;                   // (unused; grid is 1-D over all images)
+  (void)tot;
+  const size_t im = e / per_img;
+  const int rem = (int)(e - im * per_img);
+  const int c = rem >> 5, k = rem & 31;
+  const int tn = (int)(im / nslab), s = (int)(im - (size_t)tn * nslab);
+  const int wc = c >> 6, hg = (c >> 5) & 1, j = c & 31;
+  const int n = tn * U8_BN + wc * 32 + j, kk = s * U8_BK + k;
+  float w = 0.f;
+  if (n < N && kk < K) w = (hg ? wg : wh)[(size_t)n * K + kk];
+  const unsigned short w0 = bf16_rn(w);
+  const float r1 = w - bf16_f(w0);
+  const unsigned short w1 = bf16_rn(r1);
+  const float r2 = r1 - bf16_f(w1);
+  const unsigned short w2 = bf16_rn(r2);
+  const int slot = (k >> 3) ^ ((c >> 2) & 3);
+  unsigned short* o = img + im * (size_t)(3 * 128 * 32) + (size_t)c * 32 + slot * 8 + (k & 7);
+  o[0] = w0; o[128 * 32] = w1; o[2 * 128 * 32] = w2;
+}
+
+__device__ __forceinline__ u32x4 lds_read16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+// 16 bytes -> 16 bf16 (two 16-byte LDS slots).  A byte k as bf16 is the upper half of float(k): exact.
+__device__ __forceinline__ void u8x16_to_bf16(const u32x4 v, u32x4& lo, u32x4& hi) {
+  auto cvt4 = [](unsigned w, unsigned& p0, unsigned& p1) {
+    const unsigned f0 = __float_as_uint((float)(w & 0xFFu)), f1 = __float_as_uint((float)((w >> 8) & 0xFFu));
+    const unsigned f2 = __float_as_uint((float)((w >> 16) & 0xFFu)), f3 = __float_as_uint((float)(w >> 24));
+    p0 = (f0 >> 16) | (f1 & 0xFFFF0000u);
+    p1 = (f2 >> 16) | (f3 & 0xFFFF0000u);
+  };
+  unsigned a, b;
+  cvt4(v[0], a, b); lo[0] = a; lo[1] = b;
+  cvt4(v[1], a, b); lo[2] = a; lo[3] = b;
+  cvt4(v[2], a, b); hi[0] = a; hi[1] = b;
+  cvt4(v[3], a, b); hi[2] = a; hi[3] = b;
+}
+
+// GATED: the forward (columns = [h | g] pairs, gate epilogue).  !GATED: a plain product into split-K partial planes
+// part[z][M][N] -- the weight gradient runs through it with the roles swapped (rows = pixels of the gathered, transposed
+// byte rows; columns = the three-term split of dy; contraction over the batch rows).
+template <bool GATED>
+__global__ __launch_bounds__(U8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void u8_gemm_kernel(
+    const unsigned char* __restrict__ x, const int64_t* __restrict__ rows, int M, long long ldx, float x_scale,
+    const unsigned short* __restrict__ img, int nslab_total, int ksplit, const float* __restrict__ bh,
+    const float* __restrict__ bg, int N, float* __restrict__ out, float* __restrict__ save_s, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // XCD-aware bijective remap (as the fp32 GEMM): XCD x = id % 8 works on a contiguous run of tiles
+  const int ntiles = tiles_m * tiles_n;
+  int tile;
+  {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int qq = ntiles >> 3, rr = ntiles & 7;
+    tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * U8_BM, n0 = tn * (GATED ? U8_BN : 2 * U8_BN);
+  const int s_begin = blockIdx.y * ksplit;
+  const int s_end = (s_begin + ksplit < nslab_total) ? s_begin + ksplit : nslab_total;
+  const int nslab = s_end - s_begin;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
+
+  // staging roles: A -- thread = (row tid >> 1, 16-byte half tid & 1); B -- six 16-byte chunks of the 24 KB image
+  const int arow = tid >> 1, ahalf = tid & 1;
+  const int am = m0 + arow;
+  const size_t arow_g = rows ? (size_t)rows[am < M ? am : m0] : (size_t)(am < M ? am : m0);
+  const unsigned char* ap = x + arow_g * ldx + ahalf * 16 + (size_t)s_begin * U8_BK;
+  const unsigned short* bimg = img + ((size_t)tn * nslab_total + s_begin) * (3 * 128 * 32);
+  const int a_off0 = arow * 64 + (((2 * ahalf) ^ ((arow >> 2) & 3)) << 4);
+  const int a_off1 = arow * 64 + (((2 * ahalf + 1) ^ ((arow >> 2) & 3)) << 4);
+
+  f32x16u acc[2][2];        // [mt][h | g]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 ra, rb0, rb1, rb2, rb3, rb4, rb5;
+  auto load = [&](int s) {
+    ra = *reinterpret_cast<const u32x4*>(ap + (size_t)s * U8_BK);
+    const u32x4* bsrc = reinterpret_cast<const u32x4*>(bimg + (size_t)s * (3 * 128 * 32)) + tid;
+    rb0 = bsrc[0]; rb1 = bsrc[U8_NT]; rb2 = bsrc[2 * U8_NT]; rb3 = bsrc[3 * U8_NT]; rb4 = bsrc[4 * U8_NT]; rb5 = bsrc[5 * U8_NT];
+  };
+  auto store = [&](int buf) {
+    char* base = smem + buf * U8_STAGE;
+    u32x4 lo, hi;
+    u8x16_to_bf16(ra, lo, hi);
+    *reinterpret_cast<u32x4*>(base + a_off0) = lo;
+    *reinterpret_cast<u32x4*>(base + a_off1) = hi;
+    u32x4* bdst = reinterpret_cast<u32x4*>(base + U8_A_BYTES) + tid;
+    bdst[0] = rb0; bdst[U8_NT] = rb1; bdst[2 * U8_NT] = rb2; bdst[3 * U8_NT] = rb3; bdst[4 * U8_NT] = rb4; bdst[5 * U8_NT] = rb5;
+  };
+
+  if (nslab > 0) {
+    load(0);
+    store(0);
+  }
+  if (nslab > 1) load(1);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int cur = s & 1;
+    const char* As = smem + cur * U8_STAGE;
+    const char* Bs = As + U8_A_BYTES;
+    if (s + 1 < nslab) store(cur ^ 1);
+    if (s + 2 < nslab) load(s + 2);
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+      const int ks = 2 * step + lh;
+      u32x4 af[2], bf[2][3];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int r = wr * 64 + mt * 32 + l31;
+        af[mt] = lds_read16(As + r * 64 + ((ks ^ ((r >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int hg = 0; hg < 2; ++hg) {
+        const int c = wc * 64 + hg * 32 + l31;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[hg][p] = lds_read16(Bs + (p * 128 + c) * 64 + ((ks ^ ((c >> 2) & 3)) << 4));
+      }
+      // smallest terms first: the partial sums of w2 and w1 are added into the accumulator before the large w0 term
+#pragma unroll
+      for (int p = 2; p >= 0; --p)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int hg = 0; hg < 2; ++hg)
+            acc[mt][hg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt]),
+                                                                   __builtin_bit_cast(bf16x8, bf[hg][p]), acc[mt][hg], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: acc[mt][cb][r] <-> row m0 + wr*64 + mt*32 + (r&3) + 8*(r>>2) + 4*lh
+  if constexpr (GATED) {
+    const int n = n0 + wc * 32 + l31;           // output column; cb = 0: h, 1: g
+    if (n < N) {
+      const float vbh = bh ? bh[n] : 0.f, vbg = bg ? bg[n] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < M) {
+            const float h = fmaf(acc[mt][0][r], x_scale, vbh);
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * fmaf(acc[mt][1][r], x_scale, vbg)));
+            const size_t o = (size_t)m * N + n;
+            out[o] = h * sg;
+            if (save_s) save_s[o] = sg;
+          }
+        }
+    }
+  } else {
+    float* part = out + (size_t)blockIdx.y * M * N;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int n = n0 + wc * 64 + cb * 32 + l31;
+      if (n >= N) continue;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < M) part[(size_t)m * N + n] = acc[mt][cb][r];
+        }
+    }
+  }
+}
+
+// ---- weight-gradient pre-passes -----------------------------------------------------------------------------------------
+// xT [K + 1][ldt] bytes: xT[k][m] = x[rows[m]][k] for m < M (0 beyond), row K = ones (the bias-gradient row).
+// Block = 64 batch rows x 64 pixels through an LDS tile.
+__global__ __launch_bounds__(256) void u8_gather_transpose_kernel(const unsigned char* __restrict__ x,
+                                                                  const int64_t* __restrict__ rows, int M, int K,
+                                                                  long long ldx, unsigned char* __restrict__ xT,
+                                                                  long long ldt) {
+  __shared__ unsigned char tile[64][80];
+  const int m0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int t = threadIdx.x;
+  {
+    const int r = t >> 2, c = (t & 3) * 16;                 // batch row r, 16 pixels from k0 + c
+    const int m = m0 + r;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (m < M && k0 + c < K) {
+      const unsigned char* p = x + (size_t)(rows ? rows[m] : m) * ldx + k0 + c;
+      if (k0 + c + 16 <= K) v = *reinterpret_cast<const u32x4*>(p);
+      else { unsigned char b[16] = {0}; for (int i = 0; i < K - k0 - c; ++i) b[i] = p[i]; v = *reinterpret_cast<u32x4*>(b); }
+    }
+    *reinterpret_cast<u32x4*>(&tile[r][c]) = v;
+  }
+  __syncthreads();
+  {
+    const int k = t >> 2, mc = (t & 3) * 16;                // pixel k0 + k, 16 batch rows from m0 + mc
+    if (k0 + k < K && m0 + mc < ldt) {
+      unsigned char b[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) b[i] = tile[mc + i][k];
+      *reinterpret_cast<u32x4*>(xT + (size_t)(k0 + k) * ldt + m0 + mc) = *reinterpret_cast<u32x4*>(b);
+    }
+  }
+  if (blockIdx.y == 0 && t < 64 && m0 + t < ldt) xT[(size_t)K * ldt + m0 + t] = (m0 + t < M) ? (unsigned char)1 : (unsigned char)0;
+}
+
+// dy [M x N] fp32 (row stride ldy) -> the three bf16 terms of dy^T as the GEMM's B-tile images: image (tn, s) covers columns
+// n = tn*128 + c and contraction rows m = s*32 .. +31.  Truncation split: w0 = top 8 significant bits of w, w1 of w - w0,
+// w2 = the rest -- exact (24 = 3 x 8 bits), and cheaper than rounding.
+__global__ __launch_bounds__(256) void u8_prepare_dyT_kernel(const float* __restrict__ dy, int M, int N, long long ldy,
+                                                             int nslab, unsigned short* __restrict__ img) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[3 * 128 * 32];
+  const int tn = blockIdx.y, s = blockIdx.x;
+  const int t = threadIdx.x;
+  const int mi = t >> 3, m = s * 32 + mi;                   // one batch row, 16 columns
+  const int c0 = (t & 7) * 16;
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const int c = c0 + q4 * 4, n = tn * 128 + c;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+      if (n + 4 <= N && (ldy & 3) == 0) {
+        const float4 f = *reinterpret_cast<const float4*>(dy + (size_t)m * ldy + n);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+      } else {
+        for (int i = 0; i < 4; ++i) if (n + i < N) v[i] = dy[(size_t)m * ldy + n + i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned u0 = __float_as_uint(v[i]) & 0xFFFF0000u;
+      const float r1 = v[i] - __uint_as_float(u0);
+      const unsigned u1 = __float_as_uint(r1) & 0xFFFF0000u;
+      const float r2 = r1 - __uint_as_float(u1);
+      const unsigned u2 = __float_as_uint(r2);
+      const int cc = c + i;
+      const int o = cc * 32 + (((mi >> 3) ^ ((cc >> 2) & 3)) << 3) + (mi & 7);
+      lds[o] = (unsigned short)(u0 >> 16); lds[128 * 32 + o] = (unsigned short)(u1 >> 16); lds[2 * 128 * 32 + o] = (unsigned short)(u2 >> 16);
+    }
+  }
+  __syncthreads();
+  u32x4* dst = reinterpret_cast<u32x4*>(img + ((size_t)tn * nslab + s) * (3 * 128 * 32));
+  const u32x4* src = reinterpret_cast<const u32x4*>(lds);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dst[t + 256 * i] = src[t + 256 * i];
+}
+
+// dw[n][k] = x_scale * sum_z part[z][k][n] (k < K), db[n] = sum_z part[z][K][n]; fixed order
+__global__ void u8_wgrad_finish_kernel(const float* __restrict__ part, int nz, int K, int N, float x_scale,
+                                       float* __restrict__ dw, float* __restrict__ db) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)(K + 1) * N) return;
+  const int k = (int)(e / N), n = (int)(e - (size_t)k * N);
+  float a = 0.f;
+  for (int z = 0; z < nz; ++z) a += part[((size_t)z * (K + 1) + k) * N + n];
+  if (k < K) dw[(size_t)n * K + k] = a * x_scale;
+  else if (db) db[n] = a;
+}
+
+}  // namespace evae
+
+using namespace evae;
+
+static int u8_nslab(int K) { return cdiv(K, U8_BK); }
+
+extern "C" int evae_dense_u8_supported(int K, long long ldx) { return (K > 0 && (ldx % 16) == 0) ? 1 : 0; }
+
+extern "C" size_t evae_dense_u8_prepared_bytes(int N, int K) {
+  if (N <= 0 || K <= 0) return 256;
+  return align_up((size_t)cdiv(N, U8_BN) * u8_nslab(K) * (3 * 128 * 32) * sizeof(unsigned short), 256);
+}
+
+extern "C" int evae_dense_u8_prepare(const float* wh, const float* wg, int N, int K, void* prepared, size_t prepared_bytes,
+                                     evae_stream_t stream_) {
+  EVAE_REQUIRE(N > 0 && K > 0 && wh && wg && prepared, "dense_u8_prepare: bad arguments");
+  EVAE_REQUIRE(prepared_bytes >= evae_dense_u8_prepared_bytes(N, K), "dense_u8_prepare: buffer too small (%zu)", prepared_bytes);
+  const size_t elems = (size_t)cdiv(N, U8_BN) * u8_nslab(K) * 128 * 32;
+  u8_prepare_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, (hipStream_t)stream_>>>(wh, wg, N, K, u8_nslab(K),
+                                                                                      (unsigned short*)prepared);
+  return check_launch("u8_prepare_kernel");
+}
+
+extern "C" int evae_gated_dense_fwd_u8(const unsigned char* x, const int64_t* rows, int M, int K, long long ldx, float x_scale,
+                                       const void* prepared, const float* bh, const float* bg, int N, float* out,
+                                       float* save_s, evae_stream_t stream_) {
+  EVAE_REQUIRE(M >= 0 && K > 0 && N > 0, "gated_dense_fwd_u8: bad sizes M=%d K=%d N=%d", M, K, N);
+  if (M == 0) return EVAE_OK;
+  EVAE_REQUIRE(x && rows && prepared && out, "gated_dense_fwd_u8: null pointer");
+  EVAE_REQUIRE(evae_dense_u8_supported(K, ldx) && (((uintptr_t)x) & 15) == 0,
+               "gated_dense_fwd_u8: rows of the byte store must be 16-byte aligned (ldx %% 16 == 0)");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)u8_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * U8_STAGE);
+    attr = true;
+  }
+  const int tiles_m = cdiv(M, U8_BM), tiles_n = cdiv(N, U8_BN);
+  u8_gemm_kernel<true><<<tiles_m * tiles_n, U8_NT, 2 * U8_STAGE, (hipStream_t)stream_>>>(
+      x, rows, M, ldx, x_scale, (const unsigned short*)prepared, u8_nslab(K), u8_nslab(K), bh, bg, N, out, save_s, tiles_m, tiles_n);
+  return check_launch("u8_gemm_kernel<gated>");
+}
+
+// ---- weight gradient -------------------------------------------------------------------------------------------------------
+struct U8WgradLayout { size_t xT, img, part, total; long long ldt; int nslab, nz, ksplit, tiles_k, tiles_n; };
+static U8WgradLayout u8_wgrad_layout(int M, int N, int K) {
+  U8WgradLayout L;
+  L.nslab = cdiv(M, U8_BK);
+  L.ldt = (long long)L.nslab * U8_BK + 32;                  // 16-byte rows, slack for the last slab
+  L.tiles_k = cdiv(K + 1, U8_BM); L.tiles_n = cdiv(N, 2 * U8_BN);
+  // split the contraction so that about two rounds of 512 resident blocks are in flight
+  int nz = cdiv(1024, L.tiles_k * L.tiles_n);
+  if (nz > L.nslab) nz = L.nslab;
+  if (nz < 1) nz = 1;
+  L.ksplit = cdiv(L.nslab, nz);
+  L.nz = cdiv(L.nslab, L.ksplit);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
+  L.xT = take((size_t)(K + 1) * L.ldt + 64);
+  L.img = take((size_t)L.tiles_n * L.nslab * (3 * 128 * 32) * sizeof(unsigned short));
+  L.part = take((size_t)L.nz * (K + 1) * N * sizeof(float));
+  L.total = o + 256;
+  return L;
+}
+
+extern "C" size_t evae_dense_bwd_weight_u8_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 256;
+  return u8_wgrad_layout(M, N, K).total;
+}
+
+extern "C" int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long ldy, const unsigned char* x,
+                                        const int64_t* rows, int K, long long ldx, float x_scale, float* dw, float* db,
+                                        void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldy >= N && ldx >= K, "dense_bwd_weight_u8: bad sizes M=%d N=%d K=%d", M, N, K);
+  EVAE_REQUIRE(dw != nullptr, "dense_bwd_weight_u8: null dw");
+  if (M == 0) {
+    (void)hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), stream);
+    if (db) (void)hipMemsetAsync(db, 0, (size_t)N * sizeof(float), stream);
+    return check_launch("dense_bwd_weight_u8(empty)");
+  }
+  EVAE_REQUIRE(dy && x, "dense_bwd_weight_u8: null pointer");
+  EVAE_REQUIRE(evae_dense_u8_supported(K, ldx) && (((uintptr_t)x) & 15) == 0, "dense_bwd_weight_u8: unaligned byte store");
+  const U8WgradLayout L = u8_wgrad_layout(M, N, K);
+  if (ws == nullptr || ws_bytes < L.total) { set_error("dense_bwd_weight_u8: workspace too small (%zu)", ws_bytes); return EVAE_EWORKSPACE; }
+  unsigned char* xT = (unsigned char*)ws + L.xT;
+  unsigned short* img = (unsigned short*)((char*)ws + L.img);
+  float* part = (float*)((char*)ws + L.part);
+  // the padding columns m >= M of xT (up to the slab boundary + slack) must be zero: they meet dy rows that do not exist
+  u8_gather_transpose_kernel<<<dim3(cdiv((int)L.ldt, 64), cdiv(K, 64)), 256, 0, stream>>>(x, rows, M, K, ldx, xT, L.ldt);
+  u8_prepare_dyT_kernel<<<dim3(L.nslab, L.tiles_n), 256, 0, stream>>>(dy, M, N, ldy, L.nslab, img);
+  int rc = check_launch("u8 weight-gradient pre-passes");
+  if (rc) return rc;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)u8_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * U8_STAGE);
+    attr = true;
+  }
+  u8_gemm_kernel<false><<<dim3(L.tiles_k * L.tiles_n, L.nz), U8_NT, 2 * U8_STAGE, stream>>>(
+      xT, nullptr, K + 1, L.ldt, 1.0f, img, L.nslab, L.ksplit, nullptr, nullptr, N, part, nullptr, L.tiles_k, L.tiles_n);
+  rc = check_launch("u8_gemm_kernel<raw>");
+  if (rc) return rc;
+  const size_t n = (size_t)(K + 1) * N;
+  u8_wgrad_finish_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(part, L.nz, K, N, x_scale, dw, db);
+  return check_launch("u8_wgrad_finish_kernel");
+}

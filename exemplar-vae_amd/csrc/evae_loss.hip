@@ -276,6 +276,50 @@ __global__ __launch_bounds__(256) void batch_prologue_kernel(const float* __rest
     if (e0 + j < n) eps_out[e0 + j] = v[j];
 }
 
+// The same head of a step on the uint8-resident store (csrc/evae_dense_u8.hip): pixel = byte / x_div (IEEE division: the very
+// float the fp32 dataset holds), same generator streams as above; besides the fp32 batch it writes the batch's BYTES into the
+// store's staging rows (255 / 0 when binarised), which is where the first-layer kernels gather them from.
+__global__ __launch_bounds__(256) void batch_prologue_u8_kernel(const unsigned char* __restrict__ data, int64_t ldd,
+                                                                const int64_t* __restrict__ idx, int B, int D, int binarize,
+                                                                const int64_t* __restrict__ seed_ctr, float x_div,
+                                                                float* __restrict__ x_out, int64_t ldx,
+                                                                unsigned char* __restrict__ stage, int64_t lds_,
+                                                                float* __restrict__ eps_out, int zdim, int64_t nq_img) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t seed = (uint64_t)seed_ctr[0], step = (uint64_t)seed_ctr[1];
+  const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+  if (t < nq_img) {
+    const int64_t e0 = t * 4, n = (int64_t)B * D;
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (binarize) r = philox4x32(make_uint4((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)step, (uint32_t)(step >> 32) << 1), key);
+    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t e = e0 + j;
+      if (e >= n) break;
+      const int b = (int)(e / D), d = (int)(e - (int64_t)b * D);
+      const unsigned char q = data[idx[b] * ldd + d];
+      const float p = __fdiv_rn((float)q, x_div);
+      const bool one = u01(rr[j]) < p;
+      x_out[(int64_t)b * ldx + d] = binarize ? (one ? 1.0f : 0.0f) : p;
+      stage[(int64_t)b * lds_ + d] = binarize ? (one ? (unsigned char)255 : (unsigned char)0) : q;
+    }
+    return;
+  }
+  if (eps_out == nullptr) return;
+  const int64_t q = t - nq_img, e0 = q * 4, n = (int64_t)B * zdim;
+  if (e0 >= n) return;
+  const uint4 r = philox4x32(make_uint4((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)step, ((uint32_t)(step >> 32) << 1) | 1u), key);
+  const float r0 = sqrtf(-2.0f * logf(u01_open(r.x))), r1 = sqrtf(-2.0f * logf(u01_open(r.z)));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u01(r.y), &s0, &c0);
+  sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
+  const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (e0 + j < n) eps_out[e0 + j] = v[j];
+}
+
 // ELBO assembly on [B] rows in one launch: KL_i = logq_i - logp_i, loss_i = beta*KL_i - RE_i, and the three
 // batch means (models/BaseModel.py:71-75).  beta comes from device memory when the step is graph-captured.
 __global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* __restrict__ RE, const float* __restrict__ logq,
@@ -419,6 +463,20 @@ extern "C" int evae_batch_prologue(const float* data, int64_t ldd, const int64_t
   batch_prologue_kernel<<<(unsigned)cdiv(nq_img + nq_eps, (int64_t)256), 256, 0, (hipStream_t)s>>>(
       data, ldd, idx, B, D, binarize, seed_ctr, x_out, ldx, eps_out, zdim, nq_img);
   return check_launch("batch_prologue");
+}
+
+extern "C" int evae_batch_prologue_u8(const unsigned char* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
+                                      const int64_t* seed_ctr, float x_div, float* x_out, int64_t ldx, unsigned char* stage,
+                                      int64_t lds_, float* eps_out, int zdim, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && D > 0 && zdim >= 0 && ldd >= D && ldx >= D && lds_ >= D && x_div > 0.f, "batch_prologue_u8: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(data && idx && x_out && stage && seed_ctr, "batch_prologue_u8: null pointer");
+  EVAE_REQUIRE(eps_out == nullptr || zdim > 0, "batch_prologue_u8: eps_out needs zdim > 0");
+  const int64_t nq_img = ((int64_t)B * D + 3) / 4;
+  const int64_t nq_eps = eps_out ? ((int64_t)B * zdim + 3) / 4 : 0;
+  batch_prologue_u8_kernel<<<(unsigned)cdiv(nq_img + nq_eps, (int64_t)256), 256, 0, (hipStream_t)s>>>(
+      data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img);
+  return check_launch("batch_prologue_u8");
 }
 
 extern "C" int evae_bernoulli_sigmoid_bwd(const float* x, const float* mean, const float* dout, int B, int D,

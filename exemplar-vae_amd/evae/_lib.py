@@ -53,6 +53,12 @@ SIGNATURES = {
     "evae_dense_bwd_weight_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_dense_bwd_weight": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p, _z, _p]),
     "evae_dense_bwd_weight_phased": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p, _z, _i, _p]),
+    "evae_dense_u8_supported": (_i, [_i, C.c_longlong]),
+    "evae_dense_u8_prepared_bytes": (_z, [_i, _i]),
+    "evae_dense_u8_prepare": (_i, [_p, _p, _i, _i, _p, _z, _p]),
+    "evae_gated_dense_fwd_u8": (_i, [_p, _p, _i, _i, C.c_longlong, _f, _p, _p, _p, _i, _p, _p, _p]),
+    "evae_dense_bwd_weight_u8_workspace_bytes": (_z, [_i, _i, _i]),
+    "evae_dense_bwd_weight_u8": (_i, [_p, _i, _i, C.c_longlong, _p, _p, _i, C.c_longlong, _f, _p, _p, _p, _z, _p]),
     "evae_gated_dense_bwd_input": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "evae_act_bwd": (_i, [_p, _p, _z, _i, _f, _f, _p, _p]),
     "evae_conv2d_workspace_bytes": (_z, [_p, _i, _i]),
@@ -75,6 +81,7 @@ SIGNATURES = {
     "evae_step_stats_add": (_i, [_p, _p, _p, _p, _p, _p]),
     "evae_bernoulli_ll_fwd": (_i, [_p, _p, _i, _i, _p, _p]),
     "evae_batch_prologue": (_i, [_p, _l, _p, _i, _i, _i, _p, _p, _l, _p, _i, _p]),
+    "evae_batch_prologue_u8": (_i, [_p, _l, _p, _i, _i, _i, _p, _f, _p, _l, _p, _l, _p, _i, _p]),
     "evae_bernoulli_ll_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_bernoulli_sigmoid_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_log_logistic256_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),

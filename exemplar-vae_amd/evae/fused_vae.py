@@ -128,7 +128,7 @@ class VaeExactLoss(torch.autograd.Function):
     -> (loss [B], RE [B], KL [B])."""
 
     @staticmethod
-    def forward(ctx, x, x_idx, data_ext, n_data, ex_idx, c_total, eps, beta, sharded, no_mask, average, rows_ext, *params):
+    def forward(ctx, x, x_idx, data_ext, n_data, ex_idx, c_total, eps, beta, sharded, no_mask, average, rows_ext, staged, *params):
         (plv, wp, bp, w1h, b1h, w1g, b1g, w2h, b2h, w2g, b2g, wm, bm, wl, bl,
          d1h, e1h, d1g, e1g, d2h, e2h, d2g, e2g) = params
         dev = x.device
@@ -141,9 +141,14 @@ class VaeExactLoss(torch.autograd.Function):
         Z = wm.shape[0]
         f32 = dict(device=dev, dtype=torch.float32)
         x = x.contiguous()
-        # stage the batch behind the dataset; one gather list for exemplars + batch
+        # stage the batch behind the dataset; one gather list for exemplars + batch.  data_ext is the fp32 copy of the
+        # dataset or its uint8 store (models/BaseModel.py::resident_u8): then the first layer runs on the byte kernels
+        u8 = data_ext.dtype == torch.uint8
         stage = data_ext[n_data:n_data + B]
-        if x.data_ptr() != stage.data_ptr():      # the captured step (evae/graph.py) gathers the batch there itself
+        if u8:
+            if not staged:                        # the captured step (evae/graph.py) writes the bytes itself
+                stage.copy_(torch.round(x * 255.0))
+        elif x.data_ptr() != stage.data_ptr():    # the captured step gathers the batch there itself
             stage.copy_(x)
         # rows_ext: caller-kept [Cl + B] gather list whose head IS ex_idx and whose tail already names the staging rows
         if rows_ext is not None and rows_ext.numel() == Cl + B and rows_ext.data_ptr() == ex_idx.data_ptr():
@@ -174,12 +179,25 @@ class VaeExactLoss(torch.autograd.Function):
         xmean = torch.empty((B, D), **f32)
         RE = torch.empty(B, **f32)
         offb = 4 * Cl                                    # byte offset of the batch rows, per float of row width
+        if u8:
+            # both first-layer launches read the weights as three bf16 terms in tile order: split once, in front of the fork
+            prep = k.ws("u8prep", lib.evae_dense_u8_prepared_bytes(H, D))
+            _lib.check(lib.evae_dense_u8_prepare(_vp(w1h), _vp(w1g), H, D, _vp(prep), prep.numel(), k.st), "u8_prepare")
+            side.wait_stream(main)
+
+            def l1_fwd(kk, rows_ptr, M, o):
+                _lib.check(lib.evae_gated_dense_fwd_u8(_vp(data_ext), _vp(rows_ptr), M, D, ldd, 1.0 / 255.0, _vp(prep), _vp(b1h),
+                                                       _vp(b1g), H, _vp(A1.data_ptr() + o * H), _vp(s1.data_ptr() + o * H), kk.st),
+                           "gated_fwd_u8")
+        else:
+            def l1_fwd(kk, rows_ptr, M, o):
+                kk.gated_fwd(data_ext, rows_ptr, M, D, ldd, w1h, b1h, w1g, b1g, H, A1.data_ptr() + o * H, None,
+                             s1.data_ptr() + o * H)
         if Cl > 0:
-            k.gated_fwd(data_ext, rows, Cl, D, ldd, w1h, b1h, w1g, b1g, H, A1, None, s1)
+            l1_fwd(k, rows, Cl, 0)
         with torch.cuda.stream(side):
             lv_row = plv.detach().expand(Z).contiguous()   # the prior's log-variance row
-            kd.gated_fwd(data_ext, rows.data_ptr() + 8 * Cl, B, D, ldd, w1h, b1h, w1g, b1g, H,
-                         A1.data_ptr() + offb * H, None, s1.data_ptr() + offb * H)
+            l1_fwd(kd, rows.data_ptr() + 8 * Cl, B, offb)
             kd.gated_fwd(A1.data_ptr() + offb * H, None, B, H, H, w2h, b2h, w2g, b2g, H,
                          A2.data_ptr() + offb * H, None, s2.data_ptr() + offb * H)
             kd.linear_fwd(A2b, B, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, z_mean, None)
@@ -393,18 +411,26 @@ class VaeExactLoss(torch.autograd.Function):
         g_w2 = gslot("w2", 2 * H, H); g_b2 = gslot("b2", 2 * H)
         w2_args = (dq2, Mp, 2 * H, 2 * H, A1, None, H, H, g_w2, g_b2)
         g_w1 = gslot("w1", 2 * H, D); g_b1 = gslot("b1", 2 * H)
+        def w1_grad():
+            if data_ext.dtype == torch.uint8:
+                nb = lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D)
+                w = k.ws("wgrad_u8", nb)
+                _lib.check(lib.evae_dense_bwd_weight_u8(_vp(dq1), Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D, ldd, 1.0 / 255.0,
+                                                        _vp(g_w1), _vp(g_b1), _vp(w), w.numel(), k.st), "bwd_weight_u8")
+            else:
+                k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)
         if SCHED & 2:
             k.bwd_weight(*w2_args, phase=1, ws_name="wgrad2")
             w2_done = torch.cuda.Event(); w2_done.record()
-            k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)
+            w1_grad()
             with torch.cuda.stream(side):
                 side.wait_event(w2_done)
                 k.bwd_weight(*w2_args, phase=2, ws_name="wgrad2", finish_on=kd)
         else:
             k.bwd_weight(*w2_args)
-            k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)
+            w1_grad()
         main.wait_stream(side)
         ctx.bufs = None
         grads = (g_plv, g_wp, g_bp, g_w1[:H], g_b1[:H], g_w1[H:], g_b1[H:], g_w2[:H], g_b2[:H], g_w2[H:], g_b2[H:],
                  g_wm, g_bm, g_wl, g_bl, g_d1[:H], g_e1[:H], g_d1[H:], g_e1[H:], g_d2[:H], g_e2[:H], g_d2[H:], g_e2[H:])
-        return (None,) * 12 + grads
+        return (None,) * 13 + grads

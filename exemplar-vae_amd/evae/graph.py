@@ -36,7 +36,13 @@ class GraphedTrainStep:
         # changes between steps, so the captured graph needs no arange/cat
         self.lo, self.hi = shard.bounds(C) if model._sharded() else (0, C)
         Cl = self.hi - self.lo
-        self.data_ext, self.n_data = model.resident_data_ext(dataset, self.B)
+        # the fused `vae` step gathers its rows from the uint8 store when the data allow it (models/BaseModel.py::resident_u8)
+        u8 = model.resident_u8(dataset, self.B) if (a.model_name == 'vae' and model._fused_config()) else None
+        self.u8 = u8 is not None
+        if self.u8:
+            self.data_ext, self.n_data, self.x_div = u8
+        else:
+            self.data_ext, self.n_data = model.resident_data_ext(dataset, self.B)
         self.data_rows = self.data_ext[:self.n_data]
         self.stage_rows = self.data_ext[self.n_data:self.n_data + self.B]      # where the fused step wants the batch
         # Everything that varies between steps is ONE int64 control block in static device memory:
@@ -94,8 +100,13 @@ class GraphedTrainStep:
         if self.by_index:
             # the batch is rows `idx` of the HBM-resident dataset: gathered (and binarised) straight into the staging rows
             # of the fused step, no image bytes cross PCIe
-            x = self.stage_rows
-            ops.batch_prologue(self.data_rows, self.idx_flat, self.binarize, self.seed_ctr, x, self.eps_buf)
+            if self.u8:
+                x = self.x_in
+                ops.batch_prologue_u8(self.data_rows, self.idx_flat, self.binarize, self.seed_ctr, self.x_div, x,
+                                      self.stage_rows, self.eps_buf)
+            else:
+                x = self.stage_rows
+                ops.batch_prologue(self.data_rows, self.idx_flat, self.binarize, self.seed_ctr, x, self.eps_buf)
         else:
             x = torch.bernoulli(self.x_in) if self.binarize else self.x_in
         self.opt.zero_grad(set_to_none=True)      # backward then installs the fused node's gradient buffers
@@ -112,8 +123,10 @@ class GraphedTrainStep:
         if self.by_index is None:                 # once: are the loader's images the resident rows its indices name?
             ii = indices.reshape(-1).to(self.ctl.device)
             ok = bool(ii.numel() == self.B and int(ii.min()) >= 0 and int(ii.max()) < self.n_data)
-            self.by_index = ok and torch.equal(self.data_rows.index_select(0, ii),
-                                               data.reshape(self.B, -1).to(self.ctl.device, torch.float32))
+            rows_f = self.data_rows.index_select(0, ii)
+            if self.u8:
+                rows_f = rows_f.float() / self.x_div
+            self.by_index = ok and torch.equal(rows_f, data.reshape(self.B, -1).to(self.ctl.device, torch.float32))
         self._ev_up[k].synchronize()              # the upload issued two steps ago from this host buffer is done
         h = self._h_ctl[k]
         # same CPU-generator draw, with replacement, as the reference (models/BaseModel.py:245)
@@ -151,6 +164,7 @@ class GraphedTrainStep:
         try:
             self._refresh(data, indices, beta)
             self.model._eps_override = self.eps_buf if self.by_index else None
+            self.model._batch_staged = bool(self.by_index and self.u8)
             if self.graph is None:
                 # eager warm-up steps on a side stream (workspaces, attributes, RCCL channels), then capture
                 if self._calls < self.warmup_steps:
@@ -200,3 +214,4 @@ class GraphedTrainStep:
         finally:
             self.model._exemplar_indices_override = None
             self.model._eps_override = None
+            self.model._batch_staged = False

@@ -320,6 +320,52 @@ class GatedDenseFn(torch.autograd.Function):
                 (db[N:] if ctx.has_bias[1] else None))
 
 
+def u8_prepare(wh, wg, out=None):
+    """fp32 weight banks [N x K] -> the three-term bf16 tile images of the uint8 first-layer kernels"""
+    lib = _lib.load()
+    _need_cuda(wh, wg)
+    wh, wg = _f32(wh.detach()), _f32(wg.detach())
+    N, K = wh.shape
+    nb = lib.evae_dense_u8_prepared_bytes(N, K)
+    if out is None or out.numel() < nb:
+        out = torch.empty(nb, dtype=torch.uint8, device=wh.device)
+    _lib.check(lib.evae_dense_u8_prepare(_p(wh), _p(wg), N, K, _p(out), out.numel(), _stream()), "evae_dense_u8_prepare")
+    return out
+
+
+def gated_dense_fwd_u8(x_u8, rows, x_scale, prepared, bh, bg, N, out=None, save_s=None):
+    """forward only: out [M x N] for the M gathered rows of the byte store x_u8 [R x K]"""
+    lib = _lib.load()
+    _need_cuda(x_u8, rows, prepared)
+    assert x_u8.dtype == torch.uint8 and x_u8.dim() == 2 and x_u8.stride(1) == 1
+    rows = _i64(rows)
+    M, K = rows.numel(), x_u8.shape[1]
+    if out is None:
+        out = torch.empty((M, N), device=x_u8.device)
+    _lib.check(lib.evae_gated_dense_fwd_u8(_p(x_u8), _p(rows), M, K, x_u8.stride(0), float(x_scale), _p(prepared), _p(bh),
+                                           _p(bg), N, _p(out), _p(save_s), _stream()), "evae_gated_dense_fwd_u8")
+    return out
+
+
+def dense_bwd_weight_u8(dy, x_u8, rows, x_scale, dw=None, db=None, ws_name="wgrad_u8"):
+    """dw [N x K] = x_scale * dy^T x_u8[rows], db [N] = column sums of dy (dy [M x N], any row stride)"""
+    lib = _lib.load()
+    _need_cuda(dy, x_u8, rows)
+    assert dy.dtype == torch.float32 and dy.stride(1) == 1 and x_u8.dtype == torch.uint8
+    rows = _i64(rows)
+    M, N = dy.shape
+    K = x_u8.shape[1]
+    if dw is None:
+        dw = torch.empty((N, K), device=dy.device)
+    if db is None:
+        db = torch.empty(N, device=dy.device)
+    nb = lib.evae_dense_bwd_weight_u8_workspace_bytes(M, N, K)
+    ws = _workspace(ws_name, nb, dy.device)
+    _lib.check(lib.evae_dense_bwd_weight_u8(_p(dy), M, N, dy.stride(0), _p(x_u8), _p(rows), K, x_u8.stride(0), float(x_scale),
+                                            _p(dw), _p(db), _p(ws), ws.numel(), _stream()), "evae_dense_bwd_weight_u8")
+    return dw, db
+
+
 class LinearFn(torch.autograd.Function):
     """act(x W^T + b): torch.nn.Linear / utils/nn.py:29-41 NonLinear."""
 
@@ -705,6 +751,24 @@ def batch_prologue(data, idx, binarize, seed_ctr, x_out, eps_out=None):
         zd = eps_out.shape[1]
     _lib.check(lib.evae_batch_prologue(_p(data), data.stride(0), _p(idx), B, D, 1 if binarize else 0, _p(seed_ctr),
                                        _p(x_out), x_out.stride(0), _p(eps_out), zd, _stream()), "evae_batch_prologue")
+    return x_out, eps_out
+
+
+def batch_prologue_u8(data_u8, idx, binarize, seed_ctr, x_div, x_out, stage_u8, eps_out=None):
+    """batch_prologue on the uint8-resident store: x_out [B x D] fp32 and the batch's bytes into stage_u8 [B x D]."""
+    lib = _lib.load()
+    _need_cuda(data_u8, idx, seed_ctr, x_out, stage_u8)
+    B, D = x_out.shape
+    assert data_u8.dtype == torch.uint8 and stage_u8.dtype == torch.uint8 and data_u8.stride(1) == 1 and stage_u8.stride(1) == 1
+    assert x_out.dtype == torch.float32 and x_out.stride(1) == 1 and tuple(stage_u8.shape) == (B, D)
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == B and seed_ctr.dtype == torch.int64
+    zd = 0
+    if eps_out is not None:
+        assert eps_out.is_contiguous() and eps_out.dtype == torch.float32 and eps_out.shape[0] == B
+        zd = eps_out.shape[1]
+    _lib.check(lib.evae_batch_prologue_u8(_p(data_u8), data_u8.stride(0), _p(idx), B, D, 1 if binarize else 0, _p(seed_ctr),
+                                          float(x_div), _p(x_out), x_out.stride(0), _p(stage_u8), stage_u8.stride(0),
+                                          _p(eps_out), zd, _stream()), "evae_batch_prologue_u8")
     return x_out, eps_out
 
 

@@ -14,6 +14,7 @@ MI355X kernels of libevae_hip.so (evae.ops).  What changed underneath, not in be
 Out of scope: the vampprior branch and the image-generation helpers keep their
 names and run on plain torch ops."""
 import math
+import os
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -44,6 +45,7 @@ class BaseModel(nn.Module, ABC):
                                         activation=nn.Hardtanh(min_val=-4.5, max_val=0))
             self.decoder_logstd = torch.nn.Parameter(torch.tensor([0.], requires_grad=True))
         self._resident = {}          # id(dataset) -> device copy of dataset.tensors[0]
+        self._resident_u8 = {}       # id(dataset) -> uint8 device store (or None when the data are not k/255)
         self.create_model(args)
         self.he_initializer()
 
@@ -72,14 +74,17 @@ class BaseModel(nn.Module, ABC):
             return log_logistic_256(x, x_mean, x_logvar, dim=1)
         raise Exception('Wrong input type!')
 
+    def _fused_config(self):
+        """the part of _fused_path that only depends on the configuration"""
+        a = self.args
+        return (getattr(self, '_use_fused', True) and a.model_name == 'vae' and a.prior == 'exemplar_prior'
+                and a.input_type == 'binary' and a.approximate_prior is False and a.no_attention is False
+                and not getattr(a, 'same_variational_var', False))
+
     def _fused_path(self, x, x_indices, exemplars_embedding, dataset):
         """The one-node implementation (evae/fused_vae.py) covers the headline configuration: MLP `vae`,
         exemplar prior, exact (non-approximate) exemplar sets, binary inputs, training mode."""
-        a = self.args
-        return (getattr(self, '_use_fused', True) and a.model_name == 'vae' and a.prior == 'exemplar_prior'
-                and a.input_type == 'binary' and self.training and exemplars_embedding is None
-                and a.approximate_prior is False and a.no_attention is False
-                and not getattr(a, 'same_variational_var', False) and dataset is not None
+        return (self._fused_config() and self.training and exemplars_embedding is None and dataset is not None
                 and x_indices is not None and x.is_cuda and torch.is_grad_enabled())
 
     def _calculate_loss_fused(self, x, x_indices, beta, dataset, average):
@@ -97,7 +102,13 @@ class BaseModel(nn.Module, ABC):
         else:
             exemplars_indices = torch.randint(low=0, high=a.training_set_size, size=(C,))   # reference :245
             ex_local = self._indices_to_device(exemplars_indices[lo:hi])
-        data_ext, n_data = self.resident_data_ext(dataset, x.shape[0])
+        # the image store the exemplar rows are gathered from: bytes when the data are k/255 (4x less HBM, and the first
+        # layer then runs on the bf16 matrix pipe, csrc/evae_dense_u8.hip), fp32 rows otherwise
+        u8 = self.resident_u8(dataset, x.shape[0])
+        if u8 is not None:
+            data_ext, n_data = u8[0], u8[1]
+        else:
+            data_ext, n_data = self.resident_data_ext(dataset, x.shape[0])
         x2 = x.reshape(x.shape[0], -1).float()
         eps = getattr(self, '_eps_override', None)          # the captured step draws eps in its prologue launch
         if eps is None or tuple(eps.shape) != (x2.shape[0], a.z1_size):
@@ -105,9 +116,10 @@ class BaseModel(nn.Module, ABC):
         named = dict(self.named_parameters())
         params = [named[n] for n in fused_vae.PARAM_ORDER]
         beta = beta if torch.is_tensor(beta) else float(beta)
+        staged = bool(getattr(self, '_batch_staged', False))      # the captured step has put the batch into the staging rows
         return fused_vae.VaeExactLoss.apply(x2, x_indices.reshape(-1), data_ext, n_data, ex_local, C, eps,
                                             beta, (2 if getattr(a, 'shard_batch', False) else 1) if sharded else 0,
-                                            bool(a.no_mask), bool(average), rows_ext, *params)
+                                            bool(a.no_mask), bool(average), rows_ext, staged, *params)
 
     def calculate_loss(self, x, beta=1., average=False, exemplars_embedding=None, cache=None, dataset=None):
         x, x_indices = x
@@ -316,6 +328,38 @@ class BaseModel(nn.Module, ABC):
             buf[flat.shape[0]:].zero_()
             self._resident[key] = (src, buf)
         return self._resident[key][1], src.shape[0]
+
+    U8_DIV = 255.0
+
+    def resident_u8(self, dataset, batch_rows=0):
+        """(store [(N + staging) x D] uint8, N, 255.0) when every value of dataset.tensors[0] is k/255 exactly (what
+        reference utils/load_data/base_load_data.py:39-40 produces for binary / grey inputs) and rows are 16-byte multiples;
+        None otherwise (logit-transformed or (k + 0.5)/256 data stay fp32).  Checked and uploaded once per dataset object.
+        EVAE_U8_STORE=0 turns the byte store off."""
+        if os.environ.get("EVAE_U8_STORE", "1") == "0":
+            return None
+        src = dataset.tensors[0]
+        key = id(dataset)
+        n = src.shape[0]
+        need = max(self.STAGING_ROWS, int(batch_rows))
+        hit = self._resident_u8.get(key)
+        if hit is not None and hit[0] is src and (hit[1] is None or hit[1].shape[0] >= n + need):
+            return None if hit[1] is None else (hit[1], n, self.U8_DIV)
+        flat = src.reshape(n, -1)
+        D = flat.shape[1]
+        buf = None
+        if D % 16 == 0 and flat.dtype == torch.float32 and n > 0:
+            store = torch.zeros((n + need) * D + 64, dtype=torch.uint8, device=self.args.device)   # + slack behind the last row
+            buf = store[:(n + need) * D].view(n + need, D)
+            for s0 in range(0, n, 8192):
+                f = flat[s0:s0 + 8192].to(self.args.device)
+                q = torch.round(f * self.U8_DIV)
+                if not (bool((q >= 0).all()) and bool((q <= 255).all()) and torch.equal(q / self.U8_DIV, f)):
+                    buf = None
+                    break
+                buf[s0:s0 + f.shape[0]] = q.to(torch.uint8)
+        self._resident_u8[key] = (src, buf)
+        return None if buf is None else (buf, n, self.U8_DIV)
 
     def resident_data(self, dataset):
         """Device-resident fp32 view [N x D] of dataset.tensors[0]."""

@@ -193,6 +193,30 @@ int evae_dense_bwd_weight(const float* dy, int M, int N, int ldy, const float* x
 int evae_dense_bwd_weight_phased(const float* dy, int M, int N, int ldy, const float* x, const int64_t* rows,
                                  int K, int ldx, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes,
                                  int phase, evae_stream_t stream);
+/* ----------------------------------------------------------------------------------------------
+ * First encoder layer on a uint8-resident image store (the data side of models/BaseModel.py:243-248: the C exemplar images
+ * of a step are rows of dataset.tensors[0]; utils/load_data/base_load_data.py:39-40 makes those pixels k/255).  The store keeps
+ * the byte k (value = k * x_scale): a quarter of the HBM footprint and gather traffic of fp32 rows.  Bytes are exact in bf16 and
+ * an fp32 weight is exactly the sum of three bf16 terms, so the layer runs as three exact-product bf16 MFMAs per element with
+ * fp32 accumulation -- fp32-GEMM accuracy at 16/3 of the fp32 matrix rate (csrc/evae_dense_u8.hip).
+ *   evae_dense_u8_prepare    both weight banks [N x K] fp32 -> the bf16 terms in the kernel's tile order (once per weight update)
+ *   evae_gated_dense_fwd_u8  out[m] = (x[rows[m]] Wh^T * x_scale + bh) * sigmoid(x[rows[m]] Wg^T * x_scale + bg); save_s as above
+ * Rows of the store must start 16-byte aligned (ldx % 16 == 0) and the allocation must extend 32 bytes past the last row. */
+int evae_dense_u8_supported(int K, long long ldx);
+size_t evae_dense_u8_prepared_bytes(int N, int K);
+int evae_dense_u8_prepare(const float* wh, const float* wg, int N, int K, void* prepared, size_t prepared_bytes,
+                          evae_stream_t stream);
+int evae_gated_dense_fwd_u8(const unsigned char* x, const int64_t* rows, int M, int K, long long ldx, float x_scale,
+                            const void* prepared, const float* bh, const float* bg, int N,
+                            float* out /* [M x N] */, float* save_s /* [M x N] or NULL */, evae_stream_t stream);
+/* Weight gradient of that layer: dw [N x K] = x_scale * dy^T x(rows), db [N] = column sums of dy (dy [M x N], row stride ldy:
+ * the merged [dh | dg] buffer).  Same arithmetic: the byte rows are exact in bf16, dy is split exactly into three bf16 terms;
+ * pre-passes transpose the gathered bytes and lay dy^T out in tile order, the product runs split along the batch rows into
+ * workspace partials that a last launch sums in a fixed order. */
+size_t evae_dense_bwd_weight_u8_workspace_bytes(int M, int N, int K);
+int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long ldy, const unsigned char* x, const int64_t* rows,
+                             int K, long long ldx, float x_scale, float* dw /* [N x K] */, float* db /* [N] or NULL */,
+                             void* ws, size_t ws_bytes, evae_stream_t stream);
 /* dh, dg: [M x N] with row stride ldo (the two halves of one [M x 2N] buffer when ldo = 2N) */
 int evae_gated_dense_bwd_input(const float* dout, const float* out, const float* s, int M, int N,
                                float* dh, float* dg, int ldo, evae_stream_t stream);
@@ -290,6 +314,11 @@ int evae_step_stats_add(const float* loss, const float* re, const float* kl, flo
 int evae_batch_prologue(const float* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
                         const int64_t* seed_ctr /* device [2] */, float* x_out, int64_t ldx,
                         float* eps_out /* [B x zdim] or NULL */, int zdim, evae_stream_t stream);
+/* The same on a uint8-resident store (pixel = byte / x_div, e.g. 255): writes the fp32 batch x_out AND its bytes into `stage`
+ * (the staging rows of the store: 255 / 0 when binarised), where evae_gated_dense_fwd_u8 / evae_dense_bwd_weight_u8 gather them. */
+int evae_batch_prologue_u8(const unsigned char* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
+                           const int64_t* seed_ctr, float x_div, float* x_out, int64_t ldx, unsigned char* stage, int64_t lds,
+                           float* eps_out, int zdim, evae_stream_t stream);
 int evae_bernoulli_ll_fwd(const float* x, const float* mean, int B, int D, float* out,
                           evae_stream_t stream);
 int evae_bernoulli_ll_bwd(const float* x, const float* mean, const float* dout, int B, int D,

@@ -626,3 +626,46 @@ def test_workspace_growth_keeps_the_old_buffer_alive(ops):
     assert b.data_ptr() != pa and b.numel() >= 5000
     assert any(t.data_ptr() == pa for t in ops._ws_retired)
     assert ops._workspace("test_ws_growth", 4000, d).data_ptr() == b.data_ptr()
+
+
+@pytest.mark.parametrize("M,K,N,R", [(300, 784, 300, 1000), (25000, 784, 300, 50000), (130, 48, 7, 200), (1, 16, 64, 5),
+                                     (257, 560, 300, 300)])
+def test_gated_dense_forward_on_the_uint8_store(ops, M, K, N, R):
+    """First encoder layer on the byte store (grey pixels k/255): bytes are exact in bf16, fp32 weights split exactly into
+    three bf16 terms -- the bf16-MFMA kernel is held to the fp32 kernel's bar against the fp64 oracle."""
+    rs = np.random.RandomState(M + K)
+    q = (rs.randint(0, 256, (R, K)) * (rs.random_sample((R, K)) < 0.4)).astype(np.uint8)
+    rows = rs.randint(0, R, size=M).astype(np.int64)
+    wh = (rs.standard_normal((N, K)) * 0.1).astype(np.float32); wg = (rs.standard_normal((N, K)) * 0.1).astype(np.float32)
+    bh = (rs.standard_normal(N) * 0.1).astype(np.float32); bg = (rs.standard_normal(N) * 0.1).astype(np.float32)
+    store = torch.zeros(R * K + 64, dtype=torch.uint8, device="cuda")          # slack behind the last row
+    xs = store[:R * K].view(R, K); xs.copy_(torch.from_numpy(q))
+    prep = ops.u8_prepare(dev(wh), dev(wg))
+    s = torch.empty((M, N), device="cuda")
+    out = ops.gated_dense_fwd_u8(xs, dev(rows), 1.0 / 255.0, prep, dev(bh), dev(bg), N, save_s=s)
+    x64 = q[rows].astype(np.float64) / 255.0
+    h = x64 @ wh.astype(np.float64).T + bh; g = 1.0 / (1.0 + np.exp(-(x64 @ wg.astype(np.float64).T + bg)))
+    assert rel(out.cpu().numpy(), h * g) < 2e-6
+    assert rel(s.cpu().numpy(), g) < 2e-6
+    # and against the fp32 kernel on the fp32 copy of the same rows (the two are interchangeable)
+    ref32 = ops.gated_dense(dev((q.astype(np.float32) / 255.0)), dev(wh), dev(bh), dev(wg), dev(bg), rows=dev(rows))
+    assert rel(out.cpu().numpy(), ref32.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("M,K,N,R", [(300, 784, 600, 1000), (25100, 784, 600, 50000), (130, 48, 7, 200), (1, 16, 64, 5),
+                                     (257, 560, 600, 300)])
+def test_weight_gradient_on_the_uint8_store(ops, M, K, N, R):
+    """dW = dy^T x(rows) / 255 and db on the byte store (dy split exactly into three bf16 terms, bytes exact in bf16):
+    against the fp64 product and against the fp32 kernel on the fp32 copy of the same rows."""
+    rs = np.random.RandomState(M + K + 1)
+    q = (rs.randint(0, 256, (R, K)) * (rs.random_sample((R, K)) < 0.4)).astype(np.uint8)
+    rows = rs.randint(0, R, size=M).astype(np.int64)
+    dy = (rs.standard_normal((M, N)) * np.exp(rs.uniform(-6, 2, (M, 1)))).astype(np.float32)     # rows of very different scale
+    store = torch.zeros(R * K + 64, dtype=torch.uint8, device="cuda")
+    xs = store[:R * K].view(R, K); xs.copy_(torch.from_numpy(q))
+    dw, db = ops.dense_bwd_weight_u8(dev(dy), xs, dev(rows), 1.0 / 255.0)
+    ref = dy.astype(np.float64).T @ (q[rows].astype(np.float64) / 255.0)
+    assert rel(dw.cpu().numpy(), ref) < 2e-6
+    assert rel(db.cpu().numpy(), dy.astype(np.float64).sum(0)) < 2e-6
+    dw32, db32 = ops._bwd_weight(dev(dy), dev(q.astype(np.float32) / 255.0), dev(rows), K)
+    assert rel(dw.cpu().numpy(), dw32.cpu().numpy()) < 2e-6
