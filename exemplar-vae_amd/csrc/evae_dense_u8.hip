@@ -63,7 +63,7 @@ __global__ void u8_prepare_kernel(const float* __restrict__ wh, const float* __r
   o[0] = w0; o[128 * 32] = w1; o[2 * 128 * 32] = w2;
 }
 
-__device__ __forceinline__ u32x4 lds_read16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ bf16x8 lds_read16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
 // 16 bytes -> 16 bf16 (two 16-byte LDS slots).  A byte k as bf16 is the upper half of float(k): exact.
 __device__ __forceinline__ void u8x16_to_bf16(const u32x4 v, u32x4& lo, u32x4& hi) {
@@ -148,23 +148,28 @@ __global__ __launch_bounds__(U8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int cur = s & 1;
     const char* As = smem + cur * U8_STAGE;
     const char* Bs = As + U8_A_BYTES;
-    if (s + 1 < nslab) store(cur ^ 1);
-    if (s + 2 < nslab) load(s + 2);
+    // all sixteen fragment reads of the slab are issued before its first MFMA: the matrix pipe starts on the first k-step
+    // while the reads of the second are still in flight (two waves per SIMD cannot hide an LDS round trip per k-step)
+    bf16x8 af[2][2], bf[2][2][3];
 #pragma unroll
     for (int step = 0; step < 2; ++step) {
       const int ks = 2 * step + lh;
-      u32x4 af[2], bf[2][3];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int r = wr * 64 + mt * 32 + l31;
-        af[mt] = lds_read16(As + r * 64 + ((ks ^ ((r >> 2) & 3)) << 4));
+        af[step][mt] = lds_read16(As + r * 64 + ((ks ^ ((r >> 2) & 3)) << 4));
       }
 #pragma unroll
       for (int hg = 0; hg < 2; ++hg) {
         const int c = wc * 64 + hg * 32 + l31;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bf[hg][p] = lds_read16(Bs + (p * 128 + c) * 64 + ((ks ^ ((c >> 2) & 3)) << 4));
+        for (int p = 0; p < 3; ++p) bf[step][hg][p] = lds_read16(Bs + (p * 128 + c) * 64 + ((ks ^ ((c >> 2) & 3)) << 4));
       }
+    }
+    if (s + 1 < nslab) store(cur ^ 1);
+    if (s + 2 < nslab) load(s + 2);
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
       // smallest terms first: the partial sums of w2 and w1 are added into the accumulator before the large w0 term
 #pragma unroll
       for (int p = 2; p >= 0; --p)
@@ -172,8 +177,7 @@ __global__ __launch_bounds__(U8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int hg = 0; hg < 2; ++hg)
-            acc[mt][hg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt]),
-                                                                   __builtin_bit_cast(bf16x8, bf[hg][p]), acc[mt][hg], 0, 0, 0);
+            acc[mt][hg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[step][mt], bf[step][hg][p], acc[mt][hg], 0, 0, 0);
     }
     __syncthreads();
   }

@@ -81,21 +81,10 @@ class _K:
     def gated_fwd(self, x, rows, M, K, ldx, wh, bh, wg, bg, N, out, h, s):
         nb = self.lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
         w = self.ws("fwd", nb)
-        # bench.py's roofline probe times the dominant launch only: encoder layer 1 (row-gathered, no split-K)
-        probe = ops.PROBE if (nb <= 256 and rows is not None and M >= 1024) else None
-        reps = 1
-        if probe is not None:
-            # bench.py's roofline probe: the launch is repeated (same arguments, idempotent) between one event pair so
-            # that the ~5 us an event pair adds around a single launch does not inflate the kernel's duration
-            reps = 4
-            ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-            ev0.record()
-        for _ in range(reps):
-            _lib.check(self.lib.evae_gated_dense_fwd(_vp(x), _vp(rows), M, K, ldx, _vp(wh), _vp(bh), _vp(wg), _vp(bg), N,
-                                                     _vp(out), _vp(h), _vp(s), _vp(w), w.numel(), self.st), "gated_fwd")
-        if probe is not None:
-            ev1.record()
-            probe["gated_dense_fwd"].append((ev0, ev1, 2.0 * M * K * 2 * N * reps, reps))
+        ops.probed("gated_dense_fwd M=%d K=%d N=%d%s" % (M, K, N, " (row gather)" if rows is not None else ""), 2.0 * M * K * 2 * N,
+                   lambda: _lib.check(self.lib.evae_gated_dense_fwd(_vp(x), _vp(rows), M, K, ldx, _vp(wh), _vp(bh), _vp(wg), _vp(bg),
+                                                                    N, _vp(out), _vp(h), _vp(s), _vp(w), w.numel(), self.st),
+                                      "gated_fwd"))
 
     def linear_fwd(self, x, M, K, ldx, w_, b, N, act, lo, hi, y, pre):
         nb = self.lib.evae_dense_fwd_workspace_bytes(M, K, N, 0)
@@ -106,16 +95,21 @@ class _K:
     def bwd_data(self, dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, out, dg, ldo):
         nb = self.lib.evae_dense_bwd_data_workspace_bytes(M, N, K, 2 if dy2 is not None else 1)
         w = self.ws("dgrad", nb)
-        _lib.check(self.lib.evae_dense_bwd_data(_vp(dy1), _vp(w1), _vp(dy2), _vp(w2), M, N, ldy, K, _vp(out_prev),
-                                                _vp(s_prev), _vp(out), _vp(dg), ldo, _vp(w), w.numel(), self.st), "bwd_data")
+        ops.probed("dense_bwd_data M=%d N=%d%s K=%d%s" % (M, N, "+%d" % N if dy2 is not None else "", K,
+                                                          " (gate-backward epilogue)" if out_prev is not None else ""),
+                   2.0 * M * N * K * (2 if dy2 is not None else 1),
+                   lambda: _lib.check(self.lib.evae_dense_bwd_data(_vp(dy1), _vp(w1), _vp(dy2), _vp(w2), M, N, ldy, K, _vp(out_prev),
+                                                                   _vp(s_prev), _vp(out), _vp(dg), ldo, _vp(w), w.numel(), self.st),
+                                      "bwd_data"))
 
     def bwd_weight(self, dy, M, N, ldy, x, rows, K, ldx, dw, db, phase=0, ws_name="wgrad", finish_on=None):
         """phase 1 / 2: the split-K GEMM and its finish as separate calls (finish_on = the launcher whose stream runs it)"""
         nb = self.lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
         w = ops._workspace(ws_name + self.sfx, nb, self.dev)
         if phase == 0:
-            _lib.check(self.lib.evae_dense_bwd_weight(_vp(dy), M, N, ldy, _vp(x), _vp(rows), K, ldx, _vp(dw), _vp(db), 0,
-                                                      _vp(w), w.numel(), self.st), "bwd_weight")
+            ops.probed("dense_bwd_weight M=%d N=%d K=%d (+db, split-K GEMM + finish)" % (M, N, K), 2.0 * M * N * K,
+                       lambda: _lib.check(self.lib.evae_dense_bwd_weight(_vp(dy), M, N, ldy, _vp(x), _vp(rows), K, ldx, _vp(dw),
+                                                                         _vp(db), 0, _vp(w), w.numel(), self.st), "bwd_weight"))
         else:
             st = self.st if finish_on is None else finish_on.st
             _lib.check(self.lib.evae_dense_bwd_weight_phased(_vp(dy), M, N, ldy, _vp(x), _vp(rows), K, ldx, _vp(dw), _vp(db), 0,
@@ -186,9 +180,12 @@ class VaeExactLoss(torch.autograd.Function):
             side.wait_stream(main)
 
             def l1_fwd(kk, rows_ptr, M, o):
-                _lib.check(lib.evae_gated_dense_fwd_u8(_vp(data_ext), _vp(rows_ptr), M, D, ldd, 1.0 / 255.0, _vp(prep), _vp(b1h),
-                                                       _vp(b1g), H, _vp(A1.data_ptr() + o * H), _vp(s1.data_ptr() + o * H), kk.st),
-                           "gated_fwd_u8")
+                fl = 2.0 * M * D * 2 * H
+                ops.probed("gated_dense_fwd_u8 M=%d K=%d N=%d (uint8 rows, three bf16 terms)" % (M, D, H), fl,
+                           lambda: _lib.check(lib.evae_gated_dense_fwd_u8(_vp(data_ext), _vp(rows_ptr), M, D, ldd, 1.0 / 255.0, _vp(prep),
+                                                                          _vp(b1h), _vp(b1g), H, _vp(A1.data_ptr() + o * H),
+                                                                          _vp(s1.data_ptr() + o * H), kk.st), "gated_fwd_u8"),
+                           executed=3 * fl, pipe="bf16-mfma")
         else:
             def l1_fwd(kk, rows_ptr, M, o):
                 kk.gated_fwd(data_ext, rows_ptr, M, D, ldd, w1h, b1h, w1g, b1g, H, A1.data_ptr() + o * H, None,
@@ -415,8 +412,12 @@ class VaeExactLoss(torch.autograd.Function):
             if data_ext.dtype == torch.uint8:
                 nb = lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D)
                 w = k.ws("wgrad_u8", nb)
-                _lib.check(lib.evae_dense_bwd_weight_u8(_vp(dq1), Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D, ldd, 1.0 / 255.0,
-                                                        _vp(g_w1), _vp(g_b1), _vp(w), w.numel(), k.st), "bwd_weight_u8")
+                fl = 2.0 * Mp * 2 * H * D
+                ops.probed("dense_bwd_weight_u8 M=%d N=%d K=%d (uint8 rows, three bf16 terms; pre-passes + GEMM + finish)" % (Mp, 2 * H, D),
+                           fl, lambda: _lib.check(lib.evae_dense_bwd_weight_u8(_vp(dq1), Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D,
+                                                                               ldd, 1.0 / 255.0, _vp(g_w1), _vp(g_b1), _vp(w),
+                                                                               w.numel(), k.st), "bwd_weight_u8"),
+                           executed=3 * fl, pipe="bf16-mfma")
             else:
                 k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)
         if SCHED & 2:

@@ -14,7 +14,21 @@ TOPK_SQRT = 1
 
 _ws = {}
 _ws_retired = []   # replaced buffers stay allocated: a captured hipGraph (evae/graph.py) may hold their addresses
-PROBE = None   # bench.py sets {'gated_dense_fwd': []} to collect (start event, end event, flops, launches) tuples
+PROBE = None   # bench.py sets {"records": []}: (name, start event, end event, algorithmic flops, executed flops, pipe) per big launch
+
+
+def probed(name, flops, fn, executed=None, pipe="fp32-mfma", min_flops=2e9):
+    """Run fn(); while bench.py's roofline probe is on, bracket it with a HIP event pair on the current stream (launches
+    below min_flops are not worth an event pair).  `executed`: flops issued to the matrix pipe when they differ from the
+    algorithmic count (three bf16 terms per product on the uint8 path)."""
+    if PROBE is None or flops < min_flops:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    PROBE["records"].append((name, e0, e1, float(flops), float(executed if executed is not None else flops), pipe))
+    return r
 
 
 def _need_cuda(*ts):
@@ -281,19 +295,10 @@ class GatedDenseFn(torch.autograd.Function):
         s = torch.empty_like(out) if need_grad else None     # the backward needs out and s only (dg = dout*out*(1-s))
         nb = lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
         ws = _workspace("fwd", nb, x.device)
-        # bench.py's roofline probe (modular path): the row-gathered, un-split launch = encoder layer 1
-        probe = PROBE if (nb <= 256 and rows is not None and M >= 1024) else None
-        reps = 4 if probe is not None else 1         # repeated (idempotent) so the event pair's own cost is amortised
-        if probe is not None:
-            ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-            ev0.record()
-        for _ in range(reps):
-            _lib.check(lib.evae_gated_dense_fwd(_p(x), _p(rows), M, K, x.stride(0), _p(wh), _p(bh), _p(wg), _p(bg),
-                                                N, _p(out), None, _p(s), _p(ws), ws.numel(), _stream()),
-                       "evae_gated_dense_fwd")
-        if probe is not None:
-            ev1.record()
-            probe["gated_dense_fwd"].append((ev0, ev1, 2.0 * M * K * 2 * N * reps, reps))
+        probed("gated_dense_fwd M=%d K=%d N=%d%s" % (M, K, N, " (row gather)" if rows is not None else ""), 2.0 * M * K * 2 * N,
+               lambda: _lib.check(lib.evae_gated_dense_fwd(_p(x), _p(rows), M, K, x.stride(0), _p(wh), _p(bh), _p(wg), _p(bg),
+                                                           N, _p(out), None, _p(s), _p(ws), ws.numel(), _stream()),
+                                  "evae_gated_dense_fwd"))
         if need_grad:
             ctx.save_for_backward(x, rows, wh, wg, out, s)
         ctx.has_bias = (bh is not None, bg is not None)

@@ -2,6 +2,7 @@
 """Launch ONE kernel family a few times, at the shape it has in a benchmarked configuration, for `rocprofv3 --pmc` /
 `--kernel-trace --stats` passes (tools/profile_round2.sh).  usage: kernel_probe.py <which> [reps]
   fwd1        GatedDense forward, encoder layer 1 at c2: 25 000 gathered rows x 784 -> 2 x 300
+  u8fwd1 / u8wgrad1   the same layer on the uint8 store (three-term bf16 MFMA): forward / weight gradient
   fwd2        GatedDense forward, encoder layer 2: 25 000 x 300 -> 2 x 300
   dgrad2      data gradient of encoder layer 2 (dual pair, gate-backward epilogue)
   wgrad1      weight gradient of encoder layer 1 ([600 x 784] + db, gathered rows)
@@ -51,6 +52,21 @@ if which in ("fwd1", "fwd2", "dgrad2", "wgrad1", "wgrad2"):
             lib.evae_dense_bwd_weight(p(g["dpre"]), M, 2 * H, 2 * H, p(g["data"]), p(g["rows"]), D, D, p(g["dw"]), p(g["db"]), 0, p(ws), nws, st())
         else:
             lib.evae_dense_bwd_weight(p(g["dpre"]), M, 2 * H, 2 * H, p(g["a1"]), None, H, H, p(g["dw2"]), p(g["db"]), 0, p(ws), nws, st())
+elif which in ("u8fwd1", "u8wgrad1"):
+    R = N
+    q = (torch.randint(0, 256, (R, D), device=dev) * (torch.rand(R, D, device=dev) < 0.2)).to(torch.uint8)
+    store = torch.zeros(R * D + 64, dtype=torch.uint8, device=dev); xs = store[:R * D].view(R, D); xs.copy_(q)
+    rows = torch.randint(0, R, (M + 100,), device=dev)
+    wh = torch.randn(H, D, device=dev) * 0.05; wg = torch.randn(H, D, device=dev) * 0.05; b = torch.zeros(H, device=dev)
+    out = torch.empty(M, H, device=dev); s_ = torch.empty_like(out)
+    prep = ops.u8_prepare(wh, wg)
+    dy = torch.randn(M + 100, 2 * H, device=dev) * 0.01
+    dw = torch.empty(2 * H, D, device=dev); db = torch.empty(2 * H, device=dev)
+    for _ in range(reps):
+        if which == "u8fwd1":
+            ops.gated_dense_fwd_u8(xs, rows[:M], 1.0 / 255.0, prep, b, b, H, out=out, save_s=s_)
+        else:
+            ops.dense_bwd_weight_u8(dy, xs, rows, 1.0 / 255.0, dw=dw, db=db)
 elif which.startswith("prior"):
     S, Cn, zd = {"prior_iwae": (20000, 50000, 40), "prior_c5": (5000, 100000, 256), "prior_train": (100, 25000, 40)}[which]
     z = torch.randn(1, zd, device=dev) + 0.3 * torch.randn(S, zd, device=dev)
