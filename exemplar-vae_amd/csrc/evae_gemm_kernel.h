@@ -724,7 +724,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           acc[mt][nt][r] -= hc[mt][r];
-          if (masked && ((use[mt] >> r) & 1u) && ri[mt][r] == zi) { nm += 1.f; use[mt] &= ~(1u << r); }
+          if (masked && ((use[mt] >> r) & 1u) && (ri[mt][r] == zi || ri[mt][r] == (long long)EVAE_PRIOR_MASK_ALL)) { nm += 1.f; use[mt] &= ~(1u << r); }
           if ((use[mt] >> r) & 1u) tmax = fmaxf(tmax, acc[mt][nt][r]);
         }
       }
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
           if (m >= g.M) continue;
           const float d = fmaxf(g.e0[m] + zn - 2.0f * acc[mt][nt][r], 0.f);
           bool ok = nok;
-          if (masked) ok = ok && ((long long)g.pr_ridx[m] != zi);
+          if (masked) ok = ok && ((long long)g.pr_ridx[m] != zi) && ((long long)g.pr_ridx[m] != (long long)EVAE_PRIOR_MASK_ALL);
           g.out0[(size_t)m * g.ldo + n] = ok ? gq * fast_exp2(kq - d * (0.5f * kLog2e)) : 0.f;
         }
     }

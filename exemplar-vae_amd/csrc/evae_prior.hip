@@ -21,6 +21,10 @@
 
 namespace evae {
 
+// c_idx value that masks an exemplar slot for EVERY query (EVAE_PRIOR_MASK_ALL in evae_hip.h): a duplicate slot of the
+// fixed-size exemplar list of the approximate prior -- excluded from the sum and counted in nmask like a leave-one-out hit
+constexpr long long kMaskAll = EVAE_PRIOR_MASK_ALL;
+
 // inv_sigma[k] = exp(-log_var[k]/2) (zero-padded to nchunk*kc); returns -1/2 sum_k (lv_k + log 2pi)
 __device__ __forceinline__ float setup_sigma(float* __restrict__ inv_sigma, float* __restrict__ red,
                                              const float* __restrict__ log_var, int zdim, int zpad) {
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(NT) void prior_fwd_kernel(
       float cmin = INFINITY;
 #pragma unroll
       for (int j = 0; j < TE; ++j) {
-        bool hit = masked && (zi[i] == ci[j]) && evalid[j];
+        bool hit = masked && (zi[i] == ci[j] || ci[j] == kMaskAll) && evalid[j];
         ok[j] = evalid[j] && !hit;
         if (hit) nmask[i] += 1.f;
         if (ok[j]) cmin = fminf(cmin, acc[i][j]);
@@ -449,7 +453,8 @@ __global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
         v[r] = acc[nt][r] - hc[r];
         if (masked) {
           const int el = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (((use >> r) & 1u) && ci_s[pb * MFE + el] == zi[nt]) { nmask[nt] += 1.f; use &= ~(1u << r); }
+          const long long ce = ci_s[pb * MFE + el];
+          if (((use >> r) & 1u) && (ce == zi[nt] || ce == kMaskAll)) { nmask[nt] += 1.f; use &= ~(1u << r); }
         }
         if ((use >> r) & 1u) vmax = fmaxf(vmax, v[r]);
       }
@@ -740,7 +745,7 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
         int64_t cj = (masked && ev) ? c_idx[e] : -2;
 #pragma unroll
         for (int i = 0; i < TQ; ++i) {
-          bool ok = ev && !(masked && zi[i] == cj);
+          bool ok = ev && !(masked && (zi[i] == cj || cj == kMaskAll));
           float w = ok ? gi[i] * __expf(cst - 0.5f * acc[i][j] - li[i]) : 0.f;
           GW[(tq + 16 * i) * GWS + te + 16 * j] = w;
         }
@@ -978,7 +983,7 @@ __global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
         const int el = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const float d = slow ? acc[nt][r] : fmaxf(cn[el] + znq[nt] - 2.0f * acc[nt][r], 0.f);
         bool ok = e0 + el < C;
-        if (masked) ok = ok && (ci_s[el] != zi[nt]);
+        if (masked) ok = ok && (ci_s[el] != zi[nt]) && (ci_s[el] != kMaskAll);
         // exp(cst - d/2 - lse) = 2^((cst - lse) log2e - d log2e / 2)
         const float w = gq[nt] * fast_exp2((cst - lq[nt]) * kLog2e - d * kHalfLog2e);
         Ps[el * PP + ql] = ok ? w : 0.f;

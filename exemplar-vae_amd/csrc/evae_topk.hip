@@ -287,6 +287,33 @@ __global__ __launch_bounds__(NT) void topk_merge_kernel(const float* __restrict_
   }
 }
 
+// first occurrence of every position keeps its exemplar, repeats become masked slots (see evae_select_exemplars)
+__global__ __launch_bounds__(1024) void select_exemplars_kernel(const int64_t* __restrict__ pos, int n,
+                                                                const int64_t* __restrict__ cand_idx, int C,
+                                                                int64_t* __restrict__ sel_rows, int64_t* __restrict__ c_idx,
+                                                                int* __restrict__ n_unique) {
+  extern __shared__ int sp[];                 // the n positions
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) sp[i] = (int)pos[i];
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const int p = sp[i];
+    bool dup = false;
+    for (int j = 0; j < i; ++j) dup |= (sp[j] == p);
+    const int64_t row = (p >= 0 && p < C) ? cand_idx[p] : (int64_t)0;
+    sel_rows[i] = row;
+    c_idx[i] = dup ? (int64_t)EVAE_PRIOR_MASK_ALL : row;
+    mine += dup ? 0 : 1;
+  }
+  if (n_unique) {
+    atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) *n_unique = cnt;
+  }
+}
+
 static void topk_splits(int B, int N, int* nsplit, int* tps, int* nq) {
   int ntiles = cdiv(N, BE);
   *nq = cdiv(B, BQ);
@@ -365,6 +392,21 @@ extern "C" int evae_topk_merge(const float* val, const int64_t* idx, int R, int 
   EVAE_REQUIRE(val && idx && out_idx, "topk_merge: null pointer");
   topk_merge_kernel<<<cdiv(B, NT / 64), NT, 0, stream>>>(val, idx, R, B, k, 0, out_idx, out_val);
   return check_launch("topk_merge_kernel");
+}
+
+extern "C" int evae_select_exemplars(const int64_t* pos, int n, const int64_t* cand_idx, int C, int64_t* sel_rows,
+                                     int64_t* c_idx, int* n_unique, evae_stream_t stream_) {
+  EVAE_REQUIRE(n >= 0 && n <= 65536 && C >= 0, "select_exemplars: bad sizes n=%d C=%d", n, C);
+  if (n == 0) return EVAE_OK;
+  EVAE_REQUIRE(pos && cand_idx && sel_rows && c_idx, "select_exemplars: null pointer");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)select_exemplars_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 4 > 160 * 1024 ? 160 * 1024 : 65536 * 4);
+    attr = true;
+  }
+  EVAE_REQUIRE((size_t)n * 4 <= 150 * 1024, "select_exemplars: n=%d too large", n);
+  select_exemplars_kernel<<<1, 1024, (size_t)n * sizeof(int), (hipStream_t)stream_>>>(pos, n, cand_idx, C, sel_rows, c_idx, n_unique);
+  return check_launch("select_exemplars_kernel");
 }
 
 extern "C" int evae_pairwise_distance(const float* q, int B, const float* cache, int N, int zdim,

@@ -15,39 +15,99 @@
 
 namespace evae {
 
-// |row|^2 in fp32; rows of the cache also feed the global maximum (positive floats order like their bit patterns)
-__global__ void sq_norms_kernel(const float* __restrict__ x, int rows, int zdim, float* __restrict__ out,
-                                unsigned* __restrict__ max_bits) {
+// |row|^2 in fp32; rows of the cache also feed the global maximum (positive floats order like their bit patterns).
+// zdim % 4 == 0.  Wide rows (>= 128 floats): one wave per row, float4 per lane, four rows in flight per wave; narrow rows:
+// one thread per row (a 64-lane read then covers 64 short rows; every 128-byte line is used in full over the loop).
+// `zero_ints` (query launch only): per-query candidate counters to clear, `zero_bits` the running maximum -- the query launch
+// runs first, so the two housekeeping stores need no launch of their own.
+__global__ __launch_bounds__(256) void sq_norms_kernel(const float* __restrict__ x, int rows, int zdim, float* __restrict__ out,
+                                                       unsigned* __restrict__ max_bits, int* __restrict__ zero_ints, int nzero,
+                                                       unsigned* __restrict__ zero_bits) {
   const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (zero_ints)
+    for (int i = gtid; i < nzero; i += gridDim.x * blockDim.x) zero_ints[i] = 0;
+  if (zero_bits && gtid == 0) *zero_bits = 0u;
   float wmax = 0.f;
-  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {   // one wave per row
-    float s = 0.f;
-    for (int k = lane; k < zdim; k += 64) { const float v = x[(size_t)row * zdim + k]; s += v * v; }
-    s = wave_sum(s);
-    if (lane == 0) out[row] = s;
-    wmax = fmaxf(wmax, s);
+  const int cpr = zdim >> 2;
+  if (zdim >= 128) {
+    const int wpb = blockDim.x >> 6, nw = gridDim.x * wpb;
+    for (int row0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * 4; row0 < rows; row0 += nw * 4) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (row0 + r < rows)
+          for (int c = lane; c < cpr; c += 64) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (size_t)(row0 + r) * zdim + 4 * c);
+            s[r] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+          }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = wave_sum(s[r]);
+        if (lane == 0 && row0 + r < rows) out[row0 + r] = t;
+        wmax = fmaxf(wmax, t);
+      }
+    }
+  } else {
+    for (int row = gtid; row < rows; row += gridDim.x * blockDim.x) {
+      float t = 0.f;
+      for (int c = 0; c < cpr; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * zdim + 4 * c);
+        t += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+      out[row] = t;
+      wmax = fmaxf(wmax, t);
+    }
+    wmax = wave_max(wmax);
   }
-  if (max_bits && lane == 0) atomicMax(max_bits, __float_as_uint(wmax));   // one atomic per wave, not per row
+  // one atomic per BLOCK: same-address atomics from a whole device serialise at the memory side (16 384 of them cost
+  // more than streaming the 100 MB cache)
+  if (max_bits) {
+    __shared__ float wm[4];
+    if (lane == 0) wm[threadIdx.x >> 6] = wmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+      if (m > 0.f) atomicMax(max_bits, __float_as_uint(m));
+    }
+  }
 }
 
-// thr[n] = (k-th smallest of tmin[:, n]) + 2 gamma (qn[n] + cnmax); one wave per query
-__global__ void kth_threshold_kernel(const float* __restrict__ tmin, int ntiles, int ldt, int B, int k,
-                                     const float* __restrict__ qn, const unsigned* __restrict__ cnmax_bits, float gamma,
-                                     float* __restrict__ thr) {
+// thr[n] = (k-th smallest of tmin[:, n]) + 2 gamma (qn[n] + cnmax); one wave per query.  The tile minima of a query are
+// read once into registers (<= 16 per lane: up to 1024 tiles = 131 072 exemplars; longer caches fall back to re-reading)
+// and stepped through in ascending (value, tile) order k times.
+__global__ __launch_bounds__(256) void kth_threshold_kernel(const float* __restrict__ tmin, int ntiles, int ldt, int B, int k,
+                                                            const float* __restrict__ qn, const unsigned* __restrict__ cnmax_bits,
+                                                            float gamma, float* __restrict__ thr) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (n >= B) return;
-  // step through the (value, tile) pairs in ascending order k times
+  constexpr int TR = 16;
+  const bool in_regs = ntiles <= 64 * TR;
+  float v[TR];
+#pragma unroll
+  for (int j = 0; j < TR; ++j) {
+    const int t = lane + 64 * j;
+    v[j] = (in_regs && t < ntiles) ? tmin[(size_t)t * ldt + n] : INFINITY;
+  }
   float lastv = -INFINITY;
   int lastt = -1;
   for (int j = 0; j < k; ++j) {
     float bv = INFINITY;
     int bt = INT_MAX;
-    for (int t = lane; t < ntiles; t += 64) {
-      const float v = tmin[(size_t)t * ldt + n];
-      const bool after = (v > lastv) || (v == lastv && t > lastt);
-      if (after && ((v < bv) || (v == bv && t < bt))) { bv = v; bt = t; }
+    if (in_regs) {
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        const int t = lane + 64 * i;
+        const bool after = (v[i] > lastv) || (v[i] == lastv && t > lastt);
+        if (after && ((v[i] < bv) || (v[i] == bv && t < bt))) { bv = v[i]; bt = t; }
+      }
+    } else {
+      for (int t = lane; t < ntiles; t += 64) {
+        const float w = tmin[(size_t)t * ldt + n];
+        const bool after = (w > lastv) || (w == lastv && t > lastt);
+        if (after && ((w < bv) || (w == bv && t < bt))) { bv = w; bt = t; }
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -74,12 +134,19 @@ __global__ __launch_bounds__(256) void topk_exact_kernel(const float* __restrict
   float* vl = val + (size_t)n * ldc;
   const float* qr = q + (size_t)n * zdim;
   const bool do_sqrt = (flags & EVAE_TOPK_SQRT) != 0;
+  __shared__ __attribute__((aligned(16))) float qs[512];      // the query row (z_dim <= 512 on this path, multiple of 4)
+  for (int d = threadIdx.x; d < zdim; d += 256) qs[d] = qr[d];
+  __syncthreads();
   for (int c = threadIdx.x; c < M; c += 256) {
     const float* cr = cache + (size_t)cl[c] * zdim;
     double a = 0.0;
-    for (int d = 0; d < zdim; ++d) {       // same order and operations as dist_chunk_f64 (evae_topk.hip)
-      const double df = (double)qr[d] - (double)cr[d];
-      a = fma(df, df, a);
+    for (int d = 0; d < zdim; d += 4) {    // same order and operations as dist_chunk_f64 (evae_topk.hip), 16-byte loads
+      const float4 cv = *reinterpret_cast<const float4*>(cr + d);
+      const float4 qv = *reinterpret_cast<const float4*>(qs + d);
+      double df = (double)qv.x - (double)cv.x; a = fma(df, df, a);
+      df = (double)qv.y - (double)cv.y; a = fma(df, df, a);
+      df = (double)qv.z - (double)cv.z; a = fma(df, df, a);
+      df = (double)qv.w - (double)cv.w; a = fma(df, df, a);
     }
     float v = (float)a;
     if (do_sqrt) v = sqrtf(v);
@@ -134,7 +201,7 @@ static bool screen_applies(int B, int N, int zdim, int k) {
   if (off) return false;
   const int ntiles = cdiv(N, BM);
   return N >= 2048 && ntiles >= k && (zdim & 3) == 0 && (int64_t)B * N <= ((int64_t)1 << 26) &&
-         (int64_t)N * zdim < ((int64_t)1 << 29) - (1 << 22) && (int64_t)B * zdim < ((int64_t)1 << 29) - (1 << 22);
+         zdim <= 512 && (int64_t)N * zdim < ((int64_t)1 << 29) - (1 << 22) && (int64_t)B * zdim < ((int64_t)1 << 29) - (1 << 22);
 }
 static ScreenLayout screen_layout(int B, int N) {
   ScreenLayout L;
@@ -165,9 +232,10 @@ int topk_screen(const float* q, int B, const float* cache, int N, int zdim, int 
   float* cn = (float*)(w + L.cn); float* qn = (float*)(w + L.qn); unsigned* cnmax = (unsigned*)(w + L.cnmax);
   float* tmin = (float*)(w + L.tmin); float* thr = (float*)(w + L.thr); int* cnt = (int*)(w + L.cnt);
   int* cand = (int*)(w + L.cand); float* val = (float*)(w + L.val);
-  zero_ints_kernel<<<cdiv(L.ldt, 256), 256, 0, stream>>>(cnt, L.ldt, cnmax);
-  sq_norms_kernel<<<std::min(cdiv(N, 4), 2048), 256, 0, stream>>>(cache, N, zdim, cn, cnmax);
-  sq_norms_kernel<<<std::min(cdiv(B, 4), 2048), 256, 0, stream>>>(q, B, zdim, qn, nullptr);
+  // query norms first: that launch also clears the candidate counters and the running maximum of the cache norms
+  const int rpb = zdim >= 128 ? 16 : 256;       // rows one block covers per sweep
+  sq_norms_kernel<<<std::min(cdiv(B, rpb), 2048), 256, 0, stream>>>(q, B, zdim, qn, nullptr, cnt, L.ldt, cnmax);
+  sq_norms_kernel<<<std::min(cdiv(N, rpb), 1024), 256, 0, stream>>>(cache, N, zdim, cn, cnmax, nullptr, 0, nullptr);
   int rc = check_launch("sq_norms_kernel");
   if (rc) return rc;
   GemmArgs g = {};

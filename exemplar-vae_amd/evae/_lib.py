@@ -45,6 +45,7 @@ SIGNATURES = {
     "evae_pairdist_topk": (_i, [_p, _i, _p, _i, _i, _i, _u, _l, _p, _p, _p, _z, _p]),
     "evae_pairwise_distance": (_i, [_p, _i, _p, _i, _i, _p, _p]),
     "evae_topk_merge": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
+    "evae_select_exemplars": (_i, [_p, _i, _p, _i, _p, _p, _p, _p]),
     "evae_dense_fwd_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "evae_gated_dense_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _z, _p]),
     "evae_linear_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _f, _p, _p, _p, _z, _p]),

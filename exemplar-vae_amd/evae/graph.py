@@ -87,6 +87,7 @@ class GraphedTrainStep:
         self._one = torch.ones((), device=dev)
         self.out = torch.zeros(3, device=dev)       # (loss, -RE, KL) of the last step
         self.totals = torch.zeros(3, device=dev)    # running sums since reset_totals()
+        self.cache = None          # approximate prior: the latent cache in static buffers (set_cache)
         self.graph = None
         self.failed = False
         self.warmup_steps = warmup_steps
@@ -94,6 +95,17 @@ class GraphedTrainStep:
 
     def reset_totals(self):
         self.totals.zero_()
+
+    def set_cache(self, cache):
+        """Approximate prior (models/BaseModel.py:256-271): the per-epoch latent cache of utils.training.train_one_epoch.  The
+        captured launches read and refresh it in place, so it lives in static buffers that every epoch's cache is copied into."""
+        if self.cache is None or tuple(self.cache[0].shape) != tuple(cache[0].shape):
+            assert self.graph is None, "the latent cache changed shape after the step was captured"
+            self.cache = tuple(t.detach().clone() for t in cache)
+        else:
+            for dst, src in zip(self.cache, cache):
+                dst.copy_(src.detach())
+        return self.cache
 
     # the body that gets captured
     def _body(self):
@@ -110,7 +122,8 @@ class GraphedTrainStep:
         else:
             x = torch.bernoulli(self.x_in) if self.binarize else self.x_in
         self.opt.zero_grad(set_to_none=True)      # backward then installs the fused node's gradient buffers
-        loss, RE, KL = self.model.calculate_loss((x, self.idx_in), self.beta, average=True, dataset=self.dataset)
+        loss, RE, KL = self.model.calculate_loss((x, self.idx_in), self.beta, average=True, dataset=self.dataset,
+                                                 cache=self.cache)
         loss.backward(gradient=self._one)
         self.opt.step(_captured=True)
         ops.step_stats_add(loss.detach(), RE.detach(), KL.detach(), self.out, self.totals)

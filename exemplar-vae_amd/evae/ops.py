@@ -216,6 +216,24 @@ class PairwiseDistance(torch.autograd.Function):
         return dq, dc
 
 
+PRIOR_MASK_ALL = -3      # EVAE_PRIOR_MASK_ALL: a c_idx entry that masks its exemplar slot for every query
+
+
+def select_exemplars(pos, cand_idx):
+    """Static-shape form of `unique` + gather (models/BaseModel.py:265-266): pos [n] top-k positions into cand_idx [C].
+    -> (sel_rows [n] dataset rows of every slot, c_idx [n]: the row for the first slot naming a position, PRIOR_MASK_ALL
+    for its repeats)."""
+    lib = _lib.load()
+    _need_cuda(pos, cand_idx)
+    pos, cand_idx = _i64(pos), _i64(cand_idx)
+    n = pos.numel()
+    sel = torch.empty(n, dtype=torch.int64, device=pos.device)
+    cidx = torch.empty(n, dtype=torch.int64, device=pos.device)
+    _lib.check(lib.evae_select_exemplars(_p(pos), n, _p(cand_idx), cand_idx.numel(), _p(sel), _p(cidx), None, _stream()),
+               "evae_select_exemplars")
+    return sel, cidx
+
+
 def topk_merge(val, idx):
     """[R x B x k] candidate lists -> global ([B x k] idx, [B x k] val)."""
     lib = _lib.load()

@@ -176,7 +176,8 @@ class BaseModel(nn.Module, ABC):
             prob, _ = log_normal_diag_vectorized(z, centers, lv_row.unsqueeze(0))
             denominator = torch.full((len(z),), float(len(centers)), device=z.device)
             if masked:
-                mask = z_indices.reshape(-1, 1) == center_indices.to(z.device).reshape(1, -1)
+                ci = center_indices.to(z.device).reshape(1, -1)
+                mask = (z_indices.reshape(-1, 1) == ci) | (ci == ops.PRIOR_MASK_ALL)
                 prob = prob.masked_fill(mask, float('-inf'))
                 denominator = denominator - mask.sum(dim=1)
             return prob - torch.log(denominator).unsqueeze(1)
@@ -417,12 +418,22 @@ class BaseModel(nn.Module, ABC):
 
     def get_approximate_nearest_exemplars(self, z, cache, dataset):
         """kNN-pruned exemplar set (reference :256-271): candidates drawn with replacement, the batch's own
-        cache rows refreshed, top-k per batch row, union re-encoded with gradient, cache rows refreshed."""
-        exemplars_indices = self._indices_to_device(torch.randint(low=0, high=self.args.training_set_size,
-                                                                  size=(self.args.number_components,)))
+        cache rows refreshed, top-k per batch row, union re-encoded with gradient, cache rows refreshed.
+
+        On one device with the leave-one-out mask on, the union is kept in a FIXED list of B * k slots instead of the
+        data-dependent `unique`: every slot is re-encoded, the repeats of a position carry c_idx = PRIOR_MASK_ALL, which the
+        prior kernels exclude from the mixture and count like leave-one-out hits -- so the denominator is #unique - #hits as
+        in the reference, while every shape is static and the whole step can be captured into a hipGraph."""
+        override = getattr(self, '_exemplar_indices_override', None)
+        if isinstance(override, tuple):          # captured step: the candidate draw already sits in a static device buffer
+            exemplars_indices = override[0][:override[1]]
+        else:
+            exemplars_indices = self._indices_to_device(torch.randint(low=0, high=self.args.training_set_size,
+                                                                      size=(self.args.number_components,)))
         z, _, indices = z
         cached_z, cached_log_variance = cache
         cached_z[indices.reshape(-1)] = z.detach() if not cached_z.requires_grad else z
+        data = self.resident_data(dataset)
         if self._sharded():
             # the candidate list is split over the ranks: local top-k over this rank's slice, one all-gather of the
             # R x k (value, candidate position) lists per row, merge -- the exact global top-k on every rank (SURVEY 8e)
@@ -432,9 +443,13 @@ class BaseModel(nn.Module, ABC):
         else:
             sub_cache = cached_z[exemplars_indices, :]
             nearest_indices, _ = ops.pairdist_topk(z.detach(), sub_cache.detach(), self.args.approximate_k, want_val=False)
+            if self.args.no_mask is False:
+                sel_rows, c_idx = ops.select_exemplars(nearest_indices.view(-1), exemplars_indices)
+                exemplars_z, log_variance = self.q_z(data, prior=True, rows=sel_rows)
+                cached_z[sel_rows] = exemplars_z.detach() if not cached_z.requires_grad else exemplars_z
+                return (exemplars_z, log_variance, c_idx)
         nearest_indices = torch.unique(nearest_indices.view(-1))
         exemplars_indices = exemplars_indices[nearest_indices].view(-1)
-        data = self.resident_data(dataset)
         exemplars_z, log_variance = self.q_z(data, prior=True, rows=exemplars_indices)
         cached_z[exemplars_indices] = exemplars_z.detach() if not cached_z.requires_grad else exemplars_z
         return (exemplars_z, log_variance, exemplars_indices)

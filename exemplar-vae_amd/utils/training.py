@@ -27,6 +27,8 @@ def train_one_epoch(epoch, args, train_loader, model, optimizer):
     graphed = _graphed_step(args, model, optimizer, train_loader)
     if graphed is not None:
         graphed.reset_totals()
+        if cache is not None:
+            cache = graphed.set_cache(cache)      # the captured launches refresh the cache in place, in static buffers
     for data, indices, target in train_loader:
         if graphed is not None and len(data) == graphed.B:
             graphed(data, indices, beta)     # one hipGraph launch per step; sums accumulate in graphed.totals
@@ -55,9 +57,12 @@ def _graphed_step(args, model, optimizer, train_loader):
     if not getattr(args, 'use_hip_graph', True) or not str(args.device).startswith('cuda'):
         return None
     a = model.args
-    # capturable: exact exemplar prior (the approximate prior re-selects exemplars on the host every step); the `vae`
-    # model runs the one-node fused step inside the graph, every other architecture its modular autograd path
-    ok = a.prior == 'exemplar_prior' and a.approximate_prior is False
+    # capturable: the exact exemplar prior, and the approximate (cache + top-k) one on a single device with the leave-one-out
+    # mask on -- its exemplar union lives in a fixed list of B * k slots with masked repeats instead of a data-dependent
+    # `unique` (models/BaseModel.py::get_approximate_nearest_exemplars).  The `vae` model runs the one-node fused step inside
+    # the graph (exact prior), every other case its modular autograd path
+    ok = a.prior == 'exemplar_prior' and (a.approximate_prior is False or
+                                          (a.no_mask is False and not model._sharded()))
     if not ok:
         return None
     # the runner keeps the optimizer and the dataset alive, so their ids cannot be recycled while it is cached

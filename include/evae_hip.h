@@ -67,6 +67,10 @@ const char* evae_last_error(void);
  */
 /* limit < 0 restores the default; 0 sends every tile through the direct-difference path (tests).  Process-wide. */
 int evae_prior_set_norm_limit(float limit);
+/* c_idx value that masks an exemplar slot for EVERY query (excluded from the sum, counted in nmask): the duplicate slots of
+ * the fixed-size exemplar list of the approximate prior (evae_select_exemplars below), so that the denominator stays
+ * #unique - #leave-one-out hits as in models/BaseModel.py:265-270 while every shape is static. */
+#define EVAE_PRIOR_MASK_ALL (-3)
 size_t evae_prior_lse_fwd_workspace_bytes(int B, int C, int zdim);
 int evae_prior_lse_fwd(const float* z, int B, const float* centres, int C, int zdim,
                        const float* log_var /* [zdim] */,
@@ -138,6 +142,13 @@ int evae_pairwise_distance(const float* q, int B, const float* cache, int N, int
 int evae_topk_merge(const float* val /* [R x B x k] */, const int64_t* idx, int R, int B, int k,
                     int64_t* out_idx /* [B x k] */, float* out_val /* [B x k] or NULL */,
                     evae_stream_t stream);
+/* The exemplar selection of the approximate prior with static shapes (reference models/BaseModel.py:265-266:
+ * `unique(nearest_indices)` then `exemplars_indices[nearest]`): pos [n] = the flattened top-k positions (0 <= pos < C) into the
+ * candidate list cand_idx [C] of dataset rows.  sel_rows[i] = cand_idx[pos[i]] for every slot; c_idx[i] = sel_rows[i] for the
+ * first slot that names a position and EVAE_PRIOR_MASK_ALL for its repeats.  n_unique (optional, device) receives the
+ * number of distinct positions.  One block; n <= 65 536. */
+int evae_select_exemplars(const int64_t* pos, int n, const int64_t* cand_idx, int C, int64_t* sel_rows, int64_t* c_idx,
+                          int* n_unique, evae_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Dense layers on fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replace utils/nn.py:29-69 (NonLinear,

@@ -162,6 +162,86 @@ def test_graphed_step_other_architectures(model_name):
     assert rel(np.asarray(results[1]), np.asarray(results[0])) < 2e-5
 
 
+def test_graphed_step_with_the_approximate_prior():
+    """The kNN-approximate prior (reference models/BaseModel.py:256-271) inside the captured step: its exemplar union is a
+    fixed list of B * k slots with masked repeats instead of `unique`, so the step replays from a hipGraph -- same
+    trajectory (losses, parameters, latent cache) as eager launching; and the fixed-slot form equals the reference's
+    `unique` form (the sharded / no_mask code path) on the same step."""
+    from evae.graph import GraphedTrainStep
+    from utils.optimizer import AdamNormGrad
+    B, C, N, k = 16, 300, 800, 5
+    data = gi.binary_images(8, N)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    eps_all = torch.from_numpy(np.random.RandomState(4).standard_normal((8, B, 40)).astype(np.float32)).cuda()
+    results = []
+    for use_graph in (False, True):
+        args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=B, approximate_prior=True, approximate_k=k)
+        model, _ = smoke_case.build_model(torch, np, orc, args)
+        model.train()
+        it_box = {"i": 0}
+        eps_static = torch.zeros((B, 40), device="cuda")
+        model._draw_eps = lambda like: eps_static          # a static buffer: refreshed before every step, replay-safe
+        opt = AdamNormGrad(model.parameters(), lr=5e-4)
+        with torch.no_grad():
+            cache = tuple(model.cache_z(dataset))
+        torch.manual_seed(3); torch.cuda.manual_seed(3)
+        runner = GraphedTrainStep(model, opt, dataset, B, False) if use_graph else None
+        if runner is not None:
+            cache = runner.set_cache(cache)
+        losses = []
+        for it in range(7):
+            eps_static.copy_(eps_all[it])
+            xb = torch.from_numpy(data[it * B:(it + 1) * B]).cuda()
+            ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1).cuda()
+            if runner is not None:
+                losses.append(runner(xb, ib, 0.5)[0].item())
+            else:
+                opt.zero_grad()
+                loss, RE, KL = model.calculate_loss((xb, ib), 0.5, average=True, dataset=dataset, cache=cache)
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+        results.append((losses, cache[0].detach().cpu().numpy().copy(),
+                        {kk: v.detach().cpu().numpy().copy() for kk, v in model.named_parameters()}))
+        if runner is not None:
+            assert runner.graph is not None and not runner.failed
+    (l0, c0, p0), (l1, c1, p1) = results
+    assert rel(np.asarray(l1), np.asarray(l0)) < 2e-5
+    assert rel(c1, c0) < 2e-5
+    for kk in p0:
+        assert rel(p1[kk], p0[kk]) < 2e-5, kk
+    # fixed slots with masked repeats == unique (one step, same weights / draws): loss and gradients
+    outs = []
+    for no_static in (False, True):
+        args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=B, approximate_prior=True, approximate_k=k)
+        model, _ = smoke_case.build_model(torch, np, orc, args)
+        model.train()
+        model._draw_eps = lambda like: eps_all[0]
+        with torch.no_grad():
+            cache = tuple(model.cache_z(dataset))
+        torch.manual_seed(9)
+        if no_static:
+            import evae.ops as _ops
+            orig = _ops.select_exemplars
+
+            def unique_form(pos, cand):           # the reference's formulation through the same interface
+                u = torch.unique(pos.view(-1))
+                rows = cand[u]
+                return rows, rows
+            _ops.select_exemplars = unique_form
+        try:
+            xb = torch.from_numpy(data[:B]).cuda(); ib = torch.arange(B).reshape(-1, 1).cuda()
+            loss, RE, KL = model.calculate_loss((xb, ib), 0.5, average=False, dataset=dataset, cache=cache)
+            loss.mean().backward()
+        finally:
+            if no_static:
+                _ops.select_exemplars = orig
+        outs.append((loss.detach().cpu().numpy(), {kk: v.grad.cpu().numpy().copy() for kk, v in model.named_parameters()}))
+    assert rel(outs[0][0], outs[1][0]) < 1e-5
+    for kk in outs[0][1]:
+        assert rel(outs[0][1][kk], outs[1][1][kk]) < 1e-4, kk
+
+
 # ---- the other architectures (SURVEY 8a rows a12, a14-a16) against goldens of the real reference ----------
 def seeded_state_dict(model, seed, gain=1.0):
     """Same deterministic fill as tools/gen_goldens.py::seeded_state_dict (walks the state_dict in order)."""
