@@ -396,15 +396,9 @@ extern "C" int evae_topk_merge(const float* val, const int64_t* idx, int R, int 
 
 extern "C" int evae_select_exemplars(const int64_t* pos, int n, const int64_t* cand_idx, int C, int64_t* sel_rows,
                                      int64_t* c_idx, int* n_unique, evae_stream_t stream_) {
-  EVAE_REQUIRE(n >= 0 && n <= 65536 && C >= 0, "select_exemplars: bad sizes n=%d C=%d", n, C);
+  EVAE_REQUIRE(n >= 0 && n <= 16384 && C >= 0, "select_exemplars: bad sizes n=%d (<= 16384) C=%d", n, C);
   if (n == 0) return EVAE_OK;
   EVAE_REQUIRE(pos && cand_idx && sel_rows && c_idx, "select_exemplars: null pointer");
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)select_exemplars_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * 4 > 160 * 1024 ? 160 * 1024 : 65536 * 4);
-    attr = true;
-  }
-  EVAE_REQUIRE((size_t)n * 4 <= 150 * 1024, "select_exemplars: n=%d too large", n);
   select_exemplars_kernel<<<1, 1024, (size_t)n * sizeof(int), (hipStream_t)stream_>>>(pos, n, cand_idx, C, sel_rows, c_idx, n_unique);
   return check_launch("select_exemplars_kernel");
 }

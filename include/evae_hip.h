@@ -146,7 +146,7 @@ int evae_topk_merge(const float* val /* [R x B x k] */, const int64_t* idx, int 
  * `unique(nearest_indices)` then `exemplars_indices[nearest]`): pos [n] = the flattened top-k positions (0 <= pos < C) into the
  * candidate list cand_idx [C] of dataset rows.  sel_rows[i] = cand_idx[pos[i]] for every slot; c_idx[i] = sel_rows[i] for the
  * first slot that names a position and EVAE_PRIOR_MASK_ALL for its repeats.  n_unique (optional, device) receives the
- * number of distinct positions.  One block; n <= 65 536. */
+ * number of distinct positions.  One block; n <= 16 384. */
 int evae_select_exemplars(const int64_t* pos, int n, const int64_t* cand_idx, int C, int64_t* sel_rows, int64_t* c_idx,
                           int* n_unique, evae_stream_t stream);
 

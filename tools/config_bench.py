@@ -62,6 +62,8 @@ def step(i):
 if os.environ.get("GRAPH"):       # replay the whole step from a hipGraph (evae/graph.py) instead of launching eagerly
     from evae.graph import GraphedTrainStep
     runner = GraphedTrainStep(model, opt, ds, B, False)
+    if cache is not None:
+        cache = runner.set_cache(cache)
 
     def step(i):      # noqa: F811
         s = (i * B) % (N - B)
