@@ -211,9 +211,9 @@ def other_config(a, dev, rank, world):
         if c5:
             with torch.no_grad():
                 cache = tuple(model.cache_z(dataset))
-        runner = None if a.no_graph else GraphedTrainStep(model, opt, dataset, B, False)
-        if runner is not None and cache is not None:
-            cache = runner.set_cache(cache)
+        # c5: the approximate prior of a convolutional model stays on eager launches (its `unique` leaves far fewer images to
+        # re-encode than the B * k static slots a captured step would need)
+        runner = None if (c5 or a.no_graph) else GraphedTrainStep(model, opt, dataset, B, False)
 
         def step(i):
             s_ = (i * B) % (n_train - B)

@@ -443,7 +443,10 @@ class BaseModel(nn.Module, ABC):
         else:
             sub_cache = cached_z[exemplars_indices, :]
             nearest_indices, _ = ops.pairdist_topk(z.detach(), sub_cache.detach(), self.args.approximate_k, want_val=False)
-            if self.args.no_mask is False:
+            # static slots: always for the dense encoders (a repeated slot costs one thin GEMM row), for the convolutional
+            # ones only inside a captured step -- re-encoding up to B * k images where `unique` leaves a few dozen is not free
+            static = self.args.no_mask is False and (not self._is_conv() or isinstance(override, tuple))
+            if static:
                 sel_rows, c_idx = ops.select_exemplars(nearest_indices.view(-1), exemplars_indices)
                 exemplars_z, log_variance = self.q_z(data, prior=True, rows=sel_rows)
                 cached_z[sel_rows] = exemplars_z.detach() if not cached_z.requires_grad else exemplars_z

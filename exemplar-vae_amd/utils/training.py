@@ -59,10 +59,11 @@ def _graphed_step(args, model, optimizer, train_loader):
     a = model.args
     # capturable: the exact exemplar prior, and the approximate (cache + top-k) one on a single device with the leave-one-out
     # mask on -- its exemplar union lives in a fixed list of B * k slots with masked repeats instead of a data-dependent
-    # `unique` (models/BaseModel.py::get_approximate_nearest_exemplars).  The `vae` model runs the one-node fused step inside
+    # `unique` (models/BaseModel.py::get_approximate_nearest_exemplars; dense encoders only: a convolutional encoder would
+    # re-encode B * k images where `unique` leaves far fewer).  The `vae` model runs the one-node fused step inside
     # the graph (exact prior), every other case its modular autograd path
     ok = a.prior == 'exemplar_prior' and (a.approximate_prior is False or
-                                          (a.no_mask is False and not model._sharded()))
+                                          (a.no_mask is False and not model._sharded() and not model._is_conv()))
     if not ok:
         return None
     # the runner keeps the optimizer and the dataset alive, so their ids cannot be recycled while it is cached
