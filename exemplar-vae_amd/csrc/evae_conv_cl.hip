@@ -7,14 +7,15 @@
 // ========================================================================================================
 namespace evae {
 
-// wp[co][t][c] = w[co][c][t]          (forward B operand, k-contiguous rows of K = taps * C)
-__global__ void cl_permute_fwd_kernel(const float* __restrict__ w, int Co, int C, int taps, float* __restrict__ wp) {
-  const size_t n = (size_t)Co * C * taps;
+// wp[co][t][c] = w[co][c][t] for c < C, 0 for C <= c < Cv   (forward B operand, k-contiguous rows of K = taps * Cv; Cv = C
+// rounded up to a multiple of 32: the K-extent of one tap, so that a 32-wide K-slab never straddles two taps)
+__global__ void cl_permute_fwd_kernel(const float* __restrict__ w, int Co, int C, int Cv, int taps, float* __restrict__ wp) {
+  const size_t n = (size_t)Co * Cv * taps;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int t = (int)((i / C) % taps);
-    const int co = (int)(i / ((size_t)C * taps));
-    wp[i] = w[((size_t)co * C + c) * taps + t];
+    const int c = (int)(i % Cv);
+    const int t = (int)((i / Cv) % taps);
+    const int co = (int)(i / ((size_t)Cv * taps));
+    wp[i] = c < C ? w[((size_t)co * C + c) * taps + t] : 0.f;
   }
 }
 // wp[j][cc][c], cc < ld: rows of the data-gradient B operand of one stride-parity class, k' = (j, cc) with cc running
@@ -138,7 +139,7 @@ extern "C" int evae_conv2d_cl_supported(const evae_conv_desc_t* d, int what, int
     if (cl_patch_images(d, OH, OW, evae_conv2d_cl_dy_stride(ctot)) < 1) return 0;
     return what == 0 || (what == 2 && ctot % 4 == 0);
   }
-  if (what == 0) return d->C % 32 == 0;
+  if (what == 0) return d->C % 4 == 0 && d->C >= 16;      // a tap's channels are padded to a multiple of 32 in the K index only
   if (what == 1) return d->C % 4 == 0;
   return d->C % 4 == 0 && ctot % 4 == 0;
 }
@@ -149,7 +150,8 @@ extern "C" int evae_conv2d_cl_dy_stride(int ctot) { return (ctot + 31) / 32 * 32
 extern "C" size_t evae_conv2d_cl_workspace_bytes(const evae_conv_desc_t* d, int what, int gated) {
   if (!d) return 256;
   const size_t K = (size_t)d->C * d->KH * d->KW;
-  const size_t wbytes = align_up((size_t)d->Co * K * sizeof(float), 256);
+  const size_t Kv = (size_t)((d->C + 31) / 32 * 32) * d->KH * d->KW;      // forward: taps padded to a multiple of 32 channels
+  const size_t wbytes = align_up((size_t)d->Co * Kv * sizeof(float), 256);
   if (cl_patch_mode(d)) {
     int OH, OW;
     cl_out_dims(d, &OH, &OW);
@@ -223,17 +225,18 @@ extern "C" int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, con
     }
     return EVAE_OK;
   }
-  const int taps = d->KH * d->KW, K = taps * d->C, M = d->N * OH * OW;
+  const int Cv = (d->C + 31) / 32 * 32;
+  const int taps = d->KH * d->KW, K = taps * Cv, M = d->N * OH * OW;
   float* wph = (float*)ws;
   float* wpg = (float*)((char*)ws + align_up((size_t)d->Co * K * sizeof(float), 256));
-  cl_permute_fwd_kernel<<<elt_grid((size_t)d->Co * K), 256, 0, stream>>>(wh, d->Co, d->C, taps, wph);
-  if (gated) cl_permute_fwd_kernel<<<elt_grid((size_t)d->Co * K), 256, 0, stream>>>(wg, d->Co, d->C, taps, wpg);
+  cl_permute_fwd_kernel<<<elt_grid((size_t)d->Co * K), 256, 0, stream>>>(wh, d->Co, d->C, Cv, taps, wph);
+  if (gated) cl_permute_fwd_kernel<<<elt_grid((size_t)d->Co * K), 256, 0, stream>>>(wg, d->Co, d->C, Cv, taps, wpg);
   int rc = check_launch("cl_permute_fwd_kernel");
   if (rc) return rc;
   GemmArgs g = {};
   g.ones_col = -1;
   ConvMap& cv = g.cv;
-  cv.Cg = d->C; cv.ps = d->C; cv.ntaps = taps;
+  cv.Cg = Cv; cv.creal = d->C; cv.ps = d->C; cv.ntaps = taps;
   cv.RH = OH; cv.RW = OW; cv.IH = d->H; cv.IW = d->W;
   cv.rs = d->stride; cv.rsx = d->stride; cv.roy = -d->pad; cv.rox = -d->pad;
   cv.remap = 0;
@@ -337,7 +340,7 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
       cl_permute_dgrad_pair_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, taps, ldy, pt, wc);
       int rc = check_launch("cl_permute_dgrad_pair_kernel");
       if (rc) return rc;
-      cv.Cg = ldy; cv.ps = ldy; cv.ntaps = pt.n;
+      cv.Cg = ldy; cv.creal = ldy; cv.ps = ldy; cv.ntaps = pt.n;
       cv.RH = RH; cv.RW = W2; cv.IH = OH; cv.IW = OW;
       cv.rs = 1; cv.rsx = (s == 1) ? 2 : 1; cv.roy = 0; cv.rox = 0;
       cv.OH2 = d->H; cv.OW2 = W2; cv.os = s; cv.osx = 1; cv.ooy = py; cv.oox = 0;   // output rows in units of pixel pairs
@@ -402,7 +405,7 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
       cl_permute_dgrad_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, C, taps, ldy, tl, wc);
       int rc = check_launch("cl_permute_dgrad_kernel");
       if (rc) return rc;
-      cv.Cg = ldy; cv.ps = ldy; cv.ntaps = tl.n;
+      cv.Cg = ldy; cv.creal = ldy; cv.ps = ldy; cv.ntaps = tl.n;
       cv.RH = RH; cv.RW = RW; cv.IH = OH; cv.IW = OW;
       cv.rs = 1; cv.rsx = 1; cv.roy = 0; cv.rox = 0;
       cv.OH2 = d->H; cv.OW2 = d->W; cv.os = s; cv.osx = s; cv.ooy = py; cv.oox = px;
@@ -472,7 +475,7 @@ extern "C" int evae_conv2d_cl_bwd_weight(const float* dy, const float* x, const 
   (void)Mpix;
   GemmArgs g = {};
   ConvMap& cv = g.cv;
-  cv.Cg = d->C; cv.ps = d->C; cv.ntaps = taps;
+  cv.Cg = d->C; cv.creal = d->C; cv.ps = d->C; cv.ntaps = taps;
   cv.RH = OH; cv.RW = OW; cv.IH = d->H; cv.IW = d->W;
   cv.rs = d->stride; cv.rsx = d->stride; cv.roy = -d->pad; cv.rox = -d->pad;
   cv.div_rw = make_fastdiv((unsigned)OW); cv.div_rhw = make_fastdiv((unsigned)(OH * OW));

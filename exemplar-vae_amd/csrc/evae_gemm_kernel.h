@@ -41,6 +41,8 @@ static FastDiv make_fastdiv(unsigned d) {
 }
 struct ConvMap {
   int Cg, ntaps;
+  int creal;                   // CV = 1: channels of a tap that exist in the source (Cg rounded up to a multiple of 32 is the
+                               // K-extent of a tap; chunks at or beyond creal read as zero)
   int ps;                      // floats per source pixel (Cg, or 2 Cg when the h and g gradients share one buffer)
   int RH, RW, IH, IW;
   int rs, rsx, roy, rox;       // anchor of row (ry, rx) in the source: (ry*rs + roy, rx*rsx + rox)
@@ -371,10 +373,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
           // the slab is 32 channels of one tap: tap offset in an SGPR, validity = one bit per row
           const rsrc_t rA = p1 ? rA1 : rA0;
           const int tap = k0 / g.cv.Cg;                    // uniform; Cg is a multiple of 32
-          const unsigned so = (unsigned)(g.cv.tsoff[tap] + (k0 - tap * g.cv.Cg) * 4);
+          const int kin = k0 - tap * g.cv.Cg;              // first channel of this slab within the tap
+          const unsigned so = (unsigned)(g.cv.tsoff[tap] + kin * 4);
+          const int cleft = g.cv.creal - kin;              // real channels from here on (>= 32: the whole slab exists)
 #pragma unroll
           for (int i = 0; i < NVA; ++i) {
-            const bool live = (tapmask[i] >> tap) & 1ull;
+            const bool live = ((tapmask[i] >> tap) & 1ull) && (4 * ((threadIdx.x + GNT * i) & 7) + 4 <= cleft);
             ra[i] = buf_ld4(rA, live ? voA[0][i] : OOB, so);
           }
         } else {

@@ -17,6 +17,10 @@ CASES = [  # N, C, H, W, Co, k, stride, pad
     (5, 1, 28, 28, 32, 7, 1, 3), (5, 32, 28, 28, 32, 3, 2, 1), (4, 32, 14, 14, 64, 5, 1, 2),
     (4, 64, 14, 14, 64, 3, 2, 1), (6, 64, 7, 7, 6, 3, 1, 1), (3, 64, 28, 28, 1, 1, 1, 0),
     (2, 3, 16, 16, 48, 3, 2, 1), (2, 48, 8, 8, 96, 3, 2, 1), (3, 96, 4, 4, 1, 3, 1, 1), (2, 1, 9, 11, 5, 3, 2, 1),
+    # channel counts that are no multiple of 32 on the channels-last GEMM path (a tap is padded to 32-channel slabs in the
+    # K index only): fully_conv's 48-channel residual blocks, and odd small ones
+    (3, 48, 16, 16, 48, 3, 1, 1), (2, 48, 32, 32, 48, 3, 1, 1), (2, 16, 8, 8, 32, 3, 1, 1), (2, 20, 9, 9, 8, 3, 1, 1),
+    (2, 96, 16, 16, 48, 3, 1, 1), (2, 48, 8, 8, 3, 3, 1, 1),
 ]
 
 
