@@ -7,10 +7,11 @@ forward, sample + encode the C exemplars, exemplar prior, backward, AdamNormGrad
 drop-in API (models.VAE.VAE.calculate_loss -> loss.backward() -> utils.optimizer.AdamNormGrad.step),
 i.e. through libevae_hip.so.  With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU,
 RCCL) the C exemplars are sharded across the ranks and the per-shard partial log-sum-exps are merged
-(evae/shard.py, evae/fused_vae.py).  Default (--parallel dp): every rank trains on its OWN 100-image batch --
-global batch 100 N, gradients averaged, each rank scores the queries of all ranks against its exemplar shard and
-the partials return to their owners -- so the per-GPU batch is fixed ("weak" scaling) while the 25 000 exemplars
-in total are split N ways.  --parallel replica keeps one replicated 100-image batch ("strong" scaling).
+(evae/shard.py, evae/fused_vae.py).  Default (--parallel replica, the split BASELINE.json's north_star names): the SAME
+100-image batch on every rank, the 25 000 exemplars sharded N ways, one all-gather of the packed partial log-sum-exps
+per step -- total work fixed, "strong" scaling.  The same line carries, as the nested object "dp", the data-parallel
+measurement (--parallel dp): every rank trains on its OWN 100-image batch -- global batch 100 N, gradients averaged,
+each rank scores the queries of all ranks against its exemplar shard and the partials return to their owners ("weak").
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel (the fp32-MFMA GEMM behind GatedDense), algorithmic flops per
@@ -52,10 +53,13 @@ def parse():
                          "own roofline object.")
     ap.add_argument("--exemplars", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
-    ap.add_argument("--parallel", choices=("dp", "replica"), default="dp",
-                    help="with --gpus N > 1: 'dp' = every rank trains on its own 100-image batch (global batch 100 N) "
-                         "against the exemplar set sharded over the ranks (weak scaling in the batch); 'replica' = the "
-                         "same 100-image batch replicated on every rank, only the exemplars sharded (strong scaling)")
+    ap.add_argument("--parallel", choices=("replica", "dp"), default="replica",
+                    help="with --gpus N > 1: 'replica' (default, BASELINE.json's north_star split) = the same 100-image batch on "
+                         "every rank, only the 25 000 exemplars sharded: fixed total work, 'strong' scaling; 'dp' = every rank "
+                         "trains on its own 100-image batch (global batch 100 N) against the sharded exemplar set ('weak' in "
+                         "the batch).  The replica line carries the dp measurement as a nested object (--no-dp-line skips it).")
+    ap.add_argument("--no-dp-line", action="store_true", help="with --gpus N > 1: do not run the second (dp) measurement")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe-warmup", type=int, default=20,
                     help="untimed eager steps in front of the probe steps (clock ramp after the host pause)")
     ap.add_argument("--probe-steps", type=int, default=20,
@@ -375,6 +379,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    rccl_ranks, backend = 1, None
+    if world > 1:
+        t1 = torch.ones(1, device=dev)
+        dist.all_reduce(t1)                              # a real collective: every rank contributed
+        rccl_ranks, backend = int(round(float(t1.item()))), dist.get_backend()
     if a.config in ("c3", "c5", "iwae", "topk"):
         return other_config(a, dev, rank, world)
     model_name, c_default, n_train = MLP_CONFIGS[a.config]
@@ -550,6 +559,37 @@ def main():
                 "note": "utils.evaluation.calculate_likelihood on synthetic test images after the benchmark's training steps"}
 
     gb = B * world if dp else B              # images per step over all ranks
+    # collectives of one step, per rank (payload bytes sent = received per rank for an all-gather of R such pieces)
+    n_param = sum(p_.numel() for p_ in model.parameters())
+    if world == 1:
+        coll = {"count": 0, "bytes": 0, "list": []}
+    elif dp:
+        lst = [("all_gather z", 4 * B * Z), ("all_gather batch indices", 8 * B), ("all_gather partial (max, sumexp, nmask)", 12 * B * world),
+               ("all_gather (lse, coefficient)", 8 * B), ("all_reduce dz", 4 * B * world * Z), ("all_reduce parameter gradients", 4 * n_param)]
+        coll = {"count": len(lst), "bytes": sum(b_ for _, b_ in lst), "list": lst}
+    else:
+        lst = [("all_gather partial (max, sumexp, nmask)", 12 * B), ("all_reduce (dz, dlogvar)", 4 * (B * Z + Z)),
+               ("all_reduce parameter gradients", 4 * n_param)]
+        coll = {"count": len(lst), "bytes": sum(b_ for _, b_ in lst), "list": lst}
+    # second line of a multi-GPU run: the data-parallel mode, measured by a child process per rank (own rendezvous port)
+    dp_line = None
+    if world > 1 and not dp and not a.no_dp_line and not a.child:
+        import subprocess
+        env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 29))
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup),
+               "--config", a.config, "--parallel", "dp", "--child", "--iwae-images", "0", "--cpu-baseline-steps", "0",
+               "--probe-steps", "0", "--probe-warmup", "0"] + (["--no-graph"] if a.no_graph else [])
+        if a.exemplars is not None:
+            cmd += ["--exemplars", str(a.exemplars)]
+        try:
+            r_ = subprocess.run(cmd, env=env, timeout=600, capture_output=True, text=True)
+            js = [l_ for l_ in r_.stdout.splitlines() if l_.startswith("{")]
+            if rank == 0 and js:
+                d_ = json.loads(js[-1])
+                dp_line = {k_: d_[k_] for k_ in ("value", "unit", "ms_per_step", "scaling", "collectives") if k_ in d_}
+                dp_line["config"] = d_["config"]
+        except Exception as e:                                          # the main line stands on its own
+            dp_line = {"error": type(e).__name__}
     if rank == 0:
         out = {
             "metric": "training images/sec", "value": round(gb * a.steps / dt, 1), "unit": "images/sec",
@@ -569,6 +609,8 @@ def main():
                                         % (world, B, world)) if dp else
                                        ("replicated batch, exemplar-shard x%d" % world)),
                        "launch": "eager" if graphed is None else "hipGraph replay of the whole step"},
+            "collectives": coll, "rccl_ranks": rccl_ranks, "backend": backend,
+            "dp": dp_line,
             "mean_loss": round(final_loss, 4),
             "roofline": roof,
             "test_log_px": iwae,

@@ -94,14 +94,19 @@ def sharded_topk(q, cache_local, k, index_base, sqrt=False, group=None):
     return ops.topk_merge(v, i)
 
 
+# the three device kernels behind ShardedPriorLogP; tests/test_shard_gloo.py swaps in the oracle's to run the collective
+# logic (uneven and empty shards, four ranks) on CPU tensors over gloo
+KERNELS = {"fwd": lambda *a: ops.prior_lse_fwd(*a), "merge": lambda *a: ops.prior_merge(*a), "bwd": lambda *a: ops.prior_lse_bwd(*a)}
+
+
 class ShardedPriorLogP(torch.autograd.Function):
     """log p(z_i) under the exemplar mixture whose exemplars are sharded over the ranks of `group`."""
 
     @staticmethod
     def forward(ctx, z, centres_local, log_var_row, z_idx, c_idx_local, c_total, group=None):
-        m, s, n, _ = ops.prior_lse_fwd(z, centres_local, log_var_row, z_idx, c_idx_local)
+        m, s, n, _ = KERNELS["fwd"](z, centres_local, log_var_row, z_idx, c_idx_local)
         gm, gs, gn = gather_partials(m, s, n, group)
-        lp, lse = ops.prior_merge(gm, gs, gn, c_total)
+        lp, lse = KERNELS["merge"](gm, gs, gn, c_total)
         ctx.save_for_backward(z, centres_local, log_var_row, lse)
         ctx.misc = (z_idx, c_idx_local, group)
         return lp
@@ -110,7 +115,7 @@ class ShardedPriorLogP(torch.autograd.Function):
     def backward(ctx, g):
         z, centres_local, log_var_row, lse = ctx.saved_tensors
         z_idx, c_idx_local, group = ctx.misc
-        dz, dc, dlv = ops.prior_lse_bwd(z, centres_local, log_var_row, z_idx, c_idx_local, lse, g.contiguous())
+        dz, dc, dlv = KERNELS["bwd"](z, centres_local, log_var_row, z_idx, c_idx_local, lse, g.contiguous())
         packed = torch.cat((dz.reshape(-1), dlv.reshape(-1)))
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)          # one 16 KB collective
         dz = packed[:dz.numel()].reshape(dz.shape)
