@@ -59,7 +59,6 @@ def parse():
                          "trains on its own 100-image batch (global batch 100 N) against the sharded exemplar set ('weak' in "
                          "the batch).  The replica line carries the dp measurement as a nested object (--no-dp-line skips it).")
     ap.add_argument("--no-dp-line", action="store_true", help="with --gpus N > 1: do not run the second (dp) measurement")
-    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe-warmup", type=int, default=20,
                     help="untimed eager steps in front of the probe steps (clock ramp after the host pause)")
     ap.add_argument("--probe-steps", type=int, default=20,
@@ -571,25 +570,49 @@ def main():
         lst = [("all_gather partial (max, sumexp, nmask)", 12 * B), ("all_reduce (dz, dlogvar)", 4 * (B * Z + Z)),
                ("all_reduce parameter gradients", 4 * n_param)]
         coll = {"count": len(lst), "bytes": sum(b_ for _, b_ in lst), "list": lst}
-    # second line of a multi-GPU run: the data-parallel mode, measured by a child process per rank (own rendezvous port)
+    # second measurement of a multi-GPU run: the data-parallel mode, same process group, its own model / optimizer / runner
     dp_line = None
-    if world > 1 and not dp and not a.no_dp_line and not a.child:
-        import subprocess
-        env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 29))
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup),
-               "--config", a.config, "--parallel", "dp", "--child", "--iwae-images", "0", "--cpu-baseline-steps", "0",
-               "--probe-steps", "0", "--probe-warmup", "0"] + (["--no-graph"] if a.no_graph else [])
-        if a.exemplars is not None:
-            cmd += ["--exemplars", str(a.exemplars)]
+    if world > 1 and not dp and not a.no_dp_line:
         try:
-            r_ = subprocess.run(cmd, env=env, timeout=600, capture_output=True, text=True)
-            js = [l_ for l_ in r_.stdout.splitlines() if l_.startswith("{")]
-            if rank == 0 and js:
-                d_ = json.loads(js[-1])
-                dp_line = {k_: d_[k_] for k_ in ("value", "unit", "ms_per_step", "scaling", "collectives") if k_ in d_}
-                dp_line["config"] = d_["config"]
+            from evae.graph import GraphedTrainStep as _G
+            args2 = model_args("cuda:%d" % local_rank, n_ex, sharded=True, shard_batch=True, model_name=model_name, n_train=n_train)
+            torch.manual_seed(14); torch.cuda.manual_seed(14)
+            model2 = importing_model(args2)(args2).to(dev)
+            torch.cuda.manual_seed(14 + rank)
+            opt2 = AdamNormGrad(model2.parameters(), lr=5e-4)
+            model2.train()
+            run2 = None if state["graphed"] is None else _G(model2, opt2, dataset, B, True)
+
+            def step2(i):
+                s_ = (((i * world + rank)) % nb) * B
+                if run2 is not None:
+                    return run2(data_dev[s_:s_ + B], idx_host[s_:s_ + B], beta)
+                x_ = torch.bernoulli(data_dev[s_:s_ + B])
+                opt2.zero_grad()
+                l_, _, _ = model2.calculate_loss((x_, idx_all[s_:s_ + B]), beta, average=True, dataset=dataset)
+                l_.backward()
+                opt2.step()
+            for i in range(a.warmup):
+                step2(i)
+            fence()
+            t2 = time.perf_counter()
+            for i in range(a.steps):
+                step2(a.warmup + i)
+            fence()
+            dt2 = time.perf_counter() - t2
+            tt = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt2 = float(tt.item())
+            lst2 = [("all_gather z", 4 * B * Z), ("all_gather batch indices", 8 * B),
+                    ("all_gather partial (max, sumexp, nmask)", 12 * B * world), ("all_gather (lse, coefficient)", 8 * B),
+                    ("all_reduce dz", 4 * B * world * Z), ("all_reduce parameter gradients", 4 * n_param)]
+            dp_line = {"value": round(B * world * a.steps / dt2, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt2 / a.steps, 4),
+                       "scaling": "weak", "global_batch": B * world,
+                       "parallelism": "dp%d (own %d-image batch per rank) x exemplar-shard x%d" % (world, B, world),
+                       "collectives": {"count": len(lst2), "bytes": sum(b_ for _, b_ in lst2)},
+                       "launch": "eager" if (run2 is None or run2.graph is None) else "hipGraph replay of the whole step"}
         except Exception as e:                                          # the main line stands on its own
-            dp_line = {"error": type(e).__name__}
+            dp_line = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     if rank == 0:
         out = {
             "metric": "training images/sec", "value": round(gb * a.steps / dt, 1), "unit": "images/sec",
