@@ -28,6 +28,10 @@ from . import _lib, ops, shard
 
 ACT_NONE, ACT_SIGMOID, ACT_HARDTANH = ops.ACT_NONE, ops.ACT_SIGMOID, ops.ACT_HARDTANH
 
+# generation of the staging rows behind a dataset buffer (keyed by its address): a second fused forward overwrites the rows a
+# pending backward would gather its batch from -- the backward checks that its forward was the last one to stage
+_STAGE_GEN = {}
+
 # schedule switches (bit mask; tools/chain_bench.sh sweeps them): 1 = the prior's dz' / dlogvar reduction on the side stream,
 # 2 = the finish launch of encoder layer 2's weight gradient on the side stream.  Both OFF: measured at config 2 (r02), 0 ->
 # 0.975 ms/step, 1 -> 1.002, 2 -> 1.085, 3 -> 1.076 -- a launch that runs beside a CU-filling GEMM costs that GEMM more than
@@ -139,6 +143,7 @@ class VaeExactLoss(torch.autograd.Function):
         # dataset or its uint8 store (models/BaseModel.py::resident_u8): then the first layer runs on the byte kernels
         u8 = data_ext.dtype == torch.uint8
         stage = data_ext[n_data:n_data + B]
+        gen = _STAGE_GEN[data_ext.data_ptr()] = _STAGE_GEN.get(data_ext.data_ptr(), 0) + 1
         if u8:
             if not staged:                        # the captured step (evae/graph.py) writes the bytes itself
                 stage.copy_(torch.round(x * 255.0))
@@ -212,8 +217,8 @@ class VaeExactLoss(torch.autograd.Function):
         main.wait_event(z_ready)
         # ---- exemplar prior (leave-one-out mask in training unless no_mask; with its collectives when sharded) on the
         #      main stream ...
-        zi = None if no_mask else x_idx.reshape(-1)
-        ci = None if no_mask else ex_idx
+        zi = None if no_mask else ops._i64(x_idx)
+        ci = None if no_mask else ops._i64(ex_idx)
         logp = torch.empty(B, **f32); lse = torch.empty(B, **f32)
         z_all, zi_all = z, zi
         if sharded == 2:
@@ -254,6 +259,7 @@ class VaeExactLoss(torch.autograd.Function):
         ctx.k_dev = dev
         ctx.dims = (B, D, H, Z, Cl, Mp, ldd, beta, int(sharded))
         ctx.dp = (z_all, zi_all)
+        ctx.stage_gen = gen
         ctx.bufs = (x, rows, data_ext, A1, s1, A2, s2, mean_all, logvar, lv_pre, z, D1, sd1, D2, sd2,
                     xmean, lv_row, zi, ci, lse, eps)
         ctx.save_for_backward(*params)
@@ -270,6 +276,9 @@ class VaeExactLoss(torch.autograd.Function):
         (x, rows, data_ext, A1, s1, A2, s2, mean_all, logvar, lv_pre, z, D1, sd1, D2, sd2,
          xmean, lv_row, zi, ci, lse, eps) = ctx.bufs
         B, D, H, Z, Cl, Mp, ldd, beta, sharded = ctx.dims
+        if _STAGE_GEN.get(data_ext.data_ptr()) != ctx.stage_gen:
+            raise _lib.EvaeError("fused vae step: another fused forward re-used the staging rows of this dataset before this "
+                                 "backward ran (gradient accumulation over two batches): set model._use_fused = False for it")
         dev = ctx.k_dev
         k = _K(dev)
         lib = k.lib

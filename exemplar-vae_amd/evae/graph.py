@@ -87,6 +87,7 @@ class GraphedTrainStep:
         self._one = torch.ones((), device=dev)
         self.out = torch.zeros(3, device=dev)       # (loss, -RE, KL) of the last step
         self.totals = torch.zeros(3, device=dev)    # running sums since reset_totals()
+        self._adam_tables = {}     # this graph's AdamNormGrad pointer tables and member lists (utils/optimizer.py)
         self.cache = None          # approximate prior: the latent cache in static buffers (set_cache)
         self.graph = None
         self.failed = False
@@ -125,7 +126,7 @@ class GraphedTrainStep:
         loss, RE, KL = self.model.calculate_loss((x, self.idx_in), self.beta, average=True, dataset=self.dataset,
                                                  cache=self.cache)
         loss.backward(gradient=self._one)
-        self.opt.step(_captured=True)
+        self.opt.step(_captured=True, _tables=self._adam_tables)
         ops.step_stats_add(loss.detach(), RE.detach(), KL.detach(), self.out, self.totals)
         return self.out
 
@@ -155,7 +156,7 @@ class GraphedTrainStep:
         h[self._o_seed + 1] = self._calls
         hs = h[self._o_scal:].view(torch.float32)
         hs[0] = float(beta)
-        self.opt.advance_graph_step(host_out=hs[1:1 + self.ngroups])
+        self.opt.advance_graph_step(host_out=hs[1:1 + self.ngroups], tables=self._adam_tables)
         main = torch.cuda.current_stream()
         self._up.wait_event(self._ev_used[k])     # device staging block k was consumed two steps ago
         with torch.cuda.stream(self._up):
@@ -202,7 +203,7 @@ class GraphedTrainStep:
                 try:
                     with torch.cuda.graph(graph, capture_error_mode=mode):
                         self._body()
-                    getattr(self.opt, 'finish_capture', lambda: None)()
+                    self.opt.finish_capture(self._adam_tables)
                     self.graph = graph
                 except Exception as e:           # an op of this model that cannot be captured: eager from here on
                     print("evae.graph: hipGraph capture of the training step failed (%s: %s); running eagerly"

@@ -109,6 +109,9 @@ class BaseModel(nn.Module, ABC):
             data_ext, n_data = u8[0], u8[1]
         else:
             data_ext, n_data = self.resident_data_ext(dataset, x.shape[0])
+        if a.training_set_size > n_data:
+            # the reference's dataset.tensors[0][exemplars_indices] raises here; the row-gather GEMM would read staging rows
+            raise IndexError("training_set_size %d exceeds the %d rows of the dataset" % (a.training_set_size, n_data))
         x2 = x.reshape(x.shape[0], -1).float()
         eps = getattr(self, '_eps_override', None)          # the captured step draws eps in its prologue launch
         if eps is None or tuple(eps.shape) != (x2.shape[0], a.z1_size):

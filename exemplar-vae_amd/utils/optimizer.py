@@ -37,14 +37,21 @@ class AdamNormGrad(Optimizer):
         dev = self.param_groups[0]['params'][0].device
         self._graph_step_size = storage if storage is not None else [torch.zeros(1, device=dev) for _ in self.param_groups]
 
-    def advance_graph_step(self, host_out=None):
-        """Before each replay: bump the step counters (all parameters of a group share one count here) and
-        upload the bias-corrected step size -- or, with `host_out`, write it there for the caller to upload."""
+    def advance_graph_step(self, host_out=None, tables=None):
+        """Before each replay: bump the step counters of the parameters that take part in the captured step (`tables`: the
+        runner-owned dict its capture filled; before the capture, every parameter) and upload the bias-corrected step size
+        -- or, with `host_out`, write it there for the caller to upload.  The captured launches apply ONE step size per
+        group, so the participants of a group must share one step count (the reference keeps a count per parameter and
+        skips parameters without a gradient, utils/optimizer.py:50-57)."""
         for gi, group in enumerate(self.param_groups):
             step = None
-            for p in group['params']:
+            members = (tables or {}).get(("members", gi))
+            for p in (members if members is not None else group['params']):
                 st = self._init_state(p)
                 st['step'] += 1
+                if step is not None and st['step'] != step:
+                    raise RuntimeError("AdamNormGrad: parameters of one group reached the captured step with different step "
+                                       "counts (%d vs %d); step them eagerly" % (st['step'], step))
                 step = st['step']
             if step is None:
                 continue
@@ -55,12 +62,16 @@ class AdamNormGrad(Optimizer):
             else:   # fill kernel (value travels as a kernel argument: no host buffer to race with later steps)
                 self._graph_step_size[gi].fill_(v)
 
-    def finish_capture(self):
+    def finish_capture(self, tables=None):
         """After the capture of a step that contained step(_captured=True): upload the pointer tables of its launches."""
-        ops.adam_flush_tables(self._tables.values())
+        src = self._tables if tables is None else tables
+        ops.adam_flush_tables([v for k, v in src.items() if not (isinstance(k, tuple) and k and k[0] == "members")])
 
     @torch.no_grad()
-    def step(self, closure=None, _captured=False):
+    def step(self, closure=None, _captured=False, _tables=None):
+        """`_tables`: a dict owned by the caller's captured graph -- every graph keeps its own device pointer tables (its own
+        gradient buffers), so that capturing a second step on the same optimizer cannot redirect the first one's replays."""
+        tables = self._tables if _tables is None else _tables
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -79,11 +90,13 @@ class AdamNormGrad(Optimizer):
                     state['step'] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 by_step.setdefault(state['step'] if not _captured else 1, []).append((p, g, state))
+            if _captured:
+                tables[("members", gi)] = [p for items in by_step.values() for p, _, _ in items]
             for step, items in by_step.items():
                 ops.adam_normgrad_step([p.data for p, _, _ in items], [g for _, g, _ in items],
                                        [s['exp_avg'] for _, _, s in items],
                                        [s['exp_avg_sq'] for _, _, s in items],
                                        step, group['lr'], beta1, beta2, group['eps'], group['weight_decay'],
-                                       table_cache=self._tables.setdefault((gi, len(items), _captured), {}),
+                                       table_cache=tables.setdefault((gi, len(items), _captured), {}),
                                        step_size_dev=self._graph_step_size[gi] if _captured else None)
         return loss

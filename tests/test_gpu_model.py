@@ -242,6 +242,52 @@ def test_graphed_step_with_the_approximate_prior():
         assert rel(outs[0][1][kk], outs[1][1][kk]) < 1e-4, kk
 
 
+def test_two_captured_steps_on_one_optimizer_keep_their_own_pointer_tables():
+    """train_one_epoch keys its captured runners by (dataset, batch size, binarisation): two of them can share one optimizer.
+    Each graph owns its AdamNormGrad pointer table (its own gradient buffers) -- alternating replays follow the eager
+    trajectory."""
+    from evae.graph import GraphedTrainStep
+    from utils.optimizer import AdamNormGrad
+    C, N = 300, 1200
+    data = gi.binary_images(9, N)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    eps_static = {16: torch.zeros((16, 40), device="cuda"), 24: torch.zeros((24, 40), device="cuda")}
+    eps_all = torch.from_numpy(np.random.RandomState(5).standard_normal((12, 24, 40)).astype(np.float32)).cuda()
+    results = []
+    for use_graph in (False, True):
+        args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=16)
+        model, _ = smoke_case.build_model(torch, np, orc, args)
+        model.train()
+        model._use_fused = False                # modular path: eps through the _draw_eps hook
+        cur = {"B": 16}
+        model._draw_eps = lambda like: eps_static[cur["B"]]
+        opt = AdamNormGrad(model.parameters(), lr=5e-4)
+        torch.manual_seed(3); torch.cuda.manual_seed(3)
+        runners = {b: GraphedTrainStep(model, opt, dataset, b, False) for b in (16, 24)} if use_graph else None
+        losses = []
+        for it in range(12):
+            Bc = 16 if it % 2 == 0 else 24
+            cur["B"] = Bc
+            eps_static[Bc].copy_(eps_all[it, :Bc])
+            xb = torch.from_numpy(data[it * 24:it * 24 + Bc]).cuda()
+            ib = torch.arange(it * 24, it * 24 + Bc).reshape(-1, 1).cuda()
+            if runners is not None:
+                losses.append(runners[Bc](xb, ib, 0.5)[0].item())
+            else:
+                opt.zero_grad()
+                loss, RE, KL = model.calculate_loss((xb, ib), 0.5, average=True, dataset=dataset)
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+        results.append((losses, {kk: v.detach().cpu().numpy().copy() for kk, v in model.named_parameters()}))
+        if runners is not None:
+            assert all(r.graph is not None for r in runners.values())
+    (l0, p0), (l1, p1) = results
+    assert rel(np.asarray(l1), np.asarray(l0)) < 2e-5
+    for kk in p0:
+        assert rel(p1[kk], p0[kk]) < 2e-5, kk
+
+
 # ---- the other architectures (SURVEY 8a rows a12, a14-a16) against goldens of the real reference ----------
 def seeded_state_dict(model, seed, gain=1.0):
     """Same deterministic fill as tools/gen_goldens.py::seeded_state_dict (walks the state_dict in order)."""
