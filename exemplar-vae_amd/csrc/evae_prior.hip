@@ -196,27 +196,28 @@ constexpr float kPriorNormLimit = 2048.f;
 // Centre the staged (sigma-scaled) query tile: mu[k] = mean over its nvalid live rows, subtracted from those rows in place;
 // then the squared row norms and their maximum over the tile.  `scratch` = 512 floats of LDS nobody uses yet.
 // Fixed reduction order.  Contains barriers: every thread of the block calls it.
-template <int KP, int KS2>
+template <int KP, int KS2, int NTH>
 __device__ __forceinline__ float centre_queries(float* __restrict__ Qs, float* __restrict__ mu_s, float* __restrict__ zn,
                                                 float* __restrict__ zmx, float* __restrict__ scratch, int nvalid) {
   const int tid = threadIdx.x, col = tid & 63, part = tid >> 6;
   if (col < KP) {
     float a = 0.f;
+    constexpr int RP = MFQ / (NTH / 64);          // rows per wave
 #pragma unroll 4
-    for (int r = part * 16; r < part * 16 + 16; ++r) a += (r < nvalid) ? Qs[r * KS2 + col] : 0.f;
+    for (int r = part * RP; r < part * RP + RP; ++r) a += (r < nvalid) ? Qs[r * KS2 + col] : 0.f;
     scratch[part * 64 + col] = a;
   }
   __syncthreads();
   if (tid < KP) {
     float a = 0.f;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) a += scratch[p * 64 + tid];
+    for (int p = 0; p < NTH / 64; ++p) a += scratch[p * 64 + tid];
     mu_s[tid] = a / (float)nvalid;
   }
   __syncthreads();
   {
     constexpr int CPR = KP / 4;
-    for (int f = tid; f < MFQ * CPR; f += MFT) {
+    for (int f = tid; f < MFQ * CPR; f += NTH) {
       const int r = f / CPR, c = f - r * CPR;
       if (r < nvalid) {
         float4 v = *reinterpret_cast<float4*>(Qs + r * KS2 + 4 * c);
@@ -273,20 +274,24 @@ __device__ __forceinline__ void direct_tile(f32x16_t (&a)[2], const float* __res
   }
 }
 
-template <int KG, int OCC>
-__global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
+// WR = wave rows of a block: 4 -> 8 waves, tile 128 exemplars x 128 queries; 2 -> 4 waves, tile 64 x 128 -- three of those
+// blocks fit a CU (the kernel needs ~168 VGPRs: 3 waves per SIMD), and blocks in different phases are what overlaps one
+// block's exp / log-sum-exp epilogue (VALU) with another's products (matrix pipe)
+template <int KG, int WR>
+__global__ __launch_bounds__(128 * WR) void prior_fwd_mfma_kernel(
     const float* __restrict__ z, int B, const float* __restrict__ centres, int C, int zdim,
     const float* __restrict__ log_var, const int64_t* __restrict__ z_idx,
     const int64_t* __restrict__ c_idx, int tiles_per_split, float norm_limit,
     float* __restrict__ part_m, float* __restrict__ part_s, float* __restrict__ part_n) {
   constexpr int KP = KG * 8, KS2 = KP + 4, CPR = KP / 4;       // chunks (float4) per row
-  constexpr int NV = (MFE * CPR + MFT - 1) / MFT;
+  constexpr int FE = 32 * WR, FT = 128 * WR;                   // exemplars per tile, threads per block
+  constexpr int NV = (FE * CPR + FT - 1) / FT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;                          // [128][KS2]
   float* Es = Qs + MFQ * KS2;                // [128][KS2]
-  float* zn = Es + MFE * KS2;                // [128]
+  float* zn = Es + FE * KS2;                // [128]
   float* cn = zn + MFQ;                      // [2][128]
-  float* inv_sigma = cn + 2 * MFE;           // [64]
+  float* inv_sigma = cn + 2 * FE;           // [64]
   float* mu_s = inv_sigma + 64;              // [64]  mean of the query tile (sigma units)
   float* red = mu_s + 64;                    // [16]
   float* zmx = red + 16;                     // [2] (+6 padding)
@@ -295,8 +300,8 @@ __global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
   // keeps the block at 48 KB of LDS -- three blocks (24 waves) per CU instead of two, and it is waves of OTHER blocks
   // that fill a SIMD while one block sits in its exp / log-sum-exp epilogue
   float* comb = Es;
-  static_assert(4 * MFQ * 3 <= MFE * KS2, "combine buffer must fit in the exemplar tile");
-  static_assert(512 <= MFE * KS2, "centre_queries scratch must fit in the exemplar tile");
+  static_assert(WR * MFQ * 3 <= FE * KS2, "combine buffer must fit in the exemplar tile");
+  static_assert(512 <= FE * KS2, "centre_queries scratch must fit in the exemplar tile");
 
   const int split = blockIdx.x;
   const int q0 = blockIdx.y * MFQ;
@@ -309,18 +314,18 @@ __global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
   auto load_tile = [&](const float* src, int r0, int nrows, float4 (&v)[NV]) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid + MFT * i;
+      const int f = tid + FT * i;
       const int r = f / CPR, c = f - r * CPR;
-      const bool ok = f < MFE * CPR && r0 + r < nrows && 4 * c + 4 <= zdim;
+      const bool ok = f < FE * CPR && r0 + r < nrows && 4 * c + 4 <= zdim;
       v[i] = ok ? *reinterpret_cast<const float4*>(src + (size_t)(r0 + r) * zdim + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store_tile = [&](float* tile, const float4 (&v)[NV], const bool centre) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid + MFT * i;
+      const int f = tid + FT * i;
       const int r = f / CPR, c = f - r * CPR;
-      if (f < MFE * CPR) {
+      if (f < FE * CPR) {
         const float4 s4 = *reinterpret_cast<const float4*>(inv_sigma + 4 * c);
         float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (centre) m4 = *reinterpret_cast<const float4*>(mu_s + 4 * c);
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
     }
   };
   auto row_norms = [&](const float* tile, float* out) {     // threads 0..127, one row each
-    if (tid < MFE) {
+    if (tid < FE) {
       float sacc = 0.f;
 #pragma unroll
       for (int c = 0; c < CPR; ++c) {
@@ -344,14 +349,14 @@ __global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
   float4 rv[NV];
   load_tile(z, q0, B, rv);
   store_tile(Qs, rv, false);
-  const int ntiles = (C + MFE - 1) / MFE;
+  const int ntiles = (C + FE - 1) / FE;
   const int tile_begin = split * tiles_per_split;
   int tile_end = tile_begin + tiles_per_split;
   if (tile_end > ntiles) tile_end = ntiles;
-  if (tile_begin < tile_end) load_tile(centres, tile_begin * MFE, C, rv);
+  if (tile_begin < tile_end) load_tile(centres, tile_begin * FE, C, rv);
   __syncthreads();
   // the guard (block-uniform): queries too far from their tile mean for the expanded form -> direct differences
-  const bool slow_block = centre_queries<KP, KS2>(Qs, mu_s, zn, zmx, Es, (B - q0) < MFQ ? (B - q0) : MFQ) > norm_limit;
+  const bool slow_block = centre_queries<KP, KS2, FT>(Qs, mu_s, zn, zmx, Es, (B - q0) < MFQ ? (B - q0) : MFQ) > norm_limit;
 
   // this lane's two query columns
   float hz[2];
@@ -370,13 +375,13 @@ __global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
   auto tile_loop = [&](auto SLOW_) {
   constexpr bool slow = decltype(SLOW_)::value;
   for (int t = tile_begin; t < tile_end; ++t) {
-    const int e0 = t * MFE;
+    const int e0 = t * FE;
     const int pb = (t - tile_begin) & 1;
     store_tile(Es, rv, true);
-    if (masked && tid < MFE) ci_s[pb * MFE + tid] = (e0 + tid < C) ? (long long)c_idx[e0 + tid] : -2;
+    if (masked && tid < FE) ci_s[pb * FE + tid] = (e0 + tid < C) ? (long long)c_idx[e0 + tid] : -2;
     __syncthreads();
-    if (t + 1 < tile_end) load_tile(centres, (t + 1) * MFE, C, rv);
-    if constexpr (!slow) row_norms(Es, cn + pb * MFE);
+    if (t + 1 < tile_end) load_tile(centres, (t + 1) * FE, C, rv);
+    if constexpr (!slow) row_norms(Es, cn + pb * FE);
 
     f32x16_t acc[2];
 #pragma unroll
@@ -384,8 +389,7 @@ __global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
     if constexpr (!slow) {
       const float* ea = Es + (wr * 32 + l31) * KS2 + lh * 4;
       const float* qb = Qs + (wc * 64 + l31) * KS2 + lh * 4;
-      constexpr int UNR = (OCC >= 2 && KG > 2) ? 2 : KG;     // fragments in flight vs registers (two blocks per CU need <= 128)
-#pragma unroll UNR
+#pragma unroll
       for (int kg = 0; kg < KG; ++kg) {
         const float4 a = *reinterpret_cast<const float4*>(ea + kg * 8);
         const float4 b0 = *reinterpret_cast<const float4*>(qb + kg * 8);
@@ -413,14 +417,14 @@ __global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int el = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      hc[r] = slow ? 0.f : 0.5f * cn[pb * MFE + el];
+      hc[r] = slow ? 0.f : 0.5f * cn[pb * FE + el];
       if (e0 + el < C) live |= 1u << r;
     }
     if constexpr (slow) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[0][r] *= -0.5f; acc[1][r] *= -0.5f; }
     }
-    if (!masked && e0 + MFE <= C) {       // whole tile present, nothing to mask: no per-element predicates
+    if (!masked && e0 + FE <= C) {       // whole tile present, nothing to mask: no per-element predicates
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const float off = slow ? 0.f : hz[nt];
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
         v[r] = acc[nt][r] - hc[r];
         if (masked) {
           const int el = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const long long ce = ci_s[pb * MFE + el];
+          const long long ce = ci_s[pb * FE + el];
           if (((use >> r) & 1u) && (ce == zi[nt] || ce == kMaskAll)) { nmask[nt] += 1.f; use &= ~(1u << r); }
         }
         if ((use >> r) & 1u) vmax = fmaxf(vmax, v[r]);
@@ -494,9 +498,9 @@ __global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
   if (tid < MFQ && q0 + tid < B) {
     float m = INFINITY, sacc = 0.f, nacc = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) m = fminf(m, comb[(w * MFQ + tid) * 3]);
+    for (int w = 0; w < WR; ++w) m = fminf(m, comb[(w * MFQ + tid) * 3]);
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < WR; ++w) {
       const float dw = comb[(w * MFQ + tid) * 3];
       if (dw != INFINITY) sacc += comb[(w * MFQ + tid) * 3 + 1] * fast_exp2((m - dw) * kHalfLog2e);
       nacc += comb[(w * MFQ + tid) * 3 + 2];
@@ -512,35 +516,39 @@ __global__ __launch_bounds__(MFT, 2 * OCC) void prior_fwd_mfma_kernel(
 static float g_norm_limit = kPriorNormLimit;
 static float prior_norm_limit() { return g_norm_limit; }
 
-template <int KG>
-static int launch_prior_mfma(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
-                             const int64_t* z_idx, const int64_t* c_idx, int ns_max, float* pm, float* ps, float* pn,
-                             int* ns_out, hipStream_t stream) {
-  constexpr int KS2 = KG * 8 + 4;
-  const size_t lds = (size_t)(2 * 128 * KS2 + 128 + 256 + 64 + 64 + 16 + 8) * sizeof(float) + 2 * 128 * sizeof(long long);
+template <int KG, int WR>
+static int launch_prior_mfma_w(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+                               const int64_t* z_idx, const int64_t* c_idx, int ns_max, float* pm, float* ps, float* pn,
+                               int* ns_out, hipStream_t stream) {
+  constexpr int KS2 = KG * 8 + 4, FE = 32 * WR;
+  const size_t lds = (size_t)((128 + FE) * KS2 + 128 + 2 * FE + 64 + 64 + 16 + 8) * sizeof(float) + 2 * FE * sizeof(long long);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)prior_fwd_mfma_kernel<KG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)prior_fwd_mfma_kernel<KG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)prior_fwd_mfma_kernel<KG, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  static int occ = 0;
-  if (occ == 0) { const char* e = getenv("EVAE_PRIOR_OCC"); occ = (e && atoi(e) == 2) ? 2 : 1; }
-  const int nq = cdiv(B, MFQ), ntiles = cdiv(C, MFE);
-  int ns = cdiv(512, nq);
+  const int nq = cdiv(B, MFQ), ntiles = cdiv(C, FE);
+  int ns = cdiv(WR == 4 ? 512 : 1536, nq);          // two rounds of the blocks a chip holds
   if (ns > ntiles) ns = ntiles;
   if (ns > ns_max) ns = ns_max;
   if (ns < 1) ns = 1;
   const int tps = cdiv(ntiles, ns);
   ns = cdiv(ntiles, tps);
   *ns_out = ns;
-  if (occ == 1)
-    prior_fwd_mfma_kernel<KG, 1><<<dim3(ns, nq), MFT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, tps,
-                                                                     prior_norm_limit(), pm, ps, pn);
-  else
-    prior_fwd_mfma_kernel<KG, 2><<<dim3(ns, nq), MFT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, tps,
-                                                                     prior_norm_limit(), pm, ps, pn);
+  prior_fwd_mfma_kernel<KG, WR><<<dim3(ns, nq), 128 * WR, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, tps,
+                                                                       prior_norm_limit(), pm, ps, pn);
   return check_launch("prior_fwd_mfma_kernel");
+}
+
+template <int KG>
+static int launch_prior_mfma(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+                             const int64_t* z_idx, const int64_t* c_idx, int ns_max, float* pm, float* ps, float* pn,
+                             int* ns_out, hipStream_t stream) {
+  // EVAE_PRIOR_WR=4 selects the 8-wave block (128-exemplar tiles)
+  static int wr = 0;
+  if (wr == 0) { const char* e = getenv("EVAE_PRIOR_WR"); wr = (e && atoi(e) == 4) ? 4 : 2; }
+  if (wr == 4) return launch_prior_mfma_w<KG, 4>(z, B, centres, C, zdim, log_var, z_idx, c_idx, ns_max, pm, ps, pn, ns_out, stream);
+  return launch_prior_mfma_w<KG, 2>(z, B, centres, C, zdim, log_var, z_idx, c_idx, ns_max, pm, ps, pn, ns_out, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -915,7 +923,7 @@ __global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
   __syncthreads();
   // centred coordinates (every formula below is translation invariant); rows past B stay zero.  The guard of
   // prior_fwd_mfma_kernel (block-uniform): queries too far from their tile mean for the expanded form -> direct differences
-  const bool slow = centre_queries<KP, KS2>(Qs, mu_s, zn, zmx, Ps, (B - q0) < MFQ ? (B - q0) : MFQ) > norm_limit;
+  const bool slow = centre_queries<KP, KS2, MFT>(Qs, mu_s, zn, zmx, Ps, (B - q0) < MFQ ? (B - q0) : MFQ) > norm_limit;
 
   // this lane's two query columns of S
   float znq[2], gq[2], lq[2];
