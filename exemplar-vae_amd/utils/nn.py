@@ -2,9 +2,11 @@
 (reference utils/nn.py:12-114), computing through the HIP dense kernels (evae.ops).
 
 GatedDense / NonLinear / Linear run on the fp32-MFMA GEMM of libevae_hip.so with the bias, activation and
-gate fused into the epilogue.  GatedConv2d / Conv2d / HipConv2d run on the implicit-GEMM convolution kernels
-(csrc/evae_conv.hip: LDS-staged im2col + the same MFMA core; one pass over x computes both filter banks of a
-gated layer and applies the gate in the epilogue)."""
+gate fused into the epilogue.  GatedConv2d / Conv2d / HipConv2d run as channels-last convolutions on the same GEMM kernel
+(csrc/evae_conv_cl.hip: a K-slab is 32 channels of one filter tap, so the im2col gather is the dense tile with a per-slab
+offset; one pass over x computes both filter banks of a gated layer and applies the gate in the epilogue; any channel
+count >= 16 that is a multiple of 4) -- thin first layers through a patch matrix, data gradients into 1/3-channel inputs
+through the NCHW implicit-GEMM kernels of csrc/evae_conv.hip."""
 import numpy as np
 import torch
 import torch.nn as nn
