@@ -172,6 +172,30 @@ extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const floa
   return launch_finish(f, stream);
 }
 
+// The data gradient of the layer ABOVE the byte-store layer: (dh, dg) of that layer are written as the bf16 tile images the
+// weight gradient of evae_dense_bwd_weight_u8 reads (see EPI_GATE_BWD_IMG), not as an fp32 [M x 2K] buffer.
+extern "C" int evae_dense_bwd_data_img(const float* dy1, const float* w1, const float* dy2, const float* w2, int M, int N,
+                                       int ldy, int K, const float* out_prev, const float* s_prev, void* img, int img_nslab,
+                                       int m_base, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldy >= N, "dense_bwd_data_img: bad sizes M=%d N=%d K=%d", M, N, K);
+  if (M == 0) return EVAE_OK;
+  EVAE_REQUIRE(dy1 && w1 && out_prev && s_prev && img, "dense_bwd_data_img: null pointer");
+  EVAE_REQUIRE((dy2 == nullptr) == (w2 == nullptr), "dense_bwd_data_img: dy2/w2 must come together");
+  EVAE_REQUIRE(M % 4 == 0 && m_base % 4 == 0 && m_base >= 0 && img_nslab > 0 && (long long)m_base + M <= (long long)img_nslab * 32,
+               "dense_bwd_data_img: rows must come in aligned fours inside the image (M=%d m_base=%d nslab=%d)", M, m_base, img_nslab);
+  const int np = dy2 ? 2 : 1;
+  Plan pl = make_plan(M, K, total_slabs(N, np > 1 ? N : 0), false, false, 1);
+  pl.nz = 1; pl.ksplit = 0;                      // the image epilogue lives in the GEMM itself: no split-K
+  GemmArgs g = {};
+  g.ones_col = -1;
+  g.A[0] = dy1; g.B[0] = w1; g.lda[0] = ldy; g.ldb[0] = K; g.Kc[0] = N; g.npairs = np;
+  if (dy2) { g.A[1] = dy2; g.B[1] = w2; g.lda[1] = ldy; g.ldb[1] = K; g.Kc[1] = N; }
+  g.M = M; g.N = K; g.ldo = K; g.e0 = out_prev; g.e1 = s_prev;
+  g.img = (unsigned short*)img; g.img_nslab = img_nslab; g.img_mbase = m_base;
+  return launch_gemm<true, false, EPI_GATE_BWD_IMG>(g, pl, stream, "dense_bwd_data(gate, bf16 tile images)");
+}
+
 // ---- weight gradient -------------------------------------------------------------------------------------
 // The bias gradient db = column sums of dy is folded into the same GEMM: x gets a virtual all-ones
 // column K (never read from memory), so column K of dy^T [x | 1] is db.

@@ -374,6 +374,13 @@ extern "C" size_t evae_dense_bwd_weight_u8_workspace_bytes(int M, int N, int K) 
   return u8_wgrad_layout(M, N, K).total;
 }
 
+extern "C" int evae_dense_bwd_weight_u8_images(int M, int N, int K, size_t* offset, int* nslab) {
+  EVAE_REQUIRE(M > 0 && N > 0 && K > 0 && offset && nslab, "dense_bwd_weight_u8_images: bad arguments");
+  const U8WgradLayout L = u8_wgrad_layout(M, N, K);
+  *offset = L.img; *nslab = L.nslab;
+  return EVAE_OK;
+}
+
 extern "C" int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long ldy, const unsigned char* x,
                                         const int64_t* rows, int K, long long ldx, float x_scale, float* dw, float* db,
                                         void* ws, size_t ws_bytes, evae_stream_t stream_) {
@@ -385,7 +392,7 @@ extern "C" int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long
     if (db) (void)hipMemsetAsync(db, 0, (size_t)N * sizeof(float), stream);
     return check_launch("dense_bwd_weight_u8(empty)");
   }
-  EVAE_REQUIRE(dy && x, "dense_bwd_weight_u8: null pointer");
+  EVAE_REQUIRE(x, "dense_bwd_weight_u8: null pointer");      // dy == NULL: its tile images are already in the workspace
   EVAE_REQUIRE(evae_dense_u8_supported(K, ldx) && (((uintptr_t)x) & 15) == 0, "dense_bwd_weight_u8: unaligned byte store");
   const U8WgradLayout L = u8_wgrad_layout(M, N, K);
   if (ws == nullptr || ws_bytes < L.total) { set_error("dense_bwd_weight_u8: workspace too small (%zu)", ws_bytes); return EVAE_EWORKSPACE; }
@@ -394,7 +401,7 @@ extern "C" int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long
   float* part = (float*)((char*)ws + L.part);
   // the padding columns m >= M of xT (up to the slab boundary + slack) must be zero: they meet dy rows that do not exist
   u8_gather_transpose_kernel<<<dim3(cdiv((int)L.ldt, 64), cdiv(K, 64)), 256, 0, stream>>>(x, rows, M, K, ldx, xT, L.ldt);
-  u8_prepare_dyT_kernel<<<dim3(L.nslab, L.tiles_n), 256, 0, stream>>>(dy, M, N, ldy, L.nslab, img);
+  if (dy) u8_prepare_dyT_kernel<<<dim3(L.nslab, L.tiles_n), 256, 0, stream>>>(dy, M, N, ldy, L.nslab, img);
   int rc = check_launch("u8 weight-gradient pre-passes");
   if (rc) return rc;
   static bool attr = false;

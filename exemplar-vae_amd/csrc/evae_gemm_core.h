@@ -19,7 +19,10 @@ enum { EPI_LINEAR = 0, EPI_GATED = 1, EPI_GATE_BWD = 2, EPI_RAW = 3, EPI_RAW_GAT
        EPI_DIST_COLLECT = 6,   // rows with distance <= bias0[n] are appended to the candidate list of column n
        // exemplar prior at large latent sizes (evae_prior_gemm.hip): rows = exemplars, columns = queries, acc = c'.z'
        EPI_PRIOR_LSE = 7,      // per (row tile, column): max / sum exp / #masked of log N(z_n | c_m) over the tile's rows
-       EPI_PRIOR_P = 8 };      // out0[m][n] = bias1[n] exp(log N(z_n | c_m) - bias0[n])   (0 where masked)
+       EPI_PRIOR_P = 8,        // out0[m][n] = bias1[n] exp(log N(z_n | c_m) - bias0[n])   (0 where masked)
+       // EPI_GATE_BWD whose (dh, dg) leave as the three bf16 terms of [dh | dg]^T in the B-tile order of u8_gemm_kernel
+       // (csrc/evae_dense_u8.hip): the weight gradient of the byte-store layer reads them without a transposing pre-pass
+       EPI_GATE_BWD_IMG = 9 };
 
 
 // one K-slab of MFMAs: wave tile 64 x (32 NT) at rows wr*64.., cols wc*32*NT..

@@ -88,6 +88,9 @@ struct GemmArgs {
   const int64_t* pr_cidx;
   const float* pr_cst_dev;
   const unsigned* skip_flag;
+  // EPI_GATE_BWD_IMG: image base, K-slabs (of 32 rows) per column tile, row index of this launch's row 0 in the merged buffer
+  unsigned short* img;
+  int img_nslab, img_mbase;
 };
 
 // Out-of-range chunks are loaded from a clamped, always-mapped address and zeroed LATER, when the
@@ -816,6 +819,59 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
               g.out0[o] = acc[mt][0][r];
               g.out0[o + plane] = acc[mt][NT - 1][r];
             }
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_GATE_BWD_IMG) {
+    // dh = v s, dg = v (h s)(1 - s) as in EPI_GATE_BWD; column cc of the merged [dh | dg] buffer is n (dh) / N + n (dg).  A lane
+    // holds four consecutive rows per r-group: as bf16 terms they are 8 bytes of one 16-byte slot of the image
+    //   img[((cc >> 7) * nslab + (row >> 5)) * 3 + p][cc & 127][slot (row & 31) >> 3, XOR-swizzled][row & 7]
+    // (truncation split: w0 = top 8 significant bits, w1 of w - w0, w2 the rest: exact).  Rows must come in aligned fours
+    // (M % 4 == 0, img_mbase % 4 == 0: checked by the host).
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      if (n >= g.N) continue;
+      float go[MT][16], sv[MT][16];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const size_t oe = (size_t)(m < g.M ? m : 0) * g.N + n;
+          go[mt][r] = g.e0[oe];
+          sv[mt][r] = g.e1[oe];
+        }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ml = m0 + wr * 32 * MT + mt * 32 + 8 * j + 4 * lh;      // first of four rows (local)
+          if (ml >= g.M) continue;
+          const int gm = ml + g.img_mbase, slab = gm >> 5, mi = gm & 31;
+#pragma unroll
+          for (int which = 0; which < 2; ++which) {
+            const int cc = which ? g.N + n : n;
+            const int c = cc & 127;
+            unsigned t0[2] = {0u, 0u}, t1[2] = {0u, 0u}, t2[2] = {0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int r = 4 * j + i;
+              const float v = acc[mt][nt][r], s_ = sv[mt][r];
+              const float w = which ? v * go[mt][r] * (1.0f - s_) : v * s_;
+              const unsigned u0 = __float_as_uint(w) & 0xFFFF0000u;
+              const float r1 = w - __uint_as_float(u0);
+              const unsigned u1 = __float_as_uint(r1) & 0xFFFF0000u;
+              const float r2 = r1 - __uint_as_float(u1);
+              const unsigned u2 = __float_as_uint(r2);
+              const int sh = 16 * (i & 1);
+              t0[i >> 1] |= (u0 >> 16) << sh; t1[i >> 1] |= (u1 >> 16) << sh; t2[i >> 1] |= (u2 >> 16) << sh;
+            }
+            char* base = reinterpret_cast<char*>(g.img) + ((size_t)((cc >> 7) * g.img_nslab + slab) * 3 * 128 + c) * 64 +
+                         ((((mi >> 3) ^ ((c >> 2) & 3))) << 4) + ((mi & 7) << 1);
+            *reinterpret_cast<uint2*>(base) = make_uint2(t0[0], t0[1]);
+            *reinterpret_cast<uint2*>(base + 128 * 64) = make_uint2(t1[0], t1[1]);
+            *reinterpret_cast<uint2*>(base + 2 * 128 * 64) = make_uint2(t2[0], t2[1]);
           }
         }
     }

@@ -31,9 +31,13 @@ ACT_NONE, ACT_SIGMOID, ACT_HARDTANH = ops.ACT_NONE, ops.ACT_SIGMOID, ops.ACT_HAR
 # generation of the staging rows behind a dataset buffer (keyed by its address): a second fused forward overwrites the rows a
 # pending backward would gather its batch from -- the backward checks that its forward was the last one to stage
 _STAGE_GEN = {}
+_ZEROED = {}      # workspace name -> (address, shape) it was last zero-filled for
 
 # schedule switches (bit mask; tools/chain_bench.sh sweeps them): 1 = the prior's dz' / dlogvar reduction on the side stream,
-# 2 = the finish launch of encoder layer 2's weight gradient on the side stream.  Both OFF: measured at config 2 (r02), 0 ->
+# 2 = the finish launch of encoder layer 2's weight gradient on the side stream, 4 = byte store: the layer-2 data gradient writes
+# the three-term bf16 tile images of [dh | dg]^T itself (evae_dense_bwd_data_img) instead of an fp32 buffer + transposing pre-pass:
+# measured 0.7741 vs 0.7754 ms -- the 38 us pre-pass goes, but the epilogue's 8-byte scattered stores cost the GEMM +15 us and the
+# weight-gradient GEMM reads the images +11 us slower; kept as an option, off.  1 and 2 OFF: measured at config 2 (r02), 0 ->
 # 0.975 ms/step, 1 -> 1.002, 2 -> 1.085, 3 -> 1.076 -- a launch that runs beside a CU-filling GEMM costs that GEMM more than
 # the launch saves on the main stream.
 SCHED = int(os.environ.get("EVAE_SCHED", "0"))
@@ -322,7 +326,33 @@ class VaeExactLoss(torch.autograd.Function):
         kd = _K(dev, stream=side, suffix="_side")
         dmean_all = torch.empty((Mp, Z), **f32)
         dq2 = torch.empty((Mp, 2 * H), **f32)                              # [dh2 | dg2] for all C + B rows
-        dq1 = torch.empty((Mp, 2 * H), **f32)
+        # byte store: encoder layer 1's (dh, dg) leave the layer-2 data gradient as the bf16 tile images its weight gradient
+        # reads (no fp32 [Mp x 2H] buffer, no transposing pre-pass); needs row blocks in aligned fours
+        img_mode = (data_ext.dtype == torch.uint8 and Cl % 4 == 0 and B % 4 == 0 and bool(SCHED & 4))
+        dq1 = None if img_mode else torch.empty((Mp, 2 * H), **f32)
+        if img_mode:
+            nb_w1 = lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D)
+            ws_w1 = k.ws("wgrad_u8", nb_w1)
+            key = (ws_w1.data_ptr(), Mp, H, D)
+            if _ZEROED.get("wgrad_u8") != key:       # image bytes no row / column maps to must be zero: once per buffer and shape
+                ws_w1.zero_()
+                _ZEROED["wgrad_u8"] = key
+            off_img, nslab_img = C.c_size_t(0), C.c_int(0)
+            _lib.check(lib.evae_dense_bwd_weight_u8_images(Mp, 2 * H, D, C.byref(off_img), C.byref(nslab_img)), "u8_images")
+            img_ptr = ws_w1.data_ptr() + off_img.value
+
+            def l2_dgrad(kk, M, ob, m_base):
+                ops.probed("dense_bwd_data M=%d N=%d+%d K=%d (gate-backward epilogue -> bf16 tile images)" % (M, H, H, H),
+                           2.0 * M * 2 * H * H,
+                           lambda: _lib.check(lib.evae_dense_bwd_data_img(
+                               _vp(dq2.data_ptr() + ob * 2 * H), _vp(w2h), _vp(dq2.data_ptr() + ob * 2 * H + 4 * H), _vp(w2g), M, H,
+                               2 * H, H, _vp(A1.data_ptr() + ob * H), _vp(s1.data_ptr() + ob * H), _vp(img_ptr), nslab_img.value,
+                               m_base, kk.st), "bwd_data_img"))
+        else:
+            def l2_dgrad(kk, M, ob, m_base):
+                kk.bwd_data(dq2.data_ptr() + ob * 2 * H, w2h, dq2.data_ptr() + ob * 2 * H + 4 * H, w2g, M, H, 2 * H, H,
+                            A1.data_ptr() + ob * H, s1.data_ptr() + ob * H, dq1.data_ptr() + ob * 2 * H,
+                            dq1.data_ptr() + ob * 2 * H + 4 * H, 2 * H)
         dpx = torch.empty((B, D), **f32)
         dp2 = torch.empty((B, 2 * H), **f32)                               # [dh | dg] of decoder layer 2
         dp1 = torch.empty((B, 2 * H), **f32)
@@ -372,7 +402,7 @@ class VaeExactLoss(torch.autograd.Function):
         dz_ready = torch.cuda.Event(); dz_ready.record()
         if Cl > 0:
             k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H)
-            k.bwd_data(dq2, w2h, dq2.data_ptr() + 4 * H, w2g, Cl, H, 2 * H, H, A1, s1, dq1, dq1.data_ptr() + 4 * H, 2 * H)
+            l2_dgrad(k, Cl, 0, 0)
         batch_rows_done = torch.cuda.Event()
         g_plv = gslot("plv", 1)
         g_wp = gslot("wp", D, H); g_bp = gslot("bp", D)
@@ -395,9 +425,7 @@ class VaeExactLoss(torch.autograd.Function):
             # head and encoder layer 2, batch rows
             kd.bwd_data(dmean_all.data_ptr() + off * Z, wm, dlvp, wl, B, Z, Z, H, A2.data_ptr() + off * H,
                         s2.data_ptr() + off * H, dq2.data_ptr() + off * 2 * H, dq2.data_ptr() + off * 2 * H + 4 * H, 2 * H)
-            kd.bwd_data(dq2.data_ptr() + off * 2 * H, w2h, dq2.data_ptr() + off * 2 * H + 4 * H, w2g, B, H, 2 * H, H,
-                        A1.data_ptr() + off * H, s1.data_ptr() + off * H, dq1.data_ptr() + off * 2 * H,
-                        dq1.data_ptr() + off * 2 * H + 4 * H, 2 * H)
+            l2_dgrad(kd, B, off, Cl)
             batch_rows_done.record()
 
         g_wm = gslot("wm", Z, H); g_bm = gslot("bm", Z)

@@ -669,3 +669,43 @@ def test_weight_gradient_on_the_uint8_store(ops, M, K, N, R):
     assert rel(db.cpu().numpy(), dy.astype(np.float64).sum(0)) < 2e-6
     dw32, db32 = ops._bwd_weight(dev(dy), dev(q.astype(np.float32) / 255.0), dev(rows), K)
     assert rel(dw.cpu().numpy(), dw32.cpu().numpy()) < 2e-6
+
+
+def test_data_gradient_that_writes_bf16_tile_images(ops):
+    """evae_dense_bwd_data_img + evae_dense_bwd_weight_u8(dy = NULL): the layer-above data gradient leaves (dh, dg) as the
+    three-term bf16 tile images the byte-store weight gradient reads -- same dW / db as the fp32 buffer + pre-pass route,
+    with the rows arriving in two launches (exemplar rows, batch rows)."""
+    import ctypes as C
+    from evae import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(12)
+    M1, M2, H, D, R = 600, 100, 300, 784, 2000
+    M = M1 + M2
+    q = (rs.randint(0, 256, (R, D)) * (rs.random_sample((R, D)) < 0.3)).astype(np.uint8)
+    rows = dev(rs.randint(0, R, size=M).astype(np.int64))
+    store = torch.zeros(R * D + 64, dtype=torch.uint8, device="cuda"); xs = store[:R * D].view(R, D); xs.copy_(torch.from_numpy(q))
+    dq2 = dev((rs.standard_normal((M, 2 * H)) * 0.1).astype(np.float32))
+    w2h = dev((rs.standard_normal((H, H)) * 0.1).astype(np.float32)); w2g = dev((rs.standard_normal((H, H)) * 0.1).astype(np.float32))
+    a1 = dev(rs.standard_normal((M, H)).astype(np.float32)); s1 = dev(rs.random_sample((M, H)).astype(np.float32))
+    # route A: fp32 [dh | dg] buffer, then the weight gradient with its transposing pre-pass
+    dq1 = torch.empty((M, 2 * H), device="cuda")
+    ops._bwd_data(dq2.data_ptr(), w2h, dq2.data_ptr() + 4 * H, w2g, M, H, 2 * H, "cuda", out_prev=a1, s_prev=s1, out=dq1,
+                  dg_ptr=dq1.data_ptr() + 4 * H, ldo=2 * H)
+    dwA, dbA = ops.dense_bwd_weight_u8(dq1, xs, rows, 1.0 / 255.0, ws_name="t_wgrad_a")
+    # route B: tile images written by the data gradient itself
+    nb = lib.evae_dense_bwd_weight_u8_workspace_bytes(M, 2 * H, D)
+    ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    off, nslab = C.c_size_t(0), C.c_int(0)
+    _lib.check(lib.evae_dense_bwd_weight_u8_images(M, 2 * H, D, C.byref(off), C.byref(nslab)), "images")
+    img = ws.data_ptr() + off.value
+    st = ops._stream()
+    for m0, mm in ((0, M1), (M1, M2)):
+        _lib.check(lib.evae_dense_bwd_data_img(C.c_void_p(dq2.data_ptr() + 4 * m0 * 2 * H), ops._p(w2h),
+                                               C.c_void_p(dq2.data_ptr() + 4 * m0 * 2 * H + 4 * H), ops._p(w2g), mm, H, 2 * H, H,
+                                               C.c_void_p(a1.data_ptr() + 4 * m0 * H), C.c_void_p(s1.data_ptr() + 4 * m0 * H),
+                                               C.c_void_p(img), nslab.value, m0, st), "bwd_data_img")
+    dwB = torch.empty((2 * H, D), device="cuda"); dbB = torch.empty(2 * H, device="cuda")
+    _lib.check(lib.evae_dense_bwd_weight_u8(None, M, 2 * H, 2 * H, ops._p(xs), ops._p(rows), D, D, 1.0 / 255.0, ops._p(dwB),
+                                            ops._p(dbB), ops._p(ws), ws.numel(), st), "bwd_weight_u8")
+    assert rel(dwB.cpu().numpy(), dwA.cpu().numpy()) < 2e-6
+    assert rel(dbB.cpu().numpy(), dbA.cpu().numpy()) < 2e-6
