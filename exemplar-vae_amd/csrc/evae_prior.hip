@@ -296,6 +296,7 @@ __global__ __launch_bounds__(128 * WR) void prior_fwd_mfma_kernel(
   float* red = mu_s + 64;                    // [16]
   float* zmx = red + 16;                     // [2] (+6 padding)
   long long* ci_s = reinterpret_cast<long long*>(zmx + 8);             // [2][128]
+  float* Es1 = reinterpret_cast<float*>(ci_s + 2 * FE);                // [128][KS2] second exemplar tile (pipelined loop)
   // the cross-wave combine buffer [4][128][3] is only needed after the last tile: it reuses the exemplar tile, which
   // keeps the block at 48 KB of LDS -- three blocks (24 waves) per CU instead of two, and it is waves of OTHER blocks
   // that fill a SIMD while one block sits in its exp / log-sum-exp epilogue
@@ -474,7 +475,166 @@ __global__ __launch_bounds__(128 * WR) void prior_fwd_mfma_kernel(
     }
   }
   };
-  if (slow_block) tile_loop(std::true_type{}); else tile_loop(std::false_type{});
+  // Unmasked calls with several tiles per block (the IWAE evaluator: thousands of importance samples against every exemplar)
+  // run the loop SOFTWARE-PIPELINED: the products of tile t+1 are issued into a second accumulator set while the epilogue of
+  // tile t (sub, max, fma, exp2, add per pair -- as much VALU time as the products take on the matrix pipe) runs on the
+  // first, from a second exemplar buffer in LDS; one barrier per tile.  Only the last tile of the range can be ragged.
+  auto pipe_loop = [&]() {
+    auto mfma_tile = [&](f32x16_t (&a)[2], const float* E) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { a[0][r] = 0.f; a[1][r] = 0.f; }
+      const float* ea = E + (wr * 32 + l31) * KS2 + lh * 4;
+      const float* qb = Qs + (wc * 64 + l31) * KS2 + lh * 4;
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+        const float4 x = *reinterpret_cast<const float4*>(ea + kg * 8);
+        const float4 b0 = *reinterpret_cast<const float4*>(qb + kg * 8);
+        const float4 b1 = *reinterpret_cast<const float4*>(qb + 32 * KS2 + kg * 8);
+        a[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, b0.x, a[0], 0, 0, 0);
+        a[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, b1.x, a[1], 0, 0, 0);
+        a[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, b0.y, a[0], 0, 0, 0);
+        a[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, b1.y, a[1], 0, 0, 0);
+        a[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, b0.z, a[0], 0, 0, 0);
+        a[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, b1.z, a[1], 0, 0, 0);
+        a[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, b0.w, a[0], 0, 0, 0);
+        a[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, b1.w, a[1], 0, 0, 0);
+      }
+    };
+    // online log-sum-exp update from one tile's products; branch-free when the whole tile exists
+    auto epilogue = [&](const f32x16_t (&a)[2], const float* cnp, const int e0) {
+      float hc[16];
+      unsigned live = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int el = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        hc[r] = 0.5f * cnp[el];
+        if (e0 + el < C) live |= 1u << r;
+      }
+      const bool full = e0 + FE <= C;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float v[16];
+        float vmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[r] = a[nt][r] - hc[r];
+          vmax = fmaxf(vmax, (full || ((live >> r) & 1u)) ? v[r] : -INFINITY);
+        }
+        const float newm = fmaxf(um[nt], vmax - hz[nt]);
+        if (newm != -INFINITY) {                  // (a ragged tile can leave a lane group without a live row)
+          ssum[nt] *= fast_exp2((um[nt] - newm) * kLog2e);      // um == -inf -> 0 * 0
+          um[nt] = newm;
+          const float mk = -(newm + hz[nt]) * kLog2e;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = fast_exp2(fmaf(v[r], kLog2e, mk));
+            ssum[nt] += (full || ((live >> r) & 1u)) ? e : 0.f;
+          }
+        }
+      }
+    };
+    // the same for a tile that is known to be whole: straight-line code, no predicates
+    auto epilogue_full = [&](const f32x16_t (&a)[2], const float* cnp) {
+      float hc[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hc[r] = 0.5f * cnp[wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float v[16];
+        float vmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[r] = a[nt][r] - hc[r];
+          vmax = fmaxf(vmax, v[r]);
+        }
+        const float newm = fmaxf(um[nt], vmax - hz[nt]);
+        ssum[nt] *= fast_exp2((um[nt] - newm) * kLog2e);        // um == -inf -> 0 * 0
+        um[nt] = newm;
+        const float mk = -(newm + hz[nt]) * kLog2e;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ssum[nt] += fast_exp2(fmaf(v[r], kLog2e, mk));
+      }
+    };
+    f32x16_t accA[2], accB[2];
+    float* Eb[2] = {Es, Es1};
+    // tile tile_begin: staged and multiplied up front
+    store_tile(Eb[0], rv, true);
+    __syncthreads();
+    if (tile_begin + 1 < tile_end) load_tile(centres, (tile_begin + 1) * FE, C, rv);
+    row_norms(Eb[0], cn);
+    mfma_tile(accA, Eb[0]);
+    // one pipelined step: tile t (whole, products in `cur`) gets its epilogue while tile t+1 (exists) is multiplied into `nxt`
+    auto step = [&](f32x16_t (&cur)[2], f32x16_t (&nxt)[2], const int t) {
+      const int pb = (t - tile_begin) & 1;
+      store_tile(Eb[pb ^ 1], rv, true);
+      __syncthreads();           // tile t+1 is staged; the norms of tile t are complete; every wave is done with buffer pb^1's old tile
+      if (t + 2 < tile_end) load_tile(centres, (t + 2) * FE, C, rv);
+      row_norms(Eb[pb ^ 1], cn + (pb ^ 1) * FE);
+      // From here on ONE basic block in which the 8 KG matrix instructions of tile t+1 and the epilogue of tile t (16 x sub /
+      // max, the rescale, 32 x fma / exp2 / add) alternate instruction by instruction: an MFMA occupies the matrix pipe for 64
+      // cycles, and what the wave issues behind it runs on the vector ALU meanwhile.  The order is pinned with scheduling
+      // barriers (the machine scheduler otherwise clusters the MFMAs -- into two DEPENDENT chains -- and appends the VALU work).
+      const float* cnp = cn + pb * FE;
+      const float* ea = Eb[pb ^ 1] + (wr * 32 + l31) * KS2 + lh * 4;
+      const float* qb = Qs + (wc * 64 + l31) * KS2 + lh * 4;
+      float hc[16], v0[16], v1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hc[r] = 0.5f * cnp[wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+      float4 fa = *reinterpret_cast<const float4*>(ea), fb0 = *reinterpret_cast<const float4*>(qb),
+             fb1 = *reinterpret_cast<const float4*>(qb + 32 * KS2);
+      float4 ga = fa, gb0 = fb0, gb1 = fb1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { nxt[0][r] = 0.f; nxt[1][r] = 0.f; }
+      float vmax0 = -INFINITY, vmax1 = -INFINITY, mk0 = 0.f, mk1 = 0.f;
+      constexpr int NS = 8 * KG, NP = 33, PPS = (NP + NS - 1) / NS;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int kg = i >> 3, j = i & 7;
+        if (j == 0 && kg + 1 < KG) {             // fragments of the next k-group, one group ahead
+          ga = *reinterpret_cast<const float4*>(ea + (kg + 1) * 8);
+          gb0 = *reinterpret_cast<const float4*>(qb + (kg + 1) * 8);
+          gb1 = *reinterpret_cast<const float4*>(qb + 32 * KS2 + (kg + 1) * 8);
+        }
+        const float av = (j >> 1) == 0 ? fa.x : (j >> 1) == 1 ? fa.y : (j >> 1) == 2 ? fa.z : fa.w;
+        const float4 fb = (j & 1) ? fb1 : fb0;
+        const float bv = (j >> 1) == 0 ? fb.x : (j >> 1) == 1 ? fb.y : (j >> 1) == 2 ? fb.z : fb.w;
+        nxt[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, nxt[j & 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = i * PPS; p < (i + 1) * PPS; ++p) {
+          if (p < 16) {
+            v0[p] = cur[0][p] - hc[p]; v1[p] = cur[1][p] - hc[p];
+            vmax0 = fmaxf(vmax0, v0[p]); vmax1 = fmaxf(vmax1, v1[p]);
+          } else if (p == 16) {
+            const float n0 = fmaxf(um[0], vmax0 - hz[0]), n1 = fmaxf(um[1], vmax1 - hz[1]);
+            ssum[0] *= fast_exp2((um[0] - n0) * kLog2e); ssum[1] *= fast_exp2((um[1] - n1) * kLog2e);     // um == -inf -> 0 * 0
+            um[0] = n0; um[1] = n1;
+            mk0 = -(n0 + hz[0]) * kLog2e; mk1 = -(n1 + hz[1]) * kLog2e;
+          } else if (p < NP) {
+            ssum[0] += fast_exp2(fmaf(v0[p - 17], kLog2e, mk0));
+            ssum[1] += fast_exp2(fmaf(v1[p - 17], kLog2e, mk1));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (j == 7) { fa = ga; fb0 = gb0; fb1 = gb1; }
+      }
+    };
+    int t = tile_begin;
+    for (; t + 2 < tile_end; t += 2) {
+      step(accA, accB, t);
+      step(accB, accA, t + 1);
+    }
+    bool last_in_b = false;
+    if (t + 1 < tile_end) { step(accA, accB, t); ++t; last_in_b = true; }
+    __syncthreads();             // the norms of the last tile are complete
+    if (last_in_b) epilogue(accB, cn + ((t - tile_begin) & 1) * FE, t * FE);
+    else epilogue(accA, cn + ((t - tile_begin) & 1) * FE, t * FE);
+    __syncthreads();             // comb aliases the first exemplar buffer
+  };
+  if (!masked && !slow_block && tile_end - tile_begin >= 2) pipe_loop();
+  else if (slow_block) tile_loop(std::true_type{});
+  else tile_loop(std::false_type{});
   // back to squared distances for the combine below: d2_min = -2 u_max  (no live exemplar: +inf)
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) dmin[nt] = (um[nt] == -INFINITY) ? INFINITY : fmaxf(-2.0f * um[nt], 0.f);
@@ -521,7 +681,7 @@ static int launch_prior_mfma_w(const float* z, int B, const float* centres, int 
                                const int64_t* z_idx, const int64_t* c_idx, int ns_max, float* pm, float* ps, float* pn,
                                int* ns_out, hipStream_t stream) {
   constexpr int KS2 = KG * 8 + 4, FE = 32 * WR;
-  const size_t lds = (size_t)((128 + FE) * KS2 + 128 + 2 * FE + 64 + 64 + 16 + 8) * sizeof(float) + 2 * FE * sizeof(long long);
+  const size_t lds = (size_t)((128 + 2 * FE) * KS2 + 128 + 2 * FE + 64 + 64 + 16 + 8) * sizeof(float) + 2 * FE * sizeof(long long);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)prior_fwd_mfma_kernel<KG, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
