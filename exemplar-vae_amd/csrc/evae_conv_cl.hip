@@ -144,8 +144,11 @@ extern "C" int evae_conv2d_cl_supported(const evae_conv_desc_t* d, int what, int
   return d->C % 4 == 0 && ctot % 4 == 0;
 }
 
-// channels per pixel of the merged gradient buffer: ctot rounded up to a multiple of 32 (zero padding)
-extern "C" int evae_conv2d_cl_dy_stride(int ctot) { return (ctot + 31) / 32 * 32; }
+// channels per pixel of the merged gradient buffer: ctot itself when rows stay 16-byte aligned (the contraction pads a
+// pixel to a multiple of 32 channels in the K index only, reading the missing ones as zero), else ctot rounded up to a
+// multiple of 32 with real zero padding
+extern "C" int evae_conv2d_cl_dy_stride(int ctot) { return ctot % 4 == 0 ? ctot : (ctot + 31) / 32 * 32; }
+static int cl_ldv(int ldy) { return (ldy + 31) / 32 * 32; }      // K-extent of one pixel of the gradient buffer
 
 extern "C" size_t evae_conv2d_cl_workspace_bytes(const evae_conv_desc_t* d, int what, int gated) {
   if (!d) return 256;
@@ -165,8 +168,8 @@ extern "C" size_t evae_conv2d_cl_workspace_bytes(const evae_conv_desc_t* d, int 
   if (what == 0) return (gated ? 2 : 1) * wbytes + 256;
   if (what == 1) {   // one permuted copy [taps][ldy][C], class slices are disjoint parts of it
     const int ctot1 = d->Co * (gated ? 2 : 1);
-    const size_t plain = (size_t)d->KH * d->KW * evae_conv2d_cl_dy_stride(ctot1) * d->C;
-    const size_t paired = (size_t)d->KH * (d->KW + 1) * evae_conv2d_cl_dy_stride(ctot1) * 64;   // pixel-pair form (C = 32)
+    const size_t plain = (size_t)d->KH * d->KW * cl_ldv(ctot1) * d->C;
+    const size_t paired = (size_t)d->KH * (d->KW + 1) * cl_ldv(ctot1) * 64;   // pixel-pair form (C = 32)
     return align_up(std::max(plain, paired) * sizeof(float), 256) + 256;
   }
   // weight gradient: split-K partial planes [nz][ctot][K + 1]
@@ -183,10 +186,10 @@ extern "C" size_t evae_conv2d_cl_workspace_bytes(const evae_conv_desc_t* d, int 
   return align_up(best, 256) + 256;
 }
 
-extern "C" int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, const float* wh, const float* bh,
+static int cl_fwd_impl(const float* x, const evae_conv_desc_t* d, const float* wh, const float* bh,
                                   const float* wg, const float* bg, int act, float act_lo, float act_hi,
                                   float* out, float* save_h, float* save_s, void* ws, size_t ws_bytes,
-                                  evae_stream_t stream_) {
+                                  evae_stream_t stream_, const float* residual) {
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(d && x && wh && out, "conv2d_cl_fwd: null pointer");
   const bool gated = wg != nullptr;
@@ -266,6 +269,7 @@ extern "C" int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, con
       rc = launch_gemm_w<true, true, EPI_GATED, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_fwd(gated)");
     } else {
       g.out0 = out + oo; g.out1 = save_h ? save_h + oo : nullptr;    // pre-activation when requested
+      g.e0 = residual ? residual + oo : nullptr;                     // residual block: out = conv(x) + residual
       if (d->Co <= 64) rc = launch_gemm_w<true, true, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_fwd");
       else rc = launch_gemm_w<true, true, EPI_LINEAR, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_fwd");
     }
@@ -274,10 +278,27 @@ extern "C" int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, con
   return EVAE_OK;
 }
 
+extern "C" int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, const float* wh, const float* bh,
+                                  const float* wg, const float* bg, int act, float act_lo, float act_hi,
+                                  float* out, float* save_h, float* save_s, void* ws, size_t ws_bytes,
+                                  evae_stream_t stream_) {
+  return cl_fwd_impl(x, d, wh, bh, wg, bg, act, act_lo, act_hi, out, save_h, save_s, ws, ws_bytes, stream_, nullptr);
+}
+
+// out = conv(a, w) + b + residual: the forward of a fully_conv residual block (a = ELU(x), residual = x; models/fully_conv.py:13-23)
+extern "C" int evae_conv2d_cl_fwd_res(const float* a, const evae_conv_desc_t* d, const float* w, const float* b,
+                                      const float* residual, float* out, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  EVAE_REQUIRE(d && residual && d->C == d->Co && d->stride == 1 && 2 * d->pad + 1 == d->KH && d->KH == d->KW,
+               "conv2d_cl_fwd_res: a residual block keeps the tensor shape");
+  EVAE_REQUIRE(!cl_patch_mode(d), "conv2d_cl_fwd_res: thin layers are not residual blocks");
+  return cl_fwd_impl(a, d, w, b, nullptr, nullptr, EVAE_ACT_NONE, 0.f, 0.f, out, nullptr, nullptr, ws, ws_bytes, stream_, residual);
+}
+
 // dy: [N][OH][OW][ldy], ldy = evae_conv2d_cl_dy_stride(ctot): channels [0, Co) = dh, [Co, 2Co) = dg (gated), the rest
 // zero; dx: [N][H][W][C].  One GEMM per stride-parity class, contraction over (tap of the class, buffer channel).
-extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const float* wg, const evae_conv_desc_t* d,
-                                       float* dx, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+static int cl_bwd_data_impl(const float* dy, const float* wh, const float* wg, const evae_conv_desc_t* d,
+                            float* dx, void* ws, size_t ws_bytes, evae_stream_t stream_, const float* residual,
+                            const float* elu_out) {
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(d && dy && wh && dx, "conv2d_cl_bwd_data: null pointer");
   const bool gated = wg != nullptr;
@@ -286,7 +307,7 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
   int OH, OW;
   cl_out_dims(d, &OH, &OW);
   const int taps = d->KH * d->KW, s = d->stride, Co = d->Co, C = d->C;
-  const int ldy = evae_conv2d_cl_dy_stride(Co * (gated ? 2 : 1));
+  const int ldy = evae_conv2d_cl_dy_stride(Co * (gated ? 2 : 1)), ldv = cl_ldv(ldy);
   float* wp = (float*)ws;
   if (C == 32 && (s == 1 || s == 2) && d->W % 2 == 0 && d->KH * (d->KW + 1) <= 64) {
     // A 32-column result would leave half of the 64-wide tile idle.  Two x-adjacent output pixels (x = 2 rx + b) share
@@ -334,13 +355,13 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
       }
       const unsigned tbias = (unsigned)(-tmin);
       for (int u = 0; u < pt.n; ++u) cv.tsoff[u] += (int)tbias;
-      const size_t cls = (size_t)pt.n * ldy * 64;
+      const size_t cls = (size_t)pt.n * ldv * 64;
       float* wc = wp + usedp;
       usedp += cls;
-      cl_permute_dgrad_pair_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, taps, ldy, pt, wc);
+      cl_permute_dgrad_pair_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, taps, ldv, pt, wc);
       int rc = check_launch("cl_permute_dgrad_pair_kernel");
       if (rc) return rc;
-      cv.Cg = ldy; cv.creal = ldy; cv.ps = ldy; cv.ntaps = pt.n;
+      cv.Cg = ldv; cv.creal = ldy; cv.ps = ldy; cv.ntaps = pt.n;
       cv.RH = RH; cv.RW = W2; cv.IH = OH; cv.IW = OW;
       cv.rs = 1; cv.rsx = (s == 1) ? 2 : 1; cv.roy = 0; cv.rox = 0;
       cv.OH2 = d->H; cv.OW2 = W2; cv.os = s; cv.osx = 1; cv.ooy = py; cv.oox = 0;   // output rows in units of pixel pairs
@@ -349,7 +370,7 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
       cv.bias = 0;
       g.B[0] = wc;
       g.lda[0] = ldy; g.ldb[0] = 64;
-      g.Kc[0] = pt.n * ldy; g.npairs = 1;
+      g.Kc[0] = pt.n * ldv; g.npairs = 1;
       g.N = 64; g.ldo = 64;
       g.ksplit = 0;
       const int per = cl_images_per_pass(d, OH, OW, C, ldy);
@@ -399,13 +420,13 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
       const unsigned tbias = (unsigned)(-tmin);
       for (int j = 0; j < tl.n; ++j) cv.tsoff[j] += (int)tbias;
       const int RH = (d->H - py + s - 1) / s, RW = (d->W - px + s - 1) / s;
-      const size_t cls = (size_t)tl.n * ldy * C;
+      const size_t cls = (size_t)tl.n * ldv * C;
       float* wc = wp + used;
       used += cls;
-      cl_permute_dgrad_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, C, taps, ldy, tl, wc);
+      cl_permute_dgrad_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, C, taps, ldv, tl, wc);
       int rc = check_launch("cl_permute_dgrad_kernel");
       if (rc) return rc;
-      cv.Cg = ldy; cv.creal = ldy; cv.ps = ldy; cv.ntaps = tl.n;
+      cv.Cg = ldv; cv.creal = ldy; cv.ps = ldy; cv.ntaps = tl.n;
       cv.RH = RH; cv.RW = RW; cv.IH = OH; cv.IW = OW;
       cv.rs = 1; cv.rsx = 1; cv.roy = 0; cv.rox = 0;
       cv.OH2 = d->H; cv.OW2 = d->W; cv.os = s; cv.osx = s; cv.ooy = py; cv.oox = px;
@@ -414,7 +435,7 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
       cv.bias = 0;
       g.B[0] = wc;
       g.lda[0] = ldy; g.ldb[0] = C;
-      g.Kc[0] = tl.n * ldy; g.npairs = 1;
+      g.Kc[0] = tl.n * ldv; g.npairs = 1;
       g.N = C; g.ldo = C;
       g.ksplit = 0;
       const int per = cl_images_per_pass(d, OH, OW, C, ldy);
@@ -422,6 +443,8 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
         const int nn = std::min(per, d->N - n0);
         g.A[0] = dy + (size_t)n0 * OH * OW * ldy - tbias / 4;
         g.out0 = dx + (size_t)n0 * d->H * d->W * C;
+        g.e0 = residual ? residual + (size_t)n0 * d->H * d->W * C : nullptr;      // residual block: dx = dy + ELU'(x) * acc
+        g.e1 = elu_out ? elu_out + (size_t)n0 * d->H * d->W * C : nullptr;
         g.M = nn * RH * RW;
         if (C <= 64) rc = launch_gemm_w<true, false, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data");
         else rc = launch_gemm_w<true, false, EPI_LINEAR, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data");
@@ -429,6 +452,20 @@ extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const f
       }
     }
   return EVAE_OK;
+}
+
+extern "C" int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const float* wg, const evae_conv_desc_t* d,
+                                       float* dx, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  return cl_bwd_data_impl(dy, wh, wg, d, dx, ws, ws_bytes, stream_, nullptr, nullptr);
+}
+
+// dx = residual + ELU'(x) * conv_transpose(dy, w) with ELU'(x) = (a > 0 ? 1 : a + 1), a = ELU(x): the data gradient of a
+// fully_conv residual block in one launch (residual = the upstream gradient itself, un-padded [N][H][W][C])
+extern "C" int evae_conv2d_cl_bwd_data_res(const float* dy, const float* w, const evae_conv_desc_t* d, const float* residual,
+                                           const float* elu_out, float* dx, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  EVAE_REQUIRE(d && residual && elu_out && d->C == d->Co && d->stride == 1 && d->C != 32,
+               "conv2d_cl_bwd_data_res: residual block geometry (C == Co, stride 1, C != 32)");
+  return cl_bwd_data_impl(dy, w, nullptr, d, dx, ws, ws_bytes, stream_, residual, elu_out);
 }
 
 // dy as above ([..][ldy] per pixel); x: [N][H][W][C]; dw: [ctot][C][KH][KW] (nn.Conv2d layout, h rows then g rows), db: [ctot]

@@ -913,7 +913,23 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
       if (n >= g.N) continue;
       const float bias = (EPI == EPI_LINEAR && g.bias0) ? g.bias0[n] : 0.f;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        // residual blocks of fully_conv (models/fully_conv.py:13-23: x + conv(ELU(x))): e1 = ELU(x) of the block whose data
+        // gradient this is -> times ELU'(x) = (a > 0 ? 1 : a + 1); e0 = the tensor added to the result (x forward, dy
+        // backward).  Both are fetched for the whole 32-row tile BEFORE the first store: stores to out0 may alias them as far
+        // as the compiler knows, so loads placed between the stores would run one at a time.
+        float ev0[16], ev1[16];
+        const bool extras = EPI == EPI_LINEAR && (g.e0 || g.e1);
+        if (extras) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const bool ok = m < g.M;
+            const size_t o = orow(ok ? m : m0) * g.ldo + n;
+            ev0[r] = (ok && g.e0) ? g.e0[o] : 0.f;
+            ev1[r] = (ok && g.e1) ? g.e1[o] : 1.f;
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -923,11 +939,14 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
           if (EPI == EPI_LINEAR) {
             const float pre = v + bias;
             if (g.out1) g.out1[o] = pre;
-            g.out0[o] = apply_act(pre, g.act, g.lo, g.hi);
+            float res = apply_act(pre, g.act, g.lo, g.hi);
+            if (extras) res = res * (ev1[r] > 0.f ? 1.0f : ev1[r] + 1.0f) + ev0[r];
+            g.out0[o] = res;
           } else {                                // EPI_RAW: partial plane [z][M][N]
             g.out0[(size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n] = v;
           }
         }
+      }
     }
   }
 }

@@ -183,6 +183,19 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
   if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
 }
 
+// ELU (alpha = 1) over a flat array: the activation in front of a fully_conv residual block's convolution
+__global__ void elu_fwd_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 4 <= n) {
+    float4 v = *reinterpret_cast<const float4*>(x + i);
+    v.x = v.x > 0.f ? v.x : expm1f(v.x); v.y = v.y > 0.f ? v.y : expm1f(v.y);
+    v.z = v.z > 0.f ? v.z : expm1f(v.z); v.w = v.w > 0.f ? v.w : expm1f(v.w);
+    *reinterpret_cast<float4*>(out + i) = v;
+  } else {
+    for (size_t j = i; j < n; ++j) out[j] = x[j] > 0.f ? x[j] : expm1f(x[j]);
+  }
+}
+
 // Bernoulli log-likelihood backward through the sigmoid that produced `mean`: d/dpre = d/dmean * mean * (1 - mean)
 __global__ void bernoulli_sigmoid_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                              const float* __restrict__ dout, int B, int D,
@@ -477,6 +490,14 @@ extern "C" int evae_batch_prologue_u8(const unsigned char* data, int64_t ldd, co
   batch_prologue_u8_kernel<<<(unsigned)cdiv(nq_img + nq_eps, (int64_t)256), 256, 0, (hipStream_t)s>>>(
       data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img);
   return check_launch("batch_prologue_u8");
+}
+
+extern "C" int evae_elu_fwd(const float* x, size_t n, float* out, evae_stream_t s) {
+  if (n == 0) return EVAE_OK;
+  EVAE_REQUIRE(x && out && (((uintptr_t)x | (uintptr_t)out) & 15) == 0, "elu_fwd: null or unaligned pointer");
+  const size_t nthreads = (n + 3) / 4;
+  elu_fwd_kernel<<<(unsigned)((nthreads + 255) / 256), 256, 0, (hipStream_t)s>>>(x, n, out);
+  return check_launch("elu_fwd");
 }
 
 extern "C" int evae_bernoulli_sigmoid_bwd(const float* x, const float* mean, const float* dout, int B, int D,

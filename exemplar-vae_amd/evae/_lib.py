@@ -74,6 +74,9 @@ SIGNATURES = {
     "evae_conv2d_cl_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _z, _p]),
     "evae_conv2d_cl_bwd_data": (_i, [_p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_conv2d_cl_bwd_weight": (_i, [_p, _p, _p, _i, _p, _p, _p, _z, _p]),
+    "evae_elu_fwd": (_i, [_p, _z, _p, _p]),
+    "evae_conv2d_cl_fwd_res": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_conv2d_cl_bwd_data_res": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_reparam_logq_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_reparam_logq_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_reparam_logq_bwd_hardtanh": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p]),

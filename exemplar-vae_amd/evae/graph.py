@@ -173,7 +173,9 @@ class GraphedTrainStep:
     def __call__(self, data, indices, beta):
         """One training step; returns a device tensor (loss, -RE, KL) valid until the next call."""
         if self.graph is None and self._calls == 0:
-            self.opt.enable_graph_mode(storage=[self.scal[1 + g:2 + g] for g in range(self.ngroups)])
+            # this graph's launches read the step size from ITS control block (another runner on the same optimizer has its own)
+            self._adam_tables["step_size"] = [self.scal[1 + g:2 + g] for g in range(self.ngroups)]
+            self.opt.enable_graph_mode(storage=self._adam_tables["step_size"])
         self.model._exemplar_indices_override = (self.rows, self.hi - self.lo)
         try:
             self._refresh(data, indices, beta)

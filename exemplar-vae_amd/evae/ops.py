@@ -618,6 +618,61 @@ class Conv2dFn(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+class ResBlockFn(torch.autograd.Function):
+    """x + conv2d(ELU(x), w) + b -- the residual block of models/fully_conv.py:13-23 on the channels-last kernels: ELU is one
+    elementwise launch (its output is the convolution's operand AND what the backward needs), the residual add rides in the
+    convolution's epilogue, and the block's data gradient dy + ELU'(x) * conv_transpose(dy, w) is ONE launch."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        lib = _lib.load()
+        _need_cuda(x, w)
+        x = _cl(x.float()); w = _f32(w)
+        d, OH, OW = _conv_desc(x, w, 1, (w.shape[2] - 1) // 2)
+        a = torch.empty_like(x, memory_format=CL)
+        _lib.check(lib.evae_elu_fwd(_p(x), x.numel(), _p(a), _stream()), "evae_elu_fwd")
+        out = torch.empty_like(x, memory_format=CL)
+        ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 0, 0), x.device)
+        _lib.check(lib.evae_conv2d_cl_fwd_res(_p(a), C.byref(d), _p(w), _p(b), _p(x), _p(out), _p(ws), ws.numel(), _stream()),
+                   "evae_conv2d_cl_fwd_res")
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(a, w)
+        ctx.cfg = (d, b is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        a, w = ctx.saved_tensors
+        d, has_b = ctx.cfg
+        dev = dout.device
+        dy = _cl(dout.float())
+        K = d.C * d.KH * d.KW
+        dw = torch.empty((d.Co, K), device=dev); db = torch.empty(d.Co, device=dev)
+        ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 2, 0), dev)
+        _lib.check(lib.evae_conv2d_cl_bwd_weight(_p(dy), _p(a), C.byref(d), 0, _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
+                   "evae_conv2d_cl_bwd_weight")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(a, memory_format=CL)
+            ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 1, 0), dev)
+            _lib.check(lib.evae_conv2d_cl_bwd_data_res(_p(dy), _p(w), C.byref(d), _p(dy), _p(a), _p(dx), _p(ws), ws.numel(),
+                                                       _stream()), "evae_conv2d_cl_bwd_data_res")
+        return dx, dw.reshape(w.shape), (db if has_b else None)
+
+
+def res_block_supported(x, w, stride, padding):
+    """ELU -> 3x3 'same' convolution -> + x on the fused path: square odd filter, stride 1, channel count kept, C % 4 == 0,
+    C >= 16 and not 32 (that width runs the pixel-pair data gradient, which has no residual epilogue)."""
+    Co, Ci, KH, KW = w.shape
+    return (x.is_cuda and x.dim() == 4 and Co == Ci == x.shape[1] and KH == KW and KH % 2 == 1 and _int1(stride) == 1
+            and 2 * _int1(padding) + 1 == KH and Ci % 4 == 0 and Ci >= 16 and Ci != 32)
+
+
+def res_block(x, w, b):
+    return ResBlockFn.apply(x, w, b)
+
+
 def conv2d(x, w, b, stride=1, padding=0, act=ACT_NONE, lo=0.0, hi=0.0):
     return Conv2dFn.apply(x, w, b, None, None, _int1(stride), _int1(padding), act, lo, hi)
 
@@ -832,15 +887,29 @@ def adam_normgrad_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, be
             arr[i].param = params[i].data_ptr(); arr[i].grad = grads[i].data_ptr()
             arr[i].exp_avg = exp_avgs[i].data_ptr(); arr[i].exp_avg_sq = exp_avg_sqs[i].data_ptr()
             arr[i].numel = params[i].numel()
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         if torch.cuda.is_current_stream_capturing():
             # the captured launches read the table at replay time and its content (the addresses of this capture's
             # buffers) never changes afterwards: keep the bytes in the pinned buffer and let the caller upload them ONCE
             # after the capture (adam_flush_tables) instead of capturing a memcpy node that every replay would pay for
-            table_cache["pinned"].copy_(host)
+            C.memmove(table_cache["pinned"].data_ptr(), C.addressof(arr), nbytes)
             table_cache["pending"] = True
         else:
-            table.copy_(host)          # pageable source: staged before the call returns, so it cannot race
+            # eager steps: autograd hands out fresh gradient tensors every step, so the table changes every step.  A copy
+            # from pageable memory would hold the host until the stream has drained (the whole backward pass); a small
+            # ring of pinned staging buffers keeps the upload asynchronous, and a slot is reused only after its copy ran.
+            ring = table_cache.setdefault("ring", [])
+            slot = table_cache.get("ring_next", 0)
+            if len(ring) <= slot:
+                ring.append([torch.empty(nbytes, dtype=torch.uint8).pin_memory(), None])
+            pinned, ev = ring[slot]
+            if ev is not None:
+                ev.synchronize()
+            C.memmove(pinned.data_ptr(), C.addressof(arr), nbytes)
+            table.copy_(pinned, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            ring[slot][1] = ev
+            table_cache["ring_next"] = (slot + 1) % 4
         table_cache["key"] = key
     nb = lib.evae_adam_normgrad_workspace_bytes(n)
     ws = _workspace("adam", nb, dev)

@@ -1,11 +1,14 @@
 """Fully-convolutional weight-normed residual VAE, model_name='single_conv' (reference
 models/fully_conv.py:7-81), same submodule names / state_dict entries (including the BatchNorm2d the
 reference's residual block builds but never calls)."""
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn.utils import weight_norm
 
 from models.AbsModel import AbsModel
+from evae import ops
 from utils.nn import HipConv2d
 
 
@@ -21,6 +24,11 @@ class block(nn.Module):
         self.f = torch.nn.Sequential(self.activation, self.conv1)
 
     def forward(self, x):
+        conv = self.conv1
+        if x.is_cuda and os.environ.get("EVAE_RESBLOCK", "1") != "0" and ops.res_block_supported(x, conv.weight_v, conv.stride, conv.padding):
+            for hook in conv._forward_pre_hooks.values():      # weight_norm: weight = g * v / ||v|| (differentiable)
+                hook(conv, (x,))
+            return ops.res_block(x, conv.weight, conv.bias)
         return x + self.f(x)
 
 

@@ -60,17 +60,18 @@ class AdamNormGrad(Optimizer):
             if host_out is not None:
                 host_out[gi] = v
             else:   # fill kernel (value travels as a kernel argument: no host buffer to race with later steps)
-                self._graph_step_size[gi].fill_(v)
+                ((tables or {}).get("step_size") or self._graph_step_size)[gi].fill_(v)
 
     def finish_capture(self, tables=None):
         """After the capture of a step that contained step(_captured=True): upload the pointer tables of its launches."""
         src = self._tables if tables is None else tables
-        ops.adam_flush_tables([v for k, v in src.items() if not (isinstance(k, tuple) and k and k[0] == "members")])
+        ops.adam_flush_tables([v for k, v in src.items() if isinstance(k, tuple) and k and k[0] != "members"])
 
     @torch.no_grad()
     def step(self, closure=None, _captured=False, _tables=None):
         """`_tables`: a dict owned by the caller's captured graph -- every graph keeps its own device pointer tables (its own
-        gradient buffers), so that capturing a second step on the same optimizer cannot redirect the first one's replays."""
+        gradient buffers) and, under "step_size", its own device step-size scalars, so that capturing a second step on the
+        same optimizer cannot redirect the first one's replays."""
         tables = self._tables if _tables is None else _tables
         loss = None
         if closure is not None:
@@ -98,5 +99,5 @@ class AdamNormGrad(Optimizer):
                                        [s['exp_avg_sq'] for _, _, s in items],
                                        step, group['lr'], beta1, beta2, group['eps'], group['weight_decay'],
                                        table_cache=tables.setdefault((gi, len(items), _captured), {}),
-                                       step_size_dev=self._graph_step_size[gi] if _captured else None)
+                                       step_size_dev=(tables.get("step_size") or self._graph_step_size)[gi] if _captured else None)
         return loss

@@ -274,11 +274,12 @@ int evae_conv2d_bwd_weight(const float* dyh, const float* dyg, const float* x, c
  * 32-wide K-slab is 32 channels of ONE filter tap, so the im2col gather is a per-slab scalar offset plus one
  * validity bit per pixel.  Filters and their gradients keep the nn.Conv2d layout [Co][C][KH][KW].
  * `evae_conv2d_cl_supported(d, what, gated)` (what: 0 forward, 1 data gradient, 2 weight gradient) tells whether
- * the geometry qualifies (forward: C % 32 == 0; data gradient: C % 4 == 0; weight gradient:
- * C % 4 == 0 and (1|2)Co % 4 == 0; tensors below 2 GiB); otherwise use the NCHW entry points above.
- * dy of the backward calls is ONE buffer [N][OH][OW][ldy], ldy = evae_conv2d_cl_dy_stride(ctot) = ctot rounded up to a
- * multiple of 32, ctot = Co or 2 Co: channels [0, Co) hold dh, [Co, 2 Co) dg (gated layers;
- * evae_gated_dense_bwd_input writes exactly that with ldo = ldy), the padding channels must be ZERO. */
+ * the geometry qualifies (forward: C % 4 == 0 and C >= 16, or a thin first layer; data gradient: C % 4 == 0; weight
+ * gradient: C % 4 == 0 and (1|2)Co % 4 == 0; tensors below 2 GiB); otherwise use the NCHW entry points above.
+ * dy of the backward calls is ONE buffer [N][OH][OW][ldy], ctot = Co or 2 Co: channels [0, Co) hold dh, [Co, 2 Co) dg
+ * (gated layers; evae_gated_dense_bwd_input writes exactly that with ldo = ldy).  ldy = evae_conv2d_cl_dy_stride(ctot)
+ * = ctot when ctot % 4 == 0 (a plain layer's upstream gradient is used as it is), else ctot rounded up to a multiple
+ * of 32 with ZERO padding channels. */
 int evae_conv2d_cl_supported(const evae_conv_desc_t* d, int what, int gated);
 int evae_conv2d_cl_dy_stride(int ctot);
 size_t evae_conv2d_cl_workspace_bytes(const evae_conv_desc_t* d, int what, int gated);
@@ -290,6 +291,17 @@ int evae_conv2d_cl_bwd_data(const float* dy, const float* wh, const float* wg, c
                             float* dx, void* ws, size_t ws_bytes, evae_stream_t stream);
 int evae_conv2d_cl_bwd_weight(const float* dy, const float* x, const evae_conv_desc_t* d, int gated,
                               float* dw, float* db, void* ws, size_t ws_bytes, evae_stream_t stream);
+/* Residual blocks of models/fully_conv.py:13-23, y = x + conv(ELU(x)) (weight-normed 3x3, same shape in and out), on the
+ * channels-last kernels with the elementwise work in the epilogues:
+ *   evae_elu_fwd               a = ELU(x)
+ *   evae_conv2d_cl_fwd_res     y = conv(a, w) + b + residual            (residual = x)
+ *   evae_conv2d_cl_bwd_data_res dx = residual + ELU'(x) * conv_transpose(dy, w), ELU'(x) = (a > 0 ? 1 : a + 1)   (residual = dy)
+ * Channel counts with C % 4 == 0, C != 32; the weight gradient is evae_conv2d_cl_bwd_weight on (dy, a). */
+int evae_elu_fwd(const float* x, size_t n, float* out, evae_stream_t stream);
+int evae_conv2d_cl_fwd_res(const float* a, const evae_conv_desc_t* d, const float* w, const float* b, const float* residual,
+                           float* out, void* ws, size_t ws_bytes, evae_stream_t stream);
+int evae_conv2d_cl_bwd_data_res(const float* dy, const float* w, const evae_conv_desc_t* d, const float* residual,
+                                const float* elu_out, float* dx, void* ws, size_t ws_bytes, evae_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Latent sampling and log-densities on [B x zdim] / [B x D] rows.

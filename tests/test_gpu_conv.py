@@ -56,6 +56,50 @@ def test_conv2d_fwd_bwd_matches_torch(N, C, H, W, Co, k, s, p, gated):
         assert rel(wgd.grad, wgr.grad) < 1e-5 and rel(bgd.grad, bgr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("N,C,H,W,k,per", [(3, 48, 32, 32, 3, None), (2, 96, 16, 16, 3, None), (5, 48, 16, 16, 3, "2"),
+                                            (2, 16, 9, 7, 3, None), (2, 20, 8, 8, 5, None), (2, 64, 8, 8, 3, None)])
+def test_residual_block_matches_torch(N, C, H, W, k, per, monkeypatch):
+    """x + conv(ELU(x)) (models/fully_conv.py:13-23) through ops.res_block: output and all gradients against float64
+    autograd, also with the tensors processed in passes of 2 images."""
+    from evae import ops
+    if per:
+        monkeypatch.setenv("EVAE_CL_IMAGES_PER_PASS", per)
+    rs = np.random.RandomState(C + H)
+    x = torch.from_numpy((rs.standard_normal((N, C, H, W)) * 1.5).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((C, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32))
+    b = torch.from_numpy((rs.standard_normal(C) * 0.1).astype(np.float32))
+    xr, wr, br = [t.double().requires_grad_(True) for t in (x, w, b)]
+    yr = xr + F.conv2d(F.elu(xr), wr, br, 1, k // 2)
+    gout = torch.from_numpy(rs.standard_normal(tuple(yr.shape)).astype(np.float32))
+    yr.backward(gout.double())
+    xd, wd, bd = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    assert ops.res_block_supported(xd, wd, 1, k // 2)
+    y = ops.res_block(xd, wd, bd)
+    y.backward(gout.cuda())
+    assert rel(y, yr) < 1e-5 and rel(xd.grad, xr.grad) < 1e-5
+    assert rel(wd.grad, wr.grad) < 1e-5 and rel(bd.grad, br.grad) < 1e-5
+
+
+def test_fully_conv_block_module_uses_fused_path_and_matches_unfused():
+    """models.fully_conv.block (weight-normed): the fused residual path against the module's own unfused composition,
+    gradients with respect to the weight-norm parameters g and v included."""
+    from models.fully_conv import block
+    torch.manual_seed(3)
+    m = block(48, 48).cuda()
+    with torch.no_grad():
+        m.conv1.weight_g.mul_(torch.rand_like(m.conv1.weight_g) + 0.5)
+    x = torch.randn(4, 48, 16, 16, device="cuda")
+    res = []
+    for fused in (True, False):
+        xi = x.clone().requires_grad_(True)
+        m.zero_grad()
+        y = m(xi) if fused else xi + m.f(xi)
+        y.square().sum().backward()
+        res.append([y.detach(), xi.grad] + [p.grad.clone() for p in m.conv1.parameters()])
+    for a, b_ in zip(*res):
+        assert rel(a, b_) < 2e-5
+
+
 def test_conv2d_activations_and_modules():
     from utils.nn import Conv2d, GatedConv2d
     torch.manual_seed(0)
