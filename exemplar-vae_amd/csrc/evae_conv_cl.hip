@@ -1,4 +1,4 @@
-#include "evae_gemm_kernel.h"
+#include "evae_gemm_x6.h"
 
 // ========================================================================================================
 // Convolutions over channels-last tensors as instances of the GEMM of evae_gemm_kernel.h (CV = 1 / 2, see ConvMap).
@@ -22,8 +22,9 @@ __global__ void cl_permute_fwd_kernel(const float* __restrict__ w, int Co, int C
 // over the channels of the merged gradient buffer: cc < Co -> wh[cc][c][tap_j], Co <= cc < 2Co -> wg[cc - Co][c][tap_j]
 // (gated), anything beyond -> 0 (the buffer's zero padding up to a multiple of 32)
 struct TapList { int n; int t[64]; };
+// kc: the transposed arrangement wp[c][j][cc] (contraction-contiguous rows, the B operand of the split-bf16 kernel)
 __global__ void cl_permute_dgrad_kernel(const float* __restrict__ wh, const float* __restrict__ wg, int Co, int C,
-                                        int taps, int ld, TapList tl, float* __restrict__ wp) {
+                                        int taps, int ld, TapList tl, float* __restrict__ wp, int kc) {
   const size_t n = (size_t)tl.n * ld * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
@@ -32,7 +33,7 @@ __global__ void cl_permute_dgrad_kernel(const float* __restrict__ wh, const floa
     float v = 0.f;
     if (cc < Co) v = wh[((size_t)cc * C + c) * taps + tl.t[j]];
     else if (wg != nullptr && cc < 2 * Co) v = wg[((size_t)(cc - Co) * C + c) * taps + tl.t[j]];
-    wp[i] = v;
+    wp[kc ? ((size_t)c * tl.n + j) * ld + cc : i] = v;
   }
 }
 
@@ -75,7 +76,7 @@ __global__ void cl_permute_patch_w_kernel(const float* __restrict__ w, int Co, i
 // wp[u][cc][b*32 + c] = w_merged[cc][c][tb[b][u]] when tap u of the union belongs to pixel b (tb >= 0), else 0
 struct PairTaps { int n; int tb[2][64]; };
 __global__ void cl_permute_dgrad_pair_kernel(const float* __restrict__ wh, const float* __restrict__ wg, int Co, int taps,
-                                             int ld, PairTaps pt, float* __restrict__ wp) {
+                                             int ld, PairTaps pt, float* __restrict__ wp, int kc) {
   const int C = 32;
   const size_t n = (size_t)pt.n * ld * 64;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -88,7 +89,7 @@ __global__ void cl_permute_dgrad_pair_kernel(const float* __restrict__ wh, const
       if (cc < Co) v = wh[((size_t)cc * C + c) * taps + t];
       else if (wg != nullptr && cc < 2 * Co) v = wg[((size_t)(cc - Co) * C + c) * taps + t];
     }
-    wp[i] = v;
+    wp[kc ? ((size_t)col * pt.n + u) * ld + cc : i] = v;
   }
 }
 
@@ -264,13 +265,17 @@ static int cl_fwd_impl(const float* x, const evae_conv_desc_t* d, const float* w
     g.A[0] = x + xo - cv.bias / 4;     // the per-row offsets carry +bias (they are never negative)
     g.M = nn * OH * OW;
     int rc;
+    const bool x6 = gemm_x6_enabled() && g.M >= gemm_x6_min_rows();
     if (gated) {
       g.out0 = out + oo; g.out1 = save_h ? save_h + oo : nullptr; g.out2 = save_s ? save_s + oo : nullptr;
-      rc = launch_gemm_w<true, true, EPI_GATED, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_fwd(gated)");
+      if (x6) rc = launch_gemm_x6<EPI_GATED, 1, 128>(g, 1, stream, "conv2d_cl_fwd(gated, x6)");
+      else rc = launch_gemm_w<true, true, EPI_GATED, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_fwd(gated)");
     } else {
       g.out0 = out + oo; g.out1 = save_h ? save_h + oo : nullptr;    // pre-activation when requested
       g.e0 = residual ? residual + oo : nullptr;                     // residual block: out = conv(x) + residual
-      if (d->Co <= 64) rc = launch_gemm_w<true, true, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_fwd");
+      if (x6 && d->Co <= 64) rc = launch_gemm_x6<EPI_LINEAR, 1, 64>(g, 1, stream, "conv2d_cl_fwd(x6)");
+      else if (x6) rc = launch_gemm_x6<EPI_LINEAR, 1, 128>(g, 1, stream, "conv2d_cl_fwd(x6)");
+      else if (d->Co <= 64) rc = launch_gemm_w<true, true, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_fwd");
       else rc = launch_gemm_w<true, true, EPI_LINEAR, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_fwd");
     }
     if (rc) return rc;
@@ -358,7 +363,8 @@ static int cl_bwd_data_impl(const float* dy, const float* wh, const float* wg, c
       const size_t cls = (size_t)pt.n * ldv * 64;
       float* wc = wp + usedp;
       usedp += cls;
-      cl_permute_dgrad_pair_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, taps, ldv, pt, wc);
+      const bool x6 = gemm_x6_enabled() && !residual && std::min(cl_images_per_pass(d, OH, OW, C, ldy), d->N) * RH * W2 >= gemm_x6_min_rows();
+      cl_permute_dgrad_pair_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, taps, ldv, pt, wc, x6 ? 1 : 0);
       int rc = check_launch("cl_permute_dgrad_pair_kernel");
       if (rc) return rc;
       cv.Cg = ldv; cv.creal = ldy; cv.ps = ldy; cv.ntaps = pt.n;
@@ -369,7 +375,7 @@ static int cl_bwd_data_impl(const float* dy, const float* wh, const float* wg, c
       cv.div_rw = make_fastdiv((unsigned)W2); cv.div_rhw = make_fastdiv((unsigned)(RH * W2));
       cv.bias = 0;
       g.B[0] = wc;
-      g.lda[0] = ldy; g.ldb[0] = 64;
+      g.lda[0] = ldy; g.ldb[0] = x6 ? pt.n * ldv : 64;
       g.Kc[0] = pt.n * ldv; g.npairs = 1;
       g.N = 64; g.ldo = 64;
       g.ksplit = 0;
@@ -379,7 +385,8 @@ static int cl_bwd_data_impl(const float* dy, const float* wh, const float* wg, c
         g.A[0] = dy + (size_t)n0 * OH * OW * ldy - tbias / 4;
         g.out0 = dx + (size_t)n0 * d->H * d->W * C;
         g.M = nn * RH * W2;
-        rc = launch_gemm_w<true, false, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data(pixel pairs)");
+        if (x6) rc = launch_gemm_x6<EPI_LINEAR, 1, 64>(g, 1, stream, "conv2d_cl_bwd_data(pixel pairs, x6)");
+        else rc = launch_gemm_w<true, false, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data(pixel pairs)");
         if (rc) return rc;
       }
     }
@@ -423,7 +430,8 @@ static int cl_bwd_data_impl(const float* dy, const float* wh, const float* wg, c
       const size_t cls = (size_t)tl.n * ldv * C;
       float* wc = wp + used;
       used += cls;
-      cl_permute_dgrad_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, C, taps, ldv, tl, wc);
+      const bool x6 = gemm_x6_enabled() && std::min(cl_images_per_pass(d, OH, OW, C, ldy), d->N) * RH * RW >= gemm_x6_min_rows();
+      cl_permute_dgrad_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, C, taps, ldv, tl, wc, x6 ? 1 : 0);
       int rc = check_launch("cl_permute_dgrad_kernel");
       if (rc) return rc;
       cv.Cg = ldv; cv.creal = ldy; cv.ps = ldy; cv.ntaps = tl.n;
@@ -434,7 +442,7 @@ static int cl_bwd_data_impl(const float* dy, const float* wh, const float* wg, c
       cv.div_rw = make_fastdiv((unsigned)RW); cv.div_rhw = make_fastdiv((unsigned)(RH * RW));
       cv.bias = 0;
       g.B[0] = wc;
-      g.lda[0] = ldy; g.ldb[0] = C;
+      g.lda[0] = ldy; g.ldb[0] = x6 ? tl.n * ldv : C;
       g.Kc[0] = tl.n * ldv; g.npairs = 1;
       g.N = C; g.ldo = C;
       g.ksplit = 0;
@@ -446,7 +454,9 @@ static int cl_bwd_data_impl(const float* dy, const float* wh, const float* wg, c
         g.e0 = residual ? residual + (size_t)n0 * d->H * d->W * C : nullptr;      // residual block: dx = dy + ELU'(x) * acc
         g.e1 = elu_out ? elu_out + (size_t)n0 * d->H * d->W * C : nullptr;
         g.M = nn * RH * RW;
-        if (C <= 64) rc = launch_gemm_w<true, false, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data");
+        if (x6 && C <= 64) rc = launch_gemm_x6<EPI_LINEAR, 1, 64>(g, 1, stream, "conv2d_cl_bwd_data(x6)");
+        else if (x6) rc = launch_gemm_x6<EPI_LINEAR, 1, 128>(g, 1, stream, "conv2d_cl_bwd_data(x6)");
+        else if (C <= 64) rc = launch_gemm_w<true, false, EPI_LINEAR, true, 64, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data");
         else rc = launch_gemm_w<true, false, EPI_LINEAR, true, 128, 8, 1>(g, 1, stream, "conv2d_cl_bwd_data");
         if (rc) return rc;
       }

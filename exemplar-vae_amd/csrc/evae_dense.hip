@@ -25,7 +25,7 @@
 //   Workgroup ids are remapped so that each XCD owns a contiguous run of tiles (shared A row-panels
 //   stay in one L2).
 
-#include "evae_gemm_kernel.h"
+#include "evae_gemm_x6.h"
 
 namespace evae {
 
@@ -58,7 +58,25 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 
 }  // namespace evae
 
+namespace evae {
+int g_x6_enabled = -1, g_x6_min_rows = -1;
+void gemm_x6_init_policy() {
+  const char* e = getenv("EVAE_X6");
+  if (g_x6_enabled < 0) g_x6_enabled = (e && atoi(e) == 0) ? 0 : 1;
+  const char* r = getenv("EVAE_X6_MIN_ROWS");
+  if (g_x6_min_rows < 0) g_x6_min_rows = r ? atoi(r) : 2048;
+}
+}  // namespace evae
+
 using namespace evae;
+
+// enabled: 0 = fp32 matrix pipe only, 1 = split-bf16 kernel where it applies, < 0 = keep; min_rows < 0 = keep
+extern "C" int evae_gemm_x6_configure(int enabled, int min_rows) {
+  gemm_x6_init_policy();
+  if (enabled >= 0) g_x6_enabled = enabled ? 1 : 0;
+  if (min_rows >= 0) g_x6_min_rows = min_rows;
+  return EVAE_OK;
+}
 
 // ---- forward -------------------------------------------------------------------------------------------
 extern "C" size_t evae_dense_fwd_workspace_bytes(int M, int K, int N, int gated) {
@@ -82,13 +100,20 @@ extern "C" int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, 
   g.A[0] = x; g.B[0] = wh; g.Bg = wg; g.lda[0] = ldx; g.ldb[0] = K; g.Kc[0] = K; g.npairs = 1;
   g.a_rows = rows; g.M = M; g.N = N; g.bias0 = bh; g.bias1 = bg;
   g.out0 = out; g.out1 = save_h; g.out2 = save_s; g.ldo = N;
+  if (pl.nz <= 1 && gemm_x6_use(g)) return launch_gemm_x6<EPI_GATED>(g, 1, stream, "gated_dense_fwd(x6)");
   if (pl.nz <= 1) return launch_gemm<true, true, EPI_GATED>(g, pl, stream, "gated_dense_fwd");
   if (ws == nullptr || ws_bytes < evae_dense_fwd_workspace_bytes(M, K, N, 1)) {
     set_error("gated_dense_fwd: workspace too small (%zu)", ws_bytes);
     return EVAE_EWORKSPACE;
   }
   g.out0 = (float*)ws; g.out1 = g.out2 = nullptr;
-  int rc = launch_gemm<true, true, EPI_RAW_GATED>(g, pl, stream, "gated_dense_fwd(split-K)");
+  int rc;
+  if (gemm_x6_use(g)) {
+    g.ksplit = pl.ksplit;
+    rc = launch_gemm_x6<EPI_RAW_GATED>(g, pl.nz, stream, "gated_dense_fwd(split-K, x6)");
+  } else {
+    rc = launch_gemm<true, true, EPI_RAW_GATED>(g, pl, stream, "gated_dense_fwd(split-K)");
+  }
   if (rc) return rc;
   FinishArgs f = {};
   f.ones_col = -1;
@@ -112,13 +137,21 @@ extern "C" int evae_linear_fwd(const float* x, const int64_t* rows, int M, int K
   g.A[0] = x; g.B[0] = w; g.lda[0] = ldx; g.ldb[0] = K; g.Kc[0] = K; g.npairs = 1;
   g.a_rows = rows; g.M = M; g.N = N; g.bias0 = b; g.out0 = y; g.out1 = pre; g.ldo = N;
   g.act = act; g.lo = act_lo; g.hi = act_hi;
+  if (pl.nz <= 1 && gemm_x6_use(g) && gemm_x6_pick_bn(M, N) == 64) return launch_gemm_x6<EPI_LINEAR, 0, 64>(g, 1, stream, "linear_fwd(x6)");
+  if (pl.nz <= 1 && gemm_x6_use(g)) return launch_gemm_x6<EPI_LINEAR>(g, 1, stream, "linear_fwd(x6)");
   if (pl.nz <= 1) return launch_gemm<true, true, EPI_LINEAR>(g, pl, stream, "linear_fwd");
   if (ws == nullptr || ws_bytes < evae_dense_fwd_workspace_bytes(M, K, N, 0)) {
     set_error("linear_fwd: workspace too small (%zu)", ws_bytes);
     return EVAE_EWORKSPACE;
   }
   g.out0 = (float*)ws; g.out1 = nullptr;
-  int rc = launch_gemm<true, true, EPI_RAW>(g, pl, stream, "linear_fwd(split-K)");
+  int rc;
+  if (gemm_x6_use(g)) {
+    g.ksplit = pl.ksplit;
+    rc = launch_gemm_x6<EPI_RAW>(g, pl.nz, stream, "linear_fwd(split-K, x6)");
+  } else {
+    rc = launch_gemm<true, true, EPI_RAW>(g, pl, stream, "linear_fwd(split-K)");
+  }
   if (rc) return rc;
   FinishArgs f = {};
   f.ones_col = -1;
@@ -128,11 +161,29 @@ extern "C" int evae_linear_fwd(const float* x, const int64_t* rows, int M, int K
 }
 
 // ---- data gradient ---------------------------------------------------------------------------------------
+// transposed weights for the split-bf16 kernel (contraction-contiguous B): wT[p][k][n] = w_p[n][k], row stride ldt
+static int x6_wt_ld(int N) { return (N + 3) / 4 * 4; }
+static size_t x6_wt_bytes(int N, int K, int npairs) { return align_up((size_t)npairs * K * x6_wt_ld(N) * sizeof(float), 256); }
+
+__global__ __launch_bounds__(256) void transpose_pairs_kernel(const float* __restrict__ w1, const float* __restrict__ w2, int N,
+                                                              int K, int ldt, float* __restrict__ wT) {
+  __shared__ float tile[32][33];
+  const float* w = blockIdx.z ? w2 : w1;
+  float* o = wT + (size_t)blockIdx.z * K * ldt;
+  const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8)
+    tile[r][tx] = (n0 + r < N && k0 + tx < K) ? w[(size_t)(n0 + r) * K + k0 + tx] : 0.f;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (k0 + r < K && n0 + tx < ldt) o[(size_t)(k0 + r) * ldt + n0 + tx] = tile[tx][r];
+}
+
 extern "C" size_t evae_dense_bwd_data_workspace_bytes(int M, int N, int K, int npairs) {
   if (M <= 0 || K <= 0 || N <= 0) return 256;
   Plan pl = make_plan(M, K, total_slabs(N, npairs > 1 ? N : 0), false, false, 1);
-  if (pl.nz <= 1) return 256;
-  return align_up((size_t)pl.nz * M * K * sizeof(float), 256) + 256;
+  const size_t wt = x6_wt_bytes(N, K, npairs > 1 ? 2 : 1);      // transposed weights of the split-bf16 path, behind the planes
+  if (pl.nz <= 1) return 256 + wt;
+  return align_up((size_t)pl.nz * M * K * sizeof(float), 256) + wt + 256;
 }
 
 extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const float* dy2, const float* w2,
@@ -153,16 +204,40 @@ extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const floa
   g.A[0] = dy1; g.B[0] = w1; g.lda[0] = ldy; g.ldb[0] = K; g.Kc[0] = N; g.npairs = np;
   if (dy2) { g.A[1] = dy2; g.B[1] = w2; g.lda[1] = ldy; g.ldb[1] = K; g.Kc[1] = N; }
   g.M = M; g.N = K; g.out0 = dx_or_dh; g.out1 = gate ? dg : nullptr; g.ldo = ldo; g.e0 = out_prev; g.e1 = s_prev;
+  const size_t part_bytes = pl.nz > 1 ? align_up((size_t)pl.nz * M * K * sizeof(float), 256) : 0;
+  const bool x6 = gemm_x6_enabled() && M >= gemm_x6_min_rows() && ws && ws_bytes >= part_bytes + x6_wt_bytes(N, K, np) &&
+                  N % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)dy1 | (uintptr_t)dy2) & 15) == 0 && (long long)M * ldy < (1ll << 29);
+  if (x6) {
+    // contraction-contiguous weights: wT[p] = w_p^T behind the split-K planes, then the split-bf16 kernel (A = dy, B = wT)
+    const int ldt = x6_wt_ld(N);
+    float* wT = (float*)((char*)ws + part_bytes);
+    transpose_pairs_kernel<<<dim3(cdiv(K, 32), cdiv(ldt, 32), np), 256, 0, stream>>>(w1, w2, N, K, ldt, wT);
+    int rc = check_launch("transpose_pairs_kernel");
+    if (rc) return rc;
+    g.B[0] = wT; g.ldb[0] = ldt;
+    if (dy2) { g.B[1] = wT + (size_t)K * ldt; g.ldb[1] = ldt; }
+  }
   if (pl.nz <= 1) {
+    const bool narrow = x6 && gemm_x6_pick_bn(M, K) == 64;
+    if (x6 && gate && narrow) return launch_gemm_x6<EPI_GATE_BWD, 0, 64>(g, 1, stream, "dense_bwd_data(gate, x6)");
+    if (x6 && gate) return launch_gemm_x6<EPI_GATE_BWD>(g, 1, stream, "dense_bwd_data(gate, x6)");
+    if (x6 && narrow) return launch_gemm_x6<EPI_LINEAR, 0, 64>(g, 1, stream, "dense_bwd_data(x6)");
+    if (x6) return launch_gemm_x6<EPI_LINEAR>(g, 1, stream, "dense_bwd_data(x6)");
     if (gate) return launch_gemm<true, false, EPI_GATE_BWD>(g, pl, stream, "dense_bwd_data(gate)");
     return launch_gemm<true, false, EPI_LINEAR>(g, pl, stream, "dense_bwd_data");
   }
-  if (ws == nullptr || ws_bytes < evae_dense_bwd_data_workspace_bytes(M, N, K, np)) {
+  if (ws == nullptr || ws_bytes < part_bytes + 256) {
     set_error("dense_bwd_data: workspace too small (%zu)", ws_bytes);
     return EVAE_EWORKSPACE;
   }
   g.out0 = (float*)ws; g.out1 = nullptr;
-  int rc = launch_gemm<true, false, EPI_RAW>(g, pl, stream, "dense_bwd_data(split-K)");
+  int rc;
+  if (x6) {
+    g.ksplit = pl.ksplit;
+    rc = launch_gemm_x6<EPI_RAW>(g, pl.nz, stream, "dense_bwd_data(split-K, x6)");
+  } else {
+    rc = launch_gemm<true, false, EPI_RAW>(g, pl, stream, "dense_bwd_data(split-K)");
+  }
   if (rc) return rc;
   FinishArgs f = {};
   f.ones_col = -1;

@@ -204,6 +204,317 @@ struct TileLoader {
   }
 };
 
+// The epilogue of a block tile, shared by the fp32-MFMA kernel below and the split-bf16 kernel (evae_gemm_x6.h): both keep
+// acc[mt][nt] in the 32x32 C/D layout with NW/2 wave rows x 2 wave columns.
+template <int EPI, int BN_, int NW, int CV>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8 / NW][BN_ / 64], const int m0, const int n0,
+                                              const int tm, const int wr, const int wc, const int lane, float* smem) {
+  constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
+  constexpr int MT = 8 / NW, NT = BN_ / 64;
+  (void)GATED; (void)tm;
+  // ---- epilogue.  acc[mt][nt][r] <-> row m0 + wr*32*MT + mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
+  //                                    col (within the wave tile) nt*32 + (lane&31)
+  const int l31 = lane & 31, lh = lane >> 5;
+  // output row of GEMM row m (identity unless this is the data gradient of a strided convolution)
+  auto orow = [&](int m) -> size_t {
+    if (CV == 1 && g.cv.remap) {
+      const unsigned nn = fdiv((unsigned)m, g.cv.div_rhw), rem = (unsigned)m - nn * (unsigned)(g.cv.RH * g.cv.RW);
+      const unsigned ry = fdiv(rem, g.cv.div_rw), rx = rem - ry * (unsigned)g.cv.RW;
+      return ((size_t)nn * g.cv.OH2 + ry * g.cv.os + g.cv.ooy) * g.cv.OW2 + rx * g.cv.osx + g.cv.oox;
+    }
+    return (size_t)m;
+  };
+  if constexpr (EPI == EPI_DIST_TILEMIN || EPI == EPI_DIST_COLLECT) {
+    // e0 = squared norms of the A rows, e1 = of the B rows; acc = dot products
+    float tmin[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      const bool nok = n < g.N;
+      const float bn = nok ? g.e1[n] : 0.f;
+      const float thr = (EPI == EPI_DIST_COLLECT && nok) ? g.bias0[n] : -INFINITY;
+      tmin[nt] = INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < g.M) {
+            const float d = g.e0[m] + bn - 2.0f * acc[mt][nt][r];
+            if (EPI == EPI_DIST_TILEMIN) tmin[nt] = fminf(tmin[nt], d);
+            else if (nok && d <= thr) g.aux_cand[(size_t)n * g.ldo + atomicAdd(&g.aux_cnt[n], 1)] = m;
+          }
+        }
+    }
+    if (EPI == EPI_DIST_TILEMIN) {
+      // lanes l / l+32 hold the same column; then the NW/2 wave rows through LDS (free after the last barrier)
+      float* red = smem;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        tmin[nt] = fminf(tmin[nt], __shfl_xor(tmin[nt], 32, 64));
+        if (lh == 0) red[wr * BN_ + wc * 32 * NT + nt * 32 + l31] = tmin[nt];
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < BN_ && n0 + (int)threadIdx.x < g.N) {
+        float v = red[threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < NW / 2; ++w) v = fminf(v, red[w * BN_ + threadIdx.x]);
+        g.out0[(size_t)tm * g.ldo + n0 + threadIdx.x] = v;
+      }
+    }
+  } else if constexpr (EPI == EPI_PRIOR_LSE) {
+    // e0 = |c'_m|^2 (rows), e1 = |z'_n|^2 (columns), acc = c'_m . z'_n.  Per column the block's rows are reduced on
+    // t = acc - |c'|^2/2 (= -d2/2 + |z'|^2/2: the column's own norm drops out of every difference) to
+    // (max, sum exp(t - max), #masked); lanes l / l+32 hold the same column, the NW/2 wave rows meet in LDS.
+    const bool masked = g.pr_ridx != nullptr && g.pr_cidx != nullptr;
+    float hc[MT][16];
+    long long ri[MT][16];
+    unsigned live[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      live[mt] = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = m < g.M;
+        hc[mt][r] = ok ? 0.5f * g.e0[m] : 0.f;
+        ri[mt][r] = (masked && ok) ? (long long)g.pr_ridx[m] : -2;
+        if (ok) live[mt] |= 1u << r;
+      }
+    }
+    float* red = smem;          // [NW/2][BN][3], free after the last barrier of the slab loop
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      const long long zi = (masked && n < g.N) ? (long long)g.pr_cidx[n] : -1;
+      float tmax = -INFINITY, ssum = 0.f, nm = 0.f;
+      unsigned use[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        use[mt] = live[mt];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[mt][nt][r] -= hc[mt][r];
+          if (masked && ((use[mt] >> r) & 1u) && (ri[mt][r] == zi || ri[mt][r] == (long long)EVAE_PRIOR_MASK_ALL)) { nm += 1.f; use[mt] &= ~(1u << r); }
+          if ((use[mt] >> r) & 1u) tmax = fmaxf(tmax, acc[mt][nt][r]);
+        }
+      }
+      const float mk = -tmax * kLog2e;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if ((use[mt] >> r) & 1u) ssum += fast_exp2(fmaf(acc[mt][nt][r], kLog2e, mk));
+      const float ot = __shfl_xor(tmax, 32, 64), os = __shfl_xor(ssum, 32, 64), on = __shfl_xor(nm, 32, 64);
+      const float mx = fmaxf(tmax, ot);
+      const float fa = (tmax == mx) ? 1.f : fast_exp2((tmax - mx) * kLog2e);      // -inf - (-inf) never evaluated
+      const float fb = (ot == mx) ? 1.f : fast_exp2((ot - mx) * kLog2e);
+      if (lh == 0) {
+        float* cb = red + (wr * BN_ + wc * 32 * NT + nt * 32 + l31) * 3;
+        cb[0] = mx; cb[1] = ssum * fa + os * fb; cb[2] = nm + on;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < BN_ && n0 + (int)threadIdx.x < g.N) {
+      float mx = -INFINITY, sacc = 0.f, nacc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW / 2; ++w) mx = fmaxf(mx, red[(w * BN_ + threadIdx.x) * 3]);
+#pragma unroll
+      for (int w = 0; w < NW / 2; ++w) {
+        const float tw = red[(w * BN_ + threadIdx.x) * 3];
+        if (tw != -INFINITY) sacc += red[(w * BN_ + threadIdx.x) * 3 + 1] * fast_exp2((tw - mx) * kLog2e);
+        nacc += red[(w * BN_ + threadIdx.x) * 3 + 2];
+      }
+      const int n = n0 + threadIdx.x;
+      const size_t o = (size_t)tm * g.ldo + n;
+      g.out0[o] = (mx == -INFINITY) ? -INFINITY : *g.pr_cst_dev + (mx - 0.5f * g.e1[n]);
+      g.out1[o] = sacc;
+      g.out2[o] = nacc;
+    }
+  } else if constexpr (EPI == EPI_PRIOR_P) {
+    // P[m][n] = g_n exp(cst - d2_mn / 2 - lse_n), d2 = |c'|^2 + |z'|^2 - 2 acc; bias0 = lse, bias1 = upstream gradient.
+    // Columns N <= n < ldo (padding up to a multiple of 4) are written as zeros: P is the operand of two more GEMMs.
+    const bool masked = g.pr_ridx != nullptr && g.pr_cidx != nullptr;
+    const float cst = *g.pr_cst_dev;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      if (n >= g.ldo) continue;
+      const bool nok = n < g.N;
+      const float zn = nok ? g.e1[n] : 0.f;
+      const float gq = nok ? g.bias1[n] : 0.f;
+      const float kq = nok ? (cst - g.bias0[n]) * kLog2e : 0.f;
+      const long long zi = (masked && nok) ? (long long)g.pr_cidx[n] : -1;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m >= g.M) continue;
+          const float d = fmaxf(g.e0[m] + zn - 2.0f * acc[mt][nt][r], 0.f);
+          bool ok = nok;
+          if (masked) ok = ok && ((long long)g.pr_ridx[m] != zi) && ((long long)g.pr_ridx[m] != (long long)EVAE_PRIOR_MASK_ALL);
+          g.out0[(size_t)m * g.ldo + n] = ok ? gq * fast_exp2(kq - d * (0.5f * kLog2e)) : 0.f;
+        }
+    }
+  } else if (GATED) {
+    const int n = n0 + wc * 32 + l31;
+    if (n < g.N) {
+      const float bh = (EPI == EPI_GATED && g.bias0) ? g.bias0[n] : 0.f;
+      const float bg = (EPI == EPI_GATED && g.bias1) ? g.bias1[n] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < g.M) {
+            if (EPI == EPI_GATED) {
+              const float h = acc[mt][0][r] + bh;
+              // sigmoid on the hardware exp2 / rcp (about 1e-7 relative): the precise expf costs ~15 VALU instructions
+              // per element, and VALU issue is what the co-resident block's MFMAs wait on
+              const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc[mt][NT - 1][r] + bg)));
+              const size_t o = orow(m) * g.ldo + n;
+              g.out0[o] = h * s;
+              if (g.out1) g.out1[o] = h;
+              if (g.out2) g.out2[o] = s;
+            } else {   // EPI_RAW_GATED: partial planes [z][2][M][N]
+              const size_t plane = (size_t)g.M * g.N;
+              const size_t o = (size_t)blockIdx.z * 2 * plane + (size_t)m * g.N + n;
+              g.out0[o] = acc[mt][0][r];
+              g.out0[o + plane] = acc[mt][NT - 1][r];
+            }
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_GATE_BWD_IMG) {
+    // dh = v s, dg = v (h s)(1 - s) as in EPI_GATE_BWD; column cc of the merged [dh | dg] buffer is n (dh) / N + n (dg).  A lane
+    // holds four consecutive rows per r-group: as bf16 terms they are 8 bytes of one 16-byte slot of the image
+    //   img[((cc >> 7) * nslab + (row >> 5)) * 3 + p][cc & 127][slot (row & 31) >> 3, XOR-swizzled][row & 7]
+    // (truncation split: w0 = top 8 significant bits, w1 of w - w0, w2 the rest: exact).  Rows must come in aligned fours
+    // (M % 4 == 0, img_mbase % 4 == 0: checked by the host).
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      if (n >= g.N) continue;
+      float go[MT][16], sv[MT][16];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const size_t oe = (size_t)(m < g.M ? m : 0) * g.N + n;
+          go[mt][r] = g.e0[oe];
+          sv[mt][r] = g.e1[oe];
+        }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ml = m0 + wr * 32 * MT + mt * 32 + 8 * j + 4 * lh;      // first of four rows (local)
+          if (ml >= g.M) continue;
+          const int gm = ml + g.img_mbase, slab = gm >> 5, mi = gm & 31;
+#pragma unroll
+          for (int which = 0; which < 2; ++which) {
+            const int cc = which ? g.N + n : n;
+            const int c = cc & 127;
+            unsigned t0[2] = {0u, 0u}, t1[2] = {0u, 0u}, t2[2] = {0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int r = 4 * j + i;
+              const float v = acc[mt][nt][r], s_ = sv[mt][r];
+              const float w = which ? v * go[mt][r] * (1.0f - s_) : v * s_;
+              const unsigned u0 = __float_as_uint(w) & 0xFFFF0000u;
+              const float r1 = w - __uint_as_float(u0);
+              const unsigned u1 = __float_as_uint(r1) & 0xFFFF0000u;
+              const float r2 = r1 - __uint_as_float(u1);
+              const unsigned u2 = __float_as_uint(r2);
+              const int sh = 16 * (i & 1);
+              t0[i >> 1] |= (u0 >> 16) << sh; t1[i >> 1] |= (u1 >> 16) << sh; t2[i >> 1] |= (u2 >> 16) << sh;
+            }
+            char* base = reinterpret_cast<char*>(g.img) + ((size_t)((cc >> 7) * g.img_nslab + slab) * 3 * 128 + c) * 64 +
+                         ((((mi >> 3) ^ ((c >> 2) & 3))) << 4) + ((mi & 7) << 1);
+            *reinterpret_cast<uint2*>(base) = make_uint2(t0[0], t0[1]);
+            *reinterpret_cast<uint2*>(base + 128 * 64) = make_uint2(t1[0], t1[1]);
+            *reinterpret_cast<uint2*>(base + 2 * 128 * 64) = make_uint2(t2[0], t2[1]);
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_GATE_BWD) {
+    // dh = v * s, dg = v * (h s) * (1 - s) with h s and s of the layer below read from dense [M x N] arrays.  All the
+    // reads of a fragment are issued before the first store: the stores may alias them as far as the compiler knows,
+    // and a read -> store -> read chain would pay one memory latency per element (that is the whole run time of a
+    // launch with few blocks, and of a block's tail in any launch).
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      if (n >= g.N) continue;
+      float go[MT][16], sv[MT][16];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const size_t oe = (size_t)(m < g.M ? m : 0) * g.N + n;
+          go[mt][r] = g.e0[oe];
+          sv[mt][r] = g.e1[oe];
+        }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m >= g.M) continue;
+          const size_t o = orow(m) * g.ldo + n;
+          const float v = acc[mt][nt][r], s_ = sv[mt][r];
+          g.out0[o] = v * s_;                          // dh
+          g.out1[o] = v * go[mt][r] * (1.0f - s_);     // dg = v * h * s * (1 - s)
+        }
+    }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      if (n >= g.N) continue;
+      const float bias = (EPI == EPI_LINEAR && g.bias0) ? g.bias0[n] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        // residual blocks of fully_conv (models/fully_conv.py:13-23: x + conv(ELU(x))): e1 = ELU(x) of the block whose data
+        // gradient this is -> times ELU'(x) = (a > 0 ? 1 : a + 1); e0 = the tensor added to the result (x forward, dy
+        // backward).  Both are fetched for the whole 32-row tile BEFORE the first store: stores to out0 may alias them as far
+        // as the compiler knows, so loads placed between the stores would run one at a time.
+        float ev0[16], ev1[16];
+        const bool extras = EPI == EPI_LINEAR && (g.e0 || g.e1);
+        if (extras) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const bool ok = m < g.M;
+            const size_t o = orow(ok ? m : m0) * g.ldo + n;
+            ev0[r] = (ok && g.e0) ? g.e0[o] : 0.f;
+            ev1[r] = (ok && g.e1) ? g.e1[o] : 1.f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m >= g.M) continue;
+          const size_t o = orow(m) * g.ldo + n;
+          const float v = acc[mt][nt][r];
+          if (EPI == EPI_LINEAR) {
+            const float pre = v + bias;
+            if (g.out1) g.out1[o] = pre;
+            float res = apply_act(pre, g.act, g.lo, g.hi);
+            if (extras) res = res * (ev1[r] > 0.f ? 1.0f : ev1[r] + 1.0f) + ev0[r];
+            g.out0[o] = res;
+          } else {                                // EPI_RAW: partial plane [z][M][N]
+            g.out0[(size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 // GATHER_A: the rows of a KC A operand are gathered through g.a_rows (the exemplar gather of the first encoder layer).  A
 // template parameter rather than a run-time test so that the gathered launch -- the dominant one of a training step -- is
 // a kernel symbol of its own in per-kernel profiles.
@@ -648,307 +959,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
     if (t == 1.2345e-30f) g.out0[0] = t;
     return;
   }
-  // ---- epilogue.  acc[mt][nt][r] <-> row m0 + wr*32*MT + mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
-  //                                    col (within the wave tile) nt*32 + (lane&31)
-  const int l31 = lane & 31, lh = lane >> 5;
-  // output row of GEMM row m (identity unless this is the data gradient of a strided convolution)
-  auto orow = [&](int m) -> size_t {
-    if (CV == 1 && g.cv.remap) {
-      const unsigned nn = fdiv((unsigned)m, g.cv.div_rhw), rem = (unsigned)m - nn * (unsigned)(g.cv.RH * g.cv.RW);
-      const unsigned ry = fdiv(rem, g.cv.div_rw), rx = rem - ry * (unsigned)g.cv.RW;
-      return ((size_t)nn * g.cv.OH2 + ry * g.cv.os + g.cv.ooy) * g.cv.OW2 + rx * g.cv.osx + g.cv.oox;
-    }
-    return (size_t)m;
-  };
-  if constexpr (EPI == EPI_DIST_TILEMIN || EPI == EPI_DIST_COLLECT) {
-    // e0 = squared norms of the A rows, e1 = of the B rows; acc = dot products
-    float tmin[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
-      const bool nok = n < g.N;
-      const float bn = nok ? g.e1[n] : 0.f;
-      const float thr = (EPI == EPI_DIST_COLLECT && nok) ? g.bias0[n] : -INFINITY;
-      tmin[nt] = INFINITY;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < g.M) {
-            const float d = g.e0[m] + bn - 2.0f * acc[mt][nt][r];
-            if (EPI == EPI_DIST_TILEMIN) tmin[nt] = fminf(tmin[nt], d);
-            else if (nok && d <= thr) g.aux_cand[(size_t)n * g.ldo + atomicAdd(&g.aux_cnt[n], 1)] = m;
-          }
-        }
-    }
-    if (EPI == EPI_DIST_TILEMIN) {
-      // lanes l / l+32 hold the same column; then the NW/2 wave rows through LDS (free after the last barrier)
-      float* red = smem;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        tmin[nt] = fminf(tmin[nt], __shfl_xor(tmin[nt], 32, 64));
-        if (lh == 0) red[wr * BN_ + wc * 32 * NT + nt * 32 + l31] = tmin[nt];
-      }
-      __syncthreads();
-      if ((int)threadIdx.x < BN_ && n0 + (int)threadIdx.x < g.N) {
-        float v = red[threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < NW / 2; ++w) v = fminf(v, red[w * BN_ + threadIdx.x]);
-        g.out0[(size_t)tm * g.ldo + n0 + threadIdx.x] = v;
-      }
-    }
-  } else if constexpr (EPI == EPI_PRIOR_LSE) {
-    // e0 = |c'_m|^2 (rows), e1 = |z'_n|^2 (columns), acc = c'_m . z'_n.  Per column the block's rows are reduced on
-    // t = acc - |c'|^2/2 (= -d2/2 + |z'|^2/2: the column's own norm drops out of every difference) to
-    // (max, sum exp(t - max), #masked); lanes l / l+32 hold the same column, the NW/2 wave rows meet in LDS.
-    const bool masked = g.pr_ridx != nullptr && g.pr_cidx != nullptr;
-    float hc[MT][16];
-    long long ri[MT][16];
-    unsigned live[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      live[mt] = 0u;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const bool ok = m < g.M;
-        hc[mt][r] = ok ? 0.5f * g.e0[m] : 0.f;
-        ri[mt][r] = (masked && ok) ? (long long)g.pr_ridx[m] : -2;
-        if (ok) live[mt] |= 1u << r;
-      }
-    }
-    float* red = smem;          // [NW/2][BN][3], free after the last barrier of the slab loop
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
-      const long long zi = (masked && n < g.N) ? (long long)g.pr_cidx[n] : -1;
-      float tmax = -INFINITY, ssum = 0.f, nm = 0.f;
-      unsigned use[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        use[mt] = live[mt];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc[mt][nt][r] -= hc[mt][r];
-          if (masked && ((use[mt] >> r) & 1u) && (ri[mt][r] == zi || ri[mt][r] == (long long)EVAE_PRIOR_MASK_ALL)) { nm += 1.f; use[mt] &= ~(1u << r); }
-          if ((use[mt] >> r) & 1u) tmax = fmaxf(tmax, acc[mt][nt][r]);
-        }
-      }
-      const float mk = -tmax * kLog2e;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if ((use[mt] >> r) & 1u) ssum += fast_exp2(fmaf(acc[mt][nt][r], kLog2e, mk));
-      const float ot = __shfl_xor(tmax, 32, 64), os = __shfl_xor(ssum, 32, 64), on = __shfl_xor(nm, 32, 64);
-      const float mx = fmaxf(tmax, ot);
-      const float fa = (tmax == mx) ? 1.f : fast_exp2((tmax - mx) * kLog2e);      // -inf - (-inf) never evaluated
-      const float fb = (ot == mx) ? 1.f : fast_exp2((ot - mx) * kLog2e);
-      if (lh == 0) {
-        float* cb = red + (wr * BN_ + wc * 32 * NT + nt * 32 + l31) * 3;
-        cb[0] = mx; cb[1] = ssum * fa + os * fb; cb[2] = nm + on;
-      }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < BN_ && n0 + (int)threadIdx.x < g.N) {
-      float mx = -INFINITY, sacc = 0.f, nacc = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW / 2; ++w) mx = fmaxf(mx, red[(w * BN_ + threadIdx.x) * 3]);
-#pragma unroll
-      for (int w = 0; w < NW / 2; ++w) {
-        const float tw = red[(w * BN_ + threadIdx.x) * 3];
-        if (tw != -INFINITY) sacc += red[(w * BN_ + threadIdx.x) * 3 + 1] * fast_exp2((tw - mx) * kLog2e);
-        nacc += red[(w * BN_ + threadIdx.x) * 3 + 2];
-      }
-      const int n = n0 + threadIdx.x;
-      const size_t o = (size_t)tm * g.ldo + n;
-      g.out0[o] = (mx == -INFINITY) ? -INFINITY : *g.pr_cst_dev + (mx - 0.5f * g.e1[n]);
-      g.out1[o] = sacc;
-      g.out2[o] = nacc;
-    }
-  } else if constexpr (EPI == EPI_PRIOR_P) {
-    // P[m][n] = g_n exp(cst - d2_mn / 2 - lse_n), d2 = |c'|^2 + |z'|^2 - 2 acc; bias0 = lse, bias1 = upstream gradient.
-    // Columns N <= n < ldo (padding up to a multiple of 4) are written as zeros: P is the operand of two more GEMMs.
-    const bool masked = g.pr_ridx != nullptr && g.pr_cidx != nullptr;
-    const float cst = *g.pr_cst_dev;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
-      if (n >= g.ldo) continue;
-      const bool nok = n < g.N;
-      const float zn = nok ? g.e1[n] : 0.f;
-      const float gq = nok ? g.bias1[n] : 0.f;
-      const float kq = nok ? (cst - g.bias0[n]) * kLog2e : 0.f;
-      const long long zi = (masked && nok) ? (long long)g.pr_cidx[n] : -1;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m >= g.M) continue;
-          const float d = fmaxf(g.e0[m] + zn - 2.0f * acc[mt][nt][r], 0.f);
-          bool ok = nok;
-          if (masked) ok = ok && ((long long)g.pr_ridx[m] != zi) && ((long long)g.pr_ridx[m] != (long long)EVAE_PRIOR_MASK_ALL);
-          g.out0[(size_t)m * g.ldo + n] = ok ? gq * fast_exp2(kq - d * (0.5f * kLog2e)) : 0.f;
-        }
-    }
-  } else if (GATED) {
-    const int n = n0 + wc * 32 + l31;
-    if (n < g.N) {
-      const float bh = (EPI == EPI_GATED && g.bias0) ? g.bias0[n] : 0.f;
-      const float bg = (EPI == EPI_GATED && g.bias1) ? g.bias1[n] : 0.f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < g.M) {
-            if (EPI == EPI_GATED) {
-              const float h = acc[mt][0][r] + bh;
-              // sigmoid on the hardware exp2 / rcp (about 1e-7 relative): the precise expf costs ~15 VALU instructions
-              // per element, and VALU issue is what the co-resident block's MFMAs wait on
-              const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc[mt][NT - 1][r] + bg)));
-              const size_t o = orow(m) * g.ldo + n;
-              g.out0[o] = h * s;
-              if (g.out1) g.out1[o] = h;
-              if (g.out2) g.out2[o] = s;
-            } else {   // EPI_RAW_GATED: partial planes [z][2][M][N]
-              const size_t plane = (size_t)g.M * g.N;
-              const size_t o = (size_t)blockIdx.z * 2 * plane + (size_t)m * g.N + n;
-              g.out0[o] = acc[mt][0][r];
-              g.out0[o + plane] = acc[mt][NT - 1][r];
-            }
-          }
-        }
-    }
-  } else if constexpr (EPI == EPI_GATE_BWD_IMG) {
-    // dh = v s, dg = v (h s)(1 - s) as in EPI_GATE_BWD; column cc of the merged [dh | dg] buffer is n (dh) / N + n (dg).  A lane
-    // holds four consecutive rows per r-group: as bf16 terms they are 8 bytes of one 16-byte slot of the image
-    //   img[((cc >> 7) * nslab + (row >> 5)) * 3 + p][cc & 127][slot (row & 31) >> 3, XOR-swizzled][row & 7]
-    // (truncation split: w0 = top 8 significant bits, w1 of w - w0, w2 the rest: exact).  Rows must come in aligned fours
-    // (M % 4 == 0, img_mbase % 4 == 0: checked by the host).
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
-      if (n >= g.N) continue;
-      float go[MT][16], sv[MT][16];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const size_t oe = (size_t)(m < g.M ? m : 0) * g.N + n;
-          go[mt][r] = g.e0[oe];
-          sv[mt][r] = g.e1[oe];
-        }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ml = m0 + wr * 32 * MT + mt * 32 + 8 * j + 4 * lh;      // first of four rows (local)
-          if (ml >= g.M) continue;
-          const int gm = ml + g.img_mbase, slab = gm >> 5, mi = gm & 31;
-#pragma unroll
-          for (int which = 0; which < 2; ++which) {
-            const int cc = which ? g.N + n : n;
-            const int c = cc & 127;
-            unsigned t0[2] = {0u, 0u}, t1[2] = {0u, 0u}, t2[2] = {0u, 0u};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int r = 4 * j + i;
-              const float v = acc[mt][nt][r], s_ = sv[mt][r];
-              const float w = which ? v * go[mt][r] * (1.0f - s_) : v * s_;
-              const unsigned u0 = __float_as_uint(w) & 0xFFFF0000u;
-              const float r1 = w - __uint_as_float(u0);
-              const unsigned u1 = __float_as_uint(r1) & 0xFFFF0000u;
-              const float r2 = r1 - __uint_as_float(u1);
-              const unsigned u2 = __float_as_uint(r2);
-              const int sh = 16 * (i & 1);
-              t0[i >> 1] |= (u0 >> 16) << sh; t1[i >> 1] |= (u1 >> 16) << sh; t2[i >> 1] |= (u2 >> 16) << sh;
-            }
-            char* base = reinterpret_cast<char*>(g.img) + ((size_t)((cc >> 7) * g.img_nslab + slab) * 3 * 128 + c) * 64 +
-                         ((((mi >> 3) ^ ((c >> 2) & 3))) << 4) + ((mi & 7) << 1);
-            *reinterpret_cast<uint2*>(base) = make_uint2(t0[0], t0[1]);
-            *reinterpret_cast<uint2*>(base + 128 * 64) = make_uint2(t1[0], t1[1]);
-            *reinterpret_cast<uint2*>(base + 2 * 128 * 64) = make_uint2(t2[0], t2[1]);
-          }
-        }
-    }
-  } else if constexpr (EPI == EPI_GATE_BWD) {
-    // dh = v * s, dg = v * (h s) * (1 - s) with h s and s of the layer below read from dense [M x N] arrays.  All the
-    // reads of a fragment are issued before the first store: the stores may alias them as far as the compiler knows,
-    // and a read -> store -> read chain would pay one memory latency per element (that is the whole run time of a
-    // launch with few blocks, and of a block's tail in any launch).
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
-      if (n >= g.N) continue;
-      float go[MT][16], sv[MT][16];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const size_t oe = (size_t)(m < g.M ? m : 0) * g.N + n;
-          go[mt][r] = g.e0[oe];
-          sv[mt][r] = g.e1[oe];
-        }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m >= g.M) continue;
-          const size_t o = orow(m) * g.ldo + n;
-          const float v = acc[mt][nt][r], s_ = sv[mt][r];
-          g.out0[o] = v * s_;                          // dh
-          g.out1[o] = v * go[mt][r] * (1.0f - s_);     // dg = v * h * s * (1 - s)
-        }
-    }
-  } else {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
-      if (n >= g.N) continue;
-      const float bias = (EPI == EPI_LINEAR && g.bias0) ? g.bias0[n] : 0.f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        // residual blocks of fully_conv (models/fully_conv.py:13-23: x + conv(ELU(x))): e1 = ELU(x) of the block whose data
-        // gradient this is -> times ELU'(x) = (a > 0 ? 1 : a + 1); e0 = the tensor added to the result (x forward, dy
-        // backward).  Both are fetched for the whole 32-row tile BEFORE the first store: stores to out0 may alias them as far
-        // as the compiler knows, so loads placed between the stores would run one at a time.
-        float ev0[16], ev1[16];
-        const bool extras = EPI == EPI_LINEAR && (g.e0 || g.e1);
-        if (extras) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const bool ok = m < g.M;
-            const size_t o = orow(ok ? m : m0) * g.ldo + n;
-            ev0[r] = (ok && g.e0) ? g.e0[o] : 0.f;
-            ev1[r] = (ok && g.e1) ? g.e1[o] : 1.f;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m >= g.M) continue;
-          const size_t o = orow(m) * g.ldo + n;
-          const float v = acc[mt][nt][r];
-          if (EPI == EPI_LINEAR) {
-            const float pre = v + bias;
-            if (g.out1) g.out1[o] = pre;
-            float res = apply_act(pre, g.act, g.lo, g.hi);
-            if (extras) res = res * (ev1[r] > 0.f ? 1.0f : ev1[r] + 1.0f) + ev0[r];
-            g.out0[o] = res;
-          } else {                                // EPI_RAW: partial plane [z][M][N]
-            g.out0[(size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n] = v;
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<EPI, BN_, NW, CV>(g, acc, m0, n0, tm, wr, wc, lane, smem);
 }
 
 // ---- host side: plan, launch --------------------------------------------------------------------------

@@ -101,6 +101,11 @@ def prior_lse_fwd(z, centres, log_var, z_idx=None, c_idx=None, want_prob=False):
     return m, s, n, prob
 
 
+def gemm_x6_configure(enabled=-1, min_rows=-1):
+    """Policy of the split-bf16 fp32 GEMM kernel (include/evae_hip.h: evae_gemm_x6_configure)."""
+    _lib.check(_lib.load().evae_gemm_x6_configure(int(enabled), int(min_rows)), "evae_gemm_x6_configure")
+
+
 def prior_set_norm_limit(limit):
     """Largest centred squared norm (sigma units) of a query tile the matrix-core prior kernels still evaluate in the
     expanded form; above it they switch to direct differences.  Negative restores the default, 0 forces the direct path."""

@@ -174,7 +174,13 @@ int evae_select_exemplars(const int64_t* pos, int n, const int64_t* cand_idx, in
  */
 #define EVAE_ACT_NONE 0
 #define EVAE_ACT_SIGMOID 1
-#define EVAE_ACT_HARDTANH 2 /* clamp to [act_lo, act_hi] */
+#define EVAE_ACT_HARDTANH 2 /* fp32 GEMMs on the bf16 matrix pipe (csrc/evae_gemm_x6.h): operands are split in-kernel into three bf16 terms each and six
+ * partial products are accumulated in fp32 -- fp32-GEMM accuracy at up to 16/6 of the fp32 matrix rate.  Applies to launches
+ * whose operands are both contraction-contiguous (forward layers, channels-last convolutions) with at least `min_rows`
+ * output rows.  enabled: 0 off, 1 on, < 0 unchanged; min_rows < 0 unchanged.  Defaults: on, 2048 (env EVAE_X6, EVAE_X6_MIN_ROWS). */
+int evae_gemm_x6_configure(int enabled, int min_rows);
+
+/* clamp to [act_lo, act_hi] */
 
 size_t evae_dense_fwd_workspace_bytes(int M, int K, int N, int gated);
 int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, int K, int ldx,

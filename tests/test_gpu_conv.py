@@ -26,7 +26,7 @@ CASES = [  # N, C, H, W, Co, k, stride, pad
 
 @pytest.mark.parametrize("gated", [True, False])
 @pytest.mark.parametrize("N,C,H,W,Co,k,s,p", CASES)
-def test_conv2d_fwd_bwd_matches_torch(N, C, H, W, Co, k, s, p, gated):
+def test_conv2d_fwd_bwd_matches_torch(N, C, H, W, Co, k, s, p, gated, gemm_pipe):
     from evae import ops
     rs = np.random.RandomState(N + C + Co + k)
     x = torch.from_numpy(rs.standard_normal((N, C, H, W)).astype(np.float32))
@@ -58,7 +58,7 @@ def test_conv2d_fwd_bwd_matches_torch(N, C, H, W, Co, k, s, p, gated):
 
 @pytest.mark.parametrize("N,C,H,W,k,per", [(3, 48, 32, 32, 3, None), (2, 96, 16, 16, 3, None), (5, 48, 16, 16, 3, "2"),
                                             (2, 16, 9, 7, 3, None), (2, 20, 8, 8, 5, None), (2, 64, 8, 8, 3, None)])
-def test_residual_block_matches_torch(N, C, H, W, k, per, monkeypatch):
+def test_residual_block_matches_torch(N, C, H, W, k, per, monkeypatch, gemm_pipe):
     """x + conv(ELU(x)) (models/fully_conv.py:13-23) through ops.res_block: output and all gradients against float64
     autograd, also with the tensors processed in passes of 2 images."""
     from evae import ops
@@ -118,7 +118,7 @@ def test_conv2d_activations_and_modules():
 
 
 @pytest.mark.parametrize("case", [(5, 32, 28, 28, 32, 3, 2, 1), (7, 64, 7, 7, 6, 3, 1, 1), (6, 32, 14, 14, 64, 5, 1, 2)])
-def test_conv2d_channels_last_multi_pass(case, monkeypatch):
+def test_conv2d_channels_last_multi_pass(case, monkeypatch, gemm_pipe):
     """Tensors beyond 2 GiB are processed in passes over the images (31-bit buffer offsets); force 2 images per
     pass on small tensors and compare with the single-pass result."""
     from evae import ops
@@ -173,7 +173,7 @@ G6_CONV_CASES = [   # tools/gen_goldens.py::G6_CONV_CASES
 
 
 @pytest.mark.parametrize("i", range(len(G6_CONV_CASES)))
-def test_conv_modules_match_reference_golden(golden, i):
+def test_conv_modules_match_reference_golden(golden, i, gemm_pipe):
     """utils.nn.GatedConv2d / Conv2d (reference utils/nn.py:72-114) as modules: output and every gradient against the
     real reference's modules on the same weights and inputs (G6)."""
     from utils.nn import GatedConv2d, Conv2d

@@ -316,7 +316,7 @@ def test_topk_sharded_merge(ops):
 # ---------------------------------------------------------------- dense layers
 @pytest.mark.parametrize("M,K,N", [(37, 53, 24), (100, 784, 300), (1000, 300, 300), (257, 40, 300), (5000, 784, 300),
                                    (130, 294, 40)])
-def test_gated_dense_fwd_bwd(ops, M, K, N):
+def test_gated_dense_fwd_bwd(ops, M, K, N, gemm_pipe):
     rs = np.random.RandomState(M + K)
     x = rs.standard_normal((M, K)).astype(np.float32)
     wh = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32); bh = (rs.standard_normal(N) * 0.1).astype(np.float32)
@@ -378,7 +378,7 @@ def test_dense_operand_beyond_2gib(ops):
 
 
 @pytest.mark.parametrize("K", [4, 28, 32, 36, 60, 64, 68, 96, 100])
-def test_dense_k_tails(ops, K):
+def test_dense_k_tails(ops, K, gemm_pipe):
     """K tails of every length around the 32-wide slab (zero fill by out-of-range buffer offsets / masked gathers)."""
     rs = np.random.RandomState(K)
     M, N = 200, 72
@@ -396,9 +396,60 @@ def test_dense_k_tails(ops, K):
         assert rel(t[2].grad.cpu().numpy(), gout.astype(np.float64).sum(0)) < 1e-5
 
 
+@pytest.fixture
+def x6_all_rows(ops):
+    """Drive every eligible launch through the split-bf16 kernel (csrc/evae_gemm_x6.h), whatever its row count."""
+    ops.gemm_x6_configure(1, 0)
+    yield
+    ops.gemm_x6_configure(1, 2048)
+
+
+@pytest.mark.parametrize("M,K,N", [(37, 52, 24), (130, 300, 300), (1000, 300, 300), (257, 40, 300), (5000, 784, 300),
+                                   (129, 296, 40), (2500, 300, 300)])
+@pytest.mark.parametrize("spread", [0, 6])
+def test_x6_gated_dense_forward_holds_the_fp32_bar(ops, x6_all_rows, M, K, N, spread):
+    """Gated layer forward on the bf16 pipe with three-term operand splits: against the fp64 oracle at the tolerance of the
+    fp32-MFMA kernel, and no worse than that kernel by more than a small factor -- also when the operands span 10^+-spread
+    (per-column scales: the split of each element is relative to ITS magnitude)."""
+    rs = np.random.RandomState(M + K + spread)
+    x = rs.standard_normal((M, K)).astype(np.float32)
+    wh = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32); bh = (rs.standard_normal(N) * 0.1).astype(np.float32)
+    wg = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32); bg = (rs.standard_normal(N) * 0.1).astype(np.float32)
+    if spread:
+        sc = (10.0 ** rs.uniform(-spread, spread, K)).astype(np.float32)
+        x = x * sc; wh = wh / sc; wg = wg / sc
+    y, _ = orc.gated_dense(x.astype(np.float64), wh.astype(np.float64), bh.astype(np.float64), wg.astype(np.float64),
+                           bg.astype(np.float64))
+    t = [dev(a) for a in (x, wh, bh, wg, bg)]
+    out6 = ops.gated_dense(*t).cpu().numpy()
+    ops.gemm_x6_configure(0, -1)
+    out32 = ops.gated_dense(*t).cpu().numpy()
+    ops.gemm_x6_configure(1, -1)
+    e6, e32 = rel(out6, y), rel(out32, y)
+    assert e6 < 2e-6, (e6, e32)
+    assert e6 < 2.0 * e32 + 2e-7, (e6, e32)
+    assert not np.array_equal(out6, out32) or M < 2000     # the two pipes round differently: equal bits = the switch did nothing
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("M,K,N", [(300, 300, 784), (1000, 300, 40), (2049, 64, 129 * 4)])
+def test_x6_linear_forward_holds_the_fp32_bar(ops, x6_all_rows, act, M, K, N):
+    rs = np.random.RandomState(M + N + act)
+    x = rs.standard_normal((M, K)).astype(np.float32)
+    w = (rs.standard_normal((N, K)) * 4 / np.sqrt(K)).astype(np.float32); b = (rs.standard_normal(N) * 0.1).astype(np.float32)
+    pre = x.astype(np.float64) @ w.astype(np.float64).T + b
+    y = 1 / (1 + np.exp(-pre)) if act == 1 else (np.clip(pre, -6, 2) if act == 2 else pre)
+    out6 = ops.linear(dev(x), dev(w), dev(b), act, -6.0, 2.0).cpu().numpy()
+    ops.gemm_x6_configure(0, -1)
+    out32 = ops.linear(dev(x), dev(w), dev(b), act, -6.0, 2.0).cpu().numpy()
+    ops.gemm_x6_configure(1, -1)
+    e6, e32 = rel(out6, y), rel(out32, y)
+    assert e6 < 2e-6 and e6 < 2.0 * e32 + 2e-7, (e6, e32)
+
+
 @pytest.mark.parametrize("act", [0, 1, 2])
 @pytest.mark.parametrize("M,K,N", [(37, 53, 24), (100, 300, 784), (1000, 300, 40)])
-def test_linear_fwd_bwd(ops, act, M, K, N):
+def test_linear_fwd_bwd(ops, act, M, K, N, gemm_pipe):
     rs = np.random.RandomState(M + N + act)
     x = rs.standard_normal((M, K)).astype(np.float32)
     w = (rs.standard_normal((N, K)) * 4 / np.sqrt(K)).astype(np.float32); b = (rs.standard_normal(N) * 0.1).astype(np.float32)
