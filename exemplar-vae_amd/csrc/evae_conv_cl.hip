@@ -265,7 +265,7 @@ static int cl_fwd_impl(const float* x, const evae_conv_desc_t* d, const float* w
     g.A[0] = x + xo - cv.bias / 4;     // the per-row offsets carry +bias (they are never negative)
     g.M = nn * OH * OW;
     int rc;
-    const bool x6 = gemm_x6_enabled() && g.M >= gemm_x6_min_rows();
+    const bool x6 = gemm_x6_enabled() && gemm_x6_fills(g.M, d->Co, gated);
     if (gated) {
       g.out0 = out + oo; g.out1 = save_h ? save_h + oo : nullptr; g.out2 = save_s ? save_s + oo : nullptr;
       if (x6) rc = launch_gemm_x6<EPI_GATED, 1, 128>(g, 1, stream, "conv2d_cl_fwd(gated, x6)");
@@ -363,7 +363,7 @@ static int cl_bwd_data_impl(const float* dy, const float* wh, const float* wg, c
       const size_t cls = (size_t)pt.n * ldv * 64;
       float* wc = wp + usedp;
       usedp += cls;
-      const bool x6 = gemm_x6_enabled() && !residual && std::min(cl_images_per_pass(d, OH, OW, C, ldy), d->N) * RH * W2 >= gemm_x6_min_rows();
+      const bool x6 = gemm_x6_enabled() && !residual && gemm_x6_fills(std::min(cl_images_per_pass(d, OH, OW, C, ldy), d->N) * RH * W2, 64, false);
       cl_permute_dgrad_pair_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, taps, ldv, pt, wc, x6 ? 1 : 0);
       int rc = check_launch("cl_permute_dgrad_pair_kernel");
       if (rc) return rc;
@@ -430,7 +430,7 @@ static int cl_bwd_data_impl(const float* dy, const float* wh, const float* wg, c
       const size_t cls = (size_t)tl.n * ldv * C;
       float* wc = wp + used;
       used += cls;
-      const bool x6 = gemm_x6_enabled() && std::min(cl_images_per_pass(d, OH, OW, C, ldy), d->N) * RH * RW >= gemm_x6_min_rows();
+      const bool x6 = gemm_x6_enabled() && gemm_x6_fills(std::min(cl_images_per_pass(d, OH, OW, C, ldy), d->N) * RH * RW, C, false);
       cl_permute_dgrad_kernel<<<elt_grid(cls), 256, 0, stream>>>(wh, wg, Co, C, taps, ldv, tl, wc, x6 ? 1 : 0);
       int rc = check_launch("cl_permute_dgrad_kernel");
       if (rc) return rc;

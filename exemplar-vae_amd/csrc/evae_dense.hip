@@ -100,7 +100,7 @@ extern "C" int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, 
   g.A[0] = x; g.B[0] = wh; g.Bg = wg; g.lda[0] = ldx; g.ldb[0] = K; g.Kc[0] = K; g.npairs = 1;
   g.a_rows = rows; g.M = M; g.N = N; g.bias0 = bh; g.bias1 = bg;
   g.out0 = out; g.out1 = save_h; g.out2 = save_s; g.ldo = N;
-  if (pl.nz <= 1 && gemm_x6_use(g)) return launch_gemm_x6<EPI_GATED>(g, 1, stream, "gated_dense_fwd(x6)");
+  if (pl.nz <= 1 && gemm_x6_use(g, true)) return launch_gemm_x6<EPI_GATED>(g, 1, stream, "gated_dense_fwd(x6)");
   if (pl.nz <= 1) return launch_gemm<true, true, EPI_GATED>(g, pl, stream, "gated_dense_fwd");
   if (ws == nullptr || ws_bytes < evae_dense_fwd_workspace_bytes(M, K, N, 1)) {
     set_error("gated_dense_fwd: workspace too small (%zu)", ws_bytes);
@@ -108,7 +108,7 @@ extern "C" int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, 
   }
   g.out0 = (float*)ws; g.out1 = g.out2 = nullptr;
   int rc;
-  if (gemm_x6_use(g)) {
+  if (gemm_x6_use(g, true)) {
     g.ksplit = pl.ksplit;
     rc = launch_gemm_x6<EPI_RAW_GATED>(g, pl.nz, stream, "gated_dense_fwd(split-K, x6)");
   } else {
@@ -205,7 +205,7 @@ extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const floa
   if (dy2) { g.A[1] = dy2; g.B[1] = w2; g.lda[1] = ldy; g.ldb[1] = K; g.Kc[1] = N; }
   g.M = M; g.N = K; g.out0 = dx_or_dh; g.out1 = gate ? dg : nullptr; g.ldo = ldo; g.e0 = out_prev; g.e1 = s_prev;
   const size_t part_bytes = pl.nz > 1 ? align_up((size_t)pl.nz * M * K * sizeof(float), 256) : 0;
-  const bool x6 = gemm_x6_enabled() && M >= gemm_x6_min_rows() && ws && ws_bytes >= part_bytes + x6_wt_bytes(N, K, np) &&
+  const bool x6 = gemm_x6_enabled() && gemm_x6_fills(M, K, false) && ws && ws_bytes >= part_bytes + x6_wt_bytes(N, K, np) &&
                   N % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)dy1 | (uintptr_t)dy2) & 15) == 0 && (long long)M * ldy < (1ll << 29);
   if (x6) {
     // contraction-contiguous weights: wT[p] = w_p^T behind the split-K planes, then the split-bf16 kernel (A = dy, B = wT)

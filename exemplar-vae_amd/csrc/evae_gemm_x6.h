@@ -278,7 +278,17 @@ extern int g_x6_enabled, g_x6_min_rows;
 void gemm_x6_init_policy();
 static bool gemm_x6_enabled() { if (g_x6_enabled < 0) gemm_x6_init_policy(); return g_x6_enabled != 0; }
 static int gemm_x6_min_rows() { if (g_x6_min_rows < 0) gemm_x6_init_policy(); return g_x6_min_rows; }
-static bool gemm_x6_use(const GemmArgs& g) { return gemm_x6_enabled() && g.M >= gemm_x6_min_rows() && gemm_x6_ok(g); }
+// Worth it only when the launch fills the machine: at least 384 block tiles (of 512 resident slots) of 128 x 128 or
+// 128 x 64 -- narrow outputs (the 80-column heads of the encoder) leave most CUs without a block and run faster on the fp32
+// kernel's smaller tiles.  min_rows == 0 (tests) takes every eligible launch.
+static bool gemm_x6_fills(int M, int N, bool gated) {
+  if (gemm_x6_min_rows() == 0) return true;
+  const long long t128 = (long long)cdiv(M, BM) * cdiv(N, gated ? 64 : 128), t64 = (long long)cdiv(M, BM) * cdiv(N, 64);
+  return M >= gemm_x6_min_rows() && (gated ? t128 : std::max(t128, t64)) >= 384;
+}
+static bool gemm_x6_use(const GemmArgs& g, bool gated = false) {
+  return gemm_x6_enabled() && gemm_x6_fills(g.M, g.N, gated) && gemm_x6_ok(g);
+}
 
 // column tile of a plain (not gated) launch: the one that wastes less of the machine -- padding of the last column tile
 // times the occupancy of the last round of blocks (two blocks per CU, 256 CUs)

@@ -11,7 +11,7 @@
 // The fp32 expanded form is guarded like the small-z kernels: if any centred query norm exceeds the limit, a device flag
 // cancels the GEMM launches and releases the direct-difference VALU kernels of evae_prior.hip instead -- both sets of
 // launches are enqueued, the flag decides on the device, nothing is read back (hipGraph-capturable).
-#include "evae_gemm_kernel.h"
+#include "evae_gemm_x6.h"
 #include "evae_prior_gemm.h"
 
 namespace evae {
@@ -206,6 +206,12 @@ bool prior_gemm_applies(int B, int C, int zdim) {
 }
 
 static int launch_prior_gemm(GemmArgs& g, int B, bool lse, hipStream_t stream) {
+  // both operands are contraction-contiguous (centred exemplars x centred queries): the split-bf16 kernel when the launch
+  // fills the machine (the IWAE evaluator: 5000 samples x 100000 exemplars)
+  if (gemm_x6_use(g) && B > 64) {
+    if (lse) return launch_gemm_x6<EPI_PRIOR_LSE>(g, 1, stream, "prior_gemm(lse, x6)");
+    return launch_gemm_x6<EPI_PRIOR_P>(g, 1, stream, "prior_gemm(P, x6)");
+  }
   if (lse) {
     if (B <= 64) return launch_gemm_w<true, true, EPI_PRIOR_LSE, true, 64, 8>(g, 1, stream, "prior_gemm(lse)");
     return launch_gemm_w<true, true, EPI_PRIOR_LSE, true, 128, 8>(g, 1, stream, "prior_gemm(lse)");

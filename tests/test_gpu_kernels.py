@@ -158,7 +158,7 @@ def test_prior_offset_and_large_scale_latents(ops, offset, scale, masked):
 @pytest.mark.parametrize("B,C,zd,masked", [(100, 3000, 256, True), (300, 2000, 128, False), (64, 1000, 100, True),
                                            (20, 150, 294, True), (9, 70, 512, False), (130, 257, 68, True),
                                            (1, 1, 256, False), (5, 3, 72, True)])
-def test_prior_large_latent_sizes_run_as_gemms_on_the_matrix_cores(ops, B, C, zd, masked):
+def test_prior_large_latent_sizes_run_as_gemms_on_the_matrix_cores(ops, B, C, zd, masked, gemm_pipe):
     """z > 64 (fully_conv: 256 on 64 x 64 inputs, 294 on 28 x 28): forward = GEMM with a log-sum-exp epilogue, backward =
     three GEMMs (evae_prior_gemm.hip), against the fp64 oracle; odd sizes are padded by the staging pass."""
     z, c = gi.clustered_latents(500 + B + C, B, C, zd)
@@ -168,7 +168,7 @@ def test_prior_large_latent_sizes_run_as_gemms_on_the_matrix_cores(ops, B, C, zd
     _prior_fwd_bwd_vs_oracle(ops, z, c, lv, zi, ci, masked, gout)
 
 
-def test_prior_gemm_path_with_an_offset_latent_cloud(ops):
+def test_prior_gemm_path_with_an_offset_latent_cloud(ops, gemm_pipe):
     B, C, zd = 100, 2000, 256
     z, c = gi.clustered_latents(77, B, C, zd)
     z = (z * 0.5 + 40.0).astype(np.float32); c = (c * 0.5 + 40.0).astype(np.float32)
