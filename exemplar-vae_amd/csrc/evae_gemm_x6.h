@@ -16,7 +16,11 @@
 // tile 64 x 64, K-slab = 32.  LDS holds ONE slab as six planes (A0 A1 A2 B0 B1 B2) of 128 rows x 32 bf16 (64-byte rows, the
 // four 16-byte slots XOR-swizzled by (row >> 2) & 3: fragment reads and staging writes are conflict-free): 48 KB, two blocks
 // per CU.  Per slab a wave reads its 24 fragments into registers, the block meets at a barrier, and the 48 MFMAs then run
-// while the same threads split the NEXT slab (prefetched into registers one slab earlier) and write it to LDS.
+// with one micro-step of the NEXT slab's staging behind every second MFMA (split of a register pair, the three 8-byte LDS
+// writes of a chunk, the chunk's load for the slab after next).  VALU work is not free beside the matrix pipe on this
+// machine (an MFMA holds the SIMD's issue for its passes: measured, the staging adds its full issue time); pre-split B
+// operands (tile images built by a pre-pass) were measured too: same kernel time, and the extra launches cost the headline
+// step 28 us, so both operands are split in the kernel.
 #pragma once
 #include "evae_gemm_kernel.h"
 
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int p = 0; p < 3; ++p) bf[step][nt][p] = *reinterpret_cast<const x6_bf16x8*>(lds + fb[step][nt] + p * (BN_ * 64));
       }
       if constexpr (ST) __syncthreads();             // every wave holds its fragments: the planes may be overwritten
+      __builtin_amdgcn_s_setprio(1);                 // the MFMA phase ahead of the other block's fragment reads
       // 48 MFMAs: term-major inside a k-step (four independent accumulators between two uses of one), smallest terms first.
       // Behind every second MFMA one micro-step of the staging of the next slab; the chunk's load for the slab after next
       // goes out right behind its LDS writes, a whole slab before it is needed.
@@ -247,6 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               }
             }
       EVAE_SB;
+      __builtin_amdgcn_s_setprio(0);
       __syncthreads();
     };
     constexpr std::true_type T{};
