@@ -241,6 +241,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
           const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (m < g.M) {
             const float d = g.e0[m] + bn - 2.0f * acc[mt][nt][r];
+            if (EPI == EPI_DIST_TILEMIN && g.out1 && nok) g.out1[(size_t)m * g.ldo + n] = d;    // kept for the collect scan
             if (EPI == EPI_DIST_TILEMIN) tmin[nt] = fminf(tmin[nt], d);
             else if (nok && d <= thr) g.aux_cand[(size_t)n * g.ldo + atomicAdd(&g.aux_cnt[n], 1)] = m;
           }

@@ -10,7 +10,7 @@
 //      has approximate distance <= T + 2E: GEMM pass 2 appends exactly those rows to the query's candidate list;
 //   4. exact distances of the candidates, k rounds of (value, index) arg-min.
 // Cost: two passes over the [N x z] cache at GEMM speed instead of one at fp64-VALU speed (c5: 1.6 ms -> see DESIGN).
-#include "evae_gemm_kernel.h"
+#include "evae_gemm_x6.h"
 #include "evae_topk_screen.h"
 
 namespace evae {
@@ -185,6 +185,25 @@ __global__ __launch_bounds__(256) void topk_exact_kernel(const float* __restrict
   }
 }
 
+// Candidates from the stored approximate distances D[m][n] (row stride ldt): m joins the list of query n when D <= thr[n].
+// One thread per four queries of a row; the per-query counters take one atomic per candidate (a few dozen per query).
+__global__ __launch_bounds__(256) void dist_collect_kernel(const float* __restrict__ D, int N, int B, int ldt,
+                                                           const float* __restrict__ thr, int* __restrict__ cnt,
+                                                           int* __restrict__ cand, size_t ldc) {
+  const int q4 = ldt / 4;
+  const size_t total = (size_t)N * q4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / q4), n0 = 4 * (int)(i - (size_t)m * q4);
+    if (n0 >= B) continue;
+    const float4 d = *reinterpret_cast<const float4*>(D + (size_t)m * ldt + n0);
+    const float4 t = *reinterpret_cast<const float4*>(thr + n0);
+    if (d.x <= t.x) cand[(size_t)n0 * ldc + atomicAdd(&cnt[n0], 1)] = m;
+    if (n0 + 1 < B && d.y <= t.y) cand[(size_t)(n0 + 1) * ldc + atomicAdd(&cnt[n0 + 1], 1)] = m;
+    if (n0 + 2 < B && d.z <= t.z) cand[(size_t)(n0 + 2) * ldc + atomicAdd(&cnt[n0 + 2], 1)] = m;
+    if (n0 + 3 < B && d.w <= t.w) cand[(size_t)(n0 + 3) * ldc + atomicAdd(&cnt[n0 + 3], 1)] = m;
+  }
+}
+
 __global__ void zero_ints_kernel(int* p, int n, unsigned* q) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0;
@@ -192,7 +211,7 @@ __global__ void zero_ints_kernel(int* p, int n, unsigned* q) {
 }
 
 struct ScreenLayout {
-  size_t cn, qn, cnmax, tmin, thr, cnt, cand, val, total;
+  size_t cn, qn, cnmax, tmin, thr, cnt, cand, val, dist, total;
   int ntiles, ldt;
 };
 static bool screen_applies(int B, int N, int zdim, int k) {
@@ -212,6 +231,7 @@ static ScreenLayout screen_layout(int B, int N) {
   L.cn = take((size_t)N * 4); L.qn = take((size_t)L.ldt * 4); L.cnmax = take(256);
   L.tmin = take((size_t)L.ntiles * L.ldt * 4); L.thr = take((size_t)L.ldt * 4); L.cnt = take((size_t)L.ldt * 4);
   L.cand = take((size_t)B * N * 4); L.val = take((size_t)B * N * 4);
+  L.dist = take((size_t)N * L.ldt * 4);        // approximate distances of the screening GEMM, scanned by the collect pass
   L.total = o + 256;
   return L;
 }
@@ -242,18 +262,23 @@ int topk_screen(const float* q, int B, const float* cache, int N, int zdim, int 
   g.ones_col = -1;
   g.A[0] = cache; g.B[0] = q; g.lda[0] = zdim; g.ldb[0] = zdim; g.Kc[0] = zdim; g.npairs = 1;
   g.M = N; g.N = B; g.e0 = cn; g.e1 = qn; g.ksplit = 0;
-  g.out0 = tmin; g.ldo = L.ldt;
-  if (B <= 64) rc = launch_gemm_w<true, true, EPI_DIST_TILEMIN, true, 64, 8>(g, 1, stream, "topk_screen(tile minima)");
+  float* dist = (float*)(w + L.dist);
+  g.out0 = tmin; g.out1 = dist; g.ldo = L.ldt;
+  // the screening product once, on the split-bf16 kernel when the launch fills the machine; its distances are kept
+  const bool x6 = B > 64 && gemm_x6_use(g);
+  if (x6) rc = launch_gemm_x6<EPI_DIST_TILEMIN>(g, 1, stream, "topk_screen(tile minima, x6)");
+  else if (B <= 64) rc = launch_gemm_w<true, true, EPI_DIST_TILEMIN, true, 64, 8>(g, 1, stream, "topk_screen(tile minima)");
   else rc = launch_gemm_w<true, true, EPI_DIST_TILEMIN, true, 128, 8>(g, 1, stream, "topk_screen(tile minima)");
   if (rc) return rc;
-  // error bound of one approximate distance: (2K + 3) roundings of magnitude <= u (|q|^2 + |c|^2), u = 2^-24, doubled
-  const float gamma = 2.0f * (2.0f * zdim + 3.0f) * 5.9604645e-08f;
+  // error bound of one approximate distance: (2K + 3) roundings of magnitude <= u (|q|^2 + |c|^2), u = 2^-24, doubled; the
+  // split-bf16 product accumulates six partial products per element (6K + 3 roundings)
+  const float gamma = 2.0f * ((x6 ? 6.0f : 2.0f) * zdim + 3.0f) * 5.9604645e-08f;
   kth_threshold_kernel<<<cdiv(B, 4), 256, 0, stream>>>(tmin, L.ntiles, L.ldt, B, k, qn, cnmax, gamma, thr);
   rc = check_launch("kth_threshold_kernel");
   if (rc) return rc;
-  g.bias0 = thr; g.aux_cnt = cnt; g.aux_cand = cand; g.out0 = nullptr; g.ldo = N;
-  if (B <= 64) rc = launch_gemm_w<true, true, EPI_DIST_COLLECT, true, 64, 8>(g, 1, stream, "topk_screen(collect)");
-  else rc = launch_gemm_w<true, true, EPI_DIST_COLLECT, true, 128, 8>(g, 1, stream, "topk_screen(collect)");
+  dist_collect_kernel<<<(unsigned)std::min<size_t>(((size_t)N * (L.ldt / 4) + 255) / 256, 8192), 256, 0, stream>>>(
+      dist, N, B, L.ldt, thr, cnt, cand, (size_t)N);
+  rc = check_launch("dist_collect_kernel");
   if (rc) return rc;
   topk_exact_kernel<<<B, 256, 0, stream>>>(q, cache, zdim, k, flags, index_base, cnt, cand, val, (size_t)N, out_idx, out_val);
   return check_launch("topk_exact_kernel");
