@@ -78,6 +78,11 @@ extern "C" int evae_gemm_x6_configure(int enabled, int min_rows) {
   return EVAE_OK;
 }
 
+// would a launch with M output rows and N output columns (gated: N gated outputs) run on the split-bf16 kernel?
+extern "C" int evae_gemm_x6_applies(int M, int N, int gated) {
+  return (gemm_x6_enabled() && gemm_x6_fills(M, N, gated != 0)) ? 1 : 0;
+}
+
 // ---- forward -------------------------------------------------------------------------------------------
 extern "C" size_t evae_dense_fwd_workspace_bytes(int M, int K, int N, int gated) {
   if (M <= 0 || K <= 0 || N <= 0) return 256;

@@ -89,10 +89,11 @@ class _K:
     def gated_fwd(self, x, rows, M, K, ldx, wh, bh, wg, bg, N, out, h, s):
         nb = self.lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
         w = self.ws("fwd", nb)
+        ex_, pipe_ = ops.gemm_pipe(M, N, True, 2.0 * M * K * 2 * N) if rows is None else (None, "fp32-mfma")
         ops.probed("gated_dense_fwd M=%d K=%d N=%d%s" % (M, K, N, " (row gather)" if rows is not None else ""), 2.0 * M * K * 2 * N,
                    lambda: _lib.check(self.lib.evae_gated_dense_fwd(_vp(x), _vp(rows), M, K, ldx, _vp(wh), _vp(bh), _vp(wg), _vp(bg),
                                                                     N, _vp(out), _vp(h), _vp(s), _vp(w), w.numel(), self.st),
-                                      "gated_fwd"))
+                                      "gated_fwd"), executed=ex_, pipe=pipe_)
 
     def linear_fwd(self, x, M, K, ldx, w_, b, N, act, lo, hi, y, pre):
         nb = self.lib.evae_dense_fwd_workspace_bytes(M, K, N, 0)
@@ -103,12 +104,14 @@ class _K:
     def bwd_data(self, dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, out, dg, ldo):
         nb = self.lib.evae_dense_bwd_data_workspace_bytes(M, N, K, 2 if dy2 is not None else 1)
         w = self.ws("dgrad", nb)
+        fl_ = 2.0 * M * N * K * (2 if dy2 is not None else 1)
+        ex_, pipe_ = ops.gemm_pipe(M, K, False, fl_) if (N % 4 == 0 and ldy % 4 == 0) else (None, "fp32-mfma")
         ops.probed("dense_bwd_data M=%d N=%d%s K=%d%s" % (M, N, "+%d" % N if dy2 is not None else "", K,
                                                           " (gate-backward epilogue)" if out_prev is not None else ""),
-                   2.0 * M * N * K * (2 if dy2 is not None else 1),
+                   fl_,
                    lambda: _lib.check(self.lib.evae_dense_bwd_data(_vp(dy1), _vp(w1), _vp(dy2), _vp(w2), M, N, ldy, K, _vp(out_prev),
                                                                    _vp(s_prev), _vp(out), _vp(dg), ldo, _vp(w), w.numel(), self.st),
-                                      "bwd_data"))
+                                      "bwd_data"), executed=ex_, pipe=pipe_)
 
     def bwd_weight(self, dy, M, N, ldy, x, rows, K, ldx, dw, db, phase=0, ws_name="wgrad", finish_on=None):
         """phase 1 / 2: the split-K GEMM and its finish as separate calls (finish_on = the launcher whose stream runs it)"""

@@ -106,6 +106,14 @@ def gemm_x6_configure(enabled=-1, min_rows=-1):
     _lib.check(_lib.load().evae_gemm_x6_configure(int(enabled), int(min_rows)), "evae_gemm_x6_configure")
 
 
+def gemm_pipe(M, N, gated, flops):
+    """(executed flops, pipe label) of an fp32 GEMM launch with M x N outputs for the roofline probe: six bf16 products per
+    fp32 product when it takes the split-bf16 kernel."""
+    if _lib.load().evae_gemm_x6_applies(int(M), int(N), int(bool(gated))):
+        return 6.0 * flops, "bf16-mfma"
+    return flops, "fp32-mfma"
+
+
 def prior_set_norm_limit(limit):
     """Largest centred squared norm (sigma units) of a query tile the matrix-core prior kernels still evaluate in the
     expanded form; above it they switch to direct differences.  Negative restores the default, 0 forces the direct path."""
@@ -318,10 +326,11 @@ class GatedDenseFn(torch.autograd.Function):
         s = torch.empty_like(out) if need_grad else None     # the backward needs out and s only (dg = dout*out*(1-s))
         nb = lib.evae_dense_fwd_workspace_bytes(M, K, N, 1)
         ws = _workspace("fwd", nb, x.device)
+        ex_, pipe_ = gemm_pipe(M, N, True, 2.0 * M * K * 2 * N) if rows is None else (None, "fp32-mfma")
         probed("gated_dense_fwd M=%d K=%d N=%d%s" % (M, K, N, " (row gather)" if rows is not None else ""), 2.0 * M * K * 2 * N,
                lambda: _lib.check(lib.evae_gated_dense_fwd(_p(x), _p(rows), M, K, x.stride(0), _p(wh), _p(bh), _p(wg), _p(bg),
                                                            N, _p(out), None, _p(s), _p(ws), ws.numel(), _stream()),
-                                  "evae_gated_dense_fwd"))
+                                  "evae_gated_dense_fwd"), executed=ex_, pipe=pipe_)
         if need_grad:
             ctx.save_for_backward(x, rows, wh, wg, out, s)
         ctx.has_bias = (bh is not None, bg is not None)

@@ -179,6 +179,7 @@ int evae_select_exemplars(const int64_t* pos, int n, const int64_t* cand_idx, in
  * whose operands are both contraction-contiguous (forward layers, channels-last convolutions) with at least `min_rows`
  * output rows.  enabled: 0 off, 1 on, < 0 unchanged; min_rows < 0 unchanged.  Defaults: on, 2048 (env EVAE_X6, EVAE_X6_MIN_ROWS). */
 int evae_gemm_x6_configure(int enabled, int min_rows);
+int evae_gemm_x6_applies(int M, int N, int gated);   /* 1 when a launch with M x N outputs takes the split-bf16 kernel */
 
 /* clamp to [act_lo, act_hi] */
 

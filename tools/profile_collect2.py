@@ -23,13 +23,28 @@ for d in sorted(glob.glob(os.path.join(src, "stats_*"))):
     if fs:
         shutil.copy(fs[0], os.path.join(dst, "r02_%s_kernel_stats.csv" % cfg))
 # which kernel of a probe is "its" kernel
-MAIN = {"u8fwd1": "u8_gemm_kernel<true>", "u8wgrad1": "u8_gemm_kernel<false>", "fwd1": "gemm_kernel<true, true, 1", "fwd2": "gemm_kernel<true, true, 1",
-        "dgrad2": "gemm_kernel<true, false, 2", "wgrad1": "gemm_kernel<false, false, 3", "wgrad2": "gemm_kernel<false, false, 3",
-        "prior_iwae": "prior_fwd_mfma_kernel", "prior_c5": "gemm_kernel<true, true, 7", "prior_train": "prior_bwd_mfma_kernel",
-        "topk_c5": "gemm_kernel<true, true, 5", "topk_c2": "gemm_kernel<true, true, 5", "conv5_fwd": "gemm_kernel<true, true, 1",
-        "conv5_bwd": "gemm_kernel<true, false, 0", "conv96_fwd": "gemm_kernel<true, true, 0"}
+# which kernel of a probe is "its" kernel: the first alternative that appears in the counter rows (the split-bf16 kernel where
+# the launch takes it, the fp32-MFMA kernel otherwise)
+MAIN = {"u8fwd1": ["u8_gemm_kernel<true>"], "u8wgrad1": ["u8_gemm_kernel<false>"],
+        "fwd1": ["gemm_x6_kernel<1, 0", "gemm_kernel<true, true, 1"], "fwd2": ["gemm_x6_kernel<1, 0", "gemm_kernel<true, true, 1"],
+        "dgrad2": ["gemm_x6_kernel<2, 0", "gemm_kernel<true, false, 2"], "wgrad1": ["gemm_kernel<false, false, 3"],
+        "wgrad2": ["gemm_kernel<false, false, 3"], "prior_iwae": ["prior_fwd_mfma_kernel"],
+        "prior_c5": ["gemm_x6_kernel<7, 0", "gemm_kernel<true, true, 7"], "prior_train": ["prior_bwd_mfma_kernel"],
+        "topk_c5": ["gemm_x6_kernel<5, 0", "gemm_kernel<true, true, 5"], "topk_c2": ["gemm_x6_kernel<5, 0", "gemm_kernel<true, true, 5"],
+        "conv5_fwd": ["gemm_x6_kernel<1, 1", "gemm_kernel<true, true, 1"], "conv5_bwd": ["gemm_x6_kernel<0, 1", "gemm_kernel<true, false, 0"],
+        "conv96_fwd": ["gemm_x6_kernel<0, 1", "gemm_kernel<true, true, 0"]}
 summary = {}
-for probe, kern in MAIN.items():
+def pick_kernel(probe, alts):
+    for kern in alts:
+        for grp in ("sq", "fetch", "write", "sq2"):
+            fs = glob.glob(os.path.join(src, "pmc_%s_%s" % (probe, grp), "**", "*counter_collection.csv"), recursive=True)
+            if fs and any(kern in r["Kernel_Name"] for r in csv.DictReader(open(fs[0]))):
+                return kern
+    return alts[0]
+
+
+for probe, alts in MAIN.items():
+    kern = pick_kernel(probe, alts)
     rows_all, ctr = [], collections.defaultdict(list)
     for grp in ("fetch", "write", "sq", "sq2"):
         fs = glob.glob(os.path.join(src, "pmc_%s_%s" % (probe, grp), "**", "*counter_collection.csv"), recursive=True)
