@@ -279,10 +279,21 @@ extern "C" int evae_dense_bwd_data_img(const float* dy1, const float* w1, const 
 // ---- weight gradient -------------------------------------------------------------------------------------
 // The bias gradient db = column sums of dy is folded into the same GEMM: x gets a virtual all-ones
 // column K (never read from memory), so column K of dy^T [x | 1] is db.
+// split of the contraction for the split-bf16 weight-gradient kernel: enough 128 x 128 tiles x slices to fill 512 block slots,
+// at least eight K-slabs per slice
+struct X6tSplit { int nz, ksplit; };
+static X6tSplit x6t_split(int M, int N, int Kp) {
+  const int slabs = cdiv(M, BK), tiles = cdiv(N, BM) * cdiv(Kp, 128);
+  int nz = std::max(1, std::min(512 / std::max(tiles, 1), slabs / 8));
+  const int ksplit = cdiv(slabs, nz);
+  nz = cdiv(slabs, ksplit);
+  return {nz, ksplit};
+}
+
 extern "C" size_t evae_dense_bwd_weight_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 256;
   Plan pl = make_plan(N, K + 1, cdiv(M, BK), false, true, 1);
-  return align_up((size_t)pl.nz * N * (K + 1) * sizeof(float), 256) + 256;
+  return align_up((size_t)std::max(pl.nz, x6t_split(M, N, K + 1).nz) * N * (K + 1) * sizeof(float), 256) + 256;
 }
 
 // phase 0: both launches; 1: the split-K GEMM into the workspace partials; 2: the finish (sum of the partial planes in a fixed
@@ -311,13 +322,25 @@ static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const f
   GemmArgs g = {};
   g.A[0] = dy; g.B[0] = x; g.lda[0] = ldy; g.ldb[0] = ldx; g.Kc[0] = M; g.npairs = 1;
   g.b_krows = rows; g.M = N; g.N = Kp; g.out0 = part; g.ldo = Kp; g.ones_col = K;
+  // both operands k-major: the transposing variant of the split-bf16 kernel when the product is large AND its 128-wide column
+  // tiles are well filled -- measured: K = 784 (785 of 896 columns) 240 vs 260 us, K = 300 (301 of 384) 116 vs 119 us: at 78 %
+  // fill the fp32 kernel's 64-wide tiles are as fast
+  const bool x6 = gemm_x6_enabled() && gemm_x6t_ok(g) &&
+                  (gemm_x6_min_rows() == 0 || ((double)M * N * Kp >= 2e9 && Kp >= 0.85 * (cdiv(Kp, 128) * 128)));
+  const X6tSplit sp6 = x6t_split(M, N, Kp);
   if (phase != 2) {
-    int rc = launch_gemm<false, false, EPI_RAW>(g, pl, stream, "dense_bwd_weight");
+    int rc;
+    if (x6) {
+      g.ksplit = sp6.nz > 1 ? sp6.ksplit : 0;
+      rc = launch_gemm_x6t<EPI_RAW>(g, sp6.nz, stream, "dense_bwd_weight(x6)");
+    } else {
+      rc = launch_gemm<false, false, EPI_RAW>(g, pl, stream, "dense_bwd_weight");
+    }
     if (rc) return rc;
     if (phase == 1) return EVAE_OK;
   }
   FinishArgs f = {};
-  f.part = part; f.nz = pl.nz; f.M = N; f.N = Kp; f.ldo = Kp; f.epi = EPI_RAW; f.out0 = dw; f.accumulate = accumulate;
+  f.part = part; f.nz = x6 ? sp6.nz : pl.nz; f.M = N; f.N = Kp; f.ldo = Kp; f.epi = EPI_RAW; f.out0 = dw; f.accumulate = accumulate;
   f.ones_col = K; f.out_db = db;
   return launch_finish(f, stream);
 }

@@ -266,6 +266,216 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue<EPI, BN_, NW, CV>(g, acc, m0, n0, tm, wr, wc, lane, smem);
 }
 
+// ---- both operands k-major: C [M x N] = A^T B with A [Kc x M] (row stride lda), B [Kc x N] (row stride ldb) -- the weight
+// gradient dW = dy^T x (contraction over the batch rows; ones_col = virtual all-ones column of B: the bias gradient).
+// Same tile, planes, MFMA schedule and epilogue as gemm_x6_kernel; what differs is the staging: a thread loads a 4 x 4 block
+// (four consecutive contraction rows x four consecutive columns, one float4 per row), which holds, for each of its four
+// columns, four consecutive k of one LDS row = one 8-byte write per plane -- the transposition costs no instruction.  LDS row r
+// of an operand lives at physical row r ^ ((r >> 2) & 1): the 16 lanes of a ds_write_b64 pass are two column groups (rows
+// 4 n4 + i and 4 (n4 + 1) + i) x the eight 8-byte chunks of a row, and the swap gives the two rows opposite parity, i.e. the
+// two halves of the 128-byte bank period (without it every pass is a 2-way conflict); fragment reads see whole aligned
+// groups of four rows, so their conflict-free pattern is unchanged.
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x6t_kernel(const GemmArgs g) {
+  constexpr int NW = 4, MT = 2, NT = 2, BN_ = 128;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const lds = reinterpret_cast<char*>(smem);
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int tile;
+  {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int qq = ntiles >> 3, rr = ntiles & 7;
+    tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN_;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nslab = (g.Kc[0] + BK - 1) / BK;
+  int s_begin = 0, s_end = nslab;
+  if (g.ksplit > 0) {
+    s_begin = blockIdx.z * g.ksplit;
+    const int e = s_begin + g.ksplit;
+    if (e < s_end) s_end = e;
+  }
+  const rsrc_t rA = make_rsrc(g.A[0], 0x7FFFFFFFu);
+  const rsrc_t rB = make_rsrc(g.B[0], 0x7FFFFFFFu);
+
+  // staging roles: four columns 4 n4 .. 4 n4 + 3 of the tile, contraction rows 4 m4 .. 4 m4 + 3 of the slab
+  const int n4 = tid >> 3, m4 = tid & 7;
+  const bool colokA = m0 + 4 * n4 + 4 <= g.M;
+  const int cb = n0 + 4 * n4;
+  const int nlim = g.ones_col >= 0 ? g.ones_col : g.N;
+  const bool colokB = cb + 4 <= nlim;
+  const bool onesB = g.ones_col >= 0 && cb == g.ones_col;
+  unsigned voA[4], voB[4], st_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    voA[j] = colokA ? (unsigned)((4 * m4 + j) * g.lda[0] + m0 + 4 * n4) * 4u : OOB;
+    voB[j] = colokB ? (unsigned)((4 * m4 + j) * g.ldb[0] + cb) * 4u : OOB;
+    const int pr = 4 * n4 + (j ^ (n4 & 1));                       // physical row of column j
+    st_off[j] = (unsigned)(pr * 64 + ((((m4 >> 1) ^ (n4 & 3))) << 4) + (m4 & 1) * 8);
+  }
+
+  float4 ra[4], rb[4];
+  auto load_a = [&](int s) {
+    const int k0 = s * BK, kv = g.Kc[0] - k0;
+    const unsigned so = (unsigned)k0 * (unsigned)g.lda[0] * 4u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = buf_ld4(rA, (4 * m4 + j < kv) ? voA[j] : OOB, so);
+  };
+  auto load_b = [&](int s) {
+    const int k0 = s * BK, kv = g.Kc[0] - k0;
+    const unsigned so = (unsigned)k0 * (unsigned)g.ldb[0] * 4u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rb[j] = buf_ld4(rB, (4 * m4 + j < kv) ? voB[j] : OOB, so);
+      if (onesB) rb[j] = make_float4((4 * m4 + j < kv) ? 1.f : 0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto comp = [](const float4& v, int i) -> float { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); };
+  // micro-step k = 0 .. 15 of the staging of one slab: operand B (k < 8) then A; within an operand the row pair (0, 1) of its
+  // four columns, then the pair (2, 3).  One step = the split of two elements (column i, two consecutive contraction rows) and
+  // three 4-byte LDS writes; a row pair's two registers are free after its fourth column and are reloaded at once for the
+  // slab after next -- a whole slab before they are needed.  Returns 1 + (operand, pair) when a pair is done, else 0.
+  auto micro = [&](int k) -> int {
+    const bool isa = k >= 8;
+    const int kk = isa ? k - 8 : k, pair = kk >> 2, i = kk & 3;
+    unsigned p0, p1, p2;
+    const float x = isa ? comp(ra[2 * pair], i) : comp(rb[2 * pair], i);
+    const float y = isa ? comp(ra[2 * pair + 1], i) : comp(rb[2 * pair + 1], i);
+    x6_split2(x, y, p0, p1, p2);
+    char* p = lds + (isa ? 0 : 3 * X6_PLANE) + st_off[i] + 4 * pair;
+    *reinterpret_cast<unsigned*>(p) = p0;
+    *reinterpret_cast<unsigned*>(p + X6_PLANE) = p1;
+    *reinterpret_cast<unsigned*>(p + 2 * X6_PLANE) = p2;
+    return i == 3 ? 1 + (isa ? 2 : 0) + pair : 0;
+  };
+  auto reload = [&](int s, int what) {              // what - 1 = 2 * operand + pair
+    const int k0 = s * BK, kv = g.Kc[0] - k0;
+    const bool isa = what >= 3;
+    const int pair = (what - 1) & 1;
+    const unsigned so = (unsigned)k0 * (unsigned)(isa ? g.lda[0] : g.ldb[0]) * 4u;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * pair + jj;
+      const bool live = 4 * m4 + j < kv;
+      if (isa) ra[j] = buf_ld4(rA, live ? voA[j] : OOB, so);
+      else {
+        rb[j] = buf_ld4(rB, live ? voB[j] : OOB, so);
+        if (onesB) rb[j] = make_float4(live ? 1.f : 0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+
+  unsigned fa[2][MT], fb[2][NT];
+#pragma unroll
+  for (int step = 0; step < 2; ++step) {
+    const int ks = 2 * step + lh;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int r = wr * 64 + mt * 32 + l31, pr = r ^ ((r >> 2) & 1);
+      fa[step][mt] = (unsigned)(pr * 64 + ((ks ^ ((pr >> 2) & 3)) << 4));
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c = wc * 64 + nt * 32 + l31, pc = c ^ ((c >> 2) & 1);
+      fb[step][nt] = (unsigned)(3 * X6_PLANE + pc * 64 + ((ks ^ ((pc >> 2) & 3)) << 4));
+    }
+  }
+
+  if (s_begin < s_end) {
+    load_a(s_begin); load_b(s_begin);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) micro(k);
+    if (s_begin + 1 < s_end) { load_a(s_begin + 1); load_b(s_begin + 1); }
+    __syncthreads();
+    auto slab = [&](int s, auto ST_, auto LD_) {
+      constexpr bool ST = decltype(ST_)::value, LD = decltype(LD_)::value;
+      x6_bf16x8 af[2][MT][3], bf[2][NT][3];
+#pragma unroll
+      for (int step = 0; step < 2; ++step) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) af[step][mt][p] = *reinterpret_cast<const x6_bf16x8*>(lds + fa[step][mt] + p * X6_PLANE);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bf[step][nt][p] = *reinterpret_cast<const x6_bf16x8*>(lds + fb[step][nt] + p * X6_PLANE);
+      }
+      if constexpr (ST) __syncthreads();
+      __builtin_amdgcn_s_setprio(1);
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int step = 0; step < 2; ++step)
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int j = ((step * 6 + t) * MT + mt) * NT + nt;          // 0 .. 47
+              __builtin_amdgcn_sched_barrier(0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[step][mt][PA[t]], bf[step][nt][PB[t]], acc[mt][nt], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (ST) {
+                if (j % 3 == 2) {
+                  const int done = micro(j / 3);
+                  if constexpr (LD) {
+                    if (done) reload(s + 2, done);
+                  }
+                }
+              }
+            }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+      __syncthreads();
+    };
+    constexpr std::true_type T{};
+    constexpr std::false_type F{};
+    int s = s_begin;
+    for (; s + 2 < s_end; ++s) slab(s, T, T);
+    if (s + 1 < s_end) { slab(s, T, F); ++s; }
+    slab(s, F, F);
+  }
+  gemm_epilogue<EPI, BN_, NW, 0>(g, acc, m0, n0, tm, wr, wc, lane, smem);
+}
+
+// k-major operands the x6t kernel can take: no row gather, 16-byte aligned rows, column counts in fours, below 2 GiB
+static bool gemm_x6t_ok(const GemmArgs& g) {
+  if (g.b_krows != nullptr || g.a_rows != nullptr || g.npairs != 1) return false;
+  if (g.lda[0] % 4 || g.ldb[0] % 4 || g.M % 4) return false;
+  if (g.ones_col >= 0 ? (g.ones_col % 4 != 0) : (g.N % 4 != 0)) return false;
+  if (((uintptr_t)g.A[0] | (uintptr_t)g.B[0]) & 15) return false;
+  return (long long)g.Kc[0] * g.lda[0] < (1ll << 29) && (long long)g.Kc[0] * g.ldb[0] < (1ll << 29);
+}
+
+template <int EPI>
+static int launch_gemm_x6t(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_x6t_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(128));
+    attr_done = true;
+  }
+  g.tiles_m = cdiv(g.M, BM);
+  g.tiles_n = cdiv(g.N, 128);
+  g.dbg = 0;
+  dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
+  gemm_x6t_kernel<EPI><<<grid, 256, x6_lds_bytes(128), stream>>>(g);
+  return check_launch(what);
+}
+
 // operands the x6 kernel can take: contraction-contiguous, 16-byte aligned rows, offsets below 2 GiB
 static bool gemm_x6_ok(const GemmArgs& g) {
   for (int p = 0; p < g.npairs; ++p) {

@@ -51,3 +51,23 @@ for M, N, K in ((25000, 300, 300), (25000, 40, 300), (100000, 300, 300)):
         err = float((buf[:, :K].double() - ref).abs().max() / ref.abs().max())
         print("gate dgrad M=%d N=%d+%d K=%d  %s: %.1f us  %.1f TFLOP/s (fp32-equivalent)  max rel err dh %.2e" %
               (M, N, N, K, "x6  " if on else "fp32", us, fl / us / 1e6, err), flush=True)
+
+# weight gradient dW = dy^T x (+ db): both operands k-major -> gemm_x6t_kernel
+for M, N, K in ((25100, 600, 300), (25100, 600, 784), (100000, 600, 300)):
+    torch.manual_seed(2)
+    dy = torch.randn(M, N, device="cuda"); x = torch.randn(M, K, device="cuda")
+    ref = dy.double().T @ x.double()
+    fl = 2.0 * M * N * K
+    lib = _lib.load()
+    for on in (1, 0):
+        ops.gemm_x6_configure(on, 0)
+        dw = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
+        nb = lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        fn = lambda: _lib.check(lib.evae_dense_bwd_weight(ops._p(dy), M, N, N, ops._p(x), None, K, K, ops._p(dw), ops._p(db), 0,
+                                                          ops._p(ws), ws.numel(), ops._stream()), "wgrad")
+        us = timeit(fn)
+        err = float((dw.double() - ref).abs().max() / ref.abs().max())
+        errb = float((db.double() - dy.double().sum(0)).abs().max() / dy.double().sum(0).abs().max())
+        print("weight grad M=%d N=%d K=%d  %s: %.1f us  %.1f TFLOP/s (fp32-equivalent)  max rel err dw %.2e db %.2e" %
+              (M, N, K, "x6  " if on else "fp32", us, fl / us / 1e6, err, errb), flush=True)
