@@ -133,14 +133,20 @@ class VaeExactLoss(torch.autograd.Function):
     -> (loss [B], RE [B], KL [B])."""
 
     @staticmethod
-    def forward(ctx, x, x_idx, data_ext, n_data, ex_idx, c_total, eps, beta, sharded, no_mask, average, rows_ext, staged, *params):
+    def forward(ctx, x, x_idx, data_ext, n_data, ex_idx, c_total, eps, beta, sharded, no_mask, average, rows_ext, staged,
+                approx_cache, approx_k, *params):
         (plv, wp, bp, w1h, b1h, w1g, b1g, w2h, b2h, w2g, b2g, wm, bm, wl, bl,
          d1h, e1h, d1g, e1g, d2h, e2h, d2g, e2g) = params
         dev = x.device
         k = _K(dev)
         lib = k.lib
         B, D = x.shape
-        Cl = ex_idx.numel()
+        # approximate prior (reference models/BaseModel.py:256-271): ex_idx holds the CANDIDATE draw; the exemplar rows are the
+        # B * k static slots picked by the top-K over the cached latents of the candidates (repeats masked, evae_select_exemplars)
+        approx = approx_cache is not None
+        Cl = B * int(approx_k) if approx else ex_idx.numel()
+        if approx:
+            c_total = Cl
         Mp = Cl + B
         H = w1h.shape[0]
         Z = wm.shape[0]
@@ -157,7 +163,10 @@ class VaeExactLoss(torch.autograd.Function):
         elif x.data_ptr() != stage.data_ptr():    # the captured step gathers the batch there itself
             stage.copy_(x)
         # rows_ext: caller-kept [Cl + B] gather list whose head IS ex_idx and whose tail already names the staging rows
-        if rows_ext is not None and rows_ext.numel() == Cl + B and rows_ext.data_ptr() == ex_idx.data_ptr():
+        if approx:
+            rows = torch.empty(Cl + B, dtype=torch.int64, device=dev)          # head: filled behind the top-K below
+            rows[Cl:] = torch.arange(n_data, n_data + B, device=dev)
+        elif rows_ext is not None and rows_ext.numel() == Cl + B and rows_ext.data_ptr() == ex_idx.data_ptr():
             rows = rows_ext
         else:
             rows = torch.cat((ex_idx, torch.arange(n_data, n_data + B, device=dev)))
@@ -202,7 +211,7 @@ class VaeExactLoss(torch.autograd.Function):
             def l1_fwd(kk, rows_ptr, M, o):
                 kk.gated_fwd(data_ext, rows_ptr, M, D, ldd, w1h, b1h, w1g, b1g, H, A1.data_ptr() + o * H, None,
                              s1.data_ptr() + o * H)
-        if Cl > 0:
+        if Cl > 0 and not approx:
             l1_fwd(k, rows, Cl, 0)
         with torch.cuda.stream(side):
             lv_row = plv.detach().expand(Z).contiguous()   # the prior's log-variance row
@@ -210,6 +219,8 @@ class VaeExactLoss(torch.autograd.Function):
             kd.gated_fwd(A1.data_ptr() + offb * H, None, B, H, H, w2h, b2h, w2g, b2g, H,
                          A2.data_ptr() + offb * H, None, s2.data_ptr() + offb * H)
             kd.linear_fwd(A2b, B, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, z_mean, None)
+            if approx:
+                zm_ready = torch.cuda.Event(); zm_ready.record()
             kd.linear_fwd(A2b, B, H, H, wl, bl, Z, ACT_HARDTANH, -6.0, 2.0, logvar, lv_pre)
             # ---- sample, decode, reconstruct
             _lib.check(lib.evae_reparam_logq_fwd(_vp(z_mean), _vp(logvar), _vp(eps), B, Z, _vp(z), _vp(logq), kd.st), "reparam")
@@ -218,14 +229,28 @@ class VaeExactLoss(torch.autograd.Function):
             kd.gated_fwd(D1, None, B, H, H, d2h, e2h, d2g, e2g, H, D2, None, sd2)
             kd.linear_fwd(D2, B, H, H, wp, bp, D, ACT_SIGMOID, 0.0, 0.0, xmean, None)
             _lib.check(lib.evae_bernoulli_ll_fwd(_vp(x), _vp(xmean), B, D, _vp(RE), kd.st), "bernoulli")
+        ci_sel = None
+        if approx:
+            # the batch's own cache rows refreshed with its means, top-k of every batch row among the candidates' cached
+            # latents, the B * k slots re-encoded below; the rest of the batch-row path keeps running on the side stream
+            main.wait_event(zm_ready)
+            xi = ops._i64(x_idx)
+            approx_cache.index_copy_(0, xi, z_mean)
+            sub_cache = approx_cache.index_select(0, ex_idx)
+            nearest, _ = ops.pairdist_topk(z_mean, sub_cache, int(approx_k), want_val=False)
+            sel_rows, ci_sel = ops.select_exemplars(nearest.view(-1), ex_idx)
+            rows[:Cl].copy_(sel_rows)
+            l1_fwd(k, rows, Cl, 0)
         if Cl > 0:
             k.gated_fwd(A1, None, Cl, H, H, w2h, b2h, w2g, b2g, H, A2, None, s2)
             k.linear_fwd(A2, Cl, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, mean_all, None)
+        if approx:
+            approx_cache.index_copy_(0, sel_rows, centres)       # repeats of a row carry identical encodings
         main.wait_event(z_ready)
         # ---- exemplar prior (leave-one-out mask in training unless no_mask; with its collectives when sharded) on the
         #      main stream ...
         zi = None if no_mask else ops._i64(x_idx)
-        ci = None if no_mask else ops._i64(ex_idx)
+        ci = None if no_mask else (ci_sel if approx else ops._i64(ex_idx))
         logp = torch.empty(B, **f32); lse = torch.empty(B, **f32)
         z_all, zi_all = z, zi
         if sharded == 2:
@@ -474,4 +499,4 @@ class VaeExactLoss(torch.autograd.Function):
         ctx.bufs = None
         grads = (g_plv, g_wp, g_bp, g_w1[:H], g_b1[:H], g_w1[H:], g_b1[H:], g_w2[:H], g_b2[:H], g_w2[H:], g_b2[H:],
                  g_wm, g_bm, g_wl, g_bl, g_d1[:H], g_e1[:H], g_d1[H:], g_e1[H:], g_d2[:H], g_e2[:H], g_d2[H:], g_e2[H:])
-        return (None,) * 13 + grads
+        return (None,) * 15 + grads

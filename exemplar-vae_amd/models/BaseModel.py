@@ -77,17 +77,21 @@ class BaseModel(nn.Module, ABC):
     def _fused_config(self):
         """the part of _fused_path that only depends on the configuration"""
         a = self.args
+        # the approximate prior rides the same node with its B * k static exemplar slots (leave-one-out mask on, one device)
+        approx_ok = a.approximate_prior is False or (a.no_mask is False and not self._sharded())
         return (getattr(self, '_use_fused', True) and a.model_name == 'vae' and a.prior == 'exemplar_prior'
-                and a.input_type == 'binary' and a.approximate_prior is False and a.no_attention is False
+                and a.input_type == 'binary' and approx_ok and a.no_attention is False
                 and not getattr(a, 'same_variational_var', False))
 
-    def _fused_path(self, x, x_indices, exemplars_embedding, dataset):
+    def _fused_path(self, x, x_indices, exemplars_embedding, dataset, cache=None):
         """The one-node implementation (evae/fused_vae.py) covers the headline configuration: MLP `vae`,
-        exemplar prior, exact (non-approximate) exemplar sets, binary inputs, training mode."""
+        exemplar prior, exact or kNN-approximate exemplar sets, binary inputs, training mode."""
+        if self.args.approximate_prior and (cache is None or cache[0].requires_grad):
+            return False
         return (self._fused_config() and self.training and exemplars_embedding is None and dataset is not None
                 and x_indices is not None and x.is_cuda and torch.is_grad_enabled())
 
-    def _calculate_loss_fused(self, x, x_indices, beta, dataset, average):
+    def _calculate_loss_fused(self, x, x_indices, beta, dataset, average, cache=None):
         a = self.args
         C = a.number_components
         sharded = self._sharded()
@@ -120,14 +124,16 @@ class BaseModel(nn.Module, ABC):
         params = [named[n] for n in fused_vae.PARAM_ORDER]
         beta = beta if torch.is_tensor(beta) else float(beta)
         staged = bool(getattr(self, '_batch_staged', False))      # the captured step has put the batch into the staging rows
+        approx_cache = cache[0] if a.approximate_prior else None  # ex_local is then the candidate draw (reference :258)
         return fused_vae.VaeExactLoss.apply(x2, x_indices.reshape(-1), data_ext, n_data, ex_local, C, eps,
                                             beta, (2 if getattr(a, 'shard_batch', False) else 1) if sharded else 0,
-                                            bool(a.no_mask), bool(average), rows_ext, staged, *params)
+                                            bool(a.no_mask), bool(average), None if a.approximate_prior else rows_ext, staged,
+                                            approx_cache, int(a.approximate_k), *params)
 
     def calculate_loss(self, x, beta=1., average=False, exemplars_embedding=None, cache=None, dataset=None):
         x, x_indices = x
-        if self._fused_path(x, x_indices, exemplars_embedding, dataset):
-            return self._calculate_loss_fused(x, x_indices, beta, dataset, average)
+        if self._fused_path(x, x_indices, exemplars_embedding, dataset, cache):
+            return self._calculate_loss_fused(x, x_indices, beta, dataset, average, cache)
         x_mean, x_logvar, latent_stats = self.forward(x)
         x_flat = x.reshape(x.shape[0], -1) if x.dim() != 2 else x
         RE = self.reconstruction_loss(x_flat, x_mean, x_logvar)

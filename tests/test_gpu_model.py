@@ -210,12 +210,15 @@ def test_graphed_step_with_the_approximate_prior():
     assert rel(c1, c0) < 2e-5
     for kk in p0:
         assert rel(p1[kk], p0[kk]) < 2e-5, kk
-    # fixed slots with masked repeats == unique (one step, same weights / draws): loss and gradients
+    # fixed slots with masked repeats (the fused node, then the modular autograd path) == unique (the reference's formulation,
+    # modular path) on one step with the same weights / draws: loss, gradients, refreshed cache
     outs = []
-    for no_static in (False, True):
+    for fused, no_static in ((True, False), (False, False), (False, True)):
         args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=B, approximate_prior=True, approximate_k=k)
         model, _ = smoke_case.build_model(torch, np, orc, args)
         model.train()
+        model._use_fused = fused
+        assert model._fused_config() == fused
         model._draw_eps = lambda like: eps_all[0]
         with torch.no_grad():
             cache = tuple(model.cache_z(dataset))
@@ -236,10 +239,13 @@ def test_graphed_step_with_the_approximate_prior():
         finally:
             if no_static:
                 _ops.select_exemplars = orig
-        outs.append((loss.detach().cpu().numpy(), {kk: v.grad.cpu().numpy().copy() for kk, v in model.named_parameters()}))
-    assert rel(outs[0][0], outs[1][0]) < 1e-5
-    for kk in outs[0][1]:
-        assert rel(outs[0][1][kk], outs[1][1][kk]) < 1e-4, kk
+        outs.append((loss.detach().cpu().numpy(), {kk: v.grad.cpu().numpy().copy() for kk, v in model.named_parameters()},
+                     cache[0].detach().cpu().numpy().copy()))
+    for other in (1, 2):
+        assert rel(outs[0][0], outs[other][0]) < 1e-5
+        assert rel(outs[0][2], outs[other][2]) < 1e-5
+        for kk in outs[0][1]:
+            assert rel(outs[0][1][kk], outs[other][1][kk]) < 1e-4, kk
 
 
 def test_two_captured_steps_on_one_optimizer_keep_their_own_pointer_tables():
