@@ -287,30 +287,36 @@ __global__ __launch_bounds__(NT) void topk_merge_kernel(const float* __restrict_
   }
 }
 
-// first occurrence of every position keeps its exemplar, repeats become masked slots (see evae_select_exemplars)
-__global__ __launch_bounds__(1024) void select_exemplars_kernel(const int64_t* __restrict__ pos, int n,
-                                                                const int64_t* __restrict__ cand_idx, int C,
-                                                                int64_t* __restrict__ sel_rows, int64_t* __restrict__ c_idx,
-                                                                int* __restrict__ n_unique) {
-  extern __shared__ int sp[];                 // the n positions
-  __shared__ int cnt;
-  if (threadIdx.x == 0) cnt = 0;
-  for (int i = threadIdx.x; i < n; i += 1024) sp[i] = (int)pos[i];
+// first occurrence of every position keeps its exemplar, repeats become masked slots (see evae_select_exemplars).
+// Every block keeps all n positions in LDS (padded to fours with -1 - index, which never matches) and a thread decides one
+// slot by scanning the positions in front of it four at a time.
+__global__ __launch_bounds__(256) void select_exemplars_kernel(const int64_t* __restrict__ pos, int n,
+                                                               const int64_t* __restrict__ cand_idx, int C,
+                                                               int64_t* __restrict__ sel_rows, int64_t* __restrict__ c_idx,
+                                                               int* __restrict__ n_unique) {
+  extern __shared__ __attribute__((aligned(16))) int sp[];
+  const int n4 = (n + 3) & ~3;
+  for (int i = threadIdx.x; i < n4; i += 256) sp[i] = i < n ? (int)pos[i] : -1 - i;
   __syncthreads();
-  int mine = 0;
-  for (int i = threadIdx.x; i < n; i += 1024) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool first = false;
+  if (i < n) {
     const int p = sp[i];
     bool dup = false;
-    for (int j = 0; j < i; ++j) dup |= (sp[j] == p);
+    const int full = i & ~3;
+    for (int j = 0; j < full; j += 4) {
+      const int4 q = *reinterpret_cast<const int4*>(sp + j);
+      dup |= (q.x == p) | (q.y == p) | (q.z == p) | (q.w == p);
+    }
+    for (int j = full; j < i; ++j) dup |= (sp[j] == p);
     const int64_t row = (p >= 0 && p < C) ? cand_idx[p] : (int64_t)0;
     sel_rows[i] = row;
     c_idx[i] = dup ? (int64_t)EVAE_PRIOR_MASK_ALL : row;
-    mine += dup ? 0 : 1;
+    first = !dup;
   }
   if (n_unique) {
-    atomicAdd(&cnt, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) *n_unique = cnt;
+    const unsigned long long m = __ballot(first);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_unique, __popcll(m));
   }
 }
 
@@ -399,7 +405,12 @@ extern "C" int evae_select_exemplars(const int64_t* pos, int n, const int64_t* c
   EVAE_REQUIRE(n >= 0 && n <= 16384 && C >= 0, "select_exemplars: bad sizes n=%d (<= 16384) C=%d", n, C);
   if (n == 0) return EVAE_OK;
   EVAE_REQUIRE(pos && cand_idx && sel_rows && c_idx, "select_exemplars: null pointer");
-  select_exemplars_kernel<<<1, 1024, (size_t)n * sizeof(int), (hipStream_t)stream_>>>(pos, n, cand_idx, C, sel_rows, c_idx, n_unique);
+  if (n_unique) {
+    hipError_t e = hipMemsetAsync(n_unique, 0, sizeof(int), (hipStream_t)stream_);
+    EVAE_REQUIRE(e == hipSuccess, "select_exemplars: memset failed");
+  }
+  select_exemplars_kernel<<<cdiv(n, 256), 256, (size_t)((n + 3) & ~3) * sizeof(int), (hipStream_t)stream_>>>(pos, n, cand_idx, C, sel_rows,
+                                                                                                       c_idx, n_unique);
   return check_launch("select_exemplars_kernel");
 }
 

@@ -232,7 +232,7 @@ class PairwiseDistance(torch.autograd.Function):
 PRIOR_MASK_ALL = -3      # EVAE_PRIOR_MASK_ALL: a c_idx entry that masks its exemplar slot for every query
 
 
-def select_exemplars(pos, cand_idx):
+def select_exemplars(pos, cand_idx, want_count=False):
     """Static-shape form of `unique` + gather (models/BaseModel.py:265-266): pos [n] top-k positions into cand_idx [C].
     -> (sel_rows [n] dataset rows of every slot, c_idx [n]: the row for the first slot naming a position, PRIOR_MASK_ALL
     for its repeats)."""
@@ -242,9 +242,10 @@ def select_exemplars(pos, cand_idx):
     n = pos.numel()
     sel = torch.empty(n, dtype=torch.int64, device=pos.device)
     cidx = torch.empty(n, dtype=torch.int64, device=pos.device)
-    _lib.check(lib.evae_select_exemplars(_p(pos), n, _p(cand_idx), cand_idx.numel(), _p(sel), _p(cidx), None, _stream()),
+    cnt = torch.empty(1, dtype=torch.int32, device=pos.device) if want_count else None
+    _lib.check(lib.evae_select_exemplars(_p(pos), n, _p(cand_idx), cand_idx.numel(), _p(sel), _p(cidx), _p(cnt), _stream()),
                "evae_select_exemplars")
-    return sel, cidx
+    return (sel, cidx, cnt) if want_count else (sel, cidx)
 
 
 def topk_merge(val, idx):

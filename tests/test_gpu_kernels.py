@@ -313,6 +313,21 @@ def test_topk_sharded_merge(ops):
     assert torch.equal(mi, full)
 
 
+@pytest.mark.parametrize("n,C", [(1000, 25000), (1, 5), (7, 3), (1030, 40), (16384, 100000)])
+def test_select_exemplars_marks_repeats(ops, n, C):
+    """evae_select_exemplars (static-shape `unique` of reference models/BaseModel.py:265-266): every slot keeps its dataset
+    row, the first slot naming a position keeps it as c_idx, repeats get PRIOR_MASK_ALL; the count is #unique."""
+    rs = np.random.RandomState(n + C)
+    pos = rs.randint(0, C, size=n).astype(np.int64)
+    cand = rs.permutation(4 * C)[:C].astype(np.int64)
+    sel, cidx, cnt = ops.select_exemplars(dev(pos), dev(cand), want_count=True)
+    first = np.zeros(n, bool)
+    first[np.unique(pos, return_index=True)[1]] = True
+    assert np.array_equal(sel.cpu().numpy(), cand[pos])
+    assert np.array_equal(cidx.cpu().numpy(), np.where(first, cand[pos], ops.PRIOR_MASK_ALL))
+    assert int(cnt.item()) == int(first.sum())
+
+
 # ---------------------------------------------------------------- dense layers
 @pytest.mark.parametrize("M,K,N", [(37, 53, 24), (100, 784, 300), (1000, 300, 300), (257, 40, 300), (5000, 784, 300),
                                    (130, 294, 40)])
