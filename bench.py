@@ -37,7 +37,10 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: dense bf16 MFMA (no sparsity)
 PEAK_HBM_GBS = 8000.0                # same guide: HBM3E
 B, C, N_TRAIN, D, H, Z = 100, 25000, 50000, 784, 300, 40
 # the MLP configurations that run through main(): model, exemplars, training-set size
-MLP_CONFIGS = {"c1": ("vae", 1000, 50000), "c2": ("vae", 25000, 50000), "c4": ("hvae_2level", 11500, 23000)}
+MLP_CONFIGS = {"c1": ("vae", 1000, 50000), "c2": ("vae", 25000, 50000), "c4": ("hvae_2level", 11500, 23000),
+               # c2 with the kNN-approximate prior (reference models/BaseModel.py:256-271): 25 000 candidates per step, top-10 of
+               # every batch row among their cached latents, the B * k = 1000 slots re-encoded
+               "c2a": ("vae", 25000, 50000)}
 
 
 def parse():
@@ -45,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="c2", choices=("c1", "c2", "c3", "c4", "c5", "iwae", "topk"),
+    ap.add_argument("--config", default="c2", choices=("c1", "c2", "c2a", "c3", "c4", "c5", "iwae", "topk"),
                     help="BASELINE.json configuration (default c2 = the one the metric is quoted on): c1 vae C=1000; c2 vae "
                          "C=25000; c3 convhvae_2level C=25000; c4 hvae_2level C=11500 (N=23000); c5 single_conv 3x64x64, z=256, "
                          "approximate prior over 100 000 cached latents; iwae = the test log p(x) evaluator at c2 sizes; "
@@ -423,6 +426,8 @@ def main():
     dataset = torch.utils.data.TensorDataset(data, torch.arange(n_train).reshape(-1, 1), torch.arange(n_train) % 10)
     dp = world > 1 and a.parallel == "dp"
     args = model_args("cuda:%d" % local_rank, n_ex, sharded=world > 1, shard_batch=dp, model_name=model_name, n_train=n_train)
+    approx = a.config == "c2a"
+    args.approximate_prior = approx
     torch.manual_seed(14)                    # same weights and (CPU-generator) exemplar draws on every rank
     torch.cuda.manual_seed(14)
     from utils.utils import importing_model
@@ -435,6 +440,10 @@ def main():
     idx_host = torch.arange(n_train).reshape(-1, 1)      # what a DataLoader over the training set hands out
     beta = set_beta(args, 50)
     model.train()
+    cache = None
+    if approx:                                # the per-epoch latent cache of utils.training.train_one_epoch
+        with torch.no_grad():
+            cache = tuple(model.cache_z(dataset))
     nb = n_train // B
     loss_acc = torch.zeros((), device=dev)
 
@@ -445,13 +454,15 @@ def main():
         s = batch_start(i)
         x = torch.bernoulli(data_dev[s:s + B])                     # dynamic binarisation (training.py:31)
         opt.zero_grad()
-        loss, RE, KL = model.calculate_loss((x, idx_all[s:s + B]), beta, average=True, dataset=dataset)
+        loss, RE, KL = model.calculate_loss((x, idx_all[s:s + B]), beta, average=True, dataset=dataset, cache=cache)
         loss.backward()
         opt.step()
         loss_acc.add_(loss.detach())
 
     from evae.graph import GraphedTrainStep
     graphed = None if a.no_graph else GraphedTrainStep(model, opt, dataset, B, True)
+    if graphed is not None and cache is not None:
+        cache = graphed.set_cache(cache)      # static buffers: the captured launches read and refresh them in place
 
     state = {"graphed": graphed}
 
@@ -497,7 +508,7 @@ def main():
     # otherwise the event pairs time the launch at a lower clock than the timed region (and rocprof's trace of it) ran at
     for i in range(a.probe_warmup if graphed is not None else 0):
         eager_step(a.warmup + a.steps + i)
-    ops.PROBE = {"records": []}
+    ops.PROBE = {"records": [], "min_flops": 2e9 if n_ex >= 10000 and not approx else 2e8}
     for i in range(a.probe_steps if graphed is not None else 0):
         eager_step(a.warmup + a.steps + a.probe_warmup + i)
     fence()
@@ -633,9 +644,12 @@ def main():
                            "them to the fp32-MFMA kernel's bar against the fp64 oracle and compare the two kernels' errors; "
                            "EVAE_X6=0 / EVAE_U8_STORE=0 put everything back on v_mfma_f32_32x32x2_f32"),
             "config": {"workload": "%s + exemplar_prior, %s-shaped binary 28x28, N=%d, batch %d per GPU, "
-                                   "%d exemplars in total, exact prior (BASELINE.json configs[%d])"
+                                   "%d %s (BASELINE.json configs[%d]%s)"
                                    % (model_name, "omniglot" if a.config == "c4" else "dynamic_mnist", n_train, B, n_ex,
-                                      {"c1": 0, "c2": 1, "c4": 3}[a.config]),
+                                      "candidates per step, approximate prior: top-10 per batch row over their cached latents, 1000 "
+                                      "exemplar slots re-encoded" if approx else "exemplars in total, exact prior",
+                                      {"c1": 0, "c2": 1, "c2a": 1, "c4": 3}[a.config],
+                                      " with --approximate_prior True" if approx else ""),
                        "global_batch": gb, "exemplars": n_ex,
                        "parallelism": ("single GPU" if world == 1 else
                                        ("dp%d (own %d-image batch per rank) x exemplar-shard x%d, partial-LSE exchange over RCCL"
@@ -649,7 +663,7 @@ def main():
             "test_log_px": iwae,
             "cpu_baseline": None,
         }
-        if world == 1 and a.cpu_baseline_steps > 0 and model_name == "vae":
+        if world == 1 and a.cpu_baseline_steps > 0 and model_name == "vae" and not approx:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_steps, n_ex, n_train)
         print(json.dumps(out))
     if world > 1:

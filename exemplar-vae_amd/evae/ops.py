@@ -21,7 +21,7 @@ def probed(name, flops, fn, executed=None, pipe="fp32-mfma", min_flops=2e9):
     """Run fn(); while bench.py's roofline probe is on, bracket it with a HIP event pair on the current stream (launches
     below min_flops are not worth an event pair).  `executed`: flops issued to the matrix pipe when they differ from the
     algorithmic count (three bf16 terms per product on the uint8 path)."""
-    if PROBE is None or flops < min_flops:
+    if PROBE is None or flops < PROBE.get("min_flops", min_flops):
         return fn()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -10,7 +10,7 @@ mkdir -p $out
 what=${@:-bench stats pmc}
 cd /tmp && export TMPDIR=/tmp
 cd $root
-CFGS=${CFGS:-c2 c1 c4 c3 c5 iwae topk}
+CFGS=${CFGS:-c2 c2a c1 c4 c3 c5 iwae topk}
 PROBES=${PROBES:-u8fwd1 u8wgrad1 fwd1 fwd2 dgrad2 wgrad1 wgrad2 prior_iwae prior_c5 prior_train topk_c5 topk_c2 conv5_fwd conv5_bwd conv96_fwd}
 steps_of() { case $1 in c3) echo "--steps 20 --warmup 6";; c5) echo "--steps 20 --warmup 4";; *) echo "";; esac; }
 for w in $what; do
