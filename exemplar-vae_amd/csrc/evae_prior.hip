@@ -1345,6 +1345,7 @@ extern "C" size_t evae_prior_lse_fwd_workspace_bytes(int B, int C, int zdim) {
   choose_splits(B, C, &ns, &tps, &nq);
   const size_t valu = align_up((size_t)3 * ns * B * sizeof(float), 256) + 256;
   if (fwd_uses_gemm(B, C, zdim)) return std::max(valu, prior_gemm_fwd_layout(B, C, zdim, ns).total);
+  if (prior_stream_applies(B, C, zdim, false)) return std::max(valu, prior_gemm_fwd_layout(B, C, zdim, ns, true).total);
   return valu;
 }
 
@@ -1383,7 +1384,9 @@ static int prior_lse_fwd_core(const float* z, int B, const float* centres, int C
   // matrix-core path (see prior_fwd_mfma_kernel); EVAE_PRIOR_VALU=1 forces the direct-difference kernel
   static int force_valu = -1;
   if (force_valu < 0) { const char* e = getenv("EVAE_PRIOR_VALU"); force_valu = (e && atoi(e)) ? 1 : 0; }
-  if (!force_valu && out_prob == nullptr && zdim <= 64 && (zdim & 3) == 0 &&
+  const bool masked_call = z_idx != nullptr && c_idx != nullptr;
+  const bool stream6 = !force_valu && out_prob == nullptr && splits_out == nullptr && prior_stream_applies(B, C, zdim, masked_call);
+  if (!stream6 && !force_valu && out_prob == nullptr && zdim <= 64 && (zdim & 3) == 0 &&
       ((((uintptr_t)z) | ((uintptr_t)centres)) & 15) == 0) {
     int ns2 = 1, rc;
     switch ((zdim + 7) / 8) {
@@ -1406,10 +1409,11 @@ static int prior_lse_fwd_core(const float* z, int B, const float* centres, int C
     return check_launch("prior_merge_kernel(splits)");
   }
   size_t lds = prior_lds_bytes(g, false);
-  if (!force_valu && out_prob == nullptr && fwd_uses_gemm(B, C, zdim)) {
+  if (stream6 || (!force_valu && out_prob == nullptr && fwd_uses_gemm(B, C, zdim))) {
     EVAE_REQUIRE(splits_out == nullptr, "prior_lse_fwd: raw split partials are not available on the GEMM path (z_dim > 64)");
-    // matrix-core GEMM with a log-sum-exp epilogue; its norm guard hands over to the direct-difference kernel on the device
-    const PriorGemmFwdLayout L = prior_gemm_fwd_layout(B, C, zdim, ns);
+    // matrix-core GEMM with a log-sum-exp epilogue (or, for evaluator-sized calls at small z, the streaming split-bf16
+    // kernel); its norm guard hands over to the direct-difference kernel on the device
+    const PriorGemmFwdLayout L = prior_gemm_fwd_layout(B, C, zdim, ns, stream6);
     int rc = prior_gemm_fwd(z, B, centres, C, zdim, log_var, z_idx, c_idx, prior_norm_limit(), (char*)ws, L, stream);
     if (rc) return rc;
     const unsigned* flag = (const unsigned*)((char*)ws + L.flag);

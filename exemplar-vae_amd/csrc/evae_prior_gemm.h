@@ -9,7 +9,7 @@ namespace evae {
 
 struct PriorGemmFwdLayout {      // byte offsets into the caller's workspace
   size_t flag, mu, Zs, zn, Cs, cn, pm, ps, pn, total;
-  int zp, ldp, tiles_m;
+  int zp, ldp, tiles_m, stream;      // stream: the partial rows come from prior_x6_lse_kernel (one per split)
 };
 struct PriorGemmBwdLayout {
   size_t flag, mu, Zs, zn, Cs, cn, P, T, U, rs, dvp, ws_data, ws_weight, total;
@@ -19,7 +19,9 @@ struct PriorGemmBwdLayout {
 
 bool prior_gemm_applies(int B, int C, int zdim);
 // ns_valu: partial rows the direct-difference fallback (prior_fwd_kernel) writes into the same partial planes
-PriorGemmFwdLayout prior_gemm_fwd_layout(int B, int C, int zdim, int ns_valu);
+PriorGemmFwdLayout prior_gemm_fwd_layout(int B, int C, int zdim, int ns_valu, bool stream = false);
+// evaluator-sized unmasked calls at z <= 48 (IWAE): the streaming split-bf16 kernel of evae_prior_gemm.hip
+bool prior_stream_applies(int B, int C, int zdim, bool masked);
 // enqueues mean / prep / GEMM; the caller then enqueues the flag-gated fallback and prior_gemm_merge
 int prior_gemm_fwd(const float* z, int B, const float* centres, int C, int zdim, const float* log_var, const int64_t* z_idx,
                    const int64_t* c_idx, float norm_limit, char* ws, const PriorGemmFwdLayout& L, hipStream_t stream);

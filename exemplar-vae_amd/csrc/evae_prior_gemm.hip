@@ -17,24 +17,62 @@
 namespace evae {
 
 // ---- mu[k] = mean over the B queries of z[q][k] exp(-log_var[k]/2); also clears the guard flag ------------------------
+// z: [B x zdim] rows, or (count != B) the [B x zp] partial column sums of prior_colsum_part_kernel over `count` rows
 __global__ __launch_bounds__(1024) void prior_colmean_kernel(const float* __restrict__ z, int B, int zdim, int zp,
                                                              const float* __restrict__ log_var, float* __restrict__ mu,
-                                                             unsigned* __restrict__ flag) {
+                                                             unsigned* __restrict__ flag, int count) {
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
   float a = 0.f;
+  const int ld = count != B ? zp : zdim;
   if (k < zdim)
-    for (int q = part; q < B; q += 16) a += z[(size_t)q * zdim + k];
+    for (int q = part; q < B; q += 16) a += z[(size_t)q * ld + k];
   red[part][lane] = a;
   __syncthreads();
   if (part == 0 && k < zp) {
     float t = 0.f;
 #pragma unroll
     for (int p = 0; p < 16; ++p) t += red[p][lane];      // fixed order
-    mu[k] = k < zdim ? (t / (float)B) * expf(-0.5f * log_var[k]) : 0.f;
+    mu[k] = k < zdim ? (t / (float)count) * expf(-0.5f * log_var[k]) : 0.f;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 0u;
+}
+
+// Many queries (the IWAE evaluator: 20 000 samples): one block per 64 columns would walk all rows alone (330 us at
+// B = 20 000).  Two stages instead, both in a fixed order: kCmParts row slices summed by a grid of blocks into part[slice][k],
+// then the kernel above over the kCmParts partial rows (count = B).
+constexpr int kCmParts = 64;
+__global__ __launch_bounds__(1024) void prior_colsum_part_kernel(const float* __restrict__ z, int B, int zdim, int zp,
+                                                                 int rows_per, float* __restrict__ part) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per, r1 = min(B, r0 + rows_per);
+  float a = 0.f;
+  if (k < zdim)
+    for (int q = r0 + sub; q < r1; q += 16) a += z[(size_t)q * zdim + k];
+  red[sub][lane] = a;
+  __syncthreads();
+  if (sub == 0 && k < zp) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += red[p][lane];
+    part[(size_t)blockIdx.y * zp + k] = t;
+  }
+}
+// mu (and the cleared guard flag) of a call: one launch for few queries, two for many
+static void launch_colmean(const float* z, int B, int zdim, int zp, const float* log_var, float* mu, unsigned* flag,
+                           hipStream_t stream) {
+  if (B <= 4096) {
+    prior_colmean_kernel<<<cdiv(zp, 64), 1024, 0, stream>>>(z, B, zdim, zp, log_var, mu, flag, B);
+    return;
+  }
+  float* part = mu + zp;                          // [kCmParts][zp] behind mu (the layouts reserve it)
+  const int rows_per = cdiv(B, kCmParts);
+  prior_colsum_part_kernel<<<dim3(cdiv(zp, 64), kCmParts), 1024, 0, stream>>>(z, B, zdim, zp, rows_per, part);
+  // the partial rows are zp wide with zeros beyond zdim: read them as a [kCmParts x zp] matrix, divide by the real count
+  prior_colmean_kernel<<<cdiv(zp, 64), 1024, 0, stream>>>(part, kCmParts, zdim, zp, log_var, mu, flag, B);
 }
 
 // ---- scaled, centred, padded copies + squared norms; one wave per row ------------------------------------------------
@@ -77,6 +115,201 @@ __global__ __launch_bounds__(256) void prior_prep_kernel(const float* __restrict
       cn[row - Bp] = s;
     }
   }
+}
+
+// ---- evaluator-sized, unmasked calls at small latent sizes (IWAE: thousands of samples x all exemplars, z <= 48) ---------
+// The streaming counterpart of EPI_PRIOR_LSE on the split-bf16 pipe (csrc/evae_gemm_x6.h): a block owns 128 queries, keeps
+// their three-term fragments in REGISTERS, and walks over its share of the exemplar tiles with the log-sum-exp state of
+// every query column in registers too -- no per-tile partial planes.  Per tile: the (prefetched) fp32 rows are split into
+// bf16 planes in LDS (double-buffered: one barrier per tile), 6 partial products per k-step on v_mfma_f32_32x32x16_bf16
+// give c'.z' at fp32-GEMM accuracy, and the epilogue is the online LSE on t = c'.z' - |c'|^2/2 (the query's own norm is added
+// at the end).  prior_fwd_mfma_kernel spends 2/3 of its time in fp32 MFMAs at these sizes; six bf16 MFMAs per 16 k replace
+// sixteen fp32 ones.  Output: one partial row per split, in the (max log N, sum exp, #masked = 0) convention of the merge.
+template <int KS>     // k-steps of 16: K <= 16 KS <= 48
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void prior_x6_lse_kernel(
+    const float* __restrict__ Cs, int C, const float* __restrict__ cn, const float* __restrict__ Zs, int B,
+    const float* __restrict__ zn, int zp, int tiles_per_split, const float* __restrict__ cst_dev,
+    const unsigned* __restrict__ skip_flag, float* __restrict__ pm, float* __restrict__ ps, float* __restrict__ pn, int ldp) {
+  constexpr int NS = (KS + 1) / 2;                 // 32-wide slabs staged per tile
+  constexpr int SLAB = 3 * X6_PLANE;               // bytes of one slab's three planes
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (*skip_flag != 0u) return;                    // the norm guard chose the direct-difference kernel
+  char* const lds = reinterpret_cast<char*>(smem);
+  char* const Qp = lds;                            // [NS][3 planes]
+  char* const Ep = lds + NS * SLAB;                // two buffers of [NS][3 planes]
+  float* const hc_s = reinterpret_cast<float*>(lds + 3 * NS * SLAB);       // [2][128] |c'|^2 / 2 of the tile's rows
+  float* const red = hc_s + 256;                                           // [2 wave rows][128][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x, q0 = blockIdx.y * 128;
+  const int ntiles = (C + 127) / 128;
+  const int tile_begin = split * tiles_per_split;
+  const int tile_end = min(tile_begin + tiles_per_split, ntiles);
+
+  // staging roles (as gemm_x6_kernel): chunk (row, c8) = float4 c8 of a slab's 32 k of tile row `row`
+  const int c8 = tid & 7;
+  unsigned st_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    st_off[i] = (unsigned)(row * 64 + ((((c8 >> 1) ^ ((row >> 2) & 3))) << 4) + (c8 & 1) * 8);
+  }
+  auto load_tile = [&](const float* src, int r0, int nrows, float4 (&v)[NS][4]) {
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = r0 + (tid >> 3) + 32 * i, k = sl * 32 + 4 * c8;
+        v[sl][i] = (r < nrows && k + 4 <= zp) ? *reinterpret_cast<const float4*>(src + (size_t)r * zp + k)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  };
+  auto stage_tile = [&](char* base, const float4 (&v)[NS][4]) {
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned a0, a1, a2, b0, b1, b2;
+        x6_split2(v[sl][i].x, v[sl][i].y, a0, a1, a2);
+        x6_split2(v[sl][i].z, v[sl][i].w, b0, b1, b2);
+        char* p = base + sl * SLAB + st_off[i];
+        x6_u32x2 t0 = {a0, b0}, t1 = {a1, b1}, t2 = {a2, b2};
+        *reinterpret_cast<x6_u32x2*>(p) = t0;
+        *reinterpret_cast<x6_u32x2*>(p + X6_PLANE) = t1;
+        *reinterpret_cast<x6_u32x2*>(p + 2 * X6_PLANE) = t2;
+      }
+  };
+  // fragment offsets inside a slab's plane: rows of this lane, 16-byte slot of k-step `step` (0 / 1)
+  unsigned fa[2][2], fb[2][2];
+#pragma unroll
+  for (int step = 0; step < 2; ++step) {
+    const int ks = 2 * step + lh;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int r = wr * 64 + t * 32 + l31, c = wc * 64 + t * 32 + l31;
+      fa[step][t] = (unsigned)(r * 64 + ((ks ^ ((r >> 2) & 3)) << 4));
+      fb[step][t] = (unsigned)(c * 64 + ((ks ^ ((c >> 2) & 3)) << 4));
+    }
+  }
+
+  float4 rv[NS][4];
+  load_tile(Zs, q0, B, rv);
+  stage_tile(Qp, rv);
+  if (tile_begin < tile_end) load_tile(Cs, tile_begin * 128, C, rv);
+  __syncthreads();
+  x6_bf16x8 bq[KS][2][3];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        bq[ks][nt][p] = *reinterpret_cast<const x6_bf16x8*>(Qp + (ks >> 1) * SLAB + p * X6_PLANE + fb[ks & 1][nt]);
+
+  float tm_[2] = {-INFINITY, -INFINITY}, ssum[2] = {0.f, 0.f};       // running max of t and sum exp(t - max) per query column
+  for (int t = tile_begin; t < tile_end; ++t) {
+    const int pb = (t - tile_begin) & 1, e0 = t * 128;
+    char* const Eb = Ep + pb * NS * SLAB;
+    stage_tile(Eb, rv);
+    if (tid < 128) hc_s[pb * 128 + tid] = (e0 + tid < C) ? 0.5f * cn[e0 + tid] : INFINITY;      // absent rows: t = -inf
+    __syncthreads();            // the tile is staged; the other buffer (read two tiles ago) is free for the next staging
+    if (t + 1 < tile_end) load_tile(Cs, (t + 1) * 128, C, rv);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      x6_bf16x8 af[2][3];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          af[mt][p] = *reinterpret_cast<const x6_bf16x8*>(Eb + (ks >> 1) * SLAB + p * X6_PLANE + fa[ks & 1][mt]);
+#pragma unroll
+      for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][PA[tt]], bq[ks][nt][PB[tt]], acc[mt][nt], 0, 0, 0);
+    }
+    // online log-sum-exp over this tile's 64 rows of the wave, per query column
+    float hc[2][16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hc[mt][r] = hc_s[pb * 128 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      float vmax = -INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[mt][nt][r] -= hc[mt][r];
+          vmax = fmaxf(vmax, acc[mt][nt][r]);
+        }
+      if (vmax > tm_[nt]) {
+        ssum[nt] *= fast_exp2((tm_[nt] - vmax) * kLog2e);        // first tile: 0 * exp2(-inf) = 0
+        tm_[nt] = vmax;
+      }
+      if (tm_[nt] != -INFINITY) {
+        const float mk = -tm_[nt] * kLog2e;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ssum[nt] += fast_exp2(fmaf(acc[mt][nt][r], kLog2e, mk));
+      }
+    }
+  }
+  // lanes l / l + 32 hold the same column, then the two wave rows through LDS
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const float ot = __shfl_xor(tm_[nt], 32, 64), os = __shfl_xor(ssum[nt], 32, 64);
+    const float mx = fmaxf(tm_[nt], ot);
+    const float fa_ = (tm_[nt] == mx) ? 1.f : fast_exp2((tm_[nt] - mx) * kLog2e);
+    const float fb_ = (ot == mx) ? 1.f : fast_exp2((ot - mx) * kLog2e);
+    if (lh == 0) {
+      float* cb = red + (wr * 128 + wc * 64 + nt * 32 + l31) * 2;
+      cb[0] = mx; cb[1] = ssum[nt] * fa_ + os * fb_;
+    }
+  }
+  __syncthreads();
+  if (tid < 128 && q0 + tid < B) {
+    const float t0 = red[tid * 2], t1 = red[(128 + tid) * 2];
+    const float mx = fmaxf(t0, t1);
+    float sacc = 0.f;
+    if (t0 != -INFINITY) sacc += red[tid * 2 + 1] * fast_exp2((t0 - mx) * kLog2e);
+    if (t1 != -INFINITY) sacc += red[(128 + tid) * 2 + 1] * fast_exp2((t1 - mx) * kLog2e);
+    const size_t o = (size_t)split * ldp + q0 + tid;
+    pm[o] = (mx == -INFINITY) ? -INFINITY : *cst_dev + (mx - 0.5f * zn[q0 + tid]);
+    ps[o] = sacc;
+    pn[o] = 0.f;
+  }
+}
+
+// number of exemplar splits of the streaming kernel: fill the 256 CUs (one block each) with as little tail as possible,
+// at least eight tiles per block
+static int prior_x6_splits(int B, int C) {
+  const int nq = cdiv(B, 128), ntiles = cdiv(C, 128);
+  int best = 1;
+  double best_eff = 0.0;
+  for (int ns = 1; ns <= 32 && ns * 8 <= std::max(ntiles, 8); ++ns) {
+    const int tps = cdiv(ntiles, ns), nse = cdiv(ntiles, tps);
+    const long blocks = (long)nse * nq;
+    const double eff = (double)blocks / (double)(cdiv((int)blocks, 256) * 256) * ((double)ntiles / ((double)tps * nse));
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = nse; }
+  }
+  return best;
+}
+bool prior_stream_applies(int B, int C, int zdim, bool masked) {
+  return !masked && zdim <= 48 && (zdim & 3) == 0 && B >= 1024 && (int64_t)B * C >= ((int64_t)1 << 26) && gemm_x6_enabled() &&
+         prior_gemm_applies(B, C, zdim);
 }
 
 // ---- merge of per-tile partials [R x ldp] -> (max, sumexp, nmask) per query; R is chosen on the device ----------------
@@ -182,13 +415,15 @@ __global__ __launch_bounds__(1024) void prior_gemm_bwd_dlv_kernel(const float* _
 static int zpad(int zdim) { return (zdim + 3) / 4 * 4; }
 static int bpad(int B) { return (B + 3) / 4 * 4; }
 
-PriorGemmFwdLayout prior_gemm_fwd_layout(int B, int C, int zdim, int ns_valu) {
+PriorGemmFwdLayout prior_gemm_fwd_layout(int B, int C, int zdim, int ns_valu, bool stream) {
   PriorGemmFwdLayout L;
   const int zp = zpad(zdim);
-  L.zp = zp; L.ldp = bpad(B); L.tiles_m = cdiv(C, BM);
+  // partial rows: one per 128-exemplar tile (GEMM epilogue) or one per split of the streaming kernel
+  L.zp = zp; L.ldp = bpad(B); L.tiles_m = stream ? prior_x6_splits(B, C) : cdiv(C, BM);
+  L.stream = stream ? 1 : 0;
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
-  L.flag = take(256); L.mu = take((size_t)zp * 4);
+  L.flag = take(256); L.mu = take((size_t)zp * 4 * (1 + kCmParts));
   L.Zs = take((size_t)L.ldp * zp * 4); L.zn = take((size_t)L.ldp * 4);
   L.Cs = take((size_t)C * zp * 4); L.cn = take((size_t)C * 4);
   const size_t rows = (size_t)(L.tiles_m > ns_valu ? L.tiles_m : ns_valu);
@@ -232,17 +467,38 @@ __global__ void prior_cst_kernel(const float* __restrict__ log_var, int zdim, fl
 int prior_gemm_fwd(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
                    const int64_t* z_idx, const int64_t* c_idx, float norm_limit, char* ws, const PriorGemmFwdLayout& L,
                    hipStream_t stream) {
+  if (L.stream) EVAE_REQUIRE(z_idx == nullptr || c_idx == nullptr, "prior_gemm_fwd: the streaming kernel takes unmasked calls only");
   unsigned* flag = (unsigned*)(ws + L.flag);
   float* cstp = (float*)(ws + L.flag) + 16;
   float* mu = (float*)(ws + L.mu);
   float* Zs = (float*)(ws + L.Zs); float* zn = (float*)(ws + L.zn);
   float* Cs = (float*)(ws + L.Cs); float* cn = (float*)(ws + L.cn);
-  prior_colmean_kernel<<<cdiv(L.zp, 64), 1024, 0, stream>>>(z, B, zdim, L.zp, log_var, mu, flag);
+  launch_colmean(z, B, zdim, L.zp, log_var, mu, flag, stream);
   prior_cst_kernel<<<1, 64, 0, stream>>>(log_var, zdim, cstp);
   prior_prep_kernel<<<cdiv(L.ldp + C, 4), 256, 0, stream>>>(z, B, L.ldp, Zs, L.zp, zn, centres, C, Cs, cn, zdim, L.zp, log_var,
                                                             mu, norm_limit, flag);
   int rc = check_launch("prior_prep_kernel");
   if (rc) return rc;
+  if (L.stream) {
+    const int ns6 = L.tiles_m, tps = cdiv(cdiv(C, 128), ns6), ks = cdiv(L.zp, 16);
+    const size_t lds = (size_t)3 * ((ks + 1) / 2) * 3 * X6_PLANE + (256 + 512) * sizeof(float);
+    float* pm = (float*)(ws + L.pm); float* ps = (float*)(ws + L.ps); float* pn = (float*)(ws + L.pn);
+    const dim3 grid(ns6, cdiv(B, 128));
+#define EVAE_STREAM_LAUNCH(KS_)                                                                                                   \
+    do {                                                                                                                          \
+      static bool attr_done = false;                                                                                              \
+      if (!attr_done) {                                                                                                           \
+        (void)hipFuncSetAttribute((const void*)prior_x6_lse_kernel<KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024); \
+        attr_done = true;                                                                                                         \
+      }                                                                                                                           \
+      prior_x6_lse_kernel<KS_><<<grid, 256, lds, stream>>>(Cs, C, cn, Zs, B, zn, L.zp, tps, cstp, flag, pm, ps, pn, L.ldp);       \
+    } while (0)
+    if (ks <= 1) EVAE_STREAM_LAUNCH(1);
+    else if (ks == 2) EVAE_STREAM_LAUNCH(2);
+    else EVAE_STREAM_LAUNCH(3);
+#undef EVAE_STREAM_LAUNCH
+    return check_launch("prior_x6_lse_kernel");
+  }
   GemmArgs g = {};
   g.ones_col = -1;
   g.A[0] = Cs; g.B[0] = Zs; g.lda[0] = L.zp; g.ldb[0] = L.zp; g.Kc[0] = L.zp; g.npairs = 1;
@@ -265,7 +521,7 @@ PriorGemmBwdLayout prior_gemm_bwd_layout(int B, int C, int zdim) {
   L.zp = zp; L.ldz = zp + 4; L.ldp = bpad(B);
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
-  L.flag = take(256); L.mu = take((size_t)zp * 4);
+  L.flag = take(256); L.mu = take((size_t)zp * 4 * (1 + kCmParts));
   L.Zs = take((size_t)L.ldp * L.ldz * 4); L.zn = take((size_t)L.ldp * 4);
   L.Cs = take((size_t)C * zp * 4); L.cn = take((size_t)C * 4);
   L.P = take((size_t)C * L.ldp * 4);
@@ -291,7 +547,7 @@ int prior_gemm_bwd(const float* z, int B, const float* centres, int C, int zdim,
   float* Cs = (float*)(ws + L.Cs); float* cn = (float*)(ws + L.cn);
   float* P = (float*)(ws + L.P); float* T = (float*)(ws + L.T); float* U = (float*)(ws + L.U); float* rs = (float*)(ws + L.rs);
   float* dvp = (float*)(ws + L.dvp);
-  prior_colmean_kernel<<<cdiv(L.zp, 64), 1024, 0, stream>>>(z, B, zdim, L.zp, log_var, mu, flag);
+  launch_colmean(z, B, zdim, L.zp, log_var, mu, flag, stream);
   prior_cst_kernel<<<1, 64, 0, stream>>>(log_var, zdim, cstp);
   prior_prep_kernel<<<cdiv(L.ldp + C, 4), 256, 0, stream>>>(z, B, L.ldp, Zs, L.ldz, zn, centres, C, Cs, cn, zdim, L.zp, log_var,
                                                             mu, norm_limit, flag);

@@ -56,6 +56,34 @@ def test_prior_fwd_matches_oracle(ops, B, C, zd, masked):
     assert rel((raw - np.log(denom))[fin], ref_prob[fin]) < 1e-5
 
 
+@pytest.mark.parametrize("B,C,zd,offset", [(2048, 33000, 40, 0.0), (1500, 45001, 40, 3.0), (1100, 61100, 16, 0.0),
+                                           (1024, 65536, 48, -2.0), (4100, 20000, 28, 0.0)])
+def test_prior_evaluator_sized_calls_on_the_streaming_bf16_kernel(ops, B, C, zd, offset):
+    """IWAE-sized, unmasked calls at z <= 48 (thousands of samples x all exemplars) run on prior_x6_lse_kernel
+    (csrc/evae_prior_gemm.hip): queries' split fragments in registers, online log-sum-exp over the exemplar tiles, six bf16
+    products per pair.  Against the fp64 oracle on a sample of the queries (the full [B x C] matrix is not built on the host),
+    at the bar of the fp32 kernels, and against the fp32 matrix-core kernel (split-bf16 pipe switched off)."""
+    z, c = gi.clustered_latents(900 + B, B, C, zd)
+    z = (z + offset).astype(np.float32); c = (c + offset).astype(np.float32)
+    lv = np.linspace(-1.2, -0.4, zd).astype(np.float32)
+    m, s, n, _ = ops.prior_lse_fwd(dev(z), dev(c), dev(lv))
+    lp, _ = ops.prior_merge(m, s, n, C)
+    lp = lp.cpu().numpy()
+    pick = np.random.RandomState(B).choice(B, size=96, replace=False)
+    ref = orc.logsumexp_rows(orc.log_p_z_exemplar(z[pick], None, c, lv[None, :], None, test=True))
+    assert rel(lp[pick], ref) < 1e-5
+    assert float(n.abs().max()) == 0.0
+    ops.gemm_x6_configure(0, -1)
+    try:
+        m2, s2, n2, _ = ops.prior_lse_fwd(dev(z), dev(c), dev(lv))
+        lp2, _ = ops.prior_merge(m2, s2, n2, C)
+    finally:
+        ops.gemm_x6_configure(1, -1)
+    lp2 = lp2.cpu().numpy()
+    assert rel(lp, lp2) < 2e-6
+    assert not np.array_equal(lp, lp2)          # two different kernels: identical bits would mean the switch did nothing
+
+
 @pytest.mark.parametrize("B,C,zd,masked", [(8, 300, 40, True), (100, 1000, 40, True), (100, 25000, 40, True),
                                            (100, 25000, 40, False), (5, 7, 4, True), (130, 70, 64, False),
                                            (300, 2000, 40, True), (1, 1, 40, False), (129, 129, 24, True),
