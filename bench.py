@@ -304,9 +304,14 @@ def other_config(a, dev, rank, world):
         flops = 2.0 * 4 * args.S * N_TRAIN * Z
         tf = flops / us / 1e6
         traffic, tsrc = pmc_traffic("prior_fwd_iwae")
-        roof = {"bound": "mfma", "kernel": "evae::prior_fwd_mfma_kernel<5, 1> (+ the split merge): 4 x %d importance samples x %d "
-                                           "exemplars x z=%d, distance on the matrix cores, online log-sum-exp" % (args.S, N_TRAIN, Z),
-                "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+        executed, pipe = ops.gemm_pipe(N_TRAIN, 4 * args.S, False, flops)      # streaming split-bf16 kernel when the pipe is on
+        peak = PEAK_BF16_MFMA_TFLOPS if pipe == "bf16-mfma" else PEAK_FP32_MFMA_TFLOPS
+        kname = ("evae::prior_x6_lse_kernel<3> (+ staging pass and split merge; csrc/evae_prior_gemm.hip)" if pipe == "bf16-mfma"
+                 else "evae::prior_fwd_mfma_kernel<5, 4> (+ the split merge)")
+        roof = {"bound": "mfma", "kernel": kname + ": 4 x %d importance samples x %d exemplars x z=%d, distance on the matrix "
+                                                   "cores, online log-sum-exp" % (args.S, N_TRAIN, Z),
+                "achieved": round(executed / us / 1e6, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(executed / us / 1e6 / peak, 4),
+                "pipe": pipe, "algorithmic_tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": tsrc, "avg_launch_us": round(us, 2), "flops_per_launch": round(flops)}
         a.steps = n_pass * nimg
         print(json.dumps(line("IWAE test log p(x) images/sec", round(n_pass * nimg / dt, 2), "images/sec", a, dt,

@@ -126,76 +126,77 @@ __global__ __launch_bounds__(256) void prior_prep_kernel(const float* __restrict
 // at the end).  prior_fwd_mfma_kernel spends 2/3 of its time in fp32 MFMAs at these sizes; six bf16 MFMAs per 16 k replace
 // sixteen fp32 ones.  Output: one partial row per split, in the (max log N, sum exp, #masked = 0) convention of the merge.
 template <int KS>     // k-steps of 16: K <= 16 KS <= 48
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void prior_x6_lse_kernel(
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void prior_x6_lse_kernel(
     const float* __restrict__ Cs, int C, const float* __restrict__ cn, const float* __restrict__ Zs, int B,
     const float* __restrict__ zn, int zp, int tiles_per_split, const float* __restrict__ cst_dev,
     const unsigned* __restrict__ skip_flag, float* __restrict__ pm, float* __restrict__ ps, float* __restrict__ pn, int ldp) {
+  // block = 8 waves (2 exemplar halves x 4 query quarters): 128 exemplars x 256 queries per tile, wave tile 64 x 64.  The
+  // query planes (256 rows) are only needed until their fragments sit in registers: the same LDS then holds the two
+  // exemplar buffers, so the block needs 96 KB and its 8 waves give every SIMD two.
   constexpr int NS = (KS + 1) / 2;                 // 32-wide slabs staged per tile
-  constexpr int SLAB = 3 * X6_PLANE;               // bytes of one slab's three planes
+  constexpr int SLAB = 3 * X6_PLANE;               // bytes of one slab's three planes (128 rows)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (*skip_flag != 0u) return;                    // the norm guard chose the direct-difference kernel
   char* const lds = reinterpret_cast<char*>(smem);
-  char* const Qp = lds;                            // [NS][3 planes]
-  char* const Ep = lds + NS * SLAB;                // two buffers of [NS][3 planes]
-  float* const hc_s = reinterpret_cast<float*>(lds + 3 * NS * SLAB);       // [2][128] |c'|^2 / 2 of the tile's rows
-  float* const red = hc_s + 256;                                           // [2 wave rows][128][2]
+  char* const Ep = lds;                            // two buffers of [NS][3 planes][128 rows]; before the loop: the query planes
+  float* const hc_s = reinterpret_cast<float*>(lds + 2 * NS * SLAB);       // [2][128] |c'|^2 / 2 of the tile's rows
+  float* const red = hc_s + 256;                                           // [2 wave rows][256][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
-  const int split = blockIdx.x, q0 = blockIdx.y * 128;
+  const int wr = wave >> 2, wc = wave & 3, l31 = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x, q0 = blockIdx.y * 256;
   const int ntiles = (C + 127) / 128;
   const int tile_begin = split * tiles_per_split;
   const int tile_end = min(tile_begin + tiles_per_split, ntiles);
 
-  // staging roles (as gemm_x6_kernel): chunk (row, c8) = float4 c8 of a slab's 32 k of tile row `row`
+  // staging roles: chunk (row, c8) = float4 c8 of a slab's 32 k of tile row `row`; rows (tid >> 3) + 64 i
   const int c8 = tid & 7;
-  unsigned st_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (tid >> 3) + 32 * i;
-    st_off[i] = (unsigned)(row * 64 + ((((c8 >> 1) ^ ((row >> 2) & 3))) << 4) + (c8 & 1) * 8);
-  }
-  auto load_tile = [&](const float* src, int r0, int nrows, float4 (&v)[NS][4]) {
-#pragma unroll
-    for (int sl = 0; sl < NS; ++sl)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = r0 + (tid >> 3) + 32 * i, k = sl * 32 + 4 * c8;
-        v[sl][i] = (r < nrows && k + 4 <= zp) ? *reinterpret_cast<const float4*>(src + (size_t)r * zp + k)
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+  auto st_off = [&](int row) -> unsigned {
+    return (unsigned)(row * 64 + ((((c8 >> 1) ^ ((row >> 2) & 3))) << 4) + (c8 & 1) * 8);
   };
-  auto stage_tile = [&](char* base, const float4 (&v)[NS][4]) {
-#pragma unroll
-    for (int sl = 0; sl < NS; ++sl)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        unsigned a0, a1, a2, b0, b1, b2;
-        x6_split2(v[sl][i].x, v[sl][i].y, a0, a1, a2);
-        x6_split2(v[sl][i].z, v[sl][i].w, b0, b1, b2);
-        char* p = base + sl * SLAB + st_off[i];
-        x6_u32x2 t0 = {a0, b0}, t1 = {a1, b1}, t2 = {a2, b2};
-        *reinterpret_cast<x6_u32x2*>(p) = t0;
-        *reinterpret_cast<x6_u32x2*>(p + X6_PLANE) = t1;
-        *reinterpret_cast<x6_u32x2*>(p + 2 * X6_PLANE) = t2;
-      }
+  auto load_chunk = [&](const float* src, int r, int nrows, int sl) -> float4 {
+    const int k = sl * 32 + 4 * c8;
+    return (r < nrows && k + 4 <= zp) ? *reinterpret_cast<const float4*>(src + (size_t)r * zp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  // fragment offsets inside a slab's plane: rows of this lane, 16-byte slot of k-step `step` (0 / 1)
+  auto stage_chunk = [&](char* p, const float4 v) {
+    unsigned a0, a1, a2, b0, b1, b2;
+    x6_split2(v.x, v.y, a0, a1, a2);
+    x6_split2(v.z, v.w, b0, b1, b2);
+    x6_u32x2 t0 = {a0, b0}, t1 = {a1, b1}, t2 = {a2, b2};
+    *reinterpret_cast<x6_u32x2*>(p) = t0;
+    *reinterpret_cast<x6_u32x2*>(p + X6_PLANE) = t1;
+    *reinterpret_cast<x6_u32x2*>(p + 2 * X6_PLANE) = t2;
+  };
+  // fragment offsets inside a 128-row plane: rows of this lane, 16-byte slot of k-step `step` (0 / 1)
   unsigned fa[2][2], fb[2][2];
 #pragma unroll
   for (int step = 0; step < 2; ++step) {
     const int ks = 2 * step + lh;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int r = wr * 64 + t * 32 + l31, c = wc * 64 + t * 32 + l31;
+      const int r = wr * 64 + t * 32 + l31, c = (wc & 1) * 64 + t * 32 + l31;      // query rows: inside the half (wc >> 1)
       fa[step][t] = (unsigned)(r * 64 + ((ks ^ ((r >> 2) & 3)) << 4));
       fb[step][t] = (unsigned)(c * 64 + ((ks ^ ((c >> 2) & 3)) << 4));
     }
   }
 
-  float4 rv[NS][4];
-  load_tile(Zs, q0, B, rv);
-  stage_tile(Qp, rv);
-  if (tile_begin < tile_end) load_tile(Cs, tile_begin * 128, C, rv);
+  // queries: two halves of 128 rows, half h staged where exemplar buffer h will live
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 64 * i;
+        stage_chunk(Ep + h * NS * SLAB + sl * SLAB + st_off(row), load_chunk(Zs, q0 + h * 128 + row, B, sl));
+      }
+  float4 rv[NS][2];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) rv[sl][i] = load_chunk(Cs, t * 128 + (tid >> 3) + 64 * i, C, sl);
+  };
+  if (tile_begin < tile_end) load_tile(tile_begin);
   __syncthreads();
   x6_bf16x8 bq[KS][2][3];
 #pragma unroll
@@ -204,16 +205,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        bq[ks][nt][p] = *reinterpret_cast<const x6_bf16x8*>(Qp + (ks >> 1) * SLAB + p * X6_PLANE + fb[ks & 1][nt]);
+        bq[ks][nt][p] = *reinterpret_cast<const x6_bf16x8*>(Ep + (wc >> 1) * NS * SLAB + (ks >> 1) * SLAB + p * X6_PLANE + fb[ks & 1][nt]);
+  __syncthreads();              // every wave holds its query fragments: the planes become the exemplar buffers
 
   float tm_[2] = {-INFINITY, -INFINITY}, ssum[2] = {0.f, 0.f};       // running max of t and sum exp(t - max) per query column
   for (int t = tile_begin; t < tile_end; ++t) {
     const int pb = (t - tile_begin) & 1, e0 = t * 128;
     char* const Eb = Ep + pb * NS * SLAB;
-    stage_tile(Eb, rv);
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) stage_chunk(Eb + sl * SLAB + st_off((tid >> 3) + 64 * i), rv[sl][i]);
     if (tid < 128) hc_s[pb * 128 + tid] = (e0 + tid < C) ? 0.5f * cn[e0 + tid] : INFINITY;      // absent rows: t = -inf
     __syncthreads();            // the tile is staged; the other buffer (read two tiles ago) is free for the next staging
-    if (t + 1 < tile_end) load_tile(Cs, (t + 1) * 128, C, rv);
+    if (t + 1 < tile_end) load_tile(t + 1);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -275,17 +280,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float fa_ = (tm_[nt] == mx) ? 1.f : fast_exp2((tm_[nt] - mx) * kLog2e);
     const float fb_ = (ot == mx) ? 1.f : fast_exp2((ot - mx) * kLog2e);
     if (lh == 0) {
-      float* cb = red + (wr * 128 + wc * 64 + nt * 32 + l31) * 2;
+      float* cb = red + (wr * 256 + wc * 64 + nt * 32 + l31) * 2;
       cb[0] = mx; cb[1] = ssum[nt] * fa_ + os * fb_;
     }
   }
   __syncthreads();
-  if (tid < 128 && q0 + tid < B) {
-    const float t0 = red[tid * 2], t1 = red[(128 + tid) * 2];
+  if (tid < 256 && q0 + tid < B) {
+    const float t0 = red[tid * 2], t1 = red[(256 + tid) * 2];
     const float mx = fmaxf(t0, t1);
     float sacc = 0.f;
     if (t0 != -INFINITY) sacc += red[tid * 2 + 1] * fast_exp2((t0 - mx) * kLog2e);
-    if (t1 != -INFINITY) sacc += red[(128 + tid) * 2 + 1] * fast_exp2((t1 - mx) * kLog2e);
+    if (t1 != -INFINITY) sacc += red[(256 + tid) * 2 + 1] * fast_exp2((t1 - mx) * kLog2e);
     const size_t o = (size_t)split * ldp + q0 + tid;
     pm[o] = (mx == -INFINITY) ? -INFINITY : *cst_dev + (mx - 0.5f * zn[q0 + tid]);
     ps[o] = sacc;
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // number of exemplar splits of the streaming kernel: fill the 256 CUs (one block each) with as little tail as possible,
 // at least eight tiles per block
 static int prior_x6_splits(int B, int C) {
-  const int nq = cdiv(B, 128), ntiles = cdiv(C, 128);
+  const int nq = cdiv(B, 256), ntiles = cdiv(C, 128);
   int best = 1;
   double best_eff = 0.0;
   for (int ns = 1; ns <= 32 && ns * 8 <= std::max(ntiles, 8); ++ns) {
@@ -481,17 +486,17 @@ int prior_gemm_fwd(const float* z, int B, const float* centres, int C, int zdim,
   if (rc) return rc;
   if (L.stream) {
     const int ns6 = L.tiles_m, tps = cdiv(cdiv(C, 128), ns6), ks = cdiv(L.zp, 16);
-    const size_t lds = (size_t)3 * ((ks + 1) / 2) * 3 * X6_PLANE + (256 + 512) * sizeof(float);
+    const size_t lds = (size_t)2 * ((ks + 1) / 2) * 3 * X6_PLANE + (256 + 1024) * sizeof(float);
     float* pm = (float*)(ws + L.pm); float* ps = (float*)(ws + L.ps); float* pn = (float*)(ws + L.pn);
-    const dim3 grid(ns6, cdiv(B, 128));
+    const dim3 grid(ns6, cdiv(B, 256));
 #define EVAE_STREAM_LAUNCH(KS_)                                                                                                   \
     do {                                                                                                                          \
       static bool attr_done = false;                                                                                              \
       if (!attr_done) {                                                                                                           \
-        (void)hipFuncSetAttribute((const void*)prior_x6_lse_kernel<KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024); \
+        (void)hipFuncSetAttribute((const void*)prior_x6_lse_kernel<KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024); \
         attr_done = true;                                                                                                         \
       }                                                                                                                           \
-      prior_x6_lse_kernel<KS_><<<grid, 256, lds, stream>>>(Cs, C, cn, Zs, B, zn, L.zp, tps, cstp, flag, pm, ps, pn, L.ldp);       \
+      prior_x6_lse_kernel<KS_><<<grid, 512, lds, stream>>>(Cs, C, cn, Zs, B, zn, L.zp, tps, cstp, flag, pm, ps, pn, L.ldp);       \
     } while (0)
     if (ks <= 1) EVAE_STREAM_LAUNCH(1);
     else if (ks == 2) EVAE_STREAM_LAUNCH(2);
