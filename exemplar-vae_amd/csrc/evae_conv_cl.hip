@@ -182,7 +182,8 @@ extern "C" size_t evae_conv2d_cl_workspace_bytes(const evae_conv_desc_t* d, int 
   for (int nn : {std::min(per, d->N), per > 0 ? (d->N % per) : 0}) {
     if (nn <= 0) continue;
     Plan pl = make_plan(ctot, (int)K + 1, cdiv(nn * OH * OW, BK), false, true, 1);
-    best = std::max(best, (size_t)pl.nz * ctot * (K + 1) * sizeof(float));
+    const int nz6 = x6t_split(nn * OH * OW, ctot, (int)K + 1).nz;         // the split-bf16 kernel's own split
+    best = std::max(best, (size_t)std::max(pl.nz, nz6) * ctot * (K + 1) * sizeof(float));
   }
   return align_up(best, 256) + 256;
 }
@@ -539,12 +540,19 @@ extern "C" int evae_conv2d_cl_bwd_weight(const float* dy, const float* x, const 
     g.B[0] = x + (size_t)n0 * d->H * d->W * d->C;
     g.Kc[0] = mp;
     g.ksplit = pl.nz > 1 ? pl.ksplit : 0;
-    int rc;
-    if (pl.bn == 128) rc = launch_gemm_w<false, false, EPI_RAW, true, 128, 8, 2>(g, pl.nz, stream, "conv2d_cl_bwd_weight");
+    int rc, nz_used = pl.nz;
+    // both operands k-major (dy rows x im2col rows): the transposing split-bf16 kernel when its 128 x 128 tiles are well filled
+    if (gemm_x6_enabled() && gemm_x6t_ok(g, true) && d->C % 4 == 0 &&
+        (gemm_x6_min_rows() == 0 || ((double)mp * ctot * (K + 1) >= 2e9 && gemm_x6t_fill(ctot, K + 1) >= 0.85))) {
+      const X6tSplit sp6 = x6t_split(mp, ctot, K + 1);
+      g.ksplit = sp6.nz > 1 ? sp6.ksplit : 0;
+      nz_used = sp6.nz;
+      rc = launch_gemm_x6t<EPI_RAW, 2>(g, sp6.nz, stream, "conv2d_cl_bwd_weight(x6)");
+    } else if (pl.bn == 128) rc = launch_gemm_w<false, false, EPI_RAW, true, 128, 8, 2>(g, pl.nz, stream, "conv2d_cl_bwd_weight");
     else rc = launch_gemm_w<false, false, EPI_RAW, true, 64, 8, 2>(g, pl.nz, stream, "conv2d_cl_bwd_weight");
     if (rc) return rc;
     FinishArgs f = {};
-    f.part = (const float*)ws; f.nz = pl.nz; f.M = ctot; f.N = K + 1; f.ldo = K + 1; f.epi = EPI_RAW; f.out0 = dw;
+    f.part = (const float*)ws; f.nz = nz_used; f.M = ctot; f.N = K + 1; f.ldo = K + 1; f.epi = EPI_RAW; f.out0 = dw;
     f.ones_col = K; f.out_db = db; f.perm_c = d->C; f.perm_taps = taps; f.perm_k = K; f.accumulate = n0 > 0;
     rc = launch_finish(f, stream);
     if (rc) return rc;

@@ -279,17 +279,6 @@ extern "C" int evae_dense_bwd_data_img(const float* dy1, const float* w1, const 
 // ---- weight gradient -------------------------------------------------------------------------------------
 // The bias gradient db = column sums of dy is folded into the same GEMM: x gets a virtual all-ones
 // column K (never read from memory), so column K of dy^T [x | 1] is db.
-// split of the contraction for the split-bf16 weight-gradient kernel: enough 128 x 128 tiles x slices to fill 512 block slots,
-// at least eight K-slabs per slice
-struct X6tSplit { int nz, ksplit; };
-static X6tSplit x6t_split(int M, int N, int Kp) {
-  const int slabs = cdiv(M, BK), tiles = cdiv(N, BM) * cdiv(Kp, 128);
-  int nz = std::max(1, std::min(512 / std::max(tiles, 1), slabs / 8));
-  const int ksplit = cdiv(slabs, nz);
-  nz = cdiv(slabs, ksplit);
-  return {nz, ksplit};
-}
-
 extern "C" size_t evae_dense_bwd_weight_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 256;
   Plan pl = make_plan(N, K + 1, cdiv(M, BK), false, true, 1);
@@ -326,7 +315,7 @@ static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const f
   // tiles are well filled -- measured: K = 784 (785 of 896 columns) 240 vs 260 us, K = 300 (301 of 384) 116 vs 119 us: at 78 %
   // fill the fp32 kernel's 64-wide tiles are as fast
   const bool x6 = gemm_x6_enabled() && gemm_x6t_ok(g) &&
-                  (gemm_x6_min_rows() == 0 || ((double)M * N * Kp >= 2e9 && Kp >= 0.85 * (cdiv(Kp, 128) * 128)));
+                  (gemm_x6_min_rows() == 0 || ((double)M * N * Kp >= 2e9 && gemm_x6t_fill(128, Kp) >= 0.85));
   const X6tSplit sp6 = x6t_split(M, N, Kp);
   if (phase != 2) {
     int rc;

@@ -275,7 +275,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // 4 n4 + i and 4 (n4 + 1) + i) x the eight 8-byte chunks of a row, and the swap gives the two rows opposite parity, i.e. the
 // two halves of the 128-byte bank period (without it every pass is a 2-way conflict); fragment reads see whole aligned
 // groups of four rows, so their conflict-free pattern is unchanged.
-template <int EPI>
+// CV = 2: B is the im2col matrix of a channels-last convolution's weight gradient, [pixel][(tap, channel)] gathered as four
+// channels of one tap (ConvMap, evae_gemm_kernel.h); a thread's four columns are one (tap, channel group) for the whole
+// kernel, its contraction rows are decomposed into (image, y, x) per slab.
+template <int EPI, int CV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x6t_kernel(const GemmArgs g) {
   constexpr int NW = 4, MT = 2, NT = 2, BN_ = 128;
   constexpr unsigned OOB = 0x80000000u;
@@ -318,6 +321,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int nlim = g.ones_col >= 0 ? g.ones_col : g.N;
   const bool colokB = cb + 4 <= nlim;
   const bool onesB = g.ones_col >= 0 && cb == g.ones_col;
+  int coltap = 0, colch = 0;
+  if constexpr (CV == 2) { coltap = cb / g.cv.Cg; colch = cb - coltap * g.cv.Cg; if (!colokB) coltap = 0; }
   unsigned voA[4], voB[4], st_off[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -372,7 +377,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const bool live = 4 * m4 + j < kv;
       if (isa) ra[j] = buf_ld4(rA, live ? voA[j] : OOB, so);
       else {
-        rb[j] = buf_ld4(rB, live ? voB[j] : OOB, so);
+        if constexpr (CV == 2) {
+          const unsigned m = (unsigned)(k0 + 4 * m4 + j);
+          const unsigned n = fdiv(m, g.cv.div_rhw), rem = m - n * (unsigned)(g.cv.RH * g.cv.RW);
+          const unsigned ry = fdiv(rem, g.cv.div_rw), rx = rem - ry * (unsigned)g.cv.RW;
+          const int y = (int)ry * g.cv.rs + g.cv.roy + g.cv.tdy[coltap], x = (int)rx * g.cv.rsx + g.cv.rox + g.cv.tdx[coltap];
+          const bool in = live && colokB && (unsigned)y < (unsigned)g.cv.IH && (unsigned)x < (unsigned)g.cv.IW;
+          const unsigned off = (unsigned)((((int)n * g.cv.IH + y) * g.cv.IW + x) * g.cv.ps + colch) * 4u;
+          rb[j] = buf_ld4(rB, in ? off : OOB, 0u);
+        } else {
+          rb[j] = buf_ld4(rB, live ? voB[j] : OOB, so);
+        }
         if (onesB) rb[j] = make_float4(live ? 1.f : 0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -395,10 +410,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 
   if (s_begin < s_end) {
-    load_a(s_begin); load_b(s_begin);
+    load_a(s_begin); reload(s_begin, 1); reload(s_begin, 2);
 #pragma unroll
     for (int k = 0; k < 16; ++k) micro(k);
-    if (s_begin + 1 < s_end) { load_a(s_begin + 1); load_b(s_begin + 1); }
+    if (s_begin + 1 < s_end) { load_a(s_begin + 1); reload(s_begin + 1, 1); reload(s_begin + 1, 2); }
     __syncthreads();
     auto slab = [&](int s, auto ST_, auto LD_) {
       constexpr bool ST = decltype(ST_)::value, LD = decltype(LD_)::value;
@@ -453,26 +468,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // k-major operands the x6t kernel can take: no row gather, 16-byte aligned rows, column counts in fours, below 2 GiB
-static bool gemm_x6t_ok(const GemmArgs& g) {
+static bool gemm_x6t_ok(const GemmArgs& g, bool im2col_b = false) {
   if (g.b_krows != nullptr || g.a_rows != nullptr || g.npairs != 1) return false;
-  if (g.lda[0] % 4 || g.ldb[0] % 4 || g.M % 4) return false;
+  if (g.lda[0] % 4 || g.M % 4 || (!im2col_b && g.ldb[0] % 4)) return false;
   if (g.ones_col >= 0 ? (g.ones_col % 4 != 0) : (g.N % 4 != 0)) return false;
   if (((uintptr_t)g.A[0] | (uintptr_t)g.B[0]) & 15) return false;
-  return (long long)g.Kc[0] * g.lda[0] < (1ll << 29) && (long long)g.Kc[0] * g.ldb[0] < (1ll << 29);
+  return (long long)g.Kc[0] * g.lda[0] < (1ll << 29) && (im2col_b || (long long)g.Kc[0] * g.ldb[0] < (1ll << 29));
+}
+// how much of its 128 x 128 tiles a weight-gradient product [M x N] fills (the launch policy wants >= 0.85)
+static double gemm_x6t_fill(int M, int N) {
+  return ((double)M / (cdiv(M, BM) * BM)) * ((double)N / (cdiv(N, 128) * 128));
 }
 
-template <int EPI>
+// split of the contraction (M_c rows) for the weight-gradient kernel: enough 128 x 128 tiles x slices to fill 512 block slots,
+// at least eight K-slabs per slice
+struct X6tSplit { int nz, ksplit; };
+static X6tSplit x6t_split(int Mc, int N, int Kp) {
+  const int slabs = cdiv(Mc, BK), tiles = cdiv(N, BM) * cdiv(Kp, 128);
+  int nz = std::max(1, std::min(512 / std::max(tiles, 1), slabs / 8));
+  const int ksplit = cdiv(slabs, nz);
+  nz = cdiv(slabs, ksplit);
+  return {nz, ksplit};
+}
+
+template <int EPI, int CV = 0>
 static int launch_gemm_x6t(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_x6t_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(128));
+    (void)hipFuncSetAttribute((const void*)gemm_x6t_kernel<EPI, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, x6_lds_bytes(128));
     attr_done = true;
   }
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, 128);
   g.dbg = 0;
   dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
-  gemm_x6t_kernel<EPI><<<grid, 256, x6_lds_bytes(128), stream>>>(g);
+  gemm_x6t_kernel<EPI, CV><<<grid, 256, x6_lds_bytes(128), stream>>>(g);
   return check_launch(what);
 }
 
