@@ -94,7 +94,9 @@ __global__ void cl_permute_dgrad_pair_kernel(const float* __restrict__ wh, const
 }
 
 static bool cl_patch_mode(const evae_conv_desc_t* d) { return d->C % 32 != 0 && d->C * d->KH * d->KW <= 64; }
-static int cl_patch_kp(const evae_conv_desc_t* d) { return (d->C * d->KH * d->KW + 31) / 32 * 32; }
+// columns of the patch matrix: the taps, padded to fours (the GEMM kernels mask a K tail; every padded column costs 4 bytes
+// of HBM per output pixel twice, written and read)
+static int cl_patch_kp(const evae_conv_desc_t* d) { return (d->C * d->KH * d->KW + 3) / 4 * 4; }
 // images per pass of the patch path: the patch matrix of a pass stays below 1 GiB
 static int cl_patch_images(const evae_conv_desc_t* d, int OH, int OW, int chan_out) {
   const int64_t lim = (int64_t)1 << 28;     // floats
@@ -223,7 +225,10 @@ static int cl_fwd_impl(const float* x, const evae_conv_desc_t* d, const float* w
       g.M = (int)npix; g.N = d->Co; g.bias0 = bh; g.bias1 = bg; g.ldo = d->Co;
       g.act = act; g.lo = act_lo; g.hi = act_hi; g.ksplit = 0;
       g.out0 = out + oo; g.out1 = save_h ? save_h + oo : nullptr; g.out2 = (gated && save_s) ? save_s + oo : nullptr;
-      if (gated) rc = launch_gemm_w<true, true, EPI_GATED, true, 128, 8>(g, 1, stream, "conv2d_cl_fwd(patches, gated)");
+      if (gated && gemm_x6_use(g, true)) rc = launch_gemm_x6<EPI_GATED, 0, 128>(g, 1, stream, "conv2d_cl_fwd(patches, gated, x6)");
+      else if (gated) rc = launch_gemm_w<true, true, EPI_GATED, true, 128, 8>(g, 1, stream, "conv2d_cl_fwd(patches, gated)");
+      else if (gemm_x6_use(g) && d->Co <= 64) rc = launch_gemm_x6<EPI_LINEAR, 0, 64>(g, 1, stream, "conv2d_cl_fwd(patches, x6)");
+      else if (gemm_x6_use(g)) rc = launch_gemm_x6<EPI_LINEAR, 0, 128>(g, 1, stream, "conv2d_cl_fwd(patches, x6)");
       else if (d->Co <= 64) rc = launch_gemm_w<true, true, EPI_LINEAR, true, 64, 8>(g, 1, stream, "conv2d_cl_fwd(patches)");
       else rc = launch_gemm_w<true, true, EPI_LINEAR, true, 128, 8>(g, 1, stream, "conv2d_cl_fwd(patches)");
       if (rc) return rc;
