@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "exemplar-vae_amd"))
 import torch
 from evae import ops, _lib
+if os.environ.get("EVAE_LIB_PATH"):
+    _lib.LIB_PATH = os.environ["EVAE_LIB_PATH"]
 lib = _lib.load(); p, st = ops._p, ops._stream
 torch.manual_seed(0)
 N, D, H, M = 50000, 784, 300, 25000
