@@ -144,6 +144,48 @@ def test_conv2d_channels_last_multi_pass(case, monkeypatch, gemm_pipe):
         assert rel(a, b) < 2e-6
 
 
+@pytest.mark.parametrize("gated,C,Co,k,s,p,H", [(True, 32, 64, 5, 1, 2, 14), (True, 64, 64, 3, 2, 1, 14), (False, 96, 96, 3, 1, 1, 16),
+                                                (True, 1, 32, 7, 1, 3, 28)])
+def test_conv_layers_at_step_size_take_the_bf16_pipe_by_default(gated, C, Co, k, s, p, H):
+    """The layer shapes of c3 / c5 over enough images that the DEFAULT launch policy picks the split-bf16 kernels (forward,
+    data gradient, and the weight gradient where its tiles are filled): against float64 autograd on the first images (a
+    convolution is independent per image) and against the fp32-MFMA kernels on the whole tensors."""
+    from evae import ops
+    N = 2200
+    rs = np.random.RandomState(C + Co)
+    x = torch.from_numpy(rs.standard_normal((N, C, H, H)).astype(np.float32)).cuda()
+    ws_ = [torch.from_numpy((rs.standard_normal((Co, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)).cuda() for _ in range(2)]
+    bs_ = [torch.from_numpy((rs.standard_normal(Co) * 0.1).astype(np.float32)).cuda() for _ in range(2)]
+    gout = None
+    res = []
+    for pipe in (1, 0):
+        ops.gemm_x6_configure(pipe, 2048)
+        try:
+            t = [a.clone().requires_grad_(True) for a in (x, ws_[0], bs_[0], ws_[1], bs_[1])]
+            y = ops.gated_conv2d(t[0], t[1], t[2], t[3], t[4], s, p) if gated else ops.conv2d(t[0], t[1], t[2], s, p)
+            if gout is None:
+                gout = torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32)).cuda()
+            y.backward(gout)
+            res.append([y.detach()] + [a.grad for a in (t[:5] if gated else t[:3])])
+        finally:
+            ops.gemm_x6_configure(1, 2048)
+    for a, b in zip(*res):
+        assert rel(a, b) < 8e-6          # two fp32-accurate kernels, each within ~3e-6 of float64 at K = 800
+    assert not torch.equal(res[0][0], res[1][0])                 # the two pipes round differently
+    # float64 reference on the first images: output and data gradient (weight gradients sum over all images: checked above
+    # against the fp32 kernel, which the small-shape tests pin to float64)
+    n = 3
+    xr = x[:n].double().cpu().requires_grad_(True)
+    w64 = [w.double().cpu() for w in ws_]; b64 = [b.double().cpu() for b in bs_]
+    yr = F.conv2d(xr, w64[0], b64[0], s, p)
+    if gated:
+        yr = yr * torch.sigmoid(F.conv2d(xr, w64[1], b64[1], s, p))
+    yr.backward(gout[:n].double().cpu())
+    assert rel(res[0][0][:n], yr) < 1e-5
+    if C > 1:
+        assert rel(res[0][1][:n], xr.grad) < 1e-5
+
+
 def test_conv2d_patch_matrix_layer_many_images():
     """First layer of models/fully_conv.py at cache_z scale (3 -> 48 channels, 64x64, stride 2, thousands of images):
     the patch matrix is built in passes whose size must agree between the workspace query and the launch
