@@ -383,13 +383,15 @@ extern "C" int evae_dense_bwd_weight_u8_images(int M, int N, int K, size_t* offs
   return EVAE_OK;
 }
 
-extern "C" int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long ldy, const unsigned char* x,
-                                        const int64_t* rows, int K, long long ldx, float x_scale, float* dw, float* db,
-                                        void* ws, size_t ws_bytes, evae_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+// phase 0: everything; 1: the pre-passes (byte gather-transpose, dy split / transposition) into the workspace; 2: the product and
+// its finish -- so that a caller can run the bandwidth-bound pre-passes on another stream, beside a matrix-bound launch
+static int dense_bwd_weight_u8_core(const float* dy, int M, int N, long long ldy, const unsigned char* x,
+                                    const int64_t* rows, int K, long long ldx, float x_scale, float* dw, float* db,
+                                    void* ws, size_t ws_bytes, int phase, hipStream_t stream) {
   EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldy >= N && ldx >= K, "dense_bwd_weight_u8: bad sizes M=%d N=%d K=%d", M, N, K);
   EVAE_REQUIRE(dw != nullptr, "dense_bwd_weight_u8: null dw");
   if (M == 0) {
+    if (phase == 1) return EVAE_OK;
     (void)hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), stream);
     if (db) (void)hipMemsetAsync(db, 0, (size_t)N * sizeof(float), stream);
     return check_launch("dense_bwd_weight_u8(empty)");
@@ -402,10 +404,13 @@ extern "C" int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long
   unsigned short* img = (unsigned short*)((char*)ws + L.img);
   float* part = (float*)((char*)ws + L.part);
   // the padding columns m >= M of xT (up to the slab boundary + slack) must be zero: they meet dy rows that do not exist
-  u8_gather_transpose_kernel<<<dim3(cdiv((int)L.ldt, 64), cdiv(K, 64)), 256, 0, stream>>>(x, rows, M, K, ldx, xT, L.ldt);
-  if (dy) u8_prepare_dyT_kernel<<<dim3(L.nslab, L.tiles_n), 256, 0, stream>>>(dy, M, N, ldy, L.nslab, img);
-  int rc = check_launch("u8 weight-gradient pre-passes");
-  if (rc) return rc;
+  int rc = EVAE_OK;
+  if (phase != 2) {
+    u8_gather_transpose_kernel<<<dim3(cdiv((int)L.ldt, 64), cdiv(K, 64)), 256, 0, stream>>>(x, rows, M, K, ldx, xT, L.ldt);
+    if (dy) u8_prepare_dyT_kernel<<<dim3(L.nslab, L.tiles_n), 256, 0, stream>>>(dy, M, N, ldy, L.nslab, img);
+    rc = check_launch("u8 weight-gradient pre-passes");
+    if (rc || phase == 1) return rc;
+  }
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)u8_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * U8_STAGE);
@@ -418,4 +423,17 @@ extern "C" int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long
   const size_t n = (size_t)(K + 1) * N;
   u8_wgrad_finish_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(part, L.nz, K, N, x_scale, dw, db);
   return check_launch("u8_wgrad_finish_kernel");
+}
+
+extern "C" int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long ldy, const unsigned char* x,
+                                        const int64_t* rows, int K, long long ldx, float x_scale, float* dw, float* db,
+                                        void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  return dense_bwd_weight_u8_core(dy, M, N, ldy, x, rows, K, ldx, x_scale, dw, db, ws, ws_bytes, 0, (hipStream_t)stream_);
+}
+
+extern "C" int evae_dense_bwd_weight_u8_phased(const float* dy, int M, int N, long long ldy, const unsigned char* x,
+                                               const int64_t* rows, int K, long long ldx, float x_scale, float* dw, float* db,
+                                               void* ws, size_t ws_bytes, int phase, evae_stream_t stream_) {
+  EVAE_REQUIRE(phase == 1 || phase == 2, "dense_bwd_weight_u8_phased: phase must be 1 or 2");
+  return dense_bwd_weight_u8_core(dy, M, N, ldy, x, rows, K, ldx, x_scale, dw, db, ws, ws_bytes, phase, (hipStream_t)stream_);
 }

@@ -39,7 +39,9 @@ _ZEROED = {}      # workspace name -> (address, shape) it was last zero-filled f
 # measured 0.7741 vs 0.7754 ms -- the 38 us pre-pass goes, but the epilogue's 8-byte scattered stores cost the GEMM +15 us and the
 # weight-gradient GEMM reads the images +11 us slower; kept as an option, off.  1 and 2 OFF: measured at config 2 (r02), 0 ->
 # 0.975 ms/step, 1 -> 1.002, 2 -> 1.085, 3 -> 1.076 -- a launch that runs beside a CU-filling GEMM costs that GEMM more than
-# the launch saves on the main stream.
+# the launch saves on the main stream.  8 = byte store: the two bandwidth-bound pre-passes of the first layer's weight gradient
+# (evae_dense_bwd_weight_u8_phased) on the side stream beside layer 2's weight-gradient GEMM: 0.772 / 0.800 ms vs 0.744 -- the same
+# lesson once more, off.
 SCHED = int(os.environ.get("EVAE_SCHED", "0"))
 
 PARAM_ORDER = [
@@ -492,6 +494,23 @@ class VaeExactLoss(torch.autograd.Function):
             with torch.cuda.stream(side):
                 side.wait_event(w2_done)
                 k.bwd_weight(*w2_args, phase=2, ws_name="wgrad2", finish_on=kd)
+        elif (SCHED & 8) and data_ext.dtype == torch.uint8:
+            # the bandwidth-bound pre-passes of the byte layer's weight gradient (gather-transpose of the rows, split and
+            # transposition of dy) on the side stream, beside layer 2's matrix-bound weight gradient
+            nb = lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D)
+            w = k.ws("wgrad_u8", nb)
+
+            def w1_phase(phase, st):
+                _lib.check(lib.evae_dense_bwd_weight_u8_phased(_vp(dq1), Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D, ldd, 1.0 / 255.0,
+                                                               _vp(g_w1), _vp(g_b1), _vp(w), w.numel(), phase, st), "bwd_weight_u8_phased")
+            dq1_ready = torch.cuda.Event(); dq1_ready.record()
+            with torch.cuda.stream(side):
+                side.wait_event(dq1_ready)
+                w1_phase(1, kd.st)
+                pre_done = torch.cuda.Event(); pre_done.record()
+            k.bwd_weight(*w2_args)
+            main.wait_event(pre_done)
+            w1_phase(2, k.st)
         else:
             k.bwd_weight(*w2_args)
             w1_grad()

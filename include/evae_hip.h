@@ -245,6 +245,11 @@ int evae_dense_bwd_data_img(const float* dy1, const float* w1, const float* dy2,
 int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long ldy, const unsigned char* x, const int64_t* rows,
                              int K, long long ldx, float x_scale, float* dw /* [N x K] */, float* db /* [N] or NULL */,
                              void* ws, size_t ws_bytes, evae_stream_t stream);
+/* The same in two calls that may go to different streams (the caller orders them with an event): phase 1 = the pre-passes
+ * into the workspace, phase 2 = the product and its finish. */
+int evae_dense_bwd_weight_u8_phased(const float* dy, int M, int N, long long ldy, const unsigned char* x, const int64_t* rows,
+                                    int K, long long ldx, float x_scale, float* dw, float* db, void* ws, size_t ws_bytes,
+                                    int phase, evae_stream_t stream);
 /* dh, dg: [M x N] with row stride ldo (the two halves of one [M x 2N] buffer when ldo = 2N) */
 int evae_gated_dense_bwd_input(const float* dout, const float* out, const float* s, int M, int N,
                                float* dh, float* dg, int ldo, evae_stream_t stream);
