@@ -187,7 +187,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = (tid >> 3) + 64 * i;
-        stage_chunk(Ep + h * NS * SLAB + sl * SLAB + st_off(row), load_chunk(Zs, q0 + h * 128 + row, B, sl));
+        float4 v = load_chunk(Zs, q0 + h * 128 + row, B, sl);
+        v.x *= kLog2e; v.y *= kLog2e; v.z *= kLog2e; v.w *= kLog2e;      // the products come out in base-2 units: exp2(t - max) directly
+        stage_chunk(Ep + h * NS * SLAB + sl * SLAB + st_off(row), v);
       }
   float4 rv[NS][2];
   auto load_tile = [&](int t) {
@@ -216,16 +218,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int sl = 0; sl < NS; ++sl)
 #pragma unroll
       for (int i = 0; i < 2; ++i) stage_chunk(Eb + sl * SLAB + st_off((tid >> 3) + 64 * i), rv[sl][i]);
-    if (tid < 128) hc_s[pb * 128 + tid] = (e0 + tid < C) ? 0.5f * cn[e0 + tid] : INFINITY;      // absent rows: t = -inf
+    if (tid < 128) hc_s[pb * 128 + tid] = (e0 + tid < C) ? (0.5f * kLog2e) * cn[e0 + tid] : INFINITY;   // absent rows: t = -inf
     __syncthreads();            // the tile is staged; the other buffer (read two tiles ago) is free for the next staging
     if (t + 1 < tile_end) load_tile(t + 1);
+    // the accumulators start at -log2(e) |c'|^2 / 2 of their row: the products then leave t2 = log2(e) (c'.z' - |c'|^2 / 2) and the
+    // epilogue is max, subtract, exp2, add per pair (subtract and add two pairs per instruction)
     f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const float h = -hc_s[pb * 128 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        acc[mt][0][r] = h; acc[mt][1][r] = h;
+      }
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -243,32 +248,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int nt = 0; nt < 2; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][PA[tt]], bq[ks][nt][PB[tt]], acc[mt][nt], 0, 0, 0);
     }
-    // online log-sum-exp over this tile's 64 rows of the wave, per query column
-    float hc[2][16];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hc[mt][r] = hc_s[pb * 128 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+    // online log-sum-exp (base 2) over this tile's 64 rows of the wave, per query column
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       float vmax = -INFINITY;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc[mt][nt][r] -= hc[mt][r];
-          vmax = fmaxf(vmax, acc[mt][nt][r]);
-        }
+        for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, acc[mt][nt][r]);
       if (vmax > tm_[nt]) {
-        ssum[nt] *= fast_exp2((tm_[nt] - vmax) * kLog2e);        // first tile: 0 * exp2(-inf) = 0
+        ssum[nt] *= fast_exp2(tm_[nt] - vmax);        // first tile: 0 * exp2(-inf) = 0
         tm_[nt] = vmax;
       }
       if (tm_[nt] != -INFINITY) {
-        const float mk = -tm_[nt] * kLog2e;
+        const x6_f32x2 mk = {tm_[nt], tm_[nt]};
+        x6_f32x2 part = {0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) ssum[nt] += fast_exp2(fmaf(acc[mt][nt][r], kLog2e, mk));
+          for (int r = 0; r < 16; r += 2) {
+            const x6_f32x2 v = {acc[mt][nt][r], acc[mt][nt][r + 1]};
+            const x6_f32x2 d = v - mk;
+            const x6_f32x2 e = {fast_exp2(d[0]), fast_exp2(d[1])};
+            part = part + e;
+          }
+        ssum[nt] += part[0] + part[1];
       }
     }
   }
@@ -277,8 +281,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int nt = 0; nt < 2; ++nt) {
     const float ot = __shfl_xor(tm_[nt], 32, 64), os = __shfl_xor(ssum[nt], 32, 64);
     const float mx = fmaxf(tm_[nt], ot);
-    const float fa_ = (tm_[nt] == mx) ? 1.f : fast_exp2((tm_[nt] - mx) * kLog2e);
-    const float fb_ = (ot == mx) ? 1.f : fast_exp2((ot - mx) * kLog2e);
+    const float fa_ = (tm_[nt] == mx) ? 1.f : fast_exp2(tm_[nt] - mx);
+    const float fb_ = (ot == mx) ? 1.f : fast_exp2(ot - mx);
     if (lh == 0) {
       float* cb = red + (wr * 256 + wc * 64 + nt * 32 + l31) * 2;
       cb[0] = mx; cb[1] = ssum[nt] * fa_ + os * fb_;
@@ -289,10 +293,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float t0 = red[tid * 2], t1 = red[(256 + tid) * 2];
     const float mx = fmaxf(t0, t1);
     float sacc = 0.f;
-    if (t0 != -INFINITY) sacc += red[tid * 2 + 1] * fast_exp2((t0 - mx) * kLog2e);
-    if (t1 != -INFINITY) sacc += red[(256 + tid) * 2 + 1] * fast_exp2((t1 - mx) * kLog2e);
+    if (t0 != -INFINITY) sacc += red[tid * 2 + 1] * fast_exp2(t0 - mx);
+    if (t1 != -INFINITY) sacc += red[(256 + tid) * 2 + 1] * fast_exp2(t1 - mx);
     const size_t o = (size_t)split * ldp + q0 + tid;
-    pm[o] = (mx == -INFINITY) ? -INFINITY : *cst_dev + (mx - 0.5f * zn[q0 + tid]);
+    pm[o] = (mx == -INFINITY) ? -INFINITY : *cst_dev + (mx * kLn2 - 0.5f * zn[q0 + tid]);      // back from base-2 units
     ps[o] = sacc;
     pn[o] = 0.f;
   }

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libevae_hip.so")
+# EVAE_LIB_PATH: another build of the same library (ablation builds of tools/, never a fallback: the file must exist)
+LIB_PATH = os.environ.get("EVAE_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libevae_hip.so")
 
 _p = C.c_void_p
 _i = C.c_int
