@@ -72,8 +72,13 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const evae_adam_tensor_t
   if (end > t.numel) end = t.numel;
   const float step_size = step_size_dev ? step_size_dev[0] : step_size_host;
   const int nparts = (int)((t.numel + chunk - 1) / chunk);
-  double tot = 0.0;                              // same order in every block: every block sees the same norm
-  for (int i = 0; i < nparts; ++i) tot += (double)part[blockIdx.y * ANB + i];
+  // the tensor's sum of squares from its <= ANB = 128 partials: two per lane and a wave butterfly -- the same order in every
+  // wave of every block, so every block sees the same norm (a serial walk over the partials was a 115-long dependent chain in
+  // front of 2048 elements of work)
+  const int lane = threadIdx.x & 63;
+  double tot = (lane < nparts ? (double)part[blockIdx.y * ANB + lane] : 0.0) +
+               (lane + 64 < nparts ? (double)part[blockIdx.y * ANB + lane + 64] : 0.0);
+  tot = wave_sum(tot);
   const float inv = 1.0f / ((float)sqrt(tot) + 1e-7f);
   const bool vec = ((reinterpret_cast<uintptr_t>(t.grad) | reinterpret_cast<uintptr_t>(t.param) |
                      reinterpret_cast<uintptr_t>(t.exp_avg) | reinterpret_cast<uintptr_t>(t.exp_avg_sq)) & 15) == 0;
