@@ -356,8 +356,11 @@ static U8WgradLayout u8_wgrad_layout(int M, int N, int K) {
   L.nslab = cdiv(M, U8_BK);
   L.ldt = (long long)L.nslab * U8_BK + 32;                  // 16-byte rows, slack for the last slab
   L.tiles_k = cdiv(K + 1, U8_BM); L.tiles_n = cdiv(N, 2 * U8_BN);
-  // split the contraction so that about two rounds of 512 resident blocks are in flight
-  int nz = cdiv(1024, L.tiles_k * L.tiles_n);
+  // split the contraction so that ONE round of 512 resident blocks is in flight: measured at 25 100 x 600 x 784 (entry point)
+  // 512 -> 163 us, 768 -> 179, 1024 -> 175, 1536 -> 187: every slice more is another [785 x 600] partial plane written and read
+  static int slots = -1;
+  if (slots < 0) { const char* e = getenv("EVAE_U8_WGRAD_SLOTS"); slots = e ? atoi(e) : 512; }
+  int nz = slots / (L.tiles_k * L.tiles_n);
   if (nz > L.nslab) nz = L.nslab;
   if (nz < 1) nz = 1;
   L.ksplit = cdiv(L.nslab, nz);
