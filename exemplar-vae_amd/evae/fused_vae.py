@@ -43,6 +43,7 @@ _ZEROED = {}      # workspace name -> (address, shape) it was last zero-filled f
 # (evae_dense_bwd_weight_u8_phased) on the side stream beside layer 2's weight-gradient GEMM: 0.772 / 0.800 ms vs 0.744 -- the same
 # lesson once more, off.
 SCHED = int(os.environ.get("EVAE_SCHED", "0"))
+THIN_ROWS = 1024     # batch rows up to here take the fp32 split-K kernel for the first layer even on the byte store
 
 PARAM_ORDER = [
     "prior_log_variance",
@@ -216,8 +217,13 @@ class VaeExactLoss(torch.autograd.Function):
         if Cl > 0 and not approx:
             l1_fwd(k, rows, Cl, 0)
         with torch.cuda.stream(side):
-            lv_row = plv.detach().expand(Z).contiguous()   # the prior's log-variance row
-            l1_fwd(kd, rows.data_ptr() + 8 * Cl, B, offb)
+            if u8 and B <= THIN_ROWS and not (SCHED & 32):
+                # a thin launch of the byte kernel walks its 25 K-slabs on five blocks (29 us alone, 66 us beside the exemplar
+                # GEMM); the batch is here as fp32 too (x = byte / 255), and the fp32 kernel splits K over the machine
+                kd.gated_fwd(x, None, B, D, x.stride(0), w1h, b1h, w1g, b1g, H, A1.data_ptr() + offb * H, None,
+                             s1.data_ptr() + offb * H)
+            else:
+                l1_fwd(kd, rows.data_ptr() + 8 * Cl, B, offb)
             kd.gated_fwd(A1.data_ptr() + offb * H, None, B, H, H, w2h, b2h, w2g, b2g, H,
                          A2.data_ptr() + offb * H, None, s2.data_ptr() + offb * H)
             kd.linear_fwd(A2b, B, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, z_mean, None)
@@ -248,6 +254,7 @@ class VaeExactLoss(torch.autograd.Function):
             k.linear_fwd(A2, Cl, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, mean_all, None)
         if approx:
             approx_cache.index_copy_(0, sel_rows, centres)       # repeats of a row carry identical encodings
+        lv_row = plv.detach().expand(Z).contiguous()       # the prior's log-variance row (main stream: off the batch-row chain)
         main.wait_event(z_ready)
         # ---- exemplar prior (leave-one-out mask in training unless no_mask; with its collectives when sharded) on the
         #      main stream ...
