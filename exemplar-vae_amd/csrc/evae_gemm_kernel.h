@@ -91,6 +91,7 @@ struct GemmArgs {
   // EPI_GATE_BWD_IMG: image base, K-slabs (of 32 rows) per column tile, row index of this launch's row 0 in the merged buffer
   unsigned short* img;
   int img_nslab, img_mbase;
+  int ldo2;                // EPI_DIST_TILEMIN: > 0 = tile minima stored query-major, out0[n * ldo2 + tile] (else out0[tile * ldo + n])
 };
 
 // Out-of-range chunks are loaded from a clamped, always-mapped address and zeroed LATER, when the
@@ -240,7 +241,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (m < g.M) {
-            const float d = g.e0[m] + bn - 2.0f * acc[mt][nt][r];
+            // e0 == nullptr: the x6 kernel left the row norms of its tile in LDS (evae_gemm_x6.h)
+            const float d = (g.e0 ? g.e0[m] : smem[512 + m - m0]) + bn - 2.0f * acc[mt][nt][r];
             if (EPI == EPI_DIST_TILEMIN && g.out1 && nok) g.out1[(size_t)m * g.ldo + n] = d;    // kept for the collect scan
             if (EPI == EPI_DIST_TILEMIN) tmin[nt] = fminf(tmin[nt], d);
             else if (nok && d <= thr) g.aux_cand[(size_t)n * g.ldo + atomicAdd(&g.aux_cnt[n], 1)] = m;
@@ -260,7 +262,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
         float v = red[threadIdx.x];
 #pragma unroll
         for (int w = 1; w < NW / 2; ++w) v = fminf(v, red[w * BN_ + threadIdx.x]);
-        g.out0[(size_t)tm * g.ldo + n0 + threadIdx.x] = v;
+        if (g.ldo2 > 0) g.out0[(size_t)(n0 + threadIdx.x) * g.ldo2 + tm] = v;
+        else g.out0[(size_t)tm * g.ldo + n0 + threadIdx.x] = v;
       }
     }
   } else if constexpr (EPI == EPI_PRIOR_LSE) {

@@ -51,10 +51,18 @@ __device__ __forceinline__ void x6_split2(float x, float y, unsigned& p0, unsign
   p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, x6_bf16x2));
 }
 
-template <int EPI, int CV, int BN_>
+// TM = terms per operand.  3: the fp32-accurate product above.  2 (the top-K screen only, whose distances are a filter with a
+// proven error bound, re-ranked exactly afterwards): a = a0 + a1, products a0 b0 + a0 b1 + a1 b0 -- half the MFMAs, two thirds
+// of the staging; what the split drops is <= 2^-15 |a b| per product (|a1 b1| <= 2^-16 |a b| dominates).
+// EPI_DIST_TILEMIN with g.e0 == nullptr: the squared norms of the A rows (the cache) are accumulated while their slabs are
+// staged (every row is staged exactly once by its block: no pass of its own over the cache), handed to the epilogue through
+// LDS, and their maximum goes to *(unsigned*)g.aux_cnt (bit pattern, atomicMax).
+template <int EPI, int CV, int BN_, int TM = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x6_kernel(const GemmArgs g) {
   constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
+  constexpr bool NORMS = (EPI == EPI_DIST_TILEMIN);
   static_assert(BN_ == 128 || (BN_ == 64 && !GATED), "column tile: 128, or 64 for narrow plain outputs");
+  static_assert(TM == 3 || (TM == 2 && BN_ == 128), "two-term products: 128-wide column tile only");
   constexpr int NW = 4, MT = 2, NT = BN_ / 64, GNT = 256, NV = 4, NVB = BN_ / 32;   // float4 chunks per thread: A 4, B 4 or 2
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -164,19 +172,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // staging of chunk q in three micro-steps that fit between two MFMAs each: split of the first pair, split of the second
   // pair, the three 8-byte LDS writes (after which the chunk's register is free for the slab after next)
   unsigned sp[6];
+  float nrm[NV] = {0.f, 0.f, 0.f, 0.f};   // NORMS: this thread's part of |row|^2 of its four A rows
   auto stage_part = [&](int q, int part) {
     const bool isb = q >= NV;
     const int i = isb ? q - NV : q;
     const float4 v = isb ? rb[i] : ra[i];
-    if (part == 0) x6_split2(v.x, v.y, sp[0], sp[1], sp[2]);
-    else if (part == 1) x6_split2(v.z, v.w, sp[3], sp[4], sp[5]);
-    else {
+    if (part == 0) {
+      x6_split2(v.x, v.y, sp[0], sp[1], sp[2]);
+      if constexpr (NORMS) { if (!isb) nrm[i] = fmaf(v.y, v.y, fmaf(v.x, v.x, nrm[i])); }
+    } else if (part == 1) {
+      x6_split2(v.z, v.w, sp[3], sp[4], sp[5]);
+      if constexpr (NORMS) { if (!isb) nrm[i] = fmaf(v.w, v.w, fmaf(v.z, v.z, nrm[i])); }
+    } else {
       char* p = lds + (isb ? 3 * X6_PLANE : 0) + st_off[i];
       const int ps = isb ? BN_ * 64 : X6_PLANE;                    // bytes between the planes of this operand
       x6_u32x2 t0 = {sp[0], sp[3]}, t1 = {sp[1], sp[4]}, t2 = {sp[2], sp[5]};
       *reinterpret_cast<x6_u32x2*>(p) = t0;
       *reinterpret_cast<x6_u32x2*>(p + ps) = t1;
-      *reinterpret_cast<x6_u32x2*>(p + 2 * ps) = t2;
+      if constexpr (TM == 3) *reinterpret_cast<x6_u32x2*>(p + 2 * ps) = t2;
     }
   };
   auto stage = [&](int q) { stage_part(q, 0); stage_part(q, 1); stage_part(q, 2); };
@@ -207,34 +220,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define EVAE_SB __builtin_amdgcn_sched_barrier(0)
     auto slab = [&](int s, auto ST_, auto LD_) {
       constexpr bool ST = decltype(ST_)::value, LD = decltype(LD_)::value;
-      x6_bf16x8 af[2][MT][3], bf[2][NT][3];
+      x6_bf16x8 af[2][MT][TM], bf[2][NT][TM];
 #pragma unroll
       for (int step = 0; step < 2; ++step) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) af[step][mt][p] = *reinterpret_cast<const x6_bf16x8*>(lds + fa[step][mt] + p * X6_PLANE);
+          for (int p = 0; p < TM; ++p) af[step][mt][p] = *reinterpret_cast<const x6_bf16x8*>(lds + fa[step][mt] + p * X6_PLANE);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bf[step][nt][p] = *reinterpret_cast<const x6_bf16x8*>(lds + fb[step][nt] + p * (BN_ * 64));
+          for (int p = 0; p < TM; ++p) bf[step][nt][p] = *reinterpret_cast<const x6_bf16x8*>(lds + fb[step][nt] + p * (BN_ * 64));
       }
       if constexpr (ST) __syncthreads();             // every wave holds its fragments: the planes may be overwritten
       __builtin_amdgcn_s_setprio(1);                 // the MFMA phase ahead of the other block's fragment reads
       // 48 MFMAs: term-major inside a k-step (four independent accumulators between two uses of one), smallest terms first.
       // Behind every second MFMA one micro-step of the staging of the next slab; the chunk's load for the slab after next
       // goes out right behind its LDS writes, a whole slab before it is needed.
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-      constexpr int SP = (12 * MT * NT) / (3 * (NV + NVB));        // MFMAs per micro-step: 48 / 24 = 2, or 24 / 18 = 1
+      constexpr int NP = TM == 3 ? 6 : 3;                          // partial products per element pair
+      constexpr int PA[6] = {TM == 3 ? 2 : 1, 0, TM == 3 ? 1 : 0, 1, 0, 0}, PB[6] = {0, TM == 3 ? 2 : 1, TM == 3 ? 1 : 0, 0, 1, 0};
+      constexpr int SP = (2 * NP * MT * NT) / (3 * (NV + NVB));    // MFMAs per micro-step: 48 / 24 = 2, 24 / 18 = 1, 24 / 24 = 1
 #pragma unroll
       for (int step = 0; step < 2; ++step)
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < NP; ++t)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-              const int j = ((step * 6 + t) * MT + mt) * NT + nt;          // 0 .. 12 MT NT - 1
+              const int j = ((step * NP + t) * MT + mt) * NT + nt;         // 0 .. 2 NP MT NT - 1
               EVAE_SB;
               if constexpr (!(X6_ABL & 2))
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[step][mt][PA[t]], bf[step][nt][PB[t]], acc[mt][nt], 0, 0, 0);
@@ -262,6 +276,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (s + 1 < s_end) { slab(s, T, F); ++s; }
     slab(s, F, F);
 #undef EVAE_SB
+  }
+  if constexpr (NORMS) {
+    if (g.e0 == nullptr) {
+      // the eight threads of a row (consecutive lanes) add up their parts; smem[512 + row] is beyond the epilogue's scratch
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        float t = nrm[i];
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+        if (c8 == 0) smem[512 + (tid >> 3) + 32 * i] = t;
+      }
+      __syncthreads();
+      if (tid < BM) {
+        float t = (m0 + tid < g.M) ? smem[512 + tid] : 0.f;
+        t = wave_max(t);
+        if (lane == 0 && t > 0.f) atomicMax(reinterpret_cast<unsigned*>(g.aux_cnt), __float_as_uint(t));
+      }
+    }
   }
   gemm_epilogue<EPI, BN_, NW, CV>(g, acc, m0, n0, tm, wr, wc, lane, smem);
 }
@@ -550,11 +581,11 @@ static int gemm_x6_pick_bn(int M, int N) {
   return eff(128) >= eff(64) ? 128 : 64;
 }
 
-template <int EPI, int CV = 0, int BN_ = 128>
+template <int EPI, int CV = 0, int BN_ = 128, int TM = 3>
 static int launch_gemm_x6(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_x6_kernel<EPI, CV, BN_>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)gemm_x6_kernel<EPI, CV, BN_, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               x6_lds_bytes(BN_));
     attr_done = true;
   }
@@ -563,7 +594,7 @@ static int launch_gemm_x6(GemmArgs& g, int nz, hipStream_t stream, const char* w
   g.tiles_n = cdiv(g.N, GATED ? 64 : BN_);
   g.dbg = 0;
   dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
-  gemm_x6_kernel<EPI, CV, BN_><<<grid, 256, x6_lds_bytes(BN_), stream>>>(g);
+  gemm_x6_kernel<EPI, CV, BN_, TM><<<grid, 256, x6_lds_bytes(BN_), stream>>>(g);
   return check_launch(what);
 }
 

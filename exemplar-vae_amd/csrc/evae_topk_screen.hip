@@ -73,11 +73,13 @@ __global__ __launch_bounds__(256) void sq_norms_kernel(const float* __restrict__
   }
 }
 
-// thr[n] = (k-th smallest of tmin[:, n]) + 2 gamma (qn[n] + cnmax); one wave per query.  Only the VALUE of the k-th smallest
-// tile minimum matters, so it is found by a bit-wise search over the order-preserving integer image of a float: 32 steps of
-// "how many minima lie below t" = a ballot + population count per register -- no cross-lane data movement at all (the k rounds
-// of wave-wide (value, tile) arg-min reductions this replaces cost 20 us).  The tile minima of a query sit in registers
-// (<= 16 per lane: up to 1024 tiles = 131 072 exemplars; longer caches are re-read in every step).
+// thr[n] = (k-th smallest tile minimum of query n) + 2 gamma (qn[n] + cnmax); one BLOCK per query, tmin query-major [B][ldt]
+// (ldt >= ntiles: contiguous loads).  Only the VALUE of the k-th smallest minimum matters, so it is found by a bit-wise search
+// over the order-preserving integer image of a float: 32 steps of "how many minima lie below t" = a ballot + population count
+// per register, the four waves' counts met through LDS (one barrier per step, counters double-buffered) -- no cross-lane data
+// movement (the k rounds of wave-wide (value, tile) arg-min reductions of r01 cost 20 us; one wave per query with 13 registers
+// of minima 16 us at 782 tiles).  A thread holds <= 4 minima (up to 1024 tiles = 131 072 exemplars); longer caches are
+// re-read in every step.
 __device__ __forceinline__ unsigned ordered_key(float f) {
   const unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -88,17 +90,18 @@ __device__ __forceinline__ float key_to_float(unsigned k) {
 __global__ __launch_bounds__(256) void kth_threshold_kernel(const float* __restrict__ tmin, int ntiles, int ldt, int B, int k,
                                                             const float* __restrict__ qn, const unsigned* __restrict__ cnmax_bits,
                                                             float gamma, float* __restrict__ thr) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (n >= B) return;
-  constexpr int TR = 16;
-  const bool in_regs = ntiles <= 64 * TR;
-  const int used = in_regs ? (ntiles + 63) / 64 : 0;            // registers that hold anything (wave-uniform)
+  __shared__ int cnt[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x;
+  constexpr int TR = 4;
+  const bool in_regs = ntiles <= 256 * TR;
+  const int used = in_regs ? (ntiles + 255) / 256 : 0;          // registers that hold anything (block-uniform)
+  const float* row = tmin + (size_t)n * ldt;
   unsigned key[TR];
 #pragma unroll
   for (int j = 0; j < TR; ++j) {
-    const int t = lane + 64 * j;
-    key[j] = (in_regs && t < ntiles) ? ordered_key(tmin[(size_t)t * ldt + n]) : 0xFFFFFFFFu;
+    const int t = threadIdx.x + 256 * j;
+    key[j] = (in_regs && t < ntiles) ? ordered_key(row[t]) : 0xFFFFFFFFu;
   }
   // the k-th smallest key = the largest t with #(key < t) <= k - 1 (fewer than k minima exist: the largest key, +inf's image)
   unsigned ans = 0u;
@@ -110,15 +113,19 @@ __global__ __launch_bounds__(256) void kth_threshold_kernel(const float* __restr
       for (int j = 0; j < TR; ++j)
         if (j < used) below += __popcll(__ballot(key[j] < t));
     } else {
-      for (int tt = lane; tt < ((ntiles + 63) & ~63); tt += 64)
-        below += __popcll(__ballot(tt < ntiles && ordered_key(tmin[(size_t)tt * ldt + n]) < t));
+      for (int tt = threadIdx.x; tt < ((ntiles + 255) & ~255); tt += 256)
+        below += __popcll(__ballot(tt < ntiles && ordered_key(row[tt]) < t));
     }
-    if (below <= k - 1) ans = t;
+    if (lane == 0) cnt[b & 1][wave] = below;
+    __syncthreads();
+    const int all = cnt[b & 1][0] + cnt[b & 1][1] + cnt[b & 1][2] + cnt[b & 1][3];
+    if (all <= k - 1) ans = t;
   }
-  if (lane == 0) thr[n] = key_to_float(ans) + 2.0f * gamma * (qn[n] + __uint_as_float(*cnmax_bits));
+  if (threadIdx.x == 0) thr[n] = key_to_float(ans) + 2.0f * gamma * (qn[n] + __uint_as_float(*cnmax_bits));
 }
 
 // exact re-ranking of one query's candidates: block = 256 threads
+constexpr int RANK_MAX = 1024;
 __global__ __launch_bounds__(256) void topk_exact_kernel(const float* __restrict__ q, const float* __restrict__ cache,
                                                          int zdim, int k, unsigned flags, int64_t index_base,
                                                          const int* __restrict__ cnt, const int* __restrict__ cand,
@@ -151,6 +158,30 @@ __global__ __launch_bounds__(256) void topk_exact_kernel(const float* __restrict
     vl[c] = v;
   }
   __syncthreads();
+  if (M <= RANK_MAX) {
+    // few candidates (the usual case: a few dozen): every candidate counts the (value, index) pairs in front of it -- the
+    // candidates of a query are distinct rows, so the pairs are totally ordered and rank j IS output slot j; no rounds, no
+    // barriers.  The values are the ones just stored by this block.
+    __shared__ float rv[RANK_MAX];
+    __shared__ int ri[RANK_MAX];
+    for (int c = threadIdx.x; c < M; c += 256) { rv[c] = vl[c]; ri[c] = cl[c]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < M; c += 256) {
+      const float v = rv[c];
+      const int id = ri[c];
+      int rank = 0;
+      for (int o = 0; o < M; ++o) rank += ((rv[o] < v) || (rv[o] == v && ri[o] < id)) ? 1 : 0;
+      if (rank < k) {
+        out_idx[(size_t)n * k + rank] = (int64_t)id + index_base;
+        if (out_val) out_val[(size_t)n * k + rank] = v;
+      }
+    }
+    for (int j = M + threadIdx.x; j < k; j += 256) {      // fewer candidates than k: as the rounds below would leave them
+      out_idx[(size_t)n * k + j] = (int64_t)-1;
+      if (out_val) out_val[(size_t)n * k + j] = INFINITY;
+    }
+    return;
+  }
   float lastv = -INFINITY;
   int lasti = -1;
   for (int j = 0; j < k; ++j) {
@@ -210,7 +241,7 @@ __global__ void zero_ints_kernel(int* p, int n, unsigned* q) {
 
 struct ScreenLayout {
   size_t cn, qn, cnmax, tmin, thr, cnt, cand, val, dist, total;
-  int ntiles, ldt;
+  int ntiles, ldt, ldm;      // ldt: row stride of the distances (queries, padded); ldm: of the query-major tile minima
 };
 static bool screen_applies(int B, int N, int zdim, int k) {
   static int off = -1;
@@ -227,7 +258,8 @@ static ScreenLayout screen_layout(int B, int N) {
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
   L.cn = take((size_t)N * 4); L.qn = take((size_t)L.ldt * 4); L.cnmax = take(256);
-  L.tmin = take((size_t)L.ntiles * L.ldt * 4); L.thr = take((size_t)L.ldt * 4); L.cnt = take((size_t)L.ldt * 4);
+  L.ldm = (L.ntiles + 63) / 64 * 64;
+  L.tmin = take((size_t)L.ldm * L.ldt * 4); L.thr = take((size_t)L.ldt * 4); L.cnt = take((size_t)L.ldt * 4);
   L.cand = take((size_t)B * N * 4); L.val = take((size_t)B * N * 4);
   L.dist = take((size_t)N * L.ldt * 4);        // approximate distances of the screening GEMM, scanned by the collect pass
   L.total = o + 256;
@@ -253,25 +285,37 @@ int topk_screen(const float* q, int B, const float* cache, int N, int zdim, int 
   // query norms first: that launch also clears the candidate counters and the running maximum of the cache norms
   const int rpb = zdim >= 128 ? 16 : 256;       // rows one block covers per sweep
   sq_norms_kernel<<<std::min(cdiv(B, rpb), 2048), 256, 0, stream>>>(q, B, zdim, qn, nullptr, cnt, L.ldt, cnmax);
-  sq_norms_kernel<<<std::min(cdiv(N, rpb), 1024), 256, 0, stream>>>(cache, N, zdim, cn, cnmax, nullptr, 0, nullptr);
-  int rc = check_launch("sq_norms_kernel");
-  if (rc) return rc;
   GemmArgs g = {};
   g.ones_col = -1;
   g.A[0] = cache; g.B[0] = q; g.lda[0] = zdim; g.ldb[0] = zdim; g.Kc[0] = zdim; g.npairs = 1;
   g.M = N; g.N = B; g.e0 = cn; g.e1 = qn; g.ksplit = 0;
   float* dist = (float*)(w + L.dist);
-  g.out0 = tmin; g.out1 = dist; g.ldo = L.ldt;
+  g.out0 = tmin; g.out1 = dist; g.ldo = L.ldt; g.ldo2 = L.ldm;
   // the screening product once, on the split-bf16 kernel when the launch fills the machine; its distances are kept
   const bool x6 = B > 64 && gemm_x6_use(g);
-  if (x6) rc = launch_gemm_x6<EPI_DIST_TILEMIN>(g, 1, stream, "topk_screen(tile minima, x6)");
-  else if (B <= 64) rc = launch_gemm_w<true, true, EPI_DIST_TILEMIN, true, 64, 8>(g, 1, stream, "topk_screen(tile minima)");
-  else rc = launch_gemm_w<true, true, EPI_DIST_TILEMIN, true, 128, 8>(g, 1, stream, "topk_screen(tile minima)");
+  int rc;
+  if (x6) {
+    // two-term products (a filter needs a bound, not fp32 accuracy), cache norms accumulated by the kernel while it stages
+    // the rows: no pass of its own over the cache
+    g.e0 = nullptr; g.aux_cnt = reinterpret_cast<int*>(cnmax);
+    rc = launch_gemm_x6<EPI_DIST_TILEMIN, 0, 128, 2>(g, 1, stream, "topk_screen(tile minima, split-bf16)");
+  } else {
+    sq_norms_kernel<<<std::min(cdiv(N, rpb), 1024), 256, 0, stream>>>(cache, N, zdim, cn, cnmax, nullptr, 0, nullptr);
+    rc = check_launch("sq_norms_kernel");
+    if (rc) return rc;
+    if (B <= 64) rc = launch_gemm_w<true, true, EPI_DIST_TILEMIN, true, 64, 8>(g, 1, stream, "topk_screen(tile minima)");
+    else rc = launch_gemm_w<true, true, EPI_DIST_TILEMIN, true, 128, 8>(g, 1, stream, "topk_screen(tile minima)");
+  }
   if (rc) return rc;
-  // error bound of one approximate distance: (2K + 3) roundings of magnitude <= u (|q|^2 + |c|^2), u = 2^-24, doubled; the
-  // split-bf16 product accumulates six partial products per element (6K + 3 roundings)
-  const float gamma = 2.0f * ((x6 ? 6.0f : 2.0f) * zdim + 3.0f) * 5.9604645e-08f;
-  kth_threshold_kernel<<<cdiv(B, 4), 256, 0, stream>>>(tmin, L.ntiles, L.ldt, B, k, qn, cnmax, gamma, thr);
+  // error bound of one approximate distance d = |q|^2 + |c|^2 - 2 q.c, in units of (|q|^2 + |c|^2), doubled for safety.
+  // fp32 kernel: K roundings in the norms, K in the product, 3 in the combination, each <= u = 2^-24.  Two-term split-bf16
+  // kernel: K in the norms, 3K accumulated partial products (each exact in fp32), 3 in the combination, plus what the split
+  // drops: with round-to-nearest terms |a1| <= 2^-8 |a| and |a - a0 - a1| <= 2^-17 |a|, so per product
+  // |a b - (a0 b0 + a0 b1 + a1 b0)| <= |a1 b1| + 2 * 2^-17 |a b| (1 + ...) <= 2^-15 |a b|; summed over k that is
+  // <= 2^-15 sum |q_k c_k| <= 2^-16 (|q|^2 + |c|^2), twice that in d.
+  const float u = 5.9604645e-08f;
+  const float gamma = x6 ? 2.0f * ((4.0f * zdim + 3.0f) * u + 3.0517578e-05f) : 2.0f * (2.0f * zdim + 3.0f) * u;
+  kth_threshold_kernel<<<B, 256, 0, stream>>>(tmin, L.ntiles, L.ldm, B, k, qn, cnmax, gamma, thr);
   rc = check_launch("kth_threshold_kernel");
   if (rc) return rc;
   dist_collect_kernel<<<(unsigned)std::min<size_t>(((size_t)N * (L.ldt / 4) + 255) / 256, 8192), 256, 0, stream>>>(

@@ -283,14 +283,20 @@ def test_topk_small_and_ragged(ops, B, N, zd, k):
     assert np.array_equal(val.cpu().numpy(), ov)
 
 
-@pytest.mark.parametrize("B,N,zd,k,sqrt", [(64, 100000, 256, 10, False), (100, 25000, 40, 10, False), (37, 5000, 24, 64, True),
-                                          (130, 4099, 40, 7, False), (3, 2048, 8, 16, False)])
-def test_topk_screening_path_equals_exact_scan(ops, B, N, zd, k, sqrt):
+@pytest.mark.parametrize("B,N,zd,k,sqrt,offset", [(64, 100000, 256, 10, False, 0.0), (100, 25000, 40, 10, False, 0.0),
+                                                 (37, 5000, 24, 64, True, 0.0), (130, 4099, 40, 7, False, 0.0),
+                                                 (3, 2048, 8, 16, False, 0.0),
+                                                 # B > 64 over >= 384 tiles: the two-term split-bf16 screen with fused cache norms
+                                                 (100, 100000, 256, 10, False, 0.0), (128, 60000, 64, 10, True, 0.0),
+                                                 (100, 100000, 256, 10, False, 3.0), (77, 50001 // 4 * 4, 48, 5, False, -8.0)])
+def test_topk_screening_path_equals_exact_scan(ops, B, N, zd, k, sqrt, offset):
     """Large caches take the matrix-core screening + exact re-ranking path; it must return the very same indices and
     values as the exact fp64 scan kernel (forced with EVAE_TOPK_EXACT_SCAN=1 in a child process), including on
-    duplicated exemplars (ties broken by index) and clustered data."""
+    duplicated exemplars (ties broken by index), clustered data, and latents with a common offset (norms far larger than
+    the distances: the screen's error bound is what keeps the candidate set complete)."""
     import subprocess, sys, tempfile
     z, c = gi.clustered_latents(300 + B + N, B, N, zd)
+    z = (z + np.float32(offset)).astype(np.float32); c = (c + np.float32(offset)).astype(np.float32)
     c[N // 2:N // 2 + 50] = c[:50]                    # exact duplicates -> ties
     c[-7:] = z[:7] if B >= 7 else c[-7:]              # zero-distance hits at the very end of the cache
     idx, val = ops.pairdist_topk(dev(z), dev(c), k, sqrt=sqrt)
