@@ -188,15 +188,19 @@ __global__ __launch_bounds__(U8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   if constexpr (GATED) {
     const int n = n0 + wc * 32 + l31;           // output column; cb = 0: h, 1: g
     if (n < N) {
-      const float vbh = bh ? bh[n] : 0.f, vbg = bg ? bg[n] : 0.f;
+      float vbh = bh ? bh[n] : 0.f, vbg = bg ? bg[n] : 0.f;
+      asm volatile("" : "+v"(vbh));        // the wait for the two loads here, not in front of every guarded row's stores
+      asm volatile("" : "+v"(vbg));
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          // values outside the row guard, stores inside: a guarded FIRST use of the bias loads makes the compiler put a full
+          // s_waitcnt vmcnt(0) -- every store in flight included -- in front of each row's stores (evae_gemm_kernel.h)
+          const float h = fmaf(acc[mt][0][r], x_scale, vbh);
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * fmaf(acc[mt][1][r], x_scale, vbg)));
           if (m < M) {
-            const float h = fmaf(acc[mt][0][r], x_scale, vbh);
-            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * fmaf(acc[mt][1][r], x_scale, vbg)));
             const size_t o = (size_t)m * N + n;
             out[o] = h * sg;
             if (save_s) save_s[o] = sg;

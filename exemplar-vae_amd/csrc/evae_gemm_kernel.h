@@ -94,6 +94,13 @@ struct GemmArgs {
   int ldo2;                // EPI_DIST_TILEMIN: > 0 = tile minima stored query-major, out0[n * ldo2 + tile] (else out0[tile * ldo + n])
 };
 
+// "This loaded value is needed HERE": an empty asm that takes the register in and out, so the compiler places the wait for
+// its load at this point, in code every lane's path runs through.  Used in front of epilogue store loops whose rows are
+// guarded (m < M): left alone, the compiler sinks the first use of a loaded bias into the guarded blocks and, not knowing
+// whether an earlier guarded block already waited, puts a full s_waitcnt vmcnt(0) in front of every row's stores -- loads
+// and stores share vmcnt, so each row then waits for all stores in flight (measured: 10-13 us of a 17 us launch).
+#define EVAE_PIN(x) asm volatile("" : "+v"(x))
+
 // Out-of-range chunks are loaded from a clamped, always-mapped address and zeroed LATER, when the
 // prefetched registers are written to LDS: masking right after the load would make the compiler wait
 // for the prefetch before the MFMAs it is meant to overlap.
@@ -227,12 +234,37 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
   };
   if constexpr (EPI == EPI_DIST_TILEMIN || EPI == EPI_DIST_COLLECT) {
     // e0 = squared norms of the A rows, e1 = of the B rows; acc = dot products
+    // The row norms go into registers BEFORE the first store: a load behind a store waits for every store in flight
+    // (loads and stores share vmcnt and return in order), which serialised the 64 stores of a lane at one round trip
+    // each (measured: 10-13 us of a 17 us launch).  e0 == nullptr: the x6 kernel left the norms of its tile in LDS
+    // (evae_gemm_x6.h); two separate loops so that neither becomes a flat load.
+    float e0v[MT][16];
+    if (g.e0 != nullptr) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          e0v[mt][r] = m < g.M ? g.e0[m] : 0.f;
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e0v[mt][r] = smem[512 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+    }
+    float bnv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      bnv[nt] = n < g.N ? g.e1[n] : 0.f;
+    }
     float tmin[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = n0 + wc * 32 * NT + nt * 32 + l31;
       const bool nok = n < g.N;
-      const float bn = nok ? g.e1[n] : 0.f;
+      const float bn = bnv[nt];
       const float thr = (EPI == EPI_DIST_COLLECT && nok) ? g.bias0[n] : -INFINITY;
       tmin[nt] = INFINITY;
 #pragma unroll
@@ -240,12 +272,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < g.M) {
-            // e0 == nullptr: the x6 kernel left the row norms of its tile in LDS (evae_gemm_x6.h)
-            const float d = (g.e0 ? g.e0[m] : smem[512 + m - m0]) + bn - 2.0f * acc[mt][nt][r];
-            if (EPI == EPI_DIST_TILEMIN && g.out1 && nok) g.out1[(size_t)m * g.ldo + n] = d;    // kept for the collect scan
-            if (EPI == EPI_DIST_TILEMIN) tmin[nt] = fminf(tmin[nt], d);
-            else if (nok && d <= thr) g.aux_cand[(size_t)n * g.ldo + atomicAdd(&g.aux_cnt[n], 1)] = m;
+          // d is formed outside the row guard: the (single) wait for the preloaded norms then sits in code every path runs
+          // through -- inside the guard the compiler repeats a full vmcnt(0) in every guarded block, stores included
+          const bool mok = m < g.M;
+          const float d = e0v[mt][r] + bn - 2.0f * acc[mt][nt][r];
+          if (EPI == EPI_DIST_TILEMIN) {
+            if (g.out1 && nok && mok) g.out1[(size_t)m * g.ldo + n] = d;    // kept for the collect scan
+            tmin[nt] = fminf(tmin[nt], mok ? d : INFINITY);
+          } else if (mok && nok && d <= thr) {
+            g.aux_cand[(size_t)n * g.ldo + atomicAdd(&g.aux_cnt[n], 1)] = m;
           }
         }
     }
@@ -340,48 +375,80 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
     // Columns N <= n < ldo (padding up to a multiple of 4) are written as zeros: P is the operand of two more GEMMs.
     const bool masked = g.pr_ridx != nullptr && g.pr_cidx != nullptr;
     const float cst = *g.pr_cst_dev;
+    // Everything the rows need is loaded (and pinned) before the first store: a load between the stores waits for every
+    // store in flight (shared vmcnt), which ran the stores of a lane one round trip at a time.
+    float e0v[MT][16];
+    long long ri[MT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool mok = m < g.M;
+        e0v[mt][r] = mok ? g.e0[m] : 0.f;
+        ri[mt][r] = (masked && mok) ? (long long)g.pr_ridx[m] : -2;
+      }
+    float zn[NT], gq[NT], kq[NT];
+    long long zi[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wc * 32 * NT + nt * 32 + l31;
+      const bool nok = n < g.N;
+      zn[nt] = nok ? g.e1[n] : 0.f;
+      gq[nt] = nok ? g.bias1[n] : 0.f;
+      kq[nt] = nok ? (cst - g.bias0[n]) * kLog2e : 0.f;
+      zi[nt] = (masked && nok) ? (long long)g.pr_cidx[n] : -1;
+      EVAE_PIN(zn[nt]); EVAE_PIN(gq[nt]); EVAE_PIN(kq[nt]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) EVAE_PIN(e0v[mt][r]);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = n0 + wc * 32 * NT + nt * 32 + l31;
       if (n >= g.ldo) continue;
       const bool nok = n < g.N;
-      const float zn = nok ? g.e1[n] : 0.f;
-      const float gq = nok ? g.bias1[n] : 0.f;
-      const float kq = nok ? (cst - g.bias0[n]) * kLog2e : 0.f;
-      const long long zi = (masked && nok) ? (long long)g.pr_cidx[n] : -1;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m >= g.M) continue;
-          const float d = fmaxf(g.e0[m] + zn - 2.0f * acc[mt][nt][r], 0.f);
+          const float d = fmaxf(e0v[mt][r] + zn[nt] - 2.0f * acc[mt][nt][r], 0.f);
           bool ok = nok;
-          if (masked) ok = ok && ((long long)g.pr_ridx[m] != zi) && ((long long)g.pr_ridx[m] != (long long)EVAE_PRIOR_MASK_ALL);
-          g.out0[(size_t)m * g.ldo + n] = ok ? gq * fast_exp2(kq - d * (0.5f * kLog2e)) : 0.f;
+          if (masked) ok = ok && (ri[mt][r] != zi[nt]) && (ri[mt][r] != (long long)EVAE_PRIOR_MASK_ALL);
+          const float pv = ok ? gq[nt] * fast_exp2(kq[nt] - d * (0.5f * kLog2e)) : 0.f;
+          if (m < g.M) g.out0[(size_t)m * g.ldo + n] = pv;
         }
     }
   } else if (GATED) {
     const int n = n0 + wc * 32 + l31;
     if (n < g.N) {
-      const float bh = (EPI == EPI_GATED && g.bias0) ? g.bias0[n] : 0.f;
-      const float bg = (EPI == EPI_GATED && g.bias1) ? g.bias1[n] : 0.f;
+      float bh = (EPI == EPI_GATED && g.bias0) ? g.bias0[n] : 0.f;
+      float bg = (EPI == EPI_GATED && g.bias1) ? g.bias1[n] : 0.f;
+      EVAE_PIN(bh); EVAE_PIN(bg);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < g.M) {
-            if (EPI == EPI_GATED) {
-              const float h = acc[mt][0][r] + bh;
-              // sigmoid on the hardware exp2 / rcp (about 1e-7 relative): the precise expf costs ~15 VALU instructions
-              // per element, and VALU issue is what the co-resident block's MFMAs wait on
-              const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc[mt][NT - 1][r] + bg)));
+          if (EPI == EPI_GATED) {
+            // The values are formed OUTSIDE the row guard: the wait for the bias loads then sits once, in code every path
+            // runs through.  Inside the guard the compiler cannot know whether an earlier guarded block already waited and
+            // puts a full s_waitcnt vmcnt(0) -- which also waits for every store in flight -- in front of each row's
+            // stores: 32 store round trips in a row per lane (measured on the top-K epilogue: 10-13 us of a block's life).
+            const float h = acc[mt][0][r] + bh;
+            // sigmoid on the hardware exp2 / rcp (about 1e-7 relative): the precise expf costs ~15 VALU instructions
+            // per element, and VALU issue is what the co-resident block's MFMAs wait on
+            const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc[mt][NT - 1][r] + bg)));
+            if (m < g.M) {
               const size_t o = orow(m) * g.ldo + n;
               g.out0[o] = h * s;
               if (g.out1) g.out1[o] = h;
               if (g.out2) g.out2[o] = s;
-            } else {   // EPI_RAW_GATED: partial planes [z][2][M][N]
+            }
+          } else if (m < g.M) {
+            {          // EPI_RAW_GATED: partial planes [z][2][M][N]
               const size_t plane = (size_t)g.M * g.N;
               const size_t o = (size_t)blockIdx.z * 2 * plane + (size_t)m * g.N + n;
               g.out0[o] = acc[mt][0][r];
@@ -479,42 +546,53 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
     for (int nt = 0; nt < NT; ++nt) {
       const int n = n0 + wc * 32 * NT + nt * 32 + l31;
       if (n >= g.N) continue;
-      const float bias = (EPI == EPI_LINEAR && g.bias0) ? g.bias0[n] : 0.f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        // residual blocks of fully_conv (models/fully_conv.py:13-23: x + conv(ELU(x))): e1 = ELU(x) of the block whose data
-        // gradient this is -> times ELU'(x) = (a > 0 ? 1 : a + 1); e0 = the tensor added to the result (x forward, dy
-        // backward).  Both are fetched for the whole 32-row tile BEFORE the first store: stores to out0 may alias them as far
-        // as the compiler knows, so loads placed between the stores would run one at a time.
-        float ev0[16], ev1[16];
-        const bool extras = EPI == EPI_LINEAR && (g.e0 || g.e1);
-        if (extras) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const bool ok = m < g.M;
-            const size_t o = orow(ok ? m : m0) * g.ldo + n;
-            ev0[r] = (ok && g.e0) ? g.e0[o] : 0.f;
-            ev1[r] = (ok && g.e1) ? g.e1[o] : 1.f;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m >= g.M) continue;
+      float bias = (EPI == EPI_LINEAR && g.bias0) ? g.bias0[n] : 0.f;
+      EVAE_PIN(bias);
+      const bool extras = EPI == EPI_LINEAR && (g.e0 || g.e1);
+      auto put = [&](int mt, int r, float a0, float a1) {      // one element: row guard around the stores only
+        const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= g.M) return;
+        const float v = acc[mt][nt][r];
+        if (EPI == EPI_LINEAR) {
           const size_t o = orow(m) * g.ldo + n;
-          const float v = acc[mt][nt][r];
-          if (EPI == EPI_LINEAR) {
-            const float pre = v + bias;
-            if (g.out1) g.out1[o] = pre;
-            float res = apply_act(pre, g.act, g.lo, g.hi);
-            if (extras) res = res * (ev1[r] > 0.f ? 1.0f : ev1[r] + 1.0f) + ev0[r];
-            g.out0[o] = res;
-          } else {                                // EPI_RAW: partial plane [z][M][N]
-            g.out0[(size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n] = v;
-          }
+          const float pre = v + bias;
+          if (g.out1) g.out1[o] = pre;
+          float res = apply_act(pre, g.act, g.lo, g.hi);
+          if (extras) res = res * (a1 > 0.f ? 1.0f : a1 + 1.0f) + a0;
+          g.out0[o] = res;
+        } else {                                // EPI_RAW: partial plane [z][M][N]
+          g.out0[(size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n] = v;
         }
-      }
+      };
+      // residual blocks of fully_conv (models/fully_conv.py:13-23: x + conv(ELU(x))): e1 = ELU(x) of the block whose data
+      // gradient this is -> times ELU'(x) = (a > 0 ? 1 : a + 1); e0 = the tensor added to the result (x forward, dy
+      // backward).  Eight rows at a time: their sixteen values are fetched and PINNED before the first of their stores
+      // (stores to out0 may alias them as far as the compiler knows, and a wait placed inside a row guard is a full
+      // vmcnt(0), stores included).  One code path: without extras the pins have nothing to wait for but the stores of the
+      // eight rows before -- two waits per sixteen rows instead of sixteen.
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float ev0[8], ev1[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { ev0[i] = 0.f; ev1[i] = 1.f; }
+          if (extras) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int r = 8 * half + i;
+              const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              const bool ok = m < g.M;
+              const size_t o = orow(ok ? m : m0) * g.ldo + n;
+              if (ok && g.e0) ev0[i] = g.e0[o];
+              if (ok && g.e1) ev1[i] = g.e1[o];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { EVAE_PIN(ev0[i]); EVAE_PIN(ev1[i]); }
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) put(mt, 8 * half + i, ev0[i], ev1[i]);
+        }
     }
   }
 }
