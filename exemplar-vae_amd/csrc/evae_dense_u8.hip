@@ -391,14 +391,16 @@ extern "C" int evae_dense_bwd_weight_u8_images(int M, int N, int K, size_t* offs
 }
 
 // phase 0: everything; 1: the pre-passes (byte gather-transpose, dy split / transposition) into the workspace; 2: the product and
-// its finish -- so that a caller can run the bandwidth-bound pre-passes on another stream, beside a matrix-bound launch
+// its finish -- so that a caller can run the bandwidth-bound pre-passes on another stream, beside a matrix-bound launch;
+// 3: the byte gather-transpose alone (it needs the gather list only, not dy: a training step can issue it during its forward
+// pass); 4: everything but the gather-transpose (the workspace holds it)
 static int dense_bwd_weight_u8_core(const float* dy, int M, int N, long long ldy, const unsigned char* x,
                                     const int64_t* rows, int K, long long ldx, float x_scale, float* dw, float* db,
                                     void* ws, size_t ws_bytes, int phase, hipStream_t stream) {
   EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldy >= N && ldx >= K, "dense_bwd_weight_u8: bad sizes M=%d N=%d K=%d", M, N, K);
-  EVAE_REQUIRE(dw != nullptr, "dense_bwd_weight_u8: null dw");
+  EVAE_REQUIRE(dw != nullptr || phase == 3, "dense_bwd_weight_u8: null dw");
   if (M == 0) {
-    if (phase == 1) return EVAE_OK;
+    if (phase == 1 || phase == 3) return EVAE_OK;
     (void)hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), stream);
     if (db) (void)hipMemsetAsync(db, 0, (size_t)N * sizeof(float), stream);
     return check_launch("dense_bwd_weight_u8(empty)");
@@ -413,10 +415,10 @@ static int dense_bwd_weight_u8_core(const float* dy, int M, int N, long long ldy
   // the padding columns m >= M of xT (up to the slab boundary + slack) must be zero: they meet dy rows that do not exist
   int rc = EVAE_OK;
   if (phase != 2) {
-    u8_gather_transpose_kernel<<<dim3(cdiv((int)L.ldt, 64), cdiv(K, 64)), 256, 0, stream>>>(x, rows, M, K, ldx, xT, L.ldt);
-    if (dy) u8_prepare_dyT_kernel<<<dim3(L.nslab, L.tiles_n), 256, 0, stream>>>(dy, M, N, ldy, L.nslab, img);
+    if (phase != 4) u8_gather_transpose_kernel<<<dim3(cdiv((int)L.ldt, 64), cdiv(K, 64)), 256, 0, stream>>>(x, rows, M, K, ldx, xT, L.ldt);
+    if (dy && phase != 3) u8_prepare_dyT_kernel<<<dim3(L.nslab, L.tiles_n), 256, 0, stream>>>(dy, M, N, ldy, L.nslab, img);
     rc = check_launch("u8 weight-gradient pre-passes");
-    if (rc || phase == 1) return rc;
+    if (rc || phase == 1 || phase == 3) return rc;
   }
   static bool attr = false;
   if (!attr) {
@@ -441,6 +443,6 @@ extern "C" int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long
 extern "C" int evae_dense_bwd_weight_u8_phased(const float* dy, int M, int N, long long ldy, const unsigned char* x,
                                                const int64_t* rows, int K, long long ldx, float x_scale, float* dw, float* db,
                                                void* ws, size_t ws_bytes, int phase, evae_stream_t stream_) {
-  EVAE_REQUIRE(phase == 1 || phase == 2, "dense_bwd_weight_u8_phased: phase must be 1 or 2");
+  EVAE_REQUIRE(phase >= 1 && phase <= 4, "dense_bwd_weight_u8_phased: phase must be 1 .. 4");
   return dense_bwd_weight_u8_core(dy, M, N, ldy, x, rows, K, ldx, x_scale, dw, db, ws, ws_bytes, phase, (hipStream_t)stream_);
 }

@@ -31,6 +31,7 @@ ACT_NONE, ACT_SIGMOID, ACT_HARDTANH = ops.ACT_NONE, ops.ACT_SIGMOID, ops.ACT_HAR
 # generation of the staging rows behind a dataset buffer (keyed by its address): a second fused forward overwrites the rows a
 # pending backward would gather its batch from -- the backward checks that its forward was the last one to stage
 _STAGE_GEN = {}
+_XT_GEN = {}       # workspace pointer -> generation of the transposed byte rows the forward pass left there
 _ZEROED = {}      # workspace name -> (address, shape) it was last zero-filled for
 
 # schedule switches (bit mask; tools/chain_bench.sh sweeps them): 1 = the prior's dz' / dlogvar reduction on the side stream,
@@ -216,7 +217,16 @@ class VaeExactLoss(torch.autograd.Function):
                              s1.data_ptr() + o * H)
         if Cl > 0 and not approx:
             l1_fwd(k, rows, Cl, 0)
+        xt_early = bool(u8 and not approx and not (SCHED & 64))
         with torch.cuda.stream(side):
+            if xt_early:
+                # the byte layer's weight gradient wants the gathered rows transposed (pixel-major): that needs the gather list
+                # only, so it runs here, beside the exemplar encoder (which reads the same bytes), instead of in the backward's
+                # chain of launches
+                wq = k.ws("wgrad_u8", lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D))
+                xt_gen = _XT_GEN[wq.data_ptr()] = _XT_GEN.get(wq.data_ptr(), 0) + 1
+                _lib.check(lib.evae_dense_bwd_weight_u8_phased(None, Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D, ldd, 1.0 / 255.0,
+                                                               None, None, _vp(wq), wq.numel(), 3, kd.st), "bwd_weight_u8(gather)")
             if u8 and B <= THIN_ROWS and not (SCHED & 32):
                 # a thin launch of the byte kernel walks its 25 K-slabs on five blocks (29 us alone, 66 us beside the exemplar
                 # GEMM); the batch is here as fp32 too (x = byte / 255), and the fp32 kernel splits K over the machine
@@ -301,6 +311,7 @@ class VaeExactLoss(torch.autograd.Function):
         ctx.dims = (B, D, H, Z, Cl, Mp, ldd, beta, int(sharded))
         ctx.dp = (z_all, zi_all)
         ctx.stage_gen = gen
+        ctx.xt = (wq.data_ptr(), xt_gen) if xt_early else None
         ctx.bufs = (x, rows, data_ext, A1, s1, A2, s2, mean_all, logvar, lv_pre, z, D1, sd1, D2, sd2,
                     xmean, lv_row, zi, ci, lse, eps)
         ctx.save_for_backward(*params)
@@ -487,10 +498,15 @@ class VaeExactLoss(torch.autograd.Function):
                 nb = lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D)
                 w = k.ws("wgrad_u8", nb)
                 fl = 2.0 * Mp * 2 * H * D
+                # the forward pass left the transposed byte rows in the workspace (unless another step used it since)
+                have_xt = ctx.xt is not None and ctx.xt == (w.data_ptr(), _XT_GEN.get(w.data_ptr()))
                 ops.probed("dense_bwd_weight_u8 M=%d N=%d K=%d (uint8 rows, three bf16 terms; pre-passes + GEMM + finish)" % (Mp, 2 * H, D),
-                           fl, lambda: _lib.check(lib.evae_dense_bwd_weight_u8(_vp(dq1), Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D,
-                                                                               ldd, 1.0 / 255.0, _vp(g_w1), _vp(g_b1), _vp(w),
-                                                                               w.numel(), k.st), "bwd_weight_u8"),
+                           fl, lambda: _lib.check(lib.evae_dense_bwd_weight_u8_phased(_vp(dq1), Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D,
+                                                                                      ldd, 1.0 / 255.0, _vp(g_w1), _vp(g_b1), _vp(w),
+                                                                                      w.numel(), 4, k.st) if have_xt else
+                                              lib.evae_dense_bwd_weight_u8(_vp(dq1), Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D,
+                                                                           ldd, 1.0 / 255.0, _vp(g_w1), _vp(g_b1), _vp(w),
+                                                                           w.numel(), k.st), "bwd_weight_u8"),
                            executed=3 * fl, pipe="bf16-mfma")
             else:
                 k.bwd_weight(dq1, Mp, 2 * H, 2 * H, data_ext, rows, D, ldd, g_w1, g_b1)

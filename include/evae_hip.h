@@ -246,7 +246,8 @@ int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long ldy, const
                              int K, long long ldx, float x_scale, float* dw /* [N x K] */, float* db /* [N] or NULL */,
                              void* ws, size_t ws_bytes, evae_stream_t stream);
 /* The same in two calls that may go to different streams (the caller orders them with an event): phase 1 = the pre-passes
- * into the workspace, phase 2 = the product and its finish. */
+ * into the workspace, phase 2 = the product and its finish; or phase 3 = the byte gather-transpose alone (needs x / rows only,
+ * dy and dw may be NULL: a training step issues it during its forward pass), phase 4 = everything else. */
 int evae_dense_bwd_weight_u8_phased(const float* dy, int M, int N, long long ldy, const unsigned char* x, const int64_t* rows,
                                     int K, long long ldx, float x_scale, float* dw, float* db, void* ws, size_t ws_bytes,
                                     int phase, evae_stream_t stream);

@@ -771,6 +771,32 @@ def test_weight_gradient_on_the_uint8_store(ops, M, K, N, R):
     assert rel(dw.cpu().numpy(), dw32.cpu().numpy()) < 2e-6
 
 
+def test_weight_gradient_on_the_uint8_store_in_phases(ops):
+    """phase 3 (byte gather-transpose alone: what a training step issues during its forward pass, dy not yet known) followed
+    by phase 4 (everything else) = the one-call weight gradient, bit for bit; likewise phases 1 + 2."""
+    from evae import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(5)
+    M, K, N, R = 1100, 784, 600, 3000
+    q = (rs.randint(0, 256, (R, K)) * (rs.random_sample((R, K)) < 0.4)).astype(np.uint8)
+    rows = dev(rs.randint(0, R, size=M).astype(np.int64))
+    dy = dev((rs.standard_normal((M, N)) * 0.3).astype(np.float32))
+    store = torch.zeros(R * K + 64, dtype=torch.uint8, device="cuda"); xs = store[:R * K].view(R, K); xs.copy_(torch.from_numpy(q))
+    dw0, db0 = ops.dense_bwd_weight_u8(dy, xs, rows, 1.0 / 255.0, ws_name="t_ph0")
+    nb = lib.evae_dense_bwd_weight_u8_workspace_bytes(M, N, K)
+    st = torch.cuda.current_stream().cuda_stream
+    for first, second in ((3, 4), (1, 2)):
+        ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        dw = torch.full((N, K), float("nan"), device="cuda"); db = torch.full((N,), float("nan"), device="cuda")
+        none = None
+        _lib.check(lib.evae_dense_bwd_weight_u8_phased(none if first == 3 else dy.data_ptr(), M, N, N, xs.data_ptr(), rows.data_ptr(), K, K,
+                                                       1.0 / 255.0, none if first == 3 else dw.data_ptr(),
+                                                       none if first == 3 else db.data_ptr(), ws.data_ptr(), nb, first, st), "phase a")
+        _lib.check(lib.evae_dense_bwd_weight_u8_phased(dy.data_ptr(), M, N, N, xs.data_ptr(), rows.data_ptr(), K, K, 1.0 / 255.0,
+                                                       dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, second, st), "phase b")
+        assert torch.equal(dw, dw0) and torch.equal(db, db0), (first, second)
+
+
 def test_data_gradient_that_writes_bf16_tile_images(ops):
     """evae_dense_bwd_data_img + evae_dense_bwd_weight_u8(dy = NULL): the layer-above data gradient leaves (dh, dg) as the
     three-term bf16 tile images the byte-store weight gradient reads -- same dW / db as the fp32 buffer + pre-pass route,
