@@ -544,7 +544,11 @@ def main():
         # roofline object itself is the longest SINGLE kernel launch
         single = [k_ for k_ in kernels if "finish" not in k_["launch"]]
         dom = (single or kernels)[0]
-        traffic, traffic_src = pmc_traffic("c2_dominant") if a.config == "c2" and n_ex == C else (None, None)
+        # HBM traffic of the dominant launch: the PMC pass of that kernel family at these sizes (tools/kernel_probe.py names)
+        pmc_of = (("dense_bwd_weight_u8", "u8wgrad1"), ("gated_dense_fwd_u8", "u8fwd1"), ("dense_bwd_data M=%d N=%d+" % (C, H), "dgrad2"),
+                  ("dense_bwd_weight M=", "wgrad2"), ("gated_dense_fwd M=%d K=%d" % (C, H), "fwd2"))
+        probe = next((f for pre, f in pmc_of if dom["launch"].startswith(pre)), None)
+        traffic, traffic_src = pmc_traffic(probe) if (probe and a.config == "c2" and n_ex == C) else (None, None)
         roof = {"bound": "mfma", "kernel": dom["launch"] + " -- the longest launch of a step (evae::gemm_kernel / u8_gemm_kernel family)",
                 "achieved": dom["executed_tflops"], "peak": PEAKS[dom["pipe"]], "unit": "TFLOP/s", "frac": dom["frac_of_pipe_peak"],
                 "pipe": dom["pipe"], "algorithmic_tflops": dom["algorithmic_tflops"], "traffic": traffic, "traffic_source": traffic_src,
