@@ -1,15 +1,18 @@
-// Top-K by screening: the all-pairs distances are a GEMM (cache rows x queries on the fp32 matrix cores, the kernel of
-// evae_gemm_kernel.h with a distance epilogue), but only to FIND the few exemplars that can be among the k nearest;
-// those are then re-evaluated exactly -- fp64 direct differences rounded once to fp32, the arithmetic of the scan
+// Top-K by screening: the all-pairs distances are a GEMM (cache rows x queries on the matrix cores, the kernels of
+// evae_gemm_kernel.h / evae_gemm_x6.h with a distance epilogue), but only to FIND the few exemplars that can be among the k
+// nearest; those are then re-evaluated exactly -- fp64 direct differences rounded once to fp32, the arithmetic of the scan
 // kernel in evae_topk.hip -- and ordered by (value, index).  Indices and values are bit-identical to the scan kernel
 // (and to the reference's fp64 distance + topk) because the candidate set provably contains the true top-k:
-//   1. squared norms of all rows (fp32) and the largest exemplar norm;
-//   2. GEMM pass 1: per query the minimum approximate distance of every 128-exemplar tile.  The k-th smallest tile
-//      minimum T is an upper bound of the k-th smallest approximate distance (k tiles hold one element <= T each);
-//   3. with E = gamma (|q|^2 + max|c|^2) bounding the fp32 error of one approximate distance, every true top-k member
-//      has approximate distance <= T + 2E: GEMM pass 2 appends exactly those rows to the query's candidate list;
-//   4. exact distances of the candidates, k rounds of (value, index) arg-min.
-// Cost: two passes over the [N x z] cache at GEMM speed instead of one at fp64-VALU speed (c5: 1.6 ms -> see DESIGN).
+//   1. squared norms of the queries (fp32); those of the cache rows are accumulated by the GEMM while it stages them (split-
+//      bf16 kernel) or by a pass of their own (fp32 kernel), with the largest exemplar norm;
+//   2. ONE screening GEMM: per query the minimum approximate distance of every 128-exemplar tile, and all approximate
+//      distances kept.  The k-th smallest tile minimum T is an upper bound of the k-th smallest approximate distance (k tiles
+//      hold one element <= T each);
+//   3. with E = gamma (|q|^2 + max|c|^2) bounding the error of one approximate distance (gamma derived in topk_screen for
+//      either kernel), every true top-k member has approximate distance <= T + 2E: a scan of the kept distances appends
+//      exactly those rows to the query's candidate list;
+//   4. exact distances of the candidates, each ranked by the (value, index) pairs in front of it.
+// Cost: one pass over the [N x z] cache at streaming speed + a write and a read of the [N x B] distances.
 #include "evae_gemm_x6.h"
 #include "evae_topk_screen.h"
 
