@@ -288,7 +288,9 @@ def test_topk_small_and_ragged(ops, B, N, zd, k):
                                                  (3, 2048, 8, 16, False, 0.0),
                                                  # B > 64 over >= 384 tiles: the two-term split-bf16 screen with fused cache norms
                                                  (100, 100000, 256, 10, False, 0.0), (128, 60000, 64, 10, True, 0.0),
-                                                 (100, 100000, 256, 10, False, 3.0), (77, 50001 // 4 * 4, 48, 5, False, -8.0)])
+                                                 (100, 100000, 256, 10, False, 3.0), (77, 50001 // 4 * 4, 48, 5, False, -8.0),
+                                                 # several query tiles: every (row tile, query tile) block keeps its own row norms
+                                                 (300, 70000, 32, 10, False, 1.5), (513, 50048, 16, 33, True, 0.0)])
 def test_topk_screening_path_equals_exact_scan(ops, B, N, zd, k, sqrt, offset):
     """Large caches take the matrix-core screening + exact re-ranking path; it must return the very same indices and
     values as the exact fp64 scan kernel (forced with EVAE_TOPK_EXACT_SCAN=1 in a child process), including on
