@@ -448,7 +448,56 @@ class LinearFn(torch.autograd.Function):
         return dx, None, dw, (db if ctx.has_bias else None), None, None, None
 
 
-def gated_dense(x, wh, bh, wg, bg, rows=None):
+class GatedDenseU8Fn(torch.autograd.Function):
+    """GatedDense over M gathered rows of the uint8-resident image store (pixel = byte * x_scale): the first encoder layer of
+    the exemplar rows on the modular autograd path (hvae_2level, or vae outside the fused node) -- same byte kernels as the
+    fused step (csrc/evae_dense_u8.hip: bytes exact in bf16, weights / dy as three bf16 terms, fp32-GEMM accuracy)."""
+
+    @staticmethod
+    def forward(ctx, x_u8, rows, x_scale, wh, bh, wg, bg):
+        _need_cuda(x_u8, rows, wh, wg)
+        rows = _i64(rows)
+        wh, wg = _f32(wh), _f32(wg)
+        N, K = wh.shape
+        M = rows.numel()
+        prep = u8_prepare(wh.detach(), wg.detach(), out=_workspace("u8prep_mod%d" % N, _lib.load().evae_dense_u8_prepared_bytes(N, K),
+                                                                   x_u8.device))
+        need_grad = any(ctx.needs_input_grad)
+        out = torch.empty((M, N), device=x_u8.device)
+        s = torch.empty_like(out) if need_grad else None
+        fl = 2.0 * M * K * 2 * N
+        probed("gated_dense_fwd_u8 M=%d K=%d N=%d (uint8 rows, three bf16 terms)" % (M, K, N), fl,
+               lambda: gated_dense_fwd_u8(x_u8, rows, x_scale, prep, bh, bg, N, out=out, save_s=s), executed=3 * fl, pipe="bf16-mfma")
+        if need_grad:
+            ctx.save_for_backward(x_u8, rows, out, s)
+        ctx.x_scale = float(x_scale)
+        ctx.has_bias = (bh is not None, bg is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x_u8, rows, gout, s = ctx.saved_tensors
+        dout = _f32(dout)
+        M, N = gout.shape
+        K = x_u8.shape[1]
+        dpre = torch.empty((M, 2 * N), device=gout.device)          # [dh | dg]: one buffer, one weight-grad GEMM
+        base = dpre.data_ptr()
+        _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(gout), _p(s), M, N, _vp(base), _vp(base + 4 * N),
+                                                  2 * N, _stream()), "evae_gated_dense_bwd_input")
+        fl = 2.0 * M * 2 * N * K
+        dw, db = probed("dense_bwd_weight_u8 M=%d N=%d K=%d (uint8 rows, three bf16 terms; pre-passes + GEMM + finish)" % (M, 2 * N, K),
+                        fl, lambda: dense_bwd_weight_u8(dpre, x_u8, rows, ctx.x_scale, ws_name="wgrad_u8_mod"), executed=3 * fl,
+                        pipe="bf16-mfma")
+        return (None, None, None, dw[:N], (db[:N] if ctx.has_bias[0] else None), dw[N:], (db[N:] if ctx.has_bias[1] else None))
+
+
+def gated_dense(x, wh, bh, wg, bg, rows=None, x_scale=None):
+    """x fp32 [R x K] (optionally row-gathered), or the uint8 image store with x_scale (pixel = byte * x_scale; rows required)"""
+    if x.dtype == torch.uint8:
+        if rows is None or x_scale is None:
+            raise _lib.EvaeError("gated_dense on the uint8 store needs the gather list and x_scale")
+        return GatedDenseU8Fn.apply(x, rows, float(x_scale), wh, bh, wg, bg)
     return GatedDenseFn.apply(x, rows, wh, bh, wg, bg)
 
 

@@ -290,10 +290,25 @@ class BaseModel(nn.Module, ABC):
         if self._is_conv():
             return layers(x[rows])          # conv stacks: gather first, then the HIP convolution kernels (utils/nn.py)
         mods = list(layers)
-        h = mods[0](x, rows=rows)
+        if x.dtype == torch.uint8:          # the byte store (resident_u8): pixel = byte / U8_DIV, first layer on the byte kernels
+            h = mods[0](x, rows=rows, x_scale=1.0 / self.U8_DIV)
+        else:
+            h = mods[0](x, rows=rows)
         for m in mods[1:]:
             h = m(h)
         return h
+
+    def _exemplar_store(self, dataset):
+        """What the exemplar rows are gathered from on the modular path: the uint8 store when the data are k/255 and the
+        encoder starts with a plain GatedDense (utils/nn.py: gate on, no activation), the fp32 copy otherwise."""
+        if not self._is_conv() and os.environ.get("EVAE_U8_MODULAR", "1") != "0":
+            first = list(self.q_z_layers)[0]
+            if type(first).__name__ == "GatedDense" and first.no_attention is False and first.activation is None \
+                    and first.h.weight.shape[1] % 16 == 0:
+                u8 = self.resident_u8(dataset)
+                if u8 is not None:
+                    return u8[0][:u8[1]]
+        return self.resident_data(dataset)
 
     def q_z(self, x, prior=False, rows=None):
         """q(z|x) mean / log-variance (reference :205-221).  `rows` (extension): int64 device indices; the
@@ -404,7 +419,7 @@ class BaseModel(nn.Module, ABC):
                 # graph-captured step (evae/graph.py): this rank's indices already sit in a static device buffer
                 rows_ext, n_local = override
                 local = rows_ext[:n_local]
-                centres, logvar = self.q_z(self.resident_data(dataset), prior=True, rows=local)
+                centres, logvar = self.q_z(self._exemplar_store(dataset), prior=True, rows=local)
                 if self._sharded():
                     return shard.ShardedEmbedding((centres, logvar, local), total=self.args.number_components)
                 return (centres, logvar, local)
@@ -415,7 +430,7 @@ class BaseModel(nn.Module, ABC):
         return self.get_approximate_nearest_exemplars(z=(z_mean, z_log_var, x_indices), dataset=dataset, cache=cache)
 
     def _encode_exemplars(self, dataset, exemplars_indices):
-        data = self.resident_data(dataset)
+        data = self._exemplar_store(dataset)
         if self._sharded():
             lo, hi = shard.bounds(len(exemplars_indices))
             local = self._indices_to_device(exemplars_indices[lo:hi])
@@ -442,7 +457,7 @@ class BaseModel(nn.Module, ABC):
         z, _, indices = z
         cached_z, cached_log_variance = cache
         cached_z[indices.reshape(-1)] = z.detach() if not cached_z.requires_grad else z
-        data = self.resident_data(dataset)
+        data = self._exemplar_store(dataset)
         if self._sharded():
             # the candidate list is split over the ranks: local top-k over this rank's slice, one all-gather of the
             # R x k (value, candidate position) lists per row, merge -- the exact global top-k on every rank

@@ -85,10 +85,11 @@ class GatedDense(nn.Module):
         else:
             self.activation = nn.ReLU()
 
-    def forward(self, x, rows=None):
+    def forward(self, x, rows=None, x_scale=None):
         if self.no_attention is False and self.activation is None:
             x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
-            return ops.gated_dense(x2, self.h.weight, self.h.bias, self.g.weight, self.g.bias, rows=rows)
+            # x_scale: x is the uint8 image store (models/BaseModel.py::resident_u8), pixel = byte * x_scale
+            return ops.gated_dense(x2, self.h.weight, self.h.bias, self.g.weight, self.g.bias, rows=rows, x_scale=x_scale)
         h = dense(x, self.h, None, rows=rows)
         if self.activation is not None:
             h = self.activation(h)

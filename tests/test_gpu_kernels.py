@@ -773,6 +773,27 @@ def test_weight_gradient_on_the_uint8_store(ops, M, K, N, R):
     assert rel(dw.cpu().numpy(), dw32.cpu().numpy()) < 2e-6
 
 
+def test_gated_dense_autograd_on_the_uint8_store(ops):
+    """ops.gated_dense on the byte store (the modular path's exemplar encoder, e.g. hvae_2level): output and the four parameter
+    gradients against the fp32 Function on the fp32 copy of the same rows."""
+    rs = np.random.RandomState(3)
+    M, K, N, R = 1500, 784, 300, 4000
+    q = (rs.randint(0, 256, (R, K)) * (rs.random_sample((R, K)) < 0.4)).astype(np.uint8)
+    rows = dev(rs.randint(0, R, size=M).astype(np.int64))
+    store = torch.zeros(R * K + 64, dtype=torch.uint8, device="cuda"); xs = store[:R * K].view(R, K); xs.copy_(torch.from_numpy(q))
+    x32 = dev(q.astype(np.float32) / 255.0)
+    par = [dev((rs.standard_normal(sh) * 0.1).astype(np.float32)) for sh in ((N, K), (N,), (N, K), (N,))]
+    g = dev(rs.standard_normal((M, N)).astype(np.float32))
+    res = []
+    for x, kw in ((xs, dict(x_scale=1.0 / 255.0)), (x32, {})):
+        ps = [p.clone().requires_grad_(True) for p in par]
+        out = ops.gated_dense(x, ps[0], ps[1], ps[2], ps[3], rows=rows, **kw)
+        out.backward(g)
+        res.append([out.detach()] + [p.grad for p in ps])
+    for a, b in zip(*res):
+        assert rel(a.cpu().numpy(), b.cpu().numpy()) < 3e-6
+
+
 def test_weight_gradient_on_the_uint8_store_in_phases(ops):
     """phase 3 (byte gather-transpose alone: what a training step issues during its forward pass, dy not yet known) followed
     by phase 4 (everything else) = the one-call weight gradient, bit for bit; likewise phases 1 + 2."""
