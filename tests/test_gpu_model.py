@@ -865,3 +865,43 @@ def test_evaluation_loops_run_for_every_architecture(name, isz, itype, extra):
     report_knn_on_latent(L(train), L(val), L(test), model, "", d, args, val=True)
     report_knn_on_latent(L(train), L(val), L(test), model, "", d, args, val=False)
     assert all(len(v) == 2 and all(0.0 <= a <= 100.0 for a in v) for v in d.values())
+
+
+def test_fused_backward_redoes_the_byte_gather_when_another_step_used_the_workspace():
+    """The fused step transposes the gathered byte rows during its FORWARD pass into a named workspace (evae/fused_vae.py);
+    a second model's forward on another dataset in between overwrites it, and the first backward must notice (generation
+    counter) and redo the gather: same gradients as without the interleaved step."""
+    B, C, N = 32, 300, 800
+    def build(seed):
+        args = smoke_case.vae_args(number_components=C, training_set_size=N)
+        torch.manual_seed(3)
+        model, _ = smoke_case.build_model(torch, np, orc, args)
+        _, bidx, _, eps, ex_idx = smoke_case.make_case(np, B, C, N, seed, gi)
+        data = np.ascontiguousarray(gi.binary_images(seed, N).reshape(N, -1).astype(np.float32))     # k/255 data: the byte store applies
+        x = data[bidx.reshape(-1)]
+        dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+        model._draw_eps = lambda like: torch.from_numpy(eps).to(like.device)
+        model._use_fused = True
+        model.train()
+        return model, dataset, x, bidx, ex_idx
+
+    def loss_of(m, ds, x, bidx, ex_idx):
+        orig = torch.randint
+        torch.randint = lambda low=0, high=None, size=None, **kw: torch.from_numpy(ex_idx)
+        try:
+            return m.calculate_loss((torch.from_numpy(x).cuda(), torch.from_numpy(bidx).cuda()), beta=0.5, average=True, dataset=ds)[0]
+        finally:
+            torch.randint = orig
+
+    m1, ds1, x1, b1, e1 = build(71)
+    assert m1.resident_u8(ds1, B) is not None            # the byte store (and with it the forward-time gather) is in play
+    l = loss_of(m1, ds1, x1, b1, e1); l.backward()
+    ref = {n: p.grad.clone() for n, p in m1.named_parameters()}
+    m1.zero_grad(set_to_none=True)
+    m2, ds2, x2, b2, e2 = build(72)
+    l1 = loss_of(m1, ds1, x1, b1, e1)
+    l2 = loss_of(m2, ds2, x2, b2, e2)                    # same workspace names, other rows
+    l1.backward()
+    l2.backward()
+    for n, p in m1.named_parameters():
+        assert torch.equal(p.grad, ref[n]), n
