@@ -165,6 +165,71 @@ extern "C" int evae_linear_fwd(const float* x, const int64_t* rows, int M, int K
   return launch_finish(f, stream);
 }
 
+// ---- the two heads of the encoder + the sample, for thin launches -------------------------------------------------------
+// q_z_mean = Linear, q_z_logvar = Hardtanh(Linear) on the same input (models/VAE.py:24-26), then z = mean + eps exp(logvar / 2)
+// and log q(z | x) (models/BaseModel.py:79-82, utils/distributions.py:28-33).  As separate calls that is two split-K GEMMs, two
+// finish launches and the sampling kernel -- five dependent launches of the batch-row chain.  The two products share their
+// input, which is what the gated GEMM computes (bank h = mean weights, bank g = log-variance weights): one split-K launch
+// into [z][2][M][N] planes, and ONE finish launch (a wave per row) that sums the planes in fixed order, adds the biases, clamps
+// the log-variance, samples and reduces log q.
+__global__ __launch_bounds__(256) void heads_reparam_finish_kernel(const float* __restrict__ part, int nz, int M, int Z,
+                                                                   const float* __restrict__ bm, const float* __restrict__ bl,
+                                                                   float lo, float hi, const float* __restrict__ eps,
+                                                                   float* __restrict__ z_mean, float* __restrict__ lv_pre,
+                                                                   float* __restrict__ logvar, float* __restrict__ z,
+                                                                   float* __restrict__ logq) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const size_t plane = (size_t)M * Z;
+  float acc = 0.f;
+  for (int k = lane; k < Z; k += 64) {
+    const size_t o = (size_t)row * Z + k;
+    float m = 0.f, p = 0.f;
+    for (int s = 0; s < nz; ++s) { m += part[(size_t)s * 2 * plane + o]; p += part[(size_t)s * 2 * plane + plane + o]; }
+    m += bm ? bm[k] : 0.f;
+    p += bl ? bl[k] : 0.f;
+    const float lv = fminf(fmaxf(p, lo), hi);
+    const float zz = eps[o] * expf(0.5f * lv) + m;
+    z_mean[o] = m;
+    if (lv_pre) lv_pre[o] = p;
+    logvar[o] = lv;
+    z[o] = zz;
+    const float d = zz - m;
+    acc += -0.5f * (lv + kLog2Pi + d * d / expf(lv));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0 && logq) logq[row] = acc;
+}
+
+static Plan heads_plan(int M, int K, int Z) { return make_plan(M, Z, cdiv(K, BK), true, true, 2); }
+
+extern "C" size_t evae_heads_reparam_fwd_workspace_bytes(int M, int K, int Z) {
+  if (M <= 0 || K <= 0 || Z <= 0) return 256;
+  return align_up((size_t)heads_plan(M, K, Z).nz * 2 * M * Z * sizeof(float), 256) + 256;
+}
+
+extern "C" int evae_heads_reparam_fwd(const float* x, int M, int K, int ldx, const float* wm, const float* bm, const float* wl,
+                                      const float* bl, int Z, float lv_lo, float lv_hi, const float* eps, float* z_mean,
+                                      float* lv_pre, float* logvar, float* z, float* logq, void* ws, size_t ws_bytes,
+                                      evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(M >= 0 && K > 0 && Z > 0 && ldx >= K, "heads_reparam_fwd: bad sizes M=%d K=%d Z=%d ldx=%d", M, K, Z, ldx);
+  if (M == 0) return EVAE_OK;
+  EVAE_REQUIRE(x && wm && wl && eps && z_mean && logvar && z, "heads_reparam_fwd: null pointer");
+  EVAE_REQUIRE(ws && ws_bytes >= evae_heads_reparam_fwd_workspace_bytes(M, K, Z), "heads_reparam_fwd: workspace too small (%zu)", ws_bytes);
+  const Plan pl = heads_plan(M, K, Z);
+  GemmArgs g = {};
+  g.ones_col = -1;
+  g.A[0] = x; g.B[0] = wm; g.Bg = wl; g.lda[0] = ldx; g.ldb[0] = K; g.Kc[0] = K; g.npairs = 1;
+  g.M = M; g.N = Z; g.ldo = Z; g.out0 = (float*)ws;
+  int rc = launch_gemm<true, true, EPI_RAW_GATED>(g, pl, stream, "heads_reparam_fwd(split-K)");
+  if (rc) return rc;
+  heads_reparam_finish_kernel<<<cdiv(M, 4), 256, 0, stream>>>((const float*)ws, pl.nz, M, Z, bm, bl, lv_lo, lv_hi, eps, z_mean,
+                                                             lv_pre, logvar, z, logq);
+  return check_launch("heads_reparam_finish_kernel");
+}
+
 // ---- data gradient ---------------------------------------------------------------------------------------
 // transposed weights for the split-bf16 kernel (contraction-contiguous B): wT[p][k][n] = w_p[n][k], row stride ldt
 static int x6_wt_ld(int N) { return (N + 3) / 4 * 4; }

@@ -50,6 +50,8 @@ SIGNATURES = {
     "evae_dense_fwd_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "evae_gated_dense_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _z, _p]),
     "evae_linear_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _f, _p, _p, _p, _z, _p]),
+    "evae_heads_reparam_fwd_workspace_bytes": (_z, [_i, _i, _i]),
+    "evae_heads_reparam_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_dense_bwd_data_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "evae_dense_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _z, _p]),
     "evae_dense_bwd_weight_workspace_bytes": (_z, [_i, _i, _i]),

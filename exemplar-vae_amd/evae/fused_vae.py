@@ -236,12 +236,22 @@ class VaeExactLoss(torch.autograd.Function):
                 l1_fwd(kd, rows.data_ptr() + 8 * Cl, B, offb)
             kd.gated_fwd(A1.data_ptr() + offb * H, None, B, H, H, w2h, b2h, w2g, b2g, H,
                          A2.data_ptr() + offb * H, None, s2.data_ptr() + offb * H)
-            kd.linear_fwd(A2b, B, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, z_mean, None)
-            if approx:
-                zm_ready = torch.cuda.Event(); zm_ready.record()
-            kd.linear_fwd(A2b, B, H, H, wl, bl, Z, ACT_HARDTANH, -6.0, 2.0, logvar, lv_pre)
-            # ---- sample, decode, reconstruct
-            _lib.check(lib.evae_reparam_logq_fwd(_vp(z_mean), _vp(logvar), _vp(eps), B, Z, _vp(z), _vp(logq), kd.st), "reparam")
+            if B <= THIN_ROWS and not (SCHED & 1024):
+                # both heads (one gated-style split-K GEMM: bank h = mean, bank g = log-variance) and the sample in two
+                # launches instead of five
+                wh_ = kd.ws("heads", lib.evae_heads_reparam_fwd_workspace_bytes(B, H, Z))
+                _lib.check(lib.evae_heads_reparam_fwd(_vp(A2b), B, H, H, _vp(wm), _vp(bm), _vp(wl), _vp(bl), Z, -6.0, 2.0, _vp(eps),
+                                                      _vp(z_mean), _vp(lv_pre), _vp(logvar), _vp(z), _vp(logq), _vp(wh_),
+                                                      wh_.numel(), kd.st), "heads_reparam_fwd")
+                if approx:
+                    zm_ready = torch.cuda.Event(); zm_ready.record()
+            else:
+                kd.linear_fwd(A2b, B, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, z_mean, None)
+                if approx:
+                    zm_ready = torch.cuda.Event(); zm_ready.record()
+                kd.linear_fwd(A2b, B, H, H, wl, bl, Z, ACT_HARDTANH, -6.0, 2.0, logvar, lv_pre)
+                # ---- sample, decode, reconstruct
+                _lib.check(lib.evae_reparam_logq_fwd(_vp(z_mean), _vp(logvar), _vp(eps), B, Z, _vp(z), _vp(logq), kd.st), "reparam")
             z_ready = torch.cuda.Event(); z_ready.record()
             kd.gated_fwd(z, None, B, Z, Z, d1h, e1h, d1g, e1g, H, D1, None, sd1)
             kd.gated_fwd(D1, None, B, H, H, d2h, e2h, d2g, e2g, H, D2, None, sd2)

@@ -191,6 +191,14 @@ int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, int K, int 
 int evae_linear_fwd(const float* x, const int64_t* rows, int M, int K, int ldx,
                     const float* w, const float* b, int N, int act, float act_lo, float act_hi,
                     float* y, float* pre, void* ws, size_t ws_bytes, evae_stream_t stream);
+/* The two heads of the encoder on the same input and the sample, for launches of few rows (models/VAE.py:24-26,
+ * models/BaseModel.py:79-82, utils/distributions.py:28-33): z_mean = x wm^T + bm, lv_pre = x wl^T + bl, logvar = clamp(lv_pre,
+ * lv_lo, lv_hi), z = z_mean + eps exp(logvar / 2), logq[m] = log N(z | z_mean, exp(logvar)) -- one split-K GEMM (both products)
+ * and one finish launch instead of evae_linear_fwd x 2 + evae_reparam_logq_fwd (five launches).  lv_pre, logq may be NULL. */
+size_t evae_heads_reparam_fwd_workspace_bytes(int M, int K, int Z);
+int evae_heads_reparam_fwd(const float* x, int M, int K, int ldx, const float* wm, const float* bm, const float* wl,
+                           const float* bl, int Z, float lv_lo, float lv_hi, const float* eps, float* z_mean, float* lv_pre,
+                           float* logvar, float* z, float* logq, void* ws, size_t ws_bytes, evae_stream_t stream);
 /* dy1/dy2: [M x N] with row stride ldy (so dh and dg may be the two halves of one [M x 2N] buffer);
  * output(s) [M x K] with row stride ldo; out_prev/s_prev are dense [M x K]. */
 size_t evae_dense_bwd_data_workspace_bytes(int M, int N, int K, int npairs);

@@ -773,6 +773,37 @@ def test_weight_gradient_on_the_uint8_store(ops, M, K, N, R):
     assert rel(dw.cpu().numpy(), dw32.cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("M,K,Z", [(100, 300, 40), (37, 300, 40), (256, 128, 64), (5, 48, 8)])
+def test_heads_and_sample_in_one_call(ops, M, K, Z):
+    """evae_heads_reparam_fwd (both encoder heads as one split-K GEMM + one finish launch that also samples) against the fp64
+    formulas of models/VAE.py:24-26, models/BaseModel.py:79-82 and utils/distributions.py:28-33."""
+    from evae import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(M + K)
+    x = rs.standard_normal((M, K)).astype(np.float32)
+    wm = (rs.standard_normal((Z, K)) * 0.1).astype(np.float32); bm = (rs.standard_normal(Z) * 0.1).astype(np.float32)
+    wl = (rs.standard_normal((Z, K)) * 0.5).astype(np.float32); bl = (rs.standard_normal(Z) * 0.5).astype(np.float32)
+    eps = rs.standard_normal((M, Z)).astype(np.float32)
+    t = {k: dev(v) for k, v in dict(x=x, wm=wm, bm=bm, wl=wl, bl=bl, eps=eps).items()}
+    out = {k: torch.full((M, Z), float("nan"), device="cuda") for k in ("mean", "pre", "lv", "z")}
+    logq = torch.full((M,), float("nan"), device="cuda")
+    nb = lib.evae_heads_reparam_fwd_workspace_bytes(M, K, Z)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    p = lambda a: a.data_ptr()
+    _lib.check(lib.evae_heads_reparam_fwd(p(t["x"]), M, K, K, p(t["wm"]), p(t["bm"]), p(t["wl"]), p(t["bl"]), Z, -6.0, 2.0, p(t["eps"]),
+                                          p(out["mean"]), p(out["pre"]), p(out["lv"]), p(out["z"]), p(logq), p(ws), nb,
+                                          torch.cuda.current_stream().cuda_stream), "heads_reparam_fwd")
+    x64 = x.astype(np.float64)
+    mean = x64 @ wm.astype(np.float64).T + bm
+    pre = x64 @ wl.astype(np.float64).T + bl
+    lv = np.clip(pre, -6.0, 2.0)
+    z = mean + eps * np.exp(0.5 * lv)
+    lq = (-0.5 * (lv + np.log(2 * np.pi) + (z - mean) ** 2 / np.exp(lv))).sum(1)
+    assert rel(out["mean"].cpu().numpy(), mean) < 2e-6 and rel(out["pre"].cpu().numpy(), pre) < 2e-6
+    assert np.abs(out["lv"].cpu().numpy() - lv).max() < 5e-6 and rel(out["z"].cpu().numpy(), z) < 5e-6
+    assert rel(logq.cpu().numpy(), lq) < 5e-6
+
+
 def test_gated_dense_autograd_on_the_uint8_store(ops):
     """ops.gated_dense on the byte store (the modular path's exemplar encoder, e.g. hvae_2level): output and the four parameter
     gradients against the fp32 Function on the fp32 copy of the same rows."""
