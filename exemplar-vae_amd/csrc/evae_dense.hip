@@ -352,6 +352,12 @@ extern "C" size_t evae_dense_bwd_weight_workspace_bytes(int M, int N, int K) {
 
 // phase 0: both launches; 1: the split-K GEMM into the workspace partials; 2: the finish (sum of the partial planes in a fixed
 // order -> dw, db) -- so that a caller can put the finish on another stream than the GEMM that follows
+static bool thin_wgrad_direct() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EVAE_WGRAD_DIRECT"); on = e ? atoi(e) : 1; }
+  return on != 0;
+}
+
 static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const float* x,
                                  const int64_t* rows, int K, int ldx, float* dw, float* db,
                                  int accumulate, void* ws, size_t ws_bytes, int phase, hipStream_t stream) {
@@ -382,6 +388,13 @@ static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const f
   const bool x6 = gemm_x6_enabled() && gemm_x6t_ok(g) &&
                   (gemm_x6_min_rows() == 0 || ((double)M * N * Kp >= 2e9 && gemm_x6t_fill(128, Kp) >= 0.85));
   const X6tSplit sp6 = x6t_split(M, N, Kp);
+  if (phase == 0 && !accumulate && !x6 && cdiv(M, BK) <= 4 && thin_wgrad_direct()) {
+    // a contraction of at most four K-slabs (the batch rows' leaf layers): nothing to split -- the GEMM writes dw / db itself
+    Plan p1 = make_plan(N, Kp, cdiv(M, BK), false, false, 1);
+    p1.nz = 1; p1.ksplit = cdiv(M, BK);
+    g.out0 = dw; g.ldo = K; g.out1 = db; g.direct = 1;
+    return launch_gemm<false, false, EPI_RAW>(g, p1, stream, "dense_bwd_weight(direct)");
+  }
   if (phase != 2) {
     int rc;
     if (x6) {

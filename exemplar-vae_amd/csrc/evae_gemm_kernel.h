@@ -92,6 +92,8 @@ struct GemmArgs {
   unsigned short* img;
   int img_nslab, img_mbase;
   int ldo2;                // EPI_DIST_TILEMIN: > 0 = tile minima stored query-major, out0[n * ldo2 + tile] (else out0[tile * ldo + n])
+  int direct;              // EPI_RAW without split-K: out0[m * ldo + n] for n != ones_col, out1[m] for n == ones_col (a weight
+                           // gradient over a few rows writes dw / db itself: no partial plane, no finish launch)
 };
 
 // "This loaded value is needed HERE": an empty asm that takes the register in and out, so the compiler places the wait for
@@ -560,6 +562,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
           float res = apply_act(pre, g.act, g.lo, g.hi);
           if (extras) res = res * (a1 > 0.f ? 1.0f : a1 + 1.0f) + a0;
           g.out0[o] = res;
+        } else if (g.direct) {                  // EPI_RAW, one slice: the result itself (bias gradient = the ones column)
+          if (n == g.ones_col) { if (g.out1) g.out1[m] = v; }
+          else g.out0[(size_t)m * g.ldo + n] = v;
         } else {                                // EPI_RAW: partial plane [z][M][N]
           g.out0[(size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n] = v;
         }
