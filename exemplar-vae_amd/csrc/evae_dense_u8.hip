@@ -19,6 +19,7 @@
 // four 16-byte slots XOR-swizzled by (row >> 2) & 3, so every ds_read_b128 fragment read and every staging write is
 // conflict-free without padding; two stages of (A 8 KB + B 24 KB) = 64 KB per block, two blocks per CU.
 #include "evae_common.h"
+#include "evae_u8_prepare.h"
 
 namespace evae {
 
@@ -26,41 +27,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16u __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));    // native vector (HIP's uint4 struct does not always stay in registers)
 
-constexpr int U8_BM = 128, U8_BN = 64, U8_BK = 32, U8_NT = 256;
+constexpr int U8_BM = 128, U8_NT = 256;        // U8_BN = 64, U8_BK = 32: evae_u8_prepare.h
 constexpr int U8_A_BYTES = U8_BM * 64;                 // 128 rows x 32 bf16
 constexpr int U8_B_BYTES = 3 * 128 * 64;               // 3 terms x 128 columns x 32 bf16
 constexpr int U8_STAGE = U8_A_BYTES + U8_B_BYTES;      // 32 KB
 
-__device__ __forceinline__ unsigned short bf16_rn(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf16_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
-// B-tile images: image (tn, s) = [term p][column c = wc*64 + hg*32 + j][slot^swz][8 k], 24 KB each
+// B-tile images (u8_prepare_element, evae_u8_prepare.h): one thread per (tn, s, c, k) element, all three terms
 __global__ void u8_prepare_kernel(const float* __restrict__ wh, const float* __restrict__ wg, int N, int K, int nslab,
                                   unsigned short* __restrict__ img) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one (tn, s, c, k) element, all three terms
-  const size_t per_img = (size_t)128 * 32;
-  const size_t tot = (size_t)gridDim.y * 0 + per_img;                   // (unused; grid is 1-D over all images)
-  (void)tot;
-  const size_t im = e / per_img;
-  const int rem = (int)(e - im * per_img);
-  const int c = rem >> 5, k = rem & 31;
-  const int tn = (int)(im / nslab), s = (int)(im - (size_t)tn * nslab);
-  const int wc = c >> 6, hg = (c >> 5) & 1, j = c & 31;
-  const int n = tn * U8_BN + wc * 32 + j, kk = s * U8_BK + k;
-  float w = 0.f;
-  if (n < N && kk < K) w = (hg ? wg : wh)[(size_t)n * K + kk];
-  const unsigned short w0 = bf16_rn(w);
-  const float r1 = w - bf16_f(w0);
-  const unsigned short w1 = bf16_rn(r1);
-  const float r2 = r1 - bf16_f(w1);
-  const unsigned short w2 = bf16_rn(r2);
-  const int slot = (k >> 3) ^ ((c >> 2) & 3);
-  unsigned short* o = img + im * (size_t)(3 * 128 * 32) + (size_t)c * 32 + slot * 8 + (k & 7);
-  o[0] = w0; o[128 * 32] = w1; o[2 * 128 * 32] = w2;
+  u8_prepare_element((size_t)blockIdx.x * blockDim.x + threadIdx.x, wh, wg, N, K, nslab, img);
 }
 
 __device__ __forceinline__ bf16x8 lds_read16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }

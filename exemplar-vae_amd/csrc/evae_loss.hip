@@ -2,6 +2,7 @@
 // Replaces models/BaseModel.py:79-82 (reparameterize) and utils/distributions.py:28-33,44-51
 // (log_normal_diag, log_bernoulli) and their autograd.
 #include "evae_common.h"
+#include "evae_u8_prepare.h"
 
 namespace evae {
 
@@ -297,7 +298,17 @@ __global__ __launch_bounds__(256) void batch_prologue_u8_kernel(const unsigned c
                                                                 const int64_t* __restrict__ seed_ctr, float x_div,
                                                                 float* __restrict__ x_out, int64_t ldx,
                                                                 unsigned char* __restrict__ stage, int64_t lds_,
-                                                                float* __restrict__ eps_out, int zdim, int64_t nq_img) {
+                                                                float* __restrict__ eps_out, int zdim, int64_t nq_img,
+                                                                int pro_blocks, const float* __restrict__ wh,
+                                                                const float* __restrict__ wg, int wN, int wK,
+                                                                unsigned short* __restrict__ prepared, size_t prep_elems) {
+  // blocks past the prologue's: the weight split of the byte-store layer (evae_u8_prepare.h) -- the two jobs are independent
+  // and each is a few microseconds of one launch's latency at the head of every training step
+  if ((int)blockIdx.x >= pro_blocks) {
+    const size_t e = (size_t)(blockIdx.x - pro_blocks) * 256 + threadIdx.x;
+    if (e < prep_elems) u8_prepare_element(e, wh, wg, wN, wK, u8_prepare_nslab(wK), prepared);
+    return;
+  }
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t seed = (uint64_t)seed_ctr[0], step = (uint64_t)seed_ctr[1];
   const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
@@ -487,9 +498,34 @@ extern "C" int evae_batch_prologue_u8(const unsigned char* data, int64_t ldd, co
   EVAE_REQUIRE(eps_out == nullptr || zdim > 0, "batch_prologue_u8: eps_out needs zdim > 0");
   const int64_t nq_img = ((int64_t)B * D + 3) / 4;
   const int64_t nq_eps = eps_out ? ((int64_t)B * zdim + 3) / 4 : 0;
-  batch_prologue_u8_kernel<<<(unsigned)cdiv(nq_img + nq_eps, (int64_t)256), 256, 0, (hipStream_t)s>>>(
-      data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img);
+  const unsigned pro = (unsigned)cdiv(nq_img + nq_eps, (int64_t)256);
+  batch_prologue_u8_kernel<<<pro, 256, 0, (hipStream_t)s>>>(
+      data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img, (int)pro, nullptr, nullptr,
+      0, 0, nullptr, 0);
   return check_launch("batch_prologue_u8");
+}
+
+// The same launch also splits the first layer's weights into the byte kernels' bf16 tile images (evae_dense_u8_prepare): the
+// head of a training step is then one launch instead of two.
+extern "C" int evae_batch_prologue_u8_prepare(const unsigned char* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
+                                              const int64_t* seed_ctr, float x_div, float* x_out, int64_t ldx,
+                                              unsigned char* stage, int64_t lds_, float* eps_out, int zdim, const float* wh,
+                                              const float* wg, int N, int K, void* prepared, size_t prepared_bytes,
+                                              evae_stream_t s) {
+  EVAE_REQUIRE(B > 0 && D > 0 && zdim >= 0 && ldd >= D && ldx >= D && lds_ >= D && x_div > 0.f, "batch_prologue_u8_prepare: bad sizes");
+  EVAE_REQUIRE(data && idx && x_out && stage && seed_ctr, "batch_prologue_u8_prepare: null pointer");
+  EVAE_REQUIRE(eps_out == nullptr || zdim > 0, "batch_prologue_u8_prepare: eps_out needs zdim > 0");
+  EVAE_REQUIRE(N > 0 && K > 0 && wh && wg && prepared, "batch_prologue_u8_prepare: bad weight arguments");
+  const size_t elems = u8_prepare_elems(N, K);
+  EVAE_REQUIRE(prepared_bytes >= elems * 3 * sizeof(unsigned short), "batch_prologue_u8_prepare: buffer too small (%zu)", prepared_bytes);
+  const int64_t nq_img = ((int64_t)B * D + 3) / 4;
+  const int64_t nq_eps = eps_out ? ((int64_t)B * zdim + 3) / 4 : 0;
+  const unsigned pro = (unsigned)cdiv(nq_img + nq_eps, (int64_t)256);
+  const unsigned prep = (unsigned)((elems + 255) / 256);
+  batch_prologue_u8_kernel<<<pro + prep, 256, 0, (hipStream_t)s>>>(
+      data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img, (int)pro, wh, wg, N, K,
+      (unsigned short*)prepared, elems);
+  return check_launch("batch_prologue_u8_prepare");
 }
 
 extern "C" int evae_elu_fwd(const float* x, size_t n, float* out, evae_stream_t s) {

@@ -1,0 +1,43 @@
+// The weight split of the byte-store layer (csrc/evae_dense_u8.hip) as a device function: shared by u8_prepare_kernel and by
+// the step-head kernel of evae_loss.hip, which does it in the same launch as the batch prologue.
+#pragma once
+#include "evae_common.h"
+
+namespace evae {
+
+constexpr int U8_BN = 64, U8_BK = 32;
+
+__device__ __forceinline__ unsigned short bf16_rn(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+__host__ __device__ static inline int u8_prepare_nslab(int K) { return (K + U8_BK - 1) / U8_BK; }
+static inline size_t u8_prepare_elems(int N, int K) { return (size_t)((N + U8_BN - 1) / U8_BN) * u8_prepare_nslab(K) * 128 * 32; }
+
+// B-tile images: image (tn, s) = [term p][column c = wc*64 + hg*32 + j][slot^swz][8 k], 24 KB each.  Element e = one
+// (tn, s, c, k), all three terms: w = w0 + w1 + w2, round-to-nearest bf16 terms (exact: 3 x 8 significant bits).
+__device__ __forceinline__ void u8_prepare_element(size_t e, const float* __restrict__ wh, const float* __restrict__ wg, int N,
+                                                   int K, int nslab, unsigned short* __restrict__ img) {
+  const size_t per_img = (size_t)128 * 32;
+  const size_t im = e / per_img;
+  const int rem = (int)(e - im * per_img);
+  const int c = rem >> 5, k = rem & 31;
+  const int tn = (int)(im / nslab), s = (int)(im - (size_t)tn * nslab);
+  const int wc = c >> 6, hg = (c >> 5) & 1, j = c & 31;
+  const int n = tn * U8_BN + wc * 32 + j, kk = s * U8_BK + k;
+  float w = 0.f;
+  if (n < N && kk < K) w = (hg ? wg : wh)[(size_t)n * K + kk];
+  const unsigned short w0 = bf16_rn(w);
+  const float r1 = w - bf16_f(w0);
+  const unsigned short w1 = bf16_rn(r1);
+  const float r2 = r1 - bf16_f(w1);
+  const unsigned short w2 = bf16_rn(r2);
+  const int slot = (k >> 3) ^ ((c >> 2) & 3);
+  unsigned short* o = img + im * (size_t)(3 * 128 * 32) + (size_t)c * 32 + slot * 8 + (k & 7);
+  o[0] = w0; o[128 * 32] = w1; o[2 * 128 * 32] = w2;
+}
+
+}  // namespace evae

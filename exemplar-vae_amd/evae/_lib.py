@@ -94,6 +94,7 @@ SIGNATURES = {
     "evae_bernoulli_ll_fwd": (_i, [_p, _p, _i, _i, _p, _p]),
     "evae_batch_prologue": (_i, [_p, _l, _p, _i, _i, _i, _p, _p, _l, _p, _i, _p]),
     "evae_batch_prologue_u8": (_i, [_p, _l, _p, _i, _i, _i, _p, _f, _p, _l, _p, _l, _p, _i, _p]),
+    "evae_batch_prologue_u8_prepare": (_i, [_p, _l, _p, _i, _i, _i, _p, _f, _p, _l, _p, _l, _p, _i, _p, _p, _i, _i, _p, _z, _p]),
     "evae_bernoulli_ll_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_bernoulli_sigmoid_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_log_logistic256_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),

@@ -30,6 +30,7 @@ ACT_NONE, ACT_SIGMOID, ACT_HARDTANH = ops.ACT_NONE, ops.ACT_SIGMOID, ops.ACT_HAR
 
 # generation of the staging rows behind a dataset buffer (keyed by its address): a second fused forward overwrites the rows a
 # pending backward would gather its batch from -- the backward checks that its forward was the last one to stage
+PREP_DONE = {}     # prepared-weights buffer -> (w1h, w1g) pointers it was just filled from, by the step's head launch
 _STAGE_GEN = {}
 _XT_GEN = {}       # workspace pointer -> generation of the transposed byte rows the forward pass left there
 _ZEROED = {}      # workspace name -> (address, shape) it was last zero-filled for
@@ -201,7 +202,9 @@ class VaeExactLoss(torch.autograd.Function):
         if u8:
             # both first-layer launches read the weights as three bf16 terms in tile order: split once, in front of the fork
             prep = k.ws("u8prep", lib.evae_dense_u8_prepared_bytes(H, D))
-            _lib.check(lib.evae_dense_u8_prepare(_vp(w1h), _vp(w1g), H, D, _vp(prep), prep.numel(), k.st), "u8_prepare")
+            if PREP_DONE.pop(prep.data_ptr(), None) != (w1h.data_ptr(), w1g.data_ptr()):
+                # (the captured step's head launch -- evae/graph.py -- does this split beside its batch prologue and says so)
+                _lib.check(lib.evae_dense_u8_prepare(_vp(w1h), _vp(w1g), H, D, _vp(prep), prep.numel(), k.st), "u8_prepare")
             side.wait_stream(main)
 
             def l1_fwd(kk, rows_ptr, M, o):

@@ -108,6 +108,23 @@ class GraphedTrainStep:
                 dst.copy_(src.detach())
         return self.cache
 
+    def _first_layer_split(self):
+        """(w1h, w1g, prepared buffer) when the fused step on the byte store will run: its weight split then rides in the
+        prologue's launch (one launch at the head of the step instead of two); None otherwise."""
+        from . import fused_vae
+        m = self.model
+        if os.environ.get("EVAE_HEAD_MERGE", "1") == "0" or not (m._fused_config() and not m._sharded()):
+            return None
+        named = dict(m.named_parameters())
+        wh, wg = named.get("q_z_layers.0.h.weight"), named.get("q_z_layers.0.g.weight")
+        if wh is None or wg is None or not (wh.is_contiguous() and wg.is_contiguous() and wh.dtype == torch.float32):
+            return None
+        lib = fused_vae._lib.load()
+        H, D = wh.shape
+        prep = ops._workspace("u8prep", lib.evae_dense_u8_prepared_bytes(H, D), wh.device)
+        fused_vae.PREP_DONE[prep.data_ptr()] = (wh.data_ptr(), wg.data_ptr())
+        return wh.detach(), wg.detach(), prep
+
     # the body that gets captured
     def _body(self):
         if self.by_index:
@@ -116,7 +133,7 @@ class GraphedTrainStep:
             if self.u8:
                 x = self.x_in
                 ops.batch_prologue_u8(self.data_rows, self.idx_flat, self.binarize, self.seed_ctr, self.x_div, x,
-                                      self.stage_rows, self.eps_buf)
+                                      self.stage_rows, self.eps_buf, prepare=self._first_layer_split())
             else:
                 x = self.stage_rows
                 ops.batch_prologue(self.data_rows, self.idx_flat, self.binarize, self.seed_ctr, x, self.eps_buf)
@@ -125,6 +142,9 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)      # backward then installs the fused node's gradient buffers
         loss, RE, KL = self.model.calculate_loss((x, self.idx_in), self.beta, average=True, dataset=self.dataset,
                                                  cache=self.cache)
+        if self.by_index and self.u8:
+            from . import fused_vae
+            fused_vae.PREP_DONE.clear()           # (a token the fused step did not consume must not outlive this step)
         loss.backward(gradient=self._one)
         self.opt.step(_captured=True, _tables=self._adam_tables)
         ops.step_stats_add(loss.detach(), RE.detach(), KL.detach(), self.out, self.totals)

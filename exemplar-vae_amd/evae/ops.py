@@ -896,8 +896,9 @@ def batch_prologue(data, idx, binarize, seed_ctr, x_out, eps_out=None):
     return x_out, eps_out
 
 
-def batch_prologue_u8(data_u8, idx, binarize, seed_ctr, x_div, x_out, stage_u8, eps_out=None):
-    """batch_prologue on the uint8-resident store: x_out [B x D] fp32 and the batch's bytes into stage_u8 [B x D]."""
+def batch_prologue_u8(data_u8, idx, binarize, seed_ctr, x_div, x_out, stage_u8, eps_out=None, prepare=None):
+    """batch_prologue on the uint8-resident store: x_out [B x D] fp32 and the batch's bytes into stage_u8 [B x D].
+    prepare = (wh, wg, out): the same launch also splits the first layer's weights (u8_prepare) into `out`."""
     lib = _lib.load()
     _need_cuda(data_u8, idx, seed_ctr, x_out, stage_u8)
     B, D = x_out.shape
@@ -908,6 +909,15 @@ def batch_prologue_u8(data_u8, idx, binarize, seed_ctr, x_div, x_out, stage_u8, 
     if eps_out is not None:
         assert eps_out.is_contiguous() and eps_out.dtype == torch.float32 and eps_out.shape[0] == B
         zd = eps_out.shape[1]
+    if prepare is not None:
+        wh, wg, out = prepare
+        _need_cuda(wh, wg, out)
+        assert wh.dtype == torch.float32 and wh.is_contiguous() and wg.is_contiguous() and wh.shape == wg.shape
+        _lib.check(lib.evae_batch_prologue_u8_prepare(_p(data_u8), data_u8.stride(0), _p(idx), B, D, 1 if binarize else 0,
+                                                      _p(seed_ctr), float(x_div), _p(x_out), x_out.stride(0), _p(stage_u8),
+                                                      stage_u8.stride(0), _p(eps_out), zd, _p(wh), _p(wg), wh.shape[0], wh.shape[1],
+                                                      _p(out), out.numel(), _stream()), "evae_batch_prologue_u8_prepare")
+        return x_out, eps_out
     _lib.check(lib.evae_batch_prologue_u8(_p(data_u8), data_u8.stride(0), _p(idx), B, D, 1 if binarize else 0, _p(seed_ctr),
                                           float(x_div), _p(x_out), x_out.stride(0), _p(stage_u8), stage_u8.stride(0),
                                           _p(eps_out), zd, _stream()), "evae_batch_prologue_u8")

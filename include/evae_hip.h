@@ -373,6 +373,13 @@ int evae_batch_prologue(const float* data, int64_t ldd, const int64_t* idx, int 
 int evae_batch_prologue_u8(const unsigned char* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
                            const int64_t* seed_ctr, float x_div, float* x_out, int64_t ldx, unsigned char* stage, int64_t lds,
                            float* eps_out, int zdim, evae_stream_t stream);
+/* The same, and in the same launch the weight split of evae_dense_u8_prepare (wh, wg [N x K] -> prepared): the head of a
+ * training step on the byte store is one launch (exemplar-vae_amd/evae/graph.py); replaces utils/training.py:27-31 +
+ * models/BaseModel.py:79-81 as evae_batch_prologue does. */
+int evae_batch_prologue_u8_prepare(const unsigned char* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
+                                   const int64_t* seed_ctr, float x_div, float* x_out, int64_t ldx, unsigned char* stage,
+                                   int64_t lds, float* eps_out, int zdim, const float* wh, const float* wg, int N, int K,
+                                   void* prepared, size_t prepared_bytes, evae_stream_t stream);
 int evae_bernoulli_ll_fwd(const float* x, const float* mean, int B, int D, float* out,
                           evae_stream_t stream);
 int evae_bernoulli_ll_bwd(const float* x, const float* mean, const float* dout, int B, int D,
