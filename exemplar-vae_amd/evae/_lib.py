@@ -101,6 +101,7 @@ SIGNATURES = {
     "evae_log_logistic256_bwd": (_i, [_p, _p, _p, _i, _p, _i, _i, _p, _p, _p, _p]),
     "evae_adam_normgrad_workspace_bytes": (_z, [_i]),
     "evae_adam_normgrad_step": (_i, [_p, _i, _l, _i, _d, _d, _d, _d, _d, _p, _p, _z, _p]),
+    "evae_adam_normgrad_step_stats": (_i, [_p, _i, _l, _i, _d, _d, _d, _d, _d, _p, _p, _z, _p, _p, _p, _p, _p, _p]),
 }
 
 _lib = None

@@ -146,8 +146,11 @@ class GraphedTrainStep:
             from . import fused_vae
             fused_vae.PREP_DONE.clear()           # (a token the fused step did not consume must not outlive this step)
         loss.backward(gradient=self._one)
-        self.opt.step(_captured=True, _tables=self._adam_tables)
-        ops.step_stats_add(loss.detach(), RE.detach(), KL.detach(), self.out, self.totals)
+        # the step's statistics ride in the optimizer's last launch (evae_adam_normgrad_step_stats)
+        stats = (loss.detach(), RE.detach(), KL.detach(), self.out, self.totals) if os.environ.get("EVAE_TAIL_MERGE", "1") != "0" else None
+        self.opt.step(_captured=True, _tables=self._adam_tables, _stats=stats)
+        if not getattr(self.opt, "_stats_done", False):
+            ops.step_stats_add(loss.detach(), RE.detach(), KL.detach(), self.out, self.totals)
         return self.out
 
     def _refresh(self, data, indices, beta):

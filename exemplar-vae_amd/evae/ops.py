@@ -934,9 +934,10 @@ def adam_flush_tables(table_caches):
 
 
 def adam_normgrad_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps, weight_decay,
-                       table_cache=None, step_size_dev=None):
+                       table_cache=None, step_size_dev=None, stats=None):
     """One multi-tensor AdamNormGrad update (utils/optimizer.py:32-80).  `table_cache` (a dict) lets the
-    caller reuse the device pointer table while the tensor addresses stay the same."""
+    caller reuse the device pointer table while the tensor addresses stay the same.  `stats` = (loss, re, kl, step3, totals3):
+    the update's last launch also does step_stats_add's work (the captured training step: one launch less at its tail)."""
     lib = _lib.load()
     n = len(params)
     if n == 0:
@@ -987,6 +988,13 @@ def adam_normgrad_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, be
         table_cache["key"] = key
     nb = lib.evae_adam_normgrad_workspace_bytes(n)
     ws = _workspace("adam", nb, dev)
+    if stats is not None:
+        loss, re, kl, step3, totals3 = stats
+        _lib.check(lib.evae_adam_normgrad_step_stats(_p(table), n, max(p.numel() for p in params), int(step), float(lr),
+                                                     float(beta1), float(beta2), float(eps), float(weight_decay),
+                                                     _p(step_size_dev), _p(ws), ws.numel(), _p(loss), _p(re), _p(kl), _p(step3),
+                                                     _p(totals3), _stream()), "evae_adam_normgrad_step_stats")
+        return
     _lib.check(lib.evae_adam_normgrad_step(_p(table), n, max(p.numel() for p in params), int(step), float(lr),
                                            float(beta1), float(beta2), float(eps), float(weight_decay),
                                            _p(step_size_dev), _p(ws), ws.numel(), _stream()),

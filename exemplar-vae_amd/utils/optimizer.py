@@ -68,10 +68,12 @@ class AdamNormGrad(Optimizer):
         ops.adam_flush_tables([v for k, v in src.items() if isinstance(k, tuple) and k and k[0] != "members"])
 
     @torch.no_grad()
-    def step(self, closure=None, _captured=False, _tables=None):
+    def step(self, closure=None, _captured=False, _tables=None, _stats=None):
         """`_tables`: a dict owned by the caller's captured graph -- every graph keeps its own device pointer tables (its own
         gradient buffers) and, under "step_size", its own device step-size scalars, so that capturing a second step on the
-        same optimizer cannot redirect the first one's replays."""
+        same optimizer cannot redirect the first one's replays.  `_stats` = (loss, re, kl, step3, totals3) device tensors: the
+        LAST launch of this step also records the step's statistics (evae.ops.step_stats_add's work); returns True through
+        self._stats_done when it did."""
         tables = self._tables if _tables is None else _tables
         loss = None
         if closure is not None:
@@ -80,6 +82,8 @@ class AdamNormGrad(Optimizer):
         if shard.is_active():
             # the per-tensor norm needs the globally reduced gradient: reduce first, then normalise
             shard.allreduce_grads([p for group in self.param_groups for p in group['params']])
+        self._stats_done = False
+        launches = []          # (args, kwargs) of every multi-tensor launch of this step, issued below: the last one takes _stats
         for gi, group in enumerate(self.param_groups):
             beta1, beta2 = group['betas']
             by_step = {}
@@ -94,10 +98,15 @@ class AdamNormGrad(Optimizer):
             if _captured:
                 tables[("members", gi)] = [p for items in by_step.values() for p, _, _ in items]
             for step, items in by_step.items():
-                ops.adam_normgrad_step([p.data for p, _, _ in items], [g for _, g, _ in items],
-                                       [s['exp_avg'] for _, _, s in items],
-                                       [s['exp_avg_sq'] for _, _, s in items],
-                                       step, group['lr'], beta1, beta2, group['eps'], group['weight_decay'],
-                                       table_cache=tables.setdefault((gi, len(items), _captured), {}),
-                                       step_size_dev=(tables.get("step_size") or self._graph_step_size)[gi] if _captured else None)
+                launches.append((([p.data for p, _, _ in items], [g for _, g, _ in items],
+                                  [s['exp_avg'] for _, _, s in items],
+                                  [s['exp_avg_sq'] for _, _, s in items],
+                                  step, group['lr'], beta1, beta2, group['eps'], group['weight_decay']),
+                                 dict(table_cache=tables.setdefault((gi, len(items), _captured), {}),
+                                      step_size_dev=(tables.get("step_size") or self._graph_step_size)[gi] if _captured else None)))
+        for i, (a, kw) in enumerate(launches):
+            if _stats is not None and i == len(launches) - 1:
+                kw["stats"] = _stats
+                self._stats_done = True
+            ops.adam_normgrad_step(*a, **kw)
         return loss

@@ -418,6 +418,12 @@ int evae_adam_normgrad_step(const evae_adam_tensor_t* tensors /* device */, int 
                             int64_t max_numel, int step, double lr, double beta1, double beta2, double eps,
                             double weight_decay, const float* step_size_dev /* device scalar or NULL */,
                             void* ws, size_t ws_bytes, evae_stream_t stream);
+/* The same, and in its last launch the statistics of evae_step_stats_add (step3 = (loss, -re, kl), totals3 += step3; totals3
+ * may be NULL): the tail of a captured training step is one launch shorter (utils/training.py:41-46). */
+int evae_adam_normgrad_step_stats(const evae_adam_tensor_t* tensors /* device */, int n_tensors, int64_t max_numel, int step,
+                                  double lr, double beta1, double beta2, double eps, double weight_decay,
+                                  const float* step_size_dev, void* ws, size_t ws_bytes, const float* loss, const float* re,
+                                  const float* kl, float* step3, float* totals3, evae_stream_t stream);
 
 #ifdef __cplusplus
 }
