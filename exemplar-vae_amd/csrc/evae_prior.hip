@@ -757,7 +757,8 @@ __global__ __launch_bounds__(1024) void prior_elbo_fwd_kernel(const float* __res
                                                               const float* __restrict__ beta_dev, float beta_host,
                                                               float* __restrict__ logp, float* __restrict__ lse_out,
                                                               float* __restrict__ loss, float* __restrict__ KL,
-                                                              float* __restrict__ means) {
+                                                              float* __restrict__ means, float* __restrict__ cRE,
+                                                              float* __restrict__ cKL, float* __restrict__ neg_cKL) {
   // thread = (query row within a chunk of 128, one of 8 groups of partial rows): consecutive lanes read consecutive
   // queries of one partial row (coalesced), every thread keeps an online (max, sum exp, #masked) over its rows r = g, g+8, ..
   __shared__ float cm[8][128], cs[8][128], cn[8][128];
@@ -807,6 +808,10 @@ __global__ __launch_bounds__(1024) void prior_elbo_fwd_kernel(const float* __res
       const float l = beta * kl - RE[row];
       KL[row] = kl;
       loss[row] = l;
+      if (cRE != nullptr) {      // backward coefficients of "the batch mean of the loss, upstream gradient 1" (evae_elbo_bwd)
+        const float gl = 1.0f / (float)B;
+        cRE[row] = 0.f - gl; cKL[row] = 0.f + beta * gl; neg_cKL[row] = -(0.f + beta * gl);
+      }
       sl += l; sr += RE[row]; sk += kl;
     }
     __syncthreads();
@@ -1479,7 +1484,22 @@ extern "C" int evae_prior_elbo_fwd(const float* pmax, const float* psum, const f
   if (B == 0) return EVAE_OK;
   EVAE_REQUIRE(pmax && psum && pnmask && RE && logq && logp && loss && KL, "prior_elbo_fwd: null pointer");
   prior_elbo_fwd_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(pmax, psum, pnmask, R, ldp, B, c_total, RE, logq, beta_dev,
-                                                             beta_host, logp, lse, loss, KL, means);
+                                                             beta_host, logp, lse, loss, KL, means, nullptr, nullptr, nullptr);
+  return check_launch("prior_elbo_fwd_kernel");
+}
+
+// The same, and the three coefficient vectors evae_elbo_bwd would produce when what is back-propagated is the batch mean of
+// the loss with upstream gradient 1 (a captured training step: loss.backward(ones)): cRE = -1/B, cKL = beta/B, neg_cKL = -beta/B.
+// The backward pass then starts one launch later.
+extern "C" int evae_prior_elbo_fwd_coef(const float* pmax, const float* psum, const float* pnmask, int R, int ldp, int B,
+                                        float c_total, const float* RE, const float* logq, const float* beta_dev,
+                                        float beta_host, float* logp, float* lse, float* loss, float* KL, float* means,
+                                        float* cRE, float* cKL, float* neg_cKL, evae_stream_t stream_) {
+  EVAE_REQUIRE(R >= 1 && B >= 0 && ldp >= B, "prior_elbo_fwd_coef: bad sizes R=%d B=%d ldp=%d", R, B, ldp);
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(pmax && psum && pnmask && RE && logq && logp && loss && KL && cRE && cKL && neg_cKL, "prior_elbo_fwd_coef: null pointer");
+  prior_elbo_fwd_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(pmax, psum, pnmask, R, ldp, B, c_total, RE, logq, beta_dev,
+                                                             beta_host, logp, lse, loss, KL, means, cRE, cKL, neg_cKL);
   return check_launch("prior_elbo_fwd_kernel");
 }
 

@@ -39,6 +39,7 @@ SIGNATURES = {
     "evae_prior_merge": (_i, [_p, _p, _p, _i, _i, _f, _p, _p, _p]),
     "evae_prior_lse_fwd_splits": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _z, C.POINTER(C.c_int), C.POINTER(C.c_int), _p]),
     "evae_prior_elbo_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
+    "evae_prior_elbo_fwd_coef": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "evae_prior_lse_bwd_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_prior_lse_bwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_prior_lse_bwd_phased": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _p]),

@@ -30,6 +30,7 @@ ACT_NONE, ACT_SIGMOID, ACT_HARDTANH = ops.ACT_NONE, ops.ACT_SIGMOID, ops.ACT_HAR
 
 # generation of the staging rows behind a dataset buffer (keyed by its address): a second fused forward overwrites the rows a
 # pending backward would gather its batch from -- the backward checks that its forward was the last one to stage
+UNIT_UPSTREAM = [False]   # set by evae/graph.py around its step: the only backward is loss.backward(ones) on the batch mean
 PREP_DONE = {}     # prepared-weights buffer -> (w1h, w1g) pointers it was just filled from, by the step's head launch
 _STAGE_GEN = {}
 _XT_GEN = {}       # workspace pointer -> generation of the transposed byte rows the forward pass left there
@@ -316,9 +317,19 @@ class VaeExactLoss(torch.autograd.Function):
         means = torch.empty(3, **f32) if average else None
         beta_dev = beta if torch.is_tensor(beta) else None
         beta_host = 0.0 if beta_dev is not None else float(beta)
-        _lib.check(lib.evae_prior_elbo_fwd(_vp(pm), _vp(ps), _vp(pn), R, ldp, B, float(c_total), _vp(RE), _vp(logq),
-                                           _vp(beta_dev), beta_host, _vp(logp), _vp(lse), _vp(loss), _vp(KL), _vp(means),
-                                           k.st), "prior_elbo_fwd")
+        coef = None
+        if UNIT_UPSTREAM[0] and average and not sharded:
+            # the caller (evae/graph.py) promises loss.backward(ones) on the batch mean and nothing else: the backward pass's
+            # coefficient vectors are then known here (-1/B, beta/B, -beta/B) and its elbo_bwd launch is not needed
+            coef = (torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32))
+            _lib.check(lib.evae_prior_elbo_fwd_coef(_vp(pm), _vp(ps), _vp(pn), R, ldp, B, float(c_total), _vp(RE), _vp(logq),
+                                                    _vp(beta_dev), beta_host, _vp(logp), _vp(lse), _vp(loss), _vp(KL), _vp(means),
+                                                    _vp(coef[0]), _vp(coef[1]), _vp(coef[2]), k.st), "prior_elbo_fwd_coef")
+        else:
+            _lib.check(lib.evae_prior_elbo_fwd(_vp(pm), _vp(ps), _vp(pn), R, ldp, B, float(c_total), _vp(RE), _vp(logq),
+                                               _vp(beta_dev), beta_host, _vp(logp), _vp(lse), _vp(loss), _vp(KL), _vp(means),
+                                               k.st), "prior_elbo_fwd")
+        ctx.coef = coef
         ctx.set_materialize_grads(False)       # unused outputs (RE, KL) then arrive as None, not as zero-filled tensors
         ctx.k_dev = dev
         ctx.dims = (B, D, H, Z, Cl, Mp, ldd, beta, int(sharded))
@@ -364,15 +375,18 @@ class VaeExactLoss(torch.autograd.Function):
         if sharded:
             shard.register_flat_grads(gflat)
         # upstream gradients are per-row vectors (average=False) or scalars of the batch means (average=True)
-        cRE = torch.empty(B, **f32); cKL = torch.empty(B, **f32); gp = torch.empty(B, **f32)
-        gl = None if dloss is None else dloss.contiguous()
-        gr = None if dRE is None else dRE.contiguous()
-        gk = None if dKL is None else dKL.contiguous()
         beta_dev = beta if torch.is_tensor(beta) else None
-        _lib.check(lib.evae_elbo_bwd(_vp(gl), 0 if gl is None else gl.numel(), _vp(gr), 0 if gr is None else gr.numel(),
-                                     _vp(gk), 0 if gk is None else gk.numel(), _vp(beta_dev),
-                                     0.0 if beta_dev is not None else float(beta), B, _vp(cRE), _vp(cKL), _vp(gp), k.st),
-                   "elbo_bwd")
+        if ctx.coef is not None and dRE is None and dKL is None and dloss is not None and dloss.numel() == 1:
+            cRE, cKL, gp = ctx.coef              # written by the forward pass under the caller's unit-upstream promise
+        else:
+            cRE = torch.empty(B, **f32); cKL = torch.empty(B, **f32); gp = torch.empty(B, **f32)
+            gl = None if dloss is None else dloss.contiguous()
+            gr = None if dRE is None else dRE.contiguous()
+            gk = None if dKL is None else dKL.contiguous()
+            _lib.check(lib.evae_elbo_bwd(_vp(gl), 0 if gl is None else gl.numel(), _vp(gr), 0 if gr is None else gr.numel(),
+                                         _vp(gk), 0 if gk is None else gk.numel(), _vp(beta_dev),
+                                         0.0 if beta_dev is not None else float(beta), B, _vp(cRE), _vp(cKL), _vp(gp), k.st),
+                       "elbo_bwd")
         # ---- two chains from here to the weight gradients (the order of issue below is the order the captured graph starts
         #      things in, and it matters: a chain of small launches crawls next to a GEMM that fills every CU):
         #   main stream: prior term d(-cKL * logp) (+ its collectives when sharded) -> dcentres, which land in the

@@ -97,6 +97,11 @@ int evae_prior_elbo_fwd(const float* pmax, const float* psum, const float* pnmas
                         const float* RE, const float* logq, const float* beta_dev, float beta_host,
                         float* logp /* [B] */, float* lse /* [B] or NULL */, float* loss /* [B] */, float* KL /* [B] */,
                         float* means /* [3] or NULL */, evae_stream_t stream);
+/* The same, plus the coefficient vectors of evae_elbo_bwd for "batch mean of the loss, upstream gradient 1" (a captured step's
+ * loss.backward(ones)): cRE = -1/B, cKL = beta/B, neg_cKL = -beta/B -- the backward pass starts one launch later. */
+int evae_prior_elbo_fwd_coef(const float* pmax, const float* psum, const float* pnmask, int R, int ldp, int B, float c_total,
+                             const float* RE, const float* logq, const float* beta_dev, float beta_host, float* logp, float* lse,
+                             float* loss, float* KL, float* means, float* cRE, float* cKL, float* neg_cKL, evae_stream_t stream);
 
 /* Backward of sum_i grad_out_i * logprior_i through the prior (what autograd derives from
  * BaseModel.py:98-128 + distributions.py:12-25), by recomputation from the saved row LSE:
