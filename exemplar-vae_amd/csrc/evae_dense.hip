@@ -256,10 +256,12 @@ extern "C" size_t evae_dense_bwd_data_workspace_bytes(int M, int N, int K, int n
   return align_up((size_t)pl.nz * M * K * sizeof(float), 256) + wt + 256;
 }
 
-extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const float* dy2, const float* w2,
-                                   int M, int N, int ldy, int K, const float* out_prev, const float* s_prev,
-                                   float* dx_or_dh, float* dg, int ldo, void* ws, size_t ws_bytes,
-                                   evae_stream_t stream_) {
+// wT_ext: the transposed weights of the split-bf16 path ([npairs][K][x6_wt_ld(N)], evae_transpose_pairs / the step-head
+// launch) when the caller already has them -- they depend on the weights alone; NULL: transposed here, into the workspace.
+static int dense_bwd_data_core(const float* dy1, const float* w1, const float* dy2, const float* w2,
+                               int M, int N, int ldy, int K, const float* out_prev, const float* s_prev,
+                               float* dx_or_dh, float* dg, int ldo, const float* wT_ext, void* ws, size_t ws_bytes,
+                               evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldy >= N && ldo >= K, "dense_bwd_data: bad sizes M=%d N=%d K=%d", M, N, K);
   if (M == 0) return EVAE_OK;
@@ -280,10 +282,14 @@ extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const floa
   if (x6) {
     // contraction-contiguous weights: wT[p] = w_p^T behind the split-K planes, then the split-bf16 kernel (A = dy, B = wT)
     const int ldt = x6_wt_ld(N);
-    float* wT = (float*)((char*)ws + part_bytes);
-    transpose_pairs_kernel<<<dim3(cdiv(K, 32), cdiv(ldt, 32), np), 256, 0, stream>>>(w1, w2, N, K, ldt, wT);
-    int rc = check_launch("transpose_pairs_kernel");
-    if (rc) return rc;
+    const float* wT = wT_ext;
+    if (wT == nullptr) {
+      float* wTw = (float*)((char*)ws + part_bytes);
+      transpose_pairs_kernel<<<dim3(cdiv(K, 32), cdiv(ldt, 32), np), 256, 0, stream>>>(w1, w2, N, K, ldt, wTw);
+      int rc = check_launch("transpose_pairs_kernel");
+      if (rc) return rc;
+      wT = wTw;
+    }
     g.B[0] = wT; g.ldb[0] = ldt;
     if (dy2) { g.B[1] = wT + (size_t)K * ldt; g.ldb[1] = ldt; }
   }
@@ -315,6 +321,25 @@ extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const floa
   f.epi = gate ? EPI_GATE_BWD : EPI_LINEAR; f.out0 = dx_or_dh; f.out1 = gate ? dg : nullptr;
   f.e0 = out_prev; f.e1 = s_prev;
   return launch_finish(f, stream);
+}
+
+extern "C" int evae_dense_bwd_data(const float* dy1, const float* w1, const float* dy2, const float* w2,
+                                   int M, int N, int ldy, int K, const float* out_prev, const float* s_prev,
+                                   float* dx_or_dh, float* dg, int ldo, void* ws, size_t ws_bytes,
+                                   evae_stream_t stream_) {
+  return dense_bwd_data_core(dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, dx_or_dh, dg, ldo, nullptr, ws, ws_bytes, stream_);
+}
+
+extern "C" size_t evae_dense_bwd_data_wt_bytes(int N, int K, int npairs) {
+  return (N > 0 && K > 0) ? x6_wt_bytes(N, K, npairs > 1 ? 2 : 1) : 0;
+}
+extern "C" int evae_dense_bwd_data_wt_ld(int N) { return x6_wt_ld(N); }
+
+extern "C" int evae_dense_bwd_data_wt(const float* dy1, const float* w1, const float* dy2, const float* w2,
+                                      int M, int N, int ldy, int K, const float* out_prev, const float* s_prev,
+                                      float* dx_or_dh, float* dg, int ldo, const float* wT, void* ws, size_t ws_bytes,
+                                      evae_stream_t stream_) {
+  return dense_bwd_data_core(dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, dx_or_dh, dg, ldo, wT, ws, ws_bytes, stream_);
 }
 
 // The data gradient of the layer ABOVE the byte-store layer: (dh, dg) of that layer are written as the bf16 tile images the

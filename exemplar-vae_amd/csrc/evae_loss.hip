@@ -301,9 +301,18 @@ __global__ __launch_bounds__(256) void batch_prologue_u8_kernel(const unsigned c
                                                                 float* __restrict__ eps_out, int zdim, int64_t nq_img,
                                                                 int pro_blocks, const float* __restrict__ wh,
                                                                 const float* __restrict__ wg, int wN, int wK,
-                                                                unsigned short* __restrict__ prepared, size_t prep_elems) {
+                                                                unsigned short* __restrict__ prepared, size_t prep_elems,
+                                                                int prep_blocks, WtJob j0, WtJob j1) {
   // blocks past the prologue's: the weight split of the byte-store layer (evae_u8_prepare.h) -- the two jobs are independent
   // and each is a few microseconds of one launch's latency at the head of every training step
+  if ((int)blockIdx.x >= pro_blocks + prep_blocks) {
+    // ... and past those: the weight transpositions the backward pass's split-bf16 data gradients want (weights only, too)
+    __shared__ float tile[32][33];
+    const int t = (int)blockIdx.x - pro_blocks - prep_blocks;
+    if (t < j0.ntiles) wt_job_tile(j0, t, tile);
+    else if (t - j0.ntiles < j1.ntiles) wt_job_tile(j1, t - j0.ntiles, tile);
+    return;
+  }
   if ((int)blockIdx.x >= pro_blocks) {
     const size_t e = (size_t)(blockIdx.x - pro_blocks) * 256 + threadIdx.x;
     if (e < prep_elems) u8_prepare_element(e, wh, wg, wN, wK, u8_prepare_nslab(wK), prepared);
@@ -501,7 +510,7 @@ extern "C" int evae_batch_prologue_u8(const unsigned char* data, int64_t ldd, co
   const unsigned pro = (unsigned)cdiv(nq_img + nq_eps, (int64_t)256);
   batch_prologue_u8_kernel<<<pro, 256, 0, (hipStream_t)s>>>(
       data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img, (int)pro, nullptr, nullptr,
-      0, 0, nullptr, 0);
+      0, 0, nullptr, 0, 0, WtJob{}, WtJob{});
   return check_launch("batch_prologue_u8");
 }
 
@@ -511,7 +520,7 @@ extern "C" int evae_batch_prologue_u8_prepare(const unsigned char* data, int64_t
                                               const int64_t* seed_ctr, float x_div, float* x_out, int64_t ldx,
                                               unsigned char* stage, int64_t lds_, float* eps_out, int zdim, const float* wh,
                                               const float* wg, int N, int K, void* prepared, size_t prepared_bytes,
-                                              evae_stream_t s) {
+                                              const evae_wt_job_t* jobs, int njobs, evae_stream_t s) {
   EVAE_REQUIRE(B > 0 && D > 0 && zdim >= 0 && ldd >= D && ldx >= D && lds_ >= D && x_div > 0.f, "batch_prologue_u8_prepare: bad sizes");
   EVAE_REQUIRE(data && idx && x_out && stage && seed_ctr, "batch_prologue_u8_prepare: null pointer");
   EVAE_REQUIRE(eps_out == nullptr || zdim > 0, "batch_prologue_u8_prepare: eps_out needs zdim > 0");
@@ -522,9 +531,17 @@ extern "C" int evae_batch_prologue_u8_prepare(const unsigned char* data, int64_t
   const int64_t nq_eps = eps_out ? ((int64_t)B * zdim + 3) / 4 : 0;
   const unsigned pro = (unsigned)cdiv(nq_img + nq_eps, (int64_t)256);
   const unsigned prep = (unsigned)((elems + 255) / 256);
-  batch_prologue_u8_kernel<<<pro + prep, 256, 0, (hipStream_t)s>>>(
+  EVAE_REQUIRE(njobs >= 0 && njobs <= 2 && (njobs == 0 || jobs != nullptr), "batch_prologue_u8_prepare: at most two transposition jobs");
+  WtJob wj[2] = {WtJob{}, WtJob{}};
+  for (int i = 0; i < njobs; ++i) {
+    const evae_wt_job_t& q = jobs[i];
+    EVAE_REQUIRE(q.w1 && q.dst && q.N > 0 && q.K > 0 && q.ldt >= q.N, "batch_prologue_u8_prepare: bad transposition job");
+    wj[i].w1 = q.w1; wj[i].w2 = q.w2; wj[i].dst = q.dst; wj[i].N = q.N; wj[i].K = q.K; wj[i].ldt = q.ldt;
+    wj[i].tx = cdiv(q.K, 32); wj[i].ty = cdiv(q.ldt, 32); wj[i].ntiles = wj[i].tx * wj[i].ty * (q.w2 ? 2 : 1);
+  }
+  batch_prologue_u8_kernel<<<pro + prep + (unsigned)(wj[0].ntiles + wj[1].ntiles), 256, 0, (hipStream_t)s>>>(
       data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img, (int)pro, wh, wg, N, K,
-      (unsigned short*)prepared, elems);
+      (unsigned short*)prepared, elems, (int)prep, wj[0], wj[1]);
   return check_launch("batch_prologue_u8_prepare");
 }
 

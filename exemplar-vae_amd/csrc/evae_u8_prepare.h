@@ -40,4 +40,24 @@ __device__ __forceinline__ void u8_prepare_element(size_t e, const float* __rest
   o[0] = w0; o[128 * 32] = w1; o[2 * 128 * 32] = w2;
 }
 
+// A weight transposition riding in the step-head launch: dst[p][k][n] = w_p[n][k] (row stride ldt), the layout the split-bf16
+// data gradients read (evae_dense_bwd_data_wt).  Tiles of 32 x 32 through LDS, one block per tile, as transpose_pairs_kernel.
+struct WtJob {
+  const float* w1; const float* w2;      // [N x K] each (w2 NULL: one matrix)
+  float* dst;
+  int N, K, ldt, tx, ty, ntiles;         // tx = tiles along K, ty = tiles along ldt, ntiles = tx * ty * (w2 ? 2 : 1)
+};
+__device__ __forceinline__ void wt_job_tile(const WtJob& j, int t, float (*tile)[33]) {
+  const int per = j.tx * j.ty, z = t / per, r = t - z * per;
+  const int by = r / j.tx, bx = r - by * j.tx;
+  const float* w = z ? j.w2 : j.w1;
+  float* o = j.dst + (size_t)z * j.K * j.ldt;
+  const int n0 = by * 32, k0 = bx * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int rr = ty; rr < 32; rr += 8)
+    tile[rr][tx] = (n0 + rr < j.N && k0 + tx < j.K) ? w[(size_t)(n0 + rr) * j.K + k0 + tx] : 0.f;
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8)
+    if (k0 + rr < j.K && n0 + tx < j.ldt) o[(size_t)(k0 + rr) * j.ldt + n0 + tx] = tile[tx][rr];
+}
+
 }  // namespace evae

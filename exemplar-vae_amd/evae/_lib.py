@@ -24,6 +24,11 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("N", "C", "H", "W", "Co", "KH", "KW", "stride", "pad")]
 
 
+class WtJob(C.Structure):
+    """evae_wt_job_t (include/evae_hip.h)"""
+    _fields_ = [("w1", C.c_void_p), ("w2", C.c_void_p), ("dst", C.c_void_p), ("N", C.c_int), ("K", C.c_int), ("ldt", C.c_int)]
+
+
 class AdamTensor(C.Structure):
     """evae_adam_tensor_t"""
     _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("numel", _l)]
@@ -53,6 +58,9 @@ SIGNATURES = {
     "evae_linear_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _f, _p, _p, _p, _z, _p]),
     "evae_heads_reparam_fwd_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_heads_reparam_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_dense_bwd_data_wt_bytes": (_z, [_i, _i, _i]),
+    "evae_dense_bwd_data_wt_ld": (_i, [_i]),
+    "evae_dense_bwd_data_wt": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _z, _p]),
     "evae_dense_bwd_data_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "evae_dense_bwd_data": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _z, _p]),
     "evae_dense_bwd_weight_workspace_bytes": (_z, [_i, _i, _i]),
@@ -95,7 +103,8 @@ SIGNATURES = {
     "evae_bernoulli_ll_fwd": (_i, [_p, _p, _i, _i, _p, _p]),
     "evae_batch_prologue": (_i, [_p, _l, _p, _i, _i, _i, _p, _p, _l, _p, _i, _p]),
     "evae_batch_prologue_u8": (_i, [_p, _l, _p, _i, _i, _i, _p, _f, _p, _l, _p, _l, _p, _i, _p]),
-    "evae_batch_prologue_u8_prepare": (_i, [_p, _l, _p, _i, _i, _i, _p, _f, _p, _l, _p, _l, _p, _i, _p, _p, _i, _i, _p, _z, _p]),
+    "evae_batch_prologue_u8_prepare": (_i, [_p, _l, _p, _i, _i, _i, _p, _f, _p, _l, _p, _l, _p, _i, _p, _p, _i, _i, _p, _z, _p, _i,
+                                            _p]),
     "evae_bernoulli_ll_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_bernoulli_sigmoid_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_log_logistic256_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),

@@ -31,6 +31,7 @@ ACT_NONE, ACT_SIGMOID, ACT_HARDTANH = ops.ACT_NONE, ops.ACT_SIGMOID, ops.ACT_HAR
 # generation of the staging rows behind a dataset buffer (keyed by its address): a second fused forward overwrites the rows a
 # pending backward would gather its batch from -- the backward checks that its forward was the last one to stage
 UNIT_UPSTREAM = [False]   # set by evae/graph.py around its step: the only backward is loss.backward(ones) on the batch mean
+WT_DONE = {}       # (wm, w2h, w2g) pointers -> (wT of the head, wT of layer 2) the step's head launch just wrote
 PREP_DONE = {}     # prepared-weights buffer -> (w1h, w1g) pointers it was just filled from, by the step's head launch
 _STAGE_GEN = {}
 _XT_GEN = {}       # workspace pointer -> generation of the transposed byte rows the forward pass left there
@@ -107,7 +108,8 @@ class _K:
         _lib.check(self.lib.evae_linear_fwd(_vp(x), None, M, K, ldx, _vp(w_), _vp(b), N, act, lo, hi, _vp(y), _vp(pre),
                                             _vp(w), w.numel(), self.st), "linear_fwd")
 
-    def bwd_data(self, dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, out, dg, ldo):
+    def bwd_data(self, dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, out, dg, ldo, wT=None):
+        """wT: the transposed weights prepared by the step's head launch (evae_dense_bwd_data_wt), or None"""
         nb = self.lib.evae_dense_bwd_data_workspace_bytes(M, N, K, 2 if dy2 is not None else 1)
         w = self.ws("dgrad", nb)
         fl_ = 2.0 * M * N * K * (2 if dy2 is not None else 1)
@@ -115,8 +117,9 @@ class _K:
         ops.probed("dense_bwd_data M=%d N=%d%s K=%d%s" % (M, N, "+%d" % N if dy2 is not None else "", K,
                                                           " (gate-backward epilogue)" if out_prev is not None else ""),
                    fl_,
-                   lambda: _lib.check(self.lib.evae_dense_bwd_data(_vp(dy1), _vp(w1), _vp(dy2), _vp(w2), M, N, ldy, K, _vp(out_prev),
-                                                                   _vp(s_prev), _vp(out), _vp(dg), ldo, _vp(w), w.numel(), self.st),
+                   lambda: _lib.check(self.lib.evae_dense_bwd_data_wt(_vp(dy1), _vp(w1), _vp(dy2), _vp(w2), M, N, ldy, K, _vp(out_prev),
+                                                                      _vp(s_prev), _vp(out), _vp(dg), ldo, _vp(wT), _vp(w), w.numel(),
+                                                                      self.st),
                                       "bwd_data"), executed=ex_, pipe=pipe_)
 
     def bwd_weight(self, dy, M, N, ldy, x, rows, K, ldx, dw, db, phase=0, ws_name="wgrad", finish_on=None):
@@ -330,6 +333,7 @@ class VaeExactLoss(torch.autograd.Function):
                                                _vp(beta_dev), beta_host, _vp(logp), _vp(lse), _vp(loss), _vp(KL), _vp(means),
                                                k.st), "prior_elbo_fwd")
         ctx.coef = coef
+        ctx.wt = WT_DONE.pop((wm.data_ptr(), w2h.data_ptr(), w2g.data_ptr()), None)
         ctx.set_materialize_grads(False)       # unused outputs (RE, KL) then arrive as None, not as zero-filled tensors
         ctx.k_dev = dev
         ctx.dims = (B, D, H, Z, Cl, Mp, ldd, beta, int(sharded))
@@ -427,7 +431,8 @@ class VaeExactLoss(torch.autograd.Function):
             def l2_dgrad(kk, M, ob, m_base):
                 kk.bwd_data(dq2.data_ptr() + ob * 2 * H, w2h, dq2.data_ptr() + ob * 2 * H + 4 * H, w2g, M, H, 2 * H, H,
                             A1.data_ptr() + ob * H, s1.data_ptr() + ob * H, dq1.data_ptr() + ob * 2 * H,
-                            dq1.data_ptr() + ob * 2 * H + 4 * H, 2 * H)
+                            dq1.data_ptr() + ob * 2 * H + 4 * H, 2 * H,
+                            wT=None if (ctx.wt is None or kk is not k) else ctx.wt[1])
         dpx = torch.empty((B, D), **f32)
         dp2 = torch.empty((B, 2 * H), **f32)                               # [dh | dg] of decoder layer 2
         dp1 = torch.empty((B, 2 * H), **f32)
@@ -476,7 +481,8 @@ class VaeExactLoss(torch.autograd.Function):
                 prior_finish = lambda: _lib.check(lib.evae_prior_lse_bwd_phased(*pb_args, 2, kd.st), "prior_bwd(2)")
         dz_ready = torch.cuda.Event(); dz_ready.record()
         if Cl > 0:
-            k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H)
+            k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H,
+                       wT=None if ctx.wt is None else ctx.wt[0])
             l2_dgrad(k, Cl, 0, 0)
         batch_rows_done = torch.cuda.Event()
         g_plv = gslot("plv", 1)

@@ -123,7 +123,19 @@ class GraphedTrainStep:
         H, D = wh.shape
         prep = ops._workspace("u8prep", lib.evae_dense_u8_prepared_bytes(H, D), wh.device)
         fused_vae.PREP_DONE[prep.data_ptr()] = (wh.data_ptr(), wg.data_ptr())
-        return wh.detach(), wg.detach(), prep
+        # the transposed weights the two large data gradients of the backward pass read on the split-bf16 kernel
+        jobs = []
+        Cl = self.hi - self.lo
+        wm, w2h, w2g = named.get("q_z_mean.weight"), named.get("q_z_layers.1.h.weight"), named.get("q_z_layers.1.g.weight")
+        if (os.environ.get("EVAE_WT_HEAD", "1") != "0" and wm is not None and w2h is not None and w2g is not None
+                and not m.args.approximate_prior and lib.evae_gemm_x6_applies(Cl, H, 0)):
+            if getattr(self, "_wt_bufs", None) is None:       # this runner's own buffers: written in the head launch, read in the backward
+                nb1 = lib.evae_dense_bwd_data_wt_bytes(wm.shape[0], wm.shape[1], 1)
+                nb2 = lib.evae_dense_bwd_data_wt_bytes(w2h.shape[0], w2h.shape[1], 2)
+                self._wt_bufs = (torch.empty(nb1, dtype=torch.uint8, device=wh.device), torch.empty(nb2, dtype=torch.uint8, device=wh.device))
+            jobs = [(wm.detach(), None, self._wt_bufs[0]), (w2h.detach(), w2g.detach(), self._wt_bufs[1])]
+            fused_vae.WT_DONE[(wm.data_ptr(), w2h.data_ptr(), w2g.data_ptr())] = self._wt_bufs
+        return wh.detach(), wg.detach(), prep, jobs
 
     # the body that gets captured
     def _body(self):
@@ -150,6 +162,7 @@ class GraphedTrainStep:
         if self.by_index and self.u8:
             from . import fused_vae
             fused_vae.PREP_DONE.clear()           # (a token the fused step did not consume must not outlive this step)
+            fused_vae.WT_DONE.clear()
         loss.backward(gradient=self._one)
         # the step's statistics ride in the optimizer's last launch (evae_adam_normgrad_step_stats)
         stats = (loss.detach(), RE.detach(), KL.detach(), self.out, self.totals) if os.environ.get("EVAE_TAIL_MERGE", "1") != "0" else None

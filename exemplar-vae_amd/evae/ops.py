@@ -910,13 +910,22 @@ def batch_prologue_u8(data_u8, idx, binarize, seed_ctr, x_div, x_out, stage_u8, 
         assert eps_out.is_contiguous() and eps_out.dtype == torch.float32 and eps_out.shape[0] == B
         zd = eps_out.shape[1]
     if prepare is not None:
-        wh, wg, out = prepare
+        wh, wg, out = prepare[:3]
+        jobs = prepare[3] if len(prepare) > 3 else []        # [(w1, w2 or None, dst)]: transposed weights for the data gradients
         _need_cuda(wh, wg, out)
         assert wh.dtype == torch.float32 and wh.is_contiguous() and wg.is_contiguous() and wh.shape == wg.shape
+        arr = (_lib.WtJob * max(len(jobs), 1))()
+        for i, (w1, w2, dst) in enumerate(jobs):
+            assert w1.is_contiguous() and (w2 is None or (w2.is_contiguous() and w2.shape == w1.shape))
+            arr[i].w1 = w1.data_ptr(); arr[i].w2 = None if w2 is None else w2.data_ptr(); arr[i].dst = dst.data_ptr()
+            arr[i].N, arr[i].K = w1.shape
+            arr[i].ldt = lib.evae_dense_bwd_data_wt_ld(w1.shape[0])
+            assert dst.numel() * dst.element_size() >= lib.evae_dense_bwd_data_wt_bytes(w1.shape[0], w1.shape[1], 1 if w2 is None else 2)
         _lib.check(lib.evae_batch_prologue_u8_prepare(_p(data_u8), data_u8.stride(0), _p(idx), B, D, 1 if binarize else 0,
                                                       _p(seed_ctr), float(x_div), _p(x_out), x_out.stride(0), _p(stage_u8),
                                                       stage_u8.stride(0), _p(eps_out), zd, _p(wh), _p(wg), wh.shape[0], wh.shape[1],
-                                                      _p(out), out.numel(), _stream()), "evae_batch_prologue_u8_prepare")
+                                                      _p(out), out.numel(), C.cast(arr, C.c_void_p) if jobs else None, len(jobs),
+                                                      _stream()), "evae_batch_prologue_u8_prepare")
         return x_out, eps_out
     _lib.check(lib.evae_batch_prologue_u8(_p(data_u8), data_u8.stride(0), _p(idx), B, D, 1 if binarize else 0, _p(seed_ctr),
                                           float(x_div), _p(x_out), x_out.stride(0), _p(stage_u8), stage_u8.stride(0),

@@ -212,6 +212,14 @@ int evae_dense_bwd_data(const float* dy1, const float* w1, const float* dy2, con
                         const float* out_prev, const float* s_prev,
                         float* dx_or_dh, float* dg, int ldo,
                         void* ws, size_t ws_bytes, evae_stream_t stream);
+/* The same with the transposed weights of the split-bf16 path handed in (wT [npairs][K][evae_dense_bwd_data_wt_ld(N)],
+ * evae_dense_bwd_data_wt_bytes: they depend on the weights alone, so a training step prepares them in its head launch);
+ * wT == NULL: evae_dense_bwd_data.  Launches that stay on the fp32 kernel ignore wT. */
+size_t evae_dense_bwd_data_wt_bytes(int N, int K, int npairs);
+int evae_dense_bwd_data_wt_ld(int N);
+int evae_dense_bwd_data_wt(const float* dy1, const float* w1, const float* dy2, const float* w2, int M, int N, int ldy, int K,
+                           const float* out_prev, const float* s_prev, float* dx_or_dh, float* dg, int ldo, const float* wT,
+                           void* ws, size_t ws_bytes, evae_stream_t stream);
 /* dw [N x K] = dy^T x with dy [M x N] (row stride ldy), x [* x K] (row stride ldx, optional row gather);
  * db [N] = column sums of dy.  Passing the [M x 2N] buffer [dh | dg] yields [dWh ; dWg] in one launch. */
 size_t evae_dense_bwd_weight_workspace_bytes(int M, int N, int K);
@@ -381,10 +389,15 @@ int evae_batch_prologue_u8(const unsigned char* data, int64_t ldd, const int64_t
 /* The same, and in the same launch the weight split of evae_dense_u8_prepare (wh, wg [N x K] -> prepared): the head of a
  * training step on the byte store is one launch (exemplar-vae_amd/evae/graph.py); replaces utils/training.py:27-31 +
  * models/BaseModel.py:79-81 as evae_batch_prologue does. */
+/* jobs (host array, at most two): weight transpositions done by further blocks of the same launch -- dst[p][k][n] = w_p[n][k]
+ * with row stride ldt = evae_dense_bwd_data_wt_ld(N), the buffer evae_dense_bwd_data_wt takes: the backward pass of the step
+ * then has no transposition launches. */
+typedef struct { const float* w1; const float* w2; float* dst; int N, K, ldt; } evae_wt_job_t;
 int evae_batch_prologue_u8_prepare(const unsigned char* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
                                    const int64_t* seed_ctr, float x_div, float* x_out, int64_t ldx, unsigned char* stage,
                                    int64_t lds, float* eps_out, int zdim, const float* wh, const float* wg, int N, int K,
-                                   void* prepared, size_t prepared_bytes, evae_stream_t stream);
+                                   void* prepared, size_t prepared_bytes, const evae_wt_job_t* jobs, int njobs,
+                                   evae_stream_t stream);
 int evae_bernoulli_ll_fwd(const float* x, const float* mean, int B, int D, float* out,
                           evae_stream_t stream);
 int evae_bernoulli_ll_bwd(const float* x, const float* mean, const float* dout, int B, int D,

@@ -804,6 +804,48 @@ def test_heads_and_sample_in_one_call(ops, M, K, Z):
     assert rel(logq.cpu().numpy(), lq) < 5e-6
 
 
+def test_step_head_launch_also_transposes_weights_for_the_data_gradients(ops):
+    """evae_batch_prologue_u8_prepare with transposition jobs: the buffers are w^T with the row stride evae_dense_bwd_data_wt
+    expects, the weight split and the batch are what the separate launches produce, and the data gradient fed with the
+    prepared buffer equals evae_dense_bwd_data bit for bit."""
+    from evae import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(9)
+    B, D, R, H, Z, M = 16, 784, 300, 300, 40, 25000
+    q = (rs.randint(0, 256, (R, D)) * (rs.random_sample((R, D)) < 0.4)).astype(np.uint8)
+    store = torch.zeros((R + B) * D + 64, dtype=torch.uint8, device="cuda"); xs = store[:(R + B) * D].view(R + B, D)
+    xs[:R].copy_(torch.from_numpy(q))
+    idx = dev(rs.randint(0, R, size=B).astype(np.int64)); seed = dev(np.array([5, 7], dtype=np.int64))
+    wh, wg = dev((rs.standard_normal((H, D)) * 0.1).astype(np.float32)), dev((rs.standard_normal((H, D)) * 0.1).astype(np.float32))
+    wm = dev((rs.standard_normal((Z, H)) * 0.1).astype(np.float32))
+    w2h, w2g = dev((rs.standard_normal((H, H)) * 0.1).astype(np.float32)), dev((rs.standard_normal((H, H)) * 0.1).astype(np.float32))
+    t1 = torch.zeros(lib.evae_dense_bwd_data_wt_bytes(Z, H, 1), dtype=torch.uint8, device="cuda")
+    t2 = torch.zeros(lib.evae_dense_bwd_data_wt_bytes(H, H, 2), dtype=torch.uint8, device="cuda")
+    prep = torch.zeros(lib.evae_dense_u8_prepared_bytes(H, D), dtype=torch.uint8, device="cuda")
+    x = torch.empty((B, D), device="cuda"); eps = torch.empty((B, Z), device="cuda")
+    ops.batch_prologue_u8(xs[:R], idx, False, seed, 255.0, x, xs[R:], eps, prepare=(wh, wg, prep, [(wm, None, t1), (w2h, w2g, t2)]))
+    assert torch.equal(prep, ops.u8_prepare(wh, wg))
+    assert np.array_equal(x.cpu().numpy(), q[idx.cpu().numpy()].astype(np.float32) / np.float32(255.0))     # IEEE division, as the fp32 dataset
+    ld1, ld2 = lib.evae_dense_bwd_data_wt_ld(Z), lib.evae_dense_bwd_data_wt_ld(H)
+    assert torch.equal(t1.view(torch.float32)[:H * ld1].view(H, ld1)[:, :Z], wm.t())
+    tt = t2.view(torch.float32)[:2 * H * ld2].view(2, H, ld2)
+    assert torch.equal(tt[0][:, :H], w2h.t()) and torch.equal(tt[1][:, :H], w2g.t())
+    # the data gradient with the prepared buffer == the one that transposes itself
+    dq = dev((rs.standard_normal((M, 2 * H)) * 0.1).astype(np.float32))
+    a1 = dev(rs.standard_normal((M, H)).astype(np.float32)); s1 = dev(rs.random_sample((M, H)).astype(np.float32))
+    nb = lib.evae_dense_bwd_data_workspace_bytes(M, H, H, 2)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    outs = []
+    st = torch.cuda.current_stream().cuda_stream
+    for wT in (None, t2):
+        o = torch.full((M, 2 * H), float("nan"), device="cuda")
+        _lib.check(lib.evae_dense_bwd_data_wt(dq.data_ptr(), w2h.data_ptr(), dq.data_ptr() + 4 * H, w2g.data_ptr(), M, H, 2 * H, H,
+                                              a1.data_ptr(), s1.data_ptr(), o.data_ptr(), o.data_ptr() + 4 * H, 2 * H,
+                                              None if wT is None else wT.data_ptr(), ws.data_ptr(), nb, st), "bwd_data_wt")
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_gated_dense_autograd_on_the_uint8_store(ops):
     """ops.gated_dense on the byte store (the modular path's exemplar encoder, e.g. hvae_2level): output and the four parameter
     gradients against the fp32 Function on the fp32 copy of the same rows."""
