@@ -299,6 +299,13 @@ extern "C" int evae_conv2d_cl_fwd(const float* x, const evae_conv_desc_t* d, con
   return cl_fwd_impl(x, d, wh, bh, wg, bg, act, act_lo, act_hi, out, save_h, save_s, ws, ws_bytes, stream_, nullptr);
 }
 
+// One predicate for the residual-block entry points below (Python asks it instead of re-stating the geometry rules)
+extern "C" int evae_conv2d_cl_res_supported(const evae_conv_desc_t* d) {
+  if (!d || d->C != d->Co || d->stride != 1 || d->KH != d->KW || 2 * d->pad + 1 != d->KH || d->C == 32) return 0;
+  if (cl_patch_mode(d)) return 0;
+  return evae_conv2d_cl_supported(d, 0, 0) && evae_conv2d_cl_supported(d, 1, 0) && evae_conv2d_cl_supported(d, 2, 0);
+}
+
 // out = conv(a, w) + b + residual: the forward of a fully_conv residual block (a = ELU(x), residual = x; models/fully_conv.py:13-23)
 extern "C" int evae_conv2d_cl_fwd_res(const float* a, const evae_conv_desc_t* d, const float* w, const float* b,
                                       const float* residual, float* out, void* ws, size_t ws_bytes, evae_stream_t stream_) {

@@ -90,6 +90,7 @@ SIGNATURES = {
     "evae_gemm_x6_configure": (_i, [_i, _i]),
     "evae_gemm_x6_applies": (_i, [_i, _i, _i]),
     "evae_elu_fwd": (_i, [_p, _z, _p, _p]),
+    "evae_conv2d_cl_res_supported": (_i, [_p]),
     "evae_conv2d_cl_fwd_res": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_conv2d_cl_bwd_data_res": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_reparam_logq_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),

@@ -91,7 +91,8 @@ class GraphedTrainStep:
         self.cache = None          # approximate prior: the latent cache in static buffers (set_cache)
         self.graph = None
         self.failed = False
-        self.warmup_steps = warmup_steps
+        self.eager_opt = False     # True: the participants' step counts differ (resumed checkpoint): eager optimizer steps only
+        self.warmup_steps = max(2, warmup_steps)    # call 0 learns the optimizer's participants, call 1 warms the captured form
         self._calls = 0
 
     def reset_totals(self):
@@ -138,7 +139,7 @@ class GraphedTrainStep:
         return wh.detach(), wg.detach(), prep, jobs
 
     # the body that gets captured
-    def _body(self):
+    def _body(self, eager_opt=False):
         if self.by_index:
             # the batch is rows `idx` of the HBM-resident dataset: gathered (and binarised) straight into the staging rows
             # of the fused step, no image bytes cross PCIe
@@ -166,7 +167,13 @@ class GraphedTrainStep:
         loss.backward(gradient=self._one)
         # the step's statistics ride in the optimizer's last launch (evae_adam_normgrad_step_stats)
         stats = (loss.detach(), RE.detach(), KL.detach(), self.out, self.totals) if os.environ.get("EVAE_TAIL_MERGE", "1") != "0" else None
-        self.opt.step(_captured=True, _tables=self._adam_tables, _stats=stats)
+        if eager_opt:
+            # the reference's own bookkeeping (a step count per parameter, host-side step size): the runner's first call, which
+            # learns which parameters take part at all, and every call of a runner whose participants disagree on the count
+            self.opt.step()
+            self.opt._stats_done = False
+        else:
+            self.opt.step(_captured=True, _tables=self._adam_tables, _stats=stats)
         if not getattr(self.opt, "_stats_done", False):
             ops.step_stats_add(loss.detach(), RE.detach(), KL.detach(), self.out, self.totals)
         return self.out
@@ -197,7 +204,8 @@ class GraphedTrainStep:
         h[self._o_seed + 1] = self._calls
         hs = h[self._o_scal:].view(torch.float32)
         hs[0] = float(beta)
-        self.opt.advance_graph_step(host_out=hs[1:1 + self.ngroups], tables=self._adam_tables)
+        if self._calls > 0 and not self.eager_opt:      # (call 0 steps eagerly and learns the participants)
+            self.opt.advance_graph_step(host_out=hs[1:1 + self.ngroups], tables=self._adam_tables)
         main = torch.cuda.current_stream()
         self._up.wait_event(self._ev_used[k])     # device staging block k was consumed two steps ago
         with torch.cuda.stream(self._up):
@@ -224,16 +232,20 @@ class GraphedTrainStep:
             self.model._batch_staged = bool(self.by_index and self.u8)
             if self.graph is None:
                 # eager warm-up steps on a side stream (workspaces, attributes, RCCL channels), then capture
-                if self._calls < self.warmup_steps:
+                if self._calls < self.warmup_steps and not self.failed:
                     s = torch.cuda.Stream()
                     s.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(s):
-                        out = self._body()
+                        out = self._body(eager_opt=self._calls == 0)
                     torch.cuda.current_stream().wait_stream(s)
+                    if self._calls == 0 and not self.opt.learn_members(self._adam_tables):
+                        print("evae.graph: the optimizer's parameters carry different step counts (a resumed checkpoint); "
+                              "the step is not captured and AdamNormGrad steps eagerly", file=sys.stderr)
+                        self.failed = self.eager_opt = True
                     self._calls += 1
                     return out
                 if self.failed:
-                    self._body()                 # capture was refused once: keep stepping eagerly
+                    self._body(eager_opt=self.eager_opt)   # capture was refused once: keep stepping eagerly
                     self._calls += 1
                     return self.out
                 torch.cuda.synchronize()

@@ -230,6 +230,7 @@ class PairwiseDistance(torch.autograd.Function):
 
 
 PRIOR_MASK_ALL = -3      # EVAE_PRIOR_MASK_ALL: a c_idx entry that masks its exemplar slot for every query
+SELECT_EXEMPLARS_MAX = 16384   # evae_select_exemplars keeps a call's positions in one block's LDS (csrc/evae_topk.hip)
 
 
 def select_exemplars(pos, cand_idx, want_count=False):
@@ -712,25 +713,29 @@ class ResBlockFn(torch.autograd.Function):
         dev = dout.device
         dy = _cl(dout.float())
         K = d.C * d.KH * d.KW
-        dw = torch.empty((d.Co, K), device=dev); db = torch.empty(d.Co, device=dev)
-        ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 2, 0), dev)
-        _lib.check(lib.evae_conv2d_cl_bwd_weight(_p(dy), _p(a), C.byref(d), 0, _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
-                   "evae_conv2d_cl_bwd_weight")
+        dw = db = None
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            dw = torch.empty((d.Co, K), device=dev); db = torch.empty(d.Co, device=dev)
+            ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 2, 0), dev)
+            _lib.check(lib.evae_conv2d_cl_bwd_weight(_p(dy), _p(a), C.byref(d), 0, _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
+                       "evae_conv2d_cl_bwd_weight")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(a, memory_format=CL)
             ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 1, 0), dev)
             _lib.check(lib.evae_conv2d_cl_bwd_data_res(_p(dy), _p(w), C.byref(d), _p(dy), _p(a), _p(dx), _p(ws), ws.numel(),
                                                        _stream()), "evae_conv2d_cl_bwd_data_res")
-        return dx, dw.reshape(w.shape), (db if has_b else None)
+        return dx, (None if dw is None else dw.reshape(w.shape)), (db if has_b else None)
 
 
 def res_block_supported(x, w, stride, padding):
-    """ELU -> 3x3 'same' convolution -> + x on the fused path: square odd filter, stride 1, channel count kept, C % 4 == 0,
-    C >= 16 and not 32 (that width runs the pixel-pair data gradient, which has no residual epilogue)."""
-    Co, Ci, KH, KW = w.shape
-    return (x.is_cuda and x.dim() == 4 and Co == Ci == x.shape[1] and KH == KW and KH % 2 == 1 and _int1(stride) == 1
-            and 2 * _int1(padding) + 1 == KH and Ci % 4 == 0 and Ci >= 16 and Ci != 32)
+    """ELU -> 3x3 'same' convolution -> + x on the fused path?  The geometry rules live in ONE place, the library's
+    evae_conv2d_cl_res_supported (shape kept, stride 1, channel counts / workspace / images-per-pass limits of the
+    channels-last kernels); anything it refuses runs as x + f(x) on the plain layers."""
+    if not (x.is_cuda and x.dim() == 4 and w.dim() == 4 and w.shape[1] == x.shape[1]):
+        return False
+    d, _, _ = _conv_desc(x, w, _int1(stride), _int1(padding))
+    return bool(_lib.load().evae_conv2d_cl_res_supported(C.byref(d)))
 
 
 def res_block(x, w, b):

@@ -109,6 +109,14 @@ class BaseModel(nn.Module, ABC):
         # the image store the exemplar rows are gathered from: bytes when the data are k/255 (4x less HBM, and the first
         # layer then runs on the bf16 matrix pipe, csrc/evae_dense_u8.hip), fp32 rows otherwise
         u8 = self.resident_u8(dataset, x.shape[0])
+        x2 = x.reshape(x.shape[0], -1).float()
+        if u8 is not None and not getattr(self, '_batch_staged', False):
+            # eager call: the batch goes into the byte store's staging rows as round(255 x), so x itself has to be k/255 (what
+            # the loaders and dynamic binarisation hand out); a batch that is not -- augmented, noisy -- takes the fp32 store
+            # for this call instead of being quantised silently (the captured step checks its loader once, evae/graph.py)
+            q = torch.round(x2 * self.U8_DIV)
+            if not bool(((q >= 0) & (q <= 255) & (q / self.U8_DIV == x2)).all()):
+                u8 = None
         if u8 is not None:
             data_ext, n_data = u8[0], u8[1]
         else:
@@ -116,7 +124,6 @@ class BaseModel(nn.Module, ABC):
         if a.training_set_size > n_data:
             # the reference's dataset.tensors[0][exemplars_indices] raises here; the row-gather GEMM would read staging rows
             raise IndexError("training_set_size %d exceeds the %d rows of the dataset" % (a.training_set_size, n_data))
-        x2 = x.reshape(x.shape[0], -1).float()
         eps = getattr(self, '_eps_override', None)          # the captured step draws eps in its prologue launch
         if eps is None or tuple(eps.shape) != (x2.shape[0], a.z1_size):
             eps = self._draw_eps(torch.empty((x2.shape[0], a.z1_size), device=x.device))
@@ -376,13 +383,14 @@ class BaseModel(nn.Module, ABC):
         if D % 16 == 0 and flat.dtype == torch.float32 and n > 0:
             store = torch.zeros((n + need) * D + 64, dtype=torch.uint8, device=self.args.device)   # + slack behind the last row
             buf = store[:(n + need) * D].view(n + need, D)
+            bad = torch.zeros((), dtype=torch.int64, device=self.args.device)     # accumulated on the device: ONE sync per dataset
             for s0 in range(0, n, 8192):
                 f = flat[s0:s0 + 8192].to(self.args.device)
                 q = torch.round(f * self.U8_DIV)
-                if not (bool((q >= 0).all()) and bool((q <= 255).all()) and torch.equal(q / self.U8_DIV, f)):
-                    buf = None
-                    break
-                buf[s0:s0 + f.shape[0]] = q.to(torch.uint8)
+                bad += ((q < 0) | (q > 255) | (q / self.U8_DIV != f)).sum()
+                buf[s0:s0 + f.shape[0]] = q.clamp_(0, 255).to(torch.uint8)
+            if int(bad) != 0:
+                buf = store = None
         self._resident_u8[key] = (src, buf)
         return None if buf is None else (buf, n, self.U8_DIV)
 
@@ -470,6 +478,14 @@ class BaseModel(nn.Module, ABC):
             # static slots: always for the dense encoders (a repeated slot costs one thin GEMM row), for the convolutional
             # ones only inside a captured step -- re-encoding up to B * k images where `unique` leaves a few dozen is not free
             static = self.args.no_mask is False and (not self._is_conv() or isinstance(override, tuple))
+            if static and nearest_indices.numel() > ops.SELECT_EXEMPLARS_MAX:
+                # evae_select_exemplars keeps all B * k positions of a call in one block's LDS: beyond its limit the
+                # data-dependent `unique` form below takes over (not capturable: a captured step refuses this size up front)
+                if isinstance(override, tuple):
+                    raise RuntimeError("approximate prior: batch_size * approximate_k = %d exceeds the %d static slots a "
+                                       "captured step supports; run with use_hip_graph=False"
+                                       % (nearest_indices.numel(), ops.SELECT_EXEMPLARS_MAX))
+                static = False
             if static:
                 sel_rows, c_idx = ops.select_exemplars(nearest_indices.view(-1), exemplars_indices)
                 exemplars_z, log_variance = self.q_z(data, prior=True, rows=sel_rows)

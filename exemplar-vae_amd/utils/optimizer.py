@@ -37,24 +37,40 @@ class AdamNormGrad(Optimizer):
         dev = self.param_groups[0]['params'][0].device
         self._graph_step_size = storage if storage is not None else [torch.zeros(1, device=dev) for _ in self.param_groups]
 
+    def learn_members(self, tables):
+        """After an EAGER step of the runner that owns `tables`: the parameters that received a gradient are the participants
+        of its captured step (the reference skips parameters without one, utils/optimizer.py:50-57, and keeps no state for
+        them -- e.g. the unused BatchNorm2d of fully_conv's blocks).  Returns True when the participants of every group share
+        ONE step count, which is what a captured launch (one device step size per group) can express; a resumed checkpoint
+        whose participants disagree has to be stepped eagerly (the caller's fallback)."""
+        ok = True
+        for gi, group in enumerate(self.param_groups):
+            members = [p for p in group['params'] if p.grad is not None]
+            tables[("members", gi)] = members
+            ok = ok and len({self._init_state(p)['step'] for p in members}) <= 1
+        return ok
+
     def advance_graph_step(self, host_out=None, tables=None):
         """Before each replay: bump the step counters of the parameters that take part in the captured step (`tables`: the
-        runner-owned dict its capture filled; before the capture, every parameter) and upload the bias-corrected step size
-        -- or, with `host_out`, write it there for the caller to upload.  The captured launches apply ONE step size per
-        group, so the participants of a group must share one step count (the reference keeps a count per parameter and
-        skips parameters without a gradient, utils/optimizer.py:50-57)."""
+        runner-owned dict; its ("members", gi) lists come from learn_members / the capture) and upload the bias-corrected
+        step size -- or, with `host_out`, write it there for the caller to upload.  The captured launches apply ONE step size
+        per group, so the participants of a group must share one step count; nothing is mutated when they do not."""
+        plan = []
         for gi, group in enumerate(self.param_groups):
-            step = None
             members = (tables or {}).get(("members", gi))
-            for p in (members if members is not None else group['params']):
-                st = self._init_state(p)
-                st['step'] += 1
-                if step is not None and st['step'] != step:
-                    raise RuntimeError("AdamNormGrad: parameters of one group reached the captured step with different step "
-                                       "counts (%d vs %d); step them eagerly" % (st['step'], step))
-                step = st['step']
+            if members is None:
+                raise RuntimeError("AdamNormGrad.advance_graph_step: the participants of the captured step are unknown; run one "
+                                   "eager step and learn_members() first")
+            steps = {self._init_state(p)['step'] for p in members}
+            if len(steps) > 1:
+                raise RuntimeError("AdamNormGrad: parameters of one group reached the captured step with different step "
+                                   "counts %s; step them eagerly" % sorted(steps))
+            plan.append((gi, group, members, (steps.pop() + 1) if steps else None))
+        for gi, group, members, step in plan:
             if step is None:
                 continue
+            for p in members:
+                self.state[p]['step'] = step
             beta1, beta2 = group['betas']
             v = ops.adam_step_size(step, group['lr'], beta1, beta2)
             if host_out is not None:

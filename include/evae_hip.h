@@ -332,6 +332,7 @@ int evae_conv2d_cl_bwd_weight(const float* dy, const float* x, const evae_conv_d
  *   evae_conv2d_cl_bwd_data_res dx = residual + ELU'(x) * conv_transpose(dy, w), ELU'(x) = (a > 0 ? 1 : a + 1)   (residual = dy)
  * Channel counts with C % 4 == 0, C != 32; the weight gradient is evae_conv2d_cl_bwd_weight on (dy, a). */
 int evae_elu_fwd(const float* x, size_t n, float* out, evae_stream_t stream);
+int evae_conv2d_cl_res_supported(const evae_conv_desc_t* d);   /* 1 when the three *_res / weight-gradient calls of a block take d */
 int evae_conv2d_cl_fwd_res(const float* a, const evae_conv_desc_t* d, const float* w, const float* b, const float* residual,
                            float* out, void* ws, size_t ws_bytes, evae_stream_t stream);
 int evae_conv2d_cl_bwd_data_res(const float* dy, const float* w, const evae_conv_desc_t* d, const float* residual,

@@ -294,6 +294,78 @@ def test_two_captured_steps_on_one_optimizer_keep_their_own_pointer_tables():
         assert rel(p1[kk], p0[kk]) < 2e-5, kk
 
 
+def test_captured_step_after_resuming_a_checkpoint_with_unused_parameters():
+    """density_estimation.py:102's resume flow (load_model -> optimizer.load_state_dict) for single_conv, whose
+    BatchNorm2d parameters never receive a gradient: the trained parameters resume at step N, the unused ones have no state.
+    The runner's first call steps eagerly and learns the participants; the replays continue the eager trajectory, and the
+    unused parameters end with no optimizer state, as in the reference (utils/optimizer.py:50-57)."""
+    from evae.graph import GraphedTrainStep
+    from utils.optimizer import AdamNormGrad
+    from utils.utils import importing_model
+    B, C, N = 4, 24, 60
+    rs = np.random.RandomState(17)
+    data = ((rs.randint(0, 256, (N, 3 * 16 * 16)) + 0.5) / 256).astype(np.float32)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    eps_all = torch.from_numpy(rs.standard_normal((9, B, 16)).astype(np.float32)).cuda()
+    eps_static = torch.zeros((B, 16), device="cuda")
+
+    def make():
+        args = smoke_case.vae_args(model_name="single_conv", input_size=[3, 16, 16], input_type="continuous", bottleneck=1,
+                                   z1_size=16, use_logit=False, number_components=C, training_set_size=N, batch_size=B)
+        model = importing_model(args)(args)
+        model.load_state_dict(seeded_state_dict(model, 77, 0.35))
+        model = model.cuda().train()
+        model._draw_eps = lambda like: eps_static.reshape(like.shape)
+        return model, AdamNormGrad(model.parameters(), lr=5e-4)
+
+    def eager_step(model, opt, it):
+        eps_static.copy_(eps_all[it])
+        xb = torch.from_numpy(data[it * B:(it + 1) * B]).cuda()
+        ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1).cuda()
+        opt.zero_grad()
+        loss, _, _ = model.calculate_loss((xb, ib), 0.5, average=True, dataset=dataset)
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    torch.manual_seed(3)
+    model, opt = make()
+    for it in range(3):
+        eager_step(model, opt, it)
+    ck_model = {k: v.clone() for k, v in model.state_dict().items()}
+    ck_opt = opt.state_dict()
+    import copy
+    ck_opt = copy.deepcopy(ck_opt)
+    n_state = len(ck_opt["state"])
+    assert 0 < n_state < len(list(model.parameters()))            # the unused parameters carry no state
+    results = []
+    for use_graph in (False, True):
+        model, opt = make()
+        model.load_state_dict(ck_model)
+        opt.load_state_dict(copy.deepcopy(ck_opt))
+        torch.manual_seed(5)
+        runner = GraphedTrainStep(model, opt, dataset, B, False) if use_graph else None
+        losses = []
+        for it in range(3, 9):
+            if runner is None:
+                losses.append(eager_step(model, opt, it))
+            else:
+                eps_static.copy_(eps_all[it])
+                xb = torch.from_numpy(data[it * B:(it + 1) * B]).cuda()
+                ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1).cuda()
+                losses.append(runner(xb, ib, 0.5)[0].item())
+        if runner is not None:
+            assert runner.graph is not None and not runner.failed
+        assert len(opt.state_dict()["state"]) == n_state          # no state for parameters the reference would skip
+        steps = {int(st["step"]) for st in opt.state.values() if len(st)}
+        assert steps == {9}
+        results.append((losses, {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}))
+    (l0, p0), (l1, p1) = results
+    assert rel(np.asarray(l1), np.asarray(l0)) < 2e-5
+    for k in p0:
+        assert rel(p1[k], p0[k]) < 5e-5, k
+
+
 # ---- the other architectures (SURVEY 8a rows a12, a14-a16) against goldens of the real reference ----------
 def seeded_state_dict(model, seed, gain=1.0):
     """Same deterministic fill as tools/gen_goldens.py::seeded_state_dict (walks the state_dict in order)."""

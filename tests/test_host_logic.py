@@ -92,6 +92,32 @@ def test_set_beta_and_optimizer_state_layout():
     assert opt.defaults["betas"] == (0.9, 0.999) and opt.defaults["eps"] == 1e-8 and opt.defaults["weight_decay"] == 0
 
 
+def test_captured_step_bookkeeping_skips_parameters_without_a_gradient():
+    """a resumed checkpoint whose unused parameters (fully_conv's BatchNorm2d) carry no state, or another
+    step count, must neither crash the captured step nor get optimizer state the reference would not keep
+    (reference utils/optimizer.py:50-57 skips p.grad is None)."""
+    from utils.optimizer import AdamNormGrad
+    used, unused = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2))
+    opt = AdamNormGrad([used, unused], lr=5e-4)
+    st = opt._init_state(used)
+    st['step'] = 5                                    # a resumed, trained parameter; `unused` has no state at all
+    tables = {}
+    with pytest.raises(RuntimeError):                 # participants unknown: refuse instead of walking every parameter
+        opt.advance_graph_step(host_out=[0.0], tables=tables)
+    used.grad = torch.ones(3)
+    assert opt.learn_members(tables) is True and tables[("members", 0)] == [used]
+    out = [0.0]
+    opt.advance_graph_step(host_out=out, tables=tables)
+    assert opt.state[used]['step'] == 6 and len(opt.state[unused]) == 0
+    assert out[0] == pytest.approx(5e-4 * (1 - 0.999 ** 6) ** 0.5 / (1 - 0.9 ** 6))
+    # participants that disagree: reported by learn_members (the runner then steps eagerly), nothing mutated by advance
+    unused.grad = torch.ones(2)
+    assert opt.learn_members(tables) is False
+    with pytest.raises(RuntimeError):
+        opt.advance_graph_step(host_out=out, tables=tables)
+    assert opt.state[used]['step'] == 6 and opt.state[unused]['step'] == 0
+
+
 def test_he_initializer_statistics():
     from models.VAE import VAE
     torch.manual_seed(0)
