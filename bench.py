@@ -62,11 +62,13 @@ def parse():
                          "trains on its own 100-image batch (global batch 100 N) against the sharded exemplar set ('weak' in "
                          "the batch).  The replica line carries the dp measurement as a nested object (--no-dp-line skips it).")
     ap.add_argument("--no-dp-line", action="store_true", help="with --gpus N > 1: do not run the second (dp) measurement")
+    ap.add_argument("--no-ramp", action="store_true",
+                    help="skip the untimed clock-ramp replays in front of the timed region (10-step windows until two agree to 2 %%)")
     ap.add_argument("--probe-warmup", type=int, default=20,
                     help="untimed eager steps in front of the probe steps (clock ramp after the host pause)")
     ap.add_argument("--probe-steps", type=int, default=20,
                     help="eager steps run after the timed region to time the dominant kernel with HIP events")
-    ap.add_argument("--iwae-images", type=int, default=64,
+    ap.add_argument("--iwae-images", type=int, default=100,
                     help="test images for the IWAE test log p(x) leg (S=5000 samples each vs all 50 000 exemplars); 0 disables")
     ap.add_argument("--cpu-baseline-steps", type=int, default=80,
                     help="oracle steps timed for cpu_baseline (0 disables)")
@@ -85,6 +87,13 @@ def model_args(device, n_exemplars, sharded, shard_batch=False, model_name="vae"
 
 def gated_flops(M, K, N):
     return 2.0 * M * K * 2 * N
+
+
+def step_flops(model_name, n_ex):
+    """Algorithmic flops of one training step: vae = C x 3.03 MFLOP + B x 5.7 MFLOP + 6 B C z."""
+    if model_name != "vae":
+        return None
+    return n_ex * 3.0336e6 + B * 5.7e6 + 6.0 * B * n_ex * Z
 
 
 def cpu_baseline(steps, C=C, N_TRAIN=N_TRAIN):
@@ -143,13 +152,41 @@ def pmc_traffic(name):
     """HBM bytes per launch of a named kernel from the committed PMC passes (profiles/r02_pmc/<name>.json, written by
     tools/profile_collect.py from `rocprofv3 --pmc` runs of the same launch): counters cannot be read from inside the
     process, so the bench line carries the file's number and says where it came from."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc", name + ".json")
-    if os.path.exists(path):
-        try:
-            return json.load(open(path)).get("hbm_bytes_per_launch"), "file:profiles/r02_pmc/%s.json (rocprofv3 --pmc, not measured in this run)" % name
-        except Exception:
-            pass
+    for rnd in ("r03_pmc", "r02_pmc"):
+        path = os.path.join(ROOT, "profiles", rnd, str(name) + ".json")
+        if os.path.exists(path):
+            try:
+                return (json.load(open(path)).get("hbm_bytes_per_launch"),
+                        "file:profiles/%s/%s.json (rocprofv3 --pmc, not measured in this run)" % (rnd, name))
+            except Exception:
+                pass
     return None, None
+
+
+FABRIC_BOUND_BPS = 5e12     # counter bytes / launch time at or above this: the launch sits at the memory fabric, not the matrix pipe
+
+
+def bound_label(traffic_bytes, us, default="mfma"):
+    """'fabric' when the PMC pass of this launch moved >= 5 TB/s through HBM / the L2-miss path (such a
+    launch is traffic-bound whatever its flop count says), else the pipe it computes on."""
+    if traffic_bytes and us and traffic_bytes / (us * 1e-6) >= FABRIC_BOUND_BPS:
+        return "fabric"
+    return default
+
+
+def mfma_roofline(kern, flops, executed, pipe, us, traffic, tsrc, **more):
+    """achieved = ALGORITHMIC flops per launch / mean launch time, frac = achieved / dense peak of the pipe the
+    launch computes on.  The flops actually issued to that pipe (3 x / 6 x algorithmic for the byte / split-bf16 kernels) are
+    reported separately as pipe_busy_frac -- an occupancy figure that agrees with SQ_VALU_MFMA_BUSY_CYCLES, not a roofline
+    fraction."""
+    peak = PEAK_BF16_MFMA_TFLOPS if pipe == "bf16-mfma" else PEAK_FP32_MFMA_TFLOPS
+    tf = flops / us / 1e6
+    r = {"bound": bound_label(traffic, us), "kernel": kern, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+         "frac": round(tf / peak, 4), "pipe": pipe, "pipe_busy_frac": round(executed / us / 1e6 / peak, 4),
+         "executed_tflops": round(executed / us / 1e6, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+         "traffic": traffic, "traffic_source": tsrc, "avg_launch_us": round(us, 2), "flops_per_launch": round(flops)}
+    r.update(more)
+    return r
 
 
 def time_launches(fn, reps=4, pairs=12, warm=6):
@@ -172,7 +209,7 @@ def time_launches(fn, reps=4, pairs=12, warm=6):
 
 def line(metric, value, unit, a, dt, workload, roof, extra=None, world=1, launch="eager"):
     out = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic", "config": {"workload": workload, "launch": launch}, "roofline": roof,
            "cpu_baseline": None}
     out.update(extra or {})
@@ -256,16 +293,11 @@ def other_config(a, dev, rank, world):
                 flops = 2.0 * nimg * hw * hw * ci * k_ * k_ * 2 * co
                 kern = ("channels-last gated conv 32 -> 64, 5x5, 14 x 14, %d images (evae_conv2d_cl_fwd: both filter banks, gate in "
                         "the epilogue)" % nimg)
-        tf = flops / us / 1e6
-        traffic, tsrc = pmc_traffic("conv_fwd_" + a.config)
-        # split-bf16 kernel (csrc/evae_gemm_x6.h): six bf16 partial products per fp32 product, priced against the bf16 pipe
+        traffic, tsrc = pmc_traffic("conv96_fwd" if c5 else "conv5_fwd")
+        # split-bf16 kernel (csrc/evae_gemm_x6.h): six bf16 partial products per fp32 product
         executed, pipe = ops.gemm_pipe(nimg * hw * hw, co, not c5, flops)
-        peak = PEAK_BF16_MFMA_TFLOPS if pipe == "bf16-mfma" else PEAK_FP32_MFMA_TFLOPS
-        roof = {"bound": "mfma", "kernel": kern.replace("gemm_kernel<..., CV = 1>", "gemm_x6_kernel / gemm_kernel<..., CV = 1>"),
-                "achieved": round(executed / us / 1e6, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(executed / us / 1e6 / peak, 4), "pipe": pipe, "algorithmic_tflops": round(tf, 2),
-                "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
-                "avg_launch_us": round(us, 2), "flops_per_launch": round(flops)}
+        roof = mfma_roofline(kern.replace("gemm_kernel<..., CV = 1>", "gemm_x6_kernel / gemm_kernel<..., CV = 1>"), flops, executed,
+                             pipe, us, traffic, tsrc)
         wl = ("single_conv (fully_conv) + exemplar_prior, 3x64x64 continuous, z=256, approximate prior: top-10 over %d cached "
               "latents, <= 1000 exemplars re-encoded per step, batch %d (BASELINE.json configs[4], one GPU)" % (n_ex, B)) if c5 else \
              ("convhvae_2level + exemplar_prior, fashion_mnist-shaped binary 28x28, N=%d, batch %d, %d exemplars, exact prior "
@@ -302,17 +334,12 @@ def other_config(a, dev, rank, world):
             lv = clv[0].contiguous()
             us = time_launches(lambda: ops.prior_lse_fwd(zq, cz, lv), reps=2)
         flops = 2.0 * 4 * args.S * N_TRAIN * Z
-        tf = flops / us / 1e6
-        traffic, tsrc = pmc_traffic("prior_fwd_iwae")
+        traffic, tsrc = pmc_traffic("prior_iwae")
         executed, pipe = ops.gemm_pipe(N_TRAIN, 4 * args.S, False, flops)      # streaming split-bf16 kernel when the pipe is on
-        peak = PEAK_BF16_MFMA_TFLOPS if pipe == "bf16-mfma" else PEAK_FP32_MFMA_TFLOPS
         kname = ("evae::prior_x6_lse_kernel<3> (+ staging pass and split merge; csrc/evae_prior_gemm.hip)" if pipe == "bf16-mfma"
                  else "evae::prior_fwd_mfma_kernel<5, 4> (+ the split merge)")
-        roof = {"bound": "mfma", "kernel": kname + ": 4 x %d importance samples x %d exemplars x z=%d, distance on the matrix "
-                                                   "cores, online log-sum-exp" % (args.S, N_TRAIN, Z),
-                "achieved": round(executed / us / 1e6, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(executed / us / 1e6 / peak, 4),
-                "pipe": pipe, "algorithmic_tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": traffic, "traffic_source": tsrc, "avg_launch_us": round(us, 2), "flops_per_launch": round(flops)}
+        roof = mfma_roofline(kname + ": 4 x %d importance samples x %d exemplars x z=%d, distance on the matrix cores, online "
+                                     "log-sum-exp" % (args.S, N_TRAIN, Z), flops, executed, pipe, us, traffic, tsrc)
         a.steps = n_pass * nimg
         print(json.dumps(line("IWAE test log p(x) images/sec", round(n_pass * nimg / dt, 2), "images/sec", a, dt,
                               "utils.evaluation.calculate_likelihood: vae, S=%d importance samples per test image against all %d "
@@ -324,18 +351,21 @@ def other_config(a, dev, rank, world):
     for tag, Bq, N, zd in (("c2", 100, 25000, 40), ("c5", 100, 100000, 256)):
         z_np, c_np = gi.clustered_latents(3, Bq, N, zd)
         q = torch.from_numpy(z_np).to(dev); cache = torch.from_numpy(c_np).to(dev)
-        us = time_launches(lambda: ops.pairdist_topk(q, cache, 10, want_val=False), reps=2)
+        us = time_launches(lambda: ops.pairdist_topk(q, cache, 10, want_val=False), reps=2)      # k = 10 (approximate_k)
         res.append((tag, Bq, N, zd, us))
     tag, Bq, N, zd, us = res[1]
-    bytes_ = 2.0 * 4 * N * zd
+    kk = 10
+    algo_bytes = lambda Bq_, N_, z_: 4.0 * (N_ * z_ + Bq_ * z_) + 8.0 * Bq_ * kk      # ONE pass over the cache
+    bytes_ = algo_bytes(Bq, N, zd)
     gbs = bytes_ / us / 1e3
     traffic, tsrc = pmc_traffic("topk_c5")
     roof = {"bound": "hbm", "kernel": "evae_pairdist_topk at config 5 (B=%d queries, N=%d cached latents, z=%d, k=10): screening GEMM "
-                                      "passes + exact re-ranking; algorithmic bytes = two streaming passes over the [N x z] cache" % (Bq, N, zd),
+                                      "+ exact re-ranking; algorithmic bytes = 4 (N z + B z) + 8 B k: one streaming pass over the [N x z] cache" % (Bq, N, zd),
             "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
             "traffic_source": tsrc, "avg_launch_us": round(us, 2), "bytes_per_launch": round(bytes_),
             "other_sizes": {r[0]: {"B": r[1], "N": r[2], "z": r[3], "us": round(r[4], 2),
-                                   "GB/s": round(2.0 * 4 * r[2] * r[3] / r[4] / 1e3, 1)} for r in res}}
+                                   "GB/s": round(algo_bytes(r[1], r[2], r[3]) / r[4] / 1e3, 1),
+                                   "frac": round(algo_bytes(r[1], r[2], r[3]) / r[4] / 1e3 / PEAK_HBM_GBS, 4)} for r in res}}
     a.steps = 1
     print(json.dumps(line("top-K cache scan", round(Bq / (us * 1e-6), 1), "queries/sec", a, us * 1e-6,
                           "evae_pairdist_topk: k=10 nearest cached latents per query, bit-exact indices (config 5 sizes; config 2 "
@@ -496,12 +526,37 @@ def main():
 
     for i in range(a.warmup):
         step(i)
+    # Untimed, in front of the timed region (VERDICT r02 #3b): (1) the capture happens here whatever --warmup says (the runner
+    # needs its eager warm-up calls + the capturing call), (2) replays until two consecutive 10-step windows agree to 2 %
+    # (cap 0.5 s): the clocks take tens of milliseconds to come up after the host-side setup, and a 20-step timed region is
+    # 14 ms.  Every rank takes the same decisions (window times are max-reduced).
+    n_pre = a.warmup
+    g_ = state["graphed"]
+    while g_ is not None and state["graphed"] is g_ and g_.graph is None and not g_.failed and n_pre < a.warmup + 8:
+        step(n_pre); n_pre += 1
+    fence()
+    ramp_replays, ramp_ms, prev = 0, 0.0, None
+    while not a.no_ramp and ramp_ms < 500.0:
+        tw = time.perf_counter()
+        for _ in range(10):
+            step(n_pre); n_pre += 1
+        torch.cuda.synchronize()
+        w_ms = 1e3 * (time.perf_counter() - tw)
+        if world > 1:
+            tws = torch.tensor([w_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(tws, op=dist.ReduceOp.MAX)
+            w_ms = float(tws.item())
+        ramp_replays += 10; ramp_ms += w_ms
+        if prev is not None and abs(w_ms - prev) <= 0.02 * max(w_ms, prev):
+            break
+        prev = w_ms
     fence()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        step(a.warmup + i)
+        step(n_pre + i)
     fence()
     dt = time.perf_counter() - t0
+    n_done = n_pre + a.steps
     g_ = state["graphed"]
     loss_sum = float(loss_acc.item()) + (float(g_.totals[0].item()) if g_ is not None else 0.0)
     # Per-kernel timing of the dominant kernel: HIP-event pairs around every GatedDense forward launch.
@@ -512,17 +567,17 @@ def main():
     # the clocks sag during the host pause above and take ~12 eager steps (30 ms) to come back: untimed steps first,
     # otherwise the event pairs time the launch at a lower clock than the timed region (and rocprof's trace of it) ran at
     for i in range(a.probe_warmup if graphed is not None else 0):
-        eager_step(a.warmup + a.steps + i)
+        eager_step(n_done + i)
     ops.PROBE = {"records": [], "min_flops": 2e9 if n_ex >= 10000 and not approx else 2e8}
     for i in range(a.probe_steps if graphed is not None else 0):
-        eager_step(a.warmup + a.steps + a.probe_warmup + i)
+        eager_step(n_done + a.probe_warmup + i)
     fence()
     probe, ops.PROBE = ops.PROBE, None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    final_loss = loss_sum / (a.warmup + a.steps)
+    final_loss = loss_sum / n_done
 
     # roofline: every big GEMM launch of the probe steps was bracketed with a HIP event pair (evae.ops.probed); the dominant
     # kernel is the launch with the largest share of a step
@@ -531,12 +586,22 @@ def main():
         r = agg.setdefault(name, {"us": 0.0, "n": 0, "flops": fl, "executed": ex, "pipe": pipe})
         r["us"] += 1e3 * e0.elapsed_time(e1); r["n"] += 1
     PEAKS = {"fp32-mfma": PEAK_FP32_MFMA_TFLOPS, "bf16-mfma": PEAK_BF16_MFMA_TFLOPS}
+    # PMC pass (tools/kernel_probe.py names) of each launch family at the headline sizes: its counter bytes label the bound
+    pmc_of = (("dense_bwd_weight_u8", "u8wgrad1"), ("gated_dense_fwd_u8", "u8fwd1"), ("dense_bwd_data M=%d N=%d+" % (C, H), "dgrad2"),
+              ("dense_bwd_weight M=", "wgrad2"), ("gated_dense_fwd M=%d K=%d" % (C, H), "fwd2"))
+    headline = a.config == "c2" and n_ex == C
     kernels = []
     for name, r in agg.items():
         us = r["us"] / r["n"]
+        pm = next((f for pre, f in pmc_of if name.startswith(pre)), None) if headline else None
+        traffic, traffic_src = pmc_traffic(pm) if pm else (None, None)
+        peak = PEAKS[r["pipe"]]
         kernels.append({"launch": name, "pipe": r["pipe"], "avg_launch_us": round(us, 2), "launches": r["n"],
-                        "algorithmic_tflops": round(r["flops"] / us / 1e6, 2), "executed_tflops": round(r["executed"] / us / 1e6, 2),
-                        "frac_of_pipe_peak": round(r["executed"] / us / 1e6 / PEAKS[r["pipe"]], 4)})
+                        "algorithmic_tflops": round(r["flops"] / us / 1e6, 2), "frac": round(r["flops"] / us / 1e6 / peak, 4),
+                        "executed_tflops": round(r["executed"] / us / 1e6, 2),
+                        "pipe_busy_frac": round(r["executed"] / us / 1e6 / peak, 4),
+                        "bound": bound_label(traffic, us), "traffic": traffic, "traffic_source": traffic_src,
+                        "flops_per_launch": round(r["flops"])})
     kernels.sort(key=lambda k_: -k_["avg_launch_us"])
     roof = None
     if kernels:
@@ -544,19 +609,18 @@ def main():
         # roofline object itself is the longest SINGLE kernel launch
         single = [k_ for k_ in kernels if "finish" not in k_["launch"]]
         dom = (single or kernels)[0]
-        # HBM traffic of the dominant launch: the PMC pass of that kernel family at these sizes (tools/kernel_probe.py names)
-        pmc_of = (("dense_bwd_weight_u8", "u8wgrad1"), ("gated_dense_fwd_u8", "u8fwd1"), ("dense_bwd_data M=%d N=%d+" % (C, H), "dgrad2"),
-                  ("dense_bwd_weight M=", "wgrad2"), ("gated_dense_fwd M=%d K=%d" % (C, H), "fwd2"))
-        probe = next((f for pre, f in pmc_of if dom["launch"].startswith(pre)), None)
-        traffic, traffic_src = pmc_traffic(probe) if (probe and a.config == "c2" and n_ex == C) else (None, None)
-        roof = {"bound": "mfma", "kernel": dom["launch"] + " -- the longest launch of a step (evae::gemm_kernel / u8_gemm_kernel family)",
-                "achieved": dom["executed_tflops"], "peak": PEAKS[dom["pipe"]], "unit": "TFLOP/s", "frac": dom["frac_of_pipe_peak"],
-                "pipe": dom["pipe"], "algorithmic_tflops": dom["algorithmic_tflops"], "traffic": traffic, "traffic_source": traffic_src,
-                "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
-                "note": "achieved = flops issued to the matrix pipe / launch time; pipe bf16-mfma: fp32 products evaluated as bf16 "
-                        "partial products with fp32 accumulation -- three per product on the uint8 first-layer kernels (bytes are "
-                        "exact in bf16), six per product on the split-bf16 GEMM (csrc/evae_gemm_x6.h: both operands as three-term "
-                        "splits) -- so executed = 3 x or 6 x algorithmic there; pipe fp32-mfma: v_mfma_f32_32x32x2_f32",
+        roof = {"bound": dom["bound"], "kernel": dom["launch"] + " -- the longest launch of a step (evae::gemm_kernel / u8_gemm_kernel family)",
+                "achieved": dom["algorithmic_tflops"], "peak": PEAKS[dom["pipe"]], "unit": "TFLOP/s", "frac": dom["frac"],
+                "pipe": dom["pipe"], "pipe_busy_frac": dom["pipe_busy_frac"], "executed_tflops": dom["executed_tflops"],
+                "frac_of_fp32_mfma_peak": round(dom["algorithmic_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": dom["traffic"], "traffic_source": dom["traffic_source"],
+                "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"], "flops_per_launch": dom["flops_per_launch"],
+                "note": "achieved / frac = ALGORITHMIC flops per launch / mean launch time (HIP events) / dense peak of the pipe "
+                        "the launch computes on (SURVEY 8d).  pipe bf16-mfma: fp32 products evaluated as bf16 partial products with "
+                        "fp32 accumulation -- three per product on the uint8 first-layer kernels, six on the split-bf16 GEMM -- so "
+                        "the pipe issues 3 x / 6 x the algorithmic flops; that occupancy is pipe_busy_frac, not the roofline "
+                        "fraction.  bound = 'fabric' when the launch's PMC pass moved >= 5 TB/s",
+                "step_algorithmic_tflops": round(step_flops(model_name, n_ex) / (dt / a.steps) / 1e12, 2) if step_flops(model_name, n_ex) else None,
                 "kernels": kernels}
 
     # second half of BASELINE.json's metric: test log p(x) (IWAE, S = 5000, all N_train exemplars as the prior)
@@ -582,7 +646,9 @@ def main():
         model.train()
         iwae = {"neg_log_px": round(ll, 3), "images": a.iwae_images, "S": args.S, "exemplars": n_train,
                 "ms_per_image": round(1e3 * t_ll / a.iwae_images, 3),
-                "note": "utils.evaluation.calculate_likelihood on synthetic test images after the benchmark's training steps"}
+                "note": "utils.evaluation.calculate_likelihood on the first %d synthetic test images (SURVEY 8d) after the "
+                        "benchmark's few training steps of a random-init model: a smoke value of the evaluator (timing + finite, "
+                        "parity is tests/), NOT a model-quality number" % a.iwae_images}
 
     gb = B * world if dp else B              # images per step over all ranks
     # collectives of one step, per rank (payload bytes sent = received per rank for an all-gather of R such pieces)
@@ -644,7 +710,7 @@ def main():
         out = {
             "metric": "training images/sec", "value": round(gb * a.steps / dt, 1), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
-            "higher_is_better": True, "scaling": "strong" if (world > 1 and not dp) else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if dp else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "arithmetic": ("fp32 results throughout.  Large forward / data-gradient GEMMs run on the bf16 matrix pipe with every "
                            "fp32 operand split into three bf16 terms (24 mantissa bits) and six partial products accumulated in "
@@ -667,6 +733,7 @@ def main():
                        "launch": "eager" if graphed is None else "hipGraph replay of the whole step"},
             "collectives": coll, "rccl_ranks": rccl_ranks, "backend": backend,
             "dp": dp_line,
+            "ramp_replays": ramp_replays, "ramp_ms": round(ramp_ms, 2), "untimed_steps": n_pre,
             "mean_loss": round(final_loss, 4),
             "roofline": roof,
             "test_log_px": iwae,

@@ -188,7 +188,13 @@ class GraphedTrainStep:
             rows_f = self.data_rows.index_select(0, ii)
             if self.u8:
                 rows_f = rows_f.float() / self.x_div
-            self.by_index = ok and torch.equal(rows_f, data.reshape(self.B, -1).to(self.ctl.device, torch.float32))
+            xf = data.reshape(self.B, -1).to(self.ctl.device, torch.float32)
+            self.by_index = ok and torch.equal(rows_f, xf)
+            if not self.by_index and self.u8 and not torch.equal(torch.round(xf * self.x_div).clamp_(0, 255) / self.x_div, xf):
+                # images that are neither rows of the dataset nor k/255: the byte store's staging rows cannot hold them.  The
+                # eager step checks every batch and takes the fp32 store when it must (models/BaseModel.py); no capture
+                print("evae.graph: the loader's images are not k/255 values; the step is not captured", file=sys.stderr)
+                self.failed = True
         self._ev_up[k].synchronize()              # the upload issued two steps ago from this host buffer is done
         h = self._h_ctl[k]
         # same CPU-generator draw, with replacement, as the reference (models/BaseModel.py:245)

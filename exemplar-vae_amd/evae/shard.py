@@ -57,6 +57,57 @@ def bounds(n, rank=None, world_size=None):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+# ---- evaluation over a sharded latent cache (SURVEY 8e "cached / eval mode: contiguous row blocks of the [N x z] cache") -----------
+# Every rank scores the SAME queries (test images, importance samples) against ITS rows of the cache and the packed partials
+# (max, sumexp, nmask) [3 x S] are all-gathered and merged (ShardedPriorLogP's forward; 60 KB at S = 5000).  The queries are
+# sampled on every rank, so the ranks must draw the same noise: replicated_noise() gives the model a generator seeded with a
+# value rank 0 broadcasts once per evaluation loop (nothing is consumed from any rank's global generators).
+_NOISE_CALLS = [0]
+
+
+def synced_generator(device, group=None):
+    """A torch.Generator on `device` with the same seed on every rank: rank 0's torch.initial_seed() mixed with a per-process
+    call counter (loops called in the same order on every rank count alike), broadcast as one int64."""
+    _NOISE_CALLS[0] += 1
+    seed = (int(torch.initial_seed()) * 6364136223846793005 + 1442695040888963407 * _NOISE_CALLS[0]) & 0x7FFFFFFFFFFFFFFF
+    t = torch.tensor([seed], dtype=torch.int64, device=device)
+    if is_active():
+        dist.broadcast(t, src=0, group=group)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(t.item()))
+    return g
+
+
+class replicated_noise:
+    """with replicated_noise(model, embedding): ... -- while the embedding is a ShardedEmbedding, model._draw_eps draws from a
+    generator that is seeded identically on every rank (models/BaseModel.py::_draw_eps); a no-op for a plain tuple, and for a
+    model whose _draw_eps was replaced on the instance (tests injecting their own noise)."""
+
+    def __init__(self, model, embedding, device=None, group=None):
+        self.model = model
+        self.on = getattr(embedding, 'sharded_total', None) is not None and is_active()
+        self.device, self.group = device, group
+
+    def __enter__(self):
+        if self.on:
+            dev = self.device if self.device is not None else self.model.args.device
+            self.prev = getattr(self.model, '_eps_generator', None)
+            self.model._eps_generator = synced_generator(torch.device(dev), self.group)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.model._eps_generator = self.prev
+        return False
+
+
+def shard_rows(n, group=None):
+    """[lo, hi) of this rank's contiguous block of n cache rows (uneven blocks allowed, see bounds)."""
+    if not is_active():
+        return 0, int(n)
+    return bounds(n, dist.get_rank(group), dist.get_world_size(group))
+
+
 def _all_gather_flat(t, group=None):
     """One all-gather of a contiguous tensor -> [R x *t.shape] (flat 1-D buffers: accepted by RCCL and gloo)."""
     R = dist.get_world_size(group)
@@ -79,6 +130,10 @@ def gather_topk(val, idx, group=None):
 
 def sharded_topk(q, cache_local, k, index_base, sqrt=False, group=None):
     """Exact global top-k over a row-sharded cache: local top-k, one all-gather, merge kernel."""
+    if "topk" in KERNELS:                            # (tests: the oracle standing in for the two device kernels)
+        idx, val = KERNELS["topk"](q, cache_local, k, sqrt, index_base)
+        v, i = gather_topk(val, idx, group)
+        return KERNELS["topk_merge"](v, i)
     if cache_local.shape[0] >= k:
         idx, val = ops.pairdist_topk(q, cache_local, k, sqrt=sqrt, index_base=index_base)
     else:                                            # shard smaller than k (or empty): pad with empties

@@ -110,10 +110,11 @@ class BaseModel(nn.Module, ABC):
         # layer then runs on the bf16 matrix pipe, csrc/evae_dense_u8.hip), fp32 rows otherwise
         u8 = self.resident_u8(dataset, x.shape[0])
         x2 = x.reshape(x.shape[0], -1).float()
-        if u8 is not None and not getattr(self, '_batch_staged', False):
+        if u8 is not None and not getattr(self, '_batch_staged', False) and not torch.cuda.is_current_stream_capturing():
             # eager call: the batch goes into the byte store's staging rows as round(255 x), so x itself has to be k/255 (what
             # the loaders and dynamic binarisation hand out); a batch that is not -- augmented, noisy -- takes the fp32 store
-            # for this call instead of being quantised silently (the captured step checks its loader once, evae/graph.py)
+            # for this call instead of being quantised silently (a capture cannot read a flag back: the captured step checks its
+            # loader's first batch instead, evae/graph.py::_refresh, and steps eagerly when that is not k/255)
             q = torch.round(x2 * self.U8_DIV)
             if not bool(((q >= 0) & (q <= 255) & (q / self.U8_DIV == x2)).all()):
                 u8 = None
@@ -161,6 +162,9 @@ class BaseModel(nn.Module, ABC):
     def _draw_eps(self, like):
         """Standard-normal noise from the device generator (reference :81); tests override this to inject
         identical eps into the reference, the oracle and this model."""
+        g = getattr(self, '_eps_generator', None)      # evaluation over a sharded cache: the same stream on every rank (evae/shard.py)
+        if g is not None:
+            return torch.randn(like.shape, generator=g, device=like.device, dtype=like.dtype)
         return torch.randn_like(like)
 
     def reparameterize(self, mu, logvar):
@@ -343,6 +347,27 @@ class BaseModel(nn.Module, ABC):
             zs.append(m)
             lvs.append(lv)
         return torch.cat(zs, dim=0), torch.cat(lvs, dim=0)
+
+    def cache_z_shard(self, dataset, prior=True):
+        """This rank's contiguous row block of cache_z (cached / eval mode): rows [lo, hi) of the dataset encoded in
+        10 000-row chunks -> ShardedEmbedding((z [n_local x z], logvar, arange(lo, hi)), total = N).  log_p_z merges the ranks'
+        partial log-sum-exps (shard.ShardedPriorLogP); the log-variance keeps at least one row (only row 0 is read, reference
+        BaseModel.py:101), so an empty block is a valid embedding too."""
+        data = self.resident_data(dataset)
+        lo, hi = shard.shard_rows(len(data))
+        step = 10000
+        zs, lvs = [], []
+        for s in range(lo, hi, step):
+            m, lv = self.q_z(data[s:min(s + step, hi)], prior=prior)
+            zs.append(m)
+            lvs.append(lv)
+        if zs:
+            z, lv = torch.cat(zs, dim=0), torch.cat(lvs, dim=0)
+        else:
+            z = torch.zeros((0, self.args.z1_size), device=data.device)
+            lv = self.q_z(data[:1], prior=prior)[1]
+        idx = torch.arange(lo, hi, device=data.device)
+        return shard.ShardedEmbedding((z, lv, idx), total=len(data))
 
     STAGING_ROWS = 1024      # rows kept behind the resident dataset for the current batch (fused path)
 

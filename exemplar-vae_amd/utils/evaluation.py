@@ -9,12 +9,18 @@ import time
 import numpy as np
 import torch
 
+from evae import shard
 from utils.utils import load_model
 
 
 def load_all_pseudo_input(args, model, dataset):
-    """Exemplar embedding of the whole training set: (z [N x z], logvar [N x z], arange(N))."""
+    """Exemplar embedding of the whole training set: (z [N x z], logvar [N x z], arange(N)).  With args.shard_exemplars on a
+    multi-rank run every rank encodes and keeps only its contiguous row block of the cache (models/BaseModel.py::cache_z_shard,
+    SURVEY 8e): the loops below then score the same queries on every rank against 1/R of the exemplars each and merge the
+    packed partial log-sum-exps with one all-gather per call."""
     if args.prior == 'exemplar_prior':
+        if getattr(args, 'shard_exemplars', False) and shard.is_active():
+            return model.cache_z_shard(dataset)
         exemplars_z, exemplars_log_var = model.cache_z(dataset)
         return (exemplars_z, exemplars_log_var, torch.arange(len(exemplars_z)))
     if args.prior == 'vampprior':
@@ -32,10 +38,11 @@ def evaluate_loss(args, model, loader, dataset=None, exemplars_embedding=None):
     if exemplars_embedding is None:
         exemplars_embedding = load_all_pseudo_input(args, model, dataset)
     totals = torch.zeros(3, device=args.device, dtype=torch.float64)
-    for batch in loader:
-        data = batch[0].to(args.device)
-        loss, RE, KL = model.calculate_loss((data, None), average=False, exemplars_embedding=exemplars_embedding)
-        totals += torch.stack((loss.sum(), -RE.sum(), KL.sum())).double()
+    with shard.replicated_noise(model, exemplars_embedding, args.device):
+        for batch in loader:
+            data = batch[0].to(args.device)
+            loss, RE, KL = model.calculate_loss((data, None), average=False, exemplars_embedding=exemplars_embedding)
+            totals += torch.stack((loss.sum(), -RE.sum(), KL.sum())).double()
     elbo, re, kl = (totals / len(loader.dataset)).tolist()
     return elbo, re, kl
 
@@ -55,22 +62,23 @@ def calculate_likelihood(args, model, loader, S=5000, exemplars_embedding=None):
     out = torch.empty(n_img, device=args.device, dtype=torch.float64)
     t0 = time.time()
     done = 0
-    for batch in aux:
-        data = batch[0].to(args.device)
-        data = data.reshape(data.size(0), -1)
-        g = data.size(0)
-        if done // 100 != (done + g) // 100 or done == 0:
-            print(time.time() - t0)
-            t0 = time.time()
-            print('{:.2f}%'.format(done / (1. * n_img) * 100))
-        prob = model.importance_sample_losses(data, S, exemplars_embedding)
-        ll = torch.logsumexp(-prob.double().view(g, S), dim=1)
-        if model.args.use_logit:
-            lambd = model.args.lambd
-            sp = torch.nn.functional.softplus
-            ll = ll - (-sp(-data) - sp(data) - math.log((1 - 2 * lambd) / 256)).sum(dim=1).double()
-        out[done:done + g] = ll - math.log(S)
-        done += g
+    with shard.replicated_noise(model, exemplars_embedding, args.device):
+        for batch in aux:
+            data = batch[0].to(args.device)
+            data = data.reshape(data.size(0), -1)
+            g = data.size(0)
+            if done // 100 != (done + g) // 100 or done == 0:
+                print(time.time() - t0)
+                t0 = time.time()
+                print('{:.2f}%'.format(done / (1. * n_img) * 100))
+            prob = model.importance_sample_losses(data, S, exemplars_embedding)
+            ll = torch.logsumexp(-prob.double().view(g, S), dim=1)
+            if model.args.use_logit:
+                lambd = model.args.lambd
+                sp = torch.nn.functional.softplus
+                ll = ll - (-sp(-data) - sp(data) - math.log((1 - 2 * lambd) / 256)).sum(dim=1).double()
+            out[done:done + g] = ll - math.log(S)
+            done += g
     return -float(out.mean().item())
 
 
