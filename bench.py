@@ -216,10 +216,10 @@ def line(metric, value, unit, a, dt, workload, roof, extra=None, world=1, launch
     return out
 
 
-def other_config(a, dev, rank, world):
+def other_config(a, dev, rank, world, rccl_ranks=1, backend=None):
     """c3 / c5 (the convolutional configurations), iwae (the test log p(x) evaluator), topk (cache + top-K): the same JSON
     line as the headline, each with the roofline object of ITS dominant kernel.  Single GPU."""
-    assert world == 1, "--config %s runs on one GPU" % a.config
+    assert world == 1 or a.config == "iwae", "--config %s runs on one GPU" % a.config
     from argparse import Namespace
     import golden_inputs as gi
     from evae import ops
@@ -307,9 +307,11 @@ def other_config(a, dev, rank, world):
         return
     if a.config == "iwae":
         from models.VAE import VAE
-        from utils.evaluation import calculate_likelihood
+        from utils.evaluation import calculate_likelihood, load_all_pseudo_input
         import contextlib, io
-        args = model_args(str(dev), C, sharded=False)
+        # --gpus N: the [N_train x z] latent cache is split into contiguous row blocks, one per rank (cached / eval
+        # mode); every rank scores the same test images against its block, one all-gather of the packed [3 x 4S] partials per call
+        args = model_args(str(dev), C, sharded=world > 1)
         model = VAE(args).to(dev)
         data = torch.from_numpy(gi.binary_images(0, N_TRAIN))
         dataset = torch.utils.data.TensorDataset(data, torch.arange(N_TRAIN).reshape(-1, 1), torch.zeros(N_TRAIN))
@@ -318,33 +320,51 @@ def other_config(a, dev, rank, world):
         loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(test, torch.zeros(nimg)), batch_size=100)
         model.eval()
         with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
-            cz, clv = model.cache_z(dataset)
-            emb = (cz, clv, torch.arange(len(cz)))
+            emb = load_all_pseudo_input(args, model, dataset)
+            cz, clv = emb[0], emb[1]
             calculate_likelihood(args, model, torch.utils.data.DataLoader(
                 torch.utils.data.TensorDataset(test[:4], torch.zeros(4)), batch_size=4), S=args.S, exemplars_embedding=emb)
+            if world > 1:
+                dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(max(1, a.steps // 50)):
                 ll = calculate_likelihood(args, model, loader, S=args.S, exemplars_embedding=emb)
+            if world > 1:
+                dist.barrier()
             torch.cuda.synchronize()
             n_pass = max(1, a.steps // 50)
             dt = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
             # dominant kernel: the prior's forward for one evaluator pass (4 images x S samples against all N exemplars)
             zq = cz[:1] + 0.3 * torch.randn(4 * args.S, Z, device=dev)
             lv = clv[0].contiguous()
             us = time_launches(lambda: ops.prior_lse_fwd(zq, cz, lv), reps=2)
-        flops = 2.0 * 4 * args.S * N_TRAIN * Z
+        n_loc = int(cz.shape[0])                     # this rank's rows of the cache
+        flops = 2.0 * 4 * args.S * n_loc * Z
         traffic, tsrc = pmc_traffic("prior_iwae")
-        executed, pipe = ops.gemm_pipe(N_TRAIN, 4 * args.S, False, flops)      # streaming split-bf16 kernel when the pipe is on
+        executed, pipe = ops.gemm_pipe(n_loc, 4 * args.S, False, flops)      # streaming split-bf16 kernel when the pipe is on
         kname = ("evae::prior_x6_lse_kernel<3> (+ staging pass and split merge; csrc/evae_prior_gemm.hip)" if pipe == "bf16-mfma"
                  else "evae::prior_fwd_mfma_kernel<5, 4> (+ the split merge)")
         roof = mfma_roofline(kname + ": 4 x %d importance samples x %d exemplars x z=%d, distance on the matrix cores, online "
-                                     "log-sum-exp" % (args.S, N_TRAIN, Z), flops, executed, pipe, us, traffic, tsrc)
+                                     "log-sum-exp" % (args.S, n_loc, Z), flops, executed, pipe, us, traffic if world == 1 else None, tsrc if world == 1 else None)
         a.steps = n_pass * nimg
-        print(json.dumps(line("IWAE test log p(x) images/sec", round(n_pass * nimg / dt, 2), "images/sec", a, dt,
-                              "utils.evaluation.calculate_likelihood: vae, S=%d importance samples per test image against all %d "
-                              "training exemplars (the test-log-p(x) half of BASELINE.json's metric), %d test images per pass"
-                              % (args.S, N_TRAIN, nimg), roof, extra={"neg_log_px": round(float(ll), 3)})))
+        if rank == 0:
+            print(json.dumps(line("IWAE test log p(x) images/sec", round(n_pass * nimg / dt, 2), "images/sec", a, dt,
+                                  "utils.evaluation.calculate_likelihood: vae, S=%d importance samples per test image against all %d "
+                                  "training exemplars (the test-log-p(x) half of BASELINE.json's metric), %d test images per pass"
+                                  % (args.S, N_TRAIN, nimg), roof, world=world,
+                                  extra={"neg_log_px": round(float(ll), 3), "rccl_ranks": rccl_ranks, "backend": backend,
+                                         "parallelism": "single GPU" if world == 1 else
+                                         "latent cache row-sharded x%d (%d rows on rank 0), same test images on every rank, one "
+                                         "all-gather of packed partial log-sum-exps per call" % (world, n_loc),
+                                         "collectives": None if world == 1 else
+                                         {"per_call": 1, "bytes_per_call": 12 * 4 * args.S, "list": ["all_gather partial (max, sumexp, nmask) [3 x 4S]"]}})))
+        if world > 1:
+            dist.destroy_process_group()
         return
     # topk: models/BaseModel.py:263-264 (distance + topk over the candidate cache), utils/knn_on_latent.py:4-9
     res = []
@@ -427,7 +447,7 @@ def main():
         dist.all_reduce(t1)                              # a real collective: every rank contributed
         rccl_ranks, backend = int(round(float(t1.item()))), dist.get_backend()
     if a.config in ("c3", "c5", "iwae", "topk"):
-        return other_config(a, dev, rank, world)
+        return other_config(a, dev, rank, world, rccl_ranks, backend)
     model_name, c_default, n_train = MLP_CONFIGS[a.config]
     n_ex = a.exemplars if a.exemplars is not None else c_default
 

@@ -171,3 +171,85 @@ def test_two_rank_data_parallel_batches_match_single_process_global_batch():
         assert params.pop("__flat__")[0] == 1.0
         for k in params:
             assert rel(params[k], single[2][k]) < 3e-4, (rank, k)
+
+
+# ---- evaluation over a row-sharded latent cache (SURVEY 8e cached / eval mode; reference utils/evaluation.py:15-41,56-103) ----
+def _run_eval(rank, world, port, q, model_name):
+    for p in (os.path.join(ROOT, "exemplar-vae_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import contextlib, io
+    import evae_oracle as orc
+    import golden_inputs as gi
+    import smoke_case
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from evae import shard
+        from utils import evaluation, knn_on_latent
+        from utils.utils import importing_model
+        Ntr, Nte, S = 2003, 24, 200                       # odd N: row blocks of 1002 / 1001
+        data = gi.binary_images(5, Ntr)
+        test = gi.binary_images(6, Nte)
+        dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(Ntr).reshape(-1, 1), torch.arange(Ntr) % 10)
+        test_ds = torch.utils.data.TensorDataset(torch.from_numpy(test), torch.arange(Nte) % 10)
+        loader = torch.utils.data.DataLoader(test_ds, batch_size=8)
+        args = smoke_case.vae_args(model_name=model_name, number_components=500, training_set_size=Ntr, batch_size=8,
+                                   shard_exemplars=world > 1)
+        torch.manual_seed(5); torch.cuda.manual_seed(5)
+        model = importing_model(args)(args).cuda()
+        model.eval()
+        torch.manual_seed(21 + 100 * rank)                # the ranks' own generators disagree: rank 0's broadcast seed decides
+        shard._NOISE_CALLS[0] = 0
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            emb = evaluation.load_all_pseudo_input(args, model, dataset)
+            if world > 1:
+                lo, hi = shard.bounds(Ntr)
+                assert emb.sharded_total == Ntr and emb[0].shape[0] == hi - lo
+                elbo = evaluation.evaluate_loss(args, model, loader, exemplars_embedding=emb)
+                ll = evaluation.calculate_likelihood(args, model, loader, S=S, exemplars_embedding=emb)
+            else:                                         # one process: the same generators the sharded loops build
+                model._eps_generator = shard.synced_generator(torch.device("cuda"))
+                elbo = evaluation.evaluate_loss(args, model, loader, exemplars_embedding=emb)
+                model._eps_generator = shard.synced_generator(torch.device("cuda"))
+                ll = evaluation.calculate_likelihood(args, model, loader, S=S, exemplars_embedding=emb)
+                model._eps_generator = None
+            knn = {str(k): [] for k in (3, 7)}
+            tl = torch.utils.data.DataLoader(dataset, batch_size=8)
+            knn_on_latent.report_knn_on_latent(tl, loader, loader, model, "", knn, args, val=True)
+            zq = model.q_z(torch.from_numpy(test).cuda(), prior=True)[0]
+            zr = knn_on_latent._posterior_means(model, torch.from_numpy(data).cuda(), 8, sharded=world > 1)
+            nn_idx = knn_on_latent.find_nearest_neighbors(zq, zr, None).cpu().numpy()
+        q.put((rank, elbo, ll, nn_idx, knn))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model_name", ["vae", "hvae_2level"])
+def test_two_rank_sharded_evaluation_matches_single(model_name):
+    """load_all_pseudo_input -> cache_z_shard, evaluate_loss, calculate_likelihood (IWAE) and the latent kNN with the cache split
+    over two ranks == the single-process values on the same noise (ELBO / LogL to 1e-6, neighbour lists bit-exact)."""
+    ctx = mp.get_context("spawn")
+
+    def spawn(world):
+        qq = ctx.Queue()
+        port = 30300 + (os.getpid() % 1000) + (3 if model_name == "vae" else 11)
+        procs = [ctx.Process(target=_run_eval, args=(r, world, port, qq, model_name)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([qq.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return res
+    single = spawn(1)[0]
+    double = spawn(2)
+    rel = lambda a, b: abs(a - b) / max(abs(b), 1e-30)
+    for rank, elbo, ll, nn_idx, knn in double:
+        for a, b in zip(elbo, single[1]):
+            assert rel(a, b) < 1e-6, (rank, elbo, single[1])
+        assert rel(ll, single[2]) < 1e-6, (rank, ll, single[2])
+        assert np.array_equal(nn_idx, single[3])
+        assert knn == single[4] and all(np.isfinite(v).all() for v in knn.values())

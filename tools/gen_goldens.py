@@ -329,6 +329,17 @@ G19_CASES = {      # the other input geometries of the reference's datasets: RGB
 }
 
 
+G21_CASES = {      # the same single_conv geometry at gain 1 (|log p| ~ 5e7, gradients ~ 1e8 in the reference too):
+    # what an untrained He-initialised net does in fp32 -- finite, and equal to the reference to fp32 noise at that magnitude
+    "single_conv_mnist_gain1": dict(model_name="single_conv", input_size=[1, 28, 28], input_type="binary", bottleneck=6,
+                                    z1_size=294, B=4, C=16, N=40, gain=1.0),
+}
+
+
+def g21():
+    _model_cases(G21_CASES, "g21_single_conv_gain1")
+
+
 def g9():
     _model_cases(G9_CASES, "g9_models")
 
@@ -755,6 +766,6 @@ def g18():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g6_conv", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
+    which = sys.argv[1:] or ["g1_g2", "g3", "g4", "g5", "g6", "g6_conv", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
     for w in which:
         globals()[w]()
