@@ -258,20 +258,25 @@ extern "C" size_t evae_dense_bwd_data_workspace_bytes(int M, int N, int K, int n
 
 // wT_ext: the transposed weights of the split-bf16 path ([npairs][K][x6_wt_ld(N)], evae_transpose_pairs / the step-head
 // launch) when the caller already has them -- they depend on the weights alone; NULL: transposed here, into the workspace.
+// img: (dh, dg) leave as the bf16 tile images of evae_dense_bwd_weight_u8 (EPI_GATE_BWD_IMG) instead of fp32 rows
+struct ImgSink { unsigned short* img; int nslab, mbase; };
+
 static int dense_bwd_data_core(const float* dy1, const float* w1, const float* dy2, const float* w2,
                                int M, int N, int ldy, int K, const float* out_prev, const float* s_prev,
                                float* dx_or_dh, float* dg, int ldo, const float* wT_ext, void* ws, size_t ws_bytes,
-                               evae_stream_t stream_) {
+                               evae_stream_t stream_, const ImgSink* sink = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
-  EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldy >= N && ldo >= K, "dense_bwd_data: bad sizes M=%d N=%d K=%d", M, N, K);
+  EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldy >= N && (sink || ldo >= K), "dense_bwd_data: bad sizes M=%d N=%d K=%d", M, N, K);
   if (M == 0) return EVAE_OK;
-  EVAE_REQUIRE(dy1 && w1 && dx_or_dh, "dense_bwd_data: null pointer");
+  EVAE_REQUIRE(dy1 && w1 && (dx_or_dh || sink), "dense_bwd_data: null pointer");
   EVAE_REQUIRE((dy2 == nullptr) == (w2 == nullptr), "dense_bwd_data: dy2/w2 must come together");
   const bool gate = out_prev != nullptr;
-  EVAE_REQUIRE(!gate || (s_prev && dg), "dense_bwd_data: gate fusion needs out_prev, s_prev and dg");
+  EVAE_REQUIRE(!gate || (s_prev && (dg || sink)), "dense_bwd_data: gate fusion needs out_prev, s_prev and dg");
   const int np = dy2 ? 2 : 1;
   Plan pl = make_plan(M, K, total_slabs(N, np > 1 ? N : 0), false, false, 1);
+  if (sink) { pl.nz = 1; pl.ksplit = 0; }          // the image epilogue lives in the GEMM itself: no split-K
   GemmArgs g = {};
+  if (sink) { g.img = sink->img; g.img_nslab = sink->nslab; g.img_mbase = sink->mbase; }
   g.ones_col = -1;
   g.A[0] = dy1; g.B[0] = w1; g.lda[0] = ldy; g.ldb[0] = K; g.Kc[0] = N; g.npairs = np;
   if (dy2) { g.A[1] = dy2; g.B[1] = w2; g.lda[1] = ldy; g.ldb[1] = K; g.Kc[1] = N; }
@@ -295,6 +300,11 @@ static int dense_bwd_data_core(const float* dy1, const float* w1, const float* d
   }
   if (pl.nz <= 1) {
     const bool narrow = x6 && gemm_x6_pick_bn(M, K) == 64;
+    if (sink) {
+      if (x6 && narrow) return launch_gemm_x6<EPI_GATE_BWD_IMG, 0, 64>(g, 1, stream, "dense_bwd_data(gate, bf16 tile images, x6)");
+      if (x6) return launch_gemm_x6<EPI_GATE_BWD_IMG>(g, 1, stream, "dense_bwd_data(gate, bf16 tile images, x6)");
+      return launch_gemm<true, false, EPI_GATE_BWD_IMG>(g, pl, stream, "dense_bwd_data(gate, bf16 tile images)");
+    }
     if (x6 && gate && narrow) return launch_gemm_x6<EPI_GATE_BWD, 0, 64>(g, 1, stream, "dense_bwd_data(gate, x6)");
     if (x6 && gate) return launch_gemm_x6<EPI_GATE_BWD>(g, 1, stream, "dense_bwd_data(gate, x6)");
     if (x6 && narrow) return launch_gemm_x6<EPI_LINEAR, 0, 64>(g, 1, stream, "dense_bwd_data(x6)");
@@ -346,33 +356,30 @@ extern "C" int evae_dense_bwd_data_wt(const float* dy1, const float* w1, const f
 // weight gradient of evae_dense_bwd_weight_u8 reads (see EPI_GATE_BWD_IMG), not as an fp32 [M x 2K] buffer.
 extern "C" int evae_dense_bwd_data_img(const float* dy1, const float* w1, const float* dy2, const float* w2, int M, int N,
                                        int ldy, int K, const float* out_prev, const float* s_prev, void* img, int img_nslab,
-                                       int m_base, evae_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+                                       int m_base, const float* wT, void* ws, size_t ws_bytes, evae_stream_t stream_) {
   EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldy >= N, "dense_bwd_data_img: bad sizes M=%d N=%d K=%d", M, N, K);
   if (M == 0) return EVAE_OK;
   EVAE_REQUIRE(dy1 && w1 && out_prev && s_prev && img, "dense_bwd_data_img: null pointer");
-  EVAE_REQUIRE((dy2 == nullptr) == (w2 == nullptr), "dense_bwd_data_img: dy2/w2 must come together");
-  EVAE_REQUIRE(M % 4 == 0 && m_base % 4 == 0 && m_base >= 0 && img_nslab > 0 && (long long)m_base + M <= (long long)img_nslab * 32,
-               "dense_bwd_data_img: rows must come in aligned fours inside the image (M=%d m_base=%d nslab=%d)", M, m_base, img_nslab);
-  const int np = dy2 ? 2 : 1;
-  Plan pl = make_plan(M, K, total_slabs(N, np > 1 ? N : 0), false, false, 1);
-  pl.nz = 1; pl.ksplit = 0;                      // the image epilogue lives in the GEMM itself: no split-K
-  GemmArgs g = {};
-  g.ones_col = -1;
-  g.A[0] = dy1; g.B[0] = w1; g.lda[0] = ldy; g.ldb[0] = K; g.Kc[0] = N; g.npairs = np;
-  if (dy2) { g.A[1] = dy2; g.B[1] = w2; g.lda[1] = ldy; g.ldb[1] = K; g.Kc[1] = N; }
-  g.M = M; g.N = K; g.ldo = K; g.e0 = out_prev; g.e1 = s_prev;
-  g.img = (unsigned short*)img; g.img_nslab = img_nslab; g.img_mbase = m_base;
-  return launch_gemm<true, false, EPI_GATE_BWD_IMG>(g, pl, stream, "dense_bwd_data(gate, bf16 tile images)");
+  EVAE_REQUIRE(m_base % 8 == 0 && m_base >= 0 && img_nslab > 0 && (long long)m_base + M <= (long long)img_nslab * 32,
+               "dense_bwd_data_img: the launch's first image row must be a multiple of 8 inside the image (M=%d m_base=%d nslab=%d)",
+               M, m_base, img_nslab);
+  const ImgSink sink = {(unsigned short*)img, img_nslab, m_base};
+  return dense_bwd_data_core(dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, nullptr, nullptr, K, wT, ws, ws_bytes, stream_, &sink);
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------
 // The bias gradient db = column sums of dy is folded into the same GEMM: x gets a virtual all-ones
 // column K (never read from memory), so column K of dy^T [x | 1] is db.
+// partial planes the workspace must hold: whichever of the three split-K plans the launch ends up taking
+static int wgrad_max_planes(int M, int N, int K) {
+  const Plan pl = make_plan(N, K + 1, cdiv(M, BK), false, true, 1);
+  const Plan pll = make_plan_local(N, K + 1, cdiv(M, BK));
+  return std::max(std::max(pl.nz, pll.nz), x6t_split(M, N, K + 1).nz);
+}
+
 extern "C" size_t evae_dense_bwd_weight_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 256;
-  Plan pl = make_plan(N, K + 1, cdiv(M, BK), false, true, 1);
-  return align_up((size_t)std::max(pl.nz, x6t_split(M, N, K + 1).nz) * N * (K + 1) * sizeof(float), 256) + 256;
+  return align_up((size_t)wgrad_max_planes(M, N, K) * N * (K + 1) * sizeof(float), 256) + 256;
 }
 
 // phase 0: both launches; 1: the split-K GEMM into the workspace partials; 2: the finish (sum of the partial planes in a fixed
@@ -407,6 +414,11 @@ static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const f
   GemmArgs g = {};
   g.A[0] = dy; g.B[0] = x; g.lda[0] = ldy; g.ldb[0] = ldx; g.Kc[0] = M; g.npairs = 1;
   g.b_krows = rows; g.M = N; g.N = Kp; g.out0 = part; g.ldo = Kp; g.ones_col = K;
+  // a long contraction (the exemplar rows): slices laid out XCD by XCD, one round of blocks (see gemm_kernel, sk_local)
+  if (sk_local_enabled() && cdiv(M, BK) >= 256) {
+    const Plan pll = make_plan_local(N, Kp, cdiv(M, BK));
+    if (pll.nz >= 2 && pll.nz <= wgrad_max_planes(M, N, K)) { pl = pll; g.sk_local = pll.nz; }
+  }
   // both operands k-major: the transposing variant of the split-bf16 kernel when the product is large AND its 128-wide column
   // tiles are well filled -- measured: K = 784 (785 of 896 columns) 240 vs 260 us, K = 300 (301 of 384) 116 vs 119 us: at 78 %
   // fill the fp32 kernel's 64-wide tiles are as fast

@@ -65,17 +65,32 @@ __global__ __launch_bounds__(U8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const unsigned short* __restrict__ img, int nslab_total, int ksplit, const float* __restrict__ bh,
     const float* __restrict__ bg, int N, float* __restrict__ out, float* __restrict__ save_s, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // XCD-aware bijective remap (as the fp32 GEMM): XCD x = id % 8 works on a contiguous run of tiles
-  const int ntiles = tiles_m * tiles_n;
-  int tile;
-  {
+  int tm, tn, zs = 0;
+  if constexpr (GATED) {
+    // XCD-aware bijective remap (as the fp32 GEMM): XCD x = id % 8 works on a contiguous run of tiles
+    const int ntiles = tiles_m * tiles_n;
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int qq = ntiles >> 3, rr = ntiles & 7;
-    tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+    tm = tile / tiles_n; tn = tile - tm * tiles_n;
+  } else {
+    // Split-K weight gradient: the tiles_m row tiles (pixels) of one UNIT = (contraction slice z, column tile tn) read the same
+    // three-term dy^T images -- the heavy operand, 6 bytes per element -- so a unit's blocks sit on ONE XCD, dispatched
+    // back to back (ids 8 j + x -> XCD x): they walk the slice in step and all but the first find every image slab in that
+    // XCD's L2.  Units are ordered z-major and dealt to the XCDs in contiguous runs, so the column tiles of a slice (which
+    // share the byte rows) mostly meet on one XCD too.  (r02: every (row tile x column tile x slice) block streamed both
+    // operands past its XCD's L2: 710 MB read per launch against 110 MB of operands.)
+    const int nunits = ((nslab_total + ksplit - 1) / ksplit) * tiles_n;      // slices x column tiles; the grid is 1-D
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int qq = nunits >> 3, rr = nunits & 7;
+    const int ul = slot / tiles_m;
+    if (ul >= qq + (xcd < rr ? 1 : 0)) return;                // this XCD has one unit less than the grid allows for
+    const int u = xcd * qq + (xcd < rr ? xcd : rr) + ul;
+    tm = slot - ul * tiles_m;
+    zs = u / tiles_n; tn = u - zs * tiles_n;
   }
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * U8_BM, n0 = tn * (GATED ? U8_BN : 2 * U8_BN);
-  const int s_begin = blockIdx.y * ksplit;
+  const int s_begin = zs * ksplit;
   const int s_end = (s_begin + ksplit < nslab_total) ? s_begin + ksplit : nslab_total;
   const int nslab = s_end - s_begin;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(U8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         }
     }
   } else {
-    float* part = out + (size_t)blockIdx.y * M * N;
+    float* part = out + (size_t)zs * M * N;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       const int n = n0 + wc * 64 + cb * 32 + l31;
@@ -275,16 +290,46 @@ __global__ __launch_bounds__(256) void u8_prepare_dyT_kernel(const float* __rest
   for (int i = 0; i < 6; ++i) dst[t + 256 * i] = src[t + 256 * i];
 }
 
-// dw[n][k] = x_scale * sum_z part[z][k][n] (k < K), db[n] = sum_z part[z][K][n]; fixed order
-__global__ void u8_wgrad_finish_kernel(const float* __restrict__ part, int nz, int K, int N, float x_scale,
-                                       float* __restrict__ dw, float* __restrict__ db) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (size_t)(K + 1) * N) return;
-  const int k = (int)(e / N), n = (int)(e - (size_t)k * N);
-  float a = 0.f;
-  for (int z = 0; z < nz; ++z) a += part[((size_t)z * (K + 1) + k) * N + n];
-  if (k < K) dw[(size_t)n * K + k] = a * x_scale;
-  else if (db) db[n] = a;
+// dw[n][k] = x_scale * sum_z part[z][k][n] (k < K), db[n] = sum_z part[z][K][n]; fixed order.  32 x 32 tiles through LDS: the
+// planes are read along n and dw is written along k, both in full 128-byte runs (r02 wrote dw with a stride of K floats per
+// lane: 10.7-16 us for 1.9 MB; the sum over 14 planes is not what cost).
+__global__ __launch_bounds__(256) void u8_wgrad_finish_kernel(const float* __restrict__ part, int nz, int K, int N, float x_scale,
+                                                              float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t plane = (size_t)(K + 1) * N;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  const int n = n0 + tx;
+  // eight planes' worth of loads in flight before the first add (the launch is two blocks per CU: one dependent load per
+  // plane was 14 memory latencies in a row, 19 us); the sum runs over z in ascending order whatever the grouping
+  for (int z0 = 0; z0 < nz; z0 += 8) {
+    float v[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + 8 * i;
+        const bool ok = z0 + j < nz && k <= K && n < N;
+        v[j][i] = ok ? part[(size_t)(z0 + j) * plane + (size_t)k * N + n] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] += v[j][i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + 8 * i;
+    tile[ty + 8 * i][tx] = a[i];
+    if (k == K && n < N && db) db[n] = a[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nn = n0 + ty + 8 * i, k = k0 + tx;
+    if (nn < N && k < K) dw[(size_t)nn * K + k] = tile[tx][ty + 8 * i] * x_scale;
+  }
 }
 
 }  // namespace evae
@@ -336,11 +381,15 @@ static U8WgradLayout u8_wgrad_layout(int M, int N, int K) {
   L.nslab = cdiv(M, U8_BK);
   L.ldt = (long long)L.nslab * U8_BK + 32;                  // 16-byte rows, slack for the last slab
   L.tiles_k = cdiv(K + 1, U8_BM); L.tiles_n = cdiv(N, 2 * U8_BN);
-  // split the contraction so that ONE round of 512 resident blocks is in flight: measured at 25 100 x 600 x 784 (entry point)
-  // 512 -> 163 us, 768 -> 179, 1024 -> 175, 1536 -> 187: every slice more is another [785 x 600] partial plane written and read
+  // Split the contraction so that ONE round of resident blocks is in flight and every XCD holds whole units (a unit = the
+  // tiles_k row tiles of one (slice, column tile), see u8_gemm_kernel<false>): 64 block slots per XCD (32 CUs x 2) ->
+  // floor(64 / tiles_k) units per XCD.  25 100 x 600 x 784: 7 row tiles, 9 units per XCD, 72 / 5 column tiles -> 14 slices
+  // (r02 measured the entry point at 512 -> 163 us, 768 -> 179, 1024 -> 175, 1536 -> 187 blocks: every slice more is
+  // another [785 x 600] partial plane written and read)
   static int slots = -1;
   if (slots < 0) { const char* e = getenv("EVAE_U8_WGRAD_SLOTS"); slots = e ? atoi(e) : 512; }
-  int nz = slots / (L.tiles_k * L.tiles_n);
+  const int per_xcd = std::max(1, (slots / 8) / L.tiles_k);
+  int nz = (8 * per_xcd) / L.tiles_n;
   if (nz > L.nslab) nz = L.nslab;
   if (nz < 1) nz = 1;
   L.ksplit = cdiv(L.nslab, nz);
@@ -401,12 +450,12 @@ static int dense_bwd_weight_u8_core(const float* dy, int M, int N, long long ldy
     (void)hipFuncSetAttribute((const void*)u8_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * U8_STAGE);
     attr = true;
   }
-  u8_gemm_kernel<false><<<dim3(L.tiles_k * L.tiles_n, L.nz), U8_NT, 2 * U8_STAGE, stream>>>(
+  const int units = L.nz * L.tiles_n;
+  u8_gemm_kernel<false><<<8 * L.tiles_k * cdiv(units, 8), U8_NT, 2 * U8_STAGE, stream>>>(
       xT, nullptr, K + 1, L.ldt, 1.0f, img, L.nslab, L.ksplit, nullptr, nullptr, N, part, nullptr, L.tiles_k, L.tiles_n);
   rc = check_launch("u8_gemm_kernel<raw>");
   if (rc) return rc;
-  const size_t n = (size_t)(K + 1) * N;
-  u8_wgrad_finish_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(part, L.nz, K, N, x_scale, dw, db);
+  u8_wgrad_finish_kernel<<<dim3(cdiv(K + 1, 32), cdiv(N, 32)), 256, 0, stream>>>(part, L.nz, K, N, x_scale, dw, db);
   return check_launch("u8_wgrad_finish_kernel");
 }
 

@@ -243,6 +243,38 @@ static Plan make_plan(int M, int N, int slabs, bool gated, bool must_split, int 
 }
 
 
+// Split-K plan for the XCD-local block mapping of gemm_kernel (GemmArgs::sk_local): ONE round of resident blocks in which every
+// XCD holds whole units (a unit = the column tiles of one (slice, row tile)): 64 block slots per XCD -> floor(64 / tiles_n)
+// units per XCD -> at most 8 floor(64 / tiles_n) / tiles_m slices.  Returns nz = 0 when the shape does not fit the scheme.
+static Plan make_plan_local(int M, int N, int slabs) {
+  Plan best = {64, 0, slabs};
+  double best_t = 1e30;
+  const int bns[2] = {128, 64};
+  for (int bi = 0; bi < 2; ++bi) {
+    const int bn = bns[bi];
+    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, bn);
+    const int per_xcd = 64 / tiles_n;
+    if (per_xcd < 1) continue;
+    int nz = (8 * per_xcd) / tiles_m;
+    if (nz > slabs) nz = slabs;
+    if (nz < 2) continue;
+    const int ks = cdiv(slabs, nz), nze = cdiv(slabs, ks);
+    if (nze < 2) continue;
+    const double slab_cost = bn == 64 ? 0.6 : 1.0;
+    // blocks per CU decide the pace: a column-tile count that leaves CUs with one block wastes them
+    const double fill = (double)(cdiv(nze * tiles_m, 8) * tiles_n) / 64.0;
+    const double t = (ks + 1.5) * slab_cost / (fill > 0.5 ? 1.0 : 2.0 * fill) + 3.0 + (double)M * N * nze * 4.0 / 12e6;
+    if (t < best_t) { best_t = t; best = {bn, nze, ks}; }
+  }
+  return best;
+}
+
+static bool sk_local_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EVAE_SK_LOCAL"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  return on == 1;
+}
+
 static int launch_finish(const FinishArgs& f, hipStream_t stream) {
   size_t n = (size_t)f.M * f.N;
   if (f.nz >= 16 && n * 8 <= ((size_t)1 << 22))

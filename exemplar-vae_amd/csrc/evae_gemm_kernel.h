@@ -92,6 +92,7 @@ struct GemmArgs {
   unsigned short* img;
   int img_nslab, img_mbase;
   int ldo2;                // EPI_DIST_TILEMIN: > 0 = tile minima stored query-major, out0[n * ldo2 + tile] (else out0[tile * ldo + n])
+  int sk_local;            // > 0: XCD-local split-K mapping on a 1-D grid, value = number of slices (see gemm_kernel)
   int direct;              // EPI_RAW without split-K: out0[m * ldo + n] for n != ones_col, out1[m] for n == ones_col (a weight
                            // gradient over a few rows writes dw / db itself: no partial plane, no finish launch)
 };
@@ -218,10 +219,11 @@ struct TileLoader {
 // acc[mt][nt] in the 32x32 C/D layout with NW/2 wave rows x 2 wave columns.
 template <int EPI, int BN_, int NW, int CV>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8 / NW][BN_ / 64], const int m0, const int n0,
-                                              const int tm, const int wr, const int wc, const int lane, float* smem) {
+                                              const int tm, const int wr, const int wc, const int lane, float* smem,
+                                              const int zslice) {
   constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
   constexpr int MT = 8 / NW, NT = BN_ / 64;
-  (void)GATED; (void)tm;
+  (void)GATED; (void)tm; (void)zslice;
   // ---- epilogue.  acc[mt][nt][r] <-> row m0 + wr*32*MT + mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
   //                                    col (within the wave tile) nt*32 + (lane&31)
   const int l31 = lane & 31, lh = lane >> 5;
@@ -452,7 +454,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
           } else if (m < g.M) {
             {          // EPI_RAW_GATED: partial planes [z][2][M][N]
               const size_t plane = (size_t)g.M * g.N;
-              const size_t o = (size_t)blockIdx.z * 2 * plane + (size_t)m * g.N + n;
+              const size_t o = (size_t)zslice * 2 * plane + (size_t)m * g.N + n;
               g.out0[o] = acc[mt][0][r];
               g.out0[o + plane] = acc[mt][NT - 1][r];
             }
@@ -460,15 +462,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
         }
     }
   } else if constexpr (EPI == EPI_GATE_BWD_IMG) {
-    // dh = v s, dg = v (h s)(1 - s) as in EPI_GATE_BWD; column cc of the merged [dh | dg] buffer is n (dh) / N + n (dg).  A lane
-    // holds four consecutive rows per r-group: as bf16 terms they are 8 bytes of one 16-byte slot of the image
+    // dh = v s, dg = v (h s)(1 - s) as in EPI_GATE_BWD; column cc of the merged [dh | dg] buffer is n (dh) / N + n (dg).  The
+    // values leave as the bf16 tile images the byte layer's weight gradient reads (u8_gemm_kernel<false>'s B operand):
     //   img[((cc >> 7) * nslab + (row >> 5)) * 3 + p][cc & 127][slot (row & 31) >> 3, XOR-swizzled][row & 7]
-    // (truncation split: w0 = top 8 significant bits, w1 of w - w0, w2 the rest: exact).  Rows must come in aligned fours
-    // (M % 4 == 0, img_mbase % 4 == 0: checked by the host).
+    // (truncation split: w0 = top 8 significant bits, w1 of w - w0, w2 the rest: exact).  A lane holds rows 8 j + 4 lh .. + 3 of
+    // its column, its partner lane ^ 32 the other four of the same eight: the two swap halves (one cross-lane move per
+    // dword), so every lane stores whole 16-byte slots -- lanes lh = 0 the even j, lanes lh = 1 the odd j.  (r02 stored 8-byte
+    // halves: twice the store instructions, each touching 64 lines.)  The image row of this launch's row 0 (img_mbase) must
+    // be a multiple of 8; rows between M and the next multiple of 8 are written as zeros (they must not belong to
+    // another launch: the host places the shorter launch last).
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = n0 + wc * 32 * NT + nt * 32 + l31;
-      if (n >= g.N) continue;
+      if (n >= g.N) continue;                      // (the partner lane has the same n: the pair leaves together)
       float go[MT][16], sv[MT][16];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -482,33 +488,49 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ml = m0 + wr * 32 * MT + mt * 32 + 8 * j + 4 * lh;      // first of four rows (local)
-          if (ml >= g.M) continue;
-          const int gm = ml + g.img_mbase, slab = gm >> 5, mi = gm & 31;
+        for (int which = 0; which < 2; ++which) {
+          const int cc = which ? g.N + n : n;
+          const int c = cc & 127;
+          unsigned t[4][3][2];                      // [r-group j][term][dword]: four rows of one term = 8 bytes
 #pragma unroll
-          for (int which = 0; which < 2; ++which) {
-            const int cc = which ? g.N + n : n;
-            const int c = cc & 127;
-            unsigned t0[2] = {0u, 0u}, t1[2] = {0u, 0u}, t2[2] = {0u, 0u};
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) t[j][q][0] = t[j][q][1] = 0u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int r = 4 * j + i;
+              const int m = m0 + wr * 32 * MT + mt * 32 + 8 * j + 4 * lh + i;
               const float v = acc[mt][nt][r], s_ = sv[mt][r];
-              const float w = which ? v * go[mt][r] * (1.0f - s_) : v * s_;
+              float w = which ? v * go[mt][r] * (1.0f - s_) : v * s_;
+              if (m >= g.M) w = 0.f;
               const unsigned u0 = __float_as_uint(w) & 0xFFFF0000u;
               const float r1 = w - __uint_as_float(u0);
               const unsigned u1 = __float_as_uint(r1) & 0xFFFF0000u;
               const float r2 = r1 - __uint_as_float(u1);
               const unsigned u2 = __float_as_uint(r2);
               const int sh = 16 * (i & 1);
-              t0[i >> 1] |= (u0 >> 16) << sh; t1[i >> 1] |= (u1 >> 16) << sh; t2[i >> 1] |= (u2 >> 16) << sh;
+              t[j][0][i >> 1] |= (u0 >> 16) << sh; t[j][1][i >> 1] |= (u1 >> 16) << sh; t[j][2][i >> 1] |= (u2 >> 16) << sh;
             }
+          }
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2) {          // the pair of r-groups (2 q2, 2 q2 + 1): lh = 0 keeps the even one
+            const int jk = 2 * q2 + lh;             // the group this lane stores
+            const int ml = m0 + wr * 32 * MT + mt * 32 + 8 * jk;       // first of its eight rows (local)
+            const int gm = ml + g.img_mbase, slab = gm >> 5, mi = gm & 31;
             char* base = reinterpret_cast<char*>(g.img) + ((size_t)((cc >> 7) * g.img_nslab + slab) * 3 * 128 + c) * 64 +
-                         ((((mi >> 3) ^ ((c >> 2) & 3))) << 4) + ((mi & 7) << 1);
-            *reinterpret_cast<uint2*>(base) = make_uint2(t0[0], t0[1]);
-            *reinterpret_cast<uint2*>(base + 128 * 64) = make_uint2(t1[0], t1[1]);
-            *reinterpret_cast<uint2*>(base + 2 * 128 * 64) = make_uint2(t2[0], t2[1]);
+                         ((((mi >> 3) ^ ((c >> 2) & 3))) << 4);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              // send the group the partner keeps, receive the partner's half of mine
+              const unsigned s0 = lh ? t[2 * q2][q][0] : t[2 * q2 + 1][q][0];
+              const unsigned s1 = lh ? t[2 * q2][q][1] : t[2 * q2 + 1][q][1];
+              const unsigned r0 = (unsigned)__shfl_xor((int)s0, 32), r1_ = (unsigned)__shfl_xor((int)s1, 32);
+              const unsigned k0 = lh ? t[2 * q2 + 1][q][0] : t[2 * q2][q][0];
+              const unsigned k1 = lh ? t[2 * q2 + 1][q][1] : t[2 * q2][q][1];
+              // rows 0..3 of the eight come from the lh = 0 lane, rows 4..7 from the lh = 1 lane
+              const uint4 val = lh ? make_uint4(r0, r1_, k0, k1) : make_uint4(k0, k1, r0, r1_);
+              if (ml < g.M) *reinterpret_cast<uint4*>(base + (size_t)q * 128 * 64) = val;
+            }
           }
         }
     }
@@ -566,7 +588,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
           if (n == g.ones_col) { if (g.out1) g.out1[m] = v; }
           else g.out0[(size_t)m * g.ldo + n] = v;
         } else {                                // EPI_RAW: partial plane [z][M][N]
-          g.out0[(size_t)blockIdx.z * g.M * g.N + (size_t)m * g.N + n] = v;
+          g.out0[(size_t)zslice * g.M * g.N + (size_t)m * g.N + n] = v;
         }
       };
       // residual blocks of fully_conv (models/fully_conv.py:13-23: x + conv(ELU(x))): e1 = ELU(x) of the block whose data
@@ -620,15 +642,30 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
   auto As = [&](int b) -> float* { return smem + b * STAGE; };
   auto Bs = [&](int b) -> float* { return smem + b * STAGE + A_TILE_FLOATS; };
 
-  // XCD-aware bijective remap: XCD x (= id % 8) works on a contiguous run of tiles
-  const int ntiles = g.tiles_m * g.tiles_n;
-  int tile;
-  {
+  int tm, tn, zslice = blockIdx.z;
+  if (g.sk_local) {
+    // XCD-local split-K (1-D grid): a UNIT = the tiles_n column tiles of one (contraction slice, row tile) -- they read the
+    // same A tile -- sits on one XCD, dispatched back to back (ids 8 j + x -> XCD x), so its blocks walk the slice in step
+    // and share every A slab through that XCD's L2; units are ordered slice-major and dealt to the XCDs in contiguous runs,
+    // so the row tiles of a slice (sharing B) mostly meet on one XCD as well.  (r02: a split-K launch's grid (tiles, 1, nz)
+    // scattered the blocks of a slice over all eight L2s: 346 MB read against 91 MB of operands for the layer-2 weight
+    // gradient.)
+    const int nunits = g.sk_local * g.tiles_m;                // sk_local = number of slices
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int qq = nunits >> 3, rr = nunits & 7;
+    const int ul = slot / g.tiles_n;
+    if (ul >= qq + (xcd < rr ? 1 : 0)) return;
+    const int u = xcd * qq + (xcd < rr ? xcd : rr) + ul;
+    tn = slot - ul * g.tiles_n;
+    zslice = u / g.tiles_m; tm = u - zslice * g.tiles_m;
+  } else {
+    // XCD-aware bijective remap: XCD x (= id % 8) works on a contiguous run of tiles
+    const int ntiles = g.tiles_m * g.tiles_n;
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int qq = ntiles >> 3, rr = ntiles & 7;
-    tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+    tm = tile / g.tiles_n; tn = tile - tm * g.tiles_n;
   }
-  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
   const int m0 = tm * BM;
   // gated: a block covers 64 gated output columns; B tile rows = [wc][h|g][32]
   const int n0 = GATED ? tn * 64 : tn * BN_;
@@ -650,7 +687,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
   nslab[1] = g.npairs > 1 ? (g.Kc[1] + BK - 1) / BK : 0;
   int s_begin = 0, s_end = nslab[0] + nslab[1];
   if (g.ksplit > 0) {
-    s_begin = blockIdx.z * g.ksplit;
+    s_begin = zslice * g.ksplit;
     int e = s_begin + g.ksplit;
     if (e < s_end) s_end = e;
   }
@@ -1046,7 +1083,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
     if (t == 1.2345e-30f) g.out0[0] = t;
     return;
   }
-  gemm_epilogue<EPI, BN_, NW, CV>(g, acc, m0, n0, tm, wr, wc, lane, smem);
+  gemm_epilogue<EPI, BN_, NW, CV>(g, acc, m0, n0, tm, wr, wc, lane, smem, zslice);
 }
 
 // ---- host side: plan, launch --------------------------------------------------------------------------
@@ -1088,6 +1125,10 @@ static int launch_gemm_w(GemmArgs& g, int nz, hipStream_t stream, const char* wh
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, GATED ? 64 : BN_);
   dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
+  if (g.sk_local > 0) {
+    if (g.sk_local != nz || g.ksplit <= 0) { set_error("%s: XCD-local split-K needs sk_local == nz and a split contraction", what); return EVAE_EINVAL; }
+    grid = dim3(8 * g.tiles_n * cdiv(nz * g.tiles_m, 8), 1, 1);
+  }
   {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("EVAE_GEMM_DBG"); dbg = e ? atoi(e) : 0; }

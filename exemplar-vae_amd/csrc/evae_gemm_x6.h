@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
-  gemm_epilogue<EPI, BN_, NW, CV>(g, acc, m0, n0, tm, wr, wc, lane, smem);
+  gemm_epilogue<EPI, BN_, NW, CV>(g, acc, m0, n0, tm, wr, wc, lane, smem, blockIdx.z);
 }
 
 // ---- both operands k-major: C [M x N] = A^T B with A [Kc x M] (row stride lda), B [Kc x N] (row stride ldb) -- the weight
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (s + 1 < s_end) { slab(s, T, F); ++s; }
     slab(s, F, F);
   }
-  gemm_epilogue<EPI, BN_, NW, 0>(g, acc, m0, n0, tm, wr, wc, lane, smem);
+  gemm_epilogue<EPI, BN_, NW, 0>(g, acc, m0, n0, tm, wr, wc, lane, smem, blockIdx.z);
 }
 
 // k-major operands the x6t kernel can take: no row gather, 16-byte aligned rows, column counts in fours, below 2 GiB

@@ -74,7 +74,7 @@ SIGNATURES = {
     "evae_dense_bwd_weight_u8": (_i, [_p, _i, _i, C.c_longlong, _p, _p, _i, C.c_longlong, _f, _p, _p, _p, _z, _p]),
     "evae_dense_bwd_weight_u8_phased": (_i, [_p, _i, _i, C.c_longlong, _p, _p, _i, C.c_longlong, _f, _p, _p, _p, _z, _i, _p]),
     "evae_dense_bwd_weight_u8_images": (_i, [_i, _i, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
-    "evae_dense_bwd_data_img": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p]),
+    "evae_dense_bwd_data_img": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _z, _p]),
     "evae_gated_dense_bwd_input": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "evae_act_bwd": (_i, [_p, _p, _z, _i, _f, _f, _p, _p]),
     "evae_conv2d_workspace_bytes": (_z, [_p, _i, _i]),

@@ -47,6 +47,10 @@ _ZEROED = {}      # workspace name -> (address, shape) it was last zero-filled f
 # (evae_dense_bwd_weight_u8_phased) on the side stream beside layer 2's weight-gradient GEMM: 0.772 / 0.800 ms vs 0.744 -- the same
 # lesson once more, off.
 SCHED = int(os.environ.get("EVAE_SCHED", "0"))
+# byte store: encoder layer 1's (dh, dg) leave the layer-2 data gradient as the bf16 tile images of its weight gradient
+# (evae_dense_bwd_data_img; r03: 16-byte stores after a lane-pair exchange, on the split-bf16 kernel) -- no fp32 [Mp x 2H]
+# buffer, no 36-us split / transposition pre-pass.  EVAE_IMG_DGRAD=0: the fp32 buffer + pre-pass
+IMG_DGRAD = os.environ.get("EVAE_IMG_DGRAD", "1") != "0" or bool(SCHED & 4)
 THIN_ROWS = 1024     # batch rows up to here take the fp32 split-K kernel for the first layer even on the byte store
 
 PARAM_ORDER = [
@@ -407,7 +411,7 @@ class VaeExactLoss(torch.autograd.Function):
         dq2 = torch.empty((Mp, 2 * H), **f32)                              # [dh2 | dg2] for all C + B rows
         # byte store: encoder layer 1's (dh, dg) leave the layer-2 data gradient as the bf16 tile images its weight gradient
         # reads (no fp32 [Mp x 2H] buffer, no transposing pre-pass); needs row blocks in aligned fours
-        img_mode = (data_ext.dtype == torch.uint8 and Cl % 4 == 0 and B % 4 == 0 and bool(SCHED & 4))
+        img_mode = (data_ext.dtype == torch.uint8 and Cl % 8 == 0 and IMG_DGRAD)
         dq1 = None if img_mode else torch.empty((Mp, 2 * H), **f32)
         if img_mode:
             nb_w1 = lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D)
@@ -421,12 +425,16 @@ class VaeExactLoss(torch.autograd.Function):
             img_ptr = ws_w1.data_ptr() + off_img.value
 
             def l2_dgrad(kk, M, ob, m_base):
-                ops.probed("dense_bwd_data M=%d N=%d+%d K=%d (gate-backward epilogue -> bf16 tile images)" % (M, H, H, H),
-                           2.0 * M * 2 * H * H,
+                nbd = lib.evae_dense_bwd_data_workspace_bytes(M, H, H, 2)
+                wd = kk.ws("dgrad", nbd)
+                wT = None if (ctx.wt is None or kk is not k) else ctx.wt[1]
+                fl_ = 2.0 * M * 2 * H * H
+                ex_, pipe_ = ops.gemm_pipe(M, H, False, fl_)
+                ops.probed("dense_bwd_data M=%d N=%d+%d K=%d (gate-backward epilogue -> bf16 tile images)" % (M, H, H, H), fl_,
                            lambda: _lib.check(lib.evae_dense_bwd_data_img(
                                _vp(dq2.data_ptr() + ob * 2 * H), _vp(w2h), _vp(dq2.data_ptr() + ob * 2 * H + 4 * H), _vp(w2g), M, H,
                                2 * H, H, _vp(A1.data_ptr() + ob * H), _vp(s1.data_ptr() + ob * H), _vp(img_ptr), nslab_img.value,
-                               m_base, kk.st), "bwd_data_img"))
+                               m_base, _vp(wT), _vp(wd), wd.numel(), kk.st), "bwd_data_img"), executed=ex_, pipe=pipe_)
         else:
             def l2_dgrad(kk, M, ob, m_base):
                 kk.bwd_data(dq2.data_ptr() + ob * 2 * H, w2h, dq2.data_ptr() + ob * 2 * H + 4 * H, w2g, M, H, 2 * H, H,

@@ -256,13 +256,15 @@ size_t evae_dense_bwd_weight_u8_workspace_bytes(int M, int N, int K);
 /* dy may be NULL when the producer has already written its tile images into the workspace: evae_dense_bwd_weight_u8_images
  * gives their byte offset inside `ws` and the number of 32-row K-slabs per column tile; evae_dense_bwd_data_img is the data
  * gradient of the layer above with exactly that output -- (dh, dg) = the gate derivative of the layer below applied to
- * dy1 W1 (+ dy2 W2), for rows [m_base, m_base + M) of the merged [dh | dg] buffer (M and m_base multiples of 4).  Image bytes
- * that no row / column of the problem maps to (the tail of the last slab, columns beyond 2K) must be zero: zero the
- * workspace once after allocating it. */
+ * dy1 W1 (+ dy2 W2), for rows [m_base, m_base + M) of the merged [dh | dg] buffer (m_base a multiple of 8; the rows between
+ * m_base + M and the next multiple of 8 are written as zeros, so the launch that ends off a multiple of 8 goes last).  wT /
+ * ws as evae_dense_bwd_data_wt / evae_dense_bwd_data (the split-bf16 kernel's transposed weights; ws of
+ * evae_dense_bwd_data_workspace_bytes(M, N, K, pairs)).  Image bytes that no row / column of the problem maps to (the tail of
+ * the last slab, columns beyond 2K) must be zero: zero the workspace once after allocating it. */
 int evae_dense_bwd_weight_u8_images(int M, int N, int K, size_t* offset, int* nslab);
 int evae_dense_bwd_data_img(const float* dy1, const float* w1, const float* dy2, const float* w2, int M, int N, int ldy, int K,
                             const float* out_prev, const float* s_prev, void* img, int img_nslab, int m_base,
-                            evae_stream_t stream);
+                            const float* wT /* or NULL */, void* ws, size_t ws_bytes, evae_stream_t stream);
 int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long ldy, const unsigned char* x, const int64_t* rows,
                              int K, long long ldx, float x_scale, float* dw /* [N x K] */, float* db /* [N] or NULL */,
                              void* ws, size_t ws_bytes, evae_stream_t stream);
