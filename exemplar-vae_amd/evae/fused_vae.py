@@ -229,15 +229,25 @@ class VaeExactLoss(torch.autograd.Function):
         if Cl > 0 and not approx:
             l1_fwd(k, rows, Cl, 0)
         xt_early = bool(u8 and not approx and not (SCHED & 64))
+        xt_late = xt_early and not (SCHED & 128)
+        def xt_gather():
+            # the byte layer's weight gradient wants the gathered rows transposed (pixel-major): that needs the gather list
+            # only, so it runs in the forward pass on the side stream instead of in the backward's chain of launches -- r03:
+            # BEHIND the batch-row chain (it then runs beside the prior / ELBO / prior-backward launches, when the machine is
+            # nearly idle) instead of in front of it (where it delayed that chain by its 28 us and shared the exemplar
+            # encoder's bandwidth: the side stream, not the main one, was what the prior waited for)
+            wq_ = k.ws("wgrad_u8_fused", lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D))
+            gen_ = _XT_GEN[wq_.data_ptr()] = _XT_GEN.get(wq_.data_ptr(), 0) + 1
+            _lib.check(lib.evae_dense_bwd_weight_u8_phased(None, Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D, ldd, 1.0 / 255.0,
+                                                           None, None, _vp(wq_), wq_.numel(), 3, kd.st), "bwd_weight_u8(gather)")
+            return wq_, gen_
+        lv_row = torch.empty(Z, **f32)                     # the prior's log-variance row
         with torch.cuda.stream(side):
-            if xt_early:
-                # the byte layer's weight gradient wants the gathered rows transposed (pixel-major): that needs the gather list
-                # only, so it runs here, beside the exemplar encoder (which reads the same bytes), instead of in the backward's
-                # chain of launches
-                wq = k.ws("wgrad_u8", lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D))
-                xt_gen = _XT_GEN[wq.data_ptr()] = _XT_GEN.get(wq.data_ptr(), 0) + 1
-                _lib.check(lib.evae_dense_bwd_weight_u8_phased(None, Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D, ldd, 1.0 / 255.0,
-                                                               None, None, _vp(wq), wq.numel(), 3, kd.st), "bwd_weight_u8(gather)")
+            # (on the side stream, in front of everything: with the byte gather moved behind the batch-row chain the MAIN stream's
+            # head GEMM is what the prior waits for, and this 5-us launch sat between the two)
+            lv_row.copy_(plv.detach().expand(Z))
+            if xt_early and not xt_late:
+                wq, xt_gen = xt_gather()
             if u8 and B <= THIN_ROWS and not (SCHED & 32):
                 # a thin launch of the byte kernel walks its 25 K-slabs on five blocks (29 us alone, 66 us beside the exemplar
                 # GEMM); the batch is here as fp32 too (x = byte / 255), and the fp32 kernel splits K over the machine
@@ -268,6 +278,9 @@ class VaeExactLoss(torch.autograd.Function):
             kd.gated_fwd(D1, None, B, H, H, d2h, e2h, d2g, e2g, H, D2, None, sd2)
             kd.linear_fwd(D2, B, H, H, wp, bp, D, ACT_SIGMOID, 0.0, 0.0, xmean, None)
             _lib.check(lib.evae_bernoulli_ll_fwd(_vp(x), _vp(xmean), B, D, _vp(RE), kd.st), "bernoulli")
+            re_ready = torch.cuda.Event(); re_ready.record()
+            if xt_late:
+                wq, xt_gen = xt_gather()
         ci_sel = None
         if approx:
             # the batch's own cache rows refreshed with its means, top-k of every batch row among the candidates' cached
@@ -285,8 +298,7 @@ class VaeExactLoss(torch.autograd.Function):
             k.linear_fwd(A2, Cl, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, mean_all, None)
         if approx:
             approx_cache.index_copy_(0, sel_rows, centres)       # repeats of a row carry identical encodings
-        lv_row = plv.detach().expand(Z).contiguous()       # the prior's log-variance row (main stream: off the batch-row chain)
-        main.wait_event(z_ready)
+        main.wait_event(z_ready)                           # (also orders lv_row, written at the head of the side stream)
         # ---- exemplar prior (leave-one-out mask in training unless no_mask; with its collectives when sharded) on the
         #      main stream ...
         zi = None if no_mask else ops._i64(x_idx)
@@ -317,7 +329,10 @@ class VaeExactLoss(torch.autograd.Function):
                                                      w.numel(), C.byref(ns), C.byref(prow), k.st), "prior_lse_fwd_splits")
             R, ldp = ns.value, B
             pm = w.data_ptr(); ps = pm + 4 * prow.value * B; pn = ps + 4 * prow.value * B
-        main.wait_stream(side)
+        if xt_late:
+            main.wait_event(re_ready)        # (the side stream carries on with the gather; the backward pass joins it)
+        else:
+            main.wait_stream(side)
         # ---- merge of the partial log-sum-exps (splits of this device, or the gathered shards) + ELBO assembly (+ batch
         #      means) in ONE launch
         loss = torch.empty(B, **f32); KL = torch.empty(B, **f32)
@@ -411,18 +426,22 @@ class VaeExactLoss(torch.autograd.Function):
         dq2 = torch.empty((Mp, 2 * H), **f32)                              # [dh2 | dg2] for all C + B rows
         # byte store: encoder layer 1's (dh, dg) leave the layer-2 data gradient as the bf16 tile images its weight gradient
         # reads (no fp32 [Mp x 2H] buffer, no transposing pre-pass); needs row blocks in aligned fours
-        img_mode = (data_ext.dtype == torch.uint8 and Cl % 8 == 0 and IMG_DGRAD)
+        # (only where the exemplar rows' data gradient fills the machine: a thin launch pays more for the un-split image
+        # epilogue than the pre-pass it saves -- C = 200: 0.291 -> 0.301 ms)
+        img_mode = (data_ext.dtype == torch.uint8 and Cl % 8 == 0 and IMG_DGRAD and bool(lib.evae_gemm_x6_applies(Cl, H, 0)))
         dq1 = None if img_mode else torch.empty((Mp, 2 * H), **f32)
         if img_mode:
             nb_w1 = lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D)
-            ws_w1 = k.ws("wgrad_u8", nb_w1)
-            key = (ws_w1.data_ptr(), Mp, H, D)
-            if _ZEROED.get("wgrad_u8") != key:       # image bytes no row / column maps to must be zero: once per buffer and shape
-                ws_w1.zero_()
-                _ZEROED["wgrad_u8"] = key
+            ws_w1 = k.ws("wgrad_u8_fused", nb_w1)
             off_img, nslab_img = C.c_size_t(0), C.c_int(0)
             _lib.check(lib.evae_dense_bwd_weight_u8_images(Mp, 2 * H, D, C.byref(off_img), C.byref(nslab_img)), "u8_images")
             img_ptr = ws_w1.data_ptr() + off_img.value
+            key = (ws_w1.data_ptr(), Mp, H, D)
+            if _ZEROED.get("wgrad_u8") != key:       # image bytes no row / column maps to must be zero: once per buffer and shape
+                # (the IMAGE region only: the transposed byte rows the forward pass left in front of it stay)
+                nimg = ((2 * H + 127) // 128) * nslab_img.value * 3 * 128 * 32 * 2
+                ws_w1[off_img.value:off_img.value + nimg].zero_()
+                _ZEROED["wgrad_u8"] = key
 
             def l2_dgrad(kk, M, ob, m_base):
                 nbd = lib.evae_dense_bwd_data_workspace_bytes(M, H, H, 2)
@@ -514,6 +533,7 @@ class VaeExactLoss(torch.autograd.Function):
             # head and encoder layer 2, batch rows
             kd.bwd_data(dmean_all.data_ptr() + off * Z, wm, dlvp, wl, B, Z, Z, H, A2.data_ptr() + off * H,
                         s2.data_ptr() + off * H, dq2.data_ptr() + off * 2 * H, dq2.data_ptr() + off * 2 * H + 4 * H, 2 * H)
+            dq2_rows_done = torch.cuda.Event(); dq2_rows_done.record()      # all layer 2's weight gradient needs of the batch rows
             l2_dgrad(kd, B, off, Cl)
             batch_rows_done.record()
 
@@ -528,7 +548,12 @@ class VaeExactLoss(torch.autograd.Function):
                 kd.bwd_weight(dlvp, B, Z, Z, A2.data_ptr() + off * H, None, H, H, g_wl, g_bl)
                 torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
         leaves()
-        main.wait_event(batch_rows_done)
+        # SCHED & 256: layer 2's weight gradient starts as soon as the batch rows' dq2 exist, without waiting for their layer-1
+        # (dh, dg).  Measured r03 (c2): 0.668 -> 0.684-0.694 ms -- main gains 15 us, but the side stream's leaf weight gradients,
+        # which used to get the machine first, then start BEHIND layer 2's CU-filling launch (the mean head's: 27 -> 123 us)
+        # and end after the main stream's last launch.  Off.
+        split_wait = bool(SCHED & 256) and not (SCHED & 10)
+        main.wait_event(dq2_rows_done if split_wait else batch_rows_done)
         # ---- weight gradients of the two encoder layers over all C + B rows
         #      (layer 2's finish launch runs on the side stream, beside layer 1's GEMM instead of in front of it)
         g_w2 = gslot("w2", 2 * H, H); g_b2 = gslot("b2", 2 * H)
@@ -537,7 +562,7 @@ class VaeExactLoss(torch.autograd.Function):
         def w1_grad():
             if data_ext.dtype == torch.uint8:
                 nb = lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D)
-                w = k.ws("wgrad_u8", nb)
+                w = k.ws("wgrad_u8_fused", nb)
                 fl = 2.0 * Mp * 2 * H * D
                 # the forward pass left the transposed byte rows in the workspace (unless another step used it since)
                 have_xt = ctx.xt is not None and ctx.xt == (w.data_ptr(), _XT_GEN.get(w.data_ptr()))
@@ -562,7 +587,7 @@ class VaeExactLoss(torch.autograd.Function):
             # the bandwidth-bound pre-passes of the byte layer's weight gradient (gather-transpose of the rows, split and
             # transposition of dy) on the side stream, beside layer 2's matrix-bound weight gradient
             nb = lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D)
-            w = k.ws("wgrad_u8", nb)
+            w = k.ws("wgrad_u8_fused", nb)
 
             def w1_phase(phase, st):
                 _lib.check(lib.evae_dense_bwd_weight_u8_phased(_vp(dq1), Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D, ldd, 1.0 / 255.0,
@@ -577,6 +602,8 @@ class VaeExactLoss(torch.autograd.Function):
             w1_phase(2, k.st)
         else:
             k.bwd_weight(*w2_args)
+            if split_wait:
+                main.wait_event(batch_rows_done)
             w1_grad()
         main.wait_stream(side)
         ctx.bufs = None
