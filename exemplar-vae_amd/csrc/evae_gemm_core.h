@@ -220,20 +220,10 @@ struct Plan {
 // Wave-quantisation model: a launch runs in rounds of 512 resident blocks (256 CUs x 2); a block costs
 // (slabs + fixed prologue/epilogue) slab-times, a BN=64 slab ~0.6 of a BN=128 slab; split-K adds the
 // finish kernel (launch + partial traffic).  Deterministic in (M, N, slabs, gated, must_split).
-// thin launches (one row tile: the batch rows of a training step) may be planned against fewer block slots than the machine
-// has: EVAE_THIN_SLOTS (default 512 = all).  Beside a CU-filling GEMM on the other stream every block of a thin launch takes a
-// slot away from it for its short life.
-static int thin_slots() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("EVAE_THIN_SLOTS"); v = e ? atoi(e) : 512; if (v < 8) v = 8; }
-  return v;
-}
-
 static Plan make_plan(int M, int N, int slabs, bool gated, bool must_split, int planes) {
   Plan best = {128, 1, slabs};
   double best_t = 1e30;
   const int bns[2] = {128, 64};
-  const int slots = M <= BM ? thin_slots() : 512;
   for (int bi = 0; bi < (gated ? 1 : 2); ++bi) {
     const int bn = bns[bi];
     const long tiles = (long)cdiv(M, BM) * cdiv(N, gated ? 64 : bn);
@@ -242,7 +232,7 @@ static Plan make_plan(int M, int N, int slabs, bool gated, bool must_split, int 
       const int ks = cdiv(slabs, nz);
       const int nze = cdiv(slabs, ks);
       if (nze != nz) continue;
-      const long rounds = (tiles * nze + slots - 1) / slots;
+      const long rounds = (tiles * nze + 511) / 512;
       double t = rounds * (ks + 1.5) * slab_cost;
       // the finish launch: ~3 slab-times of a dependent launch inside a graph (measured: 2 -> 3 takes 0.7 % off the c2 step)
       if (nze > 1 || must_split) t += 3.0 + (double)M * N * planes * nze * 4.0 / 12e6;
