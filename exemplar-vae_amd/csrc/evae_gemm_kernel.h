@@ -392,7 +392,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
         e0v[mt][r] = mok ? g.e0[m] : 0.f;
         ri[mt][r] = (masked && mok) ? (long long)g.pr_ridx[m] : -2;
       }
-    float zn[NT], gq[NT], kq[NT];
+    float zn[NT], gq[NT], kq[NT], kq2[NT];
     long long zi[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -400,9 +400,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
       const bool nok = n < g.N;
       zn[nt] = nok ? g.e1[n] : 0.f;
       gq[nt] = nok ? g.bias1[n] : 0.f;
-      kq[nt] = nok ? (cst - g.bias0[n]) * kLog2e : 0.f;
+      kq[nt] = nok ? g.bias0[n] : 0.f;                         // token of the merge: row max ...
+      kq2[nt] = nok ? g.bias0[g.N + n] * kLog2e : 0.f;         // ... and log of the normalised sum (evae_prior.hip::prior_merge_kernel)
       zi[nt] = (masked && nok) ? (long long)g.pr_cidx[n] : -1;
-      EVAE_PIN(zn[nt]); EVAE_PIN(gq[nt]); EVAE_PIN(kq[nt]);
+      EVAE_PIN(zn[nt]); EVAE_PIN(gq[nt]); EVAE_PIN(kq[nt]); EVAE_PIN(kq2[nt]);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -421,7 +422,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
           const float d = fmaxf(e0v[mt][r] + zn[nt] - 2.0f * acc[mt][nt][r], 0.f);
           bool ok = nok;
           if (masked) ok = ok && (ri[mt][r] != zi[nt]) && (ri[mt][r] != (long long)EVAE_PRIOR_MASK_ALL);
-          const float pv = ok ? gq[nt] * fast_exp2(kq[nt] - d * (0.5f * kLog2e)) : 0.f;
+          const float pv = ok ? gq[nt] * fast_exp2(fmaf(fmaf(-0.5f, d, cst) - kq[nt], kLog2e, -kq2[nt])) : 0.f;
           if (m < g.M) g.out0[(size_t)m * g.ldo + n] = pv;
         }
     }

@@ -443,7 +443,12 @@ __global__ __launch_bounds__(128 * WR) void prior_fwd_mfma_kernel(
         }
         const float mk = -(um[nt] + off) * kLog2e;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ssum[nt] += fast_exp2(fmaf(v[r], kLog2e, mk));
+        for (int r = 0; r < 16; ++r) {
+          // direct tiles: the difference FIRST (exact near the maximum) -- fma(v, log2e, -max log2e) carries the rounding of
+          // max log2e, half an ulp of 1e8 .. 1e9 = 8 .. 128 in the exponent at the magnitudes this path exists for (r03)
+          if constexpr (slow) ssum[nt] += fast_exp2((v[r] - um[nt]) * kLog2e);
+          else ssum[nt] += fast_exp2(fmaf(v[r], kLog2e, mk));
+        }
       }
       continue;
     }
@@ -471,7 +476,10 @@ __global__ __launch_bounds__(128 * WR) void prior_fwd_mfma_kernel(
       const float mk = -(um[nt] + off) * kLog2e;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if ((use >> r) & 1u) ssum[nt] += fast_exp2(fmaf(v[r], kLog2e, mk));
+        if ((use >> r) & 1u) {
+          if constexpr (slow) ssum[nt] += fast_exp2((v[r] - um[nt]) * kLog2e);
+          else ssum[nt] += fast_exp2(fmaf(v[r], kLog2e, mk));
+        }
     }
   }
   };
@@ -736,9 +744,13 @@ __global__ __launch_bounds__(NT) void prior_merge_kernel(const float* __restrict
   n = wave_sum(n);
   if (lane == 0) {
     if (finalize) {
-      float lse = m + logf(s);
-      o0[row] = lse - logf(c_total - n);
-      if (o1 != nullptr) o1[row] = lse;
+      const float ls = logf(s);
+      o0[row] = (m + ls) - logf(c_total - n);
+      // the forward -> backward token, 2 B floats: row max and log of the normalised sum, kept APART (lse = tok0 + tok1).
+      // The backward forms (p_ij - tok0) - tok1: p_ij - tok0 is exact for the pairs that matter (p_ij is the same
+      // single-rounded cst - d2/2 the forward took its maximum over), so the softmax weights stay normalised at any
+      // magnitude of the log-density; the rounded sum m + log s lost ulp(lse) -- 8 nats at |lse| ~ 1e8 (r03, golden G21).
+      if (o1 != nullptr) { o1[row] = m; o1[B + row] = (m == -INFINITY) ? 0.f : ls; }
     } else {
       o0[row] = m; o1[row] = s; o2[row] = n;
     }
@@ -800,10 +812,11 @@ __global__ __launch_bounds__(1024) void prior_elbo_fwd_kernel(const float* __res
         if (cm[g][q] != -INFINITY) ss += cs[g][q] * expf(cm[g][q] - mm);
         nn += cn[g][q];
       }
-      const float lse = mm + logf(ss);
+      const float ls = logf(ss);
+      const float lse = mm + ls;
       const float lp = lse - logf(c_total - nn);
       logp[row] = lp;
-      if (lse_out) lse_out[row] = lse;
+      if (lse_out) { lse_out[row] = mm; lse_out[B + row] = (mm == -INFINITY) ? 0.f : ls; }      // token (max, log sum): prior_merge_kernel
       const float kl = logq[row] - lp;
       const float l = beta * kl - RE[row];
       KL[row] = kl;
@@ -872,14 +885,15 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
   const int nq_valid = (B - q0) < BQ ? (B - q0) : BQ;      // live query rows of this tile
 
   int64_t zi[TQ];
-  float gi[TQ], li[TQ];
+  float gi[TQ], li[TQ], l2[TQ];
 #pragma unroll
   for (int i = 0; i < TQ; ++i) {
     int q = q0 + tq + 16 * i;
     bool v = q < B;
     zi[i] = (masked && v) ? z_idx[q] : -1;
     gi[i] = v ? gout[q] : 0.f;
-    li[i] = v ? lse[q] : 0.f;
+    li[i] = v ? lse[q] : 0.f;               // token: row max ...
+    l2[i] = v ? lse[B + q] : 0.f;           // ... and log of the normalised sum (prior_merge_kernel)
   }
 
   // phase-2 roles
@@ -911,14 +925,22 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
       for (int i = 0; i < TQ; ++i)
 #pragma unroll
         for (int j = 0; j < TE; ++j) acc[i][j] = 0.f;
-      // distances over all chunks; chunk ch2 is staged last so phase 2 can use it
-      for (int c = 0; c < g.nchunk; ++c) {
-        int ch = (c == g.nchunk - 1) ? ch2 : (c < ch2 ? c : c + 1);
+      // distances over all chunks IN THE FORWARD'S ORDER (0, 1, ...): d2 has to come out bit for bit as in prior_fwd_kernel --
+      // the weights below are exp((p_ij - max_i) - log sum_i), and at |log p| ~ 1e8 one ulp of d2 is 16 nats (r03: staging
+      // chunk ch2 last, as phase 2 wants it, reordered the sum: gradients 1e8 x off at z = 294, |z| ~ 1e4, golden G21);
+      // chunk ch2 is then staged once more for phase 2 unless it was the last one anyway
+      for (int ch = 0; ch < g.nchunk; ++ch) {
         __syncthreads();
         if (g.nchunk > 1) stage_rows<KC>(Qs, z, q0, B, BQ, zdim, ch * KC, inv_sigma + ch * KC, vec_ok);
         stage_rows<KC>(Es, centres, e0, C, BE, zdim, ch * KC, inv_sigma + ch * KC, vec_ok);
         __syncthreads();
         dist_chunk<KC>(acc, Qs, Es, tq, te);
+      }
+      if (g.nchunk > 1 && ch2 != g.nchunk - 1) {
+        __syncthreads();
+        stage_rows<KC>(Qs, z, q0, B, BQ, zdim, ch2 * KC, inv_sigma + ch2 * KC, vec_ok);
+        stage_rows<KC>(Es, centres, e0, C, BE, zdim, ch2 * KC, inv_sigma + ch2 * KC, vec_ok);
+        __syncthreads();
       }
       // gw tile -> LDS
 #pragma unroll
@@ -929,7 +951,7 @@ __global__ __launch_bounds__(NT) void prior_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < TQ; ++i) {
           bool ok = ev && !(masked && (zi[i] == cj || cj == kMaskAll));
-          float w = ok ? gi[i] * __expf(cst - 0.5f * acc[i][j] - li[i]) : 0.f;
+          float w = ok ? gi[i] * __expf(((cst - 0.5f * acc[i][j]) - li[i]) - l2[i]) : 0.f;
           GW[(tq + 16 * i) * GWS + te + 16 * j] = w;
         }
       }
@@ -1101,7 +1123,7 @@ __global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
   const bool slow = centre_queries<KP, KS2, MFT>(Qs, mu_s, zn, zmx, Ps, (B - q0) < MFQ ? (B - q0) : MFQ) > norm_limit;
 
   // this lane's two query columns of S
-  float znq[2], gq[2], lq[2];
+  float znq[2], gq[2], lq[2], lq2[2];
   long long zi[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
@@ -1109,7 +1131,8 @@ __global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
     const bool v = q0 + ql < B;
     znq[nt] = zn[ql];
     gq[nt] = v ? gout[q0 + ql] : 0.f;
-    lq[nt] = v ? lse[q0 + ql] : 0.f;
+    lq[nt] = v ? lse[q0 + ql] : 0.f;            // token: row max, log of the normalised sum (prior_merge_kernel)
+    lq2[nt] = v ? lse[B + q0 + ql] * kLog2e : 0.f;
     zi[nt] = (masked && v) ? (long long)z_idx[q0 + ql] : -1;
   }
   // column of the T / U tiles this lane holds (clamped to the zero padding column for the operand reads)
@@ -1167,8 +1190,8 @@ __global__ __launch_bounds__(MFT) void prior_bwd_mfma_kernel(
         const float d = slow ? acc[nt][r] : fmaxf(cn[el] + znq[nt] - 2.0f * acc[nt][r], 0.f);
         bool ok = e0 + el < C;
         if (masked) ok = ok && (ci_s[el] != zi[nt]) && (ci_s[el] != kMaskAll);
-        // exp(cst - d/2 - lse) = 2^((cst - lse) log2e - d log2e / 2)
-        const float w = gq[nt] * fast_exp2((cst - lq[nt]) * kLog2e - d * kHalfLog2e);
+        // exp(p - lse), p = cst - d/2 rounded once as in the forward; (p - max) first: exact where the weight is not ~0
+        const float w = gq[nt] * fast_exp2(fmaf(fmaf(-0.5f, d, cst) - lq[nt], kLog2e, -lq2[nt]));
         Ps[el * PP + ql] = ok ? w : 0.f;
       }
     }

@@ -303,7 +303,7 @@ class VaeExactLoss(torch.autograd.Function):
         #      main stream ...
         zi = None if no_mask else ops._i64(x_idx)
         ci = None if no_mask else (ci_sel if approx else ops._i64(ex_idx))
-        logp = torch.empty(B, **f32); lse = torch.empty(B, **f32)
+        logp = torch.empty(B, **f32); lse = torch.empty((2, B), **f32)      # lse: the (max, log sum) token of the merge
         z_all, zi_all = z, zi
         if sharded == 2:
             # data-parallel batches over sharded exemplars: every rank scores the queries of ALL ranks against its
@@ -477,8 +477,9 @@ class VaeExactLoss(torch.autograd.Function):
             # in AdamNormGrad.step then yields the gradient of the global-batch mean loss, no rescaling needed.
             z_all, zi_all = ctx.dp
             RB = z_all.shape[0]
-            lg = shard._all_gather_flat(torch.stack((lse, gp)))            # [R x 2 x B]
-            lse_all = lg[:, 0].reshape(-1).contiguous(); gp_all = lg[:, 1].reshape(-1).contiguous()
+            lg = shard._all_gather_flat(torch.cat((lse.reshape(2, B), gp.reshape(1, B))))            # [R x 3 x B]
+            lse_all = torch.stack((lg[:, 0].reshape(-1), lg[:, 1].reshape(-1))).contiguous()       # token of all R B queries
+            gp_all = lg[:, 2].reshape(-1).contiguous()
             dz_all = torch.empty((RB, Z), **f32); dlv = torch.empty(Z, **f32)
             nb = lib.evae_prior_lse_bwd_workspace_bytes(RB, Cl, Z)
             w = k.ws("prior_bwd", nb)

@@ -121,14 +121,18 @@ def prior_set_norm_limit(limit):
 
 
 def prior_merge(m, s, n, c_total, out=None):
-    """[R x B] shard partials -> (logprior [B], lse [B]); `out` = caller-allocated (logprior, lse)."""
+    """[R x B] shard partials -> (logprior [B], token [2 x B]); `out` = caller-allocated (logprior, token).  The token is what
+    the backward takes in place of the row log-sum-exp: row 0 = the row maximum, row 1 = the log of the normalised sum, kept
+    apart (lse = token.sum(0)) so that exp(p_ij - lse_i) stays exact at any magnitude of the log-density
+    (csrc/evae_prior.hip::prior_merge_kernel)."""
     lib = _lib.load()
     _need_cuda(m, s, n)
     m, s, n = _f32(m), _f32(s), _f32(n)
     if m.dim() == 1:
         m, s, n = m[None], s[None], n[None]
     R, B = m.shape
-    lp, lse = out if out is not None else (torch.empty(B, device=m.device), torch.empty(B, device=m.device))
+    lp, lse = out if out is not None else (torch.empty(B, device=m.device), torch.empty((2, B), device=m.device))
+    assert lse.numel() == 2 * B and lse.is_contiguous()
     _lib.check(lib.evae_prior_merge(_p(m), _p(s), _p(n), R, B, float(c_total), _p(lp), _p(lse), _stream()),
                "evae_prior_merge")
     return lp, lse
@@ -137,6 +141,9 @@ def prior_merge(m, s, n, c_total, out=None):
 def prior_lse_bwd(z, centres, log_var, z_idx, c_idx, lse, grad_out):
     lib = _lib.load()
     _need_cuda(z, centres, log_var, lse, grad_out)
+    if lse.numel() == z.shape[0] and lse.numel() > 0:      # a plain row log-sum-exp: token (lse, 0)
+        lse = torch.stack((lse.reshape(-1).float(), torch.zeros_like(lse.reshape(-1), dtype=torch.float32)))
+    assert lse.numel() == 2 * z.shape[0], "prior_lse_bwd: lse is the [2 x B] token of prior_merge (or a plain [B] log-sum-exp)"
     z, centres, log_var = _f32(z), _f32(centres), _f32(log_var).reshape(-1)
     lse, grad_out = _f32(lse), _f32(grad_out)
     B, zd = z.shape

@@ -55,7 +55,12 @@ const char* evae_last_error(void);
  * (log_p_z(sum=False), BaseModel.py:126-127, before the `- log(denominator)` of :108).
  * evae_prior_merge combines R shard partials ([R x B] each, R >= 1) into
  *   out_logprior_i = LSE_i - log(c_total - sum_r nmask_ri)      (BaseModel.py:100,107-108,124-125)
- *   out_lse_i      = LSE_i   (un-normalised, what the backward needs)
+ *   out_lse        = the forward -> backward TOKEN, 2 B floats: [0, B) the merged row maximum M_i = max_j p_ij, [B, 2 B) the log
+ *                    of the normalised sum log sum_j exp(p_ij - M_i); LSE_i = their sum.  They travel apart because the backward
+ *                    forms (p_ij - M_i) - log sum: p_ij - M_i is exact where the weight is not negligible (p_ij is the same
+ *                    single-rounded cst - d2_ij/2 the forward took its maximum over), so exp(p_ij - LSE_i) stays a normalised
+ *                    softmax at any magnitude of the log-density (|LSE| ~ 1e8 for an untrained fully_conv net, golden G21);
+ *                    the rounded sum M + log sum would lose ulp(LSE) nats.  A caller with a plain LSE passes (LSE, 0).
  * which is the all-reduce of partial log-sum-exps of the sharded prior (gathered by the caller
  * with one RCCL all-gather; see exemplar-vae_amd/evae/shard.py).
  * Sizes: zdim <= 512.  zdim <= 64 (multiple of 4, no out_prob) runs the forward on the matrix cores in the expanded form
@@ -63,7 +68,7 @@ const char* evae_last_error(void);
  * takes the direct-difference VALU kernels.  The fp32 expanded form is kept inside the 1e-5 bar for any input: latents are
  * centred per query tile (the distance is translation invariant) and a tile whose centred squared norms (sigma units)
  * still exceed a limit is recomputed as direct differences by the same launch (evae_prior_set_norm_limit; default 4096).
- * The backward recomputes w_ij from the fp32 row LSE: exact to rounding while |lse| <~ 1e5.
+ * The backward recomputes w_ij = exp((p_ij - M_i) - log sum_i) from the token above.
  */
 /* limit < 0 restores the default; 0 sends every tile through the direct-difference path (tests).  Process-wide. */
 int evae_prior_set_norm_limit(float limit);
@@ -80,7 +85,7 @@ int evae_prior_lse_fwd(const float* z, int B, const float* centres, int C, int z
                        void* ws, size_t ws_bytes, evae_stream_t stream);
 int evae_prior_merge(const float* max /* [R x B] */, const float* sumexp, const float* nmask,
                      int R, int B, float c_total,
-                     float* out_logprior /* [B] */, float* out_lse /* [B] or NULL */,
+                     float* out_logprior /* [B] */, float* out_lse /* token [2 B] or NULL */,
                      evae_stream_t stream);
 /* The same forward, but the per-split partials of the launch stay in the workspace un-merged: three planes of
  * *plane_rows x B floats at ws, ws + plane_rows B, ws + 2 plane_rows B (max, sumexp, nmask), of which the first *nsplit
@@ -95,7 +100,7 @@ int evae_prior_lse_fwd_splits(const float* z, int B, const float* centres, int C
  * and, when means != NULL, the batch means (loss, RE, KL).  beta from device memory when beta_dev != NULL. */
 int evae_prior_elbo_fwd(const float* pmax, const float* psum, const float* pnmask, int R, int ldp, int B, float c_total,
                         const float* RE, const float* logq, const float* beta_dev, float beta_host,
-                        float* logp /* [B] */, float* lse /* [B] or NULL */, float* loss /* [B] */, float* KL /* [B] */,
+                        float* logp /* [B] */, float* lse /* token [2 B] or NULL */, float* loss /* [B] */, float* KL /* [B] */,
                         float* means /* [3] or NULL */, evae_stream_t stream);
 /* The same, plus the coefficient vectors of evae_elbo_bwd for "batch mean of the loss, upstream gradient 1" (a captured step's
  * loss.backward(ones)): cRE = -1/B, cKL = beta/B, neg_cKL = -beta/B -- the backward pass starts one launch later. */
@@ -112,7 +117,7 @@ int evae_prior_elbo_fwd_coef(const float* pmax, const float* psum, const float* 
 size_t evae_prior_lse_bwd_workspace_bytes(int B, int C, int zdim);
 int evae_prior_lse_bwd(const float* z, int B, const float* centres, int C, int zdim,
                        const float* log_var, const int64_t* z_idx, const int64_t* c_idx,
-                       const float* lse /* [B] */, const float* grad_out /* [B] */,
+                       const float* lse /* token [2 B] of evae_prior_merge */, const float* grad_out /* [B] */,
                        float* dz /* [B x zdim] */, float* dcentres /* [C x zdim] */,
                        float* dlogvar /* [zdim] */,
                        void* ws, size_t ws_bytes, evae_stream_t stream);
