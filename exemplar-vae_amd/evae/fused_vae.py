@@ -548,7 +548,9 @@ class VaeExactLoss(torch.autograd.Function):
                 kd.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1)
                 kd.bwd_weight(dlvp, B, Z, Z, A2.data_ptr() + off * H, None, H, H, g_wl, g_bl)
                 torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
-        leaves()
+        leaves()      # (issued HERE: captured after the main stream's weight gradients instead, the same launches replay at
+        #                0.82-0.94 ms for C = 200 and 1.2 ms at c2 -- this runtime's graph replay is very sensitive to where a
+        #                branch's nodes sit relative to the other branch's, r03 measurement)
         # SCHED & 256: layer 2's weight gradient starts as soon as the batch rows' dq2 exist, without waiting for their layer-1
         # (dh, dg).  Measured r03 (c2): 0.668 -> 0.684-0.694 ms -- main gains 15 us, but the side stream's leaf weight gradients,
         # which used to get the machine first, then start BEHIND layer 2's CU-filling launch (the mean head's: 27 -> 123 us)
