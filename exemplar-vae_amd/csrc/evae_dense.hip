@@ -462,6 +462,38 @@ extern "C" int evae_dense_bwd_weight_phased(const float* dy, int M, int N, int l
   return dense_bwd_weight_core(dy, M, N, ldy, x, rows, K, ldx, dw, db, accumulate, ws, ws_bytes, phase, (hipStream_t)stream_);
 }
 
+// Several thin weight gradients in one launch (gemm_group_wgrad_kernel): each job as evae_dense_bwd_weight with a
+// contraction of at most four K-slabs (M <= 128 rows), no row gather, no accumulation.  Returns EVAE_EINVAL (nothing
+// launched) when a job does not qualify: the caller then issues them one by one.
+extern "C" int evae_dense_bwd_weight_group(const evae_wgrad_job_t* jobs, int njobs, evae_stream_t stream_) {
+  EVAE_REQUIRE(jobs && njobs >= 1 && njobs <= kWgradGroupMax, "dense_bwd_weight_group: 1 .. %d jobs", kWgradGroupMax);
+  WgradGroup grp = {};
+  int total = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const evae_wgrad_job_t& w = jobs[j];
+    EVAE_REQUIRE(w.dy && w.x && w.dw && w.M > 0 && w.N > 0 && w.K > 0 && w.ldy >= w.N && w.ldx >= w.K,
+                 "dense_bwd_weight_group: bad job %d", j);
+    EVAE_REQUIRE(cdiv(w.M, BK) <= 4, "dense_bwd_weight_group: job %d contracts over %d rows (> 128)", j, w.M);
+    GemmArgs g = {};
+    g.A[0] = w.dy; g.B[0] = w.x; g.lda[0] = w.ldy; g.ldb[0] = w.ldx; g.Kc[0] = w.M; g.npairs = 1;
+    g.M = w.N; g.N = w.K + 1; g.ones_col = w.K;
+    EVAE_REQUIRE((gemm_vec_ok<false, false>(g)), "dense_bwd_weight_group: job %d is not 16-byte aligned / a multiple of 4", j);
+    grp.job[j] = {w.dy, w.x, w.dw, w.db, w.M, w.N, w.K, w.ldy, w.ldx};
+    grp.start[j] = total;
+    total += cdiv(w.N, BM) * cdiv(w.K + 1, 64);
+  }
+  grp.start[njobs] = total; grp.n = njobs;
+  for (int j = njobs + 1; j <= kWgradGroupMax; ++j) grp.start[j] = total;
+  static bool attr = false;
+  constexpr size_t lds = gemm_lds_bytes(64);
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_group_wgrad_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  gemm_group_wgrad_kernel<8><<<total, 512, lds, (hipStream_t)stream_>>>(grp);
+  return check_launch("gemm_group_wgrad_kernel");
+}
+
 extern "C" int evae_gated_dense_bwd_input(const float* dout, const float* out, const float* s, int M, int N,
                                           float* dh, float* dg, int ldo, evae_stream_t stream_) {
   if (M <= 0 || N <= 0) return EVAE_OK;

@@ -628,22 +628,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
 // GATHER_A: the rows of a KC A operand are gathered through g.a_rows (the exemplar gather of the first encoder layer).  A
 // template parameter rather than a run-time test so that the gathered launch -- the dominant one of a training step -- is
 // a kernel symbol of its own in per-kernel profiles.
+// The kernel's body is a device function of (arguments, block id, slice id): gemm_kernel runs it on blockIdx, the grouped
+// launch of several thin weight gradients (gemm_group_wgrad_kernel below) on a per-problem block id.
 template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW, int CV = 0, bool GATHER_A = false>
-__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int blk_x, const int blk_z, float* const smem) {
   constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
   constexpr int GNT = 64 * NW;
   constexpr int MT = 8 / NW;        // NW/2 wave rows x 2 wave columns; wave tile (32 MT) x (32 NT)
   constexpr int NT = BN_ / 64;
   static_assert(!GATED || BN_ == 128, "gated epilogue needs the h and g column tiles in one wave");
   constexpr int STAGE = A_TILE_FLOATS + b_tile_floats(BN_);
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   if constexpr (EPI == EPI_PRIOR_LSE || EPI == EPI_PRIOR_P) {
     if (g.skip_flag != nullptr && *g.skip_flag != 0u) return;     // block-uniform: the caller's guard chose the other path
   }
   auto As = [&](int b) -> float* { return smem + b * STAGE; };
   auto Bs = [&](int b) -> float* { return smem + b * STAGE + A_TILE_FLOATS; };
 
-  int tm, tn, zslice = blockIdx.z;
+  int tm, tn, zslice = blk_z;
   if (g.sk_local) {
     // XCD-local split-K (1-D grid): a UNIT = the tiles_n column tiles of one (contraction slice, row tile) -- they read the
     // same A tile -- sits on one XCD, dispatched back to back (ids 8 j + x -> XCD x), so its blocks walk the slice in step
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
     // scattered the blocks of a slice over all eight L2s: 346 MB read against 91 MB of operands for the layer-2 weight
     // gradient.)
     const int nunits = g.sk_local * g.tiles_m;                // sk_local = number of slices
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int id = blk_x, xcd = id & 7, slot = id >> 3;
     const int qq = nunits >> 3, rr = nunits & 7;
     const int ul = slot / g.tiles_n;
     if (ul >= qq + (xcd < rr ? 1 : 0)) return;
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
   } else {
     // XCD-aware bijective remap: XCD x (= id % 8) works on a contiguous run of tiles
     const int ntiles = g.tiles_m * g.tiles_n;
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int id = blk_x, xcd = id & 7, slot = id >> 3;
     const int qq = ntiles >> 3, rr = ntiles & 7;
     const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
     tm = tile / g.tiles_n; tn = tile - tm * g.tiles_n;
@@ -1065,7 +1066,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
 
   if ((g.dbg & 512) && g.out2) {   // clock probe: shader-clock ticks vs the constant 100 MHz counter over this block's main loop
     const long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
-    if (threadIdx.x == 0 && (blockIdx.x & 63) == 5) {
+    if (threadIdx.x == 0 && (blk_x & 63) == 5) {
       float* d = g.out2 + (size_t)(g.M - 1) * g.ldo;   // last row of the save_s output (overwritten, debug only)
       atomicAdd(d + 0, (float)(c1 - dbg_c0));
       atomicAdd(d + 1, (float)(w1 - dbg_w0));
@@ -1085,6 +1086,47 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
     return;
   }
   gemm_epilogue<EPI, BN_, NW, CV>(g, acc, m0, n0, tm, wr, wc, lane, smem, zslice);
+}
+
+template <bool A_KC, bool B_KC, int EPI, bool VEC, int BN_, int NW, int CV = 0, bool GATHER_A = false>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gemm_body<A_KC, B_KC, EPI, VEC, BN_, NW, CV, GATHER_A>(g, (int)blockIdx.x, (int)blockIdx.z, smem);
+}
+
+// ---- several thin weight gradients in ONE launch (the batch rows' leaf layers of a training step: decoder layers, the
+// log-variance head).  Every job is dw [N x K] = dy^T x over at most four K-slabs of contraction rows, written by the GEMM
+// itself (GemmArgs::direct: no partial plane, no finish) with db in the ones column; a block finds its job by the running
+// tile counts and runs gemm_body on its own copy of the arguments.  The jobs travel by value in the kernel arguments, so a
+// captured step needs no table upload.
+struct WgradJob { const float* dy; const float* x; float* dw; float* db; int M, N, K, ldy, ldx; };
+constexpr int kWgradGroupMax = 6;
+struct WgradGroup { WgradJob job[kWgradGroupMax]; int start[kWgradGroupMax + 1]; int n; };
+
+__device__ __forceinline__ const float* uni_ptr(const float* p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void gemm_group_wgrad_kernel(const WgradGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bid = blockIdx.x;
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < kWgradGroupMax; ++i)
+    if (i < grp.n && bid >= grp.start[i]) j = i;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const WgradJob& w = grp.job[j];
+  GemmArgs g = {};
+  g.A[0] = uni_ptr(w.dy); g.B[0] = uni_ptr(w.x);
+  g.lda[0] = __builtin_amdgcn_readfirstlane(w.ldy); g.ldb[0] = __builtin_amdgcn_readfirstlane(w.ldx);
+  g.Kc[0] = __builtin_amdgcn_readfirstlane(w.M); g.npairs = 1;
+  g.M = __builtin_amdgcn_readfirstlane(w.N); g.N = __builtin_amdgcn_readfirstlane(w.K) + 1;
+  g.out0 = (float*)uni_ptr(w.dw); g.out1 = (float*)uni_ptr(w.db); g.ldo = g.N - 1; g.ones_col = g.N - 1; g.direct = 1;
+  g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = (g.N + 63) / 64;
+  gemm_body<false, false, EPI_RAW, true, 64, NW>(g, bid - __builtin_amdgcn_readfirstlane(grp.start[j]), 0, smem);
 }
 
 // ---- host side: plan, launch --------------------------------------------------------------------------

@@ -29,6 +29,12 @@ class WtJob(C.Structure):
     _fields_ = [("w1", C.c_void_p), ("w2", C.c_void_p), ("dst", C.c_void_p), ("N", C.c_int), ("K", C.c_int), ("ldt", C.c_int)]
 
 
+class WgradJob(C.Structure):
+    """evae_wgrad_job_t"""
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("M", C.c_int), ("N", C.c_int),
+                ("K", C.c_int), ("ldy", C.c_int), ("ldx", C.c_int)]
+
+
 class AdamTensor(C.Structure):
     """evae_adam_tensor_t"""
     _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("numel", _l)]
@@ -75,6 +81,7 @@ SIGNATURES = {
     "evae_dense_bwd_weight_u8_phased": (_i, [_p, _i, _i, C.c_longlong, _p, _p, _i, C.c_longlong, _f, _p, _p, _p, _z, _i, _p]),
     "evae_dense_bwd_weight_u8_images": (_i, [_i, _i, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "evae_dense_bwd_data_img": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _z, _p]),
+    "evae_dense_bwd_weight_group": (_i, [_p, _i, _p]),
     "evae_gated_dense_bwd_input": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "evae_act_bwd": (_i, [_p, _p, _z, _i, _f, _f, _p, _p]),
     "evae_conv2d_workspace_bytes": (_z, [_p, _i, _i]),

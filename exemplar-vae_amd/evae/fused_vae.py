@@ -50,6 +50,7 @@ SCHED = int(os.environ.get("EVAE_SCHED", "0"))
 # byte store: encoder layer 1's (dh, dg) leave the layer-2 data gradient as the bf16 tile images of its weight gradient
 # (evae_dense_bwd_data_img; r03: 16-byte stores after a lane-pair exchange, on the split-bf16 kernel) -- no fp32 [Mp x 2H]
 # buffer, no 36-us split / transposition pre-pass.  EVAE_IMG_DGRAD=0: the fp32 buffer + pre-pass
+GROUP_LEAVES = os.environ.get("EVAE_GROUP_LEAVES", "1") != "0"      # the batch rows' four leaf weight gradients as one launch
 IMG_DGRAD = os.environ.get("EVAE_IMG_DGRAD", "1") != "0" or bool(SCHED & 4)
 THIN_ROWS = 1024     # batch rows up to here take the fp32 split-K kernel for the first layer even on the byte store
 
@@ -543,10 +544,22 @@ class VaeExactLoss(torch.autograd.Function):
         def leaves():     # nobody waits for them before the optimizer
             with torch.cuda.stream(side):
                 kd.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)     # mean head, all C + B rows
-                kd.bwd_weight(dpx, B, D, D, D2, None, H, H, g_wp, g_bp)
-                kd.bwd_weight(dp2, B, 2 * H, 2 * H, D1, None, H, H, g_d2, g_e2)
-                kd.bwd_weight(dp1, B, 2 * H, 2 * H, z, None, Z, Z, g_d1, g_e1)
-                kd.bwd_weight(dlvp, B, Z, Z, A2.data_ptr() + off * H, None, H, H, g_wl, g_bl)
+                # the four leaf layers whose contraction is the B batch rows: ONE grouped launch (evae_dense_bwd_weight_group;
+                # r02: four launches of 8-9 us each at the end of the side stream's chain)
+                jobs = ((dpx, B, D, D, D2, H, H, g_wp, g_bp), (dp2, B, 2 * H, 2 * H, D1, H, H, g_d2, g_e2),
+                        (dp1, B, 2 * H, 2 * H, z, Z, Z, g_d1, g_e1),
+                        (dlvp, B, Z, Z, A2.data_ptr() + off * H, H, H, g_wl, g_bl))
+                grouped = B <= 128 and GROUP_LEAVES and all(n_ % 4 == 0 and k_ % 4 == 0 for _, _, n_, _, _, k_, _, _, _ in jobs)
+                if grouped:
+                    arr = (_lib.WgradJob * len(jobs))()
+                    for i_, (dy_, m_, n_, ldy_, x_, k_, ldx_, dw_, db_) in enumerate(jobs):
+                        arr[i_].dy = dy_.data_ptr(); arr[i_].x = x_ if isinstance(x_, int) else x_.data_ptr()
+                        arr[i_].dw = dw_.data_ptr(); arr[i_].db = db_.data_ptr()
+                        arr[i_].M, arr[i_].N, arr[i_].K, arr[i_].ldy, arr[i_].ldx = m_, n_, k_, ldy_, ldx_
+                    _lib.check(lib.evae_dense_bwd_weight_group(C.cast(arr, C.c_void_p), len(jobs), kd.st), "bwd_weight_group")
+                else:
+                    for dy_, m_, n_, ldy_, x_, k_, ldx_, dw_, db_ in jobs:
+                        kd.bwd_weight(dy_, m_, n_, ldy_, x_, None, k_, ldx_, dw_, db_)
                 torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
         leaves()      # (issued HERE: captured after the main stream's weight gradients instead, the same launches replay at
         #                0.82-0.94 ms for C = 200 and 1.2 ms at c2 -- this runtime's graph replay is very sensitive to where a

@@ -280,6 +280,13 @@ int evae_dense_bwd_weight_u8_phased(const float* dy, int M, int N, long long ldy
                                     int K, long long ldx, float x_scale, float* dw, float* db, void* ws, size_t ws_bytes,
                                     int phase, evae_stream_t stream);
 /* dh, dg: [M x N] with row stride ldo (the two halves of one [M x 2N] buffer when ldo = 2N) */
+/* Several thin weight gradients in ONE launch (the batch rows' leaf layers of a training step: reference utils/nn.py:44-69
+ * backward of the decoder's GatedDense layers and of the log-variance head, utils/training.py:39): every job is
+ * dw [N x K] = dy^T x (+ db [N] = column sums of dy, NULL to skip) over M <= 128 contraction rows, no row gather, no accumulation,
+ * pointers 16-byte aligned and N, K, ldy, ldx multiples of 4; at most 6 jobs.  EVAE_EINVAL (nothing launched) when a job does not
+ * qualify -- issue them with evae_dense_bwd_weight then. */
+typedef struct { const float* dy; const float* x; float* dw; float* db; int M, N, K, ldy, ldx; } evae_wgrad_job_t;
+int evae_dense_bwd_weight_group(const evae_wgrad_job_t* jobs, int njobs, evae_stream_t stream);
 int evae_gated_dense_bwd_input(const float* dout, const float* out, const float* s, int M, int N,
                                float* dh, float* dg, int ldo, evae_stream_t stream);
 int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, int act, float act_lo, float act_hi,

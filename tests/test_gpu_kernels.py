@@ -957,3 +957,38 @@ def test_data_gradient_that_writes_bf16_tile_images(ops, gemm_pipe, M1, M2):
                                             ops._p(dbB), ops._p(ws), ws.numel(), st), "bwd_weight_u8")
     assert rel(dwB.cpu().numpy(), dwA.cpu().numpy()) < 2e-6
     assert rel(dbB.cpu().numpy(), dbA.cpu().numpy()) < 2e-6
+
+
+def test_grouped_thin_weight_gradients_equal_the_single_launches(ops):
+    """evae_dense_bwd_weight_group: the batch rows' four leaf weight gradients of a training step (decoder layers, log-variance
+    head; contraction = 100 batch rows) in ONE launch -- the same kernel body per job, so bit-identical to four
+    evae_dense_bwd_weight launches, and both against float64."""
+    import ctypes as C
+    from evae import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(31)
+    B = 100
+    shapes = [(784, 300), (600, 300), (600, 40), (40, 300), (8, 12), (132, 68)]      # (N, K) of dw [N x K]
+    dys = [dev((rs.standard_normal((B, n)) * 0.1).astype(np.float32)) for n, _ in shapes]
+    xs = [dev(rs.standard_normal((B, k)).astype(np.float32)) for _, k in shapes]
+    arr = (_lib.WgradJob * len(shapes))()
+    dws = [torch.empty((n, k), device="cuda") for n, k in shapes]
+    dbs = [torch.empty(n, device="cuda") for n, _ in shapes]
+    for i, ((n, k), dy, x) in enumerate(zip(shapes, dys, xs)):
+        arr[i].dy, arr[i].x, arr[i].dw, arr[i].db = dy.data_ptr(), x.data_ptr(), dws[i].data_ptr(), dbs[i].data_ptr()
+        arr[i].M, arr[i].N, arr[i].K, arr[i].ldy, arr[i].ldx = B, n, k, n, k
+    _lib.check(lib.evae_dense_bwd_weight_group(C.cast(arr, C.c_void_p), len(shapes), ops._stream()), "group")
+    for i, ((n, k), dy, x) in enumerate(zip(shapes, dys, xs)):
+        ref_w = dy.double().t() @ x.double(); ref_b = dy.double().sum(0)
+        assert rel(dws[i].cpu().numpy(), ref_w.cpu().numpy()) < 2e-6, shapes[i]
+        assert rel(dbs[i].cpu().numpy(), ref_b.cpu().numpy()) < 2e-6, shapes[i]
+        # the single-launch entry point on the same operands
+        dw1 = torch.empty((n, k), device="cuda"); db1 = torch.empty(n, device="cuda")
+        nb = lib.evae_dense_bwd_weight_workspace_bytes(B, n, k)
+        ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.evae_dense_bwd_weight(ops._p(dy), B, n, n, ops._p(x), None, k, k, ops._p(dw1), ops._p(db1), 0, ops._p(ws), nb,
+                                             ops._stream()), "single")
+        assert torch.equal(dw1, dws[i]) and torch.equal(db1, dbs[i]), shapes[i]
+    # a job the group cannot take (contraction over more than 128 rows) is refused, nothing launched
+    arr[0].M = 200
+    assert lib.evae_dense_bwd_weight_group(C.cast(arr, C.c_void_p), len(shapes), ops._stream()) != 0
