@@ -26,6 +26,7 @@
 //   stay in one L2).
 
 #include "evae_gemm_x6.h"
+#include "evae_u8_prepare.h"
 
 namespace evae {
 
@@ -392,7 +393,8 @@ static bool thin_wgrad_direct() {
 
 static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const float* x,
                                  const int64_t* rows, int K, int ldx, float* dw, float* db,
-                                 int accumulate, void* ws, size_t ws_bytes, int phase, hipStream_t stream) {
+                                 int accumulate, void* ws, size_t ws_bytes, int phase, hipStream_t stream,
+                                 FinishArgs* finish_out = nullptr) {
   EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N, "dense_bwd_weight: bad sizes M=%d N=%d K=%d", M, N, K);
   EVAE_REQUIRE(dw != nullptr, "dense_bwd_weight: null dw");
   if (ws == nullptr || ws_bytes < evae_dense_bwd_weight_workspace_bytes(M, N, K)) {
@@ -446,6 +448,7 @@ static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const f
   FinishArgs f = {};
   f.part = part; f.nz = x6 ? sp6.nz : pl.nz; f.M = N; f.N = Kp; f.ldo = Kp; f.epi = EPI_RAW; f.out0 = dw; f.accumulate = accumulate;
   f.ones_col = K; f.out_db = db;
+  if (finish_out) { *finish_out = f; return EVAE_OK; }      // (the caller only wants to know what the finish would be)
   return launch_finish(f, stream);
 }
 
@@ -460,6 +463,57 @@ extern "C" int evae_dense_bwd_weight_phased(const float* dy, int M, int N, int l
                                             int accumulate, void* ws, size_t ws_bytes, int phase, evae_stream_t stream_) {
   EVAE_REQUIRE(phase == 1 || phase == 2, "dense_bwd_weight_phased: phase must be 1 or 2");
   return dense_bwd_weight_core(dy, M, N, ldy, x, rows, K, ldx, dw, db, accumulate, ws, ws_bytes, phase, (hipStream_t)stream_);
+}
+
+// ---- ONE finish launch for the weight gradients of a training step: the byte layer's (u8_wgrad_finish_body) and up to three
+// fp32 layers' (gemm_finish_body), whose GEMMs were issued without their own finish (evae_dense_bwd_weight_phased phase 1,
+// evae_dense_bwd_weight_u8_phased phase | 16).  Blocks of 256 threads; a block belongs to one job.
+struct FinishGroup { U8FinishArgs u8; int u8_tx, u8_blocks; FinishArgs f[3]; int fstart[4]; int flanes[3]; int nf; };
+
+__global__ __launch_bounds__(256) void wgrad_finish_group_kernel(const FinishGroup grp) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  if (b < grp.u8_blocks) { u8_wgrad_finish_body(grp.u8, b % grp.u8_tx, b / grp.u8_tx, tile); return; }
+  const int fb = b - grp.u8_blocks;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (j < grp.nf && fb >= grp.fstart[j] && fb < grp.fstart[j + 1]) {
+      const size_t t = (size_t)(fb - grp.fstart[j]) * 256 + threadIdx.x;
+      if (grp.flanes[j] == 8) gemm_finish_body<8>(grp.f[j], t);
+      else gemm_finish_body<1>(grp.f[j], t);
+      return;
+    }
+  }
+}
+
+extern "C" int evae_dense_bwd_weight_finish_group(const evae_wgrad_finish_job_t* jobs, int njobs, evae_stream_t stream_) {
+  EVAE_REQUIRE(jobs && njobs >= 1 && njobs <= 4, "dense_bwd_weight_finish_group: 1 .. 4 jobs");
+  FinishGroup grp = {};
+  for (int j = 0; j < njobs; ++j) {
+    const evae_wgrad_finish_job_t& w = jobs[j];
+    if (w.byte_rows) {
+      EVAE_REQUIRE(grp.u8_blocks == 0, "dense_bwd_weight_finish_group: one byte-layer job at most");
+      int tx = 0, ty = 0;
+      int rc = u8_wgrad_finish_job(w.M, w.N, w.K, w.x_scale, w.dw, w.db, w.ws, w.ws_bytes, &grp.u8, &tx, &ty);
+      if (rc) return rc;
+      grp.u8_tx = tx; grp.u8_blocks = tx * ty;
+    } else {
+      EVAE_REQUIRE(grp.nf < 3, "dense_bwd_weight_finish_group: three fp32 jobs at most");
+      EVAE_REQUIRE(w.M > 0 && w.N > 0 && w.K > 0 && w.dw && w.ws, "dense_bwd_weight_finish_group: bad job %d", j);
+      FinishArgs f = {};
+      // phase 2 of the same call, stopped before its launch: the plan (and with it the plane count) is a function of the sizes
+      int rc = dense_bwd_weight_core((const float*)w.ws, w.M, w.N, w.ldy, (const float*)w.ws, nullptr, w.K, w.ldx, w.dw, w.db, 0,
+                                     w.ws, w.ws_bytes, 2, (hipStream_t)stream_, &f);
+      if (rc) return rc;
+      grp.f[grp.nf] = f; grp.flanes[grp.nf] = finish_lanes(f);
+      grp.fstart[grp.nf + 1] = grp.fstart[grp.nf] + (int)finish_blocks(f);
+      ++grp.nf;
+    }
+  }
+  for (int j = grp.nf + 1; j < 4; ++j) grp.fstart[j] = grp.fstart[grp.nf];
+  const int total = grp.u8_blocks + grp.fstart[grp.nf];
+  wgrad_finish_group_kernel<<<total, 256, 0, (hipStream_t)stream_>>>(grp);
+  return check_launch("wgrad_finish_group_kernel");
 }
 
 // Several thin weight gradients in one launch (gemm_group_wgrad_kernel): each job as evae_dense_bwd_weight with a

@@ -290,46 +290,10 @@ __global__ __launch_bounds__(256) void u8_prepare_dyT_kernel(const float* __rest
   for (int i = 0; i < 6; ++i) dst[t + 256 * i] = src[t + 256 * i];
 }
 
-// dw[n][k] = x_scale * sum_z part[z][k][n] (k < K), db[n] = sum_z part[z][K][n]; fixed order.  32 x 32 tiles through LDS: the
-// planes are read along n and dw is written along k, both in full 128-byte runs (r02 wrote dw with a stride of K floats per
-// lane: 10.7-16 us for 1.9 MB; the sum over 14 planes is not what cost).
-__global__ __launch_bounds__(256) void u8_wgrad_finish_kernel(const float* __restrict__ part, int nz, int K, int N, float x_scale,
-                                                              float* __restrict__ dw, float* __restrict__ db) {
+// finish: u8_wgrad_finish_body (evae_u8_prepare.h)
+__global__ __launch_bounds__(256) void u8_wgrad_finish_kernel(const U8FinishArgs u) {
   __shared__ float tile[32][33];
-  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const size_t plane = (size_t)(K + 1) * N;
-  float a[4] = {0.f, 0.f, 0.f, 0.f};
-  const int n = n0 + tx;
-  // eight planes' worth of loads in flight before the first add (the launch is two blocks per CU: one dependent load per
-  // plane was 14 memory latencies in a row, 19 us); the sum runs over z in ascending order whatever the grouping
-  for (int z0 = 0; z0 < nz; z0 += 8) {
-    float v[8][4];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = k0 + ty + 8 * i;
-        const bool ok = z0 + j < nz && k <= K && n < N;
-        v[j][i] = ok ? part[(size_t)(z0 + j) * plane + (size_t)k * N + n] : 0.f;
-      }
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] += v[j][i];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = k0 + ty + 8 * i;
-    tile[ty + 8 * i][tx] = a[i];
-    if (k == K && n < N && db) db[n] = a[i];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int nn = n0 + ty + 8 * i, k = k0 + tx;
-    if (nn < N && k < K) dw[(size_t)nn * K + k] = tile[tx][ty + 8 * i] * x_scale;
-  }
+  u8_wgrad_finish_body(u, blockIdx.x, blockIdx.y, tile);
 }
 
 }  // namespace evae
@@ -421,7 +385,9 @@ extern "C" int evae_dense_bwd_weight_u8_images(int M, int N, int K, size_t* offs
 // pass); 4: everything but the gather-transpose (the workspace holds it)
 static int dense_bwd_weight_u8_core(const float* dy, int M, int N, long long ldy, const unsigned char* x,
                                     const int64_t* rows, int K, long long ldx, float x_scale, float* dw, float* db,
-                                    void* ws, size_t ws_bytes, int phase, hipStream_t stream) {
+                                    void* ws, size_t ws_bytes, int phase_, hipStream_t stream) {
+  const bool skip_finish = (phase_ & 16) != 0;       // | 16: the GEMM leaves its partial planes, no finish launch
+  const int phase = phase_ & 15;
   EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldy >= N && ldx >= K, "dense_bwd_weight_u8: bad sizes M=%d N=%d K=%d", M, N, K);
   EVAE_REQUIRE(dw != nullptr || phase == 3, "dense_bwd_weight_u8: null dw");
   if (M == 0) {
@@ -455,9 +421,23 @@ static int dense_bwd_weight_u8_core(const float* dy, int M, int N, long long ldy
       xT, nullptr, K + 1, L.ldt, 1.0f, img, L.nslab, L.ksplit, nullptr, nullptr, N, part, nullptr, L.tiles_k, L.tiles_n);
   rc = check_launch("u8_gemm_kernel<raw>");
   if (rc) return rc;
-  u8_wgrad_finish_kernel<<<dim3(cdiv(K + 1, 32), cdiv(N, 32)), 256, 0, stream>>>(part, L.nz, K, N, x_scale, dw, db);
+  if (skip_finish) return EVAE_OK;            // the caller sums the planes in a grouped finish (evae_dense_bwd_weight_finish_group)
+  const U8FinishArgs u = {part, L.nz, K, N, x_scale, dw, db};
+  u8_wgrad_finish_kernel<<<dim3(cdiv(K + 1, 32), cdiv(N, 32)), 256, 0, stream>>>(u);
   return check_launch("u8_wgrad_finish_kernel");
 }
+
+namespace evae {
+int u8_wgrad_finish_job(int M, int N, int K, float x_scale, float* dw, float* db, void* ws, size_t ws_bytes, U8FinishArgs* out,
+                        int* tiles_x, int* tiles_y) {
+  EVAE_REQUIRE(M > 0 && N > 0 && K > 0 && dw && ws && out, "dense_bwd_weight_finish_group: bad byte-layer job");
+  const U8WgradLayout L = u8_wgrad_layout(M, N, K);
+  EVAE_REQUIRE(ws_bytes >= L.total, "dense_bwd_weight_finish_group: byte-layer workspace too small (%zu)", ws_bytes);
+  *out = {(const float*)((char*)ws + L.part), L.nz, K, N, x_scale, dw, db};
+  *tiles_x = cdiv(K + 1, 32); *tiles_y = cdiv(N, 32);
+  return EVAE_OK;
+}
+}  // namespace evae
 
 extern "C" int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long ldy, const unsigned char* x,
                                         const int64_t* rows, int K, long long ldx, float x_scale, float* dw, float* db,
@@ -468,6 +448,6 @@ extern "C" int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long
 extern "C" int evae_dense_bwd_weight_u8_phased(const float* dy, int M, int N, long long ldy, const unsigned char* x,
                                                const int64_t* rows, int K, long long ldx, float x_scale, float* dw, float* db,
                                                void* ws, size_t ws_bytes, int phase, evae_stream_t stream_) {
-  EVAE_REQUIRE(phase >= 1 && phase <= 4, "dense_bwd_weight_u8_phased: phase must be 1 .. 4");
+  EVAE_REQUIRE((phase & 15) >= 0 && (phase & 15) <= 4 && (phase & ~31) == 0 && phase != 0, "dense_bwd_weight_u8_phased: phase must be 1 .. 4 (| 16)");
   return dense_bwd_weight_u8_core(dy, M, N, ldy, x, rows, K, ldx, x_scale, dw, db, ws, ws_bytes, phase, (hipStream_t)stream_);
 }

@@ -146,10 +146,11 @@ struct FinishArgs {
 // LANES = 1: one thread per output element walks the nz planes.  LANES = 8 (many planes, small output -- e.g.
 // the [40 x 301] head gradient over 25 000 rows): eight lanes share an element, lane j sums planes j, j+8, ... and
 // a fixed butterfly adds the eight sums, so the walk is 8x shorter and still deterministic.
+// (the body is a device function of the flat thread index: gemm_finish_kernel runs it on its own grid, the grouped finish of a
+// training step's weight gradients -- csrc/evae_dense_u8.hip::wgrad_finish_group_kernel -- on a per-job index)
 template <int LANES>
-static __global__ __launch_bounds__(256) void gemm_finish_kernel(const FinishArgs f) {
+__device__ __forceinline__ void gemm_finish_body(const FinishArgs& f, const size_t t) {
   const size_t plane = (size_t)f.M * f.N;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = t / LANES;
   const int j = (int)(t % LANES);
   const bool live = i < plane;
@@ -209,6 +210,16 @@ static __global__ __launch_bounds__(256) void gemm_finish_kernel(const FinishArg
     }
   }
 }
+
+template <int LANES>
+static __global__ __launch_bounds__(256) void gemm_finish_kernel(const FinishArgs f) {
+  gemm_finish_body<LANES>(f, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// which variant launch_finish takes for a job, and the blocks of 256 threads it needs
+static inline int finish_lanes(const FinishArgs& f) { return (f.nz >= 16 && (size_t)f.M * f.N * 8 <= ((size_t)1 << 22)) ? 8 : 1; }
+static inline unsigned finish_blocks(const FinishArgs& f) { return (unsigned)(((size_t)f.M * f.N * finish_lanes(f) + 255) / 256); }
+
 
 
 struct Plan {
@@ -276,11 +287,8 @@ static bool sk_local_enabled() {
 }
 
 static int launch_finish(const FinishArgs& f, hipStream_t stream) {
-  size_t n = (size_t)f.M * f.N;
-  if (f.nz >= 16 && n * 8 <= ((size_t)1 << 22))
-    gemm_finish_kernel<8><<<(unsigned)((n * 8 + 255) / 256), 256, 0, stream>>>(f);
-  else
-    gemm_finish_kernel<1><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(f);
+  if (finish_lanes(f) == 8) gemm_finish_kernel<8><<<finish_blocks(f), 256, 0, stream>>>(f);
+  else gemm_finish_kernel<1><<<finish_blocks(f), 256, 0, stream>>>(f);
   return check_launch("gemm_finish_kernel");
 }
 

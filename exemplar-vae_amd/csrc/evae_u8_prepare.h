@@ -60,4 +60,54 @@ __device__ __forceinline__ void wt_job_tile(const WtJob& j, int t, float (*tile)
     if (k0 + rr < j.K && n0 + tx < j.ldt) o[(size_t)(k0 + rr) * j.ldt + n0 + tx] = tile[tx][rr];
 }
 
+
+// ---- finish of the byte layer's split-K weight gradient (csrc/evae_dense_u8.hip), as a device function so that the grouped
+// finish of a training step (csrc/evae_dense.hip::wgrad_finish_group_kernel) can run it beside the fp32 layers' finishes.
+// dw[n][k] = x_scale * sum_z part[z][k][n] (k < K), db[n] = sum_z part[z][K][n]; fixed order.  32 x 32 tiles through LDS: the
+// planes are read along n and dw is written along k, both in full 128-byte runs (r02 wrote dw with a stride of K floats per
+// lane); eight planes' worth of loads in flight before the first add (two blocks per CU: one dependent load per plane was 14
+// memory latencies in a row).  256 threads, tile (bx, by) of the [K + 1] x [N] plane.
+struct U8FinishArgs { const float* part; int nz, K, N; float x_scale; float* dw; float* db; };
+
+__device__ __forceinline__ void u8_wgrad_finish_body(const U8FinishArgs& u, const int bx, const int by, float (*tile)[33]) {
+  const float* __restrict__ part = u.part;
+  const int nz = u.nz, K = u.K, N = u.N;
+  const int k0 = bx * 32, n0 = by * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t plane = (size_t)(K + 1) * N;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  const int n = n0 + tx;
+  for (int z0 = 0; z0 < nz; z0 += 8) {
+    float v[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + 8 * i;
+        const bool ok = z0 + j < nz && k <= K && n < N;
+        v[j][i] = ok ? part[(size_t)(z0 + j) * plane + (size_t)k * N + n] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] += v[j][i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + 8 * i;
+    tile[ty + 8 * i][tx] = a[i];
+    if (k == K && n < N && u.db) u.db[n] = a[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nn = n0 + ty + 8 * i, k = k0 + tx;
+    if (nn < N && k < K) u.dw[(size_t)nn * K + k] = tile[tx][ty + 8 * i] * u.x_scale;
+  }
+}
+
+// host side (csrc/evae_dense_u8.hip): the finish of evae_dense_bwd_weight_u8(M, N, K) over the partial planes in `ws`
+int u8_wgrad_finish_job(int M, int N, int K, float x_scale, float* dw, float* db, void* ws, size_t ws_bytes, U8FinishArgs* out,
+                        int* tiles_x, int* tiles_y);
+
 }  // namespace evae

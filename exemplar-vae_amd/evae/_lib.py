@@ -35,6 +35,13 @@ class WgradJob(C.Structure):
                 ("K", C.c_int), ("ldy", C.c_int), ("ldx", C.c_int)]
 
 
+class WgradFinishJob(C.Structure):
+    """evae_wgrad_finish_job_t"""
+    _fields_ = [("byte_rows", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ldy", C.c_int), ("ldx", C.c_int),
+                ("x_scale", C.c_float),
+                ("dw", C.c_void_p), ("db", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+
+
 class AdamTensor(C.Structure):
     """evae_adam_tensor_t"""
     _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("numel", _l)]
@@ -82,6 +89,7 @@ SIGNATURES = {
     "evae_dense_bwd_weight_u8_images": (_i, [_i, _i, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "evae_dense_bwd_data_img": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _z, _p]),
     "evae_dense_bwd_weight_group": (_i, [_p, _i, _p]),
+    "evae_dense_bwd_weight_finish_group": (_i, [_p, _i, _p]),
     "evae_gated_dense_bwd_input": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "evae_act_bwd": (_i, [_p, _p, _z, _i, _f, _f, _p, _p]),
     "evae_conv2d_workspace_bytes": (_z, [_p, _i, _i]),

@@ -50,6 +50,13 @@ SCHED = int(os.environ.get("EVAE_SCHED", "0"))
 # byte store: encoder layer 1's (dh, dg) leave the layer-2 data gradient as the bf16 tile images of its weight gradient
 # (evae_dense_bwd_data_img; r03: 16-byte stores after a lane-pair exchange, on the split-bf16 kernel) -- no fp32 [Mp x 2H]
 # buffer, no 36-us split / transposition pre-pass.  EVAE_IMG_DGRAD=0: the fp32 buffer + pre-pass
+FINISH_GROUP_HEAD = os.environ.get("EVAE_FINISH_GROUP_HEAD", "0") == "1"   # ... the mean head's too (needs the side stream joined first)
+# One finish launch for the step's split-K weight gradients (evae_dense_bwd_weight_finish_group) instead of one behind each GEMM.
+# Measured r03 and OFF: launches that follow each other on ONE stream of the replayed graph start back to back (gap 0.0 us in
+# profiles/r03_step_timeline_C25000.txt; the ~6 us gaps sit at cross-stream joins), so the merged launch saves nothing -- it ran
+# 23.4 us against 8.7 + 10.1 for the two it replaces (c2 0.6446-0.6468 vs 0.641-0.645 ms); with the mean head's finish in it as
+# well the side stream has to be joined earlier: c2 +10 us, C = 200 +17 us.
+FINISH_GROUP = os.environ.get("EVAE_FINISH_GROUP", "0") == "1"
 GROUP_LEAVES = os.environ.get("EVAE_GROUP_LEAVES", "1") != "0"      # the batch rows' four leaf weight gradients as one launch
 IMG_DGRAD = os.environ.get("EVAE_IMG_DGRAD", "1") != "0" or bool(SCHED & 4)
 THIN_ROWS = 1024     # batch rows up to here take the fp32 split-K kernel for the first layer even on the byte store
@@ -137,8 +144,13 @@ class _K:
                                                                          _vp(db), 0, _vp(w), w.numel(), self.st), "bwd_weight"))
         else:
             st = self.st if finish_on is None else finish_on.st
-            _lib.check(self.lib.evae_dense_bwd_weight_phased(_vp(dy), M, N, ldy, _vp(x), _vp(rows), K, ldx, _vp(dw), _vp(db), 0,
-                                                             _vp(w), w.numel(), phase, st), "bwd_weight_phased")
+            call = lambda: _lib.check(self.lib.evae_dense_bwd_weight_phased(_vp(dy), M, N, ldy, _vp(x), _vp(rows), K, ldx, _vp(dw),
+                                                                            _vp(db), 0, _vp(w), w.numel(), phase, st), "bwd_weight_phased")
+            if phase == 1:
+                ops.probed("dense_bwd_weight M=%d N=%d K=%d (+db, split-K GEMM; its planes are summed by the step's last grouped launch)"
+                           % (M, N, K), 2.0 * M * N * K, call)
+            else:
+                call()
 
 
 class VaeExactLoss(torch.autograd.Function):
@@ -540,10 +552,17 @@ class VaeExactLoss(torch.autograd.Function):
             batch_rows_done.record()
 
         g_wm = gslot("wm", Z, H); g_bm = gslot("bm", Z)
+        # ONE finish launch for the three split-K weight gradients of the step (encoder layer 1 on the byte store, layer 2, mean
+        # head) at the very end, instead of one behind each GEMM: a dependent launch less on the main stream's chain
+        fin_group = FINISH_GROUP and data_ext.dtype == torch.uint8 and not (SCHED & 10) and Mp > 128
 
         def leaves():     # nobody waits for them before the optimizer
             with torch.cuda.stream(side):
-                kd.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)     # mean head, all C + B rows
+                # mean head, all C + B rows (its finish joins the step's grouped finish launch when that is on)
+                if fin_group and FINISH_GROUP_HEAD:
+                    kd.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm, phase=1, ws_name="wgradh")
+                else:
+                    kd.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)
                 # the four leaf layers whose contraction is the B batch rows: ONE grouped launch (evae_dense_bwd_weight_group;
                 # r02: four launches of 8-9 us each at the end of the side stream's chain)
                 jobs = ((dpx, B, D, D, D2, H, H, g_wp, g_bp), (dp2, B, 2 * H, 2 * H, D1, H, H, g_d2, g_e2),
@@ -575,17 +594,19 @@ class VaeExactLoss(torch.autograd.Function):
         g_w2 = gslot("w2", 2 * H, H); g_b2 = gslot("b2", 2 * H)
         w2_args = (dq2, Mp, 2 * H, 2 * H, A1, None, H, H, g_w2, g_b2)
         g_w1 = gslot("w1", 2 * H, D); g_b1 = gslot("b1", 2 * H)
-        def w1_grad():
+        def w1_grad(no_finish=False):
             if data_ext.dtype == torch.uint8:
                 nb = lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D)
                 w = k.ws("wgrad_u8_fused", nb)
                 fl = 2.0 * Mp * 2 * H * D
                 # the forward pass left the transposed byte rows in the workspace (unless another step used it since)
                 have_xt = ctx.xt is not None and ctx.xt == (w.data_ptr(), _XT_GEN.get(w.data_ptr()))
-                ops.probed("dense_bwd_weight_u8 M=%d N=%d K=%d (uint8 rows, three bf16 terms; pre-passes + GEMM + finish)" % (Mp, 2 * H, D),
+                ops.probed("dense_bwd_weight_u8 M=%d N=%d K=%d (uint8 rows, three bf16 terms; %s)"
+                           % (Mp, 2 * H, D, "GEMM; planes summed by the step's last grouped launch" if no_finish else "pre-passes + GEMM + finish"),
                            fl, lambda: _lib.check(lib.evae_dense_bwd_weight_u8_phased(_vp(dq1), Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D,
                                                                                       ldd, 1.0 / 255.0, _vp(g_w1), _vp(g_b1), _vp(w),
-                                                                                      w.numel(), 4, k.st) if have_xt else
+                                                                                      w.numel(), (4 if have_xt else 0) | (16 if no_finish else 0), k.st)
+                                              if (have_xt or no_finish) else
                                               lib.evae_dense_bwd_weight_u8(_vp(dq1), Mp, 2 * H, 2 * H, _vp(data_ext), _vp(rows), D,
                                                                            ldd, 1.0 / 255.0, _vp(g_w1), _vp(g_b1), _vp(w),
                                                                            w.numel(), k.st), "bwd_weight_u8"),
@@ -616,6 +637,24 @@ class VaeExactLoss(torch.autograd.Function):
             k.bwd_weight(*w2_args)
             main.wait_event(pre_done)
             w1_phase(2, k.st)
+        elif fin_group:
+            k.bwd_weight(*w2_args, phase=1, ws_name="wgrad2")
+            if split_wait:
+                main.wait_event(batch_rows_done)
+            w1_grad(no_finish=True)
+            if FINISH_GROUP_HEAD:
+                main.wait_stream(side)      # (the mean head's GEMM and the grouped leaves)
+            arr = (_lib.WgradFinishJob * 3)()
+            w_u8 = k.ws("wgrad_u8_fused", lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D))
+            w_2 = ops._workspace("wgrad2" + k.sfx, lib.evae_dense_bwd_weight_workspace_bytes(Mp, 2 * H, H), dev)
+            w_h = ops._workspace("wgradh" + kd.sfx, lib.evae_dense_bwd_weight_workspace_bytes(Mp, Z, H), dev)
+            fjobs = ((1, Mp, 2 * H, D, 2 * H, ldd, 1.0 / 255.0, g_w1, g_b1, w_u8), (0, Mp, 2 * H, H, 2 * H, H, 1.0, g_w2, g_b2, w_2),
+                     (0, Mp, Z, H, Z, H, 1.0, g_wm, g_bm, w_h))[:3 if FINISH_GROUP_HEAD else 2]
+            for i_, (byte_, m_, n_, k_, ldy_, ldx_, xs_, dw_, db_, ws_) in enumerate(fjobs):
+                arr[i_].byte_rows, arr[i_].M, arr[i_].N, arr[i_].K, arr[i_].ldy, arr[i_].ldx = byte_, m_, n_, k_, ldy_, ldx_
+                arr[i_].x_scale = xs_; arr[i_].dw = dw_.data_ptr(); arr[i_].db = db_.data_ptr()
+                arr[i_].ws = ws_.data_ptr(); arr[i_].ws_bytes = ws_.numel()
+            _lib.check(lib.evae_dense_bwd_weight_finish_group(C.cast(arr, C.c_void_p), len(fjobs), k.st), "bwd_weight_finish_group")
         else:
             k.bwd_weight(*w2_args)
             if split_wait:

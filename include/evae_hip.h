@@ -275,11 +275,19 @@ int evae_dense_bwd_weight_u8(const float* dy, int M, int N, long long ldy, const
                              void* ws, size_t ws_bytes, evae_stream_t stream);
 /* The same in two calls that may go to different streams (the caller orders them with an event): phase 1 = the pre-passes
  * into the workspace, phase 2 = the product and its finish; or phase 3 = the byte gather-transpose alone (needs x / rows only,
- * dy and dw may be NULL: a training step issues it during its forward pass), phase 4 = everything else. */
+ * dy and dw may be NULL: a training step issues it during its forward pass), phase 4 = everything else.  phase | 16 (also
+ * 0 | 16): no finish launch -- the partial planes stay in ws for evae_dense_bwd_weight_finish_group. */
 int evae_dense_bwd_weight_u8_phased(const float* dy, int M, int N, long long ldy, const unsigned char* x, const int64_t* rows,
                                     int K, long long ldx, float x_scale, float* dw, float* db, void* ws, size_t ws_bytes,
                                     int phase, evae_stream_t stream);
 /* dh, dg: [M x N] with row stride ldo (the two halves of one [M x 2N] buffer when ldo = 2N) */
+/* ONE finish launch for the split-K weight gradients of a training step (r03): the GEMMs were issued without their own finish
+ * -- evae_dense_bwd_weight_phased(phase 1) for fp32 rows, evae_dense_bwd_weight_u8_phased(phase | 16) for the byte layer -- and
+ * leave partial planes in their workspaces; this call sums them (fixed order, same arithmetic as the separate finish launches)
+ * into dw / db.  A job repeats the sizes, row strides and workspace of its GEMM call; byte_rows != 0: the byte layer (x_scale as there; at
+ * most one such job); at most three fp32 jobs (no row gather, no accumulation). */
+typedef struct { int byte_rows; int M, N, K, ldy, ldx; float x_scale; float* dw; float* db; void* ws; size_t ws_bytes; } evae_wgrad_finish_job_t;
+int evae_dense_bwd_weight_finish_group(const evae_wgrad_finish_job_t* jobs, int njobs, evae_stream_t stream);
 /* Several thin weight gradients in ONE launch (the batch rows' leaf layers of a training step: reference utils/nn.py:44-69
  * backward of the decoder's GatedDense layers and of the log-variance head, utils/training.py:39): every job is
  * dw [N x K] = dy^T x (+ db [N] = column sums of dy, NULL to skip) over M <= 128 contraction rows, no row gather, no accumulation,

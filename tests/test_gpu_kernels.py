@@ -992,3 +992,51 @@ def test_grouped_thin_weight_gradients_equal_the_single_launches(ops):
     # a job the group cannot take (contraction over more than 128 rows) is refused, nothing launched
     arr[0].M = 200
     assert lib.evae_dense_bwd_weight_group(C.cast(arr, C.c_void_p), len(shapes), ops._stream()) != 0
+
+
+def test_grouped_finish_of_split_k_weight_gradients_equals_the_separate_finishes(ops):
+    """evae_dense_bwd_weight_finish_group: the byte layer's and two fp32 layers' split-K planes summed by ONE launch -- same
+    bodies, same order, so bit-identical to the GEMM + own-finish entry points."""
+    import ctypes as C
+    from evae import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(41)
+    M, H, D, Z, R = 2500, 300, 784, 40, 4000
+    q = (rs.randint(0, 256, (R, D)) * (rs.random_sample((R, D)) < 0.3)).astype(np.uint8)
+    store = torch.zeros(R * D + 64, dtype=torch.uint8, device="cuda"); xs = store[:R * D].view(R, D); xs.copy_(torch.from_numpy(q))
+    rows = dev(rs.randint(0, R, size=M).astype(np.int64))
+    dq1 = dev((rs.standard_normal((M, 2 * H)) * 0.1).astype(np.float32)); dq2 = dev((rs.standard_normal((M, 2 * H)) * 0.1).astype(np.float32))
+    dm = dev((rs.standard_normal((M, Z)) * 0.1).astype(np.float32))
+    a1 = dev(rs.standard_normal((M, H)).astype(np.float32)); a2 = dev(rs.standard_normal((M, H)).astype(np.float32))
+    st = ops._stream()
+    # separate entry points
+    dw1, db1 = ops.dense_bwd_weight_u8(dq1, xs, rows, 1.0 / 255.0, ws_name="t_fg_a")
+    ref = {}
+    for tag, dy, x, n, k in (("w2", dq2, a1, 2 * H, H), ("wm", dm, a2, Z, H)):
+        dw = torch.empty((n, k), device="cuda"); db = torch.empty(n, device="cuda")
+        nb = lib.evae_dense_bwd_weight_workspace_bytes(M, n, k); ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.evae_dense_bwd_weight(ops._p(dy), M, n, n, ops._p(x), None, k, k, ops._p(dw), ops._p(db), 0, ops._p(ws), nb, st), tag)
+        ref[tag] = (dw, db)
+    # GEMMs without their finish, then the grouped finish
+    nb1 = lib.evae_dense_bwd_weight_u8_workspace_bytes(M, 2 * H, D); ws1 = torch.zeros(nb1, dtype=torch.uint8, device="cuda")
+    g1 = torch.empty((2 * H, D), device="cuda"); gb1 = torch.empty(2 * H, device="cuda")
+    _lib.check(lib.evae_dense_bwd_weight_u8_phased(ops._p(dq1), M, 2 * H, 2 * H, ops._p(xs), ops._p(rows), D, D, 1.0 / 255.0, ops._p(g1),
+                                                   ops._p(gb1), ops._p(ws1), nb1, 16, st), "u8 gemm only")
+    outs, wss = {}, {}
+    for tag, dy, x, n, k in (("w2", dq2, a1, 2 * H, H), ("wm", dm, a2, Z, H)):
+        dw = torch.empty((n, k), device="cuda"); db = torch.empty(n, device="cuda")
+        nb = lib.evae_dense_bwd_weight_workspace_bytes(M, n, k); ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.evae_dense_bwd_weight_phased(ops._p(dy), M, n, n, ops._p(x), None, k, k, ops._p(dw), ops._p(db), 0, ops._p(ws), nb, 1,
+                                                    st), tag)
+        outs[tag] = (dw, db); wss[tag] = ws
+    arr = (_lib.WgradFinishJob * 3)()
+    for i, (byte, n, k, ldx, xs_, dw, db, ws) in enumerate(((1, 2 * H, D, D, 1.0 / 255.0, g1, gb1, ws1),
+                                                            (0, 2 * H, H, H, 1.0, outs["w2"][0], outs["w2"][1], wss["w2"]),
+                                                            (0, Z, H, H, 1.0, outs["wm"][0], outs["wm"][1], wss["wm"]))):
+        arr[i].byte_rows, arr[i].M, arr[i].N, arr[i].K, arr[i].ldy, arr[i].ldx, arr[i].x_scale = byte, M, n, k, n, ldx, xs_
+        arr[i].dw, arr[i].db, arr[i].ws, arr[i].ws_bytes = dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel()
+    _lib.check(lib.evae_dense_bwd_weight_finish_group(C.cast(arr, C.c_void_p), 3, st), "finish group")
+    assert torch.equal(g1, dw1) and torch.equal(gb1, db1)
+    for tag in ("w2", "wm"):
+        assert torch.equal(outs[tag][0], ref[tag][0]) and torch.equal(outs[tag][1], ref[tag][1]), tag
+    assert rel(g1.cpu().numpy(), (dq1.double().t() @ (xs[rows].double() / 255.0)).cpu().numpy()) < 2e-6
