@@ -583,11 +583,11 @@ class VaeExactLoss(torch.autograd.Function):
         leaves()      # (issued HERE: captured after the main stream's weight gradients instead, the same launches replay at
         #                0.82-0.94 ms for C = 200 and 1.2 ms at c2 -- this runtime's graph replay is very sensitive to where a
         #                branch's nodes sit relative to the other branch's, r03 measurement)
-        # SCHED & 256: layer 2's weight gradient starts as soon as the batch rows' dq2 exist, without waiting for their layer-1
-        # (dh, dg).  Measured r03 (c2): 0.668 -> 0.684-0.694 ms -- main gains 15 us, but the side stream's leaf weight gradients,
-        # which used to get the machine first, then start BEHIND layer 2's CU-filling launch (the mean head's: 27 -> 123 us)
-        # and end after the main stream's last launch.  Off.
-        split_wait = bool(SCHED & 256) and not (SCHED & 10)
+        # Layer 2's weight gradient starts as soon as the batch rows' dq2 exist, without waiting for their layer-1 (dh, dg) (the
+        # side stream's last thin data gradient, stretched to ~40 us beside the exemplar rows' GEMM).  r03: with the leaf
+        # gradients as four launches this was 0.668 -> 0.684-0.694 ms (they then started behind layer 2's CU-filling launch and
+        # ended after the main stream); with the leaves grouped into one launch it is 0.662-0.664 -> 0.658 ms.  SCHED & 256: off.
+        split_wait = not (SCHED & (256 | 10))
         main.wait_event(dq2_rows_done if split_wait else batch_rows_done)
         # ---- weight gradients of the two encoder layers over all C + B rows
         #      (layer 2's finish launch runs on the side stream, beside layer 1's GEMM instead of in front of it)
