@@ -38,7 +38,32 @@ def _need_cuda(*ts):
                 "evae ops run on MI355X only (got a %s tensor); there is no CPU fallback" % t.device)
 
 
+_SIDE_STREAMS = set()      # raw handles of streams registered as "side" streams: launches issued there get their own workspaces
+
+
+def register_side_stream(stream):
+    """Two launches that share a named workspace must not run at the same time.  A model that issues part of its step on a
+    second stream (evae/fused_vae.py, models/AbsHModel.py) registers that stream here: every workspace requested while it is
+    the current stream -- also from autograd's backward nodes, which run on the stream of their forward -- is a separate buffer."""
+    _SIDE_STREAMS.add(int(stream.cuda_stream))
+
+
+_MODEL_SIDE = {}
+
+
+def model_side_stream(device):
+    """The registered second stream of the modular two-stream training paths (one per device, made on first use)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _MODEL_SIDE.get(key)
+    if st is None:
+        st = _MODEL_SIDE[key] = torch.cuda.Stream(device=device)
+        register_side_stream(st)
+    return st
+
+
 def _workspace(name, nbytes, device):
+    if _SIDE_STREAMS and int(torch.cuda.current_stream(device).cuda_stream) in _SIDE_STREAMS:
+        name = name + "@side"
     key = (name, device.index if device.index is not None else torch.cuda.current_device())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:

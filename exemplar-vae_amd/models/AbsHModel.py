@@ -2,11 +2,16 @@
 model declares (models.HVAE_2level, models.convHVAE_2level).  Behavioural contract: reference
 models/AbsHModel.py:8-107 -- method names, argument order, the 8-tuple of latent statistics and the flat
 [B x D] decoder outputs are what models.BaseModel and utils.evaluation rely on."""
+import os
+
 import numpy as np
 import torch
 
 from models.BaseModel import BaseModel
 from utils.distributions import log_normal_diag
+
+# training step of the dense 2-level model on two streams (calculate_loss below); EVAE_HVAE_TWO_STREAM=0: one stream
+_TWO_STREAM = os.environ.get("EVAE_HVAE_TWO_STREAM", "1") != "0"
 
 _CLAMP_LO, _CLAMP_HI = 1.0 / 512.0, 1.0 - 1.0 / 512.0
 
@@ -66,6 +71,64 @@ class BaseHModel(BaseModel):
         kl_z2 = (log_normal_diag(rows2(z2), rows2(q2_mu), rows2(q2_lv), dim=1)
                  - self.log_p_z(z=(z2, x_indices), exemplars_embedding=emb))
         return kl_z1 + kl_z2
+
+    def _two_stream_path(self, x, x_indices, exemplars_embedding, dataset):
+        a = self.args
+        return (_TWO_STREAM and self.training and a.prior == 'exemplar_prior' and a.approximate_prior is False
+                and exemplars_embedding is None and dataset is not None and x_indices is not None and x.is_cuda
+                and torch.is_grad_enabled() and not self._is_conv() and not self._sharded())
+
+    def calculate_loss(self, x, beta=1., average=False, exemplars_embedding=None, cache=None, dataset=None):
+        """Training step with the exact exemplar prior on one device (reference models/BaseModel.py:54-77 over AbsHModel.py:13-106):
+        the same modules and the same arithmetic as the one-stream path, issued on TWO streams -- the batch rows' path (eleven
+        thin dense layers, ~150 launches of a few microseconds each with their backward) on a side stream, the exemplar rows'
+        encoder q(z2 | .) and the prior on the caller's stream; they meet at z2 (forward) and at log p(z2).  Autograd runs
+        every node's backward on the stream of its forward, so the two halves of the backward pass overlap the same way.
+        r03: c4 (11 500 exemplars) 1.23 -> see DESIGN section 4; the exemplar side was waiting behind the thin launches."""
+        xx, x_indices = x
+        if not self._two_stream_path(xx, x_indices, exemplars_embedding, dataset):
+            return super().calculate_loss(x, beta, average, exemplars_embedding, cache, dataset)
+        from evae import ops
+        main = torch.cuda.current_stream()
+        side = ops.model_side_stream(xx.device)        # registered: what runs there takes its own kernel workspaces
+        side.wait_stream(main)
+        d1, d2 = self.args.z1_size, self.args.z2_size
+        with torch.cuda.stream(side):
+            # forward() of this class, in its order (the two reparameterize calls draw z2's noise, then z1's), minus p(z1 | z2)
+            xin = xx.view(-1, *self.args.input_size) if self._is_conv() else xx
+            q2_mu, q2_lv = self.q_z(xin)
+            z2 = self.reparameterize(q2_mu, q2_lv)
+            z2_ready = torch.cuda.Event(); z2_ready.record()
+            q1_mu, q1_lv = self.q_z1(xin, z2)
+            z1 = self.reparameterize(q1_mu, q1_lv)
+            z1_ready = torch.cuda.Event(); z1_ready.record()
+            x_mean, x_logvar = self.p_x(z1, z2)
+            x_flat = xx.reshape(xx.shape[0], -1) if xx.dim() != 2 else xx
+            RE = self.reconstruction_loss(x_flat, x_mean, x_logvar)
+            log_q1 = log_normal_diag(z1.view(-1, d1), q1_mu.view(-1, d1), q1_lv.view(-1, d1), dim=1)
+            log_q2 = log_normal_diag(z2.view(-1, d2), q2_mu.view(-1, d2), q2_lv.view(-1, d2), dim=1)
+        # this stream: the exemplar rows' encoder (independent of the batch: it starts at once), then what hangs off z2 alone --
+        # the prior and the p(z1 | z2) branch (its eight launches and their backward come off the longer chain)
+        emb = self.get_exemplar_set(q2_mu, q2_lv, dataset, cache, x_indices)
+        main.wait_event(z2_ready)
+        z2.record_stream(main)
+        log_prior = self.log_p_z(z=(z2.view(-1, d2), x_indices), exemplars_embedding=emb)
+        p1_mu, p1_lv = self.p_z1(z2)
+        main.wait_event(z1_ready)
+        z1.record_stream(main)
+        log_p1 = log_normal_diag(z1.view(-1, d1), p1_mu.view(-1, d1), p1_lv.view(-1, d1), dim=1)
+        lp_ready = torch.cuda.Event(); lp_ready.record()
+        log_prior.record_stream(side); log_p1.record_stream(side)
+        with torch.cuda.stream(side):
+            side.wait_event(lp_ready)
+            KL = (log_q1 - log_p1) + (log_q2 - log_prior)           # (the grouping of kl_loss)
+            loss = -RE + beta * KL
+            if average:
+                loss, RE, KL = torch.mean(loss), torch.mean(RE), torch.mean(KL)
+        main.wait_stream(side)
+        for t in (loss, RE, KL):
+            t.record_stream(main)
+        return loss, RE, KL
 
     def forward(self, x):
         q2_mu, q2_lv = self.q_z(x)
