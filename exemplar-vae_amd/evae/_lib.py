@@ -146,6 +146,10 @@ def load():
         raise EvaeError(
             "libevae_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C exemplar-vae_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    # torch first: it ships its own libamdhip64, and the library must bind to THAT runtime (the one that owns the tensors'
+    # memory and streams).  Loaded the other way round -- build() and smoke() in one process did it -- the process ends up with
+    # two HIP runtimes and every launch of this library fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch with include/evae_hip.h
