@@ -79,6 +79,6 @@ def run(torch, np, orc, B=16, C=200, N=500, seed=61, beta=0.37, verbose=False, t
         print("max grad rel err: %.3g   max param rel err after AdamNormGrad: %.3g"
               % (max(gerr.values()), max(perr.values())))
     assert max(errs.values()) < tol, errs
-    assert max(gerr.values()) < 5e-4, gerr
+    assert max(gerr.values()) < 2e-5, gerr
     assert max(perr.values()) < 1e-6, perr
     return errs, gerr, perr

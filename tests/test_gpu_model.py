@@ -413,7 +413,7 @@ G21_CASES = {      # single_conv at gain 1: |log p| ~ 1e8 in the untrained net (
 }
 # (values, gradient norms, cache rows): what fp32 resolves at that magnitude -- the KL there is a difference of two ~1e8 terms of
 # twelve un-normalised residual blocks, so agreement between two correct fp32 implementations is ~1e-4, not 1e-6
-MODEL_CASE_TOL = {"single_conv_mnist_gain1": (1e-3, 2e-2, 1e-3)}
+MODEL_CASE_TOL = {"single_conv_mnist_gain1": (1e-3, 3e-3, 1e-3)}
 
 
 @pytest.mark.parametrize("tag", list(G9_CASES) + list(G19_CASES) + list(G21_CASES))
@@ -421,7 +421,7 @@ def test_other_architectures_match_reference_golden(golden, tag):
     from utils.utils import importing_model
     g = golden("g9_models" if tag in G9_CASES else "g21_single_conv_gain1" if tag in G21_CASES else "g19_models_geometries")
     cfg = dict(G9_CASES[tag] if tag in G9_CASES else G21_CASES[tag] if tag in G21_CASES else G19_CASES[tag])
-    tol_v, tol_g, tol_c = MODEL_CASE_TOL.get(tag, (1e-4, 2e-3, 1e-4))
+    tol_v, tol_g, tol_c = MODEL_CASE_TOL.get(tag, (1e-4, 3e-4, 1e-4))
     B, C, N = cfg.pop("B"), cfg.pop("C"), cfg.pop("N")
     gain = cfg.pop("gain", 1.0)
     args = smoke_case.vae_args(number_components=C, training_set_size=N, **cfg)
@@ -517,7 +517,7 @@ def test_c5_geometry_matches_reference_golden(golden):
     norms = np.asarray([0.0 if p.grad is None else p.grad.double().norm().item() for _, p in model.named_parameters()])
     ref = g["gnorms"]
     assert norms.shape == ref.shape
-    assert np.all(np.abs(norms - ref) <= 2e-3 * np.maximum(ref, 1e-5)), np.abs(norms - ref).max()
+    assert np.all(np.abs(norms - ref) <= 1e-4 * np.maximum(ref, 1e-5)), (np.abs(norms - ref) / np.maximum(ref, 1e-5)).max()
     model.eval()
     with torch.no_grad():
         cz, clv = model.cache_z(dataset)
@@ -871,7 +871,7 @@ def test_grey_inputs_through_mlp_models_match_reference_golden(golden, tag, mode
     for n, p in model.named_parameters():
         ref = float(g[tag + "_gnorm_" + n])
         got = 0.0 if p.grad is None else p.grad.double().norm().item()
-        assert abs(got - ref) <= 2e-3 * max(ref, 1e-6), n
+        assert abs(got - ref) <= 1e-4 * max(ref, 1e-6), n
 
 
 @pytest.mark.parametrize("model_name", ["vae", "hvae_2level", "convhvae_2level"])
