@@ -680,8 +680,11 @@ def main():
                ("all_gather (lse, coefficient)", 8 * B), ("all_reduce dz", 4 * B * world * Z), ("all_reduce parameter gradients", 4 * n_param)]
         coll = {"count": len(lst), "bytes": sum(b_ for _, b_ in lst), "list": lst}
     else:
+        # replicated batch: only the encoder q(z | .) sees the rank's exemplar shard -- the flat all-reduce carries its six tensors
+        n_enc = sum(p_.numel() for nm_, p_ in model.named_parameters() if nm_.startswith(("q_z_layers", "q_z_mean")))
         lst = [("all_gather partial (max, sumexp, nmask)", 12 * B), ("all_reduce (dz, dlogvar)", 4 * (B * Z + Z)),
-               ("all_reduce parameter gradients", 4 * n_param)]
+               ("all_reduce encoder gradients (the others are identical on every rank)" if model_name == "vae"
+                else "all_reduce parameter gradients", 4 * (n_enc if model_name == "vae" else n_param))]
         coll = {"count": len(lst), "bytes": sum(b_ for _, b_ in lst), "list": lst}
     # second measurement of a multi-GPU run: the data-parallel mode, same process group, its own model / optimizer / runner
     dp_line = None

@@ -408,7 +408,10 @@ class VaeExactLoss(torch.autograd.Function):
         def gslot(name, *shape):
             o, n = offs[name]
             return gflat[o:o + n].view(*shape)
-        if sharded:
+        if sharded == 1 and os.environ.get("EVAE_REDUCE_ALL", "0") != "1":
+            # replicated batch: only the encoder's gradients (slots w1 .. bm, contiguous) differ between the ranks
+            shard.register_flat_grads(gflat, offs["w1"][0], offs["bm"][0] + (offs["bm"][1] + 63) // 64 * 64)
+        elif sharded:
             shard.register_flat_grads(gflat)
         # upstream gradients are per-row vectors (average=False) or scalars of the batch means (average=True)
         beta_dev = beta if torch.is_tensor(beta) else None

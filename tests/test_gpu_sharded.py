@@ -88,6 +88,10 @@ def _spawn(world, fused):
 def test_two_rank_sharded_training_matches_single(fused):
     single = _spawn(1, fused)[0]
     double = _spawn(2, fused)
+    # the replicas must stay bit-identical to each other: the fused step only all-reduces the encoder's gradients (the other
+    # tensors' gradients come from the replicated batch rows alone), which is only right while every rank computes the same numbers
+    for kk in double[0][2]:
+        assert np.array_equal(double[0][2][kk], double[1][2][kk]), kk
 
     def rel(a, b):
         a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
