@@ -32,13 +32,14 @@ namespace evae {
 
 __global__ void gated_bwd_input_kernel(const float* __restrict__ dout, const float* __restrict__ gout,
                                        const float* __restrict__ s, int M, int N, int ldo,
-                                       float* __restrict__ dh, float* __restrict__ dg) {
+                                       float* __restrict__ dh, float* __restrict__ dg, int ldd) {
   const size_t n = (size_t)M * N;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    const float d = dout[i], ov = gout[i], sv = s[i];
-    const size_t o = (i / N) * (size_t)ldo + (i % N);
+    const size_t row = i / N, col = i % N;
+    const float d = dout[row * (size_t)ldd + col], ov = gout[i], sv = s[i];
+    const size_t o = row * (size_t)ldo + col;
     dh[o] = d * sv;
     dg[o] = d * ov * (1.0f - sv);
   }
@@ -552,8 +553,16 @@ extern "C" int evae_gated_dense_bwd_input(const float* dout, const float* out, c
                                           float* dh, float* dg, int ldo, evae_stream_t stream_) {
   if (M <= 0 || N <= 0) return EVAE_OK;
   EVAE_REQUIRE(dout && out && s && dh && dg && ldo >= N, "gated_dense_bwd_input: bad arguments");
-  gated_bwd_input_kernel<<<elt_grid((size_t)M * N), 256, 0, (hipStream_t)stream_>>>(dout, out, s, M, N, ldo, dh, dg);
+  gated_bwd_input_kernel<<<elt_grid((size_t)M * N), 256, 0, (hipStream_t)stream_>>>(dout, out, s, M, N, ldo, dh, dg, N);
   return check_launch("gated_dense_bwd_input");
+}
+
+extern "C" int evae_gated_dense_bwd_input_ld(const float* dout, int ldd, const float* out, const float* s, int M, int N,
+                                             float* dh, float* dg, int ldo, evae_stream_t stream_) {
+  if (M <= 0 || N <= 0) return EVAE_OK;
+  EVAE_REQUIRE(dout && out && s && dh && dg && ldo >= N && ldd >= N, "gated_dense_bwd_input_ld: bad arguments");
+  gated_bwd_input_kernel<<<elt_grid((size_t)M * N), 256, 0, (hipStream_t)stream_>>>(dout, out, s, M, N, ldo, dh, dg, ldd);
+  return check_launch("gated_dense_bwd_input_ld");
 }
 
 extern "C" int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, int act, float act_lo,

@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256) void batch_prologue_u8_kernel(const unsigned c
 // ELBO assembly on [B] rows in one launch: KL_i = logq_i - logp_i, loss_i = beta*KL_i - RE_i, and the three
 // batch means (models/BaseModel.py:71-75).  beta comes from device memory when the step is graph-captured.
 __global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* __restrict__ RE, const float* __restrict__ logq,
-                                                       const float* __restrict__ logp,
+                                                       const float* __restrict__ logp, const float* __restrict__ logq2,
+                                                       const float* __restrict__ logp2,
                                                        const float* __restrict__ beta_dev, float beta_host, int B,
                                                        float* __restrict__ loss, float* __restrict__ KL,
                                                        float* __restrict__ means) {
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* __restrict__
   const float beta = beta_dev ? beta_dev[0] : beta_host;
   float sl = 0.f, sr = 0.f, sk = 0.f;
   for (int i = threadIdx.x; i < B; i += 256) {
-    const float kl = logq[i] - logp[i];
+    float kl = logq[i] - logp[i];
+    if (logq2) kl += logq2[i] - logp2[i];            // two latent layers: (log q1 - log p1) + (log q2 - log p2), models/AbsHModel.py:88-106
     const float l = beta * kl - RE[i];
     KL[i] = kl;
     loss[i] = l;
@@ -579,8 +581,18 @@ extern "C" int evae_elbo_fwd(const float* RE, const float* logq, const float* lo
   EVAE_REQUIRE(B >= 0, "elbo_fwd: bad size");
   if (B == 0) return EVAE_OK;
   EVAE_REQUIRE(RE && logq && logp && loss && KL, "elbo_fwd: null pointer");
-  elbo_fwd_kernel<<<1, 256, 0, (hipStream_t)s>>>(RE, logq, logp, beta_dev, beta_host, B, loss, KL, means);
+  elbo_fwd_kernel<<<1, 256, 0, (hipStream_t)s>>>(RE, logq, logp, nullptr, nullptr, beta_dev, beta_host, B, loss, KL, means);
   return check_launch("elbo_fwd");
+}
+
+extern "C" int evae_elbo2_fwd(const float* RE, const float* logq1, const float* logp1, const float* logq2, const float* logp2,
+                              const float* beta_dev, float beta_host, int B, float* loss, float* KL, float* means,
+                              evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0, "elbo2_fwd: bad size");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(RE && logq1 && logp1 && logq2 && logp2 && loss && KL, "elbo2_fwd: null pointer");
+  elbo_fwd_kernel<<<1, 256, 0, (hipStream_t)s>>>(RE, logq1, logp1, logq2, logp2, beta_dev, beta_host, B, loss, KL, means);
+  return check_launch("elbo2_fwd");
 }
 
 __global__ void step_stats_kernel(const float* loss, const float* re, const float* kl, float* step3, float* totals3) {

@@ -374,13 +374,14 @@ class GatedDenseFn(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib.load()
         x, rows, wh, wg, gout, s = ctx.saved_tensors
-        dout = _f32(dout)
         M, N = gout.shape
+        if not (dout.dtype == torch.float32 and dout.dim() == 2 and dout.stride(1) == 1 and dout.stride(0) >= N):
+            dout = _f32(dout)           # (a column block of a wider gradient -- half of a torch.cat's -- is read where it lies)
         K = wh.shape[1]
         dpre = torch.empty((M, 2 * N), device=gout.device)          # [dh | dg]: one buffer, one weight-grad GEMM
         base = dpre.data_ptr()
-        _lib.check(lib.evae_gated_dense_bwd_input(_p(dout), _p(gout), _p(s), M, N, _vp(base), _vp(base + 4 * N),
-                                                  2 * N, _stream()), "evae_gated_dense_bwd_input")
+        _lib.check(lib.evae_gated_dense_bwd_input_ld(_p(dout), dout.stride(0), _p(gout), _p(s), M, N, _vp(base), _vp(base + 4 * N),
+                                                     2 * N, _stream()), "evae_gated_dense_bwd_input_ld")
         dw, db = _bwd_weight(dpre, x, rows, K)                    # [dWh ; dWg], [dbh ; dbg]
         dx = None
         if ctx.needs_input_grad[0]:
@@ -811,6 +812,134 @@ class ReparamLogQ(torch.autograd.Function):
         _lib.check(lib.evae_reparam_logq_bwd(_p(mu), _p(logvar), _p(eps), _p(z), _p(dz), _p(dlogq), B, zd,
                                              _p(dmu), _p(dlv), _stream()), "evae_reparam_logq_bwd")
         return dmu, dlv, None
+
+
+class HeadsReparamFn(torch.autograd.Function):
+    """(h, wm, bm, wl, bl, eps) -> (z, z_mean, logvar, log q(z | .)): the mean head, the Hardtanh(lo, hi) log-variance head, the
+    sample and its log-density (reference models/VAE.py:24-26 / AbsHModel.py:22-29, BaseModel.py:79-82, utils/distributions.py:
+    28-33) as evae_heads_reparam_fwd's two launches (separately: 2 linear layers x 2, the sample, the density = 6), and a
+    backward of four (evae_reparam_logq_bwd_hardtanh, one data gradient over both heads, one grouped weight gradient)
+    where the separate Functions take thirteen."""
+
+    @staticmethod
+    def forward(ctx, h, wm, bm, wl, bl, eps, lo, hi):
+        lib = _lib.load()
+        _need_cuda(h, wm, wl, eps)
+        h, wm, wl, eps = _f32(h), _f32(wm), _f32(wl), _f32(eps)
+        if h.stride(1) != 1:
+            h = h.contiguous()
+        M, K = h.shape
+        Z = wm.shape[0]
+        assert wl.shape == wm.shape and wm.shape[1] == K and eps.shape == (M, Z) and eps.is_contiguous()
+        z_mean = torch.empty((M, Z), device=h.device); lv_pre = torch.empty_like(z_mean); logvar = torch.empty_like(z_mean)
+        z = torch.empty_like(z_mean); logq = torch.empty(M, device=h.device)
+        ws = _workspace("heads", lib.evae_heads_reparam_fwd_workspace_bytes(M, K, Z), h.device)
+        _lib.check(lib.evae_heads_reparam_fwd(_p(h), M, K, h.stride(0), _p(wm), _p(bm), _p(wl), _p(bl), Z, float(lo), float(hi),
+                                              _p(eps), _p(z_mean), _p(lv_pre), _p(logvar), _p(z), _p(logq), _p(ws), ws.numel(),
+                                              _stream()), "evae_heads_reparam_fwd")
+        ctx.save_for_backward(h, wm, wl, z_mean, lv_pre, logvar, eps, z)
+        ctx.set_materialize_grads(False)           # unused outputs (the moments, on the training path) arrive as None, not as zeros
+        ctx.clamp = (float(lo), float(hi))
+        ctx.has_bias = (bm is not None, bl is not None)
+        return z, z_mean, logvar, logq
+
+    @staticmethod
+    def backward(ctx, dz, dmean, dlogvar, dlogq):
+        lib = _lib.load()
+        h, wm, wl, z_mean, lv_pre, logvar, eps, z = ctx.saved_tensors
+        lo, hi = ctx.clamp
+        M, K = h.shape
+        Z = wm.shape[0]
+        if dz is None and dmean is None and dlogvar is None and dlogq is None:
+            return (None,) * 8
+        dz = None if dz is None else _f32(dz)
+        dlogq = None if dlogq is None else _f32(dlogq)
+        dmu = torch.empty_like(z_mean); dlvp = torch.empty_like(z_mean)
+        _lib.check(lib.evae_reparam_logq_bwd_hardtanh(_p(z_mean), _p(logvar), _p(eps), _p(z), _p(dz), None, _p(dlogq), _p(lv_pre),
+                                                      lo, hi, M, Z, _p(dmu), _p(dlvp), _stream()), "evae_reparam_logq_bwd_hardtanh")
+        if dmean is not None:                       # a consumer of the moments themselves (none on the training path)
+            dmu = dmu + dmean
+        if dlogvar is not None:
+            dlvp = dlvp + dlogvar * ((lv_pre > lo) & (lv_pre < hi))
+        dh = _bwd_data(dmu.data_ptr(), wm, dlvp.data_ptr(), wl, M, Z, Z, h.device) if ctx.needs_input_grad[0] else None
+        if M <= 128 and Z % 4 == 0 and K % 4 == 0 and h.stride(0) % 4 == 0:
+            dwm = torch.empty((Z, K), device=h.device); dwl = torch.empty_like(dwm)
+            dbm = torch.empty(Z, device=h.device); dbl = torch.empty_like(dbm)
+            arr = (_lib.WgradJob * 2)()
+            for j, (dy_, dw_, db_) in enumerate(((dmu, dwm, dbm), (dlvp, dwl, dbl))):
+                arr[j].dy = dy_.data_ptr(); arr[j].x = h.data_ptr(); arr[j].dw = dw_.data_ptr(); arr[j].db = db_.data_ptr()
+                arr[j].M, arr[j].N, arr[j].K, arr[j].ldy, arr[j].ldx = M, Z, K, Z, h.stride(0)
+            _lib.check(lib.evae_dense_bwd_weight_group(C.cast(arr, C.c_void_p), 2, _stream()), "evae_dense_bwd_weight_group")
+        else:
+            dwm, dbm = _bwd_weight(dmu, h, None, K)
+            dwl, dbl = _bwd_weight(dlvp, h, None, K)
+        return dh, dwm, (dbm if ctx.has_bias[0] else None), dwl, (dbl if ctx.has_bias[1] else None), None, None, None
+
+
+def heads_reparam(h, wm, bm, wl, bl, eps, lo, hi):
+    return HeadsReparamFn.apply(h, wm, bm, wl, bl, eps, lo, hi)
+
+
+class ElboFn(torch.autograd.Function):
+    """(RE, log q1, log p1[, log q2, log p2], beta) -> KL = (log q1 - log p1) [+ (log q2 - log p2)], loss = beta KL - RE, and with
+    `average` their batch means (reference models/BaseModel.py:71-77, AbsHModel.py:88-106): one launch each way (evae_elbo_fwd /
+    evae_elbo2_fwd, evae_elbo_bwd) where the tensor expressions take eight and ten.  Returns (loss, KL) per row, or the three
+    means (loss, RE, KL) as 0-d tensors.  beta: a number, or a one-element device tensor (captured steps); no gradient."""
+
+    @staticmethod
+    def forward(ctx, RE, lq1, lp1, lq2, lp2, beta, average):
+        lib = _lib.load()
+        _need_cuda(RE, lq1, lp1)
+        RE, lq1, lp1 = _f32(RE).contiguous(), _f32(lq1).contiguous(), _f32(lp1).contiguous()
+        two = lq2 is not None
+        if two:
+            lq2, lp2 = _f32(lq2).contiguous(), _f32(lp2).contiguous()
+        B = RE.numel()
+        assert RE.dim() == 1 and all(t is None or t.shape == RE.shape for t in (lq1, lp1, lq2, lp2))
+        beta_dev = beta if torch.is_tensor(beta) else None
+        beta_host = 0.0 if beta_dev is not None else float(beta)
+        loss = torch.empty(B, device=RE.device); KL = torch.empty_like(loss)
+        means = torch.empty(3, device=RE.device) if average else None
+        if two:
+            _lib.check(lib.evae_elbo2_fwd(_p(RE), _p(lq1), _p(lp1), _p(lq2), _p(lp2), _p(beta_dev), beta_host, B, _p(loss), _p(KL),
+                                          _p(means), _stream()), "evae_elbo2_fwd")
+        else:
+            _lib.check(lib.evae_elbo_fwd(_p(RE), _p(lq1), _p(lp1), _p(beta_dev), beta_host, B, _p(loss), _p(KL), _p(means),
+                                         _stream()), "evae_elbo_fwd")
+        ctx.meta = (B, two, bool(average), beta_host)
+        ctx.set_materialize_grads(False)
+        ctx.beta_dev = beta_dev
+        if average:
+            return means[0], means[1], means[2]
+        return loss, KL
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        B, two, average, beta_host = ctx.meta
+        if average:
+            gl, gr, gk = (None if g is None else _f32(g).contiguous() for g in grads)
+        else:
+            gl, gk = (None if g is None else _f32(g).contiguous() for g in grads)
+            gr = None
+        if gl is None and gr is None and gk is None:
+            return (None,) * 7
+        dev = next(g for g in (gl, gr, gk) if g is not None).device
+        coef = torch.empty((3, B), device=dev)
+        n = lambda g: 0 if g is None else g.numel()
+        _lib.check(lib.evae_elbo_bwd(_p(gl), n(gl), _p(gr), n(gr), _p(gk), n(gk), _p(ctx.beta_dev), beta_host, B, _p(coef[0]),
+                                     _p(coef[1]), _p(coef[2]), _stream()), "evae_elbo_bwd")
+        need = ctx.needs_input_grad
+        pick = lambda i, row: coef[row] if need[i] else None
+        return (pick(0, 0), pick(1, 1), pick(2, 2), pick(3, 1) if two else None, pick(4, 2) if two else None, None, None)
+
+
+def elbo(RE, logq, logp, beta, average, logq2=None, logp2=None):
+    """-> (loss, RE, KL) of models/BaseModel.py:71-77, per row or as batch means"""
+    if average:
+        return ElboFn.apply(RE, logq, logp, logq2, logp2, beta, True)
+    loss, KL = ElboFn.apply(RE, logq, logp, logq2, logp2, beta, False)
+    return loss, RE, KL
 
 
 class LogNormalDiag(torch.autograd.Function):

@@ -13,6 +13,10 @@ from utils.distributions import log_normal_diag
 # training step of the dense 2-level model on two streams (calculate_loss below); EVAE_HVAE_TWO_STREAM=0: one stream
 _TWO_STREAM = os.environ.get("EVAE_HVAE_TWO_STREAM", "1") != "0"
 
+# ... with each pair of heads + its sample + its log-density as one Function, and the loss assembly as one (evae.ops.HeadsReparamFn,
+# ElboFn: ~40 launches fewer per step); EVAE_HVAE_FUSED_HEADS=0: the separate modules
+_FUSED_HEADS = os.environ.get("EVAE_HVAE_FUSED_HEADS", "1") != "0"
+
 _CLAMP_LO, _CLAMP_HI = 1.0 / 512.0, 1.0 - 1.0 / 512.0
 
 
@@ -72,6 +76,22 @@ class BaseHModel(BaseModel):
                  - self.log_p_z(z=(z2, x_indices), exemplars_embedding=emb))
         return kl_z1 + kl_z2
 
+    def _sample_heads(self, trunk, mean_head, logvar_head, zdim):
+        """(z, mean, log-variance, log q(z | .)) of a pair of heads on `trunk`: the sample of reparameterize() (same noise draw)
+        and log_normal_diag(z, mean, logvar) of kl_loss -- through ONE Function when the heads are a Linear and a
+        Hardtanh-clamped Linear (every model of the reference: models/HVAE_2level.py:23-24,36-37)."""
+        from evae import ops
+        from utils.nn import HipLinear, NonLinear
+        if (_FUSED_HEADS and trunk.is_cuda and trunk.dim() == 2 and isinstance(mean_head, HipLinear)
+                and isinstance(logvar_head, NonLinear) and isinstance(logvar_head.activation, torch.nn.Hardtanh)):
+            eps = self._draw_eps(torch.empty((trunk.shape[0], zdim), device=trunk.device, dtype=torch.float32))
+            act = logvar_head.activation
+            return ops.heads_reparam(trunk, mean_head.weight, mean_head.bias, logvar_head.linear.weight, logvar_head.linear.bias,
+                                     eps, act.min_val, act.max_val)
+        mu, lv = mean_head(trunk).view(-1, zdim), logvar_head(trunk).view(-1, zdim)
+        z = self.reparameterize(mu, lv).view(-1, zdim)
+        return z, mu, lv, log_normal_diag(z, mu, lv, dim=1)
+
     def _two_stream_path(self, x, x_indices, exemplars_embedding, dataset):
         a = self.args
         return (_TWO_STREAM and self.training and a.prior == 'exemplar_prior' and a.approximate_prior is False
@@ -96,17 +116,14 @@ class BaseHModel(BaseModel):
         with torch.cuda.stream(side):
             # forward() of this class, in its order (the two reparameterize calls draw z2's noise, then z1's), minus p(z1 | z2)
             xin = xx.view(-1, *self.args.input_size) if self._is_conv() else xx
-            q2_mu, q2_lv = self.q_z(xin)
-            z2 = self.reparameterize(q2_mu, q2_lv)
+            z2, q2_mu, q2_lv, log_q2 = self._sample_heads(self.q_z_layers(xin), self.q_z_mean, self.q_z_logvar, d2)
             z2_ready = torch.cuda.Event(); z2_ready.record()
-            q1_mu, q1_lv = self.q_z1(xin, z2)
-            z1 = self.reparameterize(q1_mu, q1_lv)
+            joint = self.q_z1_layers_joint(torch.cat((self.q_z1_layers_x(xin), self.q_z1_layers_z2(z2)), dim=1))       # q_z1()
+            z1, q1_mu, q1_lv, log_q1 = self._sample_heads(joint, self.q_z1_mean, self.q_z1_logvar, d1)
             z1_ready = torch.cuda.Event(); z1_ready.record()
             x_mean, x_logvar = self.p_x(z1, z2)
             x_flat = xx.reshape(xx.shape[0], -1) if xx.dim() != 2 else xx
             RE = self.reconstruction_loss(x_flat, x_mean, x_logvar)
-            log_q1 = log_normal_diag(z1.view(-1, d1), q1_mu.view(-1, d1), q1_lv.view(-1, d1), dim=1)
-            log_q2 = log_normal_diag(z2.view(-1, d2), q2_mu.view(-1, d2), q2_lv.view(-1, d2), dim=1)
         # this stream: the exemplar rows' encoder (independent of the batch: it starts at once), then what hangs off z2 alone --
         # the prior and the p(z1 | z2) branch (its eight launches and their backward come off the longer chain)
         emb = self.get_exemplar_set(q2_mu, q2_lv, dataset, cache, x_indices)
@@ -121,10 +138,13 @@ class BaseHModel(BaseModel):
         log_prior.record_stream(side); log_p1.record_stream(side)
         with torch.cuda.stream(side):
             side.wait_event(lp_ready)
-            KL = (log_q1 - log_p1) + (log_q2 - log_prior)           # (the grouping of kl_loss)
-            loss = -RE + beta * KL
-            if average:
-                loss, RE, KL = torch.mean(loss), torch.mean(RE), torch.mean(KL)
+            if _FUSED_HEADS:
+                loss, RE, KL = ops.elbo(RE, log_q1, log_p1, beta, average, log_q2, log_prior)
+            else:
+                KL = (log_q1 - log_p1) + (log_q2 - log_prior)           # (the grouping of kl_loss)
+                loss = -RE + beta * KL
+                if average:
+                    loss, RE, KL = torch.mean(loss), torch.mean(RE), torch.mean(KL)
         main.wait_stream(side)
         for t in (loss, RE, KL):
             t.record_stream(main)

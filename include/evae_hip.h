@@ -297,6 +297,10 @@ typedef struct { const float* dy; const float* x; float* dw; float* db; int M, N
 int evae_dense_bwd_weight_group(const evae_wgrad_job_t* jobs, int njobs, evae_stream_t stream);
 int evae_gated_dense_bwd_input(const float* dout, const float* out, const float* s, int M, int N,
                                float* dh, float* dg, int ldo, evae_stream_t stream);
+/* the same with a row stride on dout (ldd >= N): the upstream gradient of one half of a concatenation (models/AbsHModel.py:26,37
+ * torch.cat of two gated layers' outputs) is read where it lies */
+int evae_gated_dense_bwd_input_ld(const float* dout, int ldd, const float* out, const float* s, int M, int N,
+                                  float* dh, float* dg, int ldo, evae_stream_t stream);
 int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, int act, float act_lo, float act_hi,
                  float* dpre, evae_stream_t stream);
 
@@ -389,6 +393,10 @@ int evae_log_normal_diag_bwd(const float* x, const float* mu, const float* logva
  * (n = 1: gradient of the batch mean) or a [B] vector -- into per-row coefficients cRE = d/dRE, cKL = d/dKL. */
 int evae_elbo_fwd(const float* RE, const float* logq, const float* logp, const float* beta_dev,
                   float beta_host, int B, float* loss, float* KL, float* means, evae_stream_t stream);
+/* Two latent layers (models/AbsHModel.py:88-106): KL = (logq1 - logp1) + (logq2 - logp2), in that grouping; the rest as above
+ * (evae_elbo_bwd's cKL is the gradient of both logq, neg_cKL of both logp). */
+int evae_elbo2_fwd(const float* RE, const float* logq1, const float* logp1, const float* logq2, const float* logp2,
+                   const float* beta_dev, float beta_host, int B, float* loss, float* KL, float* means, evae_stream_t stream);
 int evae_elbo_bwd(const float* dloss, int n_dloss, const float* dRE, int n_dRE, const float* dKL, int n_dKL,
                   const float* beta_dev, float beta_host, int B, float* cRE, float* cKL, float* neg_cKL,
                   evae_stream_t stream);

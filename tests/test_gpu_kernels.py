@@ -1040,3 +1040,72 @@ def test_grouped_finish_of_split_k_weight_gradients_equals_the_separate_finishes
     for tag in ("w2", "wm"):
         assert torch.equal(outs[tag][0], ref[tag][0]) and torch.equal(outs[tag][1], ref[tag][1]), tag
     assert rel(g1.cpu().numpy(), (dq1.double().t() @ (xs[rows].double() / 255.0)).cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("M,K,Z", [(100, 300, 40), (37, 300, 40), (200, 128, 64), (5, 48, 6)])
+def test_heads_sample_density_function_and_its_gradients(ops, M, K, Z):
+    """evae.ops.HeadsReparamFn (mean head, Hardtanh log-variance head, sample, log q in two launches; backward in four) against
+    the float64 tensor expressions of reference models/VAE.py:24-26, BaseModel.py:79-82, utils/distributions.py:28-33, with
+    upstream gradients on all four outputs.  (200, 128, 64) and (5, 48, 6) take the un-grouped weight-gradient calls."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    r = lambda *s, k=1.0: torch.randn(*s, device="cuda", generator=g) * k
+    h, wm, bm, wl, bl, eps = r(M, K), r(Z, K, k=0.1), r(Z, k=0.1), r(Z, K, k=0.3), r(Z), r(M, Z)
+    gz, gm, glv, gq = r(M, Z), r(M, Z), r(M, Z), r(M)
+    leaves = [t.clone().requires_grad_() for t in (h, wm, bm, wl, bl)]
+    z, mu, lv, lq = ops.heads_reparam(*leaves, eps, -6.0, 2.0)
+    ((z * gz).sum() + (mu * gm).sum() + (lv * glv).sum() + (lq * gq).sum()).backward()
+    ref = [t.double().clone().requires_grad_() for t in (h, wm, bm, wl, bl)]
+    h_, wm_, bm_, wl_, bl_ = ref
+    mu_ = h_ @ wm_.t() + bm_
+    lv_ = torch.nn.functional.hardtanh(h_ @ wl_.t() + bl_, -6.0, 2.0)
+    z_ = mu_ + eps.double() * torch.exp(0.5 * lv_)
+    lq_ = (-0.5 * (lv_ + np.log(2 * np.pi) + (z_ - mu_) ** 2 / torch.exp(lv_))).sum(1)
+    ((z_ * gz.double()).sum() + (mu_ * gm.double()).sum() + (lv_ * glv.double()).sum() + (lq_ * gq.double()).sum()).backward()
+    assert (lv_.detach().abs() == 6.0).any() or (lv_.detach() == 2.0).any() or M < 10      # the clamp is exercised
+    for a, b in ((z, z_), (mu, mu_), (lv, lv_), (lq, lq_)):
+        assert rel(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 2e-6
+    for name, a, b in zip("h wm bm wl bl".split(), leaves, ref):
+        assert rel(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < 5e-6, name
+    # only z and log q used (the training step): None upstream gradients for the moments
+    leaves2 = [t.clone().requires_grad_() for t in (h, wm, bm, wl, bl)]
+    z2, _, _, lq2 = ops.heads_reparam(*leaves2, eps, -6.0, 2.0)
+    ((z2 * gz).sum() + (lq2 * gq).sum()).backward()
+    for t in ref:
+        t.grad = None
+    mu_ = h_ @ wm_.t() + bm_
+    lv_ = torch.nn.functional.hardtanh(h_ @ wl_.t() + bl_, -6.0, 2.0)
+    z_ = mu_ + eps.double() * torch.exp(0.5 * lv_)
+    lq_ = (-0.5 * (lv_ + np.log(2 * np.pi) + (z_ - mu_) ** 2 / torch.exp(lv_))).sum(1)
+    ((z_ * gz.double()).sum() + (lq_ * gq.double()).sum()).backward()
+    for name, a, b in zip("h wm bm wl bl".split(), leaves2, ref):
+        assert rel(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < 5e-6, name
+
+
+@pytest.mark.parametrize("two", [False, True])
+@pytest.mark.parametrize("average", [False, True])
+def test_elbo_function_and_its_gradients(ops, two, average):
+    """evae.ops.ElboFn (one launch each way) against the tensor expressions of reference models/BaseModel.py:71-77 and the
+    two-level grouping of AbsHModel.py:88-106; beta as a number and as a device scalar."""
+    B = 100
+    g = torch.Generator(device="cuda").manual_seed(11)
+    ins = [torch.randn(B, device="cuda", generator=g) * s for s in (50.0, 30.0, 30.0, 20.0, 20.0)]
+    up = [torch.randn((), device="cuda", generator=g) for _ in range(3)] if average else \
+         [torch.randn(B, device="cuda", generator=g) for _ in range(3)]
+    for beta in (0.37, torch.tensor([0.37], device="cuda")):
+        leaves = [t.clone().requires_grad_() for t in ins]
+        RE, q1, p1, q2, p2 = leaves
+        loss, RE_o, KL = ops.elbo(RE, q1, p1, beta, average, q2 if two else None, p2 if two else None)
+        ((loss * up[0]).sum() + (RE_o * up[1]).sum() + (KL * up[2]).sum()).backward()
+        ref = [t.double().clone().requires_grad_() for t in ins]
+        RE_, q1_, p1_, q2_, p2_ = ref
+        KL_ = (q1_ - p1_) + (q2_ - p2_) if two else q1_ - p1_
+        loss_ = -RE_ + 0.37 * KL_
+        outs_ = (loss_.mean(), RE_.mean(), KL_.mean()) if average else (loss_, RE_, KL_)
+        sum((o * u.double()).sum() for o, u in zip(outs_, up)).backward()
+        for a, b in zip((loss, RE_o, KL), outs_):
+            assert a.shape == b.shape and rel(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-6
+        for i, (a, b) in enumerate(zip(leaves, ref)):
+            if i >= 3 and not two:
+                assert a.grad is None
+            else:
+                assert rel(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < 1e-6, i
