@@ -254,9 +254,13 @@ def other_config(a, dev, rank, world, rccl_ranks=1, backend=None):
         if c5:
             with torch.no_grad():
                 cache = tuple(model.cache_z(dataset))
-        # c5: the approximate prior of a convolutional model stays on eager launches (its `unique` leaves far fewer images to
-        # re-encode than the B * k static slots a captured step would need)
-        runner = None if (c5 or a.no_graph) else GraphedTrainStep(model, opt, dataset, B, False)
+        # c5: the approximate prior of a convolutional model stays on eager launches: its `unique` leaves ~100 images to re-encode
+        # (after the first step the refreshed cache rows share their neighbours), the B * k = 1000 static slots of a captured step
+        # re-encode all 1000 -- r03: 45.3 ms/step replayed (EVAE_C5_GRAPH=1) against 23 ms of GPU work eager
+        eager_c5 = c5 and os.environ.get("EVAE_C5_GRAPH", "0") == "0"
+        runner = None if (eager_c5 or a.no_graph) else GraphedTrainStep(model, opt, dataset, B, False)
+        if runner is not None and cache is not None:
+            cache = runner.set_cache(cache)       # static buffers: the captured launches read and refresh them in place
 
         def step(i):
             s_ = (i * B) % (n_train - B)
@@ -429,6 +433,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))
+    from evae import hostcpu
+    hostcpu.limit_host_threads()     # the eager legs (c5, iwae, topk) otherwise wake a 256-thread pool per host op: cgroup throttling
     # test hook (tests/test_gpu_sharded.py style): several ranks on ONE GPU over gloo, since RCCL refuses duplicate devices
     one_device = os.environ.get("EVAE_BENCH_ONE_DEVICE") == "1"
     if one_device:

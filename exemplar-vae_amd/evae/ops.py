@@ -38,14 +38,14 @@ def _need_cuda(*ts):
                 "evae ops run on MI355X only (got a %s tensor); there is no CPU fallback" % t.device)
 
 
-_SIDE_STREAMS = set()      # raw handles of streams registered as "side" streams: launches issued there get their own workspaces
+_SIDE_STREAMS = {}         # raw handle -> tag of streams registered as "side" streams: launches issued there get their own workspaces
 
 
-def register_side_stream(stream):
+def register_side_stream(stream, tag="side"):
     """Two launches that share a named workspace must not run at the same time.  A model that issues part of its step on a
     second stream (evae/fused_vae.py, models/AbsHModel.py) registers that stream here: every workspace requested while it is
     the current stream -- also from autograd's backward nodes, which run on the stream of their forward -- is a separate buffer."""
-    _SIDE_STREAMS.add(int(stream.cuda_stream))
+    _SIDE_STREAMS[int(stream.cuda_stream)] = tag
 
 
 _MODEL_SIDE = {}
@@ -61,9 +61,45 @@ def model_side_stream(device):
     return st
 
 
+_MODEL_LEAF = {}
+_LEAF_ACTIVE = [None]
+
+
+def model_leaf_stream(device):
+    """Third stream of the modular two-stream training paths: the weight gradients of the thin layers (leaves of the backward
+    pass: nothing but the optimizer reads them) run there, off the chain of data gradients."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _MODEL_LEAF.get(key)
+    if st is None:
+        st = _MODEL_LEAF[key] = torch.cuda.Stream(device=device)
+        register_side_stream(st, "leaf")
+    return st
+
+
+class leaf_branch:
+    """with ops.leaf_branch(stream): layers built inside (utils.nn.GatedDense) put their weight-gradient node on `stream`
+    (gated_dense_split below); stream None: no effect."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.prev = _LEAF_ACTIVE[0]
+        _LEAF_ACTIVE[0] = self.stream
+
+    def __exit__(self, *a):
+        _LEAF_ACTIVE[0] = self.prev
+
+
+def active_leaf_stream():
+    return _LEAF_ACTIVE[0]
+
+
 def _workspace(name, nbytes, device):
-    if _SIDE_STREAMS and int(torch.cuda.current_stream(device).cuda_stream) in _SIDE_STREAMS:
-        name = name + "@side"
+    if _SIDE_STREAMS:
+        tag = _SIDE_STREAMS.get(int(torch.cuda.current_stream(device).cuda_stream))
+        if tag is not None:
+            name = name + "@" + tag
     key = (name, device.index if device.index is not None else torch.cuda.current_device())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
@@ -390,6 +426,94 @@ class GatedDenseFn(torch.autograd.Function):
             dx = _bwd_data(base, wh, base + 4 * N, wg, M, N, 2 * N, gout.device)
         return (dx, None, dw[:N], (db[:N] if ctx.has_bias[0] else None), dw[N:],
                 (db[N:] if ctx.has_bias[1] else None))
+
+
+class GatedDenseDataFn(torch.autograd.Function):
+    """GatedDenseFn without the parameters' gradients: (x, wh, bh, wg, bg) -> (out, s), backward = dx only."""
+
+    @staticmethod
+    def forward(ctx, x, wh, bh, wg, bg):
+        lib = _lib.load()
+        _need_cuda(x, wh, wg)
+        x, _, M = _rows_x(x, None)
+        wh, wg = _f32(wh), _f32(wg)
+        N, K = wh.shape
+        out = torch.empty((M, N), device=x.device); s = torch.empty_like(out)
+        ws = _workspace("fwd", lib.evae_dense_fwd_workspace_bytes(M, K, N, 1), x.device)
+        _lib.check(lib.evae_gated_dense_fwd(_p(x), None, M, K, x.stride(0), _p(wh), _p(bh), _p(wg), _p(bg), N, _p(out), None, _p(s),
+                                            _p(ws), ws.numel(), _stream()), "evae_gated_dense_fwd")
+        ctx.save_for_backward(wh, wg, out, s)
+        ctx.mark_non_differentiable(s)
+        ctx.set_materialize_grads(False)
+        return out, s
+
+    @staticmethod
+    def backward(ctx, dout, _ds):
+        lib = _lib.load()
+        wh, wg, gout, s = ctx.saved_tensors
+        if dout is None or not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        M, N = gout.shape
+        if not (dout.dtype == torch.float32 and dout.dim() == 2 and dout.stride(1) == 1 and dout.stride(0) >= N):
+            dout = _f32(dout)
+        dpre = torch.empty((M, 2 * N), device=gout.device)
+        base = dpre.data_ptr()
+        _lib.check(lib.evae_gated_dense_bwd_input_ld(_p(dout), dout.stride(0), _p(gout), _p(s), M, N, _vp(base), _vp(base + 4 * N),
+                                                     2 * N, _stream()), "evae_gated_dense_bwd_input_ld")
+        return _bwd_data(base, wh, base + 4 * N, wg, M, N, 2 * N, gout.device), None, None, None, None
+
+
+class GatedDenseParamFn(torch.autograd.Function):
+    """The parameters' half of a gated layer as a node of its own: forward is an alias of the layer's output (no launch); the
+    backward turns the output's gradient into (dWh, dbh, dWg, dbg).  Built under a third stream, autograd runs it there, beside
+    the chain of data gradients instead of inside it."""
+
+    @staticmethod
+    def forward(ctx, out, s, x, wh, bh, wg, bg):
+        ctx.save_for_backward(out, s, x)
+        ctx.K = wh.shape[1]
+        ctx.has_bias = (bh is not None, bg is not None)
+        ctx.set_materialize_grads(False)
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        if dout is None:
+            return (None,) * 7
+        gout, s, x = ctx.saved_tensors
+        M, N = gout.shape
+        if not (dout.dtype == torch.float32 and dout.dim() == 2 and dout.stride(1) == 1 and dout.stride(0) >= N):
+            dout = _f32(dout)
+        st = torch.cuda.current_stream()
+        for t in (gout, s, x, dout):       # made on another stream's pool, read here
+            t.record_stream(st)
+        dpre = torch.empty((M, 2 * N), device=gout.device)
+        base = dpre.data_ptr()
+        _lib.check(lib.evae_gated_dense_bwd_input_ld(_p(dout), dout.stride(0), _p(gout), _p(s), M, N, _vp(base), _vp(base + 4 * N),
+                                                     2 * N, _stream()), "evae_gated_dense_bwd_input_ld")
+        dw, db = _bwd_weight(dpre, x, None, ctx.K)
+        return (None, None, None, dw[:N], (db[:N] if ctx.has_bias[0] else None), dw[N:], (db[N:] if ctx.has_bias[1] else None))
+
+
+class _MergeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, token):
+        return a.view_as(a)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def gated_dense_split(x, wh, bh, wg, bg, leaf):
+    """gated_dense with the parameters' gradient node on the stream `leaf` (same values, same gradients)"""
+    x2, _, _ = _rows_x(x, None)
+    det = lambda t: None if t is None else t.detach()
+    out, s = GatedDenseDataFn.apply(x2, det(wh), det(bh), det(wg), det(bg))
+    with torch.cuda.stream(leaf):
+        token = GatedDenseParamFn.apply(out.detach(), s, x2.detach(), wh, bh, wg, bg)
+    return _MergeFn.apply(out, token)
 
 
 def u8_prepare(wh, wg, out=None):

@@ -17,6 +17,10 @@ _TWO_STREAM = os.environ.get("EVAE_HVAE_TWO_STREAM", "1") != "0"
 # ElboFn: ~40 launches fewer per step); EVAE_HVAE_FUSED_HEADS=0: the separate modules
 _FUSED_HEADS = os.environ.get("EVAE_HVAE_FUSED_HEADS", "1") != "0"
 
+# EVAE_HVAE_LEAF_STREAM=1: the thin layers' weight gradients as autograd nodes on a third stream (evae.ops.gated_dense_split).  Off:
+# measured 0.861 -> 0.998 ms at c4 -- every cross-stream edge of a replayed graph costs the chain ~10 us on this runtime (r03)
+_LEAF_STREAM = os.environ.get("EVAE_HVAE_LEAF_STREAM", "0") != "0"
+
 _CLAMP_LO, _CLAMP_HI = 1.0 / 512.0, 1.0 - 1.0 / 512.0
 
 
@@ -113,7 +117,8 @@ class BaseHModel(BaseModel):
         side = ops.model_side_stream(xx.device)        # registered: what runs there takes its own kernel workspaces
         side.wait_stream(main)
         d1, d2 = self.args.z1_size, self.args.z2_size
-        with torch.cuda.stream(side):
+        leaf = ops.model_leaf_stream(xx.device) if _LEAF_STREAM else None
+        with torch.cuda.stream(side), ops.leaf_branch(leaf):
             # forward() of this class, in its order (the two reparameterize calls draw z2's noise, then z1's), minus p(z1 | z2)
             xin = xx.view(-1, *self.args.input_size) if self._is_conv() else xx
             z2, q2_mu, q2_lv, log_q2 = self._sample_heads(self.q_z_layers(xin), self.q_z_mean, self.q_z_logvar, d2)

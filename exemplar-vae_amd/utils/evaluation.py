@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-from evae import shard
+from evae import hostcpu, shard
 from utils.utils import load_model
 
 
@@ -34,6 +34,7 @@ def load_all_pseudo_input(args, model, dataset):
 
 
 def evaluate_loss(args, model, loader, dataset=None, exemplars_embedding=None):
+    hostcpu.limit_host_threads()
     model.eval()
     if exemplars_embedding is None:
         exemplars_embedding = load_all_pseudo_input(args, model, dataset)
@@ -55,6 +56,7 @@ def calculate_likelihood(args, model, loader, S=5000, exemplars_embedding=None):
     (S samples) per pass and takes the log-sum-exp on the host; here a pass carries as many images as fit in
     IWAE_ROWS_PER_LAUNCH rows -- the S copies of an image are consecutive rows, so the eps stream is consumed in the
     same order as image-by-image -- and the per-image log-sum-exp stays on the device."""
+    hostcpu.limit_host_threads()
     dataset = loader.dataset
     group = max(1, min(IWAE_ROWS_PER_LAUNCH // max(int(S), 1), 64))
     aux = torch.utils.data.DataLoader(dataset, batch_size=group)

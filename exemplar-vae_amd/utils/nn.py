@@ -88,6 +88,9 @@ class GatedDense(nn.Module):
     def forward(self, x, rows=None, x_scale=None):
         if self.no_attention is False and self.activation is None:
             x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
+            leaf = ops.active_leaf_stream()
+            if leaf is not None and rows is None and x_scale is None and torch.is_grad_enabled() and self.h.weight.requires_grad:
+                return ops.gated_dense_split(x2, self.h.weight, self.h.bias, self.g.weight, self.g.bias, leaf)
             # x_scale: x is the uint8 image store (models/BaseModel.py::resident_u8), pixel = byte * x_scale
             return ops.gated_dense(x2, self.h.weight, self.h.bias, self.g.weight, self.g.bias, rows=rows, x_scale=x_scale)
         h = dense(x, self.h, None, rows=rows)

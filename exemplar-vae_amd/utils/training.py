@@ -5,6 +5,7 @@ epoch instead of three .item() syncs per step (training.py:42-44), and the exemp
 HBM (the model keeps a device-resident copy of dataset.tensors[0])."""
 import torch
 
+from evae import hostcpu
 from evae.graph import GraphedTrainStep
 
 
@@ -15,6 +16,7 @@ def set_beta(args, epoch):
 
 
 def train_one_epoch(epoch, args, train_loader, model, optimizer):
+    hostcpu.limit_host_threads()          # once per process: this rank's share of the host cores (evae/hostcpu.py)
     model.train()
     beta = set_beta(args, epoch)
     print('beta: {}'.format(beta))
