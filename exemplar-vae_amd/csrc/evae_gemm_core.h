@@ -231,8 +231,15 @@ struct Plan {
 // Wave-quantisation model: a launch runs in rounds of 512 resident blocks (256 CUs x 2); a block costs
 // (slabs + fixed prologue/epilogue) slab-times, a BN=64 slab ~0.6 of a BN=128 slab; split-K adds the
 // finish kernel (launch + partial traffic).  Deterministic in (M, N, slabs, gated, must_split).
+static double plan_finish_cost() {
+  static double c = -1.0;
+  if (c < 0) { const char* e = getenv("EVAE_PLAN_FINISH"); c = e ? atof(e) : 3.0; }
+  return c;
+}
+
 static Plan make_plan(int M, int N, int slabs, bool gated, bool must_split, int planes) {
   Plan best = {128, 1, slabs};
+  const double fin = plan_finish_cost();
   double best_t = 1e30;
   const int bns[2] = {128, 64};
   for (int bi = 0; bi < (gated ? 1 : 2); ++bi) {
@@ -246,7 +253,7 @@ static Plan make_plan(int M, int N, int slabs, bool gated, bool must_split, int 
       const long rounds = (tiles * nze + 511) / 512;
       double t = rounds * (ks + 1.5) * slab_cost;
       // the finish launch: ~3 slab-times of a dependent launch inside a graph (measured: 2 -> 3 takes 0.7 % off the c2 step)
-      if (nze > 1 || must_split) t += 3.0 + (double)M * N * planes * nze * 4.0 / 12e6;
+      if (nze > 1 || must_split) t += fin + (double)M * N * planes * nze * 4.0 / 12e6;
       if (t < best_t) { best_t = t; best = {bn, nze, ks}; }
     }
   }
