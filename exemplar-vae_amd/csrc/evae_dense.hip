@@ -45,6 +45,24 @@ __global__ void gated_bwd_input_kernel(const float* __restrict__ dout, const flo
   }
 }
 
+// the same, four columns per thread (16-byte accesses, 32-bit index arithmetic): N, ldo, ldd multiples of 4, aligned pointers,
+// fewer than 2^31 quads -- the channels-last convolutions' gate derivative over millions of pixels was bound by the scalar
+// kernel's 64-bit division per element (c3: 7.5 % of the step)
+__global__ __launch_bounds__(256) void gated_bwd_input_v4_kernel(const float4* __restrict__ dout, const float4* __restrict__ gout,
+                                                                 const float4* __restrict__ s, unsigned nquads, unsigned nq,
+                                                                 unsigned ldo4, float4* __restrict__ dh, float4* __restrict__ dg,
+                                                                 unsigned ldd4) {
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += stride) {
+    const unsigned row = q / nq, c = q - row * nq;
+    const float4 d = dout[(size_t)row * ldd4 + c], ov = gout[q], sv = s[q];
+    const size_t o = (size_t)row * ldo4 + c;
+    dh[o] = make_float4(d.x * sv.x, d.y * sv.y, d.z * sv.z, d.w * sv.w);
+    dg[o] = make_float4(d.x * ov.x * (1.0f - sv.x), d.y * ov.y * (1.0f - sv.y), d.z * ov.z * (1.0f - sv.z),
+                        d.w * ov.w * (1.0f - sv.w));
+  }
+}
+
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yp, size_t n,
                                int act, float lo, float hi, float* __restrict__ dpre) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -549,20 +567,33 @@ extern "C" int evae_dense_bwd_weight_group(const evae_wgrad_job_t* jobs, int njo
   return check_launch("gemm_group_wgrad_kernel");
 }
 
+static int launch_gated_bwd_input(const float* dout, int ldd, const float* out, const float* s, int M, int N, float* dh, float* dg,
+                                  int ldo, hipStream_t stream) {
+  const size_t quads = (size_t)M * (N / 4);
+  const bool v4 = N % 4 == 0 && ldo % 4 == 0 && ldd % 4 == 0 && quads < ((size_t)1 << 31) &&
+                  ((((uintptr_t)dout | (uintptr_t)out | (uintptr_t)s | (uintptr_t)dh | (uintptr_t)dg) & 15) == 0);
+  if (v4) {
+    gated_bwd_input_v4_kernel<<<elt_grid(quads), 256, 0, stream>>>((const float4*)dout, (const float4*)out, (const float4*)s,
+                                                                  (unsigned)quads, (unsigned)(N / 4), (unsigned)(ldo / 4), (float4*)dh,
+                                                                  (float4*)dg, (unsigned)(ldd / 4));
+  } else {
+    gated_bwd_input_kernel<<<elt_grid((size_t)M * N), 256, 0, stream>>>(dout, out, s, M, N, ldo, dh, dg, ldd);
+  }
+  return check_launch("gated_dense_bwd_input");
+}
+
 extern "C" int evae_gated_dense_bwd_input(const float* dout, const float* out, const float* s, int M, int N,
                                           float* dh, float* dg, int ldo, evae_stream_t stream_) {
   if (M <= 0 || N <= 0) return EVAE_OK;
   EVAE_REQUIRE(dout && out && s && dh && dg && ldo >= N, "gated_dense_bwd_input: bad arguments");
-  gated_bwd_input_kernel<<<elt_grid((size_t)M * N), 256, 0, (hipStream_t)stream_>>>(dout, out, s, M, N, ldo, dh, dg, N);
-  return check_launch("gated_dense_bwd_input");
+  return launch_gated_bwd_input(dout, N, out, s, M, N, dh, dg, ldo, (hipStream_t)stream_);
 }
 
 extern "C" int evae_gated_dense_bwd_input_ld(const float* dout, int ldd, const float* out, const float* s, int M, int N,
                                              float* dh, float* dg, int ldo, evae_stream_t stream_) {
   if (M <= 0 || N <= 0) return EVAE_OK;
   EVAE_REQUIRE(dout && out && s && dh && dg && ldo >= N && ldd >= N, "gated_dense_bwd_input_ld: bad arguments");
-  gated_bwd_input_kernel<<<elt_grid((size_t)M * N), 256, 0, (hipStream_t)stream_>>>(dout, out, s, M, N, ldo, dh, dg, ldd);
-  return check_launch("gated_dense_bwd_input_ld");
+  return launch_gated_bwd_input(dout, ldd, out, s, M, N, dh, dg, ldo, (hipStream_t)stream_);
 }
 
 extern "C" int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, int act, float act_lo,
