@@ -288,27 +288,41 @@ __global__ __launch_bounds__(NT) void topk_merge_kernel(const float* __restrict_
 }
 
 // first occurrence of every position keeps its exemplar, repeats become masked slots (see evae_select_exemplars).
-// Every block keeps all n positions in LDS (padded to fours with -1 - index, which never matches) and a thread decides one
-// slot by scanning the positions in front of it four at a time.
+// A block decides 64 slots: it keeps the positions in front of its last slot in LDS (padded to fours with -1 - index, which
+// never matches); the four waves share the scan of a slot's prefix (wave w takes the fours w, w + 4, ...: every lane of a wave
+// reads the same address, a broadcast), their verdicts meet in LDS.  (r03: one thread per slot scanning its whole prefix took
+// 30 us for the 1000 slots of c2a -- 250 dependent LDS round trips in the last thread -- on the step's critical path.)
 __global__ __launch_bounds__(256) void select_exemplars_kernel(const int64_t* __restrict__ pos, int n,
                                                                const int64_t* __restrict__ cand_idx, int C,
                                                                int64_t* __restrict__ sel_rows, int64_t* __restrict__ c_idx,
                                                                int* __restrict__ n_unique) {
   extern __shared__ __attribute__((aligned(16))) int sp[];
   const int n4 = (n + 3) & ~3;
-  for (int i = threadIdx.x; i < n4; i += 256) sp[i] = i < n ? (int)pos[i] : -1 - i;
+  int* const flag = sp + n4;
+  const int hi = min(n4, (int)((blockIdx.x * 64 + 64 + 3) & ~3u));
+  for (int i = threadIdx.x; i < hi; i += 256) sp[i] = i < n ? (int)pos[i] : -1 - i;
   __syncthreads();
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  bool first = false;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  bool dup = false;
+  int p = 0;
   if (i < n) {
-    const int p = sp[i];
-    bool dup = false;
-    const int full = i & ~3;
-    for (int j = 0; j < full; j += 4) {
-      const int4 q = *reinterpret_cast<const int4*>(sp + j);
+    p = sp[i];
+    const int full = i & ~3, nf = full >> 2;
+#pragma unroll 4
+    for (int f = part; f < nf; f += 4) {
+      const int4 q = *reinterpret_cast<const int4*>(sp + 4 * f);
       dup |= (q.x == p) | (q.y == p) | (q.z == p) | (q.w == p);
     }
-    for (int j = full; j < i; ++j) dup |= (sp[j] == p);
+    if (part == 0)
+      for (int j = full; j < i; ++j) dup |= (sp[j] == p);
+  }
+  flag[threadIdx.x] = dup ? 1 : 0;
+  __syncthreads();
+  if (part != 0) return;
+  bool first = false;
+  if (i < n) {
+    dup = (flag[lane] | flag[64 + lane] | flag[128 + lane] | flag[192 + lane]) != 0;
     const int64_t row = (p >= 0 && p < C) ? cand_idx[p] : (int64_t)0;
     sel_rows[i] = row;
     c_idx[i] = dup ? (int64_t)EVAE_PRIOR_MASK_ALL : row;
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(256) void select_exemplars_kernel(const int64_t* __
   }
   if (n_unique) {
     const unsigned long long m = __ballot(first);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_unique, __popcll(m));
+    if (lane == 0 && m) atomicAdd(n_unique, __popcll(m));
   }
 }
 
@@ -409,8 +423,13 @@ extern "C" int evae_select_exemplars(const int64_t* pos, int n, const int64_t* c
     hipError_t e = hipMemsetAsync(n_unique, 0, sizeof(int), (hipStream_t)stream_);
     EVAE_REQUIRE(e == hipSuccess, "select_exemplars: memset failed");
   }
-  select_exemplars_kernel<<<cdiv(n, 256), 256, (size_t)((n + 3) & ~3) * sizeof(int), (hipStream_t)stream_>>>(pos, n, cand_idx, C, sel_rows,
-                                                                                                       c_idx, n_unique);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)select_exemplars_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr = true;
+  }
+  select_exemplars_kernel<<<cdiv(n, 64), 256, (size_t)(((n + 3) & ~3) + 256) * sizeof(int), (hipStream_t)stream_>>>(pos, n, cand_idx, C,
+                                                                                                              sel_rows, c_idx, n_unique);
   return check_launch("select_exemplars_kernel");
 }
 

@@ -303,8 +303,7 @@ class VaeExactLoss(torch.autograd.Function):
             approx_cache.index_copy_(0, xi, z_mean)
             sub_cache = approx_cache.index_select(0, ex_idx)
             nearest, _ = ops.pairdist_topk(z_mean, sub_cache, int(approx_k), want_val=False)
-            sel_rows, ci_sel = ops.select_exemplars(nearest.view(-1), ex_idx)
-            rows[:Cl].copy_(sel_rows)
+            sel_rows, ci_sel = ops.select_exemplars(nearest.view(-1), ex_idx, out_rows=rows[:Cl])     # straight into the gather list
             l1_fwd(k, rows, Cl, 0)
         if Cl > 0:
             k.gated_fwd(A1, None, Cl, H, H, w2h, b2h, w2g, b2g, H, A2, None, s2)

@@ -301,15 +301,17 @@ PRIOR_MASK_ALL = -3      # EVAE_PRIOR_MASK_ALL: a c_idx entry that masks its exe
 SELECT_EXEMPLARS_MAX = 16384   # evae_select_exemplars keeps a call's positions in one block's LDS (csrc/evae_topk.hip)
 
 
-def select_exemplars(pos, cand_idx, want_count=False):
+def select_exemplars(pos, cand_idx, want_count=False, out_rows=None):
     """Static-shape form of `unique` + gather (models/BaseModel.py:265-266): pos [n] top-k positions into cand_idx [C].
     -> (sel_rows [n] dataset rows of every slot, c_idx [n]: the row for the first slot naming a position, PRIOR_MASK_ALL
-    for its repeats)."""
+    for its repeats).  out_rows: a contiguous int64 [n] tensor to take sel_rows (the head of a step's gather list)."""
     lib = _lib.load()
     _need_cuda(pos, cand_idx)
     pos, cand_idx = _i64(pos), _i64(cand_idx)
     n = pos.numel()
-    sel = torch.empty(n, dtype=torch.int64, device=pos.device)
+    if out_rows is not None:
+        assert out_rows.dtype == torch.int64 and out_rows.numel() == n and out_rows.is_contiguous()
+    sel = out_rows if out_rows is not None else torch.empty(n, dtype=torch.int64, device=pos.device)
     cidx = torch.empty(n, dtype=torch.int64, device=pos.device)
     cnt = torch.empty(1, dtype=torch.int32, device=pos.device) if want_count else None
     _lib.check(lib.evae_select_exemplars(_p(pos), n, _p(cand_idx), cand_idx.numel(), _p(sel), _p(cidx), _p(cnt), _stream()),
