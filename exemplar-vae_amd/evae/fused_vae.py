@@ -36,6 +36,7 @@ PREP_DONE = {}     # prepared-weights buffer -> (w1h, w1g) pointers it was just 
 _STAGE_GEN = {}
 _XT_GEN = {}       # workspace pointer -> generation of the transposed byte rows the forward pass left there
 _ZEROED = {}      # workspace name -> (address, shape) it was last zero-filled for
+_APPROX_ROWS = {}  # (device, slots, batch, dataset rows) -> the approximate-prior step's gather list (static tail)
 
 # schedule switches (bit mask; tools/chain_bench.sh sweeps them): 1 = the prior's dz' / dlogvar reduction on the side stream,
 # 2 = the finish launch of encoder layer 2's weight gradient on the side stream, 4 = byte store: the layer-2 data gradient writes
@@ -190,8 +191,13 @@ class VaeExactLoss(torch.autograd.Function):
             stage.copy_(x)
         # rows_ext: caller-kept [Cl + B] gather list whose head IS ex_idx and whose tail already names the staging rows
         if approx:
-            rows = torch.empty(Cl + B, dtype=torch.int64, device=dev)          # head: filled behind the top-K below
-            rows[Cl:] = torch.arange(n_data, n_data + B, device=dev)
+            # head: filled behind the top-K below; the tail (the staging rows) never changes -- one buffer per geometry, kept
+            # (a second forward before this one's backward is refused by the staging-row generation check, which covers it too)
+            rkey = (dev, Cl, B, int(n_data))
+            rows = _APPROX_ROWS.get(rkey)
+            if rows is None:
+                rows = _APPROX_ROWS[rkey] = torch.empty(Cl + B, dtype=torch.int64, device=dev)
+                rows[Cl:] = torch.arange(n_data, n_data + B, device=dev)
         elif rows_ext is not None and rows_ext.numel() == Cl + B and rows_ext.data_ptr() == ex_idx.data_ptr():
             rows = rows_ext
         else:
