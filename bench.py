@@ -581,6 +581,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(n_pre + i)
+    t_issue = time.perf_counter() - t0          # host time to ISSUE the steps (graph launches); the fence below waits for the device
     fence()
     dt = time.perf_counter() - t0
     n_done = n_pre + a.steps
@@ -763,7 +764,7 @@ def main():
                        "launch": "eager" if graphed is None else "hipGraph replay of the whole step"},
             "collectives": coll, "rccl_ranks": rccl_ranks, "backend": backend,
             "dp": dp_line,
-            "ramp_replays": ramp_replays, "ramp_ms": round(ramp_ms, 2), "untimed_steps": n_pre,
+            "host_issue_ms_per_step": round(1e3 * t_issue / a.steps, 4), "ramp_replays": ramp_replays, "ramp_ms": round(ramp_ms, 2), "untimed_steps": n_pre,
             "mean_loss": round(final_loss, 4),
             "roofline": roof,
             "test_log_px": iwae,

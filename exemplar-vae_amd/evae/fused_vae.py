@@ -36,6 +36,7 @@ PREP_DONE = {}     # prepared-weights buffer -> (w1h, w1g) pointers it was just 
 _STAGE_GEN = {}
 _XT_GEN = {}       # workspace pointer -> generation of the transposed byte rows the forward pass left there
 _ZEROED = {}      # workspace name -> (address, shape) it was last zero-filled for
+ONE_STREAM = [os.environ.get("EVAE_ONE_STREAM", "0") == "1"]      # experiment: the whole step on the caller's stream
 _APPROX_ROWS = {}  # (device, slots, batch, dataset rows) -> the approximate-prior step's gather list (static tail)
 
 # schedule switches (bit mask; tools/chain_bench.sh sweeps them): 1 = the prior's dz' / dlogvar reduction on the side stream,
@@ -100,6 +101,8 @@ class _K:
         """Second stream for the decoder chain of the batch rows: it only meets the exemplar-prior chain at the ELBO (forward)
         and at dz (backward), so the two chains of small launches run side by side, captured as parallel branches of the
         step's hipGraph.  Collectives of the sharded prior stay on the main stream."""
+        if ONE_STREAM[0]:
+            return torch.cuda.current_stream(self.dev)
         key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         st = _K._side.get(key)
         if st is None:

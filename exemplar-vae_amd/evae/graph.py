@@ -15,11 +15,32 @@ in the control block); whatever else draws random numbers uses the CUDA generato
 capture so that every replay advances its Philox offset.  RCCL collectives of the sharded prior are captured too.
 """
 import os
+import time
 import sys
 
 import torch
 
 from . import ops, shard
+
+
+_REFRESH_PROF = os.environ.get("EVAE_REFRESH_PROF") == "1"       # host time of _refresh by part, printed at exit (tools/host_time.py)
+
+
+class _RefreshProf:
+    acc = {}
+
+    @staticmethod
+    def lap(name, t0):
+        t1 = time.perf_counter()
+        a = _RefreshProf.acc.setdefault(name, [0.0, 0])
+        a[0] += t1 - t0; a[1] += 1
+        return t1
+
+
+if _REFRESH_PROF:
+    import atexit
+    atexit.register(lambda: print("refresh: " + "; ".join("%s %.1f us" % (k, 1e6 * v[0] / max(v[1], 1)) for k, v in _RefreshProf.acc.items()),
+                                  file=sys.stderr))
 
 
 class GraphedTrainStep:
@@ -68,6 +89,16 @@ class GraphedTrainStep:
         self._h_ctl = [torch.zeros(words, dtype=torch.int64).pin_memory() for _ in range(2)]
         for h in self._h_ctl:
             h[Cl:self._o_idx] = tail
+        # numpy views of the pinned blocks: a field write through them costs ~0.3 us, through a tensor index ~3 us (r03: the
+        # replayed step of a small exemplar set is bound by the host -- 56 graph nodes at ~3.9 us of hipGraphLaunch each plus
+        # this function -- so its microseconds are the step's)
+        self._h_np = [h.numpy() for h in self._h_ctl]
+        self._h_np_f32 = [h[self._o_scal:].view(torch.float32).numpy() for h in self._h_ctl]
+        # Thin steps (host-bound): ONE upload on the step's stream straight into the control block instead of upload stream +
+        # staging block + device copy (seven stream / event calls, 65 us of host time measured); the DMA's ~10 us then sit in
+        # front of the graph, which a GPU-bound step (c2) would feel and a host-bound one does not.  EVAE_CTL_DIRECT=0/1 forces.
+        e = os.environ.get("EVAE_CTL_DIRECT")
+        self._direct = (Cl + self.B <= 8192) if e is None else e == "1"
         self._h_draw = torch.zeros(C, dtype=torch.int64)                 # the full draw when only a shard is uploaded
         self._d_ctl = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(2)]
         self._up = torch.cuda.Stream(device=dev)
@@ -195,7 +226,10 @@ class GraphedTrainStep:
                 # eager step checks every batch and takes the fp32 store when it must (models/BaseModel.py); no capture
                 print("evae.graph: the loader's images are not k/255 values; the step is not captured", file=sys.stderr)
                 self.failed = True
+        T = _RefreshProf if _REFRESH_PROF else None
+        t0 = time.perf_counter() if T else 0.0
         self._ev_up[k].synchronize()              # the upload issued two steps ago from this host buffer is done
+        if T: t0 = T.lap("wait for the block's last upload", t0)
         h = self._h_ctl[k]
         # same CPU-generator draw, with replacement, as the reference (models/BaseModel.py:245)
         if Cl == a.number_components:
@@ -203,27 +237,36 @@ class GraphedTrainStep:
         else:
             torch.randint(low=0, high=a.training_set_size, size=(a.number_components,), out=self._h_draw)
             h[:Cl] = self._h_draw[self.lo:self.hi]
+        if T: t0 = T.lap("candidate draw", t0)
         idx_on_device = indices.is_cuda
+        hn = self._h_np[k]
         if not idx_on_device:
-            h[self._o_idx:self._o_seed] = indices.reshape(-1)
-        h[self._o_seed] = self.seed
-        h[self._o_seed + 1] = self._calls
-        hs = h[self._o_scal:].view(torch.float32)
+            hn[self._o_idx:self._o_seed] = indices.reshape(-1).numpy()
+        hn[self._o_seed] = self.seed
+        hn[self._o_seed + 1] = self._calls
+        hs = self._h_np_f32[k]
         hs[0] = float(beta)
+        if T: t0 = T.lap("control block fields", t0)
         if self._calls > 0 and not self.eager_opt:      # (call 0 steps eagerly and learns the participants)
             self.opt.advance_graph_step(host_out=hs[1:1 + self.ngroups], tables=self._adam_tables)
-        main = torch.cuda.current_stream()
-        self._up.wait_event(self._ev_used[k])     # device staging block k was consumed two steps ago
-        with torch.cuda.stream(self._up):
-            self._d_ctl[k].copy_(h, non_blocking=True)
-            self._ev_up[k].record()
-        main.wait_event(self._ev_up[k])
-        self.ctl.copy_(self._d_ctl[k])
-        self._ev_used[k].record()
+        if T: t0 = T.lap("optimizer step counts", t0)
+        if self._direct:
+            self.ctl.copy_(h, non_blocking=True)
+            self._ev_up[k].record()               # (on the step's stream: host block k is free once this upload ran)
+        else:
+            main = torch.cuda.current_stream()
+            self._up.wait_event(self._ev_used[k])     # device staging block k was consumed two steps ago
+            with torch.cuda.stream(self._up):
+                self._d_ctl[k].copy_(h, non_blocking=True)
+                self._ev_up[k].record()
+            main.wait_event(self._ev_up[k])
+            self.ctl.copy_(self._d_ctl[k])
+            self._ev_used[k].record()
         if idx_on_device:
             self.idx_in.copy_(indices.reshape(self.B, 1))
         if not self.by_index:
             self.x_in.copy_(data.reshape(self.B, -1), non_blocking=True)
+        if T: T.lap("upload + copies", t0)
 
     def __call__(self, data, indices, beta):
         """One training step; returns a device tensor (loss, -RE, KL) valid until the next call."""
