@@ -1,5 +1,7 @@
 """GPU parity of the drop-in model API against the goldens generated from the real reference
 (tests/golden/g7_vae_loss.npz) and against the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -70,11 +72,15 @@ def test_no_cpu_fallback():
         ops.prior_lse_fwd(torch.zeros(2, 4), torch.zeros(3, 4), torch.zeros(4))
 
 
-@pytest.mark.parametrize("feed", ["device_indices", "host_loader", "foreign_images"])
-def test_graphed_step_matches_eager(feed):
+@pytest.mark.parametrize("feed", ["device_indices", "host_loader", "foreign_images", "host_loader_staged_upload"])
+def test_graphed_step_matches_eager(feed, monkeypatch):
     """hipGraph replay of the whole step (evae/graph.py) == the same steps launched eagerly.  `host_loader`: CPU batches
     as a DataLoader yields them (the step gathers the images from the resident dataset by index); `foreign_images`:
-    batches that are NOT rows of the dataset (the step must notice and upload the images instead)."""
+    batches that are NOT rows of the dataset (the step must notice and upload the images instead).  A step this thin uploads
+    its control block directly on its own stream; `..._staged_upload` forces the double-buffered path of the large steps."""
+    if feed == "host_loader_staged_upload":
+        monkeypatch.setenv("EVAE_CTL_DIRECT", "0")
+        feed = "host_loader"
     from evae.graph import GraphedTrainStep
     from utils.optimizer import AdamNormGrad
     B, C, N = 32, 500, 2000
@@ -119,6 +125,7 @@ def test_graphed_step_matches_eager(feed):
         if runner is not None:
             assert runner.graph is not None                       # steps 4.. were replays
             assert runner.by_index == (feed != "foreign_images")
+            assert runner._direct == (os.environ.get("EVAE_CTL_DIRECT") != "0")
     (l0, p0), (l1, p1) = results
     assert rel(np.asarray(l1), np.asarray(l0)) < 1e-5
     for k in p0:
@@ -1046,3 +1053,46 @@ def test_fused_backward_redoes_the_byte_gather_when_another_step_used_the_worksp
     l2.backward()
     for n, p in m1.named_parameters():
         assert torch.equal(p.grad, ref[n]), n
+
+
+def test_two_level_step_fused_head_functions_at_c4_size():
+    """hvae_2level at the benchmarked size (BASELINE configs[3]: 11 500 exemplars, batch 100): the two-stream step with each pair
+    of heads + sample + density as one Function and the loss assembly as one (models/AbsHModel.py, evae.ops.HeadsReparamFn /
+    ElboFn) against the same step through the separate modules, same noise: loss / RE / KL to 1e-5, every gradient norm to 1e-4."""
+    from models import AbsHModel
+    from utils.utils import importing_model
+    from argparse import Namespace
+    N, C, B = 23000, 11500, 100
+    data = torch.from_numpy(gi.binary_images(9, N))
+    dataset = torch.utils.data.TensorDataset(data, torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    args = Namespace(prior="exemplar_prior", input_type="binary", input_size=[1, 28, 28], hidden_size=300, z1_size=40, z2_size=40,
+                     model_name="hvae_2level", device="cuda", number_components=C, training_set_size=N, approximate_prior=False,
+                     approximate_k=10, no_mask=False, no_attention=False, same_variational_var=False, use_logit=False, lambd=1e-4,
+                     bottleneck=1, dataset_name="dynamic_mnist", continuous=False, batch_size=B, dynamic_binarization=False,
+                     warmup=100, S=5000)
+    torch.manual_seed(21)
+    model = importing_model(args)(args).cuda()
+    model.train()
+    x = data[:B].cuda(); idx = torch.arange(B, device="cuda").reshape(-1, 1)
+    g = torch.Generator(device="cuda")
+    out = []
+    try:
+        for fused in (True, False):
+            AbsHModel._FUSED_HEADS = fused
+            g.manual_seed(5); model._eps_generator = g          # the same z2 / z1 noise both times
+            torch.manual_seed(77)                                # the same exemplar draw
+            model.zero_grad(set_to_none=True)
+            loss, RE, KL = model.calculate_loss((x, idx), 0.5, average=True, dataset=dataset)
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append(([float(loss.detach()), float(RE.detach()), float(KL.detach())], {k: float(p.grad.double().norm()) for k, p in model.named_parameters()
+                                                              if p.grad is not None}))
+    finally:
+        AbsHModel._FUSED_HEADS = True
+        model._eps_generator = None
+    (v1, g1), (v0, g0) = out
+    assert np.isfinite(v1).all() and set(g1) == set(g0) and len(g1) >= 40
+    for a, b in zip(v1, v0):
+        assert abs(a - b) <= 1e-5 * max(abs(b), 1.0), (v1, v0)
+    for k in g0:
+        assert abs(g1[k] - g0[k]) <= 1e-4 * max(g0[k], 1e-12), (k, g1[k], g0[k])

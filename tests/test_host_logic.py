@@ -1,6 +1,7 @@
 """CPU-only checks of the host-side mirror of the reference interface: class / function names, constructor
 arguments, state_dict keys (so reference checkpoints load), the model-name mapping and the loop helpers."""
 import inspect
+import os
 from argparse import Namespace
 
 import numpy as np
@@ -263,3 +264,40 @@ def test_state_dict_names_and_shapes_of_every_architecture():
         model = importing_model(args)(args)
         got = [[k, list(v.shape)] for k, v in model.state_dict().items()]
         assert got == d["entries"], key
+
+
+def test_host_thread_budget_follows_the_cgroup_quota(monkeypatch, tmp_path):
+    """evae.hostcpu: the intra-op pool is bounded by min(8, affinity, cgroup quota, cores / local ranks); an explicit
+    OMP_NUM_THREADS stands (r03: a 256-thread pool under a 16-CPU quota froze the c5 step for 25-80 ms every few steps)."""
+    import builtins
+    import torch
+    from evae import hostcpu
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            f = tmp_path / "cpu.max"
+            f.write_text("300000 100000\n")
+            return real_open(f, *a, **k)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert hostcpu.cpu_budget() == 3
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    assert hostcpu.cpu_budget() == 1
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.delenv("OMP_NUM_THREADS", raising=False); monkeypatch.delenv("EVAE_HOST_THREADS", raising=False)
+        torch.set_num_threads(max(before, 6))
+        hostcpu._DONE[0] = False
+        assert hostcpu.limit_host_threads() == 3 and torch.get_num_threads() == 3
+        assert hostcpu.limit_host_threads() == 3                   # once per process
+        torch.set_num_threads(6)
+        hostcpu._DONE[0] = False
+        monkeypatch.setenv("OMP_NUM_THREADS", "6")
+        assert hostcpu.limit_host_threads() == 6                   # the user's setting stands
+    finally:
+        hostcpu._DONE[0] = True
+        torch.set_num_threads(before)
