@@ -387,6 +387,100 @@ extern "C" int evae_dense_bwd_data_img(const float* dy1, const float* w1, const 
   return dense_bwd_data_core(dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, nullptr, nullptr, K, wT, ws, ws_bytes, stream_, &sink);
 }
 
+
+// ---- weight gradient of a NARROW layer (N <= 64 outputs: the encoder's mean / log-variance heads, [40 x 300] over all C + B rows).
+// On the GEMM kernel its one row tile is 31 % live and 500 blocks each pay a prologue and a 128 x 64 partial tile for eight
+// K-slabs: 25 us + finish for 34 MB of operands.  Here it is what it is -- a reduction over the rows bound by reading them:
+// grid (64-column tiles of [x | 1], row slices); a block stages 32 rows of dy (all N columns) and of its x columns in LDS,
+// a thread keeps a 4 (outputs) x 4 (columns) tile in registers (its two LDS reads per row are shared by 16 lanes each:
+// broadcasts); partial planes [slice][N][K + 1] in the layout of gemm_finish_body (EPI_RAW, ones column = db).
+__global__ __launch_bounds__(256) void narrow_wgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
+                                                           int ldx, int M, int N, int K, int rows_per_slice,
+                                                           float* __restrict__ part) {
+  __shared__ float4 sdy[2][32][16];
+  __shared__ float4 sx[2][32][16];
+  const int Kp = K + 1;
+  const int k0 = blockIdx.x * 64, z = blockIdx.y;
+  const int r_begin = z * rows_per_slice, r_end = min(M, r_begin + rows_per_slice);
+  const int tid = threadIdx.x, kg = tid & 15, ng = tid >> 4;
+  const bool live = 4 * ng < N;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  // a thread stages rows (tid >> 4) and (tid >> 4) + 16 of a 32-row chunk, float4 (tid & 15) of dy and of its x columns
+  const int c4 = tid & 15, rr0 = tid >> 4;
+  const bool dy_col = 4 * c4 < N;
+  const int kx = k0 + 4 * c4;
+  const bool x_vec = kx + 3 < K;
+  float4 vd[2], vx[2];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int r = r0 + rr0 + 16 * it;
+      vd[it] = make_float4(0.f, 0.f, 0.f, 0.f); vx[it] = vd[it];
+      if (r < r_end) {
+        if (dy_col) vd[it] = *reinterpret_cast<const float4*>(dy + (size_t)r * ldy + 4 * c4);
+        if (x_vec) {
+          vx[it] = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + kx);
+        } else {                                    // the tile that holds the end of x and the virtual ones column K
+          float t[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t[j] = (kx + j < K) ? x[(size_t)r * ldx + kx + j] : (kx + j == K ? 1.f : 0.f);
+          vx[it] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { sdy[buf][rr0 + 16 * it][c4] = vd[it]; sx[buf][rr0 + 16 * it][c4] = vx[it]; }
+  };
+  fetch(r_begin);
+  stage(0);
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = r_begin; r0 < r_end; r0 += 32, buf ^= 1) {
+    const bool more = r0 + 32 < r_end;
+    if (more) fetch(r0 + 32);                       // the next chunk's loads fly while this one is multiplied
+    if (live) {
+#pragma unroll 8
+      for (int rr = 0; rr < 32; ++rr) {
+        const float4 a = sdy[buf][rr][ng], b = sx[buf][rr][kg];
+        acc[0][0] = fmaf(a.x, b.x, acc[0][0]); acc[0][1] = fmaf(a.x, b.y, acc[0][1]); acc[0][2] = fmaf(a.x, b.z, acc[0][2]); acc[0][3] = fmaf(a.x, b.w, acc[0][3]);
+        acc[1][0] = fmaf(a.y, b.x, acc[1][0]); acc[1][1] = fmaf(a.y, b.y, acc[1][1]); acc[1][2] = fmaf(a.y, b.z, acc[1][2]); acc[1][3] = fmaf(a.y, b.w, acc[1][3]);
+        acc[2][0] = fmaf(a.z, b.x, acc[2][0]); acc[2][1] = fmaf(a.z, b.y, acc[2][1]); acc[2][2] = fmaf(a.z, b.z, acc[2][2]); acc[2][3] = fmaf(a.z, b.w, acc[2][3]);
+        acc[3][0] = fmaf(a.w, b.x, acc[3][0]); acc[3][1] = fmaf(a.w, b.y, acc[3][1]); acc[3][2] = fmaf(a.w, b.z, acc[3][2]); acc[3][3] = fmaf(a.w, b.w, acc[3][3]);
+      }
+    }
+    if (more) stage(buf ^ 1);                       // (the other buffer: its last readers passed the barrier below one chunk ago)
+    __syncthreads();
+  }
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float* row = part + ((size_t)z * N + 4 * ng + i) * Kp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 4 * kg + j;
+      if (k < Kp) row[k] = acc[i][j];
+    }
+  }
+}
+
+// row slices of the narrow kernel: ~768 blocks over the column tiles, at least 128 rows (four chunks) a slice
+static int narrow_wgrad_slices(int M, int K) {
+  const int tiles = cdiv(K + 1, 64);
+  return std::max(1, std::min(cdiv(768, tiles), cdiv(M, 128)));
+}
+static bool narrow_wgrad_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EVAE_WGRAD_NARROW"); on = e ? atoi(e) : 1; }
+  return on != 0;
+}
+static bool narrow_wgrad_shape(int M, int N, int K) { return narrow_wgrad_enabled() && N <= 64 && N % 4 == 0 && M >= 2048 && K >= 64; }
+
 // ---- weight gradient -------------------------------------------------------------------------------------
 // The bias gradient db = column sums of dy is folded into the same GEMM: x gets a virtual all-ones
 // column K (never read from memory), so column K of dy^T [x | 1] is db.
@@ -394,7 +488,9 @@ extern "C" int evae_dense_bwd_data_img(const float* dy1, const float* w1, const 
 static int wgrad_max_planes(int M, int N, int K) {
   const Plan pl = make_plan(N, K + 1, cdiv(M, BK), false, true, 1);
   const Plan pll = make_plan_local(N, K + 1, cdiv(M, BK));
-  return std::max(std::max(pl.nz, pll.nz), x6t_split(M, N, K + 1).nz);
+  int nz = std::max(std::max(pl.nz, pll.nz), x6t_split(M, N, K + 1).nz);
+  if (narrow_wgrad_shape(M, N, K)) nz = std::max(nz, narrow_wgrad_slices(M, K));
+  return nz;
 }
 
 extern "C" size_t evae_dense_bwd_weight_workspace_bytes(int M, int N, int K) {
@@ -453,7 +549,17 @@ static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const f
     g.out0 = dw; g.ldo = K; g.out1 = db; g.direct = 1;
     return launch_gemm<false, false, EPI_RAW>(g, p1, stream, "dense_bwd_weight(direct)");
   }
-  if (phase != 2) {
+  // a narrow output over many rows: the streaming reduction above instead of a GEMM with one mostly empty row tile
+  const bool narrow = !x6 && rows == nullptr && narrow_wgrad_shape(M, N, K) && ldy % 4 == 0 && ldx % 4 == 0 &&
+                      ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0);
+  const int nslice = narrow ? narrow_wgrad_slices(M, K) : 0;
+  if (narrow && phase != 2) {
+    const int rps = cdiv(M, nslice);
+    narrow_wgrad_kernel<<<dim3(cdiv(Kp, 64), cdiv(M, rps)), 256, 0, stream>>>(dy, ldy, x, ldx, M, N, K, rps, part);
+    const int rc = check_launch("narrow_wgrad_kernel");
+    if (rc || phase == 1) return rc;
+  }
+  if (phase != 2 && !narrow) {
     int rc;
     if (x6) {
       g.ksplit = sp6.nz > 1 ? sp6.ksplit : 0;
@@ -465,7 +571,7 @@ static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const f
     if (phase == 1) return EVAE_OK;
   }
   FinishArgs f = {};
-  f.part = part; f.nz = x6 ? sp6.nz : pl.nz; f.M = N; f.N = Kp; f.ldo = Kp; f.epi = EPI_RAW; f.out0 = dw; f.accumulate = accumulate;
+  f.part = part; f.nz = narrow ? cdiv(M, cdiv(M, nslice)) : (x6 ? sp6.nz : pl.nz); f.M = N; f.N = Kp; f.ldo = Kp; f.epi = EPI_RAW; f.out0 = dw; f.accumulate = accumulate;
   f.ones_col = K; f.out_db = db;
   if (finish_out) { *finish_out = f; return EVAE_OK; }      // (the caller only wants to know what the finish would be)
   return launch_finish(f, stream);

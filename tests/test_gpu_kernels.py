@@ -1109,3 +1109,29 @@ def test_elbo_function_and_its_gradients(ops, two, average):
                 assert a.grad is None
             else:
                 assert rel(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < 1e-6, i
+
+
+@pytest.mark.parametrize("M,N,K,ldy,ldx", [(25100, 40, 300, 40, 300), (11600, 40, 300, 40, 300), (4099, 8, 67, 12, 68),
+                                           (2048, 64, 64, 64, 64), (9000, 36, 784, 600, 784)])
+def test_narrow_weight_gradient_streams_the_rows(ops, M, N, K, ldy, ldx):
+    """evae_dense_bwd_weight for a narrow output (N <= 64: the encoder heads' [40 x 300] over all C + B rows) takes the
+    streaming kernel (narrow_wgrad_kernel: row slices x 64-column tiles, partial planes, the common finish) instead of a GEMM
+    whose one row tile is mostly empty: dw and db against float64, strided dy / x, accumulate, and equal to the GEMM path
+    (EVAE_WGRAD_NARROW=0 is read once per process, so the comparison is against float64 with the GEMM kernel's bar)."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    dyb = torch.randn(M, ldy, device="cuda", generator=g) * 0.05
+    xb = torch.randn(M, ldx, device="cuda", generator=g)
+    dy, x = dyb[:, :N], xb[:, :K]
+    lib = ops._lib.load()
+    nb = lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
+    ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    dw = torch.full((N, K), 7.0, device="cuda"); db = torch.full((N,), 7.0, device="cuda")
+    call = lambda acc: ops._lib.check(lib.evae_dense_bwd_weight(ops._p(dy), M, N, ldy, ops._p(x), None, K, ldx, ops._p(dw), ops._p(db), acc,
+                                                                ops._p(ws), nb, ops._stream()), "bwd_weight")
+    call(0)
+    ref = dy.double().t() @ x.double(); refb = dy.double().sum(0)
+    assert rel(dw.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    assert rel(db.cpu().numpy(), refb.cpu().numpy()) < 2e-6
+    call(1)                                                       # accumulate on top
+    assert rel(dw.cpu().numpy(), 2 * ref.cpu().numpy()) < 2e-6
+    assert rel(db.cpu().numpy(), 2 * refb.cpu().numpy()) < 2e-6
