@@ -51,6 +51,7 @@ class AdamTensor(C.Structure):
 SIGNATURES = {
     "evae_version": (_i, []),
     "evae_last_error": (C.c_char_p, []),
+    "evae_ctl_upload": (_i, [_p, _p, _p, _z, _p, _p, _p, _p]),
     "evae_prior_set_norm_limit": (_i, [_f]),
     "evae_prior_lse_fwd_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_prior_lse_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),

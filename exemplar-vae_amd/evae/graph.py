@@ -14,13 +14,14 @@ counter-based generator (evae_batch_prologue: seed = torch's seed when the runne
 in the control block); whatever else draws random numbers uses the CUDA generator, which torch registers with the
 capture so that every replay advances its Philox offset.  RCCL collectives of the sharded prior are captured too.
 """
+import ctypes as C
 import os
 import time
 import sys
 
 import torch
 
-from . import ops, shard
+from . import _lib, ops, shard
 
 
 _REFRESH_PROF = os.environ.get("EVAE_REFRESH_PROF") == "1"       # host time of _refresh by part, printed at exit (tools/host_time.py)
@@ -97,6 +98,10 @@ class GraphedTrainStep:
         # Thin steps (host-bound): ONE upload on the step's stream straight into the control block instead of upload stream +
         # staging block + device copy (seven stream / event calls, 65 us of host time measured); the DMA's ~10 us then sit in
         # front of the graph, which a GPU-bound step (c2) would feel and a host-bound one does not.  EVAE_CTL_DIRECT=0/1 forces.
+        # (r03 A/Bs, profiles/r03_ab/knobs.jsonl and tools/host_time.py: run-to-run spread at these sizes is +-10 %, the two paths
+        # tie at C = 200 (0.25-0.28 either way) and the direct one is ahead at c1 (0.267 / 0.267 against 0.273 / 0.294).  The
+        # staged path's six stream / event / copy operations go through ONE C call, evae_ctl_upload: 56 us of host time instead
+        # of 65 -- the HIP calls themselves cost that, not the bindings.)
         e = os.environ.get("EVAE_CTL_DIRECT")
         self._direct = (Cl + self.B <= 8192) if e is None else e == "1"
         self._h_draw = torch.zeros(C, dtype=torch.int64)                 # the full draw when only a shard is uploaded
@@ -104,6 +109,9 @@ class GraphedTrainStep:
         self._up = torch.cuda.Stream(device=dev)
         self._ev_up = [torch.cuda.Event() for _ in range(2)]             # upload k finished (host buffer k reusable)
         self._ev_used = [torch.cuda.Event() for _ in range(2)]           # device staging k consumed by the step stream
+        for ev in self._ev_up + self._ev_used:
+            ev.record()                            # (their handles exist from here on)
+        self._ctl_bytes = words * 8
         self.by_index = None      # True once the loader's images are known to be rows of the resident dataset
         # by-index batches are gathered, binarised and given their eps by ONE launch with a counter-based generator
         # (evae_batch_prologue); the seed is torch's at construction time, the counter is the step number
@@ -254,14 +262,13 @@ class GraphedTrainStep:
             self.ctl.copy_(h, non_blocking=True)
             self._ev_up[k].record()               # (on the step's stream: host block k is free once this upload ran)
         else:
-            main = torch.cuda.current_stream()
-            self._up.wait_event(self._ev_used[k])     # device staging block k was consumed two steps ago
-            with torch.cuda.stream(self._up):
-                self._d_ctl[k].copy_(h, non_blocking=True)
-                self._ev_up[k].record()
-            main.wait_event(self._ev_up[k])
-            self.ctl.copy_(self._d_ctl[k])
-            self._ev_used[k].record()
+            # upload stream: wait until staging block k was consumed (two steps ago), copy the host block there; step stream: wait
+            # for that upload, one device-to-device copy into the control block (evae_ctl_upload: the six operations as one call)
+            _lib.check(_lib.load().evae_ctl_upload(C.c_void_p(self._d_ctl[k].data_ptr()), C.c_void_p(h.data_ptr()),
+                                                   C.c_void_p(self.ctl.data_ptr()), self._ctl_bytes,
+                                                   C.c_void_p(self._up.cuda_stream), C.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                                   C.c_void_p(self._ev_used[k].cuda_event), C.c_void_p(self._ev_up[k].cuda_event)),
+                       "evae_ctl_upload")
         if idx_on_device:
             self.idx_in.copy_(indices.reshape(self.B, 1))
         if not self.by_index:

@@ -39,6 +39,11 @@ typedef void* evae_stream_t; /* hipStream_t */
 
 int evae_version(void);
 const char* evae_last_error(void);
+/* Host-side helper of the captured training step (no reference counterpart: utils/training.py:27-46 feeds every step from the host):
+ * the double-buffered upload of the step's control block -- wait(up, ev_used); copy h_pinned -> d_stage on `up`; record(ev_up, up);
+ * wait(step, ev_up); copy d_stage -> d_ctl on `step`; record(ev_used, step) -- as one call.  ev_*: hipEvent_t handles. */
+int evae_ctl_upload(void* d_stage, const void* h_pinned, void* d_ctl, size_t bytes, evae_stream_t up, evae_stream_t step,
+                    void* ev_used, void* ev_up);
 
 /* ----------------------------------------------------------------------------------------------
  * Exemplar prior: fused all-pairs distance + leave-one-out mask + online log-sum-exp.

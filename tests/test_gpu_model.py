@@ -77,7 +77,8 @@ def test_graphed_step_matches_eager(feed, monkeypatch):
     """hipGraph replay of the whole step (evae/graph.py) == the same steps launched eagerly.  `host_loader`: CPU batches
     as a DataLoader yields them (the step gathers the images from the resident dataset by index); `foreign_images`:
     batches that are NOT rows of the dataset (the step must notice and upload the images instead).  A step this thin uploads
-    its control block directly on its own stream; `..._staged_upload` forces the double-buffered path of the large steps."""
+    its control block directly on its own stream; `..._staged_upload` forces the double-buffered path of the large steps
+    (evae_ctl_upload)."""
     if feed == "host_loader_staged_upload":
         monkeypatch.setenv("EVAE_CTL_DIRECT", "0")
         feed = "host_loader"
