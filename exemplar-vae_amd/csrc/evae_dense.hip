@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void heads_reparam_finish_kernel(const float* 
                                                                    float lo, float hi, const float* __restrict__ eps,
                                                                    float* __restrict__ z_mean, float* __restrict__ lv_pre,
                                                                    float* __restrict__ logvar, float* __restrict__ z,
-                                                                   float* __restrict__ logq) {
+                                                                   float* __restrict__ logq, const float* __restrict__ z_given) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -210,11 +210,12 @@ __global__ __launch_bounds__(256) void heads_reparam_finish_kernel(const float* 
     m += bm ? bm[k] : 0.f;
     p += bl ? bl[k] : 0.f;
     const float lv = fminf(fmaxf(p, lo), hi);
-    const float zz = eps[o] * expf(0.5f * lv) + m;
+    // z_given: the density of a sample drawn elsewhere (p(z1 | z2) of the 2-level models) instead of a fresh one
+    const float zz = z_given ? z_given[o] : eps[o] * expf(0.5f * lv) + m;
     z_mean[o] = m;
     if (lv_pre) lv_pre[o] = p;
     logvar[o] = lv;
-    z[o] = zz;
+    if (!z_given) z[o] = zz;
     const float d = zz - m;
     acc += -0.5f * (lv + kLog2Pi + d * d / expf(lv));
   }
@@ -246,8 +247,30 @@ extern "C" int evae_heads_reparam_fwd(const float* x, int M, int K, int ldx, con
   int rc = launch_gemm<true, true, EPI_RAW_GATED>(g, pl, stream, "heads_reparam_fwd(split-K)");
   if (rc) return rc;
   heads_reparam_finish_kernel<<<cdiv(M, 4), 256, 0, stream>>>((const float*)ws, pl.nz, M, Z, bm, bl, lv_lo, lv_hi, eps, z_mean,
-                                                             lv_pre, logvar, z, logq);
+                                                             lv_pre, logvar, z, logq, nullptr);
   return check_launch("heads_reparam_finish_kernel");
+}
+
+// The same two heads with the log-density of a GIVEN sample: logp[m] = log N(zq[m] | z_mean[m], exp(logvar[m])) -- p(z1 | z2) of
+// the 2-level models (models/AbsHModel.py:17-20,99-100); workspace of evae_heads_reparam_fwd_workspace_bytes.
+extern "C" int evae_heads_density_fwd(const float* x, int M, int K, int ldx, const float* wm, const float* bm, const float* wl,
+                                      const float* bl, int Z, float lv_lo, float lv_hi, const float* zq, float* z_mean, float* lv_pre,
+                                      float* logvar, float* logp, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(M >= 0 && K > 0 && Z > 0 && ldx >= K, "heads_density_fwd: bad sizes M=%d K=%d Z=%d ldx=%d", M, K, Z, ldx);
+  if (M == 0) return EVAE_OK;
+  EVAE_REQUIRE(x && wm && wl && zq && z_mean && logvar && logp, "heads_density_fwd: null pointer");
+  EVAE_REQUIRE(ws && ws_bytes >= evae_heads_reparam_fwd_workspace_bytes(M, K, Z), "heads_density_fwd: workspace too small (%zu)", ws_bytes);
+  const Plan pl = heads_plan(M, K, Z);
+  GemmArgs g = {};
+  g.ones_col = -1;
+  g.A[0] = x; g.B[0] = wm; g.Bg = wl; g.lda[0] = ldx; g.ldb[0] = K; g.Kc[0] = K; g.npairs = 1;
+  g.M = M; g.N = Z; g.ldo = Z; g.out0 = (float*)ws;
+  int rc = launch_gemm<true, true, EPI_RAW_GATED>(g, pl, stream, "heads_density_fwd(split-K)");
+  if (rc) return rc;
+  heads_reparam_finish_kernel<<<cdiv(M, 4), 256, 0, stream>>>((const float*)ws, pl.nz, M, Z, bm, bl, lv_lo, lv_hi, nullptr, z_mean,
+                                                             lv_pre, logvar, nullptr, logp, zq);
+  return check_launch("heads_density_finish");
 }
 
 // ---- data gradient ---------------------------------------------------------------------------------------

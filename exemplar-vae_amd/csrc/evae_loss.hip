@@ -83,6 +83,24 @@ __global__ void log_normal_diag_bwd_kernel(const float* __restrict__ x, const fl
   if (dlogvar) dlogvar[i] = g * (-0.5f) * (1.0f - d * d / var);
 }
 
+// ... with the Hardtanh(lo, hi) of the log-variance head folded in (dlv_pre = gradient of the head's pre-activation)
+__global__ void log_normal_diag_bwd_ht_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                              const float* __restrict__ logvar, const float* __restrict__ lv_pre, float lo, float hi,
+                                              const float* __restrict__ dout, int B, int zdim, float* __restrict__ dx,
+                                              float* __restrict__ dmu, float* __restrict__ dlv_pre) {
+  const size_t n = (size_t)B * zdim;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = dout[i / zdim];
+  const float var = expf(logvar[i]);
+  const float d = x[i] - mu[i];
+  const float t = g * (d / var);
+  if (dx) dx[i] = -t;
+  dmu[i] = t;
+  const float pre = lv_pre[i];
+  dlv_pre[i] = (pre > lo && pre < hi) ? g * (-0.5f) * (1.0f - d * d / var) : 0.f;
+}
+
 constexpr float kMinEps = 1e-5f, kMaxEps = 1.0f - 1e-5f;
 
 __global__ __launch_bounds__(LNT) void bernoulli_ll_fwd_kernel(const float* __restrict__ x,
@@ -441,6 +459,17 @@ extern "C" int evae_log_normal_diag_bwd(const float* x, const float* mu, const f
   EVAE_REQUIRE(x && mu && logvar && dout, "log_normal_diag_bwd: null pointer");
   log_normal_diag_bwd_kernel<<<ELT_GRID((size_t)B * zdim), 256, 0, (hipStream_t)s>>>(x, mu, logvar, dout, B, zdim, dx, dmu, dlogvar);
   return check_launch("log_normal_diag_bwd");
+}
+
+extern "C" int evae_log_normal_diag_bwd_hardtanh(const float* x, const float* mu, const float* logvar, const float* lv_pre,
+                                                 float lo, float hi, const float* dout, int B, int zdim, float* dx, float* dmu,
+                                                 float* dlv_pre, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0 && zdim > 0, "log_normal_diag_bwd_hardtanh: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(x && mu && logvar && lv_pre && dout && dmu && dlv_pre, "log_normal_diag_bwd_hardtanh: null pointer");
+  log_normal_diag_bwd_ht_kernel<<<ELT_GRID((size_t)B * zdim), 256, 0, (hipStream_t)s>>>(x, mu, logvar, lv_pre, lo, hi, dout, B, zdim, dx,
+                                                                                         dmu, dlv_pre);
+  return check_launch("log_normal_diag_bwd_hardtanh");
 }
 
 extern "C" int evae_bernoulli_ll_fwd(const float* x, const float* mean, int B, int D, float* out,

@@ -72,6 +72,8 @@ SIGNATURES = {
     "evae_linear_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _f, _p, _p, _p, _z, _p]),
     "evae_heads_reparam_fwd_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_heads_reparam_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_heads_density_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_log_normal_diag_bwd_hardtanh": (_i, [_p, _p, _p, _p, _f, _f, _p, _i, _i, _p, _p, _p, _p]),
     "evae_dense_bwd_data_wt_bytes": (_z, [_i, _i, _i]),
     "evae_dense_bwd_data_wt_ld": (_i, [_i]),
     "evae_dense_bwd_data_wt": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _z, _p]),

@@ -987,23 +987,85 @@ class HeadsReparamFn(torch.autograd.Function):
             dmu = dmu + dmean
         if dlogvar is not None:
             dlvp = dlvp + dlogvar * ((lv_pre > lo) & (lv_pre < hi))
-        dh = _bwd_data(dmu.data_ptr(), wm, dlvp.data_ptr(), wl, M, Z, Z, h.device) if ctx.needs_input_grad[0] else None
-        if M <= 128 and Z % 4 == 0 and K % 4 == 0 and h.stride(0) % 4 == 0:
-            dwm = torch.empty((Z, K), device=h.device); dwl = torch.empty_like(dwm)
-            dbm = torch.empty(Z, device=h.device); dbl = torch.empty_like(dbm)
-            arr = (_lib.WgradJob * 2)()
-            for j, (dy_, dw_, db_) in enumerate(((dmu, dwm, dbm), (dlvp, dwl, dbl))):
-                arr[j].dy = dy_.data_ptr(); arr[j].x = h.data_ptr(); arr[j].dw = dw_.data_ptr(); arr[j].db = db_.data_ptr()
-                arr[j].M, arr[j].N, arr[j].K, arr[j].ldy, arr[j].ldx = M, Z, K, Z, h.stride(0)
-            _lib.check(lib.evae_dense_bwd_weight_group(C.cast(arr, C.c_void_p), 2, _stream()), "evae_dense_bwd_weight_group")
-        else:
-            dwm, dbm = _bwd_weight(dmu, h, None, K)
-            dwl, dbl = _bwd_weight(dlvp, h, None, K)
-        return dh, dwm, (dbm if ctx.has_bias[0] else None), dwl, (dbl if ctx.has_bias[1] else None), None, None, None
+        return _heads_bwd(h, wm, wl, dmu, dlvp, ctx.needs_input_grad[0], ctx.has_bias) + (None, None, None)
 
 
 def heads_reparam(h, wm, bm, wl, bl, eps, lo, hi):
     return HeadsReparamFn.apply(h, wm, bm, wl, bl, eps, lo, hi)
+
+
+def _heads_bwd(h, wm, wl, dmu, dlvp, want_dh, has_bias):
+    """what the two heads' backward shares: dh over both heads in one data gradient, both weight gradients in one grouped launch"""
+    lib = _lib.load()
+    M, K = h.shape
+    Z = wm.shape[0]
+    dh = _bwd_data(dmu.data_ptr(), wm, dlvp.data_ptr(), wl, M, Z, Z, h.device) if want_dh else None
+    if M <= 128 and Z % 4 == 0 and K % 4 == 0 and h.stride(0) % 4 == 0:
+        dwm = torch.empty((Z, K), device=h.device); dwl = torch.empty_like(dwm)
+        dbm = torch.empty(Z, device=h.device); dbl = torch.empty_like(dbm)
+        arr = (_lib.WgradJob * 2)()
+        for j, (dy_, dw_, db_) in enumerate(((dmu, dwm, dbm), (dlvp, dwl, dbl))):
+            arr[j].dy = dy_.data_ptr(); arr[j].x = h.data_ptr(); arr[j].dw = dw_.data_ptr(); arr[j].db = db_.data_ptr()
+            arr[j].M, arr[j].N, arr[j].K, arr[j].ldy, arr[j].ldx = M, Z, K, Z, h.stride(0)
+        _lib.check(lib.evae_dense_bwd_weight_group(C.cast(arr, C.c_void_p), 2, _stream()), "evae_dense_bwd_weight_group")
+    else:
+        dwm, dbm = _bwd_weight(dmu, h, None, K)
+        dwl, dbl = _bwd_weight(dlvp, h, None, K)
+    return dh, dwm, (dbm if has_bias[0] else None), dwl, (dbl if has_bias[1] else None)
+
+
+class HeadsDensityFn(torch.autograd.Function):
+    """(h, wm, bm, wl, bl, zq) -> (z_mean, logvar, log N(zq | z_mean, exp(logvar))): the conditional p(z1 | z2) of the 2-level models
+    (reference models/AbsHModel.py:17-20) with the density term of kl_loss (:99-100) -- evae_heads_density_fwd's two launches
+    forward (two linear layers x 2 + the density = 5 separately), evae_log_normal_diag_bwd_hardtanh + one data gradient + one
+    grouped weight gradient backward (10 separately)."""
+
+    @staticmethod
+    def forward(ctx, h, wm, bm, wl, bl, zq, lo, hi):
+        lib = _lib.load()
+        _need_cuda(h, wm, wl, zq)
+        h, wm, wl, zq = _f32(h), _f32(wm), _f32(wl), _f32(zq)
+        M, K = h.shape
+        Z = wm.shape[0]
+        assert wl.shape == wm.shape and wm.shape[1] == K and zq.shape == (M, Z)
+        z_mean = torch.empty((M, Z), device=h.device); lv_pre = torch.empty_like(z_mean); logvar = torch.empty_like(z_mean)
+        logp = torch.empty(M, device=h.device)
+        ws = _workspace("heads", lib.evae_heads_reparam_fwd_workspace_bytes(M, K, Z), h.device)
+        _lib.check(lib.evae_heads_density_fwd(_p(h), M, K, h.stride(0), _p(wm), _p(bm), _p(wl), _p(bl), Z, float(lo), float(hi), _p(zq),
+                                              _p(z_mean), _p(lv_pre), _p(logvar), _p(logp), _p(ws), ws.numel(), _stream()),
+                   "evae_heads_density_fwd")
+        ctx.save_for_backward(h, wm, wl, z_mean, lv_pre, logvar, zq)
+        ctx.set_materialize_grads(False)
+        ctx.clamp = (float(lo), float(hi))
+        ctx.has_bias = (bm is not None, bl is not None)
+        return z_mean, logvar, logp
+
+    @staticmethod
+    def backward(ctx, dmean, dlogvar, dlogp):
+        lib = _lib.load()
+        if dmean is None and dlogvar is None and dlogp is None:
+            return (None,) * 8
+        h, wm, wl, z_mean, lv_pre, logvar, zq = ctx.saved_tensors
+        lo, hi = ctx.clamp
+        M, Z = z_mean.shape
+        dz = None
+        if dlogp is not None:
+            dmu = torch.empty_like(z_mean); dlvp = torch.empty_like(z_mean)
+            dz = torch.empty_like(z_mean) if ctx.needs_input_grad[5] else None
+            _lib.check(lib.evae_log_normal_diag_bwd_hardtanh(_p(zq), _p(z_mean), _p(logvar), _p(lv_pre), lo, hi, _p(_f32(dlogp)), M, Z,
+                                                             _p(dz), _p(dmu), _p(dlvp), _stream()), "evae_log_normal_diag_bwd_hardtanh")
+        else:
+            dmu = torch.zeros_like(z_mean); dlvp = torch.zeros_like(z_mean)
+        if dmean is not None:
+            dmu = dmu + dmean
+        if dlogvar is not None:
+            dlvp = dlvp + dlogvar * ((lv_pre > lo) & (lv_pre < hi))
+        dh, dwm, dbm, dwl, dbl = _heads_bwd(h, wm, wl, dmu, dlvp, ctx.needs_input_grad[0], ctx.has_bias)
+        return dh, dwm, dbm, dwl, dbl, dz, None, None
+
+
+def heads_density(h, wm, bm, wl, bl, zq, lo, hi):
+    return HeadsDensityFn.apply(h, wm, bm, wl, bl, zq, lo, hi)
 
 
 class ElboFn(torch.autograd.Function):

@@ -96,6 +96,18 @@ class BaseHModel(BaseModel):
         z = self.reparameterize(mu, lv).view(-1, zdim)
         return z, mu, lv, log_normal_diag(z, mu, lv, dim=1)
 
+    def _density_heads(self, trunk, mean_head, logvar_head, zq, zdim):
+        """(mean, log-variance, log N(zq | mean, exp(logvar))) of a pair of heads on `trunk` -- p(z1 | z2) and its density term"""
+        from evae import ops
+        from utils.nn import HipLinear, NonLinear
+        if (_FUSED_HEADS and trunk.is_cuda and trunk.dim() == 2 and isinstance(mean_head, HipLinear)
+                and isinstance(logvar_head, NonLinear) and isinstance(logvar_head.activation, torch.nn.Hardtanh)):
+            act = logvar_head.activation
+            return ops.heads_density(trunk, mean_head.weight, mean_head.bias, logvar_head.linear.weight, logvar_head.linear.bias,
+                                     zq.view(-1, zdim), act.min_val, act.max_val)
+        mu, lv = mean_head(trunk).view(-1, zdim), logvar_head(trunk).view(-1, zdim)
+        return mu, lv, log_normal_diag(zq.view(-1, zdim), mu, lv, dim=1)
+
     def _two_stream_path(self, x, x_indices, exemplars_embedding, dataset):
         a = self.args
         return (_TWO_STREAM and self.training and a.prior == 'exemplar_prior' and a.approximate_prior is False
@@ -135,10 +147,10 @@ class BaseHModel(BaseModel):
         main.wait_event(z2_ready)
         z2.record_stream(main)
         log_prior = self.log_p_z(z=(z2.view(-1, d2), x_indices), exemplars_embedding=emb)
-        p1_mu, p1_lv = self.p_z1(z2)
+        trunk1 = self.p_z1_layers_z2(z2)                     # p_z1(): trunk, then the two heads (with the density of z1)
         main.wait_event(z1_ready)
         z1.record_stream(main)
-        log_p1 = log_normal_diag(z1.view(-1, d1), p1_mu.view(-1, d1), p1_lv.view(-1, d1), dim=1)
+        p1_mu, p1_lv, log_p1 = self._density_heads(trunk1, self.p_z1_mean, self.p_z1_logvar, z1, d1)
         lp_ready = torch.cuda.Event(); lp_ready.record()
         log_prior.record_stream(side); log_p1.record_stream(side)
         with torch.cuda.stream(side):

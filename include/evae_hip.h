@@ -214,6 +214,11 @@ size_t evae_heads_reparam_fwd_workspace_bytes(int M, int K, int Z);
 int evae_heads_reparam_fwd(const float* x, int M, int K, int ldx, const float* wm, const float* bm, const float* wl,
                            const float* bl, int Z, float lv_lo, float lv_hi, const float* eps, float* z_mean, float* lv_pre,
                            float* logvar, float* z, float* logq, void* ws, size_t ws_bytes, evae_stream_t stream);
+/* The same two heads with the log-density of a GIVEN sample zq [M x Z] (models/AbsHModel.py:17-20 p(z1 | z2) and the
+ * log_normal_diag(z1, p1_mu, p1_lv) of :99-100): logp[m] = log N(zq[m] | z_mean[m], exp(logvar[m])); workspace as above. */
+int evae_heads_density_fwd(const float* x, int M, int K, int ldx, const float* wm, const float* bm, const float* wl,
+                           const float* bl, int Z, float lv_lo, float lv_hi, const float* zq, float* z_mean, float* lv_pre,
+                           float* logvar, float* logp, void* ws, size_t ws_bytes, evae_stream_t stream);
 /* dy1/dy2: [M x N] with row stride ldy (so dh and dg may be the two halves of one [M x 2N] buffer);
  * output(s) [M x K] with row stride ldo; out_prev/s_prev are dense [M x K]. */
 size_t evae_dense_bwd_data_workspace_bytes(int M, int N, int K, int npairs);
@@ -434,6 +439,9 @@ int evae_batch_prologue_u8_prepare(const unsigned char* data, int64_t ldd, const
                                    int64_t lds, float* eps_out, int zdim, const float* wh, const float* wg, int N, int K,
                                    void* prepared, size_t prepared_bytes, const evae_wt_job_t* jobs, int njobs,
                                    evae_stream_t stream);
+/* evae_log_normal_diag_bwd with the Hardtanh(lo, hi) of a log-variance head folded in: dlv_pre is the gradient of its pre-activation */
+int evae_log_normal_diag_bwd_hardtanh(const float* x, const float* mu, const float* logvar, const float* lv_pre, float lo, float hi,
+                                      const float* dout, int B, int zdim, float* dx, float* dmu, float* dlv_pre, evae_stream_t stream);
 int evae_bernoulli_ll_fwd(const float* x, const float* mean, int B, int D, float* out,
                           evae_stream_t stream);
 int evae_bernoulli_ll_bwd(const float* x, const float* mean, const float* dout, int B, int D,

@@ -1135,3 +1135,30 @@ def test_narrow_weight_gradient_streams_the_rows(ops, M, N, K, ldy, ldx):
     call(1)                                                       # accumulate on top
     assert rel(dw.cpu().numpy(), 2 * ref.cpu().numpy()) < 2e-6
     assert rel(db.cpu().numpy(), 2 * refb.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("M,K,Z", [(100, 300, 40), (37, 300, 40), (200, 128, 64), (5, 48, 8)])
+def test_heads_density_function_and_its_gradients(ops, M, K, Z):
+    """evae.ops.HeadsDensityFn (p(z1 | z2): mean head, Hardtanh log-variance head and log N(zq | mean, exp(logvar)) in two launches;
+    backward in four) against the float64 tensor expressions of reference models/AbsHModel.py:17-20,99-100 and
+    utils/distributions.py:28-33, upstream gradients on all three outputs, and on the density alone (the training step)."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    r = lambda *s, k=1.0: torch.randn(*s, device="cuda", generator=g) * k
+    h, wm, bm, wl, bl, zq = r(M, K), r(Z, K, k=0.1), r(Z, k=0.1), r(Z, K, k=0.3), r(Z), r(M, Z)
+    gm, glv, gp = r(M, Z), r(M, Z), r(M)
+    for only_density in (False, True):
+        leaves = [t.clone().requires_grad_() for t in (h, wm, bm, wl, bl, zq)]
+        mu, lv, lp = ops.heads_density(*leaves, -6.0, 2.0)
+        obj = (lp * gp).sum() if only_density else (mu * gm).sum() + (lv * glv).sum() + (lp * gp).sum()
+        obj.backward()
+        ref = [t.double().clone().requires_grad_() for t in (h, wm, bm, wl, bl, zq)]
+        h_, wm_, bm_, wl_, bl_, zq_ = ref
+        mu_ = h_ @ wm_.t() + bm_
+        lv_ = torch.nn.functional.hardtanh(h_ @ wl_.t() + bl_, -6.0, 2.0)
+        lp_ = (-0.5 * (lv_ + np.log(2 * np.pi) + (zq_ - mu_) ** 2 / torch.exp(lv_))).sum(1)
+        obj_ = (lp_ * gp.double()).sum() if only_density else (mu_ * gm.double()).sum() + (lv_ * glv.double()).sum() + (lp_ * gp.double()).sum()
+        obj_.backward()
+        for a, b in ((mu, mu_), (lv, lv_), (lp, lp_)):
+            assert rel(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 2e-6
+        for name, a, b in zip("h wm bm wl bl zq".split(), leaves, ref):
+            assert rel(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < 5e-6, (name, only_density)
