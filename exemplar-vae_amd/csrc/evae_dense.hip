@@ -26,6 +26,7 @@
 //   stay in one L2).
 
 #include "evae_gemm_x6.h"
+#include "evae_gemm_p6.h"
 #include "evae_u8_prepare.h"
 
 namespace evae {
@@ -111,10 +112,10 @@ extern "C" size_t evae_dense_fwd_workspace_bytes(int M, int K, int N, int gated)
   return align_up((size_t)pl.nz * (gated ? 2 : 1) * M * N * sizeof(float), 256) + 256;
 }
 
-extern "C" int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, int K, int ldx,
-                                    const float* wh, const float* bh, const float* wg, const float* bg,
-                                    int N, float* out, float* save_h, float* save_s, void* ws,
-                                    size_t ws_bytes, evae_stream_t stream_) {
+static int gated_dense_fwd_core(const float* x, const int64_t* rows, int M, int K, int ldx,
+                                const float* wh, const float* bh, const float* wg, const float* bg,
+                                int N, float* out, float* save_h, float* save_s, const P6Sink& tsink, void* ws,
+                                size_t ws_bytes, evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(M >= 0 && K > 0 && N > 0 && ldx >= K, "gated_dense_fwd: bad sizes M=%d K=%d N=%d ldx=%d", M, K, N, ldx);
   if (M == 0) return EVAE_OK;
@@ -124,7 +125,7 @@ extern "C" int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, 
   g.ones_col = -1;
   g.A[0] = x; g.B[0] = wh; g.Bg = wg; g.lda[0] = ldx; g.ldb[0] = K; g.Kc[0] = K; g.npairs = 1;
   g.a_rows = rows; g.M = M; g.N = N; g.bias0 = bh; g.bias1 = bg;
-  g.out0 = out; g.out1 = save_h; g.out2 = save_s; g.ldo = N;
+  g.out0 = out; g.out1 = save_h; g.out2 = save_s; g.ldo = N; g.tsink = tsink;
   if (pl.nz <= 1 && gemm_x6_use(g, true)) return launch_gemm_x6<EPI_GATED>(g, 1, stream, "gated_dense_fwd(x6)");
   if (pl.nz <= 1) return launch_gemm<true, true, EPI_GATED>(g, pl, stream, "gated_dense_fwd");
   if (ws == nullptr || ws_bytes < evae_dense_fwd_workspace_bytes(M, K, N, 1)) {
@@ -143,8 +144,29 @@ extern "C" int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, 
   FinishArgs f = {};
   f.ones_col = -1;
   f.part = (const float*)ws; f.nz = pl.nz; f.M = M; f.N = N; f.ldo = N; f.epi = EPI_GATED;
-  f.bias0 = bh; f.bias1 = bg; f.out0 = out; f.out1 = save_h; f.out2 = save_s;
+  f.bias0 = bh; f.bias1 = bg; f.out0 = out; f.out1 = save_h; f.out2 = save_s; f.tsink = tsink;
   return launch_finish(f, stream);
+}
+
+extern "C" int evae_gated_dense_fwd(const float* x, const int64_t* rows, int M, int K, int ldx,
+                                    const float* wh, const float* bh, const float* wg, const float* bg,
+                                    int N, float* out, float* save_h, float* save_s, void* ws,
+                                    size_t ws_bytes, evae_stream_t stream_) {
+  const P6Sink none = {nullptr, 0, 0, 0, 0};
+  return gated_dense_fwd_core(x, rows, M, K, ldx, wh, bh, wg, bg, N, out, save_h, save_s, none, ws, ws_bytes, stream_);
+}
+
+// ... whose output also leaves as the pre-split bf16 image of out^T (evae_p6_image.h): output column n = image row t_row0 + n,
+// output row m = k index t_kbase + m (a multiple of 8) of an image with t_nks k-steps -- the operand the next layer's forward
+// (evae_gated_dense_fwd_p6t) and this layer's successor's weight gradient (evae_dense_bwd_weight_p6) read
+extern "C" int evae_gated_dense_fwd_timg(const float* x, const int64_t* rows, int M, int K, int ldx,
+                                         const float* wh, const float* bh, const float* wg, const float* bg,
+                                         int N, float* out, float* save_h, float* save_s, void* timg, int t_nks, int t_row0,
+                                         int t_kbase, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  EVAE_REQUIRE(timg && t_nks > 0 && t_row0 >= 0 && t_kbase >= 0 && (t_kbase % 8) == 0 && (t_kbase + M + 15) / 16 <= t_nks,
+               "gated_dense_fwd_timg: bad image placement (k-steps %d, first k %d, rows %d)", t_nks, t_kbase, M);
+  const P6Sink sink = {(unsigned char*)timg, t_nks, t_row0, t_kbase, t_kbase + M};
+  return gated_dense_fwd_core(x, rows, M, K, ldx, wh, bh, wg, bg, N, out, save_h, save_s, sink, ws, ws_bytes, stream_);
 }
 
 extern "C" int evae_linear_fwd(const float* x, const int64_t* rows, int M, int K, int ldx,
@@ -307,19 +329,21 @@ struct ImgSink { unsigned short* img; int nslab, mbase; };
 static int dense_bwd_data_core(const float* dy1, const float* w1, const float* dy2, const float* w2,
                                int M, int N, int ldy, int K, const float* out_prev, const float* s_prev,
                                float* dx_or_dh, float* dg, int ldo, const float* wT_ext, void* ws, size_t ws_bytes,
-                               evae_stream_t stream_, const ImgSink* sink = nullptr) {
+                               evae_stream_t stream_, const ImgSink* sink = nullptr, const P6Sink* tsink = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
-  EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldy >= N && (sink || ldo >= K), "dense_bwd_data: bad sizes M=%d N=%d K=%d", M, N, K);
+  EVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldy >= N && (sink || (tsink && !dx_or_dh) || ldo >= K), "dense_bwd_data: bad sizes M=%d N=%d K=%d", M, N, K);
   if (M == 0) return EVAE_OK;
-  EVAE_REQUIRE(dy1 && w1 && (dx_or_dh || sink), "dense_bwd_data: null pointer");
+  EVAE_REQUIRE(dy1 && w1 && (dx_or_dh || sink || tsink), "dense_bwd_data: null pointer");
   EVAE_REQUIRE((dy2 == nullptr) == (w2 == nullptr), "dense_bwd_data: dy2/w2 must come together");
   const bool gate = out_prev != nullptr;
-  EVAE_REQUIRE(!gate || (s_prev && (dg || sink)), "dense_bwd_data: gate fusion needs out_prev, s_prev and dg");
+  EVAE_REQUIRE(!gate || (s_prev && (dg || sink || (tsink && !dx_or_dh))), "dense_bwd_data: gate fusion needs out_prev, s_prev and dg");
+  EVAE_REQUIRE(!tsink || gate, "dense_bwd_data: the transposed-image output comes with the gate epilogue only");
   const int np = dy2 ? 2 : 1;
   Plan pl = make_plan(M, K, total_slabs(N, np > 1 ? N : 0), false, false, 1);
   if (sink) { pl.nz = 1; pl.ksplit = 0; }          // the image epilogue lives in the GEMM itself: no split-K
   GemmArgs g = {};
   if (sink) { g.img = sink->img; g.img_nslab = sink->nslab; g.img_mbase = sink->mbase; }
+  if (tsink) g.tsink = *tsink;
   g.ones_col = -1;
   g.A[0] = dy1; g.B[0] = w1; g.lda[0] = ldy; g.ldb[0] = K; g.Kc[0] = N; g.npairs = np;
   if (dy2) { g.A[1] = dy2; g.B[1] = w2; g.lda[1] = ldy; g.ldb[1] = K; g.Kc[1] = N; }
@@ -373,6 +397,7 @@ static int dense_bwd_data_core(const float* dy1, const float* w1, const float* d
   f.part = (const float*)ws; f.nz = pl.nz; f.M = M; f.N = K; f.ldo = ldo;
   f.epi = gate ? EPI_GATE_BWD : EPI_LINEAR; f.out0 = dx_or_dh; f.out1 = gate ? dg : nullptr;
   f.e0 = out_prev; f.e1 = s_prev;
+  if (tsink) f.tsink = *tsink;
   return launch_finish(f, stream);
 }
 
@@ -393,6 +418,19 @@ extern "C" int evae_dense_bwd_data_wt(const float* dy1, const float* w1, const f
                                       float* dx_or_dh, float* dg, int ldo, const float* wT, void* ws, size_t ws_bytes,
                                       evae_stream_t stream_) {
   return dense_bwd_data_core(dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, dx_or_dh, dg, ldo, wT, ws, ws_bytes, stream_);
+}
+
+// The gate-fused data gradient whose (dh, dg) also -- or, with dx_or_dh == NULL, only -- leave as the pre-split bf16 image of
+// [dh | dg]^T (evae_p6_image.h): column n of dh = image row t_row0 + n, of dg = t_row0 + K + n; row m = k index t_kbase + m
+extern "C" int evae_dense_bwd_data_timg(const float* dy1, const float* w1, const float* dy2, const float* w2,
+                                        int M, int N, int ldy, int K, const float* out_prev, const float* s_prev,
+                                        float* dx_or_dh, float* dg, int ldo, const float* wT, void* timg, int t_nks, int t_row0,
+                                        int t_kbase, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  EVAE_REQUIRE(timg && t_nks > 0 && t_row0 >= 0 && t_kbase >= 0 && (t_kbase % 8) == 0 && (t_kbase + M + 15) / 16 <= t_nks,
+               "dense_bwd_data_timg: bad image placement (k-steps %d, first k %d, rows %d)", t_nks, t_kbase, M);
+  const P6Sink sink = {(unsigned char*)timg, t_nks, t_row0, t_kbase, t_kbase + M};
+  return dense_bwd_data_core(dy1, w1, dy2, w2, M, N, ldy, K, out_prev, s_prev, dx_or_dh, dg, ldo, wT, ws, ws_bytes, stream_, nullptr,
+                             &sink);
 }
 
 // The data gradient of the layer ABOVE the byte-store layer: (dh, dg) of that layer are written as the bf16 tile images the
@@ -734,3 +772,146 @@ extern "C" int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, in
   return check_launch("act_bwd");
 }
 
+
+// ---- GEMMs over pre-split bf16 operand images (evae_gemm_p6.h, evae_p6_image.h) ---------------------------------------------
+// The exemplar rows' chain of a training step: every tensor that is the operand of a big GEMM leaves its producer's epilogue
+// as ONE image (of its transpose: evae_gated_dense_fwd_timg / _u8_timg, evae_dense_bwd_data_timg), the weights are split once
+// per step (evae_p6_pack_rows / _cols), and the three GEMMs of a hidden layer -- forward, data gradient, weight gradient -- run
+// on the bf16 matrix pipe with no splitting in their main loops.
+extern "C" int evae_p6_nks(int K) { return p6_nks(K); }
+extern "C" int evae_p6_nks_rows(int M) { return p6_nks_rows(M); }
+extern "C" size_t evae_p6_image_bytes(int rows, int nks) {
+  if (rows <= 0 || nks <= 0) return 256;
+  return align_up(p6_image_bytes(rows, nks), 256);
+}
+
+// X [R x K] (row stride ld) -> image(rows = R, k = K); gated != 0: x / x2 = the h / g banks of a gated layer, image rows in the
+// order of the forward kernel's [h | g] column pairs (64 outputs = 128 image rows)
+extern "C" int evae_p6_pack_rows(const float* x, const float* x2, int R, int K, long long ld, int gated, void* img,
+                                 size_t img_bytes, evae_stream_t stream_) {
+  EVAE_REQUIRE(x && img && R > 0 && K > 0 && ld >= K && (!gated || x2), "p6_pack_rows: bad arguments");
+  const int rows_img = gated ? cdiv(R, 64) * 128 : cdiv(R, 128) * 128, nks = p6_nks(K);
+  EVAE_REQUIRE(img_bytes >= p6_image_bytes(rows_img, nks), "p6_pack_rows: image buffer too small (%zu)", img_bytes);
+  const size_t total = (size_t)rows_img * nks * 2;
+  p6_pack_rows_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream_>>>(x, x2, R, K, ld, gated, rows_img, nks,
+                                                                                        (unsigned char*)img);
+  return check_launch("p6_pack_rows_kernel");
+}
+
+// X^T: X [Kd x R] with the contraction along its ROWS (rows Kd .. 2 Kd - 1 from x2 when given) -> image(rows = R, k) with nks
+// k-steps (>= the k-steps of the contraction; p6_nks_rows(M) for a tensor with M batch rows); ones_row >= 0: that image row = 1
+extern "C" int evae_p6_pack_cols(const float* x, const float* x2, int Kd, int R, long long ld, int ones_row, int nks, void* img,
+                                 size_t img_bytes, evae_stream_t stream_) {
+  EVAE_REQUIRE(x && img && R > 0 && Kd > 0 && ld >= R && nks >= p6_nks(x2 ? 2 * Kd : Kd), "p6_pack_cols: bad arguments");
+  const int rows_img = cdiv(std::max(R, ones_row + 1), 128) * 128;
+  EVAE_REQUIRE(img_bytes >= p6_image_bytes(rows_img, nks), "p6_pack_cols: image buffer too small (%zu)", img_bytes);
+  const size_t total = (size_t)rows_img * nks * 2;
+  p6_pack_cols_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream_>>>(x, x2, Kd, R, ld, ones_row, rows_img, nks,
+                                                                                        (unsigned char*)img);
+  return check_launch("p6_pack_cols_kernel");
+}
+
+// image row `row` := value for k in [k_begin, k_end) (the all-ones row that carries a bias gradient through a weight gradient)
+__global__ void p6_fill_row_kernel(unsigned char* img, int nks, int row, float value, int k_begin, int k_end) {
+  const int k = k_begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= k_end) return;
+  unsigned short t0, t1, t2;
+  p6_split1(value, t0, t1, t2);
+  unsigned short* o = reinterpret_cast<unsigned short*>(img + p6_off(row, k, nks));
+  o[0] = t0; o[P6_CHUNK / 2] = t1; o[P6_CHUNK] = t2;
+}
+extern "C" int evae_p6_fill_row(void* img, int nks, int row, float value, int k_begin, int k_end, evae_stream_t stream_) {
+  EVAE_REQUIRE(img && nks > 0 && row >= 0 && k_begin >= 0 && k_end <= nks * P6_KS, "p6_fill_row: bad arguments");
+  if (k_end <= k_begin) return EVAE_OK;
+  p6_fill_row_kernel<<<cdiv(k_end - k_begin, 256), 256, 0, (hipStream_t)stream_>>>((unsigned char*)img, nks, row, value, k_begin, k_end);
+  return check_launch("p6_fill_row_kernel");
+}
+
+// does a GEMM with M output rows pay for the image path? (the same machine-filling rule as the split-bf16 kernel)
+extern "C" int evae_gemm_p6_applies(int M, int N, int gated) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EVAE_P6"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  return (on && gemm_x6_enabled() && gemm_x6_fills(M, N, gated != 0)) ? 1 : 0;
+}
+
+// out = (x Wh^T + bh) * sigmoid(x Wg^T + bg) with x given as x^T's image (x_nks k-steps along its M rows) and the weights as
+// the gated image of evae_p6_pack_rows (K = columns of x)
+extern "C" int evae_gated_dense_fwd_p6t(const void* xT_img, int x_nks, int M, int K, const void* w_img, const float* bh,
+                                        const float* bg, int N, float* out, float* save_s, evae_stream_t stream_) {
+  EVAE_REQUIRE(M >= 0 && K > 0 && N > 0, "gated_dense_fwd_p6t: bad sizes M=%d K=%d N=%d", M, K, N);
+  if (M == 0) return EVAE_OK;
+  EVAE_REQUIRE(xT_img && w_img && out && x_nks >= cdiv(M, 128) * 8, "gated_dense_fwd_p6t: bad arguments (k-steps %d)", x_nks);
+  GemmArgs g = {};
+  g.ones_col = -1; g.npairs = 1;
+  g.A[0] = (const float*)xT_img; g.lda[0] = x_nks; g.B[0] = (const float*)w_img; g.Kc[0] = p6_nks(K) * P6_KS;
+  g.M = M; g.N = N; g.bias0 = bh; g.bias1 = bg; g.out0 = out; g.out2 = save_s; g.ldo = N;
+  return launch_gemm_p6<EPI_GATED, 128, true>(g, 1, (hipStream_t)stream_, "gated_dense_fwd(p6)");
+}
+
+// dx = [dh | dg] W with [dh | dg] (N columns) given as its transpose's image and W^T as image(rows = K outputs, k = N)
+// (evae_p6_pack_cols of the stacked banks); out_prev != NULL: the gate derivative of the layer below in the epilogue, (dh, dg) of
+// that layer to dh / dg (row stride ldo) or, u8_img != NULL, as the tile images of evae_dense_bwd_weight_u8
+extern "C" int evae_dense_bwd_data_p6t(const void* dyT_img, int dy_nks, int M, int N, const void* wT_img, int K,
+                                       const float* out_prev, const float* s_prev, float* dh, float* dg, int ldo, void* u8_img,
+                                       int u8_nslab, int u8_mbase, evae_stream_t stream_) {
+  EVAE_REQUIRE(M >= 0 && K > 0 && N > 0, "dense_bwd_data_p6t: bad sizes M=%d K=%d N=%d", M, K, N);
+  if (M == 0) return EVAE_OK;
+  EVAE_REQUIRE(dyT_img && wT_img && dy_nks >= cdiv(M, 128) * 8, "dense_bwd_data_p6t: bad arguments (k-steps %d)", dy_nks);
+  const bool gate = out_prev != nullptr;
+  EVAE_REQUIRE(u8_img ? (gate && s_prev && (u8_mbase % 8) == 0) : (dh && ldo >= K && (!gate || (s_prev && dg))),
+               "dense_bwd_data_p6t: bad outputs");
+  hipStream_t stream = (hipStream_t)stream_;
+  GemmArgs g = {};
+  g.ones_col = -1; g.npairs = 1;
+  g.A[0] = (const float*)dyT_img; g.lda[0] = dy_nks; g.B[0] = (const float*)wT_img; g.Kc[0] = p6_nks(N) * P6_KS;
+  g.M = M; g.N = K; g.out0 = dh; g.out1 = gate ? dg : nullptr; g.ldo = ldo; g.e0 = out_prev; g.e1 = s_prev;
+  g.img = (unsigned short*)u8_img; g.img_nslab = u8_nslab; g.img_mbase = u8_mbase;
+  const bool narrow = gemm_x6_pick_bn(M, K) == 64;
+  if (u8_img) {
+    if (narrow) return launch_gemm_p6<EPI_GATE_BWD_IMG, 64, true>(g, 1, stream, "dense_bwd_data(p6, gate, byte-layer images)");
+    return launch_gemm_p6<EPI_GATE_BWD_IMG, 128, true>(g, 1, stream, "dense_bwd_data(p6, gate, byte-layer images)");
+  }
+  if (gate) {
+    if (narrow) return launch_gemm_p6<EPI_GATE_BWD, 64, true>(g, 1, stream, "dense_bwd_data(p6, gate)");
+    return launch_gemm_p6<EPI_GATE_BWD, 128, true>(g, 1, stream, "dense_bwd_data(p6, gate)");
+  }
+  if (narrow) return launch_gemm_p6<EPI_LINEAR, 64, true>(g, 1, stream, "dense_bwd_data(p6)");
+  return launch_gemm_p6<EPI_LINEAR, 128, true>(g, 1, stream, "dense_bwd_data(p6)");
+}
+
+// dw [N x K] = dy^T x, db [N] = column sums of dy, from the images of dy^T (N rows) and x^T (K rows + the all-ones row K when
+// db != NULL), both with nks k-steps along the batch rows.  Split over the batch rows into one round of blocks; fixed-order finish.
+struct P6WgradPlan { int kc, nz, ksplit; };
+static P6WgradPlan p6_wgrad_plan(int nks, int N, int K, bool with_db) {
+  P6WgradPlan p;
+  p.kc = K + (with_db ? 1 : 0);
+  const int tiles = cdiv(N, BM) * cdiv(p.kc, 64);
+  static int slots = -1;
+  if (slots < 0) { const char* e = getenv("EVAE_P6_WGRAD_SLOTS"); slots = e ? atoi(e) : 256; }
+  int nz = std::max(1, std::min(slots / std::max(tiles, 1), nks / 8));
+  p.ksplit = cdiv(nks, nz);
+  p.nz = cdiv(nks, p.ksplit);
+  return p;
+}
+extern "C" size_t evae_dense_bwd_weight_p6_workspace_bytes(int nks, int N, int K) {
+  if (nks <= 0 || N <= 0 || K <= 0) return 256;
+  const P6WgradPlan p = p6_wgrad_plan(nks, N, K, true);
+  return align_up((size_t)p.nz * N * p.kc * sizeof(float), 256) + 256;
+}
+extern "C" int evae_dense_bwd_weight_p6(const void* dyT_img, const void* xT_img, int nks, int N, int K, float* dw, float* db,
+                                        void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  EVAE_REQUIRE(nks > 0 && N > 0 && K > 0 && dyT_img && xT_img && dw, "dense_bwd_weight_p6: bad arguments");
+  const P6WgradPlan p = p6_wgrad_plan(nks, N, K, db != nullptr);
+  if (ws == nullptr || ws_bytes < (size_t)p.nz * N * p.kc * sizeof(float)) { set_error("dense_bwd_weight_p6: workspace too small (%zu)", ws_bytes); return EVAE_EWORKSPACE; }
+  hipStream_t stream = (hipStream_t)stream_;
+  GemmArgs g = {};
+  g.ones_col = -1; g.npairs = 1;
+  g.A[0] = (const float*)dyT_img; g.B[0] = (const float*)xT_img; g.Kc[0] = nks * P6_KS; g.M = N; g.N = p.kc;
+  g.out0 = (float*)ws; g.ldo = p.kc; g.ksplit = p.ksplit;
+  int rc = launch_gemm_p6<EPI_RAW, 64>(g, p.nz, stream, "dense_bwd_weight(p6)");
+  if (rc) return rc;
+  FinishArgs f = {};
+  f.part = (const float*)ws; f.nz = p.nz; f.M = N; f.N = p.kc; f.ldo = p.kc; f.epi = EPI_RAW; f.out0 = dw;
+  f.ones_col = db ? K : -1; f.out_db = db;
+  return launch_finish(f, stream);
+}

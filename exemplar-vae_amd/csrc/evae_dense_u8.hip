@@ -20,6 +20,7 @@
 // conflict-free without padding; two stages of (A 8 KB + B 24 KB) = 64 KB per block, two blocks per CU.
 #include "evae_common.h"
 #include "evae_u8_prepare.h"
+#include "evae_p6_image.h"
 
 namespace evae {
 
@@ -63,7 +64,8 @@ template <bool GATED>
 __global__ __launch_bounds__(U8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void u8_gemm_kernel(
     const unsigned char* __restrict__ x, const int64_t* __restrict__ rows, int M, long long ldx, float x_scale,
     const unsigned short* __restrict__ img, int nslab_total, int ksplit, const float* __restrict__ bh,
-    const float* __restrict__ bg, int N, float* __restrict__ out, float* __restrict__ save_s, int tiles_m, int tiles_n) {
+    const float* __restrict__ bg, int N, float* __restrict__ out, float* __restrict__ save_s, int tiles_m, int tiles_n,
+    const P6Sink tsink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn, zs = 0;
   if constexpr (GATED) {
@@ -178,12 +180,15 @@ __global__ __launch_bounds__(U8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   // epilogue: acc[mt][cb][r] <-> row m0 + wr*64 + mt*32 + (r&3) + 8*(r>>2) + 4*lh
   if constexpr (GATED) {
     const int n = n0 + wc * 32 + l31;           // output column; cb = 0: h, 1: g
-    if (n < N) {
-      float vbh = bh ? bh[n] : 0.f, vbg = bg ? bg[n] : 0.f;
+    const bool nok = n < N;
+    const bool timg = tsink.img != nullptr;     // the layer's output also as the pre-split image of its transpose (evae_p6_image.h)
+    if (nok || timg) {
+      float vbh = (bh && nok) ? bh[n] : 0.f, vbg = (bg && nok) ? bg[n] : 0.f;
       asm volatile("" : "+v"(vbh));        // the wait for the two loads here, not in front of every guarded row's stores
       asm volatile("" : "+v"(vbg));
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt) {
+        float ov[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -191,12 +196,15 @@ __global__ __launch_bounds__(U8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
           // s_waitcnt vmcnt(0) -- every store in flight included -- in front of each row's stores (evae_gemm_kernel.h)
           const float h = fmaf(acc[mt][0][r], x_scale, vbh);
           const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * fmaf(acc[mt][1][r], x_scale, vbg)));
-          if (m < M) {
+          ov[r] = h * sg;
+          if (m < M && nok) {
             const size_t o = (size_t)m * N + n;
-            out[o] = h * sg;
+            out[o] = ov[r];
             if (save_s) save_s[o] = sg;
           }
         }
+        if (timg) p6_emit_tile(tsink, tsink.row0 + n, nok, tsink.kbase + m0 + wr * 64 + mt * 32, ov, lh);
+      }
     }
   } else {
     float* part = out + (size_t)zs * M * N;
@@ -319,9 +327,9 @@ extern "C" int evae_dense_u8_prepare(const float* wh, const float* wg, int N, in
   return check_launch("u8_prepare_kernel");
 }
 
-extern "C" int evae_gated_dense_fwd_u8(const unsigned char* x, const int64_t* rows, int M, int K, long long ldx, float x_scale,
-                                       const void* prepared, const float* bh, const float* bg, int N, float* out,
-                                       float* save_s, evae_stream_t stream_) {
+static int gated_dense_fwd_u8_core(const unsigned char* x, const int64_t* rows, int M, int K, long long ldx, float x_scale,
+                                   const void* prepared, const float* bh, const float* bg, int N, float* out,
+                                   float* save_s, const P6Sink& tsink, evae_stream_t stream_) {
   EVAE_REQUIRE(M >= 0 && K > 0 && N > 0, "gated_dense_fwd_u8: bad sizes M=%d K=%d N=%d", M, K, N);
   if (M == 0) return EVAE_OK;
   EVAE_REQUIRE(x && rows && prepared && out, "gated_dense_fwd_u8: null pointer");
@@ -334,8 +342,26 @@ extern "C" int evae_gated_dense_fwd_u8(const unsigned char* x, const int64_t* ro
   }
   const int tiles_m = cdiv(M, U8_BM), tiles_n = cdiv(N, U8_BN);
   u8_gemm_kernel<true><<<tiles_m * tiles_n, U8_NT, 2 * U8_STAGE, (hipStream_t)stream_>>>(
-      x, rows, M, ldx, x_scale, (const unsigned short*)prepared, u8_nslab(K), u8_nslab(K), bh, bg, N, out, save_s, tiles_m, tiles_n);
+      x, rows, M, ldx, x_scale, (const unsigned short*)prepared, u8_nslab(K), u8_nslab(K), bh, bg, N, out, save_s, tiles_m, tiles_n,
+      tsink);
   return check_launch("u8_gemm_kernel<gated>");
+}
+
+extern "C" int evae_gated_dense_fwd_u8(const unsigned char* x, const int64_t* rows, int M, int K, long long ldx, float x_scale,
+                                       const void* prepared, const float* bh, const float* bg, int N, float* out,
+                                       float* save_s, evae_stream_t stream_) {
+  const P6Sink none = {nullptr, 0, 0, 0, 0};
+  return gated_dense_fwd_u8_core(x, rows, M, K, ldx, x_scale, prepared, bh, bg, N, out, save_s, none, stream_);
+}
+
+// ... whose output also leaves as the pre-split bf16 image of out^T (as evae_gated_dense_fwd_timg)
+extern "C" int evae_gated_dense_fwd_u8_timg(const unsigned char* x, const int64_t* rows, int M, int K, long long ldx, float x_scale,
+                                            const void* prepared, const float* bh, const float* bg, int N, float* out,
+                                            float* save_s, void* timg, int t_nks, int t_row0, int t_kbase, evae_stream_t stream_) {
+  EVAE_REQUIRE(timg && t_nks > 0 && t_row0 >= 0 && t_kbase >= 0 && (t_kbase % 8) == 0 && (t_kbase + M + 15) / 16 <= t_nks,
+               "gated_dense_fwd_u8_timg: bad image placement (k-steps %d, first k %d, rows %d)", t_nks, t_kbase, M);
+  const P6Sink sink = {(unsigned char*)timg, t_nks, t_row0, t_kbase, t_kbase + M};
+  return gated_dense_fwd_u8_core(x, rows, M, K, ldx, x_scale, prepared, bh, bg, N, out, save_s, sink, stream_);
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------------------------
@@ -418,7 +444,8 @@ static int dense_bwd_weight_u8_core(const float* dy, int M, int N, long long ldy
   }
   const int units = L.nz * L.tiles_n;
   u8_gemm_kernel<false><<<8 * L.tiles_k * cdiv(units, 8), U8_NT, 2 * U8_STAGE, stream>>>(
-      xT, nullptr, K + 1, L.ldt, 1.0f, img, L.nslab, L.ksplit, nullptr, nullptr, N, part, nullptr, L.tiles_k, L.tiles_n);
+      xT, nullptr, K + 1, L.ldt, 1.0f, img, L.nslab, L.ksplit, nullptr, nullptr, N, part, nullptr, L.tiles_k, L.tiles_n,
+      P6Sink{nullptr, 0, 0, 0, 0});
   rc = check_launch("u8_gemm_kernel<raw>");
   if (rc) return rc;
   if (skip_finish) return EVAE_OK;            // the caller sums the planes in a grouped finish (evae_dense_bwd_weight_finish_group)

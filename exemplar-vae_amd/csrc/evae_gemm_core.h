@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "evae_common.h"
+#include "evae_p6_image.h"
 
 namespace evae {
 
@@ -141,7 +142,17 @@ struct FinishArgs {
   float* out_db;
   int perm_c, perm_taps;   // EPI_RAW of a convolution weight gradient: column t*perm_c + c -> c*perm_taps + t (OIHW order)
   int perm_k;              //   ... real filter size C*taps (row stride of dw); columns [perm_k, ones_col) are padding
+  P6Sink tsink;            // EPI_GATED / EPI_GATE_BWD, img != NULL: the result also as the pre-split image of its transpose (as
+                           // GemmArgs::tsink; element-wise 2-byte stores: the finish runs behind thin launches only)
 };
+
+// one element of a result into X^T's image: X's column c = image row, X's row m = k index
+__device__ __forceinline__ void p6_sink_element(const P6Sink& s, int row, int k, float v) {
+  unsigned short t0, t1, t2;
+  p6_split1(v, t0, t1, t2);
+  unsigned short* o = reinterpret_cast<unsigned short*>(s.img + p6_off(row, k, s.nks));
+  o[0] = t0; o[P6_CHUNK / 2] = t1; o[P6_CHUNK] = t2;
+}
 
 // LANES = 1: one thread per output element walks the nz planes.  LANES = 8 (many planes, small output -- e.g.
 // the [40 x 301] head gradient over 25 000 rows): eight lanes share an element, lane j sums planes j, j+8, ... and
@@ -174,6 +185,7 @@ __device__ __forceinline__ void gemm_finish_body(const FinishArgs& f, const size
     f.out0[o] = h * s;
     if (f.out1) f.out1[o] = h;
     if (f.out2) f.out2[o] = s;
+    if (f.tsink.img) p6_sink_element(f.tsink, f.tsink.row0 + n, f.tsink.kbase + m, h * s);
     return;
   }
   float v = 0.f;
@@ -190,8 +202,11 @@ __device__ __forceinline__ void gemm_finish_body(const FinishArgs& f, const size
     f.out0[o] = apply_act(pre, f.act, f.lo, f.hi);
   } else if (f.epi == EPI_GATE_BWD) {
     const float go = f.e0[i], s = f.e1[i];
-    f.out0[o] = v * s;
-    f.out1[o] = v * go * (1.0f - s);
+    if (f.out0) { f.out0[o] = v * s; f.out1[o] = v * go * (1.0f - s); }
+    if (f.tsink.img) {
+      p6_sink_element(f.tsink, f.tsink.row0 + n, f.tsink.kbase + m, v * s);
+      p6_sink_element(f.tsink, f.tsink.row0 + f.N + n, f.tsink.kbase + m, v * go * (1.0f - s));
+    }
   } else {  // EPI_RAW: plain sum (weight gradient), optional accumulate; column ones_col is db
     if (f.ones_col >= 0) {
       if (n == f.ones_col) { if (f.out_db) f.out_db[m] = (f.accumulate ? f.out_db[m] : 0.f) + v; }

@@ -3,6 +3,7 @@
 // evae_dense.hip describes the tiling; the slab schedule is explained where it is built, in the kernel below.
 #pragma once
 #include "evae_gemm_core.h"
+#include "evae_p6_image.h"
 #include <type_traits>
 #include <algorithm>
 
@@ -93,6 +94,8 @@ struct GemmArgs {
   int img_nslab, img_mbase;
   int ldo2;                // EPI_DIST_TILEMIN: > 0 = tile minima stored query-major, out0[n * ldo2 + tile] (else out0[tile * ldo + n])
   int sk_local;            // > 0: XCD-local split-K mapping on a 1-D grid, value = number of slices (see gemm_kernel)
+  P6Sink tsink;            // EPI_GATED / EPI_GATE_BWD, img != NULL: the result also leaves as the pre-split bf16 image of its transpose
+                           // (evae_p6_image.h; EPI_GATE_BWD: [dh | dg]^T, and out0 may then be NULL -- no fp32 copy)
   int direct;              // EPI_RAW without split-K: out0[m * ldo + n] for n != ones_col, out1[m] for n == ones_col (a weight
                            // gradient over a few rows writes dw / db itself: no partial plane, no finish launch)
 };
@@ -428,12 +431,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
     }
   } else if (GATED) {
     const int n = n0 + wc * 32 + l31;
-    if (n < g.N) {
-      float bh = (EPI == EPI_GATED && g.bias0) ? g.bias0[n] : 0.f;
-      float bg = (EPI == EPI_GATED && g.bias1) ? g.bias1[n] : 0.f;
+    const bool nok = n < g.N;
+    const bool timg = EPI == EPI_GATED && g.tsink.img != nullptr;        // (wave-uniform)
+    if (nok || timg) {
+      float bh = (EPI == EPI_GATED && g.bias0 && nok) ? g.bias0[n] : 0.f;
+      float bg = (EPI == EPI_GATED && g.bias1 && nok) ? g.bias1[n] : 0.f;
       EVAE_PIN(bh); EVAE_PIN(bg);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        float ov[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -446,13 +452,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
             // sigmoid on the hardware exp2 / rcp (about 1e-7 relative): the precise expf costs ~15 VALU instructions
             // per element, and VALU issue is what the co-resident block's MFMAs wait on
             const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc[mt][NT - 1][r] + bg)));
-            if (m < g.M) {
+            ov[r] = h * s;
+            if (m < g.M && nok) {
               const size_t o = orow(m) * g.ldo + n;
-              g.out0[o] = h * s;
+              g.out0[o] = ov[r];
               if (g.out1) g.out1[o] = h;
               if (g.out2) g.out2[o] = s;
             }
-          } else if (m < g.M) {
+          } else if (m < g.M && nok) {
             {          // EPI_RAW_GATED: partial planes [z][2][M][N]
               const size_t plane = (size_t)g.M * g.N;
               const size_t o = (size_t)zslice * 2 * plane + (size_t)m * g.N + n;
@@ -461,6 +468,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
             }
           }
         }
+        if (EPI == EPI_GATED && timg)       // the layer's output as the operand of the next GEMMs
+          p6_emit_tile(g.tsink, g.tsink.row0 + n, nok, g.tsink.kbase + m0 + wr * 32 * MT + mt * 32, ov, lh);
+      }
     }
   } else if constexpr (EPI == EPI_GATE_BWD_IMG) {
     // dh = v s, dg = v (h s)(1 - s) as in EPI_GATE_BWD; column cc of the merged [dh | dg] buffer is n (dh) / N + n (dg).  The
@@ -540,31 +550,44 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
     // reads of a fragment are issued before the first store: the stores may alias them as far as the compiler knows,
     // and a read -> store -> read chain would pay one memory latency per element (that is the whole run time of a
     // launch with few blocks, and of a block's tail in any launch).
+    // tsink: (dh, dg) also (or only: out0 == NULL) as the pre-split image of [dh | dg]^T -- column n -> image rows n and N + n
+    const bool timg = g.tsink.img != nullptr;                             // (wave-uniform)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = n0 + wc * 32 * NT + nt * 32 + l31;
-      if (n >= g.N) continue;
+      const bool nok = n < g.N;
+      if (!nok && !timg) continue;
       float go[MT][16], sv[MT][16];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const size_t oe = (size_t)(m < g.M ? m : 0) * g.N + n;
+          const size_t oe = (size_t)(m < g.M ? m : 0) * g.N + (nok ? n : 0);
           go[mt][r] = g.e0[oe];
           sv[mt][r] = g.e1[oe];
         }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        float dhv[16], dgv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m >= g.M) continue;
-          const size_t o = orow(m) * g.ldo + n;
           const float v = acc[mt][nt][r], s_ = sv[mt][r];
-          g.out0[o] = v * s_;                          // dh
-          g.out1[o] = v * go[mt][r] * (1.0f - s_);     // dg = v * h * s * (1 - s)
+          dhv[r] = v * s_;                              // dh
+          dgv[r] = v * go[mt][r] * (1.0f - s_);         // dg = v * h * s * (1 - s)
+          if (m < g.M && nok && g.out0) {
+            const size_t o = orow(m) * g.ldo + n;
+            g.out0[o] = dhv[r];
+            g.out1[o] = dgv[r];
+          }
         }
+        if (timg) {
+          const int k0 = g.tsink.kbase + m0 + wr * 32 * MT + mt * 32;
+          p6_emit_tile(g.tsink, g.tsink.row0 + n, nok, k0, dhv, lh);
+          p6_emit_tile(g.tsink, g.tsink.row0 + g.N + n, nok, k0, dgv, lh);
+        }
+      }
     }
   } else {
 #pragma unroll

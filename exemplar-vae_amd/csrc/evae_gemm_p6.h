@@ -1,0 +1,396 @@
+// fp32 GEMM on the bf16 matrix pipe over PRE-SPLIT operands ("p6"): the arithmetic of evae_gemm_x6.h -- every fp32 element as
+// three round-to-nearest bf16 terms a = a0 + a1 + a2, six of the nine partial products on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation, smallest terms first -- but the split is done ONCE, by whoever produces the operand (a layer's epilogue, the
+// step-head launch for the weights), and the GEMM's main loop is copies and MFMAs only: no VALU work per element
+// (gemm_x6_kernel re-splits both operands of every tile in every block: 6-8 VALU instructions per MFMA, matrix pipe 32-41 %
+// busy, VERDICT r03 "What's weak" 2).
+//
+// Operand format ("p6 image", evae_p6_image.h): an operand X [R rows x K contraction] as chunks of 16 rows x 16 k (512 bytes:
+// rows of 32 bytes whose two 16-byte halves are swapped on the odd group of eight rows), three planes each, ordered (row
+// group, k-step, plane).
+// A block stages a k-step of its 128-row tile as 24 chunks with 1 KB-per-wave LDS-DMA copies (buffer_load ... lds: lanes 0-31
+// one chunk, lanes 32-63 the chunk of the next row group): no register staging, no ds_write, addresses in SGPRs.  In LDS a
+// plane of a k-step is [128 rows][32 B]; the half swap makes the ds_read_b128 fragment reads (lane = row, half = lane >> 5)
+// conflict-free without padding.  Why chunks of 16 rows and not whole 128-row tiles: the SAME image is also read across its
+// rows (next paragraph) -- 16 rows x eight consecutive k-steps x 3 planes are then one contiguous 12 KB run -- and with
+// whole tiles that reader touched 512 bytes of every 4 KB, i.e. two of the sixteen L2 channels at a time for all blocks of
+// a launch (measured: 1.7-2.7 x slower per k-step, profiles/r04_micro/p6_bench_run3).  The row-wise reader's eight chunk
+// groups per plane sit nks * 1536 bytes apart: images whose k runs along batch rows get nks = 1 (mod 8) (p6_nks_rows) so that
+// the eight groups fall on all sixteen channels.
+//
+// One image per activation tensor.  A layer's epilogue holds its output in the matrix core's C layout -- a lane owns one
+// COLUMN and sixteen rows of a 32 x 32 tile -- so the image it can write with 16-byte stores (after one lane-pair exchange)
+// is the one whose rows are the tensor's columns and whose k runs along the batch rows: X^T.  That is the operand of the
+// weight gradient (contraction over the batch rows) as it stands.  The forward / data-gradient GEMMs, which contract over
+// the tensor's COLUMNS, read the same image through the LDS transpose read (TA = true below, ds_read_b64_tr_b16: a 16-lane
+// group reads a 4 k x 16 row block and every lane receives the four k of its row): no second, row-major image in HBM
+// (+6 bytes per element written and read), no transposing pass.
+//
+// Kernel: block = 256 threads = 4 waves (2 x 2), block tile 128 x 128 (gated: 128 rows x 64 outputs = [h | g] column pairs;
+// BN_ = 64: 128 x 64), wave tile 64 x 64 (64 x 32), two blocks per CU.  LDS = ring of three k-steps (24 KB each: 72 KB per
+// block); fragments double-buffered in registers.  Iteration i: wait for this wave's pieces of k-step i + 1 (issued two
+// iterations ago), barrier (every wave's pieces have landed; every wave has the fragments of k-step i in registers, so buffer
+// i % 3 is free), then 24 MFMAs on the fragments of k-step i with the copies of k-step i + 3 (into the freed buffer) and the
+// fragment reads of k-step i + 1 placed between them.  One barrier per 24 MFMAs per wave; LDS round trips and global latency
+// hide behind two iterations of MFMAs.  Measured (tools/micro/p6_bench.hip, profiles/r04_micro/): the main loop runs at ~75 %
+// of the matrix rate the chip sustains on random data; a 256-row tile (half the B traffic per MFMA) and three other
+// schedules were tried and are not faster -- what is left of a launch is its epilogue's HBM writes.
+// Same GemmArgs / tile map / epilogues (gemm_epilogue) as the fp32 and x6 kernels: A[0], B[0] = image bases, Kc[0] = K
+// (multiple of 16), ksplit = k-steps per blockIdx.z slice (0 = all); TA: lda[0] = k-steps (of 16 batch rows) of the A image.
+#pragma once
+#include "evae_gemm_kernel.h"
+
+namespace evae {
+
+typedef __bf16 p6_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 p6_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* p6_lds_t;
+typedef __attribute__((address_space(3))) p6_bf16x4* p6_lds4_t;
+
+constexpr int P6_NS = 3;                   // LDS ring depth
+constexpr int p6_stage_bytes(int bn) { return P6_TILE + 3 * bn * 32; }
+constexpr int p6_lds_bytes(int bn) { return P6_NS * p6_stage_bytes(bn); }     // 72 KB (128) / 54 KB (64)
+
+// The LDS transpose read as inline assembly: through the builtin (__builtin_amdgcn_ds_read_tr16_b64_v4bf16) the compiler
+// orders it behind every LDS-DMA copy in flight -- an s_waitcnt vmcnt(0) in front of each read, i.e. the copy pipeline drained
+// twelve times per k-step (measured: the forward GEMM 98 us instead of 58).  The kernel's own waits cover it: every fragment
+// is read one iteration before its use, behind the barrier that follows the wait for its k-step's copies, and is consumed
+// behind the next iteration's s_waitcnt lgkmcnt(0).
+typedef unsigned p6_u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ p6_u32x2 p6_tr_read(unsigned lds_addr) {
+  p6_u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+  return r;
+}
+
+// TA: the A operand is X^T's image (rows = X's columns = this GEMM's contraction, k = X's rows = this GEMM's output rows).
+//   A stage in LDS = [plane][m-step ms = 0..7 of the 128-row tile][k row c = 0..15, stored at c ^ 4 (ms & 1)][32 B = 16 m]:
+//   the 512 bytes of (plane, ms) are the chunk (row group k0 >> 4, k-step 8 tm + ms, plane) of the image; the 24 chunks of a
+//   k-step are contiguous in HBM.  A wave copies m-steps 2 w, 2 w + 1 of every plane (lanes 0-31 / 32-63 of one 1 KB piece);
+//   the row rotation of the odd m-step puts the two 16-lane groups of a transpose read (same k rows, neighbouring m-steps) on
+//   different halves of the 256-byte bank row.
+template <int EPI, int BN_, bool TA = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_p6_kernel(const GemmArgs g) {
+  constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
+  static_assert(BN_ == 128 || (BN_ == 64 && !GATED), "column tile: 128, or 64 for narrow plain outputs");
+  constexpr int NW = 4, MT = 2, NT = BN_ / 64;
+  constexpr int SB = p6_stage_bytes(BN_), BOFF = P6_TILE, BPL = BN_ * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const lds = reinterpret_cast<char*>(smem);
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int tile;
+  {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int qq = ntiles >> 3, rr = ntiles & 7;
+    tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM;
+  const int n0 = GATED ? tn * 64 : tn * BN_;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nks = g.Kc[0] / P6_KS;
+  int s_begin = 0, s_end = nks;
+  if (g.ksplit > 0) {
+    s_begin = blockIdx.z * g.ksplit;
+    const int e = s_begin + g.ksplit;
+    if (e < s_end) s_end = e;
+  }
+  const int nst = s_end - s_begin;
+
+  // this block's row tile of A and column tile of B: eight row groups each (BN_ = 64: four), per k-step 3 x 512 bytes per row
+  // group, the groups nks * 1536 bytes apart.  TA: row group = k-step of this GEMM, the image's k-steps 8 tm .. 8 tm + 7
+  const unsigned a_nms = TA ? (unsigned)g.lda[0] : 0u;                // k-steps of X^T's image
+  const unsigned grp = (unsigned)nks * P6_GROUP;                     // bytes between the row groups of an image with nks k-steps
+  const char* const abase = reinterpret_cast<const char*>(g.A[0]) + (TA ? (size_t)tm * 8 * P6_GROUP : (size_t)tm * 8 * grp);
+  const char* const bbase = reinterpret_cast<const char*>(g.B[0]) + (size_t)(GATED ? tn * 8 : tn * (BN_ / 16)) * grp;
+  const rsrc_t rA = make_rsrc(abase, 0x7FFFFFFFu);
+  const rsrc_t rB = make_rsrc(bbase, 0x7FFFFFFFu);
+  // lane -> (row group parity lh, 16 bytes l31 of the chunk)
+  const unsigned voff_a = TA ? 0u : (unsigned)lh * grp + (unsigned)l31 * 16u;
+  const unsigned voff_b = (unsigned)lh * grp + (unsigned)l31 * 16u;
+  // TA: lane -> (m-step parity lh, k row (l31 >> 1) [rotated by 4 on the odd m-step], 16-byte half l31 & 1) of its piece
+  const unsigned voff_ta = (unsigned)lh * P6_GROUP + (unsigned)((((l31 >> 1) ^ (4 * lh)) * 32) + (l31 & 1) * 16);
+
+  // the copies of k-step ks (absolute) into ring buffer b, piece q of this wave: q = 0..2 A plane q -- rows 32 w .. 32 w + 31 =
+  // row groups 2 w, 2 w + 1 (TA: m-steps 2 w, 2 w + 1); column tile 128: q = 3..5 the same rows of B plane q - 3; column tile 64:
+  // the six 1 KB pieces (plane, row-group pair) of B go to waves 0..3 (q = 3) and 0, 1 (q = 4)
+  constexpr int NPIECE = BN_ == 128 ? 6 : 5;
+  auto issue_piece = [&](int ks, int b, int q) {
+    const unsigned so = (unsigned)ks * (unsigned)P6_GROUP;
+    char* const st = lds + b * SB;
+    if (q < 3) {
+      if constexpr (TA) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (p6_lds_t)(st + q * P6_PLANE + wave * 1024), 16, voff_ta,
+                                                 (unsigned)ks * a_nms * (unsigned)P6_GROUP + wave * 2 * P6_GROUP + q * P6_CHUNK, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (p6_lds_t)(st + q * P6_PLANE + wave * 1024), 16, voff_a,
+                                                 so + (unsigned)(2 * wave) * grp + q * P6_CHUNK, 0, 0);
+      }
+    } else if constexpr (BN_ == 128) {
+      const int p = q - 3;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (p6_lds_t)(st + BOFF + p * BPL + wave * 1024), 16, voff_b,
+                                               so + (unsigned)(2 * wave) * grp + p * P6_CHUNK, 0, 0);
+    } else {
+      if (q == 3 || wave < 2) {
+        const int idx = q == 3 ? wave : wave + 4, p = idx >> 1, j = idx & 1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (p6_lds_t)(st + BOFF + p * BPL + j * 1024), 16, voff_b,
+                                                 so + (unsigned)(2 * j) * grp + p * P6_CHUNK, 0, 0);
+      }
+    }
+  };
+  auto issue = [&](int ks, int b) {
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) issue_piece(ks, b, q);
+  };
+  // wait until at most n k-steps' worth of this wave's copies are in flight (copies complete in order)
+  auto wait_steps = [&](auto n_) {
+    constexpr int n = decltype(n_)::value;
+    if constexpr (BN_ == 128) {
+      if constexpr (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if constexpr (n == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      if constexpr (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (wave < 2) {
+        if constexpr (n == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      } else {
+        if constexpr (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
+    }
+  };
+
+  // fragment addresses (bytes inside a stage) of this lane
+  unsigned fa[MT], fb[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if constexpr (TA) {
+      // 16-lane group (ib = m-step of the fragment's 32 rows, lh = k half); lane t of it addresses k row 8 lh + (t >> 2) [+ 4 for
+      // the second read], m chunk t & 3 (4 m = 8 bytes) of m-step wr * 4 + mt * 2 + ib
+      const int ib = (lane >> 4) & 1, t = lane & 15;
+      const int ms = wr * 4 + mt * 2 + ib;
+      const int c = 8 * lh + (t >> 2);
+      fa[mt] = (unsigned)(ms * 512 + ((c ^ (4 * ib)) * 32) + (((((t & 3) >> 1) ^ lh)) << 4) + (t & 1) * 8);
+    } else {
+      const int r = wr * 64 + mt * 32 + l31;
+      fa[mt] = (unsigned)(r * 32 + ((lh ^ ((r >> 3) & 1)) << 4));
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = wc * 32 * NT + nt * 32 + l31;
+    fb[nt] = (unsigned)(BOFF + c * 32 + ((lh ^ ((c >> 3) & 1)) << 4));
+  }
+
+  const unsigned lds_base = (unsigned)(uintptr_t)(p6_lds_t)lds;          // LDS byte address of the ring
+  p6_bf16x8 af[2][MT][3], bf[2][NT][3];
+  auto read_a = [&](auto par_, int b, int mt, int p) {
+    constexpr int par = decltype(par_)::value;
+    if constexpr (TA) {
+      // k rows c and c + 4 differ by 128 bytes (the rotation c ^ 4 ib flips bit 2 of both alike: XOR it into the offset)
+      const unsigned a0 = lds_base + (unsigned)(b * SB) + fa[mt], a1 = lds_base + (unsigned)(b * SB) + (fa[mt] ^ 128u);
+      p6_u32x2 lo, hi;
+      if (p == 0) { lo = p6_tr_read<0>(a0); hi = p6_tr_read<0>(a1); }
+      else if (p == 1) { lo = p6_tr_read<P6_PLANE>(a0); hi = p6_tr_read<P6_PLANE>(a1); }
+      else { lo = p6_tr_read<2 * P6_PLANE>(a0); hi = p6_tr_read<2 * P6_PLANE>(a1); }
+      typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+      const u32x4_ v = {lo[0], lo[1], hi[0], hi[1]};
+      af[par][mt][p] = __builtin_bit_cast(p6_bf16x8, v);
+    } else {
+      af[par][mt][p] = *reinterpret_cast<const p6_bf16x8*>(lds + b * SB + fa[mt] + p * P6_PLANE);
+    }
+  };
+  auto read_b = [&](auto par_, int b, int nt, int p) {
+    constexpr int par = decltype(par_)::value;
+    bf[par][nt][p] = *reinterpret_cast<const p6_bf16x8*>(lds + b * SB + fb[nt] + p * BPL);
+  };
+  auto read_all = [&](auto par_, int b) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) read_a(par_, b, mt, p);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) read_b(par_, b, nt, p);
+    }
+  };
+
+#define EVAE_P6_SB __builtin_amdgcn_sched_barrier(0)
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};       // smallest partial products first
+  constexpr int NMF = 6 * MT * NT;                                             // MFMAs per k-step per wave: 24 (12)
+  constexpr int NRD = 3 * (MT + NT);                                           // fragment reads per k-step per wave: 12 (9)
+  // one iteration; NEXT: k-step i + 1 exists (fragments are read), ISSUE: k-step i + 3 exists (copies are issued),
+  // INFL: k-steps in flight behind i + 1 when the iteration starts (0 or 1)
+  auto iter = [&](auto par_, auto next_, auto issue_, auto infl_, int i, int bcur) {
+    constexpr int par = decltype(par_)::value;
+    constexpr bool NEXT = decltype(next_)::value, ISSUE = decltype(issue_)::value;
+    constexpr std::integral_constant<int, par ^ 1> npar{};
+    if constexpr (NEXT) wait_steps(infl_);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int bnext = bcur == P6_NS - 1 ? 0 : bcur + 1;
+    EVAE_P6_SB;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int j = (t * MT + mt) * NT + nt;
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[par][mt][PA[t]], bf[par][nt][PB[t]], acc[mt][nt], 0, 0, 0);
+          EVAE_P6_SB;
+          if constexpr (NEXT) {
+            // one fragment read behind every second MFMA (every MFMA for the narrow tile)
+            constexpr int per = NMF / NRD >= 2 ? 2 : 1;
+            if (j % per == 0 && j / per < NRD) {
+              const int k = j / per, p = k / (MT + NT), q = k - p * (MT + NT);
+              if (q < MT) read_a(npar, bnext, q, p); else read_b(npar, bnext, q - MT, p);
+            }
+            EVAE_P6_SB;
+          }
+          if constexpr (ISSUE) {
+            constexpr int stride = NMF / 6;                      // a copy behind MFMA 1, 1 + stride, ...
+            if (j % stride == 1 && j / stride < NPIECE) issue_piece(s_begin + i + 3, bcur, j / stride);
+            EVAE_P6_SB;
+          }
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+#undef EVAE_P6_SB
+
+  constexpr std::integral_constant<int, 0> I0{};
+  constexpr std::integral_constant<int, 1> I1{};
+  constexpr std::integral_constant<int, 2> I2{};
+  constexpr std::true_type T{};
+  constexpr std::false_type F{};
+  if (nst > 0) {
+    issue(s_begin, 0);
+    if (nst > 1) issue(s_begin + 1, 1);
+    if (nst > 2) issue(s_begin + 2, 2);
+    if (nst > 2) wait_steps(I2); else if (nst > 1) wait_steps(I1); else wait_steps(I0);
+    __builtin_amdgcn_s_barrier();
+    read_all(I0, 0);
+    int i = 0, b = 0;
+    auto adv = [&]() { ++i; b = b == P6_NS - 1 ? 0 : b + 1; };
+    // steady state: k-steps i + 1, i + 2 in flight or landed, i + 3 issued
+    while (i + 4 < nst) {
+      iter(I0, T, T, I1, i, b); adv();
+      iter(I1, T, T, I1, i, b); adv();
+    }
+    // tail: at most four iterations (i is even here)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (i < nst) {
+        if (i + 3 < nst) iter(I0, T, T, I1, i, b);
+        else if (i + 2 < nst) iter(I0, T, F, I1, i, b);
+        else if (i + 1 < nst) iter(I0, T, F, I0, i, b);
+        else iter(I0, F, F, I0, i, b);
+        adv();
+      }
+      if (i < nst) {
+        if (i + 3 < nst) iter(I1, T, T, I1, i, b);
+        else if (i + 2 < nst) iter(I1, T, F, I1, i, b);
+        else if (i + 1 < nst) iter(I1, T, F, I0, i, b);
+        else iter(I1, F, F, I0, i, b);
+        adv();
+      }
+    }
+    __syncthreads();             // the epilogue may use the ring as scratch
+  }
+  if (g.dbg == 4) return;        // (tools: main loop only)
+  gemm_epilogue<EPI, BN_, NW, 0>(g, acc, m0, n0, tm, wr, wc, lane, smem, blockIdx.z);
+}
+
+// ---- image builders (weights in the step head; activations in tests and on fallback paths -- the layers' epilogues write
+// theirs themselves) ----------------------------------------------------------------------------------------------------------
+// X [R x K] fp32, K-contiguous (row stride ld) -> image(rows = R, k = K).  One thread per (image row, 8 k): a 16-byte slot per
+// plane; the grid covers the padded image (rows_img rows, whole k-steps), padding = zeros.
+// gated > 0: the row order of a gated layer's weight tiles -- image row (tn, c) with c = wc * 64 + hg * 32 + j holds weight row
+// tn * 64 + wc * 32 + j of bank hg (x = bank h, x2 = bank g; evae_gemm_x6.h's [wc][h | g][32] LDS rows).
+__device__ __forceinline__ void p6_pack_rows_element(size_t t, const float* __restrict__ x, const float* __restrict__ x2, int R, int K,
+                                                     long long ld, int gated, int rows_img, int nks, unsigned char* __restrict__ img) {
+  const int kslots = nks * 2;
+  if (t >= (size_t)rows_img * kslots) return;
+  const int ri = (int)(t / kslots), ks8 = (int)(t - (size_t)ri * kslots);
+  const int k0 = ks8 * 8;
+  int r = ri;
+  const float* src = x;
+  if (gated) {
+    const int tn = ri >> 7, c = ri & 127, wc = c >> 6, hg = (c >> 5) & 1, j = c & 31;
+    r = tn * 64 + wc * 32 + j;
+    src = hg ? x2 : x;
+  }
+  unsigned short p0[8], p1[8], p2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float v = (r < R && k0 + i < K) ? src[(size_t)r * ld + k0 + i] : 0.f;
+    p6_split1(v, p0[i], p1[i], p2[i]);
+  }
+  unsigned char* o = img + p6_off(ri, k0, nks);
+  *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(p0);
+  *reinterpret_cast<uint4*>(o + P6_CHUNK) = *reinterpret_cast<const uint4*>(p1);
+  *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = *reinterpret_cast<const uint4*>(p2);
+}
+__global__ __launch_bounds__(256) void p6_pack_rows_kernel(const float* __restrict__ x, const float* __restrict__ x2, int R, int K,
+                                                           long long ld, int gated, int rows_img, int nks, unsigned char* __restrict__ img) {
+  p6_pack_rows_element((size_t)blockIdx.x * blockDim.x + threadIdx.x, x, x2, R, K, ld, gated, rows_img, nks, img);
+}
+
+// X^T: X [Kd x R] fp32 with the CONTRACTION along its rows (row stride ld; rows Kd .. 2 Kd - 1 from x2 when given: the [h | g]
+// banks of a gated layer stacked along the contraction) -> image(rows = R, k).  ones_row >= 0: that image row is 1 for k < Kd_all
+// (the bias-gradient row of a weight gradient's x operand).  One thread per (image row, 8 k); consecutive threads = consecutive
+// image rows (coalesced along a row of X).
+__device__ __forceinline__ void p6_pack_cols_element(size_t t, const float* __restrict__ x, const float* __restrict__ x2, int Kd, int R,
+                                                     long long ld, int ones_row, int rows_img, int nks, unsigned char* __restrict__ img) {
+  if (t >= (size_t)rows_img * nks * 2) return;
+  const int ks8 = (int)(t / rows_img), r = (int)(t - (size_t)ks8 * rows_img);
+  const int k0 = ks8 * 8;
+  const int Kall = x2 ? 2 * Kd : Kd;
+  unsigned short p0[8], p1[8], p2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = k0 + i;
+    float v = 0.f;
+    if (r < R && k < Kall) v = k < Kd ? x[(size_t)k * ld + r] : x2[(size_t)(k - Kd) * ld + r];
+    if (r == ones_row && k < Kall) v = 1.f;
+    p6_split1(v, p0[i], p1[i], p2[i]);
+  }
+  unsigned char* o = img + p6_off(r, k0, nks);
+  *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(p0);
+  *reinterpret_cast<uint4*>(o + P6_CHUNK) = *reinterpret_cast<const uint4*>(p1);
+  *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = *reinterpret_cast<const uint4*>(p2);
+}
+__global__ __launch_bounds__(256) void p6_pack_cols_kernel(const float* __restrict__ x, const float* __restrict__ x2, int Kd, int R,
+                                                           long long ld, int ones_row, int rows_img, int nks, unsigned char* __restrict__ img) {
+  p6_pack_cols_element((size_t)blockIdx.x * blockDim.x + threadIdx.x, x, x2, Kd, R, ld, ones_row, rows_img, nks, img);
+}
+
+template <int EPI, int BN_ = 128, bool TA = false>
+static int launch_gemm_p6(GemmArgs& g, int nz, hipStream_t stream, const char* what) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_p6_kernel<EPI, BN_, TA>, hipFuncAttributeMaxDynamicSharedMemorySize, p6_lds_bytes(BN_));
+    attr_done = true;
+  }
+  constexpr bool GATED = (EPI == EPI_GATED || EPI == EPI_RAW_GATED);
+  g.tiles_m = cdiv(g.M, BM);
+  g.tiles_n = cdiv(g.N, GATED ? 64 : BN_);
+  dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
+  gemm_p6_kernel<EPI, BN_, TA><<<grid, 256, p6_lds_bytes(BN_), stream>>>(g);
+  return check_launch(what);
+}
+
+}  // namespace evae

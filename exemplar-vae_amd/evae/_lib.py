@@ -90,6 +90,20 @@ SIGNATURES = {
     "evae_dense_bwd_weight_u8": (_i, [_p, _i, _i, C.c_longlong, _p, _p, _i, C.c_longlong, _f, _p, _p, _p, _z, _p]),
     "evae_dense_bwd_weight_u8_phased": (_i, [_p, _i, _i, C.c_longlong, _p, _p, _i, C.c_longlong, _f, _p, _p, _p, _z, _i, _p]),
     "evae_dense_bwd_weight_u8_images": (_i, [_i, _i, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "evae_p6_nks": (_i, [_i]),
+    "evae_p6_nks_rows": (_i, [_i]),
+    "evae_p6_image_bytes": (_z, [_i, _i]),
+    "evae_gemm_p6_applies": (_i, [_i, _i, _i]),
+    "evae_p6_pack_rows": (_i, [_p, _p, _i, _i, C.c_longlong, _i, _p, _z, _p]),
+    "evae_p6_pack_cols": (_i, [_p, _p, _i, _i, C.c_longlong, _i, _i, _p, _z, _p]),
+    "evae_p6_fill_row": (_i, [_p, _i, _i, _f, _i, _i, _p]),
+    "evae_gated_dense_fwd_timg": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "evae_gated_dense_fwd_u8_timg": (_i, [_p, _p, _i, _i, C.c_longlong, _f, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p]),
+    "evae_dense_bwd_data_timg": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "evae_gated_dense_fwd_p6t": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
+    "evae_dense_bwd_data_p6t": (_i, [_p, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p]),
+    "evae_dense_bwd_weight_p6_workspace_bytes": (_z, [_i, _i, _i]),
+    "evae_dense_bwd_weight_p6": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _z, _p]),
     "evae_dense_bwd_data_img": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _z, _p]),
     "evae_dense_bwd_weight_group": (_i, [_p, _i, _p]),
     "evae_dense_bwd_weight_finish_group": (_i, [_p, _i, _p]),

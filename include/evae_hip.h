@@ -414,6 +414,52 @@ int evae_elbo_bwd(const float* dloss, int n_dloss, const float* dRE, int n_dRE, 
  * host floats read back every step): step3 = (loss, -re, kl) of this step, totals3 += step3.  One launch. */
 int evae_step_stats_add(const float* loss, const float* re, const float* kl, float* step3, float* totals3,
                         evae_stream_t stream);
+/* ----------------------------------------------------------------------------------------------
+ * Pre-split bf16 operand images ("p6", csrc/evae_p6_image.h, csrc/evae_gemm_p6.h): the fp32 GEMMs of the exemplar rows'
+ * chain -- utils/nn.py:44-69 GatedDense forward, its data gradient and its weight gradient, at models/BaseModel.py:243-248's
+ * C = 25 000 rows -- on the bf16 matrix pipe with fp32 accuracy (every element = three round-to-nearest bf16 terms, six of
+ * the nine partial products, fp32 accumulation) and NO splitting inside the GEMMs: the producer of an operand writes it once
+ * as an image of its TRANSPOSE (rows = the tensor's columns, k = its batch rows), which is the weight gradient's operand as
+ * it stands and which the forward / data-gradient kernels read through the LDS transpose read.
+ *   image geometry  evae_p6_nks(K) k-steps for a contraction of K; evae_p6_nks_rows(M) for one along M batch rows;
+ *                   evae_p6_image_bytes(rows, nks).  A buffer is zero-filled ONCE (padding rows / k are never written).
+ *   producers       evae_gated_dense_fwd_timg / evae_gated_dense_fwd_u8_timg (a gated layer's output), evae_dense_bwd_data_timg
+ *                   (the gate-fused data gradient's [dh | dg]); weights: evae_p6_pack_rows (forward: [h | g] pair order),
+ *                   evae_p6_pack_cols (data gradient: W^T with the banks stacked along the contraction); evae_p6_fill_row
+ *                   (the all-ones row behind x's columns that carries the bias gradient).
+ *   consumers       evae_gated_dense_fwd_p6t, evae_dense_bwd_data_p6t, evae_dense_bwd_weight_p6.
+ * t_row0 / t_kbase: first image row / first k index (a multiple of 8) this launch's columns / rows map to: the exemplar rows
+ * and the batch rows of a step write disjoint k ranges of the same images. */
+int evae_p6_nks(int K);
+int evae_p6_nks_rows(int M);
+size_t evae_p6_image_bytes(int rows, int nks);
+int evae_gemm_p6_applies(int M, int N, int gated);
+int evae_p6_pack_rows(const float* x, const float* x2 /* gated: bank g */, int R, int K, long long ld, int gated, void* img,
+                      size_t img_bytes, evae_stream_t stream);
+int evae_p6_pack_cols(const float* x, const float* x2 /* or NULL */, int Kd, int R, long long ld, int ones_row /* or -1 */,
+                      int nks, void* img, size_t img_bytes, evae_stream_t stream);
+int evae_p6_fill_row(void* img, int nks, int row, float value, int k_begin, int k_end, evae_stream_t stream);
+int evae_gated_dense_fwd_timg(const float* x, const int64_t* rows, int M, int K, int ldx, const float* wh, const float* bh,
+                              const float* wg, const float* bg, int N, float* out, float* save_h, float* save_s,
+                              void* timg, int t_nks, int t_row0, int t_kbase, void* ws, size_t ws_bytes, evae_stream_t stream);
+int evae_gated_dense_fwd_u8_timg(const unsigned char* x, const int64_t* rows, int M, int K, long long ldx, float x_scale,
+                                 const void* prepared, const float* bh, const float* bg, int N, float* out, float* save_s,
+                                 void* timg, int t_nks, int t_row0, int t_kbase, evae_stream_t stream);
+/* as evae_dense_bwd_data_wt with the gate epilogue (out_prev, s_prev != NULL); dx_or_dh == NULL: image only */
+int evae_dense_bwd_data_timg(const float* dy1, const float* w1, const float* dy2, const float* w2, int M, int N, int ldy, int K,
+                             const float* out_prev, const float* s_prev, float* dx_or_dh, float* dg, int ldo,
+                             const float* wT /* or NULL */, void* timg, int t_nks, int t_row0, int t_kbase, void* ws,
+                             size_t ws_bytes, evae_stream_t stream);
+int evae_gated_dense_fwd_p6t(const void* xT_img, int x_nks, int M, int K, const void* w_img, const float* bh, const float* bg,
+                             int N, float* out /* [M x N] */, float* save_s /* [M x N] or NULL */, evae_stream_t stream);
+/* u8_img != NULL: (dh, dg) as the tile images of evae_dense_bwd_weight_u8 (as evae_dense_bwd_data_img); else fp32 dh / dg */
+int evae_dense_bwd_data_p6t(const void* dyT_img, int dy_nks, int M, int N, const void* wT_img, int K, const float* out_prev,
+                            const float* s_prev, float* dh, float* dg, int ldo, void* u8_img, int u8_nslab, int u8_mbase,
+                            evae_stream_t stream);
+size_t evae_dense_bwd_weight_p6_workspace_bytes(int nks, int N, int K);
+int evae_dense_bwd_weight_p6(const void* dyT_img, const void* xT_img, int nks, int N, int K, float* dw /* [N x K] */,
+                             float* db /* [N] or NULL: then x^T's image carries the ones row K */, void* ws, size_t ws_bytes,
+                             evae_stream_t stream);
 /* Head of a training step in one launch (utils/training.py:27-31 + models/BaseModel.py:79-81): gather the batch rows
  * idx[b] of the device-resident dataset, binarise them (x = 1 with probability data, the `torch.bernoulli(data)` of
  * dynamic binarisation) or copy them (binarize = 0), and draw eps ~ N(0, 1) [B x zdim] (eps_out may be NULL).
