@@ -62,6 +62,12 @@ FINISH_GROUP = os.environ.get("EVAE_FINISH_GROUP", "0") == "1"
 GROUP_LEAVES = os.environ.get("EVAE_GROUP_LEAVES", "1") != "0"      # the batch rows' four leaf weight gradients as one launch
 IMG_DGRAD = os.environ.get("EVAE_IMG_DGRAD", "1") != "0" or bool(SCHED & 4)
 THIN_ROWS = 1024     # batch rows up to here take the fp32 split-K kernel for the first layer even on the byte store
+# byte store, exact prior, a machine-filling exemplar count: encoder layer 2's three GEMMs over pre-split bf16 operand images
+# (csrc/evae_gemm_p6.h) -- layer 1's output and the heads' (dh2, dg2) leave their producers' epilogues as the images of their
+# transposes, the weights are split once per step; no fp32 operand is re-split inside a GEMM.  EVAE_P6=0: the split-bf16 /
+# fp32 kernels of r03
+P6 = os.environ.get("EVAE_P6", "1") != "0"
+_P6_READY = {}     # image buffer pointer -> (shape key) it was zero-filled (and its ones row written) for
 
 PARAM_ORDER = [
     "prior_log_variance",
@@ -229,6 +235,23 @@ class VaeExactLoss(torch.autograd.Function):
         xmean = torch.empty((B, D), **f32)
         RE = torch.empty(B, **f32)
         offb = 4 * Cl                                    # byte offset of the batch rows, per float of row width
+        p6 = bool(u8 and P6 and IMG_DGRAD and not approx and Cl > 0 and Cl % 8 == 0 and B <= THIN_ROWS and not (SCHED & 10)
+                  and lib.evae_gemm_p6_applies(Cl, H, 1) and lib.evae_gemm_x6_applies(Cl, H, 0))
+        if p6:
+            # images: h1^T (+ the all-ones row behind its H rows: the bias gradient of layer 2), [dh2 | dg2]^T, both with k along
+            # all Cl + B rows; layer 2's weights in forward ([h | g] pairs) and data-gradient (W^T, banks stacked) form
+            nks_m = lib.evae_p6_nks_rows(Mp)
+            t_h1 = k.ws("p6_h1", lib.evae_p6_image_bytes(H + 1, nks_m))
+            t_dq2 = k.ws("p6_dq2", lib.evae_p6_image_bytes(2 * H, nks_m))
+            w2_img = k.ws("p6_w2", lib.evae_p6_image_bytes((H + 63) // 64 * 128, lib.evae_p6_nks(H)))
+            w2t_img = k.ws("p6_w2t", lib.evae_p6_image_bytes(H, lib.evae_p6_nks(2 * H)))
+            for t_, rows_ in ((t_h1, H + 1), (t_dq2, 2 * H)):
+                key_ = (t_.numel(), Mp, H)
+                if _P6_READY.get(t_.data_ptr()) != key_:     # padding rows / k are never written: zero once per buffer and shape
+                    t_.zero_()
+                    if rows_ == H + 1:
+                        _lib.check(lib.evae_p6_fill_row(_vp(t_), nks_m, H, 1.0, 0, Mp, k.st), "p6_fill_row")
+                    _P6_READY[t_.data_ptr()] = key_
         if u8:
             # both first-layer launches read the weights as three bf16 terms in tile order: split once, in front of the fork
             prep = k.ws("u8prep", lib.evae_dense_u8_prepared_bytes(H, D))
@@ -239,6 +262,13 @@ class VaeExactLoss(torch.autograd.Function):
 
             def l1_fwd(kk, rows_ptr, M, o):
                 fl = 2.0 * M * D * 2 * H
+                if p6:        # ... and the output as h1^T's image, rows o / 4 .. of its k range
+                    ops.probed("gated_dense_fwd_u8 M=%d K=%d N=%d (uint8 rows, three bf16 terms; output + its pre-split image)" % (M, D, H), fl,
+                               lambda: _lib.check(lib.evae_gated_dense_fwd_u8_timg(
+                                   _vp(data_ext), _vp(rows_ptr), M, D, ldd, 1.0 / 255.0, _vp(prep), _vp(b1h), _vp(b1g), H,
+                                   _vp(A1.data_ptr() + o * H), _vp(s1.data_ptr() + o * H), _vp(t_h1), nks_m, 0, o // 4, kk.st),
+                                   "gated_fwd_u8_timg"), executed=3 * fl, pipe="bf16-mfma")
+                    return
                 ops.probed("gated_dense_fwd_u8 M=%d K=%d N=%d (uint8 rows, three bf16 terms)" % (M, D, H), fl,
                            lambda: _lib.check(lib.evae_gated_dense_fwd_u8(_vp(data_ext), _vp(rows_ptr), M, D, ldd, 1.0 / 255.0, _vp(prep),
                                                                           _vp(b1h), _vp(b1g), H, _vp(A1.data_ptr() + o * H),
@@ -268,9 +298,22 @@ class VaeExactLoss(torch.autograd.Function):
             # (on the side stream, in front of everything: with the byte gather moved behind the batch-row chain the MAIN stream's
             # head GEMM is what the prior waits for, and this 5-us launch sat between the two)
             lv_row.copy_(plv.detach().expand(Z))
+            if p6:
+                # layer 2's weights as images (they change every step); the main stream meets them behind the first layer
+                _lib.check(lib.evae_p6_pack_rows(_vp(w2h), _vp(w2g), H, H, H, 1, _vp(w2_img), w2_img.numel(), kd.st), "p6_pack_rows")
+                _lib.check(lib.evae_p6_pack_cols(_vp(w2h), _vp(w2g), H, H, H, -1, lib.evae_p6_nks(2 * H), _vp(w2t_img), w2t_img.numel(),
+                                                 kd.st), "p6_pack_cols")
+                w2_ready = torch.cuda.Event(); w2_ready.record()
             if xt_early and not xt_late:
                 wq, xt_gen = xt_gather()
-            if u8 and B <= THIN_ROWS and not (SCHED & 32):
+            if p6:
+                # the batch rows' first layer on the fp32 split-K kernel, its finish also writing rows Cl .. of h1^T's image
+                nbf = lib.evae_dense_fwd_workspace_bytes(B, D, H, 1)
+                wf = kd.ws("fwd", nbf)
+                _lib.check(lib.evae_gated_dense_fwd_timg(_vp(x), None, B, D, x.stride(0), _vp(w1h), _vp(b1h), _vp(w1g), _vp(b1g), H,
+                                                         _vp(A1.data_ptr() + offb * H), None, _vp(s1.data_ptr() + offb * H), _vp(t_h1),
+                                                         nks_m, 0, Cl, _vp(wf), wf.numel(), kd.st), "gated_fwd_timg")
+            elif u8 and B <= THIN_ROWS and not (SCHED & 32):
                 # a thin launch of the byte kernel walks its 25 K-slabs on five blocks (29 us alone, 66 us beside the exemplar
                 # GEMM); the batch is here as fp32 too (x = byte / 255), and the fp32 kernel splits K over the machine
                 kd.gated_fwd(x, None, B, D, x.stride(0), w1h, b1h, w1g, b1g, H, A1.data_ptr() + offb * H, None,
@@ -315,7 +358,15 @@ class VaeExactLoss(torch.autograd.Function):
             sel_rows, ci_sel = ops.select_exemplars(nearest.view(-1), ex_idx, out_rows=rows[:Cl])     # straight into the gather list
             l1_fwd(k, rows, Cl, 0)
         if Cl > 0:
-            k.gated_fwd(A1, None, Cl, H, H, w2h, b2h, w2g, b2g, H, A2, None, s2)
+            if p6:
+                main.wait_event(w2_ready)
+                fl2 = 2.0 * Cl * H * 2 * H
+                ops.probed("gated_dense_fwd M=%d K=%d N=%d (pre-split bf16 images)" % (Cl, H, H), fl2,
+                           lambda: _lib.check(lib.evae_gated_dense_fwd_p6t(_vp(t_h1), nks_m, Cl, H, _vp(w2_img), _vp(b2h), _vp(b2g), H,
+                                                                           _vp(A2), _vp(s2), k.st), "gated_fwd_p6t"),
+                           executed=6 * fl2, pipe="bf16-mfma")
+            else:
+                k.gated_fwd(A1, None, Cl, H, H, w2h, b2h, w2g, b2g, H, A2, None, s2)
             k.linear_fwd(A2, Cl, H, H, wm, bm, Z, ACT_NONE, 0.0, 0.0, mean_all, None)
         if approx:
             approx_cache.index_copy_(0, sel_rows, centres)       # repeats of a row carry identical encodings
@@ -380,6 +431,7 @@ class VaeExactLoss(torch.autograd.Function):
         ctx.dp = (z_all, zi_all)
         ctx.stage_gen = gen
         ctx.xt = (wq.data_ptr(), xt_gen) if xt_early else None
+        ctx.p6 = (t_h1, t_dq2, w2t_img, nks_m) if p6 else None
         ctx.bufs = (x, rows, data_ext, A1, s1, A2, s2, mean_all, logvar, lv_pre, z, D1, sd1, D2, sd2,
                     xmean, lv_row, zi, ci, lse, eps)
         ctx.save_for_backward(*params)
@@ -453,6 +505,10 @@ class VaeExactLoss(torch.autograd.Function):
         # (only where the exemplar rows' data gradient fills the machine: a thin launch pays more for the un-split image
         # epilogue than the pre-pass it saves -- C = 200: 0.291 -> 0.301 ms)
         img_mode = (data_ext.dtype == torch.uint8 and Cl % 8 == 0 and IMG_DGRAD and bool(lib.evae_gemm_x6_applies(Cl, H, 0)))
+        p6 = ctx.p6 is not None
+        if p6:
+            t_h1, t_dq2, w2t_img, nks_m = ctx.p6
+            assert img_mode
         dq1 = None if img_mode else torch.empty((Mp, 2 * H), **f32)
         if img_mode:
             nb_w1 = lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D)
@@ -468,6 +524,16 @@ class VaeExactLoss(torch.autograd.Function):
                 _ZEROED["wgrad_u8"] = key
 
             def l2_dgrad(kk, M, ob, m_base):
+                if p6 and kk is k:
+                    # the exemplar rows: [dh2 | dg2]^T's image x W2^T's image on the bf16 pipe, (dh1, dg1) as the byte layer's images
+                    fl_ = 2.0 * M * 2 * H * H
+                    ops.probed("dense_bwd_data M=%d N=%d+%d K=%d (pre-split bf16 images; gate-backward epilogue -> bf16 tile images)"
+                               % (M, H, H, H), fl_,
+                               lambda: _lib.check(lib.evae_dense_bwd_data_p6t(_vp(t_dq2), nks_m, M, 2 * H, _vp(w2t_img), H,
+                                                                              _vp(A1.data_ptr() + ob * H), _vp(s1.data_ptr() + ob * H),
+                                                                              None, None, 0, _vp(img_ptr), nslab_img.value, m_base, kk.st),
+                                                  "bwd_data_p6t"), executed=6 * fl_, pipe="bf16-mfma")
+                    return
                 nbd = lib.evae_dense_bwd_data_workspace_bytes(M, H, H, 2)
                 wd = kk.ws("dgrad", nbd)
                 wT = None if (ctx.wt is None or kk is not k) else ctx.wt[1]
@@ -533,8 +599,20 @@ class VaeExactLoss(torch.autograd.Function):
                 prior_finish = lambda: _lib.check(lib.evae_prior_lse_bwd_phased(*pb_args, 2, kd.st), "prior_bwd(2)")
         dz_ready = torch.cuda.Event(); dz_ready.record()
         if Cl > 0:
-            k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H,
-                       wT=None if ctx.wt is None else ctx.wt[0])
+            if p6:
+                # (dh2, dg2) of the exemplar rows leave as [dh2 | dg2]^T's image only: their two consumers read images
+                nbh = lib.evae_dense_bwd_data_workspace_bytes(Cl, Z, H, 1)
+                wh_ = k.ws("dgrad", nbh)
+                flh = 2.0 * Cl * Z * H
+                exh, pih = ops.gemm_pipe(Cl, H, False, flh)
+                ops.probed("dense_bwd_data M=%d N=%d K=%d (gate-backward epilogue -> pre-split image)" % (Cl, Z, H), flh,
+                           lambda: _lib.check(lib.evae_dense_bwd_data_timg(_vp(dmean_all), _vp(wm), None, None, Cl, Z, Z, H, _vp(A2), _vp(s2),
+                                                                           None, None, 2 * H, _vp(None if ctx.wt is None else ctx.wt[0]),
+                                                                           _vp(t_dq2), nks_m, 0, 0, _vp(wh_), wh_.numel(), k.st),
+                                              "bwd_data_timg"), executed=exh, pipe=pih)
+            else:
+                k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H,
+                           wT=None if ctx.wt is None else ctx.wt[0])
             l2_dgrad(k, Cl, 0, 0)
         batch_rows_done = torch.cuda.Event()
         g_plv = gslot("plv", 1)
@@ -556,8 +634,17 @@ class VaeExactLoss(torch.autograd.Function):
                                                           _vp(lv_pre), -6.0, 2.0, B, Z, _vp(dmean_all.data_ptr() + off * Z),
                                                           _vp(dlvp), kd.st), "reparam_bwd")
             # head and encoder layer 2, batch rows
-            kd.bwd_data(dmean_all.data_ptr() + off * Z, wm, dlvp, wl, B, Z, Z, H, A2.data_ptr() + off * H,
-                        s2.data_ptr() + off * H, dq2.data_ptr() + off * 2 * H, dq2.data_ptr() + off * 2 * H + 4 * H, 2 * H)
+            if p6:
+                # (fp32 rows for the batch rows' own layer-2 data gradient, and rows Cl .. of the image for the weight gradient)
+                nbh = lib.evae_dense_bwd_data_workspace_bytes(B, Z, H, 2)
+                wh2 = kd.ws("dgrad", nbh)
+                _lib.check(lib.evae_dense_bwd_data_timg(_vp(dmean_all.data_ptr() + off * Z), _vp(wm), _vp(dlvp), _vp(wl), B, Z, Z, H,
+                                                        _vp(A2.data_ptr() + off * H), _vp(s2.data_ptr() + off * H),
+                                                        _vp(dq2.data_ptr() + off * 2 * H), _vp(dq2.data_ptr() + off * 2 * H + 4 * H), 2 * H,
+                                                        None, _vp(t_dq2), nks_m, 0, Cl, _vp(wh2), wh2.numel(), kd.st), "bwd_data_timg(batch)")
+            else:
+                kd.bwd_data(dmean_all.data_ptr() + off * Z, wm, dlvp, wl, B, Z, Z, H, A2.data_ptr() + off * H,
+                            s2.data_ptr() + off * H, dq2.data_ptr() + off * 2 * H, dq2.data_ptr() + off * 2 * H + 4 * H, 2 * H)
             dq2_rows_done = torch.cuda.Event(); dq2_rows_done.record()      # all layer 2's weight gradient needs of the batch rows
             l2_dgrad(kd, B, off, Cl)
             batch_rows_done.record()
@@ -565,7 +652,7 @@ class VaeExactLoss(torch.autograd.Function):
         g_wm = gslot("wm", Z, H); g_bm = gslot("bm", Z)
         # ONE finish launch for the three split-K weight gradients of the step (encoder layer 1 on the byte store, layer 2, mean
         # head) at the very end, instead of one behind each GEMM: a dependent launch less on the main stream's chain
-        fin_group = FINISH_GROUP and data_ext.dtype == torch.uint8 and not (SCHED & 10) and Mp > 128
+        fin_group = FINISH_GROUP and data_ext.dtype == torch.uint8 and not (SCHED & 10) and Mp > 128 and not p6
 
         def leaves():     # nobody waits for them before the optimizer
             with torch.cuda.stream(side):
@@ -666,6 +753,17 @@ class VaeExactLoss(torch.autograd.Function):
                 arr[i_].x_scale = xs_; arr[i_].dw = dw_.data_ptr(); arr[i_].db = db_.data_ptr()
                 arr[i_].ws = ws_.data_ptr(); arr[i_].ws_bytes = ws_.numel()
             _lib.check(lib.evae_dense_bwd_weight_finish_group(C.cast(arr, C.c_void_p), len(fjobs), k.st), "bwd_weight_finish_group")
+        elif p6:
+            # layer 2's weight gradient (+ bias gradient through h1^T's ones row) from the two images, on the bf16 pipe
+            nbw = lib.evae_dense_bwd_weight_p6_workspace_bytes(nks_m, 2 * H, H)
+            ww = k.ws("wgrad_p6", nbw)
+            flw = 2.0 * Mp * 2 * H * H
+            ops.probed("dense_bwd_weight M=%d N=%d K=%d (+db; pre-split bf16 images, split-K GEMM + finish)" % (Mp, 2 * H, H), flw,
+                       lambda: _lib.check(lib.evae_dense_bwd_weight_p6(_vp(t_dq2), _vp(t_h1), nks_m, 2 * H, H, _vp(g_w2), _vp(g_b2), _vp(ww),
+                                                                       ww.numel(), k.st), "bwd_weight_p6"), executed=6 * flw, pipe="bf16-mfma")
+            if split_wait:
+                main.wait_event(batch_rows_done)
+            w1_grad()
         else:
             k.bwd_weight(*w2_args)
             if split_wait:
