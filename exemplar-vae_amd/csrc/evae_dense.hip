@@ -611,8 +611,13 @@ static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const f
     return launch_gemm<false, false, EPI_RAW>(g, p1, stream, "dense_bwd_weight(direct)");
   }
   // a narrow output over many rows: the streaming reduction above instead of a GEMM with one mostly empty row tile
-  const bool narrow = !x6 && rows == nullptr && narrow_wgrad_shape(M, N, K) && ldy % 4 == 0 && ldx % 4 == 0 &&
-                      ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0);
+  const bool aligned = ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0);
+  // (a phased call's second half -- and the grouped finish, which re-derives the plan from the workspace pointer -- must arrive
+  // at the SAME plane count and layout as the first: the pointer-alignment term may not differ between them, so a phased
+  // narrow-shaped call with unaligned operands is refused instead of summed wrongly later)
+  EVAE_REQUIRE(phase == 0 || x6 || rows != nullptr || !narrow_wgrad_shape(M, N, K) || ldy % 4 || ldx % 4 || aligned,
+               "dense_bwd_weight_phased: operands of a narrow weight gradient must be 16-byte aligned");
+  const bool narrow = !x6 && rows == nullptr && narrow_wgrad_shape(M, N, K) && ldy % 4 == 0 && ldx % 4 == 0 && aligned;
   const int nslice = narrow ? narrow_wgrad_slices(M, K) : 0;
   if (narrow && phase != 2) {
     const int rps = cdiv(M, nslice);

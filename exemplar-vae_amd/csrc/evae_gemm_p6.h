@@ -34,8 +34,8 @@
 // fragment reads of k-step i + 1 placed between them.  One barrier per 24 MFMAs per wave; LDS round trips and global latency
 // hide behind two iterations of MFMAs.  Measured (tools/micro/p6_bench.hip, profiles/r04_micro/): the main loop runs at ~75 %
 // of the matrix rate the chip sustains on random data; a 256-row tile (half the B traffic per MFMA) and three other
-// schedules were tried and are not faster, nor is starting every other round of blocks late so that the two blocks of a CU
-// run out of phase (run 6) -- what is left of a launch is its epilogue's HBM writes.
+// schedules were tried and are not faster, nor is starting every other round of blocks -- or the block in the odd wave slot of a CU -- late so that the two blocks of a
+// CU run out of phase (run 6) -- what is left of a launch is its epilogue's HBM writes.
 // Same GemmArgs / tile map / epilogues (gemm_epilogue) as the fp32 and x6 kernels: A[0], B[0] = image bases, Kc[0] = K
 // (multiple of 16), ksplit = k-steps per blockIdx.z slice (0 = all); TA: lda[0] = k-steps (of 16 batch rows) of the A image.
 #pragma once

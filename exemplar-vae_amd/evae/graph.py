@@ -301,7 +301,14 @@ class GraphedTrainStep:
                     self._calls += 1
                     return out
                 if self.failed:
-                    self._body(eager_opt=self.eager_opt)   # capture was refused once: keep stepping eagerly
+                    # capture was refused: keep stepping eagerly.  A refusal on the very first call (_refresh: images the byte
+                    # store cannot hold) comes before the participants of the captured optimizer form are known and before
+                    # advance_graph_step ever ran (the control block's step sizes are still 0): that call steps the reference's
+                    # way and learns the members, as a warm-up call would
+                    first = self._calls == 0
+                    self._body(eager_opt=self.eager_opt or first)
+                    if first and not self.eager_opt and not self.opt.learn_members(self._adam_tables):
+                        self.eager_opt = True
                     self._calls += 1
                     return self.out
                 torch.cuda.synchronize()
@@ -335,6 +342,8 @@ class GraphedTrainStep:
                 # capture does not execute: replay once for this call's step
             self.graph.replay()
             self._calls += 1
+            if shard.is_active() and self._calls % shard.REPLICA_CHECK_EVERY == 0:
+                shard.check_replicas(self.model.parameters())      # (replica mode's guard: raises when the ranks drifted apart)
             return self.out
         finally:
             self.model._exemplar_indices_override = None

@@ -130,10 +130,6 @@ def gather_topk(val, idx, group=None):
 
 def sharded_topk(q, cache_local, k, index_base, sqrt=False, group=None):
     """Exact global top-k over a row-sharded cache: local top-k, one all-gather, merge kernel."""
-    if "topk" in KERNELS:                            # (tests: the oracle standing in for the two device kernels)
-        idx, val = KERNELS["topk"](q, cache_local, k, sqrt, index_base)
-        v, i = gather_topk(val, idx, group)
-        return KERNELS["topk_merge"](v, i)
     if cache_local.shape[0] >= k:
         idx, val = ops.pairdist_topk(q, cache_local, k, sqrt=sqrt, index_base=index_base)
     else:                                            # shard smaller than k (or empty): pad with empties
@@ -149,19 +145,14 @@ def sharded_topk(q, cache_local, k, index_base, sqrt=False, group=None):
     return ops.topk_merge(v, i)
 
 
-# the three device kernels behind ShardedPriorLogP; tests/test_shard_gloo.py swaps in the oracle's to run the collective
-# logic (uneven and empty shards, four ranks) on CPU tensors over gloo
-KERNELS = {"fwd": lambda *a: ops.prior_lse_fwd(*a), "merge": lambda *a: ops.prior_merge(*a), "bwd": lambda *a: ops.prior_lse_bwd(*a)}
-
-
 class ShardedPriorLogP(torch.autograd.Function):
     """log p(z_i) under the exemplar mixture whose exemplars are sharded over the ranks of `group`."""
 
     @staticmethod
     def forward(ctx, z, centres_local, log_var_row, z_idx, c_idx_local, c_total, group=None):
-        m, s, n, _ = KERNELS["fwd"](z, centres_local, log_var_row, z_idx, c_idx_local)
+        m, s, n, _ = ops.prior_lse_fwd(z, centres_local, log_var_row, z_idx, c_idx_local)
         gm, gs, gn = gather_partials(m, s, n, group)
-        lp, lse = KERNELS["merge"](gm, gs, gn, c_total)
+        lp, lse = ops.prior_merge(gm, gs, gn, c_total)
         ctx.save_for_backward(z, centres_local, log_var_row, lse)
         ctx.misc = (z_idx, c_idx_local, group)
         return lp
@@ -170,7 +161,7 @@ class ShardedPriorLogP(torch.autograd.Function):
     def backward(ctx, g):
         z, centres_local, log_var_row, lse = ctx.saved_tensors
         z_idx, c_idx_local, group = ctx.misc
-        dz, dc, dlv = KERNELS["bwd"](z, centres_local, log_var_row, z_idx, c_idx_local, lse, g.contiguous())
+        dz, dc, dlv = ops.prior_lse_bwd(z, centres_local, log_var_row, z_idx, c_idx_local, lse, g.contiguous())
         packed = torch.cat((dz.reshape(-1), dlv.reshape(-1)))
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)          # one 16 KB collective
         dz = packed[:dz.numel()].reshape(dz.shape)
@@ -216,3 +207,34 @@ def allreduce_grads(params, group=None):
         n = g.numel()
         g.copy_(flat[off:off + n].view_as(g))
         off += n
+
+
+# ---- replica guard -------------------------------------------------------------------------------------------------------------
+# With the batch replicated, allreduce_grads reduces only the encoder's slice of the gradient buffer: every other parameter is
+# ASSUMED to receive the same bits on every rank (identical inputs, deterministic kernels, identical devices and seeds).  Nothing
+# in a step would notice if that ever stopped being true -- the replicas' decoders and Adam moments would drift apart silently
+# (ADVICE r03).  check_replicas is the run-time guard: a two-float fingerprint (sum and sum of squares, fp64) of the given
+# parameters, MAX- and MIN-reduced in one small collective; any difference raises.  Called every REPLICA_CHECK_EVERY steps by
+# the captured-step runner and the eager training loop (outside any capture: it reads back).
+REPLICA_CHECK_EVERY = 64
+
+
+def check_replicas(params, group=None, what="parameters"):
+    if not is_active():
+        return True
+    ps = [p.detach() for p in params if p is not None]
+    if not ps:
+        return True
+    f = torch.zeros(2, dtype=torch.float64, device=ps[0].device)
+    for p in ps:
+        d = p.double()
+        f[0] += d.sum()
+        f[1] += (d * d).sum()
+    both = torch.cat((f, -f))
+    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)       # max(f) and -min(f) in one collective
+    hi, lo = both[:2], -both[2:]
+    if not bool(torch.equal(hi, lo)):
+        raise RuntimeError("evae.shard: the replicas' %s differ between ranks (fingerprint range %s .. %s): replica mode needs "
+                           "identical seeds, devices and deterministic kernels -- set EVAE_REDUCE_ALL=1 to all-reduce every "
+                           "gradient instead" % (what, lo.tolist(), hi.tolist()))
+    return True

@@ -5,7 +5,7 @@ epoch instead of three .item() syncs per step (training.py:42-44), and the exemp
 HBM (the model keeps a device-resident copy of dataset.tensors[0])."""
 import torch
 
-from evae import hostcpu
+from evae import hostcpu, shard
 from evae.graph import GraphedTrainStep
 
 
@@ -31,7 +31,11 @@ def train_one_epoch(epoch, args, train_loader, model, optimizer):
         graphed.reset_totals()
         if cache is not None:
             cache = graphed.set_cache(cache)      # the captured launches refresh the cache in place, in static buffers
+    nstep = 0
     for data, indices, target in train_loader:
+        nstep += 1
+        if graphed is None and model._sharded() and nstep % shard.REPLICA_CHECK_EVERY == 0:
+            shard.check_replicas(model.parameters())      # replica mode's run-time guard (evae/shard.py)
         if graphed is not None and len(data) == graphed.B:
             graphed(data, indices, beta)     # one hipGraph launch per step; sums accumulate in graphed.totals
             continue

@@ -63,7 +63,10 @@ def _worker(rank, world, port, q):
             allv = v.permute(1, 0, 2).reshape(B, -1).numpy(); alli = i.permute(1, 0, 2).reshape(B, -1).numpy()
             order = np.lexsort((alli, allv), axis=1)[:, :k]
             return T(np.take_along_axis(alli, order, axis=1)), T(np.take_along_axis(allv, order, axis=1))
-        shard.KERNELS.update(fwd=fwd, merge=merge, topk=topk, topk_merge=topk_merge)
+        # the test seam lives HERE, not in the product: the device-kernel wrappers of evae.ops are replaced in this worker process
+        ops.prior_lse_fwd, ops.prior_merge = fwd, merge
+        ops.pairdist_topk = lambda qq, cache, k, sqrt=False, index_base=0, **kw: topk(qq, cache, k, sqrt, index_base)
+        ops.topk_merge = topk_merge
 
         class FullPrior:          # stands in for ops.PriorLogP (the un-sharded device kernel)
             @staticmethod
