@@ -639,6 +639,31 @@ extern "C" int evae_step_stats_add(const float* loss, const float* re, const flo
   return check_launch("step_stats_add");
 }
 
+// The two scalar <-> row moves of the exemplar prior's one log-variance (models/BaseModel.py:25-26 prior_log_variance [1],
+// :101 `center_log_variance[0, :]`): the row the prior kernels read = the value repeated zdim times, and the value's gradient =
+// the sum of the row's.  One wave each (they used to be an ATen copy and an ATen reduction inside the captured step).
+__global__ void broadcast_scalar_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+  const float v = src[0];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = v;
+}
+__global__ void sum_small_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += x[i];          // fixed order per lane, fixed butterfly: deterministic
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[0] = s;
+}
+extern "C" int evae_broadcast_scalar(const float* src, float* dst, int n, evae_stream_t s) {
+  EVAE_REQUIRE(src && dst && n >= 0, "broadcast_scalar: bad arguments");
+  if (n == 0) return EVAE_OK;
+  broadcast_scalar_kernel<<<1, 64, 0, (hipStream_t)s>>>(src, dst, n);
+  return check_launch("broadcast_scalar_kernel");
+}
+extern "C" int evae_sum_small(const float* x, int n, float* out, evae_stream_t s) {
+  EVAE_REQUIRE(x && out && n >= 0, "sum_small: bad arguments");
+  sum_small_kernel<<<1, 64, 0, (hipStream_t)s>>>(x, n, out);
+  return check_launch("sum_small_kernel");
+}
+
 extern "C" int evae_elbo_bwd(const float* dloss, int n_dloss, const float* dRE, int n_dRE, const float* dKL,
                              int n_dKL, const float* beta_dev, float beta_host, int B, float* cRE, float* cKL,
                              float* neg_cKL, evae_stream_t s) {

@@ -149,7 +149,9 @@ class _K:
         nb = self.lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
         w = ops._workspace(ws_name + self.sfx, nb, self.dev)
         if phase == 0:
+            # (a narrow output over many rows -- the heads' [40 x 300] over all C + B rows -- streams its operands once: an HBM entry)
             ops.probed("dense_bwd_weight M=%d N=%d K=%d (+db, split-K GEMM + finish)" % (M, N, K), 2.0 * M * N * K,
+                       hbm_bytes=(4.0 * M * (N + K)) if (N <= 64 and M >= 2048 and rows is None) else None, fn=
                        lambda: _lib.check(self.lib.evae_dense_bwd_weight(_vp(dy), M, N, ldy, _vp(x), _vp(rows), K, ldx, _vp(dw),
                                                                          _vp(db), 0, _vp(w), w.numel(), self.st), "bwd_weight"))
         else:
@@ -297,7 +299,7 @@ class VaeExactLoss(torch.autograd.Function):
         with torch.cuda.stream(side):
             # (on the side stream, in front of everything: with the byte gather moved behind the batch-row chain the MAIN stream's
             # head GEMM is what the prior waits for, and this 5-us launch sat between the two)
-            lv_row.copy_(plv.detach().expand(Z))
+            _lib.check(lib.evae_broadcast_scalar(_vp(plv.detach()), _vp(lv_row), Z, kd.st), "broadcast_scalar")
             if p6:
                 # layer 2's weights as images (they change every step); the main stream meets them behind the first layer
                 _lib.check(lib.evae_p6_pack_rows(_vp(w2h), _vp(w2g), H, H, H, 1, _vp(w2_img), w2_img.numel(), kd.st), "p6_pack_rows")
@@ -605,11 +607,13 @@ class VaeExactLoss(torch.autograd.Function):
                 wh_ = k.ws("dgrad", nbh)
                 flh = 2.0 * Cl * Z * H
                 exh, pih = ops.gemm_pipe(Cl, H, False, flh)
+                # a K = 40 product with a [Cl x 2H] output: it streams -- reads dmean, A2 and s2, writes 6 bytes per element of [dh | dg]
                 ops.probed("dense_bwd_data M=%d N=%d K=%d (gate-backward epilogue -> pre-split image)" % (Cl, Z, H), flh,
+                           hbm_bytes=4.0 * Cl * (Z + 2 * H) + 6.0 * Cl * 2 * H, fn=
                            lambda: _lib.check(lib.evae_dense_bwd_data_timg(_vp(dmean_all), _vp(wm), None, None, Cl, Z, Z, H, _vp(A2), _vp(s2),
                                                                            None, None, 2 * H, _vp(None if ctx.wt is None else ctx.wt[0]),
                                                                            _vp(t_dq2), nks_m, 0, 0, _vp(wh_), wh_.numel(), k.st),
-                                              "bwd_data_timg"), executed=exh, pipe=pih)
+                                              "bwd_data_timg"))
             else:
                 k.bwd_data(dmean_all, wm, None, None, Cl, Z, Z, H, A2, s2, dq2, dq2.data_ptr() + 4 * H, 2 * H,
                            wT=None if ctx.wt is None else ctx.wt[0])
@@ -677,7 +681,7 @@ class VaeExactLoss(torch.autograd.Function):
                 else:
                     for dy_, m_, n_, ldy_, x_, k_, ldx_, dw_, db_ in jobs:
                         kd.bwd_weight(dy_, m_, n_, ldy_, x_, None, k_, ldx_, dw_, db_)
-                torch.sum(dlv, dim=0, keepdim=True, out=g_plv)
+                _lib.check(lib.evae_sum_small(_vp(dlv), Z, _vp(g_plv), kd.st), "sum_small")
         leaves()      # (issued HERE: captured after the main stream's weight gradients instead, the same launches replay at
         #                0.82-0.94 ms for C = 200 and 1.2 ms at c2 -- this runtime's graph replay is very sensitive to where a
         #                branch's nodes sit relative to the other branch's, r03 measurement)

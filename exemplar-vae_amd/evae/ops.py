@@ -17,12 +17,15 @@ _ws_retired = []   # replaced buffers stay allocated: a captured hipGraph (evae/
 PROBE = None   # bench.py sets {"records": []}: (name, start event, end event, algorithmic flops, executed flops, pipe) per big launch
 
 
-def probed(name, flops, fn, executed=None, pipe="fp32-mfma", min_flops=2e9):
+def probed(name, flops, fn, executed=None, pipe="fp32-mfma", min_flops=2e9, hbm_bytes=None):
     """Run fn(); while bench.py's roofline probe is on, bracket it with a HIP event pair on the current stream (launches
     below min_flops are not worth an event pair).  `executed`: flops issued to the matrix pipe when they differ from the
-    algorithmic count (three bf16 terms per product on the uint8 path)."""
-    if PROBE is None or flops < PROBE.get("min_flops", min_flops):
+    algorithmic count (three bf16 terms per product on the uint8 path).  hbm_bytes (pipe="hbm"): the ALGORITHMIC bytes of a
+    streaming launch -- what it must read and write once -- recorded in place of the flop counts (>= 16 MB to be worth a pair)."""
+    if PROBE is None or (flops < PROBE.get("min_flops", min_flops) if hbm_bytes is None else hbm_bytes < 16e6):
         return fn()
+    if hbm_bytes is not None:
+        flops, executed, pipe = hbm_bytes, hbm_bytes, "hbm"
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()

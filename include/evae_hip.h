@@ -460,6 +460,10 @@ size_t evae_dense_bwd_weight_p6_workspace_bytes(int nks, int N, int K);
 int evae_dense_bwd_weight_p6(const void* dyT_img, const void* xT_img, int nks, int N, int K, float* dw /* [N x K] */,
                              float* db /* [N] or NULL: then x^T's image carries the ones row K */, void* ws, size_t ws_bytes,
                              evae_stream_t stream);
+/* The exemplar prior's ONE log-variance (models/BaseModel.py:25-26) as the row the prior kernels read (the reference's
+ * `center_log_variance[0, :]`, :101) and back: dst[0..n) = src[0]; out[0] = sum of x[0..n) in a fixed order.  One wave each. */
+int evae_broadcast_scalar(const float* src, float* dst, int n, evae_stream_t stream);
+int evae_sum_small(const float* x, int n, float* out, evae_stream_t stream);
 /* Head of a training step in one launch (utils/training.py:27-31 + models/BaseModel.py:79-81): gather the batch rows
  * idx[b] of the device-resident dataset, binarise them (x = 1 with probability data, the `torch.bernoulli(data)` of
  * dynamic binarisation) or copy them (binarize = 0), and draw eps ~ N(0, 1) [B x zdim] (eps_out may be NULL).

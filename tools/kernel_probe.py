@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
 """Launch ONE kernel family a few times, at the shape it has in a benchmarked configuration, for `rocprofv3 --pmc` /
-`--kernel-trace --stats` passes (tools/profile_round2.sh).  usage: kernel_probe.py <which> [reps]
+`--kernel-trace --stats` passes (tools/profile_round.sh).  usage: kernel_probe.py <which> [reps]
   fwd1        GatedDense forward, encoder layer 1 at c2: 25 000 gathered rows x 784 -> 2 x 300
   u8fwd1 / u8wgrad1   the same layer on the uint8 store (three-term bf16 MFMA): forward / weight gradient
   fwd2        GatedDense forward, encoder layer 2: 25 000 x 300 -> 2 x 300
   dgrad2      data gradient of encoder layer 2 (dual pair, gate-backward epilogue)
   wgrad1      weight gradient of encoder layer 1 ([600 x 784] + db, gathered rows)
   wgrad2      weight gradient of encoder layer 2
+  the c2 step's pre-split bf16 image path (csrc/evae_gemm_p6.h), the launches of evae/fused_vae.py's p6 mode:
+  u8fwd1_img  encoder layer 1 on the uint8 store, output + the image of its transpose (u8_gemm_kernel<true>)
+  fwd2_p6     encoder layer 2 forward over h1^T's image (gemm_p6_kernel<1, 128, true>)
+  hdgrad2_img the mean head's data gradient, gate-backward epilogue -> [dh2 | dg2]^T's image (gemm_x6_kernel<2, 0, 64, 3>)
+  dgrad2_p6   encoder layer 2's data gradient over that image, (dh1, dg1) as the byte layer's tile images (gemm_p6_kernel<9, 64, true>)
+  wgrad2_p6   encoder layer 2's weight gradient from the two images (gemm_p6_kernel<3, 64, false> + finish)
+  hwgrad      the heads' weight gradient [40 x 300] over 25 100 rows (narrow_wgrad_kernel + finish)
   prior_iwae  prior forward, 4 x 5000 importance samples x 50 000 exemplars, z = 40 (prior_fwd_mfma_kernel)
   prior_c5    prior forward, 5000 samples x 100 000 exemplars, z = 256 (GEMM + log-sum-exp epilogue)
   prior_train prior forward + backward at the training shape B = 100, C = 25 000, z = 40
@@ -52,6 +59,61 @@ if which in ("fwd1", "fwd2", "dgrad2", "wgrad1", "wgrad2"):
             lib.evae_dense_bwd_weight(p(g["dpre"]), M, 2 * H, 2 * H, p(g["data"]), p(g["rows"]), D, D, p(g["dw"]), p(g["db"]), 0, p(ws), nws, st())
         else:
             lib.evae_dense_bwd_weight(p(g["dpre"]), M, 2 * H, 2 * H, p(g["a1"]), None, H, H, p(g["dw2"]), p(g["db"]), 0, p(ws), nws, st())
+elif which in ("u8fwd1_img", "fwd2_p6", "hdgrad2_img", "dgrad2_p6", "wgrad2_p6", "hwgrad"):
+    Mp = M + 100
+    nks = lib.evae_p6_nks_rows(Mp)
+    img = lambda rows: torch.zeros(lib.evae_p6_image_bytes(rows, nks), dtype=torch.uint8, device=dev)
+    t_h1, t_dq2 = img(H + 1), img(2 * H)
+    a1 = torch.randn(Mp, H, device=dev) * (torch.rand(Mp, H, device=dev) < 0.5); s1 = torch.rand(Mp, H, device=dev)
+    a2 = torch.randn(Mp, H, device=dev); s2 = torch.rand(Mp, H, device=dev)
+    dq2 = torch.randn(Mp, 2 * H, device=dev) * 0.01
+    w2h = torch.randn(H, H, device=dev) * 0.05; w2g = torch.randn(H, H, device=dev) * 0.05; b = torch.zeros(H, device=dev)
+    _lib.check(lib.evae_p6_pack_cols(p(a1), None, Mp, H, H, -1, nks, p(t_h1), t_h1.numel(), st()), "pack h1")
+    _lib.check(lib.evae_p6_fill_row(p(t_h1), nks, H, 1.0, 0, Mp, st()), "ones row")
+    _lib.check(lib.evae_p6_pack_cols(p(dq2), None, Mp, 2 * H, 2 * H, -1, nks, p(t_dq2), t_dq2.numel(), st()), "pack dq2")
+    w2_img = torch.zeros(lib.evae_p6_image_bytes((H + 63) // 64 * 128, lib.evae_p6_nks(H)), dtype=torch.uint8, device=dev)
+    w2t_img = torch.zeros(lib.evae_p6_image_bytes(H, lib.evae_p6_nks(2 * H)), dtype=torch.uint8, device=dev)
+    _lib.check(lib.evae_p6_pack_rows(p(w2h), p(w2g), H, H, H, 1, p(w2_img), w2_img.numel(), st()), "pack w2")
+    _lib.check(lib.evae_p6_pack_cols(p(w2h), p(w2g), H, H, H, -1, lib.evae_p6_nks(2 * H), p(w2t_img), w2t_img.numel(), st()), "pack w2t")
+    out = torch.empty(M, H, device=dev); so = torch.empty(M, H, device=dev)
+    if which == "u8fwd1_img":
+        R = N
+        q = (torch.randint(0, 256, (R, D), device=dev) * (torch.rand(R, D, device=dev) < 0.2)).to(torch.uint8)
+        store = torch.zeros(R * D + 64, dtype=torch.uint8, device=dev); xs = store[:R * D].view(R, D); xs.copy_(q)
+        rows = torch.randint(0, R, (M,), device=dev)
+        wh = torch.randn(H, D, device=dev) * 0.05; wg = torch.randn(H, D, device=dev) * 0.05
+        prep = ops.u8_prepare(wh, wg)
+    elif which == "dgrad2_p6":
+        nbw = lib.evae_dense_bwd_weight_u8_workspace_bytes(Mp, 2 * H, D)
+        wsw = torch.zeros(nbw, dtype=torch.uint8, device=dev)
+        off, nslab = C.c_size_t(0), C.c_int(0)
+        _lib.check(lib.evae_dense_bwd_weight_u8_images(Mp, 2 * H, D, C.byref(off), C.byref(nslab)), "images")
+    elif which == "hdgrad2_img":
+        dmean = torch.randn(M, Z, device=dev) * 0.01; wm = torch.randn(Z, H, device=dev) * 0.05
+        nbh = lib.evae_dense_bwd_data_workspace_bytes(M, Z, H, 1); wsh = torch.zeros(nbh, dtype=torch.uint8, device=dev)
+    elif which == "wgrad2_p6":
+        nbw = lib.evae_dense_bwd_weight_p6_workspace_bytes(nks, 2 * H, H); wsw = torch.zeros(nbw, dtype=torch.uint8, device=dev)
+        dw2 = torch.empty(2 * H, H, device=dev); db2 = torch.empty(2 * H, device=dev)
+    elif which == "hwgrad":
+        dmean = torch.randn(Mp, Z, device=dev) * 0.01
+        nbw = lib.evae_dense_bwd_weight_workspace_bytes(Mp, Z, H); wsw = torch.zeros(nbw, dtype=torch.uint8, device=dev)
+        dwm = torch.empty(Z, H, device=dev); dbm = torch.empty(Z, device=dev)
+    for _ in range(reps):
+        if which == "u8fwd1_img":
+            _lib.check(lib.evae_gated_dense_fwd_u8_timg(p(xs), p(rows), M, D, D, 1.0 / 255.0, p(prep), p(b), p(b), H, p(out), p(so), p(t_h1),
+                                                        nks, 0, 0, st()), which)
+        elif which == "fwd2_p6":
+            _lib.check(lib.evae_gated_dense_fwd_p6t(p(t_h1), nks, M, H, p(w2_img), p(b), p(b), H, p(out), p(so), st()), which)
+        elif which == "hdgrad2_img":
+            _lib.check(lib.evae_dense_bwd_data_timg(p(dmean), p(wm), None, None, M, Z, Z, H, p(a2), p(s2), None, None, 2 * H, None,
+                                                    p(t_dq2), nks, 0, 0, p(wsh), nbh, st()), which)
+        elif which == "dgrad2_p6":
+            _lib.check(lib.evae_dense_bwd_data_p6t(p(t_dq2), nks, M, 2 * H, p(w2t_img), H, p(a1), p(s1), None, None, 0,
+                                                   vp(wsw.data_ptr() + off.value), nslab.value, 0, st()), which)
+        elif which == "wgrad2_p6":
+            _lib.check(lib.evae_dense_bwd_weight_p6(p(t_dq2), p(t_h1), nks, 2 * H, H, p(dw2), p(db2), p(wsw), nbw, st()), which)
+        else:
+            _lib.check(lib.evae_dense_bwd_weight(p(dmean), Mp, Z, Z, p(a2), None, H, H, p(dwm), p(dbm), 0, p(wsw), nbw, st()), which)
 elif which in ("u8fwd1", "u8wgrad1"):
     R = N
     q = (torch.randint(0, 256, (R, D), device=dev) * (torch.rand(R, D, device=dev) < 0.2)).to(torch.uint8)
