@@ -257,3 +257,58 @@ def test_two_rank_sharded_evaluation_matches_single(model_name):
         assert rel(ll, single[2]) < 1e-6, (rank, ll, single[2])
         assert np.array_equal(nn_idx, single[3])
         assert knn == single[4] and all(np.isfinite(v).all() for v in knn.values())
+
+
+# ---- bench.py itself, two ranks on one device (the multi-GPU leg the driver launches at round end, as a test) ----
+def _bench(args, world):
+    """Run bench.py the way the driver does for --gpus N (torch.distributed.run, one rank per 'GPU'), both ranks on device 0
+    over gloo (EVAE_BENCH_ONE_DEVICE: RCCL refuses duplicate devices); returns rank 0's JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ, EVAE_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + args
+    if world > 1:
+        port = 29900 + (os.getpid() % 500)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + cmd[1:]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    return json.loads(lines[-1])
+
+
+COMMON = ["--steps", "10", "--warmup", "2", "--exemplars", "2000", "--iwae-images", "0", "--cpu-baseline-steps", "0", "--probe-steps", "0",
+          "--no-ramp", "--no-graph", "--no-dp-line"]
+
+
+def test_bench_replica_mode_two_ranks_match_one_process():
+    """`bench.py --gpus 2` (replicated batch, exemplars sharded): exactly three collectives ISSUED per step (counted at
+    torch.distributed's entry points), both ranks contributed, the mean loss of 12 steps equals the single-process run's to
+    1e-6, and the replicas' parameters are bit-identical after them (evae.shard.check_replicas)."""
+    one = _bench(COMMON, 1)
+    two = _bench(COMMON, 2)
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2
+    assert two["collectives"]["count"] == 3 and two["collectives"]["issued_in_one_step"]["count"] == 3, two["collectives"]
+    assert two["steps_in_mean_loss"] == one["steps_in_mean_loss"]
+    assert abs(two["mean_loss_f64"] - one["mean_loss_f64"]) <= 1e-6 * abs(one["mean_loss_f64"]), (two["mean_loss_f64"], one["mean_loss_f64"])
+    assert two["replicas_identical"] is True
+
+
+def test_bench_data_parallel_mode_two_ranks():
+    """`bench.py --gpus 2 --parallel dp`: own batch per rank, six collectives issued per step, weak scaling line."""
+    two = _bench(COMMON + ["--parallel", "dp"], 2)
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["global_batch"] == 200
+    assert two["collectives"]["issued_in_one_step"]["count"] == two["collectives"]["count"] == 6, two["collectives"]
+    assert np.isfinite(two["mean_loss_f64"])
+
+
+def test_bench_iwae_two_ranks_match_one_process():
+    """`bench.py --gpus 2 --config iwae`: the latent cache row-sharded over two ranks; the two runs draw DIFFERENT importance
+    samples (the sharded evaluator seeds a generator all ranks share), so the estimates agree to Monte-Carlo noise only -- the
+    strict comparison with injected noise is test_two_rank_sharded_evaluation_matches_single."""
+    flags = ["--config", "iwae", "--iwae-images", "8", "--steps", "50", "--cpu-baseline-steps", "0"]
+    one = _bench(flags, 1)
+    two = _bench(flags, 2)
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2
+    assert abs(two["neg_log_px"] - one["neg_log_px"]) <= 0.02 * abs(one["neg_log_px"]), (two["neg_log_px"], one["neg_log_px"])
