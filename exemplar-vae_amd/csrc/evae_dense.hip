@@ -27,6 +27,7 @@
 
 #include "evae_gemm_x6.h"
 #include "evae_gemm_p6.h"
+#include "evae_thin.h"
 #include "evae_u8_prepare.h"
 
 namespace evae {
@@ -120,6 +121,13 @@ static int gated_dense_fwd_core(const float* x, const int64_t* rows, int M, int 
   EVAE_REQUIRE(M >= 0 && K > 0 && N > 0 && ldx >= K, "gated_dense_fwd: bad sizes M=%d K=%d N=%d ldx=%d", M, K, N, ldx);
   if (M == 0) return EVAE_OK;
   EVAE_REQUIRE(x && wh && wg && out, "gated_dense_fwd: null pointer");
+  if (rows == nullptr && thin_ok(M, K, ldx, x, (const void*)((uintptr_t)wh | (uintptr_t)wg))) {
+    // batch-sized row counts: one launch, no split-K planes (csrc/evae_thin.h)
+    ThinArgs t = {};
+    t.A = x; t.lda = ldx; t.W0 = wh; t.W1 = wg; t.M = M; t.N = N; t.K = K; t.b0 = bh; t.b1 = bg;
+    t.out0 = out; t.out1 = save_h; t.out2 = save_s; t.ldo = N; t.tsink = tsink;
+    return launch_thin<THIN_GATED, false>(t, stream, "gated_dense_fwd(thin)");
+  }
   Plan pl = make_plan(M, N, cdiv(K, BK), true, false, 2);
   GemmArgs g = {};
   g.ones_col = -1;
@@ -178,6 +186,12 @@ extern "C" int evae_linear_fwd(const float* x, const int64_t* rows, int M, int K
   EVAE_REQUIRE(act >= 0 && act <= 2, "linear_fwd: bad activation %d", act);
   if (M == 0) return EVAE_OK;
   EVAE_REQUIRE(x && w && y, "linear_fwd: null pointer");
+  if (rows == nullptr && thin_ok(M, K, ldx, x, w)) {
+    ThinArgs t = {};
+    t.A = x; t.lda = ldx; t.W0 = w; t.M = M; t.N = N; t.K = K; t.b0 = b; t.out0 = y; t.out1 = pre; t.ldo = N;
+    t.act = act; t.lo = act_lo; t.hi = act_hi;
+    return launch_thin<THIN_LINEAR, false>(t, stream, "linear_fwd(thin)");
+  }
   Plan pl = make_plan(M, N, cdiv(K, BK), false, false, 1);
   GemmArgs g = {};
   g.ones_col = -1;
@@ -339,6 +353,16 @@ static int dense_bwd_data_core(const float* dy1, const float* w1, const float* d
   EVAE_REQUIRE(!gate || (s_prev && (dg || sink || (tsink && !dx_or_dh))), "dense_bwd_data: gate fusion needs out_prev, s_prev and dg");
   EVAE_REQUIRE(!tsink || gate, "dense_bwd_data: the transposed-image output comes with the gate epilogue only");
   const int np = dy2 ? 2 : 1;
+  if (thin_ok(M, N, ldy, dy1, dy2) && (!sink || (sink->mbase % 8) == 0)) {
+    // batch-sized row counts: one launch (csrc/evae_thin.h), with whichever sinks the caller asked for
+    ThinArgs t = {};
+    t.A = dy1; t.A1 = dy2; t.lda = ldy; t.W0 = w1; t.W1 = w2; t.M = M; t.N = N; t.K = K;
+    t.out0 = dx_or_dh; t.out1 = gate ? dg : nullptr; t.ldo = ldo; t.e0 = out_prev; t.e1 = s_prev;
+    if (tsink) t.tsink = *tsink;
+    if (sink) { t.u8img = sink->img; t.u8_nslab = sink->nslab; t.u8_mbase = sink->mbase; }
+    if (gate) return launch_thin<THIN_GATE_BWD, true>(t, (hipStream_t)stream_, "dense_bwd_data(thin, gate)");
+    return launch_thin<THIN_LINEAR, true>(t, (hipStream_t)stream_, "dense_bwd_data(thin)");
+  }
   Plan pl = make_plan(M, K, total_slabs(N, np > 1 ? N : 0), false, false, 1);
   if (sink) { pl.nz = 1; pl.ksplit = 0; }          // the image epilogue lives in the GEMM itself: no split-K
   GemmArgs g = {};

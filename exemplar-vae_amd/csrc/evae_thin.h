@@ -1,0 +1,186 @@
+// Thin dense layers: the B batch rows of a training step (reference utils/training.py:27-46 at batch_size 100; utils/nn.py:44-69
+// GatedDense / NonLinear forward, their data gradients) through ONE launch each.
+//
+// The tiled GEMM kernels give a [100 x 300] layer one row tile and five column tiles: to fill the machine they split the
+// contraction over blockIdx.z and a second launch sums the partial planes -- two graph nodes per layer, and a node of the
+// replayed step costs >= 4.5 us whatever it computes (the batch-row chain was ~55 nodes = 0.25 ms).  Here a
+// block owns a 16 x 16 output tile (x 2 banks for a gated layer), its four waves take interleaved quarters of the contraction
+// straight from L2 into v_mfma_f32_16x16x4_f32 operands (no LDS staging: 100 rows of activations and one layer's weights are
+// L2-resident), the four partial tiles meet in LDS in a fixed order, and the block applies the layer's epilogue itself.
+// 133 blocks for a 300-wide gated layer, 343 for the 784-wide output layer: one node per layer, fp32 arithmetic, deterministic.
+#pragma once
+#include "evae_gemm_core.h"
+
+namespace evae {
+
+enum { THIN_GATED = 0, THIN_LINEAR = 1, THIN_GATE_BWD = 2 };     // (THIN_LINEAR with no bias / activation = the plain product)
+
+struct ThinArgs {
+  // forward (BWD = false): out [M x N] = A [M x K] W^T, W0 / W1 [N x K] (W1: the gate bank of THIN_GATED)
+  // data gradient (BWD = true): out [M x K] = dy0 W0 (+ dy1 W1), dy [M x N] (row stride lda), W [N x K]: contraction over N
+  const float* A;
+  const float* A1;         // BWD: dy of the second bank (NULL: one bank)
+  int lda;
+  const float* W0;
+  const float* W1;
+  int M, N, K;
+  const float* b0;
+  const float* b1;
+  float* out0;             // GATED: h * s; LINEAR: act(pre); GATE_BWD: dh (may be NULL when only the sinks are wanted)
+  float* out1;             // GATED: h (or NULL); LINEAR: pre (or NULL); GATE_BWD: dg
+  float* out2;             // GATED: s (or NULL)
+  int ldo;
+  const float* e0;         // GATE_BWD: gated output h s and gate s of the layer below, dense [M x K]
+  const float* e1;
+  int act;
+  float lo, hi;
+  P6Sink tsink;            // GATED / GATE_BWD: the result also into the pre-split image of its transpose (evae_p6_image.h)
+  unsigned short* u8img;   // GATE_BWD: (dh, dg) also as the tile images of evae_dense_bwd_weight_u8 (EPI_GATE_BWD_IMG's layout)
+  int u8_nslab, u8_mbase;
+};
+
+typedef float thin_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI, bool BWD>
+__global__ __launch_bounds__(256) void thin_layer_kernel(const ThinArgs t) {
+  constexpr bool TWO = (EPI == THIN_GATED);            // two accumulators: the h and g banks of a gated forward
+  __shared__ float part[4][TWO ? 2 : 1][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int nout = BWD ? t.K : t.N;                    // output columns
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  thin_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int mrow = (m0 + i < t.M) ? m0 + i : t.M - 1;                   // (rows beyond M: a valid row, discarded later)
+  if constexpr (!BWD) {
+    const int ncol = (n0 + i < t.N) ? n0 + i : t.N - 1;
+    const float* pa = t.A + (size_t)mrow * t.lda + 4 * kq;
+    const float* pw0 = t.W0 + (size_t)ncol * t.K + 4 * kq;
+    const float* pw1 = TWO ? t.W1 + (size_t)ncol * t.K + 4 * kq : nullptr;
+    const int nchunk = (t.K + 15) >> 4;
+#pragma unroll 4
+    for (int c = wave; c < nchunk; c += 4) {
+      const int k0 = c * 16;
+      const bool ok = k0 + 4 * kq + 4 <= t.K;            // (K % 4 == 0: a float4 is whole or absent)
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), w0 = a, w1 = a;
+      if (ok) {
+        a = *reinterpret_cast<const float4*>(pa + k0);
+        w0 = *reinterpret_cast<const float4*>(pw0 + k0);
+        if constexpr (TWO) w1 = *reinterpret_cast<const float4*>(pw1 + k0);
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w0.x, acc0, 0, 0, 0);
+      if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w0.y, acc0, 0, 0, 0);
+      if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w1.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w0.z, acc0, 0, 0, 0);
+      if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w0.w, acc0, 0, 0, 0);
+      if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w1.w, acc1, 0, 0, 0);
+    }
+  } else {
+    // contraction over the N rows of W, bank by bank; lane (output column i, k quarter kq) reads W[n][n0 + i] for its four n
+    const int kcol = (n0 + i < t.K) ? n0 + i : t.K - 1;
+    const int nchunk = (t.N + 15) >> 4, nbank = t.A1 ? 2 : 1;
+    for (int bank = 0; bank < nbank; ++bank) {
+      const float* pa = (bank ? t.A1 : t.A) + (size_t)mrow * t.lda + 4 * kq;
+      const float* pw = (bank ? t.W1 : t.W0) + (size_t)(4 * kq) * t.K + kcol;
+#pragma unroll 4
+      for (int c = wave; c < nchunk; c += 4) {
+        const int k0 = c * 16;
+        const bool ok = k0 + 4 * kq + 4 <= t.N;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          a = *reinterpret_cast<const float4*>(pa + k0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = pw[(size_t)(k0 + j) * t.K];
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[0], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[1], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[2], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[3], acc0, 0, 0, 0);
+      }
+    }
+  }
+  // C layout of the 16 x 16 tile: register r <-> row 4 (lane >> 4) + r, column lane & 15
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    part[wave][0][4 * kq + r][i] = acc0[r];
+    if constexpr (TWO) part[wave][1][4 * kq + r][i] = acc1[r];
+  }
+  __syncthreads();
+  const int row = tid >> 4, col = tid & 15;
+  const int m = m0 + row, n = n0 + col;
+  float v0 = ((part[0][0][row][col] + part[1][0][row][col]) + part[2][0][row][col]) + part[3][0][row][col];
+  float v1 = 0.f;
+  if constexpr (TWO) v1 = ((part[0][1][row][col] + part[1][1][row][col]) + part[2][1][row][col]) + part[3][1][row][col];
+  if (n >= nout) return;
+  if constexpr (EPI == THIN_GATED) {
+    if (m >= t.M) return;
+    const float h = v0 + (t.b0 ? t.b0[n] : 0.f);
+    const float s = 1.0f / (1.0f + expf(-(v1 + (t.b1 ? t.b1[n] : 0.f))));
+    const size_t o = (size_t)m * t.ldo + n;
+    t.out0[o] = h * s;
+    if (t.out1) t.out1[o] = h;
+    if (t.out2) t.out2[o] = s;
+    if (t.tsink.img) p6_sink_element(t.tsink, t.tsink.row0 + n, t.tsink.kbase + m, h * s);
+  } else if constexpr (EPI == THIN_LINEAR) {
+    if (m >= t.M) return;
+    const float pre = v0 + (t.b0 ? t.b0[n] : 0.f);
+    const size_t o = (size_t)m * t.ldo + n;
+    if (t.out1) t.out1[o] = pre;
+    t.out0[o] = apply_act(pre, t.act, t.lo, t.hi);
+  } else {
+    // dh = v s, dg = v (h s)(1 - s); column cc of the merged [dh | dg] buffer is n (dh) / K + n (dg)
+    const bool live = m < t.M;
+    if (!live && !(t.u8img && m < ((t.M + 7) & ~7))) return;       // (the byte-layer images want zeros up to the next multiple of 8)
+    float dh = 0.f, dg = 0.f;
+    if (live) {
+      const size_t oe = (size_t)m * t.K + n;
+      const float go = t.e0[oe], s = t.e1[oe];
+      dh = v0 * s; dg = v0 * go * (1.0f - s);
+      if (t.out0) { const size_t o = (size_t)m * t.ldo + n; t.out0[o] = dh; t.out1[o] = dg; }
+      if (t.tsink.img) {
+        p6_sink_element(t.tsink, t.tsink.row0 + n, t.tsink.kbase + m, dh);
+        p6_sink_element(t.tsink, t.tsink.row0 + t.K + n, t.tsink.kbase + m, dg);
+      }
+    }
+    if (t.u8img) {
+      // img[((cc >> 7) * nslab + (row >> 5)) * 3 + p][cc & 127][slot (row & 31) >> 3, XOR-swizzled by (c >> 2) & 3][row & 7],
+      // truncation split (csrc/evae_gemm_kernel.h, EPI_GATE_BWD_IMG)
+      const int gm = m + t.u8_mbase;
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const float w = which ? dg : dh;
+        const int cc = which ? t.K + n : n, c = cc & 127;
+        const unsigned u0 = __float_as_uint(w) & 0xFFFF0000u;
+        const float r1 = w - __uint_as_float(u0);
+        const unsigned u1 = __float_as_uint(r1) & 0xFFFF0000u;
+        const float r2 = r1 - __uint_as_float(u1);
+        const unsigned u2 = __float_as_uint(r2);
+        unsigned short* o = t.u8img + ((size_t)((cc >> 7) * t.u8_nslab + (gm >> 5)) * 3 * 128 + c) * 32 +
+                            (((((gm & 31) >> 3) ^ ((c >> 2) & 3))) << 3) + (gm & 7);
+        o[0] = (unsigned short)(u0 >> 16); o[128 * 32] = (unsigned short)(u1 >> 16); o[2 * 128 * 32] = (unsigned short)(u2 >> 16);
+      }
+    }
+  }
+}
+
+// which launches take the thin kernel: a batch-sized row count, aligned float4 rows (EVAE_THIN=0: the tiled kernels)
+static bool thin_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EVAE_THIN"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  return on == 1;
+}
+static bool thin_ok(int M, int contraction, int lda, const void* a, const void* a1) {
+  return thin_enabled() && M > 0 && M <= 128 && contraction % 4 == 0 && lda % 4 == 0 && contraction >= 16 &&
+         ((((uintptr_t)a | (uintptr_t)a1) & 15) == 0);
+}
+template <int EPI, bool BWD>
+static int launch_thin(const ThinArgs& t, hipStream_t stream, const char* what) {
+  const int nout = BWD ? t.K : t.N;
+  const int mrows = (EPI == THIN_GATE_BWD && t.u8img) ? ((t.M + 7) & ~7) : t.M;
+  thin_layer_kernel<EPI, BWD><<<dim3(cdiv(nout, 16), cdiv(mrows, 16)), 256, 0, stream>>>(t);
+  return check_launch(what);
+}
+
+}  // namespace evae

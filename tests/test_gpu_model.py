@@ -1097,3 +1097,70 @@ def test_two_level_step_fused_head_functions_at_c4_size():
         assert abs(a - b) <= 1e-5 * max(abs(b), 1.0), (v1, v0)
     for k in g0:
         assert abs(g1[k] - g0[k]) <= 1e-4 * max(g0[k], 1e-12), (k, g1[k], g0[k])
+
+
+def test_two_level_step_at_c4_size_matches_the_oracle():
+    """hvae_2level at the benchmarked size (BASELINE configs[3]: 11 500 exemplars, batch 100): per-sample loss / RE / KL of the
+    two-stream training step against an fp64 restatement of reference models/AbsHModel.py:13-106 + models/HVAE_2level.py:15-66
+    composed from the oracle's primitives (gated_dense, linear, hardtanh, log_normal_diag, log_bernoulli, log_p_z) on the same
+    weights, noise and exemplar draw -- 1e-4 relative, north_star's bar (c4 was only compared with itself)."""
+    from utils.utils import importing_model
+    from argparse import Namespace
+    N, C, B = 23000, 11500, 100
+    data_np = gi.binary_images(9, N)
+    data = torch.from_numpy(data_np)
+    dataset = torch.utils.data.TensorDataset(data, torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    args = Namespace(prior="exemplar_prior", input_type="binary", input_size=[1, 28, 28], hidden_size=300, z1_size=40, z2_size=40,
+                     model_name="hvae_2level", device="cuda", number_components=C, training_set_size=N, approximate_prior=False,
+                     approximate_k=10, no_mask=False, no_attention=False, same_variational_var=False, use_logit=False, lambd=1e-4,
+                     bottleneck=1, dataset_name="dynamic_mnist", continuous=False, batch_size=B, dynamic_binarization=False,
+                     warmup=100, S=5000)
+    torch.manual_seed(21)
+    model = importing_model(args)(args).cuda()
+    model.train()
+    rs = np.random.RandomState(4)
+    xi = rs.choice(N, size=B, replace=False).astype(np.int64)
+    x_np = data_np[xi]
+    eps2 = rs.standard_normal((B, 40)).astype(np.float32); eps1 = rs.standard_normal((B, 40)).astype(np.float32)
+    ex_idx = rs.randint(0, N, size=C).astype(np.int64)
+    ex_idx[:5] = xi[:5]                                        # leave-one-out hits
+    draws = [eps2, eps1]
+    model._draw_eps = lambda like: torch.from_numpy(draws.pop(0)).to(like.device)
+    orig = torch.randint
+    torch.randint = lambda low=0, high=None, size=None, **kw: torch.from_numpy(ex_idx.copy())
+    beta = 0.6
+    try:
+        loss, RE, KL = model.calculate_loss((torch.from_numpy(x_np).cuda(), torch.from_numpy(xi).reshape(-1, 1).cuda()), beta,
+                                            average=False, dataset=dataset)
+    finally:
+        torch.randint = orig
+    # ---- fp64 restatement from the oracle's primitives ----
+    P = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in model.state_dict().items()}
+
+    def gated(x, name):
+        y, _ = orc.gated_dense(x, P[name + ".h.weight"], P[name + ".h.bias"], P[name + ".g.weight"], P[name + ".g.bias"])
+        return y
+
+    def heads(t, mean, logvar):
+        mu = orc.linear(t, P[mean + ".weight"], P[mean + ".bias"])
+        lv = orc.hardtanh(orc.linear(t, P[logvar + ".linear.weight"], P[logvar + ".linear.bias"]), -6.0, 2.0)
+        return mu, lv
+    x64 = x_np.astype(np.float64)
+    enc2 = lambda v: gated(gated(v, "q_z_layers.0"), "q_z_layers.1")
+    q2_mu, q2_lv = heads(enc2(x64), "q_z_mean", "q_z_logvar")
+    z2 = q2_mu + eps2 * np.exp(0.5 * q2_lv)
+    joint = gated(np.concatenate((gated(x64, "q_z1_layers_x.0"), gated(z2, "q_z1_layers_z2.0")), 1), "q_z1_layers_joint.0")
+    q1_mu, q1_lv = heads(joint, "q_z1_mean", "q_z1_logvar")
+    z1 = q1_mu + eps1 * np.exp(0.5 * q1_lv)
+    p1_mu, p1_lv = heads(gated(gated(z2, "p_z1_layers_z2.0"), "p_z1_layers_z2.1"), "p_z1_mean", "p_z1_logvar")
+    top = gated(np.concatenate((gated(z1, "p_x_layers_z1.0"), gated(z2, "p_x_layers_z2.0")), 1), "p_x_layers_joint.0")
+    x_mean = orc.sigmoid(orc.linear(top, P["p_x_mean.linear.weight"], P["p_x_mean.linear.bias"]))
+    RE_ref = orc.log_bernoulli(x64, x_mean)
+    centres = orc.linear(enc2(data_np[ex_idx].astype(np.float64)), P["q_z_mean.weight"], P["q_z_mean.bias"])
+    clv = np.full((C, 40), float(P["prior_log_variance"][0]))
+    log_pz2 = orc.log_p_z(z2, xi.reshape(-1, 1), centres, clv, ex_idx, test=False)
+    KL_ref = (orc.log_normal_diag(z1, q1_mu, q1_lv) - orc.log_normal_diag(z1, p1_mu, p1_lv)
+              + orc.log_normal_diag(z2, q2_mu, q2_lv) - log_pz2)
+    loss_ref = -RE_ref + beta * KL_ref
+    for name, got, ref in (("RE", RE, RE_ref), ("KL", KL, KL_ref), ("loss", loss, loss_ref)):
+        assert rel(got.detach().cpu().numpy(), ref) < 1e-4, (name, rel(got.detach().cpu().numpy(), ref))
