@@ -274,6 +274,10 @@ extern "C" int evae_heads_reparam_fwd(const float* x, int M, int K, int ldx, con
   EVAE_REQUIRE(M >= 0 && K > 0 && Z > 0 && ldx >= K, "heads_reparam_fwd: bad sizes M=%d K=%d Z=%d ldx=%d", M, K, Z, ldx);
   if (M == 0) return EVAE_OK;
   EVAE_REQUIRE(x && wm && wl && eps && z_mean && logvar && z, "heads_reparam_fwd: null pointer");
+  if (thin_heads_ok(M, K, Z, ldx, x, wm, wl)) {       // batch-sized: one launch (csrc/evae_thin.h)
+    const ThinHeadsArgs t = {x, ldx, M, K, Z, wm, bm, wl, bl, lv_lo, lv_hi, eps, nullptr, z_mean, lv_pre, logvar, z, logq};
+    return launch_thin_heads(t, stream, "heads_reparam_fwd(thin)");
+  }
   EVAE_REQUIRE(ws && ws_bytes >= evae_heads_reparam_fwd_workspace_bytes(M, K, Z), "heads_reparam_fwd: workspace too small (%zu)", ws_bytes);
   const Plan pl = heads_plan(M, K, Z);
   GemmArgs g = {};
@@ -296,6 +300,10 @@ extern "C" int evae_heads_density_fwd(const float* x, int M, int K, int ldx, con
   EVAE_REQUIRE(M >= 0 && K > 0 && Z > 0 && ldx >= K, "heads_density_fwd: bad sizes M=%d K=%d Z=%d ldx=%d", M, K, Z, ldx);
   if (M == 0) return EVAE_OK;
   EVAE_REQUIRE(x && wm && wl && zq && z_mean && logvar && logp, "heads_density_fwd: null pointer");
+  if (thin_heads_ok(M, K, Z, ldx, x, wm, wl)) {
+    const ThinHeadsArgs t = {x, ldx, M, K, Z, wm, bm, wl, bl, lv_lo, lv_hi, nullptr, zq, z_mean, lv_pre, logvar, nullptr, logp};
+    return launch_thin_heads(t, stream, "heads_density_fwd(thin)");
+  }
   EVAE_REQUIRE(ws && ws_bytes >= evae_heads_reparam_fwd_workspace_bytes(M, K, Z), "heads_density_fwd: workspace too small (%zu)", ws_bytes);
   const Plan pl = heads_plan(M, K, Z);
   GemmArgs g = {};

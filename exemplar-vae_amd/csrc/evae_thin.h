@@ -183,4 +183,118 @@ static int launch_thin(const ThinArgs& t, hipStream_t stream, const char* what) 
   return check_launch(what);
 }
 
+
+// ---- the two heads on one trunk + the sample (or the density of a given sample), batch-sized: ONE launch ---------------------
+// mean = x Wm^T + bm, logvar = clamp(x Wl^T + bl), z = mean + eps exp(logvar / 2) (or a given z), log q = sum_k log N(z_k | ...)
+// (reference models/VAE.py:24-26, models/BaseModel.py:79-82, utils/distributions.py:28-33; what evae_heads_reparam_fwd computes
+// with a split-K GEMM and a finish launch).  A block owns 16 rows and ALL Z <= 64 columns -- wave w the columns 16 w .. -- so the
+// row reduction of log q stays inside the block: lanes of a row add their columns in a fixed order.
+struct ThinHeadsArgs {
+  const float* x; int ldx, M, K, Z;
+  const float* wm; const float* bm; const float* wl; const float* bl;
+  float lo, hi;
+  const float* eps;        // fresh sample: noise [M x Z]
+  const float* z_given;    // or: the sample whose density is wanted (eps unused)
+  float* z_mean; float* lv_pre; float* logvar; float* z; float* logq;
+};
+
+template <int NTILE>       // column tiles of 16: Z <= 16 NTILE
+__global__ __launch_bounds__(256) void thin_heads_kernel(const ThinHeadsArgs t) {
+  __shared__ float part[4][2][16][16 * NTILE + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  thin_f32x4 am[NTILE], al[NTILE];
+#pragma unroll
+  for (int j = 0; j < NTILE; ++j) { am[j] = thin_f32x4{0.f, 0.f, 0.f, 0.f}; al[j] = thin_f32x4{0.f, 0.f, 0.f, 0.f}; }
+  {
+    // wave w takes the chunks w, w + 4, ... of the contraction for every column tile (the four partial sums meet in LDS in a
+    // fixed order: the same four-way split as thin_layer_kernel, and a quarter of the accumulation chain)
+    const int mrow = (m0 + i < t.M) ? m0 + i : t.M - 1;
+    const float* pa = t.x + (size_t)mrow * t.ldx + 4 * kq;
+    const float* pm[NTILE]; const float* pl[NTILE];
+#pragma unroll
+    for (int j = 0; j < NTILE; ++j) {
+      const int ncol = (16 * j + i < t.Z) ? 16 * j + i : t.Z - 1;
+      pm[j] = t.wm + (size_t)ncol * t.K + 4 * kq;
+      pl[j] = t.wl + (size_t)ncol * t.K + 4 * kq;
+    }
+    const int nchunk = (t.K + 15) >> 4;
+#pragma unroll 2
+    for (int c = wave; c < nchunk; c += 4) {
+      const int k0 = c * 16;
+      const bool ok = k0 + 4 * kq + 4 <= t.K;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 wm4[NTILE], wl4[NTILE];
+      if (ok) a = *reinterpret_cast<const float4*>(pa + k0);
+#pragma unroll
+      for (int j = 0; j < NTILE; ++j) {
+        wm4[j] = ok ? *reinterpret_cast<const float4*>(pm[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wl4[j] = ok ? *reinterpret_cast<const float4*>(pl[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < NTILE; ++j) {
+        am[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wm4[j].x, am[j], 0, 0, 0);
+        al[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wl4[j].x, al[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < NTILE; ++j) {
+        am[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wm4[j].y, am[j], 0, 0, 0);
+        al[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wl4[j].y, al[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < NTILE; ++j) {
+        am[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wm4[j].z, am[j], 0, 0, 0);
+        al[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wl4[j].z, al[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < NTILE; ++j) {
+        am[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wm4[j].w, am[j], 0, 0, 0);
+        al[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wl4[j].w, al[j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NTILE; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        part[wave][0][4 * kq + r][16 * j + i] = am[j][r];
+        part[wave][1][4 * kq + r][16 * j + i] = al[j][r];
+      }
+  }
+  __syncthreads();
+  // 16 lanes per row, lane c of them the columns c, c + 16, ...
+  const int row = tid >> 4, c0 = tid & 15, m = m0 + row;
+  float acc = 0.f;
+  if (m < t.M) {
+    for (int k = c0; k < t.Z; k += 16) {
+      const size_t o = (size_t)m * t.Z + k;
+      const float mu = (((part[0][0][row][k] + part[1][0][row][k]) + part[2][0][row][k]) + part[3][0][row][k]) + (t.bm ? t.bm[k] : 0.f);
+      const float p = (((part[0][1][row][k] + part[1][1][row][k]) + part[2][1][row][k]) + part[3][1][row][k]) + (t.bl ? t.bl[k] : 0.f);
+      const float lv = fminf(fmaxf(p, t.lo), t.hi);
+      const float zz = t.z_given ? t.z_given[o] : t.eps[o] * expf(0.5f * lv) + mu;
+      t.z_mean[o] = mu;
+      if (t.lv_pre) t.lv_pre[o] = p;
+      t.logvar[o] = lv;
+      if (!t.z_given) t.z[o] = zz;
+      const float d = zz - mu;
+      acc += -0.5f * (lv + kLog2Pi + d * d / expf(lv));
+    }
+  }
+  // the 16 lanes of a row are consecutive lanes of one wave: fixed butterfly
+  acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64); acc += __shfl_xor(acc, 8, 64);
+  if (c0 == 0 && m < t.M && t.logq) t.logq[m] = acc;
+}
+
+static bool thin_heads_ok(int M, int K, int Z, int ldx, const void* x, const void* wm, const void* wl) {
+  return thin_ok(M, K, ldx, x, (const void*)((uintptr_t)wm | (uintptr_t)wl)) && Z <= 64;
+}
+static int launch_thin_heads(const ThinHeadsArgs& t, hipStream_t stream, const char* what) {
+  const int nt = cdiv(t.Z, 16), nb = cdiv(t.M, 16);
+  if (nt <= 1) thin_heads_kernel<1><<<nb, 256, 0, stream>>>(t);
+  else if (nt == 2) thin_heads_kernel<2><<<nb, 256, 0, stream>>>(t);
+  else if (nt == 3) thin_heads_kernel<3><<<nb, 256, 0, stream>>>(t);
+  else thin_heads_kernel<4><<<nb, 256, 0, stream>>>(t);
+  return check_launch(what);
+}
+
 }  // namespace evae

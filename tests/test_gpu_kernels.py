@@ -824,7 +824,9 @@ def test_heads_and_sample_in_one_call(ops, M, K, Z):
     z = mean + eps * np.exp(0.5 * lv)
     lq = (-0.5 * (lv + np.log(2 * np.pi) + (z - mean) ** 2 / np.exp(lv))).sum(1)
     assert rel(out["mean"].cpu().numpy(), mean) < 2e-6 and rel(out["pre"].cpu().numpy(), pre) < 2e-6
-    assert np.abs(out["lv"].cpu().numpy() - lv).max() < 5e-6 and rel(out["z"].cpu().numpy(), z) < 5e-6
+    # (the clamped log-variance is held to the bar of the pre-activation it is clipped from: an fp32 dot product's error scales
+    # with the magnitude of its terms, not with the clipped value)
+    assert np.abs(out["lv"].cpu().numpy() - lv).max() < 2e-6 * np.abs(pre).max() and rel(out["z"].cpu().numpy(), z) < 5e-6
     assert rel(logq.cpu().numpy(), lq) < 5e-6
 
 
