@@ -100,6 +100,14 @@ extern "C" int evae_gemm_x6_configure(int enabled, int min_rows) {
   return EVAE_OK;
 }
 
+// largest row count whose hidden-width layers take the one-launch thin kernels (csrc/evae_thin.h); < 0: leave as is.  Returns
+// the value in force.  (Tests of the tiled kernels at a few thousand rows set 128.)
+extern "C" int evae_thin_configure(int max_rows) {
+  (void)thin_max_rows();
+  if (max_rows >= 0) g_thin_rows = max_rows;
+  return g_thin_rows;
+}
+
 // would a launch with M output rows and N output columns (gated: N gated outputs) run on the split-bf16 kernel?
 extern "C" int evae_gemm_x6_applies(int M, int N, int gated) {
   return (gemm_x6_enabled() && gemm_x6_fills(M, N, gated != 0)) ? 1 : 0;

@@ -171,9 +171,18 @@ static bool thin_enabled() {
   if (on < 0) { const char* e = getenv("EVAE_THIN"); on = (e && atoi(e) == 0) ? 0 : 1; }
   return on == 1;
 }
+// Batch-sized row counts always; up to EVAE_THIN_ROWS (default 4096) rows when the layer is a hidden-width one (contraction
+// <= 640): measured on the captured step, C = 400 exemplars 0.219 -> 0.210 ms, C = 1000 (c1) 0.234 -> 0.224, C = 3125 (one
+// rank's shard of c2 over 8 GPUs) 0.293 -> 0.281 -- a tile there re-reads 2 x 16 rows of operands from L2 per 16 x 16 outputs,
+// which a 784-wide contraction over thousands of rows would not repay.
+static int g_thin_rows = -1;          // (this header belongs to one translation unit, evae_dense.hip: evae_thin_configure sets it)
+static int thin_max_rows() {
+  if (g_thin_rows < 0) { const char* e = getenv("EVAE_THIN_ROWS"); g_thin_rows = e ? atoi(e) : 4096; }
+  return g_thin_rows;
+}
 static bool thin_ok(int M, int contraction, int lda, const void* a, const void* a1) {
-  return thin_enabled() && M > 0 && M <= 128 && contraction % 4 == 0 && lda % 4 == 0 && contraction >= 16 &&
-         ((((uintptr_t)a | (uintptr_t)a1) & 15) == 0);
+  return thin_enabled() && M > 0 && (M <= 128 || (M <= thin_max_rows() && contraction <= 640)) && contraction % 4 == 0 &&
+         lda % 4 == 0 && contraction >= 16 && ((((uintptr_t)a | (uintptr_t)a1) & 15) == 0);
 }
 template <int EPI, bool BWD>
 static int launch_thin(const ThinArgs& t, hipStream_t stream, const char* what) {

@@ -92,6 +92,7 @@ SIGNATURES = {
     "evae_dense_bwd_weight_u8_images": (_i, [_i, _i, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "evae_broadcast_scalar": (_i, [_p, _p, _i, _p]),
     "evae_sum_small": (_i, [_p, _i, _p, _p]),
+    "evae_thin_configure": (_i, [_i]),
     "evae_p6_nks": (_i, [_i]),
     "evae_p6_nks_rows": (_i, [_i]),
     "evae_p6_image_bytes": (_z, [_i, _i]),

@@ -170,6 +170,11 @@ def gemm_x6_configure(enabled=-1, min_rows=-1):
     _lib.check(_lib.load().evae_gemm_x6_configure(int(enabled), int(min_rows)), "evae_gemm_x6_configure")
 
 
+def thin_configure(max_rows=-1):
+    """Row-count limit of the one-launch thin layer kernels (include/evae_hip.h: evae_thin_configure); returns the value in force."""
+    return int(_lib.load().evae_thin_configure(int(max_rows)))
+
+
 def gemm_pipe(M, N, gated, flops):
     """(executed flops, pipe label) of an fp32 GEMM launch with M x N outputs for the roofline probe: six bf16 products per
     fp32 product when it takes the split-bf16 kernel."""

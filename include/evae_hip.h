@@ -430,6 +430,10 @@ int evae_step_stats_add(const float* loss, const float* re, const float* kl, flo
  *   consumers       evae_gated_dense_fwd_p6t, evae_dense_bwd_data_p6t, evae_dense_bwd_weight_p6.
  * t_row0 / t_kbase: first image row / first k index (a multiple of 8) this launch's columns / rows map to: the exemplar rows
  * and the batch rows of a step write disjoint k ranges of the same images. */
+/* Layers over a batch-sized number of rows (and hidden-width layers up to max_rows rows, default 4096 / EVAE_THIN_ROWS) run as ONE
+ * launch instead of a split-K GEMM + finish (csrc/evae_thin.h; evae_gated_dense_fwd, evae_linear_fwd, evae_dense_bwd_data*,
+ * evae_heads_reparam_fwd / _density_fwd dispatch there).  max_rows < 0: query.  Returns the value in force. */
+int evae_thin_configure(int max_rows);
 int evae_p6_nks(int K);
 int evae_p6_nks_rows(int M);
 size_t evae_p6_image_bytes(int rows, int nks);

@@ -473,10 +473,14 @@ def test_dense_k_tails(ops, K, gemm_pipe):
 
 @pytest.fixture
 def x6_all_rows(ops):
-    """Drive every eligible launch through the split-bf16 kernel (csrc/evae_gemm_x6.h), whatever its row count."""
+    """Drive every eligible launch through the split-bf16 kernel (csrc/evae_gemm_x6.h), whatever its row count (and keep the
+    one-launch thin kernels, which would take hidden-width layers of a few thousand rows, to batch-sized row counts)."""
     ops.gemm_x6_configure(1, 0)
+    thin = ops.thin_configure(-1)
+    ops.thin_configure(128)
     yield
     ops.gemm_x6_configure(1, 2048)
+    ops.thin_configure(thin)
 
 
 @pytest.mark.parametrize("M,K,N", [(37, 52, 24), (130, 300, 300), (1000, 300, 300), (257, 40, 300), (5000, 784, 300),
