@@ -21,6 +21,7 @@
 #include "evae_common.h"
 #include "evae_u8_prepare.h"
 #include "evae_p6_image.h"
+#include "evae_gemm_kernel.h"
 
 namespace evae {
 
@@ -223,6 +224,208 @@ __global__ __launch_bounds__(U8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   }
 }
 
+// ---- the gated forward again, as a copy pipeline (r04) ----------------------------------------------------------------------------
+// Same tile, operands, arithmetic and results as u8_gemm_kernel<true>; what differs is how a K-slab reaches the MFMAs.  There:
+// seven 16-byte loads per thread into registers, the byte -> bf16 conversion of the whole A slab and eight ds_write_b128 in
+// front of the slab's MFMAs, the fragments of a slab read behind its barrier (matrix pipe 45 % busy, 4 VALU per MFMA,
+// profiles/r03_pmc/u8fwd1.json).  Here, as in gemm_p6_kernel: LDS-DMA copies (buffer_load / global_load ... lds: no staging
+// registers, no ds_write) -- the 24 KB weight image of slab i + 2 into a ring of two, the 4 KB of gathered BYTES of slab i + 3
+// into a ring of four (the image is L2-resident, the bytes come from HBM: one slab more of lead) -- the A bytes stay bytes in
+// LDS and are converted per fragment (12 VALU per 8 bytes, between the MFMAs), and the fragments of slab i + 1 are read and
+// converted behind the MFMAs of slab i (two fragment sets in registers).
+// The weight image (three bf16 terms: 6 bytes per weight) is the heavy operand and comes through the L2 -> LDS path, which
+// carries about 24 bytes per cycle per CU (profiles/r04_micro): at 128 rows per block the 588 MB of image reads of a
+// 25000-row launch alone take the time of the MFMAs.  NWR = 4 (eight waves, 256 rows per block, one block per CU) halves
+// the image bytes per row: 32 KB instead of 56 KB per CU and slab.
+constexpr int U8P_B = 3 * 128 * 64;
+constexpr int u8p_a_bytes(int nwr) { return nwr * 64 * 32; }
+constexpr int u8p_lds_bytes(int nwr) { return 4 * u8p_a_bytes(nwr) + 2 * U8P_B; }      // 64 KB (two blocks per CU) | 80 KB (one)
+
+typedef __attribute__((address_space(3))) void* u8p_lds_t;
+typedef __attribute__((address_space(1))) const void* u8p_glb_t;
+
+// 8 bytes (two dwords) -> 8 bf16: a byte k as bf16 is the upper half of float(k), exact
+__device__ __forceinline__ bf16x8 u8x8_to_bf16(unsigned lo, unsigned hi) {
+  auto cvt4 = [](unsigned w, unsigned& p0, unsigned& p1) {
+    // v_cvt_f32_ubyteN, then v_perm_b32 takes the upper halves of two floats: six VALU per four bytes
+    const unsigned f0 = __float_as_uint((float)(w & 0xFFu)), f1 = __float_as_uint((float)((w >> 8) & 0xFFu));
+    const unsigned f2 = __float_as_uint((float)((w >> 16) & 0xFFu)), f3 = __float_as_uint((float)(w >> 24));
+    p0 = __builtin_amdgcn_perm(f1, f0, 0x07060302u);
+    p1 = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
+  };
+  u32x4 v;
+  unsigned a, b;
+  cvt4(lo, a, b); v[0] = a; v[1] = b;
+  cvt4(hi, a, b); v[2] = a; v[3] = b;
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NWR>
+__global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void u8p_gemm_kernel(
+    const unsigned char* __restrict__ x, const int64_t* __restrict__ rows, int M, long long ldx, float x_scale,
+    const unsigned short* __restrict__ img, int nslab, const float* __restrict__ bh, const float* __restrict__ bg, int N,
+    float* __restrict__ out, float* __restrict__ save_s, int tiles_m, int tiles_n, const P6Sink tsink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int U8P_A = u8p_a_bytes(NWR), NWAVE = 2 * NWR, BM = 64 * NWR;
+  constexpr int NB = 24 / NWAVE, NB1 = NB * 2 / 3;     // B pieces per wave and slab; of them behind k-step 1
+  char* const Abuf = smem;                       // [4][BM rows][32 bytes: the two 16-byte halves swapped on odd groups of 8 rows]
+  char* const Bbuf = smem + 4 * U8P_A;           // [2][3 terms][128 columns][64 B swizzled] = the weight image of a slab
+  int tm, tn;
+  {
+    const int ntiles = tiles_m * tiles_n;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int qq = ntiles >> 3, rr = ntiles & 7;
+    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+    tm = tile / tiles_n; tn = tile - tm * tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * U8_BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
+
+  // copies.  A: this wave's piece = rows 32 w .. 32 w + 31 of the tile, lane -> (row, physical half); the half it FETCHES is
+  // swapped on odd groups of eight rows (the 16-lane groups of the fragments' ds_read_b128 then cover all banks)
+  const int crow = 32 * wave + (lane >> 1), cphys = lane & 1;
+  const int am = m0 + crow;
+  const size_t arow_g = rows ? (size_t)rows[am < M ? am : m0] : (size_t)(am < M ? am : m0);
+  const unsigned char* const asrc = x + arow_g * ldx + ((cphys ^ ((crow >> 3) & 1)) << 4);
+  const rsrc_t rB = make_rsrc(img + (size_t)tn * nslab * (3 * 128 * 32), 0x7FFFFFFFu);
+  const unsigned voffb = (unsigned)lane * 16u;
+  auto issue_a = [&](int s) {
+    __builtin_amdgcn_global_load_lds((u8p_glb_t)(asrc + (size_t)s * U8_BK), (u8p_lds_t)(Abuf + (s & 3) * U8P_A + wave * 1024), 16, 0, 0);
+  };
+  auto issue_b = [&](int s, int q) {             // piece wave + NWAVE q of the 24
+    const int idx = wave + NWAVE * q;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (u8p_lds_t)(Bbuf + (s & 1) * U8P_B + idx * 1024), 16, voffb,
+                                             (unsigned)s * (unsigned)U8P_B + idx * 1024, 0, 0);
+  };
+
+  f32x16u acc[2][2];        // [mt][h | g]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: A the lane's 8 bytes of (row, k-step), B as u8_gemm_kernel
+  unsigned fa[2][2], fb[2][2];
+#pragma unroll
+  for (int step = 0; step < 2; ++step) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int r = wr * 64 + mt * 32 + l31;
+      fa[step][mt] = (unsigned)(r * 32 + ((step ^ ((r >> 3) & 1)) << 4) + lh * 8);
+    }
+#pragma unroll
+    for (int hg = 0; hg < 2; ++hg) {
+      const int c = wc * 64 + hg * 32 + l31, ks = 2 * step + lh;
+      fb[step][hg] = (unsigned)(c * 64 + ((ks ^ ((c >> 2) & 3)) << 4));
+    }
+  }
+  // fragment set s holds k-step s of a slab: [set][mt], [set][hg][term]
+  uint2 araw[2];                        // a lane's eight bytes of a k-step: ds_read_b64, each bank touched twice by the 64 lanes
+  bf16x8 af[2][2], bf[2][2][3];
+  auto read_araw = [&](int s, int step, int mt) {
+    araw[mt] = *reinterpret_cast<const uint2*>(Abuf + (s & 3) * U8P_A + fa[step][mt]);
+  };
+  auto convert_a = [&](int step, int mt) { af[step][mt] = u8x8_to_bf16(araw[mt].x, araw[mt].y); };
+  auto read_b = [&](int s, int step, int hg, int p) {
+    bf[step][hg][p] = lds_read16(Bbuf + (s & 1) * U8P_B + p * (128 * 64) + fb[step][hg]);
+  };
+#define EVAE_U8P_SB __builtin_amdgcn_sched_barrier(0)
+  // One k-step (12 MFMAs) on fragment set STEP; behind the MFMAs the eight reads and two conversions of the NEXT k-step
+  // (k-step 1 of slab i behind k-step 0; k-step 0 of slab i + 1 behind k-step 1) and this wave's share of the copies:
+  //   k-step 1 of slab i: two thirds of its B(i + 2) pieces  -- behind the slab's one barrier: slab i's last reads were issued in k-step 0
+  //   k-step 0 of slab i: the other third of B(i + 1) and A(i + 2)
+  // Before k-step 1 reads slab i + 1, everything issued except the last copy (A(i + 2)) must have landed.
+  auto kstep = [&](auto step_, auto has1_, auto has2_, int i) {
+    constexpr int step = decltype(step_)::value;
+    constexpr bool HAS1 = decltype(has1_)::value, HAS2 = decltype(has2_)::value;     // slabs i + 1, i + 2 exist
+    constexpr bool READS = step == 0 || HAS1;
+    if constexpr (step == 1 && HAS1) {
+      if constexpr (HAS2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    EVAE_U8P_SB;
+    const int rs = step == 0 ? i : i + 1;          // the slab the reads are of
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int p = 2; p >= 0; --p)                   // smallest terms first
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int hg = 0; hg < 2; ++hg) {
+          const int j = ((2 - p) * 2 + mt) * 2 + hg;          // 0 .. 11
+          acc[mt][hg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[step][mt], bf[step][hg][p], acc[mt][hg], 0, 0, 0);
+          EVAE_U8P_SB;
+          if constexpr (READS) {
+            if (j < 2) { read_araw(rs, step ^ 1, j); EVAE_U8P_SB; }
+            else if (j < 8) { const int k = j - 2; read_b(rs, step ^ 1, k / 3, k % 3); EVAE_U8P_SB; }
+            else if (j < 10) { convert_a(step ^ 1, j - 8); EVAE_U8P_SB; }
+          }
+          if constexpr (step == 1 && HAS2) { if (j % 3 == 1 && j / 3 < NB1) { issue_b(i + 2, j / 3); EVAE_U8P_SB; } }
+          if constexpr (step == 0 && HAS1) { if ((j == 3 || j == 6) && NB1 + j / 3 - 1 < NB) { issue_b(i + 1, NB1 + j / 3 - 1); EVAE_U8P_SB; } }
+          if constexpr (step == 0 && HAS2) { if (j == 10) { issue_a(i + 2); EVAE_U8P_SB; } }
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+#undef EVAE_U8P_SB
+  constexpr std::integral_constant<int, 0> S0{};
+  constexpr std::integral_constant<int, 1> S1{};
+  constexpr std::true_type T{};
+  constexpr std::false_type F{};
+  {
+    // prologue (nslab >= 3: the host sends shorter contractions to u8_gemm_kernel)
+    issue_a(0);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) issue_b(0, q);
+    issue_a(1);
+#pragma unroll
+    for (int q = 0; q < NB1; ++q) issue_b(1, q);
+    if constexpr (NB1 == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");          // A(0), B(0) landed
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { read_araw(0, 0, mt); convert_a(0, mt); }
+#pragma unroll
+    for (int hg = 0; hg < 2; ++hg)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) read_b(0, 0, hg, p);
+    int i = 0;
+    for (; i + 2 < nslab; ++i) { kstep(S0, T, T, i); kstep(S1, T, T, i); }
+    kstep(S0, T, F, i); kstep(S1, T, F, i); ++i;
+    kstep(S0, F, F, i); kstep(S1, F, F, i);
+  }
+  // epilogue: as u8_gemm_kernel<true>
+  const int n = n0 + wc * 32 + l31;
+  const bool nok = n < N;
+  const bool timg = tsink.img != nullptr;
+  if (nok || timg) {
+    float vbh = (bh && nok) ? bh[n] : 0.f, vbg = (bg && nok) ? bg[n] : 0.f;
+    asm volatile("" : "+v"(vbh));
+    asm volatile("" : "+v"(vbg));
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float ov[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float h = fmaf(acc[mt][0][r], x_scale, vbh);
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * fmaf(acc[mt][1][r], x_scale, vbg)));
+        ov[r] = h * sg;
+        if (m < M && nok) {
+          const size_t o = (size_t)m * N + n;
+          out[o] = ov[r];
+          if (save_s) save_s[o] = sg;
+        }
+      }
+      if (timg) p6_emit_tile(tsink, tsink.row0 + n, nok, tsink.kbase + m0 + wr * 64 + mt * 32, ov, lh);
+    }
+  }
+}
+
 // ---- weight-gradient pre-passes -----------------------------------------------------------------------------------------
 // xT [K + 1][ldt] bytes: xT[k][m] = x[rows[m]][k] for m < M (0 beyond), row K = ones (the bias-gradient row).
 // Block = 64 batch rows x 64 pixels through an LDS tile.
@@ -341,6 +544,27 @@ static int gated_dense_fwd_u8_core(const unsigned char* x, const int64_t* rows, 
     attr = true;
   }
   const int tiles_m = cdiv(M, U8_BM), tiles_n = cdiv(N, U8_BN);
+  static int pipe = -1, tall = 1;
+  if (pipe < 0) {
+    const char* e = getenv("EVAE_U8_PIPE");
+    pipe = e ? atoi(e) : 1;                    // 0: never, 1: machine-filling launches, 2: whenever the contraction allows
+    const char* t = getenv("EVAE_U8_TALL");
+    tall = t ? atoi(t) : 1;
+    (void)hipFuncSetAttribute((const void*)u8p_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, u8p_lds_bytes(2));
+    (void)hipFuncSetAttribute((const void*)u8p_gemm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, u8p_lds_bytes(4));
+  }
+  if (pipe && u8_nslab(K) >= 3 && (pipe == 2 || tiles_m * tiles_n >= 256)) {
+    // a machine-filling launch: the copy-pipeline form of the same kernel; 256-row blocks when those still fill the machine
+    const int tiles_m4 = cdiv(M, 256);
+    if (tall && (tall == 2 || tiles_m4 * tiles_n >= 256)) {
+      u8p_gemm_kernel<4><<<tiles_m4 * tiles_n, 512, u8p_lds_bytes(4), (hipStream_t)stream_>>>(
+          x, rows, M, ldx, x_scale, (const unsigned short*)prepared, u8_nslab(K), bh, bg, N, out, save_s, tiles_m4, tiles_n, tsink);
+      return check_launch("u8p_gemm_kernel<4>");
+    }
+    u8p_gemm_kernel<2><<<tiles_m * tiles_n, 256, u8p_lds_bytes(2), (hipStream_t)stream_>>>(
+        x, rows, M, ldx, x_scale, (const unsigned short*)prepared, u8_nslab(K), bh, bg, N, out, save_s, tiles_m, tiles_n, tsink);
+    return check_launch("u8p_gemm_kernel<2>");
+  }
   u8_gemm_kernel<true><<<tiles_m * tiles_n, U8_NT, 2 * U8_STAGE, (hipStream_t)stream_>>>(
       x, rows, M, ldx, x_scale, (const unsigned short*)prepared, u8_nslab(K), u8_nslab(K), bh, bg, N, out, save_s, tiles_m, tiles_n,
       tsink);
