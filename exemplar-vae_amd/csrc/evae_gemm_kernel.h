@@ -93,6 +93,11 @@ struct GemmArgs {
   unsigned short* img;
   int img_nslab, img_mbase;
   int ldo2;                // EPI_DIST_TILEMIN: > 0 = tile minima stored query-major, out0[n * ldo2 + tile] (else out0[tile * ldo + n])
+  int ldq;                 // EPI_DIST_TILEMIN: > 0 = the kept distances query-major, out1[n * ldq + m], ldq a multiple of the row
+                           // tile (whole tiles are written, rows beyond M as +inf); e1 may then be NULL: |b_n|^2 is left out of
+                           // every distance of column n (a per-query constant: the two-launch top-K adds it to its threshold)
+  float* tile_max;         // x6 kernel, e0 == NULL: [2 * tiles_m] the largest |a_m|^2 of each half row tile, plain stores (instead
+                           // of the atomic maximum into aux_cnt, which wants a cleared word)
   int sk_local;            // > 0: XCD-local split-K mapping on a 1-D grid, value = number of slices (see gemm_kernel)
   P6Sink tsink;            // EPI_GATED / EPI_GATE_BWD, img != NULL: the result also leaves as the pre-split bf16 image of its transpose
                            // (evae_p6_image.h; EPI_GATE_BWD: [dh | dg]^T, and out0 may then be NULL -- no fp32 copy)
@@ -264,7 +269,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = n0 + wc * 32 * NT + nt * 32 + l31;
-      bnv[nt] = n < g.N ? g.e1[n] : 0.f;
+      bnv[nt] = (g.e1 != nullptr && n < g.N) ? g.e1[n] : 0.f;
     }
     float tmin[NT];
 #pragma unroll
@@ -274,6 +279,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
       const float bn = bnv[nt];
       const float thr = (EPI == EPI_DIST_COLLECT && nok) ? g.bias0[n] : -INFINITY;
       tmin[nt] = INFINITY;
+      float dq[4];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -284,7 +290,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
           const bool mok = m < g.M;
           const float d = e0v[mt][r] + bn - 2.0f * acc[mt][nt][r];
           if (EPI == EPI_DIST_TILEMIN) {
-            if (g.out1 && nok && mok) g.out1[(size_t)m * g.ldo + n] = d;    // kept for the collect scan
+            if (g.ldq > 0) {
+              // query-major: a lane's four consecutive rows are one 16-byte store; the two lanes of a column fill a 128-byte line
+              dq[r & 3] = mok ? d : INFINITY;
+              if ((r & 3) == 3 && nok) *reinterpret_cast<float4*>(g.out1 + (size_t)n * g.ldq + (m - 3)) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+            } else if (g.out1 && nok && mok) g.out1[(size_t)m * g.ldo + n] = d;    // kept for the collect scan
             tmin[nt] = fminf(tmin[nt], mok ? d : INFINITY);
           } else if (mok && nok && d <= thr) {
             g.aux_cand[(size_t)n * g.ldo + atomicAdd(&g.aux_cnt[n], 1)] = m;

@@ -290,7 +290,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (tid < BM) {
         float t = (m0 + tid < g.M) ? smem[512 + tid] : 0.f;
         t = wave_max(t);
-        if (lane == 0 && t > 0.f) atomicMax(reinterpret_cast<unsigned*>(g.aux_cnt), __float_as_uint(t));
+        if (g.tile_max != nullptr) { if (lane == 0) g.tile_max[2 * tm + (tid >> 6)] = t; }
+        else if (lane == 0 && t > 0.f) atomicMax(reinterpret_cast<unsigned*>(g.aux_cnt), __float_as_uint(t));
       }
     }
   }

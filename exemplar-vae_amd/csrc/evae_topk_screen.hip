@@ -13,6 +13,10 @@
 //      exactly those rows to the query's candidate list;
 //   4. exact distances of the candidates, each ranked by the (value, index) pairs in front of it.
 // Cost: one pass over the [N x z] cache at streaming speed + a write and a read of the [N x B] distances.
+// Launches (r04): TWO on the split-bf16 kernel -- the screening GEMM (cache norms and their per-tile maxima accumulated while
+// it stages the rows; distances stored query-major, without the query's own norm) and topk_finish_kernel, one 1024-thread block
+// per query for steps 1 (its norm), 2's threshold, 3 and 4.  c5 size 89 -> 66 us, c2 size 40 -> 30 us against the five launches
+// (query norms + clears, GEMM, threshold, collect, exact) that remain the form of the fp32 kernel (EVAE_X6=0, EVAE_TOPK_TWO_LAUNCH=0).
 #include "evae_gemm_x6.h"
 #include "evae_topk_screen.h"
 
@@ -90,20 +94,19 @@ __device__ __forceinline__ unsigned ordered_key(float f) {
 __device__ __forceinline__ float key_to_float(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
-__global__ __launch_bounds__(256) void kth_threshold_kernel(const float* __restrict__ tmin, int ntiles, int ldt, int B, int k,
-                                                            const float* __restrict__ qn, const unsigned* __restrict__ cnmax_bits,
-                                                            float gamma, float* __restrict__ thr) {
-  __shared__ int cnt[2][4];
+// the k-th smallest of row[0 .. ntiles) as an ordered key; every thread of the 256-thread block returns it
+template <int NT = 256>
+__device__ __forceinline__ unsigned kth_smallest_key(const float* __restrict__ row, int ntiles, int k) {
+  constexpr int NWV = NT / 64;
+  __shared__ int cnt[2][NWV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = blockIdx.x;
-  constexpr int TR = 4;
-  const bool in_regs = ntiles <= 256 * TR;
-  const int used = in_regs ? (ntiles + 255) / 256 : 0;          // registers that hold anything (block-uniform)
-  const float* row = tmin + (size_t)n * ldt;
+  constexpr int TR = 1024 / NT;
+  const bool in_regs = ntiles <= NT * TR;
+  const int used = in_regs ? (ntiles + NT - 1) / NT : 0;          // registers that hold anything (block-uniform)
   unsigned key[TR];
 #pragma unroll
   for (int j = 0; j < TR; ++j) {
-    const int t = threadIdx.x + 256 * j;
+    const int t = threadIdx.x + NT * j;
     key[j] = (in_regs && t < ntiles) ? ordered_key(row[t]) : 0xFFFFFFFFu;
   }
   // the k-th smallest key = the largest t with #(key < t) <= k - 1 (fewer than k minima exist: the largest key, +inf's image)
@@ -116,36 +119,37 @@ __global__ __launch_bounds__(256) void kth_threshold_kernel(const float* __restr
       for (int j = 0; j < TR; ++j)
         if (j < used) below += __popcll(__ballot(key[j] < t));
     } else {
-      for (int tt = threadIdx.x; tt < ((ntiles + 255) & ~255); tt += 256)
+      for (int tt = threadIdx.x; tt < ((ntiles + NT - 1) / NT) * NT; tt += NT)
         below += __popcll(__ballot(tt < ntiles && ordered_key(row[tt]) < t));
     }
     if (lane == 0) cnt[b & 1][wave] = below;
     __syncthreads();
-    const int all = cnt[b & 1][0] + cnt[b & 1][1] + cnt[b & 1][2] + cnt[b & 1][3];
+    int all = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) all += cnt[b & 1][w];
     if (all <= k - 1) ans = t;
   }
+  return ans;
+}
+__global__ __launch_bounds__(256) void kth_threshold_kernel(const float* __restrict__ tmin, int ntiles, int ldt, int B, int k,
+                                                            const float* __restrict__ qn, const unsigned* __restrict__ cnmax_bits,
+                                                            float gamma, float* __restrict__ thr) {
+  const int n = blockIdx.x;
+  const unsigned ans = kth_smallest_key(tmin + (size_t)n * ldt, ntiles, k);
   if (threadIdx.x == 0) thr[n] = key_to_float(ans) + 2.0f * gamma * (qn[n] + __uint_as_float(*cnmax_bits));
 }
 
 // exact re-ranking of one query's candidates: block = 256 threads
 constexpr int RANK_MAX = 1024;
-__global__ __launch_bounds__(256) void topk_exact_kernel(const float* __restrict__ q, const float* __restrict__ cache,
-                                                         int zdim, int k, unsigned flags, int64_t index_base,
-                                                         const int* __restrict__ cnt, const int* __restrict__ cand,
-                                                         float* __restrict__ val, size_t ldc,
-                                                         int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
-  __shared__ float sv[4];
-  __shared__ int si[4];
-  const int n = blockIdx.x;
-  const int M = cnt[n];
-  const int* cl = cand + (size_t)n * ldc;
-  float* vl = val + (size_t)n * ldc;
-  const float* qr = q + (size_t)n * zdim;
+// qs = the query row in LDS (z_dim <= 512 on this path, multiple of 4), cl / vl = query n's candidate rows / a value per candidate
+template <int NT = 256>
+__device__ __forceinline__ void topk_exact_body(const float* qs, const float* __restrict__ cache, int zdim, int k, unsigned flags,
+                                                int64_t index_base, int n, int M, const int* cl, float* vl,
+                                                int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+  __shared__ float sv[NT / 64];
+  __shared__ int si[NT / 64];
   const bool do_sqrt = (flags & EVAE_TOPK_SQRT) != 0;
-  __shared__ __attribute__((aligned(16))) float qs[512];      // the query row (z_dim <= 512 on this path, multiple of 4)
-  for (int d = threadIdx.x; d < zdim; d += 256) qs[d] = qr[d];
-  __syncthreads();
-  for (int c = threadIdx.x; c < M; c += 256) {
+  for (int c = threadIdx.x; c < M; c += NT) {
     const float* cr = cache + (size_t)cl[c] * zdim;
     double a = 0.0;
     for (int d = 0; d < zdim; d += 4) {    // same order and operations as dist_chunk_f64 (evae_topk.hip), 16-byte loads
@@ -167,9 +171,9 @@ __global__ __launch_bounds__(256) void topk_exact_kernel(const float* __restrict
     // barriers.  The values are the ones just stored by this block.
     __shared__ float rv[RANK_MAX];
     __shared__ int ri[RANK_MAX];
-    for (int c = threadIdx.x; c < M; c += 256) { rv[c] = vl[c]; ri[c] = cl[c]; }
+    for (int c = threadIdx.x; c < M; c += NT) { rv[c] = vl[c]; ri[c] = cl[c]; }
     __syncthreads();
-    for (int c = threadIdx.x; c < M; c += 256) {
+    for (int c = threadIdx.x; c < M; c += NT) {
       const float v = rv[c];
       const int id = ri[c];
       int rank = 0;
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256) void topk_exact_kernel(const float* __restrict
         if (out_val) out_val[(size_t)n * k + rank] = v;
       }
     }
-    for (int j = M + threadIdx.x; j < k; j += 256) {      // fewer candidates than k: as the rounds below would leave them
+    for (int j = M + threadIdx.x; j < k; j += NT) {      // fewer candidates than k: as the rounds below would leave them
       out_idx[(size_t)n * k + j] = (int64_t)-1;
       if (out_val) out_val[(size_t)n * k + j] = INFINITY;
     }
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void topk_exact_kernel(const float* __restrict
   for (int j = 0; j < k; ++j) {
     float bv = INFINITY;
     int bi = INT_MAX;
-    for (int c = threadIdx.x; c < M; c += 256) {
+    for (int c = threadIdx.x; c < M; c += NT) {
       const float v = vl[c];
       const int id = cl[c];
       const bool after = (v > lastv) || (v == lastv && id > lasti);
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void topk_exact_kernel(const float* __restrict
     __syncthreads();
     bv = sv[0]; bi = si[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < NT / 64; ++w)
       if ((sv[w] < bv) || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
     __syncthreads();
     lastv = bv; lasti = bi;
@@ -215,6 +219,72 @@ __global__ __launch_bounds__(256) void topk_exact_kernel(const float* __restrict
       if (out_val) out_val[(size_t)n * k + j] = bv;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void topk_exact_kernel(const float* __restrict__ q, const float* __restrict__ cache,
+                                                         int zdim, int k, unsigned flags, int64_t index_base,
+                                                         const int* __restrict__ cnt, const int* __restrict__ cand,
+                                                         float* __restrict__ val, size_t ldc,
+                                                         int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+  const int n = blockIdx.x;
+  __shared__ __attribute__((aligned(16))) float qs[512];
+  for (int d = threadIdx.x; d < zdim; d += 256) qs[d] = q[(size_t)n * zdim + d];
+  __syncthreads();
+  topk_exact_body(qs, cache, zdim, k, flags, index_base, n, cnt[n], cand + (size_t)n * ldc, val + (size_t)n * ldc, out_idx, out_val);
+}
+
+// The two-launch form's second launch (r04): everything behind the screening GEMM for ONE query per block -- its squared norm,
+// the largest cache-row norm (from the GEMM's per-tile maxima), the threshold (k-th smallest tile minimum + the error bound),
+// the scan of ITS row of the query-major distances for candidates, their exact distances and ranks.  The distances carry no
+// |q|^2 (the GEMM did not have it): a constant per query, it changes neither the order nor the bound.
+constexpr int FIN_NT = 1024;      // sixteen waves: the scan of a query's row of distances wants many loads in flight on its one CU
+__global__ __launch_bounds__(FIN_NT) void topk_finish_kernel(const float* __restrict__ q, const float* __restrict__ cache, int N,
+                                                             int zdim, int k, unsigned flags, int64_t index_base,
+                                                             const float* __restrict__ tmin, int ntiles, int ldm,
+                                                             const float* __restrict__ tile_max, const float* __restrict__ dist,
+                                                             int ldq, float gamma, int* __restrict__ cand, float* __restrict__ val,
+                                                             size_t ldc, int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+  constexpr int NWV = FIN_NT / 64;
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) float qs[512];
+  __shared__ float red[2][NWV];
+  __shared__ int ncand;
+  float qq = 0.f, cm = 0.f;
+  for (int d = threadIdx.x; d < zdim; d += FIN_NT) { const float v = q[(size_t)n * zdim + d]; qs[d] = v; qq = fmaf(v, v, qq); }
+  for (int t = threadIdx.x; t < 2 * ntiles; t += FIN_NT) cm = fmaxf(cm, tile_max[t]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { qq += __shfl_xor(qq, o, 64); cm = fmaxf(cm, __shfl_xor(cm, o, 64)); }
+  if (lane == 0) { red[0][wave] = qq; red[1][wave] = cm; }
+  if (threadIdx.x == 0) ncand = 0;
+  __syncthreads();
+  float qn = 0.f, cnmax = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) { qn += red[0][w]; cnmax = fmaxf(cnmax, red[1][w]); }
+  const unsigned key = kth_smallest_key<FIN_NT>(tmin + (size_t)n * ldm, ntiles, k);
+  const float thr = key_to_float(key) + 2.0f * gamma * (qn + cnmax);
+  int* cl = cand + (size_t)n * ldc;
+  const float* drow = dist + (size_t)n * ldq;
+  // ldq is a multiple of 128: whole float4s, rows beyond N hold +inf.  Four loads per thread in flight (64 KB per sweep of the block)
+  for (int m0 = 0; m0 < ldq; m0 += 4 * 4 * FIN_NT) {
+    float4 d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + 4 * (threadIdx.x + j * FIN_NT);
+      d[j] = m < ldq ? *reinterpret_cast<const float4*>(drow + m) : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + 4 * (threadIdx.x + j * FIN_NT);
+      if (fminf(fminf(d[j].x, d[j].y), fminf(d[j].z, d[j].w)) <= thr) {
+        if (d[j].x <= thr) cl[atomicAdd(&ncand, 1)] = m;
+        if (d[j].y <= thr) cl[atomicAdd(&ncand, 1)] = m + 1;
+        if (d[j].z <= thr) cl[atomicAdd(&ncand, 1)] = m + 2;
+        if (d[j].w <= thr) cl[atomicAdd(&ncand, 1)] = m + 3;
+      }
+    }
+  }
+  __syncthreads();
+  topk_exact_body<FIN_NT>(qs, cache, zdim, k, flags, index_base, n, ncand, cl, val + (size_t)n * ldc, out_idx, out_val);
 }
 
 // Candidates from the stored approximate distances D[m][n] (row stride ldt): m joins the list of query n when D <= thr[n].
@@ -243,8 +313,9 @@ __global__ void zero_ints_kernel(int* p, int n, unsigned* q) {
 }
 
 struct ScreenLayout {
-  size_t cn, qn, cnmax, tmin, thr, cnt, cand, val, dist, total;
-  int ntiles, ldt, ldm;      // ldt: row stride of the distances (queries, padded); ldm: of the query-major tile minima
+  size_t cn, qn, cnmax, tmin, thr, cnt, cand, val, dist, tile_max, total;
+  int ntiles, ldt, ldm, ldq;  // ldt: row stride of the distances (queries, padded); ldm: of the query-major tile minima;
+                              // ldq: of the query-major distances (whole row tiles)
 };
 static bool screen_applies(int B, int N, int zdim, int k) {
   static int off = -1;
@@ -265,6 +336,9 @@ static ScreenLayout screen_layout(int B, int N) {
   L.tmin = take((size_t)L.ldm * L.ldt * 4); L.thr = take((size_t)L.ldt * 4); L.cnt = take((size_t)L.ldt * 4);
   L.cand = take((size_t)B * N * 4); L.val = take((size_t)B * N * 4);
   L.dist = take((size_t)N * L.ldt * 4);        // approximate distances of the screening GEMM, scanned by the collect pass
+  L.ldq = L.ntiles * BM;
+  if ((size_t)L.ldq * B > (size_t)N * L.ldt) L.dist = take((size_t)L.ldq * B * 4);      // query-major form, a few rows more
+  L.tile_max = take((size_t)2 * L.ntiles * 4);
   L.total = o + 256;
   return L;
 }
@@ -285,15 +359,32 @@ int topk_screen(const float* q, int B, const float* cache, int N, int zdim, int 
   float* cn = (float*)(w + L.cn); float* qn = (float*)(w + L.qn); unsigned* cnmax = (unsigned*)(w + L.cnmax);
   float* tmin = (float*)(w + L.tmin); float* thr = (float*)(w + L.thr); int* cnt = (int*)(w + L.cnt);
   int* cand = (int*)(w + L.cand); float* val = (float*)(w + L.val);
-  // query norms first: that launch also clears the candidate counters and the running maximum of the cache norms
-  const int rpb = zdim >= 128 ? 16 : 256;       // rows one block covers per sweep
-  sq_norms_kernel<<<std::min(cdiv(B, rpb), 2048), 256, 0, stream>>>(q, B, zdim, qn, nullptr, cnt, L.ldt, cnmax);
+  float* dist = (float*)(w + L.dist);
   GemmArgs g = {};
   g.ones_col = -1;
   g.A[0] = cache; g.B[0] = q; g.lda[0] = zdim; g.ldb[0] = zdim; g.Kc[0] = zdim; g.npairs = 1;
-  g.M = N; g.N = B; g.e0 = cn; g.e1 = qn; g.ksplit = 0;
-  float* dist = (float*)(w + L.dist);
+  g.M = N; g.N = B; g.ksplit = 0;
   g.out0 = tmin; g.out1 = dist; g.ldo = L.ldt; g.ldo2 = L.ldm;
+  static int two = -1;
+  if (two < 0) { const char* e = getenv("EVAE_TOPK_TWO_LAUNCH"); two = (e && atoi(e) == 0) ? 0 : 1; }
+  if (two && gemm_x6_enabled() && gemm_x6_ok(g)) {
+    // TWO launches: the screening product on the split-bf16 kernel (two-term products: a filter needs a bound, not fp32
+    // accuracy; the cache rows' norms accumulated while it stages them, their maxima per half tile; distances query-major
+    // and without |q|^2), then one block per query for everything else.  The same kernel at any size: a 196-tile launch
+    // over a 40-wide cache is one short round of blocks, and three launches less than the fp32 form.
+    g.tile_max = (float*)(w + L.tile_max); g.ldq = L.ldq;
+    int rc = launch_gemm_x6<EPI_DIST_TILEMIN, 0, 128, 2>(g, 1, stream, "topk_screen(tile minima, split-bf16, query-major)");
+    if (rc) return rc;
+    const float u = 5.9604645e-08f;
+    const float gamma = 2.0f * ((4.0f * zdim + 3.0f) * u + 3.0517578e-05f);         // derived below
+    topk_finish_kernel<<<B, FIN_NT, 0, stream>>>(q, cache, N, zdim, k, flags, index_base, tmin, L.ntiles, L.ldm, g.tile_max, dist, L.ldq,
+                                              gamma, cand, val, (size_t)N, out_idx, out_val);
+    return check_launch("topk_finish_kernel");
+  }
+  // query norms first: that launch also clears the candidate counters and the running maximum of the cache norms
+  const int rpb = zdim >= 128 ? 16 : 256;       // rows one block covers per sweep
+  sq_norms_kernel<<<std::min(cdiv(B, rpb), 2048), 256, 0, stream>>>(q, B, zdim, qn, nullptr, cnt, L.ldt, cnmax);
+  g.e0 = cn; g.e1 = qn;
   // the screening product once, on the split-bf16 kernel when the launch fills the machine; its distances are kept
   const bool x6 = B > 64 && gemm_x6_use(g);
   int rc;
