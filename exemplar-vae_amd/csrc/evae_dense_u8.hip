@@ -239,7 +239,7 @@ __global__ __launch_bounds__(U8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 // the image bytes per row: 32 KB instead of 56 KB per CU and slab.
 constexpr int U8P_B = 3 * 128 * 64;
 constexpr int u8p_a_bytes(int nwr) { return nwr * 64 * 32; }
-constexpr int u8p_lds_bytes(int nwr) { return 4 * u8p_a_bytes(nwr) + 2 * U8P_B; }      // 64 KB (two blocks per CU) | 80 KB (one)
+constexpr int u8p_lds_bytes(int nwr, int lead) { return 4 * u8p_a_bytes(nwr) + lead * U8P_B; }      // lead 2: 64 KB (two blocks per CU) | 80 KB (one)
 
 typedef __attribute__((address_space(3))) void* u8p_lds_t;
 typedef __attribute__((address_space(1))) const void* u8p_glb_t;
@@ -260,7 +260,15 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(unsigned lo, unsigned hi) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int NWR>
+template <int N_>
+__device__ __forceinline__ void u8p_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+// L = slabs of lead of the weight-image copies = depth of their ring (the byte ring has four slots)
+// (L = 3 measured at 256 rows: 74.6 us against 74.3 with L = 2 -- hipcc puts an s_waitcnt vmcnt(0) in front of each k-step's
+// first byte read, a ds_read it can see behind a global_load ... lds into the same array, so the lead is one k-step whatever
+// the ring holds; the reads as inline assembly with hand-counted waits took the wait away, gained 2 us and failed two parity
+// tests at 10 blocks -- not kept.  profiles/r04_ab/knobs.jsonl)
+template <int NWR, int L>
 __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void u8p_gemm_kernel(
     const unsigned char* __restrict__ x, const int64_t* __restrict__ rows, int M, long long ldx, float x_scale,
     const unsigned short* __restrict__ img, int nslab, const float* __restrict__ bh, const float* __restrict__ bg, int N,
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   constexpr int U8P_A = u8p_a_bytes(NWR), NWAVE = 2 * NWR, BM = 64 * NWR;
   constexpr int NB = 24 / NWAVE, NB1 = NB * 2 / 3;     // B pieces per wave and slab; of them behind k-step 1
   char* const Abuf = smem;                       // [4][BM rows][32 bytes: the two 16-byte halves swapped on odd groups of 8 rows]
-  char* const Bbuf = smem + 4 * U8P_A;           // [2][3 terms][128 columns][64 B swizzled] = the weight image of a slab
+  char* const Bbuf = smem + 4 * U8P_A;           // [L][3 terms][128 columns][64 B swizzled] = the weight image of a slab
   int tm, tn;
   {
     const int ntiles = tiles_m * tiles_n;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   };
   auto issue_b = [&](int s, int q) {             // piece wave + NWAVE q of the 24
     const int idx = wave + NWAVE * q;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (u8p_lds_t)(Bbuf + (s & 1) * U8P_B + idx * 1024), 16, voffb,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (u8p_lds_t)(Bbuf + (s % L) * U8P_B + idx * 1024), 16, voffb,
                                              (unsigned)s * (unsigned)U8P_B + idx * 1024, 0, 0);
   };
 
@@ -331,20 +339,21 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   };
   auto convert_a = [&](int step, int mt) { af[step][mt] = u8x8_to_bf16(araw[mt].x, araw[mt].y); };
   auto read_b = [&](int s, int step, int hg, int p) {
-    bf[step][hg][p] = lds_read16(Bbuf + (s & 1) * U8P_B + p * (128 * 64) + fb[step][hg]);
+    bf[step][hg][p] = lds_read16(Bbuf + (s % L) * U8P_B + p * (128 * 64) + fb[step][hg]);
   };
 #define EVAE_U8P_SB __builtin_amdgcn_sched_barrier(0)
   // One k-step (12 MFMAs) on fragment set STEP; behind the MFMAs the eight reads and two conversions of the NEXT k-step
   // (k-step 1 of slab i behind k-step 0; k-step 0 of slab i + 1 behind k-step 1) and this wave's share of the copies:
-  //   k-step 1 of slab i: two thirds of its B(i + 2) pieces  -- behind the slab's one barrier: slab i's last reads were issued in k-step 0
-  //   k-step 0 of slab i: the other third of B(i + 1) and A(i + 2)
-  // Before k-step 1 reads slab i + 1, everything issued except the last copy (A(i + 2)) must have landed.
-  auto kstep = [&](auto step_, auto has1_, auto has2_, int i) {
+  //   k-step 1 of slab i: two thirds of its B(i + L) pieces  -- behind the slab's one barrier: slab i's last reads were issued in k-step 0
+  //   k-step 0 of slab i: the other third of B(i + L - 1) and A(i + L)
+  // Before k-step 1 reads slab i + 1, slab i + 1 must have landed: what was issued behind it may still be in flight.
+  auto kstep = [&](auto step_, auto has1_, auto has2_, auto has3_, int i) {
     constexpr int step = decltype(step_)::value;
-    constexpr bool HAS1 = decltype(has1_)::value, HAS2 = decltype(has2_)::value;     // slabs i + 1, i + 2 exist
+    constexpr bool HAS1 = decltype(has1_)::value, HAS2 = decltype(has2_)::value, HAS3 = decltype(has3_)::value;   // slabs i + 1 .. 3 exist
+    constexpr bool HASL = L == 2 ? HAS2 : HAS3, HASL1 = L == 2 ? HAS1 : HAS2;
     constexpr bool READS = step == 0 || HAS1;
     if constexpr (step == 1 && HAS1) {
-      if constexpr (HAS2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      u8p_wait_vm<(L == 3 && HAS2 ? 1 + NB : 0) + (HASL ? 1 : 0)>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -365,9 +374,9 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
             else if (j < 8) { const int k = j - 2; read_b(rs, step ^ 1, k / 3, k % 3); EVAE_U8P_SB; }
             else if (j < 10) { convert_a(step ^ 1, j - 8); EVAE_U8P_SB; }
           }
-          if constexpr (step == 1 && HAS2) { if (j % 3 == 1 && j / 3 < NB1) { issue_b(i + 2, j / 3); EVAE_U8P_SB; } }
-          if constexpr (step == 0 && HAS1) { if ((j == 3 || j == 6) && NB1 + j / 3 - 1 < NB) { issue_b(i + 1, NB1 + j / 3 - 1); EVAE_U8P_SB; } }
-          if constexpr (step == 0 && HAS2) { if (j == 10) { issue_a(i + 2); EVAE_U8P_SB; } }
+          if constexpr (step == 1 && HASL) { if (j % 3 == 1 && j / 3 < NB1) { issue_b(i + L, j / 3); EVAE_U8P_SB; } }
+          if constexpr (step == 0 && HASL1) { if ((j == 3 || j == 6) && NB1 + j / 3 - 1 < NB) { issue_b(i + L - 1, NB1 + j / 3 - 1); EVAE_U8P_SB; } }
+          if constexpr (step == 0 && HASL) { if (j == 10) { issue_a(i + L); EVAE_U8P_SB; } }
         }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -378,14 +387,13 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   constexpr std::false_type F{};
   {
     // prologue (nslab >= 3: the host sends shorter contractions to u8_gemm_kernel)
-    issue_a(0);
 #pragma unroll
-    for (int q = 0; q < NB; ++q) issue_b(0, q);
-    issue_a(1);
+    for (int sl = 0; sl < L; ++sl) {
+      issue_a(sl);
 #pragma unroll
-    for (int q = 0; q < NB1; ++q) issue_b(1, q);
-    if constexpr (NB1 == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");          // A(0), B(0) landed
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      for (int q = 0; q < (sl == L - 1 ? NB1 : NB); ++q) issue_b(sl, q);
+    }
+    u8p_wait_vm<(L - 1) + (L - 2) * NB + NB1>();                // A(0), B(0) landed
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) { read_araw(0, 0, mt); convert_a(0, mt); }
@@ -394,9 +402,10 @@ __global__ __launch_bounds__(NWR * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
       for (int p = 0; p < 3; ++p) read_b(0, 0, hg, p);
     int i = 0;
-    for (; i + 2 < nslab; ++i) { kstep(S0, T, T, i); kstep(S1, T, T, i); }
-    kstep(S0, T, F, i); kstep(S1, T, F, i); ++i;
-    kstep(S0, F, F, i); kstep(S1, F, F, i);
+    for (; i + 3 < nslab; ++i) { kstep(S0, T, T, T, i); kstep(S1, T, T, T, i); }
+    kstep(S0, T, T, F, i); kstep(S1, T, T, F, i); ++i;
+    kstep(S0, T, F, F, i); kstep(S1, T, F, F, i); ++i;
+    kstep(S0, F, F, F, i); kstep(S1, F, F, F, i);
   }
   // epilogue: as u8_gemm_kernel<true>
   const int n = n0 + wc * 32 + l31;
@@ -550,20 +559,20 @@ static int gated_dense_fwd_u8_core(const unsigned char* x, const int64_t* rows, 
     pipe = e ? atoi(e) : 1;                    // 0: never, 1: machine-filling launches, 2: whenever the contraction allows
     const char* t = getenv("EVAE_U8_TALL");
     tall = t ? atoi(t) : 1;
-    (void)hipFuncSetAttribute((const void*)u8p_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, u8p_lds_bytes(2));
-    (void)hipFuncSetAttribute((const void*)u8p_gemm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, u8p_lds_bytes(4));
+    (void)hipFuncSetAttribute((const void*)u8p_gemm_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, u8p_lds_bytes(2, 2));
+    (void)hipFuncSetAttribute((const void*)u8p_gemm_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, u8p_lds_bytes(4, 2));
   }
   if (pipe && u8_nslab(K) >= 3 && (pipe == 2 || tiles_m * tiles_n >= 256)) {
     // a machine-filling launch: the copy-pipeline form of the same kernel; 256-row blocks when those still fill the machine
     const int tiles_m4 = cdiv(M, 256);
     if (tall && (tall == 2 || tiles_m4 * tiles_n >= 256)) {
-      u8p_gemm_kernel<4><<<tiles_m4 * tiles_n, 512, u8p_lds_bytes(4), (hipStream_t)stream_>>>(
+      u8p_gemm_kernel<4, 2><<<tiles_m4 * tiles_n, 512, u8p_lds_bytes(4, 2), (hipStream_t)stream_>>>(
           x, rows, M, ldx, x_scale, (const unsigned short*)prepared, u8_nslab(K), bh, bg, N, out, save_s, tiles_m4, tiles_n, tsink);
-      return check_launch("u8p_gemm_kernel<4>");
+      return check_launch("u8p_gemm_kernel<4, 2>");
     }
-    u8p_gemm_kernel<2><<<tiles_m * tiles_n, 256, u8p_lds_bytes(2), (hipStream_t)stream_>>>(
+    u8p_gemm_kernel<2, 2><<<tiles_m * tiles_n, 256, u8p_lds_bytes(2, 2), (hipStream_t)stream_>>>(
         x, rows, M, ldx, x_scale, (const unsigned short*)prepared, u8_nslab(K), bh, bg, N, out, save_s, tiles_m, tiles_n, tsink);
-    return check_launch("u8p_gemm_kernel<2>");
+    return check_launch("u8p_gemm_kernel<2, 2>");
   }
   u8_gemm_kernel<true><<<tiles_m * tiles_n, U8_NT, 2 * U8_STAGE, (hipStream_t)stream_>>>(
       x, rows, M, ldx, x_scale, (const unsigned short*)prepared, u8_nslab(K), u8_nslab(K), bh, bg, N, out, save_s, tiles_m, tiles_n,
