@@ -838,6 +838,81 @@ __global__ __launch_bounds__(1024) void prior_elbo_fwd_kernel(const float* __res
   if (threadIdx.x < 3) means[threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) / (float)B;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same tail as TWO launches for a step on two streams (r04): the merge of the R partial rows needs nothing of the
+// reconstruction term, and the prior's backward needs nothing but the merge (token + coefficients) -- so the merge runs on
+// the prior's stream right behind the partials, spread over the queries (16 per block, 64 groups of partial rows per query:
+// every thread's <= 4 rows of loads are in flight at once instead of a six-round dependent chain in one block), and the ELBO
+// assembly (loss, KL, batch means) runs beside the prior's backward on the stream that produced RE.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void prior_merge_coef_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
+                                                                const float* __restrict__ pn, int R, int ldp, int B,
+                                                                float c_total, const float* __restrict__ beta_dev, float beta_host,
+                                                                float* __restrict__ logp, float* __restrict__ lse_out,
+                                                                float* __restrict__ cRE, float* __restrict__ cKL,
+                                                                float* __restrict__ neg_cKL) {
+  __shared__ float cm[64][17], cs[64][17], cn[64][17];
+  const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int row = blockIdx.x * 16 + q;
+  float m = -INFINITY, s = 0.f, n = 0.f;
+  if (row < B) {
+    for (int r0 = grp; r0 < R; r0 += 256) {
+      float mr[4], sr_[4], nr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + 64 * u;
+        const bool ok = r < R;
+        const size_t o = (size_t)(ok ? r : grp) * ldp + row;
+        mr[u] = ok ? pm[o] : -INFINITY; sr_[u] = ok ? ps[o] : 0.f; nr[u] = ok ? pn[o] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        n += nr[u];
+        if (mr[u] > m) { s = s * expf(m - mr[u]) + sr_[u]; m = mr[u]; }
+        else if (mr[u] != -INFINITY) s += sr_[u] * expf(mr[u] - m);
+      }
+    }
+  }
+  cm[grp][q] = m; cs[grp][q] = s; cn[grp][q] = n;
+  __syncthreads();
+  if (grp == 0 && row < B) {
+    float mm = -INFINITY, ss = 0.f, nn = 0.f;
+    for (int g = 0; g < 64; ++g) mm = fmaxf(mm, cm[g][q]);
+    for (int g = 0; g < 64; ++g) {                 // fixed order
+      if (cm[g][q] != -INFINITY) ss += cs[g][q] * expf(cm[g][q] - mm);
+      nn += cn[g][q];
+    }
+    const float ls = logf(ss);
+    logp[row] = (mm + ls) - logf(c_total - nn);
+    lse_out[row] = mm; lse_out[B + row] = (mm == -INFINITY) ? 0.f : ls;       // token (max, log sum): prior_merge_kernel
+    if (cRE != nullptr) {      // coefficients of "the batch mean of the loss, upstream gradient 1" (evae_elbo_bwd)
+      const float beta = beta_dev ? beta_dev[0] : beta_host;
+      const float gl = 1.0f / (float)B;
+      cRE[row] = 0.f - gl; cKL[row] = 0.f + beta * gl; neg_cKL[row] = -(0.f + beta * gl);
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void elbo_assemble_kernel(const float* __restrict__ logp, const float* __restrict__ RE,
+                                                            const float* __restrict__ logq, const float* __restrict__ beta_dev,
+                                                            float beta_host, int B, float* __restrict__ loss,
+                                                            float* __restrict__ KL, float* __restrict__ means) {
+  __shared__ float red[3][2];
+  const float beta = beta_dev ? beta_dev[0] : beta_host;
+  float sl = 0.f, sr = 0.f, sk = 0.f;
+  for (int row = threadIdx.x; row < B; row += 128) {          // the same rows per lane, in the same order, as prior_elbo_fwd_kernel
+    const float kl = logq[row] - logp[row];
+    const float l = beta * kl - RE[row];
+    KL[row] = kl; loss[row] = l;
+    sl += l; sr += RE[row]; sk += kl;
+  }
+  if (means == nullptr) return;
+  sl = wave_sum(sl); sr = wave_sum(sr); sk = wave_sum(sk);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sl; red[1][threadIdx.x >> 6] = sr; red[2][threadIdx.x >> 6] = sk; }
+  __syncthreads();
+  if (threadIdx.x < 3) means[threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) / (float)B;
+}
+
 __global__ void prior_fill_empty_kernel(float* m, float* s, float* n, int B) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) { m[i] = -INFINITY; s[i] = 0.f; n[i] = 0.f; }
@@ -1351,6 +1426,10 @@ __global__ void zero_kernel(float* p, size_t n) {
   if (i < n) p[i] = 0.f;
 }
 
+}  // namespace evae
+#include "evae_prior_train.h"
+namespace evae {
+
 static void choose_splits(int B, int C, int* nsplit, int* tiles_per_split, int* nq) {
   int ntiles = cdiv(C, BE);
   *nq = cdiv(B, BQ);
@@ -1528,6 +1607,29 @@ extern "C" int evae_prior_elbo_fwd_coef(const float* pmax, const float* psum, co
 
 
 
+// prior_elbo_fwd(_coef) as two launches (prior_merge_coef_kernel above): evae_prior_merge_coef on the prior's stream, evae_elbo_assemble
+// wherever RE is.  cRE / cKL / neg_cKL may all be NULL (no coefficients).
+extern "C" int evae_prior_merge_coef(const float* pmax, const float* psum, const float* pnmask, int R, int ldp, int B,
+                                     float c_total, const float* beta_dev, float beta_host, float* logp, float* lse,
+                                     float* cRE, float* cKL, float* neg_cKL, evae_stream_t stream_) {
+  EVAE_REQUIRE(R >= 1 && B >= 0 && ldp >= B, "prior_merge_coef: bad sizes R=%d B=%d ldp=%d", R, B, ldp);
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(pmax && psum && pnmask && logp && lse, "prior_merge_coef: null pointer");
+  EVAE_REQUIRE((cRE && cKL && neg_cKL) || (!cRE && !cKL && !neg_cKL), "prior_merge_coef: all three coefficient vectors or none");
+  prior_merge_coef_kernel<<<cdiv(B, 16), 1024, 0, (hipStream_t)stream_>>>(pmax, psum, pnmask, R, ldp, B, c_total, beta_dev, beta_host,
+                                                                        logp, lse, cRE, cKL, neg_cKL);
+  return check_launch("prior_merge_coef_kernel");
+}
+
+extern "C" int evae_elbo_assemble(const float* logp, const float* RE, const float* logq, const float* beta_dev, float beta_host,
+                                  int B, float* loss, float* KL, float* means, evae_stream_t stream_) {
+  EVAE_REQUIRE(B >= 0, "elbo_assemble: bad size B=%d", B);
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(logp && RE && logq && loss && KL, "elbo_assemble: null pointer");
+  elbo_assemble_kernel<<<1, 128, 0, (hipStream_t)stream_>>>(logp, RE, logq, beta_dev, beta_host, B, loss, KL, means);
+  return check_launch("elbo_assemble_kernel");
+}
+
 extern "C" int evae_prior_merge(const float* max, const float* sumexp, const float* nmask, int R, int B,
                                 float c_total, float* out_logprior, float* out_lse,
                                 evae_stream_t stream_) {
@@ -1672,3 +1774,90 @@ extern "C" int evae_prior_lse_bwd_phased(const float* z, int B, const float* cen
                             phase, (hipStream_t)stream_);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The prior of a captured training step as one launch + the dz' / dlogvar reduction (evae_prior_train.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" int evae_prior_train_applies(int B, int C, int zdim) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("EVAE_PRIOR_TRAIN"); off = (e && atoi(e) == 0) ? 1 : 0; }
+  if (off) return 0;
+  return B >= 1 && B <= MFQ && C >= 1 && cdiv(C, MFE) <= PT_MAX_BLOCKS && zdim >= 4 && zdim <= 56 && (zdim & 3) == 0;
+}
+
+static size_t prior_train_layout(int B, int C, int zdim, size_t* o_gpart, size_t* o_dz, size_t* o_dlv) {
+  const size_t nblk = (size_t)cdiv(C, MFE);
+  size_t o = align_up(3 * nblk * MFQ * sizeof(float), 256);
+  *o_gpart = o; o += align_up((size_t)3 * 8 * MFQ * sizeof(float), 256);
+  *o_dz = o;    o += align_up(nblk * B * zdim * sizeof(float), 256);
+  *o_dlv = o;   o += align_up(nblk * (zdim + 1) * sizeof(float), 256);
+  return o;
+}
+
+extern "C" size_t evae_prior_train_workspace_bytes(int B, int C, int zdim) {
+  if (B <= 0 || C <= 0 || zdim <= 0) return 256;
+  size_t a, b, c;
+  return prior_train_layout(B, C, zdim, &a, &b, &c);
+}
+
+template <int KG>
+static int launch_prior_train(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+                              const int64_t* z_idx, const int64_t* c_idx, float c_total, const float* beta_dev, float beta_host,
+                              unsigned* state, float* part, float* gpart, float* logp, float* token, float* cRE, float* cKL,
+                              float* ncKL, float* dz_part, float* dc, float* dlv_part, hipStream_t stream) {
+  constexpr int KS2 = KG * 8 + 4;
+  const size_t lds = (size_t)(2 * 128 * KS2 + 128 * 132 + 4 * 128 + 64 + 64 + 16 + 8 + 8 * 64 + 2 * 128) * sizeof(float) + 128 * sizeof(long long);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)prior_train_kernel<KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  prior_train_kernel<KG><<<cdiv(C, MFE), MFT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, c_total, beta_dev, beta_host,
+                                                            prior_norm_limit(), state, part, gpart, logp, token, cRE, cKL, ncKL,
+                                                            dz_part, dc, dlv_part);
+  return check_launch("prior_train_kernel");
+}
+
+extern "C" int evae_prior_train_step(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+                                     const int64_t* z_idx, const int64_t* c_idx, float c_total, const float* beta_dev,
+                                     float beta_host, float* logp, float* token, float* cRE, float* cKL, float* neg_cKL,
+                                     float* dz, float* dcentres, float* dlogvar, void* state, void* ws, size_t ws_bytes,
+                                     int phase, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(phase >= 0 && phase <= 2, "prior_train_step: phase must be 0, 1 or 2");
+  EVAE_REQUIRE(evae_prior_train_applies(B, C, zdim), "prior_train_step: B=%d C=%d zdim=%d is outside the one-launch form (B <= 128, "
+               "C <= %d, zdim <= 56 and a multiple of 4)", B, C, zdim, PT_MAX_BLOCKS * MFE);
+  EVAE_REQUIRE(z && centres && log_var && logp && token && dz && dcentres && dlogvar && state && ws, "prior_train_step: null pointer");
+  EVAE_REQUIRE((cRE && cKL && neg_cKL) || (!cRE && !cKL && !neg_cKL), "prior_train_step: all three coefficient vectors or none");
+  EVAE_REQUIRE(((((uintptr_t)z) | ((uintptr_t)centres)) & 15) == 0, "prior_train_step: z and centres must be 16-byte aligned");
+  size_t o_gpart, o_dz, o_dlv;
+  const size_t need = prior_train_layout(B, C, zdim, &o_gpart, &o_dz, &o_dlv);
+  if (ws_bytes < need) { set_error("prior_train_step: workspace too small (%zu < %zu)", ws_bytes, need); return EVAE_EWORKSPACE; }
+  float* part = (float*)ws;
+  float* gpart = (float*)((char*)ws + o_gpart);
+  float* dz_part = (float*)((char*)ws + o_dz);
+  float* dlv_part = (float*)((char*)ws + o_dlv);
+  const int nblk = cdiv(C, MFE);
+  int rc = EVAE_OK;
+  if (phase != 2) {
+#define EVAE_PT(KG_) rc = launch_prior_train<KG_>(z, B, centres, C, zdim, log_var, z_idx, c_idx, c_total, beta_dev, beta_host, \
+                                                  (unsigned*)state, part, gpart, logp, token, cRE, cKL, neg_cKL, dz_part, dcentres, \
+                                                  dlv_part, stream)
+    switch ((zdim + 7) / 8) {
+      case 1: EVAE_PT(1); break;
+      case 2: EVAE_PT(2); break;
+      case 3: EVAE_PT(3); break;
+      case 4: EVAE_PT(4); break;
+      case 5: EVAE_PT(5); break;
+      case 6: EVAE_PT(6); break;
+      default: EVAE_PT(7); break;
+    }
+#undef EVAE_PT
+    if (rc) return rc;
+  }
+  if (phase == 1) return EVAE_OK;
+  const int nb = cdiv(B * zdim, 64);
+  prior_bwd_finish_kernel<<<nb + cdiv(zdim, 16), 1024, 0, stream>>>(dz_part, nblk, B * zdim, zdim, log_var, dz, nb, dlv_part, nblk,
+                                                                   dlogvar, nullptr);
+  return check_launch("prior_bwd_finish_kernel");
+}

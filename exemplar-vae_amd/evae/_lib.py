@@ -59,6 +59,11 @@ SIGNATURES = {
     "evae_prior_lse_fwd_splits": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _z, C.POINTER(C.c_int), C.POINTER(C.c_int), _p]),
     "evae_prior_elbo_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
     "evae_prior_elbo_fwd_coef": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "evae_prior_merge_coef": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _f, _p, _p, _p, _p, _p, _p]),
+    "evae_elbo_assemble": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p, _p]),
+    "evae_prior_train_applies": (_i, [_i, _i, _i]),
+    "evae_prior_train_workspace_bytes": (_z, [_i, _i, _i]),
+    "evae_prior_train_step": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _f, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _p]),
     "evae_prior_lse_bwd_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_prior_lse_bwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_prior_lse_bwd_phased": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _p]),

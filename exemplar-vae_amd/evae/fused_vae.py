@@ -59,6 +59,15 @@ FINISH_GROUP_HEAD = os.environ.get("EVAE_FINISH_GROUP_HEAD", "0") == "1"   # ...
 # 23.4 us against 8.7 + 10.1 for the two it replaces (c2 0.6446-0.6468 vs 0.641-0.645 ms); with the mean head's finish in it as
 # well the side stream has to be joined earlier: c2 +10 us, C = 200 +17 us.
 FINISH_GROUP = os.environ.get("EVAE_FINISH_GROUP", "0") == "1"
+# the mean head's weight gradient (a 29-us streaming launch alone) right behind the batch rows' reparameterisation backward instead of
+# at the end of the side stream's chain: it then runs beside the HBM-bound head data gradient, not beside layer 2's data gradient
+HEADW_EARLY = int(os.environ.get("EVAE_HEADW_EARLY", "1"))
+ELBO_SPLIT = os.environ.get("EVAE_ELBO_SPLIT", "0") != "0"         # captured step: merge on the prior's stream, ELBO assembly beside it
+# (r04 A/B, profiles/r04_ab: the 7-block merge launch takes 10.7 us against the one-block merge + ELBO's 11.6 and the join it
+#  saves comes back as a 9-us gap in front of the prior's backward: c2 0.616-0.621 -> 0.623-0.629 ms.  Off; what replaced it:)
+# captured step on one device: the prior's forward partials, their merge and its backward as ONE launch in the forward pass
+# (csrc/evae_prior_train.h), the ELBO assembly on the side stream
+PRIOR_TRAIN = os.environ.get("EVAE_PRIOR_TRAIN", "1") != "0"
 GROUP_LEAVES = os.environ.get("EVAE_GROUP_LEAVES", "1") != "0"      # the batch rows' four leaf weight gradients as one launch
 IMG_DGRAD = os.environ.get("EVAE_IMG_DGRAD", "1") != "0" or bool(SCHED & 4)
 THIN_ROWS = 1024     # batch rows up to here take the fp32 split-K kernel for the first layer even on the byte store
@@ -68,6 +77,7 @@ THIN_ROWS = 1024     # batch rows up to here take the fp32 split-K kernel for th
 # fp32 kernels of r03
 P6 = os.environ.get("EVAE_P6", "1") != "0"
 _P6_READY = {}     # image buffer pointer -> (shape key) it was zero-filled (and its ones row written) for
+_ONES = {}         # device -> a one-element tensor holding 1.0 (the unit upstream gradient of a captured step)
 
 PARAM_ORDER = [
     "prior_log_variance",
@@ -296,6 +306,11 @@ class VaeExactLoss(torch.autograd.Function):
                                                            None, None, _vp(wq_), wq_.numel(), 3, kd.st), "bwd_weight_u8(gather)")
             return wq_, gen_
         lv_row = torch.empty(Z, **f32)                     # the prior's log-variance row
+        beta_dev = beta if torch.is_tensor(beta) else None
+        beta_host = 0.0 if beta_dev is not None else float(beta)
+        prior_train = bool(PRIOR_TRAIN and UNIT_UPSTREAM[0] and average and not sharded and Cl > 0 and not ONE_STREAM[0]
+                           and ops.prior_train_applies(B, Cl, Z))
+        coef = None
         with torch.cuda.stream(side):
             # (on the side stream, in front of everything: with the byte gather moved behind the batch-row chain the MAIN stream's
             # head GEMM is what the prior waits for, and this 5-us launch sat between the two)
@@ -346,6 +361,15 @@ class VaeExactLoss(torch.autograd.Function):
             kd.linear_fwd(D2, B, H, H, wp, bp, D, ACT_SIGMOID, 0.0, 0.0, xmean, None)
             _lib.check(lib.evae_bernoulli_ll_fwd(_vp(x), _vp(xmean), B, D, _vp(RE), kd.st), "bernoulli")
             re_ready = torch.cuda.Event(); re_ready.record()
+            if prior_train:
+                # the step's coefficient vectors (-1/B, beta/B, -beta/B: evae_elbo_bwd of a unit upstream gradient on the batch mean)
+                # HERE, on the stream whose backward chain reads them: that chain then waits for nothing of the prior's launch
+                coef = (torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32))
+                one = _ONES.get(dev)
+                if one is None:
+                    one = _ONES[dev] = torch.ones(1, **f32)
+                _lib.check(lib.evae_elbo_bwd(_vp(one), 1, None, 0, None, 0, _vp(beta_dev), beta_host, B, _vp(coef[0]), _vp(coef[1]),
+                                             _vp(coef[2]), kd.st), "elbo_bwd(unit)")
             if xt_late:
                 wq, xt_gen = xt_gather()
         ci_sel = None
@@ -379,6 +403,17 @@ class VaeExactLoss(torch.autograd.Function):
         ci = None if no_mask else (ci_sel if approx else ops._i64(ex_idx))
         logp = torch.empty(B, **f32); lse = torch.empty((2, B), **f32)      # lse: the (max, log sum) token of the merge
         z_all, zi_all = z, zi
+        prior_done = None
+        if prior_train:
+            # forward AND backward of the prior here: token, log p, dcentres (rows [0, Cl) of the head-gradient buffer the backward
+            # pass carries on with), dz' and dlogvar'.  ev_pre: what the side stream's backward chain waits for instead of the
+            # main stream's latest launch (it needs nothing of the prior before dz')
+            dmean_all = torch.empty((Mp, Z), **f32)
+            packed = torch.empty(B * Z + Z, **f32)
+            ev_pre = torch.cuda.Event(); ev_pre.record()
+            ops.prior_train_step(z, centres, lv_row, zi, ci, float(c_total), beta_dev if beta_dev is not None else beta_host,
+                                 out=(logp, lse, None, packed[:B * Z].view(B, Z), dmean_all[:Cl], packed[B * Z:]), stream=k.st)
+            prior_done = (dmean_all, packed, ev_pre)
         if sharded == 2:
             # data-parallel batches over sharded exemplars: every rank scores the queries of ALL ranks against its
             # shard (same pair count as B queries against all C), the partials go back to their owners
@@ -394,6 +429,8 @@ class VaeExactLoss(torch.autograd.Function):
         if sharded:
             R, ldp = m.shape[0], m.shape[1]
             pm, ps, pn = m, s, n
+        elif prior_train:
+            pass
         else:
             # one device: the per-split partials stay un-merged in the workspace
             nb = lib.evae_prior_lse_fwd_workspace_bytes(B, Cl, Z)
@@ -403,7 +440,11 @@ class VaeExactLoss(torch.autograd.Function):
                                                      w.numel(), C.byref(ns), C.byref(prow), k.st), "prior_lse_fwd_splits")
             R, ldp = ns.value, B
             pm = w.data_ptr(); ps = pm + 4 * prow.value * B; pn = ps + 4 * prow.value * B
-        if xt_late:
+        # captured step (unit upstream promise) on one device: merge on the main stream, ELBO assembly on the side stream
+        elbo_split = bool(ELBO_SPLIT and UNIT_UPSTREAM[0] and average and not sharded and xt_late and not ONE_STREAM[0])
+        if prior_train or elbo_split:
+            pass                             # the main stream does not meet the reconstruction term at all
+        elif xt_late:
             main.wait_event(re_ready)        # (the side stream carries on with the gather; the backward pass joins it)
         else:
             main.wait_stream(side)
@@ -411,10 +452,21 @@ class VaeExactLoss(torch.autograd.Function):
         #      means) in ONE launch
         loss = torch.empty(B, **f32); KL = torch.empty(B, **f32)
         means = torch.empty(3, **f32) if average else None
-        beta_dev = beta if torch.is_tensor(beta) else None
-        beta_host = 0.0 if beta_dev is not None else float(beta)
-        coef = None
-        if UNIT_UPSTREAM[0] and average and not sharded:
+        if prior_train:
+            pass          # loss / KL / means: assembled on the side stream by the backward pass, behind its wait for dz'
+        elif elbo_split:
+            # r04: the merge (token, logp, coefficients) is all the prior's backward waits for: it follows the partials on the main
+            # stream without meeting the side stream (a join and the single-block merge + ELBO launch less on the critical
+            # path); loss / KL / means are assembled on the side stream, which the backward pass joins before anyone reads them
+            coef = (torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32))
+            _lib.check(lib.evae_prior_merge_coef(_vp(pm), _vp(ps), _vp(pn), R, ldp, B, float(c_total), _vp(beta_dev), beta_host,
+                                                 _vp(logp), _vp(lse), _vp(coef[0]), _vp(coef[1]), _vp(coef[2]), k.st), "prior_merge_coef")
+            merged = torch.cuda.Event(); merged.record()
+            with torch.cuda.stream(side):
+                side.wait_event(merged)
+                _lib.check(lib.evae_elbo_assemble(_vp(logp), _vp(RE), _vp(logq), _vp(beta_dev), beta_host, B, _vp(loss), _vp(KL),
+                                                  _vp(means), kd.st), "elbo_assemble")
+        elif UNIT_UPSTREAM[0] and average and not sharded:
             # the caller (evae/graph.py) promises loss.backward(ones) on the batch mean and nothing else: the backward pass's
             # coefficient vectors are then known here (-1/B, beta/B, -beta/B) and its elbo_bwd launch is not needed
             coef = (torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32))
@@ -426,6 +478,10 @@ class VaeExactLoss(torch.autograd.Function):
                                                _vp(beta_dev), beta_host, _vp(logp), _vp(lse), _vp(loss), _vp(KL), _vp(means),
                                                k.st), "prior_elbo_fwd")
         ctx.coef = coef
+        # (kept until the backward pass has joined the side stream: the assembly reads / writes them there, behind launches of
+        #  the main stream that would otherwise be free to take their memory)
+        ctx.elbo_keep = (RE, logq, logp, loss, KL, means) if (elbo_split or prior_train) else None
+        ctx.prior_done = prior_done
         ctx.wt = WT_DONE.pop((wm.data_ptr(), w2h.data_ptr(), w2g.data_ptr()), None)
         ctx.set_materialize_grads(False)       # unused outputs (RE, KL) then arrive as None, not as zero-filled tensors
         ctx.k_dev = dev
@@ -500,7 +556,8 @@ class VaeExactLoss(torch.autograd.Function):
         main = torch.cuda.current_stream()
         side = k.side_stream()
         kd = _K(dev, stream=side, suffix="_side")
-        dmean_all = torch.empty((Mp, Z), **f32)
+        prior_done = ctx.prior_done is not None and ctx.coef is not None and cRE is ctx.coef[0]
+        dmean_all = ctx.prior_done[0] if prior_done else torch.empty((Mp, Z), **f32)
         dq2 = torch.empty((Mp, 2 * H), **f32)                              # [dh2 | dg2] for all C + B rows
         # byte store: encoder layer 1's (dh, dg) leave the layer-2 data gradient as the bf16 tile images its weight gradient
         # reads (no fp32 [Mp x 2H] buffer, no transposing pre-pass); needs row blocks in aligned fours
@@ -561,7 +618,10 @@ class VaeExactLoss(torch.autograd.Function):
         z_mean = mean_all[Cl:]
         off = 4 * Cl
         prior_finish = None
-        side.wait_stream(main)
+        if prior_done:
+            side.wait_event(ctx.prior_done[2])       # (not the prior's launch, which the forward pass put on the main stream)
+        else:
+            side.wait_stream(main)
         if sharded == 2:
             # data-parallel batches: the shard-side backward runs over the queries of all ranks (their lse and upstream
             # coefficients are gathered first); dz partials are summed over the shards and every rank keeps its rows.
@@ -581,7 +641,11 @@ class VaeExactLoss(torch.autograd.Function):
             dist.all_reduce(dz_all, op=dist.ReduceOp.SUM)
             r0 = dist.get_rank() * B
             dzp = dz_all[r0:r0 + B]
+        elif prior_done:
+            packed = ctx.prior_done[1]           # the forward pass ran the prior's backward with it (evae_prior_train_step)
+            dzp = packed[:B * Z].view(B, Z); dlv = packed[B * Z:]
         else:
+            assert ctx.prior_done is None, "fused vae step: the captured form's backward was called with another upstream gradient"
             packed = torch.empty(B * Z + Z, **f32)
             dzp = packed[:B * Z].view(B, Z); dlv = packed[B * Z:]
             nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cl, Z)
@@ -624,6 +688,9 @@ class VaeExactLoss(torch.autograd.Function):
         g_d2 = gslot("d2", 2 * H, H); g_e2 = gslot("e2", 2 * H)
         g_d1 = gslot("d1", 2 * H, Z); g_e1 = gslot("e1", 2 * H)
         g_wl = gslot("wl", Z, H); g_bl = gslot("bl", Z)
+        g_wm = gslot("wm", Z, H); g_bm = gslot("bm", Z)
+        fin_group = FINISH_GROUP and data_ext.dtype == torch.uint8 and not (SCHED & 10) and Mp > 128 and not p6
+        headw_early = bool(HEADW_EARLY and not fin_group and Cl > 0)
         with torch.cuda.stream(side):
             # through the Bernoulli log-likelihood and the sigmoid head at once, then down the decoder
             _lib.check(lib.evae_bernoulli_sigmoid_bwd(_vp(x), _vp(xmean), _vp(cRE), B, D, _vp(dpx), kd.st), "bernoulli_sigmoid_bwd")
@@ -633,10 +700,16 @@ class VaeExactLoss(torch.autograd.Function):
             side.wait_event(dz_ready)
             if prior_finish is not None:
                 prior_finish()
+            if prior_done:
+                RE_, logq_, logp_, loss_, KL_, means_ = ctx.elbo_keep
+                _lib.check(lib.evae_elbo_assemble(_vp(logp_), _vp(RE_), _vp(logq_), _vp(beta_dev), 0.0 if beta_dev is not None else float(beta),
+                                                  B, _vp(loss_), _vp(KL_), _vp(means_), kd.st), "elbo_assemble")
             # reparameterisation + log q (+ the prior's dz', + the Hardtanh of the log-variance head): one launch
             _lib.check(lib.evae_reparam_logq_bwd_hardtanh(_vp(z_mean), _vp(logvar), _vp(eps), _vp(z), _vp(dz), _vp(dzp), _vp(cKL),
                                                           _vp(lv_pre), -6.0, 2.0, B, Z, _vp(dmean_all.data_ptr() + off * Z),
                                                           _vp(dlvp), kd.st), "reparam_bwd")
+            if headw_early:
+                kd.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)       # mean head, all C + B rows
             # head and encoder layer 2, batch rows
             if p6:
                 # (fp32 rows for the batch rows' own layer-2 data gradient, and rows Cl .. of the image for the weight gradient)
@@ -653,17 +726,15 @@ class VaeExactLoss(torch.autograd.Function):
             l2_dgrad(kd, B, off, Cl)
             batch_rows_done.record()
 
-        g_wm = gslot("wm", Z, H); g_bm = gslot("bm", Z)
         # ONE finish launch for the three split-K weight gradients of the step (encoder layer 1 on the byte store, layer 2, mean
-        # head) at the very end, instead of one behind each GEMM: a dependent launch less on the main stream's chain
-        fin_group = FINISH_GROUP and data_ext.dtype == torch.uint8 and not (SCHED & 10) and Mp > 128 and not p6
+        # head) at the very end, instead of one behind each GEMM: a dependent launch less on the main stream's chain (fin_group)
 
         def leaves():     # nobody waits for them before the optimizer
             with torch.cuda.stream(side):
                 # mean head, all C + B rows (its finish joins the step's grouped finish launch when that is on)
                 if fin_group and FINISH_GROUP_HEAD:
                     kd.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm, phase=1, ws_name="wgradh")
-                else:
+                elif not headw_early:
                     kd.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)
                 # the four leaf layers whose contraction is the B batch rows: ONE grouped launch (evae_dense_bwd_weight_group;
                 # r02: four launches of 8-9 us each at the end of the side stream's chain)
@@ -689,7 +760,7 @@ class VaeExactLoss(torch.autograd.Function):
         # side stream's last thin data gradient, stretched to ~40 us beside the exemplar rows' GEMM).  r03: with the leaf
         # gradients as four launches this was 0.668 -> 0.684-0.694 ms (they then started behind layer 2's CU-filling launch and
         # ended after the main stream); with the leaves grouped into one launch it is 0.662-0.664 -> 0.658 ms.  SCHED & 256: off.
-        split_wait = not (SCHED & (256 | 10))
+        split_wait = bool(SCHED & 256) and not (SCHED & 10)    # r04: off -- the thin batch-row chain ends long before layer 2's data gradient; one join less (-4 us)
         main.wait_event(dq2_rows_done if split_wait else batch_rows_done)
         # ---- weight gradients of the two encoder layers over all C + B rows
         #      (layer 2's finish launch runs on the side stream, beside layer 1's GEMM instead of in front of it)
@@ -775,6 +846,8 @@ class VaeExactLoss(torch.autograd.Function):
             w1_grad()
         main.wait_stream(side)
         ctx.bufs = None
+        ctx.elbo_keep = None
+        ctx.prior_done = None
         grads = (g_plv, g_wp, g_bp, g_w1[:H], g_b1[:H], g_w1[H:], g_b1[H:], g_w2[:H], g_b2[:H], g_w2[H:], g_b2[H:],
                  g_wm, g_bm, g_wl, g_bl, g_d1[:H], g_e1[:H], g_d1[H:], g_e1[H:], g_d2[:H], g_e2[:H], g_d2[H:], g_e2[H:])
         return (None,) * 15 + grads

@@ -207,6 +207,53 @@ def prior_merge(m, s, n, c_total, out=None):
     return lp, lse
 
 
+_PT_STATE = {}
+
+
+def prior_train_state(device):
+    """The 256-byte inter-block state of evae_prior_train_step: one per device and stream tag, zeroed when it is made and never again"""
+    tag = _SIDE_STREAMS.get(int(torch.cuda.current_stream(device).cuda_stream), "") if _SIDE_STREAMS else ""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    st = _PT_STATE.get(key)
+    if st is None:
+        st = _PT_STATE[key] = torch.zeros(64, dtype=torch.int32, device=device)
+    return st
+
+
+def prior_train_applies(B, Cn, zd):
+    return bool(_lib.load().evae_prior_train_applies(int(B), int(Cn), int(zd)))
+
+
+def prior_train_step(z, centres, log_var, z_idx, c_idx, c_total, beta, want_coef=True, out=None, phase=0, stream=None):
+    """The exemplar prior of a captured training step in one launch (+ the dz / dlogvar reduction): returns
+    (logp [B], token [2 x B], (cRE, cKL, neg_cKL) or None, dz [B x z], dcentres [C x z], dlogvar [z]) for the loss
+    mean_i(beta (logq_i - logp_i) - RE_i) with upstream gradient 1 (csrc/evae_prior_train.h).  `beta`: float or device scalar.
+    `out` = caller-allocated (logp, token, coef, dz, dcentres, dlogvar)."""
+    lib = _lib.load()
+    _need_cuda(z, centres, log_var, z_idx, c_idx)
+    z, centres, log_var = _f32(z), _f32(centres), _f32(log_var).reshape(-1)
+    B, zd = z.shape
+    Cn = centres.shape[0]
+    z_idx, c_idx = _i64(z_idx), _i64(c_idx)
+    if z_idx is None or c_idx is None:
+        z_idx = c_idx = None
+    dev = z.device
+    if out is None:
+        f = dict(device=dev, dtype=torch.float32)
+        coef = (torch.empty(B, **f), torch.empty(B, **f), torch.empty(B, **f)) if want_coef else None
+        out = (torch.empty(B, **f), torch.empty((2, B), **f), coef, torch.empty((B, zd), **f), torch.empty((Cn, zd), **f), torch.empty(zd, **f))
+    logp, token, coef, dz, dc, dlv = out
+    beta_dev = beta if torch.is_tensor(beta) else None
+    ws = _workspace("prior_train", lib.evae_prior_train_workspace_bytes(B, Cn, zd), dev)
+    st = prior_train_state(dev)
+    c3 = coef if coef is not None else (None, None, None)
+    _lib.check(lib.evae_prior_train_step(_p(z), B, _p(centres), Cn, zd, _p(log_var), _p(z_idx), _p(c_idx), float(c_total), _p(beta_dev),
+                                         0.0 if beta_dev is not None else float(beta), _p(logp), _p(token), _p(c3[0]), _p(c3[1]), _p(c3[2]),
+                                         _p(dz), _p(dc), _p(dlv), _p(st), _p(ws), ws.numel(), int(phase),
+                                         _stream() if stream is None else stream), "evae_prior_train_step")
+    return out
+
+
 def prior_lse_bwd(z, centres, log_var, z_idx, c_idx, lse, grad_out):
     lib = _lib.load()
     _need_cuda(z, centres, log_var, lse, grad_out)

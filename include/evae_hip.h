@@ -113,6 +113,31 @@ int evae_prior_elbo_fwd_coef(const float* pmax, const float* psum, const float* 
                              const float* RE, const float* logq, const float* beta_dev, float beta_host, float* logp, float* lse,
                              float* loss, float* KL, float* means, float* cRE, float* cKL, float* neg_cKL, evae_stream_t stream);
 
+/* evae_prior_elbo_fwd(_coef) as two launches for a step on two streams: the merge of the partial rows (token, logp and -- all
+ * three or none -- the coefficient vectors) needs nothing of the reconstruction term and is all the prior's backward waits for;
+ * the ELBO assembly (loss, KL, batch means; models/BaseModel.py:71-75,124-125) runs on the stream that produced RE. */
+int evae_prior_merge_coef(const float* pmax, const float* psum, const float* pnmask, int R, int ldp, int B, float c_total,
+                          const float* beta_dev, float beta_host, float* logp /* [B] */, float* lse /* token [2 B] */,
+                          float* cRE, float* cKL, float* neg_cKL, evae_stream_t stream);
+int evae_elbo_assemble(const float* logp, const float* RE, const float* logq, const float* beta_dev, float beta_host, int B,
+                       float* loss /* [B] */, float* KL /* [B] */, float* means /* [3] or NULL */, evae_stream_t stream);
+
+/* The prior of a CAPTURED training step (one device, B <= 128 queries, C <= 30 720 exemplars, zdim <= 56 and a multiple of 4) as one
+ * launch + the dz / dlogvar reduction: forward partials, their merge (two levels of last-arriving blocks, fixed order) and the
+ * backward of -beta / B * sum_i logp_i on the products each block still holds (csrc/evae_prior_train.h).  Replaces
+ * evae_prior_lse_fwd_splits + evae_prior_merge_coef / evae_prior_elbo_fwd_coef + evae_prior_lse_bwd under the promise of
+ * evae_prior_elbo_fwd_coef (batch mean of the loss, upstream gradient 1); same arithmetic per pair as those kernels' matrix-core
+ * paths (models/BaseModel.py:98-128 and what autograd derives from it).  `state`: 256 bytes of device memory, zeroed ONCE by the
+ * caller and handed to every call (inter-block counters and a generation word; word 10 counts blocks whose bounded wait ran out --
+ * never, unless the grid was not co-resident).  phase 0: both launches; 1: the kernel; 2: the reduction (dz, dlogvar). */
+int evae_prior_train_applies(int B, int C, int zdim);
+size_t evae_prior_train_workspace_bytes(int B, int C, int zdim);
+int evae_prior_train_step(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+                          const int64_t* z_idx, const int64_t* c_idx, float c_total, const float* beta_dev, float beta_host,
+                          float* logp /* [B] */, float* token /* [2 B] */, float* cRE, float* cKL, float* neg_cKL,
+                          float* dz /* [B x zdim] */, float* dcentres /* [C x zdim] */, float* dlogvar /* [zdim] */, void* state,
+                          void* ws, size_t ws_bytes, int phase, evae_stream_t stream);
+
 /* Backward of sum_i grad_out_i * logprior_i through the prior (what autograd derives from
  * BaseModel.py:98-128 + distributions.py:12-25), by recomputation from the saved row LSE:
  *   w_ij = exp(p_ij - lse_i);  dz_i = sum_j g_i w_ij (c_j - z_i)/var;  dc_j = sum_i g_i w_ij (z_i - c_j)/var;

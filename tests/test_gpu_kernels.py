@@ -1168,3 +1168,109 @@ def test_heads_density_function_and_its_gradients(ops, M, K, Z):
             assert rel(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 2e-6
         for name, a, b in zip("h wm bm wl bl zq".split(), leaves, ref):
             assert rel(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < 5e-6, (name, only_density)
+
+
+@pytest.mark.parametrize("R,B", [(196, 100), (1, 1), (3, 17), (300, 130), (64, 16)])
+def test_elbo_tail_as_two_launches_equals_the_one_launch_form(ops, R, B):
+    """evae_prior_merge_coef + evae_elbo_assemble (r04: merge on the prior's stream, assembly beside the backward) against
+    evae_prior_elbo_fwd_coef on the same partial rows (some rows and whole queries empty), and against a float64 merge"""
+    import ctypes as C
+    lib = ops._lib.load()
+    rng = np.random.default_rng(R * 1000 + B)
+    pm = rng.normal(-300.0, 40.0, (R, B)).astype(np.float32)
+    ps = rng.uniform(1.0, 50.0, (R, B)).astype(np.float32)
+    pn = rng.integers(0, 3, (R, B)).astype(np.float32)
+    empty = rng.random((R, B)) < 0.1
+    pm[empty] = -np.inf; ps[empty] = 0.0
+    if B > 4:
+        pm[:, 3] = -np.inf; ps[:, 3] = 0.0          # a query with no unmasked exemplar at all
+    RE = rng.normal(-90.0, 5.0, B).astype(np.float32); lq = rng.normal(-40.0, 3.0, B).astype(np.float32)
+    beta, ct = 0.37, 5000.0
+    d = {k: dev(v) for k, v in dict(pm=pm, ps=ps, pn=pn, RE=RE, lq=lq).items()}
+    vp = lambda t_: C.c_void_p(t_.data_ptr())
+    st = ops._stream()
+    outs = []
+    for two in (False, True):
+        o = {k: torch.full((n_,), 7.0, device="cuda") for k, n_ in dict(logp=B, lse=2 * B, loss=B, KL=B, means=3, cRE=B, cKL=B, nck=B).items()}
+        if two:
+            ops._lib.check(lib.evae_prior_merge_coef(vp(d["pm"]), vp(d["ps"]), vp(d["pn"]), R, B, B, ct, None, beta, vp(o["logp"]),
+                                                     vp(o["lse"]), vp(o["cRE"]), vp(o["cKL"]), vp(o["nck"]), st), "merge_coef")
+            ops._lib.check(lib.evae_elbo_assemble(vp(o["logp"]), vp(d["RE"]), vp(d["lq"]), None, beta, B, vp(o["loss"]), vp(o["KL"]),
+                                                  vp(o["means"]), st), "assemble")
+        else:
+            ops._lib.check(lib.evae_prior_elbo_fwd_coef(vp(d["pm"]), vp(d["ps"]), vp(d["pn"]), R, B, B, ct, vp(d["RE"]), vp(d["lq"]), None,
+                                                        beta, vp(o["logp"]), vp(o["lse"]), vp(o["loss"]), vp(o["KL"]), vp(o["means"]),
+                                                        vp(o["cRE"]), vp(o["cKL"]), vp(o["nck"]), st), "elbo_fwd_coef")
+        torch.cuda.synchronize()
+        outs.append({k: v.cpu().numpy() for k, v in o.items()})
+    a, b = outs
+    for k in ("cRE", "cKL", "nck"):
+        assert np.array_equal(a[k], b[k]), k
+    fin = np.isfinite(a["logp"])
+    assert np.array_equal(fin, np.isfinite(b["logp"]))
+    # float64 merge of the same partials
+    M = pm.max(0).astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        S = np.where(np.isinf(pm), 0.0, ps.astype(np.float64) * np.exp(pm.astype(np.float64) - M)).sum(0)
+    ref_lp = M + np.log(np.where(S > 0, S, 1.0)) - np.log(ct - pn.astype(np.float64).sum(0))
+    assert rel(b["logp"][fin], ref_lp[fin]) < 2e-7
+    assert rel(a["logp"][fin], b["logp"][fin]) < 2e-7
+    assert np.array_equal(a["lse"][:B], b["lse"][:B])                      # the token's row maximum is exact
+    assert np.abs(a["lse"][B:][fin] - b["lse"][B:][fin]).max() < 1e-5
+    for k in ("loss", "KL"):
+        assert rel(a[k][fin], b[k][fin]) < 2e-7, k
+    if fin.all():
+        assert rel(a["means"], b["means"]) < 1e-6
+
+
+@pytest.mark.parametrize("B,C,zd,masked,limit", [(100, 25000, 40, True, None), (100, 25000, 40, False, None), (100, 200, 40, True, None),
+                                                 (128, 30720, 40, True, None), (1, 1, 40, False, None), (7, 129, 8, True, None),
+                                                 (100, 3125, 56, True, None), (100, 1000, 40, True, 0.0), (33, 11500, 40, True, None),
+                                                 (64, 1000, 4, False, 0.0)])
+def test_prior_of_a_training_step_in_one_launch(ops, B, C, zd, masked, limit):
+    """evae_prior_train_step (forward partials, two-level last-arriver merge, backward on the products each block holds) against
+    the three-launch path it replaces (evae_prior_lse_fwd + evae_prior_merge + evae_prior_lse_bwd) and against float64; launched
+    repeatedly with CHANGING inputs on the same buffers, so that a stale token / partial row from the previous launch
+    (another XCD's L2, this CU's L1) cannot pass; limit = 0 sends every tile through the direct-difference path"""
+    import ctypes as C_
+    lib = ops._lib.load()
+    assert ops.prior_train_applies(B, C, zd)
+    if limit is not None:
+        lib.evae_prior_set_norm_limit(C_.c_float(limit))
+    try:
+        lv = np.linspace(-1.5, -0.5, zd).astype(np.float32)
+        beta = 0.73
+        out = None
+        for it in range(6):
+            z, c = gi.clustered_latents(500 + 17 * it + B + C, B, C, zd)
+            z = (z * (1.0 + 0.3 * it)).astype(np.float32)
+            zi, ci = gi.mask_indices(7 + B + it, B, C, max(C // 2, 4))
+            if masked and C > 8 and it > 0:
+                ci[6] = -3                                            # a slot masked for every query (EVAE_PRIOR_MASK_ALL)
+            dz_, dc_, dlv_ = dev(z), dev(c), dev(lv)
+            zi_ = dev(zi) if masked else None; ci_ = dev(ci) if masked else None
+            out = ops.prior_train_step(dz_, dc_, dlv_, zi_, ci_, C, beta, out=out)
+            logp, token, coef, gz, gc, glv = out
+            m, s, n, _ = ops.prior_lse_fwd(dz_, dc_, dlv_, zi_, ci_)
+            lp_ref, tok_ref = ops.prior_merge(m, s, n, C)
+            g = torch.full((B,), -beta / B, device="cuda")
+            rz, rc, rlv = ops.prior_lse_bwd(dz_, dc_, dlv_, zi_, ci_, tok_ref, g)
+            torch.cuda.synchronize()
+            fin = torch.isfinite(lp_ref).cpu().numpy()
+            assert np.array_equal(fin, torch.isfinite(logp).cpu().numpy())
+            assert rel(logp.cpu().numpy()[fin], lp_ref.cpu().numpy()[fin]) < 3e-7, it
+            assert np.array_equal(token[0].cpu().numpy(), tok_ref[0].cpu().numpy()), it             # row maxima: exact
+            assert np.abs(token[1].cpu().numpy()[fin] - tok_ref[1].cpu().numpy()[fin]).max() < 2e-5, it
+            for a, b, name in ((gz, rz, "dz"), (gc, rc, "dcentres"), (glv, rlv, "dlogvar")):
+                assert rel(a.cpu().numpy(), b.cpu().numpy()) < 3e-5, (name, it)
+            assert np.array_equal(coef[0].cpu().numpy(), np.full(B, -1.0 / B, np.float32))
+            assert np.allclose(coef[1].cpu().numpy(), beta / B) and np.allclose(coef[2].cpu().numpy(), -beta / B)
+            assert int(ops.prior_train_state(torch.device("cuda", 0))[10]) == 0                     # no block's wait ran out
+            if it == 0 and B * C <= 4_000_000 and limit is None:
+                # float64 restatement (oracle primitives): log p and its gradient through the mean-of-batch coefficient
+                lp64 = orc.logsumexp_rows(orc.log_p_z_exemplar(z, zi, c, lv[None, :], ci, test=not masked))
+                ok = np.isfinite(lp64)
+                assert rel(logp.cpu().numpy()[ok], lp64[ok]) < 1e-5
+    finally:
+        if limit is not None:
+            lib.evae_prior_set_norm_limit(C_.c_float(-1.0))
