@@ -203,7 +203,8 @@ class GraphedTrainStep:
             from . import fused_vae
             fused_vae.PREP_DONE.clear()           # (a token the fused step did not consume must not outlive this step)
             fused_vae.WT_DONE.clear()
-        loss.backward(gradient=self._one)
+        with ops.deferred_wgrads(loss):          # thin layers' weight gradients behind the backward pass, grouped (evae/ops.py)
+            loss.backward(gradient=self._one)
         # the step's statistics ride in the optimizer's last launch (evae_adam_normgrad_step_stats)
         stats = (loss.detach(), RE.detach(), KL.detach(), self.out, self.totals) if os.environ.get("EVAE_TAIL_MERGE", "1") != "0" else None
         if eager_opt:

@@ -41,6 +41,7 @@ def _need_cuda(*ts):
                 "evae ops run on MI355X only (got a %s tensor); there is no CPU fallback" % t.device)
 
 
+_SIDE_STREAM_OBJS = []     # ... the stream objects themselves
 _SIDE_STREAMS = {}         # raw handle -> tag of streams registered as "side" streams: launches issued there get their own workspaces
 
 
@@ -49,6 +50,8 @@ def register_side_stream(stream, tag="side"):
     second stream (evae/fused_vae.py, models/AbsHModel.py) registers that stream here: every workspace requested while it is
     the current stream -- also from autograd's backward nodes, which run on the stream of their forward -- is a separate buffer."""
     _SIDE_STREAMS[int(stream.cuda_stream)] = tag
+    if all(s_.cuda_stream != stream.cuda_stream for s_ in _SIDE_STREAM_OBJS):
+        _SIDE_STREAM_OBJS.append(stream)
 
 
 _MODEL_SIDE = {}
@@ -394,12 +397,105 @@ def _vp(ptr):
     return C.c_void_p(ptr)
 
 
-def _bwd_weight(dy, x, rows, K, want_db=True):
-    """dw [N x K] = dy^T x(rows), db [N]; dy may be the combined [M x 2N] buffer [dh | dg]."""
+# Weight gradients of thin layers (a contraction over <= 128 batch rows) are leaves of the backward pass: nothing but the optimizer
+# reads them, yet each one is a launch on the chain of data gradients (8-15 us apiece in the 2-level model's step, a dozen of them).
+# Inside `with ops.deferred_wgrads():` (the captured step and utils.training put it around loss.backward()) such a gradient is only
+# ALLOCATED where autograd asks for it and the products are formed behind the backward pass, six jobs per grouped launch
+# (evae_dense_bwd_weight_group), on the stream the layer's backward ran on.  Only weights that ONE layer application uses per pass
+# qualify (a weight met twice -- q(z2 | x) runs over the exemplar rows and over the batch, through whichever Functions -- has its two
+# gradients added by autograd as soon as both exist): the scope walks the loss's autograd graph once and keeps the leaves that
+# exactly one edge leads to; a deferred weight that turns up a second time after all is flushed at once with every stream made
+# to wait for it.  EVAE_DEFER_WGRAD=0: off.
+_DEFER = [None]
+_DEFER_ON = os.environ.get("EVAE_DEFER_WGRAD", "1") != "0"
+
+
+def _flush_wgrads(jobs, everyone_waits=False):
+    """launch the pending jobs, grouped by the stream their layer's backward ran on; the current stream (everyone_waits: every
+    registered stream) then waits for those launches"""
+    lib = _lib.load()
+    cur = torch.cuda.current_stream()
+    by_stream = {}
+    for j in jobs:
+        by_stream.setdefault(j[8].cuda_stream, (j[8], []))[1].append(j)
+    for st, js in by_stream.values():
+        for i in range(0, len(js), 6):
+            part = js[i:i + 6]
+            arr = (_lib.WgradJob * len(part))()
+            for a, (dy, M, N, x, K, dw, db, _key, _st) in zip(arr, part):
+                a.dy = dy.data_ptr(); a.x = x.data_ptr(); a.dw = dw.data_ptr(); a.db = db.data_ptr()
+                a.M, a.N, a.K, a.ldy, a.ldx = M, N, K, dy.stride(0), x.stride(0)
+            _lib.check(lib.evae_dense_bwd_weight_group(C.cast(arr, C.c_void_p), len(part), C.c_void_p(st.cuda_stream)),
+                       "evae_dense_bwd_weight_group(deferred)")
+        waiters = [cur]
+        if everyone_waits:
+            waiters += [s_ for s_ in _SIDE_STREAM_OBJS if s_.cuda_stream != cur.cuda_stream]
+        for w_ in waiters:
+            if w_.cuda_stream != st.cuda_stream:
+                w_.wait_stream(st)
+
+
+def _single_use_leaves(root):
+    """data pointers of the leaf tensors that exactly ONE edge of root's autograd graph leads to (one layer application per pass)"""
+    counts = {}
+    fn0 = getattr(root, "grad_fn", None)
+    if fn0 is None:
+        return set()
+    seen, stack = {fn0}, [fn0]
+    while stack:
+        n = stack.pop()
+        for nf, _ in n.next_functions:
+            if nf is None:
+                continue
+            v = getattr(nf, "variable", None)
+            if v is not None:                      # AccumulateGrad of a leaf
+                counts[v.data_ptr()] = counts.get(v.data_ptr(), 0) + 1
+            elif nf not in seen:
+                seen.add(nf); stack.append(nf)
+    return {k for k, c in counts.items() if c == 1}
+
+
+class deferred_wgrads:
+    """with ops.deferred_wgrads(loss): loss.backward() -- `loss`: the tensor whose graph is about to be walked backwards (None: the
+    scope defers nothing)"""
+
+    def __init__(self, root=None):
+        self.root = root
+
+    def __enter__(self):
+        self.prev = _DEFER[0]
+        _DEFER[0] = {"jobs": [], "uses": {}, "single": _single_use_leaves(self.root)} if (_DEFER_ON and self.root is not None) else None
+        self.root = None
+        return self
+
+    def __exit__(self, et, ev, tb):
+        cur, _DEFER[0] = _DEFER[0], self.prev
+        if cur is not None and et is None and cur["jobs"]:
+            _flush_wgrads(cur["jobs"])
+        return False
+
+
+def _bwd_weight(dy, x, rows, K, want_db=True, key=None):
+    """dw [N x K] = dy^T x(rows), db [N]; dy may be the combined [M x 2N] buffer [dh | dg].  `key`: identity of the weight
+    (its data pointer) for the deferred form above."""
     lib = _lib.load()
     M, N = dy.shape
     dw = torch.empty((N, K), device=dy.device)
     db = torch.empty(N, device=dy.device) if want_db else None
+    cur = _DEFER[0]
+    if cur is not None and key is not None:
+        uses = cur["uses"][key] = cur["uses"].get(key, 0) + 1
+        if uses > 1 and any(j[7] == key for j in cur["jobs"]):
+            # a deferred weight used again in this pass: autograd is about to add the two gradients
+            _flush_wgrads(cur["jobs"], everyone_waits=True); cur["jobs"] = []
+        elif (uses == 1 and key in cur["single"] and rows is None and want_db and 0 < M <= 128 and N % 4 == 0 and K % 4 == 0
+              and dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.stride(1) == 1 and x.stride(1) == 1
+              and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and (dy.data_ptr() | x.data_ptr()) % 16 == 0):
+            # (autograd gets VIEWS of dw / db: AccumulateGrad installs a gradient it is handed without copying only while nobody
+            #  else holds that tensor object -- handed the buffers the job keeps, it would clone them, still unfilled; and a view
+            #  made here holds its base, so it is the job that keeps the bases)
+            cur["jobs"].append((dy, M, N, x, K, dw, db, key, torch.cuda.current_stream()))
+            return dw.view(N, K), db.view(N)
     nb = lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
     ws = _workspace("wgrad", nb, dy.device)
     _lib.check(lib.evae_dense_bwd_weight(_p(dy), M, N, dy.stride(0), _p(x), _p(rows), K, x.stride(0), _p(dw),
@@ -475,7 +571,7 @@ class GatedDenseFn(torch.autograd.Function):
         base = dpre.data_ptr()
         _lib.check(lib.evae_gated_dense_bwd_input_ld(_p(dout), dout.stride(0), _p(gout), _p(s), M, N, _vp(base), _vp(base + 4 * N),
                                                      2 * N, _stream()), "evae_gated_dense_bwd_input_ld")
-        dw, db = _bwd_weight(dpre, x, rows, K)                    # [dWh ; dWg], [dbh ; dbg]
+        dw, db = _bwd_weight(dpre, x, rows, K, key=wh.data_ptr())  # [dWh ; dWg], [dbh ; dbg]
         dx = None
         if ctx.needs_input_grad[0]:
             if rows is not None:
@@ -654,7 +750,7 @@ class LinearFn(torch.autograd.Function):
                        "evae_act_bwd")
         else:
             dpre = dy
-        dw, db = _bwd_weight(dpre, x, rows, w.shape[1])
+        dw, db = _bwd_weight(dpre, x, rows, w.shape[1], key=w.data_ptr())
         dx = None
         if ctx.needs_input_grad[0]:
             if rows is not None:

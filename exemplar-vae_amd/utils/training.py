@@ -6,6 +6,7 @@ HBM (the model keeps a device-resident copy of dataset.tensors[0])."""
 import torch
 
 from evae import hostcpu, shard
+from evae import ops as _ops
 from evae.graph import GraphedTrainStep
 
 
@@ -44,7 +45,8 @@ def train_one_epoch(epoch, args, train_loader, model, optimizer):
         optimizer.zero_grad()
         loss, RE, KL = model.calculate_loss((x, indices), beta, average=True, cache=cache,
                                             dataset=train_loader.dataset)
-        loss.backward()
+        with _ops.deferred_wgrads(loss):         # thin layers' weight gradients grouped behind the backward pass (evae/ops.py)
+            loss.backward()
         optimizer.step()
         with torch.no_grad():
             step_vals = torch.stack((loss.detach(), -RE.detach(), KL.detach()))

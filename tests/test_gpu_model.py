@@ -1164,3 +1164,46 @@ def test_two_level_step_at_c4_size_matches_the_oracle():
     loss_ref = -RE_ref + beta * KL_ref
     for name, got, ref in (("RE", RE, RE_ref), ("KL", KL, KL_ref), ("loss", loss, loss_ref)):
         assert rel(got.detach().cpu().numpy(), ref) < 1e-4, (name, rel(got.detach().cpu().numpy(), ref))
+
+
+@pytest.mark.parametrize("model_name,C", [("hvae_2level", 11500), ("hvae_2level", 120), ("vae", 200)])
+def test_deferred_grouped_weight_gradients_equal_the_inline_ones(model_name, C):
+    """ops.deferred_wgrads (r04): the thin layers' weight gradients allocated where autograd asks for them and filled by grouped
+    launches behind the backward pass -- every parameter's gradient bit-identical to the launch-per-layer form (the same
+    kernel body per job), none left unfilled (the buffers are poisoned with NaN first through the allocator)"""
+    from evae import ops
+    from utils.utils import importing_model
+    B, N = 100, 2 * C + 300
+    data = torch.from_numpy(gi.binary_images(9, N))
+    dataset = torch.utils.data.TensorDataset(data, torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    args = smoke_case.vae_args(model_name=model_name, number_components=C, training_set_size=N, batch_size=B)
+    torch.manual_seed(21)
+    model = importing_model(args)(args).cuda()
+    model.train()
+    model._use_fused = False                                      # the modular autograd path (the fused `vae` node has its own grouping)
+    x = data[:B].cuda(); idx = torch.arange(B, device="cuda").reshape(-1, 1)
+    g = torch.Generator(device="cuda")
+    grads = []
+    for deferred in (False, True):
+        g.manual_seed(5); model._eps_generator = g
+        torch.manual_seed(77)
+        model.zero_grad(set_to_none=True)
+        loss, RE, KL = model.calculate_loss((x, idx), 0.5, average=True, dataset=dataset)
+        torch.cuda.synchronize()
+        poison = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]      # what the backward's buffers will be cut from
+        del poison
+        if deferred:
+            with ops.deferred_wgrads(loss):
+                loss.backward()
+                njobs = len(ops._DEFER[0]["jobs"])
+            assert njobs >= (8 if model_name == "hvae_2level" else 3), njobs
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    model._eps_generator = None
+    a, b = grads
+    assert set(a) == set(b) and len(a) >= 10
+    for k in a:
+        assert torch.isfinite(b[k]).all(), k
+        assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
