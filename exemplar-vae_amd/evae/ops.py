@@ -475,6 +475,30 @@ class deferred_wgrads:
         return False
 
 
+def _try_defer(dy, x, K, key, dw=None, db=None):
+    """(dw, db) views for autograd with the product left to the scope's grouped launches, or None (not deferrable: compute now)"""
+    cur = _DEFER[0]
+    if cur is None or key is None:
+        return None
+    M, N = dy.shape
+    uses = cur["uses"][key] = cur["uses"].get(key, 0) + 1
+    if uses > 1 and any(j[7] == key for j in cur["jobs"]):
+        # a deferred weight used again in this pass: autograd is about to add the two gradients
+        _flush_wgrads(cur["jobs"], everyone_waits=True); cur["jobs"] = []
+        return None
+    if not (uses == 1 and key in cur["single"] and 0 < M <= 128 and N % 4 == 0 and K % 4 == 0
+            and dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.stride(1) == 1 and x.stride(1) == 1
+            and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and (dy.data_ptr() | x.data_ptr()) % 16 == 0):
+        return None
+    if dw is None:
+        dw = torch.empty((N, K), device=dy.device); db = torch.empty(N, device=dy.device)
+    # (autograd gets VIEWS of dw / db: AccumulateGrad installs a gradient it is handed without copying only while nobody
+    #  else holds that tensor object -- handed the buffers the job keeps, it would clone them, still unfilled; and a view
+    #  made here holds its base, so it is the job that keeps the bases)
+    cur["jobs"].append((dy, M, N, x, K, dw, db, key, torch.cuda.current_stream()))
+    return dw.view(N, K), db.view(N)
+
+
 def _bwd_weight(dy, x, rows, K, want_db=True, key=None):
     """dw [N x K] = dy^T x(rows), db [N]; dy may be the combined [M x 2N] buffer [dh | dg].  `key`: identity of the weight
     (its data pointer) for the deferred form above."""
@@ -482,20 +506,10 @@ def _bwd_weight(dy, x, rows, K, want_db=True, key=None):
     M, N = dy.shape
     dw = torch.empty((N, K), device=dy.device)
     db = torch.empty(N, device=dy.device) if want_db else None
-    cur = _DEFER[0]
-    if cur is not None and key is not None:
-        uses = cur["uses"][key] = cur["uses"].get(key, 0) + 1
-        if uses > 1 and any(j[7] == key for j in cur["jobs"]):
-            # a deferred weight used again in this pass: autograd is about to add the two gradients
-            _flush_wgrads(cur["jobs"], everyone_waits=True); cur["jobs"] = []
-        elif (uses == 1 and key in cur["single"] and rows is None and want_db and 0 < M <= 128 and N % 4 == 0 and K % 4 == 0
-              and dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.stride(1) == 1 and x.stride(1) == 1
-              and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and (dy.data_ptr() | x.data_ptr()) % 16 == 0):
-            # (autograd gets VIEWS of dw / db: AccumulateGrad installs a gradient it is handed without copying only while nobody
-            #  else holds that tensor object -- handed the buffers the job keeps, it would clone them, still unfilled; and a view
-            #  made here holds its base, so it is the job that keeps the bases)
-            cur["jobs"].append((dy, M, N, x, K, dw, db, key, torch.cuda.current_stream()))
-            return dw.view(N, K), db.view(N)
+    if rows is None and want_db and key is not None:
+        d = _try_defer(dy, x, K, key, dw, db)
+        if d is not None:
+            return d
     nb = lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
     ws = _workspace("wgrad", nb, dy.device)
     _lib.check(lib.evae_dense_bwd_weight(_p(dy), M, N, dy.stride(0), _p(x), _p(rows), K, x.stride(0), _p(dw),
@@ -1152,13 +1166,23 @@ def _heads_bwd(h, wm, wl, dmu, dlvp, want_dh, has_bias):
     Z = wm.shape[0]
     dh = _bwd_data(dmu.data_ptr(), wm, dlvp.data_ptr(), wl, M, Z, Z, h.device) if want_dh else None
     if M <= 128 and Z % 4 == 0 and K % 4 == 0 and h.stride(0) % 4 == 0:
-        dwm = torch.empty((Z, K), device=h.device); dwl = torch.empty_like(dwm)
-        dbm = torch.empty(Z, device=h.device); dbl = torch.empty_like(dbm)
-        arr = (_lib.WgradJob * 2)()
-        for j, (dy_, dw_, db_) in enumerate(((dmu, dwm, dbm), (dlvp, dwl, dbl))):
-            arr[j].dy = dy_.data_ptr(); arr[j].x = h.data_ptr(); arr[j].dw = dw_.data_ptr(); arr[j].db = db_.data_ptr()
-            arr[j].M, arr[j].N, arr[j].K, arr[j].ldy, arr[j].ldx = M, Z, K, Z, h.stride(0)
-        _lib.check(lib.evae_dense_bwd_weight_group(C.cast(arr, C.c_void_p), 2, _stream()), "evae_dense_bwd_weight_group")
+        # each head on its own: deferred behind the backward pass when its weight allows (ops.deferred_wgrads; the mean head of
+        # q(z2 | x) also encodes the exemplar rows and does not), what is left as one grouped launch here
+        res, now = {}, []
+        for name, dy_, w_ in (("m", dmu, wm), ("l", dlvp, wl)):
+            d = _try_defer(dy_, h, K, w_.data_ptr())
+            if d is not None:
+                res[name] = d
+            else:
+                dw_ = torch.empty((Z, K), device=h.device); db_ = torch.empty(Z, device=h.device)
+                res[name] = (dw_, db_); now.append((dy_, dw_, db_))
+        if now:
+            arr = (_lib.WgradJob * len(now))()
+            for j, (dy_, dw_, db_) in enumerate(now):
+                arr[j].dy = dy_.data_ptr(); arr[j].x = h.data_ptr(); arr[j].dw = dw_.data_ptr(); arr[j].db = db_.data_ptr()
+                arr[j].M, arr[j].N, arr[j].K, arr[j].ldy, arr[j].ldx = M, Z, K, dy_.stride(0), h.stride(0)
+            _lib.check(lib.evae_dense_bwd_weight_group(C.cast(arr, C.c_void_p), len(now), _stream()), "evae_dense_bwd_weight_group")
+        (dwm, dbm), (dwl, dbl) = res["m"], res["l"]
     else:
         dwm, dbm = _bwd_weight(dmu, h, None, K)
         dwl, dbl = _bwd_weight(dlvp, h, None, K)
