@@ -194,11 +194,13 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)      # backward then installs the fused node's gradient buffers
         from . import fused_vae as _fv
         _fv.UNIT_UPSTREAM[0] = os.environ.get("EVAE_UNIT_UPSTREAM", "1") != "0"     # the backward below is loss.backward(ones), nothing else
+        ops.STEP_BETA[0] = self.beta if _fv.UNIT_UPSTREAM[0] else None              # (the modular paths' prior: ops.prior_logp)
         try:
             loss, RE, KL = self.model.calculate_loss((x, self.idx_in), self.beta, average=True, dataset=self.dataset,
                                                      cache=self.cache)
         finally:
             _fv.UNIT_UPSTREAM[0] = False
+            ops.STEP_BETA[0] = None
         if self.by_index and self.u8:
             from . import fused_vae
             fused_vae.PREP_DONE.clear()           # (a token the fused step did not consume must not outlive this step)

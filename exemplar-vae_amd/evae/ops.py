@@ -299,6 +299,45 @@ class PriorLogP(torch.autograd.Function):
         return dz, dc, dlv.reshape(log_var_row.shape), None, None
 
 
+# The captured step's promise (evae/graph.py): the loss is mean_i(beta KL_i - RE_i) with log p(z_i) entering KL_i with coefficient
+# -1, and what follows is loss.backward(ones) -- so d loss / d log p(z_i) = -beta / B is known in the forward pass.  The runner
+# puts its beta (device scalar) here around calculate_loss + backward; None: no promise.
+STEP_BETA = [None]
+
+
+class PriorLogPTrain(torch.autograd.Function):
+    """PriorLogP under STEP_BETA's promise: forward partials, merge and backward in ONE launch (evae_prior_train_step,
+    csrc/evae_prior_train.h); backward() hands out the gradients the forward pass computed (EVAE_PRIOR_TRAIN_CHECK=1: after
+    checking the upstream gradient against -beta / B)."""
+
+    @staticmethod
+    def forward(ctx, z, centres, log_var_row, z_idx, c_idx, beta):
+        logp, _tok, _c, dz, dc, dlv = prior_train_step(z.detach(), centres.detach(), log_var_row.detach(), z_idx, c_idx,
+                                                       centres.shape[0], beta, want_coef=False)
+        ctx.grads = (dz, dc, dlv.reshape(log_var_row.shape))
+        ctx.beta = beta
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        dz, dc, dlv = ctx.grads
+        if os.environ.get("EVAE_PRIOR_TRAIN_CHECK") == "1" and not torch.cuda.is_current_stream_capturing():
+            want = -(ctx.beta if torch.is_tensor(ctx.beta) else torch.tensor(float(ctx.beta), device=g.device)) / g.numel()
+            assert torch.allclose(g, want.expand_as(g), rtol=1e-6, atol=0.0), "PriorLogPTrain: the upstream gradient is not -beta / B"
+        ctx.grads = None
+        return dz, dc, dlv, None, None, None
+
+
+def prior_logp(z, centres, log_var_row, z_idx, c_idx):
+    """log p(z) [B] of ONE device's exemplars, differentiable: PriorLogP, or its one-launch training form under STEP_BETA"""
+    beta = STEP_BETA[0]
+    if (beta is not None and torch.is_grad_enabled() and z.is_cuda and z.dim() == 2 and centres.dim() == 2
+            and z.dtype == torch.float32 and centres.dtype == torch.float32 and z.is_contiguous() and centres.is_contiguous()
+            and (z.data_ptr() | centres.data_ptr()) % 16 == 0 and prior_train_applies(z.shape[0], centres.shape[0], z.shape[1])):
+        return PriorLogPTrain.apply(z, centres, log_var_row, z_idx, c_idx, beta)
+    return PriorLogP.apply(z, centres, log_var_row, z_idx, c_idx)
+
+
 # ------------------------------------------------------------------------------------------------
 # distance + top-K
 # ------------------------------------------------------------------------------------------------

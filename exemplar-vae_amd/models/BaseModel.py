@@ -251,7 +251,7 @@ class BaseModel(nn.Module, ABC):
         emb_sharded = getattr(exemplars_embedding, 'sharded_total', None)
         if emb_sharded is not None:
             return shard.ShardedPriorLogP.apply(z, centers, lv_row, zi, ci, emb_sharded)
-        return ops.PriorLogP.apply(z, centers, lv_row, zi, ci)
+        return ops.prior_logp(z, centers, lv_row, zi, ci)
 
     def add_pseudoinputs(self):
         nonlinearity = nn.Hardtanh(min_val=0.0, max_val=1.0)
