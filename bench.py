@@ -658,8 +658,8 @@ def main():
     # PMC pass (tools/kernel_probe.py names) of each launch family at the headline sizes: its counter bytes label the bound
     # (launch-name prefix, probe file, kernel symbol that launch runs)
     pmc_of = (("dense_bwd_weight_u8", "u8wgrad1", "u8_gemm_kernel<false>"),
-              ("gated_dense_fwd_u8 M=%d K=%d N=%d (uint8 rows, three bf16 terms; output + its" % (C, D, H), "u8fwd1_img", "u8_gemm_kernel<true>"),
-              ("gated_dense_fwd_u8", "u8fwd1", "u8_gemm_kernel<true>"),
+              ("gated_dense_fwd_u8 M=%d K=%d N=%d (uint8 rows, three bf16 terms; output + its" % (C, D, H), "u8fwd1_img", "u8p_gemm_kernel"),
+              ("gated_dense_fwd_u8", "u8fwd1", "u8p_gemm_kernel"),
               ("dense_bwd_data M=%d N=%d+%d K=%d (pre-split" % (C, H, H, H), "dgrad2_p6", "gemm_p6_kernel<9"),
               ("dense_bwd_data M=%d N=%d+" % (C, H), "dgrad2", "gemm_x6_kernel<9"),
               ("dense_bwd_data M=%d N=%d K=%d (gate-backward epilogue -> pre-split" % (C, Z, H), "hdgrad2_img", "gemm_x6_kernel<2"),

@@ -45,14 +45,14 @@ for f in sorted(glob.glob(os.path.join(src, "timeline_C*.txt"))):
                 "# queue, kernel; under the profiler a step is 5-10 %% longer than un-profiled\n" % (n, tag, n, head))
         o.write(open(f).read())
 # which kernel of a probe is "its" kernel: the first alternative that appears in the counter rows
-MAIN = {"u8fwd1": ["u8_gemm_kernel<true>"], "u8fwd1_img": ["u8_gemm_kernel<true>"], "u8wgrad1": ["u8_gemm_kernel<false>"],
+MAIN = {"u8fwd1": ["u8p_gemm_kernel", "u8_gemm_kernel<true>"], "u8fwd1_img": ["u8p_gemm_kernel", "u8_gemm_kernel<true>"], "u8wgrad1": ["u8_gemm_kernel<false>"],
         "fwd2_p6": ["gemm_p6_kernel<1, 128, true>"], "hdgrad2_img": ["gemm_x6_kernel<2, 0", "gemm_kernel<true, false, 2"],
         "dgrad2_p6": ["gemm_p6_kernel<9, 64, true>", "gemm_p6_kernel<9, 128, true>"], "wgrad2_p6": ["gemm_p6_kernel<3, 64, false>"],
         "hwgrad": ["narrow_wgrad_kernel"],
         "fwd1": ["gemm_x6_kernel<1, 0", "gemm_kernel<true, true, 1"], "fwd2": ["gemm_x6_kernel<1, 0", "gemm_kernel<true, true, 1"],
         "dgrad2": ["gemm_x6_kernel<2, 0", "gemm_kernel<true, false, 2"], "wgrad1": ["gemm_kernel<false, false, 3"],
         "wgrad2": ["gemm_kernel<false, false, 3"], "prior_iwae": ["prior_x6_lse_kernel", "prior_fwd_mfma_kernel"],
-        "prior_c5": ["gemm_x6_kernel<7, 0", "gemm_kernel<true, true, 7"], "prior_train": ["prior_bwd_mfma_kernel"],
+        "prior_c5": ["gemm_x6_kernel<7, 0", "gemm_kernel<true, true, 7"], "prior_train": ["prior_train_kernel", "prior_bwd_mfma_kernel"],
         "topk_c5": ["gemm_x6_kernel<5, 0", "gemm_kernel<true, true, 5"], "topk_c2": ["gemm_x6_kernel<5, 0", "gemm_kernel<true, true, 5"],
         "conv5_fwd": ["gemm_x6_kernel<1, 1", "gemm_kernel<true, true, 1"], "conv5_bwd": ["gemm_x6_kernel<0, 1", "gemm_kernel<true, false, 0"],
         "conv96_fwd": ["gemm_x6_kernel<0, 1", "gemm_kernel<true, true, 0"]}
