@@ -16,7 +16,8 @@
   hwgrad      the heads' weight gradient [40 x 300] over 25 100 rows (narrow_wgrad_kernel + finish)
   prior_iwae  prior forward, 4 x 5000 importance samples x 50 000 exemplars, z = 40 (prior_fwd_mfma_kernel)
   prior_c5    prior forward, 5000 samples x 100 000 exemplars, z = 256 (GEMM + log-sum-exp epilogue)
-  prior_train prior forward + backward at the training shape B = 100, C = 25 000, z = 40
+  prior_train prior forward + backward at the training shape B = 100, C = 25 000, z = 40 (three launches, the modular form)
+  prior_train1  the same as ONE launch (evae_prior_train_step: what a captured step runs)
   topk_c2 / topk_c5   evae_pairdist_topk, k = 10 (100 x 25 000 x 40 / 100 x 100 000 x 256)
   conv5_fwd / conv5_bwd   gated conv 32 -> 64, 5 x 5, 14 x 14, 25 000 images (c3): forward / data + weight gradient
   conv96_fwd  conv 96 -> 96, 3 x 3, 16 x 16, 1100 images (c5)"""
@@ -130,14 +131,17 @@ elif which in ("u8fwd1", "u8wgrad1"):
         else:
             ops.dense_bwd_weight_u8(dy, xs, rows, 1.0 / 255.0, dw=dw, db=db)
 elif which.startswith("prior"):
-    S, Cn, zd = {"prior_iwae": (20000, 50000, 40), "prior_c5": (5000, 100000, 256), "prior_train": (100, 25000, 40)}[which]
+    S, Cn, zd = {"prior_iwae": (20000, 50000, 40), "prior_c5": (5000, 100000, 256), "prior_train": (100, 25000, 40),
+                 "prior_train1": (100, 25000, 40)}[which]
     z = torch.randn(1, zd, device=dev) + 0.3 * torch.randn(S, zd, device=dev)
-    if which == "prior_train":
+    if which.startswith("prior_train"):
         z = torch.randn(S, zd, device=dev)
     c = torch.randn(Cn, zd, device=dev); lv = torch.full((zd,), -0.5, device=dev)
     zi = torch.randint(0, N, (S,), device=dev); ci = torch.randint(0, N, (Cn,), device=dev)
     for _ in range(reps):
-        if which == "prior_train":
+        if which == "prior_train1":      # the captured step's form: forward, merge and backward as ONE launch (csrc/evae_prior_train.h)
+            ops.prior_train_step(z, c, lv, zi, ci, float(Cn), 0.7)
+        elif which == "prior_train":
             m, s_, n, _ = ops.prior_lse_fwd(z, c, lv, zi, ci)
             lp, lse = ops.prior_merge(m, s_, n, Cn)
             ops.prior_lse_bwd(z, c, lv, zi, ci, lse, torch.ones(S, device=dev))

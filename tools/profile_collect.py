@@ -52,7 +52,7 @@ MAIN = {"u8fwd1": ["u8p_gemm_kernel", "u8_gemm_kernel<true>"], "u8fwd1_img": ["u
         "fwd1": ["gemm_x6_kernel<1, 0", "gemm_kernel<true, true, 1"], "fwd2": ["gemm_x6_kernel<1, 0", "gemm_kernel<true, true, 1"],
         "dgrad2": ["gemm_x6_kernel<2, 0", "gemm_kernel<true, false, 2"], "wgrad1": ["gemm_kernel<false, false, 3"],
         "wgrad2": ["gemm_kernel<false, false, 3"], "prior_iwae": ["prior_x6_lse_kernel", "prior_fwd_mfma_kernel"],
-        "prior_c5": ["gemm_x6_kernel<7, 0", "gemm_kernel<true, true, 7"], "prior_train": ["prior_train_kernel", "prior_bwd_mfma_kernel"],
+        "prior_c5": ["gemm_x6_kernel<7, 0", "gemm_kernel<true, true, 7"], "prior_train": ["prior_bwd_mfma_kernel"], "prior_train1": ["prior_train_kernel"],
         "topk_c5": ["gemm_x6_kernel<5, 0", "gemm_kernel<true, true, 5"], "topk_c2": ["gemm_x6_kernel<5, 0", "gemm_kernel<true, true, 5"],
         "conv5_fwd": ["gemm_x6_kernel<1, 1", "gemm_kernel<true, true, 1"], "conv5_bwd": ["gemm_x6_kernel<0, 1", "gemm_kernel<true, false, 0"],
         "conv96_fwd": ["gemm_x6_kernel<0, 1", "gemm_kernel<true, true, 0"]}
