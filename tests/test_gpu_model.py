@@ -1207,3 +1207,148 @@ def test_deferred_grouped_weight_gradients_equal_the_inline_ones(model_name, C):
     for k in a:
         assert torch.isfinite(b[k]).all(), k
         assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+
+
+def test_conv_two_level_step_at_c3_size_matches_the_oracle():
+    """convhvae_2level at the benchmarked size (BASELINE configs[2]: 25 000 exemplars, batch 100): per-sample loss / RE / KL of
+    the training step against an fp64 restatement of reference models/AbsHModel.py:13-106 + models/convHVAE_2level.py:13-103
+    (convolutions: float64 torch on the CPU, reference utils/nn.py:72-97; densities and the exemplar prior: the oracle's
+    log_normal_diag / log_bernoulli / log_p_z) on the same weights, noise and exemplar draw -- 1e-4 relative.  The 25 000
+    centres enter the oracle's prior as the GPU path's own q(z2 | x) means, after 512 of them (the first 256, the last 256:
+    both ends of the launch grid) are held to the float64 encoder at 1e-5 (a convolutional encoder is independent per image;
+    all 25 000 in float64 on the host would take over a minute).  VERDICT r03 weak #1: c3 was only compared with itself."""
+    import torch.nn.functional as F
+    from utils.utils import importing_model
+    B, Cn, N = 100, 25000, 50000
+    data_np = gi.binary_images(2, N)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data_np), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    args = smoke_case.vae_args(model_name="convhvae_2level", number_components=Cn, training_set_size=N, batch_size=B,
+                               dataset_name="fashion_mnist")
+    torch.manual_seed(15); torch.cuda.manual_seed(15)
+    model = importing_model(args)(args).cuda()
+    model.train()
+    rs = np.random.RandomState(61)
+    xi = rs.choice(N, size=B, replace=False).astype(np.int64)
+    x_np = data_np[xi]
+    eps2 = rs.standard_normal((B, 40)).astype(np.float32); eps1 = rs.standard_normal((B, 40)).astype(np.float32)
+    ex_idx = rs.randint(0, N, size=Cn).astype(np.int64)
+    ex_idx[:5] = xi[:5]                                        # leave-one-out hits
+    draws = [eps2, eps1]
+    model._draw_eps = lambda like: torch.from_numpy(draws.pop(0)).to(like.device).reshape(like.shape)
+    orig = torch.randint
+    torch.randint = lambda low=0, high=None, size=None, **kw: torch.from_numpy(ex_idx.copy())
+    beta = 0.6
+    try:
+        loss, RE, KL = model.calculate_loss((torch.from_numpy(x_np).cuda(), torch.from_numpy(xi).reshape(-1, 1).cuda()), beta,
+                                            average=False, dataset=dataset)
+        with torch.no_grad():
+            centres_gpu = model.q_z(torch.from_numpy(data_np[ex_idx]).cuda(), prior=True)[0].double().cpu().numpy()
+    finally:
+        torch.randint = orig
+    assert not draws
+    # ---- fp64 restatement ----
+    T = {k: v.detach().double().cpu() for k, v in model.state_dict().items()}
+    P = {k: v.numpy() for k, v in T.items()}
+
+    def gconv(h, name, st, pd):
+        return F.conv2d(h, T[name + ".h.weight"], T[name + ".h.bias"], st, pd) * \
+            torch.sigmoid(F.conv2d(h, T[name + ".g.weight"], T[name + ".g.bias"], st, pd))
+
+    def stack(v, name, spec):
+        h = torch.from_numpy(v).double().reshape(-1, 1, 28, 28)
+        for li, (st, pd) in enumerate(spec):
+            h = gconv(h, "%s.%d" % (name, li), st, pd)
+        return h.reshape(h.shape[0], -1).numpy()
+
+    def gated(v, name):
+        y, _ = orc.gated_dense(v, P[name + ".h.weight"], P[name + ".h.bias"], P[name + ".g.weight"], P[name + ".g.bias"])
+        return y
+
+    def heads(t, mean, logvar):
+        mu = orc.linear(t, P[mean + ".linear.weight"], P[mean + ".linear.bias"])
+        lv = orc.hardtanh(orc.linear(t, P[logvar + ".linear.weight"], P[logvar + ".linear.bias"]), -6.0, 2.0)
+        return mu, lv
+    ENC2 = ((1, 3), (2, 1), (1, 2), (2, 1), (1, 1)); ENC1 = ((1, 1), (2, 1), (1, 1), (2, 1), (1, 1))
+    x64 = x_np.astype(np.float64)
+    q2_mu, q2_lv = heads(stack(x64, "q_z_layers", ENC2), "q_z_mean", "q_z_logvar")
+    z2 = q2_mu + eps2 * np.exp(0.5 * q2_lv)
+    joint = gated(np.concatenate((stack(x64, "q_z1_layers_x", ENC1), gated(z2, "q_z1_layers_z2.0")), 1), "q_z1_layers_joint.0")
+    q1_mu, q1_lv = heads(joint, "q_z1_mean", "q_z1_logvar")
+    z1 = q1_mu + eps1 * np.exp(0.5 * q1_lv)
+    p1_mu, p1_lv = heads(gated(gated(z2, "p_z1_layers_z2.0"), "p_z1_layers_z2.1"), "p_z1_mean", "p_z1_logvar")
+    pre = gated(np.concatenate((gated(z1, "p_x_layers_z1.0"), gated(z2, "p_x_layers_z2.0")), 1), "p_x_layers_joint_pre.0")
+    h = torch.from_numpy(pre).reshape(-1, 1, 28, 28)
+    for li in range(4):
+        h = gconv(h, "p_x_layers_joint.%d" % li, 1, 1)
+    x_mean = torch.sigmoid(F.conv2d(h, T["p_x_mean.conv.weight"], T["p_x_mean.conv.bias"])).reshape(B, -1).numpy()
+    RE_ref = orc.log_bernoulli(x64, x_mean)
+    sample = np.r_[0:256, Cn - 256:Cn]
+    c64 = orc.linear(stack(data_np[ex_idx[sample]].astype(np.float64), "q_z_layers", ENC2), P["q_z_mean.linear.weight"], P["q_z_mean.linear.bias"])
+    assert rel(centres_gpu[sample], c64) < 1e-5, rel(centres_gpu[sample], c64)
+    clv = np.full((Cn, 40), float(P["prior_log_variance"][0]))
+    log_pz2 = orc.log_p_z(z2, xi.reshape(-1, 1), centres_gpu, clv, ex_idx, test=False)
+    KL_ref = (orc.log_normal_diag(z1, q1_mu, q1_lv) - orc.log_normal_diag(z1, p1_mu, p1_lv)
+              + orc.log_normal_diag(z2, q2_mu, q2_lv) - log_pz2)
+    loss_ref = -RE_ref + beta * KL_ref
+    for name, got, ref in (("RE", RE, RE_ref), ("KL", KL, KL_ref), ("loss", loss, loss_ref)):
+        assert rel(got.detach().cpu().numpy(), ref) < 1e-4, (name, rel(got.detach().cpu().numpy(), ref))
+
+
+def test_single_conv_training_step_at_c5_size():
+    """BASELINE configs[4] at its own size (only c5's top-K and geometry were under test): `single_conv`
+    on 3 x 64 x 64, z = 256, approximate prior over 100 000 candidates drawn from a 100 000-image training set, k = 10, batch
+    100 -- one eager training step (cache of all latents, refresh of the batch's rows, top-K among the candidates' cached
+    latents, <= 1000 exemplars re-encoded, loss, backward) on the split-bf16 pipe and on the fp32-MFMA pipe: loss / RE / KL
+    finite and equal to 1e-5, every gradient norm to 1e-3; the step's top-K (batch means against the 100 000 cached latents,
+    reference models/BaseModel.py:263-264) bit-equal to the oracle's float64 scan with its (value, index) order."""
+    from evae import ops
+    from utils.utils import importing_model
+    from argparse import Namespace
+    B, N, k = 100, 100000, 10
+    isz = [3, 64, 64]
+    args = Namespace(prior="exemplar_prior", input_type="continuous", input_size=isz, hidden_size=300, z1_size=256, z2_size=40,
+                     model_name="single_conv", device="cuda", number_components=N, training_set_size=N, approximate_prior=True,
+                     approximate_k=k, no_mask=False, no_attention=False, same_variational_var=False, use_logit=False, lambd=1e-4,
+                     bottleneck=1, dataset_name="celeba", continuous=True, batch_size=B, dynamic_binarization=False, warmup=100,
+                     S=5000, shard_exemplars=False, shard_batch=False)
+    torch.manual_seed(44); torch.cuda.manual_seed(44)
+    model = importing_model(args)(args).cuda()
+    model.train()
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    # images with structure (a few prototypes + noise) so that neighbours in latent space mean something
+    protos = torch.randint(0, 256, (32, 12288), device="cuda", generator=g).float()
+    which = torch.randint(0, 32, (N,), device="cuda", generator=g)
+    data_dev = ((protos[which] * 0.7 + torch.randint(0, 77, (N, 12288), device="cuda", generator=g, dtype=torch.int16).float()).floor() + 0.5) / 256
+    del protos
+    dataset = torch.utils.data.TensorDataset(data_dev, torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    idx_all = torch.arange(N, device="cuda").reshape(-1, 1)
+    cand = torch.randperm(N, device="cuda", generator=g).cpu()    # the step's candidate draw (the reference: torch.randint on the host)
+    rs = np.random.RandomState(12)
+    eps = torch.from_numpy(rs.standard_normal((B, 256)).astype(np.float32)).cuda()
+    res = []
+    for pipe in (1, 0):
+        ops.gemm_x6_configure(pipe, 2048)
+        orig = torch.randint
+        try:
+            with torch.no_grad():
+                cache = tuple(t.clone() for t in model.cache_z(dataset))
+            torch.randint = lambda low=0, high=None, size=None, **kw: cand.clone()
+            model._draw_eps = lambda like: eps.reshape(like.shape)
+            model.zero_grad()
+            loss, RE, KL = model.calculate_loss((data_dev[500:500 + B], idx_all[500:500 + B]), 0.5, average=True, cache=cache,
+                                                dataset=dataset)
+            loss.backward()
+        finally:
+            torch.randint = orig
+            ops.gemm_x6_configure(1, 2048)
+        res.append((np.asarray([loss.item(), RE.item(), KL.item()]),
+                    np.asarray([p.grad.double().norm().item() for p in model.parameters() if p.grad is not None]), cache))
+    assert np.isfinite(res[0][0]).all() and np.isfinite(res[0][1]).all()
+    assert rel(res[0][0], res[1][0]) < 1e-5, (res[0][0], res[1][0])
+    assert np.all(np.abs(res[0][1] - res[1][1]) <= 1e-3 * np.maximum(res[1][1], 1e-6))
+    # the step's top-K at this size against the oracle (the cache AFTER the step holds the batch's refreshed rows)
+    cz = res[0][2][0]
+    q = cz[500:500 + B].contiguous()
+    idx, val = ops.pairdist_topk(q, cz, k)
+    _, ref_idx = orc.nearest_exemplars_topk(q.double().cpu().numpy(), cz.double().cpu().numpy(), k)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
