@@ -808,6 +808,28 @@ extern "C" int evae_gated_dense_bwd_input_ld(const float* dout, int ldd, const f
   return launch_gated_bwd_input(dout, ldd, out, s, M, N, dh, dg, ldo, (hipStream_t)stream_);
 }
 
+// A gated layer's whole backward with respect to its input: [dh | dg] (row stride ldp, for the weight gradient) and
+// dx = dh Wh + dg Wg.  Batch-sized row counts take ONE launch (thin_gated_bwd_kernel: the gate derivative in the operand load);
+// anything else the element-wise launch + evae_dense_bwd_data, with the same bits.  EVAE_THIN_GATE_BWD=0: always two launches.
+extern "C" int evae_gated_dense_bwd(const float* dout, int ldd, const float* out, const float* s, int M, int N, const float* wh,
+                                    const float* wg, int K, float* dpre, int ldp, float* dx, int ldo, void* ws, size_t ws_bytes,
+                                    evae_stream_t stream_) {
+  if (M <= 0) return EVAE_OK;
+  EVAE_REQUIRE(dout && out && s && wh && wg && dpre && dx && N > 0 && K > 0 && ldd >= N && ldp >= 2 * N && ldo >= K,
+               "gated_dense_bwd: bad arguments (M=%d N=%d K=%d)", M, N, K);
+  static int fused = -1;
+  if (fused < 0) { const char* e = getenv("EVAE_THIN_GATE_BWD"); fused = (e && atoi(e) == 0) ? 0 : 1; }
+  const uintptr_t al = (uintptr_t)dout | (uintptr_t)out | (uintptr_t)s | (uintptr_t)dpre;
+  if (fused && thin_ok(M, N, ldd, (const void*)al, nullptr) && N % 4 == 0 && ldp % 4 == 0) {
+    ThinGateBwdArgs t = {dout, ldd, out, s, wh, wg, M, N, K, dpre, ldp, dx, ldo};
+    thin_gated_bwd_kernel<<<dim3(cdiv(K, 16), cdiv(M, 16)), 256, 0, (hipStream_t)stream_>>>(t);
+    return check_launch("gated_dense_bwd(thin)");
+  }
+  int rc = launch_gated_bwd_input(dout, ldd, out, s, M, N, dpre, dpre + N, ldp, (hipStream_t)stream_);
+  if (rc != EVAE_OK) return rc;
+  return dense_bwd_data_core(dpre, wh, dpre + N, wg, M, N, ldp, K, nullptr, nullptr, dx, nullptr, ldo, nullptr, ws, ws_bytes, stream_);
+}
+
 extern "C" int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, int act, float act_lo,
                             float act_hi, float* dpre, evae_stream_t stream_) {
   if (n == 0) return EVAE_OK;

@@ -165,6 +165,72 @@ __global__ __launch_bounds__(256) void thin_layer_kernel(const ThinArgs t) {
   }
 }
 
+// A gated layer's backward of the modular autograd path as ONE launch (r04): the gate derivative (dh, dg) = (dout s, dout (h s)(1 - s))
+// of reference utils/nn.py:62-68 formed in the operand load of the data gradient dx = dh Wh + dg Wg, instead of an element-wise
+// launch that writes [dh | dg] and a data-gradient launch that reads it back (two nodes of ~5 us on the batch rows' chain of the
+// 2-level models, twelve times per step).  Same tiling, contraction split and summation order as thin_layer_kernel<THIN_LINEAR,
+// true> over two banks -- dx is bit-identical to the two-launch form -- and the blocks of the first column tile also store
+// [dh | dg] (row stride ldp) for the layer's weight gradient.
+struct ThinGateBwdArgs {
+  const float* dout; int ldd;      // [M x N] gradient of the layer's output
+  const float* gout;               // [M x N] the layer's output h s (dense)
+  const float* s;                  // [M x N] its gate
+  const float* Wh; const float* Wg;   // [N x K]
+  int M, N, K;
+  float* dpre; int ldp;            // [M x 2N]: dh | dg
+  float* dx; int ldo;              // [M x K]
+};
+
+__global__ __launch_bounds__(256) void thin_gated_bwd_kernel(const ThinGateBwdArgs t) {
+  __shared__ float part[4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  thin_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int mrow = (m0 + i < t.M) ? m0 + i : t.M - 1;
+  const int kcol = (n0 + i < t.K) ? n0 + i : t.K - 1;
+  const int nchunk = (t.N + 15) >> 4;
+  const bool writer = blockIdx.x == 0 && m0 + i < t.M;
+  const float* pd = t.dout + (size_t)mrow * t.ldd + 4 * kq;
+  const float* pg = t.gout + (size_t)mrow * t.N + 4 * kq;
+  const float* ps = t.s + (size_t)mrow * t.N + 4 * kq;
+  float* pp = t.dpre + (size_t)mrow * t.ldp + 4 * kq;
+  for (int bank = 0; bank < 2; ++bank) {
+    const float* pw = (bank ? t.Wg : t.Wh) + (size_t)(4 * kq) * t.K + kcol;
+#pragma unroll 4
+    for (int c = wave; c < nchunk; c += 4) {
+      const int k0 = c * 16;
+      const bool ok = k0 + 4 * kq + 4 <= t.N;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      float w[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const float4 d = *reinterpret_cast<const float4*>(pd + k0);
+        const float4 sv = *reinterpret_cast<const float4*>(ps + k0);
+        if (bank == 0) {
+          a = make_float4(d.x * sv.x, d.y * sv.y, d.z * sv.z, d.w * sv.w);
+        } else {
+          const float4 ov = *reinterpret_cast<const float4*>(pg + k0);
+          a = make_float4(d.x * ov.x * (1.0f - sv.x), d.y * ov.y * (1.0f - sv.y), d.z * ov.z * (1.0f - sv.z), d.w * ov.w * (1.0f - sv.w));
+        }
+        if (writer) *reinterpret_cast<float4*>(pp + (bank ? t.N : 0) + k0) = a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = pw[(size_t)(k0 + j) * t.K];
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[3], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[wave][4 * kq + r][i] = acc[r];
+  __syncthreads();
+  const int row = tid >> 4, col = tid & 15;
+  const int m = m0 + row, n = n0 + col;
+  if (m >= t.M || n >= t.K) return;
+  t.dx[(size_t)m * t.ldo + n] = ((part[0][row][col] + part[1][row][col]) + part[2][row][col]) + part[3][row][col];
+}
+
 // which launches take the thin kernel: a batch-sized row count, aligned float4 rows (EVAE_THIN=0: the tiled kernels)
 static bool thin_enabled() {
   static int on = -1;

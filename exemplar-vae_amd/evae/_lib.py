@@ -117,6 +117,7 @@ SIGNATURES = {
     "evae_dense_bwd_weight_finish_group": (_i, [_p, _i, _p]),
     "evae_gated_dense_bwd_input": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "evae_gated_dense_bwd_input_ld": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _i, _p]),
+    "evae_gated_dense_bwd": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _z, _p]),
     "evae_act_bwd": (_i, [_p, _p, _z, _i, _f, _f, _p, _p]),
     "evae_conv2d_workspace_bytes": (_z, [_p, _i, _i]),
     "evae_conv2d_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _z, _p]),

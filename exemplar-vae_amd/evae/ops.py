@@ -575,6 +575,19 @@ def _bwd_data(dy1_ptr, w1, dy2_ptr, w2, M, N, ldy, device, out_prev=None, s_prev
     return out
 
 
+def _gated_bwd(dout, gout, s, wh, wg, dpre):
+    """A gated layer's backward wrt its input (reference utils/nn.py:62-68 under autograd): fills dpre = [dh | dg] for the weight
+    gradient and returns dx = dh Wh + dg Wg (evae_gated_dense_bwd: one launch for batch-sized row counts)."""
+    lib = _lib.load()
+    M, N = gout.shape
+    K = wh.shape[1]
+    dx = torch.empty((M, K), device=gout.device)
+    ws = _workspace("dgrad", lib.evae_dense_bwd_data_workspace_bytes(M, N, K, 2), gout.device)
+    _lib.check(lib.evae_gated_dense_bwd(_p(dout), dout.stride(0), _p(gout), _p(s), M, N, _p(wh), _p(wg), K, _p(dpre), 2 * N,
+                                        _p(dx), K, _p(ws), ws.numel(), _stream()), "evae_gated_dense_bwd")
+    return dx
+
+
 def _rows_x(x, rows):
     """Validate the (x, rows) pair: x is [R x K] with unit inner stride; rows gathers M rows of it."""
     x = x if x.dtype == torch.float32 else x.float()
@@ -622,14 +635,15 @@ class GatedDenseFn(torch.autograd.Function):
         K = wh.shape[1]
         dpre = torch.empty((M, 2 * N), device=gout.device)          # [dh | dg]: one buffer, one weight-grad GEMM
         base = dpre.data_ptr()
-        _lib.check(lib.evae_gated_dense_bwd_input_ld(_p(dout), dout.stride(0), _p(gout), _p(s), M, N, _vp(base), _vp(base + 4 * N),
-                                                     2 * N, _stream()), "evae_gated_dense_bwd_input_ld")
-        dw, db = _bwd_weight(dpre, x, rows, K, key=wh.data_ptr())  # [dWh ; dWg], [dbh ; dbg]
         dx = None
         if ctx.needs_input_grad[0]:
             if rows is not None:
                 raise _lib.EvaeError("gradient wrt a row-gathered input is not supported")
-            dx = _bwd_data(base, wh, base + 4 * N, wg, M, N, 2 * N, gout.device)
+            dx = _gated_bwd(dout, gout, s, wh, wg, dpre)           # gate derivative + data gradient (one launch when batch-sized)
+        else:
+            _lib.check(lib.evae_gated_dense_bwd_input_ld(_p(dout), dout.stride(0), _p(gout), _p(s), M, N, _vp(base), _vp(base + 4 * N),
+                                                         2 * N, _stream()), "evae_gated_dense_bwd_input_ld")
+        dw, db = _bwd_weight(dpre, x, rows, K, key=wh.data_ptr())  # [dWh ; dWg], [dbh ; dbg]
         return (dx, None, dw[:N], (db[:N] if ctx.has_bias[0] else None), dw[N:],
                 (db[N:] if ctx.has_bias[1] else None))
 
@@ -663,10 +677,7 @@ class GatedDenseDataFn(torch.autograd.Function):
         if not (dout.dtype == torch.float32 and dout.dim() == 2 and dout.stride(1) == 1 and dout.stride(0) >= N):
             dout = _f32(dout)
         dpre = torch.empty((M, 2 * N), device=gout.device)
-        base = dpre.data_ptr()
-        _lib.check(lib.evae_gated_dense_bwd_input_ld(_p(dout), dout.stride(0), _p(gout), _p(s), M, N, _vp(base), _vp(base + 4 * N),
-                                                     2 * N, _stream()), "evae_gated_dense_bwd_input_ld")
-        return _bwd_data(base, wh, base + 4 * N, wg, M, N, 2 * N, gout.device), None, None, None, None
+        return _gated_bwd(dout, gout, s, wh, wg, dpre), None, None, None, None
 
 
 class GatedDenseParamFn(torch.autograd.Function):

@@ -336,6 +336,13 @@ int evae_gated_dense_bwd_input(const float* dout, const float* out, const float*
  * torch.cat of two gated layers' outputs) is read where it lies */
 int evae_gated_dense_bwd_input_ld(const float* dout, int ldd, const float* out, const float* s, int M, int N,
                                   float* dh, float* dg, int ldo, evae_stream_t stream);
+/* a gated layer's whole backward with respect to its input (reference utils/nn.py:62-68 under autograd): [dh | dg] = (dout s,
+ * dout (h s)(1 - s)) into dpre [M x 2N] (row stride ldp) for the weight gradient, dx [M x K] = dh Wh + dg Wg.  One launch for
+ * batch-sized row counts (the gate derivative formed in the operand load), evae_gated_dense_bwd_input_ld + evae_dense_bwd_data
+ * otherwise -- the same bits either way; ws as for evae_dense_bwd_data(M, N, K, 2 pairs). */
+int evae_gated_dense_bwd(const float* dout, int ldd, const float* out, const float* s, int M, int N, const float* wh,
+                         const float* wg, int K, float* dpre, int ldp, float* dx, int ldo, void* ws, size_t ws_bytes,
+                         evae_stream_t stream);
 int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, int act, float act_lo, float act_hi,
                  float* dpre, evae_stream_t stream);
 

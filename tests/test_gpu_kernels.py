@@ -1274,3 +1274,52 @@ def test_prior_of_a_training_step_in_one_launch(ops, B, C, zd, masked, limit):
     finally:
         if limit is not None:
             lib.evae_prior_set_norm_limit(C_.c_float(-1.0))
+
+
+@pytest.mark.parametrize("M,N,K,ldd", [(100, 300, 300, 300), (100, 300, 40, 600), (100, 300, 784, 300), (100, 784, 600, 784),
+                                       (7, 20, 36, 20), (128, 296, 588, 296), (1438, 300, 300, 300), (3000, 300, 784, 300)])
+def test_gated_backward_with_the_gate_derivative_in_the_operand_load(ops, M, N, K, ldd):
+    """evae_gated_dense_bwd (r04): a gated layer's backward wrt its input -- [dh | dg] = (dout s, dout (h s)(1 - s)) and
+    dx = dh Wh + dg Wg, reference utils/nn.py:62-68 under autograd -- as ONE launch for batch-sized row counts (the gate
+    derivative formed in the data gradient's operand load) against the two-launch form (evae_gated_dense_bwd_input_ld +
+    evae_dense_bwd_data) bit for bit, and both against float64; dout may be a column block of a wider gradient (ldd > N: one
+    half of a torch.cat's).  The last shape is past the thin kernels' row bound: the entry point takes the two launches itself."""
+    from evae import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(M + N + K)
+    wide = dev((rs.standard_normal((M, ldd)) * 0.1).astype(np.float32))
+    dout = wide[:, ldd - N:]                                         # (16-byte aligned: N and ldd are multiples of 4)
+    h = dev(rs.standard_normal((M, N)).astype(np.float32))
+    s = torch.sigmoid(dev(rs.standard_normal((M, N)).astype(np.float32)))
+    gout = h * s
+    wh = dev((rs.standard_normal((N, K)) * 0.05).astype(np.float32)); wg = dev((rs.standard_normal((N, K)) * 0.05).astype(np.float32))
+    st = ops._stream()
+    nb = lib.evae_dense_bwd_data_workspace_bytes(M, N, K, 2)
+    ws = torch.zeros(max(nb, 256), dtype=torch.uint8, device="cuda")
+    dpre = torch.full((M, 2 * N), float("nan"), device="cuda"); dx = torch.full((M, K), float("nan"), device="cuda")
+    _lib.check(lib.evae_gated_dense_bwd(ops._p(dout), ldd, ops._p(gout), ops._p(s), M, N, ops._p(wh), ops._p(wg), K, ops._p(dpre), 2 * N,
+                                        ops._p(dx), K, ops._p(ws), ws.numel(), st), "gated_dense_bwd")
+    dpre2 = torch.empty((M, 2 * N), device="cuda"); dx2 = torch.empty((M, K), device="cuda")
+    base = dpre2.data_ptr()
+    _lib.check(lib.evae_gated_dense_bwd_input_ld(ops._p(dout), ldd, ops._p(gout), ops._p(s), M, N, ops._vp(base), ops._vp(base + 4 * N), 2 * N,
+                                                 st), "bwd_input_ld")
+    _lib.check(lib.evae_dense_bwd_data(ops._vp(base), ops._p(wh), ops._vp(base + 4 * N), ops._p(wg), M, N, 2 * N, K, None, None, ops._p(dx2),
+                                       None, K, ops._p(ws), ws.numel(), st), "bwd_data")
+    assert torch.equal(dpre, dpre2)
+    assert torch.equal(dx, dx2)
+    d64, s64, g64 = dout.double(), s.double(), gout.double()
+    dh, dg = d64 * s64, d64 * g64 * (1 - s64)
+    ref = dh @ wh.double() + dg @ wg.double()
+    assert rel(dx.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    assert rel(dpre.cpu().numpy(), torch.cat((dh, dg), 1).cpu().numpy()) < 1e-6
+    # through autograd: the modular layer's gradients against float64 autograd
+    x = dev(rs.standard_normal((M, K)).astype(np.float32)).requires_grad_(True)
+    bh = dev(np.zeros(N, np.float32)); bg = dev(np.zeros(N, np.float32))
+    whp, wgp = wh.clone().requires_grad_(True), wg.clone().requires_grad_(True)
+    y = ops.GatedDenseFn.apply(x, None, whp, bh, wgp, bg)
+    y.backward(dout)
+    x6 = x.detach().double().requires_grad_(True); wh6 = wh.double().requires_grad_(True); wg6 = wg.double().requires_grad_(True)
+    y6 = (x6 @ wh6.t()) * torch.sigmoid(x6 @ wg6.t())
+    y6.backward(dout.double())
+    for got, ref_ in ((x.grad, x6.grad), (whp.grad, wh6.grad), (wgp.grad, wg6.grad)):
+        assert rel(got.cpu().numpy(), ref_.cpu().numpy()) < 3e-6
