@@ -948,14 +948,22 @@ extern "C" int evae_dense_bwd_data_p6t(const void* dyT_img, int dy_nks, int M, i
 
 // dw [N x K] = dy^T x, db [N] = column sums of dy, from the images of dy^T (N rows) and x^T (K rows + the all-ones row K when
 // db != NULL), both with nks k-steps along the batch rows.  Split over the batch rows into one round of blocks; fixed-order finish.
-struct P6WgradPlan { int kc, nz, ksplit; };
+struct P6WgradPlan { int kc, nz, ksplit, local; };
 static P6WgradPlan p6_wgrad_plan(int nks, int N, int K, bool with_db) {
   P6WgradPlan p;
   p.kc = K + (with_db ? 1 : 0);
   const int tiles = cdiv(N, BM) * cdiv(p.kc, 64);
-  static int slots = -1;
+  static int slots = -1, local = -1;
   if (slots < 0) { const char* e = getenv("EVAE_P6_WGRAD_SLOTS"); slots = e ? atoi(e) : 256; }
+  if (local < 0) { const char* e = getenv("EVAE_P6_WGRAD_LOCAL"); local = e ? atoi(e) : 16; }      // slices of the XCD-local form (0: off)
   int nz = std::max(1, std::min(slots / std::max(tiles, 1), nks / 8));
+  // a long contraction: 8 or 16 slices, each slice's tiles on one XCD (gemm_p6_kernel, sk_local); two blocks per CU are resident,
+  // so up to 64 blocks per XCD run in one round
+  p.local = 0;
+  if (local >= 8 && nz >= 8) {
+    const int want = (local >= 16 && tiles * 2 <= 64 && nks / 16 >= 8) ? 16 : 8;
+    if (tiles * (want / 8) <= 64) { nz = want; p.local = 1; }
+  }
   p.ksplit = cdiv(nks, nz);
   p.nz = cdiv(nks, p.ksplit);
   return p;
@@ -974,7 +982,7 @@ extern "C" int evae_dense_bwd_weight_p6(const void* dyT_img, const void* xT_img,
   GemmArgs g = {};
   g.ones_col = -1; g.npairs = 1;
   g.A[0] = (const float*)dyT_img; g.B[0] = (const float*)xT_img; g.Kc[0] = nks * P6_KS; g.M = N; g.N = p.kc;
-  g.out0 = (float*)ws; g.ldo = p.kc; g.ksplit = p.ksplit;
+  g.out0 = (float*)ws; g.ldo = p.kc; g.ksplit = p.ksplit; g.sk_local = p.local ? p.nz : 0;
   int rc = launch_gemm_p6<EPI_RAW, 64>(g, p.nz, stream, "dense_bwd_weight(p6)");
   if (rc) return rc;
   FinishArgs f = {};

@@ -80,8 +80,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = reinterpret_cast<char*>(smem);
   const int ntiles = g.tiles_m * g.tiles_n;
-  int tile;
-  {
+  int tile, zs = blockIdx.z;
+  if (g.sk_local > 0) {
+    // split contraction, XCD-local (r04): 1-D grid of 8 * ceil(slices / 8) * ntiles blocks; XCD x (= block id mod 8) runs ALL the
+    // tiles of slices x, x + 8, ...: the blocks that share a slice's operand strips sit on one L2 and walk the slice in step
+    // (PMC of the 3-D grid at 600 x 301 x 25 100: 478 MB per launch against 135 MB of operand images, 7.4 TB/s -- every XCD met
+    // every slice)
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int j = slot / ntiles;
+    tile = slot - j * ntiles;
+    zs = xcd + 8 * j;
+    if (zs >= g.sk_local) return;
+  } else {
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int qq = ntiles >> 3, rr = ntiles & 7;
     tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int nks = g.Kc[0] / P6_KS;
   int s_begin = 0, s_end = nks;
   if (g.ksplit > 0) {
-    s_begin = blockIdx.z * g.ksplit;
+    s_begin = zs * g.ksplit;
     const int e = s_begin + g.ksplit;
     if (e < s_end) s_end = e;
   }
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();             // the epilogue may use the ring as scratch
   }
   if (g.dbg == 4) return;        // (tools: main loop only)
-  gemm_epilogue<EPI, BN_, NW, 0>(g, acc, m0, n0, tm, wr, wc, lane, smem, blockIdx.z);
+  gemm_epilogue<EPI, BN_, NW, 0>(g, acc, m0, n0, tm, wr, wc, lane, smem, zs);
 }
 
 // ---- image builders (weights in the step head; activations in tests and on fallback paths -- the layers' epilogues write
@@ -390,6 +400,10 @@ static int launch_gemm_p6(GemmArgs& g, int nz, hipStream_t stream, const char* w
   g.tiles_m = cdiv(g.M, BM);
   g.tiles_n = cdiv(g.N, GATED ? 64 : BN_);
   dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
+  if (g.sk_local > 0) {
+    if (g.sk_local != nz || g.ksplit <= 0) { set_error("%s: XCD-local split needs sk_local == nz and a split contraction", what); return EVAE_EINVAL; }
+    grid = dim3(8 * cdiv(nz, 8) * g.tiles_m * g.tiles_n, 1, 1);
+  }
   gemm_p6_kernel<EPI, BN_, TA><<<grid, 256, p6_lds_bytes(BN_), stream>>>(g);
   return check_launch(what);
 }
