@@ -748,7 +748,7 @@ extern "C" int evae_dense_bwd_weight_finish_group(const evae_wgrad_finish_job_t*
 }
 
 // Several thin weight gradients in one launch (gemm_group_wgrad_kernel): each job as evae_dense_bwd_weight with a
-// contraction of at most four K-slabs (M <= 128 rows), no row gather, no accumulation.  Returns EVAE_EINVAL (nothing
+// contraction of at most four K-slabs (M <= 128 rows), no row gather; job.accumulate: dw += dy^T x, db += column sums.  Returns EVAE_EINVAL (nothing
 // launched) when a job does not qualify: the caller then issues them one by one.
 extern "C" int evae_dense_bwd_weight_group(const evae_wgrad_job_t* jobs, int njobs, evae_stream_t stream_) {
   EVAE_REQUIRE(jobs && njobs >= 1 && njobs <= kWgradGroupMax, "dense_bwd_weight_group: 1 .. %d jobs", kWgradGroupMax);
@@ -763,7 +763,7 @@ extern "C" int evae_dense_bwd_weight_group(const evae_wgrad_job_t* jobs, int njo
     g.A[0] = w.dy; g.B[0] = w.x; g.lda[0] = w.ldy; g.ldb[0] = w.ldx; g.Kc[0] = w.M; g.npairs = 1;
     g.M = w.N; g.N = w.K + 1; g.ones_col = w.K;
     EVAE_REQUIRE((gemm_vec_ok<false, false>(g)), "dense_bwd_weight_group: job %d is not 16-byte aligned / a multiple of 4", j);
-    grp.job[j] = {w.dy, w.x, w.dw, w.db, w.M, w.N, w.K, w.ldy, w.ldx};
+    grp.job[j] = {w.dy, w.x, w.dw, w.db, w.M, w.N, w.K, w.ldy, w.ldx, w.accumulate ? 1 : 0};
     grp.start[j] = total;
     total += cdiv(w.N, BM) * cdiv(w.K + 1, 64);
   }

@@ -619,8 +619,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[8
           if (extras) res = res * (a1 > 0.f ? 1.0f : a1 + 1.0f) + a0;
           g.out0[o] = res;
         } else if (g.direct) {                  // EPI_RAW, one slice: the result itself (bias gradient = the ones column)
-          if (n == g.ones_col) { if (g.out1) g.out1[m] = v; }
-          else g.out0[(size_t)m * g.ldo + n] = v;
+          // direct == 2: added to what is there (the second application of a shared layer accumulates into the first one's
+          // gradient: old + v, the very bits of the sum autograd would form)
+          if (n == g.ones_col) { if (g.out1) g.out1[m] = (g.direct == 2) ? g.out1[m] + v : v; }
+          else { float* o = g.out0 + (size_t)m * g.ldo + n; *o = (g.direct == 2) ? *o + v : v; }
         } else {                                // EPI_RAW: partial plane [z][M][N]
           g.out0[(size_t)zslice * g.M * g.N + (size_t)m * g.N + n] = v;
         }
@@ -1132,7 +1134,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_kernel(const GemmArgs g)
 // itself (GemmArgs::direct: no partial plane, no finish) with db in the ones column; a block finds its job by the running
 // tile counts and runs gemm_body on its own copy of the arguments.  The jobs travel by value in the kernel arguments, so a
 // captured step needs no table upload.
-struct WgradJob { const float* dy; const float* x; float* dw; float* db; int M, N, K, ldy, ldx; };
+struct WgradJob { const float* dy; const float* x; float* dw; float* db; int M, N, K, ldy, ldx, accumulate; };
 constexpr int kWgradGroupMax = 6;
 struct WgradGroup { WgradJob job[kWgradGroupMax]; int start[kWgradGroupMax + 1]; int n; };
 
@@ -1157,7 +1159,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void gemm_group_wgrad_kernel(const
   g.lda[0] = __builtin_amdgcn_readfirstlane(w.ldy); g.ldb[0] = __builtin_amdgcn_readfirstlane(w.ldx);
   g.Kc[0] = __builtin_amdgcn_readfirstlane(w.M); g.npairs = 1;
   g.M = __builtin_amdgcn_readfirstlane(w.N); g.N = __builtin_amdgcn_readfirstlane(w.K) + 1;
-  g.out0 = (float*)uni_ptr(w.dw); g.out1 = (float*)uni_ptr(w.db); g.ldo = g.N - 1; g.ones_col = g.N - 1; g.direct = 1;
+  g.out0 = (float*)uni_ptr(w.dw); g.out1 = (float*)uni_ptr(w.db); g.ldo = g.N - 1; g.ones_col = g.N - 1;
+  g.direct = __builtin_amdgcn_readfirstlane(w.accumulate) ? 2 : 1;
   g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = (g.N + 63) / 64;
   gemm_body<false, false, EPI_RAW, true, 64, NW>(g, bid - __builtin_amdgcn_readfirstlane(grp.start[j]), 0, smem);
 }

@@ -32,7 +32,7 @@ class WtJob(C.Structure):
 class WgradJob(C.Structure):
     """evae_wgrad_job_t"""
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("M", C.c_int), ("N", C.c_int),
-                ("K", C.c_int), ("ldy", C.c_int), ("ldx", C.c_int)]
+                ("K", C.c_int), ("ldy", C.c_int), ("ldx", C.c_int), ("accumulate", C.c_int)]
 
 
 class WgradFinishJob(C.Structure):

@@ -461,9 +461,12 @@ def _flush_wgrads(jobs, everyone_waits=False):
         for i in range(0, len(js), 6):
             part = js[i:i + 6]
             arr = (_lib.WgradJob * len(part))()
-            for a, (dy, M, N, x, K, dw, db, _key, _st) in zip(arr, part):
+            for a, (dy, M, N, x, K, dw, db, _key, _st, made_ev) in zip(arr, part):
                 a.dy = dy.data_ptr(); a.x = x.data_ptr(); a.dw = dw.data_ptr(); a.db = db.data_ptr()
                 a.M, a.N, a.K, a.ldy, a.ldx = M, N, K, dy.stride(0), x.stride(0)
+                if made_ev is not None:            # dw += ...: behind the launch that wrote the other application's gradient
+                    a.accumulate = 1
+                    st.wait_event(made_ev)
             _lib.check(lib.evae_dense_bwd_weight_group(C.cast(arr, C.c_void_p), len(part), C.c_void_p(st.cuda_stream)),
                        "evae_dense_bwd_weight_group(deferred)")
         waiters = [cur]
@@ -503,7 +506,8 @@ class deferred_wgrads:
 
     def __enter__(self):
         self.prev = _DEFER[0]
-        _DEFER[0] = {"jobs": [], "uses": {}, "single": _single_use_leaves(self.root)} if (_DEFER_ON and self.root is not None) else None
+        _DEFER[0] = ({"jobs": [], "uses": {}, "made": {}, "single": _single_use_leaves(self.root)}
+                     if (_DEFER_ON and self.root is not None) else None)
         self.root = None
         return self
 
@@ -525,17 +529,42 @@ def _try_defer(dy, x, K, key, dw=None, db=None):
         # a deferred weight used again in this pass: autograd is about to add the two gradients
         _flush_wgrads(cur["jobs"], everyone_waits=True); cur["jobs"] = []
         return None
-    if not (uses == 1 and key in cur["single"] and 0 < M <= 128 and N % 4 == 0 and K % 4 == 0
+    thin = (0 < M <= 128 and N % 4 == 0 and K % 4 == 0
             and dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.stride(1) == 1 and x.stride(1) == 1
-            and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and (dy.data_ptr() | x.data_ptr()) % 16 == 0):
+            and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and (dy.data_ptr() | x.data_ptr()) % 16 == 0)
+    made = cur["made"].get(key)
+    if uses == 2 and made is not None and thin and _ACC_WGRAD and made[0].shape == (N, K) and made[1] is not None:
+        # the layer's OTHER application (q(z2 | .) over the exemplar rows: a big GEMM, already launched) made this weight's
+        # gradient in this pass: the batch rows' product is ADDED to it by a grouped launch behind the backward pass, and this
+        # application hands autograd nothing -- the sum autograd would form with an element-wise launch per tensor (ten per step
+        # of the 2-level model, four of them behind the last weight gradient, in front of the optimizer) is formed in place
+        cur["jobs"].append((dy, M, N, x, K, made[0], made[1], key, torch.cuda.current_stream(), made[2]))
+        return _ACCUMULATED
+    if not (uses == 1 and key in cur["single"] and thin):
         return None
     if dw is None:
         dw = torch.empty((N, K), device=dy.device); db = torch.empty(N, device=dy.device)
     # (autograd gets VIEWS of dw / db: AccumulateGrad installs a gradient it is handed without copying only while nobody
     #  else holds that tensor object -- handed the buffers the job keeps, it would clone them, still unfilled; and a view
     #  made here holds its base, so it is the job that keeps the bases)
-    cur["jobs"].append((dy, M, N, x, K, dw, db, key, torch.cuda.current_stream()))
+    cur["jobs"].append((dy, M, N, x, K, dw, db, key, torch.cuda.current_stream(), None))
     return dw.view(N, K), db.view(N)
+
+
+_ACCUMULATED = (None, None)          # _bwd_weight's answer when the product joins a gradient made earlier in the pass
+_ACC_WGRAD = os.environ.get("EVAE_ACC_WGRAD", "1") != "0"
+
+
+def _note_made(key, dw, db):
+    """A weight gradient computed NOW (not deferred) inside a deferred_wgrads scope: remembered under the weight's identity, with
+    an event behind its launches, so that a second application of the layer can add its product to it (see _try_defer).  Returns
+    the views to hand to autograd (the scope keeps the bases: handed the bases themselves, AccumulateGrad would clone them)."""
+    cur = _DEFER[0]
+    if cur is None or key is None or not _ACC_WGRAD or db is None or key in cur["made"] or cur["uses"].get(key, 0) != 1:
+        return dw, db
+    ev = torch.cuda.Event(); ev.record()
+    cur["made"][key] = (dw, db, ev)
+    return dw.view(dw.shape), db.view(db.shape)
 
 
 def _bwd_weight(dy, x, rows, K, want_db=True, key=None):
@@ -549,11 +578,13 @@ def _bwd_weight(dy, x, rows, K, want_db=True, key=None):
         d = _try_defer(dy, x, K, key, dw, db)
         if d is not None:
             return d
+    elif key is not None and _DEFER[0] is not None:
+        _DEFER[0]["uses"][key] = _DEFER[0]["uses"].get(key, 0) + 1
     nb = lib.evae_dense_bwd_weight_workspace_bytes(M, N, K)
     ws = _workspace("wgrad", nb, dy.device)
     _lib.check(lib.evae_dense_bwd_weight(_p(dy), M, N, dy.stride(0), _p(x), _p(rows), K, x.stride(0), _p(dw),
                                          _p(db), 0, _p(ws), ws.numel(), _stream()), "evae_dense_bwd_weight")
-    return dw, db
+    return _note_made(key, dw, db)
 
 
 def _bwd_data(dy1_ptr, w1, dy2_ptr, w2, M, N, ldy, device, out_prev=None, s_prev=None, out=None, dg_ptr=None, ldo=None):
@@ -644,6 +675,8 @@ class GatedDenseFn(torch.autograd.Function):
             _lib.check(lib.evae_gated_dense_bwd_input_ld(_p(dout), dout.stride(0), _p(gout), _p(s), M, N, _vp(base), _vp(base + 4 * N),
                                                          2 * N, _stream()), "evae_gated_dense_bwd_input_ld")
         dw, db = _bwd_weight(dpre, x, rows, K, key=wh.data_ptr())  # [dWh ; dWg], [dbh ; dbg]
+        if dw is None:             # added, behind the backward pass, to the gradient the layer's other application made (_try_defer)
+            return (dx, None, None, None, None, None)
         return (dx, None, dw[:N], (db[:N] if ctx.has_bias[0] else None), dw[N:],
                 (db[N:] if ctx.has_bias[1] else None))
 
@@ -845,6 +878,7 @@ class GatedDenseU8Fn(torch.autograd.Function):
                lambda: gated_dense_fwd_u8(x_u8, rows, x_scale, prep, bh, bg, N, out=out, save_s=s), executed=3 * fl, pipe="bf16-mfma")
         if need_grad:
             ctx.save_for_backward(x_u8, rows, out, s)
+        ctx.wkey = wh.data_ptr()
         ctx.x_scale = float(x_scale)
         ctx.has_bias = (bh is not None, bg is not None)
         return out
@@ -864,6 +898,9 @@ class GatedDenseU8Fn(torch.autograd.Function):
         dw, db = probed("dense_bwd_weight_u8 M=%d N=%d K=%d (uint8 rows, three bf16 terms; pre-passes + GEMM + finish)" % (M, 2 * N, K),
                         fl, lambda: dense_bwd_weight_u8(dpre, x_u8, rows, ctx.x_scale, ws_name="wgrad_u8_mod"), executed=3 * fl,
                         pipe="bf16-mfma")
+        if _DEFER[0] is not None:          # (the batch rows' application of this layer may add its product to this one: _try_defer)
+            _DEFER[0]["uses"][ctx.wkey] = _DEFER[0]["uses"].get(ctx.wkey, 0) + 1
+            dw, db = _note_made(ctx.wkey, dw, db)
         return (None, None, None, dw[:N], (db[:N] if ctx.has_bias[0] else None), dw[N:], (db[N:] if ctx.has_bias[1] else None))
 
 

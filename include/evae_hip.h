@@ -325,10 +325,11 @@ typedef struct { int byte_rows; int M, N, K, ldy, ldx; float x_scale; float* dw;
 int evae_dense_bwd_weight_finish_group(const evae_wgrad_finish_job_t* jobs, int njobs, evae_stream_t stream);
 /* Several thin weight gradients in ONE launch (the batch rows' leaf layers of a training step: reference utils/nn.py:44-69
  * backward of the decoder's GatedDense layers and of the log-variance head, utils/training.py:39): every job is
- * dw [N x K] = dy^T x (+ db [N] = column sums of dy, NULL to skip) over M <= 128 contraction rows, no row gather, no accumulation,
+ * dw [N x K] = dy^T x (+ db [N] = column sums of dy, NULL to skip) over M <= 128 contraction rows, no row gather; accumulate != 0:
+ * added to what dw / db hold (the second application of a layer both row sets run through: autograd's sum, formed in place),
  * pointers 16-byte aligned and N, K, ldy, ldx multiples of 4; at most 6 jobs.  EVAE_EINVAL (nothing launched) when a job does not
  * qualify -- issue them with evae_dense_bwd_weight then. */
-typedef struct { const float* dy; const float* x; float* dw; float* db; int M, N, K, ldy, ldx; } evae_wgrad_job_t;
+typedef struct { const float* dy; const float* x; float* dw; float* db; int M, N, K, ldy, ldx, accumulate; } evae_wgrad_job_t;
 int evae_dense_bwd_weight_group(const evae_wgrad_job_t* jobs, int njobs, evae_stream_t stream);
 int evae_gated_dense_bwd_input(const float* dout, const float* out, const float* s, int M, int N,
                                float* dh, float* dg, int ldo, evae_stream_t stream);
