@@ -89,11 +89,12 @@ def gated_flops(M, K, N):
     return 2.0 * M * K * 2 * N
 
 
-def step_flops(model_name, n_ex):
-    """Algorithmic flops of one training step: vae = C x 3.03 MFLOP + B x 5.7 MFLOP + 6 B C z."""
+def step_flops(model_name, n_ex, enc_rows=None):
+    """Algorithmic flops of one training step: vae = C x 3.03 MFLOP + B x 5.7 MFLOP + 6 B C z.  enc_rows: the exemplar
+    rows the encoder really runs over (a captured step encodes the DISTINCT rows of the draw: fewer flops, not a faster rate)."""
     if model_name != "vae":
         return None
-    return n_ex * 3.0336e6 + B * 5.7e6 + 6.0 * B * n_ex * Z
+    return (n_ex if enc_rows is None else enc_rows) * 3.0336e6 + B * 5.7e6 + 6.0 * B * n_ex * Z
 
 
 def cpu_baseline(steps, C=C, N_TRAIN=N_TRAIN):
@@ -668,6 +669,8 @@ def main():
               ("dense_bwd_weight M=", "wgrad2", "gemm_kernel<false, false, 3"),
               ("gated_dense_fwd M=%d K=%d N=%d (pre-split" % (C, H, H), "fwd2_p6", "gemm_p6_kernel<1"),
               ("gated_dense_fwd M=%d K=%d" % (C, H), "fwd2", "gemm_x6_kernel<1"))
+    dd_ = getattr(state["graphed"], "dedup", None) if state.get("graphed") is not None else None
+    enc_rows = dd_["cap"] if dd_ else None
     headline = a.config == "c2" and n_ex == C
     kernels = []
     for name, r in agg.items():
@@ -704,7 +707,7 @@ def main():
                         "fp32 accumulation -- three per product on the uint8 first-layer kernels, six on the split-bf16 GEMM -- so "
                         "the pipe issues 3 x / 6 x the algorithmic flops; that occupancy is pipe_busy_frac, not the roofline "
                         "fraction.  bound = 'fabric' when the launch's PMC pass moved >= 5 TB/s",
-                "step_algorithmic_tflops": round(step_flops(model_name, n_ex) / (dt / a.steps) / 1e12, 2) if step_flops(model_name, n_ex) else None,
+                "step_algorithmic_tflops": round(step_flops(model_name, n_ex, enc_rows) / (dt / a.steps) / 1e12, 2) if step_flops(model_name, n_ex) else None,
                 "kernels": kernels}
 
     # second half of BASELINE.json's metric: test log p(x) (IWAE, S = 5000, all N_train exemplars as the prior)
@@ -826,6 +829,16 @@ def main():
             "step_ms": step_ms,
             "mean_loss": round(final_loss, 4), "mean_loss_f64": final_loss, "steps_in_mean_loss": n_done,
             "replicas_identical": replicas_identical,
+            "exemplar_rows": (None if not dd_ else
+                              {"drawn": n_ex, "encoded_per_step": dd_["cap"], "distinct_in_the_last_step": dd_["distinct"],
+                               "note": "the reference draws its exemplars WITH replacement (models/BaseModel.py:245): %d draws from %d "
+                                       "images name ~%d distinct ones.  The captured step encodes a fixed %d rows (the distinct ones, "
+                                       "padded with multiplicity 0); the prior still sees all %d draws (centres gathered from the distinct "
+                                       "rows' encodings, leave-one-out mask and denominator on the draws), a distinct row's gradient is "
+                                       "its multiplicity x one draw's.  Same loss and gradients as encoding every draw "
+                                       "(tests/test_gpu_model.py::test_graphed_step_over_distinct_exemplar_rows_matches_eager); "
+                                       "EVAE_DEDUP=0 encodes every draw.  roofline.kernels[] are timed on eager probe steps that encode "
+                                       "all %d draws" % (n_ex, n_train, dd_["distinct"], dd_["cap"], n_ex, n_ex)}),
             "roofline": roof,
             "test_log_px": iwae,
             "cpu_baseline": None,

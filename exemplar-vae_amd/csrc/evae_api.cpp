@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdint.h>
+#include <vector>
 
 #include "../../include/evae_hip.h"
 
@@ -34,4 +36,33 @@ extern "C" int evae_ctl_upload(void* d_stage, const void* h_pinned, void* d_ctl,
   if (e == hipSuccess) e = hipEventRecord(ev_used, step);
   if (e != hipSuccess) { evae::set_error("ctl_upload: %s", hipGetErrorString(e)); return EVAE_ELAUNCH; }
   return EVAE_OK;
+}
+
+// Duplicates among the exemplar draw of a step (reference models/BaseModel.py:245: torch.randint WITH replacement -- 25 000 draws
+// from 50 000 rows name ~19 700 distinct images): the distinct rows in first-occurrence order, every draw's position among them,
+// one draw per distinct row and the multiplicities.  Host-side, one pass, O(draws) with a stamp table of n_rows words kept
+// between calls (thread-local).  rows / rep / mult have `cap` entries: the tail behind the U distinct rows is padded with
+// (rows[0], 0, 0.0f).  Returns U, or -1 when U > cap (nothing usable was written) or an index is out of range.
+extern "C" int evae_host_dedup(const int64_t* draws, int n_draws, int64_t n_rows, int cap, int64_t* rows, int64_t* inv, int64_t* rep,
+                               float* mult) {
+  if (!draws || !rows || !inv || !rep || !mult || n_draws <= 0 || n_rows <= 0 || cap <= 0) { evae::set_error("host_dedup: bad arguments"); return -1; }
+  static thread_local std::vector<uint32_t> stamp, slot;
+  static thread_local uint32_t gen = 0;
+  if ((int64_t)stamp.size() < n_rows) { stamp.assign((size_t)n_rows, 0u); slot.assign((size_t)n_rows, 0u); gen = 0; }
+  if (++gen == 0) { std::fill(stamp.begin(), stamp.end(), 0u); gen = 1; }
+  int U = 0;
+  for (int j = 0; j < n_draws; ++j) {
+    const int64_t i = draws[j];
+    if (i < 0 || i >= n_rows) { evae::set_error("host_dedup: index %lld outside [0, %lld)", (long long)i, (long long)n_rows); return -1; }
+    if (stamp[(size_t)i] != gen) {
+      if (U == cap) { evae::set_error("host_dedup: more than %d distinct rows among %d draws", cap, n_draws); return -1; }
+      stamp[(size_t)i] = gen; slot[(size_t)i] = (uint32_t)U;
+      rows[U] = i; rep[U] = j; mult[U] = 1.0f; inv[j] = U; ++U;
+    } else {
+      const uint32_t u = slot[(size_t)i];
+      inv[j] = u; mult[u] += 1.0f;
+    }
+  }
+  for (int u = U; u < cap; ++u) { rows[u] = rows[0]; rep[u] = 0; mult[u] = 0.0f; }
+  return U;
 }

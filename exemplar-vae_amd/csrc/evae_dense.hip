@@ -830,6 +830,30 @@ extern "C" int evae_gated_dense_bwd(const float* dout, int ldd, const float* out
   return dense_bwd_data_core(dpre, wh, dpre + N, wg, M, N, ldp, K, nullptr, nullptr, dx, nullptr, ldo, nullptr, ws, ws_bytes, stream_);
 }
 
+// dst[r][:] = scale[r] * src[idx[r]][:] (scale NULL: 1): the captured step's bridge between the distinct exemplar rows it encodes
+// and the draws the prior sees (centres of all draws from the distinct rows' encodings; a distinct row's head gradient from one
+// of its draws x its multiplicity -- evae/fused_vae.py::DEDUP).  z % 4 == 0, 16-byte aligned rows.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float4* __restrict__ src, const long long* __restrict__ idx,
+                                                          const float* __restrict__ scale, unsigned n, unsigned z4,
+                                                          float4* __restrict__ dst) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * z4) return;
+  const unsigned r = i / z4, c = i - r * z4;
+  float4 v = src[(size_t)idx[r] * z4 + c];
+  if (scale) { const float w = scale[r]; v.x *= w; v.y *= w; v.z *= w; v.w *= w; }
+  dst[i] = v;
+}
+extern "C" int evae_gather_rows(const float* src, const int64_t* idx, const float* scale, int n, int z, float* dst,
+                                evae_stream_t stream_) {
+  if (n <= 0) return EVAE_OK;
+  EVAE_REQUIRE(src && idx && dst && z > 0 && z % 4 == 0 && ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) &&
+               (long long)n * (z / 4) < (1ll << 31), "gather_rows: bad arguments (n=%d z=%d)", n, z);
+  const unsigned total = (unsigned)n * (unsigned)(z / 4);
+  gather_rows_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream_>>>((const float4*)src, (const long long*)idx, scale, (unsigned)n,
+                                                                          (unsigned)(z / 4), (float4*)dst);
+  return check_launch("gather_rows");
+}
+
 extern "C" int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, int act, float act_lo,
                             float act_hi, float* dpre, evae_stream_t stream_) {
   if (n == 0) return EVAE_OK;

@@ -52,6 +52,7 @@ SIGNATURES = {
     "evae_version": (_i, []),
     "evae_last_error": (C.c_char_p, []),
     "evae_ctl_upload": (_i, [_p, _p, _p, _z, _p, _p, _p, _p]),
+    "evae_host_dedup": (_i, [_p, _i, C.c_int64, _i, _p, _p, _p, _p]),
     "evae_prior_set_norm_limit": (_i, [_f]),
     "evae_prior_lse_fwd_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_prior_lse_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
@@ -117,6 +118,7 @@ SIGNATURES = {
     "evae_dense_bwd_weight_finish_group": (_i, [_p, _i, _p]),
     "evae_gated_dense_bwd_input": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "evae_gated_dense_bwd_input_ld": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _i, _p]),
+    "evae_gather_rows": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_gated_dense_bwd": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _z, _p]),
     "evae_act_bwd": (_i, [_p, _p, _z, _i, _f, _f, _p, _p]),
     "evae_conv2d_workspace_bytes": (_z, [_p, _i, _i]),

@@ -91,6 +91,14 @@ PARAM_ORDER = [
 ]
 
 
+# The duplicates among the exemplar draw, set by the captured step's runner around its forward pass (evae/graph.py): None, or
+# (draws [C] int64, inv [C] int64, rep [Cl] int64, mult [Cl] fp32) with ex_idx = the Cl DISTINCT rows (padded, multiplicity 0).  The
+# encoder then runs over the distinct rows only; the prior sees all C draws -- centres gathered through inv, leave-one-out mask on
+# the draws' indices -- and a distinct row's head gradient is mult x the gradient of ONE of its draws (duplicates have identical
+# centres, hence identical prior gradients).  Same loss, same gradients as encoding every draw (reference models/BaseModel.py:243-254).
+DEDUP = [None]
+
+
 def _vp(v):
     if v is None:
         return None
@@ -308,8 +316,14 @@ class VaeExactLoss(torch.autograd.Function):
         lv_row = torch.empty(Z, **f32)                     # the prior's log-variance row
         beta_dev = beta if torch.is_tensor(beta) else None
         beta_host = 0.0 if beta_dev is not None else float(beta)
+        dd = DEDUP[0]
+        if dd is not None and (approx or sharded or dd[2].numel() != Cl or dd[3].numel() != Cl):
+            raise _lib.EvaeError("fused step: the runner's duplicate tables do not belong to this exemplar set")
+        Cp = dd[0].numel() if dd is not None else Cl          # exemplars the prior sees (all draws)
         prior_train = bool(PRIOR_TRAIN and UNIT_UPSTREAM[0] and average and not sharded and Cl > 0 and not ONE_STREAM[0]
-                           and ops.prior_train_applies(B, Cl, Z))
+                           and ops.prior_train_applies(B, Cp, Z))
+        if dd is not None and not prior_train:
+            raise _lib.EvaeError("fused step: duplicate tables need the one-launch prior of a captured step (EVAE_DEDUP=0 turns them off)")
         coef = None
         with torch.cuda.stream(side):
             # (on the side stream, in front of everything: with the byte gather moved behind the batch-row chain the MAIN stream's
@@ -400,7 +414,7 @@ class VaeExactLoss(torch.autograd.Function):
         # ---- exemplar prior (leave-one-out mask in training unless no_mask; with its collectives when sharded) on the
         #      main stream ...
         zi = None if no_mask else ops._i64(x_idx)
-        ci = None if no_mask else (ci_sel if approx else ops._i64(ex_idx))
+        ci = None if no_mask else (ci_sel if approx else ops._i64(dd[0] if dd is not None else ex_idx))
         logp = torch.empty(B, **f32); lse = torch.empty((2, B), **f32)      # lse: the (max, log sum) token of the merge
         z_all, zi_all = z, zi
         prior_done = None
@@ -411,8 +425,17 @@ class VaeExactLoss(torch.autograd.Function):
             dmean_all = torch.empty((Mp, Z), **f32)
             packed = torch.empty(B * Z + Z, **f32)
             ev_pre = torch.cuda.Event(); ev_pre.record()
-            ops.prior_train_step(z, centres, lv_row, zi, ci, float(c_total), beta_dev if beta_dev is not None else beta_host,
-                                 out=(logp, lse, None, packed[:B * Z].view(B, Z), dmean_all[:Cl], packed[B * Z:]), stream=k.st)
+            if dd is not None:
+                # the prior over all C draws: centres of the draws gathered from the distinct rows' encodings; a distinct row's
+                # gradient = multiplicity x the gradient of one of its draws
+                centres_x = torch.empty((Cp, Z), **f32); dc_x = torch.empty((Cp, Z), **f32)
+                _lib.check(lib.evae_gather_rows(_vp(centres), _vp(dd[1]), None, Cp, Z, _vp(centres_x), k.st), "gather_rows(centres)")
+                ops.prior_train_step(z, centres_x, lv_row, zi, ci, float(c_total), beta_dev if beta_dev is not None else beta_host,
+                                     out=(logp, lse, None, packed[:B * Z].view(B, Z), dc_x, packed[B * Z:]), stream=k.st)
+                _lib.check(lib.evae_gather_rows(_vp(dc_x), _vp(dd[2]), _vp(dd[3]), Cl, Z, _vp(dmean_all), k.st), "gather_rows(dcentres)")
+            else:
+                ops.prior_train_step(z, centres, lv_row, zi, ci, float(c_total), beta_dev if beta_dev is not None else beta_host,
+                                     out=(logp, lse, None, packed[:B * Z].view(B, Z), dmean_all[:Cl], packed[B * Z:]), stream=k.st)
             prior_done = (dmean_all, packed, ev_pre)
         if sharded == 2:
             # data-parallel batches over sharded exemplars: every rank scores the queries of ALL ranks against its

@@ -15,6 +15,7 @@ in the control block); whatever else draws random numbers uses the CUDA generato
 capture so that every replay advances its Philox offset.  RCCL collectives of the sharded prior are captured too.
 """
 import ctypes as C
+import math
 import os
 import time
 import sys
@@ -75,9 +76,42 @@ class GraphedTrainStep:
         # waits for a DMA engine or for the host.
         self.ngroups = len(optimizer.param_groups)
         nsc = 1 + self.ngroups
-        self._o_idx, self._o_seed = Cl + self.B, Cl + 2 * self.B
+        # Duplicates among the draw (the reference draws WITH replacement, models/BaseModel.py:245): when they are worth it the
+        # gather list holds the DISTINCT rows only -- `cap` of them, a fixed count the distinct rows of a draw stay under by
+        # eight standard deviations, padded with multiplicity 0 -- and the block carries the draw itself, every draw's
+        # position among the distinct rows, one draw per distinct row and the multiplicities behind its scalars
+        # (evae_host_dedup on the host; evae/fused_vae.py::DEDUP for what the step does with them).  EVAE_DEDUP=0: off.
+        self.dedup = None
+        Cd = Cl                                  # rows of the gather list's head
+        Nt = int(a.training_set_size)
+        from . import fused_vae as _fv0
+        if (os.environ.get("EVAE_DEDUP", "1") != "0" and self.u8 and Cl == C and not a.approximate_prior and not model._sharded()
+                and a.model_name == 'vae' and Nt > 0
+                # (what the step does with the tables needs the one-launch prior of a captured step: the same predicate as there)
+                and os.environ.get("EVAE_UNIT_UPSTREAM", "1") != "0" and _fv0.PRIOR_TRAIN and not _fv0.ONE_STREAM[0]
+                and ops.prior_train_applies(self.B, C, int(a.z1_size))):
+            # distinct rows among C draws from Nt: mean Nt (1 - q), variance Nt q (1 - q) + Nt (Nt - 1) (q2 - q^2) with q = (1 - 1/Nt)^C
+            # the chance that a given row is not drawn, q2 = (1 - 2/Nt)^C that two given rows are not (the occupancies are
+            # negatively correlated: c2's 25 000 of 50 000 give 19 673 +- 52); cap = mean + 8 sigma, whole 128-row tiles
+            lq = C * math.log1p(-1.0 / Nt) if Nt > 1 else -math.inf
+            q = math.exp(lq)
+            dq = q * q * math.expm1(C * math.log1p(-2.0 / Nt) - 2.0 * lq) if Nt > 2 else 0.0       # q2 - q^2
+            mean_u = Nt * (1.0 - q)
+            var_u = max(Nt * q * (1.0 - q) + Nt * (Nt - 1.0) * dq, 1.0)
+            cap = min(C, int(math.ceil((mean_u + 8.0 * math.sqrt(var_u) + 32.0) / 128.0)) * 128)
+            if cap <= 0.92 * C:
+                self.dedup = {"cap": cap, "distinct": 0}
+                Cd = cap
+        self._Cd = Cd
+        self._o_idx, self._o_seed = Cd + self.B, Cd + 2 * self.B
         self._o_scal = self._o_seed + 2
         words = self._o_scal + (nsc + 1) // 2
+        if self.dedup is not None:
+            self._o_draw = words
+            self._o_inv = self._o_draw + C
+            self._o_rep = self._o_inv + C
+            self._o_mult = self._o_rep + Cd
+            words = self._o_mult + (Cd + 1) // 2
         self.ctl = torch.zeros(words, dtype=torch.int64, device=dev)
         self.rows = self.ctl[:self._o_idx]
         self.idx_flat = self.ctl[self._o_idx:self._o_seed]
@@ -86,10 +120,14 @@ class GraphedTrainStep:
         self.scal = self.ctl[self._o_scal:].view(torch.float32)[:nsc]
         self.beta = self.scal[0:1].reshape(())
         tail = torch.arange(self.n_data, self.n_data + self.B)
-        self.rows[Cl:] = tail.to(dev)
+        self.rows[Cd:] = tail.to(dev)
         self._h_ctl = [torch.zeros(words, dtype=torch.int64).pin_memory() for _ in range(2)]
         for h in self._h_ctl:
-            h[Cl:self._o_idx] = tail
+            h[Cd:self._o_idx] = tail
+        if self.dedup is not None:
+            self.dedup["tables"] = (self.ctl[self._o_draw:self._o_inv], self.ctl[self._o_inv:self._o_rep],
+                                    self.ctl[self._o_rep:self._o_mult], self.ctl[self._o_mult:].view(torch.float32)[:Cd])
+            self.dedup["host_mult"] = [h[self._o_mult:].view(torch.float32) for h in self._h_ctl]
         # numpy views of the pinned blocks: a field write through them costs ~0.3 us, through a tensor index ~3 us (r03: the
         # replayed step of a small exemplar set is bound by the host -- 56 graph nodes at ~3.9 us of hipGraphLaunch each plus
         # this function -- so its microseconds are the step's)
@@ -103,7 +141,7 @@ class GraphedTrainStep:
         # staged path's six stream / event / copy operations go through ONE C call, evae_ctl_upload: 56 us of host time instead
         # of 65 -- the HIP calls themselves cost that, not the bindings.)
         e = os.environ.get("EVAE_CTL_DIRECT")
-        self._direct = (Cl + self.B <= 8192) if e is None else e == "1"
+        self._direct = (Cd + self.B <= 8192) if e is None else e == "1"
         self._h_draw = torch.zeros(C, dtype=torch.int64)                 # the full draw when only a shard is uploaded
         self._d_ctl = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(2)]
         self._up = torch.cuda.Stream(device=dev)
@@ -195,11 +233,13 @@ class GraphedTrainStep:
         from . import fused_vae as _fv
         _fv.UNIT_UPSTREAM[0] = os.environ.get("EVAE_UNIT_UPSTREAM", "1") != "0"     # the backward below is loss.backward(ones), nothing else
         ops.STEP_BETA[0] = self.beta if _fv.UNIT_UPSTREAM[0] else None              # (the modular paths' prior: ops.prior_logp)
+        _fv.DEDUP[0] = self.dedup["tables"] if self.dedup is not None else None
         try:
             loss, RE, KL = self.model.calculate_loss((x, self.idx_in), self.beta, average=True, dataset=self.dataset,
                                                      cache=self.cache)
         finally:
             _fv.UNIT_UPSTREAM[0] = False
+            _fv.DEDUP[0] = None
             ops.STEP_BETA[0] = None
         if self.by_index and self.u8:
             from . import fused_vae
@@ -243,7 +283,17 @@ class GraphedTrainStep:
         if T: t0 = T.lap("wait for the block's last upload", t0)
         h = self._h_ctl[k]
         # same CPU-generator draw, with replacement, as the reference (models/BaseModel.py:245)
-        if Cl == a.number_components:
+        if self.dedup is not None:
+            dr = h[self._o_draw:self._o_inv]
+            torch.randint(low=0, high=a.training_set_size, size=(Cl,), out=dr)
+            cap = self.dedup["cap"]
+            nu = _lib.load().evae_host_dedup(C.c_void_p(dr.data_ptr()), Cl, int(a.training_set_size), cap, C.c_void_p(h.data_ptr()),
+                                             C.c_void_p(h[self._o_inv:].data_ptr()), C.c_void_p(h[self._o_rep:].data_ptr()),
+                                             C.c_void_p(self.dedup["host_mult"][k].data_ptr()))
+            if nu < 0:
+                raise RuntimeError("captured step: " + _lib.load().evae_last_error().decode("utf-8", "replace") + " -- EVAE_DEDUP=0 encodes every draw")
+            self.dedup["distinct"] = nu
+        elif Cl == a.number_components:
             torch.randint(low=0, high=a.training_set_size, size=(Cl,), out=h[:Cl])
         else:
             torch.randint(low=0, high=a.training_set_size, size=(a.number_components,), out=self._h_draw)
@@ -284,7 +334,7 @@ class GraphedTrainStep:
             # this graph's launches read the step size from ITS control block (another runner on the same optimizer has its own)
             self._adam_tables["step_size"] = [self.scal[1 + g:2 + g] for g in range(self.ngroups)]
             self.opt.enable_graph_mode(storage=self._adam_tables["step_size"])
-        self.model._exemplar_indices_override = (self.rows, self.hi - self.lo)
+        self.model._exemplar_indices_override = (self.rows, self._Cd)
         try:
             self._refresh(data, indices, beta)
             self.model._eps_override = self.eps_buf if self.by_index else None

@@ -45,6 +45,13 @@ const char* evae_last_error(void);
 int evae_ctl_upload(void* d_stage, const void* h_pinned, void* d_ctl, size_t bytes, evae_stream_t up, evae_stream_t step,
                     void* ev_used, void* ev_up);
 
+/* Host-side (no device work): the duplicates among a step's exemplar draw.  The reference draws number_components indices WITH
+ * replacement (models/BaseModel.py:245) and encodes every draw; an image drawn twice has the same encoding, the same prior
+ * term and the same gradient twice.  draws [n_draws] -> rows [cap]: the distinct indices in first-occurrence order (tail padded
+ * with rows[0]); inv [n_draws]: each draw's position in rows; rep [cap]: one draw of each distinct row (padding: 0); mult [cap]:
+ * multiplicities as floats (padding: 0).  Returns the number of distinct rows, or -1 (more than cap / index out of range). */
+int evae_host_dedup(const int64_t* draws, int n_draws, int64_t n_rows, int cap, int64_t* rows, int64_t* inv, int64_t* rep, float* mult);
+
 /* ----------------------------------------------------------------------------------------------
  * Exemplar prior: fused all-pairs distance + leave-one-out mask + online log-sum-exp.
  * Replaces utils/distributions.py:12-25 (pairwise_distance, log_normal_diag_vectorized) and
@@ -344,6 +351,9 @@ int evae_gated_dense_bwd_input_ld(const float* dout, int ldd, const float* out, 
 int evae_gated_dense_bwd(const float* dout, int ldd, const float* out, const float* s, int M, int N, const float* wh,
                          const float* wg, int K, float* dpre, int ldp, float* dx, int ldo, void* ws, size_t ws_bytes,
                          evae_stream_t stream);
+/* dst [n x z] = scale[r] * src[idx[r]] (scale NULL: 1), z a multiple of 4: the bridge between the DISTINCT exemplar rows a captured
+ * step encodes and the draws (with replacement, models/BaseModel.py:245) its prior sees -- see evae_host_dedup */
+int evae_gather_rows(const float* src, const int64_t* idx, const float* scale, int n, int z, float* dst, evae_stream_t stream);
 int evae_act_bwd(const float* dy, const float* y_or_pre, size_t n, int act, float act_lo, float act_hi,
                  float* dpre, evae_stream_t stream);
 

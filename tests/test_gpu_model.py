@@ -1352,3 +1352,52 @@ def test_single_conv_training_step_at_c5_size():
     idx, val = ops.pairdist_topk(q, cz, k)
     _, ref_idx = orc.nearest_exemplars_topk(q.double().cpu().numpy(), cz.double().cpu().numpy(), k)
     assert np.array_equal(idx.cpu().numpy(), ref_idx)
+
+
+@pytest.mark.parametrize("upload", ["direct", "staged"])
+def test_graphed_step_over_distinct_exemplar_rows_matches_eager(upload, monkeypatch):
+    """EVAE_DEDUP=1 (r04): the captured step encodes the DISTINCT rows of the exemplar draw only (4 000 draws with replacement from
+    4 000 images name ~2 530 of them), the prior sees every draw through a gather of the distinct rows' encodings, a distinct
+    row's gradient is its multiplicity x one draw's -- same losses and same parameters after seven steps as the eager step that
+    encodes every draw (reference models/BaseModel.py:243-254), to 1e-5."""
+    monkeypatch.setenv("EVAE_DEDUP", "1")
+    monkeypatch.setenv("EVAE_CTL_DIRECT", "1" if upload == "direct" else "0")
+    from evae.graph import GraphedTrainStep
+    from utils.optimizer import AdamNormGrad
+    B, C, N = 100, 4000, 4000
+    data = gi.binary_images(15, N)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    results = []
+    for use_graph in (False, True):
+        args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=B)
+        model, _ = smoke_case.build_model(torch, np, orc, args)
+        model.train()
+        opt = AdamNormGrad(model.parameters(), lr=5e-4)
+        torch.manual_seed(13); torch.cuda.manual_seed(13)
+        runner = GraphedTrainStep(model, opt, dataset, B, False) if use_graph else None
+        losses = []
+        for it in range(7):
+            xb = torch.from_numpy(data[it * B:(it + 1) * B])
+            ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1)
+            if runner is not None:
+                losses.append(runner(xb, ib, 0.5)[0].item())
+                assert 0 < runner.dedup["distinct"] <= runner.dedup["cap"] < 0.92 * C
+            else:
+                xb, ib = xb.cuda(), ib.cuda()
+                from evae import ops as _ops
+                eps = torch.empty((B, args.z1_size), device="cuda")
+                _ops.batch_prologue(torch.from_numpy(data).cuda(), ib.reshape(-1).contiguous(), False,
+                                    torch.tensor([13, it], dtype=torch.int64, device="cuda"), torch.empty_like(xb), eps)
+                model._eps_override = eps
+                opt.zero_grad()
+                loss, RE, KL = model.calculate_loss((xb, ib), 0.5, average=True, dataset=dataset)
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+        results.append((losses, {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}))
+        if runner is not None:
+            assert runner.graph is not None and runner.by_index and runner.dedup is not None
+    (l0, p0), (l1, p1) = results
+    assert rel(np.asarray(l1), np.asarray(l0)) < 1e-5
+    for k in p0:
+        assert rel(p1[k], p0[k]) < 1e-5, k

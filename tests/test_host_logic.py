@@ -301,3 +301,32 @@ def test_host_thread_budget_follows_the_cgroup_quota(monkeypatch, tmp_path):
     finally:
         hostcpu._DONE[0] = True
         torch.set_num_threads(before)
+
+
+def test_host_dedup_of_an_exemplar_draw():
+    """evae_host_dedup (host side of the captured step, r04): the distinct rows of a draw with replacement (reference
+    models/BaseModel.py:245) in first-occurrence order, every draw's position among them, one draw per distinct row, the
+    multiplicities; padding behind the distinct rows; refusal when they do not fit."""
+    import ctypes as C
+    from evae import _lib
+    lib = _lib.load()
+    for n, N, seed in ((25000, 50000, 0), (1000, 50000, 1), (64, 8, 2), (1, 1, 3)):
+        rs = np.random.RandomState(seed)
+        d = torch.from_numpy(rs.randint(0, N, n).astype(np.int64))
+        cap = min(n, N) + 5
+        rows = torch.full((cap,), -7, dtype=torch.int64); inv = torch.zeros(n, dtype=torch.int64)
+        rep = torch.full((cap,), -7, dtype=torch.int64); mult = torch.full((cap,), -7.0)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        for _ in range(2):             # (the stamp table is kept between calls)
+            U = lib.evae_host_dedup(p(d), n, N, cap, p(rows), p(inv), p(rep), p(mult))
+        dn, r, iv, rp, m = d.numpy(), rows.numpy(), inv.numpy(), rep.numpy(), mult.numpy()
+        uniq, first = np.unique(dn, return_index=True)
+        assert U == len(uniq)
+        assert np.array_equal(r[:U], dn[np.sort(first)])                    # first-occurrence order
+        assert np.array_equal(r[iv], dn) and np.array_equal(iv[rp[:U]], np.arange(U))
+        assert np.array_equal(m[:U], np.bincount(dn, minlength=N)[r[:U]].astype(np.float32))
+        assert (r[U:] == r[0]).all() and (rp[U:] == 0).all() and (m[U:] == 0).all()
+        if U > 1:
+            assert lib.evae_host_dedup(p(d), n, N, U - 1, p(rows), p(inv), p(rep), p(mult)) == -1
+    bad = torch.tensor([0, 9], dtype=torch.int64)
+    assert lib.evae_host_dedup(C.c_void_p(bad.data_ptr()), 2, 5, 4, p(rows), p(inv), p(rep), p(mult)) == -1
