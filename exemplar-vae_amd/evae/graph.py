@@ -85,11 +85,14 @@ class GraphedTrainStep:
         Cd = Cl                                  # rows of the gather list's head
         Nt = int(a.training_set_size)
         from . import fused_vae as _fv0
-        if (os.environ.get("EVAE_DEDUP", "1") != "0" and self.u8 and Cl == C and not a.approximate_prior and not model._sharded()
-                and a.model_name == 'vae' and Nt > 0
-                # (what the step does with the tables needs the one-launch prior of a captured step: the same predicate as there)
-                and os.environ.get("EVAE_UNIT_UPSTREAM", "1") != "0" and _fv0.PRIOR_TRAIN and not _fv0.ONE_STREAM[0]
-                and ops.prior_train_applies(self.B, C, int(a.z1_size))):
+        want = (os.environ.get("EVAE_DEDUP", "1") != "0" and Cl == C and not a.approximate_prior and not model._sharded() and Nt > 0
+                and a.prior == 'exemplar_prior' and int(a.z1_size) % 4 == 0)
+        if want and a.model_name == 'vae' and model._fused_config():
+            # the fused node: what it does with the tables needs the byte store and the one-launch prior of a captured step (the
+            # same predicate as there).  Every other model meets them in get_exemplar_set (models/BaseModel.py, ops.ExpandRowsFn)
+            want = (self.u8 and os.environ.get("EVAE_UNIT_UPSTREAM", "1") != "0" and _fv0.PRIOR_TRAIN and not _fv0.ONE_STREAM[0]
+                    and ops.prior_train_applies(self.B, C, int(a.z1_size)))
+        if want:
             # distinct rows among C draws from Nt: mean Nt (1 - q), variance Nt q (1 - q) + Nt (Nt - 1) (q2 - q^2) with q = (1 - 1/Nt)^C
             # the chance that a given row is not drawn, q2 = (1 - 2/Nt)^C that two given rows are not (the occupancies are
             # negatively correlated: c2's 25 000 of 50 000 give 19 673 +- 52); cap = mean + 8 sigma, whole 128-row tiles
@@ -335,6 +338,7 @@ class GraphedTrainStep:
             self._adam_tables["step_size"] = [self.scal[1 + g:2 + g] for g in range(self.ngroups)]
             self.opt.enable_graph_mode(storage=self._adam_tables["step_size"])
         self.model._exemplar_indices_override = (self.rows, self._Cd)
+        self.model._exemplar_dedup = self.dedup["tables"] if self.dedup is not None else None
         try:
             self._refresh(data, indices, beta)
             self.model._eps_override = self.eps_buf if self.by_index else None
@@ -400,5 +404,6 @@ class GraphedTrainStep:
             return self.out
         finally:
             self.model._exemplar_indices_override = None
+            self.model._exemplar_dedup = None
             self.model._eps_override = None
             self.model._batch_staged = False

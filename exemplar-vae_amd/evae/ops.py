@@ -631,6 +631,41 @@ def _rows_x(x, rows):
     return x, rows, M
 
 
+class ExpandRowsFn(torch.autograd.Function):
+    """Encodings of the DISTINCT exemplar rows [U x z] -> encodings of every draw [C x z] (out[j] = src[inv[j]]), for a captured
+    step that encodes each distinct image once (the reference draws with replacement, models/BaseModel.py:245, and encodes every
+    draw).  Backward: a distinct row's gradient = its multiplicity x the gradient of ONE of its draws (rep) -- duplicates have
+    identical encodings, hence identical gradients from the prior; padding rows have multiplicity 0.  evae_gather_rows both ways."""
+
+    @staticmethod
+    def forward(ctx, src, inv, rep, mult):
+        lib = _lib.load()
+        src = _f32(src)
+        if not src.is_contiguous():
+            src = src.contiguous()
+        n, z = inv.numel(), src.shape[1]
+        out = torch.empty((n, z), device=src.device)
+        _lib.check(lib.evae_gather_rows(_p(src), _p(inv), None, n, z, _p(out), _stream()), "evae_gather_rows")
+        ctx.save_for_backward(rep, mult)
+        ctx.u = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        rep, mult = ctx.saved_tensors
+        g = _f32(g)
+        if not g.is_contiguous():
+            g = g.contiguous()
+        out = torch.empty((ctx.u, g.shape[1]), device=g.device)
+        _lib.check(lib.evae_gather_rows(_p(g), _p(rep), _p(mult), ctx.u, g.shape[1], _p(out), _stream()), "evae_gather_rows(bwd)")
+        return out, None, None, None
+
+
+def expand_rows(src, inv, rep, mult):
+    return ExpandRowsFn.apply(src, inv, rep, mult)
+
+
 class GatedDenseFn(torch.autograd.Function):
     """utils/nn.py:44-69 (activation None, gate on): h(x) * sigmoid(g(x)), optional row gather."""
 

@@ -476,6 +476,15 @@ class BaseModel(nn.Module, ABC):
                 rows_ext, n_local = override
                 local = rows_ext[:n_local]
                 centres, logvar = self.q_z(self._exemplar_store(dataset), prior=True, rows=local)
+                dd = getattr(self, '_exemplar_dedup', None)
+                if dd is not None and not self._sharded():
+                    # the gather list holds the DISTINCT rows of the draw (evae/graph.py): the prior gets every draw's encoding,
+                    # log-variance and index -- what the reference's one-encoding-per-draw hands it (:243-254)
+                    draws, inv, rep, mult = dd
+                    centres = ops.expand_rows(centres, inv, rep, mult)
+                    logvar = self.prior_log_variance.expand(draws.numel(), self.args.z1_size)
+                    logvar._evae_prior_scalar = self.prior_log_variance
+                    local = draws
                 if self._sharded():
                     return shard.ShardedEmbedding((centres, logvar, local), total=self.args.number_components)
                 return (centres, logvar, local)

@@ -1401,3 +1401,50 @@ def test_graphed_step_over_distinct_exemplar_rows_matches_eager(upload, monkeypa
     assert rel(np.asarray(l1), np.asarray(l0)) < 1e-5
     for k in p0:
         assert rel(p1[k], p0[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("model_name", ["hvae_2level", "convhvae_2level", "vae_modular"])
+def test_graphed_modular_step_over_distinct_exemplar_rows_matches_eager(model_name, monkeypatch):
+    """EVAE_DEDUP on the modular autograd path (r04): get_exemplar_set encodes the DISTINCT rows of the draw and hands the prior
+    every draw's encoding through ops.ExpandRowsFn (forward: gather; backward: multiplicity x one draw's gradient) -- the
+    hierarchical, convolutional and un-fused `vae` models replay the same trajectory as the eager step that encodes every draw
+    (reference models/BaseModel.py:243-254), 2 400 draws with replacement from 2 400 images."""
+    monkeypatch.setenv("EVAE_DEDUP", "1")
+    from evae.graph import GraphedTrainStep
+    from utils.optimizer import AdamNormGrad
+    from utils.utils import importing_model
+    B, C, N = 16, 2400, 2400
+    data = gi.binary_images(16, N)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    results = []
+    for use_graph in (False, True):
+        args = smoke_case.vae_args(model_name="vae" if model_name == "vae_modular" else model_name, number_components=C,
+                                   training_set_size=N, batch_size=B)
+        torch.manual_seed(5); torch.cuda.manual_seed(5)
+        model = importing_model(args)(args).cuda()
+        if model_name == "vae_modular":
+            model._use_fused = False
+        model.train()
+        opt = AdamNormGrad(model.parameters(), lr=5e-4)
+        torch.manual_seed(3); torch.cuda.manual_seed(3)
+        runner = GraphedTrainStep(model, opt, dataset, B, False) if use_graph else None
+        losses = []
+        for it in range(6):
+            xb = torch.from_numpy(data[it * B:(it + 1) * B]).cuda()
+            ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1).cuda()
+            if runner is not None:
+                losses.append(runner(xb, ib, 0.5)[0].item())
+                assert 0 < runner.dedup["distinct"] <= runner.dedup["cap"] < 0.92 * C
+            else:
+                opt.zero_grad()
+                loss, RE, KL = model.calculate_loss((xb, ib), 0.5, average=True, dataset=dataset)
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+        results.append((losses, {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}))
+        if runner is not None:
+            assert runner.graph is not None and not runner.failed and runner.dedup is not None
+    (l0, p0), (l1, p1) = results
+    assert rel(np.asarray(l1), np.asarray(l0)) < 2e-5
+    for k_ in p0:
+        assert rel(p1[k_], p0[k_]) < 5e-5, k_
