@@ -313,7 +313,16 @@ def other_config(a, dev, rank, world, rccl_ranks=1, backend=None):
               "latents, <= 1000 exemplars re-encoded per step, batch %d (BASELINE.json configs[4], one GPU)" % (n_ex, B)) if c5 else \
              ("convhvae_2level + exemplar_prior, fashion_mnist-shaped binary 28x28, N=%d, batch %d, %d exemplars, exact prior "
               "(BASELINE.json configs[2])" % (n_train, B, n_ex))
+        dd_ = getattr(runner, "dedup", None) if runner is not None else None
+        ex_rows = None if not dd_ else {
+            "drawn": n_ex, "encoded_per_step": dd_["cap"], "distinct_in_the_last_step": dd_["distinct"],
+            "note": "the exemplars are drawn WITH replacement (reference models/BaseModel.py:245); the captured step encodes the distinct "
+                    "images of the draw once (a fixed %d rows, padded with multiplicity 0), the prior sees every draw (ops.ExpandRowsFn); same "
+                    "loss and gradients as encoding every draw (tests/test_gpu_model.py::"
+                    "test_graphed_modular_step_over_distinct_exemplar_rows_matches_eager); EVAE_DEDUP=0 encodes every draw.  The roofline "
+                    "kernel below is timed at all %d images" % (dd_["cap"], n_ex)}
         print(json.dumps(line("training images/sec", round(B * a.steps / dt, 1), "images/sec", a, dt, wl, roof,
+                              extra={"exemplar_rows": ex_rows},
                               launch="eager" if runner is None or runner.graph is None else "hipGraph replay of the whole step")))
         return
     if a.config == "iwae":
