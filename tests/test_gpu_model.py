@@ -1448,3 +1448,37 @@ def test_graphed_modular_step_over_distinct_exemplar_rows_matches_eager(model_na
     assert rel(np.asarray(l1), np.asarray(l0)) < 2e-5
     for k_ in p0:
         assert rel(p1[k_], p0[k_]) < 5e-5, k_
+
+
+def test_distinct_rows_step_at_config2_size_equals_the_every_draw_step(monkeypatch):
+    """BASELINE configs[1] itself (25 000 draws from 50 000 images, batch 100): five captured steps that encode the ~19 700
+    distinct images of each draw (20 224 rows) against five captured steps that encode every draw (EVAE_DEDUP=0) from the same
+    seeds -- the same losses and the same parameters to 1e-5 (the two differ in the order of a few sums only)."""
+    from evae.graph import GraphedTrainStep
+    from utils.optimizer import AdamNormGrad
+    B, C, N = 100, 25000, 50000
+    data = gi.binary_images(0, N)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    results = []
+    for dedup in ("1", "0"):
+        monkeypatch.setenv("EVAE_DEDUP", dedup)
+        args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=B)
+        model, _ = smoke_case.build_model(torch, np, orc, args)
+        model.train()
+        opt = AdamNormGrad(model.parameters(), lr=5e-4)
+        torch.manual_seed(23); torch.cuda.manual_seed(23)
+        runner = GraphedTrainStep(model, opt, dataset, B, True)
+        losses = []
+        for it in range(5):
+            xb = torch.from_numpy(data[it * B:(it + 1) * B])
+            ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1)
+            losses.append(runner(xb, ib, 0.5)[0].item())
+        assert runner.graph is not None
+        assert (runner.dedup is not None) == (dedup == "1")
+        if dedup == "1":
+            assert runner.dedup["cap"] == 20224 and 19300 < runner.dedup["distinct"] < 20050
+        results.append((losses, {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}))
+    (l1, p1), (l0, p0) = results
+    assert rel(np.asarray(l1), np.asarray(l0)) < 1e-5
+    for k_ in p0:
+        assert rel(p1[k_], p0[k_]) < 1e-5, k_
