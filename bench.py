@@ -637,13 +637,22 @@ def main():
     # after the timed region (identical kernels, identical shapes); the rocprofv3 summary of the whole
     # command (profiles/) reports the same average for this kernel.
     graphed = state["graphed"]
+    dd_ = getattr(graphed, "dedup", None) if graphed is not None else None
+    enc_rows = dd_["cap"] if dd_ else None
     # the clocks sag during the host pause above and take ~12 eager steps (30 ms) to come back: untimed steps first,
     # otherwise the event pairs time the launch at a lower clock than the timed region (and rocprof's trace of it) ran at
+    def probe_step(i):
+        # the runner's own step issued eagerly (same control block, same rows -- the distinct exemplar rows when it encodes those --
+        # same optimizer form); plain eager steps when the capture was refused
+        if graphed.graph is None:
+            return eager_step(i)
+        s_ = batch_start(i)
+        graphed.step_eagerly(data_dev[s_:s_ + B], idx_host[s_:s_ + B], beta)
     for i in range(a.probe_warmup if graphed is not None else 0):
-        eager_step(n_done + i)
+        probe_step(n_done + i)
     ops.PROBE = {"records": [], "min_flops": 2e9 if n_ex >= 10000 and not approx else 2e8}
     for i in range(a.probe_steps if graphed is not None else 0):
-        eager_step(n_done + a.probe_warmup + i)
+        probe_step(n_done + a.probe_warmup + i)
     fence()
     probe, ops.PROBE = ops.PROBE, None
     if world > 1:
@@ -667,25 +676,26 @@ def main():
     PEAKS = {"fp32-mfma": PEAK_FP32_MFMA_TFLOPS, "bf16-mfma": PEAK_BF16_MFMA_TFLOPS}
     # PMC pass (tools/kernel_probe.py names) of each launch family at the headline sizes: its counter bytes label the bound
     # (launch-name prefix, probe file, kernel symbol that launch runs)
+    Cm = enc_rows if enc_rows else C            # exemplar rows of the step's large launches
     pmc_of = (("dense_bwd_weight_u8", "u8wgrad1", "u8_gemm_kernel<false>"),
-              ("gated_dense_fwd_u8 M=%d K=%d N=%d (uint8 rows, three bf16 terms; output + its" % (C, D, H), "u8fwd1_img", "u8p_gemm_kernel"),
+              ("gated_dense_fwd_u8 M=%d K=%d N=%d (uint8 rows, three bf16 terms; output + its" % (Cm, D, H), "u8fwd1_img", "u8p_gemm_kernel"),
               ("gated_dense_fwd_u8", "u8fwd1", "u8p_gemm_kernel"),
-              ("dense_bwd_data M=%d N=%d+%d K=%d (pre-split" % (C, H, H, H), "dgrad2_p6", "gemm_p6_kernel<9"),
-              ("dense_bwd_data M=%d N=%d+" % (C, H), "dgrad2", "gemm_x6_kernel<9"),
-              ("dense_bwd_data M=%d N=%d K=%d (gate-backward epilogue -> pre-split" % (C, Z, H), "hdgrad2_img", "gemm_x6_kernel<2"),
-              ("dense_bwd_weight M=%d N=%d K=%d (+db; pre-split" % (C + B, 2 * H, H), "wgrad2_p6", "gemm_p6_kernel<3"),
-              ("dense_bwd_weight M=%d N=%d K=%d" % (C + B, Z, H), "hwgrad", "narrow_wgrad_kernel"),
+              ("dense_bwd_data M=%d N=%d+%d K=%d (pre-split" % (Cm, H, H, H), "dgrad2_p6", "gemm_p6_kernel<9"),
+              ("dense_bwd_data M=%d N=%d+" % (Cm, H), "dgrad2", "gemm_x6_kernel<9"),
+              ("dense_bwd_data M=%d N=%d K=%d (gate-backward epilogue -> pre-split" % (Cm, Z, H), "hdgrad2_img", "gemm_x6_kernel<2"),
+              ("dense_bwd_weight M=%d N=%d K=%d (+db; pre-split" % (Cm + B, 2 * H, H), "wgrad2_p6", "gemm_p6_kernel<3"),
+              ("dense_bwd_weight M=%d N=%d K=%d" % (Cm + B, Z, H), "hwgrad", "narrow_wgrad_kernel"),
               ("dense_bwd_weight M=", "wgrad2", "gemm_kernel<false, false, 3"),
-              ("gated_dense_fwd M=%d K=%d N=%d (pre-split" % (C, H, H), "fwd2_p6", "gemm_p6_kernel<1"),
-              ("gated_dense_fwd M=%d K=%d" % (C, H), "fwd2", "gemm_x6_kernel<1"))
-    dd_ = getattr(state["graphed"], "dedup", None) if state.get("graphed") is not None else None
-    enc_rows = dd_["cap"] if dd_ else None
+              ("gated_dense_fwd M=%d K=%d N=%d (pre-split" % (Cm, H, H), "fwd2_p6", "gemm_p6_kernel<1"),
+              ("gated_dense_fwd M=%d K=%d" % (Cm, H), "fwd2", "gemm_x6_kernel<1"))
     headline = a.config == "c2" and n_ex == C
     kernels = []
     for name, r in agg.items():
         us = r["us"] / r["n"]
         pm = next(((f, sym) for pre, f, sym in pmc_of if name.startswith(pre)), None) if headline else None
         traffic, traffic_src = pmc_traffic(*pm) if pm else (None, None)
+        if traffic is not None and enc_rows and traffic_src:
+            traffic_src += "; the PMC pass ran this launch at %d exemplar rows, the step runs it at %d" % (C, enc_rows)
         if r["pipe"] == "hbm":       # a streaming launch: algorithmic bytes / time against the HBM peak
             kernels.append({"launch": name, "pipe": "hbm", "avg_launch_us": round(us, 2), "launches": r["n"],
                             "algorithmic_tb_per_s": round(r["flops"] / us / 1e6, 3), "frac": round(r["flops"] / us / 1e6 / (PEAK_HBM_GBS / 1000.0), 4),
@@ -846,8 +856,8 @@ def main():
                                        "rows' encodings, leave-one-out mask and denominator on the draws), a distinct row's gradient is "
                                        "its multiplicity x one draw's.  Same loss and gradients as encoding every draw "
                                        "(tests/test_gpu_model.py::test_graphed_step_over_distinct_exemplar_rows_matches_eager); "
-                                       "EVAE_DEDUP=0 encodes every draw.  roofline.kernels[] are timed on eager probe steps that encode "
-                                       "all %d draws" % (n_ex, n_train, dd_["distinct"], dd_["cap"], n_ex, n_ex)}),
+                                       "EVAE_DEDUP=0 encodes every draw.  roofline.kernels[] time the step's own launches (the same control block and rows, "
+                                       "issued eagerly: GraphedTrainStep.step_eagerly)" % (n_ex, n_train, dd_["distinct"], dd_["cap"], n_ex)}),
             "roofline": roof,
             "test_log_px": iwae,
             "cpu_baseline": None,

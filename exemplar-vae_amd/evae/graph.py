@@ -331,6 +331,26 @@ class GraphedTrainStep:
             self.x_in.copy_(data.reshape(self.B, -1), non_blocking=True)
         if T: T.lap("upload + copies", t0)
 
+    def step_eagerly(self, data, indices, beta):
+        """The SAME step -- same control block, same launches, same shapes (the distinct exemplar rows, the captured optimizer
+        form) -- issued launch by launch instead of replayed: bench.py brackets its large launches with HIP events this way (event
+        pairs cannot be read back from inside a replayed graph).  Only after the graph exists."""
+        assert self.graph is not None, "step_eagerly: the step has not been captured yet"
+        self.model._exemplar_indices_override = (self.rows, self._Cd)
+        self.model._exemplar_dedup = self.dedup["tables"] if self.dedup is not None else None
+        try:
+            self._refresh(data, indices, beta)
+            self.model._eps_override = self.eps_buf if self.by_index else None
+            self.model._batch_staged = bool(self.by_index and self.u8)
+            self._body(eager_opt=self.eager_opt)
+            self._calls += 1
+            return self.out
+        finally:
+            self.model._exemplar_indices_override = None
+            self.model._exemplar_dedup = None
+            self.model._eps_override = None
+            self.model._batch_staged = False
+
     def __call__(self, data, indices, beta):
         """One training step; returns a device tensor (loss, -RE, KL) valid until the next call."""
         if self.graph is None and self._calls == 0:
