@@ -46,20 +46,23 @@ extern "C" int evae_ctl_upload(void* d_stage, const void* h_pinned, void* d_ctl,
 extern "C" int evae_host_dedup(const int64_t* draws, int n_draws, int64_t n_rows, int cap, int64_t* rows, int64_t* inv, int64_t* rep,
                                float* mult) {
   if (!draws || !rows || !inv || !rep || !mult || n_draws <= 0 || n_rows <= 0 || cap <= 0) { evae::set_error("host_dedup: bad arguments"); return -1; }
-  static thread_local std::vector<uint32_t> stamp, slot;
+  // one table entry per dataset row: (generation of the call that last saw it) << 32 | its position among the distinct rows
+  static thread_local std::vector<uint64_t> tab;
   static thread_local uint32_t gen = 0;
-  if ((int64_t)stamp.size() < n_rows) { stamp.assign((size_t)n_rows, 0u); slot.assign((size_t)n_rows, 0u); gen = 0; }
-  if (++gen == 0) { std::fill(stamp.begin(), stamp.end(), 0u); gen = 1; }
+  if ((int64_t)tab.size() < n_rows) { tab.assign((size_t)n_rows, 0ull); gen = 0; }
+  if (++gen == 0) { std::fill(tab.begin(), tab.end(), 0ull); gen = 1; }
+  const uint64_t tag = (uint64_t)gen << 32;
   int U = 0;
   for (int j = 0; j < n_draws; ++j) {
     const int64_t i = draws[j];
     if (i < 0 || i >= n_rows) { evae::set_error("host_dedup: index %lld outside [0, %lld)", (long long)i, (long long)n_rows); return -1; }
-    if (stamp[(size_t)i] != gen) {
+    const uint64_t e = tab[(size_t)i];
+    if ((e >> 32) != gen) {
       if (U == cap) { evae::set_error("host_dedup: more than %d distinct rows among %d draws", cap, n_draws); return -1; }
-      stamp[(size_t)i] = gen; slot[(size_t)i] = (uint32_t)U;
+      tab[(size_t)i] = tag | (uint32_t)U;
       rows[U] = i; rep[U] = j; mult[U] = 1.0f; inv[j] = U; ++U;
     } else {
-      const uint32_t u = slot[(size_t)i];
+      const uint32_t u = (uint32_t)e;
       inv[j] = u; mult[u] += 1.0f;
     }
   }
