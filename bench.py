@@ -629,6 +629,7 @@ def main():
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     step_ms = {"p50": round(per_step[len(per_step) // 2], 4), "p90": round(per_step[min(len(per_step) - 1, (9 * len(per_step)) // 10)], 4),
                "min": round(per_step[0], 4), "max": round(per_step[-1], 4)} if per_step else None
+    ops.prior_train_check()          # the one-launch prior's co-residency guard: raises if any block of any step gave up (outside the timed region)
     n_done = n_pre + a.steps
     g_ = state["graphed"]
     loss_sum = float(loss_acc.item()) + (float(g_.totals[0].item()) if g_ is not None else 0.0)

@@ -1778,11 +1778,63 @@ extern "C" int evae_prior_lse_bwd_phased(const float* z, int B, const float* cen
 // ------------------------------------------------------------------------------------------------
 // The prior of a captured training step as one launch + the dz' / dlogvar reduction (evae_prior_train.h)
 // ------------------------------------------------------------------------------------------------
+template <int KG> static size_t prior_train_lds() {
+  constexpr int KS2 = KG * 8 + 4;
+  return (size_t)(2 * 128 * KS2 + 128 * 132 + 4 * 128 + 64 + 64 + 16 + 8 + 8 * 64 + 2 * 128) * sizeof(float) + 128 * sizeof(long long);
+}
+template <int KG> static int prior_train_occ() {
+  int n = 0;
+  (void)hipFuncSetAttribute((const void*)prior_train_kernel<KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prior_train_lds<KG>());
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, prior_train_kernel<KG>, MFT, prior_train_lds<KG>()) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+// Blocks of prior_train_kernel<KG> the CURRENT device keeps resident at once (its inter-block exchange spins on a generation word:
+// the whole grid must be co-resident -- ADVICE r04): CUs of the device (a CPX / DPX partition or a smaller part reports fewer) x
+// blocks per CU from the occupancy query for the kernel's registers and LDS, minus a margin of one CU in sixteen for launches of
+// other streams that hold CUs while the grid starts, never above PT_MAX_BLOCKS.  0 = no device / query failed: the one-launch
+// form is then not offered and callers take the three-launch prior.
+static int prior_train_block_limit(int kg) {
+  static int cache[16][8];            // [device][kg]: 0 = not asked yet, -1 = none
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (dev < 0 || dev >= 16 || kg < 1 || kg > 7) return 0;
+  if (cache[dev][kg] == 0) {
+    int cus = 0, occ = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
+    switch (kg) {
+      case 1: occ = prior_train_occ<1>(); break;
+      case 2: occ = prior_train_occ<2>(); break;
+      case 3: occ = prior_train_occ<3>(); break;
+      case 4: occ = prior_train_occ<4>(); break;
+      case 5: occ = prior_train_occ<5>(); break;
+      case 6: occ = prior_train_occ<6>(); break;
+      default: occ = prior_train_occ<7>(); break;
+    }
+    const long lim = (long)cus * occ - (cus + 15) / 16;
+    cache[dev][kg] = lim > 0 ? (int)std::min<long>(lim, PT_MAX_BLOCKS) : -1;
+  }
+  return cache[dev][kg] > 0 ? cache[dev][kg] : 0;
+}
+
 extern "C" int evae_prior_train_applies(int B, int C, int zdim) {
   static int off = -1;
   if (off < 0) { const char* e = getenv("EVAE_PRIOR_TRAIN"); off = (e && atoi(e) == 0) ? 1 : 0; }
   if (off) return 0;
-  return B >= 1 && B <= MFQ && C >= 1 && cdiv(C, MFE) <= PT_MAX_BLOCKS && zdim >= 4 && zdim <= 56 && (zdim & 3) == 0;
+  if (!(B >= 1 && B <= MFQ && C >= 1 && zdim >= 4 && zdim <= 56 && (zdim & 3) == 0)) return 0;
+  return cdiv(C, MFE) <= prior_train_block_limit((zdim + 7) / 8);
+}
+
+// Blocks that gave up waiting in any evae_prior_train_step launch on this state block since it was zeroed (state[10]); read and
+// cleared by the host at a point where it synchronises anyway (end of epoch, replica check): non-zero = some step's dz /
+// dcentres / dlogvar were formed with a stale token -- the caller must raise.
+extern "C" int evae_prior_train_gave_up(void* state, evae_stream_t stream_) {
+  EVAE_REQUIRE(state, "prior_train_gave_up: null state");
+  unsigned v = 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (hipMemcpyAsync(&v, (const unsigned*)state + 10, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess) { set_error("prior_train_gave_up: read-back failed"); return EVAE_EINVAL; }
+  if (v) (void)hipMemsetAsync((unsigned*)state + 10, 0, sizeof(unsigned), stream);
+  return (int)std::min<unsigned>(v, 0x3FFFFFFFu);
 }
 
 static size_t prior_train_layout(int B, int C, int zdim, size_t* o_gpart, size_t* o_dz, size_t* o_dlv) {
@@ -1805,8 +1857,7 @@ static int launch_prior_train(const float* z, int B, const float* centres, int C
                               const int64_t* z_idx, const int64_t* c_idx, float c_total, const float* beta_dev, float beta_host,
                               unsigned* state, float* part, float* gpart, float* logp, float* token, float* cRE, float* cKL,
                               float* ncKL, float* dz_part, float* dc, float* dlv_part, hipStream_t stream) {
-  constexpr int KS2 = KG * 8 + 4;
-  const size_t lds = (size_t)(2 * 128 * KS2 + 128 * 132 + 4 * 128 + 64 + 64 + 16 + 8 + 8 * 64 + 2 * 128) * sizeof(float) + 128 * sizeof(long long);
+  const size_t lds = prior_train_lds<KG>();
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)prior_train_kernel<KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1826,7 +1877,8 @@ extern "C" int evae_prior_train_step(const float* z, int B, const float* centres
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(phase >= 0 && phase <= 2, "prior_train_step: phase must be 0, 1 or 2");
   EVAE_REQUIRE(evae_prior_train_applies(B, C, zdim), "prior_train_step: B=%d C=%d zdim=%d is outside the one-launch form (B <= 128, "
-               "C <= %d, zdim <= 56 and a multiple of 4)", B, C, zdim, PT_MAX_BLOCKS * MFE);
+               "C <= %d = the blocks this device keeps resident x 128, zdim <= 56 and a multiple of 4)", B, C, zdim,
+               prior_train_block_limit((zdim + 7) / 8) * MFE);
   EVAE_REQUIRE(z && centres && log_var && logp && token && dz && dcentres && dlogvar && state && ws, "prior_train_step: null pointer");
   EVAE_REQUIRE((cRE && cKL && neg_cKL) || (!cRE && !cKL && !neg_cKL), "prior_train_step: all three coefficient vectors or none");
   EVAE_REQUIRE(((((uintptr_t)z) | ((uintptr_t)centres)) & 15) == 0, "prior_train_step: z and centres must be 16-byte aligned");

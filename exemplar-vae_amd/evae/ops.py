@@ -223,6 +223,22 @@ def prior_train_state(device):
     return st
 
 
+def prior_train_check():
+    """Raise if any block of any one-launch prior (evae_prior_train_step) gave up waiting for the other blocks since the last
+    check: its grid was not co-resident (another tenant of the device, a partition smaller than the query said) and some step's
+    dz / dcentres / dlogvar were formed with a stale token.  Reads back: call it where the host synchronises anyway (end of an
+    epoch, the replica check, the end of a timed loop) -- never inside a capture."""
+    lib = _lib.load()
+    for key, st in list(_PT_STATE.items()):
+        n = lib.evae_prior_train_gave_up(_p(st), torch.cuda.current_stream(st.device).cuda_stream)
+        if n < 0:
+            _lib.check(n, "evae_prior_train_gave_up")
+        if n > 0:
+            raise RuntimeError("evae: %d block(s) of the one-launch exemplar prior gave up waiting for the rest of their grid (device "
+                               "%s): gradients of at least one step are wrong.  The grid was not co-resident -- set "
+                               "EVAE_PRIOR_TRAIN=0 to use the three-launch prior on this device" % (n, key[0]))
+
+
 def prior_train_applies(B, Cn, zd):
     return bool(_lib.load().evae_prior_train_applies(int(B), int(Cn), int(zd)))
 
@@ -478,11 +494,16 @@ def _flush_wgrads(jobs, everyone_waits=False):
 
 
 def _single_use_leaves(root):
-    """data pointers of the leaf tensors that exactly ONE edge of root's autograd graph leads to (one layer application per pass)"""
+    """(single, stealable): data pointers of the leaf tensors that exactly ONE edge of root's autograd graph leads to (one layer
+    application per pass), and of the leaves whose AccumulateGrad will INSTALL the tensor it is handed instead of adding it to an
+    existing one -- .grad is None and no tensor hooks.  Deferring (or accumulating in place) hands autograd a buffer that is
+    filled later: a leaf with a gradient already there would get `grad += <unfilled buffer>` at once (zero_grad(set_to_none=
+    False), gradient accumulation, a second backward), so only stealable leaves qualify; the others are computed on the spot."""
     counts = {}
+    stealable = set()
     fn0 = getattr(root, "grad_fn", None)
     if fn0 is None:
-        return set()
+        return set(), set()
     seen, stack = {fn0}, [fn0]
     while stack:
         n = stack.pop()
@@ -492,9 +513,11 @@ def _single_use_leaves(root):
             v = getattr(nf, "variable", None)
             if v is not None:                      # AccumulateGrad of a leaf
                 counts[v.data_ptr()] = counts.get(v.data_ptr(), 0) + 1
+                if v.grad is None and not getattr(v, "_backward_hooks", None):
+                    stealable.add(v.data_ptr())
             elif nf not in seen:
                 seen.add(nf); stack.append(nf)
-    return {k for k, c in counts.items() if c == 1}
+    return {k for k, c in counts.items() if c == 1 and k in stealable}, stealable
 
 
 class deferred_wgrads:
@@ -506,8 +529,11 @@ class deferred_wgrads:
 
     def __enter__(self):
         self.prev = _DEFER[0]
-        _DEFER[0] = ({"jobs": [], "uses": {}, "made": {}, "single": _single_use_leaves(self.root)}
-                     if (_DEFER_ON and self.root is not None) else None)
+        if _DEFER_ON and self.root is not None:
+            single, stealable = _single_use_leaves(self.root)
+            _DEFER[0] = {"jobs": [], "uses": {}, "made": {}, "single": single, "stealable": stealable}
+        else:
+            _DEFER[0] = None
         self.root = None
         return self
 
@@ -560,7 +586,8 @@ def _note_made(key, dw, db):
     an event behind its launches, so that a second application of the layer can add its product to it (see _try_defer).  Returns
     the views to hand to autograd (the scope keeps the bases: handed the bases themselves, AccumulateGrad would clone them)."""
     cur = _DEFER[0]
-    if cur is None or key is None or not _ACC_WGRAD or db is None or key in cur["made"] or cur["uses"].get(key, 0) != 1:
+    if (cur is None or key is None or not _ACC_WGRAD or db is None or key in cur["made"] or cur["uses"].get(key, 0) != 1
+            or key not in cur["stealable"]):
         return dw, db
     ev = torch.cuda.Event(); ev.record()
     cur["made"][key] = (dw, db, ev)

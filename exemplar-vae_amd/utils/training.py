@@ -55,6 +55,7 @@ def train_one_epoch(epoch, args, train_loader, model, optimizer):
                 cache = (cache[0].detach(), cache[1].detach())
     if graphed is not None:
         totals = graphed.totals.clone() if totals is None else totals + graphed.totals
+    _ops.prior_train_check()       # the one-launch prior's co-residency guard (reads back; the .tolist() below synchronises anyway)
     train_loss, train_re, train_kl = (totals / len(train_loader)).tolist()
     return train_loss, train_re, train_kl
 

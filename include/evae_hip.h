@@ -137,7 +137,10 @@ int evae_elbo_assemble(const float* logp, const float* RE, const float* logq, co
  * paths (models/BaseModel.py:98-128 and what autograd derives from it).  `state`: 256 bytes of device memory, zeroed ONCE by the
  * caller and handed to every call (inter-block counters and a generation word; word 10 counts blocks whose bounded wait ran out --
  * never, unless the grid was not co-resident).  phase 0: both launches; 1: the kernel; 2: the reduction (dz, dlogvar). */
-int evae_prior_train_applies(int B, int C, int zdim);
+int evae_prior_train_applies(int B, int C, int zdim);   /* also: the grid fits the CURRENT device's resident blocks (CUs x occupancy, with a margin) */
+/* word 10 of `state`, read back and cleared (synchronises `stream`): > 0 = that many blocks gave up waiting since the last call --
+ * gradients of some step are wrong and the caller must raise; < 0 = EVAE_E*.  Call where the host synchronises anyway. */
+int evae_prior_train_gave_up(void* state, evae_stream_t stream);
 size_t evae_prior_train_workspace_bytes(int B, int C, int zdim);
 int evae_prior_train_step(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
                           const int64_t* z_idx, const int64_t* c_idx, float c_total, const float* beta_dev, float beta_host,

@@ -1209,6 +1209,48 @@ def test_deferred_grouped_weight_gradients_equal_the_inline_ones(model_name, C):
         assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
 
 
+@pytest.mark.parametrize("model_name,C", [("hvae_2level", 120), ("vae", 200)])
+def test_deferred_weight_gradients_with_gradients_already_there(model_name, C):
+    """a deferred (or in-place accumulated) weight gradient is a buffer filled AFTER autograd has been handed it, which is
+    only right while AccumulateGrad installs it (.grad is None).  With gradients already there (zero_grad(set_to_none=False),
+    gradient accumulation over two backward passes) the scope must compute those leaves on the spot: two accumulated passes inside
+    the scope == the same two passes without it, bit for bit, and nothing is deferred on the second pass."""
+    from evae import ops
+    from utils.utils import importing_model
+    B, N = 100, 2 * C + 300
+    data = torch.from_numpy(gi.binary_images(9, N))
+    dataset = torch.utils.data.TensorDataset(data, torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    args = smoke_case.vae_args(model_name=model_name, number_components=C, training_set_size=N, batch_size=B)
+    torch.manual_seed(21)
+    model = importing_model(args)(args).cuda()
+    model.train()
+    model._use_fused = False
+    x = data[:B].cuda(); idx = torch.arange(B, device="cuda").reshape(-1, 1)
+    g = torch.Generator(device="cuda")
+    grads = []
+    for deferred in (False, True):
+        model.zero_grad(set_to_none=True)
+        for rep in range(2):                                      # the second pass meets the first one's gradients
+            g.manual_seed(5 + rep); model._eps_generator = g
+            torch.manual_seed(77 + rep)
+            loss, RE, KL = model.calculate_loss((x, idx), 0.5, average=True, dataset=dataset)
+            if deferred:
+                with ops.deferred_wgrads(loss):
+                    loss.backward()
+                    njobs = len(ops._DEFER[0]["jobs"])
+                assert (njobs > 0) if rep == 0 else (njobs == 0), (rep, njobs)
+            else:
+                loss.backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    model._eps_generator = None
+    a, b = grads
+    assert set(a) == set(b) and len(a) >= 10
+    for k in a:
+        assert torch.isfinite(b[k]).all(), k
+        assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+
+
 def test_conv_two_level_step_at_c3_size_matches_the_oracle():
     """convhvae_2level at the benchmarked size (BASELINE configs[2]: 25 000 exemplars, batch 100): per-sample loss / RE / KL of
     the training step against an fp64 restatement of reference models/AbsHModel.py:13-106 + models/convHVAE_2level.py:13-103
