@@ -47,62 +47,105 @@ struct CwGeom {
   static constexpr int KST = BN >= 64 ? 2 : 4;          // k-steps per ring stage: a multiple of four 1 KB copies (one set per wave)
   static constexpr int BST = KST * BKS;                 // a ring stage
   static constexpr int LOOP_LDS = WIN + 2 * BST;
-  static constexpr int EPI_LDS = 2 * R * 68 * 4;        // epilogue staging: two fp32 arrays [R][64 + 4]
-  static constexpr int LDS = LOOP_LDS > EPI_LDS ? LOOP_LDS : EPI_LDS;
+  // epilogue staging: fp32 [R][BNO + 4] (gated: two of them, BNO = BN / 2 result columns)
+  static constexpr int lds_bytes(bool gated) {
+    const int epi = gated ? 2 * R * (BN / 2 + 4) * 4 : R * (BN + 4) * 4;
+    return LOOP_LDS > epi ? LOOP_LDS : epi;
+  }
   static constexpr int NPIECE = KST * 3 * (BN / 32);    // 1 KB copies per ring stage
   static_assert(NPIECE % 4 == 0, "every wave issues the same number of copies per stage");
 };
 
+// The taps of a launch: up to four input segments (the stride-parity sub-images of a strided layer's input; one segment otherwise),
+// each with a RECTANGLE of tap offsets (dy, dx) in [dy0, dy0 + ndy) x [dx0, dx0 + ndx) relative to the output pixel -- the taps of a
+// stride-s filter that fall on one parity class are consecutive offsets -- and the filter tap of an offset: kh = a dy + bh,
+// kw = a dx + bw (forward, stride s, input parity (py, px): a = s, b = p + pad; data gradient of a stride-s layer into the
+// input pixels of parity (py, px): a = -s, b = p + pad).
+struct CwSegTaps { int dy0, ndy, dx0, ndx, bh, bw; };
+struct CwTaps { int nseg, a; CwSegTaps s[4]; };
+
 struct ConvWinArgs {
   const unsigned char* xin;   // pixel image of the input, nks_in channel groups per pixel
   int nks_in;
-  int ncg;                    // channel groups contracted over (k-steps = ncg * ntaps), starting at group cg0 of the image
+  int ncg;                    // channel groups contracted over per segment, starting at group cg0 of the image
   int cg0;
-  int N, H, W, KH, KW, pad;   // stride 1, 2 pad + 1 == KH == KW: output H x W
+  int N, H, W;                // images; height and width of the OUTPUT grid = of every input segment
+  int plo, phi;               // tap offsets lie in [-plo, phi]: the window grid is (H + plo + phi) x (W + plo + phi)
+  int nsp;                    // 32-slot pieces of the window actually needed (<= SLOTS / 32; cw_window_slots)
   int PW, SP;
   FastDiv div_w, div_hw, div_pw, div_sp;
-  const unsigned char* wimg;  // filter image: BN rows per column tile, k = (cg * ntaps + tap) * 16 + c
+  int istride;                // input image rows per image (segments * H * W)
+  int in_planar;              // 1: the input (ONE segment) is stored parity-planar (see cw_planar)
+  int ioff[4];                // input row of segment s, pixel (n, y, x): n * istride + ioff[s] + y * W + x
+  CwTaps taps;
+  const unsigned char* wimg;  // filter image: BN rows per column tile, k-steps ordered (segment, channel group, tap raster)
   int nks_w;
   int M;                      // N * H * W
   int Co;                     // real output columns (gated: channels per bank)
   int tiles_n;
   const float* bias0;
   const float* bias1;
+  // rows of the result.  Pixel images (oimg, eimg): n * ostride + ooff + y * W + x, or (out_planar) n * H * W + cw_planar(y, x).
+  // fp32 tensors (out_s, out_f, e_s) are ALWAYS channels-last in natural pixel order: row (n * nat_h + y * nat_s + nat_y) * nat_w +
+  // x * nat_s + nat_x -- the identity unless the launch writes one stride-parity class of a larger grid (data gradient of a
+  // strided layer: nat_s = stride, (nat_y, nat_x) = the class, nat_h x nat_w = the layer's input grid)
+  int ostride, ooff;
+  int out_planar;
+  int nat_h, nat_w, nat_s, nat_y, nat_x;
   unsigned char* oimg;        // pixel image of the result (nks_o channel groups; result column c at image channel och0 + c;
   int nks_o, och0;            //   CW_DGRAD_GATE: dh at och0 + c, dg at och0 + Co + c)
-  float* out_s;               // gated forward: the gate s, fp32 [M][Co]
-  float* out_f;               // fp32 copy of the result [M][ldo] (optional; CW_DGRAD_GATE: [dh | dg], dg at column Co + c)
+  float* out_s;               // gated forward: the gate s, fp32 [rows][Co]
+  float* out_f;               // fp32 copy of the result [rows][ldo] (optional; CW_DGRAD_GATE: [dh | dg], dg at column Co + c)
   int ldo;
   const unsigned char* eimg;  // CW_DGRAD_GATE: pixel image of the forward output of the layer below (nks_e groups, channel ech0 + c) ...
   int nks_e, ech0;
-  const float* e_s;           // ... and its gate [M][Co]: [dh | dg] = [v s | v out (1 - s)]
+  const float* e_s;           // ... and its gate [rows][Co]: [dh | dg] = [v s | v out (1 - s)]
   int dbg;
 };
 
+// parity-planar pixel order of an H x W image (H, W even): the four stride-2 parity classes (y & 1, x & 1) as four H/2 x W/2
+// sub-images one after the other -- what a layer whose consumer has stride 2 writes, so that the consumer's taps of one parity
+// class are stride-1 shifts of one sub-image
+__host__ __device__ __forceinline__ int cw_planar(int y, int x, int H, int W) {
+  return (((y & 1) * 2 + (x & 1)) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+}
+
+__host__ __device__ __forceinline__ size_t p6_off64(size_t r, int k, int nks) {
+  return ((r >> 4) * nks + (k >> 4)) * P6_GROUP + (size_t)(((int)(r & 15)) * 32 + ((((k >> 3) & 1) ^ ((int)(r >> 3) & 1)) << 4) + (k & 7) * 2);
+}
+
 // ---- filter images ------------------------------------------------------------------------------------------------------------
-// k = (cg * taps + t) * 16 + cl <-> contraction channel cc = cg * 16 + cl, tap t.  Rows, per column tile of bn rows:
+// k-step ks <-> (segment, channel group cg, tap (i, j) of the segment's rectangle) in that nesting; contraction channel cc = cg * 16 + cl;
+// filter tap (kh, kw) = (a (dy0 + i) + bh, a (dx0 + j) + bw).  Rows, per column tile of bn rows:
 // mode 0 (gated forward): row (tn, c), c = wc * 64 + hg * 32 + j <-> bank hg (w0 = h, w1 = g), output channel tn * (bn / 2) + wc * 32 + j
 // mode 2 (plain forward): row r <-> output channel r
 // mode 1 (data gradient): row r <-> INPUT channel r of the layer (the data gradient's output channel); cc = merged gradient
-//   channel (cc < Co: bank h, output channel cc; else bank g, cc - Co), filter tap (KH - 1 - th, KW - 1 - tw) of t = (th, tw):
-//   the flipped filter
+//   channel (cc < Co: bank h, output channel cc; else bank g, cc - Co)
 // w layout: nn.Conv2d's [Co][Ci][KH][KW]
 __global__ __launch_bounds__(256) void cw_pack_filter_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int Co, int Ci,
-                                                             int taps, int mode, int bn, int rows_img, int nks, unsigned char* __restrict__ img) {
+                                                             int KH, int KW, CwTaps tp, int ncg, int mode, int bn, int rows_img, int nks,
+                                                             unsigned char* __restrict__ img) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int kslots = nks * 2;
   if (t >= (size_t)rows_img * kslots) return;
   const int ri = (int)(t / kslots), ks8 = (int)(t - (size_t)ri * kslots);
   const int k0 = ks8 * 8;
-  const int kstep = k0 >> 4, tap = kstep % taps, cg = kstep / taps;
+  int kstep = k0 >> 4, sg = 0;
+  while (sg < tp.nseg - 1 && kstep >= ncg * tp.s[sg].ndy * tp.s[sg].ndx) { kstep -= ncg * tp.s[sg].ndy * tp.s[sg].ndx; ++sg; }
+  const int nt = tp.s[sg].ndy * tp.s[sg].ndx;
+  const int cg = kstep / nt, ti = kstep - cg * nt, i = ti / tp.s[sg].ndx, j = ti - i * tp.s[sg].ndx;
+  const int kh = tp.a * (tp.s[sg].dy0 + i) + tp.s[sg].bh, kw = tp.a * (tp.s[sg].dx0 + j) + tp.s[sg].bw;
+  const bool tap_ok = cg < ncg && kh >= 0 && kh < KH && kw >= 0 && kw < KW;
+  const int tap = kh * KW + kw, taps = KH * KW;
   unsigned short p0[8], p1[8], p2[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int cc = cg * 16 + (k0 & 15) + i;     // contraction channel
+  for (int e = 0; e < 8; ++e) {
+    const int cc = cg * 16 + (k0 & 15) + e;     // contraction channel
     float v = 0.f;
-    if (mode == 0) {
-      const int tn = ri / bn, c = ri - tn * bn, wc = c >> 6, hg = (c >> 5) & 1, j = c & 31;
-      const int co = tn * (bn / 2) + wc * 32 + j;
+    if (!tap_ok) {
+    } else if (mode == 0) {
+      const int tn = ri / bn, c = ri - tn * bn, wc = c >> 6, hg = (c >> 5) & 1, jj = c & 31;
+      const int co = tn * (bn / 2) + wc * 32 + jj;
       const float* src = hg ? w1 : w0;
       if (co < Co && cc < Ci) v = src[((size_t)co * Ci + cc) * taps + tap];
     } else if (mode == 2) {
@@ -112,10 +155,10 @@ __global__ __launch_bounds__(256) void cw_pack_filter_kernel(const float* __rest
       if (ri < Ci && cc < ctot) {
         const float* src = cc < Co ? w0 : w1;
         const int co = cc < Co ? cc : cc - Co;
-        v = src[((size_t)co * Ci + ri) * taps + (taps - 1 - tap)];
+        v = src[((size_t)co * Ci + ri) * taps + tap];
       }
     }
-    p6_split1(v, p0[i], p1[i], p2[i]);
+    p6_split1(v, p0[e], p1[e], p2[e]);
   }
   unsigned char* o = img + p6_off(ri, k0, nks);
   *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(p0);
@@ -123,15 +166,61 @@ __global__ __launch_bounds__(256) void cw_pack_filter_kernel(const float* __rest
   *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = *reinterpret_cast<const uint4*>(p2);
 }
 
-// window slots a block of R consecutive output pixels needs, maximised over the block starts that occur
-static int cw_window_slots(int H, int W, int KH, int KW, int pad, int R) {
-  const int PW = W + 2 * pad, SP = (H + 2 * pad) * PW, HW = H * W;
+// k-steps of a launch's contraction
+static int cw_ksteps(const CwTaps& tp, int ncg) {
+  int n = 0;
+  for (int s = 0; s < tp.nseg; ++s) n += ncg * tp.s[s].ndy * tp.s[s].ndx;
+  return n;
+}
+// the taps of a forward convolution (stride 1 or 2) / of the data gradient into input parity class (py, px)
+static CwTaps cw_taps_fwd(int K, int stride, int pad, int* plo, int* phi) {
+  CwTaps tp = {};
+  tp.a = stride;
+  int lo = 0, hi = 0;
+  for (int py = 0; py < stride; ++py)
+    for (int px = 0; px < stride; ++px) {
+      // input row stride * (y + dy) + p = stride * y + kh - pad  ->  kh = stride * dy + p + pad
+      auto range = [&](int p, int& d0, int& nd) {
+        int dmin = 1 << 30, dmax = -(1 << 30);
+        for (int k = 0; k < K; ++k) if ((k - pad - p) % stride == 0) { const int d = (k - pad - p) / stride; dmin = std::min(dmin, d); dmax = std::max(dmax, d); }
+        d0 = dmin; nd = dmax >= dmin ? dmax - dmin + 1 : 0;
+      };
+      CwSegTaps& s = tp.s[tp.nseg];
+      range(py, s.dy0, s.ndy); range(px, s.dx0, s.ndx);
+      s.bh = py + pad; s.bw = px + pad;
+      if (s.ndy > 0 && s.ndx > 0) {
+        lo = std::max(lo, std::max(-s.dy0, -s.dx0)); hi = std::max(hi, std::max(s.dy0 + s.ndy - 1, s.dx0 + s.ndx - 1));
+      } else { s.ndy = s.ndx = 0; s.dy0 = s.dx0 = 0; }
+      ++tp.nseg;
+    }
+  *plo = lo; *phi = hi;
+  return tp;
+}
+static CwTaps cw_taps_dgrad(int K, int stride, int pad, int py, int px, int* plo, int* phi) {
+  CwTaps tp = {};
+  tp.a = -stride; tp.nseg = 1;
+  // output pixel y' = y + dy of the layer reads input row stride * y + p through tap kh = p + pad - stride * dy
+  auto range = [&](int p, int& d0, int& nd) {
+    int dmin = 1 << 30, dmax = -(1 << 30);
+    for (int k = 0; k < K; ++k) if ((p + pad - k) % stride == 0) { const int d = (p + pad - k) / stride; dmin = std::min(dmin, d); dmax = std::max(dmax, d); }
+    d0 = dmin; nd = dmax >= dmin ? dmax - dmin + 1 : 0;
+  };
+  CwSegTaps& s = tp.s[0];
+  range(py, s.dy0, s.ndy); range(px, s.dx0, s.ndx);
+  s.bh = py + pad; s.bw = px + pad;
+  *plo = std::max(0, std::max(-s.dy0, -s.dx0)); *phi = std::max(0, std::max(s.dy0 + s.ndy - 1, s.dx0 + s.ndx - 1));
+  return tp;
+}
+
+// window slots a block of R consecutive output pixels needs, maximised over the block starts
+static int cw_window_slots(int H, int W, int plo, int phi, int R) {
+  const int PW = W + plo + phi, SP = (H + plo + phi) * PW, HW = H * W;
   int best = 0;
   for (int r0 = 0; r0 < HW; ++r0) {           // first pixel of a block, modulo the image (every residue: M need not be regular)
     const int y0 = r0 / W, x0 = r0 % W;
     const int last = r0 + R - 1;
     const int n1 = last / HW, r1 = last % HW, y1 = r1 / W, x1 = r1 % W;
-    const int q0 = y0 * PW + x0, q1 = n1 * SP + (y1 + KH - 1) * PW + x1 + KW - 1;
+    const int q0 = y0 * PW + x0, q1 = n1 * SP + (y1 + plo + phi) * PW + x1 + plo + phi;
     best = std::max(best, q1 - q0 + 1);
   }
   return best;
@@ -165,15 +254,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
   const int m0 = tm * R;
-  const int HW = g.H * g.W, ntaps = g.KH * g.KW;
+  const int HW = g.H * g.W;
 
   // first pixel of the block -> base slot; base pixel of the buffer resource (16-pixel aligned, at or before every pixel a tap reads)
   const unsigned nf = fdiv((unsigned)m0, g.div_hw), remf = (unsigned)m0 - nf * (unsigned)HW;
   const unsigned yf = fdiv(remf, g.div_w), xf = remf - yf * (unsigned)g.W;
   const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)g.PW + xf);
-  int bp = m0 - g.pad * g.W - g.pad;
-  bp = bp < 0 ? 0 : (bp & ~15);
-  const int base_pix = __builtin_amdgcn_readfirstlane(bp);
+  // base row of the buffer resource over the input image: the first row of the block's first image (16-row aligned); every row a
+  // tap reads lies at or behind it
+  const int base_pix = __builtin_amdgcn_readfirstlane((int)((nf * (unsigned)g.istride) & ~15u));
   const rsrc_t rB = make_rsrc(g.wimg + (size_t)tn * (BN / 16) * g.nks_w * P6_GROUP, 0x7FFFFFFFu);
 
   f32x16 acc[MT][NT];
@@ -270,12 +359,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_s_setprio(0);
   };
 
-  const int S = ntaps;                           // k-steps per channel group
   constexpr std::true_type T{};
   constexpr std::false_type F{};
-  for (int cgi = 0; cgi < g.ncg; ++cgi) {
-    if (cgi > 0) __syncthreads();                // every wave is done with the previous group's window and ring
-    const int ksc = cgi * S;                     // first k-step of the group
+  int ksc = 0;                                   // first k-step of the current (segment, channel group)
+  bool first = true;
+  for (int sg = 0; sg < g.taps.nseg; ++sg) {
+   const int S = g.taps.s[sg].ndy * g.taps.s[sg].ndx;          // k-steps per channel group: the segment's taps
+   const int ndx = g.taps.s[sg].ndx;
+   const int to0 = (g.taps.s[sg].dy0 + g.plo) * g.PW + g.taps.s[sg].dx0 + g.plo;
+   if (S == 0) continue;
+   for (int cgi = 0; cgi < g.ncg; ++cgi, ksc += S) {
+    if (!first) __syncthreads();                 // every wave is done with the previous window and ring
+    first = false;
     issue_b(ksc, 0, S < KST ? S : KST);
     if (S > KST) issue_b(ksc + KST, 1, S - KST < KST ? S - KST : KST);
     // ---- window of this channel group: slot pieces j = wave, wave + 4, ... (32 slots each), one copy per plane ----
@@ -284,17 +379,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int jj = 0; jj < (SLOTS / 32 + 3) / 4; ++jj) {
         const int j = wave + 4 * jj;
-        if (j < SLOTS / 32) {
+        if (j < g.nsp) {
           const int s = 32 * j + (lane >> 1), hp = lane & 1;
           const unsigned q = (unsigned)(qbase + s);
           const unsigned n = fdiv(q, g.div_sp), r = q - n * (unsigned)g.SP;
           const unsigned py = fdiv(r, g.div_pw), px = r - py * (unsigned)g.PW;
-          const int y = (int)py - g.pad, x = (int)px - g.pad;
+          const int y = (int)py - g.plo, x = (int)px - g.plo;
           const bool ok = (int)n < g.N && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
-          const int pix = ((int)n * g.H + y) * g.W + x;
+          const int pix = (int)n * g.istride + (g.in_planar ? cw_planar(y, x, g.H, g.W) : g.ioff[sg] + y * g.W + x);
           const int rel = pix - base_pix;
           const unsigned gh = (unsigned)(hp ^ ((s >> 3) & 1) ^ ((pix >> 3) & 1));
-          const unsigned voff = ok ? (unsigned)(rel >> 4) * (unsigned)(g.nks_in * P6_GROUP) + (unsigned)((rel & 15) * 32) + (gh << 4) : 0x80000000u;
+          unsigned vin = (unsigned)(rel >> 4) * (unsigned)(g.nks_in * P6_GROUP) + (unsigned)((rel & 15) * 32) + (gh << 4);
+          EVAE_PIN(vin);                                             // (computed by every lane: a select, not a branch)
+          const unsigned voff = ok ? vin : 0x80000000u;
 #pragma unroll
           for (int p = 0; p < 3; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (p6_lds_t)(lds + p * WP + j * 1024), 16, voff, (unsigned)(p * P6_CHUNK), 0, 0);
@@ -303,10 +400,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    int kw = 0, to = 0;                          // tap column, tap offset in slots (kh PW + kw)
+    int kw = 0, to = to0;                        // tap column, tap offset in slots
     unsigned an[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) an[mt] = a_addr(mt, 0);
+    for (int mt = 0; mt < MT; ++mt) an[mt] = a_addr(mt, to0);
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -315,9 +412,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int nt = 0; nt < NT; ++nt) read_b(I0, 0, 0, nt, p);
     }
     auto next_tap = [&]() {                      // branch-free (scalar selects)
-      const bool wrap = kw + 1 == g.KW;
+      const bool wrap = kw + 1 == ndx;
       kw = wrap ? 0 : kw + 1;
-      to += wrap ? g.PW - g.KW + 1 : 1;
+      to += wrap ? g.PW - ndx + 1 : 1;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) an[mt] = a_addr(mt, to);
     };
@@ -377,6 +474,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     while (KST * (st + 4) <= S) { stage_full(I0, st); stage_full(I1, st + 1); st += 2; }
     for (; st + 1 < nst; st += 2) { stage_tail(I0, st); stage_tail(I1, st + 1); }
     if (st < nst) stage_tail(I0, st);
+   }
   }
 #undef EVAE_CW_SB
   __syncthreads();                 // the epilogue stages through the window's LDS
@@ -426,15 +524,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int i = 0; i < NPC; ++i) {
     const int pid = tid + 256 * i;
     const int r16 = pid & 15, c8 = (pid >> 4) % C8, rg = pid / (16 * C8);
-    const int row = rg * 16 + r16, m = m0 + row;
+    const int row = rg * 16 + r16, mm = m0 + row;
     const int ch = tn * BNO + c8 * 8;                         // first of the eight result columns
-    if (m >= g.M || ch >= g.Co) continue;
+    if (mm >= g.M || ch >= g.Co) continue;
+    // rows of pixel mm = (n, y, x): m in the pixel images, mn in the fp32 tensors
+    size_t m, mn;
+    {
+      const unsigned n = fdiv((unsigned)mm, g.div_hw), rem = (unsigned)mm - n * (unsigned)HW;
+      const unsigned y = fdiv(rem, g.div_w), x = rem - y * (unsigned)g.W;
+      m = g.out_planar ? (size_t)n * HW + cw_planar((int)y, (int)x, g.H, g.W) : (size_t)n * g.ostride + g.ooff + rem;
+      mn = ((size_t)n * g.nat_h + y * g.nat_s + g.nat_y) * g.nat_w + x * g.nat_s + g.nat_x;
+    }
     const float4 o0 = *reinterpret_cast<const float4*>(so + row * RP + c8 * 8), o1 = *reinterpret_cast<const float4*>(so + row * RP + c8 * 8 + 4);
     auto put_img = [&](int chan, const float4& a, const float4& b) {
       unsigned t0[4], t1[4], t2[4];
       p6_split2(a.x, a.y, t0[0], t1[0], t2[0]); p6_split2(a.z, a.w, t0[1], t1[1], t2[1]);
       p6_split2(b.x, b.y, t0[2], t1[2], t2[2]); p6_split2(b.z, b.w, t0[3], t1[3], t2[3]);
-      unsigned char* o = g.oimg + p6_off(m, chan, g.nks_o);
+      unsigned char* o = g.oimg + p6_off64(m, chan, g.nks_o);
       *reinterpret_cast<uint4*>(o) = make_uint4(t0[0], t0[1], t0[2], t0[3]);
       *reinterpret_cast<uint4*>(o + P6_CHUNK) = make_uint4(t1[0], t1[1], t1[2], t1[3]);
       *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = make_uint4(t2[0], t2[1], t2[2], t2[3]);
@@ -443,25 +549,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float4 s0 = *reinterpret_cast<const float4*>(ss + row * RP + c8 * 8), s1 = *reinterpret_cast<const float4*>(ss + row * RP + c8 * 8 + 4);
       if (g.oimg) put_img(g.och0 + ch, o0, o1);
       if (g.out_s) {
-        float* sp = g.out_s + (size_t)m * g.Co + ch;
+        float* sp = g.out_s + mn * g.Co + ch;
         *reinterpret_cast<float4*>(sp) = s0; *reinterpret_cast<float4*>(sp + 4) = s1;
       }
       if (g.out_f) {
-        float* op = g.out_f + (size_t)m * g.ldo + ch;
+        float* op = g.out_f + mn * g.ldo + ch;
         *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
       }
     } else if constexpr (EPI == CW_PLAIN) {
       if (g.oimg) put_img(g.och0 + ch, o0, o1);
       if (g.out_f) {
-        float* op = g.out_f + (size_t)m * g.ldo + ch;
+        float* op = g.out_f + mn * g.ldo + ch;
         *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
       }
     } else {
       // gate derivative of the layer below at (pixel m, channels ch .. ch + 7): out = the sum of its image's three terms (exact), s
       // fp32; dh = v s, dg = v out (1 - s)   (reference utils/nn.py:92-97 under autograd)
-      const unsigned char* e = g.eimg + p6_off(m, g.ech0 + ch, g.nks_e);
+      const unsigned char* e = g.eimg + p6_off64(m, g.ech0 + ch, g.nks_e);
       const uint4 e0 = *reinterpret_cast<const uint4*>(e), e1 = *reinterpret_cast<const uint4*>(e + P6_CHUNK), e2 = *reinterpret_cast<const uint4*>(e + 2 * P6_CHUNK);
-      const float* sp = g.e_s + (size_t)m * g.Co + ch;
+      const float* sp = g.e_s + mn * g.Co + ch;
       const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
       const unsigned w0[4] = {e0.x, e0.y, e0.z, e0.w}, w1[4] = {e1.x, e1.y, e1.z, e1.w}, w2[4] = {e2.x, e2.y, e2.z, e2.w};
       const float v[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
@@ -480,7 +586,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         put_img(g.och0 + g.Co + ch, make_float4(dg[0], dg[1], dg[2], dg[3]), make_float4(dg[4], dg[5], dg[6], dg[7]));
       }
       if (g.out_f) {
-        float* op = g.out_f + (size_t)m * g.ldo + ch;
+        float* op = g.out_f + mn * g.ldo + ch;
         *reinterpret_cast<float4*>(op) = make_float4(dh[0], dh[1], dh[2], dh[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(dh[4], dh[5], dh[6], dh[7]);
         *reinterpret_cast<float4*>(op + g.Co) = make_float4(dg[0], dg[1], dg[2], dg[3]); *reinterpret_cast<float4*>(op + g.Co + 4) = make_float4(dg[4], dg[5], dg[6], dg[7]);
       }
@@ -493,15 +599,319 @@ static int launch_conv_win(ConvWinArgs& g, hipStream_t stream, const char* what)
   typedef CwGeom<WR, NT, SLOTS> G;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_win_kernel<EPI, WR, NT, SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    (void)hipFuncSetAttribute((const void*)conv_win_kernel<EPI, WR, NT, SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::lds_bytes(EPI == CW_FWD_GATED));
     attr_done = true;
   }
-  g.PW = g.W + 2 * g.pad; g.SP = (g.H + 2 * g.pad) * g.PW;
+  g.PW = g.W + g.plo + g.phi; g.SP = (g.H + g.plo + g.phi) * g.PW;
+  g.div_w = make_fastdiv((unsigned)g.W); g.div_hw = make_fastdiv((unsigned)(g.H * g.W));
+  g.div_pw = make_fastdiv((unsigned)g.PW); g.div_sp = make_fastdiv((unsigned)g.SP);
+  if (g.istride == 0) g.istride = g.H * g.W;
+  if (g.ostride == 0) g.ostride = g.H * g.W;
+  if (g.nat_s == 0) { g.nat_s = 1; g.nat_h = g.H; g.nat_w = g.W; g.nat_y = g.nat_x = 0; }
+  g.M = g.N * g.H * g.W;
+  const int tiles_m = cdiv(g.M, G::R);
+  conv_win_kernel<EPI, WR, NT, SLOTS><<<dim3(tiles_m * g.tiles_n), 256, G::lds_bytes(EPI == CW_FWD_GATED), stream>>>(g);
+  return check_launch(what);
+}
+
+
+// =================================================================================================================================
+// Weight gradient over pixel images: dW[cc][ci][tap] = sum over output pixels of dy[pixel][cc] * x[pixel + tap][ci]  (cc: the merged
+// [dh | dg] channels; reference utils/nn.py:92-97 under autograd).  The contraction runs over PIXELS, so both operands are read through
+// the LDS transpose read (ds_read_b64_tr_b16) from their pixel-major images: dy's rows of a 32-pixel chunk, gathered (its row order
+// may be parity-planar), and the window of input pixels the chunk's taps touch.
+//
+// Shape: M = 2 Co <= 128 merged channels, N = taps x 32 input channels (a channel-group pair), K = all pixels.  The result is small
+// and the operands are streamed once, so the lever is accumulator space, not tiles: a block is four waves, ONE per SIMD with the
+// whole 512-register file, each wave holds one 32-channel row tile against EVERY tap's column tile (25 x 16 = 400 accumulator
+// registers for a 5 x 5 filter), and one block per CU streams 32-pixel stages (dy rows 24 KB + window 37 KB, double-buffered) at
+// 150 MFMAs per wave per 16 pixels: ~26 bytes copied per MFMA (gemm_p6: 256).  Every block owns a contiguous run of pixel chunks
+// (split contraction) and writes its partial [cc][tap][ci] plane; evae::cw_wgrad_finish_kernel adds the planes in block order
+// (deterministic) into nn.Conv2d's [cc][ci][kh][kw] layout.  The bias gradient is one more column tile against a constant ones
+// operand (three of the six products: the ones have a single non-zero term).
+// =================================================================================================================================
+struct CwWgradArgs {
+  const unsigned char* dyimg; int nks_dy;     // merged-gradient image, channel groups per pixel (2 Co / 16)
+  int dy_planar;                              // its rows are parity-planar (the layer's consumer has stride 2)
+  const unsigned char* ximg; int nks_x, xcg0; // input image; the channel-group pair contracted here starts at group xcg0
+  int nseg, istride, ioff[4];                 // input segments (rows n * istride + ioff[s] + y * W + x)
+  int N, H, W, plo, phi, PW, SP;
+  FastDiv div_w, div_hw, div_pw, div_sp;
+  int M;                                      // N * H * W output pixels
+  int tile_seg[32], tile_to[32], tile_tap[32];   // per column tile: input segment, tap offset in window slots, filter tap kh * KW + kw
+  int ntap_f, Cin, CC;                        // filter taps (KH * KW), input channels of the layer, merged channels 2 Co
+  int cper, nchunk;                           // chunks per block, chunks in all
+  float* part;                                // [blocks][CC][ntap_f][Cin] partial planes (only this launch's taps / channel pair are written)
+  float* dbpart;                              // [blocks][CC]
+  int dbg;                                    // tools: 1 = no copies after the first stage, 2 = copies only (no MFMA stream)
+};
+
+template <int NTW, int WSL>
+struct CwWgGeom {
+  static constexpr int RK = 32;                                  // pixels per stage (two k-steps)
+  static constexpr int DYCG = 3 * RK * 32 + 128;                 // one channel group of the dy chunk (three planes of [32 rows][32 B]); + 128:
+  static constexpr int XPL = WSL * 32;                           //   the two 16-lane groups of a transpose read (even / odd channel group)
+  static constexpr int XCG = 3 * XPL + 128;                      //   then fall on different bank halves
+  static constexpr int DY = 8 * DYCG;                            // up to 128 merged channels
+  static constexpr int STAGE = DY + 2 * XCG;
+  static constexpr int LDS = 2 * STAGE;
+  static constexpr int NXP = WSL / 32;                           // 32-slot pieces of a window plane
+};
+
+// NTW column tiles (taps) per wave, window of WSL slots; ONE input segment (stride-1 layers)
+template <int NTW, int WSL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wgrad_win_kernel(const CwWgradArgs g) {
+  typedef CwWgGeom<NTW, WSL> G;
+  constexpr int RK = G::RK, NKS = RK / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const lds = reinterpret_cast<char*>(smem);
+  const unsigned lds_base = (unsigned)(uintptr_t)(p6_lds_t)lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < 4);
+  const int l31 = lane & 31, lh = lane >> 5, ib = (lane >> 4) & 1, t16 = lane & 15;
+  const int HW = g.H * g.W;
+  const int c0 = blockIdx.x * g.cper, c1 = min(c0 + g.cper, g.nchunk);
+  const int ncgdy = g.nks_dy;
+  const bool active = 2 * wave < ncgdy;            // this wave's row tile exists (merged channels 32 wave .. 32 wave + 31)
+
+  f32x16 acc[NTW + 1];
+#pragma unroll
+  for (int j = 0; j <= NTW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // Stage of chunk c -> ring buffer buf, in three units per wave so that they can be placed between the MFMA groups of the stage
+  // before (their address arithmetic is VALU work: ~20 instructions per unit).  Copies: dy 24 (cg, plane) pieces, window NXP slot
+  // pieces x 6 (cg, plane) parts.  With NXP = 6: waves 0, 1 copy two slot pieces (12 parts) + 3 dy pieces, waves 2, 3 one slot
+  // piece (6) + 9 dy pieces: 15 copies each.
+  static_assert(G::NXP == 6, "copy assignment below is written for six slot pieces");
+  auto issue_unit = [&](int c, int buf, int unit) {
+    char* const st = lds + buf * G::STAGE;
+    const int p0 = c * RK;
+    const unsigned nf = fdiv((unsigned)p0, g.div_hw), remf = (unsigned)p0 - nf * (unsigned)HW;
+    const unsigned yf = fdiv(remf, g.div_w), xf = remf - yf * (unsigned)g.W;
+    if (unit == 0) {
+      // ---- dy rows p0 .. p0 + 31 (image rows: natural or parity-planar), relative to the first image of the chunk ----
+      const int dbase = (int)((nf * (unsigned)HW) & ~15u);
+      const rsrc_t rD = make_rsrc(g.dyimg + (size_t)(dbase >> 4) * g.nks_dy * P6_GROUP, 0x7FFFFFFFu);
+      const int r = lane >> 1, hp = lane & 1;
+      const int mm = p0 + r;
+      const bool ok = mm < g.M;
+      const unsigned mc = ok ? (unsigned)mm : 0u;
+      const unsigned n = fdiv(mc, g.div_hw), rem = mc - n * (unsigned)HW;
+      const unsigned y = fdiv(rem, g.div_w), x = rem - y * (unsigned)g.W;
+      const int row = (int)n * HW + (g.dy_planar ? cw_planar((int)y, (int)x, g.H, g.W) : (int)rem);
+      const int rel = row - dbase;
+      const unsigned gh = (unsigned)(hp ^ ((row >> 3) & 1));          // the image's own half swap; LDS keeps logical halves in place
+      unsigned vin = (unsigned)(rel >> 4) * (unsigned)(g.nks_dy * P6_GROUP) + (unsigned)((rel & 15) * 32) + (gh << 4);
+      EVAE_PIN(vin);                                                 // (computed by every lane: a select, not a branch)
+      const unsigned voff = ok ? vin : 0x80000000u;
+      // dy pieces: ids 0..5 -> waves 0, 1 (three each); ids 6..23 -> waves 2, 3 (nine each)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int id = wave < 2 ? wave * 3 + q : 6 + (wave - 2) * 9 + q;
+        const int cg = id / 3, p = id - cg * 3;
+        if ((wave >= 2 || q < 3) && cg < ncgdy)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rD, (p6_lds_t)(st + cg * G::DYCG + p * (RK * 32)), 16, voff, (unsigned)(cg * P6_GROUP + p * P6_CHUNK), 0, 0);
+      }
+    } else {
+      // ---- window slot piece jj: unit 1 -> piece `wave` (all four waves), unit 2 -> pieces 4, 5 (waves 0, 1) ----
+      if (unit == 2 && wave >= 2) return;
+      const int jj = unit == 1 ? wave : 4 + wave;
+      const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)g.PW + xf);
+      const int xbase = (int)((nf * (unsigned)g.istride) & ~15u);
+      const rsrc_t rX = make_rsrc(g.ximg + ((size_t)(xbase >> 4) * g.nks_x + (size_t)g.xcg0) * P6_GROUP, 0x7FFFFFFFu);
+      const int s = 32 * jj + (lane >> 1), hp = lane & 1;
+      const unsigned q = (unsigned)(qbase + s);
+      const unsigned n = fdiv(q, g.div_sp), r = q - n * (unsigned)g.SP;
+      const unsigned py = fdiv(r, g.div_pw), px = r - py * (unsigned)g.PW;
+      const int y = (int)py - g.plo, x = (int)px - g.plo;
+      const bool ok = (int)n < g.N && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+      const int pix = (int)n * g.istride + g.ioff[0] + y * g.W + x;
+      const int rel = pix - xbase;
+      const unsigned gh = (unsigned)(hp ^ ((pix >> 3) & 1));
+      unsigned vin = (unsigned)(rel >> 4) * (unsigned)(g.nks_x * P6_GROUP) + (unsigned)((rel & 15) * 32) + (gh << 4);
+      EVAE_PIN(vin);
+      const unsigned voff = ok ? vin : 0x80000000u;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int cg = k / 3, p = k - cg * 3;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (p6_lds_t)(st + G::DY + cg * G::XCG + p * G::XPL + jj * 1024), 16, voff,
+                                                 (unsigned)(cg * P6_GROUP + p * P6_CHUNK), 0, 0);
+      }
+    }
+  };
+  auto issue_stage = [&](int c, int buf) { issue_unit(c, buf, 0); issue_unit(c, buf, 1); issue_unit(c, buf, 2); };
+
+  // window slot (relative to the stage's base slot) of chunk row r: this lane's k rows are 16 ks + 8 lh + (t16 >> 2) (+ 4)
+  auto slot_of = [&](int p0, int qbase, int r) -> int {
+    int mm = p0 + r;
+    mm = mm < g.M ? mm : g.M - 1;
+    const unsigned n = fdiv((unsigned)mm, g.div_hw), rem = (unsigned)mm - n * (unsigned)HW;
+    const unsigned y = fdiv(rem, g.div_w), x = rem - y * (unsigned)g.W;
+    return (int)(n * (unsigned)g.SP + y * (unsigned)g.PW + x) - qbase;
+  };
+
+  // the ones operand of the bias column: column 0 = 1.0 (plane 0 only)
+  p6_bf16x8 ones;
+  {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const unsigned v = l31 == 0 ? 0x3F803F80u : 0u;
+    const u32x4_ o = {v, v, v, v};
+    ones = __builtin_bit_cast(p6_bf16x8, o);
+  }
+  // a fragment = two transpose reads (k rows c and c + 4 -> the 8 k of this lane's row); the halves stay separate until the wait
+  // for them has passed (inline-asm results are invisible to the compiler's own lgkmcnt bookkeeping)
+  struct Raw { p6_u32x2 lo, hi; };
+  auto tr2 = [&](Raw& f, unsigned a0, unsigned a1) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a1));
+  };
+  auto cook = [&](const Raw& f) -> p6_bf16x8 {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ v = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
+    return __builtin_bit_cast(p6_bf16x8, v);
+  };
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};       // smallest partial products first
+
+  const int nst = c1 - c0;
+  if (nst > 0) {
+    issue_stage(c0, 0);
+    for (int i = 0; i < nst; ++i) {
+      const int buf = i & 1, c = c0 + i;
+      // this wave's copies of stage i have landed; barrier: everybody's have, and everybody is done with stage i - 1 (the other
+      // buffer), which the copies of stage i + 1 -- issued between this stage's MFMA groups -- overwrite
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const bool more = i + 1 < nst && !(g.dbg & 1);
+      if (g.dbg & 2) { if (more) issue_stage(c + 1, buf ^ 1); continue; }
+      const unsigned st = lds_base + (unsigned)(buf * G::STAGE);
+      const int p0 = c * RK;
+      const unsigned nf = fdiv((unsigned)p0, g.div_hw), remf = (unsigned)p0 - nf * (unsigned)HW;
+      const unsigned yf = fdiv(remf, g.div_w), xf = remf - yf * (unsigned)g.W;
+      const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)g.PW + xf);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int kr = 16 * ks + 8 * lh + (t16 >> 2);
+        // A: this wave's 32 merged channels = channel groups 2 wave, 2 wave + 1 (ib); rows kr, kr + 4
+        Raw ar[3];
+        {
+          const unsigned a0 = st + (unsigned)((2 * wave + ib) * G::DYCG + kr * 32 + (t16 & 3) * 8);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) tr2(ar[p], a0 + p * (RK * 32), a0 + p * (RK * 32) + 128);
+        }
+        // B: window slots of rows kr, kr + 4 (+ the tile's tap offset), channel group ib of the pair
+        const unsigned xb = st + (unsigned)(G::DY + ib * G::XCG + (t16 & 3) * 8);
+        const unsigned b0 = xb + (unsigned)(slot_of(p0, qbase, kr) * 32), b1 = xb + (unsigned)(slot_of(p0, qbase, kr + 4) * 32);
+        // column tiles in pairs (two independent accumulator chains alternate on the matrix pipe); the bias column is the partner
+        // of the last tile when NTW is odd, else a group of its own
+        // column tiles in groups of four: four independent accumulator chains alternate on the matrix pipe (pairs measured the same: the stream is issue-bound, not latency-bound); the bias column is the last column of all
+        constexpr int GS = 4, NCOL = NTW + 1, NGRP = (NCOL + GS - 1) / GS;
+        Raw br[2][GS][3];
+        // read #e (0 .. 6 GS - 1) of the group starting at column j into buffer par: column u = e / 6, plane p = (e % 6) / 2, half = e & 1
+        auto read_one = [&](int par, int j, int e) {
+          const int u = e / 6, p = (e % 6) >> 1, hf = e & 1;
+          if (j + u < NTW) {
+            const unsigned a = (hf ? b1 : b0) + (unsigned)(g.tile_to[j + u] * 32) + p * G::XPL;
+            if (hf) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(br[par][u][p].hi) : "v"(a));
+            else asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(br[par][u][p].lo) : "v"(a));
+          }
+        };
+#pragma unroll
+        for (int e = 0; e < 6 * GS; ++e) read_one(0, 0, e);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        p6_bf16x8 af[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[p] = cook(ar[p]);
+#pragma unroll
+        for (int jg = 0; jg < NGRP; ++jg) {
+          const int par = jg & 1, j = GS * jg;
+          if (jg > 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+          __builtin_amdgcn_sched_barrier(0);
+          p6_bf16x8 bf_[GS][3];
+#pragma unroll
+          for (int u = 0; u < GS; ++u)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) if (j + u < NTW) bf_[u][p] = cook(br[par][u][p]);
+          __builtin_amdgcn_sched_barrier(0);
+          // 6 GS MFMAs, one transpose read of the NEXT group behind each (a wave whose row tile does not exist -- fewer than 128
+          // merged channels -- runs the same stream on whatever its LDS rows hold and stores nothing: no branch around the MFMAs,
+          // whose accumulators would otherwise be copied at every join)
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int u = 0; u < GS; ++u) {
+              if (j + u < NTW) acc[j + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], bf_[u][PB[q]], acc[j + u], 0, 0, 0);
+              else if (j + u == NTW && PB[q] == 0) acc[NTW] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], ones, acc[NTW], 0, 0, 0);   // bias column: a2, a1, a0 against the ones
+              __builtin_amdgcn_sched_barrier(0);
+              if (jg + 1 < NGRP) read_one(par ^ 1, j + GS, q * GS + u);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          // a unit of the next stage's copies behind the first three MFMA groups of the stage (the matrix pipe works them off meanwhile)
+          if (ks == 0 && jg < 3 && more) issue_unit(c + 1, buf ^ 1, jg);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  // ---- partial plane of this block: part[block][cc][tap][ci], dbpart[block][cc] ----
+  if (active) {
+    float* const pb = g.part + (size_t)blockIdx.x * g.CC * g.ntap_f * g.Cin;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int tap = g.tile_tap[j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cc = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (cc < g.CC) pb[((size_t)cc * g.ntap_f + tap) * g.Cin + g.xcg0 * 16 + l31] = acc[j][r];
+      }
+    }
+    if (g.dbpart && l31 == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cc = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (cc < g.CC) g.dbpart[(size_t)blockIdx.x * g.CC + cc] = acc[NTW][r];
+      }
+    }
+  }
+}
+
+// dw[cc][ci][tap] = sum over blocks of part[b][cc][tap][ci]; db[cc] = sum of dbpart[b][cc]  (block order: deterministic)
+__global__ __launch_bounds__(256) void cw_wgrad_finish_kernel(const float* __restrict__ part, const float* __restrict__ dbpart, int nblk, int CC,
+                                                              int ntap, int Cin, float* __restrict__ dw, float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = CC * ntap * Cin;
+  if (i < n) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + i];
+    const int ci = i % Cin, tap = (i / Cin) % ntap, cc = i / (Cin * ntap);
+    dw[((size_t)cc * Cin + ci) * ntap + tap] = s;
+  }
+  if (db && i < CC) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += dbpart[(size_t)b * CC + i];
+    db[i] = s;
+  }
+}
+
+template <int NTW, int WSL>
+static int launch_conv_wgrad_win(CwWgradArgs& g, int nblk, hipStream_t stream, const char* what) {
+  typedef CwWgGeom<NTW, WSL> G;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<NTW, WSL>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    attr_done = true;
+  }
+  g.PW = g.W + g.plo + g.phi; g.SP = (g.H + g.plo + g.phi) * g.PW;
   g.div_w = make_fastdiv((unsigned)g.W); g.div_hw = make_fastdiv((unsigned)(g.H * g.W));
   g.div_pw = make_fastdiv((unsigned)g.PW); g.div_sp = make_fastdiv((unsigned)g.SP);
   g.M = g.N * g.H * g.W;
-  const int tiles_m = cdiv(g.M, G::R);
-  conv_win_kernel<EPI, WR, NT, SLOTS><<<dim3(tiles_m * g.tiles_n), 256, G::LDS, stream>>>(g);
+  if (g.istride == 0) g.istride = g.H * g.W;
+  g.nchunk = cdiv(g.M, G::RK);
+  g.cper = cdiv(g.nchunk, nblk);
+  conv_wgrad_win_kernel<NTW, WSL><<<dim3(cdiv(g.nchunk, g.cper)), 256, G::LDS, stream>>>(g);
   return check_launch(what);
 }
 

@@ -44,31 +44,55 @@ static double img_at(const std::vector<unsigned char>& img, int r, int k, int nk
   return s;
 }
 
-// gated forward, stride 1, 'same' padding
-static void case_fwd(int N, int C, int H, int Co, int K, int reps) {
-  const int W = H, pad = (K - 1) / 2, taps = K * K, M = N * H * W;
-  typedef CwGeom<2, 2, 320> G;
-  auto hx = rnd((size_t)M * C, 1), hwh = rnd((size_t)Co * C * taps, 2, 0.05f), hwg = rnd((size_t)Co * C * taps, 3, 0.05f), hbh = rnd(Co, 4, 0.3f), hbg = rnd(Co, 5, 0.3f);
+struct Layer { int C, Hin, Co, K, stride, pad; };
+
+// rows of an Hin x Hin activation in the order a consumer of stride `cs` wants them
+static size_t row_of(int n, int y, int x, int Hin, int cs) {
+  return cs == 2 ? (size_t)n * Hin * Hin + cw_planar(y, x, Hin, Hin) : ((size_t)n * Hin + y) * Hin + x;
+}
+
+template <int WR, int NT, int SLOTS>
+static bool setup_geom(ConvWinArgs& g, int H, int plo, int phi, const char* what) {
+  typedef CwGeom<WR, NT, SLOTS> G;
+  const int slots = cw_window_slots(H, H, plo, phi, G::R);
+  if (slots > SLOTS) { printf("%s: window of %d slots does not fit %d\n", what, slots, SLOTS); return false; }
+  g.nsp = (slots + 31) / 32;
+  return true;
+}
+
+// gated forward of layer L over N images; `ocs`: stride of the layer that consumes the output (its rows go parity-planar for 2)
+static void case_fwd(int N, Layer L, int ocs, int reps) {
+  const int C = L.C, Hin = L.Hin, Co = L.Co, K = L.K, st = L.stride, pad = L.pad, H = Hin / st, taps = K * K;
+  const int Min = N * Hin * Hin, M = N * H * H;
+  auto hx = rnd((size_t)Min * C, 1), hwh = rnd((size_t)Co * C * taps, 2, 0.05f), hwg = rnd((size_t)Co * C * taps, 3, 0.05f), hbh = rnd(Co, 4, 0.3f), hbg = rnd(Co, 5, 0.3f);
+  // input rows in the order THIS layer wants (planar when it has stride 2); hx is indexed [row_of(..)][C]
   float* dx = dev(hx); float* dwh = dev(hwh); float* dwg = dev(hwg); float* dbh = dev(hbh); float* dbg = dev(hbg);
-  const int nks_in = C / 16, ncg = C / 16, nks_w = ncg * taps, tiles_n = (Co + 63) / 64, nks_o = Co / 16;
-  const int Mi = (M + 127) / 128 * 128;
-  unsigned char* ix = devz<unsigned char>(p6_image_bytes(M, nks_in));
-  unsigned char* iw = devz<unsigned char>(p6_image_bytes(tiles_n * 128, nks_w) + 4096);
+  int plo, phi;
+  const CwTaps tp = cw_taps_fwd(K, st, pad, &plo, &phi);
+  const int nks_in = C / 16, ncg = C / 16, nks_w = cw_ksteps(tp, ncg), nks_o = Co / 16;
+  const int bn = Co >= 64 ? 128 : 64, tiles_n = (2 * Co + bn - 1) / bn;
+  const int Mi = (Min + 127) / 128 * 128;
+  unsigned char* ix = devz<unsigned char>(p6_image_bytes(Min, nks_in));
+  unsigned char* iw = devz<unsigned char>(p6_image_bytes(tiles_n * bn, nks_w) + 8192);
   unsigned char* io = devz<unsigned char>(p6_image_bytes(M, nks_o));
   float* ds = devz<float>((size_t)M * Co); float* dout = devz<float>((size_t)M * Co);
-  p6_pack_rows_kernel<<<(unsigned)(((size_t)Mi * nks_in * 2 + 255) / 256), 256>>>(dx, nullptr, M, C, C, 0, Mi, nks_in, ix);
-  cw_pack_filter_kernel<<<(unsigned)(((size_t)tiles_n * 128 * nks_w * 2 + 255) / 256), 256>>>(dwh, dwg, Co, C, taps, 0, 128, tiles_n * 128, nks_w, iw);
+  p6_pack_rows_kernel<<<(unsigned)(((size_t)Mi * nks_in * 2 + 255) / 256), 256>>>(dx, nullptr, Min, C, C, 0, Mi, nks_in, ix);
+  const int wrows = (tiles_n * bn + 127) / 128 * 128;
+  cw_pack_filter_kernel<<<(unsigned)(((size_t)wrows * nks_w * 2 + 255) / 256), 256>>>(dwh, dwg, Co, C, K, K, tp, ncg, 0, bn, wrows, nks_w, iw);
   CK(hipDeviceSynchronize());
-  const int slots = cw_window_slots(H, W, K, K, pad, G::R);
   ConvWinArgs g; memset(&g, 0, sizeof(g));
-  g.xin = ix; g.nks_in = nks_in; g.ncg = ncg; g.cg0 = 0; g.N = N; g.H = H; g.W = W; g.KH = K; g.KW = K; g.pad = pad;
+  g.xin = ix; g.nks_in = nks_in; g.ncg = ncg; g.cg0 = 0; g.N = N; g.H = H; g.W = H; g.plo = plo; g.phi = phi; g.taps = tp;
+  g.istride = st * st * H * H; for (int s2 = 0; s2 < st * st; ++s2) g.ioff[s2] = s2 * H * H;
   g.wimg = iw; g.nks_w = nks_w; g.Co = Co; g.tiles_n = tiles_n; g.bias0 = dbh; g.bias1 = dbg;
+  g.out_planar = ocs == 2;
   g.oimg = io; g.nks_o = nks_o; g.och0 = 0; g.out_s = ds; g.out_f = dout; g.ldo = Co;
-  if (slots > 320) { printf("fwd C=%d H=%d Co=%d k=%d: window of %d slots does not fit\n", C, H, Co, K, slots); return; }
-  auto run = [&](ConvWinArgs& a) { launch_conv_win<CW_FWD_GATED, 2, 2, 320>(a, 0, "cw fwd"); };
+  char what[128]; snprintf(what, sizeof what, "cw fwd   N=%d C=%d Hin=%d Co=%d k=%d s=%d (out rows %s)", N, C, Hin, Co, K, st, ocs == 2 ? "planar" : "natural");
+  bool ok;
+  if (bn == 128) ok = setup_geom<2, 2, 320>(g, H, plo, phi, what); else ok = setup_geom<4, 2, 576>(g, H, plo, phi, what);
+  if (!ok) return;
+  auto run = [&](ConvWinArgs& a) { if (bn == 128) launch_conv_win<CW_FWD_GATED, 2, 2, 320>(a, 0, "cw fwd"); else launch_conv_win<CW_FWD_GATED, 4, 2, 576>(a, 0, "cw fwd"); };
   run(g);
   CK(hipDeviceSynchronize());
-  const float t = time_us([&] { run(g); }, reps);
   ConvWinArgs g2 = g; g2.out_f = nullptr;
   const float t2 = time_us([&] { run(g2); }, reps);
   ConvWinArgs gn = g; gn.dbg = 4;
@@ -83,16 +107,17 @@ static void case_fwd(int N, int C, int H, int Co, int K, int reps) {
   for (int sidx = 0; sidx < 160; ++sidx) {
     int m = (int)(((long long)sidx * 2654435761ll) % M);
     if (sidx < 8) m = (sidx & 1) ? M - 1 - sidx : sidx * 13;              // corners / first and last images
-    if (sidx >= 8 && sidx < 24) m = (sidx - 8) * (H * W / 16) + (sidx & 1 ? H * W * (N - 1) : 0);
+    if (sidx >= 8 && sidx < 24) m = (sidx - 8) * (H * H / 16) + (sidx & 1 ? H * H * (N - 1) : 0);
     if (m >= M) m = M - 1;
-    const int n = m / (H * W), y = (m / W) % H, x = m % W;
+    const int n = m / (H * H), y = (m / H) % H, x = m % H;
+    const size_t orow = row_of(n, y, x, H, ocs), nrow = row_of(n, y, x, H, 1);
     for (int co = 0; co < Co; ++co) {
       double h = hbh[co], gg = hbg[co];
       for (int kh = 0; kh < K; ++kh)
         for (int kw = 0; kw < K; ++kw) {
-          const int yy = y + kh - pad, xx = x + kw - pad;
-          if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-          const float* px = &hx[((size_t)(n * H + yy) * W + xx) * C];
+          const int yy = st * y + kh - pad, xx = st * x + kw - pad;
+          if (yy < 0 || yy >= Hin || xx < 0 || xx >= Hin) continue;
+          const float* px = &hx[row_of(n, yy, xx, Hin, st) * C];
           for (int c = 0; c < C; ++c) {
             h += (double)px[c] * hwh[((size_t)co * C + c) * taps + kh * K + kw];
             gg += (double)px[c] * hwg[((size_t)co * C + c) * taps + kh * K + kw];
@@ -100,97 +125,196 @@ static void case_fwd(int N, int C, int H, int Co, int K, int reps) {
         }
       const double s = 1.0 / (1.0 + exp(-gg)), r = h * s;
       rmax = fmax(rmax, fabs(r));
-      eo = fmax(eo, fabs(ho[(size_t)m * Co + co] - r));
-      es = fmax(es, fabs(hs[(size_t)m * Co + co] - s));
-      ei = fmax(ei, fabs(img_at(himg, m, co, nks_o) - r));
+      eo = fmax(eo, fabs(ho[nrow * Co + co] - r));
+      es = fmax(es, fabs(hs[nrow * Co + co] - s));
+      ei = fmax(ei, fabs(img_at(himg, (int)orow, co, nks_o) - r));
     }
   }
   const double gf = 4.0 * M * Co * C * taps * 1e-9;
-  printf("cw fwd  N=%d C=%d H=%d Co=%d k=%d (window %d slots, %d blocks): %.1f us %.0f TF (%.3f of the 6-product ceiling 417) | without the fp32 copy %.1f us | main loop only %.1f us | err/max: out %.2e s %.2e image %.2e\n",
-         N, C, H, Co, K, slots, (M + G::R - 1) / G::R * tiles_n, t, gf / t * 1e3, gf / t * 1e3 / 417.0, t2, tn, eo / rmax, es, ei / rmax);
+  printf("%s: %.1f us %.0f TF | main loop only %.1f us | err/max: out %.2e s %.2e image %.2e\n", what, t2, gf / t2 * 1e3, tn, eo / rmax, es, ei / rmax);
   hipFree(dx); hipFree(dwh); hipFree(dwg); hipFree(ix); hipFree(iw); hipFree(io); hipFree(ds); hipFree(dout);
 }
 
-// data gradient of a gated layer C -> Co (stride 1), with the gate derivative of the layer below (C channels) in the epilogue:
-// v = conv_transpose([dh | dg], [wh | wg]);  [dh' | dg'] = [v s' | v out' (1 - s')]
-static void case_dgrad(int N, int C, int H, int Co, int K, int reps) {
-  const int W = H, pad = (K - 1) / 2, taps = K * K, M = N * H * W, ctot = 2 * Co;
-  typedef CwGeom<4, 1, 576> G;
-  if (C != 32) { printf("dgrad bench: C = 32 only\n"); return; }
+// data gradient of gated layer L (C -> Co) with the gate derivative of the layer below (C channels) in the epilogue:
+// v = conv_transpose([dh | dg], [wh | wg]);  [dh' | dg'] = [v s' | v out' (1 - s')].  dy rows: `dcs` order (the stride of L's consumer);
+// the result's rows (L's input pixels): planar when L has stride 2
+static void case_dgrad(int N, Layer L, int dcs, int reps) {
+  const int C = L.C, Hin = L.Hin, Co = L.Co, K = L.K, st = L.stride, pad = L.pad, H = Hin / st, taps = K * K, ctot = 2 * Co;
+  const int Min = N * Hin * Hin, M = N * H * H;
   auto hdy = rnd((size_t)M * ctot, 11, 0.1f), hwh = rnd((size_t)Co * C * taps, 2, 0.05f), hwg = rnd((size_t)Co * C * taps, 3, 0.05f);
-  auto ho_ = rnd((size_t)M * C, 12), hs_ = rnd((size_t)M * C, 13);
+  auto ho_ = rnd((size_t)Min * C, 12), hs_ = rnd((size_t)Min * C, 13);      // ho_: rows in image order (planar for stride 2); hs_: natural
   for (auto& v : hs_) v = 1.f / (1.f + expf(-v));
   float* ddy = dev(hdy); float* dwh = dev(hwh); float* dwg = dev(hwg); float* dob = dev(ho_); float* dsb = dev(hs_);
-  const int nks_in = ctot / 16, ncg = ctot / 16, nks_w = ncg * taps, nks_e = C / 16, nks_o = 2 * C / 16;
-  const int Mi = (M + 127) / 128 * 128;
+  const int nks_in = ctot / 16, ncg = ctot / 16, nks_e = C / 16, nks_o = 2 * C / 16;
+  const int Mi = (M + 127) / 128 * 128, Mini = (Min + 127) / 128 * 128;
   unsigned char* idy = devz<unsigned char>(p6_image_bytes(M, nks_in));
-  unsigned char* iw = devz<unsigned char>(p6_image_bytes(128, nks_w) + 4096);
-  unsigned char* ie = devz<unsigned char>(p6_image_bytes(M, nks_e));
-  unsigned char* io = devz<unsigned char>(p6_image_bytes(M, nks_o));
-  float* dout = devz<float>((size_t)M * 2 * C);
+  unsigned char* ie = devz<unsigned char>(p6_image_bytes(Min, nks_e));
+  unsigned char* io = devz<unsigned char>(p6_image_bytes(Min, nks_o));
+  float* dout = devz<float>((size_t)Min * 2 * C);
   p6_pack_rows_kernel<<<(unsigned)(((size_t)Mi * nks_in * 2 + 255) / 256), 256>>>(ddy, nullptr, M, ctot, ctot, 0, Mi, nks_in, idy);
-  p6_pack_rows_kernel<<<(unsigned)(((size_t)Mi * nks_e * 2 + 255) / 256), 256>>>(dob, nullptr, M, C, C, 0, Mi, nks_e, ie);
-  cw_pack_filter_kernel<<<(unsigned)(((size_t)128 * nks_w * 2 + 255) / 256), 256>>>(dwh, dwg, Co, C, taps, 1, 32, 128, nks_w, iw);
+  p6_pack_rows_kernel<<<(unsigned)(((size_t)Mini * nks_e * 2 + 255) / 256), 256>>>(dob, nullptr, Min, C, C, 0, Mini, nks_e, ie);
+  char what[128]; snprintf(what, sizeof what, "cw dgrad N=%d C=%d Hin=%d Co=%d k=%d s=%d (dy rows %s)", N, C, Hin, Co, K, st, dcs == 2 ? "planar" : "natural");
+  // one launch per input parity class
+  std::vector<ConvWinArgs> gs; std::vector<unsigned char*> iws;
+  double ksum = 0;
+  for (int py = 0; py < st; ++py)
+    for (int px = 0; px < st; ++px) {
+      int plo, phi;
+      const CwTaps tp = cw_taps_dgrad(K, st, pad, py, px, &plo, &phi);
+      const int nks_w = cw_ksteps(tp, ncg);
+      unsigned char* iw = devz<unsigned char>(p6_image_bytes(128, nks_w) + 8192);
+      cw_pack_filter_kernel<<<(unsigned)(((size_t)128 * nks_w * 2 + 255) / 256), 256>>>(dwh, dwg, Co, C, K, K, tp, ncg, 1, C, 128, nks_w, iw);
+      ConvWinArgs g; memset(&g, 0, sizeof(g));
+      g.xin = idy; g.nks_in = nks_in; g.ncg = ncg; g.N = N; g.H = H; g.W = H; g.plo = plo; g.phi = phi; g.taps = tp;
+      g.istride = H * H; g.in_planar = dcs == 2;
+      g.wimg = iw; g.nks_w = nks_w; g.Co = C; g.tiles_n = 1;
+      g.ostride = st * st * H * H; g.ooff = (py * st + px) * H * H;
+      g.nat_h = Hin; g.nat_w = Hin; g.nat_s = st; g.nat_y = py; g.nat_x = px;
+      g.oimg = io; g.nks_o = nks_o; g.och0 = 0; g.out_f = dout; g.ldo = 2 * C;
+      g.eimg = ie; g.nks_e = nks_e; g.ech0 = 0; g.e_s = dsb;
+      bool ok;
+      if (C == 32) ok = setup_geom<4, 1, 576>(g, H, plo, phi, what); else ok = setup_geom<4, 2, 576>(g, H, plo, phi, what);
+      if (!ok) return;
+      gs.push_back(g); iws.push_back(iw); ksum += nks_w;
+    }
   CK(hipDeviceSynchronize());
-  const int slots = cw_window_slots(H, W, K, K, pad, G::R);
-  ConvWinArgs g; memset(&g, 0, sizeof(g));
-  g.xin = idy; g.nks_in = nks_in; g.ncg = ncg; g.cg0 = 0; g.N = N; g.H = H; g.W = W; g.KH = K; g.KW = K; g.pad = pad;
-  g.wimg = iw; g.nks_w = nks_w; g.Co = C; g.tiles_n = 1;
-  g.oimg = io; g.nks_o = nks_o; g.och0 = 0; g.out_f = dout; g.ldo = 2 * C;
-  g.eimg = ie; g.nks_e = nks_e; g.ech0 = 0; g.e_s = dsb;
-  if (slots > 576) { printf("dgrad: window of %d slots does not fit\n", slots); return; }
-  auto run = [&](ConvWinArgs& a) { launch_conv_win<CW_DGRAD_GATE, 4, 1, 576>(a, 0, "cw dgrad"); };
-  run(g);
+  auto run = [&](bool f32, int dbg) {
+    for (auto g : gs) {
+      if (!f32) g.out_f = nullptr;
+      g.dbg = dbg;
+      if (C == 32) launch_conv_win<CW_DGRAD_GATE, 4, 1, 576>(g, 0, "cw dgrad"); else launch_conv_win<CW_DGRAD_GATE, 4, 2, 576>(g, 0, "cw dgrad");
+    }
+  };
+  run(true, 0);
   CK(hipDeviceSynchronize());
-  const float t = time_us([&] { run(g); }, reps);
-  ConvWinArgs g2 = g; g2.out_f = nullptr;
-  const float t2 = time_us([&] { run(g2); }, reps);
-  ConvWinArgs gn = g; gn.dbg = 4;
-  const float tn = time_us([&] { run(gn); }, reps);
-  run(g);
+  const float t2 = time_us([&] { run(false, 0); }, reps);
+  const float tn = time_us([&] { run(false, 4); }, reps);
+  run(true, 0);
   CK(hipDeviceSynchronize());
-  std::vector<float> ho((size_t)M * 2 * C);
-  std::vector<unsigned char> himg(p6_image_bytes(M, nks_o));
+  std::vector<float> ho((size_t)Min * 2 * C);
+  std::vector<unsigned char> himg(p6_image_bytes(Min, nks_o));
   CK(hipMemcpy(ho.data(), dout, ho.size() * 4, hipMemcpyDeviceToHost));
   CK(hipMemcpy(himg.data(), io, himg.size(), hipMemcpyDeviceToHost));
   double eo = 0, ei = 0, rmax = 0;
   for (int sidx = 0; sidx < 120; ++sidx) {
-    int m = (int)(((long long)sidx * 2654435761ll) % M);
-    if (sidx < 8) m = (sidx & 1) ? M - 1 - sidx : sidx * 13;
-    if (m >= M) m = M - 1;
-    const int n = m / (H * W), y = (m / W) % H, x = m % W;
+    int m = (int)(((long long)sidx * 2654435761ll) % Min);
+    if (sidx < 8) m = (sidx & 1) ? Min - 1 - sidx : sidx * 13;
+    if (m >= Min) m = Min - 1;
+    const int n = m / (Hin * Hin), Y = (m / Hin) % Hin, X = m % Hin;
+    const size_t orow = row_of(n, Y, X, Hin, st), nrow = row_of(n, Y, X, Hin, 1);
     for (int c = 0; c < C; ++c) {
       double v = 0;
       for (int kh = 0; kh < K; ++kh)
         for (int kw = 0; kw < K; ++kw) {
-          const int yy = y - kh + pad, xx = x - kw + pad;          // output pixel whose tap (kh, kw) reads (y, x)
-          if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-          const float* py = &hdy[((size_t)(n * H + yy) * W + xx) * ctot];
+          const int ty = Y + pad - kh, tx = X + pad - kw;            // = stride * (output pixel whose tap (kh, kw) reads (Y, X))
+          if (ty < 0 || tx < 0 || ty % st || tx % st) continue;
+          const int yy = ty / st, xx = tx / st;
+          if (yy >= H || xx >= H) continue;
+          const float* py_ = &hdy[row_of(n, yy, xx, H, dcs) * ctot];
           for (int co = 0; co < Co; ++co) {
-            v += (double)py[co] * hwh[((size_t)co * C + c) * taps + kh * K + kw];
-            v += (double)py[Co + co] * hwg[((size_t)co * C + c) * taps + kh * K + kw];
+            v += (double)py_[co] * hwh[((size_t)co * C + c) * taps + kh * K + kw];
+            v += (double)py_[Co + co] * hwg[((size_t)co * C + c) * taps + kh * K + kw];
           }
         }
-      const double s = hs_[(size_t)m * C + c], o = ho_[(size_t)m * C + c];
+      const double s = hs_[nrow * C + c], o = ho_[orow * C + c];
       const double dh = v * s, dg = v * o * (1.0 - s);
       rmax = fmax(rmax, fmax(fabs(dh), fabs(dg)));
-      eo = fmax(eo, fmax(fabs(ho[(size_t)m * 2 * C + c] - dh), fabs(ho[(size_t)m * 2 * C + C + c] - dg)));
-      ei = fmax(ei, fmax(fabs(img_at(himg, m, c, nks_o) - dh), fabs(img_at(himg, m, C + c, nks_o) - dg)));
+      eo = fmax(eo, fmax(fabs(ho[nrow * 2 * C + c] - dh), fabs(ho[nrow * 2 * C + C + c] - dg)));
+      ei = fmax(ei, fmax(fabs(img_at(himg, (int)orow, c, nks_o) - dh), fabs(img_at(himg, (int)orow, C + c, nks_o) - dg)));
     }
   }
   const double gf = 2.0 * M * ctot * C * taps * 1e-9;
-  printf("cw dgrad N=%d C=%d H=%d Co=%d k=%d (window %d slots, %d blocks): %.1f us %.0f TF (%.3f of 417) | without the fp32 copy %.1f us | main loop only %.1f us | err/max: fp32 %.2e image %.2e\n",
-         N, C, H, Co, K, slots, (M + G::R - 1) / G::R, t, gf / t * 1e3, gf / t * 1e3 / 417.0, t2, tn, eo / rmax, ei / rmax);
-  hipFree(ddy); hipFree(dwh); hipFree(dwg); hipFree(dob); hipFree(dsb); hipFree(idy); hipFree(iw); hipFree(ie); hipFree(io); hipFree(dout);
+  printf("%s: %.1f us %.0f TF | main loop only %.1f us | err/max: fp32 %.2e image %.2e\n", what, t2, gf / t2 * 1e3, tn, eo / rmax, ei / rmax);
+  hipFree(ddy); hipFree(dwh); hipFree(dwg); hipFree(dob); hipFree(dsb); hipFree(idy); hipFree(ie); hipFree(io); hipFree(dout);
+  for (auto p_ : iws) hipFree(p_);
+}
+
+// weight gradient of a stride-1 gated layer L: dW[cc][ci][tap], db[cc] from the merged-gradient image and the input image
+static void case_wgrad(int N, Layer L, int dcs, int reps) {
+  const int C = L.C, H = L.Hin, Co = L.Co, K = L.K, pad = L.pad, taps = K * K, CC = 2 * Co;
+  const int M = N * H * H;
+  if (L.stride != 1 || C != 32 || taps != 25) { printf("wgrad bench: 5 x 5, stride 1, 32 input channels only\n"); return; }
+  auto hdy = rnd((size_t)M * CC, 21, 0.1f), hx = rnd((size_t)M * C, 22);          // hdy rows in `dcs` order, hx natural
+  float* ddy = dev(hdy); float* dx = dev(hx);
+  const int nks_dy = CC / 16, nks_x = C / 16, Mi = (M + 127) / 128 * 128;
+  unsigned char* idy = devz<unsigned char>(p6_image_bytes(M, nks_dy));
+  unsigned char* ix = devz<unsigned char>(p6_image_bytes(M, nks_x));
+  p6_pack_rows_kernel<<<(unsigned)(((size_t)Mi * nks_dy * 2 + 255) / 256), 256>>>(ddy, nullptr, M, CC, CC, 0, Mi, nks_dy, idy);
+  p6_pack_rows_kernel<<<(unsigned)(((size_t)Mi * nks_x * 2 + 255) / 256), 256>>>(dx, nullptr, M, C, C, 0, Mi, nks_x, ix);
+  int plo, phi;
+  const CwTaps tp = cw_taps_fwd(K, 1, pad, &plo, &phi);
+  constexpr int WSL = 192;
+  const int slots = cw_window_slots(H, H, plo, phi, 32);
+  if (slots > WSL) { printf("wgrad: window of %d slots does not fit %d\n", slots, WSL); return; }
+  const int nblk = 256;
+  float* part = devz<float>((size_t)nblk * CC * taps * C); float* dbp = devz<float>((size_t)nblk * CC);
+  float* dw = devz<float>((size_t)CC * C * taps); float* db = devz<float>(CC);
+  CwWgradArgs g; memset(&g, 0, sizeof(g));
+  g.dyimg = idy; g.nks_dy = nks_dy; g.dy_planar = dcs == 2; g.ximg = ix; g.nks_x = nks_x; g.xcg0 = 0; g.nseg = 1;
+  g.N = N; g.H = H; g.W = H; g.plo = plo; g.phi = phi;
+  const int PW = H + plo + phi;
+  g.ntap_f = taps; g.Cin = C; g.CC = CC; g.part = part; g.dbpart = dbp;
+  // the 25 taps as two launches of 13 and 12 column tiles (accumulator space: 16 registers per tile)
+  CwWgradArgs ga = g, gb = g;
+  for (int t = 0; t < 13; ++t) { ga.tile_to[t] = (t / K) * PW + t % K; ga.tile_tap[t] = t; }
+  for (int t = 13; t < 25; ++t) { gb.tile_to[t - 13] = (t / K) * PW + t % K; gb.tile_tap[t - 13] = t; }
+  gb.dbpart = nullptr;
+  auto run = [&]() {
+    launch_conv_wgrad_win<13, WSL>(ga, nblk, 0, "cw wgrad");
+    launch_conv_wgrad_win<12, WSL>(gb, nblk, 0, "cw wgrad");
+    const int nb = (int)((size_t)ga.nchunk + ga.cper - 1) / ga.cper;
+    cw_wgrad_finish_kernel<<<(CC * taps * C + 255) / 256, 256>>>(part, dbp, nb, CC, taps, C, dw, db);
+  };
+  run();
+  CK(hipDeviceSynchronize());
+  const float t = time_us(run, reps);
+  if (!getenv("CW_NOABL")) {
+    ga.dbg = gb.dbg = 1; const float t_nocopy = time_us(run, reps);
+    ga.dbg = gb.dbg = 2; const float t_copyonly = time_us(run, reps);
+    ga.dbg = gb.dbg = 0; run(); CK(hipDeviceSynchronize());
+    printf("          (MFMA stream without the copies %.1f us; copies without the MFMA stream %.1f us)\n", t_nocopy, t_copyonly);
+  }
+  std::vector<float> hw((size_t)CC * C * taps), hb(CC);
+  CK(hipMemcpy(hw.data(), dw, hw.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), db, hb.size() * 4, hipMemcpyDeviceToHost));
+  double e = 0, rm = 0, eb = 0, rb = 0;
+  for (int sidx = 0; sidx < 40; ++sidx) {
+    const int cc = (sidx * 37) % CC, ci = (sidx * 11) % C, tap = (sidx * 7) % taps, kh = tap / K, kw = tap % K;
+    double r = 0, b = 0;
+    for (int n = 0; n < N; ++n)
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < H; ++x) {
+          const double d = hdy[row_of(n, y, x, H, dcs) * CC + cc];
+          b += d;
+          const int yy = y + kh - pad, xx = x + kw - pad;
+          if (yy < 0 || yy >= H || xx < 0 || xx >= H) continue;
+          r += d * hx[row_of(n, yy, xx, H, 1) * C + ci];
+        }
+    rm = fmax(rm, fabs(r)); e = fmax(e, fabs(hw[((size_t)cc * C + ci) * taps + tap] - r));
+    rb = fmax(rb, fabs(b)); eb = fmax(eb, fabs(hb[cc] - b));
+  }
+  const double gf = 2.0 * M * CC * C * taps * 1e-9;
+  printf("cw wgrad N=%d C=%d H=%d Co=%d k=%d (dy rows %s, window %d slots, %d blocks): %.1f us %.0f TF | err/max: dw %.2e db %.2e\n", N, C, H, Co, K,
+         dcs == 2 ? "planar" : "natural", slots, nblk, t, gf / t * 1e3, e / rm, eb / fmax(rb, 1e-30));
+  hipFree(ddy); hipFree(dx); hipFree(idy); hipFree(ix); hipFree(part); hipFree(dbp); hipFree(dw); hipFree(db);
 }
 
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 20224;
   const int reps = argc > 2 ? atoi(argv[2]) : 10;
   const char* only = argc > 3 ? argv[3] : "";
-  if (!*only) { case_fwd(37, 32, 14, 64, 5, 2); case_dgrad(37, 32, 14, 64, 5, 2); }
-  if (!*only || !strcmp(only, "fwd5")) case_fwd(N, 32, 14, 64, 5, reps);
-  if (!*only || !strcmp(only, "fwd3")) case_fwd(N, 32, 14, 64, 3, reps);
-  if (!*only || !strcmp(only, "dgrad5")) case_dgrad(N, 32, 14, 64, 5, reps);
+  const Layer L2 = {32, 28, 32, 3, 2, 1}, L3 = {32, 14, 64, 5, 1, 2}, L4 = {64, 14, 64, 3, 2, 1}, L3k3 = {32, 14, 64, 3, 1, 1};
+  if (!*only) {
+    case_fwd(37, L3, 1, 2); case_fwd(37, L3, 2, 2); case_fwd(37, L2, 1, 2); case_fwd(37, L4, 1, 2);
+    case_dgrad(37, L3, 1, 2); case_dgrad(37, L3, 2, 2); case_dgrad(37, L2, 1, 2); case_dgrad(37, L4, 1, 2);
+    case_wgrad(37, L3, 1, 2); case_wgrad(37, L3, 2, 2);
+  }
+  if (!*only || !strcmp(only, "wgrad5")) case_wgrad(N, L3, 2, reps);
+  if (!*only || !strcmp(only, "fwd5")) case_fwd(N, L3, 2, reps);
+  if (!*only || !strcmp(only, "fwd3")) case_fwd(N, L3k3, 1, reps);
+  if (!*only || !strcmp(only, "fwdL2")) case_fwd(N, L2, 1, reps);
+  if (!*only || !strcmp(only, "fwdL4")) case_fwd(N, L4, 1, reps);
+  if (!*only || !strcmp(only, "dgrad5")) case_dgrad(N, L3, 2, reps);
+  if (!*only || !strcmp(only, "dgradL2")) case_dgrad(N, L2, 1, reps);
+  if (!*only || !strcmp(only, "dgradL4")) case_dgrad(N, L4, 1, reps);
   return 0;
 }
