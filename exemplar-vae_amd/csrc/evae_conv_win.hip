@@ -1,0 +1,302 @@
+// C ABI of the window convolutions over pre-split pixel images (evae_conv_win.h): the gated convolution layers of the
+// convolutional encoders (reference utils/nn.py:72-97, models/convHVAE_2level.py:21-46) between two layers of a stack, where
+// activations never exist as fp32 tensors unless a caller asks for a copy.
+#include "evae_conv_win.h"
+
+namespace evae {
+
+// fp32 channels-last [N][H][W][C] -> pixel image (rows natural or parity-planar); one thread per (pixel, 8 channels)
+__global__ __launch_bounds__(256) void cw_pack_image_kernel(const float* __restrict__ x, int N, int H, int W, int C, int planar,
+                                                            unsigned char* __restrict__ img) {
+  const int c8n = C >> 3, nks = C >> 4;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)N * H * W * c8n;
+  if (t >= total) return;
+  // thread -> pixel fastest inside 16, then the 8-channel group, then the 16-pixel groups (whole 512-byte chunks per 32 lanes)
+  const size_t grp = t / ((size_t)16 * c8n);
+  const int r = (int)(t - grp * 16 * c8n), c8 = r >> 4, p16 = r & 15;
+  const size_t m = grp * 16 + p16;
+  if (m >= (size_t)N * H * W) return;
+  const float4 a = *reinterpret_cast<const float4*>(x + m * C + c8 * 8), b = *reinterpret_cast<const float4*>(x + m * C + c8 * 8 + 4);
+  size_t row = m;
+  if (planar) {
+    const size_t n = m / ((size_t)H * W);
+    const int rem = (int)(m - n * H * W), y = rem / W, xx = rem - y * W;
+    row = n * H * W + cw_planar(y, xx, H, W);
+  }
+  unsigned t0[4], t1[4], t2[4];
+  p6_split2(a.x, a.y, t0[0], t1[0], t2[0]); p6_split2(a.z, a.w, t0[1], t1[1], t2[1]);
+  p6_split2(b.x, b.y, t0[2], t1[2], t2[2]); p6_split2(b.z, b.w, t0[3], t1[3], t2[3]);
+  unsigned char* o = img + p6_off64(row, c8 * 8, nks);
+  *reinterpret_cast<uint4*>(o) = make_uint4(t0[0], t0[1], t0[2], t0[3]);
+  *reinterpret_cast<uint4*>(o + P6_CHUNK) = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+  *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+}
+
+// [dh | dg] = [v s | v out (1 - s)] for an upstream gradient v that exists as an fp32 tensor (the layer above ran outside the
+// stack): v, s fp32 natural [rows][C]; out from its pixel image (rows natural or planar); result -> pixel image in the image's row
+// order (2 C channels) and / or fp32 natural [rows][2 C]
+__global__ __launch_bounds__(256) void cw_gate_bwd_image_kernel(const float* __restrict__ v, const unsigned char* __restrict__ eimg, int planar,
+                                                                const float* __restrict__ s, int N, int H, int W, int C,
+                                                                unsigned char* __restrict__ oimg, float* __restrict__ out_f) {
+  const int c8n = C >> 3, nks_e = C >> 4, nks_o = C >> 3;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t grp = t / ((size_t)16 * c8n);
+  const int r = (int)(t - grp * 16 * c8n), c8 = r >> 4, p16 = r & 15;
+  const size_t m = grp * 16 + p16;
+  if (m >= (size_t)N * H * W) return;
+  size_t row = m;
+  if (planar) {
+    const size_t n = m / ((size_t)H * W);
+    const int rem = (int)(m - n * H * W), y = rem / W, xx = rem - y * W;
+    row = n * H * W + cw_planar(y, xx, H, W);
+  }
+  const int ch = c8 * 8;
+  const float4 v0 = *reinterpret_cast<const float4*>(v + m * C + ch), v1 = *reinterpret_cast<const float4*>(v + m * C + ch + 4);
+  const float4 s0 = *reinterpret_cast<const float4*>(s + m * C + ch), s1 = *reinterpret_cast<const float4*>(s + m * C + ch + 4);
+  const unsigned char* e = eimg + p6_off64(row, ch, nks_e);
+  const uint4 e0 = *reinterpret_cast<const uint4*>(e), e1 = *reinterpret_cast<const uint4*>(e + P6_CHUNK), e2 = *reinterpret_cast<const uint4*>(e + 2 * P6_CHUNK);
+  const unsigned w0[4] = {e0.x, e0.y, e0.z, e0.w}, w1[4] = {e1.x, e1.y, e1.z, e1.w}, w2[4] = {e2.x, e2.y, e2.z, e2.w};
+  const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  float dh[8], dg[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int sh = 16 * (k & 1);
+    const float ov = (__uint_as_float(((w2[k >> 1] >> sh) & 0xFFFFu) << 16) + __uint_as_float(((w1[k >> 1] >> sh) & 0xFFFFu) << 16)) +
+                     __uint_as_float(((w0[k >> 1] >> sh) & 0xFFFFu) << 16);
+    dh[k] = vv[k] * sv[k];
+    dg[k] = vv[k] * ov * (1.0f - sv[k]);
+  }
+  auto put_img = [&](int chan, const float* a) {
+    unsigned t0[4], t1[4], t2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p6_split2(a[2 * i], a[2 * i + 1], t0[i], t1[i], t2[i]);
+    unsigned char* o = oimg + p6_off64(row, chan, nks_o);
+    *reinterpret_cast<uint4*>(o) = make_uint4(t0[0], t0[1], t0[2], t0[3]);
+    *reinterpret_cast<uint4*>(o + P6_CHUNK) = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+    *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+  };
+  if (oimg) { put_img(ch, dh); put_img(C + ch, dg); }
+  if (out_f) {
+    float* op = out_f + m * 2 * C + ch;
+    *reinterpret_cast<float4*>(op) = make_float4(dh[0], dh[1], dh[2], dh[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(dh[4], dh[5], dh[6], dh[7]);
+    *reinterpret_cast<float4*>(op + C) = make_float4(dg[0], dg[1], dg[2], dg[3]); *reinterpret_cast<float4*>(op + C + 4) = make_float4(dg[4], dg[5], dg[6], dg[7]);
+  }
+}
+
+static bool cw_geometry_ok(const evae_conv_desc_t* d) {
+  if (!d || d->N <= 0 || d->KH != d->KW || (d->KH & 1) == 0 || d->pad * 2 + 1 != d->KH) return false;
+  if (d->stride != 1 && d->stride != 2) return false;
+  if (d->stride == 2 && ((d->H | d->W) & 1)) return false;
+  if (d->H != d->W) return false;                                  // (square grids: the only ones the encoders have)
+  if ((long long)d->N * d->H * d->W >= (1ll << 31)) return false;
+  return true;
+}
+// forward tile shape: 0 = none, 1 = 128 pixels x 64 gated outputs (Co % 64 == 0), 2 = 256 pixels x 32 gated outputs
+static int cw_fwd_shape(const evae_conv_desc_t* d) {
+  if (!cw_geometry_ok(d) || d->C % 16 != 0 || d->Co % 32 != 0) return 0;
+  int plo, phi;
+  (void)cw_taps_fwd(d->KH, d->stride, d->pad, &plo, &phi);
+  const int OH = d->H / d->stride;
+  if (d->Co % 64 == 0 && cw_window_slots(OH, OH, plo, phi, 128) <= 320) return 1;
+  if (cw_window_slots(OH, OH, plo, phi, 256) <= 576) return 2;
+  return 0;
+}
+// data gradient (into C channels): 1 = 32-column tiles (C == 32), 2 = 64-column tiles (C % 64 == 0)
+static int cw_dgrad_shape(const evae_conv_desc_t* d) {
+  if (!cw_geometry_ok(d) || d->Co % 8 != 0) return 0;
+  const int shape = d->C == 32 ? 1 : (d->C % 64 == 0 ? 2 : 0);
+  if (!shape) return 0;
+  const int OH = d->H / d->stride;
+  for (int py = 0; py < d->stride; ++py)
+    for (int px = 0; px < d->stride; ++px) {
+      int plo, phi;
+      (void)cw_taps_dgrad(d->KH, d->stride, d->pad, py, px, &plo, &phi);
+      if (cw_window_slots(OH, OH, plo, phi, 256) > 576) return 0;
+    }
+  return shape;
+}
+// weight gradient: stride 1, 32 input channels per launch pair, 3 x 3 or 5 x 5
+static int cw_wgrad_ok(const evae_conv_desc_t* d) {
+  if (!cw_geometry_ok(d) || d->stride != 1 || d->C % 32 != 0 || d->Co % 8 != 0 || 2 * d->Co > 128) return 0;
+  if (d->KH != 3 && d->KH != 5) return 0;
+  int plo, phi;
+  (void)cw_taps_fwd(d->KH, 1, d->pad, &plo, &phi);
+  return cw_window_slots(d->H, d->W, plo, phi, 32) <= 192;
+}
+constexpr int CW_WGRAD_BLOCKS = 256;
+
+}  // namespace evae
+
+using namespace evae;
+
+extern "C" size_t evae_cw_image_bytes(long long rows, int channels) {
+  if (rows <= 0 || channels <= 0 || channels % 16 != 0) return 0;
+  return p6_image_bytes((int)rows, channels / 16);
+}
+
+extern "C" int evae_cw_supported(const evae_conv_desc_t* d, int what) {
+  if (what == 0) return cw_fwd_shape(d) != 0;
+  if (what == 1) return cw_dgrad_shape(d) != 0;
+  if (what == 2) return cw_wgrad_ok(d);
+  return 0;
+}
+
+extern "C" size_t evae_cw_workspace_bytes(const evae_conv_desc_t* d, int what) {
+  if (!d) return 256;
+  const int taps = d->KH * d->KW;
+  if (what == 0) {
+    const int bn = cw_fwd_shape(d) == 1 ? 128 : 64, tiles_n = cdiv(2 * d->Co, bn);
+    return p6_image_bytes(tiles_n * bn, (d->C / 16) * taps) + 8192;
+  }
+  if (what == 1) {
+    const int bn = d->C == 32 ? 32 : 64, tiles_n = cdiv(d->C, bn);
+    return (size_t)d->stride * d->stride * (p6_image_bytes(tiles_n * bn, (2 * d->Co / 16) * taps) + 8192);   // one filter image per parity class (upper bound)
+  }
+  return align_up((size_t)CW_WGRAD_BLOCKS * 2 * d->Co * taps * d->C * sizeof(float), 256) + align_up((size_t)CW_WGRAD_BLOCKS * 2 * d->Co * sizeof(float), 256) + 256;
+}
+
+extern "C" int evae_cw_pack_image(const float* x, int N, int H, int W, int C, int planar, void* img, evae_stream_t stream_) {
+  EVAE_REQUIRE(x && img && N > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0, "cw_pack_image: bad arguments (channels a multiple of 16)");
+  EVAE_REQUIRE(!planar || ((H | W) & 1) == 0, "cw_pack_image: parity-planar rows need even H and W");
+  const size_t rows = (size_t)N * H * W, rows16 = (rows + 15) / 16 * 16;
+  const size_t total = rows16 * (size_t)(C / 8);
+  cw_pack_image_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream_>>>(x, N, H, W, C, planar, (unsigned char*)img);
+  return check_launch("cw_pack_image_kernel");
+}
+
+extern "C" int evae_cw_gate_bwd_image(const float* v, const void* eimg, int planar, const float* s, int N, int H, int W, int C, void* oimg,
+                                      float* out_f, evae_stream_t stream_) {
+  EVAE_REQUIRE(v && eimg && s && (oimg || out_f) && N > 0 && C > 0 && C % 16 == 0, "cw_gate_bwd_image: bad arguments");
+  EVAE_REQUIRE(!planar || ((H | W) & 1) == 0, "cw_gate_bwd_image: parity-planar rows need even H and W");
+  const size_t rows = (size_t)N * H * W, rows16 = (rows + 15) / 16 * 16;
+  const size_t total = rows16 * (size_t)(C / 8);
+  cw_gate_bwd_image_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream_>>>(v, (const unsigned char*)eimg, planar, s, N, H, W, C,
+                                                                                      (unsigned char*)oimg, out_f);
+  return check_launch("cw_gate_bwd_image_kernel");
+}
+
+// Forward of a gated layer: out = (conv(x, wh) + bh) * sigmoid(conv(x, wg) + bg).  ximg: the input's pixel image (rows natural for
+// a stride-1 layer, parity-planar for a stride-2 one); oimg: the output's image (rows parity-planar when out_planar: the consumer has
+// stride 2); out_s: the gate, fp32 natural [N OH OW][Co]; out_f: fp32 copy of the output or NULL.
+extern "C" int evae_cw_fwd_gated(const void* ximg, const evae_conv_desc_t* d, const float* wh, const float* bh, const float* wg,
+                                 const float* bg, void* oimg, int out_planar, float* out_s, float* out_f, void* ws, size_t ws_bytes,
+                                 evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int shape = cw_fwd_shape(d);
+  EVAE_REQUIRE(shape != 0, "cw_fwd_gated: unsupported geometry");
+  EVAE_REQUIRE(ximg && wh && wg && (oimg || out_f) && ws, "cw_fwd_gated: null pointer");
+  EVAE_REQUIRE(ws_bytes >= evae_cw_workspace_bytes(d, 0), "cw_fwd_gated: workspace too small");
+  const int st = d->stride, OH = d->H / st, K = d->KH;
+  EVAE_REQUIRE(!out_planar || (OH & 1) == 0, "cw_fwd_gated: parity-planar output rows need an even output grid");
+  int plo, phi;
+  const CwTaps tp = cw_taps_fwd(K, st, d->pad, &plo, &phi);
+  const int ncg = d->C / 16, nks_w = cw_ksteps(tp, ncg);
+  const int bn = shape == 1 ? 128 : 64, tiles_n = cdiv(2 * d->Co, bn), wrows = (tiles_n * bn + 127) / 128 * 128;
+  unsigned char* iw = (unsigned char*)ws;
+  cw_pack_filter_kernel<<<(unsigned)(((size_t)wrows * nks_w * 2 + 255) / 256), 256, 0, stream>>>(wh, wg, d->Co, d->C, K, K, tp, ncg, 0, bn, wrows, nks_w, iw);
+  int rc = check_launch("cw_pack_filter_kernel");
+  if (rc) return rc;
+  ConvWinArgs g = {};
+  g.xin = (const unsigned char*)ximg; g.nks_in = ncg; g.ncg = ncg; g.N = d->N; g.H = OH; g.W = OH; g.plo = plo; g.phi = phi; g.taps = tp;
+  g.istride = st * st * OH * OH;
+  for (int s2 = 0; s2 < st * st; ++s2) g.ioff[s2] = s2 * OH * OH;
+  g.wimg = iw; g.nks_w = nks_w; g.Co = d->Co; g.tiles_n = tiles_n; g.bias0 = bh; g.bias1 = bg;
+  g.out_planar = out_planar;
+  g.oimg = (unsigned char*)oimg; g.nks_o = d->Co / 16; g.out_s = out_s; g.out_f = out_f; g.ldo = d->Co;
+  if (shape == 1) {
+    g.nsp = (cw_window_slots(OH, OH, plo, phi, 128) + 31) / 32;
+    return launch_conv_win<CW_FWD_GATED, 2, 2, 320>(g, stream, "cw_fwd_gated");
+  }
+  g.nsp = (cw_window_slots(OH, OH, plo, phi, 256) + 31) / 32;
+  return launch_conv_win<CW_FWD_GATED, 4, 2, 576>(g, stream, "cw_fwd_gated");
+}
+
+// Data gradient of a gated layer (C -> Co) with the gate derivative of the layer below in the epilogue.  dyimg: the merged [dh | dg]
+// image of THIS layer's output (rows planar when dy_planar); eimg / e_s: forward output (image) and gate (fp32 natural) of the
+// layer below = this layer's input, image rows planar when this layer has stride 2; result: [dh | dg] of the layer below as an
+// image in eimg's row order (oimg, 2 C channels) and / or fp32 natural [N H W][2 C] (out_f).
+extern "C" int evae_cw_bwd_data_gate(const void* dyimg, int dy_planar, const evae_conv_desc_t* d, const float* wh, const float* wg,
+                                     const void* eimg, const float* e_s, void* oimg, float* out_f, void* ws, size_t ws_bytes,
+                                     evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int shape = cw_dgrad_shape(d);
+  EVAE_REQUIRE(shape != 0, "cw_bwd_data_gate: unsupported geometry");
+  EVAE_REQUIRE(dyimg && wh && wg && eimg && e_s && (oimg || out_f) && ws, "cw_bwd_data_gate: null pointer");
+  EVAE_REQUIRE(ws_bytes >= evae_cw_workspace_bytes(d, 1), "cw_bwd_data_gate: workspace too small");
+  const int st = d->stride, OH = d->H / st, K = d->KH, C = d->C, Co = d->Co;
+  const int ncg = 2 * Co / 16, bn = shape == 1 ? 32 : 64, tiles_n = cdiv(C, bn), wrows = (tiles_n * bn + 127) / 128 * 128;
+  size_t used = 0;
+  for (int py = 0; py < st; ++py)
+    for (int px = 0; px < st; ++px) {
+      int plo, phi;
+      const CwTaps tp = cw_taps_dgrad(K, st, d->pad, py, px, &plo, &phi);
+      const int nks_w = cw_ksteps(tp, ncg);
+      ConvWinArgs g = {};
+      g.N = d->N; g.H = OH; g.W = OH; g.plo = plo; g.phi = phi; g.taps = tp;
+      g.ostride = st * st * OH * OH; g.ooff = (py * st + px) * OH * OH;
+      g.nat_h = d->H; g.nat_w = d->W; g.nat_s = st; g.nat_y = py; g.nat_x = px;
+      g.Co = C; g.tiles_n = tiles_n;
+      g.oimg = (unsigned char*)oimg; g.nks_o = 2 * C / 16; g.out_f = out_f; g.ldo = 2 * C;
+      g.eimg = (const unsigned char*)eimg; g.nks_e = C / 16; g.e_s = e_s;
+      if (nks_w == 0) {
+        // no tap reaches this class (stride larger than the filter): its gradient is zero -- not a case the encoders have
+        set_error("cw_bwd_data_gate: a parity class without taps (filter smaller than the stride)");
+        return EVAE_EINVAL;
+      }
+      unsigned char* iw = (unsigned char*)ws + used;
+      used += p6_image_bytes(wrows, nks_w) + 8192;
+      cw_pack_filter_kernel<<<(unsigned)(((size_t)wrows * nks_w * 2 + 255) / 256), 256, 0, stream>>>(wh, wg, Co, C, K, K, tp, ncg, 1, bn, wrows, nks_w, iw);
+      int rc = check_launch("cw_pack_filter_kernel");
+      if (rc) return rc;
+      g.xin = (const unsigned char*)dyimg; g.nks_in = ncg; g.ncg = ncg; g.istride = OH * OH; g.in_planar = dy_planar;
+      g.wimg = iw; g.nks_w = nks_w;
+      g.nsp = (cw_window_slots(OH, OH, plo, phi, 256) + 31) / 32;
+      if (shape == 1) rc = launch_conv_win<CW_DGRAD_GATE, 4, 1, 576>(g, stream, "cw_bwd_data_gate");
+      else rc = launch_conv_win<CW_DGRAD_GATE, 4, 2, 576>(g, stream, "cw_bwd_data_gate");
+      if (rc) return rc;
+    }
+  return EVAE_OK;
+}
+
+// Weight gradient of a stride-1 gated layer from the merged-gradient image (rows planar when dy_planar) and the input image (rows
+// natural): dw [2 Co][C][K][K] (h rows then g rows: nn.Conv2d layout), db [2 Co].
+extern "C" int evae_cw_bwd_weight(const void* dyimg, int dy_planar, const void* ximg, const evae_conv_desc_t* d, float* dw, float* db,
+                                  void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(cw_wgrad_ok(d), "cw_bwd_weight: unsupported geometry");
+  EVAE_REQUIRE(dyimg && ximg && dw && ws, "cw_bwd_weight: null pointer");
+  EVAE_REQUIRE(ws_bytes >= evae_cw_workspace_bytes(d, 2), "cw_bwd_weight: workspace too small");
+  const int K = d->KH, taps = K * K, CC = 2 * d->Co, C = d->C, H = d->H;
+  EVAE_REQUIRE(!dy_planar || (H & 1) == 0, "cw_bwd_weight: parity-planar rows need an even grid");
+  float* part = (float*)ws;
+  float* dbp = (float*)((char*)ws + align_up((size_t)CW_WGRAD_BLOCKS * CC * taps * C * sizeof(float), 256));
+  int plo, phi;
+  (void)cw_taps_fwd(K, 1, d->pad, &plo, &phi);
+  const int PW = H + plo + phi;
+  CwWgradArgs g = {};
+  g.dyimg = (const unsigned char*)dyimg; g.nks_dy = CC / 16; g.dy_planar = dy_planar;
+  g.ximg = (const unsigned char*)ximg; g.nks_x = C / 16; g.nseg = 1;
+  g.N = d->N; g.H = H; g.W = H; g.plo = plo; g.phi = phi;
+  g.ntap_f = taps; g.Cin = C; g.CC = CC; g.part = part;
+  int nblk = 0;
+  bool first = true;
+  for (int cp = 0; cp < C / 32; ++cp) {            // channel-group pairs of the input
+    g.xcg0 = 2 * cp;
+    for (int t0 = 0; t0 < taps; ) {
+      const int nt = taps == 25 ? (t0 == 0 ? 13 : 12) : 9;
+      for (int t = 0; t < nt; ++t) { const int tt = t0 + t; g.tile_seg[t] = 0; g.tile_to[t] = (tt / K) * PW + tt % K; g.tile_tap[t] = tt; }
+      g.dbpart = first ? dbp : nullptr;
+      int rc;
+      if (nt == 13) rc = launch_conv_wgrad_win<13, 192>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      else if (nt == 12) rc = launch_conv_wgrad_win<12, 192>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      else rc = launch_conv_wgrad_win<9, 192>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      if (rc) return rc;
+      nblk = cdiv(g.nchunk, g.cper);
+      first = false;
+      t0 += nt;
+    }
+  }
+  cw_wgrad_finish_kernel<<<(CC * taps * C + 255) / 256, 256, 0, stream>>>(part, dbp, nblk, CC, taps, C, dw, db);
+  return check_launch("cw_wgrad_finish_kernel");
+}

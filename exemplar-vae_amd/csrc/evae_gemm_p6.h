@@ -355,7 +355,7 @@ __device__ __forceinline__ void p6_pack_rows_element(size_t t, const float* __re
   *reinterpret_cast<uint4*>(o + P6_CHUNK) = *reinterpret_cast<const uint4*>(p1);
   *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = *reinterpret_cast<const uint4*>(p2);
 }
-__global__ __launch_bounds__(256) void p6_pack_rows_kernel(const float* __restrict__ x, const float* __restrict__ x2, int R, int K,
+static __global__ __launch_bounds__(256) void p6_pack_rows_kernel(const float* __restrict__ x, const float* __restrict__ x2, int R, int K,
                                                            long long ld, int gated, int rows_img, int nks, unsigned char* __restrict__ img) {
   p6_pack_rows_element((size_t)blockIdx.x * blockDim.x + threadIdx.x, x, x2, R, K, ld, gated, rows_img, nks, img);
 }
@@ -384,7 +384,7 @@ __device__ __forceinline__ void p6_pack_cols_element(size_t t, const float* __re
   *reinterpret_cast<uint4*>(o + P6_CHUNK) = *reinterpret_cast<const uint4*>(p1);
   *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = *reinterpret_cast<const uint4*>(p2);
 }
-__global__ __launch_bounds__(256) void p6_pack_cols_kernel(const float* __restrict__ x, const float* __restrict__ x2, int Kd, int R,
+static __global__ __launch_bounds__(256) void p6_pack_cols_kernel(const float* __restrict__ x, const float* __restrict__ x2, int Kd, int R,
                                                            long long ld, int ones_row, int rows_img, int nks, unsigned char* __restrict__ img) {
   p6_pack_cols_element((size_t)blockIdx.x * blockDim.x + threadIdx.x, x, x2, Kd, R, ld, ones_row, rows_img, nks, img);
 }

@@ -138,6 +138,14 @@ SIGNATURES = {
     "evae_conv2d_cl_res_supported": (_i, [_p]),
     "evae_conv2d_cl_fwd_res": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_conv2d_cl_bwd_data_res": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_cw_image_bytes": (_z, [C.c_longlong, _i]),
+    "evae_cw_supported": (_i, [_p, _i]),
+    "evae_cw_workspace_bytes": (_z, [_p, _i]),
+    "evae_cw_pack_image": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "evae_cw_fwd_gated": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _z, _p]),
+    "evae_cw_bwd_data_gate": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_cw_gate_bwd_image": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "evae_cw_bwd_weight": (_i, [_p, _i, _p, _p, _p, _p, _p, _z, _p]),
     "evae_reparam_logq_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_reparam_logq_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_reparam_logq_bwd_hardtanh": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p]),

@@ -1224,6 +1224,186 @@ def gated_conv2d(x, wh, bh, wg, bg, stride=1, padding=0):
 
 
 # ------------------------------------------------------------------------------------------------
+# a stack of gated convolutions on pre-split pixel images (csrc/evae_conv_win.h)
+# ------------------------------------------------------------------------------------------------
+CONV_STACK_MIN_IMAGES = int(os.environ.get("EVAE_CONV_STACK_MIN", "1024"))     # below: the layer-by-layer path (batch rows)
+CONV_STACK_ON = os.environ.get("EVAE_CONV_STACK", "1") != "0"
+
+
+def conv_stack_depth(x_shape, layers):
+    """How many leading layers of a stack of gated convolutions `layers` = [(wh, stride, pad), ...] the image pipeline takes:
+    layer 0 on the channels-last kernels (an input that is data: no gradient), layers 1 .. b - 1 on the window kernels with their
+    activations as pixel images.  0 = not worth it / not supported."""
+    lib = _lib.load()
+    N, Cc, H, W = x_shape
+    if len(layers) < 2:
+        return 0
+    b = 0
+    for i, (wh, st, pd) in enumerate(layers):
+        Co, Ci, KH, KW = wh.shape
+        if Ci != Cc:
+            break
+        d = _lib.ConvDesc(N, Cc, H, W, Co, KH, KW, int(st), int(pd))
+        if i == 0:
+            if not lib.evae_conv2d_cl_supported(C.byref(d), 0, 1) or not lib.evae_conv2d_cl_supported(C.byref(d), 2, 1) or Co % 16:
+                break
+        elif not (lib.evae_cw_supported(C.byref(d), 0) and lib.evae_cw_supported(C.byref(d), 1) and Co % 16 == 0):
+            break
+        b = i + 1
+        Cc, H, W = Co, (H + 2 * pd - KH) // st + 1, (W + 2 * pd - KW) // st + 1
+    return b if b >= 2 else 0
+
+
+class GatedConvStackFn(torch.autograd.Function):
+    """Layers 0 .. b - 1 of a stack of gated convolutions act(h(x)) * sigmoid(g(x)) (reference utils/nn.py:72-97, as
+    models/convHVAE_2level.py:21-46 chains them) with every activation between two layers as a pre-split pixel image
+    (include/evae_hip.h, evae_cw_*): a layer's epilogue writes the image the next layer's window loads read; in the backward pass a
+    layer's data gradient applies the gate derivative of the layer below in its epilogue and writes the merged [dh | dg] image
+    that layer's own gradients read -- no elementwise pass, no patch matrix, no fp32 activation except where a kernel outside
+    the family still wants one.  x is data (no gradient).  args: x, n, cfg = ((stride, pad), ...), then wh, bh, wg, bg per layer."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        lib = _lib.load()
+        b = len(cfg)
+        L = [params[4 * i:4 * i + 4] for i in range(b)]
+        _need_cuda(x, *[t for t in params if t is not None])
+        x = _cl(x.float())
+        dev = x.device
+        need_grad = any(ctx.needs_input_grad[2:])
+        N = x.shape[0]
+        ds, shp = [], []
+        Cc, H, W = x.shape[1], x.shape[2], x.shape[3]
+        for i in range(b):
+            Co, Ci, KH, KW = L[i][0].shape
+            st, pd = cfg[i]
+            ds.append(_lib.ConvDesc(N, Cc, H, W, Co, KH, KW, int(st), int(pd)))
+            Cc, H, W = Co, (H + 2 * pd - KH) // st + 1, (W + 2 * pd - KW) // st + 1
+            shp.append((Co, H, W))
+        wg_cw = [i >= 1 and bool(lib.evae_cw_supported(C.byref(ds[i]), 2)) for i in range(b)]     # weight gradient on the window kernels
+        planar = [i + 1 < b and cfg[i + 1][0] == 2 for i in range(b)]                                # row order of layer i's output image
+        fmt = dict(device=dev, memory_format=CL)
+
+        def image(rows, ch):
+            return torch.empty(int(lib.evae_cw_image_bytes(rows, ch)), dtype=torch.uint8, device=dev)
+
+        # layer 0: channels-last kernels on the data, then its output as an image
+        d0 = ds[0]
+        Co0, H0, W0 = shp[0]
+        out0 = torch.empty((N, Co0, H0, W0), **fmt)
+        s0 = torch.empty((N, Co0, H0, W0), **fmt)
+        wh0, bh0, wg0, bg0 = L[0]
+        ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d0), 0, 1), dev)
+        _lib.check(lib.evae_conv2d_cl_fwd(_p(x), C.byref(d0), _p(_f32(wh0)), _p(bh0), _p(_f32(wg0)), _p(bg0), ACT_NONE, 0.0, 0.0,
+                                          _p(out0), None, _p(s0), _p(ws), ws.numel(), _stream()), "evae_conv2d_cl_fwd")
+        imgs = [image(N * H0 * W0, Co0)]
+        _lib.check(lib.evae_cw_pack_image(_p(out0), N, H0, W0, Co0, int(planar[0]), _p(imgs[0]), _stream()), "evae_cw_pack_image")
+        outf = [out0 if (need_grad and not wg_cw[1]) else None]         # fp32 copies: the input of a layer whose weight gradient runs outside the family
+        gates = [s0 if need_grad else None]
+        for i in range(1, b):
+            Co, Hh, Ww = shp[i]
+            wh, bh, wg, bg = L[i]
+            oimg = image(N * Hh * Ww, Co)
+            last = i == b - 1
+            s = torch.empty((N, Co, Hh, Ww), **fmt) if need_grad else None
+            of = torch.empty((N, Co, Hh, Ww), **fmt) if (last or (need_grad and not wg_cw[i + 1])) else None
+            ws = _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(ds[i]), 0), dev)
+            _lib.check(lib.evae_cw_fwd_gated(_p(imgs[i - 1]), C.byref(ds[i]), _p(_f32(wh)), _p(bh), _p(_f32(wg)), _p(bg), _p(oimg), int(planar[i]),
+                                             _p(s), _p(of), _p(ws), ws.numel(), _stream()), "evae_cw_fwd_gated")
+            imgs.append(oimg); gates.append(s); outf.append(of)
+            if not need_grad:
+                imgs[i - 1] = None
+        out = outf[b - 1]
+        if need_grad:
+            ctx.save_for_backward(x, *[t for t in params if t is not None])
+            ctx.keep = (imgs, gates, outf[:b - 1], ds, shp, planar, wg_cw, [[t is not None for t in L[i]] for i in range(b)])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        imgs, gates, outf, ds, shp, planar, wg_cw, has = ctx.keep
+        saved = list(ctx.saved_tensors)
+        x = saved.pop(0)
+        b = len(ds)
+        L = []
+        for i in range(b):
+            L.append([saved.pop(0) if h else None for h in has[i]])
+        dev = dout.device
+        N = x.shape[0]
+        dout = _cl(dout.float())
+        grads = [None] * (4 * b)
+
+        def image(rows, ch):
+            return torch.empty(int(lib.evae_cw_image_bytes(rows, ch)), dtype=torch.uint8, device=dev)
+
+        def put(i, dw, db):
+            Co = shp[i][0]
+            wshape = L[i][0].shape
+            grads[4 * i] = dw[:Co].reshape(wshape)
+            grads[4 * i + 2] = dw[Co:].reshape(wshape)
+            if has[i][1]:
+                grads[4 * i + 1] = db[:Co]
+            if has[i][3]:
+                grads[4 * i + 3] = db[Co:]
+
+        # exit of the stack: gate derivative of the last layer from the fp32 upstream gradient
+        Co, Hh, Ww = shp[b - 1]
+        dyimg = image(N * Hh * Ww, 2 * Co)
+        dyf = torch.empty((N, 2 * Co, Hh, Ww), device=dev, memory_format=CL) if not wg_cw[b - 1] else None
+        _lib.check(lib.evae_cw_gate_bwd_image(_p(dout), _p(imgs[b - 1]), 0, _p(gates[b - 1]), N, Hh, Ww, Co, _p(dyimg), _p(dyf), _stream()),
+                   "evae_cw_gate_bwd_image")
+        imgs[b - 1] = None; gates[b - 1] = None
+        for i in range(b - 1, 0, -1):
+            d = ds[i]
+            Co = shp[i][0]
+            K = d.C * d.KH * d.KW
+            dw = torch.empty((2 * Co, K), device=dev); db = torch.empty(2 * Co, device=dev)
+            if wg_cw[i]:
+                ws = _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(d), 2), dev)
+                _lib.check(lib.evae_cw_bwd_weight(_p(dyimg), int(planar[i]), _p(imgs[i - 1]), C.byref(d), _p(dw), _p(db), _p(ws), ws.numel(),
+                                                  _stream()), "evae_cw_bwd_weight")
+            else:
+                ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d), 2, 1), dev)
+                _lib.check(lib.evae_conv2d_cl_bwd_weight(_p(dyf), _p(outf[i - 1]), C.byref(d), 1, _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
+                           "evae_conv2d_cl_bwd_weight")
+            put(i, dw, db)
+            # data gradient + gate derivative of layer i - 1
+            Cp, Hp, Wp = shp[i - 1]
+            want_img = i - 1 >= 1
+            want_f = (i - 1 == 0) or not wg_cw[i - 1]
+            nimg = image(N * Hp * Wp, 2 * Cp) if want_img else None
+            nf = torch.empty((N, 2 * Cp, Hp, Wp), device=dev, memory_format=CL) if want_f else None
+            ws = _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(d), 1), dev)
+            _lib.check(lib.evae_cw_bwd_data_gate(_p(dyimg), int(planar[i]), C.byref(d), _p(_f32(L[i][0])), _p(_f32(L[i][2])), _p(imgs[i - 1]),
+                                                 _p(gates[i - 1]), _p(nimg), _p(nf), _p(ws), ws.numel(), _stream()), "evae_cw_bwd_data_gate")
+            imgs[i - 1] = None; gates[i - 1] = None
+            if i - 1 < len(outf):
+                pass
+            dyimg, dyf = nimg, nf
+        # layer 0: weight gradient on the channels-last kernels from the merged fp32 gradient
+        d0 = ds[0]
+        Co0 = shp[0][0]
+        K0 = d0.C * d0.KH * d0.KW
+        dw = torch.empty((2 * Co0, K0), device=dev); db = torch.empty(2 * Co0, device=dev)
+        ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d0), 2, 1), dev)
+        _lib.check(lib.evae_conv2d_cl_bwd_weight(_p(dyf), _p(x), C.byref(d0), 1, _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
+                   "evae_conv2d_cl_bwd_weight")
+        put(0, dw, db)
+        ctx.keep = None
+        return (None, None) + tuple(grads)
+
+
+def gated_conv_stack(x, layers):
+    """layers = [(wh, bh, wg, bg, stride, pad), ...] -> output of the last one (logical NCHW, channels-last storage)"""
+    cfg = tuple((_int1(l[4]), _int1(l[5])) for l in layers)
+    flat = []
+    for l in layers:
+        flat += [l[0], l[1], l[2], l[3]]
+    return GatedConvStackFn.apply(x, cfg, *flat)
+
+
+# ------------------------------------------------------------------------------------------------
 # latent sampling / log-densities
 # ------------------------------------------------------------------------------------------------
 class ReparamLogQ(torch.autograd.Function):

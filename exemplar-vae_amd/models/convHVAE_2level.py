@@ -6,7 +6,7 @@ import numpy as np
 import torch.nn as nn
 
 from models.AbsHModel import BaseHModel
-from utils.nn import Conv2d, GatedConv2d, GatedDense, NonLinear
+from utils.nn import Conv2d, GatedConv2d, GatedConvStack, GatedDense, NonLinear
 
 # flattened size of the 6-channel feature map the two conv encoders end in, per dataset family
 _ENCODER_FEATURES = {'freyfaces': 210, 'cifar10': 384, 'svhn': 384}
@@ -32,7 +32,7 @@ class VAE(BaseHModel):
         for c_out, k, s, p in table:
             layers.append(GatedConv2d(c_in, c_out, k, s, p, no_attention=self.args.no_attention))
             c_in = c_out
-        return nn.Sequential(*layers)
+        return GatedConvStack(*layers)
 
     def _dense_stack(self, *widths, plain=False):
         kw = {} if plain else {'no_attention': self.args.no_attention}

@@ -127,6 +127,26 @@ class GatedConv2d(nn.Module):
         return h * ops.conv2d(x, self.g.weight, self.g.bias, self.g.stride, self.g.padding, ops.ACT_SIGMOID)
 
 
+class GatedConvStack(nn.Sequential):
+    """nn.Sequential of GatedConv2d layers (same children, same state_dict keys) whose leading layers run as ONE operator over
+    pre-split pixel images when the batch is large (evae.ops.GatedConvStackFn: the exemplar rows of a training step, cache_z);
+    small batches and anything the image kernels do not take go layer by layer as before."""
+
+    def forward(self, x):
+        mods = list(self)
+        if (ops.CONV_STACK_ON and x.is_cuda and x.dim() == 4 and x.shape[0] >= ops.CONV_STACK_MIN_IMAGES and not x.requires_grad
+                and all(isinstance(m, GatedConv2d) and m.no_attention is False and m.activation is None and m.h.dilation == (1, 1)
+                        and m.h.groups == 1 for m in mods)):
+            spec = [(m.h.weight, ops._int1(m.h.stride), ops._int1(m.h.padding)) for m in mods]
+            b = ops.conv_stack_depth(tuple(x.shape), spec)
+            if b:
+                h = ops.gated_conv_stack(x, [(m.h.weight, m.h.bias, m.g.weight, m.g.bias, m.h.stride, m.h.padding) for m in mods[:b]])
+                for m in mods[b:]:
+                    h = m(h)
+                return h
+        return super().forward(x)
+
+
 class Conv2d(nn.Module):
     def __init__(self, input_channels, output_channels, kernel_size, stride, padding, dilation=1,
                  activation=None, bias=True):

@@ -420,6 +420,40 @@ int evae_conv2d_cl_fwd_res(const float* a, const evae_conv_desc_t* d, const floa
 int evae_conv2d_cl_bwd_data_res(const float* dy, const float* w, const evae_conv_desc_t* d, const float* residual,
                                 const float* elu_out, float* dx, void* ws, size_t ws_bytes, evae_stream_t stream);
 
+/* Window convolutions over pre-split pixel images (csrc/evae_conv_win.h): the gated layers BETWEEN two layers of a convolutional
+ * encoder stack (reference utils/nn.py:72-97, models/convHVAE_2level.py:21-46), whose activations then never exist as fp32
+ * tensors.  A "pixel image" holds an activation [pixels x channels] (channels % 16 == 0) as three bf16 planes per 16 pixels x 16
+ * channels (6 bytes per element, evae_cw_image_bytes): the exact three-term split of every fp32 value, written by the producing
+ * layer's epilogue, read by the next layer's forward, by the data gradient (the merged [dh | dg] image) and by the weight gradient.
+ * Row order of an image: natural (n, y, x), or PARITY-PLANAR -- the four stride-2 parity classes of an image as four sub-images
+ * -- when the tensor's consumer has stride 2.  fp32 side tensors (gates, optional copies) are always natural channels-last.
+ * The forward contraction keeps the window of input pixels of a block's taps resident in LDS (one copy per channel group, not per
+ * tap); arithmetic: six bf16 partial products per fp32 product, fp32 accumulate (the fp32 bar, as evae_gated_dense_fwd's x6 path).
+ *   evae_cw_supported(d, what): what = 0 forward (C % 16 == 0, Co % 32 == 0, odd square filter with pad = (K - 1) / 2, stride 1 | 2,
+ *     square even grid), 1 data gradient (C == 32 or C % 64 == 0), 2 weight gradient (stride 1, C % 32 == 0, 3 x 3 | 5 x 5, 2 Co <= 128).
+ *   evae_cw_pack_image: fp32 channels-last [N][H][W][C] -> image (rows natural | planar) -- the entry of a stack.
+ *   evae_cw_fwd_gated: out = (conv(x, wh) + bh) * sigmoid(conv(x, wg) + bg); x image rows natural (stride 1) | planar (stride 2);
+ *     oimg (rows planar when out_planar), out_s = the gate fp32 [N OH OW][Co], out_f = optional fp32 copy of out.
+ *   evae_cw_bwd_data_gate: v = conv_transpose([dh | dg], [wh | wg]) and, in the epilogue, the gate derivative of the layer BELOW
+ *     (its output image eimg -- rows planar when d->stride == 2 -- and gate e_s): [dh' | dg'] = [v s' | v out' (1 - s')] as an image
+ *     in eimg's row order (oimg, 2 C channels) and / or fp32 natural [N H W][2 C] (out_f).
+ *   evae_cw_gate_bwd_image: the same gate derivative for an upstream gradient v that is an fp32 tensor (exit of a stack).
+ *   evae_cw_bwd_weight: dw [2 Co][C][K][K], db [2 Co] from the merged-gradient image and the input image (contraction over pixels
+ *     through the LDS transpose read; partial planes per block, added in block order: deterministic). */
+size_t evae_cw_image_bytes(long long rows, int channels);
+int evae_cw_supported(const evae_conv_desc_t* d, int what);
+size_t evae_cw_workspace_bytes(const evae_conv_desc_t* d, int what);
+int evae_cw_pack_image(const float* x, int N, int H, int W, int C, int planar, void* img, evae_stream_t stream);
+int evae_cw_fwd_gated(const void* ximg, const evae_conv_desc_t* d, const float* wh, const float* bh, const float* wg, const float* bg,
+                      void* oimg, int out_planar, float* out_s, float* out_f, void* ws, size_t ws_bytes, evae_stream_t stream);
+int evae_cw_bwd_data_gate(const void* dyimg, int dy_planar, const evae_conv_desc_t* d, const float* wh, const float* wg,
+                          const void* eimg, const float* e_s, void* oimg, float* out_f, void* ws, size_t ws_bytes,
+                          evae_stream_t stream);
+int evae_cw_gate_bwd_image(const float* v, const void* eimg, int planar, const float* s, int N, int H, int W, int C, void* oimg,
+                           float* out_f, evae_stream_t stream);
+int evae_cw_bwd_weight(const void* dyimg, int dy_planar, const void* ximg, const evae_conv_desc_t* d, float* dw, float* db,
+                       void* ws, size_t ws_bytes, evae_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Latent sampling and log-densities on [B x zdim] / [B x D] rows.
  * evae_reparam_logq: z = mu + eps*exp(logvar/2) (models/BaseModel.py:79-82, eps supplied by the

@@ -248,3 +248,78 @@ def test_conv_modules_match_reference_golden(golden, i, gemm_pipe):
         assert abs(np.linalg.norm(arr.astype(np.float64)) - float(g["c%d_%s_norm" % (i, key)])) <= tol * float(g["c%d_%s_norm" % (i, key)])
     for name, prm in m.named_parameters():
         assert rel(prm.grad.cpu().numpy(), g["c%d_d_%s" % (i, name)]) < 1e-4, name
+
+
+# ---- the gated-convolution stack over pre-split pixel images (csrc/evae_conv_win.h, evae.ops.GatedConvStackFn) ----------------
+_WIDE = ((32, 7, 1, 3), (32, 3, 2, 1), (64, 5, 1, 2), (64, 3, 2, 1), (6, 3, 1, 1))       # q(z2 | x) of models/convHVAE_2level.py
+_NARROW = ((32, 3, 1, 1), (32, 3, 2, 1), (64, 3, 1, 1), (64, 3, 2, 1), (6, 3, 1, 1))     # x-branch of q(z1 | x, z2)
+
+
+def _stack(table, seed):
+    from utils.nn import GatedConv2d, GatedConvStack
+    torch.manual_seed(seed)
+    layers, c = [], 1
+    for co, k, s, p in table:
+        layers.append(GatedConv2d(c, co, k, s, p))
+        c = co
+    net = GatedConvStack(*layers)
+    for prm in net.parameters():                     # lively gates and biases
+        with torch.no_grad():
+            prm.mul_(1.5).add_(0.02 * torch.randn_like(prm))
+    return net
+
+
+@pytest.mark.parametrize("table,N", [(_WIDE, 37), (_WIDE, 130), (_NARROW, 37)])
+def test_gated_conv_stack_on_pixel_images_matches_float64(table, N):
+    """Forward output and every parameter gradient of the image pipeline (layer 0 on the channels-last kernels, layers 1-3 on the
+    window kernels: stride 1 and 2, 3 x 3 and 5 x 5, parity-planar and natural image rows, the gate derivative in the data gradients'
+    epilogues, the weight gradient over pixel images where it applies) against torch float64 on the CPU (reference
+    utils/nn.py:72-97 chained as models/convHVAE_2level.py:21-46), and against the layer-by-layer HIP path."""
+    from evae import ops
+    net = _stack(table, 3)
+    rs = np.random.RandomState(N)
+    x = torch.from_numpy((rs.rand(N, 1, 28, 28) < 0.3).astype(np.float32))
+    ref = _stack(table, 3).double()
+    ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    h = x.double()
+    for m in ref:
+        h = F.conv2d(h, m.h.weight, m.h.bias, m.h.stride, m.h.padding) * torch.sigmoid(F.conv2d(h, m.g.weight, m.g.bias, m.g.stride, m.g.padding))
+    gout = torch.from_numpy(rs.standard_normal(tuple(h.shape)).astype(np.float32))
+    h.backward(gout.double())
+    net = net.cuda()
+    spec = [(m.h.weight, 1 if m.h.stride == (1, 1) else 2, m.h.padding[0]) for m in net]
+    assert ops.conv_stack_depth((N, 1, 28, 28), spec) == 4, "layers 0-3 run on the image pipeline, the 6-channel layer outside"
+    old_min = ops.CONV_STACK_MIN_IMAGES
+    outs, grads = [], []
+    try:
+        for stack_on in (True, False):
+            ops.CONV_STACK_MIN_IMAGES = 1 if stack_on else 1 << 30
+            net.zero_grad(set_to_none=True)
+            y = net(x.cuda())
+            y.backward(gout.cuda())
+            torch.cuda.synchronize()
+            outs.append(y.detach()); grads.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    finally:
+        ops.CONV_STACK_MIN_IMAGES = old_min
+    assert rel(outs[0], h) < 2e-5 and rel(outs[1], h) < 2e-5
+    refg = dict(ref.named_parameters())
+    for k in grads[0]:
+        assert torch.isfinite(grads[0][k]).all(), k
+        assert rel(grads[0][k], refg[k].grad) < 3e-5, (k, rel(grads[0][k], refg[k].grad), rel(grads[1][k], refg[k].grad))
+
+
+def test_gated_conv_stack_without_gradients():
+    """cache_z / evaluation: the stack under no_grad (no gates, no fp32 copies kept) equals the layer-by-layer path"""
+    from evae import ops
+    net = _stack(_WIDE, 5).cuda()
+    x = (torch.rand(64, 1, 28, 28, device="cuda") < 0.3).float()
+    old_min = ops.CONV_STACK_MIN_IMAGES
+    try:
+        with torch.no_grad():
+            ops.CONV_STACK_MIN_IMAGES = 1
+            a = net(x)
+            ops.CONV_STACK_MIN_IMAGES = 1 << 30
+            b = net(x)
+    finally:
+        ops.CONV_STACK_MIN_IMAGES = old_min
+    assert rel(a, b) < 1e-5
