@@ -853,6 +853,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (ks == 0 && jg < 3 && more) issue_unit(c + 1, buf ^ 1, jg);
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (ks == 0 && more) {                       // fewer than three groups (few column tiles): the remaining units
+#pragma unroll
+          for (int u = NGRP; u < 3; ++u) issue_unit(c + 1, buf ^ 1, u);
+        }
       }
     }
   }
