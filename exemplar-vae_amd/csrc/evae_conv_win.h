@@ -228,6 +228,130 @@ static int cw_window_slots(int H, int W, int plo, int phi, int R) {
 
 enum { CW_FWD_GATED = 0, CW_DGRAD_GATE = 1, CW_PLAIN = 2 };
 
+// The epilogue of a block tile (R pixels x BN columns; acc in the matrix core's C layout, 4 waves as WR x WC, wave tile 64 x 32 NT),
+// shared by the window kernels and the first-layer kernel; every wave of the block must have left its main loop (the staging
+// reuses the loop's LDS).
+template <int EPI, int R, int BN, int NT, int WC>
+__device__ __forceinline__ void cw_epilogue(const ConvWinArgs& g, f32x16 (&acc)[2][NT], const int m0, const int tn, const int wr, const int wc,
+                                            const int lane, const int tid, float* const smem) {
+  constexpr int MT = 2;
+  constexpr bool GATED = EPI == CW_FWD_GATED;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int HW = g.H * g.W;
+  // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+  // The result leaves pixel-major: a lane of the matrix core's C layout owns one column (channel) and sixteen rows of a 32 x 32 tile,
+  // the images want the channels of a pixel side by side -> through LDS as [row][BNO channels] fp32 (row pitch BNO + 4 floats), then
+  // 16-byte accesses per (row, 8 channels) piece.
+  constexpr int BNO = GATED ? BN / 2 : BN;      // result columns of the block
+  constexpr int RP = BNO + 4;
+  float* const so = smem;                       // [R][RP]
+  float* const ss = smem + R * RP;              // [R][RP]   (gated: the gate)
+  if constexpr (GATED) {
+    const int cl = wc * 32 + l31, c = tn * BNO + cl;
+    const bool cok = c < g.Co;
+    const float bh = (g.bias0 && cok) ? g.bias0[c] : 0.f, bg = (g.bias1 && cok) ? g.bias1[c] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float h = acc[mt][0][r] + bh;
+        const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc[mt][1][r] + bg)));
+        so[row * RP + cl] = cok ? h * s : 0.f;
+        ss[row * RP + cl] = s;
+      }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int cl = wc * 32 * NT + nt * 32 + l31, c = tn * BNO + cl;
+      const float b = (EPI == CW_PLAIN && g.bias0 && c < g.Co) ? g.bias0[c] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          so[row * RP + cl] = acc[mt][nt][r] + b;
+        }
+    }
+  }
+  __syncthreads();
+  // pieces (row, 8 channels): thread -> row fastest inside 16 (the 16 pixels of an image chunk), then the 8-channel group, then the
+  // 16-row groups: the 32 lanes of a (chunk, channel group) pair fill whole 512-byte chunks of the image
+  constexpr int C8 = BNO / 8, NPC = R * C8 / 256;
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int pid = tid + 256 * i;
+    const int r16 = pid & 15, c8 = (pid >> 4) % C8, rg = pid / (16 * C8);
+    const int row = rg * 16 + r16, mm = m0 + row;
+    const int ch = tn * BNO + c8 * 8;                         // first of the eight result columns
+    if (mm >= g.M || ch >= g.Co) continue;
+    // rows of pixel mm = (n, y, x): m in the pixel images, mn in the fp32 tensors
+    size_t m, mn;
+    {
+      const unsigned n = fdiv((unsigned)mm, g.div_hw), rem = (unsigned)mm - n * (unsigned)HW;
+      const unsigned y = fdiv(rem, g.div_w), x = rem - y * (unsigned)g.W;
+      m = g.out_planar ? (size_t)n * HW + cw_planar((int)y, (int)x, g.H, g.W) : (size_t)n * g.ostride + g.ooff + rem;
+      mn = ((size_t)n * g.nat_h + y * g.nat_s + g.nat_y) * g.nat_w + x * g.nat_s + g.nat_x;
+    }
+    const float4 o0 = *reinterpret_cast<const float4*>(so + row * RP + c8 * 8), o1 = *reinterpret_cast<const float4*>(so + row * RP + c8 * 8 + 4);
+    auto put_img = [&](int chan, const float4& a, const float4& b) {
+      unsigned t0[4], t1[4], t2[4];
+      p6_split2(a.x, a.y, t0[0], t1[0], t2[0]); p6_split2(a.z, a.w, t0[1], t1[1], t2[1]);
+      p6_split2(b.x, b.y, t0[2], t1[2], t2[2]); p6_split2(b.z, b.w, t0[3], t1[3], t2[3]);
+      unsigned char* o = g.oimg + p6_off64(m, chan, g.nks_o);
+      *reinterpret_cast<uint4*>(o) = make_uint4(t0[0], t0[1], t0[2], t0[3]);
+      *reinterpret_cast<uint4*>(o + P6_CHUNK) = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+      *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+    };
+    if constexpr (GATED) {
+      const float4 s0 = *reinterpret_cast<const float4*>(ss + row * RP + c8 * 8), s1 = *reinterpret_cast<const float4*>(ss + row * RP + c8 * 8 + 4);
+      if (g.oimg) put_img(g.och0 + ch, o0, o1);
+      if (g.out_s) {
+        float* sp = g.out_s + mn * g.Co + ch;
+        *reinterpret_cast<float4*>(sp) = s0; *reinterpret_cast<float4*>(sp + 4) = s1;
+      }
+      if (g.out_f) {
+        float* op = g.out_f + mn * g.ldo + ch;
+        *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
+      }
+    } else if constexpr (EPI == CW_PLAIN) {
+      if (g.oimg) put_img(g.och0 + ch, o0, o1);
+      if (g.out_f) {
+        float* op = g.out_f + mn * g.ldo + ch;
+        *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
+      }
+    } else {
+      // gate derivative of the layer below at (pixel m, channels ch .. ch + 7): out = the sum of its image's three terms (exact), s
+      // fp32; dh = v s, dg = v out (1 - s)   (reference utils/nn.py:92-97 under autograd)
+      const unsigned char* e = g.eimg + p6_off64(m, g.ech0 + ch, g.nks_e);
+      const uint4 e0 = *reinterpret_cast<const uint4*>(e), e1 = *reinterpret_cast<const uint4*>(e + P6_CHUNK), e2 = *reinterpret_cast<const uint4*>(e + 2 * P6_CHUNK);
+      const float* sp = g.e_s + mn * g.Co + ch;
+      const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+      const unsigned w0[4] = {e0.x, e0.y, e0.z, e0.w}, w1[4] = {e1.x, e1.y, e1.z, e1.w}, w2[4] = {e2.x, e2.y, e2.z, e2.w};
+      const float v[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      float dh[8], dg[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int sh = 16 * (k & 1);
+        // smallest terms first: the sum of the three bf16 terms reproduces the fp32 value they were split from
+        const float ov = (__uint_as_float(((w2[k >> 1] >> sh) & 0xFFFFu) << 16) + __uint_as_float(((w1[k >> 1] >> sh) & 0xFFFFu) << 16)) +
+                         __uint_as_float(((w0[k >> 1] >> sh) & 0xFFFFu) << 16);
+        dh[k] = v[k] * sv[k];
+        dg[k] = v[k] * ov * (1.0f - sv[k]);
+      }
+      if (g.oimg) {
+        put_img(g.och0 + ch, make_float4(dh[0], dh[1], dh[2], dh[3]), make_float4(dh[4], dh[5], dh[6], dh[7]));
+        put_img(g.och0 + g.Co + ch, make_float4(dg[0], dg[1], dg[2], dg[3]), make_float4(dg[4], dg[5], dg[6], dg[7]));
+      }
+      if (g.out_f) {
+        float* op = g.out_f + mn * g.ldo + ch;
+        *reinterpret_cast<float4*>(op) = make_float4(dh[0], dh[1], dh[2], dh[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(dh[4], dh[5], dh[6], dh[7]);
+        *reinterpret_cast<float4*>(op + g.Co) = make_float4(dg[0], dg[1], dg[2], dg[3]); *reinterpret_cast<float4*>(op + g.Co + 4) = make_float4(dg[4], dg[5], dg[6], dg[7]);
+      }
+    }
+  }
+}
+
 // EPI: CW_FWD_GATED: [h | g] column pairs (BN / 2 gated outputs per column tile), result -> pixel image + gate (+ fp32 copy);
 //      CW_PLAIN: BN plain columns, fp32 result (+ bias) and / or its pixel image;
 //      CW_DGRAD_GATE: BN plain columns = the channels of the layer below, gate derivative of that layer in the epilogue,
@@ -480,118 +604,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __syncthreads();                 // the epilogue stages through the window's LDS
   if (g.dbg == 4) return;
 
-  // ---- epilogue ---------------------------------------------------------------------------------------------------------------
-  // The result leaves pixel-major: a lane of the matrix core's C layout owns one column (channel) and sixteen rows of a 32 x 32 tile,
-  // the images want the channels of a pixel side by side -> through LDS as [row][BNO channels] fp32 (row pitch BNO + 4 floats), then
-  // 16-byte accesses per (row, 8 channels) piece.
-  constexpr int BNO = GATED ? BN / 2 : BN;      // result columns of the block
-  constexpr int RP = BNO + 4;
-  float* const so = smem;                       // [R][RP]
-  float* const ss = smem + R * RP;              // [R][RP]   (gated: the gate)
-  if constexpr (GATED) {
-    const int cl = wc * 32 + l31, c = tn * BNO + cl;
-    const bool cok = c < g.Co;
-    const float bh = (g.bias0 && cok) ? g.bias0[c] : 0.f, bg = (g.bias1 && cok) ? g.bias1[c] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float h = acc[mt][0][r] + bh;
-        const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc[mt][1][r] + bg)));
-        so[row * RP + cl] = cok ? h * s : 0.f;
-        ss[row * RP + cl] = s;
-      }
-  } else {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int cl = wc * 32 * NT + nt * 32 + l31, c = tn * BNO + cl;
-      const float b = (EPI == CW_PLAIN && g.bias0 && c < g.Co) ? g.bias0[c] : 0.f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          so[row * RP + cl] = acc[mt][nt][r] + b;
-        }
-    }
-  }
-  __syncthreads();
-  // pieces (row, 8 channels): thread -> row fastest inside 16 (the 16 pixels of an image chunk), then the 8-channel group, then the
-  // 16-row groups: the 32 lanes of a (chunk, channel group) pair fill whole 512-byte chunks of the image
-  constexpr int C8 = BNO / 8, NPC = R * C8 / 256;
-#pragma unroll
-  for (int i = 0; i < NPC; ++i) {
-    const int pid = tid + 256 * i;
-    const int r16 = pid & 15, c8 = (pid >> 4) % C8, rg = pid / (16 * C8);
-    const int row = rg * 16 + r16, mm = m0 + row;
-    const int ch = tn * BNO + c8 * 8;                         // first of the eight result columns
-    if (mm >= g.M || ch >= g.Co) continue;
-    // rows of pixel mm = (n, y, x): m in the pixel images, mn in the fp32 tensors
-    size_t m, mn;
-    {
-      const unsigned n = fdiv((unsigned)mm, g.div_hw), rem = (unsigned)mm - n * (unsigned)HW;
-      const unsigned y = fdiv(rem, g.div_w), x = rem - y * (unsigned)g.W;
-      m = g.out_planar ? (size_t)n * HW + cw_planar((int)y, (int)x, g.H, g.W) : (size_t)n * g.ostride + g.ooff + rem;
-      mn = ((size_t)n * g.nat_h + y * g.nat_s + g.nat_y) * g.nat_w + x * g.nat_s + g.nat_x;
-    }
-    const float4 o0 = *reinterpret_cast<const float4*>(so + row * RP + c8 * 8), o1 = *reinterpret_cast<const float4*>(so + row * RP + c8 * 8 + 4);
-    auto put_img = [&](int chan, const float4& a, const float4& b) {
-      unsigned t0[4], t1[4], t2[4];
-      p6_split2(a.x, a.y, t0[0], t1[0], t2[0]); p6_split2(a.z, a.w, t0[1], t1[1], t2[1]);
-      p6_split2(b.x, b.y, t0[2], t1[2], t2[2]); p6_split2(b.z, b.w, t0[3], t1[3], t2[3]);
-      unsigned char* o = g.oimg + p6_off64(m, chan, g.nks_o);
-      *reinterpret_cast<uint4*>(o) = make_uint4(t0[0], t0[1], t0[2], t0[3]);
-      *reinterpret_cast<uint4*>(o + P6_CHUNK) = make_uint4(t1[0], t1[1], t1[2], t1[3]);
-      *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = make_uint4(t2[0], t2[1], t2[2], t2[3]);
-    };
-    if constexpr (GATED) {
-      const float4 s0 = *reinterpret_cast<const float4*>(ss + row * RP + c8 * 8), s1 = *reinterpret_cast<const float4*>(ss + row * RP + c8 * 8 + 4);
-      if (g.oimg) put_img(g.och0 + ch, o0, o1);
-      if (g.out_s) {
-        float* sp = g.out_s + mn * g.Co + ch;
-        *reinterpret_cast<float4*>(sp) = s0; *reinterpret_cast<float4*>(sp + 4) = s1;
-      }
-      if (g.out_f) {
-        float* op = g.out_f + mn * g.ldo + ch;
-        *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
-      }
-    } else if constexpr (EPI == CW_PLAIN) {
-      if (g.oimg) put_img(g.och0 + ch, o0, o1);
-      if (g.out_f) {
-        float* op = g.out_f + mn * g.ldo + ch;
-        *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
-      }
-    } else {
-      // gate derivative of the layer below at (pixel m, channels ch .. ch + 7): out = the sum of its image's three terms (exact), s
-      // fp32; dh = v s, dg = v out (1 - s)   (reference utils/nn.py:92-97 under autograd)
-      const unsigned char* e = g.eimg + p6_off64(m, g.ech0 + ch, g.nks_e);
-      const uint4 e0 = *reinterpret_cast<const uint4*>(e), e1 = *reinterpret_cast<const uint4*>(e + P6_CHUNK), e2 = *reinterpret_cast<const uint4*>(e + 2 * P6_CHUNK);
-      const float* sp = g.e_s + mn * g.Co + ch;
-      const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
-      const unsigned w0[4] = {e0.x, e0.y, e0.z, e0.w}, w1[4] = {e1.x, e1.y, e1.z, e1.w}, w2[4] = {e2.x, e2.y, e2.z, e2.w};
-      const float v[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-      float dh[8], dg[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int sh = 16 * (k & 1);
-        // smallest terms first: the sum of the three bf16 terms reproduces the fp32 value they were split from
-        const float ov = (__uint_as_float(((w2[k >> 1] >> sh) & 0xFFFFu) << 16) + __uint_as_float(((w1[k >> 1] >> sh) & 0xFFFFu) << 16)) +
-                         __uint_as_float(((w0[k >> 1] >> sh) & 0xFFFFu) << 16);
-        dh[k] = v[k] * sv[k];
-        dg[k] = v[k] * ov * (1.0f - sv[k]);
-      }
-      if (g.oimg) {
-        put_img(g.och0 + ch, make_float4(dh[0], dh[1], dh[2], dh[3]), make_float4(dh[4], dh[5], dh[6], dh[7]));
-        put_img(g.och0 + g.Co + ch, make_float4(dg[0], dg[1], dg[2], dg[3]), make_float4(dg[4], dg[5], dg[6], dg[7]));
-      }
-      if (g.out_f) {
-        float* op = g.out_f + mn * g.ldo + ch;
-        *reinterpret_cast<float4*>(op) = make_float4(dh[0], dh[1], dh[2], dh[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(dh[4], dh[5], dh[6], dh[7]);
-        *reinterpret_cast<float4*>(op + g.Co) = make_float4(dg[0], dg[1], dg[2], dg[3]); *reinterpret_cast<float4*>(op + g.Co + 4) = make_float4(dg[4], dg[5], dg[6], dg[7]);
-      }
-    }
-  }
+  cw_epilogue<EPI, R, BN, NT, WC>(g, acc, m0, tn, wr, wc, lane, tid, smem);
 }
 
 template <int EPI, int WR, int NT, int SLOTS>
@@ -614,6 +627,253 @@ static int launch_conv_win(ConvWinArgs& g, hipStream_t stream, const char* what)
   return check_launch(what);
 }
 
+
+// =================================================================================================================================
+// The FIRST layer of a stack (one input channel: the data; reference models/convHVAE_2level.py:21-27, GatedConv2d(1, 32, 7, 1, 3)): a
+// contraction over <= 50 taps is no work for the bf16 pipe -- the layer is bound by the 10 bytes per output element it writes -- so
+// it runs on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: exact fp32, two taps per instruction) straight from an fp32
+// window of the input pixels in LDS (the LDS-staged im2col of north_star; no patch matrix), the filters in registers, and leaves
+// through the window kernels' epilogue: pixel image (parity-planar when the next layer has stride 2) + gate.
+// Block = 256 output pixels x 64 columns [h 32 | g 32], four waves of 64 pixels; two blocks per CU.
+// =================================================================================================================================
+struct ConvFirstArgs {
+  ConvWinArgs e;              // geometry (N, H, W, plo = phi = pad, PW, SP, fastdivs, M, Co, tiles_n, biases) and everything the epilogue reads
+  const float* x;             // [N][H][W] fp32
+  const float* w0;            // [Co][1][K][K]
+  const float* w1;
+  int K;
+};
+
+template <int SLOTS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_first_kernel(const ConvFirstArgs a) {
+  const ConvWinArgs& g = a.e;
+  constexpr int R = 256, MT = 2, NT = 2, NKS = 25;        // <= 50 taps
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int ntiles = gridDim.x;
+  int tile;
+  {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int qq = ntiles >> 3, rr = ntiles & 7;
+    tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * R, HW = g.H * g.W, K = a.K, taps = K * K;
+  const unsigned nf = fdiv((unsigned)m0, g.div_hw), remf = (unsigned)m0 - nf * (unsigned)HW;
+  const unsigned yf = fdiv(remf, g.div_w), xf = remf - yf * (unsigned)g.W;
+  const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)g.PW + xf);
+  // window: fp32 slots qbase .. qbase + SLOTS - 1 (zero outside the images)
+  for (int s = tid; s < SLOTS; s += 256) {
+    const unsigned q = (unsigned)(qbase + s);
+    const unsigned n = fdiv(q, g.div_sp), r = q - n * (unsigned)g.SP;
+    const unsigned py = fdiv(r, g.div_pw), px = r - py * (unsigned)g.PW;
+    const int y = (int)py - g.plo, x = (int)px - g.plo;
+    const bool ok = (int)n < g.N && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+    smem[s] = ok ? a.x[((size_t)n * g.H + y) * g.W + x] : 0.f;
+  }
+  // filters: k-step ks = taps 2 ks, 2 ks + 1 (this lane: tap 2 ks + lh), column l31 of bank nt
+  float wv[NT][NKS];
+  {
+    const int co = tn * 32 + l31;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int t = 2 * ks + lh;
+      const bool ok = t < taps && co < g.Co;
+      wv[0][ks] = ok ? a.w0[(size_t)co * taps + t] : 0.f;
+      wv[1][ks] = ok ? a.w1[(size_t)co * taps + t] : 0.f;
+    }
+  }
+  int sl[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int m = m0 + wave * 64 + mt * 32 + l31;
+    m = m < g.M ? m : g.M - 1;
+    const unsigned n = fdiv((unsigned)m, g.div_hw), rem = (unsigned)m - n * (unsigned)HW;
+    const unsigned y = fdiv(rem, g.div_w), x = rem - y * (unsigned)g.W;
+    sl[mt] = (int)(n * (unsigned)g.SP + y * (unsigned)g.PW + x) - qbase;
+  }
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __syncthreads();
+  // this lane's tap (kh, kw): starts at tap lh, advances by two per k-step; taps beyond the filter read slot offset 0 (weight 0)
+  int kh = 0, kw = lh;
+  if (kw >= K) { kw -= K; ++kh; }
+  float av[2][MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) av[0][mt] = smem[sl[mt] + kh * g.PW + kw];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int par = ks & 1;
+    if (ks + 1 < NKS) {
+      kw += 2;
+      if (kw >= K) { kw -= K; ++kh; }
+      if (kw >= K) { kw -= K; ++kh; }            // (K = 1)
+      const int off = kh < K ? kh * g.PW + kw : 0;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) av[par ^ 1][mt] = smem[sl[mt] + off];
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[par][mt], wv[nt][ks], acc[mt][nt], 0, 0, 0);
+  }
+  __syncthreads();
+  cw_epilogue<CW_FWD_GATED, R, 64, NT, 1>(g, acc, m0, tn, wave, 0, lane, tid, smem);
+}
+
+template <int SLOTS>
+static int launch_conv_first(ConvFirstArgs& a, hipStream_t stream, const char* what) {
+  ConvWinArgs& g = a.e;
+  constexpr int LDS = 2 * 256 * (32 + 4) * 4 > SLOTS * 4 ? 2 * 256 * (32 + 4) * 4 : SLOTS * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_first_kernel<SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  g.PW = g.W + g.plo + g.phi; g.SP = (g.H + g.plo + g.phi) * g.PW;
+  g.div_w = make_fastdiv((unsigned)g.W); g.div_hw = make_fastdiv((unsigned)(g.H * g.W));
+  g.div_pw = make_fastdiv((unsigned)g.PW); g.div_sp = make_fastdiv((unsigned)g.SP);
+  g.ostride = g.H * g.W;
+  g.nat_s = 1; g.nat_h = g.H; g.nat_w = g.W; g.nat_y = g.nat_x = 0;
+  g.M = g.N * g.H * g.W;
+  conv_first_kernel<SLOTS><<<dim3(cdiv(g.M, 256) * g.tiles_n), 256, LDS, stream>>>(a);
+  return check_launch(what);
+}
+
+// Weight gradient of the first layer: dW[cc][tap] = sum over pixels of dy[pixel][cc] * x[pixel + tap], db[cc] = sum of dy -- dy the
+// merged fp32 gradient [N H W][CC] (CC = 2 Co <= 64) the data gradient of the layer above wrote.  fp32 matrix instruction again:
+// rows = the 64 merged channels (A = dy^T straight from global memory: 32 lanes x 4 bytes of one pixel's channels per load), columns
+// = the taps (B from the fp32 window in LDS; column `taps` reads a constant 1: the bias gradient), two pixels per instruction.
+// A block walks a contiguous run of 256-pixel stages (split contraction), its four waves 64 pixels each; the waves' sums meet in
+// LDS, the blocks' partial [64][64] planes in cw_first_wgrad_finish_kernel (block order: deterministic).
+struct ConvFirstWgradArgs {
+  ConvWinArgs e;              // geometry
+  const float* x;             // [N][H][W]
+  const float* dy;            // [N H W][CC]
+  int CC, K;
+  int cper, nstage;
+  float* part;                // [blocks][64][64]
+};
+
+template <int SLOTS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_first_wgrad_kernel(const ConvFirstWgradArgs a) {
+  const ConvWinArgs& g = a.e;
+  constexpr int R = 256, MT = 2, NT = 2;
+  __shared__ float win[2][SLOTS];
+  __shared__ int stab[2][R];
+  __shared__ float red[4][64][17];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int HW = g.H * g.W, K = a.K, taps = K * K;
+  const int c0 = blockIdx.x * a.cper, c1 = min(c0 + a.cper, a.nstage);
+  // this lane's B columns: taps l31 and 32 + l31 -> slot offsets; column == taps: the ones column (bias gradient)
+  int toff[NT]; bool tone[NT], tok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int t = nt * 32 + l31;
+    tok[nt] = t < taps; tone[nt] = t == taps;
+    toff[nt] = tok[nt] ? (t / K) * g.PW + t % K : 0;
+  }
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto load_stage = [&](int c, int buf) {
+    const int p0 = c * R;
+    const unsigned nf = fdiv((unsigned)p0, g.div_hw), remf = (unsigned)p0 - nf * (unsigned)HW;
+    const unsigned yf = fdiv(remf, g.div_w), xf = remf - yf * (unsigned)g.W;
+    const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)g.PW + xf);
+    for (int s = tid; s < SLOTS; s += 256) {
+      const unsigned q = (unsigned)(qbase + s);
+      const unsigned n = fdiv(q, g.div_sp), r = q - n * (unsigned)g.SP;
+      const unsigned py = fdiv(r, g.div_pw), px = r - py * (unsigned)g.PW;
+      const int y = (int)py - g.plo, x = (int)px - g.plo;
+      const bool ok = (int)n < g.N && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+      win[buf][s] = ok ? a.x[((size_t)n * g.H + y) * g.W + x] : 0.f;
+    }
+    {
+      int m = p0 + tid;
+      m = m < g.M ? m : g.M - 1;
+      const unsigned n = fdiv((unsigned)m, g.div_hw), rem = (unsigned)m - n * (unsigned)HW;
+      const unsigned y = fdiv(rem, g.div_w), x = rem - y * (unsigned)g.W;
+      stab[buf][tid] = (int)(n * (unsigned)g.SP + y * (unsigned)g.PW + x) - qbase;
+    }
+  };
+  if (c0 < c1) load_stage(c0, 0);
+  for (int c = c0; c < c1; ++c) {
+    const int buf = (c - c0) & 1;
+    __syncthreads();                                   // stage c is in LDS; everybody is done with the other buffer
+    if (c + 1 < c1) load_stage(c + 1, buf ^ 1);
+    const int p0 = c * R + wave * 64;                  // this wave's 64 pixels = 32 k-steps of two
+    constexpr int UN = 8;
+#pragma unroll 1
+    for (int j0 = 0; j0 < 32; j0 += UN) {
+      float av[UN][MT], bv[UN][NT];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int pl = wave * 64 + 2 * (j0 + u) + lh;  // pixel of this lane's k row, local to the stage
+        const size_t pg = (size_t)c * R + pl;
+        const bool ok = pg < (size_t)g.M;
+        const float* d = a.dy + (ok ? pg : 0) * a.CC;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[u][mt] = (ok && mt * 32 + l31 < a.CC) ? d[mt * 32 + l31] : 0.f;
+        const int sb = stab[buf][pl];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { const float v = win[buf][sb + toff[nt]]; bv[u][nt] = tone[nt] ? 1.f : (tok[nt] ? v : 0.f); }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt], bv[u][nt], acc[mt][nt], 0, 0, 0);
+    }
+    (void)p0;
+  }
+  // the four waves' sums -> one [64][64] plane per block (fixed order), through LDS one 16-row slab at a time
+  float* const pb = a.part + (size_t)blockIdx.x * 64 * 64;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave][lane][r] = acc[mt][nt][r];
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = ((red[0][lane][r] + red[1][lane][r]) + red[2][lane][r]) + red[3][lane][r];
+          const int cc = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = nt * 32 + l31;
+          pb[cc * 64 + col] = v;
+        }
+      }
+    }
+}
+
+// dw[cc][tap] = sum over blocks of part[b][cc][tap], db[cc] = ... part[b][cc][taps]
+__global__ __launch_bounds__(256) void cw_first_wgrad_finish_kernel(const float* __restrict__ part, int nblk, int CC, int taps, float* __restrict__ dw,
+                                                                    float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= CC * 64) return;
+  const int cc = i >> 6, col = i & 63;
+  if (col > taps) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * 4096 + i];
+  if (col < taps) dw[cc * taps + col] = s;
+  else if (db) db[cc] = s;
+}
 
 // =================================================================================================================================
 // Weight gradient over pixel images: dW[cc][ci][tap] = sum over output pixels of dy[pixel][cc] * x[pixel + tap][ci]  (cc: the merged

@@ -128,6 +128,13 @@ static int cw_wgrad_ok(const evae_conv_desc_t* d) {
   return cw_window_slots(OH, OH, plo, phi, 32) <= 192;
 }
 constexpr int CW_WGRAD_BLOCKS = 256;
+constexpr int CW_FIRST_SLOTS = 768, CW_FIRST_WGRAD_BLOCKS = 512;
+// first layer (one input channel): <= 50 taps, stride 1, 'same' padding, Co a multiple of 32; weight gradient: 2 Co <= 64
+static int cw_first_ok(const evae_conv_desc_t* d, int wgrad) {
+  if (!cw_geometry_ok(d) || d->C != 1 || d->stride != 1 || d->KH * d->KW > 49 || d->Co % 32 != 0) return 0;
+  if (wgrad && 2 * d->Co > 64) return 0;
+  return cw_window_slots(d->H, d->W, d->pad, d->pad, 256) <= CW_FIRST_SLOTS;
+}
 
 }  // namespace evae
 
@@ -142,6 +149,8 @@ extern "C" int evae_cw_supported(const evae_conv_desc_t* d, int what) {
   if (what == 0) return cw_fwd_shape(d) != 0;
   if (what == 1) return cw_dgrad_shape(d) != 0;
   if (what == 2) return cw_wgrad_ok(d);
+  if (what == 3) return cw_first_ok(d, 0);
+  if (what == 4) return cw_first_ok(d, 1);
   return 0;
 }
 
@@ -319,4 +328,45 @@ extern "C" int evae_cw_bwd_weight(const void* dyimg, int dy_planar, const void* 
   }
   cw_wgrad_finish_kernel<<<(CC * taps * C + 255) / 256, 256, 0, stream>>>(part, dbp, nblk, CC, taps, C, dw, db);
   return check_launch("cw_wgrad_finish_kernel");
+}
+
+// First layer of a stack (C == 1): x fp32 [N][H][W] -> output image (rows planar when out_planar) + gate (+ fp32 copy); exact fp32
+// arithmetic (fp32 matrix instruction).  what: 3 = forward, 4 = weight gradient in evae_cw_supported.
+extern "C" int evae_cw_first_fwd(const float* x, const evae_conv_desc_t* d, const float* wh, const float* bh, const float* wg, const float* bg,
+                                 void* oimg, int out_planar, float* out_s, float* out_f, evae_stream_t stream_) {
+  EVAE_REQUIRE(cw_first_ok(d, 0), "cw_first_fwd: unsupported geometry");
+  EVAE_REQUIRE(x && wh && wg && (oimg || out_f), "cw_first_fwd: null pointer");
+  EVAE_REQUIRE(!out_planar || ((d->H | d->W) & 1) == 0, "cw_first_fwd: parity-planar output rows need an even grid");
+  ConvFirstArgs a = {};
+  ConvWinArgs& g = a.e;
+  g.N = d->N; g.H = d->H; g.W = d->W; g.plo = g.phi = d->pad; g.Co = d->Co; g.tiles_n = d->Co / 32; g.bias0 = bh; g.bias1 = bg;
+  g.out_planar = out_planar; g.oimg = (unsigned char*)oimg; g.nks_o = d->Co / 16; g.out_s = out_s; g.out_f = out_f; g.ldo = d->Co;
+  a.x = x; a.w0 = wh; a.w1 = wg; a.K = d->KH;
+  return launch_conv_first<CW_FIRST_SLOTS>(a, (hipStream_t)stream_, "cw_first_fwd");
+}
+
+extern "C" size_t evae_cw_first_workspace_bytes(void) { return (size_t)CW_FIRST_WGRAD_BLOCKS * 4096 * sizeof(float) + 256; }
+
+// dy: merged fp32 gradient [N H W][2 Co] (what evae_cw_bwd_data_gate writes as out_f); dw [2 Co][K K], db [2 Co]
+extern "C" int evae_cw_first_bwd_weight(const float* dy, const float* x, const evae_conv_desc_t* d, float* dw, float* db, void* ws,
+                                        size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(cw_first_ok(d, 1), "cw_first_bwd_weight: unsupported geometry");
+  EVAE_REQUIRE(dy && x && dw && ws && ws_bytes >= evae_cw_first_workspace_bytes(), "cw_first_bwd_weight: null pointer / workspace too small");
+  ConvFirstWgradArgs a = {};
+  ConvWinArgs& g = a.e;
+  g.N = d->N; g.H = d->H; g.W = d->W; g.plo = g.phi = d->pad;
+  g.PW = g.W + 2 * d->pad; g.SP = (g.H + 2 * d->pad) * g.PW;
+  g.div_w = make_fastdiv((unsigned)g.W); g.div_hw = make_fastdiv((unsigned)(g.H * g.W));
+  g.div_pw = make_fastdiv((unsigned)g.PW); g.div_sp = make_fastdiv((unsigned)g.SP);
+  g.M = g.N * g.H * g.W;
+  a.x = x; a.dy = dy; a.CC = 2 * d->Co; a.K = d->KH; a.part = (float*)ws;
+  a.nstage = cdiv(g.M, 256);
+  a.cper = cdiv(a.nstage, CW_FIRST_WGRAD_BLOCKS);
+  const int nblk = cdiv(a.nstage, a.cper);
+  conv_first_wgrad_kernel<CW_FIRST_SLOTS><<<nblk, 256, 0, stream>>>(a);
+  int rc = check_launch("conv_first_wgrad_kernel");
+  if (rc) return rc;
+  cw_first_wgrad_finish_kernel<<<(a.CC * 64 + 255) / 256, 256, 0, stream>>>(a.part, nblk, a.CC, d->KH * d->KW, dw, db);
+  return check_launch("cw_first_wgrad_finish_kernel");
 }

@@ -1260,7 +1260,8 @@ class GatedConvStackFn(torch.autograd.Function):
     (include/evae_hip.h, evae_cw_*): a layer's epilogue writes the image the next layer's window loads read; in the backward pass a
     layer's data gradient applies the gate derivative of the layer below in its epilogue and writes the merged [dh | dg] image
     that layer's own gradients read -- no elementwise pass, no patch matrix, no fp32 activation except where a kernel outside
-    the family still wants one.  x is data (no gradient).  args: x, n, cfg = ((stride, pad), ...), then wh, bh, wg, bg per layer."""
+    the family still wants one.  Layer 0 reads the data itself (evae_cw_first_*: exact fp32 from a window of the input in LDS, no
+    patch matrix).  x is data (no gradient).  args: x, n, cfg = ((stride, pad), ...), then wh, bh, wg, bg per layer."""
 
     @staticmethod
     def forward(ctx, x, cfg, *params):
@@ -1287,18 +1288,25 @@ class GatedConvStackFn(torch.autograd.Function):
         def image(rows, ch):
             return torch.empty(int(lib.evae_cw_image_bytes(rows, ch)), dtype=torch.uint8, device=dev)
 
-        # layer 0: channels-last kernels on the data, then its output as an image
+        # layer 0 on the data: the first-layer kernel (fp32 window in LDS -> image + gate), or the channels-last kernels + a packing pass
         d0 = ds[0]
         Co0, H0, W0 = shp[0]
-        out0 = torch.empty((N, Co0, H0, W0), **fmt)
-        s0 = torch.empty((N, Co0, H0, W0), **fmt)
         wh0, bh0, wg0, bg0 = L[0]
-        ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d0), 0, 1), dev)
-        _lib.check(lib.evae_conv2d_cl_fwd(_p(x), C.byref(d0), _p(_f32(wh0)), _p(bh0), _p(_f32(wg0)), _p(bg0), ACT_NONE, 0.0, 0.0,
-                                          _p(out0), None, _p(s0), _p(ws), ws.numel(), _stream()), "evae_conv2d_cl_fwd")
+        first_fwd = bool(lib.evae_cw_supported(C.byref(d0), 3))
+        first_wg = bool(lib.evae_cw_supported(C.byref(d0), 4))
+        need_out0 = need_grad and not wg_cw[1]
         imgs = [image(N * H0 * W0, Co0)]
-        _lib.check(lib.evae_cw_pack_image(_p(out0), N, H0, W0, Co0, int(planar[0]), _p(imgs[0]), _stream()), "evae_cw_pack_image")
-        outf = [out0 if (need_grad and not wg_cw[1]) else None]         # fp32 copies: the input of a layer whose weight gradient runs outside the family
+        s0 = torch.empty((N, Co0, H0, W0), **fmt) if (need_grad or not first_fwd) else None
+        out0 = torch.empty((N, Co0, H0, W0), **fmt) if (need_out0 or not first_fwd) else None
+        if first_fwd:
+            _lib.check(lib.evae_cw_first_fwd(_p(x), C.byref(d0), _p(_f32(wh0)), _p(bh0), _p(_f32(wg0)), _p(bg0), _p(imgs[0]), int(planar[0]),
+                                             _p(s0), _p(out0), _stream()), "evae_cw_first_fwd")
+        else:
+            ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d0), 0, 1), dev)
+            _lib.check(lib.evae_conv2d_cl_fwd(_p(x), C.byref(d0), _p(_f32(wh0)), _p(bh0), _p(_f32(wg0)), _p(bg0), ACT_NONE, 0.0, 0.0,
+                                              _p(out0), None, _p(s0), _p(ws), ws.numel(), _stream()), "evae_conv2d_cl_fwd")
+            _lib.check(lib.evae_cw_pack_image(_p(out0), N, H0, W0, Co0, int(planar[0]), _p(imgs[0]), _stream()), "evae_cw_pack_image")
+        outf = [out0 if need_out0 else None]         # fp32 copies: the input of a layer whose weight gradient runs outside the family
         gates = [s0 if need_grad else None]
         for i in range(1, b):
             Co, Hh, Ww = shp[i]
@@ -1316,13 +1324,13 @@ class GatedConvStackFn(torch.autograd.Function):
         out = outf[b - 1]
         if need_grad:
             ctx.save_for_backward(x, *[t for t in params if t is not None])
-            ctx.keep = (imgs, gates, outf[:b - 1], ds, shp, planar, wg_cw, [[t is not None for t in L[i]] for i in range(b)])
+            ctx.keep = (imgs, gates, outf[:b - 1], ds, shp, planar, wg_cw, [[t is not None for t in L[i]] for i in range(b)], first_wg)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        imgs, gates, outf, ds, shp, planar, wg_cw, has = ctx.keep
+        imgs, gates, outf, ds, shp, planar, wg_cw, has, first_wg = ctx.keep
         saved = list(ctx.saved_tensors)
         x = saved.pop(0)
         b = len(ds)
@@ -1386,9 +1394,14 @@ class GatedConvStackFn(torch.autograd.Function):
         Co0 = shp[0][0]
         K0 = d0.C * d0.KH * d0.KW
         dw = torch.empty((2 * Co0, K0), device=dev); db = torch.empty(2 * Co0, device=dev)
-        ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d0), 2, 1), dev)
-        _lib.check(lib.evae_conv2d_cl_bwd_weight(_p(dyf), _p(x), C.byref(d0), 1, _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
-                   "evae_conv2d_cl_bwd_weight")
+        if first_wg:
+            ws = _workspace("cw", lib.evae_cw_first_workspace_bytes(), dev)
+            _lib.check(lib.evae_cw_first_bwd_weight(_p(dyf), _p(x), C.byref(d0), _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
+                       "evae_cw_first_bwd_weight")
+        else:
+            ws = _workspace("conv", lib.evae_conv2d_cl_workspace_bytes(C.byref(d0), 2, 1), dev)
+            _lib.check(lib.evae_conv2d_cl_bwd_weight(_p(dyf), _p(x), C.byref(d0), 1, _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
+                       "evae_conv2d_cl_bwd_weight")
         put(0, dw, db)
         ctx.keep = None
         return (None, None) + tuple(grads)

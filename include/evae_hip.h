@@ -453,6 +453,18 @@ int evae_cw_gate_bwd_image(const float* v, const void* eimg, int planar, const f
                            float* out_f, evae_stream_t stream);
 int evae_cw_bwd_weight(const void* dyimg, int dy_planar, const void* ximg, const evae_conv_desc_t* d, float* dw, float* db,
                        void* ws, size_t ws_bytes, evae_stream_t stream);
+/* The FIRST layer of a stack (one input channel = the data; GatedConv2d(1, 32, 7, 1, 3) of models/convHVAE_2level.py:21-27): a
+ * contraction over <= 49 taps is bound by the bytes it writes, so it runs in exact fp32 (v_mfma_f32_32x32x2_f32) from an fp32
+ * window of the input in LDS (no patch matrix) and leaves as the next layer's pixel image + gate.  evae_cw_supported(d, 3 | 4):
+ * forward | weight gradient (C == 1, stride 1, 'same' padding, Co % 32 == 0; weight gradient 2 Co <= 64).
+ *   evae_cw_first_fwd: x fp32 [N][H][W] -> oimg (rows planar when out_planar), out_s [N H W][Co], optional fp32 copy out_f.
+ *   evae_cw_first_bwd_weight: dw [2 Co][K K], db [2 Co] from the merged fp32 gradient dy [N H W][2 Co] (evae_cw_bwd_data_gate's
+ *     out_f) and x; partial planes per block added in block order (deterministic). */
+int evae_cw_first_fwd(const float* x, const evae_conv_desc_t* d, const float* wh, const float* bh, const float* wg, const float* bg,
+                      void* oimg, int out_planar, float* out_s, float* out_f, evae_stream_t stream);
+size_t evae_cw_first_workspace_bytes(void);
+int evae_cw_first_bwd_weight(const float* dy, const float* x, const evae_conv_desc_t* d, float* dw, float* db, void* ws,
+                             size_t ws_bytes, evae_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Latent sampling and log-densities on [B x zdim] / [B x D] rows.
