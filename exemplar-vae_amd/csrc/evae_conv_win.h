@@ -894,8 +894,10 @@ struct CwWgradArgs {
   const unsigned char* dyimg; int nks_dy;     // merged-gradient image, channel groups per pixel (2 Co / 16)
   int dy_planar;                              // its rows are parity-planar (the layer's consumer has stride 2)
   const unsigned char* ximg; int nks_x, xcg0; // input image; the channel-group pair contracted here starts at group xcg0
-  int nseg, istride, ioff[4];                 // input segments (rows n * istride + ioff[s] + y * W + x)
-  int N, H, W, plo, phi, PW, SP;
+  int nseg, istride, ioff[4];                 // input rows: n * istride + ioff[0] + y * Win + x, or (x_planar) n * istride + cw_planar(y, x)
+  int xs, x_planar;                           // stride of the layer: the window lies on the INPUT grid (H xs) x (W xs), tap (kh, kw) of output
+                                              // pixel (y, x) reads input (y xs + kh - plo, x xs + kw - plo); x_planar: the image is parity-planar
+  int N, H, W, plo, phi, PW, SP;              // H x W: the OUTPUT grid; PW, SP: the padded input grid
   FastDiv div_w, div_hw, div_pw, div_sp;
   int M;                                      // N * H * W output pixels
   int tile_seg[32], tile_to[32], tile_tap[32];   // per column tile: input segment, tap offset in window slots, filter tap kh * KW + kw
@@ -906,22 +908,34 @@ struct CwWgradArgs {
   int dbg;                                    // tools: 1 = no copies after the first stage, 2 = copies only (no MFMA stream)
 };
 
-template <int NTW, int WSL>
+// window slots (on the padded INPUT grid) the taps of R consecutive output pixels touch
+static int cw_wgrad_window_slots(int H, int W, int K, int pad, int xs, int R) {
+  const int PW = W * xs + 2 * pad, SP = (H * xs + 2 * pad) * PW, HW = H * W;
+  int best = 0;
+  for (int r0 = 0; r0 < HW; ++r0) {
+    const int y0 = r0 / W, x0 = r0 % W, last = r0 + R - 1;
+    const int n1 = last / HW, r1 = last % HW, y1 = r1 / W, x1 = r1 % W;
+    best = std::max(best, n1 * SP + (xs * y1 + K - 1) * PW + xs * x1 + K - 1 - ((xs * y0) * PW + xs * x0) + 1);
+  }
+  return best;
+}
+
+template <int NTW, int WSL, int NCGDY>
 struct CwWgGeom {
   static constexpr int RK = 32;                                  // pixels per stage (two k-steps)
   static constexpr int DYCG = 3 * RK * 32 + 128;                 // one channel group of the dy chunk (three planes of [32 rows][32 B]); + 128:
   static constexpr int XPL = WSL * 32;                           //   the two 16-lane groups of a transpose read (even / odd channel group)
   static constexpr int XCG = 3 * XPL + 128;                      //   then fall on different bank halves
-  static constexpr int DY = 8 * DYCG;                            // up to 128 merged channels
+  static constexpr int DY = NCGDY * DYCG;                        // NCGDY channel groups of merged gradient (128 channels: 8)
   static constexpr int STAGE = DY + 2 * XCG;
   static constexpr int LDS = 2 * STAGE;
   static constexpr int NXP = WSL / 32;                           // 32-slot pieces of a window plane
 };
 
-// NTW column tiles (taps) per wave, window of WSL slots; ONE input segment (stride-1 layers)
-template <int NTW, int WSL>
+// NTW column tiles (taps) per wave, window of WSL slots on the input grid, NCGDY channel groups of dy
+template <int NTW, int WSL, int NCGDY>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wgrad_win_kernel(const CwWgradArgs g) {
-  typedef CwWgGeom<NTW, WSL> G;
+  typedef CwWgGeom<NTW, WSL, NCGDY> G;
   constexpr int RK = G::RK, NKS = RK / 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = reinterpret_cast<char*>(smem);
@@ -941,11 +955,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // Stage of chunk c -> ring buffer buf, in three units per wave so that they can be placed between the MFMA groups of the stage
-  // before (their address arithmetic is VALU work: ~20 instructions per unit).  Copies: dy 24 (cg, plane) pieces, window NXP slot
-  // pieces x 6 (cg, plane) parts.  With NXP = 6: waves 0, 1 copy two slot pieces (12 parts) + 3 dy pieces, waves 2, 3 one slot
-  // piece (6) + 9 dy pieces: 15 copies each.
-  static_assert(G::NXP == 6, "copy assignment below is written for six slot pieces");
+  // Stage of chunk c -> ring buffer buf, in units per wave so that they can be placed between the MFMA groups of the stage before
+  // (their address arithmetic is VALU work: ~20 instructions per unit).  Unit 0: the dy rows -- 3 NCGDY (cg, plane) pieces, the
+  // same number per wave; unit k >= 1: window slot piece wave + 4 (k - 1) (if it exists), its six (cg, plane) parts.
+  constexpr int NUNIT = 1 + (G::NXP + 3) / 4;
+  static_assert((3 * NCGDY) % 4 == 0, "dy pieces: the same number per wave");
+  const int Hin = g.H * g.xs, Win = g.W * g.xs;
   auto issue_unit = [&](int c, int buf, int unit) {
     char* const st = lds + buf * G::STAGE;
     const int p0 = c * RK;
@@ -967,19 +982,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       unsigned vin = (unsigned)(rel >> 4) * (unsigned)(g.nks_dy * P6_GROUP) + (unsigned)((rel & 15) * 32) + (gh << 4);
       EVAE_PIN(vin);                                                 // (computed by every lane: a select, not a branch)
       const unsigned voff = ok ? vin : 0x80000000u;
-      // dy pieces: ids 0..5 -> waves 0, 1 (three each); ids 6..23 -> waves 2, 3 (nine each)
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const int id = wave < 2 ? wave * 3 + q : 6 + (wave - 2) * 9 + q;
-        const int cg = id / 3, p = id - cg * 3;
-        if ((wave >= 2 || q < 3) && cg < ncgdy)
+      for (int q = 0; q < 3 * NCGDY / 4; ++q) {
+        const int id = wave + 4 * q, cg = id / 3, p = id - cg * 3;
+        if (cg < ncgdy)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rD, (p6_lds_t)(st + cg * G::DYCG + p * (RK * 32)), 16, voff, (unsigned)(cg * P6_GROUP + p * P6_CHUNK), 0, 0);
       }
     } else {
-      // ---- window slot piece jj: unit 1 -> piece `wave` (all four waves), unit 2 -> pieces 4, 5 (waves 0, 1) ----
-      if (unit == 2 && wave >= 2) return;
-      const int jj = unit == 1 ? wave : 4 + wave;
-      const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)g.PW + xf);
+      // ---- window slot piece jj of the input grid ----
+      const int jj = wave + 4 * (unit - 1);
+      if (jj >= G::NXP) return;
+      const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)(g.xs * g.PW) + xf * (unsigned)g.xs);
       const int xbase = (int)((nf * (unsigned)g.istride) & ~15u);
       const rsrc_t rX = make_rsrc(g.ximg + ((size_t)(xbase >> 4) * g.nks_x + (size_t)g.xcg0) * P6_GROUP, 0x7FFFFFFFu);
       const int s = 32 * jj + (lane >> 1), hp = lane & 1;
@@ -987,8 +1000,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const unsigned n = fdiv(q, g.div_sp), r = q - n * (unsigned)g.SP;
       const unsigned py = fdiv(r, g.div_pw), px = r - py * (unsigned)g.PW;
       const int y = (int)py - g.plo, x = (int)px - g.plo;
-      const bool ok = (int)n < g.N && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
-      const int pix = (int)n * g.istride + g.ioff[0] + y * g.W + x;
+      const bool ok = (int)n < g.N && (unsigned)y < (unsigned)Hin && (unsigned)x < (unsigned)Win;
+      const int pix = (int)n * g.istride + (g.x_planar ? cw_planar(y, x, Hin, Win) : g.ioff[0] + y * Win + x);
       const int rel = pix - xbase;
       const unsigned gh = (unsigned)(hp ^ ((pix >> 3) & 1));
       unsigned vin = (unsigned)(rel >> 4) * (unsigned)(g.nks_x * P6_GROUP) + (unsigned)((rel & 15) * 32) + (gh << 4);
@@ -1002,7 +1015,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
   };
-  auto issue_stage = [&](int c, int buf) { issue_unit(c, buf, 0); issue_unit(c, buf, 1); issue_unit(c, buf, 2); };
+  auto issue_stage = [&](int c, int buf) {
+#pragma unroll
+    for (int u = 0; u < NUNIT; ++u) issue_unit(c, buf, u);
+  };
 
   // window slot (relative to the stage's base slot) of chunk row r: this lane's k rows are 16 ks + 8 lh + (t16 >> 2) (+ 4)
   auto slot_of = [&](int p0, int qbase, int r) -> int {
@@ -1010,7 +1026,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     mm = mm < g.M ? mm : g.M - 1;
     const unsigned n = fdiv((unsigned)mm, g.div_hw), rem = (unsigned)mm - n * (unsigned)HW;
     const unsigned y = fdiv(rem, g.div_w), x = rem - y * (unsigned)g.W;
-    return (int)(n * (unsigned)g.SP + y * (unsigned)g.PW + x) - qbase;
+    return (int)(n * (unsigned)g.SP + y * (unsigned)(g.xs * g.PW) + x * (unsigned)g.xs) - qbase;
   };
 
   // the ones operand of the bias column: column 0 = 1.0 (plane 0 only)
@@ -1050,7 +1066,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int p0 = c * RK;
       const unsigned nf = fdiv((unsigned)p0, g.div_hw), remf = (unsigned)p0 - nf * (unsigned)HW;
       const unsigned yf = fdiv(remf, g.div_w), xf = remf - yf * (unsigned)g.W;
-      const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)g.PW + xf);
+      const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)(g.xs * g.PW) + xf * (unsigned)g.xs);
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         const int kr = 16 * ks + 8 * lh + (t16 >> 2);
@@ -1110,12 +1126,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               __builtin_amdgcn_sched_barrier(0);
             }
           // a unit of the next stage's copies behind the first three MFMA groups of the stage (the matrix pipe works them off meanwhile)
-          if (ks == 0 && jg < 3 && more) issue_unit(c + 1, buf ^ 1, jg);
+          if (ks == 0 && jg < NUNIT && more) issue_unit(c + 1, buf ^ 1, jg);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (ks == 0 && more) {                       // fewer than three groups (few column tiles): the remaining units
 #pragma unroll
-          for (int u = NGRP; u < 3; ++u) issue_unit(c + 1, buf ^ 1, u);
+          for (int u = NGRP; u < NUNIT; ++u) issue_unit(c + 1, buf ^ 1, u);
         }
       }
     }
@@ -1160,22 +1176,23 @@ __global__ __launch_bounds__(256) void cw_wgrad_finish_kernel(const float* __res
   }
 }
 
-template <int NTW, int WSL>
+template <int NTW, int WSL, int NCGDY>
 static int launch_conv_wgrad_win(CwWgradArgs& g, int nblk, hipStream_t stream, const char* what) {
-  typedef CwWgGeom<NTW, WSL> G;
+  typedef CwWgGeom<NTW, WSL, NCGDY> G;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<NTW, WSL>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<NTW, WSL, NCGDY>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     attr_done = true;
   }
-  g.PW = g.W + g.plo + g.phi; g.SP = (g.H + g.plo + g.phi) * g.PW;
+  if (g.xs == 0) g.xs = 1;
+  g.PW = g.W * g.xs + g.plo + g.phi; g.SP = (g.H * g.xs + g.plo + g.phi) * g.PW;
   g.div_w = make_fastdiv((unsigned)g.W); g.div_hw = make_fastdiv((unsigned)(g.H * g.W));
   g.div_pw = make_fastdiv((unsigned)g.PW); g.div_sp = make_fastdiv((unsigned)g.SP);
   g.M = g.N * g.H * g.W;
-  if (g.istride == 0) g.istride = g.H * g.W;
+  if (g.istride == 0) g.istride = g.H * g.W * g.xs * g.xs;
   g.nchunk = cdiv(g.M, G::RK);
   g.cper = cdiv(g.nchunk, nblk);
-  conv_wgrad_win_kernel<NTW, WSL><<<dim3(cdiv(g.nchunk, g.cper)), 256, G::LDS, stream>>>(g);
+  conv_wgrad_win_kernel<NTW, WSL, NCGDY><<<dim3(cdiv(g.nchunk, g.cper)), 256, G::LDS, stream>>>(g);
   return check_launch(what);
 }
 

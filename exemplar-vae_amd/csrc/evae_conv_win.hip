@@ -116,16 +116,20 @@ static int cw_dgrad_shape(const evae_conv_desc_t* d) {
     }
   return shape;
 }
-// weight gradient: 32 input channels per launch; stride 1: 3 x 3 | 5 x 5 (column tiles = all taps, 13 + 12 for 5 x 5); stride 2,
-// 3 x 3: one launch per input parity segment (4 / 2 / 2 / 1 taps)
+// weight gradient: 32 input channels per launch, every tap of the filter as a column tile of one launch (5 x 5: 13 + 12).  Variant:
+// 1 = 5 x 5 stride 1 (window 192 slots, 128 merged channels), 2 = 3 x 3 stride 1, 3 = 3 x 3 stride 2 with <= 64 merged channels
+// (window 320), 4 = 3 x 3 stride 2 with <= 128 (window 256)
 static int cw_wgrad_ok(const evae_conv_desc_t* d) {
   if (!cw_geometry_ok(d) || d->C % 32 != 0 || d->Co % 8 != 0 || 2 * d->Co > 128) return 0;
-  if (d->stride == 1 && d->KH != 3 && d->KH != 5) return 0;
-  if (d->stride == 2 && d->KH != 3) return 0;
-  int plo, phi;
-  (void)cw_taps_fwd(d->KH, d->stride, d->pad, &plo, &phi);
   const int OH = d->H / d->stride;
-  return cw_window_slots(OH, OH, plo, phi, 32) <= 192;
+  const int need = cw_wgrad_window_slots(OH, OH, d->KH, d->pad, d->stride, 32);
+  if (d->stride == 1 && d->KH == 5) return need <= 192 ? 1 : 0;
+  if (d->stride == 1 && d->KH == 3) return need <= 192 ? 2 : 0;
+  if (d->stride == 2 && d->KH == 3) {
+    if (2 * d->Co <= 64 && need <= 320) return 3;
+    return need <= 256 ? 4 : 0;
+  }
+  return 0;
 }
 constexpr int CW_WGRAD_BLOCKS = 256;
 constexpr int CW_FIRST_SLOTS = 768, CW_FIRST_WGRAD_BLOCKS = 512;
@@ -276,54 +280,38 @@ extern "C" int evae_cw_bwd_data_gate(const void* dyimg, int dy_planar, const eva
 extern "C" int evae_cw_bwd_weight(const void* dyimg, int dy_planar, const void* ximg, const evae_conv_desc_t* d, float* dw, float* db,
                                   void* ws, size_t ws_bytes, evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  EVAE_REQUIRE(cw_wgrad_ok(d), "cw_bwd_weight: unsupported geometry");
+  const int variant = cw_wgrad_ok(d);
+  EVAE_REQUIRE(variant != 0, "cw_bwd_weight: unsupported geometry");
   EVAE_REQUIRE(dyimg && ximg && dw && ws, "cw_bwd_weight: null pointer");
   EVAE_REQUIRE(ws_bytes >= evae_cw_workspace_bytes(d, 2), "cw_bwd_weight: workspace too small");
   const int K = d->KH, taps = K * K, CC = 2 * d->Co, C = d->C, st = d->stride, OH = d->H / st;
   EVAE_REQUIRE(!dy_planar || (OH & 1) == 0, "cw_bwd_weight: parity-planar rows need an even grid");
   float* part = (float*)ws;
   float* dbp = (float*)((char*)ws + align_up((size_t)CW_WGRAD_BLOCKS * CC * taps * C * sizeof(float), 256));
-  int plo, phi;
-  const CwTaps tp = cw_taps_fwd(K, st, d->pad, &plo, &phi);
-  const int PW = OH + plo + phi;
+  const int PW = OH * st + 2 * d->pad;
   CwWgradArgs g = {};
   g.dyimg = (const unsigned char*)dyimg; g.nks_dy = CC / 16; g.dy_planar = dy_planar;
   g.ximg = (const unsigned char*)ximg; g.nks_x = C / 16; g.nseg = 1;
-  g.N = d->N; g.H = OH; g.W = OH; g.plo = plo; g.phi = phi;
-  g.istride = st * st * OH * OH;
+  g.N = d->N; g.H = OH; g.W = OH; g.plo = d->pad; g.phi = d->pad; g.xs = st; g.x_planar = st == 2;
   g.ntap_f = taps; g.Cin = C; g.CC = CC; g.part = part;
   int nblk = 0;
   bool first = true;
   for (int cp = 0; cp < C / 32; ++cp) {            // channel-group pairs of the input
     g.xcg0 = 2 * cp;
-    for (int sg = 0; sg < tp.nseg; ++sg) {
-      const CwSegTaps& S = tp.s[sg];
-      const int nseg_t = S.ndy * S.ndx;
-      g.ioff[0] = sg * OH * OH;
-      for (int t0 = 0; t0 < nseg_t; ) {
-        const int nt = nseg_t == 25 ? (t0 == 0 ? 13 : 12) : nseg_t;
-        for (int t = 0; t < nt; ++t) {
-          const int tt = t0 + t, i = tt / S.ndx, j = tt % S.ndx;
-          g.tile_seg[t] = 0;
-          g.tile_to[t] = (S.dy0 + i + plo) * PW + S.dx0 + j + plo;
-          g.tile_tap[t] = (tp.a * (S.dy0 + i) + S.bh) * K + tp.a * (S.dx0 + j) + S.bw;
-        }
-        g.dbpart = first ? dbp : nullptr;
-        int rc;
-        switch (nt) {
-          case 13: rc = launch_conv_wgrad_win<13, 192>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight"); break;
-          case 12: rc = launch_conv_wgrad_win<12, 192>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight"); break;
-          case 9: rc = launch_conv_wgrad_win<9, 192>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight"); break;
-          case 4: rc = launch_conv_wgrad_win<4, 192>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight"); break;
-          case 2: rc = launch_conv_wgrad_win<2, 192>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight"); break;
-          case 1: rc = launch_conv_wgrad_win<1, 192>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight"); break;
-          default: set_error("cw_bwd_weight: %d column tiles per launch are not instantiated", nt); return EVAE_EINVAL;
-        }
-        if (rc) return rc;
-        nblk = cdiv(g.nchunk, g.cper);
-        first = false;
-        t0 += nt;
-      }
+    for (int t0 = 0; t0 < taps; ) {
+      const int nt = taps == 25 ? (t0 == 0 ? 13 : 12) : taps;
+      for (int t = 0; t < nt; ++t) { const int tt = t0 + t; g.tile_seg[t] = 0; g.tile_to[t] = (tt / K) * PW + tt % K; g.tile_tap[t] = tt; }
+      g.dbpart = first ? dbp : nullptr;
+      int rc;
+      if (variant == 1) rc = nt == 13 ? launch_conv_wgrad_win<13, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight")
+                                      : launch_conv_wgrad_win<12, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      else if (variant == 2) rc = launch_conv_wgrad_win<9, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      else if (variant == 3) rc = launch_conv_wgrad_win<9, 320, 4>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      else rc = launch_conv_wgrad_win<9, 256, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      if (rc) return rc;
+      nblk = cdiv(g.nchunk, g.cper);
+      first = false;
+      t0 += nt;
     }
   }
   cw_wgrad_finish_kernel<<<(CC * taps * C + 255) / 256, 256, 0, stream>>>(part, dbp, nblk, CC, taps, C, dw, db);

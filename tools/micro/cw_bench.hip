@@ -244,7 +244,7 @@ static void case_wgrad(int N, Layer L, int dcs, int reps) {
   int plo, phi;
   const CwTaps tp = cw_taps_fwd(K, 1, pad, &plo, &phi);
   constexpr int WSL = 192;
-  const int slots = cw_window_slots(H, H, plo, phi, 32);
+  const int slots = cw_wgrad_window_slots(H, H, K, pad, 1, 32);
   if (slots > WSL) { printf("wgrad: window of %d slots does not fit %d\n", slots, WSL); return; }
   const int nblk = 256;
   float* part = devz<float>((size_t)nblk * CC * taps * C); float* dbp = devz<float>((size_t)nblk * CC);
@@ -260,8 +260,8 @@ static void case_wgrad(int N, Layer L, int dcs, int reps) {
   for (int t = 13; t < 25; ++t) { gb.tile_to[t - 13] = (t / K) * PW + t % K; gb.tile_tap[t - 13] = t; }
   gb.dbpart = nullptr;
   auto run = [&]() {
-    launch_conv_wgrad_win<13, WSL>(ga, nblk, 0, "cw wgrad");
-    launch_conv_wgrad_win<12, WSL>(gb, nblk, 0, "cw wgrad");
+    launch_conv_wgrad_win<13, WSL, 8>(ga, nblk, 0, "cw wgrad");
+    launch_conv_wgrad_win<12, WSL, 8>(gb, nblk, 0, "cw wgrad");
     const int nb = (int)((size_t)ga.nchunk + ga.cper - 1) / ga.cper;
     cw_wgrad_finish_kernel<<<(CC * taps * C + 255) / 256, 256>>>(part, dbp, nb, CC, taps, C, dw, db);
   };
