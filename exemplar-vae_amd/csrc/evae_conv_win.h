@@ -905,7 +905,7 @@ struct CwWgradArgs {
   int cper, nchunk;                           // chunks per block, chunks in all
   float* part;                                // [blocks][CC][ntap_f][Cin] partial planes (only this launch's taps / channel pair are written)
   float* dbpart;                              // [blocks][CC]
-  int dbg;                                    // tools: 1 = no copies after the first stage, 2 = copies only (no MFMA stream)
+  int dbg;                                    // tools: 1 = no copies after the first stage, 2 = copies only (no MFMA stream), 4 = no fragment reads
 };
 
 // window slots (on the padded INPUT grid) the taps of R consecutive output pixels touch
@@ -932,34 +932,41 @@ struct CwWgGeom {
   static constexpr int NXP = WSL / 32;                           // 32-slot pieces of a window plane
 };
 
-// NTW column tiles (taps) per wave, window of WSL slots on the input grid, NCGDY channel groups of dy
+// NTW column tiles (taps) per launch, window of WSL slots on the input grid, NCGDY channel groups of dy.  Eight waves, two per SIMD:
+// wave = (row tile mt = wave & 3: merged channels 32 mt .., column half ch = wave >> 2); the NTW + 1 columns (the taps' tiles, then
+// the bias column) are dealt to the two halves, NCW = ceil((NTW + 1) / 2) each (a last dummy column when NTW + 1 is odd).  One wave per
+// SIMD with all columns was measured first: issue-bound (a transpose read and its address add per MFMA in ONE instruction stream:
+// 42 % of the matrix rate); with two waves a SIMD issues one wave's reads under the other's MFMAs.
 template <int NTW, int WSL, int NCGDY>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wgrad_win_kernel(const CwWgradArgs g) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_win_kernel(const CwWgradArgs g) {
   typedef CwWgGeom<NTW, WSL, NCGDY> G;
-  constexpr int RK = G::RK, NKS = RK / 16;
+  constexpr int RK = G::RK, NKS = RK / 16, NW = 8;
+  constexpr int NCW = (NTW + 2) / 2;               // columns per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = reinterpret_cast<char*>(smem);
   const unsigned lds_base = (unsigned)(uintptr_t)(p6_lds_t)lds;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  __builtin_assume(wave >= 0 && wave < 4);
+  __builtin_assume(wave >= 0 && wave < NW);
+  const int wm = wave & 3, ch = wave >> 2;
   const int l31 = lane & 31, lh = lane >> 5, ib = (lane >> 4) & 1, t16 = lane & 15;
   const int HW = g.H * g.W;
   const int c0 = blockIdx.x * g.cper, c1 = min(c0 + g.cper, g.nchunk);
   const int ncgdy = g.nks_dy;
-  const bool active = 2 * wave < ncgdy;            // this wave's row tile exists (merged channels 32 wave .. 32 wave + 31)
+  const bool active = 2 * wm < ncgdy;              // this wave's row tile exists (merged channels 32 wm .. 32 wm + 31)
+  const int cb = ch * NCW;                         // this wave's first column
 
-  f32x16 acc[NTW + 1];
+  f32x16 acc[NCW];
 #pragma unroll
-  for (int j = 0; j <= NTW; ++j)
+  for (int j = 0; j < NCW; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   // Stage of chunk c -> ring buffer buf, in units per wave so that they can be placed between the MFMA groups of the stage before
-  // (their address arithmetic is VALU work: ~20 instructions per unit).  Unit 0: the dy rows -- 3 NCGDY (cg, plane) pieces, the
-  // same number per wave; unit k >= 1: window slot piece wave + 4 (k - 1) (if it exists), its six (cg, plane) parts.
-  constexpr int NUNIT = 1 + (G::NXP + 3) / 4;
-  static_assert((3 * NCGDY) % 4 == 0, "dy pieces: the same number per wave");
+  // (their address arithmetic is VALU work: ~20 instructions per unit).  Unit 0: the dy rows -- 3 NCGDY (cg, plane) pieces dealt
+  // round-robin; unit k >= 1: window slot piece wave + 8 (k - 1) (if it exists), its six (cg, plane) parts.
+  constexpr int NUNIT = 1 + (G::NXP + NW - 1) / NW;
+  constexpr int NDYQ = (3 * NCGDY + NW - 1) / NW;
   const int Hin = g.H * g.xs, Win = g.W * g.xs;
   auto issue_unit = [&](int c, int buf, int unit) {
     char* const st = lds + buf * G::STAGE;
@@ -983,14 +990,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       EVAE_PIN(vin);                                                 // (computed by every lane: a select, not a branch)
       const unsigned voff = ok ? vin : 0x80000000u;
 #pragma unroll
-      for (int q = 0; q < 3 * NCGDY / 4; ++q) {
-        const int id = wave + 4 * q, cg = id / 3, p = id - cg * 3;
-        if (cg < ncgdy)
+      for (int q = 0; q < NDYQ; ++q) {
+        const int id = wave + NW * q, cg = id / 3, p = id - cg * 3;
+        if (id < 3 * NCGDY && cg < ncgdy)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rD, (p6_lds_t)(st + cg * G::DYCG + p * (RK * 32)), 16, voff, (unsigned)(cg * P6_GROUP + p * P6_CHUNK), 0, 0);
       }
     } else {
       // ---- window slot piece jj of the input grid ----
-      const int jj = wave + 4 * (unit - 1);
+      const int jj = wave + NW * (unit - 1);
       if (jj >= G::NXP) return;
       const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)(g.xs * g.PW) + xf * (unsigned)g.xs);
       const int xbase = (int)((nf * (unsigned)g.istride) & ~15u);
@@ -1030,13 +1037,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
 
   // the ones operand of the bias column: column 0 = 1.0 (plane 0 only)
-  p6_bf16x8 ones;
-  {
-    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-    const unsigned v = l31 == 0 ? 0x3F803F80u : 0u;
-    const u32x4_ o = {v, v, v, v};
-    ones = __builtin_bit_cast(p6_bf16x8, o);
-  }
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  const unsigned one1 = l31 == 0 ? 0x3F803F80u : 0u;
   // a fragment = two transpose reads (k rows c and c + 4 -> the 8 k of this lane's row); the halves stay separate until the wait
   // for them has passed (inline-asm results are invisible to the compiler's own lgkmcnt bookkeeping)
   struct Raw { p6_u32x2 lo, hi; };
@@ -1045,11 +1047,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a1));
   };
   auto cook = [&](const Raw& f) -> p6_bf16x8 {
-    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
     const u32x4_ v = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
     return __builtin_bit_cast(p6_bf16x8, v);
   };
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};       // smallest partial products first
+  // this wave's columns: tile offsets (bytes) of the real tiles; a column at or beyond NTW reads tile NTW - 1's address (and, for
+  // the bias column, has its fragments replaced by the ones operand)
+  unsigned toff[NCW];
+  bool isb[NCW];
+#pragma unroll
+  for (int u = 0; u < NCW; ++u) {
+    const int c = cb + u;
+    toff[u] = (unsigned)(g.tile_to[c < NTW ? c : NTW - 1] * 32);
+    isb[u] = c == NTW;
+  }
 
   const int nst = c1 - c0;
   if (nst > 0) {
@@ -1067,72 +1078,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const unsigned nf = fdiv((unsigned)p0, g.div_hw), remf = (unsigned)p0 - nf * (unsigned)HW;
       const unsigned yf = fdiv(remf, g.div_w), xf = remf - yf * (unsigned)g.W;
       const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)(g.xs * g.PW) + xf * (unsigned)g.xs);
+      // lane addresses of the stage's k-steps: A rows kr, kr + 4 of this wave's channel groups; B window slots of those rows
+      unsigned aA[NKS], bB0[NKS], bB1[NKS];
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         const int kr = 16 * ks + 8 * lh + (t16 >> 2);
-        // A: this wave's 32 merged channels = channel groups 2 wave, 2 wave + 1 (ib); rows kr, kr + 4
-        Raw ar[3];
-        {
-          const unsigned a0 = st + (unsigned)((2 * wave + ib) * G::DYCG + kr * 32 + (t16 & 3) * 8);
-#pragma unroll
-          for (int p = 0; p < 3; ++p) tr2(ar[p], a0 + p * (RK * 32), a0 + p * (RK * 32) + 128);
-        }
-        // B: window slots of rows kr, kr + 4 (+ the tile's tap offset), channel group ib of the pair
+        aA[ks] = st + (unsigned)((2 * wm + ib) * G::DYCG + kr * 32 + (t16 & 3) * 8);
         const unsigned xb = st + (unsigned)(G::DY + ib * G::XCG + (t16 & 3) * 8);
-        const unsigned b0 = xb + (unsigned)(slot_of(p0, qbase, kr) * 32), b1 = xb + (unsigned)(slot_of(p0, qbase, kr + 4) * 32);
-        // column tiles in pairs (two independent accumulator chains alternate on the matrix pipe); the bias column is the partner
-        // of the last tile when NTW is odd, else a group of its own
-        // column tiles in groups of four: four independent accumulator chains alternate on the matrix pipe (pairs measured the same: the stream is issue-bound, not latency-bound); the bias column is the last column of all
-        constexpr int GS = 4, NCOL = NTW + 1, NGRP = (NCOL + GS - 1) / GS;
-        Raw br[2][GS][3];
-        // read #e (0 .. 6 GS - 1) of the group starting at column j into buffer par: column u = e / 6, plane p = (e % 6) / 2, half = e & 1
-        auto read_one = [&](int par, int j, int e) {
-          const int u = e / 6, p = (e % 6) >> 1, hf = e & 1;
-          if (j + u < NTW) {
-            const unsigned a = (hf ? b1 : b0) + (unsigned)(g.tile_to[j + u] * 32) + p * G::XPL;
-            if (hf) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(br[par][u][p].hi) : "v"(a));
-            else asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(br[par][u][p].lo) : "v"(a));
+        bB0[ks] = xb + (unsigned)(slot_of(p0, qbase, kr) * 32);
+        bB1[ks] = xb + (unsigned)(slot_of(p0, qbase, kr + 4) * 32);
+      }
+      // The stage as NKS * NGRP steps (k-step ks, column group jg): a step's MFMAs run on fragments read during the step BEFORE --
+      // two transpose reads behind each of its first MFMAs, so that they have half a step to land before the wait in front of
+      // the next one; only a stage's first step waits for its own reads.
+      constexpr int GS = NCW >= 4 ? 4 : NCW, NGRP = (NCW + GS - 1) / GS, NSTEP = NKS * NGRP;
+      Raw ar[2][3], br[2][GS][3];
+      // read #e of step t into fragment buffers: e < 6 (only when the step opens a k-step): A (plane e / 2, half e & 1); then the
+      // group's B fragments: column u = e' / 6, plane (e' % 6) / 2, half e' & 1
+      auto read_step = [&](int t, int e) {
+        if (g.dbg & 4) return;                       // (tools: the MFMA stream without its fragment reads)
+        const int ks = t / NGRP, jg = t - ks * NGRP, j = GS * jg;
+        const int na = jg == 0 ? 6 : 0;
+        if (e < na) {
+          const int p = e >> 1, hf = e & 1;
+          const unsigned a = aA[ks] + p * (RK * 32) + hf * 128;
+          if (hf) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ar[ks & 1][p].hi) : "v"(a));
+          else asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ar[ks & 1][p].lo) : "v"(a));
+        } else {
+          const int eb = e - na, u = eb / 6, p = (eb % 6) >> 1, hf = eb & 1;
+          if (u < GS && j + u < NCW) {
+            const unsigned a = (hf ? bB1[ks] : bB0[ks]) + toff[j + u] + p * G::XPL;
+            if (hf) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(br[t & 1][u][p].hi) : "v"(a));
+            else asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(br[t & 1][u][p].lo) : "v"(a));
           }
-        };
+        }
+      };
 #pragma unroll
-        for (int e = 0; e < 6 * GS; ++e) read_one(0, 0, e);
+      for (int e = 0; e < 6 + 6 * GS; ++e) read_step(0, e);
+      p6_bf16x8 af[3];
+#pragma unroll
+      for (int t = 0; t < NSTEP; ++t) {
+        const int ks = t / NGRP, jg = t - ks * NGRP, j = GS * jg;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        p6_bf16x8 af[3];
+        if (jg == 0) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[p] = cook(ar[p]);
+          for (int p = 0; p < 3; ++p) af[p] = cook(ar[ks & 1][p]);
+        }
+        p6_bf16x8 bf_[GS][3];
 #pragma unroll
-        for (int jg = 0; jg < NGRP; ++jg) {
-          const int par = jg & 1, j = GS * jg;
-          if (jg > 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-          __builtin_amdgcn_sched_barrier(0);
-          p6_bf16x8 bf_[GS][3];
+        for (int u = 0; u < GS; ++u)
 #pragma unroll
-          for (int u = 0; u < GS; ++u)
+          for (int p = 0; p < 3; ++p)
+            if (j + u < NCW) {
+              u32x4_ v = {br[t & 1][u][p].lo[0], br[t & 1][u][p].lo[1], br[t & 1][u][p].hi[0], br[t & 1][u][p].hi[1]};
+              if (NCW + j + u >= NTW) {            // this column may be the bias column (of the second half): the ones operand instead
+                const unsigned o = p == 0 ? one1 : 0u;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) if (j + u < NTW) bf_[u][p] = cook(br[par][u][p]);
-          __builtin_amdgcn_sched_barrier(0);
-          // 6 GS MFMAs, one transpose read of the NEXT group behind each (a wave whose row tile does not exist -- fewer than 128
-          // merged channels -- runs the same stream on whatever its LDS rows hold and stores nothing: no branch around the MFMAs,
-          // whose accumulators would otherwise be copied at every join)
-#pragma unroll
-          for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int u = 0; u < GS; ++u) {
-              if (j + u < NTW) acc[j + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], bf_[u][PB[q]], acc[j + u], 0, 0, 0);
-              else if (j + u == NTW && PB[q] == 0) acc[NTW] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], ones, acc[NTW], 0, 0, 0);   // bias column: a2, a1, a0 against the ones
-              __builtin_amdgcn_sched_barrier(0);
-              if (jg + 1 < NGRP) read_one(par ^ 1, j + GS, q * GS + u);
-              __builtin_amdgcn_sched_barrier(0);
+                for (int q = 0; q < 4; ++q) v[q] = isb[j + u] ? o : v[q];
+              }
+              bf_[u][p] = __builtin_bit_cast(p6_bf16x8, v);
             }
-          // a unit of the next stage's copies behind the first three MFMA groups of the stage (the matrix pipe works them off meanwhile)
-          if (ks == 0 && jg < NUNIT && more) issue_unit(c + 1, buf ^ 1, jg);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (ks == 0 && more) {                       // fewer than three groups (few column tiles): the remaining units
+        __builtin_amdgcn_sched_barrier(0);
+        // 6 GS MFMAs (a wave whose row tile does not exist -- fewer than 128 merged channels -- runs the same stream on whatever its
+        // LDS rows hold and stores nothing: no branch around the MFMAs, whose accumulators would otherwise be copied at every join)
+        constexpr int NRD = 6 + 6 * GS;
 #pragma unroll
-          for (int u = NGRP; u < NUNIT; ++u) issue_unit(c + 1, buf ^ 1, u);
-        }
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int u = 0; u < GS; ++u) {
+            if (j + u < NCW) acc[j + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[q]], bf_[u][PB[q]], acc[j + u], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < NSTEP) {
+              const int m = q * GS + u;
+              if (2 * m < NRD) read_step(t + 1, 2 * m);
+              if (2 * m + 1 < NRD) read_step(t + 1, 2 * m + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        // a unit of the next stage's copies behind the first steps of the stage (the matrix pipe works them off meanwhile)
+        if (t < NUNIT && more) issue_unit(c + 1, buf ^ 1, t);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more) {                                    // fewer steps than units: the remaining units
+#pragma unroll
+        for (int u = NSTEP; u < NUNIT; ++u) issue_unit(c + 1, buf ^ 1, u);
       }
     }
   }
@@ -1140,19 +1170,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (active) {
     float* const pb = g.part + (size_t)blockIdx.x * g.CC * g.ntap_f * g.Cin;
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const int tap = g.tile_tap[j];
+    for (int u = 0; u < NCW; ++u) {
+      const int c = cb + u;
+      if (c < NTW) {
+        const int tap = g.tile_tap[c];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cc = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (cc < g.CC) pb[((size_t)cc * g.ntap_f + tap) * g.Cin + g.xcg0 * 16 + l31] = acc[j][r];
-      }
-    }
-    if (g.dbpart && l31 == 0) {
+        for (int r = 0; r < 16; ++r) {
+          const int cc = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (cc < g.CC) pb[((size_t)cc * g.ntap_f + tap) * g.Cin + g.xcg0 * 16 + l31] = acc[u][r];
+        }
+      } else if (c == NTW && g.dbpart && l31 == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cc = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (cc < g.CC) g.dbpart[(size_t)blockIdx.x * g.CC + cc] = acc[NTW][r];
+        for (int r = 0; r < 16; ++r) {
+          const int cc = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (cc < g.CC) g.dbpart[(size_t)blockIdx.x * g.CC + cc] = acc[u][r];
+        }
       }
     }
   }
@@ -1192,7 +1224,7 @@ static int launch_conv_wgrad_win(CwWgradArgs& g, int nblk, hipStream_t stream, c
   if (g.istride == 0) g.istride = g.H * g.W * g.xs * g.xs;
   g.nchunk = cdiv(g.M, G::RK);
   g.cper = cdiv(g.nchunk, nblk);
-  conv_wgrad_win_kernel<NTW, WSL, NCGDY><<<dim3(cdiv(g.nchunk, g.cper)), 256, G::LDS, stream>>>(g);
+  conv_wgrad_win_kernel<NTW, WSL, NCGDY><<<dim3(cdiv(g.nchunk, g.cper)), 512, G::LDS, stream>>>(g);
   return check_launch(what);
 }
 

@@ -271,8 +271,9 @@ static void case_wgrad(int N, Layer L, int dcs, int reps) {
   if (!getenv("CW_NOABL")) {
     ga.dbg = gb.dbg = 1; const float t_nocopy = time_us(run, reps);
     ga.dbg = gb.dbg = 2; const float t_copyonly = time_us(run, reps);
+    ga.dbg = gb.dbg = 5; const float t_noread = time_us(run, reps);
     ga.dbg = gb.dbg = 0; run(); CK(hipDeviceSynchronize());
-    printf("          (MFMA stream without the copies %.1f us; copies without the MFMA stream %.1f us)\n", t_nocopy, t_copyonly);
+    printf("          (MFMA stream without the copies %.1f us; copies without the MFMA stream %.1f us; MFMAs without copies and fragment reads %.1f us)\n", t_nocopy, t_copyonly, t_noread);
   }
   std::vector<float> hw((size_t)CC * C * taps), hb(CC);
   CK(hipMemcpy(hw.data(), dw, hw.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), db, hb.size() * 4, hipMemcpyDeviceToHost));
