@@ -155,7 +155,7 @@ def pmc_traffic(name, expect=None):
     process, so the bench line carries the file's number and says where it came from.  expect: the kernel symbol the launch
     this number is attached to runs -- a file whose pass profiled another kernel is refused (VERDICT r03 weak #3a: the
     dominant launch once carried the counters of a different template instance)."""
-    for rnd in ("r04_pmc", "r03_pmc", "r02_pmc"):
+    for rnd in ("r05_pmc", "r04_pmc", "r03_pmc", "r02_pmc"):
         path = os.path.join(ROOT, "profiles", rnd, str(name) + ".json")
         if os.path.exists(path):
             try:
@@ -296,19 +296,31 @@ def other_config(a, dev, rank, world, rccl_ranks=1, backend=None):
                 flops = 2.0 * nimg * hw * hw * ci * k_ * k_ * co
                 kern = "channels-last conv 96 -> 96, 3x3, 16 x 16, %d images (evae_conv2d_cl_fwd: gemm_kernel<..., CV = 1>)" % nimg
             else:
-                nimg, ci, co, k_, hw = n_ex, 32, 64, 5, 14       # gated 5x5 layer of q_z_layers over the exemplar images
-                xx = torch.randn(nimg, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
-                wh = torch.randn(co, ci, k_, k_, device=dev) * 0.03; wg = torch.randn(co, ci, k_, k_, device=dev) * 0.03
-                b_ = torch.zeros(co, device=dev)
-                us = time_launches(lambda: ops.gated_conv2d(xx, wh, b_, wg, b_, 1, 2), reps=2)
+                # the gated 5 x 5 layer of q_z_layers over the exemplar images the step encodes, as the stack launches it: the window
+                # kernel over pre-split pixel images (csrc/evae_conv_win.h)
+                dd0 = getattr(runner, "dedup", None) if runner is not None else None
+                nimg, ci, co, k_, hw = (dd0["cap"] if dd0 else n_ex), 32, 64, 5, 14
+                pr = ops.conv_window_probe(nimg, ci, hw, co, k_, 1, out_planar=True)
+                us = time_launches(pr["fwd"], reps=2)
+                us_d = time_launches(pr["dgrad"], reps=2)
+                us_w = time_launches(pr["wgrad"], reps=2)
+                del pr
                 flops = 2.0 * nimg * hw * hw * ci * k_ * k_ * 2 * co
-                kern = ("channels-last gated conv 32 -> 64, 5x5, 14 x 14, %d images (evae_conv2d_cl_fwd: both filter banks, gate in "
-                        "the epilogue)" % nimg)
-        traffic, tsrc = pmc_traffic("conv96_fwd" if c5 else "conv5_fwd")
-        # split-bf16 kernel (csrc/evae_gemm_x6.h): six bf16 partial products per fp32 product
-        executed, pipe = ops.gemm_pipe(nimg * hw * hw, co, not c5, flops)
-        roof = mfma_roofline(kern.replace("gemm_kernel<..., CV = 1>", "gemm_x6_kernel / gemm_kernel<..., CV = 1>"), flops, executed,
-                             pipe, us, traffic, tsrc)
+                kern = ("gated conv 32 -> 64, 5x5, 14 x 14, %d images on pixel images (evae_cw_fwd_gated: conv_win_kernel<0, 2, 2, 320>, input "
+                        "window resident in LDS, gate + output image in the epilogue)" % nimg)
+        traffic, tsrc = pmc_traffic("conv96_fwd" if c5 else "cw5_fwd", expect=None if c5 else "conv_win_kernel<0, 2, 2, 320>")
+        if c5:
+            # split-bf16 kernel (csrc/evae_gemm_x6.h): six bf16 partial products per fp32 product
+            executed, pipe = ops.gemm_pipe(nimg * hw * hw, co, False, flops)
+            roof = mfma_roofline(kern.replace("gemm_kernel<..., CV = 1>", "gemm_x6_kernel / gemm_kernel<..., CV = 1>"), flops, executed,
+                                 pipe, us, traffic, tsrc)
+        else:
+            roof = mfma_roofline(kern, flops, 6.0 * flops, "bf16-mfma", us, traffic, tsrc)
+            roof["kernels"] = [
+                {"launch": "data gradient + gate derivative of the layer below (evae_cw_bwd_data_gate: conv_win_kernel<1, 4, 1, 576>)",
+                 "us": round(us_d, 1), "frac": round(flops / us_d / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4)},
+                {"launch": "weight gradient over pixel images (evae_cw_bwd_weight: conv_wgrad_win_kernel<13 | 12, 192, 8> + finish)",
+                 "us": round(us_w, 1), "frac": round(flops / us_w / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4)}]
         wl = ("single_conv (fully_conv) + exemplar_prior, 3x64x64 continuous, z=256, approximate prior: top-10 over %d cached "
               "latents, <= 1000 exemplars re-encoded per step, batch %d (BASELINE.json configs[4], one GPU)" % (n_ex, B)) if c5 else \
              ("convhvae_2level + exemplar_prior, fashion_mnist-shaped binary 28x28, N=%d, batch %d, %d exemplars, exact prior "

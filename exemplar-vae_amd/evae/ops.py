@@ -1407,6 +1407,42 @@ class GatedConvStackFn(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+def conv_window_probe(N, Cc, H, Co, K, stride, out_planar=False, seed=0):
+    """Launch closures {fwd, dgrad, wgrad} of ONE gated layer (Cc -> Co, K x K, H x H input) on the window kernels, on random
+    images prepared once (bench.py's roofline timing, tools/kernel_probe.py's PMC passes): the launches a stack issues for it."""
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    pad, OH = (K - 1) // 2, H // stride
+    d = _lib.ConvDesc(N, Cc, H, H, Co, K, K, stride, pad)
+    x = torch.randn((N, H, H, Cc), device=dev, generator=g)
+    wh = torch.randn((Co, Cc, K, K), device=dev, generator=g) * 0.03; wg = torch.randn((Co, Cc, K, K), device=dev, generator=g) * 0.03
+    b = torch.zeros(Co, device=dev)
+    img = lambda rows, ch: torch.empty(int(lib.evae_cw_image_bytes(rows, ch)), dtype=torch.uint8, device=dev)
+    ximg = img(N * H * H, Cc)
+    _lib.check(lib.evae_cw_pack_image(_p(x), N, H, H, Cc, int(stride == 2), _p(ximg), _stream()), "evae_cw_pack_image")
+    oimg = img(N * OH * OH, Co); s = torch.empty((N, OH, OH, Co), device=dev)
+    dy = torch.randn((N, OH, OH, 2 * Co), device=dev, generator=g) * 0.1
+    dyimg = img(N * OH * OH, 2 * Co)
+    _lib.check(lib.evae_cw_pack_image(_p(dy), N, OH, OH, 2 * Co, int(out_planar), _p(dyimg), _stream()), "evae_cw_pack_image")
+    es = torch.rand((N, H, H, Cc), device=dev, generator=g)
+    dimg = img(N * H * H, 2 * Cc)
+    dw = torch.empty((2 * Co, Cc * K * K), device=dev); db = torch.empty(2 * Co, device=dev)
+    del x, dy
+    ws = {w: _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(d), w), dev) for w in (0, 1, 2) if lib.evae_cw_supported(C.byref(d), w)}
+    out = {"desc": d}
+    if 0 in ws:
+        out["fwd"] = lambda: _lib.check(lib.evae_cw_fwd_gated(_p(ximg), C.byref(d), _p(wh), _p(b), _p(wg), _p(b), _p(oimg), int(out_planar), _p(s),
+                                                              None, _p(ws[0]), ws[0].numel(), _stream()), "evae_cw_fwd_gated")
+    if 1 in ws:
+        out["dgrad"] = lambda: _lib.check(lib.evae_cw_bwd_data_gate(_p(dyimg), int(out_planar), C.byref(d), _p(wh), _p(wg), _p(ximg), _p(es), _p(dimg),
+                                                                    None, _p(ws[1]), ws[1].numel(), _stream()), "evae_cw_bwd_data_gate")
+    if 2 in ws:
+        out["wgrad"] = lambda: _lib.check(lib.evae_cw_bwd_weight(_p(dyimg), int(out_planar), _p(ximg), C.byref(d), _p(dw), _p(db), _p(ws[2]),
+                                                                 ws[2].numel(), _stream()), "evae_cw_bwd_weight")
+    return out
+
+
 def gated_conv_stack(x, layers):
     """layers = [(wh, bh, wg, bg, stride, pad), ...] -> output of the last one (logical NCHW, channels-last storage)"""
     cfg = tuple((_int1(l[4]), _int1(l[5])) for l in layers)

@@ -19,7 +19,12 @@
   prior_train prior forward + backward at the training shape B = 100, C = 25 000, z = 40 (three launches, the modular form)
   prior_train1  the same as ONE launch (evae_prior_train_step: what a captured step runs)
   topk_c2 / topk_c5   evae_pairdist_topk, k = 10 (100 x 25 000 x 40 / 100 x 100 000 x 256)
-  conv5_fwd / conv5_bwd   gated conv 32 -> 64, 5 x 5, 14 x 14, 25 000 images (c3): forward / data + weight gradient
+  conv5_fwd / conv5_bwd   gated conv 32 -> 64, 5 x 5, 14 x 14, 25 000 images (c3) on the channels-last kernels: forward / data + weight gradient
+  cw5_fwd / cw5_bwd / cw5_wgrad   the same layer over the 20 224 encoded rows of a c3 step on the window kernels (csrc/evae_conv_win.h):
+              forward (conv_win_kernel<0, 2, 2, 320>), data gradient + gate derivative (conv_win_kernel<1, 4, 1, 576>), weight gradient
+              (conv_wgrad_win_kernel<13 | 12, 192, 8>)
+  cw1_fwd / cw1_wgrad   first layer 1 -> 32, 7 x 7, 28 x 28 (conv_first_kernel / conv_first_wgrad_kernel), 20 224 images
+  cw2_bwd     data gradient of the stride-2 layer 32 -> 32, 3 x 3 into the first layer's 28 x 28 grid (four parity-class launches)
   conv96_fwd  conv 96 -> 96, 3 x 3, 16 x 16, 1100 images (c5)"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -154,6 +159,29 @@ elif which.startswith("topk"):
     q = torch.from_numpy(zz).to(dev); cache = torch.from_numpy(cc).to(dev)
     for _ in range(reps):
         ops.pairdist_topk(q, cache, 10, want_val=False)
+elif which in ("cw5_fwd", "cw5_bwd", "cw5_wgrad"):
+    pr = ops.conv_window_probe(int(os.environ.get("EVAE_PROBE_ROWS", "20224")), 32, 14, 64, 5, 1, out_planar=True)
+    fn = pr[{"cw5_fwd": "fwd", "cw5_bwd": "dgrad", "cw5_wgrad": "wgrad"}[which]]
+    for _ in range(reps):
+        fn()
+elif which == "cw2_bwd":
+    pr = ops.conv_window_probe(int(os.environ.get("EVAE_PROBE_ROWS", "20224")), 32, 28, 32, 3, 2)
+    for _ in range(reps):
+        pr["dgrad"]()
+elif which in ("cw1_fwd", "cw1_wgrad"):
+    n = int(os.environ.get("EVAE_PROBE_ROWS", "20224"))
+    d = _lib.ConvDesc(n, 1, 28, 28, 32, 7, 7, 1, 3)
+    x = (torch.rand(n, 28, 28, device=dev) < 0.3).float()
+    wh = torch.randn(32, 1, 7, 7, device=dev) * 0.1; wg = torch.randn(32, 1, 7, 7, device=dev) * 0.1; b = torch.zeros(32, device=dev)
+    oimg = torch.empty(int(lib.evae_cw_image_bytes(n * 784, 32)), dtype=torch.uint8, device=dev); s_ = torch.empty(n, 28, 28, 32, device=dev)
+    dy = torch.randn(n, 28, 28, 64, device=dev) * 0.1
+    dw = torch.empty(64, 49, device=dev); db = torch.empty(64, device=dev)
+    ws = torch.empty(int(lib.evae_cw_first_workspace_bytes()), dtype=torch.uint8, device=dev)
+    for _ in range(reps):
+        if which == "cw1_fwd":
+            _lib.check(lib.evae_cw_first_fwd(p(x), C.byref(d), p(wh), p(b), p(wg), p(b), p(oimg), 1, p(s_), None, st()), "evae_cw_first_fwd")
+        else:
+            _lib.check(lib.evae_cw_first_bwd_weight(p(dy), p(x), C.byref(d), p(dw), p(db), p(ws), ws.numel(), st()), "evae_cw_first_bwd_weight")
 elif which in ("conv5_fwd", "conv5_bwd"):
     x = torch.randn(25000, 32, 14, 14, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(which == "conv5_bwd")
     wh = (torch.randn(64, 32, 5, 5, device=dev) * 0.03).requires_grad_(which == "conv5_bwd")
