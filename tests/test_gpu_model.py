@@ -1524,3 +1524,68 @@ def test_distinct_rows_step_at_config2_size_equals_the_every_draw_step(monkeypat
     assert rel(np.asarray(l1), np.asarray(l0)) < 1e-5
     for k_ in p0:
         assert rel(p1[k_], p0[k_]) < 1e-5, k_
+
+
+def test_captured_distinct_rows_steps_at_config2_size_match_the_oracle(monkeypatch):
+    """the BENCHMARKED object itself -- the captured step that encodes the distinct rows of the draw, at
+    BASELINE configs[1]'s size (B = 100, C = 25 000 draws with replacement from N = 50 000) -- against the oracle's train step
+    (reference utils/training.py:27-40 + models/BaseModel.py:54-77,243-254 + utils/optimizer.py:32-80), three steps in a row with
+    the same injected draws and noise: per-step loss / RE / KL to 1e-4, every parameter after the third step to 1e-5."""
+    from evae.graph import GraphedTrainStep
+    from utils.optimizer import AdamNormGrad
+    B, C, N, beta = 100, 25000, 50000, 0.5
+    data = gi.binary_images(0, N)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    monkeypatch.setenv("EVAE_DEDUP", "1")
+    args = smoke_case.vae_args(number_components=C, training_set_size=N, batch_size=B)
+    model, p = smoke_case.build_model(torch, np, orc, args)
+    model.train()
+    opt = AdamNormGrad(model.parameters(), lr=5e-4)
+    rs = np.random.RandomState(91)
+    nsteps = 4                                                    # (the runner's first calls step eagerly, then capture, then replay)
+    draws = [rs.randint(0, N, size=(C,)).astype(np.int64) for _ in range(nsteps)]
+    epss = [rs.standard_normal((B, 40)).astype(np.float32) for _ in range(nsteps)]
+    eps_dev = torch.zeros((B, 40), device="cuda")
+    model._draw_eps = lambda like: eps_dev                        # static buffer: the captured launches read it at every replay
+    cur = {"i": 0}
+    orig = torch.randint
+
+    def fake_randint(low=0, high=None, size=None, out=None, **kw):
+        d = torch.from_numpy(draws[cur["i"]])
+        if out is not None:
+            out.copy_(d[:out.numel()])
+            return out
+        return d
+    monkeypatch.setattr(torch, "randint", fake_randint)
+    runner = GraphedTrainStep(model, opt, dataset, B, False)
+    got = []
+    for it in range(nsteps):
+        cur["i"] = it
+        eps_dev.copy_(torch.from_numpy(epss[it])); torch.cuda.synchronize()
+        xb = torch.from_numpy(data[it * B:(it + 1) * B]); ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1)
+        out = runner(xb, ib, beta)
+        torch.cuda.synchronize()
+        got.append([float(out[0].item()), float(out[1].item()), float(out[2].item())])
+    monkeypatch.setattr(torch, "randint", orig)
+    assert runner.graph is not None and runner.dedup is not None and runner.dedup["cap"] == 20224
+    # the oracle, same inputs
+    opt_state = {}
+    po = {k: v.copy() for k, v in p.items()}
+    for it in range(nsteps):
+        x = data[it * B:(it + 1) * B]; bidx = np.arange(it * B, (it + 1) * B).reshape(-1, 1)
+        fwd, _ = orc.vae_train_step(po, opt_state, x, bidx, epss[it], data[draws[it]], draws[it], beta, lr=5e-4)
+        ref = [float(np.mean(fwd["loss"])), float(np.mean(fwd["RE"])), float(np.mean(fwd["KL"]))]
+        for name, a_, b_ in zip(("loss", "RE", "KL"), got[it], ref):
+            sign = -1.0 if name == "RE" and a_ * b_ < 0 else 1.0      # (the loop's running sums carry -RE)
+            assert abs(sign * a_ - b_) <= 1e-4 * max(abs(b_), 1e-30), (it, name, a_, b_)
+    # Adam's first steps are sign-like (m / sqrt(v) ~ +-1 whatever the gradient's size), so an element whose gradient is at the
+    # rounding level of the two implementations may move by lr in either direction: every parameter to 1e-5 of its tensor's largest
+    # entry, except at most one element in 10 000, which stays within the 4 x lr such an element can travel in four steps
+    worst = {}
+    for name, prm in model.named_parameters():
+        a_ = prm.detach().cpu().numpy().astype(np.float64); b_ = po[name].astype(np.float64)
+        err = np.abs(a_ - b_) / max(np.abs(b_).max(), 1e-30)
+        worst[name] = (float(err.max()), float((err > 1e-5).mean()))
+        assert np.abs(a_ - b_).max() <= 4 * 5e-4 * 1.01, (name, worst[name])
+        assert (err > 1e-5).mean() <= 1e-4, (name, worst[name])
+    print("captured c2 steps vs oracle: worst (max rel err, fraction above 1e-5):", max(worst.values()))
