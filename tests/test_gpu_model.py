@@ -1255,10 +1255,11 @@ def test_conv_two_level_step_at_c3_size_matches_the_oracle():
     """convhvae_2level at the benchmarked size (BASELINE configs[2]: 25 000 exemplars, batch 100): per-sample loss / RE / KL of
     the training step against an fp64 restatement of reference models/AbsHModel.py:13-106 + models/convHVAE_2level.py:13-103
     (convolutions: float64 torch on the CPU, reference utils/nn.py:72-97; densities and the exemplar prior: the oracle's
-    log_normal_diag / log_bernoulli / log_p_z) on the same weights, noise and exemplar draw -- 1e-4 relative.  The 25 000
-    centres enter the oracle's prior as the GPU path's own q(z2 | x) means, after 512 of them (the first 256, the last 256:
-    both ends of the launch grid) are held to the float64 encoder at 1e-5 (a convolutional encoder is independent per image;
-    all 25 000 in float64 on the host would take over a minute).  VERDICT r03 weak #1: c3 was only compared with itself."""
+    log_normal_diag / log_bernoulli / log_p_z) on the same weights, noise and exemplar draw -- 1e-4 relative.  Of the 25 000
+    centres of the oracle's prior, a 2 048-row shard (the first 1 024, the last 1 024: both ends of the launch grid, the
+    leave-one-out rows included) comes from the float64 encoder -- and the GPU path's rows are held to it at 1e-5 --, the rest are
+    the GPU path's own q(z2 | x) means (a convolutional encoder is independent per image; all 25 000 in float64 on the host
+    would take minutes).  VERDICT r03 weak #1: c3 was only compared with itself."""
     import torch.nn.functional as F
     from utils.utils import importing_model
     B, Cn, N = 100, 25000, 50000
@@ -1324,11 +1325,15 @@ def test_conv_two_level_step_at_c3_size_matches_the_oracle():
         h = gconv(h, "p_x_layers_joint.%d" % li, 1, 1)
     x_mean = torch.sigmoid(F.conv2d(h, T["p_x_mean.conv.weight"], T["p_x_mean.conv.bias"])).reshape(B, -1).numpy()
     RE_ref = orc.log_bernoulli(x64, x_mean)
-    sample = np.r_[0:256, Cn - 256:Cn]
+    # a 2 048-row shard of the centres (both ends of the launch grid, the leave-one-out rows among them) from the float64 encoder:
+    # held against the GPU path's rows at 1e-5 AND handed to the oracle's prior in place of them
+    sample = np.r_[0:1024, Cn - 1024:Cn]
     c64 = orc.linear(stack(data_np[ex_idx[sample]].astype(np.float64), "q_z_layers", ENC2), P["q_z_mean.linear.weight"], P["q_z_mean.linear.bias"])
     assert rel(centres_gpu[sample], c64) < 1e-5, rel(centres_gpu[sample], c64)
+    centres_ref = centres_gpu.copy()
+    centres_ref[sample] = c64
     clv = np.full((Cn, 40), float(P["prior_log_variance"][0]))
-    log_pz2 = orc.log_p_z(z2, xi.reshape(-1, 1), centres_gpu, clv, ex_idx, test=False)
+    log_pz2 = orc.log_p_z(z2, xi.reshape(-1, 1), centres_ref, clv, ex_idx, test=False)
     KL_ref = (orc.log_normal_diag(z1, q1_mu, q1_lv) - orc.log_normal_diag(z1, p1_mu, p1_lv)
               + orc.log_normal_diag(z2, q2_mu, q2_lv) - log_pz2)
     loss_ref = -RE_ref + beta * KL_ref
