@@ -170,6 +170,18 @@ def pmc_traffic(name, expect=None):
     return None, None
 
 
+def pmc_rows(name):
+    """exemplar rows the committed PMC pass of `name` ran at (None: no file / an older file without the field = 25 000)"""
+    for rnd in ("r05_pmc", "r04_pmc", "r03_pmc", "r02_pmc"):
+        path = os.path.join(ROOT, "profiles", rnd, str(name) + ".json")
+        if os.path.exists(path):
+            try:
+                return int(json.load(open(path)).get("rows", 25000))
+            except Exception:
+                return None
+    return None
+
+
 FABRIC_BOUND_BPS = 5e12     # counter bytes / launch time at or above this: the launch sits at the memory fabric, not the matrix pipe
 
 
@@ -691,15 +703,15 @@ def main():
     # (launch-name prefix, probe file, kernel symbol that launch runs)
     Cm = enc_rows if enc_rows else C            # exemplar rows of the step's large launches
     pmc_of = (("dense_bwd_weight_u8", "u8wgrad1", "u8_gemm_kernel<false>"),
-              ("gated_dense_fwd_u8 M=%d K=%d N=%d (uint8 rows, three bf16 terms; output + its" % (Cm, D, H), "u8fwd1_img", "u8p_gemm_kernel"),
-              ("gated_dense_fwd_u8", "u8fwd1", "u8p_gemm_kernel"),
-              ("dense_bwd_data M=%d N=%d+%d K=%d (pre-split" % (Cm, H, H, H), "dgrad2_p6", "gemm_p6_kernel<9"),
+              ("gated_dense_fwd_u8 M=%d K=%d N=%d (uint8 rows, three bf16 terms; output + its" % (Cm, D, H), "u8fwd1_img", "u8p_gemm_kernel<4, 2>"),
+              ("gated_dense_fwd_u8", "u8fwd1", "u8p_gemm_kernel<4, 2>"),
+              ("dense_bwd_data M=%d N=%d+%d K=%d (pre-split" % (Cm, H, H, H), "dgrad2_p6", "gemm_p6_kernel<9, 128, true>"),
               ("dense_bwd_data M=%d N=%d+" % (Cm, H), "dgrad2", "gemm_x6_kernel<9"),
-              ("dense_bwd_data M=%d N=%d K=%d (gate-backward epilogue -> pre-split" % (Cm, Z, H), "hdgrad2_img", "gemm_x6_kernel<2"),
-              ("dense_bwd_weight M=%d N=%d K=%d (+db; pre-split" % (Cm + B, 2 * H, H), "wgrad2_p6", "gemm_p6_kernel<3"),
+              ("dense_bwd_data M=%d N=%d K=%d (gate-backward epilogue -> pre-split" % (Cm, Z, H), "hdgrad2_img", "gemm_x6_kernel<2, 0, 128, 3>"),
+              ("dense_bwd_weight M=%d N=%d K=%d (+db; pre-split" % (Cm + B, 2 * H, H), "wgrad2_p6", "gemm_p6_kernel<3, 64, false>"),
               ("dense_bwd_weight M=%d N=%d K=%d" % (Cm + B, Z, H), "hwgrad", "narrow_wgrad_kernel"),
               ("dense_bwd_weight M=", "wgrad2", "gemm_kernel<false, false, 3"),
-              ("gated_dense_fwd M=%d K=%d N=%d (pre-split" % (Cm, H, H), "fwd2_p6", "gemm_p6_kernel<1"),
+              ("gated_dense_fwd M=%d K=%d N=%d (pre-split" % (Cm, H, H), "fwd2_p6", "gemm_p6_kernel<1, 128, true>"),
               ("gated_dense_fwd M=%d K=%d" % (Cm, H), "fwd2", "gemm_x6_kernel<1"))
     headline = a.config == "c2" and n_ex == C
     kernels = []
@@ -707,8 +719,10 @@ def main():
         us = r["us"] / r["n"]
         pm = next(((f, sym) for pre, f, sym in pmc_of if name.startswith(pre)), None) if headline else None
         traffic, traffic_src = pmc_traffic(*pm) if pm else (None, None)
-        if traffic is not None and enc_rows and traffic_src:
-            traffic_src += "; the PMC pass ran this launch at %d exemplar rows, the step runs it at %d" % (C, enc_rows)
+        if traffic is not None and traffic_src and pm:
+            prows = pmc_rows(pm[0])
+            if prows is not None and prows != Cm:
+                traffic_src += "; the PMC pass ran this launch at %d exemplar rows, the step runs it at %d" % (prows, Cm)
         if r["pipe"] == "hbm":       # a streaming launch: algorithmic bytes / time against the HBM peak
             kernels.append({"launch": name, "pipe": "hbm", "avg_launch_us": round(us, 2), "launches": r["n"],
                             "algorithmic_tb_per_s": round(r["flops"] / us / 1e6, 3), "frac": round(r["flops"] / us / 1e6 / (PEAK_HBM_GBS / 1000.0), 4),

@@ -35,7 +35,9 @@ lib = _lib.load(); dev = torch.device("cuda"); p, st = ops._p, ops._stream
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd1"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 torch.manual_seed(0)
-N, D, H, Z, M = 50000, 784, 300, 40, 25000
+N, D, H, Z = 50000, 784, 300, 40
+# exemplar rows of the large launches: what a captured c2 / c3 step encodes (the distinct rows of its 25 000 draws, evae/graph.py)
+M = int(os.environ.get("EVAE_PROBE_ROWS", "20224"))
 vp = lambda a: C.c_void_p(a)
 
 

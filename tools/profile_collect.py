@@ -47,7 +47,7 @@ for f in sorted(glob.glob(os.path.join(src, "timeline_C*.txt"))):
 # which kernel of a probe is "its" kernel: the first alternative that appears in the counter rows
 MAIN = {"u8fwd1": ["u8p_gemm_kernel", "u8_gemm_kernel<true>"], "u8fwd1_img": ["u8p_gemm_kernel", "u8_gemm_kernel<true>"], "u8wgrad1": ["u8_gemm_kernel<false>"],
         "fwd2_p6": ["gemm_p6_kernel<1, 128, true>"], "hdgrad2_img": ["gemm_x6_kernel<2, 0", "gemm_kernel<true, false, 2"],
-        "dgrad2_p6": ["gemm_p6_kernel<9, 64, true>", "gemm_p6_kernel<9, 128, true>"], "wgrad2_p6": ["gemm_p6_kernel<3, 64, false>"],
+        "dgrad2_p6": ["gemm_p6_kernel<9, 128, true>", "gemm_p6_kernel<9, 64, true>"], "wgrad2_p6": ["gemm_p6_kernel<3, 64, false>"],
         "hwgrad": ["narrow_wgrad_kernel"],
         "fwd1": ["gemm_x6_kernel<1, 0", "gemm_kernel<true, true, 1"], "fwd2": ["gemm_x6_kernel<1, 0", "gemm_kernel<true, true, 1"],
         "dgrad2": ["gemm_x6_kernel<2, 0", "gemm_kernel<true, false, 2"], "wgrad1": ["gemm_kernel<false, false, 3"],
@@ -87,7 +87,7 @@ for probe, alts in MAIN.items():
     if not ctr:
         continue
     c = {k: sum(v) / len(v) for k, v in ctr.items()}
-    out = {"probe": "tools/kernel_probe.py %s" % probe, "kernel": kern, "kernel_symbol": rows_all[0]["Kernel_Name"][:160], "commit": head,
+    out = {"probe": "tools/kernel_probe.py %s" % probe, "rows": int(os.environ.get("EVAE_PROBE_ROWS", "20224")), "kernel": kern, "kernel_symbol": rows_all[0]["Kernel_Name"][:160], "commit": head,
            "launches_averaged": len(next(iter(ctr.values()))), "counters_per_launch": {k: round(v, 1) for k, v in sorted(c.items())}}
     if "FETCH_SIZE" in c:
         out["hbm_read_bytes_per_launch"] = round(2 * c["FETCH_SIZE"] * 1024)
