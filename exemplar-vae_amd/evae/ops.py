@@ -1230,6 +1230,10 @@ CONV_STACK_MIN_IMAGES = int(os.environ.get("EVAE_CONV_STACK_MIN", "1024"))     #
 CONV_STACK_ON = os.environ.get("EVAE_CONV_STACK", "1") != "0"
 
 
+def _pad32(c):
+    return (int(c) + 31) // 32 * 32
+
+
 def conv_stack_depth(x_shape, layers):
     """How many leading layers of a stack of gated convolutions `layers` = [(wh, stride, pad), ...] the image pipeline takes:
     layer 0 on the channels-last kernels (an input that is data: no gradient), layers 1 .. b - 1 on the window kernels with their
@@ -1243,11 +1247,16 @@ def conv_stack_depth(x_shape, layers):
         Co, Ci, KH, KW = wh.shape
         if Ci != Cc:
             break
-        d = _lib.ConvDesc(N, Cc, H, W, Co, KH, KW, int(st), int(pd))
+        # the LAST layer of the module may have any output width: it runs with its filters zero-padded to a multiple of 32
+        # output channels (a 6-channel layer as 32: five times the matrix work of a layer that has 1 % of the stack's)
+        Cop = _pad32(Co) if i == len(layers) - 1 else Co
+        d = _lib.ConvDesc(N, Cc, H, W, Cop, KH, KW, int(st), int(pd))
         if i == 0:
             if not lib.evae_conv2d_cl_supported(C.byref(d), 0, 1) or not lib.evae_conv2d_cl_supported(C.byref(d), 2, 1) or Co % 16:
                 break
-        elif not (lib.evae_cw_supported(C.byref(d), 0) and lib.evae_cw_supported(C.byref(d), 1) and Co % 16 == 0):
+        elif not (lib.evae_cw_supported(C.byref(d), 0) and lib.evae_cw_supported(C.byref(d), 1) and lib.evae_cw_supported(C.byref(d), 2)
+                  if Cop != Co else
+                  lib.evae_cw_supported(C.byref(d), 0) and lib.evae_cw_supported(C.byref(d), 1) and Co % 16 == 0):
             break
         b = i + 1
         Cc, H, W = Co, (H + 2 * pd - KH) // st + 1, (W + 2 * pd - KW) // st + 1
@@ -1267,8 +1276,16 @@ class GatedConvStackFn(torch.autograd.Function):
     def forward(ctx, x, cfg, *params):
         lib = _lib.load()
         b = len(cfg)
-        L = [params[4 * i:4 * i + 4] for i in range(b)]
+        L = [list(params[4 * i:4 * i + 4]) for i in range(b)]
         _need_cuda(x, *[t for t in params if t is not None])
+        co_real = [int(L[i][0].shape[0]) for i in range(b)]
+        if b >= 2 and co_real[b - 1] % 32:
+            # last layer of the module: output channels zero-padded to a multiple of 32 (conv_stack_depth)
+            padc = _pad32(co_real[b - 1]) - co_real[b - 1]
+            wh_, bh_, wg_, bg_ = L[b - 1]
+            zw = wh_.new_zeros((padc,) + tuple(wh_.shape[1:]))
+            L[b - 1] = [torch.cat((_f32(wh_), zw)), None if bh_ is None else torch.cat((bh_.float(), bh_.new_zeros(padc))),
+                        torch.cat((_f32(wg_), zw)), None if bg_ is None else torch.cat((bg_.float(), bg_.new_zeros(padc)))]
         x = _cl(x.float())
         dev = x.device
         need_grad = any(ctx.needs_input_grad[2:])
@@ -1324,13 +1341,14 @@ class GatedConvStackFn(torch.autograd.Function):
         out = outf[b - 1]
         if need_grad:
             ctx.save_for_backward(x, *[t for t in params if t is not None])
-            ctx.keep = (imgs, gates, outf[:b - 1], ds, shp, planar, wg_cw, [[t is not None for t in L[i]] for i in range(b)], first_wg)
-        return out
+            ctx.keep = (imgs, gates, outf[:b - 1], ds, shp, planar, wg_cw, [[t is not None for t in params[4 * i:4 * i + 4]] for i in range(b)], first_wg,
+                        co_real)
+        return out if co_real[b - 1] == shp[b - 1][0] else out[:, :co_real[b - 1]]
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        imgs, gates, outf, ds, shp, planar, wg_cw, has, first_wg = ctx.keep
+        imgs, gates, outf, ds, shp, planar, wg_cw, has, first_wg, co_real = ctx.keep
         saved = list(ctx.saved_tensors)
         x = saved.pop(0)
         b = len(ds)
@@ -1339,6 +1357,14 @@ class GatedConvStackFn(torch.autograd.Function):
             L.append([saved.pop(0) if h else None for h in has[i]])
         dev = dout.device
         N = x.shape[0]
+        if co_real[b - 1] != shp[b - 1][0]:       # the padded last layer: its missing channels have no upstream gradient
+            full = torch.zeros((N, shp[b - 1][0], dout.shape[2], dout.shape[3]), device=dev, memory_format=CL)
+            full[:, :co_real[b - 1]] = dout
+            dout = full
+            wlast = L[b - 1]
+            padc = shp[b - 1][0] - co_real[b - 1]
+            zw = wlast[0].new_zeros((padc,) + tuple(wlast[0].shape[1:]))
+            L[b - 1] = [torch.cat((_f32(wlast[0]), zw)), wlast[1], torch.cat((_f32(wlast[2]), zw)), wlast[3]]
         dout = _cl(dout.float())
         grads = [None] * (4 * b)
 
@@ -1346,14 +1372,14 @@ class GatedConvStackFn(torch.autograd.Function):
             return torch.empty(int(lib.evae_cw_image_bytes(rows, ch)), dtype=torch.uint8, device=dev)
 
         def put(i, dw, db):
-            Co = shp[i][0]
-            wshape = L[i][0].shape
-            grads[4 * i] = dw[:Co].reshape(wshape)
-            grads[4 * i + 2] = dw[Co:].reshape(wshape)
+            Co, Cr = shp[i][0], co_real[i]
+            wshape = (Cr,) + tuple(L[i][0].shape[1:])
+            grads[4 * i] = dw[:Cr].reshape(wshape)
+            grads[4 * i + 2] = dw[Co:Co + Cr].reshape(wshape)
             if has[i][1]:
-                grads[4 * i + 1] = db[:Co]
+                grads[4 * i + 1] = db[:Cr]
             if has[i][3]:
-                grads[4 * i + 3] = db[Co:]
+                grads[4 * i + 3] = db[Co:Co + Cr]
 
         # exit of the stack: gate derivative of the last layer from the fp32 upstream gradient
         Co, Hh, Ww = shp[b - 1]

@@ -271,9 +271,9 @@ def _stack(table, seed):
 
 @pytest.mark.parametrize("table,N", [(_WIDE, 37), (_WIDE, 130), (_NARROW, 37)])
 def test_gated_conv_stack_on_pixel_images_matches_float64(table, N):
-    """Forward output and every parameter gradient of the image pipeline (layer 0 on the channels-last kernels, layers 1-3 on the
+    """Forward output and every parameter gradient of the image pipeline (layer 0 on the first-layer kernels, layers 1-4 on the
     window kernels: stride 1 and 2, 3 x 3 and 5 x 5, parity-planar and natural image rows, the gate derivative in the data gradients'
-    epilogues, the weight gradient over pixel images where it applies) against torch float64 on the CPU (reference
+    epilogues, the weight gradients over pixel images, the 6-channel last layer zero-padded to 32 channels) against torch float64 on the CPU (reference
     utils/nn.py:72-97 chained as models/convHVAE_2level.py:21-46), and against the layer-by-layer HIP path."""
     from evae import ops
     net = _stack(table, 3)
@@ -288,7 +288,7 @@ def test_gated_conv_stack_on_pixel_images_matches_float64(table, N):
     h.backward(gout.double())
     net = net.cuda()
     spec = [(m.h.weight, 1 if m.h.stride == (1, 1) else 2, m.h.padding[0]) for m in net]
-    assert ops.conv_stack_depth((N, 1, 28, 28), spec) == 4, "layers 0-3 run on the image pipeline, the 6-channel layer outside"
+    assert ops.conv_stack_depth((N, 1, 28, 28), spec) == 5, "all five layers run on the image pipeline (the 6-channel one zero-padded to 32)"
     old_min = ops.CONV_STACK_MIN_IMAGES
     outs, grads = [], []
     try:
