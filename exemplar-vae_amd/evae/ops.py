@@ -1358,7 +1358,7 @@ class GatedConvStackFn(torch.autograd.Function):
         dev = dout.device
         N = x.shape[0]
         if co_real[b - 1] != shp[b - 1][0]:       # the padded last layer: its missing channels have no upstream gradient
-            full = torch.zeros((N, shp[b - 1][0], dout.shape[2], dout.shape[3]), device=dev, memory_format=CL)
+            full = torch.empty((N, shp[b - 1][0], dout.shape[2], dout.shape[3]), device=dev, memory_format=CL).zero_()
             full[:, :co_real[b - 1]] = dout
             dout = full
             wlast = L[b - 1]
