@@ -226,7 +226,7 @@ static int cw_window_slots(int H, int W, int plo, int phi, int R) {
   return best;
 }
 
-enum { CW_FWD_GATED = 0, CW_DGRAD_GATE = 1, CW_PLAIN = 2 };
+enum { CW_FWD_GATED = 0, CW_DGRAD_GATE = 1, CW_PLAIN = 2, CW_RES_FWD = 3, CW_RES_BWD = 4 };
 
 // The epilogue of a block tile (R pixels x BN columns; acc in the matrix core's C layout, 4 waves as WR x WC, wave tile 64 x 32 NT),
 // shared by the window kernels and the first-layer kernel; every wave of the block must have left its main loop (the staging
@@ -264,7 +264,7 @@ __device__ __forceinline__ void cw_epilogue(const ConvWinArgs& g, f32x16 (&acc)[
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int cl = wc * 32 * NT + nt * 32 + l31, c = tn * BNO + cl;
-      const float b = (EPI == CW_PLAIN && g.bias0 && c < g.Co) ? g.bias0[c] : 0.f;
+      const float b = ((EPI == CW_PLAIN || EPI == CW_RES_FWD) && g.bias0 && c < g.Co) ? g.bias0[c] : 0.f;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -320,6 +320,44 @@ __device__ __forceinline__ void cw_epilogue(const ConvWinArgs& g, f32x16 (&acc)[
         float* op = g.out_f + mn * g.ldo + ch;
         *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
       }
+    } else if constexpr (EPI == CW_RES_FWD) {
+      // residual block of models/fully_conv.py:13-23: y = x + conv(ELU(x)) + b.  e_s = x (fp32, natural rows); out_f = y; oimg = the
+      // image of ELU(y): the next block's convolution operand AND what its backward derives ELU'(y) from
+      const float* rp = g.e_s + mn * g.Co + ch;
+      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+      const float y[8] = {o0.x + r0.x, o0.y + r0.y, o0.z + r0.z, o0.w + r0.w, o1.x + r1.x, o1.y + r1.y, o1.z + r1.z, o1.w + r1.w};
+      if (g.out_f) {
+        float* op = g.out_f + mn * g.ldo + ch;
+        *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(y[4], y[5], y[6], y[7]);
+      }
+      if (g.oimg) {
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = y[k] > 0.f ? y[k] : expm1f(y[k]);
+        put_img(g.och0 + ch, make_float4(a[0], a[1], a[2], a[3]), make_float4(a[4], a[5], a[6], a[7]));
+      }
+    } else if constexpr (EPI == CW_RES_BWD) {
+      // its data gradient: dx = dy + ELU'(x) * conv_transpose(dy, w), ELU'(x) = (a > 0 ? 1 : a + 1) with a = ELU(x) summed back from
+      // its image (eimg); e_s = dy (fp32, natural rows); out_f = dx, oimg = the image of dx (the next data / weight gradients' operand)
+      const unsigned char* e = g.eimg + p6_off64(m, g.ech0 + ch, g.nks_e);
+      const uint4 e0 = *reinterpret_cast<const uint4*>(e), e1 = *reinterpret_cast<const uint4*>(e + P6_CHUNK), e2 = *reinterpret_cast<const uint4*>(e + 2 * P6_CHUNK);
+      const float* rp = g.e_s + mn * g.Co + ch;
+      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+      const unsigned w0[4] = {e0.x, e0.y, e0.z, e0.w}, w1[4] = {e1.x, e1.y, e1.z, e1.w}, w2[4] = {e2.x, e2.y, e2.z, e2.w};
+      const float v[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w}, rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+      float dx[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int sh = 16 * (k & 1);
+        const float av = (__uint_as_float(((w2[k >> 1] >> sh) & 0xFFFFu) << 16) + __uint_as_float(((w1[k >> 1] >> sh) & 0xFFFFu) << 16)) +
+                         __uint_as_float(((w0[k >> 1] >> sh) & 0xFFFFu) << 16);
+        dx[k] = rv[k] + (av > 0.f ? 1.0f : av + 1.0f) * v[k];
+      }
+      if (g.out_f) {
+        float* op = g.out_f + mn * g.ldo + ch;
+        *reinterpret_cast<float4*>(op) = make_float4(dx[0], dx[1], dx[2], dx[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(dx[4], dx[5], dx[6], dx[7]);
+      }
+      if (g.oimg) put_img(g.och0 + ch, make_float4(dx[0], dx[1], dx[2], dx[3]), make_float4(dx[4], dx[5], dx[6], dx[7]));
     } else {
       // gate derivative of the layer below at (pixel m, channels ch .. ch + 7): out = the sum of its image's three terms (exact), s
       // fp32; dh = v s, dg = v out (1 - s)   (reference utils/nn.py:92-97 under autograd)
@@ -1014,11 +1052,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       unsigned vin = (unsigned)(rel >> 4) * (unsigned)(g.nks_x * P6_GROUP) + (unsigned)((rel & 15) * 32) + (gh << 4);
       EVAE_PIN(vin);
       const unsigned voff = ok ? vin : 0x80000000u;
+      const bool cg1 = g.xcg0 + 1 < g.nks_x;               // (an odd number of channel groups: the last pair's second group reads as zeros)
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         const int cg = k / 3, p = k - cg * 3;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (p6_lds_t)(st + G::DY + cg * G::XCG + p * G::XPL + jj * 1024), 16, voff,
-                                                 (unsigned)(cg * P6_GROUP + p * P6_CHUNK), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (p6_lds_t)(st + G::DY + cg * G::XCG + p * G::XPL + jj * 1024), 16,
+                                                 (cg == 0 || cg1) ? voff : 0x80000000u, (unsigned)(cg * P6_GROUP + p * P6_CHUNK), 0, 0);
       }
     }
   };
@@ -1177,7 +1216,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cc = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (cc < g.CC) pb[((size_t)cc * g.ntap_f + tap) * g.Cin + g.xcg0 * 16 + l31] = acc[u][r];
+          if (cc < g.CC && g.xcg0 * 16 + l31 < g.Cin) pb[((size_t)cc * g.ntap_f + tap) * g.Cin + g.xcg0 * 16 + l31] = acc[u][r];
         }
       } else if (c == NTW && g.dbpart && l31 == 0) {
 #pragma unroll

@@ -6,7 +6,7 @@
 namespace evae {
 
 // fp32 channels-last [N][H][W][C] -> pixel image (rows natural or parity-planar); one thread per (pixel, 8 channels)
-__global__ __launch_bounds__(256) void cw_pack_image_kernel(const float* __restrict__ x, int N, int H, int W, int C, int planar,
+__global__ __launch_bounds__(256) void cw_pack_image_kernel(const float* __restrict__ x, int N, int H, int W, int C, int planar, int elu,
                                                             unsigned char* __restrict__ img) {
   const int c8n = C >> 3, nks = C >> 4;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -17,7 +17,11 @@ __global__ __launch_bounds__(256) void cw_pack_image_kernel(const float* __restr
   const int r = (int)(t - grp * 16 * c8n), c8 = r >> 4, p16 = r & 15;
   const size_t m = grp * 16 + p16;
   if (m >= (size_t)N * H * W) return;
-  const float4 a = *reinterpret_cast<const float4*>(x + m * C + c8 * 8), b = *reinterpret_cast<const float4*>(x + m * C + c8 * 8 + 4);
+  float4 a = *reinterpret_cast<const float4*>(x + m * C + c8 * 8), b = *reinterpret_cast<const float4*>(x + m * C + c8 * 8 + 4);
+  if (elu) {
+    a.x = a.x > 0.f ? a.x : expm1f(a.x); a.y = a.y > 0.f ? a.y : expm1f(a.y); a.z = a.z > 0.f ? a.z : expm1f(a.z); a.w = a.w > 0.f ? a.w : expm1f(a.w);
+    b.x = b.x > 0.f ? b.x : expm1f(b.x); b.y = b.y > 0.f ? b.y : expm1f(b.y); b.z = b.z > 0.f ? b.z : expm1f(b.z); b.w = b.w > 0.f ? b.w : expm1f(b.w);
+  }
   size_t row = m;
   if (planar) {
     const size_t n = m / ((size_t)H * W);
@@ -105,7 +109,7 @@ static int cw_fwd_shape(const evae_conv_desc_t* d) {
 // data gradient (into C channels): 1 = 32-column tiles (C == 32), 2 = 64-column tiles (C % 64 == 0)
 static int cw_dgrad_shape(const evae_conv_desc_t* d) {
   if (!cw_geometry_ok(d) || d->Co % 8 != 0) return 0;
-  const int shape = d->C == 32 ? 1 : (d->C % 64 == 0 ? 2 : 0);
+  const int shape = d->C == 32 ? 1 : (d->C % 16 == 0 ? 2 : 0);
   if (!shape) return 0;
   const int OH = d->H / d->stride;
   for (int py = 0; py < d->stride; ++py)
@@ -119,14 +123,15 @@ static int cw_dgrad_shape(const evae_conv_desc_t* d) {
 // weight gradient: 32 input channels per launch, every tap of the filter as a column tile of one launch (5 x 5: 13 + 12).  Variant:
 // 1 = 5 x 5 stride 1 (window 192 slots, 128 merged channels), 2 = 3 x 3 stride 1, 3 = 3 x 3 stride 2 with <= 64 merged channels
 // (window 320), 4 = 3 x 3 stride 2 with <= 128 (window 256)
-static int cw_wgrad_ok(const evae_conv_desc_t* d) {
-  if (!cw_geometry_ok(d) || d->C % 32 != 0 || d->Co % 8 != 0 || 2 * d->Co > 128) return 0;
+static int cw_wgrad_ok(const evae_conv_desc_t* d, int gated = 1) {
+  const int CCq = gated ? 2 * d->Co : d->Co;
+  if (!cw_geometry_ok(d) || d->C % 16 != 0 || CCq % 16 != 0 || CCq > 128) return 0;
   const int OH = d->H / d->stride;
   const int need = cw_wgrad_window_slots(OH, OH, d->KH, d->pad, d->stride, 32);
   if (d->stride == 1 && d->KH == 5) return need <= 192 ? 1 : 0;
-  if (d->stride == 1 && d->KH == 3) return need <= 192 ? 2 : 0;
+  if (d->stride == 1 && d->KH == 3) return need <= 192 ? 2 : ((CCq <= 64 && need <= 320) ? 3 : 0);    // (wide grids: the 320-slot window of variant 3)
   if (d->stride == 2 && d->KH == 3) {
-    if (2 * d->Co <= 64 && need <= 320) return 3;
+    if (CCq <= 64 && need <= 320) return 3;
     return need <= 256 ? 4 : 0;
   }
   return 0;
@@ -169,15 +174,21 @@ extern "C" size_t evae_cw_workspace_bytes(const evae_conv_desc_t* d, int what) {
     const int bn = d->C == 32 ? 32 : 64, tiles_n = cdiv(d->C, bn);
     return (size_t)d->stride * d->stride * (p6_image_bytes(tiles_n * bn, (2 * d->Co / 16) * taps) + 8192);   // one filter image per parity class (upper bound)
   }
-  return align_up((size_t)CW_WGRAD_BLOCKS * 2 * d->Co * taps * d->C * sizeof(float), 256) + align_up((size_t)CW_WGRAD_BLOCKS * 2 * d->Co * sizeof(float), 256) + 256;
+  if (what == 5 || what == 6) {      // residual block: a plain filter image, 64-column tiles
+    const int tiles_n = cdiv(d->Co, 64), wrows = (tiles_n * 64 + 127) / 128 * 128;
+    return p6_image_bytes(wrows, (d->C / 16) * taps) + 8192;
+  }
+  const int CCw = what == 7 ? d->Co : 2 * d->Co;
+  return align_up((size_t)CW_WGRAD_BLOCKS * CCw * taps * d->C * sizeof(float), 256) + align_up((size_t)CW_WGRAD_BLOCKS * CCw * sizeof(float), 256) + 256;
 }
 
 extern "C" int evae_cw_pack_image(const float* x, int N, int H, int W, int C, int planar, void* img, evae_stream_t stream_) {
+  // planar: bit 0 = parity-planar rows, bit 1 = the image of ELU(x) instead of x
   EVAE_REQUIRE(x && img && N > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0, "cw_pack_image: bad arguments (channels a multiple of 16)");
-  EVAE_REQUIRE(!planar || ((H | W) & 1) == 0, "cw_pack_image: parity-planar rows need even H and W");
+  EVAE_REQUIRE(!(planar & 1) || ((H | W) & 1) == 0, "cw_pack_image: parity-planar rows need even H and W");
   const size_t rows = (size_t)N * H * W, rows16 = (rows + 15) / 16 * 16;
   const size_t total = rows16 * (size_t)(C / 8);
-  cw_pack_image_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream_>>>(x, N, H, W, C, planar, (unsigned char*)img);
+  cw_pack_image_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream_>>>(x, N, H, W, C, planar & 1, (planar >> 1) & 1, (unsigned char*)img);
   return check_launch("cw_pack_image_kernel");
 }
 
@@ -277,14 +288,14 @@ extern "C" int evae_cw_bwd_data_gate(const void* dyimg, int dy_planar, const eva
 
 // Weight gradient of a gated layer from the merged-gradient image (rows planar when dy_planar) and the input image (rows natural
 // for a stride-1 layer, parity-planar for a stride-2 one): dw [2 Co][C][K][K] (h rows then g rows: nn.Conv2d layout), db [2 Co].
-extern "C" int evae_cw_bwd_weight(const void* dyimg, int dy_planar, const void* ximg, const evae_conv_desc_t* d, float* dw, float* db,
-                                  void* ws, size_t ws_bytes, evae_stream_t stream_) {
+static int cw_bwd_weight_impl(const void* dyimg, int dy_planar, const void* ximg, const evae_conv_desc_t* d, int gated, float* dw, float* db,
+                              void* ws, size_t ws_bytes, evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  const int variant = cw_wgrad_ok(d);
+  const int variant = cw_wgrad_ok(d, gated);
   EVAE_REQUIRE(variant != 0, "cw_bwd_weight: unsupported geometry");
   EVAE_REQUIRE(dyimg && ximg && dw && ws, "cw_bwd_weight: null pointer");
-  EVAE_REQUIRE(ws_bytes >= evae_cw_workspace_bytes(d, 2), "cw_bwd_weight: workspace too small");
-  const int K = d->KH, taps = K * K, CC = 2 * d->Co, C = d->C, st = d->stride, OH = d->H / st;
+  EVAE_REQUIRE(ws_bytes >= evae_cw_workspace_bytes(d, gated ? 2 : 7), "cw_bwd_weight: workspace too small");
+  const int K = d->KH, taps = K * K, CC = gated ? 2 * d->Co : d->Co, C = d->C, st = d->stride, OH = d->H / st;
   EVAE_REQUIRE(!dy_planar || (OH & 1) == 0, "cw_bwd_weight: parity-planar rows need an even grid");
   float* part = (float*)ws;
   float* dbp = (float*)((char*)ws + align_up((size_t)CW_WGRAD_BLOCKS * CC * taps * C * sizeof(float), 256));
@@ -296,7 +307,7 @@ extern "C" int evae_cw_bwd_weight(const void* dyimg, int dy_planar, const void* 
   g.ntap_f = taps; g.Cin = C; g.CC = CC; g.part = part;
   int nblk = 0;
   bool first = true;
-  for (int cp = 0; cp < C / 32; ++cp) {            // channel-group pairs of the input
+  for (int cp = 0; cp < (C / 16 + 1) / 2; ++cp) {  // channel-group pairs of the input (an odd last group: half a pair)
     g.xcg0 = 2 * cp;
     for (int t0 = 0; t0 < taps; ) {
       const int nt = taps == 25 ? (t0 == 0 ? 13 : 12) : taps;
@@ -316,6 +327,72 @@ extern "C" int evae_cw_bwd_weight(const void* dyimg, int dy_planar, const void* 
   }
   cw_wgrad_finish_kernel<<<(CC * taps * C + 255) / 256, 256, 0, stream>>>(part, dbp, nblk, CC, taps, C, dw, db);
   return check_launch("cw_wgrad_finish_kernel");
+}
+
+extern "C" int evae_cw_bwd_weight(const void* dyimg, int dy_planar, const void* ximg, const evae_conv_desc_t* d, float* dw, float* db,
+                                  void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  return cw_bwd_weight_impl(dyimg, dy_planar, ximg, d, 1, dw, db, ws, ws_bytes, stream_);
+}
+
+// ---- residual blocks y = x + conv(ELU(x), w) + b (reference models/fully_conv.py:13-23; C == Co, stride 1, 'same' padding) on pixel images ----
+static int cw_res_ok(const evae_conv_desc_t* d) {
+  if (!cw_geometry_ok(d) || d->stride != 1 || d->C != d->Co || d->C % 16 != 0 || d->Co > 128) return 0;
+  if (cw_window_slots(d->H, d->W, d->pad, d->pad, 256) > 576) return 0;
+  return cw_wgrad_ok(d, 0) != 0;
+}
+extern "C" int evae_cw_res_supported(const evae_conv_desc_t* d) { return cw_res_ok(d); }
+
+// aimg: the image of ELU(x) (natural rows); x: fp32 [N H W][C]; y = x + conv(ELU(x)) + b -> out_f (fp32) and / or oimg = the image of ELU(y)
+extern "C" int evae_cw_res_fwd(const void* aimg, const evae_conv_desc_t* d, const float* w, const float* b, const float* x, float* out_f,
+                               void* oimg, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(cw_res_ok(d), "cw_res_fwd: unsupported geometry");
+  EVAE_REQUIRE(aimg && w && x && (out_f || oimg) && ws && ws_bytes >= evae_cw_workspace_bytes(d, 5), "cw_res_fwd: null pointer / workspace too small");
+  const int K = d->KH, C = d->C, ncg = C / 16, tiles_n = cdiv(C, 64), wrows = (tiles_n * 64 + 127) / 128 * 128;
+  int plo, phi;
+  const CwTaps tp = cw_taps_fwd(K, 1, d->pad, &plo, &phi);
+  const int nks_w = cw_ksteps(tp, ncg);
+  unsigned char* iw = (unsigned char*)ws;
+  cw_pack_filter_kernel<<<(unsigned)(((size_t)wrows * nks_w * 2 + 255) / 256), 256, 0, stream>>>(w, nullptr, C, C, K, K, tp, ncg, 2, 64, wrows, nks_w, iw);
+  int rc = check_launch("cw_pack_filter_kernel");
+  if (rc) return rc;
+  ConvWinArgs g = {};
+  g.xin = (const unsigned char*)aimg; g.nks_in = ncg; g.ncg = ncg; g.N = d->N; g.H = d->H; g.W = d->W; g.plo = plo; g.phi = phi; g.taps = tp;
+  g.wimg = iw; g.nks_w = nks_w; g.Co = C; g.tiles_n = tiles_n; g.bias0 = b;
+  g.oimg = (unsigned char*)oimg; g.nks_o = ncg; g.out_f = out_f; g.ldo = C; g.e_s = x;
+  g.nsp = (cw_window_slots(d->H, d->W, plo, phi, 256) + 31) / 32;
+  return launch_conv_win<CW_RES_FWD, 4, 2, 576>(g, stream, "cw_res_fwd");
+}
+
+// dx = dy + ELU'(x) * conv_transpose(dy, w): dyimg = the image of dy, dy_f the same gradient in fp32, aimg = the image of ELU(x);
+// -> dx_f (fp32) and / or dximg (the image of dx: the operand of the block below's gradients)
+extern "C" int evae_cw_res_bwd_data(const void* dyimg, const evae_conv_desc_t* d, const float* w, const void* aimg, const float* dy_f,
+                                    float* dx_f, void* dximg, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(cw_res_ok(d), "cw_res_bwd_data: unsupported geometry");
+  EVAE_REQUIRE(dyimg && w && aimg && dy_f && (dx_f || dximg) && ws && ws_bytes >= evae_cw_workspace_bytes(d, 5),
+               "cw_res_bwd_data: null pointer / workspace too small");
+  const int K = d->KH, C = d->C, ncg = C / 16, tiles_n = cdiv(C, 64), wrows = (tiles_n * 64 + 127) / 128 * 128;
+  int plo, phi;
+  const CwTaps tp = cw_taps_dgrad(K, 1, d->pad, 0, 0, &plo, &phi);
+  const int nks_w = cw_ksteps(tp, ncg);
+  unsigned char* iw = (unsigned char*)ws;
+  cw_pack_filter_kernel<<<(unsigned)(((size_t)wrows * nks_w * 2 + 255) / 256), 256, 0, stream>>>(w, nullptr, C, C, K, K, tp, ncg, 1, 64, wrows, nks_w, iw);
+  int rc = check_launch("cw_pack_filter_kernel");
+  if (rc) return rc;
+  ConvWinArgs g = {};
+  g.xin = (const unsigned char*)dyimg; g.nks_in = ncg; g.ncg = ncg; g.N = d->N; g.H = d->H; g.W = d->W; g.plo = plo; g.phi = phi; g.taps = tp;
+  g.wimg = iw; g.nks_w = nks_w; g.Co = C; g.tiles_n = tiles_n;
+  g.oimg = (unsigned char*)dximg; g.nks_o = ncg; g.out_f = dx_f; g.ldo = C; g.e_s = dy_f;
+  g.eimg = (const unsigned char*)aimg; g.nks_e = ncg;
+  g.nsp = (cw_window_slots(d->H, d->W, plo, phi, 256) + 31) / 32;
+  return launch_conv_win<CW_RES_BWD, 4, 2, 576>(g, stream, "cw_res_bwd_data");
+}
+
+// weight gradient of a plain (un-gated) stride-1 layer: dw [Co][C][K][K], db [Co] from dy's image and the input's image
+extern "C" int evae_cw_bwd_weight_plain(const void* dyimg, const void* ximg, const evae_conv_desc_t* d, float* dw, float* db, void* ws,
+                                        size_t ws_bytes, evae_stream_t stream_) {
+  return cw_bwd_weight_impl(dyimg, 0, ximg, d, 0, dw, db, ws, ws_bytes, stream_);
 }
 
 // First layer of a stack (C == 1): x fp32 [N][H][W] -> output image (rows planar when out_planar) + gate (+ fp32 copy); exact fp32

@@ -146,6 +146,10 @@ SIGNATURES = {
     "evae_cw_bwd_data_gate": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_cw_gate_bwd_image": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p]),
     "evae_cw_bwd_weight": (_i, [_p, _i, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_cw_res_supported": (_i, [_p]),
+    "evae_cw_res_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_cw_res_bwd_data": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_cw_bwd_weight_plain": (_i, [_p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_cw_first_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "evae_cw_first_workspace_bytes": (_z, []),
     "evae_cw_first_bwd_weight": (_i, [_p, _p, _p, _p, _p, _p, _z, _p]),

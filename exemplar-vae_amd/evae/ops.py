@@ -1433,6 +1433,112 @@ class GatedConvStackFn(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+RES_STACK_MIN_PIXELS = int(os.environ.get("EVAE_RES_STACK_MIN_PIXELS", "16384"))
+
+
+def res_stack_supported(x, weights):
+    """A run of residual blocks x + conv(ELU(x)) (models/fully_conv.py:13-23) on the window kernels?  (same channel count in and
+    out, stride 1, enough pixels to fill the machine)"""
+    if not (CONV_STACK_ON and x.is_cuda and x.dim() == 4 and len(weights) >= 1):
+        return False
+    N, Cc, H, W = x.shape
+    if N * H * W < RES_STACK_MIN_PIXELS:
+        return False
+    lib = _lib.load()
+    for w in weights:
+        Co, Ci, KH, KW = w.shape
+        if Ci != Cc or Co != Cc:
+            return False
+        d = _lib.ConvDesc(N, Cc, H, W, Co, KH, KW, 1, (KH - 1) // 2)
+        if not lib.evae_cw_res_supported(C.byref(d)):
+            return False
+    return True
+
+
+class ResStackFn(torch.autograd.Function):
+    """A run of residual blocks x_{k+1} = x_k + conv(ELU(x_k), w_k) + b_k (reference models/fully_conv.py:13-23) on pixel images: every
+    block's convolution reads the image of ELU(x_k) that the block before wrote in its epilogue (the entry packs it once), adds bias
+    and residual in its own; in the backward pass one launch per block forms dx_k = dx_{k+1} + ELU'(x_k) conv_transpose(dx_{k+1}, w_k)
+    -- ELU' from the saved image -- and writes it as fp32 and as the image the next block's two gradients read.  No ELU launch, no
+    fp32 activation kept for the backward.  args: x, then (w, b) per block."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        lib = _lib.load()
+        nb = len(params) // 2
+        ws_ = [_f32(params[2 * k]) for k in range(nb)]
+        bs_ = [params[2 * k + 1] for k in range(nb)]
+        _need_cuda(x, *ws_)
+        x = _cl(x.float())
+        dev = x.device
+        N, Cc, H, W = x.shape
+        need_grad = any(ctx.needs_input_grad)
+        fmt = dict(device=dev, memory_format=CL)
+        image = lambda: torch.empty(int(lib.evae_cw_image_bytes(N * H * W, Cc)), dtype=torch.uint8, device=dev)
+        ds = [_lib.ConvDesc(N, Cc, H, W, Cc, w.shape[2], w.shape[3], 1, (w.shape[2] - 1) // 2) for w in ws_]
+        a = image()
+        _lib.check(lib.evae_cw_pack_image(_p(x), N, H, W, Cc, 2, _p(a), _stream()), "evae_cw_pack_image(ELU)")
+        imgs = [a]
+        cur = x
+        for k in range(nb):
+            last = k == nb - 1
+            y = torch.empty((N, Cc, H, W), **fmt)
+            o = None if last else image()
+            ws = _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(ds[k]), 5), dev)
+            _lib.check(lib.evae_cw_res_fwd(_p(imgs[k]), C.byref(ds[k]), _p(ws_[k]), _p(bs_[k]), _p(cur), _p(y), _p(o), _p(ws), ws.numel(), _stream()),
+                       "evae_cw_res_fwd")
+            if not last:
+                imgs.append(o)
+            if not need_grad:
+                imgs[k] = None
+            cur = y
+        if need_grad:
+            ctx.save_for_backward(*ws_)
+            ctx.keep = (imgs, ds, [b is not None for b in bs_])
+        return cur
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        imgs, ds, has_b = ctx.keep
+        ws_ = list(ctx.saved_tensors)
+        nb = len(ds)
+        dev = dout.device
+        dy = _cl(dout.float())
+        N, Cc, H, W = dy.shape
+        image = lambda: torch.empty(int(lib.evae_cw_image_bytes(N * H * W, Cc)), dtype=torch.uint8, device=dev)
+        dyimg = image()
+        _lib.check(lib.evae_cw_pack_image(_p(dy), N, H, W, Cc, 0, _p(dyimg), _stream()), "evae_cw_pack_image")
+        grads = [None] * (2 * nb)
+        for k in range(nb - 1, -1, -1):
+            d = ds[k]
+            K = d.C * d.KH * d.KW
+            dw = torch.empty((Cc, K), device=dev); db = torch.empty(Cc, device=dev)
+            ws = _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(d), 7), dev)
+            _lib.check(lib.evae_cw_bwd_weight_plain(_p(dyimg), _p(imgs[k]), C.byref(d), _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
+                       "evae_cw_bwd_weight_plain")
+            grads[2 * k] = dw.reshape(ws_[k].shape)
+            if has_b[k]:
+                grads[2 * k + 1] = db
+            dx = torch.empty((N, Cc, H, W), device=dev, memory_format=CL)
+            dximg = image() if k > 0 else None
+            ws = _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(d), 5), dev)
+            _lib.check(lib.evae_cw_res_bwd_data(_p(dyimg), C.byref(d), _p(ws_[k]), _p(imgs[k]), _p(dy), _p(dx), _p(dximg), _p(ws), ws.numel(),
+                                                _stream()), "evae_cw_res_bwd_data")
+            imgs[k] = None
+            dy, dyimg = dx, dximg
+        ctx.keep = None
+        return (dy if ctx.needs_input_grad[0] else None,) + tuple(grads)
+
+
+def res_stack(x, blocks):
+    """blocks = [(w, b), ...] -> x after the run of residual blocks"""
+    flat = []
+    for w, b in blocks:
+        flat += [w, b]
+    return ResStackFn.apply(x, *flat)
+
+
 def conv_window_probe(N, Cc, H, Co, K, stride, out_planar=False, seed=0):
     """Launch closures {fwd, dgrad, wgrad} of ONE gated layer (Cc -> Co, K x K, H x H input) on the window kernels, on random
     images prepared once (bench.py's roofline timing, tools/kernel_probe.py's PMC passes): the launches a stack issues for it."""

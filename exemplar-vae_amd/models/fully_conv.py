@@ -32,6 +32,32 @@ class block(nn.Module):
         return x + self.f(x)
 
 
+class _Seq(nn.Sequential):
+    """nn.Sequential (same children, same state_dict keys) that hands every run of consecutive residual blocks to ONE operator over
+    pre-split pixel images (evae.ops.ResStackFn) when the tensor is large enough to fill the machine."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, block) and x.is_cuda and os.environ.get("EVAE_RESBLOCK", "1") != "0":
+                j = i
+                while j < len(mods) and isinstance(mods[j], block):
+                    j += 1
+                run = mods[i:j]
+                if ops.res_stack_supported(x, [b.conv1.weight_v for b in run]):
+                    for b in run:                        # weight_norm: weight = g * v / ||v|| (differentiable, torch's own hook)
+                        for hook in b.conv1._forward_pre_hooks.values():
+                            hook(b.conv1, (x,))
+                    x = ops.res_stack(x, [(b.conv1.weight, b.conv1.bias) for b in run])
+                    i = j
+                    continue
+            x = m(x)
+            i += 1
+        return x
+
+
 def _wn_conv(cin, cout, stride=1):
     return weight_norm(HipConv2d(in_channels=cin, out_channels=cout, kernel_size=3, stride=stride, padding=1))
 
@@ -45,12 +71,12 @@ class VAE(AbsModel):
         self.cs = 48
         self.bottleneck = self.args.bottleneck
         cs, c_in = self.cs, self.args.input_size[0]
-        self.q_z_layers = nn.Sequential(
+        self.q_z_layers = _Seq(
             _wn_conv(c_in, cs, 2), nn.ELU(), *[block(cs, cs) for _ in range(6)],
             _wn_conv(cs, cs * 2, 2), nn.ELU(), *[block(cs * 2, cs * 2) for _ in range(6)])
         self.q_z_mean = _wn_conv(cs * 2, self.bottleneck)
         self.q_z_logvar = _wn_conv(cs * 2, self.bottleneck)
-        self.p_x_layers = nn.Sequential(
+        self.p_x_layers = _Seq(
             nn.Upsample(scale_factor=2), _wn_conv(self.bottleneck, cs * 2), nn.ELU(),
             *[block(cs * 2, cs * 2) for _ in range(6)],
             nn.Upsample(scale_factor=2), _wn_conv(cs * 2, cs), nn.ELU(), *[block(cs, cs) for _ in range(6)])

@@ -431,7 +431,7 @@ int evae_conv2d_cl_bwd_data_res(const float* dy, const float* w, const evae_conv
  * tap); arithmetic: six bf16 partial products per fp32 product, fp32 accumulate (the fp32 bar, as evae_gated_dense_fwd's x6 path).
  *   evae_cw_supported(d, what): what = 0 forward (C % 16 == 0, Co % 32 == 0, odd square filter with pad = (K - 1) / 2, stride 1 | 2,
  *     square even grid), 1 data gradient (C == 32 or C % 64 == 0), 2 weight gradient (stride 1, C % 32 == 0, 3 x 3 | 5 x 5, 2 Co <= 128).
- *   evae_cw_pack_image: fp32 channels-last [N][H][W][C] -> image (rows natural | planar) -- the entry of a stack.
+ *   evae_cw_pack_image: fp32 channels-last [N][H][W][C] -> image (planar bit 0: rows parity-planar; bit 1: the image of ELU(x)) -- the entry of a stack.
  *   evae_cw_fwd_gated: out = (conv(x, wh) + bh) * sigmoid(conv(x, wg) + bg); x image rows natural (stride 1) | planar (stride 2);
  *     oimg (rows planar when out_planar), out_s = the gate fp32 [N OH OW][Co], out_f = optional fp32 copy of out.
  *   evae_cw_bwd_data_gate: v = conv_transpose([dh | dg], [wh | wg]) and, in the epilogue, the gate derivative of the layer BELOW
@@ -453,6 +453,20 @@ int evae_cw_gate_bwd_image(const float* v, const void* eimg, int planar, const f
                            float* out_f, evae_stream_t stream);
 int evae_cw_bwd_weight(const void* dyimg, int dy_planar, const void* ximg, const evae_conv_desc_t* d, float* dw, float* db,
                        void* ws, size_t ws_bytes, evae_stream_t stream);
+/* Residual blocks y = x + conv(ELU(x), w) + b of models/fully_conv.py:13-23 (C == Co <= 128, C % 16 == 0, stride 1, 'same' padding) on
+ * pixel images: a block's convolution operand is the image of ELU(x), which the block before writes in its epilogue and from which
+ * the backward derives ELU'(x) = (a > 0 ? 1 : a + 1).  evae_cw_pack_image's `planar` bit 1 asks for the image of ELU(x) (entry of a run).
+ *   evae_cw_res_fwd: y -> out_f (fp32 [N H W][C]) and / or oimg = image of ELU(y).
+ *   evae_cw_res_bwd_data: dx = dy + ELU'(x) conv_transpose(dy, w): dyimg + dy_f (the same gradient, fp32), aimg -> dx_f and / or dximg.
+ *   evae_cw_bwd_weight_plain: dw [Co][C][K][K], db [Co] from dy's image and the input image (the image of ELU(x)).
+ * Workspace: evae_cw_workspace_bytes(d, 5) for the two convolutions, (d, 7) for the weight gradient. */
+int evae_cw_res_supported(const evae_conv_desc_t* d);
+int evae_cw_res_fwd(const void* aimg, const evae_conv_desc_t* d, const float* w, const float* b, const float* x, float* out_f, void* oimg,
+                    void* ws, size_t ws_bytes, evae_stream_t stream);
+int evae_cw_res_bwd_data(const void* dyimg, const evae_conv_desc_t* d, const float* w, const void* aimg, const float* dy_f, float* dx_f,
+                         void* dximg, void* ws, size_t ws_bytes, evae_stream_t stream);
+int evae_cw_bwd_weight_plain(const void* dyimg, const void* ximg, const evae_conv_desc_t* d, float* dw, float* db, void* ws,
+                             size_t ws_bytes, evae_stream_t stream);
 /* The FIRST layer of a stack (one input channel = the data; GatedConv2d(1, 32, 7, 1, 3) of models/convHVAE_2level.py:21-27): a
  * contraction over <= 49 taps is bound by the bytes it writes, so it runs in exact fp32 (v_mfma_f32_32x32x2_f32) from an fp32
  * window of the input in LDS (no patch matrix) and leaves as the next layer's pixel image + gate.  evae_cw_supported(d, 3 | 4):

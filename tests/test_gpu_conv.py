@@ -323,3 +323,36 @@ def test_gated_conv_stack_without_gradients():
     finally:
         ops.CONV_STACK_MIN_IMAGES = old_min
     assert rel(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("N,C,H,nblk", [(20, 48, 32, 3), (70, 96, 16, 2), (5, 48, 64, 2), (33, 16, 32, 1)])
+def test_residual_block_run_on_pixel_images_matches_float64(N, C, H, nblk):
+    """A run of residual blocks x + conv(ELU(x)) (reference models/fully_conv.py:13-23) through evae.ops.ResStackFn -- window kernels
+    over pixel images, ELU image written by the block before, ELU' from the saved image, weight gradients over pixel images
+    (48 channels: an odd number of channel groups) -- output and every gradient against torch float64 on the CPU."""
+    from evae import ops
+    rs = np.random.RandomState(N + C + H)
+    x = torch.from_numpy((rs.standard_normal((N, C, H, H)) * 1.5).astype(np.float32))
+    ws = [torch.from_numpy((rs.standard_normal((C, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)) for _ in range(nblk)]
+    bs = [torch.from_numpy((rs.standard_normal(C) * 0.1).astype(np.float32)) for _ in range(nblk)]
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]; br = [b.double().requires_grad_(True) for b in bs]
+    h = xr
+    for w, b in zip(wr, br):
+        h = h + F.conv2d(F.elu(h), w, b, 1, 1)
+    gout = torch.from_numpy(rs.standard_normal(tuple(h.shape)).astype(np.float32))
+    h.backward(gout.double())
+    xd = x.cuda().requires_grad_(True)
+    wd = [w.cuda().requires_grad_(True) for w in ws]; bd = [b.cuda().requires_grad_(True) for b in bs]
+    old = ops.RES_STACK_MIN_PIXELS
+    try:
+        ops.RES_STACK_MIN_PIXELS = 1
+        assert ops.res_stack_supported(xd, wd)
+        y = ops.res_stack(xd, list(zip(wd, bd)))
+        y.backward(gout.cuda())
+    finally:
+        ops.RES_STACK_MIN_PIXELS = old
+    assert rel(y, h) < 2e-5 and rel(xd.grad, xr.grad) < 2e-5
+    for k in range(nblk):
+        assert rel(wd[k].grad, wr[k].grad) < 3e-5, (k, rel(wd[k].grad, wr[k].grad))
+        assert rel(bd[k].grad, br[k].grad) < 3e-5, (k, rel(bd[k].grad, br[k].grad))
