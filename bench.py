@@ -301,12 +301,17 @@ def other_config(a, dev, rank, world, rccl_ranks=1, backend=None):
         # the dominant kernel, timed with HIP events at the shape it has in the step
         with torch.no_grad():
             if c5:
-                nimg, ci, co, k_, hw = 1100, 96, 96, 3, 16      # residual-block convolution over batch + re-encoded exemplars
-                xx = torch.randn(nimg, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
-                w_ = torch.randn(co, ci, k_, k_, device=dev) * 0.03; b_ = torch.zeros(co, device=dev)
-                us = time_launches(lambda: ops.conv2d(xx, w_, b_, 1, 1), reps=2)
+                # a residual block of the decoder (96 channels, 32 x 32, the batch's 100 images) as the step launches it: the window
+                # kernel over pixel images with bias + residual + the next block's ELU image in the epilogue (csrc/evae_conv_win.h)
+                nimg, ci, co, k_, hw = B, 96, 96, 3, 32
+                pr = ops.res_window_probe(nimg, ci, hw, k_)
+                us = time_launches(pr["fwd"], reps=4)
+                us_d = time_launches(pr["dgrad"], reps=4)
+                us_w = time_launches(pr["wgrad"], reps=4)
+                del pr
                 flops = 2.0 * nimg * hw * hw * ci * k_ * k_ * co
-                kern = "channels-last conv 96 -> 96, 3x3, 16 x 16, %d images (evae_conv2d_cl_fwd: gemm_kernel<..., CV = 1>)" % nimg
+                kern = ("residual block 96 -> 96, 3x3, 32 x 32, %d images on pixel images (evae_cw_res_fwd: conv_win_kernel<3, 4, 2, 576>, "
+                        "bias + residual + ELU image in the epilogue)" % nimg)
             else:
                 # the gated 5 x 5 layer of q_z_layers over the exemplar images the step encodes, as the stack launches it: the window
                 # kernel over pre-split pixel images (csrc/evae_conv_win.h)
@@ -320,12 +325,14 @@ def other_config(a, dev, rank, world, rccl_ranks=1, backend=None):
                 flops = 2.0 * nimg * hw * hw * ci * k_ * k_ * 2 * co
                 kern = ("gated conv 32 -> 64, 5x5, 14 x 14, %d images on pixel images (evae_cw_fwd_gated: conv_win_kernel<0, 2, 2, 320>, input "
                         "window resident in LDS, gate + output image in the epilogue)" % nimg)
-        traffic, tsrc = pmc_traffic("conv96_fwd" if c5 else "cw5_fwd", expect=None if c5 else "conv_win_kernel<0, 2, 2, 320>")
+        traffic, tsrc = pmc_traffic("res96_fwd" if c5 else "cw5_fwd", expect="conv_win_kernel<3, 4, 2, 576>" if c5 else "conv_win_kernel<0, 2, 2, 320>")
         if c5:
-            # split-bf16 kernel (csrc/evae_gemm_x6.h): six bf16 partial products per fp32 product
-            executed, pipe = ops.gemm_pipe(nimg * hw * hw, co, False, flops)
-            roof = mfma_roofline(kern.replace("gemm_kernel<..., CV = 1>", "gemm_x6_kernel / gemm_kernel<..., CV = 1>"), flops, executed,
-                                 pipe, us, traffic, tsrc)
+            roof = mfma_roofline(kern, flops, 6.0 * flops, "bf16-mfma", us, traffic, tsrc)
+            roof["kernels"] = [
+                {"launch": "its data gradient dx = dy + ELU'(x) conv_transpose(dy, w) (evae_cw_res_bwd_data: conv_win_kernel<4, 4, 2, 576>)",
+                 "us": round(us_d, 1), "frac": round(flops / us_d / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4)},
+                {"launch": "its weight gradient over pixel images (evae_cw_bwd_weight_plain: conv_wgrad_win_kernel<9, 192, 8> x 3 channel-group pairs + finish)",
+                 "us": round(us_w, 1), "frac": round(flops / us_w / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4)}]
         else:
             roof = mfma_roofline(kern, flops, 6.0 * flops, "bf16-mfma", us, traffic, tsrc)
             roof["kernels"] = [

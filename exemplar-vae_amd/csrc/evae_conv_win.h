@@ -1229,23 +1229,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-// dw[cc][ci][tap] = sum over blocks of part[b][cc][tap][ci]; db[cc] = sum of dbpart[b][cc]  (block order: deterministic)
+// dw[cc][ci][tap] = sum over blocks of part[b][cc][tap][ci]; db[cc] = sum of dbpart[b][cc].  Deterministic: a thread block = 32 outputs
+// x 8 slices of the planes (slice q sums planes q, q + 8, ... in order), the eight slice sums meet in LDS in a fixed order.  (One
+// thread per output walking all 256 planes was a 256-deep dependent chain on ~300 blocks: 109 us per call in the c5 step.)
 __global__ __launch_bounds__(256) void cw_wgrad_finish_kernel(const float* __restrict__ part, const float* __restrict__ dbpart, int nblk, int CC,
                                                               int ntap, int Cin, float* __restrict__ dw, float* __restrict__ db) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float red[8][33];
+  const int lane = threadIdx.x & 31, q = threadIdx.x >> 5;
   const int n = CC * ntap * Cin;
-  if (i < n) {
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + i];
-    const int ci = i % Cin, tap = (i / Cin) % ntap, cc = i / (Cin * ntap);
-    dw[((size_t)cc * Cin + ci) * ntap + tap] = s;
+  const int i = blockIdx.x * 32 + lane;
+  const int nw = (n + 31) / 32;                 // blocks that reduce dw; the rest reduce db
+  float s = 0.f;
+  if (blockIdx.x < nw) {
+    if (i < n)
+      for (int b = q; b < nblk; b += 8) s += part[(size_t)b * n + i];
+  } else {
+    const int j = (blockIdx.x - nw) * 32 + lane;
+    if (db && j < CC)
+      for (int b = q; b < nblk; b += 8) s += dbpart[(size_t)b * CC + j];
   }
-  if (db && i < CC) {
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += dbpart[(size_t)b * CC + i];
-    db[i] = s;
+  red[q][lane] = s;
+  __syncthreads();
+  if (q == 0) {
+    float t = red[0][lane];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][lane];
+    if (blockIdx.x < nw) {
+      if (i < n) {
+        const int ci = i % Cin, tap = (i / Cin) % ntap, cc = i / (Cin * ntap);
+        dw[((size_t)cc * Cin + ci) * ntap + tap] = t;
+      }
+    } else {
+      const int j = (blockIdx.x - nw) * 32 + lane;
+      if (db && j < CC) db[j] = t;
+    }
   }
 }
+static inline int cw_wgrad_finish_blocks(int CC, int ntap, int Cin) { return (CC * ntap * Cin + 31) / 32 + (CC + 31) / 32; }
 
 template <int NTW, int WSL, int NCGDY>
 static int launch_conv_wgrad_win(CwWgradArgs& g, int nblk, hipStream_t stream, const char* what) {

@@ -325,7 +325,7 @@ static int cw_bwd_weight_impl(const void* dyimg, int dy_planar, const void* ximg
       t0 += nt;
     }
   }
-  cw_wgrad_finish_kernel<<<(CC * taps * C + 255) / 256, 256, 0, stream>>>(part, dbp, nblk, CC, taps, C, dw, db);
+  cw_wgrad_finish_kernel<<<cw_wgrad_finish_blocks(CC, taps, C), 256, 0, stream>>>(part, dbp, nblk, CC, taps, C, dw, db);
   return check_launch("cw_wgrad_finish_kernel");
 }
 

@@ -1539,6 +1539,32 @@ def res_stack(x, blocks):
     return ResStackFn.apply(x, *flat)
 
 
+def res_window_probe(N, Cc, H, K=3, seed=0):
+    """Launch closures {fwd, dgrad, wgrad} of ONE residual block x + conv(ELU(x)) (Cc channels, H x H) on the window kernels, on
+    random images prepared once (bench.py's c5 roofline timing, tools/kernel_probe.py)."""
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    d = _lib.ConvDesc(N, Cc, H, H, Cc, K, K, 1, (K - 1) // 2)
+    x = torch.randn((N, H, H, Cc), device=dev, generator=g)
+    w = torch.randn((Cc, Cc, K, K), device=dev, generator=g) * 0.03; b = torch.zeros(Cc, device=dev)
+    img = lambda: torch.empty(int(lib.evae_cw_image_bytes(N * H * H, Cc)), dtype=torch.uint8, device=dev)
+    a, o, dyimg, dximg = img(), img(), img(), img()
+    _lib.check(lib.evae_cw_pack_image(_p(x), N, H, H, Cc, 2, _p(a), _stream()), "evae_cw_pack_image")
+    dy = torch.randn((N, H, H, Cc), device=dev, generator=g) * 0.1
+    _lib.check(lib.evae_cw_pack_image(_p(dy), N, H, H, Cc, 0, _p(dyimg), _stream()), "evae_cw_pack_image")
+    y = torch.empty_like(x); dx = torch.empty_like(x)
+    dw = torch.empty((Cc, Cc * K * K), device=dev); db = torch.empty(Cc, device=dev)
+    w5 = _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(d), 5), dev)
+    w7 = _workspace("cw_wgrad", lib.evae_cw_workspace_bytes(C.byref(d), 7), dev)
+    return {"desc": d,
+            "fwd": lambda: _lib.check(lib.evae_cw_res_fwd(_p(a), C.byref(d), _p(w), _p(b), _p(x), _p(y), _p(o), _p(w5), w5.numel(), _stream()), "evae_cw_res_fwd"),
+            "dgrad": lambda: _lib.check(lib.evae_cw_res_bwd_data(_p(dyimg), C.byref(d), _p(w), _p(a), _p(dy), _p(dx), _p(dximg), _p(w5), w5.numel(),
+                                                                 _stream()), "evae_cw_res_bwd_data"),
+            "wgrad": lambda: _lib.check(lib.evae_cw_bwd_weight_plain(_p(dyimg), _p(a), C.byref(d), _p(dw), _p(db), _p(w7), w7.numel(), _stream()),
+                                        "evae_cw_bwd_weight_plain")}
+
+
 def conv_window_probe(N, Cc, H, Co, K, stride, out_planar=False, seed=0):
     """Launch closures {fwd, dgrad, wgrad} of ONE gated layer (Cc -> Co, K x K, H x H input) on the window kernels, on random
     images prepared once (bench.py's roofline timing, tools/kernel_probe.py's PMC passes): the launches a stack issues for it."""

@@ -23,6 +23,7 @@
   cw5_fwd / cw5_bwd / cw5_wgrad   the same layer over the 20 224 encoded rows of a c3 step on the window kernels (csrc/evae_conv_win.h):
               forward (conv_win_kernel<0, 2, 2, 320>), data gradient + gate derivative (conv_win_kernel<1, 4, 1, 576>), weight gradient
               (conv_wgrad_win_kernel<13 | 12, 192, 8>)
+  res96_fwd / res96_bwd / res96_wgrad   a residual block 96 -> 96, 3 x 3, 32 x 32, 100 images (c5's decoder) on the window kernels
   cw1_fwd / cw1_wgrad   first layer 1 -> 32, 7 x 7, 28 x 28 (conv_first_kernel / conv_first_wgrad_kernel), 20 224 images
   cw2_bwd     data gradient of the stride-2 layer 32 -> 32, 3 x 3 into the first layer's 28 x 28 grid (four parity-class launches)
   conv96_fwd  conv 96 -> 96, 3 x 3, 16 x 16, 1100 images (c5)"""
@@ -165,6 +166,11 @@ elif which in ("cw5_fwd", "cw5_bwd", "cw5_wgrad"):
     pr = ops.conv_window_probe(int(os.environ.get("EVAE_PROBE_ROWS", "20224")), 32, 14, 64, 5, 1, out_planar=True)
     fn = pr[{"cw5_fwd": "fwd", "cw5_bwd": "dgrad", "cw5_wgrad": "wgrad"}[which]]
     for _ in range(reps):
+        fn()
+elif which in ("res96_fwd", "res96_bwd", "res96_wgrad"):
+    pr = ops.res_window_probe(100, 96, 32)
+    fn = pr[{"res96_fwd": "fwd", "res96_bwd": "dgrad", "res96_wgrad": "wgrad"}[which]]
+    for _ in range(reps * 4):
         fn()
 elif which == "cw2_bwd":
     pr = ops.conv_window_probe(int(os.environ.get("EVAE_PROBE_ROWS", "20224")), 32, 28, 32, 3, 2)

@@ -263,7 +263,7 @@ static void case_wgrad(int N, Layer L, int dcs, int reps) {
     launch_conv_wgrad_win<13, WSL, 8>(ga, nblk, 0, "cw wgrad");
     launch_conv_wgrad_win<12, WSL, 8>(gb, nblk, 0, "cw wgrad");
     const int nb = (int)((size_t)ga.nchunk + ga.cper - 1) / ga.cper;
-    cw_wgrad_finish_kernel<<<(CC * taps * C + 255) / 256, 256>>>(part, dbp, nb, CC, taps, C, dw, db);
+    cw_wgrad_finish_kernel<<<cw_wgrad_finish_blocks(CC, taps, C), 256>>>(part, dbp, nb, CC, taps, C, dw, db);
   };
   run();
   CK(hipDeviceSynchronize());

@@ -14,7 +14,7 @@ what=${@:-bench stats pmc timeline}
 cd /tmp && export TMPDIR=/tmp
 cd $root
 CFGS=${CFGS:-c2 c2a c1 c4 c3 c5 iwae topk}
-PROBES=${PROBES:-u8fwd1 u8fwd1_img fwd2_p6 hdgrad2_img dgrad2_p6 wgrad2_p6 u8wgrad1 hwgrad fwd2 dgrad2 wgrad2 prior_iwae prior_c5 prior_train prior_train1 topk_c5 topk_c2 cw5_fwd cw5_bwd cw5_wgrad cw2_bwd cw1_fwd cw1_wgrad conv96_fwd}
+PROBES=${PROBES:-u8fwd1 u8fwd1_img fwd2_p6 hdgrad2_img dgrad2_p6 wgrad2_p6 u8wgrad1 hwgrad fwd2 dgrad2 wgrad2 prior_iwae prior_c5 prior_train prior_train1 topk_c5 topk_c2 cw5_fwd cw5_bwd cw5_wgrad cw2_bwd cw1_fwd cw1_wgrad res96_fwd res96_bwd res96_wgrad}
 steps_of() { case $1 in c3) echo "--steps 20 --warmup 6";; c5) echo "--steps 20 --warmup 4";; *) echo "";; esac; }
 for w in $what; do
   if [ $w = bench ]; then
