@@ -971,22 +971,25 @@ struct CwWgGeom {
 };
 
 // NTW column tiles (taps) per launch, window of WSL slots on the input grid, NCGDY channel groups of dy.  Eight waves, two per SIMD:
-// wave = (row tile mt = wave & 3: merged channels 32 mt .., column half ch = wave >> 2); the NTW + 1 columns (the taps' tiles, then
-// the bias column) are dealt to the two halves, NCW = ceil((NTW + 1) / 2) each (a last dummy column when NTW + 1 is odd).  One wave per
-// SIMD with all columns was measured first: issue-bound (a transpose read and its address add per MFMA in ONE instruction stream:
-// 42 % of the matrix rate); with two waves a SIMD issues one wave's reads under the other's MFMAs.
+// wave = (row tile wm = wave % MW: merged channels 32 wm .., column part ch = wave / MW); MW = 4 row tiles (<= 128 merged channels)
+// x 2 column halves, or MW = 2 (<= 64 merged channels: NCGDY <= 4) x 4 column quarters -- so that every wave has a row tile that
+// exists.  The NTW + 1 columns (the taps' tiles, then the bias column) are dealt to the column parts, NCW = ceil((NTW + 1) / parts)
+// each (dummy columns at the end).  One wave per SIMD with all columns was measured first: issue-bound (a transpose read and its
+// address add per MFMA in ONE instruction stream: 42 % of the matrix rate); with two waves a SIMD issues one wave's reads under the
+// other's MFMAs.
 template <int NTW, int WSL, int NCGDY>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_win_kernel(const CwWgradArgs g) {
   typedef CwWgGeom<NTW, WSL, NCGDY> G;
   constexpr int RK = G::RK, NKS = RK / 16, NW = 8;
-  constexpr int NCW = (NTW + 2) / 2;               // columns per wave
+  constexpr int MW = NCGDY <= 4 ? 2 : 4, CQ = NW / MW;
+  constexpr int NCW = (NTW + 1 + CQ - 1) / CQ;     // columns per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = reinterpret_cast<char*>(smem);
   const unsigned lds_base = (unsigned)(uintptr_t)(p6_lds_t)lds;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < NW);
-  const int wm = wave & 3, ch = wave >> 2;
+  const int wm = wave % MW, ch = wave / MW;
   const int l31 = lane & 31, lh = lane >> 5, ib = (lane >> 4) & 1, t16 = lane & 15;
   const int HW = g.H * g.W;
   const int c0 = blockIdx.x * g.cper, c1 = min(c0 + g.cper, g.nchunk);
@@ -1171,7 +1174,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int p = 0; p < 3; ++p)
             if (j + u < NCW) {
               u32x4_ v = {br[t & 1][u][p].lo[0], br[t & 1][u][p].lo[1], br[t & 1][u][p].hi[0], br[t & 1][u][p].hi[1]};
-              if (NCW + j + u >= NTW) {            // this column may be the bias column (of the second half): the ones operand instead
+              if ((CQ - 1) * NCW + j + u >= NTW) {  // this column may be the bias column (of a later column part): the ones operand instead
                 const unsigned o = p == 0 ? one1 : 0u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = isb[j + u] ? o : v[q];

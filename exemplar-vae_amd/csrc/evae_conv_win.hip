@@ -316,6 +316,7 @@ static int cw_bwd_weight_impl(const void* dyimg, int dy_planar, const void* ximg
       int rc;
       if (variant == 1) rc = nt == 13 ? launch_conv_wgrad_win<13, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight")
                                       : launch_conv_wgrad_win<12, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      else if (variant == 2 && CC <= 64) rc = launch_conv_wgrad_win<9, 192, 4>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
       else if (variant == 2) rc = launch_conv_wgrad_win<9, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
       else if (variant == 3) rc = launch_conv_wgrad_win<9, 320, 4>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
       else rc = launch_conv_wgrad_win<9, 256, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
