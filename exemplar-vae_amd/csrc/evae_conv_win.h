@@ -100,6 +100,7 @@ struct ConvWinArgs {
   const unsigned char* eimg;  // CW_DGRAD_GATE: pixel image of the forward output of the layer below (nks_e groups, channel ech0 + c) ...
   int nks_e, ech0;
   const float* e_s;           // ... and its gate [rows][Co]: [dh | dg] = [v s | v out (1 - s)]
+  int stagger;                // launches of more than one round of blocks: the first 512 blocks start (id / 128) * stagger * 2048 clocks late
   int dbg;
 };
 
@@ -231,9 +232,20 @@ enum { CW_FWD_GATED = 0, CW_DGRAD_GATE = 1, CW_PLAIN = 2, CW_RES_FWD = 3, CW_RES
 // The epilogue of a block tile (R pixels x BN columns; acc in the matrix core's C layout, 4 waves as WR x WC, wave tile 64 x 32 NT),
 // shared by the window kernels and the first-layer kernel; every wave of the block must have left its main loop (the staging
 // reuses the loop's LDS).
+// ELU for the image of a residual block's output: y > 0 ? y : e^y - 1, branch-free (the library expm1f is a divergent call per element):
+// below -0.35 the hardware exponential minus one loses no more than ~3e-7 relative, above it the series (next term < 6e-9)
+__device__ __forceinline__ float cw_elu(float y) {
+  const float u = __builtin_amdgcn_exp2f(1.4426950408889634f * y) - 1.0f;
+  const float p = y * (1.0f + y * (0.5f + y * (0.16666667f + y * (0.041666668f + y * (0.0083333338f + y * (0.0013888889f + y * 0.0001984127f))))));
+  const float e = y < -0.35f ? u : p;
+  return y > 0.f ? y : e;
+}
+
+// bias[]: the bias of this lane's column in each column tile (gated: h, g), loaded by the caller before its main loop; cok0: gated --
+// this lane's column is a real channel
 template <int EPI, int R, int BN, int NT, int WC>
-__device__ __forceinline__ void cw_epilogue(const ConvWinArgs& g, f32x16 (&acc)[2][NT], const int m0, const int tn, const int wr, const int wc,
-                                            const int lane, const int tid, float* const smem) {
+__device__ __forceinline__ void cw_epilogue(const ConvWinArgs& g, f32x16 (&acc)[2][NT], const float (&bias)[2], const bool cok0, const int m0, const int tn,
+                                            const int wr, const int wc, const int lane, const int tid, float* const smem) {
   constexpr int MT = 2;
   constexpr bool GATED = EPI == CW_FWD_GATED;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -246,146 +258,201 @@ __device__ __forceinline__ void cw_epilogue(const ConvWinArgs& g, f32x16 (&acc)[
   constexpr int RP = BNO + 4;
   float* const so = smem;                       // [R][RP]
   float* const ss = smem + R * RP;              // [R][RP]   (gated: the gate)
+  // pieces (row, 8 channels): thread -> row fastest inside 16 (the 16 pixels of an image chunk), then the 8-channel group, then the
+  // 16-row groups: the 32 lanes of a (chunk, channel group) pair fill whole 512-byte chunks of the image.
+  // What a piece reads from memory (residual / upstream gradient e_s, the saved image eimg) is requested for a GROUP of pieces at a
+  // time, one group ahead of the group being finished, the first one before the accumulators are staged: a request's latency (and
+  // that of the stores in front of it -- loads and stores retire in order) is paid once per block, not once per piece.
+  constexpr int C8 = BNO / 8, NPC = R * C8 / 256, GP = NPC < 4 ? NPC : 4, NG = NPC / GP;
+  static_assert(NPC % GP == 0, "pieces per thread: whole groups");
+  constexpr bool RD_S = EPI == CW_RES_FWD || EPI == CW_RES_BWD || EPI == CW_DGRAD_GATE;
+  constexpr bool RD_I = EPI == CW_RES_BWD || EPI == CW_DGRAD_GATE;
+  unsigned pm[NPC], pmn[NPC];                // rows of piece i: in the pixel images / in the fp32 tensors
+  bool pok[NPC];
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int pid = tid + 256 * i;
+    const int r16 = pid & 15, c8 = (pid >> 4) % C8, rg = pid / (16 * C8);
+    const int mm = m0 + rg * 16 + r16;
+    pok[i] = mm < g.M && tn * BNO + c8 * 8 < g.Co;
+    const unsigned mc = pok[i] ? (unsigned)mm : 0u;               // (an idle piece reads pixel 0: a valid address, nothing stored)
+    const unsigned n = fdiv(mc, g.div_hw), rem = mc - n * (unsigned)HW;
+    const unsigned y = fdiv(rem, g.div_w), x = rem - y * (unsigned)g.W;
+    pm[i] = g.out_planar ? n * (unsigned)HW + (unsigned)cw_planar((int)y, (int)x, g.H, g.W) : n * (unsigned)g.ostride + (unsigned)g.ooff + rem;
+    pmn[i] = (n * (unsigned)g.nat_h + y * (unsigned)g.nat_s + (unsigned)g.nat_y) * (unsigned)g.nat_w + x * (unsigned)g.nat_s + (unsigned)g.nat_x;
+  }
+  float4 es[2][GP][2];
+  uint4 ei[2][GP][3];
+  auto request = [&](auto set_, int gi) {
+    constexpr int set = decltype(set_)::value;
+#pragma unroll
+    for (int j = 0; j < GP; ++j) {
+      const int i = gi * GP + j, pid = tid + 256 * i, c8 = (pid >> 4) % C8;
+      const int ch = pok[i] ? tn * BNO + c8 * 8 : 0;
+      if constexpr (RD_S) {
+        const float* rp = g.e_s + (size_t)pmn[i] * g.Co + ch;
+        es[set][j][0] = *reinterpret_cast<const float4*>(rp); es[set][j][1] = *reinterpret_cast<const float4*>(rp + 4);
+      }
+      if constexpr (RD_I) {
+        const unsigned char* e = g.eimg + p6_off64(pm[i], g.ech0 + ch, g.nks_e);
+        ei[set][j][0] = *reinterpret_cast<const uint4*>(e); ei[set][j][1] = *reinterpret_cast<const uint4*>(e + P6_CHUNK);
+        ei[set][j][2] = *reinterpret_cast<const uint4*>(e + 2 * P6_CHUNK);
+      }
+    }
+  };
+  constexpr std::integral_constant<int, 0> S0{};
+  constexpr std::integral_constant<int, 1> S1{};
+  if constexpr (RD_S || RD_I) request(S0, 0);
+
   if constexpr (GATED) {
-    const int cl = wc * 32 + l31, c = tn * BNO + cl;
-    const bool cok = c < g.Co;
-    const float bh = (g.bias0 && cok) ? g.bias0[c] : 0.f, bg = (g.bias1 && cok) ? g.bias1[c] : 0.f;
+    const int cl = wc * 32 + l31;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float h = acc[mt][0][r] + bh;
-        const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc[mt][1][r] + bg)));
-        so[row * RP + cl] = cok ? h * s : 0.f;
+        const float h = acc[mt][0][r] + bias[0];
+        const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc[mt][1][r] + bias[1])));
+        so[row * RP + cl] = cok0 ? h * s : 0.f;
         ss[row * RP + cl] = s;
       }
   } else {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int cl = wc * 32 * NT + nt * 32 + l31, c = tn * BNO + cl;
-      const float b = ((EPI == CW_PLAIN || EPI == CW_RES_FWD) && g.bias0 && c < g.Co) ? g.bias0[c] : 0.f;
+      const int cl = wc * 32 * NT + nt * 32 + l31;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          so[row * RP + cl] = acc[mt][nt][r] + b;
+          so[row * RP + cl] = acc[mt][nt][r] + bias[nt];
         }
     }
   }
   __syncthreads();
-  // pieces (row, 8 channels): thread -> row fastest inside 16 (the 16 pixels of an image chunk), then the 8-channel group, then the
-  // 16-row groups: the 32 lanes of a (chunk, channel group) pair fill whole 512-byte chunks of the image
-  constexpr int C8 = BNO / 8, NPC = R * C8 / 256;
+
+  auto finish = [&](auto set_, int gi) {
+    constexpr int set = decltype(set_)::value;
 #pragma unroll
-  for (int i = 0; i < NPC; ++i) {
-    const int pid = tid + 256 * i;
-    const int r16 = pid & 15, c8 = (pid >> 4) % C8, rg = pid / (16 * C8);
-    const int row = rg * 16 + r16, mm = m0 + row;
-    const int ch = tn * BNO + c8 * 8;                         // first of the eight result columns
-    if (mm >= g.M || ch >= g.Co) continue;
-    // rows of pixel mm = (n, y, x): m in the pixel images, mn in the fp32 tensors
-    size_t m, mn;
-    {
-      const unsigned n = fdiv((unsigned)mm, g.div_hw), rem = (unsigned)mm - n * (unsigned)HW;
-      const unsigned y = fdiv(rem, g.div_w), x = rem - y * (unsigned)g.W;
-      m = g.out_planar ? (size_t)n * HW + cw_planar((int)y, (int)x, g.H, g.W) : (size_t)n * g.ostride + g.ooff + rem;
-      mn = ((size_t)n * g.nat_h + y * g.nat_s + g.nat_y) * g.nat_w + x * g.nat_s + g.nat_x;
+    for (int j = 0; j < GP; ++j) {
+      const int i = gi * GP + j, pid = tid + 256 * i;
+      const int r16 = pid & 15, c8 = (pid >> 4) % C8, rg = pid / (16 * C8);
+      const int row = rg * 16 + r16;
+      const int ch = tn * BNO + c8 * 8;                         // first of the eight result columns
+      const size_t m = pm[i], mn = pmn[i];
+      const float4 o0 = *reinterpret_cast<const float4*>(so + row * RP + c8 * 8), o1 = *reinterpret_cast<const float4*>(so + row * RP + c8 * 8 + 4);
+      auto put_img = [&](int chan, const float4& a, const float4& b) {
+        unsigned t0[4], t1[4], t2[4];
+        p6_split2(a.x, a.y, t0[0], t1[0], t2[0]); p6_split2(a.z, a.w, t0[1], t1[1], t2[1]);
+        p6_split2(b.x, b.y, t0[2], t1[2], t2[2]); p6_split2(b.z, b.w, t0[3], t1[3], t2[3]);
+        unsigned char* o = g.oimg + p6_off64(m, chan, g.nks_o);
+        *reinterpret_cast<uint4*>(o) = make_uint4(t0[0], t0[1], t0[2], t0[3]);
+        *reinterpret_cast<uint4*>(o + P6_CHUNK) = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+        *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+      };
+      // element k of the saved image's piece: the sum of its three bf16 terms, smallest first (reproduces the fp32 value they were split from)
+      auto img_val = [&](int k) -> float {
+        const unsigned w0[4] = {ei[set][j][0].x, ei[set][j][0].y, ei[set][j][0].z, ei[set][j][0].w};
+        const unsigned w1[4] = {ei[set][j][1].x, ei[set][j][1].y, ei[set][j][1].z, ei[set][j][1].w};
+        const unsigned w2[4] = {ei[set][j][2].x, ei[set][j][2].y, ei[set][j][2].z, ei[set][j][2].w};
+        const int sh = 16 * (k & 1);
+        return (__uint_as_float(((w2[k >> 1] >> sh) & 0xFFFFu) << 16) + __uint_as_float(((w1[k >> 1] >> sh) & 0xFFFFu) << 16)) +
+               __uint_as_float(((w0[k >> 1] >> sh) & 0xFFFFu) << 16);
+      };
+      const float v[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+      const float rv[8] = {es[set][j][0].x, es[set][j][0].y, es[set][j][0].z, es[set][j][0].w, es[set][j][1].x, es[set][j][1].y, es[set][j][1].z, es[set][j][1].w};
+      if (!pok[i]) continue;
+      if constexpr (GATED) {
+        const float4 s0 = *reinterpret_cast<const float4*>(ss + row * RP + c8 * 8), s1 = *reinterpret_cast<const float4*>(ss + row * RP + c8 * 8 + 4);
+        if (g.oimg) put_img(g.och0 + ch, o0, o1);
+        if (g.out_s) {
+          float* sp = g.out_s + mn * g.Co + ch;
+          *reinterpret_cast<float4*>(sp) = s0; *reinterpret_cast<float4*>(sp + 4) = s1;
+        }
+        if (g.out_f) {
+          float* op = g.out_f + mn * g.ldo + ch;
+          *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
+        }
+      } else if constexpr (EPI == CW_PLAIN) {
+        if (g.oimg) put_img(g.och0 + ch, o0, o1);
+        if (g.out_f) {
+          float* op = g.out_f + mn * g.ldo + ch;
+          *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
+        }
+      } else if constexpr (EPI == CW_RES_FWD) {
+        // residual block of models/fully_conv.py:13-23: y = x + conv(ELU(x)) + b.  e_s = x (fp32, natural rows); out_f = y; oimg = the
+        // image of ELU(y): the next block's convolution operand AND what its backward derives ELU'(y) from
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = v[k] + rv[k];
+        if (g.out_f) {
+          float* op = g.out_f + mn * g.ldo + ch;
+          *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        }
+        if (g.oimg) {
+          float a[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a[k] = cw_elu(y[k]);
+          put_img(g.och0 + ch, make_float4(a[0], a[1], a[2], a[3]), make_float4(a[4], a[5], a[6], a[7]));
+        }
+      } else if constexpr (EPI == CW_RES_BWD) {
+        // its data gradient: dx = dy + ELU'(x) * conv_transpose(dy, w), ELU'(x) = (a > 0 ? 1 : a + 1) with a = ELU(x) summed back from
+        // its image (eimg); e_s = dy (fp32, natural rows); out_f = dx, oimg = the image of dx (the next data / weight gradients' operand)
+        float dx[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float av = img_val(k);
+          dx[k] = rv[k] + (av > 0.f ? 1.0f : av + 1.0f) * v[k];
+        }
+        if (g.out_f) {
+          float* op = g.out_f + mn * g.ldo + ch;
+          *reinterpret_cast<float4*>(op) = make_float4(dx[0], dx[1], dx[2], dx[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(dx[4], dx[5], dx[6], dx[7]);
+        }
+        if (g.oimg) put_img(g.och0 + ch, make_float4(dx[0], dx[1], dx[2], dx[3]), make_float4(dx[4], dx[5], dx[6], dx[7]));
+      } else {
+        // gate derivative of the layer below at (pixel m, channels ch .. ch + 7): out = the sum of its image's three terms (exact), s
+        // fp32 (e_s); dh = v s, dg = v out (1 - s)   (reference utils/nn.py:92-97 under autograd)
+        float dh[8], dg[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float ov = img_val(k);
+          dh[k] = v[k] * rv[k];
+          dg[k] = v[k] * ov * (1.0f - rv[k]);
+        }
+        if (g.oimg) {
+          put_img(g.och0 + ch, make_float4(dh[0], dh[1], dh[2], dh[3]), make_float4(dh[4], dh[5], dh[6], dh[7]));
+          put_img(g.och0 + g.Co + ch, make_float4(dg[0], dg[1], dg[2], dg[3]), make_float4(dg[4], dg[5], dg[6], dg[7]));
+        }
+        if (g.out_f) {
+          float* op = g.out_f + mn * g.ldo + ch;
+          *reinterpret_cast<float4*>(op) = make_float4(dh[0], dh[1], dh[2], dh[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(dh[4], dh[5], dh[6], dh[7]);
+          *reinterpret_cast<float4*>(op + g.Co) = make_float4(dg[0], dg[1], dg[2], dg[3]); *reinterpret_cast<float4*>(op + g.Co + 4) = make_float4(dg[4], dg[5], dg[6], dg[7]);
+        }
+      }
     }
-    const float4 o0 = *reinterpret_cast<const float4*>(so + row * RP + c8 * 8), o1 = *reinterpret_cast<const float4*>(so + row * RP + c8 * 8 + 4);
-    auto put_img = [&](int chan, const float4& a, const float4& b) {
-      unsigned t0[4], t1[4], t2[4];
-      p6_split2(a.x, a.y, t0[0], t1[0], t2[0]); p6_split2(a.z, a.w, t0[1], t1[1], t2[1]);
-      p6_split2(b.x, b.y, t0[2], t1[2], t2[2]); p6_split2(b.z, b.w, t0[3], t1[3], t2[3]);
-      unsigned char* o = g.oimg + p6_off64(m, chan, g.nks_o);
-      *reinterpret_cast<uint4*>(o) = make_uint4(t0[0], t0[1], t0[2], t0[3]);
-      *reinterpret_cast<uint4*>(o + P6_CHUNK) = make_uint4(t1[0], t1[1], t1[2], t1[3]);
-      *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = make_uint4(t2[0], t2[1], t2[2], t2[3]);
-    };
-    if constexpr (GATED) {
-      const float4 s0 = *reinterpret_cast<const float4*>(ss + row * RP + c8 * 8), s1 = *reinterpret_cast<const float4*>(ss + row * RP + c8 * 8 + 4);
-      if (g.oimg) put_img(g.och0 + ch, o0, o1);
-      if (g.out_s) {
-        float* sp = g.out_s + mn * g.Co + ch;
-        *reinterpret_cast<float4*>(sp) = s0; *reinterpret_cast<float4*>(sp + 4) = s1;
-      }
-      if (g.out_f) {
-        float* op = g.out_f + mn * g.ldo + ch;
-        *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
-      }
-    } else if constexpr (EPI == CW_PLAIN) {
-      if (g.oimg) put_img(g.och0 + ch, o0, o1);
-      if (g.out_f) {
-        float* op = g.out_f + mn * g.ldo + ch;
-        *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
-      }
-    } else if constexpr (EPI == CW_RES_FWD) {
-      // residual block of models/fully_conv.py:13-23: y = x + conv(ELU(x)) + b.  e_s = x (fp32, natural rows); out_f = y; oimg = the
-      // image of ELU(y): the next block's convolution operand AND what its backward derives ELU'(y) from
-      const float* rp = g.e_s + mn * g.Co + ch;
-      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-      const float y[8] = {o0.x + r0.x, o0.y + r0.y, o0.z + r0.z, o0.w + r0.w, o1.x + r1.x, o1.y + r1.y, o1.z + r1.z, o1.w + r1.w};
-      if (g.out_f) {
-        float* op = g.out_f + mn * g.ldo + ch;
-        *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(y[4], y[5], y[6], y[7]);
-      }
-      if (g.oimg) {
-        float a[8];
+  };
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a[k] = y[k] > 0.f ? y[k] : expm1f(y[k]);
-        put_img(g.och0 + ch, make_float4(a[0], a[1], a[2], a[3]), make_float4(a[4], a[5], a[6], a[7]));
-      }
-    } else if constexpr (EPI == CW_RES_BWD) {
-      // its data gradient: dx = dy + ELU'(x) * conv_transpose(dy, w), ELU'(x) = (a > 0 ? 1 : a + 1) with a = ELU(x) summed back from
-      // its image (eimg); e_s = dy (fp32, natural rows); out_f = dx, oimg = the image of dx (the next data / weight gradients' operand)
-      const unsigned char* e = g.eimg + p6_off64(m, g.ech0 + ch, g.nks_e);
-      const uint4 e0 = *reinterpret_cast<const uint4*>(e), e1 = *reinterpret_cast<const uint4*>(e + P6_CHUNK), e2 = *reinterpret_cast<const uint4*>(e + 2 * P6_CHUNK);
-      const float* rp = g.e_s + mn * g.Co + ch;
-      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-      const unsigned w0[4] = {e0.x, e0.y, e0.z, e0.w}, w1[4] = {e1.x, e1.y, e1.z, e1.w}, w2[4] = {e2.x, e2.y, e2.z, e2.w};
-      const float v[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w}, rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-      float dx[8];
+  for (int gi = 0; gi < NG; ++gi) {
+    if (gi & 1) { if constexpr (RD_S || RD_I) { if (gi + 1 < NG) request(S0, gi + 1); } finish(S1, gi); }
+    else { if constexpr (RD_S || RD_I) { if (gi + 1 < NG) request(S1, gi + 1); } finish(S0, gi); }
+  }
+}
+
+// the bias of this lane's columns (see cw_epilogue), requested before the main loop
+template <int EPI, int BN, int NT, int WC>
+__device__ __forceinline__ void cw_load_bias(const ConvWinArgs& g, int tn, int wc, int lane, float (&bias)[2], bool& cok0) {
+  const int l31 = lane & 31;
+  bias[0] = bias[1] = 0.f; cok0 = true;
+  if constexpr (EPI == CW_FWD_GATED) {
+    const int c = tn * (BN / 2) + wc * 32 + l31;
+    cok0 = c < g.Co;
+    if (g.bias0 && cok0) bias[0] = g.bias0[c];
+    if (g.bias1 && cok0) bias[1] = g.bias1[c];
+  } else if constexpr (EPI == CW_PLAIN || EPI == CW_RES_FWD) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int sh = 16 * (k & 1);
-        const float av = (__uint_as_float(((w2[k >> 1] >> sh) & 0xFFFFu) << 16) + __uint_as_float(((w1[k >> 1] >> sh) & 0xFFFFu) << 16)) +
-                         __uint_as_float(((w0[k >> 1] >> sh) & 0xFFFFu) << 16);
-        dx[k] = rv[k] + (av > 0.f ? 1.0f : av + 1.0f) * v[k];
-      }
-      if (g.out_f) {
-        float* op = g.out_f + mn * g.ldo + ch;
-        *reinterpret_cast<float4*>(op) = make_float4(dx[0], dx[1], dx[2], dx[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(dx[4], dx[5], dx[6], dx[7]);
-      }
-      if (g.oimg) put_img(g.och0 + ch, make_float4(dx[0], dx[1], dx[2], dx[3]), make_float4(dx[4], dx[5], dx[6], dx[7]));
-    } else {
-      // gate derivative of the layer below at (pixel m, channels ch .. ch + 7): out = the sum of its image's three terms (exact), s
-      // fp32; dh = v s, dg = v out (1 - s)   (reference utils/nn.py:92-97 under autograd)
-      const unsigned char* e = g.eimg + p6_off64(m, g.ech0 + ch, g.nks_e);
-      const uint4 e0 = *reinterpret_cast<const uint4*>(e), e1 = *reinterpret_cast<const uint4*>(e + P6_CHUNK), e2 = *reinterpret_cast<const uint4*>(e + 2 * P6_CHUNK);
-      const float* sp = g.e_s + mn * g.Co + ch;
-      const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
-      const unsigned w0[4] = {e0.x, e0.y, e0.z, e0.w}, w1[4] = {e1.x, e1.y, e1.z, e1.w}, w2[4] = {e2.x, e2.y, e2.z, e2.w};
-      const float v[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-      float dh[8], dg[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int sh = 16 * (k & 1);
-        // smallest terms first: the sum of the three bf16 terms reproduces the fp32 value they were split from
-        const float ov = (__uint_as_float(((w2[k >> 1] >> sh) & 0xFFFFu) << 16) + __uint_as_float(((w1[k >> 1] >> sh) & 0xFFFFu) << 16)) +
-                         __uint_as_float(((w0[k >> 1] >> sh) & 0xFFFFu) << 16);
-        dh[k] = v[k] * sv[k];
-        dg[k] = v[k] * ov * (1.0f - sv[k]);
-      }
-      if (g.oimg) {
-        put_img(g.och0 + ch, make_float4(dh[0], dh[1], dh[2], dh[3]), make_float4(dh[4], dh[5], dh[6], dh[7]));
-        put_img(g.och0 + g.Co + ch, make_float4(dg[0], dg[1], dg[2], dg[3]), make_float4(dg[4], dg[5], dg[6], dg[7]));
-      }
-      if (g.out_f) {
-        float* op = g.out_f + mn * g.ldo + ch;
-        *reinterpret_cast<float4*>(op) = make_float4(dh[0], dh[1], dh[2], dh[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(dh[4], dh[5], dh[6], dh[7]);
-        *reinterpret_cast<float4*>(op + g.Co) = make_float4(dg[0], dg[1], dg[2], dg[3]); *reinterpret_cast<float4*>(op + g.Co + 4) = make_float4(dg[4], dg[5], dg[6], dg[7]);
-      }
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c = tn * BN + wc * 32 * NT + nt * 32 + l31;
+      if (g.bias0 && c < g.Co) bias[nt] = g.bias0[c];
     }
   }
 }
@@ -417,6 +484,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
   const int m0 = tm * R;
   const int HW = g.H * g.W;
+  // Blocks that start together reach their epilogues together: the memory system then sees the stores of all 512 resident blocks
+  // at once while every matrix pipe idles, and the two blocks of a CU cannot cover each other.  The first resident blocks therefore
+  // start in four groups a fraction of a block's duration apart (measured on the residual blocks of fully_conv: -10 .. -16 %).
+  if (g.stagger > 0 && blockIdx.x < 512) {
+    const int nsl = (int)(blockIdx.x >> 7) * g.stagger;
+    for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(32);       // 2048 clocks a unit
+  }
 
   // first pixel of the block -> base slot; base pixel of the buffer resource (16-pixel aligned, at or before every pixel a tap reads)
   const unsigned nf = fdiv((unsigned)m0, g.div_hw), remf = (unsigned)m0 - nf * (unsigned)HW;
@@ -427,6 +501,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int base_pix = __builtin_amdgcn_readfirstlane((int)((nf * (unsigned)g.istride) & ~15u));
   const rsrc_t rB = make_rsrc(g.wimg + (size_t)tn * (BN / 16) * g.nks_w * P6_GROUP, 0x7FFFFFFFu);
 
+  float bias[2];
+  bool cok0;
+  cw_load_bias<EPI, BN, NT, WC>(g, tn, wc, lane, bias, cok0);
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -541,7 +618,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int jj = 0; jj < (SLOTS / 32 + 3) / 4; ++jj) {
         const int j = wave + 4 * jj;
+#ifdef EVAE_CW_ABL
+        if (j < g.nsp && !((g.dbg & 8) && ksc > 0)) {          // (tools: only the first window of a block is copied)
+#else
         if (j < g.nsp) {
+#endif
           const int s = 32 * j + (lane >> 1), hp = lane & 1;
           const unsigned q = (unsigned)(qbase + s);
           const unsigned n = fdiv(q, g.div_sp), r = q - n * (unsigned)g.SP;
@@ -640,9 +721,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 #undef EVAE_CW_SB
   __syncthreads();                 // the epilogue stages through the window's LDS
-  if (g.dbg == 4) return;
+  if (g.dbg & 4) return;
 
-  cw_epilogue<EPI, R, BN, NT, WC>(g, acc, m0, tn, wr, wc, lane, tid, smem);
+  cw_epilogue<EPI, R, BN, NT, WC>(g, acc, bias, cok0, m0, tn, wr, wc, lane, tid, smem);
 }
 
 template <int EPI, int WR, int NT, int SLOTS>
@@ -661,6 +742,8 @@ static int launch_conv_win(ConvWinArgs& g, hipStream_t stream, const char* what)
   if (g.nat_s == 0) { g.nat_s = 1; g.nat_h = g.H; g.nat_w = g.W; g.nat_y = g.nat_x = 0; }
   g.M = g.N * g.H * g.W;
   const int tiles_m = cdiv(g.M, G::R);
+  if (g.stagger == 0 && tiles_m * g.tiles_n > 640) { const int u = g.nks_w / 8; g.stagger = u < 1 ? 1 : (u > 8 ? 8 : u); }
+  if (g.stagger < 0) g.stagger = 0;
   conv_win_kernel<EPI, WR, NT, SLOTS><<<dim3(tiles_m * g.tiles_n), 256, G::lds_bytes(EPI == CW_FWD_GATED), stream>>>(g);
   return check_launch(what);
 }
@@ -763,7 +846,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[par][mt], wv[nt][ks], acc[mt][nt], 0, 0, 0);
   }
   __syncthreads();
-  cw_epilogue<CW_FWD_GATED, R, 64, NT, 1>(g, acc, m0, tn, wave, 0, lane, tid, smem);
+  float bias[2];
+  bool cok0;
+  cw_load_bias<CW_FWD_GATED, 64, NT, 1>(g, tn, 0, lane, bias, cok0);
+  cw_epilogue<CW_FWD_GATED, R, 64, NT, 1>(g, acc, bias, cok0, m0, tn, wave, 0, lane, tid, smem);
 }
 
 template <int SLOTS>

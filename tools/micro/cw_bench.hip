@@ -1,6 +1,7 @@
 // Stand-alone check + timing of the window convolution kernels (csrc/evae_conv_win.h) at convhvae_2level's layer shapes.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -w -I exemplar-vae_amd/csrc tools/micro/cw_bench.hip -o tools/micro/cw_bench
 // Run on the GPU box: tools/micro/cw_bench [images] [reps]
+#define EVAE_CW_ABL 1
 #include "evae_conv_win.h"
 #include <cstdarg>
 #include <cstdio>
@@ -27,7 +28,7 @@ template <class T> static T* dev(const std::vector<T>& h) { T* p; CK(hipMalloc(&
 template <class T> static T* devz(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T))); CK(hipMemset(p, 0, n * sizeof(T))); return p; }
 template <class F> static float time_us(F f, int reps) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for (int i = 0; i < 3; ++i) f();
+  for (int i = 0; i < 3 + reps; ++i) f();           // (warm clocks: as many launches as are timed)
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(a));
   for (int i = 0; i < reps; ++i) f();
@@ -86,6 +87,7 @@ static void case_fwd(int N, Layer L, int ocs, int reps) {
   g.wimg = iw; g.nks_w = nks_w; g.Co = Co; g.tiles_n = tiles_n; g.bias0 = dbh; g.bias1 = dbg;
   g.out_planar = ocs == 2;
   g.oimg = io; g.nks_o = nks_o; g.och0 = 0; g.out_s = ds; g.out_f = dout; g.ldo = Co;
+  if (getenv("CW_STAG")) g.stagger = atoi(getenv("CW_STAG"));
   char what[128]; snprintf(what, sizeof what, "cw fwd   N=%d C=%d Hin=%d Co=%d k=%d s=%d (out rows %s)", N, C, Hin, Co, K, st, ocs == 2 ? "planar" : "natural");
   bool ok;
   if (bn == 128) ok = setup_geom<2, 2, 320>(g, H, plo, phi, what); else ok = setup_geom<4, 2, 576>(g, H, plo, phi, what);
@@ -175,6 +177,7 @@ static void case_dgrad(int N, Layer L, int dcs, int reps) {
       bool ok;
       if (C == 32) ok = setup_geom<4, 1, 576>(g, H, plo, phi, what); else ok = setup_geom<4, 2, 576>(g, H, plo, phi, what);
       if (!ok) return;
+      if (getenv("CW_STAG")) g.stagger = atoi(getenv("CW_STAG"));
       gs.push_back(g); iws.push_back(iw); ksum += nks_w;
     }
   CK(hipDeviceSynchronize());
@@ -299,6 +302,53 @@ static void case_wgrad(int N, Layer L, int dcs, int reps) {
   hipFree(ddy); hipFree(dx); hipFree(idy); hipFree(ix); hipFree(part); hipFree(dbp); hipFree(dw); hipFree(db);
 }
 
+// timing of ONE residual block x + conv(ELU(x)) + b (forward, data gradient) at fully_conv's shapes, with ablations (no check: tests/test_gpu_conv.py)
+static void case_res(int N, int C, int H, int reps) {
+  const int K = 3, M = N * H * H, ncg = C / 16, tiles_n = (C + 63) / 64, wrows = (tiles_n * 64 + 127) / 128 * 128;
+  auto hx = rnd((size_t)M * C, 1), hw = rnd((size_t)C * C * 9, 2, 0.05f), hb = rnd(C, 4, 0.3f);
+  float* dx = dev(hx); float* dw = dev(hw); float* db = dev(hb);
+  int plo, phi;
+  const CwTaps tp = cw_taps_fwd(K, 1, 1, &plo, &phi);
+  const int nks_w = cw_ksteps(tp, ncg);
+  const int Mi = (M + 127) / 128 * 128;
+  unsigned char* ix = devz<unsigned char>(p6_image_bytes(M, ncg));
+  unsigned char* iw = devz<unsigned char>(p6_image_bytes(wrows, nks_w) + 8192);
+  unsigned char* io = devz<unsigned char>(p6_image_bytes(M, ncg));
+  float* dout = devz<float>((size_t)M * C);
+  p6_pack_rows_kernel<<<(unsigned)(((size_t)Mi * ncg * 2 + 255) / 256), 256>>>(dx, nullptr, M, C, C, 0, Mi, ncg, ix);
+  cw_pack_filter_kernel<<<(unsigned)(((size_t)wrows * nks_w * 2 + 255) / 256), 256>>>(dw, nullptr, C, C, K, K, tp, ncg, 2, 64, wrows, nks_w, iw);
+  CK(hipDeviceSynchronize());
+  ConvWinArgs g; memset(&g, 0, sizeof(g));
+  g.xin = ix; g.nks_in = ncg; g.ncg = ncg; g.N = N; g.H = H; g.W = H; g.plo = plo; g.phi = phi; g.taps = tp;
+  g.wimg = iw; g.nks_w = nks_w; g.Co = C; g.tiles_n = tiles_n; g.bias0 = db;
+  g.oimg = io; g.nks_o = ncg; g.out_f = dout; g.ldo = C; g.e_s = dx;
+  g.eimg = ix; g.nks_e = ncg;
+  if (!setup_geom<4, 2, 576>(g, H, plo, phi, "res")) return;
+  auto run = [&](ConvWinArgs& a) { launch_conv_win<CW_RES_FWD, 4, 2, 576>(a, 0, "res fwd"); };
+  auto runb = [&](ConvWinArgs& a) { launch_conv_win<CW_RES_BWD, 4, 2, 576>(a, 0, "res bwd"); };
+  const float t_full = time_us([&] { run(g); }, reps);
+  ConvWinArgs a = g; a.dbg = 4;
+  const float t_loop = time_us([&] { run(a); }, reps);
+  a.dbg = 4 | 8;
+  const float t_loop1w = time_us([&] { run(a); }, reps);
+  a = g; a.oimg = nullptr;
+  const float t_noimg = time_us([&] { run(a); }, reps);
+  a = g; a.out_f = nullptr;
+  const float t_nof = time_us([&] { run(a); }, reps);
+  const float tb_full = time_us([&] { runb(g); }, reps);
+  {
+    for (int n = -1; n <= 8; n += (n < 0 ? 2 : 1)) {
+      a = g; a.stagger = n; const float tf = time_us([&] { run(a); }, reps);
+      a = g; a.stagger = n; const float tb = time_us([&] { runb(a); }, reps);
+      printf("  stagger %d: fwd %.1f us bwd %.1f us\n", n, tf, tb);
+    }
+  }
+  const double gf = 2.0 * M * C * C * 9 * 1e-9;
+  printf("res block N=%d C=%d H=%d (%d blocks): fwd %.1f us %.0f TF | loop only %.1f | loop, one window %.1f | no image out %.1f | no fp32 out %.1f | bwd %.1f us\n",
+         N, C, H, (M + 255) / 256 * tiles_n, t_full, gf / t_full * 1e3, t_loop, t_loop1w, t_noimg, t_nof, tb_full);
+  hipFree(dx); hipFree(dw); hipFree(db); hipFree(ix); hipFree(iw); hipFree(io); hipFree(dout);
+}
+
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 20224;
   const int reps = argc > 2 ? atoi(argv[2]) : 10;
@@ -309,6 +359,7 @@ int main(int argc, char** argv) {
     case_dgrad(37, L3, 1, 2); case_dgrad(37, L3, 2, 2); case_dgrad(37, L2, 1, 2); case_dgrad(37, L4, 1, 2);
     case_wgrad(37, L3, 1, 2); case_wgrad(37, L3, 2, 2);
   }
+  if (!strcmp(only, "res")) { case_res(100, 48, 64, reps); case_res(100, 96, 32, reps); case_res(203, 48, 32, reps); case_res(203, 96, 16, reps); return 0; }
   if (!*only || !strcmp(only, "wgrad5")) case_wgrad(N, L3, 2, reps);
   if (!*only || !strcmp(only, "fwd5")) case_fwd(N, L3, 2, reps);
   if (!*only || !strcmp(only, "fwd3")) case_fwd(N, L3k3, 1, reps);

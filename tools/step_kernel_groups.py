@@ -17,3 +17,11 @@ for r in rows[a:b]:
 print("step span ms %.2f, kernels %d, sum of kernel times ms %.2f" % ((int(rows[b - 1]["End_Timestamp"]) - t0) / 1e6, b - a, busy / 1e3))
 for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
     print("%-74s n %4d total %8.1f us avg %7.1f" % (k, n, t, t / n))
+if len(sys.argv) > 3:                      # every launch of the step in order: offset, duration, gap before it, grid, name
+    prev = t0
+    for r in rows[a:b]:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if sys.argv[3] == "all" or sys.argv[3] in r["Kernel_Name"]:
+            print("%9.1f us  dur %7.1f  gap %6.1f  grid %7s wg %4s  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size", "?")),
+                                                                    r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?")), r["Kernel_Name"][:90]))
+        prev = max(prev, e)
