@@ -191,6 +191,63 @@ __global__ __launch_bounds__(LNT) void log_logistic256_bwd_kernel(const float* _
   }
 }
 
+// The same two kernels for long rows (D >= 4096: fully_conv's 3 x 64 x 64 images, B = 100 rows): one block of sixteen waves per row --
+// a wave per row leaves a 100-row batch on 100 of the chip's 1024 SIMDs -- wave sums combined in wave order (deterministic).
+constexpr int LWT = 1024;
+__global__ __launch_bounds__(LWT) void log_logistic256_fwd_wide_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                       const float* __restrict__ logvar, int lv_scalar, int B,
+                                                                       int D, float* __restrict__ out) {
+  __shared__ float red[LWT / 64];
+  const int row = blockIdx.x;
+  const float lv0 = lv_scalar ? logvar[0] : 0.f;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < D; k += LWT) {
+    const size_t o = (size_t)row * D + k;
+    float cp, cm, u, v;
+    acc += logf(ll256_terms(x[o], mean[o], lv_scalar ? lv0 : logvar[o], cp, cm, u, v));
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < LWT / 64; ++w) t += red[w];
+    out[row] = t;
+  }
+}
+
+__global__ __launch_bounds__(LWT) void log_logistic256_bwd_wide_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                       const float* __restrict__ logvar, int lv_scalar,
+                                                                       const float* __restrict__ dout, int B, int D,
+                                                                       float* __restrict__ dmean, float* __restrict__ dlogvar) {
+  __shared__ float red[LWT / 64];
+  const int row = blockIdx.x;
+  const float lv0 = lv_scalar ? logvar[0] : 0.f;
+  const float g = dout[row];
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < D; k += LWT) {
+    const size_t o = (size_t)row * D + k;
+    const float lv = lv_scalar ? lv0 : logvar[o];
+    float cp, cm, u, v;
+    const float r = g / ll256_terms(x[o], mean[o], lv, cp, cm, u, v);
+    const float a = cp * (1.0f - cp), b = cm * (1.0f - cm);
+    if (dmean) dmean[o] = -r * (a - b) * expf(-lv);
+    const float dl = -r * (a * u - b * v);
+    if (lv_scalar) acc += dl;
+    else if (dlogvar) dlogvar[o] = dl;
+  }
+  if (lv_scalar && dlogvar) {
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < LWT / 64; ++w) t += red[w];
+      dlogvar[row] = t;
+    }
+  }
+}
+
 // out[0] = sum of v[0..n) in a fixed order (one block)
 __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
   __shared__ float red[4];
@@ -495,7 +552,8 @@ extern "C" int evae_log_logistic256_fwd(const float* x, const float* mean, const
   EVAE_REQUIRE(B >= 0 && D > 0, "log_logistic256_fwd: bad sizes");
   if (B == 0) return EVAE_OK;
   EVAE_REQUIRE(x && mean && logvar && out, "log_logistic256_fwd: null pointer");
-  log_logistic256_fwd_kernel<<<ROWS_GRID(B), LNT, 0, (hipStream_t)s>>>(x, mean, logvar, lv_scalar, B, D, out);
+  if (D >= 4096) log_logistic256_fwd_wide_kernel<<<B, LWT, 0, (hipStream_t)s>>>(x, mean, logvar, lv_scalar, B, D, out);
+  else log_logistic256_fwd_kernel<<<ROWS_GRID(B), LNT, 0, (hipStream_t)s>>>(x, mean, logvar, lv_scalar, B, D, out);
   return check_launch("log_logistic256_fwd");
 }
 
@@ -509,8 +567,9 @@ extern "C" int evae_log_logistic256_bwd(const float* x, const float* mean, const
   }
   EVAE_REQUIRE(x && mean && logvar && dout, "log_logistic256_bwd: null pointer");
   EVAE_REQUIRE(!(lv_scalar && dlogvar) || ws_rows, "log_logistic256_bwd: a scalar log-variance needs ws_rows [B]");
-  log_logistic256_bwd_kernel<<<ROWS_GRID(B), LNT, 0, (hipStream_t)s>>>(x, mean, logvar, lv_scalar, dout, B, D, dmean,
-                                                                       lv_scalar ? (dlogvar ? ws_rows : nullptr) : dlogvar);
+  float* const dl = lv_scalar ? (dlogvar ? ws_rows : nullptr) : dlogvar;
+  if (D >= 4096) log_logistic256_bwd_wide_kernel<<<B, LWT, 0, (hipStream_t)s>>>(x, mean, logvar, lv_scalar, dout, B, D, dmean, dl);
+  else log_logistic256_bwd_kernel<<<ROWS_GRID(B), LNT, 0, (hipStream_t)s>>>(x, mean, logvar, lv_scalar, dout, B, D, dmean, dl);
   if (lv_scalar && dlogvar) sum_rows_kernel<<<1, 256, 0, (hipStream_t)s>>>(ws_rows, B, dlogvar);
   return check_launch("log_logistic256_bwd");
 }

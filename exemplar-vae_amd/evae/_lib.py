@@ -153,6 +153,8 @@ SIGNATURES = {
     "evae_cw_first_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "evae_cw_first_workspace_bytes": (_z, []),
     "evae_cw_first_bwd_weight": (_i, [_p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_weight_norm_set_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p]),
+    "evae_weight_norm_set_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "evae_reparam_logq_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_reparam_logq_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_reparam_logq_bwd_hardtanh": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p]),

@@ -1433,6 +1433,60 @@ class GatedConvStackFn(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+class WeightNormSetFn(torch.autograd.Function):
+    """w_i = v_i * (g_i / ||v_i||) (norm over all but dim 0: torch.nn.utils.weight_norm as reference models/fully_conv.py:18,41-58
+    wraps its convolutions) for a SET of filters in ONE launch, and one more for all their (dv_i, dg_i).  args: v_0, g_0, v_1, g_1, ..."""
+
+    @staticmethod
+    def forward(ctx, *vg):
+        lib = _lib.load()
+        vs = [_f32(t) for t in vg[0::2]]
+        gs = [_f32(t) for t in vg[1::2]]
+        _need_cuda(*vs, *gs)
+        ws = [torch.empty_like(v) for v in vs]
+        rows = (C.c_int * len(vs))(*[v.shape[0] for v in vs])
+        cols = (C.c_int * len(vs))(*[v.numel() // v.shape[0] for v in vs])
+        for k in range(0, len(vs), 32):
+            n = min(32, len(vs) - k)
+            _lib.check(lib.evae_weight_norm_set_fwd(n, _ptr_array(vs[k:k + n]), _ptr_array(gs[k:k + n]), _ptr_array(ws[k:k + n]),
+                                                    C.byref(rows, 4 * k), C.byref(cols, 4 * k), _stream()), "evae_weight_norm_set_fwd")
+        ctx.save_for_backward(*vs, *gs)
+        return tuple(ws)
+
+    @staticmethod
+    def backward(ctx, *dws):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        n_all = len(saved) // 2
+        vs, gs = list(saved[:n_all]), list(saved[n_all:])
+        dws = [torch.zeros_like(v) if d is None else _f32(d) for d, v in zip(dws, vs)]
+        dvs = [torch.empty_like(v) for v in vs]
+        dgs = [torch.empty_like(g) for g in gs]
+        rows = (C.c_int * n_all)(*[v.shape[0] for v in vs])
+        cols = (C.c_int * n_all)(*[v.numel() // v.shape[0] for v in vs])
+        for k in range(0, n_all, 32):
+            n = min(32, n_all - k)
+            _lib.check(lib.evae_weight_norm_set_bwd(n, _ptr_array(vs[k:k + n]), _ptr_array(gs[k:k + n]), _ptr_array(dws[k:k + n]),
+                                                    _ptr_array(dvs[k:k + n]), _ptr_array(dgs[k:k + n]), C.byref(rows, 4 * k), C.byref(cols, 4 * k),
+                                                    _stream()), "evae_weight_norm_set_bwd")
+        out = []
+        for dv, dg in zip(dvs, dgs):
+            out += [dv, dg]
+        return tuple(out)
+
+
+def weight_norm_set(pairs):
+    """pairs = [(v, g), ...] -> [w, ...]   (one launch; autograd through to every v and g)"""
+    flat = []
+    for v, g in pairs:
+        flat += [v, g]
+    return list(WeightNormSetFn.apply(*flat))
+
+
 RES_STACK_MIN_PIXELS = int(os.environ.get("EVAE_RES_STACK_MIN_PIXELS", "16384"))
 
 

@@ -480,6 +480,14 @@ size_t evae_cw_first_workspace_bytes(void);
 int evae_cw_first_bwd_weight(const float* dy, const float* x, const evae_conv_desc_t* d, float* dw, float* db, void* ws,
                              size_t ws_bytes, evae_stream_t stream);
 
+/* Weight normalisation of a SET of filters in one launch (torch.nn.utils.weight_norm over dim 0, the wrapper of every convolution
+ * of reference models/fully_conv.py:18,41-58): w_i [rows_i][cols_i] = v_i * (g_i / ||v_i row||), n <= 32 filters a call;
+ * _bwd: dv_i, dg_i [rows_i] from dw_i.  Sums in a fixed order (deterministic). */
+int evae_weight_norm_set_fwd(int n, const void* const* v, const void* const* g, void* const* w, const int* rows, const int* cols,
+                             evae_stream_t stream);
+int evae_weight_norm_set_bwd(int n, const void* const* v, const void* const* g, const void* const* dw, void* const* dv, void* const* dg,
+                             const int* rows, const int* cols, evae_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Latent sampling and log-densities on [B x zdim] / [B x D] rows.
  * evae_reparam_logq: z = mu + eps*exp(logvar/2) (models/BaseModel.py:79-82, eps supplied by the

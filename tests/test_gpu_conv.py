@@ -356,3 +356,28 @@ def test_residual_block_run_on_pixel_images_matches_float64(N, C, H, nblk):
     for k in range(nblk):
         assert rel(wd[k].grad, wr[k].grad) < 3e-5, (k, rel(wd[k].grad, wr[k].grad))
         assert rel(bd[k].grad, br[k].grad) < 3e-5, (k, rel(bd[k].grad, br[k].grad))
+
+
+@pytest.mark.gpu
+def test_weight_norm_set_matches_torch_weight_norm():
+    """evae.ops.weight_norm_set (one launch for every weight-normed filter of a fully_conv network pass, reference
+    models/fully_conv.py:18,41-58) against torch._weight_norm in float64: values and the gradients wrt every v and g; 40 filters (two
+    calls of <= 32 inside), one of them unused downstream (zero gradient)."""
+    from evae import ops
+    torch.manual_seed(5)
+    shapes = [(48, 3, 3, 3), (48, 48, 3, 3), (96, 48, 3, 3), (96, 96, 3, 3), (1, 96, 3, 3), (3, 48, 3, 3)] * 6 + [(7, 5, 1, 1)] * 4
+    vs = [torch.randn(s, device="cuda", requires_grad=True) for s in shapes]
+    gs = [(torch.rand((s[0], 1, 1, 1), device="cuda") + 0.5).requires_grad_(True) for s in shapes]
+    ws = ops.weight_norm_set(list(zip(vs, gs)))
+    cots = [torch.randn_like(w) for w in ws]
+    sum((w * c).sum() for w, c in list(zip(ws, cots))[:-1]).backward()
+    for k, (v, g, w, c) in enumerate(zip(vs, gs, ws, cots)):
+        v64, g64 = v.detach().double().requires_grad_(True), g.detach().double().requires_grad_(True)
+        w64 = torch._weight_norm(v64, g64, 0)
+        assert (w.double() - w64).abs().max() <= 2e-6 * w64.abs().max()
+        if k + 1 == len(ws):
+            assert v.grad.abs().max() == 0 and g.grad.abs().max() == 0
+            continue
+        (w64 * c.double()).sum().backward()
+        assert (v.grad.double() - v64.grad).abs().max() <= 1e-5 * v64.grad.abs().max()
+        assert (g.grad.double() - g64.grad).abs().max() <= 1e-5 * g64.grad.abs().max() + 1e-6
