@@ -100,6 +100,7 @@ struct ConvWinArgs {
   const unsigned char* eimg;  // CW_DGRAD_GATE: pixel image of the forward output of the layer below (nks_e groups, channel ech0 + c) ...
   int nks_e, ech0;
   const float* e_s;           // ... and its gate [rows][Co]: [dh | dg] = [v s | v out (1 - s)]
+  int act;                    // CW_PLAIN: bit 0 = ELU on the result (out_f and the image hold ELU(conv + b)), bit 1 = the image holds ELU of that
   int stagger;                // launches of more than one round of blocks: the first 512 blocks start (id / 128) * stagger * 2048 clocks late
   int dbg;
 };
@@ -374,10 +375,20 @@ __device__ __forceinline__ void cw_epilogue(const ConvWinArgs& g, f32x16 (&acc)[
           *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
         }
       } else if constexpr (EPI == CW_PLAIN) {
-        if (g.oimg) put_img(g.och0 + ch, o0, o1);
+        // plain convolution (+ ELU: the weight-normed convolutions in front of fully_conv's residual runs, models/fully_conv.py:41-58)
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = (g.act & 1) ? cw_elu(v[k]) : v[k];
         if (g.out_f) {
           float* op = g.out_f + mn * g.ldo + ch;
-          *reinterpret_cast<float4*>(op) = o0; *reinterpret_cast<float4*>(op + 4) = o1;
+          *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]); *reinterpret_cast<float4*>(op + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        }
+        if (g.oimg) {
+          if (g.act & 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = cw_elu(y[k]);
+          }
+          put_img(g.och0 + ch, make_float4(y[0], y[1], y[2], y[3]), make_float4(y[4], y[5], y[6], y[7]));
         }
       } else if constexpr (EPI == CW_RES_FWD) {
         // residual block of models/fully_conv.py:13-23: y = x + conv(ELU(x)) + b.  e_s = x (fp32, natural rows); out_f = y; oimg = the

@@ -37,6 +37,49 @@ __global__ __launch_bounds__(256) void cw_pack_image_kernel(const float* __restr
   *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = make_uint4(t2[0], t2[1], t2[2], t2[3]);
 }
 
+// The general form: x has Cx <= C real channels (the image's other channels are zero) in rows of ldx floats (channels-last) or as
+// contiguous NCHW planes (nchw); optionally times ELU'(pre) with aux = ELU(pre) (fp32, same layout as x has channels-last, row
+// stride lda): the gradient entering a convolution that an ELU follows.
+__global__ __launch_bounds__(256) void cw_pack_image_ex_kernel(const float* __restrict__ x, long long ldx, int Cx, int nchw,
+                                                               const float* __restrict__ aux, long long lda, int N, int H, int W, int C,
+                                                               int planar, int elu, unsigned char* __restrict__ img) {
+  const int c8n = C >> 3, nks = C >> 4;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)N * H * W * c8n;
+  if (t >= total) return;
+  const size_t grp = t / ((size_t)16 * c8n);
+  const int r = (int)(t - grp * 16 * c8n), c8 = r >> 4, p16 = r & 15;
+  const size_t m = grp * 16 + p16;
+  const size_t HW = (size_t)H * W;
+  if (m >= (size_t)N * HW) return;
+  const size_t n = m / HW;
+  const int rem = (int)(m - n * HW);
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = c8 * 8 + k;
+    float a = 0.f;
+    if (c < Cx) {
+      a = nchw ? x[(n * Cx + c) * HW + rem] : x[m * ldx + c];
+      if (aux) { const float e = aux[m * lda + c]; a *= e > 0.f ? 1.0f : e + 1.0f; }
+      if (elu) a = a > 0.f ? a : expm1f(a);
+    }
+    v[k] = a;
+  }
+  size_t row = m;
+  if (planar) {
+    const int y = rem / W, xx = rem - y * W;
+    row = n * HW + cw_planar(y, xx, H, W);
+  }
+  unsigned t0[4], t1[4], t2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p6_split2(v[2 * i], v[2 * i + 1], t0[i], t1[i], t2[i]);
+  unsigned char* o = img + p6_off64(row, c8 * 8, nks);
+  *reinterpret_cast<uint4*>(o) = make_uint4(t0[0], t0[1], t0[2], t0[3]);
+  *reinterpret_cast<uint4*>(o + P6_CHUNK) = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+  *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+}
+
 // [dh | dg] = [v s | v out (1 - s)] for an upstream gradient v that exists as an fp32 tensor (the layer above ran outside the
 // stack): v, s fp32 natural [rows][C]; out from its pixel image (rows natural or planar); result -> pixel image in the image's row
 // order (2 C channels) and / or fp32 natural [rows][2 C]
@@ -190,6 +233,20 @@ extern "C" int evae_cw_pack_image(const float* x, int N, int H, int W, int C, in
   const size_t total = rows16 * (size_t)(C / 8);
   cw_pack_image_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream_>>>(x, N, H, W, C, planar & 1, (planar >> 1) & 1, (unsigned char*)img);
   return check_launch("cw_pack_image_kernel");
+}
+
+extern "C" int evae_cw_pack_image_ex(const float* x, long long ldx, int Cx, int nchw, const float* aux, long long lda, int N, int H, int W,
+                                     int C, int flags, void* img, evae_stream_t stream_) {
+  // flags: bit 0 = parity-planar rows, bit 1 = the image of ELU(x)
+  EVAE_REQUIRE(x && img && N > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0 && Cx > 0 && Cx <= C, "cw_pack_image_ex: bad arguments");
+  EVAE_REQUIRE(nchw || ldx >= Cx, "cw_pack_image_ex: row stride smaller than the channel count");
+  EVAE_REQUIRE(!aux || lda >= Cx, "cw_pack_image_ex: aux row stride smaller than the channel count");
+  EVAE_REQUIRE(!(flags & 1) || ((H | W) & 1) == 0, "cw_pack_image_ex: parity-planar rows need even H and W");
+  const size_t rows = (size_t)N * H * W, rows16 = (rows + 15) / 16 * 16;
+  const size_t total = rows16 * (size_t)(C / 8);
+  cw_pack_image_ex_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream_>>>(x, ldx, Cx, nchw, aux, lda, N, H, W, C, flags & 1,
+                                                                                     (flags >> 1) & 1, (unsigned char*)img);
+  return check_launch("cw_pack_image_ex_kernel");
 }
 
 extern "C" int evae_cw_gate_bwd_image(const float* v, const void* eimg, int planar, const float* s, int N, int H, int W, int C, void* oimg,
@@ -394,6 +451,115 @@ extern "C" int evae_cw_res_bwd_data(const void* dyimg, const evae_conv_desc_t* d
 extern "C" int evae_cw_bwd_weight_plain(const void* dyimg, const void* ximg, const evae_conv_desc_t* d, float* dw, float* db, void* ws,
                                         size_t ws_bytes, evae_stream_t stream_) {
   return cw_bwd_weight_impl(dyimg, 0, ximg, d, 0, dw, db, ws, ws_bytes, stream_);
+}
+
+// ---- plain convolutions (3 x 3, stride 1 or 2, 'same' padding) on pixel images: fully_conv's weight-normed convolutions outside its
+// residual runs (models/fully_conv.py:41-58).  d->C / d->Co are the REAL channel counts; an image carries them rounded up to 16
+// (zeros above), a filter tile zero rows / columns for them.
+static int cup16(int c) { return (c + 15) / 16 * 16; }
+// what: 0 forward, 1 data gradient, 2 weight gradient (evae_cw_bwd_weight_plain on a descriptor with the rounded channel counts)
+static int cw_plain_ok(const evae_conv_desc_t* d, int what) {
+  if (!cw_geometry_ok(d) || d->KH != 3 || d->C <= 0 || d->Co <= 0) return 0;
+  const int OH = d->H / d->stride;
+  if (what == 0) {
+    if (d->Co > 128) return 0;
+    int plo, phi;
+    (void)cw_taps_fwd(3, d->stride, d->pad, &plo, &phi);
+    return cw_window_slots(OH, OH, plo, phi, 256) <= 576;
+  }
+  if (what == 1) {
+    if (d->C > 128 || d->C % 8 != 0) return 0;
+    for (int py = 0; py < d->stride; ++py)
+      for (int px = 0; px < d->stride; ++px) {
+        int plo, phi;
+        (void)cw_taps_dgrad(3, d->stride, d->pad, py, px, &plo, &phi);
+        if (cw_window_slots(OH, OH, plo, phi, 256) > 576) return 0;
+      }
+    return 1;
+  }
+  evae_conv_desc_t r = *d;
+  r.C = cup16(d->C); r.Co = cup16(d->Co);
+  return cw_wgrad_ok(&r, 0) != 0;
+}
+extern "C" int evae_cw_plain_supported(const evae_conv_desc_t* d, int what) { return what >= 0 && what <= 2 ? cw_plain_ok(d, what) : 0; }
+
+extern "C" size_t evae_cw_plain_workspace_bytes(const evae_conv_desc_t* d, int what) {
+  if (!d) return 256;
+  if (what == 2) { evae_conv_desc_t r = *d; r.C = cup16(d->C); r.Co = cup16(d->Co); return evae_cw_workspace_bytes(&r, 7); }
+  const int rows = what == 0 ? d->Co : d->C, kch = what == 0 ? d->C : d->Co;
+  const int wrows = (cdiv(rows, 64) * 64 + 127) / 128 * 128;
+  return (size_t)d->stride * d->stride * (p6_image_bytes(wrows, (cup16(kch) / 16) * 9) + 8192);
+}
+
+// ximg: the input's image (cup16(C) channels; rows natural for stride 1, parity-planar for stride 2).  y = conv(x, w) + b, act bit 0:
+// y = ELU(y); -> out_f fp32 [N OH OW][ldo] (ldo >= Co rounded up to 8: whole 8-channel pieces are written, zeros above Co) and / or
+// oimg (cup16(Co) channels... rows planar when out_planar), holding ELU(y) when act bit 1.
+extern "C" int evae_cw_plain_fwd(const void* ximg, const evae_conv_desc_t* d, const float* w, const float* b, int act, float* out_f, int ldo,
+                                 void* oimg, int out_planar, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(cw_plain_ok(d, 0), "cw_plain_fwd: unsupported geometry");
+  EVAE_REQUIRE(ximg && w && (out_f || oimg) && ws && ws_bytes >= evae_cw_plain_workspace_bytes(d, 0), "cw_plain_fwd: null pointer / workspace too small");
+  EVAE_REQUIRE(!out_f || ldo >= (d->Co + 7) / 8 * 8, "cw_plain_fwd: ldo smaller than the output channels rounded up to 8");
+  const int st = d->stride, OH = d->H / st, Co = d->Co, ncg = cup16(d->C) / 16;
+  EVAE_REQUIRE(!out_planar || (OH & 1) == 0, "cw_plain_fwd: parity-planar output rows need an even output grid");
+  int plo, phi;
+  const CwTaps tp = cw_taps_fwd(3, st, d->pad, &plo, &phi);
+  const int nks_w = cw_ksteps(tp, ncg);
+  const int bn = Co <= 32 ? 32 : 64, tiles_n = cdiv(Co, bn), wrows = (tiles_n * bn + 127) / 128 * 128;
+  unsigned char* iw = (unsigned char*)ws;
+  cw_pack_filter_kernel<<<(unsigned)(((size_t)wrows * nks_w * 2 + 255) / 256), 256, 0, stream>>>(w, nullptr, Co, d->C, 3, 3, tp, ncg, 2, bn, wrows, nks_w, iw);
+  int rc = check_launch("cw_pack_filter_kernel");
+  if (rc) return rc;
+  ConvWinArgs g = {};
+  g.xin = (const unsigned char*)ximg; g.nks_in = ncg; g.ncg = ncg; g.N = d->N; g.H = OH; g.W = OH; g.plo = plo; g.phi = phi; g.taps = tp;
+  g.istride = st * st * OH * OH;
+  for (int s2 = 0; s2 < st * st; ++s2) g.ioff[s2] = s2 * OH * OH;
+  g.wimg = iw; g.nks_w = nks_w; g.Co = Co; g.tiles_n = tiles_n; g.bias0 = b; g.act = act;
+  g.out_planar = out_planar;
+  g.oimg = (unsigned char*)oimg; g.nks_o = cup16(Co) / 16; g.out_f = out_f; g.ldo = ldo;
+  g.nsp = (cw_window_slots(OH, OH, plo, phi, 256) + 31) / 32;
+  if (bn == 32) return launch_conv_win<CW_PLAIN, 4, 1, 576>(g, stream, "cw_plain_fwd");
+  return launch_conv_win<CW_PLAIN, 4, 2, 576>(g, stream, "cw_plain_fwd");
+}
+
+// dyimg: the image of the gradient wrt the convolution's result (cup16(Co) channels, rows planar when dy_planar) -> the gradient wrt
+// its input: dx_f fp32 natural [N H W][ldx] (ldx >= C, C % 8 == 0) and / or dximg (C % 16 == 0; rows planar for a stride-2 layer, the
+// order its input image has)
+extern "C" int evae_cw_plain_bwd_data(const void* dyimg, int dy_planar, const evae_conv_desc_t* d, const float* w, float* dx_f, int ldx,
+                                      void* dximg, void* ws, size_t ws_bytes, evae_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVAE_REQUIRE(cw_plain_ok(d, 1), "cw_plain_bwd_data: unsupported geometry");
+  EVAE_REQUIRE(dyimg && w && (dx_f || dximg) && ws && ws_bytes >= evae_cw_plain_workspace_bytes(d, 1), "cw_plain_bwd_data: null pointer / workspace too small");
+  EVAE_REQUIRE(!dx_f || ldx >= d->C, "cw_plain_bwd_data: ldx smaller than the channel count");
+  EVAE_REQUIRE(!dximg || d->C % 16 == 0, "cw_plain_bwd_data: an image needs a multiple of 16 channels");
+  const int st = d->stride, OH = d->H / st, C = d->C, Co = d->Co;
+  const int ncg = cup16(Co) / 16, bn = C <= 32 ? 32 : 64, tiles_n = cdiv(C, bn), wrows = (tiles_n * bn + 127) / 128 * 128;
+  size_t used = 0;
+  for (int py = 0; py < st; ++py)
+    for (int px = 0; px < st; ++px) {
+      int plo, phi;
+      const CwTaps tp = cw_taps_dgrad(3, st, d->pad, py, px, &plo, &phi);
+      const int nks_w = cw_ksteps(tp, ncg);
+      EVAE_REQUIRE(nks_w > 0, "cw_plain_bwd_data: a parity class without taps");
+      ConvWinArgs g = {};
+      g.N = d->N; g.H = OH; g.W = OH; g.plo = plo; g.phi = phi; g.taps = tp;
+      g.ostride = st * st * OH * OH; g.ooff = (py * st + px) * OH * OH;
+      g.nat_h = d->H; g.nat_w = d->W; g.nat_s = st; g.nat_y = py; g.nat_x = px;
+      g.Co = C; g.tiles_n = tiles_n;
+      g.oimg = (unsigned char*)dximg; g.nks_o = C / 16; g.out_f = dx_f; g.ldo = ldx;
+      unsigned char* iw = (unsigned char*)ws + used;
+      used += p6_image_bytes(wrows, nks_w) + 8192;
+      cw_pack_filter_kernel<<<(unsigned)(((size_t)wrows * nks_w * 2 + 255) / 256), 256, 0, stream>>>(w, nullptr, Co, C, 3, 3, tp, ncg, 1, bn, wrows, nks_w, iw);
+      int rc = check_launch("cw_pack_filter_kernel");
+      if (rc) return rc;
+      g.xin = (const unsigned char*)dyimg; g.nks_in = ncg; g.ncg = ncg; g.istride = OH * OH; g.in_planar = dy_planar;
+      g.wimg = iw; g.nks_w = nks_w;
+      g.nsp = (cw_window_slots(OH, OH, plo, phi, 256) + 31) / 32;
+      if (bn == 32) rc = launch_conv_win<CW_PLAIN, 4, 1, 576>(g, stream, "cw_plain_bwd_data");
+      else rc = launch_conv_win<CW_PLAIN, 4, 2, 576>(g, stream, "cw_plain_bwd_data");
+      if (rc) return rc;
+    }
+  return EVAE_OK;
 }
 
 // First layer of a stack (C == 1): x fp32 [N][H][W] -> output image (rows planar when out_planar) + gate (+ fp32 copy); exact fp32

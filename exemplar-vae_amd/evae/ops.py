@@ -1433,6 +1433,104 @@ class GatedConvStackFn(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+def _cup(c, m):
+    return (c + m - 1) // m * m
+
+
+def plain_conv_supported(x, w, stride, padding, need_dx=None):
+    """A 3 x 3 'same' convolution (stride 1 or 2, any channel counts <= 128) on the window kernels?  (enough pixels to fill the machine)"""
+    if not (CONV_STACK_ON and x.is_cuda and x.dim() == 4 and w.dim() == 4):
+        return False
+    N, Cc, H, W = x.shape
+    Co, Ci, KH, KW = w.shape
+    st = stride[0] if isinstance(stride, (tuple, list)) else stride
+    pd = padding[0] if isinstance(padding, (tuple, list)) else padding
+    if Ci != Cc or KH != 3 or KW != 3 or pd != 1 or st not in (1, 2) or N * H * W < RES_STACK_MIN_PIXELS // 4:
+        return False
+    lib = _lib.load()
+    d = _lib.ConvDesc(N, Cc, H, W, Co, 3, 3, st, 1)
+    need_dx = x.requires_grad if need_dx is None else need_dx
+    grads = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
+    ok = bool(lib.evae_cw_plain_supported(C.byref(d), 0))
+    if ok and grads:
+        ok = bool(lib.evae_cw_plain_supported(C.byref(d), 2)) and (not need_dx or bool(lib.evae_cw_plain_supported(C.byref(d), 1)))
+    return ok
+
+
+class PlainConvFn(torch.autograd.Function):
+    """y = conv2d(x, w, b) (3 x 3, 'same', stride 1 or 2), optionally ELU(y), on the window kernels over pixel images: the weight-normed
+    convolutions outside fully_conv's residual runs and its 3-channel output head (reference models/fully_conv.py:41-58).  The input is
+    split into its image once (parity-planar rows for stride 2) and kept for the weight gradient; the gradient arrives in whatever
+    layout autograd hands it (NCHW from the likelihood) and is packed -- times ELU'(y) when the ELU was fused -- into the image both
+    gradients read."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, elu):
+        lib = _lib.load()
+        w = _f32(w)
+        _need_cuda(x, w)
+        x = x.float()
+        nchw = 1 if (x.is_contiguous() and not x.is_contiguous(memory_format=CL)) else 0       # (the data arrives as NCHW planes)
+        if not nchw:
+            x = _cl(x)
+        dev = x.device
+        N, Cc, H, W = x.shape
+        Co = w.shape[0]
+        st = int(stride)
+        OH, OW = H // st, W // st
+        d = _lib.ConvDesc(N, Cc, H, W, Co, 3, 3, st, 1)
+        Cp, Cop, Co8 = _cup(Cc, 16), _cup(Co, 16), _cup(Co, 8)
+        ximg = torch.empty(int(lib.evae_cw_image_bytes(N * H * W, Cp)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.evae_cw_pack_image_ex(_p(x), Cc, Cc, nchw, None, 0, N, H, W, Cp, 1 if st == 2 else 0, _p(ximg), _stream()), "evae_cw_pack_image_ex")
+        out = torch.empty((N, OH, OW, Co8), device=dev)
+        ws = _workspace("cw", lib.evae_cw_plain_workspace_bytes(C.byref(d), 0), dev)
+        _lib.check(lib.evae_cw_plain_fwd(_p(ximg), C.byref(d), _p(w), _p(b), 1 if elu else 0, _p(out), Co8, None, 0, _p(ws), ws.numel(), _stream()),
+                   "evae_cw_plain_fwd")
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(w)
+            ctx.keep = (ximg, d, out if elu else None, b is not None, (Cp, Cop, Co8))
+        return out.permute(0, 3, 1, 2)[:, :Co]
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (w,) = ctx.saved_tensors
+        ximg, d, act, has_b, (Cp, Cop, Co8) = ctx.keep
+        ctx.keep = None
+        dev = dy.device
+        N, Cc, H, W, Co, st = d.N, d.C, d.H, d.W, d.Co, d.stride
+        OH, OW = H // st, W // st
+        dy = dy.float()
+        if dy.is_contiguous():
+            nchw, ldy = 1, 0
+        elif dy.permute(0, 2, 3, 1).is_contiguous():
+            nchw, ldy = 0, Co
+        else:
+            dy, nchw, ldy = dy.contiguous(), 1, 0
+        dyimg = torch.empty(int(lib.evae_cw_image_bytes(N * OH * OW, Cop)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.evae_cw_pack_image_ex(_p(dy), ldy, Co, nchw, _p(act), Co8, N, OH, OW, Cop, 0, _p(dyimg), _stream()), "evae_cw_pack_image_ex(dy)")
+        gw = gb = gx = None
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            r = _lib.ConvDesc(N, Cp, H, W, Cop, 3, 3, st, 1)
+            dwp = torch.empty((Cop, Cp, 3, 3), device=dev); dbp = torch.empty(Cop, device=dev)
+            ws = _workspace("cw", lib.evae_cw_plain_workspace_bytes(C.byref(d), 2), dev)
+            _lib.check(lib.evae_cw_bwd_weight_plain(_p(dyimg), _p(ximg), C.byref(r), _p(dwp), _p(dbp), _p(ws), ws.numel(), _stream()),
+                       "evae_cw_bwd_weight_plain")
+            gw = dwp[:Co, :Cc].contiguous() if (Cop != Co or Cp != Cc) else dwp
+            gb = dbp[:Co] if has_b else None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, H, W, Cc), device=dev)
+            ws = _workspace("cw", lib.evae_cw_plain_workspace_bytes(C.byref(d), 1), dev)
+            _lib.check(lib.evae_cw_plain_bwd_data(_p(dyimg), 0, C.byref(d), _p(w), _p(dx), Cc, None, _p(ws), ws.numel(), _stream()),
+                       "evae_cw_plain_bwd_data")
+            gx = dx.permute(0, 3, 1, 2)
+        return gx, gw, gb, None, None
+
+
+def plain_conv(x, w, b, stride=1, elu=False):
+    return PlainConvFn.apply(x, w, b, int(stride[0] if isinstance(stride, (tuple, list)) else stride), bool(elu))
+
+
 def _ptr_array(ts):
     return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 

@@ -88,8 +88,14 @@ class _Seq(nn.Sequential):
                     x = ops.res_block(x, weight(m.conv1), m.conv1.bias)
                     i += 1
                     continue
-            if fused and _is_wn(m) and id(m) in wn:
-                x = ops.conv2d(x, wn[id(m)], m.bias, m.stride, m.padding)
+            if fused and _is_wn(m):
+                w = weight(m)
+                elu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ELU)
+                if os.environ.get("EVAE_PLAIN_CONV", "1") != "0" and ops.plain_conv_supported(x, w, m.stride, m.padding):
+                    x = ops.plain_conv(x, w, m.bias, m.stride, elu=elu)            # (the ELU behind it in its epilogue)
+                    i += 2 if elu else 1
+                    continue
+                x = ops.conv2d(x, w, m.bias, m.stride, m.padding)
             else:
                 x = m(x)
             i += 1
@@ -108,6 +114,8 @@ class _HeadConv(HipConv2d):
         stack = self.__dict__.get("_stack")
         w = stack.head_weight(self) if stack is not None else None
         if w is not None:
+            if os.environ.get("EVAE_PLAIN_CONV", "1") != "0" and ops.plain_conv_supported(x, w, self.stride, self.padding):
+                return ops.plain_conv(x, w, self.bias, self.stride)
             return ops.conv2d(x, w, self.bias, self.stride, self.padding)
         return super().__call__(x)
 

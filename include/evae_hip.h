@@ -480,6 +480,24 @@ size_t evae_cw_first_workspace_bytes(void);
 int evae_cw_first_bwd_weight(const float* dy, const float* x, const evae_conv_desc_t* d, float* dw, float* db, void* ws,
                              size_t ws_bytes, evae_stream_t stream);
 
+/* Plain 3 x 3 convolutions ('same' padding, stride 1 or 2) on pixel images: fully_conv's weight-normed convolutions outside its residual
+ * runs and its output head (reference models/fully_conv.py:41-58).  d->C / d->Co are the REAL channel counts (any: 3 -> 48, 48 -> 3);
+ * an image carries them rounded up to 16 with zeros above.  evae_cw_plain_supported(d, what): 0 forward, 1 data gradient (C % 8 == 0),
+ * 2 weight gradient (= evae_cw_bwd_weight_plain on a descriptor with both counts rounded up to 16; slice dw / db).
+ *   evae_cw_pack_image_ex: fp32 -> image for x with Cx <= C real channels, rows of ldx floats (channels-last) or contiguous NCHW planes
+ *     (nchw), optionally times ELU'(pre) given aux = ELU(pre) (channels-last rows of lda floats); flags as evae_cw_pack_image.
+ *   evae_cw_plain_fwd: y = conv(x, w) + b; act bit 0: y = ELU(y), bit 1: the image holds ELU(y) (a residual run reads it);
+ *     out_f [N OH OW][ldo] (ldo >= Co rounded up to 8, zeros above Co) and / or oimg.
+ *   evae_cw_plain_bwd_data: dx_f [N H W][ldx] and / or dximg from the image of dy (rows planar when dy_planar). */
+int evae_cw_plain_supported(const evae_conv_desc_t* d, int what);
+size_t evae_cw_plain_workspace_bytes(const evae_conv_desc_t* d, int what);
+int evae_cw_pack_image_ex(const float* x, long long ldx, int Cx, int nchw, const float* aux, long long lda, int N, int H, int W, int C,
+                          int flags, void* img, evae_stream_t stream);
+int evae_cw_plain_fwd(const void* ximg, const evae_conv_desc_t* d, const float* w, const float* b, int act, float* out_f, int ldo,
+                      void* oimg, int out_planar, void* ws, size_t ws_bytes, evae_stream_t stream);
+int evae_cw_plain_bwd_data(const void* dyimg, int dy_planar, const evae_conv_desc_t* d, const float* w, float* dx_f, int ldx, void* dximg,
+                           void* ws, size_t ws_bytes, evae_stream_t stream);
+
 /* Weight normalisation of a SET of filters in one launch (torch.nn.utils.weight_norm over dim 0, the wrapper of every convolution
  * of reference models/fully_conv.py:18,41-58): w_i [rows_i][cols_i] = v_i * (g_i / ||v_i row||), n <= 32 filters a call;
  * _bwd: dv_i, dg_i [rows_i] from dw_i.  Sums in a fixed order (deterministic). */

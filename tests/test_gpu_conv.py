@@ -381,3 +381,47 @@ def test_weight_norm_set_matches_torch_weight_norm():
         (w64 * c.double()).sum().backward()
         assert (v.grad.double() - v64.grad).abs().max() <= 1e-5 * v64.grad.abs().max()
         assert (g.grad.double() - g64.grad).abs().max() <= 1e-5 * g64.grad.abs().max() + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,H,Co,stride,elu,xgrad,layout", [
+    (20, 48, 32, 3, 1, False, True, "nchw"),        # the output head of fully_conv (48 -> 3), gradient from the likelihood as NCHW planes
+    (24, 3, 32, 48, 2, True, False, "nchw"),        # its first convolution: the data, stride 2, ELU behind
+    (20, 48, 32, 96, 2, True, None, "cl"),          # 48 -> 96 stride 2: forward only (the weight gradient's stride-2 window of 96 merged
+                                                    # channels does not fit LDS at this grid: training keeps evae.ops.conv2d there)
+    (6, 96, 64, 48, 1, True, True, "cl"),           # 96 -> 48 on the 64 x 64 grid + ELU
+    (33, 16, 16, 24, 1, False, True, "cl"),         # ragged last block, channels that are no multiple of 16 / 32
+])
+def test_plain_convolution_on_pixel_images_matches_float64(N, C, H, Co, stride, elu, xgrad, layout):
+    """evae.ops.plain_conv (3 x 3 'same' convolution, stride 1 / 2, optional fused ELU: the convolutions outside fully_conv's residual
+    runs, reference models/fully_conv.py:41-58) against torch conv2d (+ ELU) in float64: output and the gradients wrt input, weight
+    and bias, the gradient handed over as NCHW planes or channels-last."""
+    from evae import ops
+    torch.manual_seed(N + C)
+    x = torch.randn(N, C, H, H, device="cuda")
+    if layout == "cl":
+        x = x.contiguous(memory_format=torch.channels_last)
+    fwd_only = xgrad is None
+    x.requires_grad_(bool(xgrad))
+    w = (torch.randn(Co, C, 3, 3, device="cuda") * 0.1).requires_grad_(not fwd_only)
+    b = (torch.randn(Co, device="cuda") * 0.3).requires_grad_(not fwd_only)
+    assert ops.plain_conv_supported(x, w, stride, 1)
+    y = ops.plain_conv(x, w, b, stride, elu=elu)
+    x64, w64, b64 = (t.detach().double().requires_grad_(not fwd_only) for t in (x, w, b))
+    r = torch.nn.functional.conv2d(x64, w64, b64, stride=stride, padding=1)
+    if elu:
+        r = torch.nn.functional.elu(r)
+    assert y.shape == r.shape
+    assert (y.double() - r).abs().max() <= 2e-6 * r.abs().max()
+    if fwd_only:
+        assert not ops.plain_conv_supported(x, w.detach().requires_grad_(True), stride, 1)
+        return
+    g = torch.randn(r.shape, device="cuda")
+    if layout == "cl":
+        g = g.contiguous(memory_format=torch.channels_last)
+    y.backward(g)
+    r.backward(g.double())
+    assert (w.grad.double() - w64.grad).abs().max() <= 3e-6 * w64.grad.abs().max()
+    assert (b.grad.double() - b64.grad).abs().max() <= 3e-6 * b64.grad.abs().max()
+    if xgrad:
+        assert (x.grad.double() - x64.grad).abs().max() <= 3e-6 * x64.grad.abs().max()
