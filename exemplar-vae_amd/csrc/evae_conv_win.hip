@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void cw_pack_image_kernel(const float* __restr
 // stride lda): the gradient entering a convolution that an ELU follows.
 __global__ __launch_bounds__(256) void cw_pack_image_ex_kernel(const float* __restrict__ x, long long ldx, int Cx, int nchw,
                                                                const float* __restrict__ aux, long long lda, int N, int H, int W, int C,
-                                                               int planar, int elu, unsigned char* __restrict__ img) {
+                                                               int planar, int elu, int up, unsigned char* __restrict__ img) {
   const int c8n = C >> 3, nks = C >> 4;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)N * H * W * c8n;
@@ -60,7 +60,13 @@ __global__ __launch_bounds__(256) void cw_pack_image_ex_kernel(const float* __re
     const int c = c8 * 8 + k;
     float a = 0.f;
     if (c < Cx) {
-      a = nchw ? x[(n * Cx + c) * HW + rem] : x[m * ldx + c];
+      if (up) {                                  // x is the half-resolution tensor: nearest-neighbour upsampling by 2 (nn.Upsample(scale_factor=2))
+        const int y = rem / W, xx = rem - y * W, h2 = H >> 1, w2 = W >> 1;
+        const size_t ms = (n * h2 + (y >> 1)) * w2 + (xx >> 1);
+        a = nchw ? x[(n * Cx + c) * ((size_t)h2 * w2) + (size_t)(y >> 1) * w2 + (xx >> 1)] : x[ms * ldx + c];
+      } else {
+        a = nchw ? x[(n * Cx + c) * HW + rem] : x[m * ldx + c];
+      }
       if (aux) { const float e = aux[m * lda + c]; a *= e > 0.f ? 1.0f : e + 1.0f; }
       if (elu) a = a > 0.f ? a : expm1f(a);
     }
@@ -237,16 +243,40 @@ extern "C" int evae_cw_pack_image(const float* x, int N, int H, int W, int C, in
 
 extern "C" int evae_cw_pack_image_ex(const float* x, long long ldx, int Cx, int nchw, const float* aux, long long lda, int N, int H, int W,
                                      int C, int flags, void* img, evae_stream_t stream_) {
-  // flags: bit 0 = parity-planar rows, bit 1 = the image of ELU(x)
+  // flags: bit 0 = parity-planar rows, bit 1 = the image of ELU(x), bit 2 = x is [N][H / 2][W / 2]: nearest upsampling by 2 on the way
   EVAE_REQUIRE(x && img && N > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0 && Cx > 0 && Cx <= C, "cw_pack_image_ex: bad arguments");
+  EVAE_REQUIRE(!(flags & 4) || (((H | W) & 1) == 0 && !aux), "cw_pack_image_ex: upsampling needs even H and W (and takes no aux)");
   EVAE_REQUIRE(nchw || ldx >= Cx, "cw_pack_image_ex: row stride smaller than the channel count");
   EVAE_REQUIRE(!aux || lda >= Cx, "cw_pack_image_ex: aux row stride smaller than the channel count");
   EVAE_REQUIRE(!(flags & 1) || ((H | W) & 1) == 0, "cw_pack_image_ex: parity-planar rows need even H and W");
   const size_t rows = (size_t)N * H * W, rows16 = (rows + 15) / 16 * 16;
   const size_t total = rows16 * (size_t)(C / 8);
   cw_pack_image_ex_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream_>>>(x, ldx, Cx, nchw, aux, lda, N, H, W, C, flags & 1,
-                                                                                     (flags >> 1) & 1, (unsigned char*)img);
+                                                                                     (flags >> 1) & 1, (flags >> 2) & 1, (unsigned char*)img);
   return check_launch("cw_pack_image_ex_kernel");
+}
+
+// gradient of nearest upsampling by 2: dx [N][H / 2][W / 2][C] = the sum of the four dy [N][H][W][ld] pixels it was copied to
+__global__ __launch_bounds__(256) void cw_upsample2_bwd_kernel(const float* __restrict__ dy, long long ld, int N, int H, int W, int C,
+                                                               float* __restrict__ dx) {
+  const int c4n = C >> 2, h2 = H >> 1, w2 = W >> 1;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)N * h2 * w2 * c4n) return;
+  const int c4 = (int)(t % c4n);
+  const size_t p = t / c4n;
+  const int x = (int)(p % w2), y = (int)((p / w2) % h2);
+  const size_t n = p / ((size_t)w2 * h2);
+  const float* s = dy + ((n * H + 2 * y) * W + 2 * x) * ld + c4 * 4;
+  const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + ld);
+  const float4 c = *reinterpret_cast<const float4*>(s + (size_t)W * ld), d = *reinterpret_cast<const float4*>(s + (size_t)W * ld + ld);
+  *reinterpret_cast<float4*>(dx + p * C + c4 * 4) = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+}
+
+extern "C" int evae_cw_upsample2_bwd(const float* dy, long long ld, int N, int H, int W, int C, float* dx, evae_stream_t stream_) {
+  EVAE_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && ((H | W) & 1) == 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0, "cw_upsample2_bwd: bad arguments");
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
+  cw_upsample2_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream_>>>(dy, ld, N, H, W, C, dx);
+  return check_launch("cw_upsample2_bwd_kernel");
 }
 
 extern "C" int evae_cw_gate_bwd_image(const float* v, const void* eimg, int planar, const float* s, int N, int H, int W, int C, void* oimg,
@@ -468,7 +498,7 @@ static int cw_plain_ok(const evae_conv_desc_t* d, int what) {
     return cw_window_slots(OH, OH, plo, phi, 256) <= 576;
   }
   if (what == 1) {
-    if (d->C > 128 || d->C % 8 != 0) return 0;
+    if (d->C > 128) return 0;
     for (int py = 0; py < d->stride; ++py)
       for (int px = 0; px < d->stride; ++px) {
         int plo, phi;
@@ -530,7 +560,7 @@ extern "C" int evae_cw_plain_bwd_data(const void* dyimg, int dy_planar, const ev
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(cw_plain_ok(d, 1), "cw_plain_bwd_data: unsupported geometry");
   EVAE_REQUIRE(dyimg && w && (dx_f || dximg) && ws && ws_bytes >= evae_cw_plain_workspace_bytes(d, 1), "cw_plain_bwd_data: null pointer / workspace too small");
-  EVAE_REQUIRE(!dx_f || ldx >= d->C, "cw_plain_bwd_data: ldx smaller than the channel count");
+  EVAE_REQUIRE(!dx_f || ldx >= (d->C + 7) / 8 * 8, "cw_plain_bwd_data: ldx smaller than the channel count rounded up to 8");
   EVAE_REQUIRE(!dximg || d->C % 16 == 0, "cw_plain_bwd_data: an image needs a multiple of 16 channels");
   const int st = d->stride, OH = d->H / st, C = d->C, Co = d->Co;
   const int ncg = cup16(Co) / 16, bn = C <= 32 ? 32 : 64, tiles_n = cdiv(C, bn), wrows = (tiles_n * bn + 127) / 128 * 128;

@@ -156,6 +156,7 @@ SIGNATURES = {
     "evae_cw_plain_supported": (_i, [_p, _i]),
     "evae_cw_plain_workspace_bytes": (_z, [_p, _i]),
     "evae_cw_pack_image_ex": (_i, [_p, C.c_longlong, _i, _i, _p, C.c_longlong, _i, _i, _i, _i, _i, _p, _p]),
+    "evae_cw_upsample2_bwd": (_i, [_p, C.c_longlong, _i, _i, _i, _i, _p, _p]),
     "evae_cw_plain_fwd": (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, _p, _z, _p]),
     "evae_cw_plain_bwd_data": (_i, [_p, _i, _p, _p, _p, _i, _p, _p, _z, _p]),
     "evae_weight_norm_set_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p]),

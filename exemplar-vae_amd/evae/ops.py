@@ -1437,11 +1437,14 @@ def _cup(c, m):
     return (c + m - 1) // m * m
 
 
-def plain_conv_supported(x, w, stride, padding, need_dx=None):
-    """A 3 x 3 'same' convolution (stride 1 or 2, any channel counts <= 128) on the window kernels?  (enough pixels to fill the machine)"""
+def plain_conv_supported(x, w, stride, padding, need_dx=None, upsample=False):
+    """A 3 x 3 'same' convolution (stride 1 or 2, any channel counts <= 128) on the window kernels?  (enough pixels to fill the machine;
+    upsample: x is the half-resolution tensor in front of nn.Upsample(scale_factor=2))"""
     if not (CONV_STACK_ON and x.is_cuda and x.dim() == 4 and w.dim() == 4):
         return False
     N, Cc, H, W = x.shape
+    if upsample:
+        H, W = 2 * H, 2 * W
     Co, Ci, KH, KW = w.shape
     st = stride[0] if isinstance(stride, (tuple, list)) else stride
     pd = padding[0] if isinstance(padding, (tuple, list)) else padding
@@ -1465,7 +1468,7 @@ class PlainConvFn(torch.autograd.Function):
     gradients read."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, elu):
+    def forward(ctx, x, w, b, stride, elu, upsample=False):
         lib = _lib.load()
         w = _f32(w)
         _need_cuda(x, w)
@@ -1475,27 +1478,30 @@ class PlainConvFn(torch.autograd.Function):
             x = _cl(x)
         dev = x.device
         N, Cc, H, W = x.shape
+        if upsample:                                   # nn.Upsample(scale_factor=2) in front of the convolution: done by the pack
+            H, W = 2 * H, 2 * W
         Co = w.shape[0]
         st = int(stride)
         OH, OW = H // st, W // st
         d = _lib.ConvDesc(N, Cc, H, W, Co, 3, 3, st, 1)
         Cp, Cop, Co8 = _cup(Cc, 16), _cup(Co, 16), _cup(Co, 8)
         ximg = torch.empty(int(lib.evae_cw_image_bytes(N * H * W, Cp)), dtype=torch.uint8, device=dev)
-        _lib.check(lib.evae_cw_pack_image_ex(_p(x), Cc, Cc, nchw, None, 0, N, H, W, Cp, 1 if st == 2 else 0, _p(ximg), _stream()), "evae_cw_pack_image_ex")
+        _lib.check(lib.evae_cw_pack_image_ex(_p(x), Cc, Cc, nchw, None, 0, N, H, W, Cp, (1 if st == 2 else 0) | (4 if upsample else 0), _p(ximg),
+                                             _stream()), "evae_cw_pack_image_ex")
         out = torch.empty((N, OH, OW, Co8), device=dev)
         ws = _workspace("cw", lib.evae_cw_plain_workspace_bytes(C.byref(d), 0), dev)
         _lib.check(lib.evae_cw_plain_fwd(_p(ximg), C.byref(d), _p(w), _p(b), 1 if elu else 0, _p(out), Co8, None, 0, _p(ws), ws.numel(), _stream()),
                    "evae_cw_plain_fwd")
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(w)
-            ctx.keep = (ximg, d, out if elu else None, b is not None, (Cp, Cop, Co8))
+            ctx.keep = (ximg, d, out if elu else None, b is not None, (Cp, Cop, Co8), bool(upsample))
         return out.permute(0, 3, 1, 2)[:, :Co]
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
         (w,) = ctx.saved_tensors
-        ximg, d, act, has_b, (Cp, Cop, Co8) = ctx.keep
+        ximg, d, act, has_b, (Cp, Cop, Co8), upsample = ctx.keep
         ctx.keep = None
         dev = dy.device
         N, Cc, H, W, Co, st = d.N, d.C, d.H, d.W, d.Co, d.stride
@@ -1519,16 +1525,21 @@ class PlainConvFn(torch.autograd.Function):
             gw = dwp[:Co, :Cc].contiguous() if (Cop != Co or Cp != Cc) else dwp
             gb = dbp[:Co] if has_b else None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((N, H, W, Cc), device=dev)
+            C8 = _cup(Cc, 8)
+            dx = torch.empty((N, H, W, C8), device=dev)
             ws = _workspace("cw", lib.evae_cw_plain_workspace_bytes(C.byref(d), 1), dev)
-            _lib.check(lib.evae_cw_plain_bwd_data(_p(dyimg), 0, C.byref(d), _p(w), _p(dx), Cc, None, _p(ws), ws.numel(), _stream()),
+            _lib.check(lib.evae_cw_plain_bwd_data(_p(dyimg), 0, C.byref(d), _p(w), _p(dx), C8, None, _p(ws), ws.numel(), _stream()),
                        "evae_cw_plain_bwd_data")
-            gx = dx.permute(0, 3, 1, 2)
-        return gx, gw, gb, None, None
+            if upsample:
+                lo = torch.empty((N, H // 2, W // 2, C8), device=dev)
+                _lib.check(lib.evae_cw_upsample2_bwd(_p(dx), C8, N, H, W, C8, _p(lo), _stream()), "evae_cw_upsample2_bwd")
+                dx = lo
+            gx = dx.permute(0, 3, 1, 2)[:, :Cc]
+        return gx, gw, gb, None, None, None
 
 
-def plain_conv(x, w, b, stride=1, elu=False):
-    return PlainConvFn.apply(x, w, b, int(stride[0] if isinstance(stride, (tuple, list)) else stride), bool(elu))
+def plain_conv(x, w, b, stride=1, elu=False, upsample=False):
+    return PlainConvFn.apply(x, w, b, int(stride[0] if isinstance(stride, (tuple, list)) else stride), bool(elu), bool(upsample))
 
 
 def _ptr_array(ts):

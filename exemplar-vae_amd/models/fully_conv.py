@@ -88,6 +88,15 @@ class _Seq(nn.Sequential):
                     x = ops.res_block(x, weight(m.conv1), m.conv1.bias)
                     i += 1
                     continue
+            if (fused and isinstance(m, nn.Upsample) and m.scale_factor in (2, 2.0) and m.mode == "nearest" and i + 1 < len(mods) and _is_wn(mods[i + 1])
+                    and os.environ.get("EVAE_PLAIN_CONV", "1") != "0"):
+                c = mods[i + 1]
+                w = weight(c)
+                if ops.plain_conv_supported(x, w, c.stride, c.padding, upsample=True):      # the upsampling happens in the image pack
+                    elu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ELU)
+                    x = ops.plain_conv(x, w, c.bias, c.stride, elu=elu, upsample=True)
+                    i += 3 if elu else 2
+                    continue
             if fused and _is_wn(m):
                 w = weight(m)
                 elu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ELU)

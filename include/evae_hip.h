@@ -488,7 +488,12 @@ int evae_cw_first_bwd_weight(const float* dy, const float* x, const evae_conv_de
  *     (nchw), optionally times ELU'(pre) given aux = ELU(pre) (channels-last rows of lda floats); flags as evae_cw_pack_image.
  *   evae_cw_plain_fwd: y = conv(x, w) + b; act bit 0: y = ELU(y), bit 1: the image holds ELU(y) (a residual run reads it);
  *     out_f [N OH OW][ldo] (ldo >= Co rounded up to 8, zeros above Co) and / or oimg.
- *   evae_cw_plain_bwd_data: dx_f [N H W][ldx] and / or dximg from the image of dy (rows planar when dy_planar). */
+ *   evae_cw_plain_bwd_data: dx_f [N H W][ldx] (ldx >= C rounded up to 8: whole 8-channel pieces, zeros above C) and / or dximg
+ *     (C % 16 == 0) from the image of dy (rows planar when dy_planar).
+ *   evae_cw_pack_image_ex flag bit 2: x is the half-resolution tensor [N][H / 2][W / 2] -- nn.Upsample(scale_factor=2) in front of the
+ *     convolution (models/fully_conv.py:50,54) happens in the pack; evae_cw_upsample2_bwd: its gradient, dx [N][H/2][W/2][C] = the sum
+ *     of the four dy [N][H][W][ld] pixels. */
+int evae_cw_upsample2_bwd(const float* dy, long long ld, int N, int H, int W, int C, float* dx, evae_stream_t stream);
 int evae_cw_plain_supported(const evae_conv_desc_t* d, int what);
 size_t evae_cw_plain_workspace_bytes(const evae_conv_desc_t* d, int what);
 int evae_cw_pack_image_ex(const float* x, long long ldx, int Cx, int nchw, const float* aux, long long lda, int N, int H, int W, int C,

@@ -391,6 +391,8 @@ def test_weight_norm_set_matches_torch_weight_norm():
                                                     # channels does not fit LDS at this grid: training keeps evae.ops.conv2d there)
     (6, 96, 64, 48, 1, True, True, "cl"),           # 96 -> 48 on the 64 x 64 grid + ELU
     (33, 16, 16, 24, 1, False, True, "cl"),         # ragged last block, channels that are no multiple of 16 / 32
+    (40, 1, 32, 96, 1, True, True, "up"),           # the decoder's first convolution: ONE channel, nn.Upsample(2) in front (16 -> 32)
+    (7, 96, 64, 48, 1, True, True, "up"),           # its second: 96 -> 48 behind nn.Upsample(2) (32 -> 64)
 ])
 def test_plain_convolution_on_pixel_images_matches_float64(N, C, H, Co, stride, elu, xgrad, layout):
     """evae.ops.plain_conv (3 x 3 'same' convolution, stride 1 / 2, optional fused ELU: the convolutions outside fully_conv's residual
@@ -398,17 +400,18 @@ def test_plain_convolution_on_pixel_images_matches_float64(N, C, H, Co, stride, 
     and bias, the gradient handed over as NCHW planes or channels-last."""
     from evae import ops
     torch.manual_seed(N + C)
-    x = torch.randn(N, C, H, H, device="cuda")
+    up = layout == "up"
+    x = torch.randn(N, C, H // 2 if up else H, H // 2 if up else H, device="cuda")
     if layout == "cl":
         x = x.contiguous(memory_format=torch.channels_last)
     fwd_only = xgrad is None
     x.requires_grad_(bool(xgrad))
     w = (torch.randn(Co, C, 3, 3, device="cuda") * 0.1).requires_grad_(not fwd_only)
     b = (torch.randn(Co, device="cuda") * 0.3).requires_grad_(not fwd_only)
-    assert ops.plain_conv_supported(x, w, stride, 1)
-    y = ops.plain_conv(x, w, b, stride, elu=elu)
+    assert ops.plain_conv_supported(x, w, stride, 1, upsample=up)
+    y = ops.plain_conv(x, w, b, stride, elu=elu, upsample=up)
     x64, w64, b64 = (t.detach().double().requires_grad_(not fwd_only) for t in (x, w, b))
-    r = torch.nn.functional.conv2d(x64, w64, b64, stride=stride, padding=1)
+    r = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x64, scale_factor=2) if up else x64, w64, b64, stride=stride, padding=1)
     if elu:
         r = torch.nn.functional.elu(r)
     assert y.shape == r.shape
