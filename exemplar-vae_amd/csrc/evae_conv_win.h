@@ -1044,10 +1044,12 @@ struct CwWgradArgs {
 };
 
 // window slots (on the padded INPUT grid) the taps of R consecutive output pixels touch
-static int cw_wgrad_window_slots(int H, int W, int K, int pad, int xs, int R) {
+// (align: the runs start at multiples of `align` pixels -- their residues modulo the image are the multiples of gcd(align, H W))
+static int cw_wgrad_window_slots(int H, int W, int K, int pad, int xs, int R, int align = 1) {
   const int PW = W * xs + 2 * pad, SP = (H * xs + 2 * pad) * PW, HW = H * W;
-  int best = 0;
-  for (int r0 = 0; r0 < HW; ++r0) {
+  int best = 0, step = align, t = HW;
+  while (t) { const int r = step % t; step = t; t = r; }          // gcd(align, HW)
+  for (int r0 = 0; r0 < HW; r0 += step) {
     const int y0 = r0 / W, x0 = r0 % W, last = r0 + R - 1;
     const int n1 = last / HW, r1 = last % HW, y1 = r1 / W, x1 = r1 % W;
     best = std::max(best, n1 * SP + (xs * y1 + K - 1) * PW + xs * x1 + K - 1 - ((xs * y0) * PW + xs * x0) + 1);
@@ -1055,15 +1057,15 @@ static int cw_wgrad_window_slots(int H, int W, int K, int pad, int xs, int R) {
   return best;
 }
 
-template <int NTW, int WSL, int NCGDY>
+template <int NTW, int WSL, int NCGDY, int SS = 1>
 struct CwWgGeom {
   static constexpr int RK = 32;                                  // pixels per stage (two k-steps)
   static constexpr int DYCG = 3 * RK * 32 + 128;                 // one channel group of the dy chunk (three planes of [32 rows][32 B]); + 128:
   static constexpr int XPL = WSL * 32;                           //   the two 16-lane groups of a transpose read (even / odd channel group)
   static constexpr int XCG = 3 * XPL + 128;                      //   then fall on different bank halves
   static constexpr int DY = NCGDY * DYCG;                        // NCGDY channel groups of merged gradient (128 channels: 8)
-  static constexpr int STAGE = DY + 2 * XCG;
-  static constexpr int LDS = 2 * STAGE;
+  static constexpr int WINB = 2 * XCG;                           // a window: both channel groups of the pair
+  static constexpr int LDS = 2 * DY + 2 * WINB;                  // dy ring [2][DY], then the window ring [2][WINB]
   static constexpr int NXP = WSL / 32;                           // 32-slot pieces of a window plane
 };
 
@@ -1074,9 +1076,12 @@ struct CwWgGeom {
 // each (dummy columns at the end).  One wave per SIMD with all columns was measured first: issue-bound (a transpose read and its
 // address add per MFMA in ONE instruction stream: 42 % of the matrix rate); with two waves a SIMD issues one wave's reads under the
 // other's MFMAs.
-template <int NTW, int WSL, int NCGDY>
+// SS: a window serves SS consecutive 32-pixel stages (a block's run of chunks starts at a multiple of SS): the taps of 32 pixels touch
+// ~3 rows of the padded grid -- six to nine times the pixels -- and consecutive stages nearly the same rows; copied once per SS stages
+// (its pieces dealt to those stages), the window costs a fraction of the dy rows instead of three to five times them.
+template <int NTW, int WSL, int NCGDY, int SS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_win_kernel(const CwWgradArgs g) {
-  typedef CwWgGeom<NTW, WSL, NCGDY> G;
+  typedef CwWgGeom<NTW, WSL, NCGDY, SS> G;
   constexpr int RK = G::RK, NKS = RK / 16, NW = 8;
   constexpr int MW = NCGDY <= 4 ? 2 : 4, CQ = NW / MW;
   constexpr int NCW = (NTW + 1 + CQ - 1) / CQ;     // columns per wave
@@ -1106,8 +1111,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int NUNIT = 1 + (G::NXP + NW - 1) / NW;
   constexpr int NDYQ = (3 * NCGDY + NW - 1) / NW;
   const int Hin = g.H * g.xs, Win = g.W * g.xs;
+  // unit 0: chunk c's dy rows -> dy buffer `buf`; unit k >= 1: chunk c is the first of a group of SS, its window -> window buffer `buf`
   auto issue_unit = [&](int c, int buf, int unit) {
-    char* const st = lds + buf * G::STAGE;
+    char* const st = lds + (unit == 0 ? buf * G::DY : 2 * G::DY + buf * G::WINB - G::DY);      // (window parts are addressed st + DY + ...)
     const int p0 = c * RK;
     const unsigned nf = fdiv((unsigned)p0, g.div_hw), remf = (unsigned)p0 - nf * (unsigned)HW;
     const unsigned yf = fdiv(remf, g.div_w), xf = remf - yf * (unsigned)g.W;
@@ -1161,10 +1167,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   };
-  auto issue_stage = [&](int c, int buf) {
-#pragma unroll
-    for (int u = 0; u < NUNIT; ++u) issue_unit(c, buf, u);
-  };
 
   // window slot (relative to the stage's base slot) of chunk row r: this lane's k rows are 16 ks + 8 lh + (t16 >> 2) (+ 4)
   auto slot_of = [&](int p0, int qbase, int r) -> int {
@@ -1203,18 +1205,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   const int nst = c1 - c0;
   if (nst > 0) {
-    issue_stage(c0, 0);
+#pragma unroll
+    for (int u = 0; u < NUNIT; ++u) issue_unit(c0, 0, u);
     for (int i = 0; i < nst; ++i) {
       const int buf = i & 1, c = c0 + i;
-      // this wave's copies of stage i have landed; barrier: everybody's have, and everybody is done with stage i - 1 (the other
-      // buffer), which the copies of stage i + 1 -- issued between this stage's MFMA groups -- overwrite
+      const int sup = i / SS, sq = i - sup * SS, wbuf = sup & 1;       // window group, stage inside it, its buffer
+      // this wave's copies have landed; barrier: everybody's have, and everybody is done with stage i - 1: its dy buffer is
+      // overwritten by the copies of stage i + 1 and -- when it closed a group -- its window buffer by the next group's window,
+      // both issued between this stage's MFMA groups
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       const bool more = i + 1 < nst && !(g.dbg & 1);
-      if (g.dbg & 2) { if (more) issue_stage(c + 1, buf ^ 1); continue; }
-      const unsigned st = lds_base + (unsigned)(buf * G::STAGE);
-      const int p0 = c * RK;
-      const unsigned nf = fdiv((unsigned)p0, g.div_hw), remf = (unsigned)p0 - nf * (unsigned)HW;
+      const bool morew = (sup + 1) * SS < nst && !(g.dbg & 1);         // a next group exists: its window's units are dealt to this group's stages
+      if (g.dbg & 2) {
+        if (more) issue_unit(c + 1, buf ^ 1, 0);
+#pragma unroll
+        for (int u = 1; u < NUNIT; ++u) if (morew && (u - 1) % SS == sq) issue_unit(c0 + (sup + 1) * SS, wbuf ^ 1, u);
+        continue;
+      }
+      const unsigned st = lds_base + (unsigned)(buf * G::DY);                                   // dy rows of this stage
+      const unsigned sw = lds_base + (unsigned)(2 * G::DY + wbuf * G::WINB);                     // window of this group
+      const int p0 = c * RK, p0w = (c0 + sup * SS) * RK;
+      const unsigned nf = fdiv((unsigned)p0w, g.div_hw), remf = (unsigned)p0w - nf * (unsigned)HW;
       const unsigned yf = fdiv(remf, g.div_w), xf = remf - yf * (unsigned)g.W;
       const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)(g.xs * g.PW) + xf * (unsigned)g.xs);
       // lane addresses of the stage's k-steps: A rows kr, kr + 4 of this wave's channel groups; B window slots of those rows
@@ -1223,7 +1235,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int ks = 0; ks < NKS; ++ks) {
         const int kr = 16 * ks + 8 * lh + (t16 >> 2);
         aA[ks] = st + (unsigned)((2 * wm + ib) * G::DYCG + kr * 32 + (t16 & 3) * 8);
-        const unsigned xb = st + (unsigned)(G::DY + ib * G::XCG + (t16 & 3) * 8);
+        const unsigned xb = sw + (unsigned)(ib * G::XCG + (t16 & 3) * 8);
         bB0[ks] = xb + (unsigned)(slot_of(p0, qbase, kr) * 32);
         bB1[ks] = xb + (unsigned)(slot_of(p0, qbase, kr + 4) * 32);
       }
@@ -1295,13 +1307,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-        // a unit of the next stage's copies behind the first steps of the stage (the matrix pipe works them off meanwhile)
-        if (t < NUNIT && more) issue_unit(c + 1, buf ^ 1, t);
+        // a unit of the coming copies behind the first steps of the stage (the matrix pipe works them off meanwhile): the next
+        // stage's dy rows, this stage's share of the next group's window
+        if (t == 0) { if (more) issue_unit(c + 1, buf ^ 1, 0); }
+        else if (t < NUNIT) { if (morew && (t - 1) % SS == sq) issue_unit(c0 + (sup + 1) * SS, wbuf ^ 1, t); }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (more) {                                    // fewer steps than units: the remaining units
+      {                                              // fewer steps than units: the remaining units
 #pragma unroll
-        for (int u = NSTEP; u < NUNIT; ++u) issue_unit(c + 1, buf ^ 1, u);
+        for (int u = NSTEP; u < NUNIT; ++u) {
+          if (u == 0) { if (more) issue_unit(c + 1, buf ^ 1, 0); }
+          else if (morew && (u - 1) % SS == sq) issue_unit(c0 + (sup + 1) * SS, wbuf ^ 1, u);
+        }
       }
     }
   }
@@ -1367,12 +1384,13 @@ __global__ __launch_bounds__(256) void cw_wgrad_finish_kernel(const float* __res
 }
 static inline int cw_wgrad_finish_blocks(int CC, int ntap, int Cin) { return (CC * ntap * Cin + 31) / 32 + (CC + 31) / 32; }
 
-template <int NTW, int WSL, int NCGDY>
+template <int NTW, int WSL, int NCGDY, int SS = 1>
 static int launch_conv_wgrad_win(CwWgradArgs& g, int nblk, hipStream_t stream, const char* what) {
-  typedef CwWgGeom<NTW, WSL, NCGDY> G;
+  typedef CwWgGeom<NTW, WSL, NCGDY, SS> G;
+  static_assert(G::LDS <= 160 * 1024, "stage ring beyond a CU's LDS");
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<NTW, WSL, NCGDY>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<NTW, WSL, NCGDY, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     attr_done = true;
   }
   if (g.xs == 0) g.xs = 1;
@@ -1383,7 +1401,15 @@ static int launch_conv_wgrad_win(CwWgradArgs& g, int nblk, hipStream_t stream, c
   if (g.istride == 0) g.istride = g.H * g.W * g.xs * g.xs;
   g.nchunk = cdiv(g.M, G::RK);
   g.cper = cdiv(g.nchunk, nblk);
-  conv_wgrad_win_kernel<NTW, WSL, NCGDY><<<dim3(cdiv(g.nchunk, g.cper)), 512, G::LDS, stream>>>(g);
+  if (cw_wgrad_window_slots(g.H, g.W, g.plo + g.phi + 1, g.plo, g.xs, G::RK * SS) > WSL) {
+    // the window holds SS stages only from aligned starts: every block's run starts at a multiple of SS chunks
+    g.cper = (g.cper + SS - 1) / SS * SS;
+    if (cw_wgrad_window_slots(g.H, g.W, g.plo + g.phi + 1, g.plo, g.xs, G::RK * SS, G::RK * SS) > WSL) {
+      set_error("%s: window of %d slots too small for %d stages", what, WSL, SS);
+      return EVAE_EINVAL;
+    }
+  }
+  conv_wgrad_win_kernel<NTW, WSL, NCGDY, SS><<<dim3(cdiv(g.nchunk, g.cper)), 512, G::LDS, stream>>>(g);
   return check_launch(what);
 }
 

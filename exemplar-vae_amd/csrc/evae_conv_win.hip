@@ -178,7 +178,13 @@ static int cw_wgrad_ok(const evae_conv_desc_t* d, int gated = 1) {
   const int OH = d->H / d->stride;
   const int need = cw_wgrad_window_slots(OH, OH, d->KH, d->pad, d->stride, 32);
   if (d->stride == 1 && d->KH == 5) return need <= 192 ? 1 : 0;
-  if (d->stride == 1 && d->KH == 3) return need <= 192 ? 2 : ((CCq <= 64 && need <= 320) ? 3 : 0);    // (wide grids: the 320-slot window of variant 3)
+  if (d->stride == 1 && d->KH == 3) {
+    // a window for several stages (variants 5 / 6): four stages in 288 slots with <= 64 merged channels (aligned runs where the grid
+    // is wide), two stages in 224 slots with <= 128
+    if (CCq <= 64 && cw_wgrad_window_slots(OH, OH, 3, d->pad, 1, 128, 128) <= 288) return 5;
+    if (CCq > 64 && cw_wgrad_window_slots(OH, OH, 3, d->pad, 1, 64) <= 224) return 6;
+    return need <= 192 ? 2 : ((CCq <= 64 && need <= 320) ? 3 : 0);    // (wide grids: the 320-slot window of variant 3)
+  }
   if (d->stride == 2 && d->KH == 3) {
     if (CCq <= 64 && need <= 320) return 3;
     return need <= 256 ? 4 : 0;
@@ -403,6 +409,8 @@ static int cw_bwd_weight_impl(const void* dyimg, int dy_planar, const void* ximg
       int rc;
       if (variant == 1) rc = nt == 13 ? launch_conv_wgrad_win<13, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight")
                                       : launch_conv_wgrad_win<12, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      else if (variant == 5) rc = launch_conv_wgrad_win<9, 288, 4, 4>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      else if (variant == 6) rc = launch_conv_wgrad_win<9, 224, 8, 2>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
       else if (variant == 2 && CC <= 64) rc = launch_conv_wgrad_win<9, 192, 4>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
       else if (variant == 2) rc = launch_conv_wgrad_win<9, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
       else if (variant == 3) rc = launch_conv_wgrad_win<9, 320, 4>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
