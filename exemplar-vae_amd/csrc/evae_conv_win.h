@@ -1065,7 +1065,8 @@ struct CwWgGeom {
   static constexpr int XCG = 3 * XPL + 128;                      //   then fall on different bank halves
   static constexpr int DY = NCGDY * DYCG;                        // NCGDY channel groups of merged gradient (128 channels: 8)
   static constexpr int WINB = 2 * XCG;                           // a window: both channel groups of the pair
-  static constexpr int LDS = 2 * DY + 2 * WINB;                  // dy ring [2][DY], then the window ring [2][WINB]
+  static constexpr int DR = SS > 1 ? 3 : 2;                      // dy ring depth: with a shared window the dy rows are requested TWO stages ahead
+  static constexpr int LDS = DR * DY + 2 * WINB;                 // dy ring [DR][DY], then the window ring [2][WINB]
   static constexpr int NXP = WSL / 32;                           // 32-slot pieces of a window plane
 };
 
@@ -1111,9 +1112,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int NUNIT = 1 + (G::NXP + NW - 1) / NW;
   constexpr int NDYQ = (3 * NCGDY + NW - 1) / NW;
   const int Hin = g.H * g.xs, Win = g.W * g.xs;
-  // unit 0: chunk c's dy rows -> dy buffer `buf`; unit k >= 1: chunk c is the first of a group of SS, its window -> window buffer `buf`
-  auto issue_unit = [&](int c, int buf, int unit) {
-    char* const st = lds + (unit == 0 ? buf * G::DY : 2 * G::DY + buf * G::WINB - G::DY);      // (window parts are addressed st + DY + ...)
+  // unit 0: chunk c's dy rows -> dy buffer `buf`; unit k >= 1: chunk c is the first of a group of SS, its window -> window buffer `buf`.
+  // Returns the number of copy instructions this wave issued (the wait in front of a later stage leaves the newest ones in flight).
+  auto issue_unit = [&](int c, int buf, int unit) -> int {
+    char* const st = lds + (unit == 0 ? buf * G::DY : G::DR * G::DY + buf * G::WINB - G::DY);      // (window parts are addressed st + DY + ...)
+    int issued = 0;
     const int p0 = c * RK;
     const unsigned nf = fdiv((unsigned)p0, g.div_hw), remf = (unsigned)p0 - nf * (unsigned)HW;
     const unsigned yf = fdiv(remf, g.div_w), xf = remf - yf * (unsigned)g.W;
@@ -1125,9 +1128,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int mm = p0 + r;
       const bool ok = mm < g.M;
       const unsigned mc = ok ? (unsigned)mm : 0u;
-      const unsigned n = fdiv(mc, g.div_hw), rem = mc - n * (unsigned)HW;
-      const unsigned y = fdiv(rem, g.div_w), x = rem - y * (unsigned)g.W;
-      const int row = (int)n * HW + (g.dy_planar ? cw_planar((int)y, (int)x, g.H, g.W) : (int)rem);
+      int row = (int)mc;                                              // natural rows: the pixel index itself
+      if (g.dy_planar) {
+        const unsigned n = fdiv(mc, g.div_hw), rem = mc - n * (unsigned)HW;
+        const unsigned y = fdiv(rem, g.div_w), x = rem - y * (unsigned)g.W;
+        row = (int)n * HW + cw_planar((int)y, (int)x, g.H, g.W);
+      }
       const int rel = row - dbase;
       const unsigned gh = (unsigned)(hp ^ ((row >> 3) & 1));          // the image's own half swap; LDS keeps logical halves in place
       unsigned vin = (unsigned)(rel >> 4) * (unsigned)(g.nks_dy * P6_GROUP) + (unsigned)((rel & 15) * 32) + (gh << 4);
@@ -1136,13 +1142,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int q = 0; q < NDYQ; ++q) {
         const int id = wave + NW * q, cg = id / 3, p = id - cg * 3;
-        if (id < 3 * NCGDY && cg < ncgdy)
+        if (id < 3 * NCGDY && cg < ncgdy) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rD, (p6_lds_t)(st + cg * G::DYCG + p * (RK * 32)), 16, voff, (unsigned)(cg * P6_GROUP + p * P6_CHUNK), 0, 0);
+          ++issued;
+        }
       }
     } else {
       // ---- window slot piece jj of the input grid ----
       const int jj = wave + NW * (unit - 1);
-      if (jj >= G::NXP) return;
+      if (jj >= G::NXP) return 0;
+      issued = 6;
       const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)(g.xs * g.PW) + xf * (unsigned)g.xs);
       const int xbase = (int)((nf * (unsigned)g.istride) & ~15u);
       const rsrc_t rX = make_rsrc(g.ximg + ((size_t)(xbase >> 4) * g.nks_x + (size_t)g.xcg0) * P6_GROUP, 0x7FFFFFFFu);
@@ -1165,6 +1174,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (p6_lds_t)(st + G::DY + cg * G::XCG + p * G::XPL + jj * 1024), 16,
                                                  (cg == 0 || cg1) ? voff : 0x80000000u, (unsigned)(cg * P6_GROUP + p * P6_CHUNK), 0, 0);
       }
+    }
+    return issued;
+  };
+  // s_waitcnt vmcnt(n) for a wave-uniform n (copies retire in order: the newest n may stay in flight)
+  auto wait_copies = [&](int n) {
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
     }
   };
 
@@ -1203,41 +1228,60 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     isb[u] = c == NTW;
   }
 
+  // lane addresses of stage i's k-steps (dy buffer bufi): A rows kr, kr + 4 of this wave's channel groups; B window slots of those rows.
+  // ~100 VALU instructions -- computed for stage i + 1 between the MFMAs of stage i's last step: in front of the stage, behind its
+  // barrier, both waves of a SIMD would do them at the same time with the matrix pipe idle (measured: 1600 of a stage's 3900 clocks)
+  auto stage_addrs = [&](int i, int bufi, unsigned (&A)[NKS], unsigned (&B0)[NKS], unsigned (&B1)[NKS]) {
+    const int sup = i / SS, wbuf = sup & 1;
+    const unsigned st = lds_base + (unsigned)(bufi * G::DY);                                  // dy rows of the stage
+    const unsigned sw = lds_base + (unsigned)(G::DR * G::DY + wbuf * G::WINB);                // window of its group
+    const int p0 = (c0 + i) * RK, p0w = (c0 + sup * SS) * RK;
+    const unsigned nf = fdiv((unsigned)p0w, g.div_hw), remf = (unsigned)p0w - nf * (unsigned)HW;
+    const unsigned yf = fdiv(remf, g.div_w), xf = remf - yf * (unsigned)g.W;
+    const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)(g.xs * g.PW) + xf * (unsigned)g.xs);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int kr = 16 * ks + 8 * lh + (t16 >> 2);
+      A[ks] = st + (unsigned)((2 * wm + ib) * G::DYCG + kr * 32 + (t16 & 3) * 8);
+      const unsigned xb = sw + (unsigned)(ib * G::XCG + (t16 & 3) * 8);
+      B0[ks] = xb + (unsigned)(slot_of(p0, qbase, kr) * 32);
+      B1[ks] = xb + (unsigned)(slot_of(p0, qbase, kr + 4) * 32);
+    }
+  };
+
+#ifdef EVAE_CW_ABL
+  const int dbg = g.dbg;                             // (tools/micro/cw_bench.hip: ablations; the library build carries no such branches)
+#else
+  constexpr int dbg = 0;
+#endif
   const int nst = c1 - c0;
+  constexpr int LA = G::DR - 1;                     // stages the dy rows are requested ahead
+  static_assert(SS == 1 || NUNIT <= SS, "a shared window's units: one per stage, the last two stages before the group it serves");
   if (nst > 0) {
+    int flying = 0;                                 // copies this wave issued in the latest slot (they may stay in flight over the next wait)
 #pragma unroll
-    for (int u = 0; u < NUNIT; ++u) issue_unit(c0, 0, u);
-    for (int i = 0; i < nst; ++i) {
-      const int buf = i & 1, c = c0 + i;
+    for (int u = NUNIT - 1; u >= 0; --u) (void)issue_unit(c0, 0, u);          // window first, then the dy rows
+    if (LA == 2 && nst > 1 && !(dbg & 1)) flying = issue_unit(c0 + 1, 1, 0);
+    int buf = 0;
+    unsigned aA[NKS], bB0[NKS], bB1[NKS], nA[NKS], nB0[NKS], nB1[NKS];
+    stage_addrs(0, 0, aA, bB0, bB1);
+    for (int i = 0; i < nst; ++i, buf = buf + 1 == G::DR ? 0 : buf + 1) {
+      const int c = c0 + i;
       const int sup = i / SS, sq = i - sup * SS, wbuf = sup & 1;       // window group, stage inside it, its buffer
-      // this wave's copies have landed; barrier: everybody's have, and everybody is done with stage i - 1: its dy buffer is
-      // overwritten by the copies of stage i + 1 and -- when it closed a group -- its window buffer by the next group's window,
-      // both issued between this stage's MFMA groups
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int nbuf = LA == 2 ? (buf == 0 ? 2 : buf - 1) : buf ^ 1;   // dy buffer of stage i + LA (= that of stage i - 1)
+      // this stage's copies have landed (LA == 2: those of the slot before the latest one); barrier: everybody's have, and everybody
+      // is done with stage i - 1: its dy buffer is overwritten by the copies of stage i + LA and -- when it closed a group -- its
+      // window buffer by the next group's window, both issued between this stage's MFMA groups
+      wait_copies(LA == 2 ? flying : 0);
       __builtin_amdgcn_s_barrier();
-      const bool more = i + 1 < nst && !(g.dbg & 1);
-      const bool morew = (sup + 1) * SS < nst && !(g.dbg & 1);         // a next group exists: its window's units are dealt to this group's stages
-      if (g.dbg & 2) {
-        if (more) issue_unit(c + 1, buf ^ 1, 0);
+      const bool more = i + LA < nst && !(dbg & 1);
+      const bool morew = (sup + 1) * SS < nst && !(dbg & 1);         // a next group exists: its window's units are dealt to this group's stages
+      flying = 0;
+      if (dbg & 2) {
 #pragma unroll
-        for (int u = 1; u < NUNIT; ++u) if (morew && (u - 1) % SS == sq) issue_unit(c0 + (sup + 1) * SS, wbuf ^ 1, u);
+        for (int u = 1; u < NUNIT; ++u) if (morew && (SS == 1 || u - 1 == sq)) flying += issue_unit(c0 + (sup + 1) * SS, wbuf ^ 1, u);
+        if (more) flying += issue_unit(c + LA, nbuf, 0);
         continue;
-      }
-      const unsigned st = lds_base + (unsigned)(buf * G::DY);                                   // dy rows of this stage
-      const unsigned sw = lds_base + (unsigned)(2 * G::DY + wbuf * G::WINB);                     // window of this group
-      const int p0 = c * RK, p0w = (c0 + sup * SS) * RK;
-      const unsigned nf = fdiv((unsigned)p0w, g.div_hw), remf = (unsigned)p0w - nf * (unsigned)HW;
-      const unsigned yf = fdiv(remf, g.div_w), xf = remf - yf * (unsigned)g.W;
-      const int qbase = (int)(nf * (unsigned)g.SP + yf * (unsigned)(g.xs * g.PW) + xf * (unsigned)g.xs);
-      // lane addresses of the stage's k-steps: A rows kr, kr + 4 of this wave's channel groups; B window slots of those rows
-      unsigned aA[NKS], bB0[NKS], bB1[NKS];
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const int kr = 16 * ks + 8 * lh + (t16 >> 2);
-        aA[ks] = st + (unsigned)((2 * wm + ib) * G::DYCG + kr * 32 + (t16 & 3) * 8);
-        const unsigned xb = sw + (unsigned)(ib * G::XCG + (t16 & 3) * 8);
-        bB0[ks] = xb + (unsigned)(slot_of(p0, qbase, kr) * 32);
-        bB1[ks] = xb + (unsigned)(slot_of(p0, qbase, kr + 4) * 32);
       }
       // The stage as NKS * NGRP steps (k-step ks, column group jg): a step's MFMAs run on fragments read during the step BEFORE --
       // two transpose reads behind each of its first MFMAs, so that they have half a step to land before the wait in front of
@@ -1247,7 +1291,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // read #e of step t into fragment buffers: e < 6 (only when the step opens a k-step): A (plane e / 2, half e & 1); then the
       // group's B fragments: column u = e' / 6, plane (e' % 6) / 2, half e' & 1
       auto read_step = [&](int t, int e) {
-        if (g.dbg & 4) return;                       // (tools: the MFMA stream without its fragment reads)
+        if (dbg & 4) return;                         // (tools: the MFMA stream without its fragment reads)
         const int ks = t / NGRP, jg = t - ks * NGRP, j = GS * jg;
         const int na = jg == 0 ? 6 : 0;
         if (e < na) {
@@ -1283,7 +1327,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int p = 0; p < 3; ++p)
             if (j + u < NCW) {
               u32x4_ v = {br[t & 1][u][p].lo[0], br[t & 1][u][p].lo[1], br[t & 1][u][p].hi[0], br[t & 1][u][p].hi[1]};
-              if ((CQ - 1) * NCW + j + u >= NTW) {  // this column may be the bias column (of a later column part): the ones operand instead
+              if ((NTW - (j + u)) % NCW == 0 && (NTW - (j + u)) / NCW < CQ && NTW >= j + u) {  // this column is some column part's bias column: the ones operand instead
                 const unsigned o = p == 0 ? one1 : 0u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = isb[j + u] ? o : v[q];
@@ -1304,22 +1348,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               const int m = q * GS + u;
               if (2 * m < NRD) read_step(t + 1, 2 * m);
               if (2 * m + 1 < NRD) read_step(t + 1, 2 * m + 1);
+            } else if (q == 1 && u == 0) {
+              stage_addrs(i + 1, buf + 1 == G::DR ? 0 : buf + 1, nA, nB0, nB1);      // (the last step reads nothing ahead: room for the next stage's addresses)
             }
             __builtin_amdgcn_sched_barrier(0);
           }
         // a unit of the coming copies behind the first steps of the stage (the matrix pipe works them off meanwhile): the next
         // stage's dy rows, this stage's share of the next group's window
-        if (t == 0) { if (more) issue_unit(c + 1, buf ^ 1, 0); }
-        else if (t < NUNIT) { if (morew && (t - 1) % SS == sq) issue_unit(c0 + (sup + 1) * SS, wbuf ^ 1, t); }
+        // (window units first: the wait in front of the next stage leaves only this slot's copies in flight, in issue order)
+        if (t + 1 < NUNIT) { if (morew && (SS == 1 || t == sq)) flying += issue_unit(c0 + (sup + 1) * SS, wbuf ^ 1, t + 1); }
+        else if (t + 1 == NUNIT) { if (more) flying += issue_unit(c + LA, nbuf, 0); }
         __builtin_amdgcn_sched_barrier(0);
       }
       {                                              // fewer steps than units: the remaining units
 #pragma unroll
         for (int u = NSTEP; u < NUNIT; ++u) {
-          if (u == 0) { if (more) issue_unit(c + 1, buf ^ 1, 0); }
-          else if (morew && (u - 1) % SS == sq) issue_unit(c0 + (sup + 1) * SS, wbuf ^ 1, u);
+          if (u + 1 < NUNIT) { if (morew && (SS == 1 || u == sq)) flying += issue_unit(c0 + (sup + 1) * SS, wbuf ^ 1, u + 1); }
+          else if (more) flying += issue_unit(c + LA, nbuf, 0);
         }
       }
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) { aA[ks] = nA[ks]; bB0[ks] = nB0[ks]; bB1[ks] = nB1[ks]; }
     }
   }
   // ---- partial plane of this block: part[block][cc][tap][ci], dbpart[block][cc] ----

@@ -349,6 +349,40 @@ static void case_res(int N, int C, int H, int reps) {
   hipFree(dx); hipFree(dw); hipFree(db); hipFree(ix); hipFree(iw); hipFree(io); hipFree(dout);
 }
 
+// timing + ablations of ONE launch of the 3 x 3 stride-1 weight gradient at fully_conv's residual shapes (first channel-group pair)
+template <int WSL, int NCG, int SS>
+static void case_wgrad3(int N, int C, int H, int reps) {
+  const int K = 3, taps = 9, CC = C, M = N * H * H;
+  auto hdy = rnd((size_t)M * CC, 21, 0.1f), hx = rnd((size_t)M * C, 22);
+  float* ddy = dev(hdy); float* dx = dev(hx);
+  const int nks = C / 16, Mi = (M + 127) / 128 * 128;
+  unsigned char* idy = devz<unsigned char>(p6_image_bytes(M, nks));
+  unsigned char* ix = devz<unsigned char>(p6_image_bytes(M, nks));
+  p6_pack_rows_kernel<<<(unsigned)(((size_t)Mi * nks * 2 + 255) / 256), 256>>>(ddy, nullptr, M, CC, CC, 0, Mi, nks, idy);
+  p6_pack_rows_kernel<<<(unsigned)(((size_t)Mi * nks * 2 + 255) / 256), 256>>>(dx, nullptr, M, C, C, 0, Mi, nks, ix);
+  const int nblk = 256;
+  float* part = devz<float>((size_t)nblk * CC * taps * C); float* dbp = devz<float>((size_t)nblk * CC);
+  CwWgradArgs g; memset(&g, 0, sizeof(g));
+  g.dyimg = idy; g.nks_dy = nks; g.ximg = ix; g.nks_x = nks; g.xcg0 = 0; g.nseg = 1;
+  g.N = N; g.H = H; g.W = H; g.plo = 1; g.phi = 1; g.xs = 1;
+  const int PW = H + 2;
+  g.ntap_f = taps; g.Cin = C; g.CC = CC; g.part = part; g.dbpart = dbp;
+  for (int t = 0; t < 9; ++t) { g.tile_to[t] = (t / K) * PW + t % K; g.tile_tap[t] = t; }
+  auto run = [&]() { launch_conv_wgrad_win<9, WSL, NCG, SS>(g, nblk, 0, "cw wgrad3"); };
+  run(); CK(hipDeviceSynchronize());
+  const float t = time_us(run, reps);
+  g.dbg = 1; const float t_nocopy = time_us(run, reps);
+  g.dbg = 2; const float t_copyonly = time_us(run, reps);
+  g.dbg = 5; const float t_noread = time_us(run, reps);
+  g.dbg = 4; const float t_noread_copies = time_us(run, reps);
+  g.dbg = 0;
+  const double mf = (double)M / 16 * (NCG <= 4 ? 2 : 4) * 10 * 6;
+  printf("cw wgrad3 N=%d C=%d H=%d <9,%d,%d,%d> (%d blocks x %d chunks): %.1f us (%.0f M MFMA: %.1f us at 49 M/ms) | no copies after the first %.1f | copies only %.1f | "
+         "MFMAs alone %.1f | MFMAs + copies, no fragment reads %.1f\n", N, C, H, WSL, NCG, SS, (g.nchunk + g.cper - 1) / g.cper, g.cper, t, mf * 1e-6, mf / 49e3,
+         t_nocopy, t_copyonly, t_noread, t_noread_copies);
+  hipFree(ddy); hipFree(dx); hipFree(idy); hipFree(ix); hipFree(part); hipFree(dbp);
+}
+
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 20224;
   const int reps = argc > 2 ? atoi(argv[2]) : 10;
@@ -358,6 +392,11 @@ int main(int argc, char** argv) {
     case_fwd(37, L3, 1, 2); case_fwd(37, L3, 2, 2); case_fwd(37, L2, 1, 2); case_fwd(37, L4, 1, 2);
     case_dgrad(37, L3, 1, 2); case_dgrad(37, L3, 2, 2); case_dgrad(37, L2, 1, 2); case_dgrad(37, L4, 1, 2);
     case_wgrad(37, L3, 1, 2); case_wgrad(37, L3, 2, 2);
+  }
+  if (!strcmp(only, "wgrad3")) {
+    case_wgrad3<288, 4, 4>(100, 48, 64, reps); case_wgrad3<320, 4, 1>(100, 48, 64, reps); case_wgrad3<288, 4, 4>(100, 48, 32, reps); case_wgrad3<192, 4, 1>(100, 48, 32, reps);
+    case_wgrad3<224, 8, 2>(100, 96, 32, reps); case_wgrad3<192, 8, 1>(100, 96, 32, reps); case_wgrad3<224, 8, 2>(100, 96, 16, reps);
+    return 0;
   }
   if (!strcmp(only, "res")) { case_res(100, 48, 64, reps); case_res(100, 96, 32, reps); case_res(203, 48, 32, reps); case_res(203, 96, 16, reps); return 0; }
   if (!*only || !strcmp(only, "wgrad5")) case_wgrad(N, L3, 2, reps);
