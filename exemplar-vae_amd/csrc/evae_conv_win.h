@@ -1080,7 +1080,10 @@ struct CwWgGeom {
 // SS: a window serves SS consecutive 32-pixel stages (a block's run of chunks starts at a multiple of SS): the taps of 32 pixels touch
 // ~3 rows of the padded grid -- six to nine times the pixels -- and consecutive stages nearly the same rows; copied once per SS stages
 // (its pieces dealt to those stages), the window costs a fraction of the dy rows instead of three to five times them.
-template <int NTW, int WSL, int NCGDY, int SS>
+// PAIR: the launch contracts ONE channel group (the odd last one of the input): a column tile is then that group at TWO taps --
+// columns 0 .. 15 tap tile_to[2 c], columns 16 .. 31 tap tile_to[2 c + 1] -- instead of a channel-group pair at one tap with the
+// second group all zeros: five column tiles for nine taps, not nine (48-channel layers: a fifth of their weight gradient).
+template <int NTW, int WSL, int NCGDY, int SS, bool PAIR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_win_kernel(const CwWgradArgs g) {
   typedef CwWgGeom<NTW, WSL, NCGDY, SS> G;
   constexpr int RK = G::RK, NKS = RK / 16, NW = 8;
@@ -1168,8 +1171,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       EVAE_PIN(vin);
       const unsigned voff = ok ? vin : 0x80000000u;
       const bool cg1 = g.xcg0 + 1 < g.nks_x;               // (an odd number of channel groups: the last pair's second group reads as zeros)
+      if (PAIR) issued = 3;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
+      for (int k = 0; k < (PAIR ? 3 : 6); ++k) {
         const int cg = k / 3, p = k - cg * 3;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (p6_lds_t)(st + G::DY + cg * G::XCG + p * G::XPL + jj * 1024), 16,
                                                  (cg == 0 || cg1) ? voff : 0x80000000u, (unsigned)(cg * P6_GROUP + p * P6_CHUNK), 0, 0);
@@ -1224,7 +1228,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int u = 0; u < NCW; ++u) {
     const int c = cb + u;
-    toff[u] = (unsigned)(g.tile_to[c < NTW ? c : NTW - 1] * 32);
+    const int cq = c < NTW ? c : NTW - 1;
+    toff[u] = PAIR ? (unsigned)((ib ? g.tile_to[2 * cq + 1] : g.tile_to[2 * cq]) * 32) : (unsigned)(g.tile_to[cq] * 32);
     isb[u] = c == NTW;
   }
 
@@ -1243,7 +1248,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int ks = 0; ks < NKS; ++ks) {
       const int kr = 16 * ks + 8 * lh + (t16 >> 2);
       A[ks] = st + (unsigned)((2 * wm + ib) * G::DYCG + kr * 32 + (t16 & 3) * 8);
-      const unsigned xb = sw + (unsigned)(ib * G::XCG + (t16 & 3) * 8);
+      const unsigned xb = sw + (unsigned)((PAIR ? 0 : ib * G::XCG) + (t16 & 3) * 8);
       B0[ks] = xb + (unsigned)(slot_of(p0, qbase, kr) * 32);
       B1[ks] = xb + (unsigned)(slot_of(p0, qbase, kr + 4) * 32);
     }
@@ -1378,11 +1383,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int u = 0; u < NCW; ++u) {
       const int c = cb + u;
       if (c < NTW) {
-        const int tap = g.tile_tap[c];
+        const int tap = PAIR ? g.tile_tap[2 * c + ib] : g.tile_tap[c];           // (PAIR: tap < 0 = the empty half of the last tile)
+        const int ci = g.xcg0 * 16 + (PAIR ? (l31 & 15) : l31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cc = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (cc < g.CC && g.xcg0 * 16 + l31 < g.Cin) pb[((size_t)cc * g.ntap_f + tap) * g.Cin + g.xcg0 * 16 + l31] = acc[u][r];
+          if (cc < g.CC && ci < g.Cin && tap >= 0) pb[((size_t)cc * g.ntap_f + tap) * g.Cin + ci] = acc[u][r];
         }
       } else if (c == NTW && g.dbpart && l31 == 0) {
 #pragma unroll
@@ -1433,13 +1439,13 @@ __global__ __launch_bounds__(256) void cw_wgrad_finish_kernel(const float* __res
 }
 static inline int cw_wgrad_finish_blocks(int CC, int ntap, int Cin) { return (CC * ntap * Cin + 31) / 32 + (CC + 31) / 32; }
 
-template <int NTW, int WSL, int NCGDY, int SS = 1>
+template <int NTW, int WSL, int NCGDY, int SS = 1, bool PAIR = false>
 static int launch_conv_wgrad_win(CwWgradArgs& g, int nblk, hipStream_t stream, const char* what) {
   typedef CwWgGeom<NTW, WSL, NCGDY, SS> G;
   static_assert(G::LDS <= 160 * 1024, "stage ring beyond a CU's LDS");
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<NTW, WSL, NCGDY, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<NTW, WSL, NCGDY, SS, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     attr_done = true;
   }
   if (g.xs == 0) g.xs = 1;
@@ -1458,7 +1464,7 @@ static int launch_conv_wgrad_win(CwWgradArgs& g, int nblk, hipStream_t stream, c
       return EVAE_EINVAL;
     }
   }
-  conv_wgrad_win_kernel<NTW, WSL, NCGDY, SS><<<dim3(cdiv(g.nchunk, g.cper)), 512, G::LDS, stream>>>(g);
+  conv_wgrad_win_kernel<NTW, WSL, NCGDY, SS, PAIR><<<dim3(cdiv(g.nchunk, g.cper)), 512, G::LDS, stream>>>(g);
   return check_launch(what);
 }
 

@@ -409,6 +409,12 @@ static int cw_bwd_weight_impl(const void* dyimg, int dy_planar, const void* ximg
       int rc;
       if (variant == 1) rc = nt == 13 ? launch_conv_wgrad_win<13, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight")
                                       : launch_conv_wgrad_win<12, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      else if ((variant == 5 || variant == 6) && 2 * cp + 1 == C / 16) {
+        // the odd last channel group: two taps per column tile (five tiles for the nine taps)
+        for (int t = 0; t < 10; ++t) { g.tile_to[t] = t < 9 ? (t / K) * PW + t % K : 0; g.tile_tap[t] = t < 9 ? t : -1; }
+        rc = variant == 5 ? launch_conv_wgrad_win<5, 288, 4, 4, true>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight")
+                          : launch_conv_wgrad_win<5, 224, 8, 2, true>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      }
       else if (variant == 5) rc = launch_conv_wgrad_win<9, 288, 4, 4>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
       else if (variant == 6) rc = launch_conv_wgrad_win<9, 224, 8, 2>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
       else if (variant == 2 && CC <= 64) rc = launch_conv_wgrad_win<9, 192, 4>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");

@@ -1,7 +1,9 @@
 // Stand-alone check + timing of the window convolution kernels (csrc/evae_conv_win.h) at convhvae_2level's layer shapes.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -w -I exemplar-vae_amd/csrc tools/micro/cw_bench.hip -o tools/micro/cw_bench
 // Run on the GPU box: tools/micro/cw_bench [images] [reps]
+#ifndef CW_PLAIN_BUILD           // -DCW_PLAIN_BUILD: the kernels as the library builds them (no ablation branches): the timings that count
 #define EVAE_CW_ABL 1
+#endif
 #include "evae_conv_win.h"
 #include <cstdarg>
 #include <cstdio>
