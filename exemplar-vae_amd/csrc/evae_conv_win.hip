@@ -442,6 +442,12 @@ static int cw_res_ok(const evae_conv_desc_t* d) {
   if (cw_window_slots(d->H, d->W, d->pad, d->pad, 256) > 576) return 0;
   return cw_wgrad_ok(d, 0) != 0;
 }
+// few pixels (256-pixel row tiles would leave CUs without a block, or with one and nobody to cover its waits): 128-pixel row tiles,
+// same 64 columns (2 x 2 waves of 64 x 32)
+static bool cw_res_small(const evae_conv_desc_t* d, int plo, int phi) {
+  const long long M = (long long)d->N * d->H * d->W;
+  return cdiv((int)((M + 255) / 256), 1) * cdiv(d->C, 64) <= 320 && cw_window_slots(d->H, d->W, plo, phi, 128) <= 320;
+}
 extern "C" int evae_cw_res_supported(const evae_conv_desc_t* d) { return cw_res_ok(d); }
 
 // aimg: the image of ELU(x) (natural rows); x: fp32 [N H W][C]; y = x + conv(ELU(x)) + b -> out_f (fp32) and / or oimg = the image of ELU(y)
@@ -462,6 +468,10 @@ extern "C" int evae_cw_res_fwd(const void* aimg, const evae_conv_desc_t* d, cons
   g.xin = (const unsigned char*)aimg; g.nks_in = ncg; g.ncg = ncg; g.N = d->N; g.H = d->H; g.W = d->W; g.plo = plo; g.phi = phi; g.taps = tp;
   g.wimg = iw; g.nks_w = nks_w; g.Co = C; g.tiles_n = tiles_n; g.bias0 = b;
   g.oimg = (unsigned char*)oimg; g.nks_o = ncg; g.out_f = out_f; g.ldo = C; g.e_s = x;
+  if (cw_res_small(d, plo, phi)) {
+    g.nsp = (cw_window_slots(d->H, d->W, plo, phi, 128) + 31) / 32;
+    return launch_conv_win<CW_RES_FWD, 2, 1, 320>(g, stream, "cw_res_fwd");
+  }
   g.nsp = (cw_window_slots(d->H, d->W, plo, phi, 256) + 31) / 32;
   return launch_conv_win<CW_RES_FWD, 4, 2, 576>(g, stream, "cw_res_fwd");
 }
@@ -487,6 +497,10 @@ extern "C" int evae_cw_res_bwd_data(const void* dyimg, const evae_conv_desc_t* d
   g.wimg = iw; g.nks_w = nks_w; g.Co = C; g.tiles_n = tiles_n;
   g.oimg = (unsigned char*)dximg; g.nks_o = ncg; g.out_f = dx_f; g.ldo = C; g.e_s = dy_f;
   g.eimg = (const unsigned char*)aimg; g.nks_e = ncg;
+  if (cw_res_small(d, plo, phi)) {
+    g.nsp = (cw_window_slots(d->H, d->W, plo, phi, 128) + 31) / 32;
+    return launch_conv_win<CW_RES_BWD, 2, 1, 320>(g, stream, "cw_res_bwd_data");
+  }
   g.nsp = (cw_window_slots(d->H, d->W, plo, phi, 256) + 31) / 32;
   return launch_conv_win<CW_RES_BWD, 4, 2, 576>(g, stream, "cw_res_bwd_data");
 }
