@@ -331,14 +331,14 @@ def other_config(a, dev, rank, world, rccl_ranks=1, backend=None):
             roof["kernels"] = [
                 {"launch": "its data gradient dx = dy + ELU'(x) conv_transpose(dy, w) (evae_cw_res_bwd_data: conv_win_kernel<4, 4, 2, 576>)",
                  "us": round(us_d, 1), "frac": round(flops / us_d / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4)},
-                {"launch": "its weight gradient over pixel images (evae_cw_bwd_weight_plain: conv_wgrad_win_kernel<9, 192, 8> x 3 channel-group pairs + finish)",
+                {"launch": "its weight gradient over pixel images (evae_cw_bwd_weight_plain: conv_wgrad_win_kernel<9, 224, 8, 2, false> x 3 channel-group pairs + finish)",
                  "us": round(us_w, 1), "frac": round(flops / us_w / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4)}]
         else:
             roof = mfma_roofline(kern, flops, 6.0 * flops, "bf16-mfma", us, traffic, tsrc)
             roof["kernels"] = [
                 {"launch": "data gradient + gate derivative of the layer below (evae_cw_bwd_data_gate: conv_win_kernel<1, 4, 1, 576>)",
                  "us": round(us_d, 1), "frac": round(flops / us_d / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4)},
-                {"launch": "weight gradient over pixel images (evae_cw_bwd_weight: conv_wgrad_win_kernel<13 | 12, 192, 8> + finish)",
+                {"launch": "weight gradient over pixel images (evae_cw_bwd_weight: conv_wgrad_win_kernel<13 | 12, 192, 8, 1, false> + finish)",
                  "us": round(us_w, 1), "frac": round(flops / us_w / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4)}]
         wl = ("single_conv (fully_conv) + exemplar_prior, 3x64x64 continuous, z=256, approximate prior: top-10 over %d cached "
               "latents, <= 1000 exemplars re-encoded per step, batch %d (BASELINE.json configs[4], one GPU)" % (n_ex, B)) if c5 else \

@@ -22,7 +22,7 @@
   conv5_fwd / conv5_bwd   gated conv 32 -> 64, 5 x 5, 14 x 14, 25 000 images (c3) on the channels-last kernels: forward / data + weight gradient
   cw5_fwd / cw5_bwd / cw5_wgrad   the same layer over the 20 224 encoded rows of a c3 step on the window kernels (csrc/evae_conv_win.h):
               forward (conv_win_kernel<0, 2, 2, 320>), data gradient + gate derivative (conv_win_kernel<1, 4, 1, 576>), weight gradient
-              (conv_wgrad_win_kernel<13 | 12, 192, 8>)
+              (conv_wgrad_win_kernel<13 | 12, 192, 8, 1, false>)
   res96_fwd / res96_bwd / res96_wgrad   a residual block 96 -> 96, 3 x 3, 32 x 32, 100 images (c5's decoder) on the window kernels
   cw1_fwd / cw1_wgrad   first layer 1 -> 32, 7 x 7, 28 x 28 (conv_first_kernel / conv_first_wgrad_kernel), 20 224 images
   cw2_bwd     data gradient of the stride-2 layer 32 -> 32, 3 x 3 into the first layer's 28 x 28 grid (four parity-class launches)

@@ -56,9 +56,9 @@ MAIN = {"u8fwd1": ["u8p_gemm_kernel", "u8_gemm_kernel<true>"], "u8fwd1_img": ["u
         "topk_c5": ["gemm_x6_kernel<5, 0", "gemm_kernel<true, true, 5"], "topk_c2": ["gemm_x6_kernel<5, 0", "gemm_kernel<true, true, 5"],
         "conv5_fwd": ["gemm_x6_kernel<1, 1", "gemm_kernel<true, true, 1"], "conv5_bwd": ["gemm_x6_kernel<0, 1", "gemm_kernel<true, false, 0"],
         "conv96_fwd": ["gemm_x6_kernel<0, 1", "gemm_kernel<true, true, 0"],
-        "cw5_fwd": ["conv_win_kernel<0, 2, 2, 320>"], "cw5_bwd": ["conv_win_kernel<1, 4, 1, 576>"], "cw5_wgrad": ["conv_wgrad_win_kernel<13, 192, 8>"],
+        "cw5_fwd": ["conv_win_kernel<0, 2, 2, 320>"], "cw5_bwd": ["conv_win_kernel<1, 4, 1, 576>"], "cw5_wgrad": ["conv_wgrad_win_kernel<13, 192, 8, 1, false>"],
         "cw2_bwd": ["conv_win_kernel<1, 4, 1, 576>"], "res96_fwd": ["conv_win_kernel<3, 4, 2, 576>"], "res96_bwd": ["conv_win_kernel<4, 4, 2, 576>"],
-        "res96_wgrad": ["conv_wgrad_win_kernel<9, 192, 8>"], "cw1_fwd": ["conv_first_kernel"], "cw1_wgrad": ["conv_first_wgrad_kernel"]}
+        "res96_wgrad": ["conv_wgrad_win_kernel<9, 224, 8, 2, false>"], "cw1_fwd": ["conv_first_kernel"], "cw1_wgrad": ["conv_first_wgrad_kernel"]}
 summary = {}
 
 
