@@ -23,7 +23,15 @@ def git(*a):
 
 
 head = git("rev-parse", "HEAD")
-dirty = [l for l in git("status", "--porcelain", "--", "exemplar-vae_amd", "bench.py", "tools", "include").splitlines() if l]
+SRC = ("exemplar-vae_amd", "bench.py", "tools", "include")
+dirty = [l for l in git("status", "--porcelain", "--", *SRC).splitlines() if l]
+# the commit the GPU box ran (tools/profile_round.sh leaves it in <tag>/HEAD): later commits that only add profiles / docs do not change it
+box = os.path.join(src, "HEAD")
+ran = open(box).read().strip() if os.path.exists(box) and os.path.getsize(box) > 0 else head
+if ran != head:
+    drift = [l for l in git("diff", "--name-only", ran, head, "--", *SRC).splitlines() if l and not l.startswith("tools/profile_")]
+    dirty += ["changed since %s: %s" % (ran[:12], l) for l in drift]
+    head = ran
 stamp = {"commit": head, "source_tree_clean": not dirty, "uncommitted": dirty[:20]}
 for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
     cfg = os.path.basename(f)[len("bench_"):-len(".json")]
