@@ -10,8 +10,8 @@ __global__ __launch_bounds__(256) void cw_pack_image_kernel(const float* __restr
                                                             unsigned char* __restrict__ img) {
   const int c8n = C >> 3, nks = C >> 4;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)N * H * W * c8n;
-  if (t >= total) return;
+  // (no early exit on the thread index: inside a 16-pixel group the threads run channel-group-major, so the last, partial group's
+  // pixels sit behind thread N H W (C / 8) -- the pixel test below is the only one)
   // thread -> pixel fastest inside 16, then the 8-channel group, then the 16-pixel groups (whole 512-byte chunks per 32 lanes)
   const size_t grp = t / ((size_t)16 * c8n);
   const int r = (int)(t - grp * 16 * c8n), c8 = r >> 4, p16 = r & 15;
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void cw_pack_image_ex_kernel(const float* __re
                                                                int planar, int elu, int up, unsigned char* __restrict__ img) {
   const int c8n = C >> 3, nks = C >> 4;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)N * H * W * c8n;
-  if (t >= total) return;
+  // (no early exit on the thread index: inside a 16-pixel group the threads run channel-group-major, so the last, partial group's
+  // pixels sit behind thread N H W (C / 8) -- the pixel test below is the only one)
   const size_t grp = t / ((size_t)16 * c8n);
   const int r = (int)(t - grp * 16 * c8n), c8 = r >> 4, p16 = r & 15;
   const size_t m = grp * 16 + p16;

@@ -391,6 +391,8 @@ def test_weight_norm_set_matches_torch_weight_norm():
                                                     # channels does not fit LDS at this grid: training keeps evae.ops.conv2d there)
     (6, 96, 64, 48, 1, True, True, "cl"),           # 96 -> 48 on the 64 x 64 grid + ELU
     (33, 16, 16, 24, 1, False, True, "cl"),         # ragged last block, channels that are no multiple of 16 / 32
+    (9, 1, 28, 48, 2, True, False, "nchw"),         # 9 x 14 x 14 = 1 764 output pixels: no multiple of 16 (a partial last image chunk of dy)
+    (9, 32, 28, 48, 2, False, True, "cl"),
     (40, 1, 32, 96, 1, True, True, "up"),           # the decoder's first convolution: ONE channel, nn.Upsample(2) in front (16 -> 32)
     (7, 96, 64, 48, 1, True, True, "up"),           # its second: 96 -> 48 behind nn.Upsample(2) (32 -> 64)
 ])
