@@ -62,6 +62,7 @@ def parse():
                          "trains on its own 100-image batch (global batch 100 N) against the sharded exemplar set ('weak' in "
                          "the batch).  The replica line carries the dp measurement as a nested object (--no-dp-line skips it).")
     ap.add_argument("--no-dp-line", action="store_true", help="with --gpus N > 1: do not run the second (dp) measurement")
+    ap.add_argument("--no-amdahl", action="store_true", help="skip the amdahl_ceiling object (a second process at 200 exemplars)")
     ap.add_argument("--no-ramp", action="store_true",
                     help="skip the untimed clock-ramp replays in front of the timed region (10-step windows until two agree to 2 %%)")
     ap.add_argument("--probe-warmup", type=int, default=20,
@@ -469,6 +470,26 @@ def capture_probe():
     ok = abs(float(y[0].item()) - world * (world + 1) / 2.0) < 1e-3 and abs(float(out[-1].item()) - world) < 1e-3
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
+
+
+def amdahl_ceiling(ms_full, n_ex, small=200):
+    """Replica mode (--parallel replica: the same batch on every rank, only the exemplars sharded) has a replicated part -- the batch
+    rows' own forward / backward, the optimizer, the prior's merge -- that no rank count shrinks.  Measured here as the step at
+    C = `small` exemplars (a second process on this box, same kernels): t(R ranks) >= t_small + (t_full - t_small) / R, before any
+    collective.  The driver computes scaling efficiency itself; this is the ceiling those numbers are bounded by."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--exemplars", str(small), "--steps", "300", "--warmup", "30", "--iwae-images", "0",
+           "--cpu-baseline-steps", "0", "--probe-steps", "0", "--probe-warmup", "0", "--no-amdahl"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        ms_small = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["ms_per_step"]
+    except Exception as e:                     # a reported extra, never a reason to lose the bench line
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
+    sharded = max(ms_full - ms_small, 0.0)
+    return {"mode": "replica (exemplars sharded, batch replicated), collectives not counted", "ms_per_step_full": round(ms_full, 4),
+            "ms_per_step_at_%d_exemplars" % small: ms_small, "replicated_fraction": round(ms_small / ms_full, 3),
+            "max_speedup": {str(R): round(ms_full / (ms_small + sharded / R), 2) for R in (2, 4, 8)},
+            "note": "t(R) >= t(C = %d) + (t(C = %d) - t(C = %d)) / R; dp mode (--parallel dp) and growth in the exemplar count are not bound by it" % (small, n_ex, small)}
 
 
 def main():
@@ -898,6 +919,8 @@ def main():
         }
         if world == 1 and a.cpu_baseline_steps > 0 and model_name == "vae" and not approx:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_steps, n_ex, n_train)
+        if world == 1 and a.config == "c2" and a.exemplars is None and not a.no_amdahl:
+            out["amdahl_ceiling"] = amdahl_ceiling(1e3 * dt / a.steps, n_ex)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
