@@ -1057,14 +1057,14 @@ static int cw_wgrad_window_slots(int H, int W, int K, int pad, int xs, int R, in
   return best;
 }
 
-template <int NTW, int WSL, int NCGDY, int SS = 1>
+template <int NTW, int WSL, int NCGDY, int SS = 1, bool PAIR = false>
 struct CwWgGeom {
   static constexpr int RK = 32;                                  // pixels per stage (two k-steps)
   static constexpr int DYCG = 3 * RK * 32 + 128;                 // one channel group of the dy chunk (three planes of [32 rows][32 B]); + 128:
   static constexpr int XPL = WSL * 32;                           //   the two 16-lane groups of a transpose read (even / odd channel group)
   static constexpr int XCG = 3 * XPL + 128;                      //   then fall on different bank halves
   static constexpr int DY = NCGDY * DYCG;                        // NCGDY channel groups of merged gradient (128 channels: 8)
-  static constexpr int WINB = 2 * XCG;                           // a window: both channel groups of the pair
+  static constexpr int WINB = PAIR ? XCG : 2 * XCG;              // a window: both channel groups of the pair (PAIR: the one group)
   static constexpr int DR = SS > 1 ? 3 : 2;                      // dy ring depth: with a shared window the dy rows are requested TWO stages ahead
   static constexpr int LDS = DR * DY + 2 * WINB;                 // dy ring [DR][DY], then the window ring [2][WINB]
   static constexpr int NXP = WSL / 32;                           // 32-slot pieces of a window plane
@@ -1085,7 +1085,7 @@ struct CwWgGeom {
 // second group all zeros: five column tiles for nine taps, not nine (48-channel layers: a fifth of their weight gradient).
 template <int NTW, int WSL, int NCGDY, int SS, bool PAIR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_win_kernel(const CwWgradArgs g) {
-  typedef CwWgGeom<NTW, WSL, NCGDY, SS> G;
+  typedef CwWgGeom<NTW, WSL, NCGDY, SS, PAIR> G;
   constexpr int RK = G::RK, NKS = RK / 16, NW = 8;
   constexpr int MW = NCGDY <= 4 ? 2 : 4, CQ = NW / MW;
   constexpr int NCW = (NTW + 1 + CQ - 1) / CQ;     // columns per wave
@@ -1441,7 +1441,7 @@ static inline int cw_wgrad_finish_blocks(int CC, int ntap, int Cin) { return (CC
 
 template <int NTW, int WSL, int NCGDY, int SS = 1, bool PAIR = false>
 static int launch_conv_wgrad_win(CwWgradArgs& g, int nblk, hipStream_t stream, const char* what) {
-  typedef CwWgGeom<NTW, WSL, NCGDY, SS> G;
+  typedef CwWgGeom<NTW, WSL, NCGDY, SS, PAIR> G;
   static_assert(G::LDS <= 160 * 1024, "stage ring beyond a CU's LDS");
   static bool attr_done = false;
   if (!attr_done) {

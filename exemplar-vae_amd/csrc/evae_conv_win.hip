@@ -187,7 +187,11 @@ static int cw_wgrad_ok(const evae_conv_desc_t* d, int gated = 1) {
   }
   if (d->stride == 2 && d->KH == 3) {
     if (CCq <= 64 && need <= 320) return 3;
-    return need <= 256 ? 4 : 0;
+    if (need <= 256) return 4;
+    // wider grids (fully_conv's 64 -> 32 and 32 -> 16 layers): the window on the input grid fits LDS for ONE channel group at a time
+    // -- every group as a two-taps-per-tile launch (variants 7 / 8)
+    if (CCq <= 64 && need <= 416) return 7;
+    return need <= 288 ? 8 : 0;
   }
   return 0;
 }
@@ -400,8 +404,9 @@ static int cw_bwd_weight_impl(const void* dyimg, int dy_planar, const void* ximg
   g.ntap_f = taps; g.Cin = C; g.CC = CC; g.part = part;
   int nblk = 0;
   bool first = true;
-  for (int cp = 0; cp < (C / 16 + 1) / 2; ++cp) {  // channel-group pairs of the input (an odd last group: half a pair)
-    g.xcg0 = 2 * cp;
+  const bool single = variant == 7 || variant == 8;       // one channel group per launch
+  for (int cp = 0; cp < (single ? C / 16 : (C / 16 + 1) / 2); ++cp) {  // channel-group pairs of the input (an odd last group: half a pair)
+    g.xcg0 = single ? cp : 2 * cp;
     for (int t0 = 0; t0 < taps; ) {
       const int nt = taps == 25 ? (t0 == 0 ? 13 : 12) : taps;
       for (int t = 0; t < nt; ++t) { const int tt = t0 + t; g.tile_seg[t] = 0; g.tile_to[t] = (tt / K) * PW + tt % K; g.tile_tap[t] = tt; }
@@ -409,6 +414,11 @@ static int cw_bwd_weight_impl(const void* dyimg, int dy_planar, const void* ximg
       int rc;
       if (variant == 1) rc = nt == 13 ? launch_conv_wgrad_win<13, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight")
                                       : launch_conv_wgrad_win<12, 192, 8>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      else if (single) {
+        for (int t = 0; t < 10; ++t) { g.tile_to[t] = t < 9 ? (t / K) * PW + t % K : 0; g.tile_tap[t] = t < 9 ? t : -1; }
+        rc = variant == 7 ? launch_conv_wgrad_win<5, 416, 4, 1, true>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight")
+                          : launch_conv_wgrad_win<5, 288, 8, 1, true>(g, CW_WGRAD_BLOCKS, stream, "cw_bwd_weight");
+      }
       else if ((variant == 5 || variant == 6) && 2 * cp + 1 == C / 16) {
         // the odd last channel group: two taps per column tile (five tiles for the nine taps)
         for (int t = 0; t < 10; ++t) { g.tile_to[t] = t < 9 ? (t / K) * PW + t % K : 0; g.tile_tap[t] = t < 9 ? t : -1; }

@@ -206,7 +206,7 @@ class GraphedTrainStep:
         fused_vae.PREP_DONE[prep.data_ptr()] = (wh.data_ptr(), wg.data_ptr())
         # the transposed weights the two large data gradients of the backward pass read on the split-bf16 kernel
         jobs = []
-        Cl = self.hi - self.lo
+        Cl = getattr(self, "_Cd", self.hi - self.lo)      # the rows the fused node encodes (the distinct ones of a draw when dedup is on)
         wm, w2h, w2g = named.get("q_z_mean.weight"), named.get("q_z_layers.1.h.weight"), named.get("q_z_layers.1.g.weight")
         if (os.environ.get("EVAE_WT_HEAD", "1") != "0" and wm is not None and w2h is not None and w2g is not None
                 and not m.args.approximate_prior and lib.evae_gemm_x6_applies(Cl, H, 0)):

@@ -124,7 +124,8 @@ class BaseModel(nn.Module, ABC):
             if nq < 4 or nq % 32 == 0 or os.environ.get("EVAE_CHECK_BATCH", "0") == "1" or cnt.get((kq, "bad"), False):
                 q = torch.round(x2 * self.U8_DIV)
                 bad = not bool(((q >= 0) & (q <= 255) & (q / self.U8_DIV == x2)).all())
-                cnt[(kq, "bad")] = bad            # (a loader that once handed out other images is checked on every batch)
+                cnt[(kq, "bad")] = bad or cnt.get((kq, "bad"), False)      # sticky: a loader that once handed out other images is
+                                                                            # checked on every batch from then on
                 if bad:
                     u8 = None
         if u8 is not None:

@@ -387,8 +387,8 @@ def test_weight_norm_set_matches_torch_weight_norm():
 @pytest.mark.parametrize("N,C,H,Co,stride,elu,xgrad,layout", [
     (20, 48, 32, 3, 1, False, True, "nchw"),        # the output head of fully_conv (48 -> 3), gradient from the likelihood as NCHW planes
     (24, 3, 32, 48, 2, True, False, "nchw"),        # its first convolution: the data, stride 2, ELU behind
-    (20, 48, 32, 96, 2, True, None, "cl"),          # 48 -> 96 stride 2: forward only (the weight gradient's stride-2 window of 96 merged
-                                                    # channels does not fit LDS at this grid: training keeps evae.ops.conv2d there)
+    (20, 48, 32, 96, 2, True, True, "cl"),          # 48 -> 96 stride 2 + ELU (weight gradient: one channel group per launch, variant 8)
+    (5, 3, 64, 48, 2, True, False, "nchw"),         # fully_conv's first convolution at its own grid (64 -> 32: variant 7)
     (6, 96, 64, 48, 1, True, True, "cl"),           # 96 -> 48 on the 64 x 64 grid + ELU
     (33, 16, 16, 24, 1, False, True, "cl"),         # ragged last block, channels that are no multiple of 16 / 32
     (9, 1, 28, 48, 2, True, False, "nchw"),         # 9 x 14 x 14 = 1 764 output pixels: no multiple of 16 (a partial last image chunk of dy)
