@@ -297,6 +297,7 @@ def other_config(a, dev, rank, world, rccl_ranks=1, backend=None):
         t0 = time.perf_counter()
         for i in range(a.steps):
             step(a.warmup + i)
+        t_issue = time.perf_counter() - t0       # the host has issued every launch (eager legs: is the step host-bound?)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         # the dominant kernel, timed with HIP events at the shape it has in the step
@@ -354,7 +355,7 @@ def other_config(a, dev, rank, world, rccl_ranks=1, backend=None):
                     "test_graphed_modular_step_over_distinct_exemplar_rows_matches_eager); EVAE_DEDUP=0 encodes every draw.  The roofline "
                     "kernel below is timed at all %d images" % (dd_["cap"], n_ex)}
         print(json.dumps(line("training images/sec", round(B * a.steps / dt, 1), "images/sec", a, dt, wl, roof,
-                              extra={"exemplar_rows": ex_rows},
+                              extra={"exemplar_rows": ex_rows, "host_issue_ms_per_step": round(1e3 * t_issue / a.steps, 3)},
                               launch="eager" if runner is None or runner.graph is None else "hipGraph replay of the whole step")))
         return
     if a.config == "iwae":
