@@ -124,10 +124,9 @@ __host__ __device__ __forceinline__ size_t p6_off64(size_t r, int k, int nks) {
 // mode 1 (data gradient): row r <-> INPUT channel r of the layer (the data gradient's output channel); cc = merged gradient
 //   channel (cc < Co: bank h, output channel cc; else bank g, cc - Co)
 // w layout: nn.Conv2d's [Co][Ci][KH][KW]
-__global__ __launch_bounds__(256) void cw_pack_filter_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int Co, int Ci,
-                                                             int KH, int KW, CwTaps tp, int ncg, int mode, int bn, int rows_img, int nks,
-                                                             unsigned char* __restrict__ img) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void cw_pack_filter_body(const size_t t, const float* __restrict__ w0, const float* __restrict__ w1, int Co, int Ci,
+                                                    int KH, int KW, const CwTaps& tp, int ncg, int mode, int bn, int rows_img, int nks,
+                                                    unsigned char* __restrict__ img) {
   const int kslots = nks * 2;
   if (t >= (size_t)rows_img * kslots) return;
   const int ri = (int)(t / kslots), ks8 = (int)(t - (size_t)ri * kslots);
@@ -168,6 +167,27 @@ __global__ __launch_bounds__(256) void cw_pack_filter_kernel(const float* __rest
   *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = *reinterpret_cast<const uint4*>(p2);
 }
 
+__global__ __launch_bounds__(256) void cw_pack_filter_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int Co, int Ci,
+                                                             int KH, int KW, CwTaps tp, int ncg, int mode, int bn, int rows_img, int nks,
+                                                             unsigned char* __restrict__ img) {
+  cw_pack_filter_body((size_t)blockIdx.x * blockDim.x + threadIdx.x, w0, w1, Co, Ci, KH, KW, tp, ncg, mode, bn, rows_img, nks, img);
+}
+// The filters of a RUN of same-shaped plain layers (fully_conv's residual runs), forward (mode 2, blockIdx.z = 0) and data-gradient
+// (mode 1, z = 1) images, in one launch: blockIdx.y = layer; images `stride` bytes apart behind fwd / bwd (either may be NULL)
+struct CwPackSet {
+  const float* w[16];
+  unsigned char* fwd; unsigned char* bwd;
+  size_t stride;
+  int C, K, ncg, rows_img, nks;
+  CwTaps tpf, tpb;
+};
+__global__ __launch_bounds__(256) void cw_pack_filter_set_kernel(const CwPackSet s) {
+  const int j = blockIdx.y, dir = blockIdx.z;
+  unsigned char* const base = dir ? s.bwd : s.fwd;
+  if (!base) return;
+  cw_pack_filter_body((size_t)blockIdx.x * blockDim.x + threadIdx.x, s.w[j], nullptr, s.C, s.C, s.K, s.K, dir ? s.tpb : s.tpf, s.ncg, dir ? 1 : 2, 64,
+                      s.rows_img, s.nks, base + (size_t)j * s.stride);
+}
 // k-steps of a launch's contraction
 static int cw_ksteps(const CwTaps& tp, int ncg) {
   int n = 0;
@@ -214,8 +234,36 @@ static CwTaps cw_taps_dgrad(int K, int stride, int pad, int py, int px, int* plo
   return tp;
 }
 
+// (the two slot counts below walk every residue of a block start modulo the image -- thousands of iterations -- and every launch asks
+// several times: remembered per thread; an eager fully_conv step is ~500 launches and waits for its host)
+struct CwSlotMemo { int key[7]; int val; };
+static inline bool cw_memo_get(CwSlotMemo (&tab)[32], int& n, const int (&key)[7], int* val) {
+  for (int i = 0; i < n; ++i) {
+    bool eq = true;
+    for (int j = 0; j < 7; ++j) eq = eq && tab[i].key[j] == key[j];
+    if (eq) { *val = tab[i].val; return true; }
+  }
+  return false;
+}
+static inline void cw_memo_put(CwSlotMemo (&tab)[32], int& n, const int (&key)[7], int val) {
+  CwSlotMemo& e = tab[n < 32 ? n++ : (key[0] + key[4]) & 31];
+  for (int j = 0; j < 7; ++j) e.key[j] = key[j];
+  e.val = val;
+}
+
 // window slots a block of R consecutive output pixels needs, maximised over the block starts
+static int cw_window_slots_walk(int H, int W, int plo, int phi, int R);
 static int cw_window_slots(int H, int W, int plo, int phi, int R) {
+  static thread_local CwSlotMemo tab[32];
+  static thread_local int n = 0;
+  const int key[7] = {H, W, plo, phi, R, 0, 0};
+  int v;
+  if (cw_memo_get(tab, n, key, &v)) return v;
+  v = cw_window_slots_walk(H, W, plo, phi, R);
+  cw_memo_put(tab, n, key, v);
+  return v;
+}
+static int cw_window_slots_walk(int H, int W, int plo, int phi, int R) {
   const int PW = W + plo + phi, SP = (H + plo + phi) * PW, HW = H * W;
   int best = 0;
   for (int r0 = 0; r0 < HW; ++r0) {           // first pixel of a block, modulo the image (every residue: M need not be regular)
@@ -1045,7 +1093,18 @@ struct CwWgradArgs {
 
 // window slots (on the padded INPUT grid) the taps of R consecutive output pixels touch
 // (align: the runs start at multiples of `align` pixels -- their residues modulo the image are the multiples of gcd(align, H W))
+static int cw_wgrad_window_slots_walk(int H, int W, int K, int pad, int xs, int R, int align);
 static int cw_wgrad_window_slots(int H, int W, int K, int pad, int xs, int R, int align = 1) {
+  static thread_local CwSlotMemo tab[32];
+  static thread_local int n = 0;
+  const int key[7] = {H, W, K, pad, xs, R, align};
+  int v;
+  if (cw_memo_get(tab, n, key, &v)) return v;
+  v = cw_wgrad_window_slots_walk(H, W, K, pad, xs, R, align);
+  cw_memo_put(tab, n, key, v);
+  return v;
+}
+static int cw_wgrad_window_slots_walk(int H, int W, int K, int pad, int xs, int R, int align) {
   const int PW = W * xs + 2 * pad, SP = (H * xs + 2 * pad) * PW, HW = H * W;
   int best = 0, step = align, t = HW;
   while (t) { const int r = step % t; step = t; t = r; }          // gcd(align, HW)

@@ -460,20 +460,41 @@ static bool cw_res_small(const evae_conv_desc_t* d, int plo, int phi) {
 }
 extern "C" int evae_cw_res_supported(const evae_conv_desc_t* d) { return cw_res_ok(d); }
 
+// The filter images of a run of n <= 16 same-shaped blocks in ONE launch: forward images behind fwd_imgs, data-gradient images behind
+// bwd_imgs (either may be NULL), evae_cw_workspace_bytes(d, 5) apart; evae_cw_res_fwd / _bwd_data take one as `ws` with w == NULL.
+extern "C" int evae_cw_res_pack_filters(const evae_conv_desc_t* d, int n, const void* const* w, void* fwd_imgs, void* bwd_imgs,
+                                        evae_stream_t stream_) {
+  EVAE_REQUIRE(cw_res_ok(d), "cw_res_pack_filters: unsupported geometry");
+  EVAE_REQUIRE(n >= 1 && n <= 16 && w && (fwd_imgs || bwd_imgs), "cw_res_pack_filters: 1 .. 16 filters, at least one destination");
+  CwPackSet s = {};
+  for (int i = 0; i < n; ++i) { EVAE_REQUIRE(w[i], "cw_res_pack_filters: null filter"); s.w[i] = (const float*)w[i]; }
+  const int K = d->KH, C = d->C, tiles_n = cdiv(C, 64);
+  int plo, phi;
+  s.tpf = cw_taps_fwd(K, 1, d->pad, &plo, &phi);
+  s.tpb = cw_taps_dgrad(K, 1, d->pad, 0, 0, &plo, &phi);
+  s.C = C; s.K = K; s.ncg = C / 16; s.rows_img = (tiles_n * 64 + 127) / 128 * 128; s.nks = cw_ksteps(s.tpf, s.ncg);
+  EVAE_REQUIRE(cw_ksteps(s.tpb, s.ncg) == s.nks, "cw_res_pack_filters: forward and data-gradient contractions differ");
+  s.fwd = (unsigned char*)fwd_imgs; s.bwd = (unsigned char*)bwd_imgs; s.stride = evae_cw_workspace_bytes(d, 5);
+  cw_pack_filter_set_kernel<<<dim3((unsigned)(((size_t)s.rows_img * s.nks * 2 + 255) / 256), n, 2), 256, 0, (hipStream_t)stream_>>>(s);
+  return check_launch("cw_pack_filter_set_kernel");
+}
+
 // aimg: the image of ELU(x) (natural rows); x: fp32 [N H W][C]; y = x + conv(ELU(x)) + b -> out_f (fp32) and / or oimg = the image of ELU(y)
 extern "C" int evae_cw_res_fwd(const void* aimg, const evae_conv_desc_t* d, const float* w, const float* b, const float* x, float* out_f,
                                void* oimg, void* ws, size_t ws_bytes, evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(cw_res_ok(d), "cw_res_fwd: unsupported geometry");
-  EVAE_REQUIRE(aimg && w && x && (out_f || oimg) && ws && ws_bytes >= evae_cw_workspace_bytes(d, 5), "cw_res_fwd: null pointer / workspace too small");
+  EVAE_REQUIRE(aimg && x && (out_f || oimg) && ws && ws_bytes >= evae_cw_workspace_bytes(d, 5), "cw_res_fwd: null pointer / workspace too small");
   const int K = d->KH, C = d->C, ncg = C / 16, tiles_n = cdiv(C, 64), wrows = (tiles_n * 64 + 127) / 128 * 128;
   int plo, phi;
   const CwTaps tp = cw_taps_fwd(K, 1, d->pad, &plo, &phi);
   const int nks_w = cw_ksteps(tp, ncg);
   unsigned char* iw = (unsigned char*)ws;
-  cw_pack_filter_kernel<<<(unsigned)(((size_t)wrows * nks_w * 2 + 255) / 256), 256, 0, stream>>>(w, nullptr, C, C, K, K, tp, ncg, 2, 64, wrows, nks_w, iw);
-  int rc = check_launch("cw_pack_filter_kernel");
-  if (rc) return rc;
+  if (w) {                                       // (w == NULL: ws holds the filter image evae_cw_res_pack_filters wrote)
+    cw_pack_filter_kernel<<<(unsigned)(((size_t)wrows * nks_w * 2 + 255) / 256), 256, 0, stream>>>(w, nullptr, C, C, K, K, tp, ncg, 2, 64, wrows, nks_w, iw);
+    int rc = check_launch("cw_pack_filter_kernel");
+    if (rc) return rc;
+  }
   ConvWinArgs g = {};
   g.xin = (const unsigned char*)aimg; g.nks_in = ncg; g.ncg = ncg; g.N = d->N; g.H = d->H; g.W = d->W; g.plo = plo; g.phi = phi; g.taps = tp;
   g.wimg = iw; g.nks_w = nks_w; g.Co = C; g.tiles_n = tiles_n; g.bias0 = b;
@@ -492,16 +513,18 @@ extern "C" int evae_cw_res_bwd_data(const void* dyimg, const evae_conv_desc_t* d
                                     float* dx_f, void* dximg, void* ws, size_t ws_bytes, evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(cw_res_ok(d), "cw_res_bwd_data: unsupported geometry");
-  EVAE_REQUIRE(dyimg && w && aimg && dy_f && (dx_f || dximg) && ws && ws_bytes >= evae_cw_workspace_bytes(d, 5),
+  EVAE_REQUIRE(dyimg && aimg && dy_f && (dx_f || dximg) && ws && ws_bytes >= evae_cw_workspace_bytes(d, 5),
                "cw_res_bwd_data: null pointer / workspace too small");
   const int K = d->KH, C = d->C, ncg = C / 16, tiles_n = cdiv(C, 64), wrows = (tiles_n * 64 + 127) / 128 * 128;
   int plo, phi;
   const CwTaps tp = cw_taps_dgrad(K, 1, d->pad, 0, 0, &plo, &phi);
   const int nks_w = cw_ksteps(tp, ncg);
   unsigned char* iw = (unsigned char*)ws;
-  cw_pack_filter_kernel<<<(unsigned)(((size_t)wrows * nks_w * 2 + 255) / 256), 256, 0, stream>>>(w, nullptr, C, C, K, K, tp, ncg, 1, 64, wrows, nks_w, iw);
-  int rc = check_launch("cw_pack_filter_kernel");
-  if (rc) return rc;
+  if (w) {                                       // (w == NULL: ws holds the data-gradient filter image evae_cw_res_pack_filters wrote)
+    cw_pack_filter_kernel<<<(unsigned)(((size_t)wrows * nks_w * 2 + 255) / 256), 256, 0, stream>>>(w, nullptr, C, C, K, K, tp, ncg, 1, 64, wrows, nks_w, iw);
+    int rc = check_launch("cw_pack_filter_kernel");
+    if (rc) return rc;
+  }
   ConvWinArgs g = {};
   g.xin = (const unsigned char*)dyimg; g.nks_in = ncg; g.ncg = ncg; g.N = d->N; g.H = d->H; g.W = d->W; g.plo = plo; g.phi = phi; g.taps = tp;
   g.wimg = iw; g.nks_w = nks_w; g.Co = C; g.tiles_n = tiles_n;
@@ -627,6 +650,40 @@ extern "C" int evae_cw_plain_bwd_data(const void* dyimg, int dy_planar, const ev
       else rc = launch_conv_win<CW_PLAIN, 4, 2, 576>(g, stream, "cw_plain_bwd_data");
       if (rc) return rc;
     }
+  return EVAE_OK;
+}
+
+// A whole run of n <= 16 residual blocks in ONE call (the launches are the same; what goes is n - 1 trips through the caller's
+// language per direction -- an eager fully_conv step is ~500 launches and waits for its host).
+//   forward: block k reads aimg_k (k == 0: aimg0, else oimg[k - 1]) and x_k (x0 / out_f[k - 1]), writes out_f[k] and oimg[k]
+//   (oimg[n - 1] may be NULL); fimgs: the forward filter images of evae_cw_res_pack_filters.
+extern "C" int evae_cw_res_run_fwd(const evae_conv_desc_t* d, int n, const void* fimgs, const void* const* bias, const void* aimg0, const float* x0,
+                                   void* const* out_f, void* const* oimg, evae_stream_t stream) {
+  EVAE_REQUIRE(n >= 1 && n <= 16 && fimgs && bias && aimg0 && x0 && out_f && oimg, "cw_res_run_fwd: null pointer / 1 .. 16 blocks");
+  const size_t fb = evae_cw_workspace_bytes(d, 5);
+  for (int k = 0; k < n; ++k) {
+    const int rc = evae_cw_res_fwd(k ? oimg[k - 1] : aimg0, d, nullptr, (const float*)bias[k], k ? (const float*)out_f[k - 1] : x0, (float*)out_f[k], oimg[k],
+                                   (char*)fimgs + (size_t)k * fb, fb, stream);
+    if (rc) return rc;
+  }
+  return EVAE_OK;
+}
+//   backward, blocks n - 1 .. 0: weight gradient (dw[k], db[k]; db[k] may be NULL) from the image of the gradient entering block k
+//   (dyimg_top for the last one, else dximg[k + 1]) and aimgs[k] = the image of ELU(x_k); data gradient -> dx_f[k], dximg[k]
+//   (dximg[0] may be NULL); bimgs: the data-gradient filter images; ws: evae_cw_workspace_bytes(d, 7) bytes.
+extern "C" int evae_cw_res_run_bwd(const evae_conv_desc_t* d, int n, const void* bimgs, const void* const* aimgs, const void* dyimg_top,
+                                   const float* dy_top, void* const* dx_f, void* const* dximg, void* const* dw, void* const* db, void* ws,
+                                   size_t ws_bytes, evae_stream_t stream) {
+  EVAE_REQUIRE(n >= 1 && n <= 16 && bimgs && aimgs && dyimg_top && dy_top && dx_f && dximg && dw && db && ws, "cw_res_run_bwd: null pointer / 1 .. 16 blocks");
+  const size_t fb = evae_cw_workspace_bytes(d, 5);
+  for (int k = n - 1; k >= 0; --k) {
+    const void* dyi = k == n - 1 ? dyimg_top : dximg[k + 1];
+    const float* dyf = k == n - 1 ? dy_top : (const float*)dx_f[k + 1];
+    int rc = evae_cw_bwd_weight_plain(dyi, aimgs[k], d, (float*)dw[k], (float*)db[k], ws, ws_bytes, stream);
+    if (rc) return rc;
+    rc = evae_cw_res_bwd_data(dyi, d, nullptr, aimgs[k], dyf, (float*)dx_f[k], dximg[k], (char*)bimgs + (size_t)k * fb, fb, stream);
+    if (rc) return rc;
+  }
   return EVAE_OK;
 }
 

@@ -153,6 +153,9 @@ SIGNATURES = {
     "evae_cw_first_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "evae_cw_first_workspace_bytes": (_z, []),
     "evae_cw_first_bwd_weight": (_i, [_p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_cw_res_run_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "evae_cw_res_run_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_cw_res_pack_filters": (_i, [_p, _i, _p, _p, _p, _p]),
     "evae_cw_plain_supported": (_i, [_p, _i]),
     "evae_cw_plain_workspace_bytes": (_z, [_p, _i]),
     "evae_cw_pack_image_ex": (_i, [_p, C.c_longlong, _i, _i, _p, C.c_longlong, _i, _i, _i, _i, _i, _p, _p]),

@@ -1623,7 +1623,8 @@ class ResStackFn(torch.autograd.Function):
     block's convolution reads the image of ELU(x_k) that the block before wrote in its epilogue (the entry packs it once), adds bias
     and residual in its own; in the backward pass one launch per block forms dx_k = dx_{k+1} + ELU'(x_k) conv_transpose(dx_{k+1}, w_k)
     -- ELU' from the saved image -- and writes it as fp32 and as the image the next block's two gradients read.  No ELU launch, no
-    fp32 activation kept for the backward.  args: x, then (w, b) per block."""
+    fp32 activation kept for the backward.  The filter images of the whole run are packed in one launch and each direction is ONE
+    call into the library (evae_cw_res_run_fwd / _bwd): an eager fully_conv step waits for its host.  args: x, then (w, b) per block."""
 
     @staticmethod
     def forward(ctx, x, *params):
@@ -1636,62 +1637,57 @@ class ResStackFn(torch.autograd.Function):
         dev = x.device
         N, Cc, H, W = x.shape
         need_grad = any(ctx.needs_input_grad)
-        fmt = dict(device=dev, memory_format=CL)
-        image = lambda: torch.empty(int(lib.evae_cw_image_bytes(N * H * W, Cc)), dtype=torch.uint8, device=dev)
-        ds = [_lib.ConvDesc(N, Cc, H, W, Cc, w.shape[2], w.shape[3], 1, (w.shape[2] - 1) // 2) for w in ws_]
-        a = image()
-        _lib.check(lib.evae_cw_pack_image(_p(x), N, H, W, Cc, 2, _p(a), _stream()), "evae_cw_pack_image(ELU)")
-        imgs = [a]
-        cur = x
-        for k in range(nb):
-            last = k == nb - 1
-            y = torch.empty((N, Cc, H, W), **fmt)
-            o = None if last else image()
-            ws = _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(ds[k]), 5), dev)
-            _lib.check(lib.evae_cw_res_fwd(_p(imgs[k]), C.byref(ds[k]), _p(ws_[k]), _p(bs_[k]), _p(cur), _p(y), _p(o), _p(ws), ws.numel(), _stream()),
-                       "evae_cw_res_fwd")
-            if not last:
-                imgs.append(o)
-            if not need_grad:
-                imgs[k] = None
-            cur = y
+        st = _stream()
+        d = _lib.ConvDesc(N, Cc, H, W, Cc, ws_[0].shape[2], ws_[0].shape[3], 1, (ws_[0].shape[2] - 1) // 2)
+        assert nb <= 16 and all(tuple(w.shape) == tuple(ws_[0].shape) for w in ws_), "a run: <= 16 blocks of one shape"
+        ib = int(lib.evae_cw_image_bytes(N * H * W, Cc))
+        fb = int(lib.evae_cw_workspace_bytes(C.byref(d), 5))
+        imgs = torch.empty((nb, ib), dtype=torch.uint8, device=dev)           # images of ELU(x_0) .. ELU(x_{nb-1})
+        ys = torch.empty((nb, N, H, W, Cc), device=dev)                        # x_1 .. x_nb, channels-last
+        filt = torch.empty(((2 if need_grad else 1), nb, fb), dtype=torch.uint8, device=dev)
+        _lib.check(lib.evae_cw_pack_image(_p(x), N, H, W, Cc, 2, _p(imgs[0]), st), "evae_cw_pack_image(ELU)")
+        _lib.check(lib.evae_cw_res_pack_filters(C.byref(d), nb, _ptr_array(ws_), _p(filt[0]), _p(filt[1]) if need_grad else None, st),
+                   "evae_cw_res_pack_filters")
+        VP = C.c_void_p * nb
+        bias = VP(*[None if b is None else b.data_ptr() for b in bs_])
+        outf = VP(*[ys[k].data_ptr() for k in range(nb)])
+        oimg = VP(*[imgs[k + 1].data_ptr() if k + 1 < nb else None for k in range(nb)])
+        _lib.check(lib.evae_cw_res_run_fwd(C.byref(d), nb, _p(filt[0]), bias, _p(imgs[0]), _p(x), outf, oimg, st), "evae_cw_res_run_fwd")
         if need_grad:
             ctx.save_for_backward(*ws_)
-            ctx.keep = (imgs, ds, [b is not None for b in bs_])
-        return cur
+            ctx.keep = (imgs, d, [b is not None for b in bs_], filt[1], bs_)
+        return ys[nb - 1].permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        imgs, ds, has_b = ctx.keep
+        imgs, d, has_b, bimg, bs_ = ctx.keep
+        ctx.keep = None
         ws_ = list(ctx.saved_tensors)
-        nb = len(ds)
+        nb = len(ws_)
         dev = dout.device
         dy = _cl(dout.float())
         N, Cc, H, W = dy.shape
-        image = lambda: torch.empty(int(lib.evae_cw_image_bytes(N * H * W, Cc)), dtype=torch.uint8, device=dev)
-        dyimg = image()
-        _lib.check(lib.evae_cw_pack_image(_p(dy), N, H, W, Cc, 0, _p(dyimg), _stream()), "evae_cw_pack_image")
-        grads = [None] * (2 * nb)
-        for k in range(nb - 1, -1, -1):
-            d = ds[k]
-            K = d.C * d.KH * d.KW
-            dw = torch.empty((Cc, K), device=dev); db = torch.empty(Cc, device=dev)
-            ws = _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(d), 7), dev)
-            _lib.check(lib.evae_cw_bwd_weight_plain(_p(dyimg), _p(imgs[k]), C.byref(d), _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
-                       "evae_cw_bwd_weight_plain")
-            grads[2 * k] = dw.reshape(ws_[k].shape)
-            if has_b[k]:
-                grads[2 * k + 1] = db
-            dx = torch.empty((N, Cc, H, W), device=dev, memory_format=CL)
-            dximg = image() if k > 0 else None
-            ws = _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(d), 5), dev)
-            _lib.check(lib.evae_cw_res_bwd_data(_p(dyimg), C.byref(d), _p(ws_[k]), _p(imgs[k]), _p(dy), _p(dx), _p(dximg), _p(ws), ws.numel(),
-                                                _stream()), "evae_cw_res_bwd_data")
-            imgs[k] = None
-            dy, dyimg = dx, dximg
-        ctx.keep = None
-        return (dy if ctx.needs_input_grad[0] else None,) + tuple(grads)
+        st = _stream()
+        ib = imgs.shape[1]
+        dimgs = torch.empty((nb, ib), dtype=torch.uint8, device=dev)          # [k]: image of dx_k (k >= 1); [0]: image of the incoming gradient
+        _lib.check(lib.evae_cw_pack_image(_p(dy), N, H, W, Cc, 0, _p(dimgs[0]), st), "evae_cw_pack_image")
+        dxs = torch.empty((nb, N, H, W, Cc), device=dev)
+        dws = torch.empty((nb,) + tuple(ws_[0].shape), device=dev)
+        dbs = torch.empty((nb, Cc), device=dev)
+        ws = _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(d), 7), dev)
+        VP = C.c_void_p * nb
+        aim = VP(*[imgs[k].data_ptr() for k in range(nb)])
+        dxf = VP(*[dxs[k].data_ptr() for k in range(nb)])
+        dxi = VP(*[dimgs[k].data_ptr() if k >= 1 else None for k in range(nb)])
+        dwp = VP(*[dws[k].data_ptr() for k in range(nb)])
+        dbp = VP(*[dbs[k].data_ptr() for k in range(nb)])
+        _lib.check(lib.evae_cw_res_run_bwd(C.byref(d), nb, _p(bimg), aim, _p(dimgs[0]), _p(dy), dxf, dxi, dwp, dbp, _p(ws), ws.numel(), st),
+                   "evae_cw_res_run_bwd")
+        grads = []
+        for k in range(nb):
+            grads += [dws[k], dbs[k] if has_b[k] else None]
+        return (dxs[0].permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None,) + tuple(grads)
 
 
 def res_stack(x, blocks):

@@ -463,6 +463,19 @@ int evae_cw_bwd_weight(const void* dyimg, int dy_planar, const void* ximg, const
 int evae_cw_res_supported(const evae_conv_desc_t* d);
 int evae_cw_res_fwd(const void* aimg, const evae_conv_desc_t* d, const float* w, const float* b, const float* x, float* out_f, void* oimg,
                     void* ws, size_t ws_bytes, evae_stream_t stream);
+/* evae_cw_res_pack_filters: the filter images of a run of n <= 16 same-shaped blocks in one launch (forward images behind fwd_imgs,
+ * data-gradient images behind bwd_imgs, evae_cw_workspace_bytes(d, 5) apart; either may be NULL); evae_cw_res_fwd / _bwd_data then
+ * take an image as `ws` with w == NULL. */
+int evae_cw_res_pack_filters(const evae_conv_desc_t* d, int n, const void* const* w, void* fwd_imgs, void* bwd_imgs, evae_stream_t stream);
+/* A whole run of n <= 16 blocks per call (same launches, n - 1 fewer trips through the host language per direction):
+ *   evae_cw_res_run_fwd: block k reads aimg0 / oimg[k - 1] and x0 / out_f[k - 1], writes out_f[k], oimg[k] (oimg[n - 1] may be NULL);
+ *   evae_cw_res_run_bwd: blocks n - 1 .. 0: dw[k], db[k] (may be NULL) from the gradient image entering block k (dyimg_top / dximg[k + 1])
+ *     and aimgs[k] = the image of ELU(x_k); dx_f[k], dximg[k] (dximg[0] may be NULL); ws: evae_cw_workspace_bytes(d, 7) bytes.
+ *   fimgs / bimgs: the filter images of evae_cw_res_pack_filters. */
+int evae_cw_res_run_fwd(const evae_conv_desc_t* d, int n, const void* fimgs, const void* const* bias, const void* aimg0, const float* x0,
+                        void* const* out_f, void* const* oimg, evae_stream_t stream);
+int evae_cw_res_run_bwd(const evae_conv_desc_t* d, int n, const void* bimgs, const void* const* aimgs, const void* dyimg_top, const float* dy_top,
+                        void* const* dx_f, void* const* dximg, void* const* dw, void* const* db, void* ws, size_t ws_bytes, evae_stream_t stream);
 int evae_cw_res_bwd_data(const void* dyimg, const evae_conv_desc_t* d, const float* w, const void* aimg, const float* dy_f, float* dx_f,
                          void* dximg, void* ws, size_t ws_bytes, evae_stream_t stream);
 int evae_cw_bwd_weight_plain(const void* dyimg, const void* ximg, const evae_conv_desc_t* d, float* dw, float* db, void* ws,
