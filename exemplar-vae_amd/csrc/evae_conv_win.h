@@ -1358,17 +1358,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (dbg & 4) return;                         // (tools: the MFMA stream without its fragment reads)
         const int ks = t / NGRP, jg = t - ks * NGRP, j = GS * jg;
         const int na = jg == 0 ? 6 : 0;
+        // (plane / half offsets as the instruction's offset field: t and e are constants once the step loop is unrolled)
         if (e < na) {
           const int p = e >> 1, hf = e & 1;
-          const unsigned a = aA[ks] + p * (RK * 32) + hf * 128;
-          if (hf) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ar[ks & 1][p].hi) : "v"(a));
-          else asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ar[ks & 1][p].lo) : "v"(a));
+          if (hf) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ar[ks & 1][p].hi) : "v"(aA[ks]), "n"(p * (RK * 32) + hf * 128));
+          else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ar[ks & 1][p].lo) : "v"(aA[ks]), "n"(p * (RK * 32) + hf * 128));
         } else {
           const int eb = e - na, u = eb / 6, p = (eb % 6) >> 1, hf = eb & 1;
           if (u < GS && j + u < NCW) {
-            const unsigned a = (hf ? bB1[ks] : bB0[ks]) + toff[j + u] + p * G::XPL;
-            if (hf) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(br[t & 1][u][p].hi) : "v"(a));
-            else asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(br[t & 1][u][p].lo) : "v"(a));
+            const unsigned a = (hf ? bB1[ks] : bB0[ks]) + toff[j + u];
+            if (hf) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(br[t & 1][u][p].hi) : "v"(a), "n"(p * G::XPL));
+            else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(br[t & 1][u][p].lo) : "v"(a), "n"(p * G::XPL));
           }
         }
       };
