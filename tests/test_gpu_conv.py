@@ -325,7 +325,9 @@ def test_gated_conv_stack_without_gradients():
     assert rel(a, b) < 1e-5
 
 
-@pytest.mark.parametrize("N,C,H,nblk", [(20, 48, 32, 3), (70, 96, 16, 2), (5, 48, 64, 2), (33, 16, 32, 1)])
+@pytest.mark.parametrize("N,C,H,nblk", [(20, 48, 32, 3), (70, 96, 16, 2), (5, 48, 64, 2), (33, 16, 32, 1),
+                                        # fully_conv on 28 x 28 inputs: 14 x 14 and 7 x 7 grids, pixel counts that are no multiple of 16 / 32 / 256
+                                        (9, 48, 14, 2), (90, 96, 7, 2), (101, 48, 14, 1), (3, 96, 14, 1)])
 def test_residual_block_run_on_pixel_images_matches_float64(N, C, H, nblk):
     """A run of residual blocks x + conv(ELU(x)) (reference models/fully_conv.py:13-23) through evae.ops.ResStackFn -- window kernels
     over pixel images, ELU image written by the block before, ELU' from the saved image, weight gradients over pixel images
@@ -393,6 +395,9 @@ def test_weight_norm_set_matches_torch_weight_norm():
     (33, 16, 16, 24, 1, False, True, "cl"),         # ragged last block, channels that are no multiple of 16 / 32
     (9, 1, 28, 48, 2, True, False, "nchw"),         # 9 x 14 x 14 = 1 764 output pixels: no multiple of 16 (a partial last image chunk of dy)
     (9, 32, 28, 48, 2, False, True, "cl"),
+    (23, 48, 14, 96, 2, True, True, "cl"),          # 14 -> 7 (fully_conv on 28 x 28 inputs), 23 x 7 x 7 = 1 127 output pixels
+    (23, 96, 14, 48, 1, True, True, "up"),          # 7 -> 14 behind nn.Upsample(2)
+    (37, 48, 14, 1, 1, False, True, "cl"),          # its one-channel head
     (40, 1, 32, 96, 1, True, True, "up"),           # the decoder's first convolution: ONE channel, nn.Upsample(2) in front (16 -> 32)
     (7, 96, 64, 48, 1, True, True, "up"),           # its second: 96 -> 48 behind nn.Upsample(2) (32 -> 64)
 ])

@@ -1604,3 +1604,49 @@ def test_captured_distinct_rows_steps_at_config2_size_match_the_oracle(monkeypat
         assert np.abs(a_ - b_).max() <= 4 * 5e-4 * 1.01, (name, worst[name])
         assert (err > 1e-5).mean() <= 1e-4, (name, worst[name])
     print("captured c2 steps vs oracle: worst (max rel err, fraction above 1e-5):", max(worst.values()))
+
+
+@pytest.mark.gpu
+def test_single_conv_on_28x28_inputs_window_path_matches_the_r04_kernels():
+    """`single_conv` on 1 x 28 x 28 binary inputs (14 x 14 and 7 x 7 grids, bottleneck 6) with a batch large enough for the pixel-image
+    window kernels (128 images + 150 exemplars): one training step's per-row loss / RE / KL and every gradient against the same step on
+    the r04 kernels (evae.ops.CONV_STACK_ON = False, torch's weight norm) -- the path the reference-generated goldens pin at 4 images."""
+    from evae import ops
+    from utils.utils import importing_model
+    B, C, N = 128, 150, 400
+    args = smoke_case.vae_args(model_name="single_conv", input_size=[1, 28, 28], input_type="binary", bottleneck=6, z1_size=294,
+                               number_components=C, training_set_size=N, batch_size=B)
+    torch.manual_seed(21)
+    model = importing_model(args)(args).cuda()
+    model.train()
+    rs = np.random.RandomState(8)
+    data = (rs.random_sample((N, 784)) < 0.3).astype(np.float32)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    idx = torch.from_numpy(rs.randint(0, N, (B, 1)).astype(np.int64))
+    x = torch.from_numpy(data[idx[:, 0].numpy()]).cuda()
+    ex = torch.from_numpy(rs.randint(0, N, (C,)).astype(np.int64))
+    eps = torch.from_numpy(rs.standard_normal((B, 294)).astype(np.float32)).cuda()
+    res = []
+    for window in (True, False):
+        orig, stack_on = torch.randint, ops.CONV_STACK_ON
+        try:
+            ops.CONV_STACK_ON = window
+            os.environ["EVAE_WN_SET"] = "1" if window else "0"
+            torch.randint = lambda low=0, high=None, size=None, **kw: ex.clone()
+            model._draw_eps = lambda like: eps.reshape(like.shape)
+            model.zero_grad()
+            loss, RE, KL = model.calculate_loss((x, idx.cuda()), 0.5, average=False, dataset=dataset)
+            loss.mean().backward()
+        finally:
+            torch.randint = orig
+            ops.CONV_STACK_ON = stack_on
+            os.environ.pop("EVAE_WN_SET", None)
+        res.append((np.stack([t.detach().double().cpu().numpy().reshape(-1) for t in (loss, RE, KL)]),
+                    [None if p.grad is None else p.grad.double().cpu().numpy() for p in model.parameters()]))
+    assert np.isfinite(res[0][0]).all()
+    for j, what in enumerate(("loss", "RE", "KL")):
+        assert rel(res[0][0][j], res[1][0][j]) < 2e-5, (what, rel(res[0][0][j], res[1][0][j]))
+    for a, b in zip(res[0][1], res[1][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-8)
