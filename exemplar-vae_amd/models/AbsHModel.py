@@ -12,6 +12,7 @@ from utils.distributions import log_normal_diag
 
 # training step of the dense 2-level model on two streams (calculate_loss below); EVAE_HVAE_TWO_STREAM=0: one stream
 _TWO_STREAM = os.environ.get("EVAE_HVAE_TWO_STREAM", "1") != "0"
+_TWO_STREAM_CONV = os.environ.get("EVAE_HVAE_TWO_STREAM_CONV", "1") != "0"      # the convolutional 2-level model too (r05: c3 31.4 -> 29.9 ms)
 
 # ... with each pair of heads + its sample + its log-density as one Function, and the loss assembly as one (evae.ops.HeadsReparamFn,
 # ElboFn: ~40 launches fewer per step); EVAE_HVAE_FUSED_HEADS=0: the separate modules
@@ -112,7 +113,7 @@ class BaseHModel(BaseModel):
         a = self.args
         return (_TWO_STREAM and self.training and a.prior == 'exemplar_prior' and a.approximate_prior is False
                 and exemplars_embedding is None and dataset is not None and x_indices is not None and x.is_cuda
-                and torch.is_grad_enabled() and not self._is_conv() and not self._sharded())
+                and torch.is_grad_enabled() and (not self._is_conv() or _TWO_STREAM_CONV) and not self._sharded())
 
     def calculate_loss(self, x, beta=1., average=False, exemplars_embedding=None, cache=None, dataset=None):
         """Training step with the exact exemplar prior on one device (reference models/BaseModel.py:54-77 over AbsHModel.py:13-106):
@@ -133,9 +134,11 @@ class BaseHModel(BaseModel):
         with torch.cuda.stream(side), ops.leaf_branch(leaf):
             # forward() of this class, in its order (the two reparameterize calls draw z2's noise, then z1's), minus p(z1 | z2)
             xin = xx.view(-1, *self.args.input_size) if self._is_conv() else xx
-            z2, q2_mu, q2_lv, log_q2 = self._sample_heads(self.q_z_layers(xin), self.q_z_mean, self.q_z_logvar, d2)
+            conv = self._is_conv()
+            flat = (lambda t: t.reshape(t.size(0), -1)) if conv else (lambda t: t)       # conv features -> (c, y, x) rows, as q_z / q_z1 do
+            z2, q2_mu, q2_lv, log_q2 = self._sample_heads(flat(self.q_z_layers(xin)), self.q_z_mean, self.q_z_logvar, d2)
             z2_ready = torch.cuda.Event(); z2_ready.record()
-            joint = self.q_z1_layers_joint(torch.cat((self.q_z1_layers_x(xin), self.q_z1_layers_z2(z2)), dim=1))       # q_z1()
+            joint = self.q_z1_layers_joint(torch.cat((flat(self.q_z1_layers_x(xin)), self.q_z1_layers_z2(z2)), dim=1))       # q_z1()
             z1, q1_mu, q1_lv, log_q1 = self._sample_heads(joint, self.q_z1_mean, self.q_z1_logvar, d1)
             z1_ready = torch.cuda.Event(); z1_ready.record()
             x_mean, x_logvar = self.p_x(z1, z2)
