@@ -152,14 +152,39 @@ class BaseModel(nn.Module, ABC):
         x, x_indices = x
         if self._fused_path(x, x_indices, exemplars_embedding, dataset, cache):
             return self._calculate_loss_fused(x, x_indices, beta, dataset, average, cache)
-        x_mean, x_logvar, latent_stats = self.forward(x)
         x_flat = x.reshape(x.shape[0], -1) if x.dim() != 2 else x
-        RE = self.reconstruction_loss(x_flat, x_mean, x_logvar)
-        KL = self.kl_loss(latent_stats, exemplars_embedding, dataset, cache, x_indices)
+        if self._decoder_beside_prior(x, exemplars_embedding, dataset):
+            # The decoder p(x | z) and the reconstruction term need z and nothing of the prior; the prior's exemplar set (top-k over the
+            # cache, a device-to-host read of the neighbour list, ~100 images re-encoded -- small launches that fill no machine) needs
+            # mu and nothing of the decoder: the decoder goes to a side stream.  Autograd runs every node's backward on the stream of
+            # its forward, so the two backward halves overlap the same way, and the host's wait for the neighbour list no longer
+            # idles the GPU (reference models/BaseModel.py:54-77, same modules, same arithmetic).  EVAE_DECODER_STREAM=0: one stream.
+            main = torch.cuda.current_stream()
+            side = ops.model_side_stream(x.device)
+            mu, logvar = self.q_z(x)
+            z = self.reparameterize(mu, logvar)
+            side.wait_stream(main)
+            z.record_stream(side)
+            with torch.cuda.stream(side):
+                x_mean, x_logvar = self.p_x(z)
+                RE = self.reconstruction_loss(x_flat, x_mean, x_logvar)
+            KL = self.kl_loss((z, mu, logvar), exemplars_embedding, dataset, cache, x_indices)
+            main.wait_stream(side)
+            RE.record_stream(main)
+        else:
+            x_mean, x_logvar, latent_stats = self.forward(x)
+            RE = self.reconstruction_loss(x_flat, x_mean, x_logvar)
+            KL = self.kl_loss(latent_stats, exemplars_embedding, dataset, cache, x_indices)
         loss = -RE + beta * KL
         if average:
             loss, RE, KL = torch.mean(loss), torch.mean(RE), torch.mean(KL)
         return loss, RE, KL
+
+    def _decoder_beside_prior(self, x, exemplars_embedding, dataset):
+        a = self.args
+        return (os.environ.get("EVAE_DECODER_STREAM", "1") != "0" and self.training and x.is_cuda and torch.is_grad_enabled()
+                and a.model_name == 'single_conv' and a.prior == 'exemplar_prior' and exemplars_embedding is None and dataset is not None
+                and not self._sharded() and not torch.cuda.is_current_stream_capturing())
 
     def importance_sample_losses(self, data, S, exemplars_embedding):
         """-ELBO of S importance samples for each row of `data` [g x D] -> [g * S], sample s of image i at row i * S + s
