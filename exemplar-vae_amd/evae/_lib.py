@@ -222,3 +222,31 @@ def check(rc, what=""):
     if rc != 0:
         msg = load().evae_last_error().decode("utf-8", "replace")
         raise EvaeError("%s failed (%d): %s" % (what, rc, msg))
+
+
+class count_calls:
+    """`with count_calls("evae_cw_") as n:` -- counts this process's calls of the entry points whose name starts with the prefix
+    (n: name -> calls) while the block runs.  For tests that must know WHICH kernels family served a model (e.g. that the
+    pixel-image convolution operators, not the layer-by-layer ones, ran); the library itself keeps no counters."""
+
+    def __init__(self, prefix):
+        self.prefix, self.counts, self._saved = prefix, {}, {}
+
+    def __enter__(self):
+        lib = load()
+        for name in SIGNATURES:
+            if name.startswith(self.prefix):
+                fn = getattr(lib, name)
+                self._saved[name] = fn
+
+                def proxy(*a, _fn=fn, _name=name):
+                    self.counts[_name] = self.counts.get(_name, 0) + 1
+                    return _fn(*a)
+                setattr(lib, name, proxy)
+        return self.counts
+
+    def __exit__(self, *exc):
+        lib = load()
+        for name, fn in self._saved.items():
+            setattr(lib, name, fn)
+        return False

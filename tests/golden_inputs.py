@@ -57,3 +57,19 @@ def gray_images(seed, N, D=784):
     from the raw dataset tensor while the batch is binarised (training.py:31 vs BaseModel.py:247)."""
     rs = np.random.RandomState(seed)
     return ((rs.randint(0, 256, size=(N, D)) / 255.0) * (rs.random_sample((N, D)) < 0.2)).astype(np.float32)
+
+
+def g23_inputs(B, C, N, D, zdim, seed=95):
+    """G23 (single_conv, 3 x 64 x 64 at a batch that switches the pixel-image operators on): N structured colour images (a coarse 8 x 8
+    random field per channel, nearest-upsampled, plus pixel noise; values (k + 0.5) / 256 as utils/load_data/base_load_data.py:36
+    produces), a batch of B of them slightly perturbed, C distinct candidate rows, eps."""
+    rs = np.random.RandomState(seed)
+    side = int(round((D // 3) ** 0.5))
+    coarse = rs.randint(32, 224, (N, 3, 8, 8)).astype(np.float32)
+    img = np.repeat(np.repeat(coarse, side // 8, axis=2), side // 8, axis=3) + rs.randint(-24, 25, (N, 3, side, side))
+    data = ((np.clip(img, 0, 255).astype(np.int64) + 0.5) / 256).astype(np.float32).reshape(N, D)
+    bidx = rs.choice(N, size=(B, 1), replace=False).astype(np.int64)
+    x = np.clip(data[bidx[:, 0]] + rs.randint(-6, 7, (B, D)).astype(np.float32) / 256, 0.5 / 256, 255.5 / 256).astype(np.float32)
+    cand = rs.choice(N, size=C, replace=False).astype(np.int64)
+    eps = rs.standard_normal((B, zdim)).astype(np.float32)
+    return data, x, bidx, cand, eps

@@ -424,11 +424,33 @@ G21_CASES = {      # single_conv at gain 1: |log p| ~ 1e8 in the untrained net (
 MODEL_CASE_TOL = {"single_conv_mnist_gain1": (1e-3, 3e-3, 1e-3)}
 
 
+G22_CASES = {      # more than 1 024 exemplar rows: the exemplar encoder runs as evae.ops.GatedConvStackFn (pixel-image window kernels)
+    "convhvae_stack": dict(model_name="convhvae_2level", input_size=[1, 28, 28], input_type="binary", B=8, C=1280, N=2000),
+}
+
+
 @pytest.mark.parametrize("tag", list(G9_CASES) + list(G19_CASES) + list(G21_CASES))
 def test_other_architectures_match_reference_golden(golden, tag):
-    from utils.utils import importing_model
     g = golden("g9_models" if tag in G9_CASES else "g21_single_conv_gain1" if tag in G21_CASES else "g19_models_geometries")
     cfg = dict(G9_CASES[tag] if tag in G9_CASES else G21_CASES[tag] if tag in G21_CASES else G19_CASES[tag])
+    _model_case_against_golden(g, tag, cfg)
+
+
+def test_conv_stack_operator_matches_reference_golden(golden, gemm_pipe):
+    """G22: convhvae_2level (reference models/convHVAE_2level.py:13-97) with 1 280 exemplar rows and a 2 000-row
+    cache_z -- sizes at which the exemplar encoder is evae.ops.GatedConvStackFn on the window kernels (csrc/evae_conv_win.h), asserted
+    by counting the evae_cw_* calls -- against the real reference's loss / RE / KL (1e-4), gradient norms (3e-4) and cache rows, on both
+    matrix pipes of the dense layers around it."""
+    from evae import _lib
+    with _lib.count_calls("evae_cw_") as n:
+        _model_case_against_golden(golden("g22_convhvae_stack"), "convhvae_stack", dict(G22_CASES["convhvae_stack"]))
+    # training step: first layer + 3 gated window layers forward, the same backward; cache_z: one more forward of the stack
+    assert n.get("evae_cw_first_fwd", 0) >= 2 and n.get("evae_cw_fwd_gated", 0) >= 6, n
+    assert n.get("evae_cw_bwd_data_gate", 0) >= 3 and n.get("evae_cw_bwd_weight", 0) >= 3 and n.get("evae_cw_first_bwd_weight", 0) >= 1, n
+
+
+def _model_case_against_golden(g, tag, cfg):
+    from utils.utils import importing_model
     tol_v, tol_g, tol_c = MODEL_CASE_TOL.get(tag, (1e-4, 3e-4, 1e-4))
     B, C, N = cfg.pop("B"), cfg.pop("C"), cfg.pop("N")
     gain = cfg.pop("gain", 1.0)
@@ -526,6 +548,64 @@ def test_c5_geometry_matches_reference_golden(golden):
     ref = g["gnorms"]
     assert norms.shape == ref.shape
     assert np.all(np.abs(norms - ref) <= 1e-4 * np.maximum(ref, 1e-5)), (np.abs(norms - ref) / np.maximum(ref, 1e-5)).max()
+    model.eval()
+    with torch.no_grad():
+        cz, clv = model.cache_z(dataset)
+        loss, RE, KL = model.calculate_loss((torch.from_numpy(x).cuda(), None), average=False,
+                                            exemplars_embedding=(cz, clv, torch.arange(len(cz))))
+    for kk, v in (("loss", loss), ("RE", RE), ("KL", KL)):
+        assert rel(v.cpu().numpy(), g["eval_" + kk]) < 1e-4, kk
+
+
+def test_c5_window_operators_match_reference_golden(golden, gemm_pipe):
+    """G23: G20's model -- single_conv (reference models/fully_conv.py:12-81) on 3 x 64 x 64, z1 = 256, cache + top-k
+    prior (models/BaseModel.py:256-271) -- on a batch of 64 images and 94 re-encoded neighbours: 16 384 pixels even in the 96-channel
+    16 x 16 runs, so every residual run is evae.ops.ResStackFn, the convolutions around them PlainConvFn and the weight norm the
+    one-launch WeightNormSetFn (asserted by counting the library calls).  Against the real reference: loss / RE / KL 1e-4, gradient
+    norms 3e-4, the cache refresh, then the evaluation path; on both matrix pipes."""
+    from utils.utils import importing_model
+    from evae import _lib
+    g = golden("g23_c5_window_size")
+    B, C, N, k, gain = 64, 160, 320, 3, 0.35
+    args = smoke_case.vae_args(model_name="single_conv", dataset_name="celeba", input_size=[3, 64, 64], input_type="continuous",
+                               continuous=True, use_logit=False, bottleneck=1, z1_size=256, number_components=C,
+                               training_set_size=N, approximate_prior=True, approximate_k=k)
+    model = importing_model(args)(args)
+    model.load_state_dict(seeded_state_dict(model, 79, gain))
+    model = model.to("cuda")
+    D = int(np.prod(args.input_size))
+    data, x, bidx, _, eps = gi.g23_inputs(B, C, N, D, args.z1_size)
+    cand = g["cand"].astype(np.int64)                     # the generator's candidate draw (an input; chosen for a wide top-k boundary)
+    model._draw_eps = lambda like: torch.from_numpy(eps).to(like.device).reshape(like.shape)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    model.train()
+    with _lib.count_calls("evae_") as n:
+        with torch.no_grad():
+            cache = tuple(model.cache_z(dataset))
+        assert rel(cache[0][:32].cpu().numpy(), g["cache_before_head"]) < 1e-4
+        orig = torch.randint
+        torch.randint = lambda low=0, high=None, size=None, **kw: torch.from_numpy(cand.copy())
+        try:
+            model.zero_grad()
+            loss, RE, KL = model.calculate_loss((torch.from_numpy(x).cuda(), torch.from_numpy(bidx).cuda()), beta=0.7,
+                                                average=False, cache=cache, dataset=dataset)
+            loss.mean().backward()
+        finally:
+            torch.randint = orig
+        torch.cuda.synchronize()
+    # the window path ran: 8 residual runs forward in the step (encoder x 2 passes x 2 runs + decoder 2 runs ...), their backward,
+    # the plain convolutions, the one-launch weight norm both ways -- and no layer-by-layer residual block
+    assert n.get("evae_cw_res_run_fwd", 0) >= 8 and n.get("evae_cw_res_run_bwd", 0) >= 6, n
+    assert n.get("evae_cw_plain_fwd", 0) >= 8 and n.get("evae_cw_plain_bwd_data", 0) >= 4, n
+    assert n.get("evae_weight_norm_set_fwd", 0) >= 3 and n.get("evae_weight_norm_set_bwd", 0) >= 2, n
+    assert "evae_conv2d_cl_fwd_res" not in n and "evae_conv2d_cl_fwd" not in n, n       # no layer-by-layer convolution served it
+    for kk, v in (("loss", loss), ("RE", RE), ("KL", KL)):
+        assert rel(v.detach().cpu().numpy(), g[kk]) < 1e-4, kk
+    assert rel(cache[0].detach().cpu().numpy(), g["cache_after"]) < 1e-4
+    norms = np.asarray([0.0 if p.grad is None else p.grad.double().norm().item() for _, p in model.named_parameters()])
+    ref = g["gnorms"]
+    assert norms.shape == ref.shape
+    assert np.all(np.abs(norms - ref) <= 3e-4 * np.maximum(ref, 1e-5)), (np.abs(norms - ref) / np.maximum(ref, 1e-5)).max()
     model.eval()
     with torch.no_grad():
         cz, clv = model.cache_z(dataset)
