@@ -570,16 +570,117 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const float* __restri
   }
 }
 
-// row slices of the narrow kernel: ~768 blocks over the column tiles, at least 128 rows (four chunks) a slice
+// r06: the same reduction on the fp32 matrix instruction, each operand row read ONCE.  The VALU form above re-reads dy for every
+// 64-column tile, spends 64 x 320 FMAs per row on the vector pipe (10 us chip-wide) and leaves 154 planes for a finish that gathers
+// them in 32-byte pieces: 57 + 31 us inside the c2 step, BESIDE layer 2's data gradient, which they stretch from 60 to 98 us.
+// Here: one block per row slice, one wave per 64 columns of [x | 1]; a k-step is FOUR rows -- lane l reads the float4 of columns
+// 64 w + 4 (l & 15) .. + 3 of row r0 + (l >> 4) (a wave: four rows x 256 contiguous bytes) and one dy element per 16-output tile,
+// and v_mfma_f32_16x16x4_f32 (exact fp32, A = dy^T, B = one component of the float4: MFMA j of a tile owns columns 4 n + j) adds
+// the products into 16 NT x 4 accumulators.  Planes [slice][N][K + 1] as before; summed by narrow_finish_kernel below.
+template <int NT>
+__global__ __launch_bounds__(1024) void narrow_wgrad_mfma_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
+                                                                 int ldx, int M, int N, int K, int rows_per_slice,
+                                                                 float* __restrict__ part) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int U = 4;                                        // k-steps (of four rows) whose loads are in flight together
+  const int Kp = K + 1;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, kr = l >> 4, cq = l & 15;
+  const int z = blockIdx.x;
+  const int r_begin = z * rows_per_slice, r_end = min(M, r_begin + rows_per_slice);
+  const int c = w * 64 + 4 * cq;
+  const bool x_vec = c + 3 < K;
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int r0 = r_begin; r0 < r_end; r0 += 4 * U) {
+    float4 xv[U];
+    float a[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + 4 * u + kr;
+      const bool live = r < r_end;
+      xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) {
+        if (x_vec) {
+          xv[u] = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+        } else if (c <= K) {                                  // the piece that holds the end of x and the virtual ones column K
+          float t4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t4[j] = (c + j < K) ? x[(size_t)r * ldx + c + j] : (c + j == K ? 1.f : 0.f);
+          xv[u] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a[u][t] = (live && 16 * t + cq < N) ? dy[(size_t)r * ldy + 16 * t + cq] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], xv[u].x, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], xv[u].y, acc[t][1], 0, 0, 0);
+        acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], xv[u].z, acc[t][2], 0, 0, 0);
+        acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], xv[u].w, acc[t][3], 0, 0, 0);
+      }
+  }
+  // D of MFMA j, tile t: lane l holds outputs 16 t + 4 (l >> 4) + reg of column 64 w + 4 (l & 15) + j
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i = 16 * t + 4 * kr + reg;
+      if (i < N) {
+        float* row = part + ((size_t)z * N + i) * Kp + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < Kp) row[j] = acc[t][j][reg];
+      }
+    }
+}
+
+// the planes of the kernel above -> dw [N x K], db [N] (column K): 64 consecutive outputs per block, wave g of 16 sums planes
+// g, g + 16, ... (a wave reads 256 contiguous bytes of a plane), the 16 sums meet in LDS and are added in a fixed order
+__global__ __launch_bounds__(1024) void narrow_finish_kernel(const float* __restrict__ part, int nz, int N, int K, float* __restrict__ dw,
+                                                             float* __restrict__ db, int accumulate) {
+  __shared__ float red[16][64];
+  const int Kp = K + 1;
+  const size_t plane = (size_t)N * Kp;
+  const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const size_t i = (size_t)blockIdx.x * 64 + l;
+  float v = 0.f;
+  if (i < plane)
+    for (int z = g; z < nz; z += 16) v += part[(size_t)z * plane + i];
+  red[g][l] = v;
+  __syncthreads();
+  if (g != 0 || i >= plane) return;
+  float s = red[0][l];
+#pragma unroll
+  for (int q = 1; q < 16; ++q) s += red[q][l];
+  const int m = (int)(i / Kp), n = (int)(i - (size_t)m * Kp);
+  if (n == K) { if (db) db[m] = (accumulate ? db[m] : 0.f) + s; }
+  else { const size_t o = (size_t)m * K + n; dw[o] = (accumulate ? dw[o] : 0.f) + s; }
+}
+
+static int narrow_wgrad_form() {       // EVAE_WGRAD_NARROW: 0 = the GEMM kernel, 1 = the VALU reduction (r03), 2 (default) = fp32 MFMA (r06)
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("EVAE_WGRAD_NARROW"); on = e ? atoi(e) : 2; }
+  return on;
+}
+static bool narrow_mfma_shape(int N, int K) { return narrow_wgrad_form() >= 2 && N <= 64 && K + 1 <= 1024; }
+// rows of a slice of the MFMA form: whole 16-row groups of loads, at most 256 slices
+static int narrow_mfma_rows(int M) { return std::max(64, (int)align_up((size_t)cdiv(M, 256), 16)); }
+
+// row slices of the narrow kernels.  VALU form: ~768 blocks over the column tiles, at least 128 rows (four chunks) a slice
 static int narrow_wgrad_slices(int M, int K) {
   const int tiles = cdiv(K + 1, 64);
   return std::max(1, std::min(cdiv(768, tiles), cdiv(M, 128)));
 }
-static bool narrow_wgrad_enabled() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("EVAE_WGRAD_NARROW"); on = e ? atoi(e) : 1; }
-  return on != 0;
+static int narrow_planes(int M, int N, int K) {
+  return narrow_mfma_shape(N, K) ? cdiv(M, narrow_mfma_rows(M)) : cdiv(M, cdiv(M, narrow_wgrad_slices(M, K)));
 }
+static bool narrow_wgrad_enabled() { return narrow_wgrad_form() != 0; }
 static bool narrow_wgrad_shape(int M, int N, int K) { return narrow_wgrad_enabled() && N <= 64 && N % 4 == 0 && M >= 2048 && K >= 64; }
 
 // ---- weight gradient -------------------------------------------------------------------------------------
@@ -590,7 +691,7 @@ static int wgrad_max_planes(int M, int N, int K) {
   const Plan pl = make_plan(N, K + 1, cdiv(M, BK), false, true, 1);
   const Plan pll = make_plan_local(N, K + 1, cdiv(M, BK));
   int nz = std::max(std::max(pl.nz, pll.nz), x6t_split(M, N, K + 1).nz);
-  if (narrow_wgrad_shape(M, N, K)) nz = std::max(nz, narrow_wgrad_slices(M, K));
+  if (narrow_wgrad_shape(M, N, K)) nz = std::max(nz, std::max(narrow_wgrad_slices(M, K), narrow_planes(M, N, K)));
   return nz;
 }
 
@@ -659,9 +760,20 @@ static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const f
                "dense_bwd_weight_phased: operands of a narrow weight gradient must be 16-byte aligned");
   const bool narrow = !x6 && rows == nullptr && narrow_wgrad_shape(M, N, K) && ldy % 4 == 0 && ldx % 4 == 0 && aligned;
   const int nslice = narrow ? narrow_wgrad_slices(M, K) : 0;
+  const bool narrow_mfma = narrow && narrow_mfma_shape(N, K);
   if (narrow && phase != 2) {
-    const int rps = cdiv(M, nslice);
-    narrow_wgrad_kernel<<<dim3(cdiv(Kp, 64), cdiv(M, rps)), 256, 0, stream>>>(dy, ldy, x, ldx, M, N, K, rps, part);
+    if (narrow_mfma) {
+      const int rps = narrow_mfma_rows(M), nb = cdiv(M, rps), nt = 64 * cdiv(Kp, 64);
+      switch (cdiv(N, 16)) {
+        case 1: narrow_wgrad_mfma_kernel<1><<<nb, nt, 0, stream>>>(dy, ldy, x, ldx, M, N, K, rps, part); break;
+        case 2: narrow_wgrad_mfma_kernel<2><<<nb, nt, 0, stream>>>(dy, ldy, x, ldx, M, N, K, rps, part); break;
+        case 3: narrow_wgrad_mfma_kernel<3><<<nb, nt, 0, stream>>>(dy, ldy, x, ldx, M, N, K, rps, part); break;
+        default: narrow_wgrad_mfma_kernel<4><<<nb, nt, 0, stream>>>(dy, ldy, x, ldx, M, N, K, rps, part); break;
+      }
+    } else {
+      const int rps = cdiv(M, nslice);
+      narrow_wgrad_kernel<<<dim3(cdiv(Kp, 64), cdiv(M, rps)), 256, 0, stream>>>(dy, ldy, x, ldx, M, N, K, rps, part);
+    }
     const int rc = check_launch("narrow_wgrad_kernel");
     if (rc || phase == 1) return rc;
   }
@@ -677,9 +789,13 @@ static int dense_bwd_weight_core(const float* dy, int M, int N, int ldy, const f
     if (phase == 1) return EVAE_OK;
   }
   FinishArgs f = {};
-  f.part = part; f.nz = narrow ? cdiv(M, cdiv(M, nslice)) : (x6 ? sp6.nz : pl.nz); f.M = N; f.N = Kp; f.ldo = Kp; f.epi = EPI_RAW; f.out0 = dw; f.accumulate = accumulate;
+  f.part = part; f.nz = narrow ? narrow_planes(M, N, K) : (x6 ? sp6.nz : pl.nz); f.M = N; f.N = Kp; f.ldo = Kp; f.epi = EPI_RAW; f.out0 = dw; f.accumulate = accumulate;
   f.ones_col = K; f.out_db = db;
   if (finish_out) { *finish_out = f; return EVAE_OK; }      // (the caller only wants to know what the finish would be)
+  if (narrow_mfma) {
+    narrow_finish_kernel<<<cdiv(N * Kp, 64), 1024, 0, stream>>>(part, f.nz, N, K, dw, db, accumulate);
+    return check_launch("narrow_finish_kernel");
+  }
   return launch_finish(f, stream);
 }
 

@@ -317,13 +317,11 @@ class VaeExactLoss(torch.autograd.Function):
         beta_dev = beta if torch.is_tensor(beta) else None
         beta_host = 0.0 if beta_dev is not None else float(beta)
         dd = DEDUP[0]
-        if dd is not None and (approx or sharded or dd[2].numel() != Cl or dd[3].numel() != Cl):
-            raise _lib.EvaeError("fused step: the runner's duplicate tables do not belong to this exemplar set")
-        Cp = dd[0].numel() if dd is not None else Cl          # exemplars the prior sees (all draws)
+        if dd is not None and (approx or dd[2].numel() != Cl or dd[3].numel() != Cl):
+            raise _lib.EvaeError("fused step: the duplicate tables do not belong to this exemplar set")
+        Cp = dd[0].numel() if dd is not None else Cl          # exemplars the prior sees (all draws; this rank's when sharded)
         prior_train = bool(PRIOR_TRAIN and UNIT_UPSTREAM[0] and average and not sharded and Cl > 0 and not ONE_STREAM[0]
                            and ops.prior_train_applies(B, Cp, Z))
-        if dd is not None and not prior_train:
-            raise _lib.EvaeError("fused step: duplicate tables need the one-launch prior of a captured step (EVAE_DEDUP=0 turns them off)")
         coef = None
         with torch.cuda.stream(side):
             # (on the side stream, in front of everything: with the byte gather moved behind the batch-row chain the MAIN stream's
@@ -411,6 +409,12 @@ class VaeExactLoss(torch.autograd.Function):
         if approx:
             approx_cache.index_copy_(0, sel_rows, centres)       # repeats of a row carry identical encodings
         main.wait_event(z_ready)                           # (also orders lv_row, written at the head of the side stream)
+        # the centres the prior sees: one per DRAW.  With duplicate tables outside the one-launch prior (eager steps, sharded steps:
+        # r06) they are gathered from the distinct rows' encodings here and the prior's kernels run over them as over any exemplar set
+        centres_p = centres
+        if dd is not None and not prior_train:
+            centres_p = torch.empty((Cp, Z), **f32)
+            _lib.check(lib.evae_gather_rows(_vp(centres), _vp(dd[1]), None, Cp, Z, _vp(centres_p), k.st), "gather_rows(centres)")
         # ---- exemplar prior (leave-one-out mask in training unless no_mask; with its collectives when sharded) on the
         #      main stream ...
         zi = None if no_mask else ops._i64(x_idx)
@@ -442,12 +446,12 @@ class VaeExactLoss(torch.autograd.Function):
             # shard (same pair count as B queries against all C), the partials go back to their owners
             z_all = shard._all_gather_flat(z).reshape(-1, Z)
             zi_all = None if zi is None else shard._all_gather_flat(zi.contiguous()).reshape(-1)
-            m, s, n, _ = ops.prior_lse_fwd(z_all, centres, lv_row, zi_all, ci)
+            m, s, n, _ = ops.prior_lse_fwd(z_all, centres_p, lv_row, zi_all, ci)
             m, s, n = shard.gather_partials(m, s, n)                  # [R x R*B] each
             r0 = dist.get_rank() * B
             m, s, n = (t[:, r0:r0 + B].contiguous() for t in (m, s, n))
         elif sharded:
-            m, s, n, _ = ops.prior_lse_fwd(z, centres, lv_row, zi, ci)
+            m, s, n, _ = ops.prior_lse_fwd(z, centres_p, lv_row, zi, ci)
             m, s, n = shard.gather_partials(m, s, n)
         if sharded:
             R, ldp = m.shape[0], m.shape[1]
@@ -456,10 +460,10 @@ class VaeExactLoss(torch.autograd.Function):
             pass
         else:
             # one device: the per-split partials stay un-merged in the workspace
-            nb = lib.evae_prior_lse_fwd_workspace_bytes(B, Cl, Z)
+            nb = lib.evae_prior_lse_fwd_workspace_bytes(B, Cp, Z)
             w = k.ws("prior_fwd", nb)
             ns, prow = C.c_int(0), C.c_int(0)
-            _lib.check(lib.evae_prior_lse_fwd_splits(_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(w),
+            _lib.check(lib.evae_prior_lse_fwd_splits(_vp(z), B, _vp(centres_p), Cp, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(w),
                                                      w.numel(), C.byref(ns), C.byref(prow), k.st), "prior_lse_fwd_splits")
             R, ldp = ns.value, B
             pm = w.data_ptr(); ps = pm + 4 * prow.value * B; pn = ps + 4 * prow.value * B
@@ -505,6 +509,7 @@ class VaeExactLoss(torch.autograd.Function):
         #  the main stream that would otherwise be free to take their memory)
         ctx.elbo_keep = (RE, logq, logp, loss, KL, means) if (elbo_split or prior_train) else None
         ctx.prior_done = prior_done
+        ctx.dd = (dd, centres_p) if (dd is not None and not prior_train) else None
         ctx.wt = WT_DONE.pop((wm.data_ptr(), w2h.data_ptr(), w2g.data_ptr()), None)
         ctx.set_materialize_grads(False)       # unused outputs (RE, KL) then arrive as None, not as zero-filled tensors
         ctx.k_dev = dev
@@ -641,6 +646,15 @@ class VaeExactLoss(torch.autograd.Function):
         z_mean = mean_all[Cl:]
         off = 4 * Cl
         prior_finish = None
+        # duplicate tables outside the one-launch prior: the prior's backward runs over the per-draw centres and a distinct row's
+        # gradient is multiplicity x one of its draws' (evae_gather_rows with a scale), written where the head's data gradient reads
+        dd_, centres_p = ctx.dd if ctx.dd is not None else (None, centres)
+        Cp = centres_p.shape[0]
+        dc_out = torch.empty((Cp, Z), **f32) if dd_ is not None else dmean_all
+
+        def dc_fold():
+            if dd_ is not None:
+                _lib.check(lib.evae_gather_rows(_vp(dc_out), _vp(dd_[2]), _vp(dd_[3]), Cl, Z, _vp(dmean_all), k.st), "gather_rows(dcentres)")
         if prior_done:
             side.wait_event(ctx.prior_done[2])       # (not the prior's launch, which the forward pass put on the main stream)
         else:
@@ -656,11 +670,12 @@ class VaeExactLoss(torch.autograd.Function):
             lse_all = torch.stack((lg[:, 0].reshape(-1), lg[:, 1].reshape(-1))).contiguous()       # token of all R B queries
             gp_all = lg[:, 2].reshape(-1).contiguous()
             dz_all = torch.empty((RB, Z), **f32); dlv = torch.empty(Z, **f32)
-            nb = lib.evae_prior_lse_bwd_workspace_bytes(RB, Cl, Z)
+            nb = lib.evae_prior_lse_bwd_workspace_bytes(RB, Cp, Z)
             w = k.ws("prior_bwd", nb)
-            _lib.check(lib.evae_prior_lse_bwd(_vp(z_all), RB, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi_all), _vp(ci), _vp(lse_all),
-                                              _vp(gp_all), _vp(dz_all), _vp(dmean_all), _vp(dlv), _vp(w), w.numel(), k.st),
+            _lib.check(lib.evae_prior_lse_bwd(_vp(z_all), RB, _vp(centres_p), Cp, Z, _vp(lv_row), _vp(zi_all), _vp(ci), _vp(lse_all),
+                                              _vp(gp_all), _vp(dz_all), _vp(dc_out), _vp(dlv), _vp(w), w.numel(), k.st),
                        "prior_bwd")
+            dc_fold()
             dist.all_reduce(dz_all, op=dist.ReduceOp.SUM)
             r0 = dist.get_rank() * B
             dzp = dz_all[r0:r0 + B]
@@ -671,12 +686,13 @@ class VaeExactLoss(torch.autograd.Function):
             assert ctx.prior_done is None, "fused vae step: the captured form's backward was called with another upstream gradient"
             packed = torch.empty(B * Z + Z, **f32)
             dzp = packed[:B * Z].view(B, Z); dlv = packed[B * Z:]
-            nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cl, Z)
+            nb = lib.evae_prior_lse_bwd_workspace_bytes(B, Cp, Z)
             w = k.ws("prior_bwd", nb)
-            pb_args = (_vp(z), B, _vp(centres), Cl, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp), _vp(dzp),
-                       _vp(dmean_all), _vp(dlv), _vp(w), w.numel())
-            if sharded == 1 or not (SCHED & 1):
+            pb_args = (_vp(z), B, _vp(centres_p), Cp, Z, _vp(lv_row), _vp(zi), _vp(ci), _vp(lse), _vp(gp), _vp(dzp),
+                       _vp(dc_out), _vp(dlv), _vp(w), w.numel())
+            if sharded == 1 or dd_ is not None or not (SCHED & 1):
                 _lib.check(lib.evae_prior_lse_bwd(*pb_args, k.st), "prior_bwd")
+                dc_fold()
                 if sharded == 1:
                     dist.all_reduce(packed, op=dist.ReduceOp.SUM)
                     if Cl > 0:
@@ -871,6 +887,7 @@ class VaeExactLoss(torch.autograd.Function):
         ctx.bufs = None
         ctx.elbo_keep = None
         ctx.prior_done = None
+        ctx.dd = None
         grads = (g_plv, g_wp, g_bp, g_w1[:H], g_b1[:H], g_w1[H:], g_b1[H:], g_w2[:H], g_b2[:H], g_w2[H:], g_b2[H:],
                  g_wm, g_bm, g_wl, g_bl, g_d1[:H], g_e1[:H], g_d1[H:], g_e1[H:], g_d2[:H], g_e2[:H], g_d2[H:], g_e2[H:])
         return (None,) * 15 + grads

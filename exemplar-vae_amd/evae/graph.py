@@ -85,24 +85,27 @@ class GraphedTrainStep:
         Cd = Cl                                  # rows of the gather list's head
         Nt = int(a.training_set_size)
         from . import fused_vae as _fv0
-        want = (os.environ.get("EVAE_DEDUP", "1") != "0" and Cl == C and not a.approximate_prior and not model._sharded() and Nt > 0
+        sharded = model._sharded()
+        want = (os.environ.get("EVAE_DEDUP", "1") != "0" and (Cl == C or sharded) and Cl > 0 and not a.approximate_prior and Nt > 0
                 and a.prior == 'exemplar_prior' and int(a.z1_size) % 4 == 0)
-        if want and a.model_name == 'vae' and model._fused_config():
-            # the fused node: what it does with the tables needs the byte store and the one-launch prior of a captured step (the
-            # same predicate as there).  Every other model meets them in get_exemplar_set (models/BaseModel.py, ops.ExpandRowsFn)
+        if want and a.model_name == 'vae' and model._fused_config() and not sharded:
+            # the fused node on one device: what it does with the tables needs the byte store and the one-launch prior of a captured
+            # step (the same predicate as there).  A sharded fused step gathers the per-draw centres for the prior's own kernels (r06);
+            # every other model meets the tables in get_exemplar_set (models/BaseModel.py, ops.ExpandRowsFn)
             want = (self.u8 and os.environ.get("EVAE_UNIT_UPSTREAM", "1") != "0" and _fv0.PRIOR_TRAIN and not _fv0.ONE_STREAM[0]
                     and ops.prior_train_applies(self.B, C, int(a.z1_size)))
         if want:
-            # distinct rows among C draws from Nt: mean Nt (1 - q), variance Nt q (1 - q) + Nt (Nt - 1) (q2 - q^2) with q = (1 - 1/Nt)^C
-            # the chance that a given row is not drawn, q2 = (1 - 2/Nt)^C that two given rows are not (the occupancies are
-            # negatively correlated: c2's 25 000 of 50 000 give 19 673 +- 52); cap = mean + 8 sigma, whole 128-row tiles
-            lq = C * math.log1p(-1.0 / Nt) if Nt > 1 else -math.inf
+            # distinct rows among the Cl draws of this process (all C on one device, its shard of the common draw otherwise) from Nt:
+            # mean Nt (1 - q), variance Nt q (1 - q) + Nt (Nt - 1) (q2 - q^2) with q = (1 - 1/Nt)^Cl the chance that a given row is not
+            # drawn, q2 = (1 - 2/Nt)^Cl that two given rows are not (the occupancies are negatively correlated: c2's 25 000 of
+            # 50 000 give 19 673 +- 52); cap = mean + 8 sigma, whole 128-row tiles
+            lq = Cl * math.log1p(-1.0 / Nt) if Nt > 1 else -math.inf
             q = math.exp(lq)
-            dq = q * q * math.expm1(C * math.log1p(-2.0 / Nt) - 2.0 * lq) if Nt > 2 else 0.0       # q2 - q^2
+            dq = q * q * math.expm1(Cl * math.log1p(-2.0 / Nt) - 2.0 * lq) if Nt > 2 else 0.0       # q2 - q^2
             mean_u = Nt * (1.0 - q)
             var_u = max(Nt * q * (1.0 - q) + Nt * (Nt - 1.0) * dq, 1.0)
-            cap = min(C, int(math.ceil((mean_u + 8.0 * math.sqrt(var_u) + 32.0) / 128.0)) * 128)
-            if cap <= 0.92 * C:
+            cap = min(Cl, int(math.ceil((mean_u + 8.0 * math.sqrt(var_u) + 32.0) / 128.0)) * 128)
+            if cap <= 0.92 * Cl:
                 self.dedup = {"cap": cap, "distinct": 0}
                 Cd = cap
         self._Cd = Cd
@@ -111,8 +114,8 @@ class GraphedTrainStep:
         words = self._o_scal + (nsc + 1) // 2
         if self.dedup is not None:
             self._o_draw = words
-            self._o_inv = self._o_draw + C
-            self._o_rep = self._o_inv + C
+            self._o_inv = self._o_draw + Cl
+            self._o_rep = self._o_inv + Cl
             self._o_mult = self._o_rep + Cd
             words = self._o_mult + (Cd + 1) // 2
         self.ctl = torch.zeros(words, dtype=torch.int64, device=dev)
@@ -171,6 +174,8 @@ class GraphedTrainStep:
         self.cache = None          # approximate prior: the latent cache in static buffers (set_cache)
         self.graph = None
         self.failed = False
+        self._overflow = None      # set by _refresh when a draw has more distinct rows than the captured step holds: (draws | staging rows)
+        self.overflow_steps = 0
         self.eager_opt = False     # True: the participants' step counts differ (resumed checkpoint): eager optimizer steps only
         self.warmup_steps = max(2, warmup_steps)    # call 0 learns the optimizer's participants, call 1 warms the captured form
         self._calls = 0
@@ -219,7 +224,18 @@ class GraphedTrainStep:
         return wh.detach(), wg.detach(), prep, jobs
 
     # the body that gets captured
-    def _body(self, eager_opt=False):
+    def _eager_tables(self):
+        """The optimizer tables of this runner's captured-FORM steps that are issued eagerly (step_eagerly, _every_draw_step): the
+        graph's step-size scalars, but their own pointer tables -- an eager step's gradient buffers are fresh allocations, and
+        writing their addresses into the table the captured launches read would redirect every later replay."""
+        t = getattr(self, "_adam_tables_eager", None)
+        if t is None:
+            t = self._adam_tables_eager = {}
+        if "step_size" in self._adam_tables:
+            t["step_size"] = self._adam_tables["step_size"]
+        return t
+
+    def _body(self, eager_opt=False, tables=None):
         if self.by_index:
             # the batch is rows `idx` of the HBM-resident dataset: gathered (and binarised) straight into the staging rows
             # of the fused step, no image bytes cross PCIe
@@ -258,7 +274,7 @@ class GraphedTrainStep:
             self.opt.step()
             self.opt._stats_done = False
         else:
-            self.opt.step(_captured=True, _tables=self._adam_tables, _stats=stats)
+            self.opt.step(_captured=True, _tables=self._adam_tables if tables is None else tables, _stats=stats)
         if not getattr(self.opt, "_stats_done", False):
             ops.step_stats_add(loss.detach(), RE.detach(), KL.detach(), self.out, self.totals)
         return self.out
@@ -288,13 +304,23 @@ class GraphedTrainStep:
         # same CPU-generator draw, with replacement, as the reference (models/BaseModel.py:245)
         if self.dedup is not None:
             dr = h[self._o_draw:self._o_inv]
-            torch.randint(low=0, high=a.training_set_size, size=(Cl,), out=dr)
+            if Cl == a.number_components:
+                torch.randint(low=0, high=a.training_set_size, size=(Cl,), out=dr)
+            else:                                 # sharded: the common draw (same CPU generator state on every rank), this rank's slice
+                torch.randint(low=0, high=a.training_set_size, size=(a.number_components,), out=self._h_draw)
+                dr.copy_(self._h_draw[self.lo:self.hi])
             cap = self.dedup["cap"]
             nu = _lib.load().evae_host_dedup(C.c_void_p(dr.data_ptr()), Cl, int(a.training_set_size), cap, C.c_void_p(h.data_ptr()),
                                              C.c_void_p(h[self._o_inv:].data_ptr()), C.c_void_p(h[self._o_rep:].data_ptr()),
                                              C.c_void_p(self.dedup["host_mult"][k].data_ptr()))
             if nu < 0:
-                raise RuntimeError("captured step: " + _lib.load().evae_last_error().decode("utf-8", "replace") + " -- EVAE_DEDUP=0 encodes every draw")
+                # more distinct rows than the captured step has room for (its fixed count sits eight standard deviations above the
+                # mean: ~1e-15 per draw): THIS step is issued eagerly with every draw encoded -- the same loss and gradients
+                # (__call__ / step_eagerly look at _overflow) -- and the next one replays again
+                Cd_ = self._Cd
+                self._overflow = torch.cat((dr, h[Cd_:self._o_idx])).to(self.ctl.device)
+                h[:Cd_] = dr[:Cd_]                # (a valid gather list for the block that is uploaded all the same; never read)
+                nu = 0
             self.dedup["distinct"] = nu
         elif Cl == a.number_components:
             torch.randint(low=0, high=a.training_set_size, size=(Cl,), out=h[:Cl])
@@ -342,7 +368,9 @@ class GraphedTrainStep:
             self._refresh(data, indices, beta)
             self.model._eps_override = self.eps_buf if self.by_index else None
             self.model._batch_staged = bool(self.by_index and self.u8)
-            self._body(eager_opt=self.eager_opt)
+            if self._overflow is not None:
+                return self._every_draw_step()
+            self._body(eager_opt=self.eager_opt, tables=self._eager_tables())
             self._calls += 1
             return self.out
         finally:
@@ -350,6 +378,24 @@ class GraphedTrainStep:
             self.model._exemplar_dedup = None
             self.model._eps_override = None
             self.model._batch_staged = False
+
+    def _every_draw_step(self):
+        """One step issued eagerly with EVERY draw encoded (no distinct-row tables): what a draw that does not fit the captured
+        step's fixed row count gets instead of an exception.  Same control block (batch, seed, beta, step sizes), same optimizer form."""
+        rows_ext, self._overflow = self._overflow, None
+        Cl = self.hi - self.lo
+        self.model._exemplar_indices_override = (rows_ext, Cl)
+        self.model._exemplar_dedup = None
+        dd, self.dedup = self.dedup, None
+        try:
+            self._body(eager_opt=self.eager_opt or self._calls == 0, tables=self._eager_tables() if self.graph is not None else None)
+            if self._calls == 0 and not self.eager_opt and not self.opt.learn_members(self._adam_tables):
+                self.failed = self.eager_opt = True
+        finally:
+            self.dedup = dd
+        self._calls += 1
+        self.overflow_steps += 1
+        return self.out
 
     def __call__(self, data, indices, beta):
         """One training step; returns a device tensor (loss, -RE, KL) valid until the next call."""
@@ -363,6 +409,8 @@ class GraphedTrainStep:
             self._refresh(data, indices, beta)
             self.model._eps_override = self.eps_buf if self.by_index else None
             self.model._batch_staged = bool(self.by_index and self.u8)
+            if self._overflow is not None:
+                return self._every_draw_step()
             if self.graph is None:
                 # eager warm-up steps on a side stream (workspaces, attributes, RCCL channels), then capture
                 if self._calls < self.warmup_steps and not self.failed:

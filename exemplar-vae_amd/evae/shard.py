@@ -24,6 +24,8 @@ of dz [R*B x z] of which every rank keeps its rows.  dcentres / dlogvar are then
 the mean all-reduce of the parameter gradients gives exactly the gradient of the global-batch mean loss (no
 rescaling): tests/test_gpu_sharded.py checks 2 ranks x B against 1 process x 2B.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -39,8 +41,13 @@ class ShardedEmbedding(tuple):
         return obj
 
 
+# EVAE_SHARD_FORCE=1: the sharded code path (collectives included) also in a process group of ONE rank -- how the one leased GPU of the
+# build box executes the RCCL branch (tests/test_gpu_sharded.py::test_rccl_group_of_one_rank_*); nothing else sets it
+FORCE = [os.environ.get("EVAE_SHARD_FORCE") == "1"]
+
+
 def is_active():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE[0])
 
 
 def world():

