@@ -312,6 +312,394 @@ __global__ void zero_ints_kernel(int* p, int n, unsigned* q) {
   if (i == 0 && q) *q = 0u;
 }
 
+// ======================================================================================================================
+// r06: the cache scan + top-K as ONE launch.  The two-launch form above writes the [N x B] approximate
+// distances (40 MB at c5) and reads them back: 182 MB of traffic for 102 MB of cache.  Here nothing but candidates leaves a block:
+//   * a block streams ITS contiguous range of cache rows once (fp32 rows -> two bf16 terms while staging, their squared norms
+//     accumulated on the way), 128-row tiles against all <= 128 queries; the queries' fragments (two terms) stay in registers,
+//     wave w owning queries 32 w .. 32 w + 31, so that a lane pair (l, l ^ 32) holds all 128 distances of ONE query;
+//   * a valid upper bound T' of the k-th smallest approximate distance comes for free: every lane keeps MG = ceil(k / 2) running
+//     GROUP minima over the rows it has seen (register j of a tile belongs to group j mod MG); the 2 MG minima of a lane pair are 2 MG
+//     >= k distinct rows, so max of them >= the k-th smallest distance of the whole cache -- the tile-minima argument of the
+//     two-launch form, inside a lane;
+//   * a row is a candidate when d <= T' + 2 gamma (|q|^2 + largest row norm seen): (value, row) goes to the query's list in LDS,
+//     flushed once per block (one atomic per query to reserve the global range; a full LDS list spills straight to the global one);
+//   * blocks 0 .. B-1 then wait for every block to have flushed (an arrival counter; the others exit) and finish ONE query each:
+//     exact k-th smallest approximate distance among its candidates (every row with one of the k smallest approximate distances
+//     is a candidate: it is <= any T'), the final candidates d <= T + 2 gamma (|q|^2 + max |c|^2), their exact fp64 distances and
+//     ranks (topk_exact_body: bit-identical indices and values to the scan kernel by the argument at the head of this file).
+// HBM traffic = the cache + the queries + a few MB of candidates.
+constexpr int TS_NT = 256, TS_SLOTS = 48, TS_NQ = 128, TS_MAX_BLOCKS = 1024;
+struct TopkStreamArgs {
+  const float* q; const float* cache;
+  int B, N, zdim, k; unsigned flags; int64_t index_base;
+  int rows_per_block; float gamma;
+  int abl;                            // tools only (EVAE_TS_ABL): 1 = leave before the finish stage, 2 = also emit nothing, 4 = also no MFMAs
+  unsigned* counters;                 // [0, 128): entries of a query's OVERFLOW list; [256, 256 + blocks): a block's flag (its lists are flushed)
+  float* cmaxb;                       // [blocks] the largest |c|^2 of a block's rows
+  int* gcnt;                          // [B][blocks] candidates of (query, block)
+  float* gval; int* gidx;             // [B][blocks][TS_SLOTS] (approximate distance without |q|^2, row): fixed regions, no atomics
+  float* oval; int* oidx; size_t cap; // [B][cap] candidates beyond a block's TS_SLOTS (rare; appended with an atomic)
+  int* cand; float* val; size_t ldc;  // the exact stage's lists
+  int64_t* out_idx; float* out_val;
+};
+template <int CKS> constexpr int ts_row_bytes() { return CKS * 32 + 16; }                 // a staged row of one term: CKS x 16 bf16 + pad
+template <int CKS> constexpr int ts_stage_bytes() { return 2 * 128 * ts_row_bytes<CKS>(); }
+template <int CKS> constexpr size_t ts_lds_bytes() {
+  return 2 * (size_t)ts_stage_bytes<CKS>() + 2 * 128 * 4 + 16 + 2 * TS_NQ * 4 + 2 * (size_t)TS_NQ * TS_SLOTS * 4;
+}
+// (x, y) -> the two bf16 terms of each, term t of x in the low half of p[t]
+__device__ __forceinline__ void ts_split2(float x, float y, unsigned& p0, unsigned& p1) {
+  x6_f32x2 r = {x, y};
+  p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, x6_bf16x2));
+  x6_f32x2 h = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xFFFF0000u)};
+  r = r - h;
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, x6_bf16x2));
+}
+
+// a candidate (approximate distance, row) of query nq: the block's LDS list, or the query's global overflow list when that is full.
+// Out of line: the 64 call sites of a tile's epilogue are a compare and a branch each (the unrolled form was 1000 instructions of
+// a kernel whose straight-line code then no longer fitted the instruction cache: 27 us of fetch stalls per block at c2)
+__device__ __attribute__((noinline)) void ts_emit(float d, int row, int nq, int* lcnt, float* lv, int* li, unsigned* counters,
+                                                  float* oval, int* oidx, size_t cap) {
+  const int slot = atomicAdd(&lcnt[nq], 1);
+  if (slot < TS_SLOTS) { lv[nq * TS_SLOTS + slot] = d; li[nq * TS_SLOTS + slot] = row; }
+  else {
+    const unsigned gs = atomicAdd(&counters[nq], 1u);
+    oval[(size_t)nq * cap + gs] = d; oidx[(size_t)nq * cap + gs] = row;
+  }
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void ts_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); ts_static_for<I + 1, N>(f); }
+}
+
+template <int KS, int CKS, int MG>
+__global__ __launch_bounds__(TS_NT) void topk_stream_kernel(const TopkStreamArgs a) {
+  static_assert(KS % CKS == 0 && (KS / CKS) % 2 == 0, "chunks per tile must be even (register sets alternate)");
+  constexpr int NCH = KS / CKS;                    // chunks of a tile
+  constexpr int RS = ts_row_bytes<CKS>(), TERM = 128 * RS, STAGE = 2 * TERM;
+  constexpr int LPR = 4 * CKS;                     // lanes (float4s) per row of a chunk
+  constexpr int RSTEP = TS_NT / LPR, NJ = 128 / RSTEP;       // a thread stages rows r0 + RSTEP j
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const stA = lds;
+  float* const cn_l = reinterpret_cast<float*>(lds + 2 * STAGE);         // [2][128]
+  unsigned* const cmax_l = reinterpret_cast<unsigned*>(cn_l + 256);
+  int* const lcnt = reinterpret_cast<int*>(cmax_l + 4);                   // [128]
+  int* const lbase = lcnt + TS_NQ;
+  float* const lv = reinterpret_cast<float*>(lbase + TS_NQ);              // [128][SLOTS]
+  int* const li = reinterpret_cast<int*>(lv + TS_NQ * TS_SLOTS);
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, half = l >> 5;
+  const int nq = 32 * w + (l & 31);
+  const bool q_live = nq < a.B;
+  const int zdim = a.zdim;
+  if (tid < TS_NQ) lcnt[tid] = 0;
+  if (tid == 0) *cmax_l = 0u;
+  unsigned long long* const stamp = reinterpret_cast<unsigned long long*>(a.counters + 256 + TS_MAX_BLOCKS) + 32 * (blockIdx.x == 0 ? 0 : 1);
+  const bool stamping = (a.abl & 64) && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100);
+  int nstamp = 0;
+  auto mark = [&]() { if (stamping && nstamp < 32) stamp[nstamp++] = wall_clock64(); };
+  mark();
+  const int rb = blockIdx.x * a.rows_per_block;
+  const int row_end = min(a.N, rb + a.rows_per_block);
+  const int ntile = rb < row_end ? (row_end - rb + 127) / 128 : 0;
+  // ---- the queries' fragments: B operand of v_mfma_f32_32x32x16_bf16, lane l: query l & 31 of the wave, k = 16 s + 8 (l >> 5) .. + 7
+  x6_bf16x8 bq[KS][2];
+  float qn = 0.f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k0 = 16 * s + 8 * half;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (q_live && k0 < zdim) v0 = *reinterpret_cast<const float4*>(a.q + (size_t)nq * zdim + k0);
+    if (q_live && k0 + 4 < zdim) v1 = *reinterpret_cast<const float4*>(a.q + (size_t)nq * zdim + k0 + 4);
+    qn += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w + v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+    unsigned t0[4], t1[4];
+    ts_split2(v0.x, v0.y, t0[0], t1[0]); ts_split2(v0.z, v0.w, t0[1], t1[1]);
+    ts_split2(v1.x, v1.y, t0[2], t1[2]); ts_split2(v1.z, v1.w, t0[3], t1[3]);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    bq[s][0] = __builtin_bit_cast(x6_bf16x8, (u32x4){t0[0], t0[1], t0[2], t0[3]});
+    bq[s][1] = __builtin_bit_cast(x6_bf16x8, (u32x4){t1[0], t1[1], t1[2], t1[3]});
+  }
+  qn += __shfl_xor(qn, 32, 64);
+  mark();
+  // ---- staging: thread -> float4 kq of rows r0 + RSTEP j of a chunk
+  const int kq = tid % LPR, r0 = tid / LPR;
+  float4 R[2][NJ];
+  float ns[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) ns[j] = 0.f;
+  // (rows_per_block is a multiple of 128: every tile of a block is whole, except the cache's very last one -- its rows beyond N
+  //  are read from row N - 1 and masked in the epilogue; columns beyond zdim, when zdim is no multiple of the chunk, are zeroed by
+  //  a select: no branch per load, one uniform branch per chunk for the prefetch that would run past the block's end)
+  auto load = [&](auto SET, int tile, int ck) {
+    constexpr int S = decltype(SET)::value;
+    if (tile >= ntile) return;
+    const int kk = ck * (CKS * 16) + 4 * kq;
+    const bool k_live = kk < zdim;
+    const int kc = min(kk, zdim - 4);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int row = min(rb + tile * 128 + r0 + RSTEP * j, a.N - 1);
+      float4 v = *reinterpret_cast<const float4*>(a.cache + (size_t)row * zdim + kc);
+      if (!k_live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      R[S][j] = v;
+    }
+  };
+  f32x16 acc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+  float gmin[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) gmin[g] = INFINITY;
+  load(std::integral_constant<int, 0>{}, 0, 0);
+  load(std::integral_constant<int, 1>{}, 0, 1);
+  __syncthreads();
+  for (int tile = 0; tile < ntile; ++tile) {
+    constexpr int nmt = 4;
+    ts_static_for<0, NCH>([&](auto CK_) {
+      constexpr int ck = decltype(CK_)::value;
+      char* const st = stA + ((ck & 1) ? STAGE : 0);
+      // chunk (tile, ck) sits in register set ck & 1: split it into the stage, then refill the set with the chunk two ahead
+      auto stage_set = [&](auto SET) {
+        constexpr int S = decltype(SET)::value;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float4 v = R[S][j];
+          ns[j] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+          unsigned p0a, p1a, p0b, p1b;
+          ts_split2(v.x, v.y, p0a, p1a); ts_split2(v.z, v.w, p0b, p1b);
+          char* dst = st + (r0 + RSTEP * j) * RS + kq * 8;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(p0a, p0b);
+          *reinterpret_cast<uint2*>(dst + TERM) = make_uint2(p1a, p1b);
+        }
+        const int nt = (ck + 2 < NCH) ? tile : tile + 1, nc = (ck + 2 < NCH) ? ck + 2 : ck + 2 - NCH;
+        load(SET, nt, nc);
+      };
+      if constexpr ((ck & 1) == 0) stage_set(std::integral_constant<int, 0>{}); else stage_set(std::integral_constant<int, 1>{});
+      if constexpr (ck == NCH - 1) {
+        // the tile's rows are complete: their squared norms (summed over the LPR lanes of a row) for the epilogue, their maximum
+        float* cnp = cn_l + (tile & 1) * 128;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          float t = ns[j];
+#pragma unroll
+          for (int o = 1; o < LPR; o <<= 1) t += __shfl_xor(t, o, 64);
+          if (kq == 0) { cnp[r0 + RSTEP * j] = t; atomicMax(cmax_l, __float_as_uint(t)); }
+          ns[j] = 0.f;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s2 = 0; s2 < CKS; ++s2) {
+        const int s = ck * CKS + s2;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          if (!(a.abl & 4)) {
+            const char* src = st + (32 * mt + (l & 31)) * RS + s2 * 32 + 16 * half;
+            const x6_bf16x8 a0 = *reinterpret_cast<const x6_bf16x8*>(src);
+            const x6_bf16x8 a1 = *reinterpret_cast<const x6_bf16x8*>(src + TERM);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[s][0], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[s][1], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[s][0], acc[mt], 0, 0, 0);
+          }
+        }
+      }
+    });
+    mark();
+    // ---- the tile's epilogue: d = |c|^2 - 2 q.c (no |q|^2: a constant per query), group minima, threshold, candidates
+    {
+      const float* cnp = cn_l + (tile & 1) * 128;
+      const float cmax_seen = __uint_as_float(*cmax_l);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        if (mt < nmt) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int rl = 32 * mt + 8 * g4 + 4 * half;
+            const float4 c4 = *reinterpret_cast<const float4*>(cnp + rl);
+            const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float d = fmaf(-2.0f, acc[mt][4 * g4 + i], cc[i]);
+              if (tile * 128 + rl + i >= row_end - rb) d = INFINITY;
+              acc[mt][4 * g4 + i] = d;
+              gmin[4 * g4 + i] = fminf(gmin[4 * g4 + i], d);
+            }
+          }
+        }
+      }
+      // the MG-th smallest of the lane's 16 group minima (MG distinct rows at or below it): a min / max insertion chain
+      float sm[MG];
+#pragma unroll
+      for (int j = 0; j < MG; ++j) sm[j] = INFINITY;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        float v = gmin[g];
+#pragma unroll
+        for (int j = 0; j < MG; ++j) { const float lo = fminf(sm[j], v); v = fmaxf(sm[j], v); sm[j] = lo; }
+      }
+      float tb = sm[MG - 1];
+      tb = fmaxf(tb, __shfl_xor(tb, 32, 64));
+      const float thr = tb + 2.0f * a.gamma * (qn + cmax_seen);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        if (mt < nmt) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float d = acc[mt][i];
+            if (q_live && d <= thr && d < INFINITY && !(a.abl & 2))
+              ts_emit(d, rb + tile * 128 + 32 * mt + 8 * (i >> 2) + 4 * half + (i & 3), nq, lcnt, lv, li, a.counters, a.oval, a.oidx, a.cap);
+            acc[mt][i] = 0.f;
+          }
+        }
+      }
+    }
+  }
+  mark();
+  // ---- flush this block's lists into ITS regions of the queries' candidate stores (no atomics), then raise its flag
+  __syncthreads();
+  const int nblk = gridDim.x;
+  for (int e = tid; e < TS_NQ * TS_SLOTS; e += TS_NT) {
+    const int qq = e / TS_SLOTS, i = e - qq * TS_SLOTS;
+    if (qq < a.B && i < min(lcnt[qq], TS_SLOTS)) {
+      const size_t o = ((size_t)qq * nblk + blockIdx.x) * TS_SLOTS + i;
+      a.gval[o] = lv[e]; a.gidx[o] = li[e];
+    }
+  }
+  if (tid < a.B) a.gcnt[(size_t)tid * nblk + blockIdx.x] = min(lcnt[tid], TS_SLOTS);
+  if (tid == 0) a.cmaxb[blockIdx.x] = __uint_as_float(*cmax_l);
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(&a.counters[256 + blockIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  mark();
+  if ((int)blockIdx.x >= a.B || (a.abl & 1)) return;
+  // ---- one query per block from here (blocks beyond B have left): wait until every block has raised its flag
+  for (;;) {
+    int ok = 1;
+    for (int b = tid; b < nblk; b += TS_NT)
+      ok &= (__hip_atomic_load(&a.counters[256 + b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0;
+    if (__syncthreads_and(ok)) break;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  __threadfence();
+  mark();
+  float* const qs = reinterpret_cast<float*>(lds);                 // [<= 256] the query row (the stream's LDS is free now)
+  float* const tmn = qs + 512;                                     // [256] thread minima
+  float* const sv = tmn + TS_NT;                                   // [1024] candidates' values below the coarse bound
+  int* const scnt = reinterpret_cast<int*>(sv + 1024);             // [2]
+  float* const red = reinterpret_cast<float*>(scnt + 4);           // [8]
+  float* const fv = red + 8;                                       // [TS_SLOTS][256] a thread's block list
+  for (int n = blockIdx.x; n < a.B; n += nblk) {
+    // a thread owns the lists of blocks tid, tid + 256, ... and a stride of the overflow list
+    const int Mo = (int)__hip_atomic_load(&a.counters[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float* ov = a.oval + (size_t)n * a.cap;
+    const int* oi = a.oidx + (size_t)n * a.cap;
+    float qq2 = 0.f, cm = 0.f;
+    for (int d = tid; d < zdim; d += TS_NT) { const float v = a.q[(size_t)n * zdim + d]; qs[d] = v; qq2 = fmaf(v, v, qq2); }
+    for (int b = tid; b < nblk; b += TS_NT) cm = fmaxf(cm, a.cmaxb[b]);
+    qq2 = wave_sum(qq2); cm = wave_max(cm);
+    if (l == 0) { red[w] = qq2; red[4 + w] = cm; }
+    if (tid == 0) { scnt[0] = 0; scnt[1] = 0; }
+    // this thread's block list (one per thread: <= 256 blocks; more are walked from memory): its TS_SLOTS values into LDS by
+    // independent 16-byte loads (column tid of fv[slot][256]: conflict-free), then short loops over the count
+    int cnt0 = 0;
+    {
+      const bool has = tid < nblk;
+      cnt0 = has ? a.gcnt[(size_t)n * nblk + tid] : 0;
+      const float4* gv4 = reinterpret_cast<const float4*>(a.gval + ((size_t)n * nblk + (has ? tid : 0)) * TS_SLOTS);
+      float4 t4[TS_SLOTS / 4];
+#pragma unroll
+      for (int i = 0; i < TS_SLOTS / 4; ++i) t4[i] = gv4[i];
+#pragma unroll
+      for (int i = 0; i < TS_SLOTS / 4; ++i) {
+        fv[(4 * i) * TS_NT + tid] = t4[i].x; fv[(4 * i + 1) * TS_NT + tid] = t4[i].y;
+        fv[(4 * i + 2) * TS_NT + tid] = t4[i].z; fv[(4 * i + 3) * TS_NT + tid] = t4[i].w;
+      }
+    }
+    auto sweep = [&](auto&& f) {                  // f(value, pointer to its row index)
+      const int* gi0 = a.gidx + ((size_t)n * nblk + tid) * TS_SLOTS;
+      for (int i = 0; i < cnt0; ++i) f(fv[i * TS_NT + tid], gi0 + i);
+      for (int b = tid + TS_NT; b < nblk; b += TS_NT) {
+        const int c = a.gcnt[(size_t)n * nblk + b];
+        const float* gv = a.gval + ((size_t)n * nblk + b) * TS_SLOTS;
+        for (int i = 0; i < c; ++i) f(gv[i], a.gidx + ((size_t)n * nblk + b) * TS_SLOTS + i);
+      }
+      for (int i = tid; i < Mo; i += TS_NT) f(ov[i], oi + i);
+    };
+    mark();
+    float mn = INFINITY;
+    sweep([&](float v, const int*) { mn = fminf(mn, v); });
+    tmn[tid] = mn;
+    __syncthreads();
+    const float qnn = red[0] + red[1] + red[2] + red[3];
+    const float cmax = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    // coarse bound: the k-th smallest of the 256 thread minima (distinct candidates, k <= 32 of them at or below it)
+    const float t2 = key_to_float(kth_smallest_key<TS_NT>(tmn, TS_NT, a.k));
+    sweep([&](float v, const int*) { if (v <= t2 && v < INFINITY) { const int s_ = atomicAdd(&scnt[0], 1); if (s_ < 1024) sv[s_] = v; } });
+    __syncthreads();
+    const int ns_ = scnt[0];
+    // the k-th smallest approximate distance of the whole cache is among those at or below the coarse bound.  More than 1024 of
+    // them (masses of equal distances): the bound itself serves -- looser, still an upper bound of it
+    const float tk = ns_ <= 1024 ? key_to_float(kth_smallest_key<TS_NT>(sv, ns_, a.k)) : t2;
+    const float thr = tk + 2.0f * a.gamma * (qnn + cmax);
+    int* cl = a.cand + (size_t)n * a.ldc;
+    mark();
+    sweep([&](float v, const int* rowp) { if (v <= thr && v < INFINITY) cl[atomicAdd(&scnt[1], 1)] = *rowp; });
+    __syncthreads();
+    mark();
+    topk_exact_body<TS_NT>(qs, a.cache, zdim, a.k, a.flags, a.index_base, n, scnt[1], cl, a.val + (size_t)n * a.ldc, a.out_idx, a.out_val);
+    __syncthreads();
+    mark();
+  }
+}
+
+// OPT-IN (EVAE_TOPK_STREAM=1, read per call so that a test can switch it): measured r06 at c5 size 140 us against the two-launch
+// form's 67 -- correct (bit-exact indices, tests/test_gpu_kernels.py::test_topk_stream_*), not yet fast: per tile the main loop
+// takes 14 us (stage -> barrier -> fragment reads -> MFMAs run back to back in ONE wave per SIMD; the two-launch GEMM has two), the
+// epilogue 14 us (an LDS atomic round trip per candidate), the flush 20 us, the finish 34 us
+static bool stream_applies(int B, int N, int zdim, int k) {
+  const char* e = getenv("EVAE_TOPK_STREAM");
+  const bool on = e && atoi(e) != 0;
+  return on && B <= TS_NQ && zdim <= 256 && k <= 32 && N >= 2048;
+}
+static int stream_blocks(int N, int* rows_per_block) {
+  static int cus = 0;
+  if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+  const int rpb = std::max(128, (int)align_up((size_t)cdiv(N, cus), 128));      // whole 128-row tiles
+  *rows_per_block = rpb;
+  return cdiv(N, rpb);
+}
+struct StreamLayout { size_t counters, cmaxb, gcnt, gval, gidx, oval, oidx, cand, val, total; };
+static StreamLayout stream_layout(int B, int N) {
+  StreamLayout L; size_t o = 0;
+  int rpb; const int nb = stream_blocks(N, &rpb);
+  auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
+  L.counters = take((256 + TS_MAX_BLOCKS) * 4 + 8192);            // (+ tools-only time stamps, EVAE_TS_ABL & 64)
+  L.cmaxb = take((size_t)TS_MAX_BLOCKS * 4); L.gcnt = take((size_t)B * nb * 4);
+  L.gval = take((size_t)B * nb * TS_SLOTS * 4); L.gidx = take((size_t)B * nb * TS_SLOTS * 4);
+  L.oval = take((size_t)B * N * 4); L.oidx = take((size_t)B * N * 4);
+  L.cand = take((size_t)B * N * 4); L.val = L.oval;              // the exact stage's values re-use the drained overflow values
+  L.total = o + 256;
+  return L;
+}
+template <int KS, int CKS>
+static int launch_stream(const TopkStreamArgs& a, int nblocks, hipStream_t stream) {
+  const size_t lds = ts_lds_bytes<CKS>();
+  auto go = [&](auto kern) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    kern<<<nblocks, TS_NT, lds, stream>>>(a);
+  };
+  if (a.k <= 10) go(topk_stream_kernel<KS, CKS, 5>);
+  else if (a.k <= 20) go(topk_stream_kernel<KS, CKS, 10>);
+  else go(topk_stream_kernel<KS, CKS, 16>);
+  return check_launch("topk_stream_kernel");
+}
+
 struct ScreenLayout {
   size_t cn, qn, cnmax, tmin, thr, cnt, cand, val, dist, tile_max, total;
   int ntiles, ldt, ldm, ldq;  // ldt: row stride of the distances (queries, padded); ldm: of the query-major tile minima;
@@ -345,13 +733,37 @@ static ScreenLayout screen_layout(int B, int N) {
 
 size_t topk_screen_workspace_bytes(int B, int N, int zdim, int k) {
   if (!screen_applies(B, N, zdim, k)) return 0;
-  return screen_layout(B, N).total;
+  const size_t two = screen_layout(B, N).total;
+  const bool shape = B <= TS_NQ && zdim <= 256 && k <= 32 && N >= 2048;      // (whatever EVAE_TOPK_STREAM says now: a later call may differ)
+  return shape ? std::max(two, stream_layout(B, N).total) : two;
 }
 
 int topk_screen(const float* q, int B, const float* cache, int N, int zdim, int k, unsigned flags, int64_t index_base,
                 int64_t* out_idx, float* out_val, void* ws, size_t ws_bytes, hipStream_t stream, int* handled) {
   *handled = 0;
   if (!screen_applies(B, N, zdim, k) || (((uintptr_t)q | (uintptr_t)cache) & 15) != 0) return EVAE_OK;
+  if (stream_applies(B, N, zdim, k) && ws != nullptr && ws_bytes >= stream_layout(B, N).total) {
+    // ONE launch (+ a 1 KB memset node for its counters)
+    const StreamLayout S = stream_layout(B, N);
+    char* w_ = (char*)ws;
+    TopkStreamArgs a = {};
+    a.q = q; a.cache = cache; a.B = B; a.N = N; a.zdim = zdim; a.k = k; a.flags = flags; a.index_base = index_base;
+    const int nb = stream_blocks(N, &a.rows_per_block);
+    { static int abl = -1; if (abl < 0) { const char* e = getenv("EVAE_TS_ABL"); abl = e ? atoi(e) : 0; } a.abl = abl; }
+    const float u_ = 5.9604645e-08f;
+    a.gamma = 2.0f * ((4.0f * zdim + 3.0f) * u_ + 3.0517578e-05f);      // the two-term bound derived below
+    a.counters = (unsigned*)(w_ + S.counters); a.cmaxb = (float*)(w_ + S.cmaxb); a.gcnt = (int*)(w_ + S.gcnt);
+    a.gval = (float*)(w_ + S.gval); a.gidx = (int*)(w_ + S.gidx);
+    a.oval = (float*)(w_ + S.oval); a.oidx = (int*)(w_ + S.oidx); a.cap = (size_t)N;
+    a.cand = (int*)(w_ + S.cand); a.val = (float*)(w_ + S.val); a.ldc = (size_t)N;
+    a.out_idx = out_idx; a.out_val = out_val;
+    if (nb > TS_MAX_BLOCKS) { set_error("topk_stream: %d blocks", nb); return EVAE_EINVAL; }
+    if (hipMemsetAsync(a.counters, 0, (256 + TS_MAX_BLOCKS) * 4, stream) != hipSuccess) return check_launch("topk_stream(counters)");
+    *handled = 1;
+    if (zdim <= 64) return launch_stream<4, 2>(a, nb, stream);
+    if (zdim <= 128) return launch_stream<8, 2>(a, nb, stream);
+    return launch_stream<16, 4>(a, nb, stream);
+  }
   const ScreenLayout L = screen_layout(B, N);
   if (ws == nullptr || ws_bytes < L.total) return EVAE_OK;
   *handled = 1;

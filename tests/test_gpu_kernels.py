@@ -339,6 +339,33 @@ def test_topk_screening_path_equals_exact_scan(ops, B, N, zd, k, sqrt, offset):
     assert np.array_equal(val.cpu().numpy(), rv)
 
 
+@pytest.mark.parametrize("B,N,zd,k,sqrt,offset", [(100, 100000, 256, 10, False, 0.0), (100, 25000, 40, 10, False, 0.0),
+                                                 (64, 100000, 256, 10, False, 3.0), (128, 60000, 64, 20, True, 0.0),
+                                                 (37, 5000, 24, 32, True, 0.0), (3, 2048, 8, 16, False, -8.0),
+                                                 (77, 50001 // 4 * 4, 48, 5, False, 0.0)])
+def test_topk_stream_kernel_equals_the_two_launch_form(ops, golden, monkeypatch, B, N, zd, k, sqrt, offset):
+    """EVAE_TOPK_STREAM=1 (r06, opt-in): the cache scan + top-K as ONE launch (csrc/evae_topk_screen.hip::topk_stream_kernel: per-block
+    candidate lists from lane-local bounds, flags instead of a second launch, the same exact re-ranking) returns the very indices and
+    values of the default two-launch form -- duplicated exemplars (ties by index), zero-distance hits at the end of the cache, a
+    common offset (norms far above the distances) included; and G4's reference indices at c2 / c5 sizes."""
+    z, c = gi.clustered_latents(500 + B + N, B, N, zd)
+    z = (z + np.float32(offset)).astype(np.float32); c = (c + np.float32(offset)).astype(np.float32)
+    c[N // 2:N // 2 + 50] = c[:50]
+    c[-7:] = z[:7] if B >= 7 else c[-7:]
+    monkeypatch.delenv("EVAE_TOPK_STREAM", raising=False)
+    ri, rv = ops.pairdist_topk(dev(z), dev(c), k, sqrt=sqrt)
+    monkeypatch.setenv("EVAE_TOPK_STREAM", "1")
+    idx, val = ops.pairdist_topk(dev(z), dev(c), k, sqrt=sqrt)
+    assert torch.equal(idx, ri) and torch.equal(val, rv)
+    if (B, N, zd, k, offset) == (100, 25000, 40, 10, 0.0):
+        g = golden("g4_topk")
+        for tag, (b_, n_, z_) in (("c2", (100, 25000, 40)), ("c5", (64, 100000, 256))):
+            zz, cc = gi.clustered_latents(31 if tag == "c2" else 32, b_, n_, z_)
+            got, gval = ops.pairdist_topk(dev(zz), dev(cc), 10)
+            assert np.array_equal(got.cpu().numpy(), g[tag + "_idx"].astype(np.int64)), tag
+            assert np.array_equal(gval.cpu().numpy(), g[tag + "_val"]), tag
+
+
 def test_pairwise_distance_golden(ops, golden):
     g = golden("g1_g2_distance")
     for zdim in (40, 256):
