@@ -343,10 +343,10 @@ struct TopkStreamArgs {
   int* cand; float* val; size_t ldc;  // the exact stage's lists
   int64_t* out_idx; float* out_val;
 };
-template <int CKS> constexpr int ts_row_bytes() { return CKS * 32 + 16; }                 // a staged row of one term: CKS x 16 bf16 + pad
-template <int CKS> constexpr int ts_stage_bytes() { return 2 * 128 * ts_row_bytes<CKS>(); }
-template <int CKS> constexpr size_t ts_lds_bytes() {
-  return 2 * (size_t)ts_stage_bytes<CKS>() + 2 * 128 * 4 + 16 + 2 * TS_NQ * 4 + 2 * (size_t)TS_NQ * TS_SLOTS * 4;
+template <int KS> constexpr int ts_row_bytes() { return KS * 32 + 16; }                  // a staged row of one term: KS x 16 bf16 + pad
+template <int KS> constexpr int ts_stage_bytes() { return 2 * 32 * ts_row_bytes<KS>(); }    // a chunk: 32 rows, both terms
+template <int KS> constexpr size_t ts_lds_bytes() {
+  return 2 * (size_t)ts_stage_bytes<KS>() + 2 * 128 * 4 + 16 + 2 * TS_NQ * 4 + 2 * ((size_t)TS_NQ * TS_SLOTS + TS_NT) * 4;
 }
 // (x, y) -> the two bf16 terms of each, term t of x in the low half of p[t]
 __device__ __forceinline__ void ts_split2(float x, float y, unsigned& p0, unsigned& p1) {
@@ -370,18 +370,24 @@ __device__ __attribute__((noinline)) void ts_emit(float d, int row, int nq, int*
   }
 }
 
+// v of the lane DPP control CTRL names (0x120 + n: rotate right by n inside the lane's row of 16)
+template <int CTRL>
+__device__ __forceinline__ float ts_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void ts_static_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); ts_static_for<I + 1, N>(f); }
 }
 
-template <int KS, int CKS, int MG>
+template <int KS, int MG>
 __global__ __launch_bounds__(TS_NT) void topk_stream_kernel(const TopkStreamArgs a) {
-  static_assert(KS % CKS == 0 && (KS / CKS) % 2 == 0, "chunks per tile must be even (register sets alternate)");
-  constexpr int NCH = KS / CKS;                    // chunks of a tile
-  constexpr int RS = ts_row_bytes<CKS>(), TERM = 128 * RS, STAGE = 2 * TERM;
-  constexpr int LPR = 4 * CKS;                     // lanes (float4s) per row of a chunk
-  constexpr int RSTEP = TS_NT / LPR, NJ = 128 / RSTEP;       // a thread stages rows r0 + RSTEP j
+  constexpr int NCH = 4;                           // chunks of a tile: 32 rows x the whole (padded) row each -> one MFMA row tile
+  constexpr int RS = ts_row_bytes<KS>(), TERM = 32 * RS, STAGE = 2 * TERM;
+  constexpr int F4R = 4 * KS;                      // float4s of a padded row
+  constexpr int NJ = 32 * F4R / TS_NT;             // float4s a thread stages per chunk: f = 256 j + tid -> row f / F4R, float4 f % F4R
+  static_assert(NJ >= 1 && 64 % F4R == 0, "a row's float4s sit in one wave's load");
   typedef float f32x16 __attribute__((ext_vector_type(16)));
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* const stA = lds;
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(TS_NT) void topk_stream_kernel(const TopkStreamArgs
   int* const lcnt = reinterpret_cast<int*>(cmax_l + 4);                   // [128]
   int* const lbase = lcnt + TS_NQ;
   float* const lv = reinterpret_cast<float*>(lbase + TS_NQ);              // [128][SLOTS]
-  int* const li = reinterpret_cast<int*>(lv + TS_NQ * TS_SLOTS);
+  int* const li = reinterpret_cast<int*>(lv + TS_NQ * TS_SLOTS + TS_NT);   // (+ a dummy slot per thread behind either list)
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, half = l >> 5;
   const int nq = 32 * w + (l & 31);
   const bool q_live = nq < a.B;
@@ -424,28 +430,39 @@ __global__ __launch_bounds__(TS_NT) void topk_stream_kernel(const TopkStreamArgs
   }
   qn += __shfl_xor(qn, 32, 64);
   mark();
-  // ---- staging: thread -> float4 kq of rows r0 + RSTEP j of a chunk
-  const int kq = tid % LPR, r0 = tid / LPR;
+  // ---- staging.  A chunk = 32 consecutive cache rows in full: 32 KB of contiguous memory at z = 256, read by 64-lane loads of
+  // one whole row each (the k-chunked first form of this kernel visited every DRAM page four times, 256 bytes a visit: 2.3 us per
+  // 32 KB chunk).  Register set S holds a chunk on its way to LDS stage S.  Pipeline (one barrier per chunk): while the MFMAs of chunk
+  // c run from stage c & 1, the same wave splits chunk c + 1 (loaded two iterations ago) into the other stage -- a float4 every
+  // other k-step, behind that k-step's MFMAs, so that vector and matrix pipes overlap within ONE wave per SIMD -- and refills its
+  // registers with chunk c + 3.  rows_per_block is a multiple of 128: every tile of a block is whole, except the cache's very last
+  // one -- its rows beyond N are read from row N - 1 and masked in the epilogue; columns beyond zdim are zeroed by a select.
   float4 R[2][NJ];
-  float ns[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) ns[j] = 0.f;
-  // (rows_per_block is a multiple of 128: every tile of a block is whole, except the cache's very last one -- its rows beyond N
-  //  are read from row N - 1 and masked in the epilogue; columns beyond zdim, when zdim is no multiple of the chunk, are zeroed by
-  //  a select: no branch per load, one uniform branch per chunk for the prefetch that would run past the block's end)
-  auto load = [&](auto SET, int tile, int ck) {
-    constexpr int S = decltype(SET)::value;
-    if (tile >= ntile) return;
-    const int kk = ck * (CKS * 16) + 4 * kq;
-    const bool k_live = kk < zdim;
-    const int kc = min(kk, zdim - 4);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int row = min(rb + tile * 128 + r0 + RSTEP * j, a.N - 1);
-      float4 v = *reinterpret_cast<const float4*>(a.cache + (size_t)row * zdim + kc);
-      if (!k_live) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      R[S][j] = v;
-    }
+  auto load1 = [&](auto SET, auto J, int tile, int ck) {
+    constexpr int S = decltype(SET)::value, j = decltype(J)::value;
+    const int f = TS_NT * j + tid, kk = 4 * (f % F4R);
+    const int row = min(rb + tile * 128 + 32 * ck + f / F4R, a.N - 1);
+    float4 v = *reinterpret_cast<const float4*>(a.cache + (size_t)row * zdim + min(kk, zdim - 4));
+    if (kk >= zdim) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    R[S][j] = v;
+  };
+  // ... its two bf16 terms into the stage, its row's squared norm (the F4R lanes of a row reduce among themselves) into the
+  // tile's norm table and the running maximum
+  auto stage1 = [&](auto SET, auto J, char* st, int tile, int ck) {
+    constexpr int S = decltype(SET)::value, j = decltype(J)::value;
+    const int f = TS_NT * j + tid, rr = f / F4R, kq = f % F4R;
+    const float4 v = R[S][j];
+    float t = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    unsigned p0a, p1a, p0b, p1b;
+    ts_split2(v.x, v.y, p0a, p1a); ts_split2(v.z, v.w, p0b, p1b);
+    char* dst = st + rr * RS + kq * 8;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(p0a, p0b);
+    *reinterpret_cast<uint2*>(dst + TERM) = make_uint2(p1a, p1b);
+    // (rotations inside the 16-lane DPP rows: vector instructions, no trip through the LDS crossbar; then across rows)
+    t += ts_dpp<0x128>(t); t += ts_dpp<0x124>(t); t += ts_dpp<0x122>(t); t += ts_dpp<0x121>(t);
+    if constexpr (F4R >= 32) t += __shfl_xor(t, 16, 64);
+    if constexpr (F4R >= 64) t += __shfl_xor(t, 32, 64);
+    if (kq == 0) { cn_l[(tile & 1) * 128 + 32 * ck + rr] = t; atomicMax(cmax_l, __float_as_uint(t)); }
   };
   f32x16 acc[4];
 #pragma unroll
@@ -455,68 +472,57 @@ __global__ __launch_bounds__(TS_NT) void topk_stream_kernel(const TopkStreamArgs
   float gmin[16];
 #pragma unroll
   for (int g = 0; g < 16; ++g) gmin[g] = INFINITY;
-  load(std::integral_constant<int, 0>{}, 0, 0);
-  load(std::integral_constant<int, 1>{}, 0, 1);
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  if (ntile > 0) {
+    ts_static_for<0, NJ>([&](auto J) { load1(I0{}, J, 0, 0); });
+    ts_static_for<0, NJ>([&](auto J) { load1(I1{}, J, 0, 1); });
+    ts_static_for<0, NJ>([&](auto J) { stage1(I0{}, J, stA, 0, 0); load1(I0{}, J, 0, 2); });
+  }
   __syncthreads();
   for (int tile = 0; tile < ntile; ++tile) {
-    constexpr int nmt = 4;
     ts_static_for<0, NCH>([&](auto CK_) {
       constexpr int ck = decltype(CK_)::value;
-      char* const st = stA + ((ck & 1) ? STAGE : 0);
-      // chunk (tile, ck) sits in register set ck & 1: split it into the stage, then refill the set with the chunk two ahead
-      auto stage_set = [&](auto SET) {
-        constexpr int S = decltype(SET)::value;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const float4 v = R[S][j];
-          ns[j] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-          unsigned p0a, p1a, p0b, p1b;
-          ts_split2(v.x, v.y, p0a, p1a); ts_split2(v.z, v.w, p0b, p1b);
-          char* dst = st + (r0 + RSTEP * j) * RS + kq * 8;
-          *reinterpret_cast<uint2*>(dst) = make_uint2(p0a, p0b);
-          *reinterpret_cast<uint2*>(dst + TERM) = make_uint2(p1a, p1b);
-        }
-        const int nt = (ck + 2 < NCH) ? tile : tile + 1, nc = (ck + 2 < NCH) ? ck + 2 : ck + 2 - NCH;
-        load(SET, nt, nc);
+      constexpr int SN = (ck + 1) & 1;                             // register set / stage of the NEXT chunk
+      const char* const st = stA + ((ck & 1) ? STAGE : 0);
+      char* const stn = stA + (SN ? STAGE : 0);
+      // next chunk = (tile, ck + 1) or (tile + 1, 0); the chunk that refills its registers is three ahead of this one
+      const int n_tile = (ck + 1 < NCH) ? tile : tile + 1, n_ck = (ck + 1) % NCH;
+      const int f_tile = (ck + 3 < NCH) ? tile : tile + 1, f_ck = (ck + 3) % NCH;
+      const bool n_live = n_tile < ntile, f_live = f_tile < ntile;
+      x6_bf16x8 a0[2], a1[2];
+      auto frags = [&](int buf, int s) {
+        const char* src = st + (l & 31) * RS + s * 32 + 16 * half;
+        a0[buf] = *reinterpret_cast<const x6_bf16x8*>(src);
+        a1[buf] = *reinterpret_cast<const x6_bf16x8*>(src + TERM);
       };
-      if constexpr ((ck & 1) == 0) stage_set(std::integral_constant<int, 0>{}); else stage_set(std::integral_constant<int, 1>{});
-      if constexpr (ck == NCH - 1) {
-        // the tile's rows are complete: their squared norms (summed over the LPR lanes of a row) for the epilogue, their maximum
-        float* cnp = cn_l + (tile & 1) * 128;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          float t = ns[j];
-#pragma unroll
-          for (int o = 1; o < LPR; o <<= 1) t += __shfl_xor(t, o, 64);
-          if (kq == 0) { cnp[r0 + RSTEP * j] = t; atomicMax(cmax_l, __float_as_uint(t)); }
-          ns[j] = 0.f;
+      frags(0, 0);
+      ts_static_for<0, KS>([&](auto S_) {
+        constexpr int s = decltype(S_)::value;
+        if constexpr (s + 1 < KS) frags((s + 1) & 1, s + 1);
+        if (!(a.abl & 4)) {
+          acc[ck] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s & 1], bq[s][0], acc[ck], 0, 0, 0);
+          acc[ck] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[s & 1], bq[s][1], acc[ck], 0, 0, 0);
+          acc[ck] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[s & 1], bq[s][0], acc[ck], 0, 0, 0);
         }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int s2 = 0; s2 < CKS; ++s2) {
-        const int s = ck * CKS + s2;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          if (!(a.abl & 4)) {
-            const char* src = st + (32 * mt + (l & 31)) * RS + s2 * 32 + 16 * half;
-            const x6_bf16x8 a0 = *reinterpret_cast<const x6_bf16x8*>(src);
-            const x6_bf16x8 a1 = *reinterpret_cast<const x6_bf16x8*>(src + TERM);
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[s][0], acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[s][1], acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[s][0], acc[mt], 0, 0, 0);
+        // a float4 of the next chunk into the other stage every KS / NJ k-steps, behind this k-step's MFMAs; its register refilled
+        if constexpr (s % (KS / NJ) == 0) {
+          if (n_live) {
+            constexpr int j = s / (KS / NJ);
+            stage1(std::integral_constant<int, SN>{}, std::integral_constant<int, j>{}, stn, n_tile, n_ck);
+            if (f_live) load1(std::integral_constant<int, SN>{}, std::integral_constant<int, j>{}, f_tile, f_ck);
           }
         }
-      }
-    });
-    mark();
-    // ---- the tile's epilogue: d = |c|^2 - 2 q.c (no |q|^2: a constant per query), group minima, threshold, candidates
-    {
-      const float* cnp = cn_l + (tile & 1) * 128;
-      const float cmax_seen = __uint_as_float(*cmax_l);
+      });
+      if constexpr (ck == NCH - 1) {
+        // ---- the tile's epilogue: d = |c|^2 - 2 q.c (no |q|^2: a constant per query), group minima, threshold, candidates.
+        // (its norms went to LDS one barrier ago)
+        mark();
+        const float* cnp = cn_l + (tile & 1) * 128;
+        const float cmax_seen = __uint_as_float(*cmax_l);
+        const int rows_left = row_end - rb - tile * 128;            // rows of this tile inside the cache (>= 128 except at its end)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        if (mt < nmt) {
+        for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const int rl = 32 * mt + 8 * g4 + 4 * half;
@@ -525,56 +531,72 @@ __global__ __launch_bounds__(TS_NT) void topk_stream_kernel(const TopkStreamArgs
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               float d = fmaf(-2.0f, acc[mt][4 * g4 + i], cc[i]);
-              if (tile * 128 + rl + i >= row_end - rb) d = INFINITY;
+              if (rl + i >= rows_left) d = __builtin_nanf("");     // a row beyond the cache: below no threshold, ignored by fminf
               acc[mt][4 * g4 + i] = d;
               gmin[4 * g4 + i] = fminf(gmin[4 * g4 + i], d);
             }
           }
         }
-      }
-      // the MG-th smallest of the lane's 16 group minima (MG distinct rows at or below it): a min / max insertion chain
-      float sm[MG];
+        // the MG-th smallest of the lane's 16 group minima (MG distinct rows at or below it): a min / max insertion chain
+        float sm[MG];
 #pragma unroll
-      for (int j = 0; j < MG; ++j) sm[j] = INFINITY;
+        for (int j = 0; j < MG; ++j) sm[j] = INFINITY;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        float v = gmin[g];
+        for (int g = 0; g < 16; ++g) {
+          float v = gmin[g];
 #pragma unroll
-        for (int j = 0; j < MG; ++j) { const float lo = fminf(sm[j], v); v = fmaxf(sm[j], v); sm[j] = lo; }
-      }
-      float tb = sm[MG - 1];
-      tb = fmaxf(tb, __shfl_xor(tb, 32, 64));
-      const float thr = tb + 2.0f * a.gamma * (qn + cmax_seen);
+          for (int j = 0; j < MG; ++j) { const float lo = fminf(sm[j], v); v = fmaxf(sm[j], v); sm[j] = lo; }
+        }
+        float tb = sm[MG - 1];
+        tb = fmaxf(tb, __shfl_xor(tb, 32, 64));
+        const float thr = (q_live && !(a.abl & 2)) ? tb + 2.0f * a.gamma * (qn + cmax_seen) : -INFINITY;
+        // candidates: count them, reserve the lane's slots with ONE LDS atomic, then write every value -- those that do not pass
+        // (or do not fit) to a dummy slot: no branch and no atomic round trip per register
+        int cpass = 0;
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        if (mt < nmt) {
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) cpass += (acc[mt][i] <= thr) ? 1 : 0;
+        int base = 0;
+        if (cpass > 0) base = atomicAdd(&lcnt[nq], cpass);
+        const bool fits = base + cpass <= TS_SLOTS;                 // (almost always: the block's list of this query has room)
+        int off = base;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const float d = acc[mt][i];
-            if (q_live && d <= thr && d < INFINITY && !(a.abl & 2))
-              ts_emit(d, rb + tile * 128 + 32 * mt + 8 * (i >> 2) + 4 * half + (i & 3), nq, lcnt, lv, li, a.counters, a.oval, a.oidx, a.cap);
+            const bool pass = d <= thr;
+            const int row = rb + tile * 128 + 32 * mt + 8 * (i >> 2) + 4 * half + (i & 3);
+            const int at = (pass && off < TS_SLOTS) ? nq * TS_SLOTS + off : TS_NQ * TS_SLOTS + tid;
+            lv[at] = d; li[at] = row;
+            if (!fits && pass && off >= TS_SLOTS) {                 // rare: the query's global overflow list
+              const unsigned gs = atomicAdd(&a.counters[nq], 1u);
+              a.oval[(size_t)nq * a.cap + gs] = d; a.oidx[(size_t)nq * a.cap + gs] = row;
+            }
+            off += pass ? 1 : 0;
             acc[mt][i] = 0.f;
           }
         }
       }
-    }
+      __syncthreads();
+    });
   }
   mark();
-  // ---- flush this block's lists into ITS regions of the queries' candidate stores (no atomics), then raise its flag
-  __syncthreads();
+  // ---- flush this block's lists into ITS regions of the queries' candidate stores (no atomics), then raise its flag: a wave
+  // takes every fourth query, its lanes the slots
   const int nblk = gridDim.x;
-  for (int e = tid; e < TS_NQ * TS_SLOTS; e += TS_NT) {
-    const int qq = e / TS_SLOTS, i = e - qq * TS_SLOTS;
-    if (qq < a.B && i < min(lcnt[qq], TS_SLOTS)) {
-      const size_t o = ((size_t)qq * nblk + blockIdx.x) * TS_SLOTS + i;
-      a.gval[o] = lv[e]; a.gidx[o] = li[e];
-    }
+  for (int qq = w; qq < a.B; qq += TS_NT / 64) {
+    const int c = min(lcnt[qq], TS_SLOTS);
+    const size_t o = ((size_t)qq * nblk + blockIdx.x) * TS_SLOTS;
+    if (l < c) { a.gval[o + l] = lv[qq * TS_SLOTS + l]; a.gidx[o + l] = li[qq * TS_SLOTS + l]; }
+    if (l == 0) a.gcnt[(size_t)qq * nblk + blockIdx.x] = c;
   }
-  if (tid < a.B) a.gcnt[(size_t)tid * nblk + blockIdx.x] = min(lcnt[tid], TS_SLOTS);
   if (tid == 0) a.cmaxb[blockIdx.x] = __uint_as_float(*cmax_l);
+  mark();
   __threadfence();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(&a.counters[256 + blockIdx.x], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(&a.counters[256 + blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   mark();
   if ((int)blockIdx.x >= a.B || (a.abl & 1)) return;
   // ---- one query per block from here (blocks beyond B have left): wait until every block has raised its flag
@@ -657,10 +679,17 @@ __global__ __launch_bounds__(TS_NT) void topk_stream_kernel(const TopkStreamArgs
   }
 }
 
-// OPT-IN (EVAE_TOPK_STREAM=1, read per call so that a test can switch it): measured r06 at c5 size 140 us against the two-launch
-// form's 67 -- correct (bit-exact indices, tests/test_gpu_kernels.py::test_topk_stream_*), not yet fast: per tile the main loop
-// takes 14 us (stage -> barrier -> fragment reads -> MFMAs run back to back in ONE wave per SIMD; the two-launch GEMM has two), the
-// epilogue 14 us (an LDS atomic round trip per candidate), the flush 20 us, the finish 34 us
+// OPT-IN (EVAE_TOPK_STREAM=1, read per call so that a test can switch it).  Measured r06 (rocprofv3, tools/ts_prof.sh; phase stamps
+// tools/ts_stamps.py): c5 size 146 us against the two-launch form's 67, c2 size 62 against 30 -- correct (bit-exact indices and
+// values, tests/test_gpu_kernels.py::test_topk_stream_kernel_equals_the_two_launch_form), not yet fast.  Where the time goes at c5
+// (block 0, us): queries 4, four tiles 19 each (15 without any MFMA: the staging of a 32 KB chunk -- loads, two-term split, LDS
+// writes, row norms -- takes 4 us of ONE wave per SIMD, the compiler's code for it is a chain of waits and uniform branches), the
+// last epilogue 5, flush 4, fence + flag 11, waiting for the slowest block 14, lists to LDS 6, bounds 15, final sweep 4, exact
+// ranks 10.  Steps tried on the way: global atomics per (block, query) reservation 435 us -> fixed regions 159; candidates by
+// an LDS atomic each 14 us per tile -> counted + one atomic per lane 5; k-chunked staging (four visits per DRAM page) vs whole rows:
+// equal.  What it needs next: the staging of chunk c + 1 issued as straight-line code between the MFMAs of chunk c (hand-scheduled:
+// sched_group_barrier), two waves per SIMD (queries' fragments in LDS instead of 128 registers), and a finish that starts per query
+// as soon as ITS candidates are in -- DESIGN section 7.
 static bool stream_applies(int B, int N, int zdim, int k) {
   const char* e = getenv("EVAE_TOPK_STREAM");
   const bool on = e && atoi(e) != 0;
@@ -686,17 +715,17 @@ static StreamLayout stream_layout(int B, int N) {
   L.total = o + 256;
   return L;
 }
-template <int KS, int CKS>
+template <int KS>
 static int launch_stream(const TopkStreamArgs& a, int nblocks, hipStream_t stream) {
-  const size_t lds = ts_lds_bytes<CKS>();
+  const size_t lds = ts_lds_bytes<KS>();
   auto go = [&](auto kern) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     kern<<<nblocks, TS_NT, lds, stream>>>(a);
   };
-  if (a.k <= 10) go(topk_stream_kernel<KS, CKS, 5>);
-  else if (a.k <= 20) go(topk_stream_kernel<KS, CKS, 10>);
-  else go(topk_stream_kernel<KS, CKS, 16>);
+  if (a.k <= 10) go(topk_stream_kernel<KS, 5>);
+  else if (a.k <= 20) go(topk_stream_kernel<KS, 10>);
+  else go(topk_stream_kernel<KS, 16>);
   return check_launch("topk_stream_kernel");
 }
 
@@ -760,9 +789,9 @@ int topk_screen(const float* q, int B, const float* cache, int N, int zdim, int 
     if (nb > TS_MAX_BLOCKS) { set_error("topk_stream: %d blocks", nb); return EVAE_EINVAL; }
     if (hipMemsetAsync(a.counters, 0, (256 + TS_MAX_BLOCKS) * 4, stream) != hipSuccess) return check_launch("topk_stream(counters)");
     *handled = 1;
-    if (zdim <= 64) return launch_stream<4, 2>(a, nb, stream);
-    if (zdim <= 128) return launch_stream<8, 2>(a, nb, stream);
-    return launch_stream<16, 4>(a, nb, stream);
+    if (zdim <= 64) return launch_stream<4>(a, nb, stream);
+    if (zdim <= 128) return launch_stream<8>(a, nb, stream);
+    return launch_stream<16>(a, nb, stream);
   }
   const ScreenLayout L = screen_layout(B, N);
   if (ws == nullptr || ws_bytes < L.total) return EVAE_OK;
