@@ -63,6 +63,8 @@ def parse():
                          "the batch).  The replica line carries the dp measurement as a nested object (--no-dp-line skips it).")
     ap.add_argument("--no-dp-line", action="store_true", help="with --gpus N > 1: do not run the second (dp) measurement")
     ap.add_argument("--no-amdahl", action="store_true", help="skip the amdahl_ceiling object (a second process at 200 exemplars)")
+    ap.add_argument("--no-graph-profile", action="store_true",
+                    help="headline line only: do not run the child process under rocprofv3 that times the kernels INSIDE the replayed graph")
     ap.add_argument("--no-ramp", action="store_true",
                     help="skip the untimed clock-ramp replays in front of the timed region (10-step windows until two agree to 2 %%)")
     ap.add_argument("--probe-warmup", type=int, default=20,
@@ -148,6 +150,103 @@ def cpu_baseline(steps, C=C, N_TRAIN=N_TRAIN):
             "kind": "port",
             "sample": "%d steps of the numpy oracle's vae train step (B=%d, C=%d, N=%d) on %d BLAS threads of a %d-CPU host%s"
                       % (steps, B, C, N_TRAIN, threads, os.cpu_count(), note)}
+
+
+def graph_kernel_stats(steps=60):
+    """Durations of the kernels INSIDE the replayed hipGraph: HIP event pairs cannot be read back from a replay, so a child process
+    runs the same headline step under `rocprofv3 --kernel-trace --stats` (the command whose summary is committed under profiles/) and
+    its per-kernel averages come back: {kernel name: (calls, average us)}, or (None, why not)."""
+    import csv, glob, shutil, subprocess, tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROFILER_", "ROCP_", "ROCPROF_")) for k in os.environ):
+        return None, "this process is itself running under a profiler"
+    d = tempfile.mkdtemp(prefix="evae_graphprof_", dir="/tmp")
+    cmd = [rp, "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "g", "--", sys.executable, os.path.abspath(__file__),
+           "--config", "c2", "--steps", str(steps), "--warmup", "10", "--no-amdahl", "--cpu-baseline-steps", "0", "--iwae-images", "0",
+           "--probe-steps", "0", "--probe-warmup", "0", "--no-graph-profile"]
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=300, capture_output=True, text=True)
+        files = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, "rocprofv3 child failed (rc %d)" % r.returncode
+        line_ = next((l for l in r.stdout.splitlines() if l.startswith("{")), None)
+        ms = json.loads(line_)["ms_per_step"] if line_ else None
+        out = {}
+        for row in csv.DictReader(open(files[0])):
+            out[row["Name"]] = (int(row["Calls"]), float(row["AverageNs"]) / 1e3)
+        return out, {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --config c2 --steps %d --warmup 10 (no probe, no baselines)" % steps,
+                     "ms_per_step_under_the_profiler": ms}
+    except Exception as e:
+        return None, "%s: %s" % (type(e).__name__, str(e)[:120])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _blas_limit(n):
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=n)
+    except Exception:
+        import contextlib
+        return contextlib.nullcontext()
+
+
+def cpu_baseline_topk(q, cache, k, seconds=8.0):
+    """The oracle's restatement of models/BaseModel.py:263-264 (fp64 expanded distance + ordered top-k) on the host, on as many of
+    the bench's queries as fit the time budget (at least 4)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import evae_oracle as orc
+    qn, cn = q.cpu().numpy(), cache.cpu().numpy()
+    threads = min(os.cpu_count(), 16)
+    with _blas_limit(threads):
+        orc.nearest_exemplars_topk(qn[:2], cn, k)
+        done, t_tot = 0, 0.0
+        while done < len(qn) and (t_tot < seconds or done < 4):
+            t0 = time.perf_counter()
+            orc.nearest_exemplars_topk(qn[done:done + 4], cn, k)
+            t_tot += time.perf_counter() - t0; done += 4
+    return {"value": round(done / t_tot, 2), "unit": "queries/sec", "cores": threads, "kind": "port",
+            "sample": "%d of the %d queries against all %d x %d cached latents through the numpy oracle (evae_oracle.nearest_exemplars_topk: "
+                      "float64 distances + ordered top-%d), %d BLAS threads of a %d-CPU host" % (done, len(qn), cn.shape[0], cn.shape[1], k, threads, os.cpu_count())}
+
+
+def cpu_baseline_iwae(n_images, S, n_train, seconds=20.0):
+    """utils/evaluation.py:72-103 restated with the oracle's functions on the host: per test image S importance samples through
+    encoder, decoder, log q and the exemplar prior over all n_train cached latents, log-mean-exp.  As many images as fit the budget."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import evae_oracle as orc
+    import golden_inputs as gi
+    p = orc.vae_init_params(np.random.RandomState(123))
+    data = gi.binary_images(0, n_train)
+    test = gi.binary_images(2, max(n_images, 1))
+    rs = np.random.RandomState(5)
+    threads = min(os.cpu_count(), 16)
+    with _blas_limit(threads):
+        centres, clv, _ = orc.vae_q_z(p, data, prior=True)
+        cidx = np.arange(n_train)
+        done, t_tot = 0, 0.0
+        while done < n_images and (t_tot < seconds or done < 1):
+            t0 = time.perf_counter()
+            acc = []
+            for s0 in range(0, S, 500):                 # the reference's own mini-batches of S (utils/evaluation.py:86-93)
+                x = np.repeat(test[done:done + 1], 500, axis=0)
+                eps = rs.standard_normal((500, Z)).astype(np.float32)
+                r = orc.vae_calculate_loss(p, x, None, eps, ("embedding", centres, clv, cidx), training=False)
+                acc.append(-r["loss"])
+            a_ = np.concatenate(acc).astype(np.float64)
+            _ = a_.max() + np.log(np.exp(a_ - a_.max()).mean())
+            t_tot += time.perf_counter() - t0; done += 1
+    return {"value": round(done / t_tot, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d test image(s), S = %d importance samples each against all %d cached latents, through the numpy oracle's vae functions "
+                      "(%d BLAS threads of a %d-CPU host; the real reference in the build container: 5.81 s per image on 8 cores, "
+                      "bench/ref_cpu_container.json)" % (done, S, n_train, threads, os.cpu_count())}
+
+
+NO_PORT = ("no CPU port of this model exists: the numpy oracle restates the `vae` path (SURVEY 8c); %s is held to goldens generated by "
+           "importing the real reference (tests/golden, tools/gen_goldens.py) and to float64 torch restatements inside the tests, neither "
+           "of which may be imported by bench.py.  The reference itself cannot travel to the GPU box")
 
 
 def pmc_traffic(name, expect=None):
@@ -355,7 +454,9 @@ def other_config(a, dev, rank, world, rccl_ranks=1, backend=None):
                     "test_graphed_modular_step_over_distinct_exemplar_rows_matches_eager); EVAE_DEDUP=0 encodes every draw.  The roofline "
                     "kernel below is timed at all %d images" % (dd_["cap"], n_ex)}
         print(json.dumps(line("training images/sec", round(B * a.steps / dt, 1), "images/sec", a, dt, wl, roof,
-                              extra={"exemplar_rows": ex_rows, "host_issue_ms_per_step": round(1e3 * t_issue / a.steps, 3)},
+                              extra={"exemplar_rows": ex_rows, "host_issue_ms_per_step": round(1e3 * t_issue / a.steps, 3),
+                                     "cpu_baseline": None,
+                                     "cpu_baseline_reason": NO_PORT % ("single_conv (fully_conv)" if c5 else "convhvae_2level")},
                               launch="eager" if runner is None or runner.graph is None else "hipGraph replay of the whole step")))
         return
     if a.config == "iwae":
@@ -411,6 +512,8 @@ def other_config(a, dev, rank, world, rccl_ranks=1, backend=None):
                                   "training exemplars (the test-log-p(x) half of BASELINE.json's metric), %d test images per pass"
                                   % (args.S, N_TRAIN, nimg), roof, world=world,
                                   extra={"neg_log_px": round(float(ll), 3), "rccl_ranks": rccl_ranks, "backend": backend,
+                                         "cpu_baseline": (cpu_baseline_iwae(4, args.S, N_TRAIN) if (world == 1 and a.cpu_baseline_steps > 0) else None),
+                                         "cpu_baseline_reason": None if (world == 1 and a.cpu_baseline_steps > 0) else "rank 0 at N = 1 only / --cpu-baseline-steps 0",
                                          "parallelism": "single GPU" if world == 1 else
                                          "latent cache row-sharded x%d (%d rows on rank 0), same test images on every rank, one "
                                          "all-gather of packed partial log-sum-exps per call" % (world, n_loc),
@@ -440,9 +543,11 @@ def other_config(a, dev, rank, world, rccl_ranks=1, backend=None):
                                    "GB/s": round(algo_bytes(r[1], r[2], r[3]) / r[4] / 1e3, 1),
                                    "frac": round(algo_bytes(r[1], r[2], r[3]) / r[4] / 1e3 / PEAK_HBM_GBS, 4)} for r in res}}
     a.steps = 1
+    cb = cpu_baseline_topk(q, cache, kk) if a.cpu_baseline_steps > 0 else None
     print(json.dumps(line("top-K cache scan", round(Bq / (us * 1e-6), 1), "queries/sec", a, us * 1e-6,
                           "evae_pairdist_topk: k=10 nearest cached latents per query, bit-exact indices (config 5 sizes; config 2 "
-                          "sizes in roofline.other_sizes)", roof)))
+                          "sizes in roofline.other_sizes)", roof,
+                          extra={"cpu_baseline": cb, "cpu_baseline_reason": None if cb else "--cpu-baseline-steps 0"})))
 
 
 def capture_probe():
@@ -738,7 +843,7 @@ def main():
               ("dense_bwd_data M=%d N=%d+" % (Cm, H), "dgrad2", "gemm_x6_kernel<9"),
               ("dense_bwd_data M=%d N=%d K=%d (gate-backward epilogue -> pre-split" % (Cm, Z, H), "hdgrad2_img", "gemm_x6_kernel<2, 0, 128, 3>"),
               ("dense_bwd_weight M=%d N=%d K=%d (+db; pre-split" % (Cm + B, 2 * H, H), "wgrad2_p6", "gemm_p6_kernel<3, 64, false>"),
-              ("dense_bwd_weight M=%d N=%d K=%d" % (Cm + B, Z, H), "hwgrad", "narrow_wgrad_kernel"),
+              ("dense_bwd_weight M=%d N=%d K=%d" % (Cm + B, Z, H), "hwgrad", "narrow_wgrad_mfma_kernel"),
               ("dense_bwd_weight M=", "wgrad2", "gemm_kernel<false, false, 3"),
               ("gated_dense_fwd M=%d K=%d N=%d (pre-split" % (Cm, H, H), "fwd2_p6", "gemm_p6_kernel<1, 128, true>"),
               ("gated_dense_fwd M=%d K=%d" % (Cm, H), "fwd2", "gemm_x6_kernel<1"))
@@ -764,14 +869,59 @@ def main():
                         "pipe_busy_frac": round(r["executed"] / us / 1e6 / peak, 4),
                         "bound": bound_label(traffic, us), "traffic": traffic, "traffic_source": traffic_src,
                         "flops_per_launch": round(r["flops"])})
-    kernels.sort(key=lambda k_: -k_["avg_launch_us"])
+    # ... and the same launches INSIDE the replayed graph: a child run under rocprofv3; the eager event pairs above
+    # time a launch alone-ish (the host paces eager steps), inside the replay it shares the machine with the side stream's launches
+    gstats, gsrc = (None, "not the headline configuration on one GPU") if not (headline and world == 1 and state["graphed"] is not None and rank == 0) \
+        else (None, "--no-graph-profile") if a.no_graph_profile else graph_kernel_stats()
+    sym_of = {pre: sym for pre, _, sym in pmc_of}
+    for k_ in kernels:
+        k_["in_graph_avg_launch_us"] = None
+        sym = next((sy for pre, sy in sym_of.items() if k_["launch"].startswith(pre)), None) if gstats else None
+        hit = [(n_, v_) for n_, v_ in (gstats or {}).items() if sym and sym in n_]
+        if len(hit) == 1 and "finish" in k_["launch"]:
+            # an entry that brackets several launches (pre-passes / split-K GEMM / finish): its GEMM kernel alone, inside the replay
+            k_["kernel_symbol"] = hit[0][0][:120]
+            k_["in_graph_gemm_kernel_us"] = round(hit[0][1][1], 2)
+        elif len(hit) == 1:
+            us_g = hit[0][1][1]
+            k_["kernel_symbol"] = hit[0][0][:120]
+            k_["in_graph_avg_launch_us"] = round(us_g, 2)
+            k_["in_graph_calls"] = hit[0][1][0]
+            per = k_.get("flops_per_launch") if k_["pipe"] != "hbm" else k_.get("bytes_per_launch")
+            if k_["pipe"] == "hbm":
+                k_["in_graph_frac"] = round(per / us_g / 1e6 / (PEAK_HBM_GBS / 1000.0), 4)
+            else:
+                k_["in_graph_algorithmic_tflops"] = round(per / us_g / 1e6, 2)
+                k_["in_graph_frac"] = round(per / us_g / 1e6 / PEAKS[k_["pipe"]], 4)
+    key_us = lambda k_: k_["in_graph_avg_launch_us"] if k_["in_graph_avg_launch_us"] is not None else k_["avg_launch_us"]
+    kernels.sort(key=lambda k_: -key_us(k_))
     roof = None
     if kernels:
         # entries that bracket several launches (a weight gradient = pre-passes / split-K GEMM + finish) are listed, the
-        # roofline object itself is the longest SINGLE kernel launch
+        # roofline object itself is the longest SINGLE kernel launch -- of the replayed graph when the child run delivered
         single = [k_ for k_ in kernels if "finish" not in k_["launch"] and k_["pipe"] != "hbm"]
         dom = (single or kernels)[0]
-        roof = {"bound": dom["bound"], "kernel": dom["launch"] + " -- the longest launch of a step (evae::gemm_kernel / u8_gemm_kernel family)",
+        in_graph = dom["in_graph_avg_launch_us"] is not None
+        if in_graph:                              # the roofline numbers of the replay, the eager ones kept beside them
+            dom = dict(dom, eager_avg_launch_us=dom["avg_launch_us"], eager_frac=dom["frac"], avg_launch_us=dom["in_graph_avg_launch_us"],
+                       algorithmic_tflops=dom["in_graph_algorithmic_tflops"], frac=dom["in_graph_frac"],
+                       executed_tflops=round(dom["executed_tflops"] * dom["avg_launch_us"] / dom["in_graph_avg_launch_us"], 2),
+                       pipe_busy_frac=round(dom["pipe_busy_frac"] * dom["avg_launch_us"] / dom["in_graph_avg_launch_us"], 4),
+                       launches=dom.get("in_graph_calls", dom["launches"]))
+        gem = [(k_, k_["in_graph_avg_launch_us"] if k_["in_graph_avg_launch_us"] is not None else k_.get("in_graph_gemm_kernel_us"))
+               for k_ in kernels if k_["pipe"] != "hbm"]
+        gem = [(k_, u_) for k_, u_ in gem if u_ is not None and k_["flops_per_launch"] >= 2e9]
+        agg_g = None
+        if gem:
+            tf_ = sum(k_["flops_per_launch"] for k_, _ in gem); tu_ = sum(u_ for _, u_ in gem)
+            agg_g = {"launches": len(gem), "kernels": [k_["launch"][:60] for k_, _ in gem], "flops": round(tf_), "us": round(tu_, 1), "algorithmic_tflops": round(tf_ / tu_ / 1e6, 1),
+                     "frac_of_bf16_mfma_peak": round(tf_ / tu_ / 1e6 / PEAK_BF16_MFMA_TFLOPS, 4),
+                     "frac_of_fp32_mfma_peak": round(tf_ / tu_ / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
+                     "note": "time-weighted over the step's large GEMM launches as they run inside the replayed graph"}
+        roof = {"bound": dom["bound"], "kernel": dom["launch"] + (" -- the longest launch of the REPLAYED step (rocprofv3 kernel trace of a child run of this command)"
+                                                                  if in_graph else " -- the longest launch of the step issued eagerly under HIP events"),
+                "timing_source": (gsrc if in_graph else {"eager_event_pairs": True, "in_graph": gsrc}),
+                "gemm_aggregate": agg_g,
                 "achieved": dom["algorithmic_tflops"], "peak": PEAKS[dom["pipe"]], "unit": "TFLOP/s", "frac": dom["frac"],
                 "pipe": dom["pipe"], "pipe_busy_frac": dom["pipe_busy_frac"], "executed_tflops": dom["executed_tflops"],
                 "frac_of_fp32_mfma_peak": round(dom["algorithmic_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -920,6 +1070,11 @@ def main():
         }
         if world == 1 and a.cpu_baseline_steps > 0 and model_name == "vae" and not approx:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_steps, n_ex, n_train)
+        else:
+            out["cpu_baseline_reason"] = ("rank 0 at N = 1 only" if world > 1 else "--cpu-baseline-steps 0" if a.cpu_baseline_steps <= 0 else
+                                          (NO_PORT % "hvae_2level") if model_name != "vae" else
+                                          "the oracle's training step restates the exact prior; the approximate (cache + top-k) step is held to "
+                                          "golden G10 of the real reference")
         if world == 1 and a.config == "c2" and a.exemplars is None and not a.no_amdahl:
             out["amdahl_ceiling"] = amdahl_ceiling(1e3 * dt / a.steps, n_ex)
         print(json.dumps(out))

@@ -24,7 +24,7 @@ for w in $what; do
     done
   elif [ $w = stats ]; then
     for c in $CFGS; do
-      extra="--iwae-images 0 --cpu-baseline-steps 0 --no-amdahl"; [ $c = iwae ] && extra="--cpu-baseline-steps 0"
+      extra="--iwae-images 0 --cpu-baseline-steps 0 --no-amdahl --no-graph-profile"; [ $c = iwae ] && extra="--cpu-baseline-steps 0"
       timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$c -o $c -- python bench.py --config $c $(steps_of $c) $extra > $out/stats_${c}_stdout.txt 2>&1
       echo "stats $c rc=$?"
     done
