@@ -1242,25 +1242,33 @@ def conv_stack_depth(x_shape, layers):
     N, Cc, H, W = x_shape
     if len(layers) < 2:
         return 0
-    b = 0
+    # ok_inner[i]: layer i can be an INNER layer of the run (its output feeds the next layer as an image: Co % 16 == 0, real width);
+    # ok_last[i]: it can be the LAST TAKEN layer -- GatedConvStackFn zero-pads that one's filters to a multiple of 32 output
+    # channels whenever Co % 32 != 0 (a 6-channel layer as 32: five times the matrix work of a layer that has 1 % of the stack's), so
+    # the padded geometry is what has to be supported.  Every layer >= 1 needs a weight-gradient path: the window kernel, or
+    # the channels-last one (the truncated-depth case checked the unpadded width, and no weight-gradient fallback)
+    ok_inner, ok_last = [], []
     for i, (wh, st, pd) in enumerate(layers):
         Co, Ci, KH, KW = wh.shape
         if Ci != Cc:
             break
-        # the LAST layer of the module may have any output width: it runs with its filters zero-padded to a multiple of 32
-        # output channels (a 6-channel layer as 32: five times the matrix work of a layer that has 1 % of the stack's)
-        Cop = _pad32(Co) if i == len(layers) - 1 else Co
-        d = _lib.ConvDesc(N, Cc, H, W, Cop, KH, KW, int(st), int(pd))
-        if i == 0:
-            if not lib.evae_conv2d_cl_supported(C.byref(d), 0, 1) or not lib.evae_conv2d_cl_supported(C.byref(d), 2, 1) or Co % 16:
-                break
-        elif not (lib.evae_cw_supported(C.byref(d), 0) and lib.evae_cw_supported(C.byref(d), 1) and lib.evae_cw_supported(C.byref(d), 2)
-                  if Cop != Co else
-                  lib.evae_cw_supported(C.byref(d), 0) and lib.evae_cw_supported(C.byref(d), 1) and Co % 16 == 0):
+
+        def supported(co):
+            d = _lib.ConvDesc(N, Cc, H, W, co, KH, KW, int(st), int(pd))
+            if i == 0:
+                return bool(lib.evae_conv2d_cl_supported(C.byref(d), 0, 1) and lib.evae_conv2d_cl_supported(C.byref(d), 2, 1))
+            return bool(lib.evae_cw_supported(C.byref(d), 0) and lib.evae_cw_supported(C.byref(d), 1)
+                        and (lib.evae_cw_supported(C.byref(d), 2) or lib.evae_conv2d_cl_supported(C.byref(d), 2, 1)))
+        ok_inner.append(Co % 16 == 0 and supported(Co))
+        ok_last.append(i >= 1 and (supported(Co) if Co % 32 == 0 else supported(_pad32(Co))))
+        if not ok_inner[-1]:
             break
-        b = i + 1
         Cc, H, W = Co, (H + 2 * pd - KH) // st + 1, (W + 2 * pd - KW) // st + 1
-    return b if b >= 2 else 0
+    # the longest prefix whose inner layers are all fine and whose last layer can close the run
+    for b in range(len(ok_last), 1, -1):
+        if ok_last[b - 1] and all(ok_inner[:b - 1]):
+            return b
+    return 0
 
 
 class GatedConvStackFn(torch.autograd.Function):
@@ -1602,7 +1610,7 @@ RES_STACK_MIN_PIXELS = int(os.environ.get("EVAE_RES_STACK_MIN_PIXELS", "16384"))
 def res_stack_supported(x, weights):
     """A run of residual blocks x + conv(ELU(x)) (models/fully_conv.py:13-23) on the window kernels?  (same channel count in and
     out, stride 1, enough pixels to fill the machine)"""
-    if not (CONV_STACK_ON and x.is_cuda and x.dim() == 4 and len(weights) >= 1):
+    if not (CONV_STACK_ON and x.is_cuda and x.dim() == 4 and 1 <= len(weights) <= 16):      # (evae_cw_res_run_*: at most 16 blocks a call)
         return False
     N, Cc, H, W = x.shape
     if N * H * W < RES_STACK_MIN_PIXELS:
@@ -1643,7 +1651,11 @@ class ResStackFn(torch.autograd.Function):
         ib = int(lib.evae_cw_image_bytes(N * H * W, Cc))
         fb = int(lib.evae_cw_workspace_bytes(C.byref(d), 5))
         imgs = torch.empty((nb, ib), dtype=torch.uint8, device=dev)           # images of ELU(x_0) .. ELU(x_{nb-1})
-        ys = torch.empty((nb, N, H, W, Cc), device=dev)                        # x_1 .. x_nb, channels-last
+        # x_1 .. x_nb, channels-last: block k reads x_k and writes x_{k+1}, only the last is returned -- two scratch buffers take turns for
+        # the ones in between (a 6-block run at 10 000 rows of cache_z kept 2.9 GB alive through the returned view)
+        y_last = torch.empty((N, H, W, Cc), device=dev)
+        y_tmp = torch.empty((min(2, nb - 1), N, H, W, Cc), device=dev) if nb > 1 else None
+        ys = [y_last if k == nb - 1 else y_tmp[k & 1] for k in range(nb)]
         filt = torch.empty(((2 if need_grad else 1), nb, fb), dtype=torch.uint8, device=dev)
         _lib.check(lib.evae_cw_pack_image(_p(x), N, H, W, Cc, 2, _p(imgs[0]), st), "evae_cw_pack_image(ELU)")
         _lib.check(lib.evae_cw_res_pack_filters(C.byref(d), nb, _ptr_array(ws_), _p(filt[0]), _p(filt[1]) if need_grad else None, st),
@@ -1656,7 +1668,7 @@ class ResStackFn(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(*ws_)
             ctx.keep = (imgs, d, [b is not None for b in bs_], filt[1], bs_)
-        return ys[nb - 1].permute(0, 3, 1, 2)
+        return y_last.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dout):
@@ -1670,9 +1682,15 @@ class ResStackFn(torch.autograd.Function):
         N, Cc, H, W = dy.shape
         st = _stream()
         ib = imgs.shape[1]
-        dimgs = torch.empty((nb, ib), dtype=torch.uint8, device=dev)          # [k]: image of dx_k (k >= 1); [0]: image of the incoming gradient
-        _lib.check(lib.evae_cw_pack_image(_p(dy), N, H, W, Cc, 0, _p(dimgs[0]), st), "evae_cw_pack_image")
-        dxs = torch.empty((nb, N, H, W, Cc), device=dev)
+        # image of the incoming gradient, and of dx_k (k >= 1): block k reads dx_{k+1} (fp32 and image) and writes dx_k -- two of each
+        # take turns, dx_0 (the one returned) has its own fp32 buffer and no image
+        dtop = torch.empty((ib,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.evae_cw_pack_image(_p(dy), N, H, W, Cc, 0, _p(dtop), st), "evae_cw_pack_image")
+        dimg2 = torch.empty((min(2, nb - 1), ib), dtype=torch.uint8, device=dev) if nb > 1 else None
+        dimgs = [None if k == 0 else dimg2[(k - 1) & 1] for k in range(nb)]
+        dx0 = torch.empty((N, H, W, Cc), device=dev)
+        dx_tmp = torch.empty((min(2, nb - 1), N, H, W, Cc), device=dev) if nb > 1 else None
+        dxs = [dx0 if k == 0 else dx_tmp[(k - 1) & 1] for k in range(nb)]
         dws = torch.empty((nb,) + tuple(ws_[0].shape), device=dev)
         dbs = torch.empty((nb, Cc), device=dev)
         ws = _workspace("cw", lib.evae_cw_workspace_bytes(C.byref(d), 7), dev)
@@ -1680,14 +1698,15 @@ class ResStackFn(torch.autograd.Function):
         aim = VP(*[imgs[k].data_ptr() for k in range(nb)])
         dxf = VP(*[dxs[k].data_ptr() for k in range(nb)])
         dxi = VP(*[dimgs[k].data_ptr() if k >= 1 else None for k in range(nb)])
+        dimg_top = dtop
         dwp = VP(*[dws[k].data_ptr() for k in range(nb)])
         dbp = VP(*[dbs[k].data_ptr() for k in range(nb)])
-        _lib.check(lib.evae_cw_res_run_bwd(C.byref(d), nb, _p(bimg), aim, _p(dimgs[0]), _p(dy), dxf, dxi, dwp, dbp, _p(ws), ws.numel(), st),
+        _lib.check(lib.evae_cw_res_run_bwd(C.byref(d), nb, _p(bimg), aim, _p(dimg_top), _p(dy), dxf, dxi, dwp, dbp, _p(ws), ws.numel(), st),
                    "evae_cw_res_run_bwd")
         grads = []
         for k in range(nb):
             grads += [dws[k], dbs[k] if has_b[k] else None]
-        return (dxs[0].permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None,) + tuple(grads)
+        return (dx0.permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None,) + tuple(grads)
 
 
 def res_stack(x, blocks):

@@ -12,7 +12,8 @@ from utils.distributions import log_normal_diag
 
 # training step of the dense 2-level model on two streams (calculate_loss below); EVAE_HVAE_TWO_STREAM=0: one stream
 _TWO_STREAM = os.environ.get("EVAE_HVAE_TWO_STREAM", "1") != "0"
-_TWO_STREAM_CONV = os.environ.get("EVAE_HVAE_TWO_STREAM_CONV", "1") != "0"      # the convolutional 2-level model too (r05: c3 31.4 -> 29.9 ms)
+def _two_stream_conv():     # the convolutional 2-level model too (r05: c3 31.4 -> 29.9 ms); read per call so that a test can switch it
+    return os.environ.get("EVAE_HVAE_TWO_STREAM_CONV", "1") != "0"
 
 # ... with each pair of heads + its sample + its log-density as one Function, and the loss assembly as one (evae.ops.HeadsReparamFn,
 # ElboFn: ~40 launches fewer per step); EVAE_HVAE_FUSED_HEADS=0: the separate modules
@@ -113,7 +114,7 @@ class BaseHModel(BaseModel):
         a = self.args
         return (_TWO_STREAM and self.training and a.prior == 'exemplar_prior' and a.approximate_prior is False
                 and exemplars_embedding is None and dataset is not None and x_indices is not None and x.is_cuda
-                and torch.is_grad_enabled() and (not self._is_conv() or _TWO_STREAM_CONV) and not self._sharded())
+                and torch.is_grad_enabled() and (not self._is_conv() or _two_stream_conv()) and not self._sharded())
 
     def calculate_loss(self, x, beta=1., average=False, exemplars_embedding=None, cache=None, dataset=None):
         """Training step with the exact exemplar prior on one device (reference models/BaseModel.py:54-77 over AbsHModel.py:13-106):

@@ -28,6 +28,8 @@ class AbsModel(BaseModel):
     def p_x(self, z):
         """-> (mean [B x D], log-variance [B x D] or [1 x D] zeros for binary data)"""
         mean = self.p_x_mean(self.p_x_layers(self._decoder_input(z)))
+        if hasattr(self.p_x_layers, 'clear_heads'):
+            self.p_x_layers.clear_heads()
         D = self._flat_dim()
         kind = self.args.input_type
         if kind == 'binary':

@@ -394,6 +394,8 @@ class BaseModel(nn.Module, ABC):
         z_q_logvar = z_q_logvar.reshape(-1, self.args.z1_size)
         if prior is True and self.args.prior == 'exemplar_prior':
             z_q_logvar._evae_prior_scalar = self.prior_log_variance       # (see log_p_z)
+        if hasattr(self.q_z_layers, 'clear_heads'):
+            self.q_z_layers.clear_heads()        # (fully_conv: a head weight nobody fetched -- q_z_logvar's under prior=True -- must not outlive the pass)
         return z_q_mean.reshape(-1, self.args.z1_size), z_q_logvar
 
     def cache_z(self, dataset, prior=True, cuda=True):

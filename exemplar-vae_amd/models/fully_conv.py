@@ -44,6 +44,17 @@ class _Seq(nn.Sequential):
 
     heads = ()                                             # weight-normed convolutions applied to this stack's output
 
+    def clear_heads(self):
+        """Drop this pass's head weights that no head fetched (q_z(prior=True) never calls q_z_logvar, so every training
+        step left a non-leaf, grad-requiring tensor -- and through it the whole weight-norm graph -- on the module: copy.deepcopy raised
+        'only graph leaves support deepcopy', torch.save pickled it, a later head call could have used a stale weight)."""
+        self.__dict__.pop("_head_w", None)
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st.pop("_head_w", None)                            # never part of a copy / a pickle
+        return st
+
     def head_weight(self, m):
         """the weight of head `m` from this pass's set (None: not computed -> the module's own hook does it)"""
         return self._head_w.pop(id(m), None) if getattr(self, "_head_w", None) else None

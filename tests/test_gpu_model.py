@@ -506,6 +506,81 @@ def _model_case_against_golden(g, tag, cfg):
         assert rel(v.cpu().numpy(), g["%s_eval_%s" % (tag, k)]) < tol_v, (tag, k)
 
 
+@pytest.mark.parametrize("tag,env", [("single_conv", "EVAE_DECODER_STREAM"), ("convhvae_2level", "EVAE_HVAE_TWO_STREAM_CONV")])
+def test_two_stream_steps_equal_the_one_stream_steps(tag, env, monkeypatch):
+    """the steps of the convolutional models run on two streams (single_conv: the decoder beside the prior's exemplar set,
+    models/BaseModel.py::_decoder_beside_prior; convhvae_2level: the batch rows beside the exemplar encoder, models/AbsHModel.py) -- same
+    kernels, same per-stream workspaces, so loss / RE / KL and every gradient must be BIT-equal to the one-stream step (a cross-stream
+    race would show here).  G9's model cases, both settings of the switch, twice each way round."""
+    from utils.utils import importing_model
+    cfg = dict(G9_CASES[tag]); B, C, N = cfg.pop("B"), cfg.pop("C"), cfg.pop("N")
+    args = smoke_case.vae_args(number_components=C, training_set_size=N, **cfg)
+    D = int(np.prod(args.input_size))
+    rs = np.random.RandomState(191)
+    if args.input_type == "binary":
+        data = gi.gray_images(192, N, D); x = (rs.random_sample((B, D)) < 0.3).astype(np.float32)
+    else:
+        data = ((rs.randint(0, 256, (N, D)) + 0.5) / 256).astype(np.float32); x = ((rs.randint(0, 256, (B, D)) + 0.5) / 256).astype(np.float32)
+    bidx = rs.randint(0, N, size=(B, 1)).astype(np.int64)
+    ex_idx = rs.randint(0, N, size=(C,)).astype(np.int64)
+    eps_list = [rs.standard_normal((B, args.z1_size)).astype(np.float32) for _ in range(2)]
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    outs = []
+    for setting in ("1", "0", "1", "0"):
+        monkeypatch.setenv(env, setting)
+        model = importing_model(args)(args)
+        model.load_state_dict(seeded_state_dict(model, 77, 0.35 if tag == "single_conv" else 1.0))
+        model = model.to("cuda"); model.train()
+        it = {"i": 0}
+
+        def draw(like, it=it):
+            e = torch.from_numpy(eps_list[it["i"] % 2]).to(like.device).reshape(like.shape); it["i"] += 1
+            return e
+        model._draw_eps = draw
+        orig = torch.randint
+        torch.randint = lambda low=0, high=None, size=None, **kw: torch.from_numpy(ex_idx)
+        try:
+            loss, RE, KL = model.calculate_loss((torch.from_numpy(x).cuda(), torch.from_numpy(bidx).cuda()), beta=0.6, average=False,
+                                                dataset=dataset)
+            loss.mean().backward()
+        finally:
+            torch.randint = orig
+        torch.cuda.synchronize()
+        outs.append(([t.detach().clone() for t in (loss, RE, KL)], {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    for (v, g_) in outs[1:]:
+        for a_, b_ in zip(v, outs[0][0]):
+            assert torch.equal(a_, b_)
+        assert set(g_) == set(outs[0][1])
+        for k in g_:
+            if tag == "single_conv":
+                assert torch.equal(g_[k], outs[0][1][k]), k
+            else:
+                # (the 2-level model's q(z2 | x) encoder serves the batch rows AND the exemplar rows: autograd adds the two
+                #  contributions to one .grad in the order the streams deliver them -- the same two addends, either order)
+                assert rel(g_[k].cpu().numpy(), outs[0][1][k].cpu().numpy()) < 1e-6, k
+
+
+def test_single_conv_stack_keeps_no_head_weight_after_a_pass():
+    """q_z(prior=True) never fetches q_z_logvar's weight from the stack's one-launch weight-norm set; the leftover (a non-leaf
+    tensor holding the set's autograd graph) used to stay on the module until the next forward -- kept alive by it, pickled with it, and a
+    head called without its stack's forward would have used it.  (copy.deepcopy of the whole model fails in the reference too:
+    torch.nn.utils.weight_norm leaves a non-leaf `weight` on every weight-normed layer from construction on.)"""
+    import copy, pickle
+    from utils.utils import importing_model
+    args = smoke_case.vae_args(model_name="single_conv", dataset_name="celeba", input_size=[3, 32, 32], input_type="continuous",
+                               continuous=True, use_logit=False, bottleneck=1, z1_size=64, number_components=8, training_set_size=16)
+    model = importing_model(args)(args).cuda(); model.train()
+    mu, _ = model.q_z(torch.rand(16, 3 * 32 * 32, device="cuda"), prior=True)      # 16 x 32 x 32 pixels: the one-launch set is on
+    assert "_head_w" not in model.q_z_layers.__dict__
+    mu.sum().backward()
+    xm, _ = model.p_x(torch.randn(16, 64, device="cuda"))
+    assert "_head_w" not in model.p_x_layers.__dict__
+    model.q_z_layers._head_w = {1: mu}                                              # even if one were there: not part of the state
+    assert "_head_w" not in model.q_z_layers.__getstate__()
+    model.q_z_layers.clear_heads()
+    pickle.dumps(model.state_dict())
+
+
 def test_c5_geometry_matches_reference_golden(golden):
     """BASELINE config 5's geometry through the model API: single_conv (models/fully_conv.py) on 3 x 64 x 64, z1 = 256
     (bottleneck 1), 256-bin logistic likelihood, approximate cache + top-k prior (models/BaseModel.py:256-271) -- loss,

@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
-"""Find reads of uninitialised device memory: run test functions with torch.empty / empty_like / Tensor.new_empty returning NaN-filled
-float tensors (a fresh process usually sees zero pages there, a long one whatever was freed before).
+"""Find reads of uninitialised device memory: run test functions with torch.empty / empty_like / Tensor.new_empty returning poisoned
+tensors -- NaN in floating-point ones, 0xFF bytes in uint8 ones (the pixel / operand images are uint8 buffers: 0xFFFF is a NaN bf16
+pattern in every one of the three split terms) -- where a fresh process usually sees zero pages and a long one whatever was freed before.
   python tools/poison_empty.py tests/test_gpu_model.py::test_configuration_matrix_trains_one_step[11] ...   (pytest node ids)"""
 import sys
 import torch
-_e, _el = torch.empty, torch.empty_like
+_e, _el, _ne = torch.empty, torch.empty_like, torch.Tensor.new_empty
 
 
 def _poison(t):
-    if t.is_cuda and t.is_floating_point() and t.numel() > 0:
-        t.fill_(float("nan"))
+    if t.is_cuda and t.numel() > 0:
+        if t.is_floating_point():
+            t.fill_(float("nan"))
+        elif t.dtype == torch.uint8:
+            t.fill_(255)
     return t
 
 
 torch.empty = lambda *a, **k: _poison(_e(*a, **k))
 torch.empty_like = lambda *a, **k: _poison(_el(*a, **k))
+torch.Tensor.new_empty = lambda self, *a, **k: _poison(_ne(self, *a, **k))
 import pytest
 sys.exit(pytest.main(["-x", "-q", "-m", "gpu"] + sys.argv[1:]))
