@@ -1389,11 +1389,27 @@ __global__ __launch_bounds__(1024) void prior_bwd_finish_kernel(const float* __r
                                                                 float* __restrict__ dz, int nb_dz,
                                                                 const float* __restrict__ dlv_part, int nblocks,
                                                                 float* __restrict__ dlogvar,
-                                                                const unsigned* __restrict__ run_flag) {
+                                                                const unsigned* __restrict__ run_flag,
+                                                                const float* __restrict__ fold_src = nullptr, const int64_t* __restrict__ fold_rep = nullptr,
+                                                                const float* __restrict__ fold_mult = nullptr, float* __restrict__ fold_dst = nullptr,
+                                                                int fold_rows = 0, int nb_lv = 0) {
   __shared__ float red[16][64];
   if (run_flag != nullptr && *run_flag == 0u) return;
   const int lane = threadIdx.x & 63;
   const int part = threadIdx.x >> 6;
+  if (fold_dst != nullptr && (int)blockIdx.x >= nb_dz + nb_lv) {
+    // the blocks behind the two reductions (r06): dst[u] = mult[u] * src[rep[u]] -- the per-draw centre gradients folded onto the
+    // DISTINCT rows of the draw (a distinct row's gradient = multiplicity x one of its draws'; padding rows: multiplicity 0)
+    const int q = zdim >> 2;
+    const size_t i = (size_t)((int)blockIdx.x - nb_dz - nb_lv) * 1024 + threadIdx.x;
+    if (i < (size_t)fold_rows * q) {
+      const int u = (int)(i / q), c = (int)(i - (size_t)u * q);
+      const float m = fold_mult[u];
+      const float4 v = *reinterpret_cast<const float4*>(fold_src + (size_t)fold_rep[u] * zdim + 4 * c);
+      *reinterpret_cast<float4*>(fold_dst + (size_t)u * zdim + 4 * c) = make_float4(m * v.x, m * v.y, m * v.z, m * v.w);
+    }
+    return;
+  }
   if ((int)blockIdx.x >= nb_dz) {
     const int k = ((int)blockIdx.x - nb_dz) * 16 + part;
     if (k >= zdim) return;
@@ -1853,7 +1869,7 @@ extern "C" size_t evae_prior_train_workspace_bytes(int B, int C, int zdim) {
 }
 
 template <int KG>
-static int launch_prior_train(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+static int launch_prior_train(const float* z, int B, const float* centres, const int64_t* row_map, int C, int zdim, const float* log_var,
                               const int64_t* z_idx, const int64_t* c_idx, float c_total, const float* beta_dev, float beta_host,
                               unsigned* state, float* part, float* gpart, float* logp, float* token, float* cRE, float* cKL,
                               float* ncKL, float* dz_part, float* dc, float* dlv_part, hipStream_t stream) {
@@ -1863,17 +1879,21 @@ static int launch_prior_train(const float* z, int B, const float* centres, int C
     (void)hipFuncSetAttribute((const void*)prior_train_kernel<KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  prior_train_kernel<KG><<<cdiv(C, MFE), MFT, lds, stream>>>(z, B, centres, C, zdim, log_var, z_idx, c_idx, c_total, beta_dev, beta_host,
+  prior_train_kernel<KG><<<cdiv(C, MFE), MFT, lds, stream>>>(z, B, centres, row_map, C, zdim, log_var, z_idx, c_idx, c_total, beta_dev, beta_host,
                                                             prior_norm_limit(), state, part, gpart, logp, token, cRE, cKL, ncKL,
                                                             dz_part, dc, dlv_part);
   return check_launch("prior_train_kernel");
 }
 
-extern "C" int evae_prior_train_step(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
-                                     const int64_t* z_idx, const int64_t* c_idx, float c_total, const float* beta_dev,
-                                     float beta_host, float* logp, float* token, float* cRE, float* cKL, float* neg_cKL,
-                                     float* dz, float* dcentres, float* dlogvar, void* state, void* ws, size_t ws_bytes,
-                                     int phase, evae_stream_t stream_) {
+// rows_inv != NULL: the step encoded each DISTINCT image of its draw once -- `centres` holds the n_rows distinct rows' encodings,
+// exemplar j of the prior is row rows_inv[j]; the per-draw centre gradients go to dc_draws [C x zdim] (scratch) and the reduction launch
+// folds them onto the distinct rows: dcentres[u] = rows_mult[u] * dc_draws[rows_rep[u]], u < n_rows
+static int prior_train_step_core(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+                                 const int64_t* z_idx, const int64_t* c_idx, float c_total, const float* beta_dev,
+                                 float beta_host, float* logp, float* token, float* cRE, float* cKL, float* neg_cKL,
+                                 float* dz, float* dcentres, float* dlogvar, void* state, void* ws, size_t ws_bytes,
+                                 int phase, evae_stream_t stream_, const int64_t* rows_inv, const int64_t* rows_rep,
+                                 const float* rows_mult, int n_rows, float* dc_draws) {
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(phase >= 0 && phase <= 2, "prior_train_step: phase must be 0, 1 or 2");
   EVAE_REQUIRE(evae_prior_train_applies(B, C, zdim), "prior_train_step: B=%d C=%d zdim=%d is outside the one-launch form (B <= 128, "
@@ -1892,9 +1912,9 @@ extern "C" int evae_prior_train_step(const float* z, int B, const float* centres
   const int nblk = cdiv(C, MFE);
   int rc = EVAE_OK;
   if (phase != 2) {
-#define EVAE_PT(KG_) rc = launch_prior_train<KG_>(z, B, centres, C, zdim, log_var, z_idx, c_idx, c_total, beta_dev, beta_host, \
-                                                  (unsigned*)state, part, gpart, logp, token, cRE, cKL, neg_cKL, dz_part, dcentres, \
-                                                  dlv_part, stream)
+#define EVAE_PT(KG_) rc = launch_prior_train<KG_>(z, B, centres, rows_inv, C, zdim, log_var, z_idx, c_idx, c_total, beta_dev, beta_host, \
+                                                  (unsigned*)state, part, gpart, logp, token, cRE, cKL, neg_cKL, dz_part, \
+                                                  rows_inv ? dc_draws : dcentres, dlv_part, stream)
     switch ((zdim + 7) / 8) {
       case 1: EVAE_PT(1); break;
       case 2: EVAE_PT(2); break;
@@ -1908,8 +1928,31 @@ extern "C" int evae_prior_train_step(const float* z, int B, const float* centres
     if (rc) return rc;
   }
   if (phase == 1) return EVAE_OK;
-  const int nb = cdiv(B * zdim, 64);
-  prior_bwd_finish_kernel<<<nb + cdiv(zdim, 16), 1024, 0, stream>>>(dz_part, nblk, B * zdim, zdim, log_var, dz, nb, dlv_part, nblk,
-                                                                   dlogvar, nullptr);
+  const int nb = cdiv(B * zdim, 64), nlv = cdiv(zdim, 16);
+  const int nfold = rows_inv ? cdiv(n_rows * (zdim / 4), 1024) : 0;
+  prior_bwd_finish_kernel<<<nb + nlv + nfold, 1024, 0, stream>>>(dz_part, nblk, B * zdim, zdim, log_var, dz, nb, dlv_part, nblk,
+                                                                dlogvar, nullptr, rows_inv ? dc_draws : nullptr, rows_rep, rows_mult,
+                                                                rows_inv ? dcentres : nullptr, n_rows, nlv);
   return check_launch("prior_bwd_finish_kernel");
+}
+
+extern "C" int evae_prior_train_step(const float* z, int B, const float* centres, int C, int zdim, const float* log_var,
+                                     const int64_t* z_idx, const int64_t* c_idx, float c_total, const float* beta_dev,
+                                     float beta_host, float* logp, float* token, float* cRE, float* cKL, float* neg_cKL,
+                                     float* dz, float* dcentres, float* dlogvar, void* state, void* ws, size_t ws_bytes,
+                                     int phase, evae_stream_t stream_) {
+  return prior_train_step_core(z, B, centres, C, zdim, log_var, z_idx, c_idx, c_total, beta_dev, beta_host, logp, token, cRE, cKL, neg_cKL,
+                               dz, dcentres, dlogvar, state, ws, ws_bytes, phase, stream_, nullptr, nullptr, nullptr, 0, nullptr);
+}
+
+extern "C" int evae_prior_train_step_rows(const float* z, int B, const float* centres, int n_rows, const int64_t* rows_inv,
+                                          const int64_t* rows_rep, const float* rows_mult, int C, int zdim, const float* log_var,
+                                          const int64_t* z_idx, const int64_t* c_idx, float c_total, const float* beta_dev,
+                                          float beta_host, float* logp, float* token, float* cRE, float* cKL, float* neg_cKL,
+                                          float* dz, float* dcentres, float* dc_draws, float* dlogvar, void* state, void* ws,
+                                          size_t ws_bytes, evae_stream_t stream_) {
+  EVAE_REQUIRE(rows_inv && rows_rep && rows_mult && dc_draws && n_rows >= 1, "prior_train_step_rows: null row tables");
+  EVAE_REQUIRE((((uintptr_t)dc_draws | (uintptr_t)dcentres) & 15) == 0, "prior_train_step_rows: gradient buffers must be 16-byte aligned");
+  return prior_train_step_core(z, B, centres, C, zdim, log_var, z_idx, c_idx, c_total, beta_dev, beta_host, logp, token, cRE, cKL, neg_cKL,
+                               dz, dcentres, dlogvar, state, ws, ws_bytes, 0, stream_, rows_inv, rows_rep, rows_mult, n_rows, dc_draws);
 }

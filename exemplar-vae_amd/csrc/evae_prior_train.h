@@ -43,7 +43,7 @@ __device__ __forceinline__ void pt_merge_one(float& m, float& s, float& n, float
 
 template <int KG>
 __global__ __launch_bounds__(MFT) void prior_train_kernel(
-    const float* __restrict__ z, int B, const float* __restrict__ centres, int C, int zdim,
+    const float* __restrict__ z, int B, const float* __restrict__ centres, const int64_t* __restrict__ row_map /* [C] or NULL */, int C, int zdim,
     const float* __restrict__ log_var, const int64_t* __restrict__ z_idx, const int64_t* __restrict__ c_idx,
     float c_total, const float* __restrict__ beta_dev, float beta_host, float norm_limit,
     unsigned* __restrict__ state, float* __restrict__ part /* [3][nblk][128] */, float* __restrict__ gpart /* [3][8][128] */,
@@ -80,13 +80,15 @@ __global__ __launch_bounds__(MFT) void prior_train_kernel(
   stamp(0);
   const float cst = setup_sigma(inv_sigma, red, log_var, zdim, KP);   // contains a barrier
 
-  auto load_tile = [&](const float* src, int r0, int nrows, float4 (&v)[NV]) {
+  // (map: exemplar j of the prior is row map[j] of src -- the draws of a step that encoded each DISTINCT image once, r06)
+  auto load_tile = [&](const float* src, const int64_t* map, int r0, int nrows, float4 (&v)[NV]) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid + MFT * i;
       const int r = f / CPR, c = f - r * CPR;
       const bool ok = f < MFE * CPR && r0 + r < nrows && 4 * c + 4 <= zdim;
-      v[i] = ok ? *reinterpret_cast<const float4*>(src + (size_t)(r0 + r) * zdim + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const size_t row = ok ? (map ? (size_t)map[r0 + r] : (size_t)(r0 + r)) : 0;
+      v[i] = ok ? *reinterpret_cast<const float4*>(src + row * zdim + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store_tile = [&](float* tile, const float4 (&v)[NV], const bool centre) {
@@ -106,10 +108,10 @@ __global__ __launch_bounds__(MFT) void prior_train_kernel(
   };
 
   float4 rv[NV];
-  load_tile(z, 0, B, rv);
+  load_tile(z, nullptr, 0, B, rv);
   store_tile(Qs, rv, false);
   const int e0 = blk * MFE;
-  load_tile(centres, e0, C, rv);
+  load_tile(centres, row_map, e0, C, rv);
   __syncthreads();
   const bool slow = centre_queries<KP, KS2, MFT>(Qs, mu_s, zn, zmx, Ps, B < MFQ ? B : MFQ) > norm_limit;
   stamp(1);

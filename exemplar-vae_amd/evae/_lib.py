@@ -66,6 +66,7 @@ SIGNATURES = {
     "evae_prior_train_gave_up": (_i, [_p, _p]),
     "evae_prior_train_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_prior_train_step": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _f, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _p]),
+    "evae_prior_train_step_rows": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _p, _f, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_prior_lse_bwd_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_prior_lse_bwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_prior_lse_bwd_phased": (_i, [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _p]),

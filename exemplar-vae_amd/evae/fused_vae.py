@@ -61,7 +61,7 @@ FINISH_GROUP_HEAD = os.environ.get("EVAE_FINISH_GROUP_HEAD", "0") == "1"   # ...
 FINISH_GROUP = os.environ.get("EVAE_FINISH_GROUP", "0") == "1"
 # the mean head's weight gradient (a 29-us streaming launch alone) right behind the batch rows' reparameterisation backward instead of
 # at the end of the side stream's chain: it then runs beside the HBM-bound head data gradient, not beside layer 2's data gradient
-HEADW_EARLY = int(os.environ.get("EVAE_HEADW_EARLY", "1"))
+HEADW_EARLY = int(os.environ.get("EVAE_HEADW_EARLY", "0"))   # r06: OFF -- with the head gradient in front of them the batch rows' thin data gradients (which the main stream's layer-2 weight gradient waits for) finished 20 us after layer 2's data gradient: 0.553 -> 0.542 ms
 ELBO_SPLIT = os.environ.get("EVAE_ELBO_SPLIT", "0") != "0"         # captured step: merge on the prior's stream, ELBO assembly beside it
 # (r04 A/B, profiles/r04_ab: the 7-block merge launch takes 10.7 us against the one-block merge + ELBO's 11.6 and the join it
 #  saves comes back as a 9-us gap in front of the prior's backward: c2 0.616-0.621 -> 0.623-0.629 ms.  Off; what replaced it:)
@@ -429,18 +429,33 @@ class VaeExactLoss(torch.autograd.Function):
             dmean_all = torch.empty((Mp, Z), **f32)
             packed = torch.empty(B * Z + Z, **f32)
             ev_pre = torch.cuda.Event(); ev_pre.record()
+            keep_alive = None
             if dd is not None:
                 # the prior over all C draws: centres of the draws gathered from the distinct rows' encodings; a distinct row's
                 # gradient = multiplicity x the gradient of one of its draws
-                centres_x = torch.empty((Cp, Z), **f32); dc_x = torch.empty((Cp, Z), **f32)
-                _lib.check(lib.evae_gather_rows(_vp(centres), _vp(dd[1]), None, Cp, Z, _vp(centres_x), k.st), "gather_rows(centres)")
-                ops.prior_train_step(z, centres_x, lv_row, zi, ci, float(c_total), beta_dev if beta_dev is not None else beta_host,
-                                     out=(logp, lse, None, packed[:B * Z].view(B, Z), dc_x, packed[B * Z:]), stream=k.st)
-                _lib.check(lib.evae_gather_rows(_vp(dc_x), _vp(dd[2]), _vp(dd[3]), Cl, Z, _vp(dmean_all), k.st), "gather_rows(dcentres)")
+                dc_x = torch.empty((Cp, Z), **f32)
+                keep_alive = [dc_x]
+                if os.environ.get("EVAE_PRIOR_ROWS", "1") != "0":
+                    # r06: the kernel reads draw j's centre through inv[j] and the reduction launch folds the per-draw gradients onto the
+                    # distinct rows: the two gather launches around the prior are gone (2 x ~5 us of the critical path)
+                    ops.prior_train_step_rows(z, centres, (dd[1], dd[2], dd[3]), lv_row, zi, ci, float(c_total),
+                                              beta_dev if beta_dev is not None else beta_host,
+                                              out=(logp, lse, None, packed[:B * Z].view(B, Z), dmean_all[:Cl], packed[B * Z:]), dc_draws=dc_x,
+                                              stream=k.st)
+                else:
+                    centres_x = torch.empty((Cp, Z), **f32)
+                    keep_alive.append(centres_x)
+                    _lib.check(lib.evae_gather_rows(_vp(centres), _vp(dd[1]), None, Cp, Z, _vp(centres_x), k.st), "gather_rows(centres)")
+                    ops.prior_train_step(z, centres_x, lv_row, zi, ci, float(c_total), beta_dev if beta_dev is not None else beta_host,
+                                         out=(logp, lse, None, packed[:B * Z].view(B, Z), dc_x, packed[B * Z:]), stream=k.st)
+                    _lib.check(lib.evae_gather_rows(_vp(dc_x), _vp(dd[2]), _vp(dd[3]), Cl, Z, _vp(dmean_all), k.st), "gather_rows(dcentres)")
             else:
                 ops.prior_train_step(z, centres, lv_row, zi, ci, float(c_total), beta_dev if beta_dev is not None else beta_host,
                                      out=(logp, lse, None, packed[:B * Z].view(B, Z), dmean_all[:Cl], packed[B * Z:]), stream=k.st)
-            prior_done = (dmean_all, packed, ev_pre)
+            # (the scratch of this launch rides along: the side stream's backward chain starts at ev_pre -- BESIDE the prior's launch -- and
+            #  its buffers are allocated while the main stream is current; a scratch tensor freed at the end of this forward would be
+            #  handed to them while the prior still reads / writes it.  r06: an allocation-order change made exactly that happen)
+            prior_done = (dmean_all, packed, ev_pre, keep_alive)
         if sharded == 2:
             # data-parallel batches over sharded exemplars: every rank scores the queries of ALL ranks against its
             # shard (same pair count as B queries against all C), the partials go back to their owners

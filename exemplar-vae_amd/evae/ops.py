@@ -243,6 +243,26 @@ def prior_train_applies(B, Cn, zd):
     return bool(_lib.load().evae_prior_train_applies(int(B), int(Cn), int(zd)))
 
 
+def prior_train_step_rows(z, centres, rows, log_var, z_idx, c_idx, c_total, beta, out, dc_draws, stream=None):
+    """prior_train_step for a step that encoded each distinct image once: centres [n_rows x z], rows = (inv [C], rep [n_rows],
+    mult [n_rows]); out = (logp, token, coef, dz, dcentres [n_rows x z], dlogvar), dc_draws [C x z] scratch."""
+    lib = _lib.load()
+    inv, rep, mult = rows
+    B, zd = z.shape
+    Cn = inv.numel()
+    logp, token, coef, dz, dc, dlv = out
+    beta_dev = beta if torch.is_tensor(beta) else None
+    ws = _workspace("prior_train", lib.evae_prior_train_workspace_bytes(B, Cn, zd), z.device)
+    st = prior_train_state(z.device)
+    c3 = coef if coef is not None else (None, None, None)
+    _lib.check(lib.evae_prior_train_step_rows(_p(z), B, _p(centres), centres.shape[0], _p(inv), _p(rep), _p(mult), Cn, zd, _p(log_var),
+                                              _p(_i64(z_idx)), _p(_i64(c_idx)), float(c_total), _p(beta_dev),
+                                              0.0 if beta_dev is not None else float(beta), _p(logp), _p(token), _p(c3[0]), _p(c3[1]),
+                                              _p(c3[2]), _p(dz), _p(dc), _p(dc_draws), _p(dlv), _p(st), _p(ws), ws.numel(),
+                                              _stream() if stream is None else stream), "evae_prior_train_step_rows")
+    return out
+
+
 def prior_train_step(z, centres, log_var, z_idx, c_idx, c_total, beta, want_coef=True, out=None, phase=0, stream=None):
     """The exemplar prior of a captured training step in one launch (+ the dz / dlogvar reduction): returns
     (logp [B], token [2 x B], (cRE, cKL, neg_cKL) or None, dz [B x z], dcentres [C x z], dlogvar [z]) for the loss

@@ -147,6 +147,17 @@ int evae_prior_train_step(const float* z, int B, const float* centres, int C, in
                           float* logp /* [B] */, float* token /* [2 B] */, float* cRE, float* cKL, float* neg_cKL,
                           float* dz /* [B x zdim] */, float* dcentres /* [C x zdim] */, float* dlogvar /* [zdim] */, void* state,
                           void* ws, size_t ws_bytes, int phase, evae_stream_t stream);
+/* ... of a step that encoded each DISTINCT image of its draw once (the reference draws with replacement and encodes every draw,
+ * models/BaseModel.py:243-254): `centres` = the n_rows distinct rows' encodings, exemplar j of the prior = row rows_inv[j] (j < C); the
+ * per-draw centre gradients land in the scratch dc_draws [C x zdim] and the reduction launch folds them:
+ * dcentres[u] = rows_mult[u] * dc_draws[rows_rep[u]] for u < n_rows (padding rows carry multiplicity 0).  Same two launches as
+ * evae_prior_train_step -- no gather launch in front of the prior, none behind it (r06). */
+int evae_prior_train_step_rows(const float* z, int B, const float* centres, int n_rows, const int64_t* rows_inv, const int64_t* rows_rep,
+                               const float* rows_mult, int C, int zdim, const float* log_var, const int64_t* z_idx,
+                               const int64_t* c_idx, float c_total, const float* beta_dev, float beta_host, float* logp, float* token,
+                               float* cRE, float* cKL, float* neg_cKL, float* dz, float* dcentres /* [n_rows x zdim] */,
+                               float* dc_draws /* [C x zdim] */, float* dlogvar, void* state, void* ws, size_t ws_bytes,
+                               evae_stream_t stream);
 
 /* Backward of sum_i grad_out_i * logprior_i through the prior (what autograd derives from
  * BaseModel.py:98-128 + distributions.py:12-25), by recomputation from the saved row LSE:
