@@ -13,7 +13,7 @@
   hdgrad2_img the mean head's data gradient, gate-backward epilogue -> [dh2 | dg2]^T's image (gemm_x6_kernel<2, 0, 64, 3>)
   dgrad2_p6   encoder layer 2's data gradient over that image, (dh1, dg1) as the byte layer's tile images (gemm_p6_kernel<9, 64, true>)
   wgrad2_p6   encoder layer 2's weight gradient from the two images (gemm_p6_kernel<3, 64, false> + finish)
-  hwgrad      the heads' weight gradient [40 x 300] over 25 100 rows (narrow_wgrad_kernel + finish)
+  hwgrad      the heads' weight gradient [40 x 300] over 25 100 rows (narrow_wgrad_mfma_kernel + narrow_finish_kernel)
   prior_iwae  prior forward, 4 x 5000 importance samples x 50 000 exemplars, z = 40 (prior_fwd_mfma_kernel)
   prior_c5    prior forward, 5000 samples x 100 000 exemplars, z = 256 (GEMM + log-sum-exp epilogue)
   prior_train prior forward + backward at the training shape B = 100, C = 25 000, z = 40 (three launches, the modular form)

@@ -56,7 +56,7 @@ for f in sorted(glob.glob(os.path.join(src, "timeline_C*.txt"))):
 MAIN = {"u8fwd1": ["u8p_gemm_kernel", "u8_gemm_kernel<true>"], "u8fwd1_img": ["u8p_gemm_kernel", "u8_gemm_kernel<true>"], "u8wgrad1": ["u8_gemm_kernel<false>"],
         "fwd2_p6": ["gemm_p6_kernel<1, 128, true>"], "hdgrad2_img": ["gemm_x6_kernel<2, 0", "gemm_kernel<true, false, 2"],
         "dgrad2_p6": ["gemm_p6_kernel<9, 128, true>", "gemm_p6_kernel<9, 64, true>"], "wgrad2_p6": ["gemm_p6_kernel<3, 64, false>"],
-        "hwgrad": ["narrow_wgrad_kernel"],
+        "hwgrad": ["narrow_wgrad_mfma_kernel", "narrow_wgrad_kernel"],
         "fwd1": ["gemm_x6_kernel<1, 0", "gemm_kernel<true, true, 1"], "fwd2": ["gemm_x6_kernel<1, 0", "gemm_kernel<true, true, 1"],
         "dgrad2": ["gemm_x6_kernel<2, 0", "gemm_kernel<true, false, 2"], "wgrad1": ["gemm_kernel<false, false, 3"],
         "wgrad2": ["gemm_kernel<false, false, 3"], "prior_iwae": ["prior_x6_lse_kernel", "prior_fwd_mfma_kernel"],
