@@ -45,4 +45,4 @@ for w in $what; do
     done
   fi
 done
-git -C $root rev-parse HEAD > $out/HEAD 2>/dev/null || cp $root/.gpurun_head $out/HEAD 2>/dev/null || true
+git -C $root rev-parse HEAD > $out/HEAD 2>/dev/null || cp $root/.gpurun_head $out/HEAD 2>/dev/null || true   # (.gpurun_head: written by the caller before gpurun -- `git rev-parse HEAD > .gpurun_head` -- the box has no .git)
