@@ -1527,7 +1527,8 @@ def test_single_conv_training_step_at_c5_size():
     100 -- one eager training step (cache of all latents, refresh of the batch's rows, top-K among the candidates' cached
     latents, <= 1000 exemplars re-encoded, loss, backward) on the split-bf16 pipe and on the fp32-MFMA pipe: loss / RE / KL
     finite and equal to 1e-5, every gradient norm to 1e-3; the step's top-K (batch means against the 100 000 cached latents,
-    reference models/BaseModel.py:263-264) bit-equal to the oracle's float64 scan with its (value, index) order."""
+    reference models/BaseModel.py:263-264) bit-equal to the oracle's float64 scan with its (value, index) order; every batch row's KL
+    against the oracle's prior and posterior densities over the exemplar set the reference would re-encode (1e-4)."""
     from evae import ops
     from utils.utils import importing_model
     from argparse import Namespace
@@ -1589,6 +1590,26 @@ def test_single_conv_training_step_at_c5_size():
     idx, val = ops.pairdist_topk(q, cz, k)
     _, ref_idx = orc.nearest_exemplars_topk(q.double().cpu().numpy(), cz.double().cpu().numpy(), k)
     assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    # r06: the step's KL at THIS size against the oracle -- log q(z | x) - log p(z) with the exemplar set the
+    # reference's get_approximate_nearest_exemplars arrives at (models/BaseModel.py:256-271: batch rows of the cache refreshed with their
+    # means, top-k of every batch row among the candidates' cached latents, `unique`, those images re-encoded): the encoder's outputs
+    # (pinned by G20 / G23) go to evae_oracle.log_p_z / log_normal_diag in float64
+    with torch.no_grad():
+        xb = data_dev[500:500 + B]
+        mu, lv = model.q_z(xb)
+        z = mu + eps.reshape(mu.shape) * torch.exp(0.5 * lv)
+        cache0 = model.cache_z(dataset)[0].clone()
+        cache0[500:500 + B] = mu
+        near, _ = ops.pairdist_topk(mu, cache0[cand.cuda()].contiguous(), k)
+        pos = torch.unique(near.reshape(-1))
+        sel = cand.cuda()[pos]
+        centres = model.q_z(data_dev[sel], prior=True)[0]
+    assert 10 <= sel.numel() <= B * k
+    plv = float(model.prior_log_variance.item())
+    log_p = orc.log_p_z(z.double().cpu().numpy(), np.arange(500, 500 + B).reshape(-1, 1), centres.double().cpu().numpy(),
+                        np.full((sel.numel(), 256), plv), sel.cpu().numpy(), test=False)
+    log_q = orc.log_normal_diag(z.double().cpu().numpy(), mu.double().cpu().numpy(), lv.double().cpu().numpy())
+    assert rel(res[0][0][2], log_q - log_p) < 1e-4, rel(res[0][0][2], log_q - log_p)
 
 
 @pytest.mark.parametrize("upload", ["direct", "staged"])
