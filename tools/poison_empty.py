@@ -2,7 +2,10 @@
 """Find reads of uninitialised device memory: run test functions with torch.empty / empty_like / Tensor.new_empty returning poisoned
 tensors -- NaN in floating-point ones, 0xFF bytes in uint8 ones (the pixel / operand images are uint8 buffers: 0xFFFF is a NaN bf16
 pattern in every one of the three split terms) -- where a fresh process usually sees zero pages and a long one whatever was freed before.
-  python tools/poison_empty.py tests/test_gpu_model.py::test_configuration_matrix_trains_one_step[11] ...   (pytest node ids)"""
+  python tools/poison_empty.py tests/test_gpu_model.py::test_configuration_matrix_trains_one_step[11] ...   (pytest node ids)
+Limit (r06): the fill runs on the stream that is current at the allocation.  The fused `vae` step allocates a side-stream launch's output
+while the main stream is current, so the poison can land BEHIND the producer's write (no dependency orders them) and a captured
+two-stream step reports NaN where nothing is read uninitialised (the r05 tree fails the same way); trust it on one-stream paths."""
 import sys
 import torch
 _e, _el, _ne = torch.empty, torch.empty_like, torch.Tensor.new_empty
