@@ -78,7 +78,7 @@ class GraphedTrainStep:
         nsc = 1 + self.ngroups
         # Duplicates among the draw (the reference draws WITH replacement, models/BaseModel.py:245): when they are worth it the
         # gather list holds the DISTINCT rows only -- `cap` of them, a fixed count the distinct rows of a draw stay under by
-        # eight standard deviations, padded with multiplicity 0 -- and the block carries the draw itself, every draw's
+        # five standard deviations (eight until r06), padded with multiplicity 0 -- and the block carries the draw itself, every draw's
         # position among the distinct rows, one draw per distinct row and the multiplicities behind its scalars
         # (evae_host_dedup on the host; evae/fused_vae.py::DEDUP for what the step does with them).  EVAE_DEDUP=0: off.
         self.dedup = None
@@ -98,13 +98,16 @@ class GraphedTrainStep:
             # distinct rows among the Cl draws of this process (all C on one device, its shard of the common draw otherwise) from Nt:
             # mean Nt (1 - q), variance Nt q (1 - q) + Nt (Nt - 1) (q2 - q^2) with q = (1 - 1/Nt)^Cl the chance that a given row is not
             # drawn, q2 = (1 - 2/Nt)^Cl that two given rows are not (the occupancies are negatively correlated: c2's 25 000 of
-            # 50 000 give 19 673 +- 52); cap = mean + 8 sigma, whole 128-row tiles
+            # 50 000 give 19 673 +- 52); cap = mean + 5 sigma (+ 32 rows), whole 128-row tiles
             lq = Cl * math.log1p(-1.0 / Nt) if Nt > 1 else -math.inf
             q = math.exp(lq)
             dq = q * q * math.expm1(Cl * math.log1p(-2.0 / Nt) - 2.0 * lq) if Nt > 2 else 0.0       # q2 - q^2
             mean_u = Nt * (1.0 - q)
             var_u = max(Nt * q * (1.0 - q) + Nt * (Nt - 1.0) * dq, 1.0)
-            cap = min(Cl, int(math.ceil((mean_u + 8.0 * math.sqrt(var_u) + 32.0) / 128.0)) * 128)
+            # (r06: five standard deviations, it was eight -- a draw that does not fit is stepped eagerly once since r06, so the margin
+            #  only has to make that rare: c2's 19 968 rows sit 5.6 sigma above the mean, ~1e-8 per step; 20 224 before)
+            nsig = float(os.environ.get("EVAE_DEDUP_SIGMAS", "5"))
+            cap = min(Cl, int(math.ceil((mean_u + nsig * math.sqrt(var_u) + 32.0) / 128.0)) * 128)
             if cap <= 0.92 * Cl:
                 self.dedup = {"cap": cap, "distinct": 0}
                 Cd = cap
@@ -314,7 +317,7 @@ class GraphedTrainStep:
                                              C.c_void_p(h[self._o_inv:].data_ptr()), C.c_void_p(h[self._o_rep:].data_ptr()),
                                              C.c_void_p(self.dedup["host_mult"][k].data_ptr()))
             if nu < 0:
-                # more distinct rows than the captured step has room for (its fixed count sits eight standard deviations above the
+                # more distinct rows than the captured step has room for (its fixed count sits five standard deviations above the
                 # mean: ~1e-15 per draw): THIS step is issued eagerly with every draw encoded -- the same loss and gradients
                 # (__call__ / step_eagerly look at _overflow) -- and the next one replays again
                 Cd_ = self._Cd

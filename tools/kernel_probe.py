@@ -20,7 +20,7 @@
   prior_train1  the same as ONE launch (evae_prior_train_step: what a captured step runs)
   topk_c2 / topk_c5   evae_pairdist_topk, k = 10 (100 x 25 000 x 40 / 100 x 100 000 x 256)
   conv5_fwd / conv5_bwd   gated conv 32 -> 64, 5 x 5, 14 x 14, 25 000 images (c3) on the channels-last kernels: forward / data + weight gradient
-  cw5_fwd / cw5_bwd / cw5_wgrad   the same layer over the 20 224 encoded rows of a c3 step on the window kernels (csrc/evae_conv_win.h):
+  cw5_fwd / cw5_bwd / cw5_wgrad   the same layer over the 19 968 encoded rows of a c3 step on the window kernels (csrc/evae_conv_win.h):
               forward (conv_win_kernel<0, 2, 2, 320>), data gradient + gate derivative (conv_win_kernel<1, 4, 1, 576>), weight gradient
               (conv_wgrad_win_kernel<13 | 12, 192, 8, 1, false>)
   res96_fwd / res96_bwd / res96_wgrad   a residual block 96 -> 96, 3 x 3, 32 x 32, 100 images (c5's decoder) on the window kernels
@@ -38,7 +38,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 torch.manual_seed(0)
 N, D, H, Z = 50000, 784, 300, 40
 # exemplar rows of the large launches: what a captured c2 / c3 step encodes (the distinct rows of its 25 000 draws, evae/graph.py)
-M = int(os.environ.get("EVAE_PROBE_ROWS", "20224"))
+M = int(os.environ.get("EVAE_PROBE_ROWS", "19968"))
 vp = lambda a: C.c_void_p(a)
 
 
@@ -163,7 +163,7 @@ elif which.startswith("topk"):
     for _ in range(reps):
         ops.pairdist_topk(q, cache, 10, want_val=False)
 elif which in ("cw5_fwd", "cw5_bwd", "cw5_wgrad"):
-    pr = ops.conv_window_probe(int(os.environ.get("EVAE_PROBE_ROWS", "20224")), 32, 14, 64, 5, 1, out_planar=True)
+    pr = ops.conv_window_probe(int(os.environ.get("EVAE_PROBE_ROWS", "19968")), 32, 14, 64, 5, 1, out_planar=True)
     fn = pr[{"cw5_fwd": "fwd", "cw5_bwd": "dgrad", "cw5_wgrad": "wgrad"}[which]]
     for _ in range(reps):
         fn()
@@ -173,11 +173,11 @@ elif which in ("res96_fwd", "res96_bwd", "res96_wgrad"):
     for _ in range(reps * 4):
         fn()
 elif which == "cw2_bwd":
-    pr = ops.conv_window_probe(int(os.environ.get("EVAE_PROBE_ROWS", "20224")), 32, 28, 32, 3, 2)
+    pr = ops.conv_window_probe(int(os.environ.get("EVAE_PROBE_ROWS", "19968")), 32, 28, 32, 3, 2)
     for _ in range(reps):
         pr["dgrad"]()
 elif which in ("cw1_fwd", "cw1_wgrad"):
-    n = int(os.environ.get("EVAE_PROBE_ROWS", "20224"))
+    n = int(os.environ.get("EVAE_PROBE_ROWS", "19968"))
     d = _lib.ConvDesc(n, 1, 28, 28, 32, 7, 7, 1, 3)
     x = (torch.rand(n, 28, 28, device=dev) < 0.3).float()
     wh = torch.randn(32, 1, 7, 7, device=dev) * 0.1; wg = torch.randn(32, 1, 7, 7, device=dev) * 0.1; b = torch.zeros(32, device=dev)

@@ -96,7 +96,7 @@ for probe, alts in MAIN.items():
     if not ctr:
         continue
     c = {k: sum(v) / len(v) for k, v in ctr.items()}
-    out = {"probe": "tools/kernel_probe.py %s" % probe, "rows": int(os.environ.get("EVAE_PROBE_ROWS", "20224")), "kernel": kern, "kernel_symbol": rows_all[0]["Kernel_Name"][:160], "commit": head,
+    out = {"probe": "tools/kernel_probe.py %s" % probe, "rows": int(os.environ.get("EVAE_PROBE_ROWS", "19968")), "kernel": kern, "kernel_symbol": rows_all[0]["Kernel_Name"][:160], "commit": head,
            "launches_averaged": len(next(iter(ctr.values()))), "counters_per_launch": {k: round(v, 1) for k, v in sorted(c.items())}}
     if "FETCH_SIZE" in c:
         out["hbm_read_bytes_per_launch"] = round(2 * c["FETCH_SIZE"] * 1024)
