@@ -255,7 +255,7 @@ def pmc_traffic(name, expect=None):
     process, so the bench line carries the file's number and says where it came from.  expect: the kernel symbol the launch
     this number is attached to runs -- a file whose pass profiled another kernel is refused (VERDICT r03 weak #3a: the
     dominant launch once carried the counters of a different template instance)."""
-    for rnd in ("r05_pmc", "r04_pmc", "r03_pmc", "r02_pmc"):
+    for rnd in ("r06_pmc", "r05_pmc", "r04_pmc", "r03_pmc", "r02_pmc"):
         path = os.path.join(ROOT, "profiles", rnd, str(name) + ".json")
         if os.path.exists(path):
             try:
@@ -272,7 +272,7 @@ def pmc_traffic(name, expect=None):
 
 def pmc_rows(name):
     """exemplar rows the committed PMC pass of `name` ran at (None: no file / an older file without the field = 25 000)"""
-    for rnd in ("r05_pmc", "r04_pmc", "r03_pmc", "r02_pmc"):
+    for rnd in ("r06_pmc", "r05_pmc", "r04_pmc", "r03_pmc", "r02_pmc"):
         path = os.path.join(ROOT, "profiles", rnd, str(name) + ".json")
         if os.path.exists(path):
             try:
