@@ -784,7 +784,8 @@ def main():
     t_issue = time.perf_counter() - t0          # host time to ISSUE the steps (graph launches); the fence below waits for the device
     fence()
     dt = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    per_step_raw = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    per_step = sorted(per_step_raw)
     step_ms = {"p50": round(per_step[len(per_step) // 2], 4), "p90": round(per_step[min(len(per_step) - 1, (9 * len(per_step)) // 10)], 4),
                "min": round(per_step[0], 4), "max": round(per_step[-1], 4)} if per_step else None
     ops.prior_train_check()          # the one-launch prior's co-residency guard: raises if any block of any step gave up (outside the timed region)
@@ -1052,6 +1053,7 @@ def main():
             "dp": dp_line,
             "host_issue_ms_per_step": round(1e3 * t_issue / a.steps, 4), "ramp_replays": ramp_replays, "ramp_ms": round(ramp_ms, 2), "untimed_steps": n_pre,
             "step_ms": step_ms,
+            **({"per_step_ms": [round(t_, 4) for t_ in per_step_raw]} if os.environ.get("EVAE_BENCH_DUMP_STEPS") == "1" else {}),
             "mean_loss": round(final_loss, 4), "mean_loss_f64": final_loss, "steps_in_mean_loss": n_done,
             "replicas_identical": replicas_identical,
             "exemplar_rows": (None if not dd_ else
