@@ -106,7 +106,7 @@ class BaseModel(nn.Module, ABC):
             ex_local = override[lo:hi]
         else:
             exemplars_indices = torch.randint(low=0, high=a.training_set_size, size=(C,))   # reference :245
-            eager_dd = self._dedup_draws(exemplars_indices[lo:hi])
+            eager_dd = self._dedup_draws(exemplars_indices[lo:hi]) if not exemplars_indices.is_cuda else None
             ex_local = eager_dd[0] if eager_dd is not None else self._indices_to_device(exemplars_indices[lo:hi])
         # the image store the exemplar rows are gathered from: bytes when the data are k/255 (4x less HBM, and the first
         # layer then runs on the bf16 matrix pipe, csrc/evae_dense_u8.hip), fp32 rows otherwise
