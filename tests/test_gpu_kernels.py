@@ -1304,6 +1304,47 @@ def test_prior_of_a_training_step_in_one_launch(ops, B, C, zd, masked, limit):
             lib.evae_prior_set_norm_limit(C_.c_float(-1.0))
 
 
+@pytest.mark.parametrize("B,C,N,zd", [(100, 25000, 50000, 40), (100, 4000, 4000, 40), (7, 300, 150, 8), (128, 11500, 23000, 40), (33, 129, 129, 56)])
+def test_prior_of_a_training_step_over_the_draws_of_distinct_rows(ops, B, C, N, zd):
+    """evae_prior_train_step_rows (r06): the one-launch prior of a step that encoded each DISTINCT image of its draw once (C draws with
+    replacement from N images; rows / inv / rep / mult from evae_host_dedup, distinct rows padded with multiplicity 0) -- log p, token,
+    dz, dlogvar BIT-equal to evae_prior_train_step over the gathered per-draw centres (same kernel, the centres read through the row
+    map), and its folded centre gradients equal to multiplicity x the per-draw gradient of the representative draw, padding rows zero."""
+    import ctypes as C_
+    lib = ops._lib.load()
+    rs = np.random.RandomState(C + B)
+    draws = torch.from_numpy(rs.randint(0, N, size=C).astype(np.int64))
+    cap = (C + 7) // 8 * 8
+    rows = torch.zeros(cap, dtype=torch.int64); inv = torch.zeros(C, dtype=torch.int64); rep = torch.zeros(cap, dtype=torch.int64)
+    mult = torch.zeros(cap, dtype=torch.float32)
+    nu = lib.evae_host_dedup(C_.c_void_p(draws.data_ptr()), C, N, cap, C_.c_void_p(rows.data_ptr()), C_.c_void_p(inv.data_ptr()),
+                             C_.c_void_p(rep.data_ptr()), C_.c_void_p(mult.data_ptr()))
+    assert 0 < nu <= C
+    Cd = (nu + 7) // 8 * 8
+    z, cu = gi.clustered_latents(900 + B + C, B, Cd, zd)                 # encodings of the distinct rows (padding rows: anything)
+    lv = np.linspace(-1.2, -0.4, zd).astype(np.float32)
+    zi = rs.randint(0, N, size=B).astype(np.int64)
+    zi[:3] = draws.numpy()[:3]                                           # leave-one-out hits on the draws
+    dz_, dcu, dlv_ = dev(z), dev(cu), dev(lv)
+    inv_d, rep_d, mult_d, ci_d, zi_d = inv.cuda(), rep[:Cd].cuda(), mult[:Cd].cuda(), draws.cuda(), dev(zi)
+    f = dict(device="cuda", dtype=torch.float32)
+    beta = 0.61
+    for it in range(3):                                                  # repeated launches on the same buffers (stale tokens cannot pass)
+        out = (torch.empty(B, **f), torch.empty((2, B), **f), None, torch.empty((B, zd), **f), torch.full((Cd, zd), 7.0, **f), torch.empty(zd, **f))
+        dc_draws = torch.empty((C, zd), **f)
+        ops.prior_train_step_rows(dz_, dcu, (inv_d, rep_d, mult_d), dlv_, zi_d, ci_d, C, beta, out, dc_draws)
+        cx = dcu[inv_d].contiguous()                                     # every draw's centre
+        ref = ops.prior_train_step(dz_, cx, dlv_, zi_d, ci_d, C, beta, want_coef=False)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), it
+        assert torch.equal(out[3], ref[3]) and torch.equal(out[5], ref[5]), it
+        assert torch.equal(dc_draws, ref[4]), it
+        fold = mult_d[:, None] * ref[4][rep_d]
+        assert torch.equal(out[4], fold), it
+        assert float(out[4][nu:].abs().max()) == 0.0 if Cd > nu else True
+        dz_ = dz_ * 1.01
+
+
 @pytest.mark.parametrize("M,N,K,ldd", [(100, 300, 300, 300), (100, 300, 40, 600), (100, 300, 784, 300), (100, 784, 600, 784),
                                        (7, 20, 36, 20), (128, 296, 588, 296), (1438, 300, 300, 300), (3000, 300, 784, 300)])
 def test_gated_backward_with_the_gate_derivative_in_the_operand_load(ops, M, N, K, ldd):
