@@ -66,13 +66,15 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const evae_adam_tensor_t
                                                         float omb2, float eps, float weight_decay,
                                                         const float* __restrict__ st_loss, const float* __restrict__ st_re,
                                                         const float* __restrict__ st_kl, float* __restrict__ st_step3,
-                                                        float* __restrict__ st_tot3) {
+                                                        float* __restrict__ st_tot3, int* __restrict__ st_toggle) {
   // the step's statistics (evae_step_stats_add) in this launch, the last of a captured training step: (loss, -RE, KL) of the
   // step and their running sums -- one launch less at the tail of every step
   if (st_step3 != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) {
     const float v = threadIdx.x == 0 ? st_loss[0] : (threadIdx.x == 1 ? -st_re[0] : st_kl[0]);
     st_step3[threadIdx.x] = v;
     if (st_tot3) st_tot3[threadIdx.x] += v;
+    // ... and the parity of the control block's staging blocks (evae_batch_prologue_u8_step reads it at the head of the next step)
+    if (st_toggle && threadIdx.x == 0) st_toggle[0] ^= 1;
   }
   const evae_adam_tensor_t t = ts[blockIdx.y];
   const int64_t chunk = adam_chunk(t.numel);
@@ -129,7 +131,7 @@ static int adam_normgrad_core(const evae_adam_tensor_t* tensors, int n_tensors,
                               int64_t max_numel, int step, double lr, double beta1, double beta2,
                               double eps, double weight_decay, const float* step_size_dev,
                               void* ws, size_t ws_bytes, const float* st_loss, const float* st_re, const float* st_kl,
-                              float* st_step3, float* st_tot3, evae_stream_t stream_) {
+                              float* st_step3, float* st_tot3, int* st_toggle, evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(n_tensors >= 0 && step >= 1, "adam_normgrad_step: bad arguments");
   if (n_tensors == 0) return EVAE_OK;
@@ -151,7 +153,7 @@ static int adam_normgrad_core(const evae_adam_tensor_t* tensors, int n_tensors,
   if (rc) return rc;
   adam_step_kernel<<<dim3(gx, n_tensors), 256, 0, stream>>>(tensors, part, step_size, step_size_dev, (float)beta1, (float)(1.0 - beta1),
                                                            (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay,
-                                                           st_loss, st_re, st_kl, st_step3, st_tot3);
+                                                           st_loss, st_re, st_kl, st_step3, st_tot3, st_toggle);
   return check_launch("adam_step");
 }
 
@@ -160,15 +162,15 @@ extern "C" int evae_adam_normgrad_step(const evae_adam_tensor_t* tensors, int n_
                                        double eps, double weight_decay, const float* step_size_dev,
                                        void* ws, size_t ws_bytes, evae_stream_t stream_) {
   return adam_normgrad_core(tensors, n_tensors, max_numel, step, lr, beta1, beta2, eps, weight_decay, step_size_dev, ws, ws_bytes,
-                            nullptr, nullptr, nullptr, nullptr, nullptr, stream_);
+                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream_);
 }
 
 extern "C" int evae_adam_normgrad_step_stats(const evae_adam_tensor_t* tensors, int n_tensors,
                                              int64_t max_numel, int step, double lr, double beta1, double beta2,
                                              double eps, double weight_decay, const float* step_size_dev,
                                              void* ws, size_t ws_bytes, const float* loss, const float* re, const float* kl,
-                                             float* step3, float* totals3, evae_stream_t stream_) {
+                                             float* step3, float* totals3, int* toggle, evae_stream_t stream_) {
   EVAE_REQUIRE(n_tensors > 0 && loss && re && kl && step3, "adam_normgrad_step_stats: null pointer or empty tensor table");
   return adam_normgrad_core(tensors, n_tensors, max_numel, step, lr, beta1, beta2, eps, weight_decay, step_size_dev, ws, ws_bytes,
-                            loss, re, kl, step3, totals3, stream_);
+                            loss, re, kl, step3, totals3, toggle, stream_);
 }

@@ -27,13 +27,15 @@ extern "C" int evae_ctl_upload(void* d_stage, const void* h_pinned, void* d_ctl,
                                void* ev_used_, void* ev_up_) {
   hipStream_t up = (hipStream_t)up_, step = (hipStream_t)step_;
   hipEvent_t ev_used = (hipEvent_t)ev_used_, ev_up = (hipEvent_t)ev_up_;
-  if (!d_stage || !h_pinned || !d_ctl || !ev_used || !ev_up) { evae::set_error("ctl_upload: null argument"); return EVAE_EINVAL; }
+  if (!d_stage || !h_pinned || !ev_used || !ev_up) { evae::set_error("ctl_upload: null argument"); return EVAE_EINVAL; }
   hipError_t e = hipStreamWaitEvent(up, ev_used, 0);                                   // staging block consumed two steps ago
   if (e == hipSuccess) e = hipMemcpyAsync(d_stage, h_pinned, bytes, hipMemcpyHostToDevice, up);
   if (e == hipSuccess) e = hipEventRecord(ev_up, up);                                   // host block reusable once this ran
   if (e == hipSuccess) e = hipStreamWaitEvent(step, ev_up, 0);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_ctl, d_stage, bytes, hipMemcpyDeviceToDevice, step);
-  if (e == hipSuccess) e = hipEventRecord(ev_used, step);
+  if (d_ctl) {
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ctl, d_stage, bytes, hipMemcpyDeviceToDevice, step);
+    if (e == hipSuccess) e = hipEventRecord(ev_used, step);
+  }
   if (e != hipSuccess) { evae::set_error("ctl_upload: %s", hipGetErrorString(e)); return EVAE_ELAUNCH; }
   return EVAE_OK;
 }

@@ -368,16 +368,33 @@ __global__ __launch_bounds__(256) void batch_prologue_kernel(const float* __rest
 // The same head of a step on the uint8-resident store (csrc/evae_dense_u8.hip): pixel = byte / x_div (IEEE division: the very
 // float the fp32 dataset holds), same generator streams as above; besides the fp32 batch it writes the batch's BYTES into the
 // store's staging rows (255 / 0 when binarised), which is where the first-layer kernels gather them from.
-__global__ __launch_bounds__(256) void batch_prologue_u8_kernel(const unsigned char* __restrict__ data, int64_t ldd,
-                                                                const int64_t* __restrict__ idx, int B, int D, int binarize,
-                                                                const int64_t* __restrict__ seed_ctr, float x_div,
-                                                                float* __restrict__ x_out, int64_t ldx,
-                                                                unsigned char* __restrict__ stage, int64_t lds_,
-                                                                float* __restrict__ eps_out, int zdim, int64_t nq_img,
-                                                                int pro_blocks, const float* __restrict__ wh,
-                                                                const float* __restrict__ wg, int wN, int wK,
-                                                                unsigned short* __restrict__ prepared, size_t prep_elems,
-                                                                int prep_blocks, WtJob j0, WtJob j1) {
+// The control block of a captured step (exemplar-vae_amd/evae/graph.py) handed over by the SAME launch: the host uploads step n's
+// block into staging block n & 1; this kernel reads the batch indices and the generator's counter from the staging block the
+// device-side parity word names, and further blocks copy that staging block into the control block every later launch of the
+// step reads.  The parity is flipped by the step's LAST launch (evae_adam_normgrad_step_stats' toggle): a count of finished
+// blocks in here -- one returning device-scope atomic per block on one word -- cost 95 ns per block, 238 us for the 2 500
+// blocks of this launch at c2 (tools/prologue_probe.py).  (r06: the hand-over was a device-to-device copy node in front of
+// the graph -- ~27 us of the c2 step between the blit and the seam behind it.)
+struct CtlJob {
+  const uint4* s[2];
+  uint4* ctl;
+  size_t n16;
+  const int* state;      // [0] parity of the staging block this step reads
+  size_t idx_off, seed_off;   // in 8-byte words from the start of a block
+  int blocks;
+};
+
+__device__ __forceinline__ void batch_prologue_u8_body(const unsigned char* __restrict__ data, int64_t ldd,
+                                                       const int64_t* __restrict__ idx, int B, int D, int binarize,
+                                                       const int64_t* __restrict__ seed_ctr, float x_div,
+                                                       float* __restrict__ x_out, int64_t ldx,
+                                                       unsigned char* __restrict__ stage, int64_t lds_,
+                                                       float* __restrict__ eps_out, int zdim, int64_t nq_img,
+                                                       int pro_blocks, const float* __restrict__ wh,
+                                                       const float* __restrict__ wg, int wN, int wK,
+                                                       unsigned short* __restrict__ prepared, size_t prep_elems,
+                                                       int prep_blocks, const WtJob& j0, const WtJob& j1, const uint4* ctl_src,
+                                                       const CtlJob& cj) {
   // blocks past the prologue's: the weight split of the byte-store layer (evae_u8_prepare.h) -- the two jobs are independent
   // and each is a few microseconds of one launch's latency at the head of every training step
   if ((int)blockIdx.x >= pro_blocks + prep_blocks) {
@@ -386,6 +403,10 @@ __global__ __launch_bounds__(256) void batch_prologue_u8_kernel(const unsigned c
     const int t = (int)blockIdx.x - pro_blocks - prep_blocks;
     if (t < j0.ntiles) wt_job_tile(j0, t, tile);
     else if (t - j0.ntiles < j1.ntiles) wt_job_tile(j1, t - j0.ntiles, tile);
+    else if (ctl_src) {                                 // ... and behind those: staging block -> control block
+      const int cb = t - j0.ntiles - j1.ntiles;
+      for (size_t i = (size_t)cb * 256 + threadIdx.x; i < cj.n16; i += (size_t)cj.blocks * 256) cj.ctl[i] = ctl_src[i];
+    }
     return;
   }
   if ((int)blockIdx.x >= pro_blocks) {
@@ -426,6 +447,28 @@ __global__ __launch_bounds__(256) void batch_prologue_u8_kernel(const unsigned c
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (e0 + j < n) eps_out[e0 + j] = v[j];
+}
+
+__global__ __launch_bounds__(256) void batch_prologue_u8_kernel(const unsigned char* __restrict__ data, int64_t ldd,
+                                                                const int64_t* idx, int B, int D, int binarize,
+                                                                const int64_t* seed_ctr, float x_div,
+                                                                float* __restrict__ x_out, int64_t ldx,
+                                                                unsigned char* __restrict__ stage, int64_t lds_,
+                                                                float* __restrict__ eps_out, int zdim, int64_t nq_img,
+                                                                int pro_blocks, const float* __restrict__ wh,
+                                                                const float* __restrict__ wg, int wN, int wK,
+                                                                unsigned short* __restrict__ prepared, size_t prep_elems,
+                                                                int prep_blocks, WtJob j0, WtJob j1, CtlJob cj) {
+  const uint4* src = nullptr;
+  int par = 0;
+  if (cj.state) {                                       // the staging block of THIS step: the index list and the counter are read there
+    par = cj.state[0] & 1;
+    src = cj.s[par];
+    idx = (const int64_t*)src + cj.idx_off;
+    seed_ctr = (const int64_t*)src + cj.seed_off;
+  }
+  batch_prologue_u8_body(data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img, pro_blocks, wh,
+                         wg, wN, wK, prepared, prep_elems, prep_blocks, j0, j1, src, cj);
 }
 
 // ELBO assembly on [B] rows in one launch: KL_i = logq_i - logp_i, loss_i = beta*KL_i - RE_i, and the three
@@ -588,20 +631,56 @@ extern "C" int evae_batch_prologue(const float* data, int64_t ldd, const int64_t
   return check_launch("batch_prologue");
 }
 
-extern "C" int evae_batch_prologue_u8(const unsigned char* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
-                                      const int64_t* seed_ctr, float x_div, float* x_out, int64_t ldx, unsigned char* stage,
-                                      int64_t lds_, float* eps_out, int zdim, evae_stream_t s) {
-  EVAE_REQUIRE(B >= 0 && D > 0 && zdim >= 0 && ldd >= D && ldx >= D && lds_ >= D && x_div > 0.f, "batch_prologue_u8: bad sizes");
-  if (B == 0) return EVAE_OK;
-  EVAE_REQUIRE(data && idx && x_out && stage && seed_ctr, "batch_prologue_u8: null pointer");
-  EVAE_REQUIRE(eps_out == nullptr || zdim > 0, "batch_prologue_u8: eps_out needs zdim > 0");
+// One launch for the whole head of a step on the byte store: the batch, optionally the first layer's weight split and the
+// backward pass's weight transpositions, optionally the hand-over of the step's control block (CtlJob above).
+static int launch_prologue_u8(const char* who, const unsigned char* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
+                              const int64_t* seed_ctr, float x_div, float* x_out, int64_t ldx, unsigned char* stage, int64_t lds_,
+                              float* eps_out, int zdim, const float* wh, const float* wg, int N, int K, void* prepared,
+                              size_t prepared_bytes, const evae_wt_job_t* jobs, int njobs, const evae_ctl_job_t* ctl, evae_stream_t s) {
+  EVAE_REQUIRE(B > 0 && D > 0 && zdim >= 0 && ldd >= D && ldx >= D && lds_ >= D && x_div > 0.f, "%s: bad sizes", who);
+  EVAE_REQUIRE(data && x_out && stage && ((idx && seed_ctr) || ctl), "%s: null pointer", who);
+  EVAE_REQUIRE(eps_out == nullptr || zdim > 0, "%s: eps_out needs zdim > 0", who);
+  size_t elems = 0;
+  if (wh || wg || prepared) {
+    EVAE_REQUIRE(N > 0 && K > 0 && wh && wg && prepared, "%s: bad weight arguments", who);
+    elems = u8_prepare_elems(N, K);
+    EVAE_REQUIRE(prepared_bytes >= elems * 3 * sizeof(unsigned short), "%s: buffer too small (%zu)", who, prepared_bytes);
+  }
   const int64_t nq_img = ((int64_t)B * D + 3) / 4;
   const int64_t nq_eps = eps_out ? ((int64_t)B * zdim + 3) / 4 : 0;
   const unsigned pro = (unsigned)cdiv(nq_img + nq_eps, (int64_t)256);
-  batch_prologue_u8_kernel<<<pro, 256, 0, (hipStream_t)s>>>(
-      data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img, (int)pro, nullptr, nullptr,
-      0, 0, nullptr, 0, 0, WtJob{}, WtJob{});
-  return check_launch("batch_prologue_u8");
+  const unsigned prep = (unsigned)((elems + 255) / 256);
+  EVAE_REQUIRE(njobs >= 0 && njobs <= 2 && (njobs == 0 || jobs != nullptr), "%s: at most two transposition jobs", who);
+  WtJob wj[2] = {WtJob{}, WtJob{}};
+  for (int i = 0; i < njobs; ++i) {
+    const evae_wt_job_t& q = jobs[i];
+    EVAE_REQUIRE(q.w1 && q.dst && q.N > 0 && q.K > 0 && q.ldt >= q.N, "%s: bad transposition job", who);
+    wj[i].w1 = q.w1; wj[i].w2 = q.w2; wj[i].dst = q.dst; wj[i].N = q.N; wj[i].K = q.K; wj[i].ldt = q.ldt;
+    wj[i].tx = cdiv(q.K, 32); wj[i].ty = cdiv(q.ldt, 32); wj[i].ntiles = wj[i].tx * wj[i].ty * (q.w2 ? 2 : 1);
+  }
+  CtlJob cj{};
+  if (ctl) {
+    EVAE_REQUIRE(ctl->stage0 && ctl->stage1 && ctl->ctl && ctl->state && ctl->bytes > 0 && ctl->bytes % 16 == 0, "%s: bad control-block job", who);
+    EVAE_REQUIRE((((uintptr_t)ctl->stage0 | (uintptr_t)ctl->stage1 | (uintptr_t)ctl->ctl) & 15) == 0, "%s: unaligned control block", who);
+    EVAE_REQUIRE((ctl->idx_word + (size_t)B) * 8 <= ctl->bytes && (ctl->seed_word + 2) * 8 <= ctl->bytes, "%s: control-block fields outside the block", who);
+    cj.s[0] = (const uint4*)ctl->stage0; cj.s[1] = (const uint4*)ctl->stage1; cj.ctl = (uint4*)ctl->ctl;
+    cj.n16 = ctl->bytes / 16; cj.state = (const int*)ctl->state; cj.idx_off = ctl->idx_word; cj.seed_off = ctl->seed_word;
+    cj.blocks = (int)std::min<size_t>(128, (cj.n16 + 255) / 256);
+  }
+  batch_prologue_u8_kernel<<<pro + prep + (unsigned)(wj[0].ntiles + wj[1].ntiles + cj.blocks), 256, 0, (hipStream_t)s>>>(
+      data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img, (int)pro, wh, wg, N, K,
+      (unsigned short*)prepared, elems, (int)prep, wj[0], wj[1], cj);
+  return check_launch(who);
+}
+
+extern "C" int evae_batch_prologue_u8(const unsigned char* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
+                                      const int64_t* seed_ctr, float x_div, float* x_out, int64_t ldx, unsigned char* stage,
+                                      int64_t lds_, float* eps_out, int zdim, evae_stream_t s) {
+  EVAE_REQUIRE(B >= 0, "batch_prologue_u8: bad sizes");
+  if (B == 0) return EVAE_OK;
+  EVAE_REQUIRE(idx && seed_ctr, "batch_prologue_u8: null pointer");
+  return launch_prologue_u8("batch_prologue_u8", data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim,
+                            nullptr, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, s);
 }
 
 // The same launch also splits the first layer's weights into the byte kernels' bf16 tile images (evae_dense_u8_prepare): the
@@ -611,28 +690,19 @@ extern "C" int evae_batch_prologue_u8_prepare(const unsigned char* data, int64_t
                                               unsigned char* stage, int64_t lds_, float* eps_out, int zdim, const float* wh,
                                               const float* wg, int N, int K, void* prepared, size_t prepared_bytes,
                                               const evae_wt_job_t* jobs, int njobs, evae_stream_t s) {
-  EVAE_REQUIRE(B > 0 && D > 0 && zdim >= 0 && ldd >= D && ldx >= D && lds_ >= D && x_div > 0.f, "batch_prologue_u8_prepare: bad sizes");
-  EVAE_REQUIRE(data && idx && x_out && stage && seed_ctr, "batch_prologue_u8_prepare: null pointer");
-  EVAE_REQUIRE(eps_out == nullptr || zdim > 0, "batch_prologue_u8_prepare: eps_out needs zdim > 0");
-  EVAE_REQUIRE(N > 0 && K > 0 && wh && wg && prepared, "batch_prologue_u8_prepare: bad weight arguments");
-  const size_t elems = u8_prepare_elems(N, K);
-  EVAE_REQUIRE(prepared_bytes >= elems * 3 * sizeof(unsigned short), "batch_prologue_u8_prepare: buffer too small (%zu)", prepared_bytes);
-  const int64_t nq_img = ((int64_t)B * D + 3) / 4;
-  const int64_t nq_eps = eps_out ? ((int64_t)B * zdim + 3) / 4 : 0;
-  const unsigned pro = (unsigned)cdiv(nq_img + nq_eps, (int64_t)256);
-  const unsigned prep = (unsigned)((elems + 255) / 256);
-  EVAE_REQUIRE(njobs >= 0 && njobs <= 2 && (njobs == 0 || jobs != nullptr), "batch_prologue_u8_prepare: at most two transposition jobs");
-  WtJob wj[2] = {WtJob{}, WtJob{}};
-  for (int i = 0; i < njobs; ++i) {
-    const evae_wt_job_t& q = jobs[i];
-    EVAE_REQUIRE(q.w1 && q.dst && q.N > 0 && q.K > 0 && q.ldt >= q.N, "batch_prologue_u8_prepare: bad transposition job");
-    wj[i].w1 = q.w1; wj[i].w2 = q.w2; wj[i].dst = q.dst; wj[i].N = q.N; wj[i].K = q.K; wj[i].ldt = q.ldt;
-    wj[i].tx = cdiv(q.K, 32); wj[i].ty = cdiv(q.ldt, 32); wj[i].ntiles = wj[i].tx * wj[i].ty * (q.w2 ? 2 : 1);
-  }
-  batch_prologue_u8_kernel<<<pro + prep + (unsigned)(wj[0].ntiles + wj[1].ntiles), 256, 0, (hipStream_t)s>>>(
-      data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img, (int)pro, wh, wg, N, K,
-      (unsigned short*)prepared, elems, (int)prep, wj[0], wj[1]);
-  return check_launch("batch_prologue_u8_prepare");
+  EVAE_REQUIRE(idx && seed_ctr && wh && wg && prepared, "batch_prologue_u8_prepare: null pointer");
+  return launch_prologue_u8("batch_prologue_u8_prepare", data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_,
+                            eps_out, zdim, wh, wg, N, K, prepared, prepared_bytes, jobs, njobs, nullptr, s);
+}
+
+// ... and the step's control block (wh / wg / prepared NULL: no weight split)
+extern "C" int evae_batch_prologue_u8_step(const unsigned char* data, int64_t ldd, int B, int D, int binarize, float x_div,
+                                           float* x_out, int64_t ldx, unsigned char* stage, int64_t lds_, float* eps_out, int zdim,
+                                           const float* wh, const float* wg, int N, int K, void* prepared, size_t prepared_bytes,
+                                           const evae_wt_job_t* jobs, int njobs, const evae_ctl_job_t* ctl, evae_stream_t s) {
+  EVAE_REQUIRE(ctl, "batch_prologue_u8_step: no control-block job");
+  return launch_prologue_u8("batch_prologue_u8_step", data, ldd, nullptr, B, D, binarize, nullptr, x_div, x_out, ldx, stage, lds_,
+                            eps_out, zdim, wh, wg, N, K, prepared, prepared_bytes, jobs, njobs, ctl, s);
 }
 
 extern "C" int evae_elu_fwd(const float* x, size_t n, float* out, evae_stream_t s) {

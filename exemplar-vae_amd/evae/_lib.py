@@ -29,6 +29,12 @@ class WtJob(C.Structure):
     _fields_ = [("w1", C.c_void_p), ("w2", C.c_void_p), ("dst", C.c_void_p), ("N", C.c_int), ("K", C.c_int), ("ldt", C.c_int)]
 
 
+class CtlJob(C.Structure):
+    """evae_ctl_job_t"""
+    _fields_ = [("stage0", C.c_void_p), ("stage1", C.c_void_p), ("ctl", C.c_void_p), ("bytes", C.c_size_t), ("state", C.c_void_p),
+                ("idx_word", C.c_size_t), ("seed_word", C.c_size_t)]
+
+
 class WgradJob(C.Structure):
     """evae_wgrad_job_t"""
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("M", C.c_int), ("N", C.c_int),
@@ -179,13 +185,14 @@ SIGNATURES = {
     "evae_batch_prologue_u8": (_i, [_p, _l, _p, _i, _i, _i, _p, _f, _p, _l, _p, _l, _p, _i, _p]),
     "evae_batch_prologue_u8_prepare": (_i, [_p, _l, _p, _i, _i, _i, _p, _f, _p, _l, _p, _l, _p, _i, _p, _p, _i, _i, _p, _z, _p, _i,
                                             _p]),
+    "evae_batch_prologue_u8_step": (_i, [_p, _l, _i, _i, _i, _f, _p, _l, _p, _l, _p, _i, _p, _p, _i, _i, _p, _z, _p, _i, _p, _p]),
     "evae_bernoulli_ll_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_bernoulli_sigmoid_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_log_logistic256_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "evae_log_logistic256_bwd": (_i, [_p, _p, _p, _i, _p, _i, _i, _p, _p, _p, _p]),
     "evae_adam_normgrad_workspace_bytes": (_z, [_i]),
     "evae_adam_normgrad_step": (_i, [_p, _i, _l, _i, _d, _d, _d, _d, _d, _p, _p, _z, _p]),
-    "evae_adam_normgrad_step_stats": (_i, [_p, _i, _l, _i, _d, _d, _d, _d, _d, _p, _p, _z, _p, _p, _p, _p, _p, _p]),
+    "evae_adam_normgrad_step_stats": (_i, [_p, _i, _l, _i, _d, _d, _d, _d, _d, _p, _p, _z, _p, _p, _p, _p, _p, _p, _p]),
 }
 
 _lib = None

@@ -121,6 +121,7 @@ class GraphedTrainStep:
             self._o_rep = self._o_inv + Cl
             self._o_mult = self._o_rep + Cd
             words = self._o_mult + (Cd + 1) // 2
+        words += words & 1                          # (whole 16-byte words: the prologue's hand-over copies uint4s)
         self.ctl = torch.zeros(words, dtype=torch.int64, device=dev)
         self.rows = self.ctl[:self._o_idx]
         self.idx_flat = self.ctl[self._o_idx:self._o_seed]
@@ -159,6 +160,14 @@ class GraphedTrainStep:
         for ev in self._ev_up + self._ev_used:
             ev.record()                            # (their handles exist from here on)
         self._ctl_bytes = words * 8
+        # r06: on the byte store the step's FIRST launch hands the block over itself (evae_batch_prologue_u8_step: it reads the
+        # batch indices and the counter from staging block `parity`, copies that block into self.ctl for every later launch, and
+        # the step's LAST launch -- the optimizer's, which carries the statistics too -- flips the parity): no device-to-device
+        # copy node in front of the graph.  The parity lives on the device; eager steps set it from the host's count.
+        self._handover = ((not self._direct) and self.u8 and os.environ.get("EVAE_CTL_HANDOVER", "1") != "0"
+                          and os.environ.get("EVAE_TAIL_MERGE", "1") != "0")
+        self._ho_state = torch.zeros(2, dtype=torch.int32, device=dev)
+        self._ho_par = [torch.full((1,), k, dtype=torch.int32, device=dev) for k in range(2)]
         self.by_index = None      # True once the loader's images are known to be rows of the resident dataset
         # by-index batches are gathered, binarised and given their eps by ONE launch with a counter-based generator
         # (evae_batch_prologue); the seed is torch's at construction time, the counter is the step number
@@ -244,8 +253,13 @@ class GraphedTrainStep:
             # of the fused step, no image bytes cross PCIe
             if self.u8:
                 x = self.x_in
+                job = None
+                if self._handover:
+                    job = (self._d_ctl[0], self._d_ctl[1], self.ctl, self._ho_state, self._o_idx, self._o_seed)
+                    if not torch.cuda.is_current_stream_capturing():
+                        self._ho_state[:1].copy_(self._ho_par[self._calls & 1])     # (eager: the block this call uploaded)
                 ops.batch_prologue_u8(self.data_rows, self.idx_flat, self.binarize, self.seed_ctr, self.x_div, x,
-                                      self.stage_rows, self.eps_buf, prepare=self._first_layer_split())
+                                      self.stage_rows, self.eps_buf, prepare=self._first_layer_split(), ctl_job=job)
             else:
                 x = self.stage_rows
                 ops.batch_prologue(self.data_rows, self.idx_flat, self.binarize, self.seed_ctr, x, self.eps_buf)
@@ -271,6 +285,9 @@ class GraphedTrainStep:
             loss.backward(gradient=self._one)
         # the step's statistics ride in the optimizer's last launch (evae_adam_normgrad_step_stats)
         stats = (loss.detach(), RE.detach(), KL.detach(), self.out, self.totals) if os.environ.get("EVAE_TAIL_MERGE", "1") != "0" else None
+        ho = self._handover and self.by_index
+        if ho and stats is not None:
+            stats = stats + (self._ho_state,)     # (the parity of the control block's staging blocks: flipped by the same launch)
         if eager_opt:
             # the reference's own bookkeeping (a step count per parameter, host-side step size): the runner's first call, which
             # learns which parameters take part at all, and every call of a runner whose participants disagree on the count
@@ -280,10 +297,12 @@ class GraphedTrainStep:
             self.opt.step(_captured=True, _tables=self._adam_tables if tables is None else tables, _stats=stats)
         if not getattr(self.opt, "_stats_done", False):
             ops.step_stats_add(loss.detach(), RE.detach(), KL.detach(), self.out, self.totals)
+            if ho:
+                self._ho_state[:1].bitwise_xor_(1)
         return self.out
 
     def _refresh(self, data, indices, beta):
-        k = self._calls & 1
+        k = self._k_used = self._calls & 1
         Cl = self.hi - self.lo
         a = self.model.args
         if self.by_index is None:                 # once: are the loader's images the resident rows its indices name?
@@ -349,13 +368,15 @@ class GraphedTrainStep:
         else:
             # upload stream: wait until staging block k was consumed (two steps ago), copy the host block there; step stream: wait
             # for that upload, one device-to-device copy into the control block (evae_ctl_upload: the six operations as one call)
+            ho = self._handover and self.by_index
             _lib.check(_lib.load().evae_ctl_upload(C.c_void_p(self._d_ctl[k].data_ptr()), C.c_void_p(h.data_ptr()),
-                                                   C.c_void_p(self.ctl.data_ptr()), self._ctl_bytes,
+                                                   None if ho else C.c_void_p(self.ctl.data_ptr()), self._ctl_bytes,
                                                    C.c_void_p(self._up.cuda_stream), C.c_void_p(torch.cuda.current_stream().cuda_stream),
                                                    C.c_void_p(self._ev_used[k].cuda_event), C.c_void_p(self._ev_up[k].cuda_event)),
                        "evae_ctl_upload")
         if idx_on_device:
-            self.idx_in.copy_(indices.reshape(self.B, 1))
+            dst = self._d_ctl[k][self._o_idx:self._o_seed] if (self._handover and self.by_index and not self._direct) else self.idx_flat
+            dst.copy_(indices.reshape(self.B))
         if not self.by_index:
             self.x_in.copy_(data.reshape(self.B, -1), non_blocking=True)
         if T: T.lap("upload + copies", t0)
@@ -377,6 +398,8 @@ class GraphedTrainStep:
             self._calls += 1
             return self.out
         finally:
+            if self._handover and self.by_index:
+                self._ev_used[self._k_used].record()      # (staging block k was read by this step's first launch)
             self.model._exemplar_indices_override = None
             self.model._exemplar_dedup = None
             self.model._eps_override = None
@@ -474,6 +497,8 @@ class GraphedTrainStep:
                 shard.check_replicas(self.model.parameters())      # (replica mode's guard: raises when the ranks drifted apart)
             return self.out
         finally:
+            if self._handover and self.by_index:
+                self._ev_used[self._k_used].record()      # (staging block k was read by this step's first launch)
             self.model._exemplar_indices_override = None
             self.model._exemplar_dedup = None
             self.model._eps_override = None

@@ -2159,9 +2159,11 @@ def batch_prologue(data, idx, binarize, seed_ctr, x_out, eps_out=None):
     return x_out, eps_out
 
 
-def batch_prologue_u8(data_u8, idx, binarize, seed_ctr, x_div, x_out, stage_u8, eps_out=None, prepare=None):
+def batch_prologue_u8(data_u8, idx, binarize, seed_ctr, x_div, x_out, stage_u8, eps_out=None, prepare=None, ctl_job=None):
     """batch_prologue on the uint8-resident store: x_out [B x D] fp32 and the batch's bytes into stage_u8 [B x D].
-    prepare = (wh, wg, out): the same launch also splits the first layer's weights (u8_prepare) into `out`."""
+    prepare = (wh, wg, out): the same launch also splits the first layer's weights (u8_prepare) into `out`.
+    ctl_job = (stage0, stage1, ctl, state, idx_word, seed_word): the same launch hands over a captured step's control block
+    (evae_batch_prologue_u8_step): idx / seed_ctr are then read from the staging block the device-side parity names."""
     lib = _lib.load()
     _need_cuda(data_u8, idx, seed_ctr, x_out, stage_u8)
     B, D = x_out.shape
@@ -2172,6 +2174,8 @@ def batch_prologue_u8(data_u8, idx, binarize, seed_ctr, x_div, x_out, stage_u8, 
     if eps_out is not None:
         assert eps_out.is_contiguous() and eps_out.dtype == torch.float32 and eps_out.shape[0] == B
         zd = eps_out.shape[1]
+    wh = wg = out = None
+    jobs, arr = [], None
     if prepare is not None:
         wh, wg, out = prepare[:3]
         jobs = prepare[3] if len(prepare) > 3 else []        # [(w1, w2 or None, dst)]: transposed weights for the data gradients
@@ -2184,9 +2188,23 @@ def batch_prologue_u8(data_u8, idx, binarize, seed_ctr, x_div, x_out, stage_u8, 
             arr[i].N, arr[i].K = w1.shape
             arr[i].ldt = lib.evae_dense_bwd_data_wt_ld(w1.shape[0])
             assert dst.numel() * dst.element_size() >= lib.evae_dense_bwd_data_wt_bytes(w1.shape[0], w1.shape[1], 1 if w2 is None else 2)
+    N, K = (wh.shape if wh is not None else (0, 0))
+    if ctl_job is not None:
+        s0, s1, ctl, state, idx_word, seed_word = ctl_job
+        _need_cuda(s0, s1, ctl, state)
+        assert s0.dtype == s1.dtype == ctl.dtype == torch.int64 and s0.numel() == s1.numel() == ctl.numel() and ctl.numel() % 2 == 0
+        assert state.dtype == torch.int32 and state.numel() >= 2 and s0.is_contiguous() and s1.is_contiguous() and ctl.is_contiguous()
+        cj = _lib.CtlJob(s0.data_ptr(), s1.data_ptr(), ctl.data_ptr(), ctl.numel() * 8, state.data_ptr(), int(idx_word), int(seed_word))
+        _lib.check(lib.evae_batch_prologue_u8_step(_p(data_u8), data_u8.stride(0), B, D, 1 if binarize else 0, float(x_div), _p(x_out),
+                                                   x_out.stride(0), _p(stage_u8), stage_u8.stride(0), _p(eps_out), zd, _p(wh), _p(wg),
+                                                   N, K, _p(out), out.numel() if out is not None else 0,
+                                                   C.cast(arr, C.c_void_p) if jobs else None, len(jobs), C.addressof(cj), _stream()),
+                   "evae_batch_prologue_u8_step")
+        return x_out, eps_out
+    if prepare is not None:
         _lib.check(lib.evae_batch_prologue_u8_prepare(_p(data_u8), data_u8.stride(0), _p(idx), B, D, 1 if binarize else 0,
                                                       _p(seed_ctr), float(x_div), _p(x_out), x_out.stride(0), _p(stage_u8),
-                                                      stage_u8.stride(0), _p(eps_out), zd, _p(wh), _p(wg), wh.shape[0], wh.shape[1],
+                                                      stage_u8.stride(0), _p(eps_out), zd, _p(wh), _p(wg), N, K,
                                                       _p(out), out.numel(), C.cast(arr, C.c_void_p) if jobs else None, len(jobs),
                                                       _stream()), "evae_batch_prologue_u8_prepare")
         return x_out, eps_out
@@ -2208,7 +2226,7 @@ def adam_flush_tables(table_caches):
 def adam_normgrad_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps, weight_decay,
                        table_cache=None, step_size_dev=None, stats=None):
     """One multi-tensor AdamNormGrad update (utils/optimizer.py:32-80).  `table_cache` (a dict) lets the
-    caller reuse the device pointer table while the tensor addresses stay the same.  `stats` = (loss, re, kl, step3, totals3):
+    caller reuse the device pointer table while the tensor addresses stay the same.  `stats` = (loss, re, kl, step3, totals3[, toggle]):
     the update's last launch also does step_stats_add's work (the captured training step: one launch less at its tail)."""
     lib = _lib.load()
     n = len(params)
@@ -2261,11 +2279,13 @@ def adam_normgrad_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, be
     nb = lib.evae_adam_normgrad_workspace_bytes(n)
     ws = _workspace("adam", nb, dev)
     if stats is not None:
-        loss, re, kl, step3, totals3 = stats
+        loss, re, kl, step3, totals3 = stats[:5]
+        toggle = stats[5] if len(stats) > 5 else None       # int32 device word the launch XORs with 1 (evae/graph.py's hand-over)
+        assert toggle is None or (toggle.dtype == torch.int32 and toggle.is_cuda)
         _lib.check(lib.evae_adam_normgrad_step_stats(_p(table), n, max(p.numel() for p in params), int(step), float(lr),
                                                      float(beta1), float(beta2), float(eps), float(weight_decay),
                                                      _p(step_size_dev), _p(ws), ws.numel(), _p(loss), _p(re), _p(kl), _p(step3),
-                                                     _p(totals3), _stream()), "evae_adam_normgrad_step_stats")
+                                                     _p(totals3), _p(toggle), _stream()), "evae_adam_normgrad_step_stats")
         return
     _lib.check(lib.evae_adam_normgrad_step(_p(table), n, max(p.numel() for p in params), int(step), float(lr),
                                            float(beta1), float(beta2), float(eps), float(weight_decay),

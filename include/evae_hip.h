@@ -41,7 +41,9 @@ int evae_version(void);
 const char* evae_last_error(void);
 /* Host-side helper of the captured training step (no reference counterpart: utils/training.py:27-46 feeds every step from the host):
  * the double-buffered upload of the step's control block -- wait(up, ev_used); copy h_pinned -> d_stage on `up`; record(ev_up, up);
- * wait(step, ev_up); copy d_stage -> d_ctl on `step`; record(ev_used, step) -- as one call.  ev_*: hipEvent_t handles. */
+ * wait(step, ev_up); copy d_stage -> d_ctl on `step`; record(ev_used, step) -- as one call.  ev_*: hipEvent_t handles.
+ * d_ctl = NULL: no device copy and no record(ev_used) -- the step's first launch takes the block from d_stage itself
+ * (evae_batch_prologue_u8_step) and the caller records ev_used behind the step. */
 int evae_ctl_upload(void* d_stage, const void* h_pinned, void* d_ctl, size_t bytes, evae_stream_t up, evae_stream_t step,
                     void* ev_used, void* ev_up);
 
@@ -654,6 +656,17 @@ int evae_batch_prologue_u8_prepare(const unsigned char* data, int64_t ldd, const
                                    int64_t lds, float* eps_out, int zdim, const float* wh, const float* wg, int N, int K,
                                    void* prepared, size_t prepared_bytes, const evae_wt_job_t* jobs, int njobs,
                                    evae_stream_t stream);
+/* ... and the hand-over of a captured step's control block in the same launch (exemplar-vae_amd/evae/graph.py): the host
+ * uploads step n's block into staging block n & 1 (evae_ctl_upload with d_ctl = NULL); the launch reads the batch indices
+ * (idx_word) and the generator's (seed, counter) pair (seed_word; 8-byte words from the start of a block) from the staging block
+ * that the parity word state[0] names (0 / 1) and copies that block into `ctl`, which every later launch of the step reads.
+ * The launch does not write the parity: the step's last launch flips it (evae_adam_normgrad_step_stats' toggle) or the caller
+ * sets it.  bytes: a multiple of 16.  wh / wg / prepared may be NULL (no weight split). */
+typedef struct { const void* stage0; const void* stage1; void* ctl; size_t bytes; const int* state; size_t idx_word, seed_word; } evae_ctl_job_t;
+int evae_batch_prologue_u8_step(const unsigned char* data, int64_t ldd, int B, int D, int binarize, float x_div, float* x_out,
+                                int64_t ldx, unsigned char* stage, int64_t lds, float* eps_out, int zdim, const float* wh,
+                                const float* wg, int N, int K, void* prepared, size_t prepared_bytes, const evae_wt_job_t* jobs,
+                                int njobs, const evae_ctl_job_t* ctl, evae_stream_t stream);
 /* evae_log_normal_diag_bwd with the Hardtanh(lo, hi) of a log-variance head folded in: dlv_pre is the gradient of its pre-activation */
 int evae_log_normal_diag_bwd_hardtanh(const float* x, const float* mu, const float* logvar, const float* lv_pre, float lo, float hi,
                                       const float* dout, int B, int zdim, float* dx, float* dmu, float* dlv_pre, evae_stream_t stream);
@@ -696,11 +709,12 @@ int evae_adam_normgrad_step(const evae_adam_tensor_t* tensors /* device */, int 
                             double weight_decay, const float* step_size_dev /* device scalar or NULL */,
                             void* ws, size_t ws_bytes, evae_stream_t stream);
 /* The same, and in its last launch the statistics of evae_step_stats_add (step3 = (loss, -re, kl), totals3 += step3; totals3
- * may be NULL): the tail of a captured training step is one launch shorter (utils/training.py:41-46). */
+ * may be NULL): the tail of a captured training step is one launch shorter (utils/training.py:41-46).  toggle (may be NULL): a
+ * device word that launch XORs with 1 -- the parity of the control block's staging blocks (evae_batch_prologue_u8_step). */
 int evae_adam_normgrad_step_stats(const evae_adam_tensor_t* tensors /* device */, int n_tensors, int64_t max_numel, int step,
                                   double lr, double beta1, double beta2, double eps, double weight_decay,
                                   const float* step_size_dev, void* ws, size_t ws_bytes, const float* loss, const float* re,
-                                  const float* kl, float* step3, float* totals3, evae_stream_t stream);
+                                  const float* kl, float* step3, float* totals3, int* toggle, evae_stream_t stream);
 
 #ifdef __cplusplus
 }

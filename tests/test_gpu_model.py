@@ -1707,6 +1707,61 @@ def test_a_draw_with_too_many_distinct_rows_steps_eagerly_once(model_name, monke
         assert rel(p1[k_], p0[k_]) < 2e-5, k_
 
 
+@pytest.mark.parametrize("model_name", ["vae", "hvae_2level"])
+def test_control_block_handed_over_by_the_first_launch_equals_the_copied_one(model_name, monkeypatch):
+    """r06: on the byte store the step's first launch takes the control block from the staging block a device-side parity word
+    names and copies it on (evae_batch_prologue_u8_step); the optimizer's last launch flips the parity.  Same trajectory as the
+    device-to-device copy in front of the graph (EVAE_CTL_HANDOVER=0) across warm-up, capture, replays, one eager every-draw step
+    (a draw that does not fit) and one step_eagerly in between; parity and step counter in step with the host's count."""
+    monkeypatch.setenv("EVAE_DEDUP", "1")
+    monkeypatch.setenv("EVAE_CTL_DIRECT", "0")         # (the staged upload, as at c2: thin steps upload straight into the block)
+    from evae import _lib
+    from evae.graph import GraphedTrainStep
+    from utils.optimizer import AdamNormGrad
+    from utils.utils import importing_model
+    B, C, N = 100, 4000, 4000
+    data = gi.binary_images(15, N)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    lib = _lib.load()
+    real = lib.evae_host_dedup
+    results = []
+    for handover in ("0", "1"):
+        monkeypatch.setenv("EVAE_CTL_HANDOVER", handover)
+        args = smoke_case.vae_args(model_name=model_name, number_components=C, training_set_size=N, batch_size=B)
+        torch.manual_seed(5); torch.cuda.manual_seed(5)
+        model = importing_model(args)(args).cuda()
+        model.train()
+        opt = AdamNormGrad(model.parameters(), lr=5e-4)
+        torch.manual_seed(13); torch.cuda.manual_seed(13)
+        runner = GraphedTrainStep(model, opt, dataset, B, False)
+        on = handover == "1" and model_name == "vae"       # (the byte store -- and with it the hand-over -- is the fused `vae` step's)
+        assert runner._handover == on and not runner._direct
+        calls = {"n": 0}
+
+        def dedup(*a, calls=calls):
+            calls["n"] += 1
+            return -1 if calls["n"] - 1 == 4 else real(*a)
+        monkeypatch.setattr(lib, "evae_host_dedup", dedup)
+        losses = []
+        with _lib.count_calls("evae_batch_prologue_u8_step") as n_step:
+            for it in range(10):
+                xb = torch.from_numpy(data[it * B:(it + 1) * B])
+                ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1)
+                step = runner.step_eagerly if it == 6 else runner
+                losses.append(step(xb, ib, 0.5)[0].item())
+                if on:
+                    assert int(runner._ho_state[0]) == runner._calls & 1, it
+                    assert int(runner.ctl[runner._o_seed + 1]) == runner._calls - 1, it
+        monkeypatch.setattr(lib, "evae_host_dedup", real)
+        assert runner.graph is not None and not runner.failed and runner.overflow_steps == 1
+        assert (n_step.get("evae_batch_prologue_u8_step", 0) > 0) == on
+        results.append((losses, {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}))
+    (l0, p0), (l1, p1) = results
+    assert rel(np.asarray(l1), np.asarray(l0)) < 1e-5
+    for k_ in p0:
+        assert rel(p1[k_], p0[k_]) < 2e-5, k_
+
+
 @pytest.mark.parametrize("model_name", ["hvae_2level", "convhvae_2level", "vae_modular"])
 def test_graphed_modular_step_over_distinct_exemplar_rows_matches_eager(model_name, monkeypatch):
     """EVAE_DEDUP on the modular autograd path (r04): get_exemplar_set encodes the DISTINCT rows of the draw and hands the prior
