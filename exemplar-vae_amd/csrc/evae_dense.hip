@@ -274,16 +274,44 @@ extern "C" size_t evae_heads_reparam_fwd_workspace_bytes(int M, int K, int Z) {
   return align_up((size_t)heads_plan(M, K, Z).nz * 2 * M * Z * sizeof(float), 256) + 256;
 }
 
+static int heads_reparam_fwd_core(const float* x, int M, int K, int ldx, const float* wm, const float* bm, const float* wl,
+                                  const float* bl, int Z, float lv_lo, float lv_hi, const float* eps, float* z_mean,
+                                  float* lv_pre, float* logvar, float* z, float* logq, void* ws, size_t ws_bytes,
+                                  const float* bc_src, float* bc_dst, int bc_n, evae_stream_t stream_);
+
 extern "C" int evae_heads_reparam_fwd(const float* x, int M, int K, int ldx, const float* wm, const float* bm, const float* wl,
                                       const float* bl, int Z, float lv_lo, float lv_hi, const float* eps, float* z_mean,
                                       float* lv_pre, float* logvar, float* z, float* logq, void* ws, size_t ws_bytes,
                                       evae_stream_t stream_) {
+  return heads_reparam_fwd_core(x, M, K, ldx, wm, bm, wl, bl, Z, lv_lo, lv_hi, eps, z_mean, lv_pre, logvar, z, logq, ws, ws_bytes,
+                                nullptr, nullptr, 0, stream_);
+}
+
+// ... and dst[0 .. n) = src[0] in the same launch when the batch-sized kernel serves (evae_broadcast_scalar's work: the exemplar
+// prior's log-variance row, which the step's prior launch reads behind this one); returns EVAE_EINVAL without launching anything
+// when it does not (evae_heads_reparam_fwd_bcast_applies says so up front).
+extern "C" int evae_heads_reparam_fwd_bcast_applies(int M, int K, int Z, int ldx) {
+  return M > 0 && thin_heads_ok(M, K, Z, ldx, nullptr, nullptr, nullptr) ? 1 : 0;
+}
+extern "C" int evae_heads_reparam_fwd_bcast(const float* x, int M, int K, int ldx, const float* wm, const float* bm, const float* wl,
+                                            const float* bl, int Z, float lv_lo, float lv_hi, const float* eps, float* z_mean,
+                                            float* lv_pre, float* logvar, float* z, float* logq, const float* src, float* dst,
+                                            int n, evae_stream_t stream_) {
+  EVAE_REQUIRE(src && dst && n > 0 && M > 0 && thin_heads_ok(M, K, Z, ldx, x, wm, wl), "heads_reparam_fwd_bcast: not the batch-sized case");
+  return heads_reparam_fwd_core(x, M, K, ldx, wm, bm, wl, bl, Z, lv_lo, lv_hi, eps, z_mean, lv_pre, logvar, z, logq, nullptr, 0,
+                                src, dst, n, stream_);
+}
+
+static int heads_reparam_fwd_core(const float* x, int M, int K, int ldx, const float* wm, const float* bm, const float* wl,
+                                  const float* bl, int Z, float lv_lo, float lv_hi, const float* eps, float* z_mean,
+                                  float* lv_pre, float* logvar, float* z, float* logq, void* ws, size_t ws_bytes,
+                                  const float* bc_src, float* bc_dst, int bc_n, evae_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVAE_REQUIRE(M >= 0 && K > 0 && Z > 0 && ldx >= K, "heads_reparam_fwd: bad sizes M=%d K=%d Z=%d ldx=%d", M, K, Z, ldx);
   if (M == 0) return EVAE_OK;
   EVAE_REQUIRE(x && wm && wl && eps && z_mean && logvar && z, "heads_reparam_fwd: null pointer");
   if (thin_heads_ok(M, K, Z, ldx, x, wm, wl)) {       // batch-sized: one launch (csrc/evae_thin.h)
-    const ThinHeadsArgs t = {x, ldx, M, K, Z, wm, bm, wl, bl, lv_lo, lv_hi, eps, nullptr, z_mean, lv_pre, logvar, z, logq};
+    const ThinHeadsArgs t = {x, ldx, M, K, Z, wm, bm, wl, bl, lv_lo, lv_hi, eps, nullptr, z_mean, lv_pre, logvar, z, logq, bc_src, bc_dst, bc_n};
     return launch_thin_heads(t, stream, "heads_reparam_fwd(thin)");
   }
   EVAE_REQUIRE(ws && ws_bytes >= evae_heads_reparam_fwd_workspace_bytes(M, K, Z), "heads_reparam_fwd: workspace too small (%zu)", ws_bytes);

@@ -311,6 +311,91 @@ __global__ void reparam_logq_bwd_ht_kernel(const float* __restrict__ mu, const f
   dlv_pre[i] = (pre > lo && pre < hi) ? dl : 0.f;
 }
 
+// ---- merged element-wise launches of a captured step (r06: a replayed node costs the host 3.6 us whatever it computes) ----
+// Reconstruction term of a step whose backward is loss.backward(ones) on the batch means: RE[b] (bernoulli_ll_fwd_kernel), the
+// step's coefficient vectors (elbo_bwd_kernel of a unit upstream: cRE = -1/B, cKL = beta/B, neg_cKL = -beta/B) and the gradient
+// of the sigmoid head's pre-activation (bernoulli_sigmoid_bwd_kernel with dout = cRE) -- the same arithmetic as the three
+// launches, element by element, in one pass over x / mean.
+__global__ __launch_bounds__(LNT) void bernoulli_unit_step_kernel(const float* __restrict__ x, const float* __restrict__ mean, int B,
+                                                                  int D, const float* __restrict__ beta_dev, float beta_host,
+                                                                  float* __restrict__ RE, float* __restrict__ cRE,
+                                                                  float* __restrict__ cKL, float* __restrict__ neg_cKL,
+                                                                  float* __restrict__ dpre) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (LNT / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float beta = beta_dev ? beta_dev[0] : beta_host;
+  const float invb = 1.0f / (float)B;
+  const float gl = 1.0f * invb;
+  const float ck = 0.f + beta * gl;
+  const float cre = 0.f - gl;
+  float acc = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const size_t o = (size_t)row * D + k;
+    const float mv = mean[o];
+    const bool inside = (mv >= kMinEps) && (mv <= kMaxEps);
+    const float p = fminf(fmaxf(mv, kMinEps), kMaxEps);
+    const float xv = x[o];
+    acc += xv * logf(p) + (1.0f - xv) * logf(1.0f - p);
+    const float dm = inside ? cre * (xv / p - (1.0f - xv) / (1.0f - p)) : 0.f;
+    dpre[o] = dm * mv * (1.0f - mv);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) { RE[row] = acc; cRE[row] = cre; cKL[row] = ck; neg_cKL[row] = -ck; }
+}
+
+// reparam_logq_bwd_ht_kernel, and in one more block of the same launch the two single-block launches that sat beside it on the
+// batch rows' chain: the ELBO's assembly (evae_elbo_assemble: same rows per lane, same order) and the sum of the prior's
+// log-variance gradient row (sum_small_kernel's order: lane i the elements i, i + 64, ...).
+__global__ __launch_bounds__(256) void reparam_logq_bwd_ht_tail_kernel(
+    const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps, const float* __restrict__ z,
+    const float* __restrict__ dz, const float* __restrict__ dz2, const float* __restrict__ dlogq, const float* __restrict__ lv_pre,
+    float lo, float hi, int B, int zdim, float* __restrict__ dmu, float* __restrict__ dlv_pre, int elt_blocks,
+    const float* __restrict__ a_logp, const float* __restrict__ a_RE, const float* __restrict__ a_logq,
+    const float* __restrict__ beta_dev, float beta_host, float* __restrict__ a_loss, float* __restrict__ a_KL,
+    float* __restrict__ a_means, const float* __restrict__ sum_src, int sum_n, float* __restrict__ sum_dst) {
+  if ((int)blockIdx.x < elt_blocks) {
+    const size_t n = (size_t)B * zdim;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int row = (int)(i / zdim);
+    const float m = mu[i], lv = logvar[i];
+    const float var = expf(lv), sd = expf(0.5f * lv);
+    const float d = z[i] - m;
+    const float gq = dlogq ? dlogq[row] : 0.f;
+    const float up = (dz ? dz[i] : 0.f) + (dz2 ? dz2[i] : 0.f);
+    const float gz = up + gq * (-(d / var));
+    dmu[i] = gz + gq * (d / var);
+    const float dl = gz * eps[i] * sd * 0.5f + gq * (-0.5f) * (1.0f - d * d / var);
+    const float pre = lv_pre[i];
+    dlv_pre[i] = (pre > lo && pre < hi) ? dl : 0.f;
+    return;
+  }
+  __shared__ float red[3][2];
+  if (sum_dst && threadIdx.x >= 192) {                   // the block's last wave: the row's sum
+    const int l = threadIdx.x - 192;
+    float s = 0.f;
+    for (int i = l; i < sum_n; i += 64) s += sum_src[i];
+    s = wave_sum(s);
+    if (l == 0) sum_dst[0] = s;
+  }
+  if (a_loss == nullptr) return;
+  const float beta = beta_dev ? beta_dev[0] : beta_host;
+  float sl = 0.f, sr = 0.f, sk = 0.f;
+  if (threadIdx.x < 128)
+    for (int row = threadIdx.x; row < B; row += 128) {
+      const float kl = a_logq[row] - a_logp[row];
+      const float l = beta * kl - a_RE[row];
+      a_KL[row] = kl; a_loss[row] = l;
+      sl += l; sr += a_RE[row]; sk += kl;
+    }
+  if (a_means == nullptr) return;
+  sl = wave_sum(sl); sr = wave_sum(sr); sk = wave_sum(sk);
+  if (threadIdx.x < 128 && (threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sl; red[1][threadIdx.x >> 6] = sr; red[2][threadIdx.x >> 6] = sk; }
+  __syncthreads();
+  if (threadIdx.x < 3) a_means[threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) / (float)B;
+}
+
 // ---- head of a training step: batch gather + dynamic binarisation + eps, one launch ---------------------------------
 // Counter-based generator (Philox4x32-10): element e of stream s at step t always gets the same 128 random bits for a
 // given seed, whatever the launch geometry -- a replayed hipGraph only needs the step counter in device memory.
@@ -732,6 +817,32 @@ extern "C" int evae_reparam_logq_bwd_hardtanh(const float* mu, const float* logv
   reparam_logq_bwd_ht_kernel<<<ELT_GRID((size_t)B * zdim), 256, 0, (hipStream_t)s>>>(mu, logvar, eps, z, dz, dz2, dlogq, lv_pre,
                                                                                       lo, hi, B, zdim, dmu, dlv_pre);
   return check_launch("reparam_logq_bwd_hardtanh");
+}
+
+extern "C" int evae_reparam_logq_bwd_hardtanh_tail(const float* mu, const float* logvar, const float* eps, const float* z,
+                                                   const float* dz, const float* dz2, const float* dlogq, const float* lv_pre,
+                                                   float lo, float hi, int B, int zdim, float* dmu, float* dlv_pre,
+                                                   const float* logp, const float* RE, const float* logq, const float* beta_dev,
+                                                   float beta_host, float* loss, float* KL, float* means, const float* sum_src,
+                                                   int sum_n, float* sum_dst, evae_stream_t s) {
+  EVAE_REQUIRE(B > 0 && zdim > 0 && sum_n >= 0, "reparam_logq_bwd_hardtanh_tail: bad sizes");
+  EVAE_REQUIRE(mu && logvar && eps && z && lv_pre && dmu && dlv_pre, "reparam_logq_bwd_hardtanh_tail: null pointer");
+  EVAE_REQUIRE(loss == nullptr || (logp && RE && logq && KL), "reparam_logq_bwd_hardtanh_tail: incomplete ELBO arguments");
+  EVAE_REQUIRE(sum_dst == nullptr || sum_src, "reparam_logq_bwd_hardtanh_tail: incomplete sum arguments");
+  const unsigned eb = (unsigned)(((size_t)B * zdim + 255) / 256);
+  const unsigned tail = (loss || sum_dst) ? 1u : 0u;
+  reparam_logq_bwd_ht_tail_kernel<<<eb + tail, 256, 0, (hipStream_t)s>>>(mu, logvar, eps, z, dz, dz2, dlogq, lv_pre, lo, hi, B, zdim, dmu,
+                                                                         dlv_pre, (int)eb, logp, RE, logq, beta_dev, beta_host, loss, KL,
+                                                                         means, sum_src, sum_n, sum_dst);
+  return check_launch("reparam_logq_bwd_hardtanh_tail");
+}
+
+extern "C" int evae_bernoulli_unit_step(const float* x, const float* mean, int B, int D, const float* beta_dev, float beta_host,
+                                        float* RE, float* cRE, float* cKL, float* neg_cKL, float* dpre, evae_stream_t s) {
+  EVAE_REQUIRE(B > 0 && D > 0, "bernoulli_unit_step: bad sizes");
+  EVAE_REQUIRE(x && mean && RE && cRE && cKL && neg_cKL && dpre, "bernoulli_unit_step: null pointer");
+  bernoulli_unit_step_kernel<<<ROWS_GRID(B), LNT, 0, (hipStream_t)s>>>(x, mean, B, D, beta_dev, beta_host, RE, cRE, cKL, neg_cKL, dpre);
+  return check_launch("bernoulli_unit_step");
 }
 
 extern "C" int evae_elbo_fwd(const float* RE, const float* logq, const float* logp, const float* beta_dev,

@@ -271,6 +271,7 @@ struct ThinHeadsArgs {
   const float* eps;        // fresh sample: noise [M x Z]
   const float* z_given;    // or: the sample whose density is wanted (eps unused)
   float* z_mean; float* lv_pre; float* logvar; float* z; float* logq;
+  const float* bc_src; float* bc_dst; int bc_n;     // block 0 also writes bc_dst[0 .. bc_n) = bc_src[0] (evae_broadcast_scalar's work)
 };
 
 template <int NTILE>       // column tiles of 16: Z <= 16 NTILE
@@ -279,6 +280,10 @@ __global__ __launch_bounds__(256) void thin_heads_kernel(const ThinHeadsArgs t) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * 16;
+  if (t.bc_dst && blockIdx.x == 0) {
+    const float v = t.bc_src[0];
+    for (int j = tid; j < t.bc_n; j += 256) t.bc_dst[j] = v;
+  }
   thin_f32x4 am[NTILE], al[NTILE];
 #pragma unroll
   for (int j = 0; j < NTILE; ++j) { am[j] = thin_f32x4{0.f, 0.f, 0.f, 0.f}; al[j] = thin_f32x4{0.f, 0.f, 0.f, 0.f}; }

@@ -86,6 +86,8 @@ SIGNATURES = {
     "evae_linear_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _i, _f, _f, _p, _p, _p, _z, _p]),
     "evae_heads_reparam_fwd_workspace_bytes": (_z, [_i, _i, _i]),
     "evae_heads_reparam_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "evae_heads_reparam_fwd_bcast_applies": (_i, [_i, _i, _i, _i]),
+    "evae_heads_reparam_fwd_bcast": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "evae_heads_density_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _p, _p, _z, _p]),
     "evae_log_normal_diag_bwd_hardtanh": (_i, [_p, _p, _p, _p, _f, _f, _p, _i, _i, _p, _p, _p, _p]),
     "evae_dense_bwd_data_wt_bytes": (_z, [_i, _i, _i]),
@@ -174,6 +176,8 @@ SIGNATURES = {
     "evae_reparam_logq_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_reparam_logq_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "evae_reparam_logq_bwd_hardtanh": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p]),
+    "evae_reparam_logq_bwd_hardtanh_tail": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p,
+                                                 _p, _i, _p, _p]),
     "evae_log_normal_diag_fwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_log_normal_diag_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
     "evae_elbo_fwd": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p, _p]),
@@ -188,6 +192,7 @@ SIGNATURES = {
     "evae_batch_prologue_u8_step": (_i, [_p, _l, _i, _i, _i, _f, _p, _l, _p, _l, _p, _i, _p, _p, _i, _i, _p, _z, _p, _i, _p, _p]),
     "evae_bernoulli_ll_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_bernoulli_sigmoid_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+    "evae_bernoulli_unit_step": (_i, [_p, _p, _i, _i, _p, _f, _p, _p, _p, _p, _p, _p]),
     "evae_log_logistic256_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "evae_log_logistic256_bwd": (_i, [_p, _p, _p, _i, _p, _i, _i, _p, _p, _p, _p]),
     "evae_adam_normgrad_workspace_bytes": (_z, [_i]),

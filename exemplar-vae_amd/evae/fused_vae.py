@@ -36,6 +36,20 @@ PREP_DONE = {}     # prepared-weights buffer -> (w1h, w1g) pointers it was just 
 _STAGE_GEN = {}
 _XT_GEN = {}       # workspace pointer -> generation of the transposed byte rows the forward pass left there
 _ZEROED = {}      # workspace name -> (address, shape) it was last zero-filled for
+# r06: element-wise launches of the batch rows' chain merged into their neighbours (a replayed graph node costs the host 3.6 us):
+# bit 0 the log-variance row's broadcast rides in the heads' launch; bit 1 RE + the unit coefficients + the sigmoid head's gradient
+# are one launch (evae_bernoulli_unit_step); bits 2 / 3 the ELBO's assembly / the log-variance gradient's sum ride in the
+# reparameterisation's backward (evae_reparam_logq_bwd_hardtanh_tail): five nodes less per step, bit-equal results.  Un-profiled
+# (tools/ab_node_merge.sh, profiles/r06_ab/node_merge.txt): C = 200 0.199 -> 0.189 ms, c1 0.217 -> 0.208, c2a 0.315 -> 0.310; at c2
+# (GPU-bound) bits 0, 1, 3 are neutral and bit 2 costs 5 us -- the assembly then sits ON the chain the layer-2 weight gradient waits
+# for instead of in front of it --, so it is merged in host-bound steps only.
+def node_merge(Cl, B):
+    e = os.environ.get("EVAE_NODE_MERGE")
+    if e is not None:
+        return int(e)
+    return 15 if Cl + B <= 8192 else 11
+
+
 ONE_STREAM = [os.environ.get("EVAE_ONE_STREAM", "0") == "1"]      # experiment: the whole step on the caller's stream
 _APPROX_ROWS = {}  # (device, slots, batch, dataset rows) -> the approximate-prior step's gather list (static tail)
 
@@ -326,7 +340,10 @@ class VaeExactLoss(torch.autograd.Function):
         with torch.cuda.stream(side):
             # (on the side stream, in front of everything: with the byte gather moved behind the batch-row chain the MAIN stream's
             # head GEMM is what the prior waits for, and this 5-us launch sat between the two)
-            _lib.check(lib.evae_broadcast_scalar(_vp(plv.detach()), _vp(lv_row), Z, kd.st), "broadcast_scalar")
+            thin_heads = B <= THIN_ROWS and not (SCHED & 1024)
+            bc_in_heads = bool((node_merge(Cl, B) & 1) and thin_heads and lib.evae_heads_reparam_fwd_bcast_applies(B, H, Z, H))
+            if not bc_in_heads:
+                _lib.check(lib.evae_broadcast_scalar(_vp(plv.detach()), _vp(lv_row), Z, kd.st), "broadcast_scalar")
             if p6:
                 # layer 2's weights as images (they change every step); the main stream meets them behind the first layer
                 _lib.check(lib.evae_p6_pack_rows(_vp(w2h), _vp(w2g), H, H, H, 1, _vp(w2_img), w2_img.numel(), kd.st), "p6_pack_rows")
@@ -351,13 +368,18 @@ class VaeExactLoss(torch.autograd.Function):
                 l1_fwd(kd, rows.data_ptr() + 8 * Cl, B, offb)
             kd.gated_fwd(A1.data_ptr() + offb * H, None, B, H, H, w2h, b2h, w2g, b2g, H,
                          A2.data_ptr() + offb * H, None, s2.data_ptr() + offb * H)
-            if B <= THIN_ROWS and not (SCHED & 1024):
+            if thin_heads:
                 # both heads (one gated-style split-K GEMM: bank h = mean, bank g = log-variance) and the sample in two
                 # launches instead of five
-                wh_ = kd.ws("heads", lib.evae_heads_reparam_fwd_workspace_bytes(B, H, Z))
-                _lib.check(lib.evae_heads_reparam_fwd(_vp(A2b), B, H, H, _vp(wm), _vp(bm), _vp(wl), _vp(bl), Z, -6.0, 2.0, _vp(eps),
-                                                      _vp(z_mean), _vp(lv_pre), _vp(logvar), _vp(z), _vp(logq), _vp(wh_),
-                                                      wh_.numel(), kd.st), "heads_reparam_fwd")
+                if bc_in_heads:
+                    _lib.check(lib.evae_heads_reparam_fwd_bcast(_vp(A2b), B, H, H, _vp(wm), _vp(bm), _vp(wl), _vp(bl), Z, -6.0, 2.0,
+                                                                _vp(eps), _vp(z_mean), _vp(lv_pre), _vp(logvar), _vp(z), _vp(logq),
+                                                                _vp(plv.detach()), _vp(lv_row), Z, kd.st), "heads_reparam_fwd_bcast")
+                else:
+                    wh_ = kd.ws("heads", lib.evae_heads_reparam_fwd_workspace_bytes(B, H, Z))
+                    _lib.check(lib.evae_heads_reparam_fwd(_vp(A2b), B, H, H, _vp(wm), _vp(bm), _vp(wl), _vp(bl), Z, -6.0, 2.0, _vp(eps),
+                                                          _vp(z_mean), _vp(lv_pre), _vp(logvar), _vp(z), _vp(logq), _vp(wh_),
+                                                          wh_.numel(), kd.st), "heads_reparam_fwd")
                 if approx:
                     zm_ready = torch.cuda.Event(); zm_ready.record()
             else:
@@ -371,9 +393,17 @@ class VaeExactLoss(torch.autograd.Function):
             kd.gated_fwd(z, None, B, Z, Z, d1h, e1h, d1g, e1g, H, D1, None, sd1)
             kd.gated_fwd(D1, None, B, H, H, d2h, e2h, d2g, e2g, H, D2, None, sd2)
             kd.linear_fwd(D2, B, H, H, wp, bp, D, ACT_SIGMOID, 0.0, 0.0, xmean, None)
-            _lib.check(lib.evae_bernoulli_ll_fwd(_vp(x), _vp(xmean), B, D, _vp(RE), kd.st), "bernoulli")
+            dpx_fwd = None
+            if prior_train and (node_merge(Cl, B) & 2):
+                # RE, the step's coefficient vectors and the sigmoid head's gradient in one launch (the backward pass skips its own)
+                coef = (torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32))
+                dpx_fwd = torch.empty((B, D), **f32)
+                _lib.check(lib.evae_bernoulli_unit_step(_vp(x), _vp(xmean), B, D, _vp(beta_dev), beta_host, _vp(RE), _vp(coef[0]),
+                                                        _vp(coef[1]), _vp(coef[2]), _vp(dpx_fwd), kd.st), "bernoulli_unit_step")
+            else:
+                _lib.check(lib.evae_bernoulli_ll_fwd(_vp(x), _vp(xmean), B, D, _vp(RE), kd.st), "bernoulli")
             re_ready = torch.cuda.Event(); re_ready.record()
-            if prior_train:
+            if prior_train and dpx_fwd is None:
                 # the step's coefficient vectors (-1/B, beta/B, -beta/B: evae_elbo_bwd of a unit upstream gradient on the batch mean)
                 # HERE, on the stream whose backward chain reads them: that chain then waits for nothing of the prior's launch
                 coef = (torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32))
@@ -520,6 +550,7 @@ class VaeExactLoss(torch.autograd.Function):
                                                _vp(beta_dev), beta_host, _vp(logp), _vp(lse), _vp(loss), _vp(KL), _vp(means),
                                                k.st), "prior_elbo_fwd")
         ctx.coef = coef
+        ctx.dpx = dpx_fwd
         # (kept until the backward pass has joined the side stream: the assembly reads / writes them there, behind launches of
         #  the main stream that would otherwise be free to take their memory)
         ctx.elbo_keep = (RE, logq, logp, loss, KL, means) if (elbo_split or prior_train) else None
@@ -652,7 +683,8 @@ class VaeExactLoss(torch.autograd.Function):
                             A1.data_ptr() + ob * H, s1.data_ptr() + ob * H, dq1.data_ptr() + ob * 2 * H,
                             dq1.data_ptr() + ob * 2 * H + 4 * H, 2 * H,
                             wT=None if (ctx.wt is None or kk is not k) else ctx.wt[1])
-        dpx = torch.empty((B, D), **f32)
+        dpx_done = ctx.dpx is not None and ctx.coef is not None and cRE is ctx.coef[0]     # (evae_bernoulli_unit_step, forward pass)
+        dpx = ctx.dpx if dpx_done else torch.empty((B, D), **f32)
         dp2 = torch.empty((B, 2 * H), **f32)                               # [dh | dg] of decoder layer 2
         dp1 = torch.empty((B, 2 * H), **f32)
         dz = torch.empty((B, Z), **f32)
@@ -747,21 +779,38 @@ class VaeExactLoss(torch.autograd.Function):
         headw_early = bool(HEADW_EARLY and not fin_group and Cl > 0)
         with torch.cuda.stream(side):
             # through the Bernoulli log-likelihood and the sigmoid head at once, then down the decoder
-            _lib.check(lib.evae_bernoulli_sigmoid_bwd(_vp(x), _vp(xmean), _vp(cRE), B, D, _vp(dpx), kd.st), "bernoulli_sigmoid_bwd")
+            if not dpx_done:
+                _lib.check(lib.evae_bernoulli_sigmoid_bwd(_vp(x), _vp(xmean), _vp(cRE), B, D, _vp(dpx), kd.st), "bernoulli_sigmoid_bwd")
             kd.bwd_data(dpx, wp, None, None, B, D, D, H, D2, sd2, dp2, dp2.data_ptr() + 4 * H, 2 * H)
             kd.bwd_data(dp2, d2h, dp2.data_ptr() + 4 * H, d2g, B, H, 2 * H, H, D1, sd1, dp1, dp1.data_ptr() + 4 * H, 2 * H)
             kd.bwd_data(dp1, d1h, dp1.data_ptr() + 4 * H, d1g, B, H, 2 * H, Z, None, None, dz, None, Z)
             side.wait_event(dz_ready)
             if prior_finish is not None:
                 prior_finish()
-            if prior_done:
-                RE_, logq_, logp_, loss_, KL_, means_ = ctx.elbo_keep
-                _lib.check(lib.evae_elbo_assemble(_vp(logp_), _vp(RE_), _vp(logq_), _vp(beta_dev), 0.0 if beta_dev is not None else float(beta),
-                                                  B, _vp(loss_), _vp(KL_), _vp(means_), kd.st), "elbo_assemble")
-            # reparameterisation + log q (+ the prior's dz', + the Hardtanh of the log-variance head): one launch
-            _lib.check(lib.evae_reparam_logq_bwd_hardtanh(_vp(z_mean), _vp(logvar), _vp(eps), _vp(z), _vp(dz), _vp(dzp), _vp(cKL),
-                                                          _vp(lv_pre), -6.0, 2.0, B, Z, _vp(dmean_all.data_ptr() + off * Z),
-                                                          _vp(dlvp), kd.st), "reparam_bwd")
+            NODE_MERGE = node_merge(Cl, B)
+            if NODE_MERGE & 12:
+                # reparameterisation + log q (+ the prior's dz', + the Hardtanh of the log-variance head), and in one more block of
+                # the launch the ELBO's assembly (bit 2) and the sum of the prior's log-variance gradient row (bit 3)
+                RE_, logq_, logp_, loss_, KL_, means_ = ctx.elbo_keep if prior_done else (None,) * 6
+                if prior_done and not (NODE_MERGE & 4):
+                    _lib.check(lib.evae_elbo_assemble(_vp(logp_), _vp(RE_), _vp(logq_), _vp(beta_dev), 0.0 if beta_dev is not None else float(beta),
+                                                      B, _vp(loss_), _vp(KL_), _vp(means_), kd.st), "elbo_assemble")
+                    loss_ = None
+                sum_here = bool(NODE_MERGE & 8)
+                _lib.check(lib.evae_reparam_logq_bwd_hardtanh_tail(
+                    _vp(z_mean), _vp(logvar), _vp(eps), _vp(z), _vp(dz), _vp(dzp), _vp(cKL), _vp(lv_pre), -6.0, 2.0, B, Z,
+                    _vp(dmean_all.data_ptr() + off * Z), _vp(dlvp), _vp(logp_), _vp(RE_), _vp(logq_), _vp(beta_dev),
+                    0.0 if beta_dev is not None else float(beta), _vp(loss_), _vp(KL_), _vp(means_),
+                    _vp(dlv) if sum_here else None, Z, _vp(g_plv) if sum_here else None, kd.st), "reparam_bwd_tail")
+            else:
+                if prior_done:
+                    RE_, logq_, logp_, loss_, KL_, means_ = ctx.elbo_keep
+                    _lib.check(lib.evae_elbo_assemble(_vp(logp_), _vp(RE_), _vp(logq_), _vp(beta_dev), 0.0 if beta_dev is not None else float(beta),
+                                                      B, _vp(loss_), _vp(KL_), _vp(means_), kd.st), "elbo_assemble")
+                # reparameterisation + log q (+ the prior's dz', + the Hardtanh of the log-variance head): one launch
+                _lib.check(lib.evae_reparam_logq_bwd_hardtanh(_vp(z_mean), _vp(logvar), _vp(eps), _vp(z), _vp(dz), _vp(dzp), _vp(cKL),
+                                                              _vp(lv_pre), -6.0, 2.0, B, Z, _vp(dmean_all.data_ptr() + off * Z),
+                                                              _vp(dlvp), kd.st), "reparam_bwd")
             if headw_early:
                 kd.bwd_weight(dmean_all, Mp, Z, Z, A2, None, H, H, g_wm, g_bm)       # mean head, all C + B rows
             # head and encoder layer 2, batch rows
@@ -806,7 +855,8 @@ class VaeExactLoss(torch.autograd.Function):
                 else:
                     for dy_, m_, n_, ldy_, x_, k_, ldx_, dw_, db_ in jobs:
                         kd.bwd_weight(dy_, m_, n_, ldy_, x_, None, k_, ldx_, dw_, db_)
-                _lib.check(lib.evae_sum_small(_vp(dlv), Z, _vp(g_plv), kd.st), "sum_small")
+                if not (NODE_MERGE & 8):
+                    _lib.check(lib.evae_sum_small(_vp(dlv), Z, _vp(g_plv), kd.st), "sum_small")
         leaves()      # (issued HERE: captured after the main stream's weight gradients instead, the same launches replay at
         #                0.82-0.94 ms for C = 200 and 1.2 ms at c2 -- this runtime's graph replay is very sensitive to where a
         #                branch's nodes sit relative to the other branch's, r03 measurement)

@@ -262,6 +262,13 @@ size_t evae_heads_reparam_fwd_workspace_bytes(int M, int K, int Z);
 int evae_heads_reparam_fwd(const float* x, int M, int K, int ldx, const float* wm, const float* bm, const float* wl,
                            const float* bl, int Z, float lv_lo, float lv_hi, const float* eps, float* z_mean, float* lv_pre,
                            float* logvar, float* z, float* logq, void* ws, size_t ws_bytes, evae_stream_t stream);
+/* The same in the batch-sized case only (one launch; evae_heads_reparam_fwd_bcast_applies says whether M, K, Z, ldx are), and
+ * dst[0 .. n) = src[0] by the same launch: evae_broadcast_scalar's work -- the exemplar prior's log-variance row
+ * (models/BaseModel.py:101), which the step's prior launch reads behind this one -- without a graph node of its own. */
+int evae_heads_reparam_fwd_bcast_applies(int M, int K, int Z, int ldx);
+int evae_heads_reparam_fwd_bcast(const float* x, int M, int K, int ldx, const float* wm, const float* bm, const float* wl,
+                                 const float* bl, int Z, float lv_lo, float lv_hi, const float* eps, float* z_mean, float* lv_pre,
+                                 float* logvar, float* z, float* logq, const float* src, float* dst, int n, evae_stream_t stream);
 /* The same two heads with the log-density of a GIVEN sample zq [M x Z] (models/AbsHModel.py:17-20 p(z1 | z2) and the
  * log_normal_diag(z1, p1_mu, p1_lv) of :99-100): logp[m] = log N(zq[m] | z_mean[m], exp(logvar[m])); workspace as above. */
 int evae_heads_density_fwd(const float* x, int M, int K, int ldx, const float* wm, const float* bm, const float* wl,
@@ -555,6 +562,14 @@ int evae_reparam_logq_bwd_hardtanh(const float* mu, const float* logvar, const f
                                    const float* dz, const float* dz2, const float* dlogq, const float* lv_pre,
                                    float lo, float hi, int B, int zdim, float* dmu, float* dlv_pre,
                                    evae_stream_t stream);
+/* ... and, in one more block of the same launch, the two single-block launches that sat beside it on the batch rows' chain of a
+ * captured step: evae_elbo_assemble (logp, RE, logq -> loss, KL, means; loss = NULL: not wanted) and evae_sum_small
+ * (sum_dst[0] = sum of sum_src[0 .. sum_n); sum_dst = NULL: not wanted).  Same arithmetic and summation order as the three. */
+int evae_reparam_logq_bwd_hardtanh_tail(const float* mu, const float* logvar, const float* eps, const float* z, const float* dz,
+                                        const float* dz2, const float* dlogq, const float* lv_pre, float lo, float hi, int B,
+                                        int zdim, float* dmu, float* dlv_pre, const float* logp, const float* RE,
+                                        const float* logq, const float* beta_dev, float beta_host, float* loss, float* KL,
+                                        float* means, const float* sum_src, int sum_n, float* sum_dst, evae_stream_t stream);
 int evae_log_normal_diag_fwd(const float* x, const float* mu, const float* logvar, int B, int zdim,
                              float* out, evae_stream_t stream);
 int evae_log_normal_diag_bwd(const float* x, const float* mu, const float* logvar, const float* dout,
@@ -687,6 +702,12 @@ int evae_log_logistic256_bwd(const float* x, const float* mean, const float* log
 /* d/dpre when mean = sigmoid(pre) (the p_x_mean head of models/BaseModel.py:28-29): the two steps in one launch */
 int evae_bernoulli_sigmoid_bwd(const float* x, const float* mean, const float* dout, int B, int D,
                                float* dpre, evae_stream_t stream);
+/* The reconstruction term of a step whose backward is loss.backward(ones) on the batch means (utils/training.py:33-36), one
+ * launch for three: RE [B] (evae_bernoulli_ll_fwd), the coefficient vectors of evae_elbo_bwd for a unit upstream gradient of the
+ * mean loss (cRE = -1/B, cKL = beta/B, neg_cKL = -beta/B; beta from device memory when beta_dev != NULL) and
+ * dpre = evae_bernoulli_sigmoid_bwd(x, mean, cRE) -- the same arithmetic, element by element. */
+int evae_bernoulli_unit_step(const float* x, const float* mean, int B, int D, const float* beta_dev, float beta_host, float* RE,
+                             float* cRE, float* cKL, float* neg_cKL, float* dpre, evae_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * AdamNormGrad (utils/optimizer.py:32-80): g <- g/(||g||_2 + 1e-7) per tensor, then Adam with eps

@@ -1707,6 +1707,52 @@ def test_a_draw_with_too_many_distinct_rows_steps_eagerly_once(model_name, monke
         assert rel(p1[k_], p0[k_]) < 2e-5, k_
 
 
+@pytest.mark.parametrize("C", [200, 4000])
+def test_merged_element_wise_launches_leave_the_trajectory_unchanged(C, monkeypatch):
+    """r06: the log-variance row's broadcast in the heads' launch, RE + unit coefficients + sigmoid gradient as one launch
+    (evae_bernoulli_unit_step) and the ELBO's assembly + log-variance gradient's sum in the reparameterisation's backward
+    (evae_reparam_logq_bwd_hardtanh_tail) compute what the five launches they replace computed, in the same order: a captured `vae`
+    run with them is the run without them (EVAE_NODE_MERGE=0), and each merged entry point was actually called."""
+    from evae import _lib
+    from evae.graph import GraphedTrainStep
+    from utils.optimizer import AdamNormGrad
+    from utils.utils import importing_model
+    B, N = 100, 4000
+    data = gi.binary_images(17, N)
+    dataset = torch.utils.data.TensorDataset(torch.from_numpy(data), torch.arange(N).reshape(-1, 1), torch.zeros(N))
+    results = []
+    for mask in ("0", "15"):
+        monkeypatch.setenv("EVAE_NODE_MERGE", mask)
+        args = smoke_case.vae_args(model_name="vae", number_components=C, training_set_size=N, batch_size=B)
+        torch.manual_seed(5); torch.cuda.manual_seed(5)
+        model = importing_model(args)(args).cuda()
+        model.train()
+        opt = AdamNormGrad(model.parameters(), lr=5e-4)
+        torch.manual_seed(13); torch.cuda.manual_seed(13)
+        runner = GraphedTrainStep(model, opt, dataset, B, False)
+        out = []
+        with _lib.count_calls("evae_") as n:
+            for it in range(7):
+                xb = torch.from_numpy(data[it * B:(it + 1) * B])
+                ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1)
+                out.append(runner(xb, ib, 0.5).cpu().numpy().copy())
+        assert runner.graph is not None and not runner.failed
+        merged = ("evae_heads_reparam_fwd_bcast", "evae_bernoulli_unit_step", "evae_reparam_logq_bwd_hardtanh_tail")
+        replaced = ("evae_broadcast_scalar", "evae_sum_small", "evae_elbo_assemble", "evae_bernoulli_sigmoid_bwd")
+        # (the runner's first call steps the reference's way -- no unit-upstream promise --, so the un-merged Bernoulli launches
+        #  appear once in either run)
+        if mask == "0":
+            assert not any(n.get(f, 0) for f in merged), n
+        else:
+            assert all(n.get(f, 0) >= 2 for f in merged), n
+            assert n.get("evae_broadcast_scalar", 0) == 0 and n.get("evae_sum_small", 0) == 0, n
+        results.append((np.asarray(out), {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}))
+    (l0, p0), (l1, p1) = results
+    assert np.array_equal(l0, l1), np.abs(l0 - l1).max()
+    for k_ in p0:
+        assert np.array_equal(p0[k_], p1[k_]), k_
+
+
 @pytest.mark.parametrize("model_name", ["vae", "hvae_2level"])
 def test_control_block_handed_over_by_the_first_launch_equals_the_copied_one(model_name, monkeypatch):
     """r06: on the byte store the step's first launch takes the control block from the staging block a device-side parity word
