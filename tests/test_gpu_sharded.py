@@ -334,6 +334,10 @@ def _run_rccl_one(q, model_name, port, sharded):
         sys.path.insert(0, p)
     if sharded:
         os.environ["EVAE_SHARD_FORCE"] = "1"
+    staged = model_name.endswith("_staged")
+    if staged:           # the control block through the upload stream and the first launch's hand-over, as at 12 500 exemplars per rank
+        os.environ["EVAE_CTL_DIRECT"] = "0"
+        model_name = model_name[:-len("_staged")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import evae_oracle as orc
@@ -375,20 +379,21 @@ def _run_rccl_one(q, model_name, port, sharded):
             losses.append(runner(xb, ib, 0.7)[0].item())
         torch.cuda.synchronize()
         info = {"captured": runner.graph is not None, "failed": bool(runner.failed), "dedup": runner.dedup is not None,
-                "sharded": bool(model._sharded()), "seen": seen}
+                "sharded": bool(model._sharded()), "seen": seen, "handover": bool(runner._handover and runner.by_index),
+                "parity": (int(runner._ho_state[0]), runner._calls & 1), "counter": (int(runner.ctl[runner._o_seed + 1]), runner._calls - 1)}
         q.put((losses, {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}, info))
     finally:
         if sharded:
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model_name", ["vae", "hvae_2level"])
+@pytest.mark.parametrize("model_name", ["vae", "hvae_2level", "vae_staged"])
 def test_rccl_group_of_one_rank_captures_and_replays_the_sharded_step(model_name):
     ctx = mp.get_context("spawn")
     out = []
     for sharded in (False, True):
         q = ctx.Queue()
-        port = 30700 + (os.getpid() % 1000) + (5 if model_name == "vae" else 17)
+        port = 30700 + (os.getpid() % 1000) + {"vae": 5, "vae_staged": 11}.get(model_name, 17)
         p = ctx.Process(target=_run_rccl_one, args=(q, model_name, port, sharded))
         p.start()
         try:
@@ -402,6 +407,11 @@ def test_rccl_group_of_one_rank_captures_and_replays_the_sharded_step(model_name
     assert i0["captured"] and not i0["failed"] and not i0["sharded"]
     assert i1["sharded"] and i1["captured"] and not i1["failed"], i1
     assert i1["dedup"], i1                                  # the per-shard distinct-row tables were on (5 001 draws from 4 000 rows)
+    if model_name == "vae_staged":                          # (r06) the sharded step's first launch handed the control block over
+        for i_ in (i0, i1):
+            assert i_["handover"] and i_["parity"][0] == i_["parity"][1] and i_["counter"][0] == i_["counter"][1], i_
+    else:
+        assert not i1["handover"], i1
     names = [n for n, _ in i1["seen"]]
     # every step issues the partials' all-gather, the (dz, dlogvar) all-reduce and the gradient all-reduce; at least one step's worth
     # of them was issued INSIDE the capture (and then replayed five times)
