@@ -6,7 +6,9 @@ over 8 GPUs it is a few hundred microseconds, far below what eager launching can
 What varies between steps lives in ONE static int64 control block that is refreshed before each replay: the exemplar
 indices (still drawn by the CPU generator exactly like reference models/BaseModel.py:245), the dataset indices of the
 batch, beta and AdamNormGrad's bias-corrected step sizes.  The host writes a pinned copy (double-buffered), a copy
-stream uploads it ahead of time and the step's stream only runs a device-to-device copy in front of the graph launch.
+stream uploads it ahead of time into one of two device staging blocks, and the step takes it from there: on the byte store
+its first launch copies the staging block into the control block itself (r06; a device-to-device copy in front of the graph
+otherwise); thin steps upload straight into the block.
 The batch images themselves are rows of the HBM-resident dataset: the graph gathers (and binarises) them by index, so
 no image bytes cross PCIe (checked once against the loader's first batch; a loader that hands out other images gets
 them uploaded instead).  The gather, the dynamic binarisation and the eps of the fused `vae` step are one launch of a
@@ -72,8 +74,8 @@ class GraphedTrainStep:
         #   [exemplar rows (Cl) | staging rows (B, constant) | batch dataset indices (B) | generator seed, step counter |
         #    beta, Adam step sizes (fp32)]
         # The host fills a pinned copy (double-buffered), a copy stream uploads it ahead of time into a device staging
-        # block, and the step's own stream only runs one device-to-device copy in front of the graph launch -- it never
-        # waits for a DMA engine or for the host.
+        # block, and the step's own stream only takes it from there (the first launch's hand-over below, or one device-to-device
+        # copy in front of the graph launch) -- it never waits for a DMA engine or for the host.
         self.ngroups = len(optimizer.param_groups)
         nsc = 1 + self.ngroups
         # Duplicates among the draw (the reference draws WITH replacement, models/BaseModel.py:245): when they are worth it the
