@@ -325,65 +325,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue<EPI, BN_, NW, 0>(g, acc, m0, n0, tm, wr, wc, lane, smem, zs);
 }
 
-// ---- image builders (weights in the step head; activations in tests and on fallback paths -- the layers' epilogues write
-// theirs themselves) ----------------------------------------------------------------------------------------------------------
-// X [R x K] fp32, K-contiguous (row stride ld) -> image(rows = R, k = K).  One thread per (image row, 8 k): a 16-byte slot per
-// plane; the grid covers the padded image (rows_img rows, whole k-steps), padding = zeros.
-// gated > 0: the row order of a gated layer's weight tiles -- image row (tn, c) with c = wc * 64 + hg * 32 + j holds weight row
-// tn * 64 + wc * 32 + j of bank hg (x = bank h, x2 = bank g; evae_gemm_x6.h's [wc][h | g][32] LDS rows).
-__device__ __forceinline__ void p6_pack_rows_element(size_t t, const float* __restrict__ x, const float* __restrict__ x2, int R, int K,
-                                                     long long ld, int gated, int rows_img, int nks, unsigned char* __restrict__ img) {
-  const int kslots = nks * 2;
-  if (t >= (size_t)rows_img * kslots) return;
-  const int ri = (int)(t / kslots), ks8 = (int)(t - (size_t)ri * kslots);
-  const int k0 = ks8 * 8;
-  int r = ri;
-  const float* src = x;
-  if (gated) {
-    const int tn = ri >> 7, c = ri & 127, wc = c >> 6, hg = (c >> 5) & 1, j = c & 31;
-    r = tn * 64 + wc * 32 + j;
-    src = hg ? x2 : x;
-  }
-  unsigned short p0[8], p1[8], p2[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float v = (r < R && k0 + i < K) ? src[(size_t)r * ld + k0 + i] : 0.f;
-    p6_split1(v, p0[i], p1[i], p2[i]);
-  }
-  unsigned char* o = img + p6_off(ri, k0, nks);
-  *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(p0);
-  *reinterpret_cast<uint4*>(o + P6_CHUNK) = *reinterpret_cast<const uint4*>(p1);
-  *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = *reinterpret_cast<const uint4*>(p2);
-}
+// (the image builders' element functions p6_pack_rows_element / p6_pack_cols_element: evae_p6_image.h)
 static __global__ __launch_bounds__(256) void p6_pack_rows_kernel(const float* __restrict__ x, const float* __restrict__ x2, int R, int K,
                                                            long long ld, int gated, int rows_img, int nks, unsigned char* __restrict__ img) {
   p6_pack_rows_element((size_t)blockIdx.x * blockDim.x + threadIdx.x, x, x2, R, K, ld, gated, rows_img, nks, img);
 }
 
-// X^T: X [Kd x R] fp32 with the CONTRACTION along its rows (row stride ld; rows Kd .. 2 Kd - 1 from x2 when given: the [h | g]
-// banks of a gated layer stacked along the contraction) -> image(rows = R, k).  ones_row >= 0: that image row is 1 for k < Kd_all
-// (the bias-gradient row of a weight gradient's x operand).  One thread per (image row, 8 k); consecutive threads = consecutive
-// image rows (coalesced along a row of X).
-__device__ __forceinline__ void p6_pack_cols_element(size_t t, const float* __restrict__ x, const float* __restrict__ x2, int Kd, int R,
-                                                     long long ld, int ones_row, int rows_img, int nks, unsigned char* __restrict__ img) {
-  if (t >= (size_t)rows_img * nks * 2) return;
-  const int ks8 = (int)(t / rows_img), r = (int)(t - (size_t)ks8 * rows_img);
-  const int k0 = ks8 * 8;
-  const int Kall = x2 ? 2 * Kd : Kd;
-  unsigned short p0[8], p1[8], p2[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int k = k0 + i;
-    float v = 0.f;
-    if (r < R && k < Kall) v = k < Kd ? x[(size_t)k * ld + r] : x2[(size_t)(k - Kd) * ld + r];
-    if (r == ones_row && k < Kall) v = 1.f;
-    p6_split1(v, p0[i], p1[i], p2[i]);
-  }
-  unsigned char* o = img + p6_off(r, k0, nks);
-  *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(p0);
-  *reinterpret_cast<uint4*>(o + P6_CHUNK) = *reinterpret_cast<const uint4*>(p1);
-  *reinterpret_cast<uint4*>(o + 2 * P6_CHUNK) = *reinterpret_cast<const uint4*>(p2);
-}
 static __global__ __launch_bounds__(256) void p6_pack_cols_kernel(const float* __restrict__ x, const float* __restrict__ x2, int Kd, int R,
                                                            long long ld, int ones_row, int rows_img, int nks, unsigned char* __restrict__ img) {
   p6_pack_cols_element((size_t)blockIdx.x * blockDim.x + threadIdx.x, x, x2, Kd, R, ld, ones_row, rows_img, nks, img);

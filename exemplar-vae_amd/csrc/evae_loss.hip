@@ -3,6 +3,7 @@
 // (log_normal_diag, log_bernoulli) and their autograd.
 #include "evae_common.h"
 #include "evae_u8_prepare.h"
+#include "evae_p6_image.h"
 
 namespace evae {
 
@@ -460,6 +461,16 @@ __global__ __launch_bounds__(256) void batch_prologue_kernel(const float* __rest
 // blocks in here -- one returning device-scope atomic per block on one word -- cost 95 ns per block, 238 us for the 2 500
 // blocks of this launch at c2 (tools/prologue_probe.py).  (r06: the hand-over was a device-to-device copy node in front of
 // the graph -- ~27 us of the c2 step between the blit and the seam behind it.)
+// ... and the step's weight images of the pre-split GEMMs (evae_p6_pack_rows / _cols: weights only, like the split above) as
+// further blocks: two launches and one cross-stream join less at the head of the c2 step.
+struct PackJob {
+  const float* x; const float* x2;
+  unsigned char* img;
+  long long ld;
+  int cols;              // 0: evae_p6_pack_rows(x, x2, R, K, ld, flag = gated); 1: evae_p6_pack_cols(x, x2, Kd = K, R, ld, flag = ones_row, nks)
+  int R, K, flag, rows_img, nks, blocks;
+};
+
 struct CtlJob {
   const uint4* s[2];
   uint4* ctl;
@@ -479,7 +490,7 @@ __device__ __forceinline__ void batch_prologue_u8_body(const unsigned char* __re
                                                        const float* __restrict__ wg, int wN, int wK,
                                                        unsigned short* __restrict__ prepared, size_t prep_elems,
                                                        int prep_blocks, const WtJob& j0, const WtJob& j1, const uint4* ctl_src,
-                                                       const CtlJob& cj) {
+                                                       const CtlJob& cj, const PackJob& p0, const PackJob& p1) {
   // blocks past the prologue's: the weight split of the byte-store layer (evae_u8_prepare.h) -- the two jobs are independent
   // and each is a few microseconds of one launch's latency at the head of every training step
   if ((int)blockIdx.x >= pro_blocks + prep_blocks) {
@@ -488,8 +499,14 @@ __device__ __forceinline__ void batch_prologue_u8_body(const unsigned char* __re
     const int t = (int)blockIdx.x - pro_blocks - prep_blocks;
     if (t < j0.ntiles) wt_job_tile(j0, t, tile);
     else if (t - j0.ntiles < j1.ntiles) wt_job_tile(j1, t - j0.ntiles, tile);
-    else if (ctl_src) {                                 // ... and behind those: staging block -> control block
-      const int cb = t - j0.ntiles - j1.ntiles;
+    else if (t - j0.ntiles - j1.ntiles < p0.blocks + p1.blocks) {      // ... the weight images of the pre-split GEMMs
+      const int pb = t - j0.ntiles - j1.ntiles;
+      const PackJob& pj = pb < p0.blocks ? p0 : p1;
+      const size_t e = (size_t)(pb < p0.blocks ? pb : pb - p0.blocks) * 256 + threadIdx.x;
+      if (pj.cols) p6_pack_cols_element(e, pj.x, pj.x2, pj.K, pj.R, pj.ld, pj.flag, pj.rows_img, pj.nks, pj.img);
+      else p6_pack_rows_element(e, pj.x, pj.x2, pj.R, pj.K, pj.ld, pj.flag, pj.rows_img, pj.nks, pj.img);
+    } else if (ctl_src) {                               // ... and behind those: staging block -> control block
+      const int cb = t - j0.ntiles - j1.ntiles - p0.blocks - p1.blocks;
       for (size_t i = (size_t)cb * 256 + threadIdx.x; i < cj.n16; i += (size_t)cj.blocks * 256) cj.ctl[i] = ctl_src[i];
     }
     return;
@@ -543,7 +560,8 @@ __global__ __launch_bounds__(256) void batch_prologue_u8_kernel(const unsigned c
                                                                 int pro_blocks, const float* __restrict__ wh,
                                                                 const float* __restrict__ wg, int wN, int wK,
                                                                 unsigned short* __restrict__ prepared, size_t prep_elems,
-                                                                int prep_blocks, WtJob j0, WtJob j1, CtlJob cj) {
+                                                                int prep_blocks, WtJob j0, WtJob j1, CtlJob cj, PackJob p0,
+                                                                PackJob p1) {
   const uint4* src = nullptr;
   int par = 0;
   if (cj.state) {                                       // the staging block of THIS step: the index list and the counter are read there
@@ -553,7 +571,7 @@ __global__ __launch_bounds__(256) void batch_prologue_u8_kernel(const unsigned c
     seed_ctr = (const int64_t*)src + cj.seed_off;
   }
   batch_prologue_u8_body(data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img, pro_blocks, wh,
-                         wg, wN, wK, prepared, prep_elems, prep_blocks, j0, j1, src, cj);
+                         wg, wN, wK, prepared, prep_elems, prep_blocks, j0, j1, src, cj, p0, p1);
 }
 
 // ELBO assembly on [B] rows in one launch: KL_i = logq_i - logp_i, loss_i = beta*KL_i - RE_i, and the three
@@ -721,7 +739,8 @@ extern "C" int evae_batch_prologue(const float* data, int64_t ldd, const int64_t
 static int launch_prologue_u8(const char* who, const unsigned char* data, int64_t ldd, const int64_t* idx, int B, int D, int binarize,
                               const int64_t* seed_ctr, float x_div, float* x_out, int64_t ldx, unsigned char* stage, int64_t lds_,
                               float* eps_out, int zdim, const float* wh, const float* wg, int N, int K, void* prepared,
-                              size_t prepared_bytes, const evae_wt_job_t* jobs, int njobs, const evae_ctl_job_t* ctl, evae_stream_t s) {
+                              size_t prepared_bytes, const evae_wt_job_t* jobs, int njobs, const evae_ctl_job_t* ctl,
+                              const evae_p6_pack_job_t* packs, int npacks, evae_stream_t s) {
   EVAE_REQUIRE(B > 0 && D > 0 && zdim >= 0 && ldd >= D && ldx >= D && lds_ >= D && x_div > 0.f, "%s: bad sizes", who);
   EVAE_REQUIRE(data && x_out && stage && ((idx && seed_ctr) || ctl), "%s: null pointer", who);
   EVAE_REQUIRE(eps_out == nullptr || zdim > 0, "%s: eps_out needs zdim > 0", who);
@@ -752,9 +771,26 @@ static int launch_prologue_u8(const char* who, const unsigned char* data, int64_
     cj.n16 = ctl->bytes / 16; cj.state = (const int*)ctl->state; cj.idx_off = ctl->idx_word; cj.seed_off = ctl->seed_word;
     cj.blocks = (int)std::min<size_t>(128, (cj.n16 + 255) / 256);
   }
-  batch_prologue_u8_kernel<<<pro + prep + (unsigned)(wj[0].ntiles + wj[1].ntiles + cj.blocks), 256, 0, (hipStream_t)s>>>(
-      data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img, (int)pro, wh, wg, N, K,
-      (unsigned short*)prepared, elems, (int)prep, wj[0], wj[1], cj);
+  EVAE_REQUIRE(npacks >= 0 && npacks <= 2 && (npacks == 0 || packs != nullptr), "%s: at most two image jobs", who);
+  PackJob pk[2] = {PackJob{}, PackJob{}};
+  for (int i = 0; i < npacks; ++i) {
+    const evae_p6_pack_job_t& q = packs[i];
+    EVAE_REQUIRE(q.x && q.img && q.R > 0 && q.K > 0, "%s: bad image job", who);
+    PackJob& o = pk[i];
+    o.x = q.x; o.x2 = q.x2; o.img = (unsigned char*)q.img; o.ld = q.ld; o.cols = q.cols ? 1 : 0; o.R = q.R; o.K = q.K; o.flag = q.flag;
+    if (o.cols) {          // evae_p6_pack_cols' checks and geometry
+      EVAE_REQUIRE(q.ld >= q.R && q.nks >= p6_nks(q.x2 ? 2 * q.K : q.K), "%s: bad image job (columns)", who);
+      o.rows_img = cdiv(std::max(q.R, q.flag + 1), 128) * 128; o.nks = q.nks;
+    } else {               // evae_p6_pack_rows'
+      EVAE_REQUIRE(q.ld >= q.K && (!q.flag || q.x2), "%s: bad image job (rows)", who);
+      o.rows_img = q.flag ? cdiv(q.R, 64) * 128 : cdiv(q.R, 128) * 128; o.nks = p6_nks(q.K);
+    }
+    EVAE_REQUIRE(q.img_bytes >= p6_image_bytes(o.rows_img, o.nks), "%s: image buffer too small (%zu)", who, q.img_bytes);
+    o.blocks = (int)(((size_t)o.rows_img * o.nks * 2 + 255) / 256);
+  }
+  batch_prologue_u8_kernel<<<pro + prep + (unsigned)(wj[0].ntiles + wj[1].ntiles + pk[0].blocks + pk[1].blocks + cj.blocks), 256, 0,
+                             (hipStream_t)s>>>(data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim, nq_img,
+                                               (int)pro, wh, wg, N, K, (unsigned short*)prepared, elems, (int)prep, wj[0], wj[1], cj, pk[0], pk[1]);
   return check_launch(who);
 }
 
@@ -765,7 +801,7 @@ extern "C" int evae_batch_prologue_u8(const unsigned char* data, int64_t ldd, co
   if (B == 0) return EVAE_OK;
   EVAE_REQUIRE(idx && seed_ctr, "batch_prologue_u8: null pointer");
   return launch_prologue_u8("batch_prologue_u8", data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_, eps_out, zdim,
-                            nullptr, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, s);
+                            nullptr, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, s);
 }
 
 // The same launch also splits the first layer's weights into the byte kernels' bf16 tile images (evae_dense_u8_prepare): the
@@ -777,17 +813,18 @@ extern "C" int evae_batch_prologue_u8_prepare(const unsigned char* data, int64_t
                                               const evae_wt_job_t* jobs, int njobs, evae_stream_t s) {
   EVAE_REQUIRE(idx && seed_ctr && wh && wg && prepared, "batch_prologue_u8_prepare: null pointer");
   return launch_prologue_u8("batch_prologue_u8_prepare", data, ldd, idx, B, D, binarize, seed_ctr, x_div, x_out, ldx, stage, lds_,
-                            eps_out, zdim, wh, wg, N, K, prepared, prepared_bytes, jobs, njobs, nullptr, s);
+                            eps_out, zdim, wh, wg, N, K, prepared, prepared_bytes, jobs, njobs, nullptr, nullptr, 0, s);
 }
 
 // ... and the step's control block (wh / wg / prepared NULL: no weight split)
 extern "C" int evae_batch_prologue_u8_step(const unsigned char* data, int64_t ldd, int B, int D, int binarize, float x_div,
                                            float* x_out, int64_t ldx, unsigned char* stage, int64_t lds_, float* eps_out, int zdim,
                                            const float* wh, const float* wg, int N, int K, void* prepared, size_t prepared_bytes,
-                                           const evae_wt_job_t* jobs, int njobs, const evae_ctl_job_t* ctl, evae_stream_t s) {
+                                           const evae_wt_job_t* jobs, int njobs, const evae_ctl_job_t* ctl,
+                                           const evae_p6_pack_job_t* packs, int npacks, evae_stream_t s) {
   EVAE_REQUIRE(ctl, "batch_prologue_u8_step: no control-block job");
   return launch_prologue_u8("batch_prologue_u8_step", data, ldd, nullptr, B, D, binarize, nullptr, x_div, x_out, ldx, stage, lds_,
-                            eps_out, zdim, wh, wg, N, K, prepared, prepared_bytes, jobs, njobs, ctl, s);
+                            eps_out, zdim, wh, wg, N, K, prepared, prepared_bytes, jobs, njobs, ctl, packs, npacks, s);
 }
 
 extern "C" int evae_elu_fwd(const float* x, size_t n, float* out, evae_stream_t s) {

@@ -35,6 +35,12 @@ class CtlJob(C.Structure):
                 ("idx_word", C.c_size_t), ("seed_word", C.c_size_t)]
 
 
+class P6PackJob(C.Structure):
+    """evae_p6_pack_job_t"""
+    _fields_ = [("x", C.c_void_p), ("x2", C.c_void_p), ("img", C.c_void_p), ("img_bytes", C.c_size_t), ("ld", C.c_longlong),
+                ("cols", C.c_int), ("R", C.c_int), ("K", C.c_int), ("flag", C.c_int), ("nks", C.c_int)]
+
+
 class WgradJob(C.Structure):
     """evae_wgrad_job_t"""
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("M", C.c_int), ("N", C.c_int),
@@ -189,7 +195,7 @@ SIGNATURES = {
     "evae_batch_prologue_u8": (_i, [_p, _l, _p, _i, _i, _i, _p, _f, _p, _l, _p, _l, _p, _i, _p]),
     "evae_batch_prologue_u8_prepare": (_i, [_p, _l, _p, _i, _i, _i, _p, _f, _p, _l, _p, _l, _p, _i, _p, _p, _i, _i, _p, _z, _p, _i,
                                             _p]),
-    "evae_batch_prologue_u8_step": (_i, [_p, _l, _i, _i, _i, _f, _p, _l, _p, _l, _p, _i, _p, _p, _i, _i, _p, _z, _p, _i, _p, _p]),
+    "evae_batch_prologue_u8_step": (_i, [_p, _l, _i, _i, _i, _f, _p, _l, _p, _l, _p, _i, _p, _p, _i, _i, _p, _z, _p, _i, _p, _p, _i, _p]),
     "evae_bernoulli_ll_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_bernoulli_sigmoid_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "evae_bernoulli_unit_step": (_i, [_p, _p, _i, _i, _p, _f, _p, _p, _p, _p, _p, _p]),

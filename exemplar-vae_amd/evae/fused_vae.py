@@ -32,6 +32,8 @@ ACT_NONE, ACT_SIGMOID, ACT_HARDTANH = ops.ACT_NONE, ops.ACT_SIGMOID, ops.ACT_HAR
 # pending backward would gather its batch from -- the backward checks that its forward was the last one to stage
 UNIT_UPSTREAM = [False]   # set by evae/graph.py around its step: the only backward is loss.backward(ones) on the batch mean
 WT_DONE = {}       # (wm, w2h, w2g) pointers -> (wT of the head, wT of layer 2) the step's head launch just wrote
+P6_LAST = [None]   # (w2h ptr, w2g ptr, H, forward image, data-gradient image) of the last step that took the pre-split layer 2
+P6_DONE = {}       # (w2h ptr, w2g ptr) -> True when the step's head launch just built both images (evae/graph.py)
 PREP_DONE = {}     # prepared-weights buffer -> (w1h, w1g) pointers it was just filled from, by the step's head launch
 _STAGE_GEN = {}
 _XT_GEN = {}       # workspace pointer -> generation of the transposed byte rows the forward pass left there
@@ -344,12 +346,16 @@ class VaeExactLoss(torch.autograd.Function):
             bc_in_heads = bool((node_merge(Cl, B) & 1) and thin_heads and lib.evae_heads_reparam_fwd_bcast_applies(B, H, Z, H))
             if not bc_in_heads:
                 _lib.check(lib.evae_broadcast_scalar(_vp(plv.detach()), _vp(lv_row), Z, kd.st), "broadcast_scalar")
+            w2_ready = None
             if p6:
-                # layer 2's weights as images (they change every step); the main stream meets them behind the first layer
-                _lib.check(lib.evae_p6_pack_rows(_vp(w2h), _vp(w2g), H, H, H, 1, _vp(w2_img), w2_img.numel(), kd.st), "p6_pack_rows")
-                _lib.check(lib.evae_p6_pack_cols(_vp(w2h), _vp(w2g), H, H, H, -1, lib.evae_p6_nks(2 * H), _vp(w2t_img), w2t_img.numel(),
-                                                 kd.st), "p6_pack_cols")
-                w2_ready = torch.cuda.Event(); w2_ready.record()
+                # layer 2's weights as images (they change every step); the main stream meets them behind the first layer --
+                # unless the captured step's head launch built them (evae/graph.py: two launches and one join less)
+                P6_LAST[0] = (w2h.data_ptr(), w2g.data_ptr(), H, w2_img, w2t_img)
+                if not P6_DONE.pop((w2h.data_ptr(), w2g.data_ptr()), False):
+                    _lib.check(lib.evae_p6_pack_rows(_vp(w2h), _vp(w2g), H, H, H, 1, _vp(w2_img), w2_img.numel(), kd.st), "p6_pack_rows")
+                    _lib.check(lib.evae_p6_pack_cols(_vp(w2h), _vp(w2g), H, H, H, -1, lib.evae_p6_nks(2 * H), _vp(w2t_img),
+                                                     w2t_img.numel(), kd.st), "p6_pack_cols")
+                    w2_ready = torch.cuda.Event(); w2_ready.record()
             if xt_early and not xt_late:
                 wq, xt_gen = xt_gather()
             if p6:
@@ -427,7 +433,8 @@ class VaeExactLoss(torch.autograd.Function):
             l1_fwd(k, rows, Cl, 0)
         if Cl > 0:
             if p6:
-                main.wait_event(w2_ready)
+                if w2_ready is not None:
+                    main.wait_event(w2_ready)
                 fl2 = 2.0 * Cl * H * 2 * H
                 ops.probed("gated_dense_fwd M=%d K=%d N=%d (pre-split bf16 images)" % (Cl, H, H), fl2,
                            lambda: _lib.check(lib.evae_gated_dense_fwd_p6t(_vp(t_h1), nks_m, Cl, H, _vp(w2_img), _vp(b2h), _vp(b2g), H,

@@ -235,7 +235,18 @@ class GraphedTrainStep:
                 self._wt_bufs = (torch.empty(nb1, dtype=torch.uint8, device=wh.device), torch.empty(nb2, dtype=torch.uint8, device=wh.device))
             jobs = [(wm.detach(), None, self._wt_bufs[0]), (w2h.detach(), w2g.detach(), self._wt_bufs[1])]
             fused_vae.WT_DONE[(wm.data_ptr(), w2h.data_ptr(), w2g.data_ptr())] = self._wt_bufs
-        return wh.detach(), wg.detach(), prep, jobs
+        # layer 2's weight images of the pre-split GEMMs (fused_vae's p6 path, when the last step took it): built by the head
+        # launch too -- they depend on the weights alone -- instead of two launches on the side stream and a join in front of
+        # layer 2's forward GEMM (rides with the control block's hand-over: evae_batch_prologue_u8_step)
+        packs = []
+        last = fused_vae.P6_LAST[0]
+        if (os.environ.get("EVAE_P6_HEAD", "1") != "0" and self._handover and self.by_index and last is not None
+                and w2h is not None and w2g is not None and last[:2] == (w2h.data_ptr(), w2g.data_ptr())):
+            H2, w2_img, w2t_img = last[2], last[3], last[4]
+            packs = [(0, w2h.detach(), w2g.detach(), H2, H2, H2, 1, 0, w2_img),
+                     (1, w2h.detach(), w2g.detach(), H2, H2, H2, -1, lib.evae_p6_nks(2 * H2), w2t_img)]
+            fused_vae.P6_DONE[(w2h.data_ptr(), w2g.data_ptr())] = True
+        return wh.detach(), wg.detach(), prep, jobs, packs
 
     # the body that gets captured
     def _eager_tables(self):
@@ -260,8 +271,10 @@ class GraphedTrainStep:
                     job = (self._d_ctl[0], self._d_ctl[1], self.ctl, self._ho_state, self._o_idx, self._o_seed)
                     if not torch.cuda.is_current_stream_capturing():
                         self._ho_state[:1].copy_(self._ho_par[self._calls & 1])     # (eager: the block this call uploaded)
+                prep = self._first_layer_split()
                 ops.batch_prologue_u8(self.data_rows, self.idx_flat, self.binarize, self.seed_ctr, self.x_div, x,
-                                      self.stage_rows, self.eps_buf, prepare=self._first_layer_split(), ctl_job=job)
+                                      self.stage_rows, self.eps_buf, prepare=prep, ctl_job=job,
+                                      packs=prep[4] if (prep is not None and job is not None) else None)
             else:
                 x = self.stage_rows
                 ops.batch_prologue(self.data_rows, self.idx_flat, self.binarize, self.seed_ctr, x, self.eps_buf)
@@ -283,6 +296,7 @@ class GraphedTrainStep:
             from . import fused_vae
             fused_vae.PREP_DONE.clear()           # (a token the fused step did not consume must not outlive this step)
             fused_vae.WT_DONE.clear()
+            fused_vae.P6_DONE.clear()
         with ops.deferred_wgrads(loss):          # thin layers' weight gradients behind the backward pass, grouped (evae/ops.py)
             loss.backward(gradient=self._one)
         # the step's statistics ride in the optimizer's last launch (evae_adam_normgrad_step_stats)

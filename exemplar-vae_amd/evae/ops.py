@@ -2159,11 +2159,13 @@ def batch_prologue(data, idx, binarize, seed_ctr, x_out, eps_out=None):
     return x_out, eps_out
 
 
-def batch_prologue_u8(data_u8, idx, binarize, seed_ctr, x_div, x_out, stage_u8, eps_out=None, prepare=None, ctl_job=None):
+def batch_prologue_u8(data_u8, idx, binarize, seed_ctr, x_div, x_out, stage_u8, eps_out=None, prepare=None, ctl_job=None, packs=None):
     """batch_prologue on the uint8-resident store: x_out [B x D] fp32 and the batch's bytes into stage_u8 [B x D].
     prepare = (wh, wg, out): the same launch also splits the first layer's weights (u8_prepare) into `out`.
     ctl_job = (stage0, stage1, ctl, state, idx_word, seed_word): the same launch hands over a captured step's control block
-    (evae_batch_prologue_u8_step): idx / seed_ctr are then read from the staging block the device-side parity names."""
+    (evae_batch_prologue_u8_step): idx / seed_ctr are then read from the staging block the device-side parity names.
+    packs (with ctl_job only) = [(cols, x, x2 or None, R, K, ld, flag, nks, img)]: weight images of the pre-split GEMMs built by the
+    same launch (evae_p6_pack_rows / _cols)."""
     lib = _lib.load()
     _need_cuda(data_u8, idx, seed_ctr, x_out, stage_u8)
     B, D = x_out.shape
@@ -2195,12 +2197,22 @@ def batch_prologue_u8(data_u8, idx, binarize, seed_ctr, x_div, x_out, stage_u8, 
         assert s0.dtype == s1.dtype == ctl.dtype == torch.int64 and s0.numel() == s1.numel() == ctl.numel() and ctl.numel() % 2 == 0
         assert state.dtype == torch.int32 and state.numel() >= 2 and s0.is_contiguous() and s1.is_contiguous() and ctl.is_contiguous()
         cj = _lib.CtlJob(s0.data_ptr(), s1.data_ptr(), ctl.data_ptr(), ctl.numel() * 8, state.data_ptr(), int(idx_word), int(seed_word))
+        packs = packs or []
+        parr = (_lib.P6PackJob * max(len(packs), 1))()
+        for i, (cols, px, px2, pr, pk, pld, pflag, pnks, pimg) in enumerate(packs):
+            _need_cuda(px, px2, pimg)
+            assert px.dtype == torch.float32 and px.is_contiguous() and (px2 is None or px2.is_contiguous())
+            parr[i].x = px.data_ptr(); parr[i].x2 = None if px2 is None else px2.data_ptr(); parr[i].img = pimg.data_ptr()
+            parr[i].img_bytes = pimg.numel() * pimg.element_size(); parr[i].ld = int(pld); parr[i].cols = 1 if cols else 0
+            parr[i].R, parr[i].K, parr[i].flag, parr[i].nks = int(pr), int(pk), int(pflag), int(pnks)
         _lib.check(lib.evae_batch_prologue_u8_step(_p(data_u8), data_u8.stride(0), B, D, 1 if binarize else 0, float(x_div), _p(x_out),
                                                    x_out.stride(0), _p(stage_u8), stage_u8.stride(0), _p(eps_out), zd, _p(wh), _p(wg),
                                                    N, K, _p(out), out.numel() if out is not None else 0,
-                                                   C.cast(arr, C.c_void_p) if jobs else None, len(jobs), C.addressof(cj), _stream()),
+                                                   C.cast(arr, C.c_void_p) if jobs else None, len(jobs), C.addressof(cj),
+                                                   C.cast(parr, C.c_void_p) if packs else None, len(packs), _stream()),
                    "evae_batch_prologue_u8_step")
         return x_out, eps_out
+    assert not packs, "batch_prologue_u8: image jobs ride with the control block's hand-over only"
     if prepare is not None:
         _lib.check(lib.evae_batch_prologue_u8_prepare(_p(data_u8), data_u8.stride(0), _p(idx), B, D, 1 if binarize else 0,
                                                       _p(seed_ctr), float(x_div), _p(x_out), x_out.stride(0), _p(stage_u8),

@@ -678,10 +678,15 @@ int evae_batch_prologue_u8_prepare(const unsigned char* data, int64_t ldd, const
  * The launch does not write the parity: the step's last launch flips it (evae_adam_normgrad_step_stats' toggle) or the caller
  * sets it.  bytes: a multiple of 16.  wh / wg / prepared may be NULL (no weight split). */
 typedef struct { const void* stage0; const void* stage1; void* ctl; size_t bytes; const int* state; size_t idx_word, seed_word; } evae_ctl_job_t;
+/* packs (host array, at most two): weight images of the pre-split GEMMs built by further blocks of the same launch --
+ * cols == 0: evae_p6_pack_rows(x, x2, R, K, ld, gated = flag, img, img_bytes); cols != 0: evae_p6_pack_cols(x, x2, Kd = K, R, ld,
+ * ones_row = flag, nks, img, img_bytes) -- the same images, bit for bit. */
+typedef struct { const float* x; const float* x2; void* img; size_t img_bytes; long long ld; int cols, R, K, flag, nks; } evae_p6_pack_job_t;
 int evae_batch_prologue_u8_step(const unsigned char* data, int64_t ldd, int B, int D, int binarize, float x_div, float* x_out,
                                 int64_t ldx, unsigned char* stage, int64_t lds, float* eps_out, int zdim, const float* wh,
                                 const float* wg, int N, int K, void* prepared, size_t prepared_bytes, const evae_wt_job_t* jobs,
-                                int njobs, const evae_ctl_job_t* ctl, evae_stream_t stream);
+                                int njobs, const evae_ctl_job_t* ctl, const evae_p6_pack_job_t* packs, int npacks,
+                                evae_stream_t stream);
 /* evae_log_normal_diag_bwd with the Hardtanh(lo, hi) of a log-variance head folded in: dlv_pre is the gradient of its pre-activation */
 int evae_log_normal_diag_bwd_hardtanh(const float* x, const float* mu, const float* logvar, const float* lv_pre, float lo, float hi,
                                       const float* dout, int B, int zdim, float* dx, float* dmu, float* dlv_pre, evae_stream_t stream);

@@ -1924,15 +1924,21 @@ def test_captured_distinct_rows_steps_at_config2_size_match_the_oracle(monkeypat
     monkeypatch.setattr(torch, "randint", fake_randint)
     runner = GraphedTrainStep(model, opt, dataset, B, False)
     got = []
-    for it in range(nsteps):
-        cur["i"] = it
-        eps_dev.copy_(torch.from_numpy(epss[it])); torch.cuda.synchronize()
-        xb = torch.from_numpy(data[it * B:(it + 1) * B]); ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1)
-        out = runner(xb, ib, beta)
-        torch.cuda.synchronize()
-        got.append([float(out[0].item()), float(out[1].item()), float(out[2].item())])
+    from evae import _lib as _evl
+    with _evl.count_calls("evae_") as ncalls:
+        for it in range(nsteps):
+            cur["i"] = it
+            eps_dev.copy_(torch.from_numpy(epss[it])); torch.cuda.synchronize()
+            xb = torch.from_numpy(data[it * B:(it + 1) * B]); ib = torch.arange(it * B, (it + 1) * B).reshape(-1, 1)
+            out = runner(xb, ib, beta)
+            torch.cuda.synchronize()
+            got.append([float(out[0].item()), float(out[1].item()), float(out[2].item())])
     monkeypatch.setattr(torch, "randint", orig)
     assert runner.graph is not None and runner.dedup is not None and runner.dedup["cap"] == 19968
+    # (r06) the head launch of the step handed the control block over and built layer 2's weight images from the second call on:
+    # the stand-alone image launches ran in the first call only
+    assert ncalls.get("evae_batch_prologue_u8_step", 0) >= 3 and ncalls.get("evae_p6_pack_rows", 0) == 1 \
+        and ncalls.get("evae_p6_pack_cols", 0) == 1, {k_: v_ for k_, v_ in ncalls.items() if "p6_pack" in k_ or "prologue" in k_}
     # the oracle, same inputs
     opt_state = {}
     po = {k: v.copy() for k, v in p.items()}
